@@ -1,0 +1,3 @@
+// oracle shim: forwards to the single minimal header (test infrastructure only)
+#pragma once
+#include "../opencv.hpp"

@@ -1,0 +1,167 @@
+// oracle/opencv_shim/opencv2/opencv.hpp — TEST INFRASTRUCTURE ONLY.
+//
+// A minimal stand-in for the slice of OpenCV that the reference's src/ORBextractor.cc and
+// include/ORBextractor.h use (includes at ORBextractor.cc:54-57, ORBextractor.h:24).  OpenCV is not
+// installed in this image and cannot be (no network), so to run the reference's *own* extractor
+// source as the oracle we compile it, unmodified and read in place from /root/reference, against
+// this header (oracle/Makefile -> oracle/_ref/).  The same header lets tests compile the product's
+// C++ facade (include/orb_slam3_amd/ORBextractor.h) without OpenCV.
+//
+// The arithmetic of cv::resize / cv::FAST / cv::GaussianBlur / cv::fastAtan2 / cvRound lives in
+// ../../orb_primitives.h and is a restatement of OpenCV's scalar algorithms — PARITY UNPINNED
+// against a real OpenCV (see that header).
+#pragma once
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <vector>
+#include "../../orb_primitives.h"
+
+#define CV_PI 3.1415926535897932384626433832795
+#define CV_8U 0
+#define CV_8UC1 0
+#define CV_32F 5
+
+typedef unsigned char uchar;
+
+static inline int cvRound(double v) { return orbp::round_half_even(v); }
+static inline int cvFloor(double v) { return orbp::floor_i(v); }
+static inline int cvCeil(double v) { return orbp::ceil_i(v); }
+
+namespace cv {
+
+// Gaussian taps variant used by GaussianBlur below (orb_primitives.h gauss7_taps); settable by
+// the test drivers so that both OpenCV generations can be exercised.
+inline int& shim_gauss_variant() { static int v = 0; return v; }
+
+template <typename T> struct Point_ {
+    T x, y;
+    Point_() : x(0), y(0) {}
+    Point_(T _x, T _y) : x(_x), y(_y) {}
+};
+typedef Point_<int> Point2i;
+typedef Point2i Point;
+typedef Point_<float> Point2f;
+static inline Point2f& operator*=(Point2f& p, float s) { p.x = p.x * s; p.y = p.y * s; return p; }
+
+struct Size { int width, height; Size() : width(0), height(0) {} Size(int w, int h) : width(w), height(h) {} };
+struct Rect { int x, y, width, height; Rect() : x(0), y(0), width(0), height(0) {} Rect(int _x, int _y, int w, int h) : x(_x), y(_y), width(w), height(h) {} };
+
+struct KeyPoint {
+    Point2f pt; float size, angle, response; int octave, class_id;
+    KeyPoint() : pt(0, 0), size(0), angle(-1), response(0), octave(0), class_id(-1) {}
+    KeyPoint(float x, float y, float _size, float _angle = -1, float _response = 0, int _octave = 0, int _class_id = -1)
+        : pt(x, y), size(_size), angle(_angle), response(_response), octave(_octave), class_id(_class_id) {}
+};
+
+enum { INTER_LINEAR = 1 };
+enum { BORDER_REFLECT_101 = 4, BORDER_DEFAULT = 4, BORDER_ISOLATED = 16 };
+enum { NORM_L1 = 2 };
+
+struct MatStep {
+    size_t v; MatStep() : v(0) {} MatStep(size_t s) : v(s) {}
+    operator size_t() const { return v; }
+};
+
+class Mat {
+public:
+    int rows, cols; uchar* data; MatStep step;
+    Mat() : rows(0), cols(0), data(nullptr), step(0), type_(CV_8UC1) {}
+    Mat(int r, int c, int type) : Mat() { create(r, c, type); }
+    Mat(Size s, int type) : Mat() { create(s.height, s.width, type); }
+    // user-data constructor (no ownership)
+    Mat(int r, int c, int type, void* d, size_t st = 0) : rows(r), cols(c), data((uchar*)d), step(st ? st : (size_t)c * esz(type)), type_(type) {}
+    static Mat zeros(int r, int c, int type) { Mat m(r, c, type); if (m.data) memset(m.data, 0, (size_t)r * m.step); return m; }
+    void create(int r, int c, int type) {
+        if (data && r == rows && c == cols && type == type_) return;
+        type_ = type; rows = r; cols = c; step = (size_t)c * esz(type);
+        buf_ = std::shared_ptr<std::vector<uchar>>(new std::vector<uchar>((size_t)r * step + 64));
+        data = buf_->data();
+    }
+    void create(Size s, int type) { create(s.height, s.width, type); }
+    void release() { buf_.reset(); data = nullptr; rows = cols = 0; step = 0; }
+    bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+    int type() const { return type_; }
+    Size size() const { return Size(cols, rows); }
+    size_t step1() const { return step / esz1(type_); }
+    size_t elemSize() const { return esz(type_); }
+    Mat operator()(const Rect& r) const { Mat m(*this); m.data = data + (size_t)r.y * step + (size_t)r.x * esz(type_); m.rows = r.height; m.cols = r.width; return m; }
+    Mat rowRange(int a, int b) const { return (*this)(Rect(0, a, cols, b - a)); }
+    Mat colRange(int a, int b) const { return (*this)(Rect(a, 0, b - a, rows)); }
+    Mat row(int y) const { return rowRange(y, y + 1); }
+    Mat clone() const { Mat m(rows, cols, type_); for (int y = 0; y < rows; y++) memcpy(m.data + (size_t)y * m.step, data + (size_t)y * step, (size_t)cols * esz(type_)); return m; }
+    void copyTo(Mat& dst) const { dst.create(rows, cols, type_); for (int y = 0; y < rows; y++) memcpy(dst.data + (size_t)y * dst.step, data + (size_t)y * step, (size_t)cols * esz(type_)); }
+    void copyTo(Mat&& dst) const { copyTo(dst); }   // e.g. desc.row(i).copyTo(descriptors.row(j))
+    template <typename T> T& at(int y, int x) { return *(T*)(data + (size_t)y * step + (size_t)x * sizeof(T)); }
+    template <typename T> const T& at(int y, int x) const { return *(const T*)(data + (size_t)y * step + (size_t)x * sizeof(T)); }
+    uchar* ptr(int y = 0) { return data + (size_t)y * step; }
+    const uchar* ptr(int y = 0) const { return data + (size_t)y * step; }
+    template <typename T> T* ptr(int y = 0) { return (T*)(data + (size_t)y * step); }
+    template <typename T> const T* ptr(int y = 0) const { return (const T*)(data + (size_t)y * step); }
+private:
+    static size_t esz(int type) { return type == CV_32F ? 4 : 1; }
+    static size_t esz1(int type) { return esz(type); }
+    int type_;
+    std::shared_ptr<std::vector<uchar>> buf_;
+};
+
+class _InputArray {
+public:
+    _InputArray(const Mat& m) : m_(const_cast<Mat*>(&m)) {}
+    bool empty() const { return m_->empty(); }
+    Mat getMat() const { return *m_; }
+protected:
+    Mat* m_;
+};
+class _OutputArray : public _InputArray {
+public:
+    _OutputArray(Mat& m) : _InputArray(m) {}
+    void create(int r, int c, int type) const { m_->create(r, c, type); }
+    void release() const { m_->release(); }
+};
+typedef const _InputArray& InputArray;
+typedef const _OutputArray& OutputArray;
+
+static inline float fastAtan2(float y, float x) { return orbp::fast_atan2_deg(y, x); }
+
+static inline void FAST(const Mat& img, std::vector<KeyPoint>& kps, int threshold, bool nonmax = true) {
+    std::vector<orbp::FastPoint> pts;
+    orbp::fast9_16(img.data, img.cols, img.rows, img.step, threshold, nonmax, pts);
+    kps.clear();
+    for (const auto& p : pts) kps.push_back(KeyPoint((float)p.x, (float)p.y, 7.f, -1, (float)p.score));
+}
+
+static inline void resize(const Mat& src, Mat& dst, Size dsize, double = 0, double = 0, int = INTER_LINEAR) {
+    dst.create(dsize, src.type());
+    orbp::resize_linear_u8(src.data, src.cols, src.rows, src.step, dst.data, dst.cols, dst.rows, dst.step);
+}
+
+static inline void copyMakeBorder(const Mat& src, Mat& dst, int top, int bottom, int left, int right, int /*borderType*/) {
+    dst.create(src.rows + top + bottom, src.cols + left + right, src.type());
+    orbp::make_border_reflect101(src.data, src.cols, src.rows, src.step, dst.data, dst.step, top, bottom, left, right);
+}
+
+static inline void GaussianBlur(const Mat& src, Mat& dst, Size ksize, double sx, double sy = 0, int = BORDER_DEFAULT) {
+    assert(ksize.width == 7 && ksize.height == 7 && sx == 2.0 && (sy == 2.0 || sy == 0.0));
+    (void)ksize; (void)sx; (void)sy;
+    dst.create(src.rows, src.cols, src.type());
+    orbp::gaussian_blur7_u8(src.data, src.cols, src.rows, src.step, dst.data, dst.step, shim_gauss_variant());
+}
+
+static inline double norm(const Mat& a, const Mat& b, int /*NORM_L1*/) {
+    return orbp::norm_l1_u8(a.data, a.step, b.data, b.step, a.cols, a.rows);
+}
+
+struct KeyPointsFilter {   // referenced only by the reference's dead ComputeKeyPointsOld
+    static void retainBest(std::vector<KeyPoint>& kps, int n) {
+        if (n >= 0 && (int)kps.size() > n) {
+            std::stable_sort(kps.begin(), kps.end(), [](const KeyPoint& a, const KeyPoint& b) { return a.response > b.response; });
+            kps.resize(n);
+        }
+    }
+};
+
+}  // namespace cv

@@ -1,0 +1,68 @@
+"""Deterministic synthetic inputs (no dataset is available offline).
+
+S1 "corner field": random bright/dark rectangles over a low-frequency gradient plus Gaussian noise,
+which yields >= 10x the per-level feature quota in FAST candidates, like a textured EuRoC frame.
+The stereo pair renders the same rectangles with a per-rectangle disparity (depth layers) and
+independent noise, so the row search / SAD / parabola stages of Frame::ComputeStereoMatches
+(reference src/Frame.cc:1102-1358) all trigger.
+"""
+import numpy as np
+
+SEED0 = 0x0BB5
+
+
+def _scene(rng, w, h, nrect):
+    x = rng.integers(-20, w, nrect)
+    y = rng.integers(-20, h, nrect)
+    rw = rng.integers(4, 41, nrect)
+    rh = rng.integers(4, 41, nrect)
+    contrast = rng.integers(20, 121, nrect) * rng.choice([-1, 1], nrect)
+    disp = rng.integers(2, 61, nrect)
+    return x, y, rw, rh, contrast, disp
+
+
+def _render(w, h, scene, shift_sign, base_shift, contrast_div):
+    x, y, rw, rh, contrast, disp = scene
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = 110.0 + 50.0 * np.sin((xx + shift_sign * base_shift) / 97.0) * np.cos(yy / 71.0)
+    for i in range(len(x)):
+        x0 = int(x[i] - shift_sign * disp[i]); y0 = int(y[i])
+        xa, xb = max(x0, 0), min(x0 + int(rw[i]), w)
+        ya, yb = max(y0, 0), min(y0 + int(rh[i]), h)
+        if xa < xb and ya < yb:
+            img[ya:yb, xa:xb] += contrast[i] / contrast_div
+    return img
+
+
+def corner_field(w=752, h=480, seed=0, nrect=3000, noise=3.0, contrast_div=1.0):
+    """S1 (contrast_div=1) / S2 low texture (contrast_div=6) single image, uint8 HxW."""
+    rng = np.random.default_rng(SEED0 + seed)
+    sc = _scene(rng, w, h, nrect)
+    img = _render(w, h, sc, 0, 0, contrast_div) + rng.normal(0, noise, (h, w))
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def stereo_pair(w=752, h=480, seed=0, nrect=3000, noise=3.0):
+    """Rectified stereo pair (left, right): right = per-rectangle shifted left + independent noise."""
+    rng = np.random.default_rng(SEED0 + seed)
+    sc = _scene(rng, w, h, nrect)
+    left = _render(w, h, sc, 0, 0, 1.0) + rng.normal(0, noise, (h, w))
+    right = _render(w, h, sc, 1, 4, 1.0) + rng.normal(0, noise, (h, w))
+    cv = lambda a: np.clip(np.rint(a), 0, 255).astype(np.uint8)
+    return cv(left), cv(right)
+
+
+def sparse_corners(w=752, h=480, seed=0, ncorner=40):
+    """S3: flat image with a few isolated corners (empty cells, N < nfeatures)."""
+    rng = np.random.default_rng(SEED0 + 7919 + seed)
+    img = np.full((h, w), 100, np.uint8)
+    for _ in range(ncorner):
+        x0 = int(rng.integers(25, w - 60)); y0 = int(rng.integers(25, h - 60))
+        img[y0:y0 + int(rng.integers(8, 30)), x0:x0 + int(rng.integers(8, 30))] = int(rng.integers(150, 255))
+    return img
+
+
+def uniform_noise(w=752, h=480, seed=0):
+    """S4: uniform random bytes (stress: a candidate at almost every local maximum)."""
+    rng = np.random.default_rng(SEED0 + 104729 + seed)
+    return rng.integers(0, 256, (h, w), dtype=np.uint8)

@@ -1,0 +1,180 @@
+"""ctypes bindings for the CPU oracle (TEST INFRASTRUCTURE: tests/, smoke() and bench cpu_baseline only)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+def build():
+    subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True, stdout=subprocess.DEVNULL)
+
+
+def _load(path):
+    return C.CDLL(path) if os.path.exists(path) else None
+
+
+_ORACLE = None
+_REF = None
+
+
+def oracle():
+    global _ORACLE
+    if _ORACLE is None:
+        p = os.path.join(ORACLE_DIR, "liborb_oracle.so")
+        if not os.path.exists(p):
+            build()
+        L = C.CDLL(p)
+        L.orbo_create.restype = C.c_void_p
+        L.orbo_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orbo_destroy.argtypes = [C.c_void_p]
+        L.orbo_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.orbo_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.orbo_level_info.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_int)] * 3 + [C.POINTER(C.c_float)]
+        for f in (L.orbo_level_image, L.orbo_level_blurred):
+            f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orbo_level_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orbo_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orbo_quadtree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orbo_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.orbo_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float,
+                                          C.c_void_p, C.c_void_p]
+        L.orbo_knn2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        for f in (L.orbo_cosf, L.orbo_sinf):
+            f.restype = C.c_float
+            f.argtypes = [C.c_float]
+        L.orbo_fast_atan2.restype = C.c_float
+        L.orbo_fast_atan2.argtypes = [C.c_float, C.c_float]
+        _ORACLE = L
+    return _ORACLE
+
+
+def reference():
+    """The reference's own ORBextractor.cc built against the shim (oracle/_ref); None if absent."""
+    global _REF
+    if _REF is None:
+        p = os.path.join(ORACLE_DIR, "_ref", "libref_orb.so")
+        if not os.path.exists(p) and os.path.exists("/root/reference/src/ORBextractor.cc"):
+            build()
+        if not os.path.exists(p):
+            return None
+        L = C.CDLL(p)
+        L.ref_orb_create.restype = C.c_void_p
+        L.ref_orb_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.ref_orb_destroy.argtypes = [C.c_void_p]
+        L.ref_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.ref_orb_pyramid_level.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.ref_orb_keypoints_per_level.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.ref_orb_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+        _REF = L
+    return _REF
+
+
+class OracleExtractor:
+    """Our C++ restatement (oracle/orb_oracle.cpp)."""
+
+    def __init__(self, nfeatures=1200, scale=1.2, nlevels=8, ini=20, mn=7, gauss_variant=0):
+        self.L = oracle()
+        self.nlevels = nlevels
+        self.cap = nfeatures + 3 * nlevels + 64
+        self.h = self.L.orbo_create(nfeatures, scale, nlevels, ini, mn, gauss_variant)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orbo_destroy(self.h)
+            self.h = None
+
+    def extract(self, img, lap=(0, 0)):
+        img = np.ascontiguousarray(img, np.uint8)
+        kps = np.zeros(self.cap, KP_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n = C.c_int()
+        mono = self.L.orbo_extract(self.h, img.ctypes.data, img.shape[1], img.shape[0], img.strides[0],
+                                   lap[0], lap[1], kps.ctypes.data, desc.ctypes.data, self.cap, C.byref(n))
+        assert mono > -2, "oracle extract failed %d" % mono
+        return mono, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def level_info(self, l):
+        w, h, q, s = C.c_int(), C.c_int(), C.c_int(), C.c_float()
+        self.L.orbo_level_info(self.h, l, C.byref(w), C.byref(h), C.byref(q), C.byref(s))
+        return w.value, h.value, q.value, s.value
+
+    def level_image(self, l, blurred=False):
+        w, h, _, _ = self.level_info(l)
+        a = np.zeros((h, w), np.uint8)
+        (self.L.orbo_level_blurred if blurred else self.L.orbo_level_image)(self.h, l, a.ctypes.data)
+        return a
+
+    def level_candidates(self, l):
+        cap = 1 << 18
+        a = np.zeros((cap, 3), np.int32)
+        n = self.L.orbo_level_candidates(self.h, l, a.ctypes.data, cap)
+        assert n <= cap
+        return a[:n].copy()
+
+    def level_keypoints(self, l):
+        a = np.zeros(self.cap, KP_DTYPE)
+        n = self.L.orbo_level_keypoints(self.h, l, a.ctypes.data, self.cap)
+        return a[:n].copy()
+
+    def tables(self):
+        nl = self.nlevels
+        q = np.zeros(nl, np.int32); um = np.zeros(16, np.int32)
+        f = [np.zeros(nl, np.float32) for _ in range(4)]
+        self.L.orbo_tables(self.h, q.ctypes.data, um.ctypes.data, *[x.ctypes.data for x in f])
+        return q, um, f
+
+
+class ReferenceExtractor:
+    """The reference's own ORBextractor (src/ORBextractor.cc) built against the OpenCV shim."""
+
+    def __init__(self, nfeatures=1200, scale=1.2, nlevels=8, ini=20, mn=7, gauss_variant=0):
+        self.L = reference()
+        assert self.L is not None, "oracle/_ref/libref_orb.so missing"
+        self.nlevels = nlevels
+        self.gv = gauss_variant
+        self.cap = nfeatures + 3 * nlevels + 64
+        self.h = self.L.ref_orb_create(nfeatures, scale, nlevels, ini, mn)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ref_orb_destroy(self.h)
+            self.h = None
+
+    def extract(self, img, lap=(0, 0)):
+        img = np.ascontiguousarray(img, np.uint8)
+        kps = np.zeros(self.cap, KP_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n = C.c_int()
+        mono = self.L.ref_orb_extract(self.h, img.ctypes.data, img.shape[1], img.shape[0], img.strides[0],
+                                      lap[0], lap[1], self.gv, kps.ctypes.data, desc.ctypes.data, self.cap, C.byref(n))
+        assert n.value <= self.cap
+        return mono, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def level_image(self, l):
+        cap = 1 << 22
+        a = np.zeros(cap, np.uint8)
+        w, h = C.c_int(), C.c_int()
+        r = self.L.ref_orb_pyramid_level(self.h, l, a.ctypes.data, cap, C.byref(w), C.byref(h))
+        assert r == 0
+        return a[:w.value * h.value].reshape(h.value, w.value).copy()
+
+    def tables(self):
+        nl = self.nlevels
+        q = np.zeros(nl, np.int32); um = np.zeros(16, np.int32); pat = np.zeros(1024, np.int32)
+        f = [np.zeros(nl, np.float32) for _ in range(4)]
+        self.L.ref_orb_tables(self.h, q.ctypes.data, um.ctypes.data, pat.ctypes.data, *[x.ctypes.data for x in f])
+        return q, um, pat, f
+
+
+def kps_equal(a, b):
+    """Bit-exact comparison of keypoint records (angle compared as bit pattern)."""
+    return a.shape == b.shape and a.tobytes() == b.tobytes()
