@@ -1,0 +1,134 @@
+/* orbx.h — C ABI of the MI355X-native ORB front-end (liborbx_hip.so).
+ *
+ * Drop-in boundary for the two reference classes that own the hot path:
+ *   ORB_SLAM3::ORBextractor   /root/reference/include/ORBextractor.h:43-109
+ *   ORB_SLAM3::ORBmatcher     /root/reference/include/ORBmatcher.h:36-103  (+ the stereo association that
+ *                             Frame runs on the extractor's pyramids, src/Frame.cc:1102-1358, :1530-1587)
+ * The reference has no FFI layer of its own: callers use those classes directly.  The C++ facade in
+ * include/orb_slam3_amd/ keeps the reference's class names, signatures and return conventions and forwards to
+ * the functions below; INTEGRATION.md shows the binding a maintainer adds.
+ *
+ * Conventions: plain pointers and sizes only.  Every function returns an int status (0 = ORBX_OK, < 0 =
+ * error) unless stated otherwise.  A handle owns one GPU stream pair and all device memory it needs; calls
+ * on ONE handle must not overlap in time (the reference never calls one ORBextractor instance
+ * concurrently, src/Frame.cc:136-141), calls on DIFFERENT handles may run from different threads.
+ * Nothing here ever computes on the CPU: if no GPU / HIP runtime is usable, orbx_create fails.
+ */
+#ifndef ORBX_H
+#define ORBX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBX_OK 0
+#define ORBX_E_EMPTY (-1)      /* empty image: ORBextractor::operator() returns -1, src/ORBextractor.cc:1561-1562 */
+#define ORBX_E_ARG (-2)        /* bad argument / image too small for the 35-px FAST cell grid */
+#define ORBX_E_DEVICE (-3)     /* HIP error (no device, allocation or launch failure) */
+#define ORBX_E_CAPACITY (-4)   /* caller buffer too small (n_out still reports the required size) */
+#define ORBX_E_INTERNAL (-5)   /* device-side capacity check tripped */
+
+/* cv::KeyPoint as the reference fills it (src/ORBextractor.cc:1184-1198, :587): 28 bytes */
+typedef struct OrbxKeyPoint {
+    float x, y;        /* level-0 pixel coordinates (level coords * mvScaleFactor[octave]) */
+    float size;        /* int(31 * scale) */
+    float angle;       /* degrees [0,360], cv::fastAtan2 of the intensity-centroid moments */
+    float response;    /* FAST corner score (OpenCV cornerScore), NOT a Harris score */
+    int32_t octave;
+    int32_t class_id;  /* always -1 */
+} OrbxKeyPoint;
+
+typedef struct orbx_extractor orbx_extractor;
+
+/* number of usable GPUs (0 if none) */
+int orbx_device_count(void);
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)  include/ORBextractor.h:49-50,
+ * src/ORBextractor.cc:468-571.  device_id selects the GPU (one process per GPU in multi-GPU runs). */
+int orbx_create(orbx_extractor** out, int nfeatures, float scale_factor, int nlevels,
+                int ini_th_fast, int min_th_fast, int device_id);
+void orbx_destroy(orbx_extractor* h);
+
+/* Which 8-bit 7x7 sigma=2 Gaussian the linked OpenCV would apply (src/ORBextractor.cc:1632):
+ * 0 = OpenCV >= 3.4/4.x fixed-point path, taps [18,34,48,56,48,34,18]/256 (default)
+ * 1 = OpenCV 3.2 integer separable filter, taps [18,34,49,55,49,34,18]/256 */
+int orbx_set_gaussian_taps(orbx_extractor* h, int variant);
+
+/* Pre-allocate for images of width x height and batches up to max_batch (otherwise done lazily). */
+int orbx_reserve(orbx_extractor* h, int width, int height, int max_batch);
+
+/* Getters of include/ORBextractor.h:61-81 (by value in the reference). */
+int orbx_get_levels(const orbx_extractor* h);
+float orbx_get_scale_factor(const orbx_extractor* h);
+int orbx_get_level_tables(const orbx_extractor* h, float* scale, float* inv_scale, float* sigma2,
+                          float* inv_sigma2, int* features_per_level, int* umax16);
+/* Upper bound of keypoints per image (nfeatures + 3 per level, src/ORBextractor.cc:912,1006): size output buffers with it. */
+int orbx_max_keypoints(const orbx_extractor* h);
+
+/* ORBextractor::operator()(image, mask, keypoints, descriptors, vLappingArea)  include/ORBextractor.h:57-59,
+ * src/ORBextractor.cc:1557-1682.  image: 8-bit grey, host memory.  kps: cap records, desc: cap x 32 bytes (row i <->
+ * keypoint i).  *n_out = number of keypoints, *mono_index_out = the reference's return value (monoIndex).
+ * Blocking (the reference call is synchronous). */
+int orbx_extract(orbx_extractor* h, const uint8_t* image, int width, int height, int stride,
+                 int lap0, int lap1, OrbxKeyPoint* kps, uint8_t* desc, int cap,
+                 int* n_out, int* mono_index_out);
+
+/* Batched form: B independent images of identical size, image b at images + b*image_stride.
+ * images_on_device != 0: `images` is device memory of this handle's GPU (see orbx_device_alloc).
+ * Asynchronous: enqueues on the handle's stream; results stay resident on the device for orbx_fetch and
+ * for the orbm_* matchers.  */
+int orbx_extract_batch(orbx_extractor* h, int B, const uint8_t* images, int width, int height, int stride,
+                       size_t image_stride, int images_on_device, int lap0, int lap1);
+/* Copy the results of the last batch to the host (blocking).  kps: [B][cap], desc: [B][cap][32], n_out/mono_out: [B]. */
+int orbx_fetch(orbx_extractor* h, OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n_out, int* mono_out);
+int orbx_sync(orbx_extractor* h);
+
+/* mvImagePyramid[level] of image `image_index` of the last batch (public member include/ORBextractor.h:83; the
+ * un-bordered level — the 19-px reflect border is never read by the hot path).  blurred != 0 returns the
+ * GaussianBlur'ed level used for the descriptors.  dst may be NULL to query the size. */
+int orbx_pyramid_level(orbx_extractor* h, int image_index, int level, int blurred, uint8_t* dst,
+                       int dst_stride, int* width, int* height);
+
+/* device memory helpers so a caller can keep inputs resident (bench, multi-camera rigs) */
+int orbx_device_alloc(orbx_extractor* h, size_t bytes, void** dptr);
+int orbx_device_free(orbx_extractor* h, void* dptr);
+int orbx_device_upload(orbx_extractor* h, void* dptr, const void* host, size_t bytes);
+
+/* Per-stage GPU time of the last batch, HIP events on the launching streams.  names is a static table. */
+#define ORBX_NSTAGES 8
+int orbx_profile_enable(orbx_extractor* h, int on);
+int orbx_profile_get(orbx_extractor* h, float ms[ORBX_NSTAGES]);
+const char* orbx_stage_name(int i);
+
+/* Stage probes for parity tests (level-ordered intermediate results of image `image_index`). */
+int orbx_debug_candidates(orbx_extractor* h, int image_index, int level, int* xys, int cap);       /* returns count; (x,y,score) rel. to the 16-px border, reference order */
+int orbx_debug_level_keys(orbx_extractor* h, int image_index, int level, int* xys, int cap);       /* quadtree output in list order */
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* ORBmatcher::DescriptorDistance (include/ORBmatcher.h:44, src/ORBmatcher.cc:2383-2403), all pairs:
+ * out[i*nb + j] = Hamming(a[i], b[j]).  Host buffers; runs on the handle's GPU. */
+int orbm_hamming_matrix(orbx_extractor* h, const uint8_t* a, int na, const uint8_t* b, int nb, int* out);
+
+/* Frame::ComputeStereoMatches (src/Frame.cc:1102-1358) for B rectified pairs: pair p uses image
+ * left_first+p of `left`'s last batch and image right_first+p of `right`'s last batch (left == right is allowed:
+ * one handle that extracted [L0..LB-1, R0..RB-1]).  bf = mbf, b = mb (include/Frame.h:209-212).  Asynchronous. */
+int orbm_stereo_match(orbx_extractor* left, int left_first, orbx_extractor* right, int right_first,
+                      int B, float bf, float b);
+/* uRight/depth: [B][cap] (mvuRight / mvDepth, -1 = none), n_matches: [B].  Blocking. */
+int orbm_stereo_fetch(orbx_extractor* left, int B, float* uRight, float* depth, int cap, int* n_matches);
+
+/* Matching part of Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1553-1562): brute-force Hamming 2-NN of
+ * left[monoLeft:] against right[monoRight:] + Lowe ratio (0.7).  Outputs [B][cap], indexed by query row
+ * relative to monoLeft; idx relative to monoRight (DMatch.queryIdx/trainIdx).  Blocking fetch. */
+int orbm_knn2(orbx_extractor* left, int left_first, orbx_extractor* right, int right_first, int B);
+int orbm_knn2_fetch(orbx_extractor* left, int B, int* idx0, int* dist0, int* idx1, int* dist1,
+                    uint8_t* ratio_ok, int cap);
+
+const char* orbx_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBX_H */

@@ -23,7 +23,9 @@
 #include <cstring>
 #include <vector>
 #include "orb_primitives.h"
+static const signed char kBriefPattern[1024] = {
 #include "../orb_slam3_detailed_comments_amd/csrc/brief_pattern.inc"
+};
 
 namespace {
 

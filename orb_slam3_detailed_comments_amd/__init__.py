@@ -1,0 +1,5 @@
+"""MI355X-native ORB front-end for ORB-SLAM3 (extract + match): hand-written HIP kernels for gfx950 behind
+the reference's ORBextractor / ORBmatcher interfaces.  See DESIGN.md and include/orbx.h."""
+from ._lib import KP_DTYPE, OrbxError, load_hip  # noqa: F401
+from .extractor import ORBextractor  # noqa: F401
+from .matcher import ORBmatcher, ComputeStereoMatches, StereoFishEyeKnn  # noqa: F401

@@ -1,0 +1,97 @@
+"""ctypes binding of the C ABI in include/orbx.h.
+
+The product library is the hipcc-built, in-tree ``liborbx_hip.so``.  There is NO CPU fallback: if the
+library is missing or no GPU is usable, loading / creating an extractor raises.  (Tests may bind the same
+class to ``tests/emu/liborbx_emu.so`` — the kernel sources compiled for a CPU SIMT emulator — by passing an
+explicit path; the package itself never does.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, "liborbx_hip.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+NSTAGES = 8
+
+ORBX_OK, ORBX_E_EMPTY, ORBX_E_ARG, ORBX_E_DEVICE, ORBX_E_CAPACITY, ORBX_E_INTERNAL = 0, -1, -2, -3, -4, -5
+
+# every symbol include/orbx.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "orbx_device_count", "orbx_create", "orbx_destroy", "orbx_set_gaussian_taps", "orbx_reserve",
+    "orbx_get_levels", "orbx_get_scale_factor", "orbx_get_level_tables", "orbx_max_keypoints",
+    "orbx_extract", "orbx_extract_batch", "orbx_fetch", "orbx_sync", "orbx_pyramid_level",
+    "orbx_device_alloc", "orbx_device_free", "orbx_device_upload", "orbx_profile_enable",
+    "orbx_profile_get", "orbx_stage_name", "orbx_debug_candidates", "orbx_debug_level_keys",
+    "orbm_hamming_matrix", "orbm_stereo_match", "orbm_stereo_fetch", "orbm_knn2", "orbm_knn2_fetch",
+    "orbx_last_error",
+]
+
+
+class OrbxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("orbx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class OrbxLib:
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+        self.path = path
+        L = self.L = C.CDLL(path)
+        vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+        ip = C.POINTER(C.c_int)
+        L.orbx_device_count.restype = i
+        L.orbx_create.argtypes = [C.POINTER(vp), i, f, i, i, i, i]
+        L.orbx_destroy.argtypes = [vp]; L.orbx_destroy.restype = None
+        L.orbx_set_gaussian_taps.argtypes = [vp, i]
+        L.orbx_reserve.argtypes = [vp, i, i, i]
+        L.orbx_get_levels.argtypes = [vp]
+        L.orbx_get_scale_factor.argtypes = [vp]; L.orbx_get_scale_factor.restype = f
+        L.orbx_get_level_tables.argtypes = [vp] + [vp] * 6
+        L.orbx_max_keypoints.argtypes = [vp]
+        L.orbx_extract.argtypes = [vp, vp, i, i, i, i, i, vp, vp, i, ip, ip]
+        L.orbx_extract_batch.argtypes = [vp, i, vp, i, i, i, sz, i, i, i]
+        L.orbx_fetch.argtypes = [vp, vp, vp, i, vp, vp]
+        L.orbx_sync.argtypes = [vp]
+        L.orbx_pyramid_level.argtypes = [vp, i, i, i, vp, i, ip, ip]
+        L.orbx_device_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+        L.orbx_device_free.argtypes = [vp, vp]
+        L.orbx_device_upload.argtypes = [vp, vp, vp, sz]
+        L.orbx_profile_enable.argtypes = [vp, i]
+        L.orbx_profile_get.argtypes = [vp, vp]
+        L.orbx_stage_name.argtypes = [i]; L.orbx_stage_name.restype = C.c_char_p
+        L.orbx_debug_candidates.argtypes = [vp, i, i, vp, i]
+        L.orbx_debug_level_keys.argtypes = [vp, i, i, vp, i]
+        L.orbm_hamming_matrix.argtypes = [vp, vp, i, vp, i, vp]
+        L.orbm_stereo_match.argtypes = [vp, i, vp, i, i, f, f]
+        L.orbm_stereo_fetch.argtypes = [vp, i, vp, vp, i, vp]
+        L.orbm_knn2.argtypes = [vp, i, vp, i, i]
+        L.orbm_knn2_fetch.argtypes = [vp, i, vp, vp, vp, vp, vp, i]
+        L.orbx_last_error.restype = C.c_char_p
+
+    def check(self, rc):
+        if rc != 0:
+            raise OrbxError(rc, (self.L.orbx_last_error() or b"").decode())
+        return rc
+
+    def stage_names(self):
+        return [self.L.orbx_stage_name(k).decode() for k in range(NSTAGES)]
+
+
+_HIP = None
+
+
+def load_hip():
+    """The product library.  Raises if it is not built or cannot be loaded — never falls back to CPU."""
+    global _HIP
+    if _HIP is None:
+        _HIP = OrbxLib(HIP_LIB_PATH)
+    return _HIP

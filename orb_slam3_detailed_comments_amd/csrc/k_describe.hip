@@ -1,0 +1,143 @@
+// k_describe.hip — per-keypoint kernels of the ORB extractor:
+//   k_layout        final output index of every keypoint: level scaling + lapping-area front/back
+//                   reorder of ORBextractor::operator() (src/ORBextractor.cc:1613-1681) as prefix sums
+//   k_orient_brief  one wave64 per keypoint: IC_Angle (:91-138, :580-591) on the raw level, then the
+//                   256-bit steered BRIEF (:150-203) on the blurred level; 64 lanes x 4 rounds of
+//                   __ballot assemble the four 64-bit descriptor words directly.
+#include "orbx_types.h"
+#include "orbx_block.h"
+#include "glibc_sincosf_model.h"
+
+namespace orbx {
+
+// rBRIEF pattern (data table of the reference, src/ORBextractor.cc:206-464), read through the scalar/L1 path
+__device__ const signed char d_brief_pattern[1024] = {
+#include "brief_pattern.inc"
+};
+#define BRIEF_PATTERN d_brief_pattern
+
+// cv::fastAtan2 (OpenCV core mathfuncs): fp32, explicit IEEE ops, no contraction.
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float s = (float)(180.0 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s;
+    const float p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
+    const float eps = 2.2204460492503131e-16f;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps)); c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps)); c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+// grid (B), 256 threads.
+__global__ void __launch_bounds__(256) k_layout(const LevelInfo* __restrict__ lv, int nlevels,
+                                                const uint32_t* __restrict__ lvl_keys, int kp_total_cap,
+                                                const int* __restrict__ lvl_count, int lap0, int lap1,
+                                                int* __restrict__ final_idx, int* __restrict__ n_out, int* __restrict__ mono_out) {
+    __shared__ unsigned long long s_scan[20];
+    const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
+    int total = 0;
+    for (int l = 0; l < nlevels; l++) total += lvl_count[(size_t)b * nlevels + l];
+    int mono_run = 0, lap_run = 0;
+    for (int l = 0; l < nlevels; l++) {
+        const LevelInfo L = lv[l];
+        const int cnt = lvl_count[(size_t)b * nlevels + l];
+        for (int i0 = 0; i0 < cnt; i0 += 256) {
+            const int i = i0 + tid;
+            int lap = 0, valid = 0;
+            if (i < cnt) {
+                valid = 1;
+                float xf = (float)(key_x(lvl_keys[(size_t)b * kp_total_cap + L.kp_off + i]) + kBorder);
+                if (l != 0) xf = __fmul_rn(xf, L.scale);
+                lap = (xf >= (float)lap0 && xf <= (float)lap1) ? 1 : 0;
+            }
+            const unsigned long long v = (unsigned long long)(valid && !lap) | ((unsigned long long)lap << 32);
+            unsigned long long tot;
+            const unsigned long long ex = block_excl_scan<unsigned long long>(v, &tot, s_scan);
+            if (valid) {
+                const int idx = lap ? (total - 1 - (lap_run + (int)(ex >> 32))) : (mono_run + (int)(ex & 0xFFFFFFFFu));
+                final_idx[(size_t)b * kp_total_cap + L.kp_off + i] = idx;
+            }
+            mono_run += (int)(tot & 0xFFFFFFFFu); lap_run += (int)(tot >> 32);
+        }
+    }
+    if (tid == 0) { n_out[b] = total; mono_out[b] = mono_run; }
+}
+
+// grid (ceil(kp_total_cap/4), B), 256 threads = 4 keypoints.
+__global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restrict__ lv, int nlevels,
+                                                      const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t pyr_stride,
+                                                      const uint32_t* __restrict__ lvl_keys, int kp_total_cap,
+                                                      const int* __restrict__ lvl_count, const int* __restrict__ final_idx,
+                                                      UmaxTab umax, KeyPointRec* __restrict__ out_kps,
+                                                      unsigned long long* __restrict__ out_desc) {
+    const int b = (int)blockIdx.y;
+    const int lane = lane_id();
+    const int slot = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (slot >= kp_total_cap) return;
+    int level = 0;
+    for (int l = 1; l < nlevels; l++) if (slot >= lv[l].kp_off) level = l;
+    const LevelInfo L = lv[level];
+    const int i = slot - L.kp_off;
+    if (i >= lvl_count[(size_t)b * nlevels + level]) return;
+    const uint32_t key = lvl_keys[(size_t)b * kp_total_cap + slot];
+    const int x = key_x(key) + kBorder, y = key_y(key) + kBorder;
+    // ---- IC_Angle: lanes 0..30 take rows v = 0,-1..-15, lanes 32..62 rows v = 1..15 ----
+    const uint8_t* raw = pyr + (size_t)b * pyr_stride + L.off + (size_t)y * L.pitch + x;
+    const int half = lane >> 5, col = lane & 31, u = col - kHalfPatch;
+    int m10 = 0, m01 = 0;
+    if (col < 31) {
+#pragma unroll 4
+        for (int it = 0; it < 16; it++) {
+            const int v = half ? it + 1 : -it;
+            const int av = v < 0 ? -v : v;
+            if (av <= kHalfPatch) {
+                const int au = u < 0 ? -u : u;
+                if (au <= umax.u[av]) {
+                    const int I = raw[(ptrdiff_t)v * L.pitch + u];
+                    m10 += u * I; m01 += v * I;
+                }
+            }
+        }
+    }
+    m10 = wave_sum(m10); m01 = wave_sum(m01);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    // ---- steered BRIEF on the blurred level ----
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    const float rad = __fmul_rn(angle, factorPI);
+    const float a = glibc_cosf(rad), bb = glibc_sinf(rad);
+    const uint8_t* ctr = blur + (size_t)b * pyr_stride + L.off + (size_t)y * L.pitch + x;
+    const int fi = final_idx[(size_t)b * kp_total_cap + slot];
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const signed char* p = &BRIEF_PATTERN[4 * (64 * r + lane)];
+        const float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
+        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, bb), __fmul_rn(y0, a)));
+        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, bb)));
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, bb), __fmul_rn(y1, a)));
+        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, bb)));
+        const int t0 = ctr[(ptrdiff_t)r0 * L.pitch + c0];
+        const int t1 = ctr[(ptrdiff_t)r1 * L.pitch + c1];
+        const unsigned long long w = __ballot(t0 < t1);
+        if (lane == r) mine = w;
+    }
+    if (lane < 4) out_desc[((size_t)b * kp_total_cap + fi) * 4 + lane] = mine;
+    if (lane == 0) {
+        KeyPointRec k;
+        float xf = (float)x, yf = (float)y;
+        if (level != 0) { xf = __fmul_rn(xf, L.scale); yf = __fmul_rn(yf, L.scale); }
+        k.x = xf; k.y = yf; k.size = (float)L.patch; k.angle = angle; k.response = (float)key_s(key);
+        k.octave = level; k.class_id = -1;
+        out_kps[(size_t)b * kp_total_cap + fi] = k;
+    }
+}
+
+}  // namespace orbx

@@ -1,0 +1,201 @@
+// k_match.hip — descriptor matching kernels (integer/bitwise; wave64 popcount + min reductions):
+//   k_hamming_matrix  all-pairs ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:2383-2403)
+//   k_stereo_match    Frame::ComputeStereoMatches steps 1-4 (src/Frame.cc:1102-1340): row-band
+//                     candidate search, best Hamming, 11x11 SAD over 11 shifts, parabola sub-pixel fit
+//   k_stereo_median   step 5 (:1343-1357): reject matches with SAD >= 1.5*1.4*median
+//   k_knn2            BFMatcher(NORM_HAMMING).knnMatch(k=2) + Lowe ratio of
+//                     Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1553-1562)
+// Descriptors are read as 4 x u64 (the reference reads 8 x int32; the popcount sum is identical).
+#include "orbx_types.h"
+#include "orbx_block.h"
+
+namespace orbx {
+
+__device__ __forceinline__ int hamming256(const unsigned long long* __restrict__ a, const unsigned long long* __restrict__ b) {
+    return __popcll(a[0] ^ b[0]) + __popcll(a[1] ^ b[1]) + __popcll(a[2] ^ b[2]) + __popcll(a[3] ^ b[3]);
+}
+
+// out[i*nb + j] = distance(descA[i], descB[j]);  grid (ceil(nb/256), na)
+__global__ void __launch_bounds__(256) k_hamming_matrix(const unsigned long long* __restrict__ A, int na,
+                                                        const unsigned long long* __restrict__ Bm, int nb,
+                                                        int* __restrict__ out) {
+    const int i = (int)blockIdx.y, j = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= na || j >= nb) return;
+    out[(size_t)i * nb + j] = hamming256(A + 4 * (size_t)i, Bm + 4 * (size_t)j);
+}
+
+// grid (ceil(cap/4), B); one wave per left keypoint.
+// kpsL/descL/nL: left extractor outputs (stride cap); same for right; pyrL/pyrR: raw pyramids.
+__global__ void __launch_bounds__(256) k_stereo_match(const LevelInfo* __restrict__ lv,
+                                                      const KeyPointRec* __restrict__ kpsL, const unsigned long long* __restrict__ descL, const int* __restrict__ nL,
+                                                      const KeyPointRec* __restrict__ kpsR, const unsigned long long* __restrict__ descR, const int* __restrict__ nR,
+                                                      int cap, const uint8_t* __restrict__ pyrL, const uint8_t* __restrict__ pyrR, size_t pyr_stride,
+                                                      StereoParams P, float* __restrict__ uRight, float* __restrict__ depth, int* __restrict__ sad) {
+    const int b = (int)blockIdx.y, lane = lane_id();
+    const int iL = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (iL >= cap) return;
+    const size_t o = (size_t)b * cap + iL;
+    if (iL >= nL[b]) { if (lane == 0) { uRight[o] = -1.0f; depth[o] = -1.0f; sad[o] = -1; } return; }
+    const KeyPointRec kL = kpsL[o];
+    const int levelL = kL.octave;
+    const float uL = kL.x, vL = kL.y;
+    const float maxD = __fdiv_rn(P.mbf, P.mb);
+    const float minU = __fsub_rn(uL, maxD), maxU = uL;
+    float out_u = -1.0f, out_d = -1.0f; int out_sad = -1;
+    const int rowL = __float2int_rz(vL);
+    const int nr = nR[b];
+    unsigned best = ((unsigned)P.th_high << 16) | 0xFFFFu;
+    if (!(maxU < 0)) {
+        const unsigned long long* dl = descL + 4 * o;
+        const unsigned long long d0 = dl[0], d1 = dl[1], d2 = dl[2], d3 = dl[3];
+        for (int iR = lane; iR < nr; iR += 64) {
+            const KeyPointRec kR = kpsR[(size_t)b * cap + iR];
+            const float r = __fmul_rn(2.0f, lv[kR.octave].scale);
+            const int maxr = (int)ceilf(__fadd_rn(kR.y, r)), minr = (int)floorf(__fsub_rn(kR.y, r));
+            if (rowL < minr || rowL > maxr) continue;
+            if (kR.octave < levelL - 1 || kR.octave > levelL + 1) continue;
+            if (kR.x >= minU && kR.x <= maxU) {
+                const unsigned long long* dr = descR + 4 * ((size_t)b * cap + iR);
+                const int dist = __popcll(d0 ^ dr[0]) + __popcll(d1 ^ dr[1]) + __popcll(d2 ^ dr[2]) + __popcll(d3 ^ dr[3]);
+                const unsigned cand = ((unsigned)dist << 16) | (unsigned)iR;
+                if (dist < (int)(best >> 16)) best = cand;   // strict '<': first (lowest iR) minimum wins
+            }
+        }
+    }
+    best = wave_min_u32(best);   // lowest distance, then lowest right index == sequential first-min
+    const int bestDist = (int)(best >> 16);
+    if (bestDist < P.th_orb && (best & 0xFFFFu) != 0xFFFFu) {
+        const int bestIdxR = (int)(best & 0xFFFFu);
+        const float uR0 = kpsR[(size_t)b * cap + bestIdxR].x;
+        const LevelInfo Lv = lv[levelL];
+        const float sf = Lv.inv_scale;
+        const float scaleduL = roundf(__fmul_rn(kL.x, sf)), scaledvL = roundf(__fmul_rn(kL.y, sf));
+        const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
+        const int w = 5, Lh = 5;
+        const float iniu = scaleduR0 + (float)(Lh - w), endu = scaleduR0 + (float)(Lh + w + 1);
+        const int cu = (int)scaleduL, cv = (int)scaledvL, cr = (int)scaleduR0;
+        // the reference only guards iniu/endu (:1265); the extra clause keeps every read inside the level
+        const bool inb = cv - w >= 0 && cv + w < Lv.h && cu - w >= 0 && cu + w < Lv.w && cr - Lh - w >= 0 && cr + Lh + w < Lv.w;
+        if (!(iniu < 0 || endu >= (float)Lv.w) && inb) {
+            const uint8_t* IL = pyrL + (size_t)b * pyr_stride + Lv.off;
+            const uint8_t* IR = pyrR + (size_t)b * pyr_stride + Lv.off;
+            int acc[11];
+#pragma unroll
+            for (int k = 0; k < 11; k++) acc[k] = 0;
+#pragma unroll
+            for (int rep = 0; rep < 2; rep++) {
+                const int idx = lane + 64 * rep;
+                if (idx < 121) {
+                    const int row = idx / 11, col = idx - row * 11;
+                    const int a = IL[(size_t)(cv - w + row) * Lv.pitch + (cu - w + col)];
+                    const uint8_t* rp = IR + (size_t)(cv - w + row) * Lv.pitch + (cr - w - Lh + col);
+#pragma unroll
+                    for (int k = 0; k < 11; k++) { const int d = a - (int)rp[k]; acc[k] += d < 0 ? -d : d; }
+                }
+            }
+            int bestS = 0x7FFFFFFF, bestinc = 0;
+            int vd[11];
+#pragma unroll
+            for (int k = 0; k < 11; k++) { vd[k] = wave_sum(acc[k]); if (vd[k] < bestS) { bestS = vd[k]; bestinc = k - Lh; } }
+            if (!(bestinc == -Lh || bestinc == Lh)) {
+                float dist1 = 0, dist2 = 0, dist3 = 0;
+#pragma unroll
+                for (int k = 1; k < 10; k++) if (k == bestinc + Lh) { dist1 = (float)vd[k - 1]; dist2 = (float)vd[k]; dist3 = (float)vd[k + 1]; }
+                const float deltaR = __fdiv_rn(__fsub_rn(dist1, dist3),
+                                               __fmul_rn(2.0f, __fsub_rn(__fadd_rn(dist1, dist3), __fmul_rn(2.0f, dist2))));
+                if (!(deltaR < -1 || deltaR > 1)) {
+                    float bestuR = __fmul_rn(Lv.scale, __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
+                    float disparity = __fsub_rn(uL, bestuR);
+                    if (disparity >= 0 && disparity < maxD) {
+                        if (disparity <= 0) { disparity = 0.01f; bestuR = (float)((double)uL - 0.01); }
+                        out_d = __fdiv_rn(P.mbf, disparity);
+                        out_u = bestuR;
+                        out_sad = bestS;
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) { uRight[o] = out_u; depth[o] = out_d; sad[o] = out_sad; }
+}
+
+// grid (B), 256 threads.  LDS: cap ints.
+__global__ void __launch_bounds__(256) k_stereo_median(const int* __restrict__ nL, int cap,
+                                                       float* __restrict__ uRight, float* __restrict__ depth,
+                                                       const int* __restrict__ sad, int* __restrict__ n_matches) {
+    ORBX_DYN_SMEM(smem);
+    __shared__ unsigned long long s_scan[20];
+    __shared__ int s_med[1];
+    int* list = (int*)smem;
+    const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const int n = nL[b];
+    int cnt = 0;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        const int s = i < n ? sad[(size_t)b * cap + i] : -1;
+        unsigned long long tot;
+        const int pos = (int)block_excl_scan<unsigned long long>((unsigned long long)(s >= 0), &tot, s_scan);
+        if (s >= 0) list[cnt + pos] = s;
+        cnt += (int)tot;
+    }
+    if (tid == 0) s_med[0] = -1;
+    __syncthreads();
+    if (cnt == 0) { if (tid == 0) n_matches[b] = 0; return; }
+    const int k = cnt / 2;
+    for (int i = tid; i < cnt; i += 256) {
+        const int e = list[i];
+        int less = 0, eq = 0;
+        for (int j = 0; j < cnt; j++) { const int v = list[j]; less += v < e; eq += v == e; }
+        if (less <= k && k < less + eq) s_med[0] = e;
+    }
+    __syncthreads();
+    const float median = (float)s_med[0];
+    const float thDist = __fmul_rn(1.5f * 1.4f, median);
+    int kept = 0;
+    for (int i = tid; i < n; i += 256) {
+        const int s = sad[(size_t)b * cap + i];
+        if (s >= 0) {
+            if (!((float)s < thDist)) { uRight[(size_t)b * cap + i] = -1.0f; depth[(size_t)b * cap + i] = -1.0f; }
+            else kept++;
+        }
+    }
+    kept = wave_sum(kept);
+    if ((tid & 63) == 0) s_scan[tid >> 6] = (unsigned long long)kept;
+    __syncthreads();
+    if (tid == 0) n_matches[b] = (int)(s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3]);
+}
+
+// grid (ceil(cap/4), B); wave per query.  Query rows [qoff[b], nq[b]) of descQ, train rows [toff[b], nt[b]) of descT.
+// Outputs are indexed by query row relative to qoff; indices are relative to toff (like DMatch.trainIdx).
+__global__ void __launch_bounds__(256) k_knn2(const unsigned long long* __restrict__ descQ, const int* __restrict__ qoff, const int* __restrict__ nq,
+                                              const unsigned long long* __restrict__ descT, const int* __restrict__ toff, const int* __restrict__ nt,
+                                              int cap, int* __restrict__ idx0, int* __restrict__ dist0, int* __restrict__ idx1, int* __restrict__ dist1,
+                                              uint8_t* __restrict__ ratio_ok) {
+    const int b = (int)blockIdx.y, lane = lane_id();
+    const int q = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int q0 = qoff ? qoff[b] : 0, t0 = toff ? toff[b] : 0;
+    const int nQ = nq[b] - q0, nT = nt[b] - t0;
+    if (q >= cap) return;
+    const size_t o = (size_t)b * cap + q;
+    if (q >= nQ) { if (lane == 0) { idx0[o] = -1; idx1[o] = -1; dist0[o] = -1; dist1[o] = -1; ratio_ok[o] = 0; } return; }
+    const unsigned long long* dq = descQ + 4 * ((size_t)b * cap + q0 + q);
+    const unsigned long long a0 = dq[0], a1 = dq[1], a2 = dq[2], a3 = dq[3];
+    unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;   // (dist << 16 | idx), lexicographic == strict '<' insertion order
+    for (int j = lane; j < nT; j += 64) {
+        const unsigned long long* dt = descT + 4 * ((size_t)b * cap + t0 + j);
+        const int d = __popcll(a0 ^ dt[0]) + __popcll(a1 ^ dt[1]) + __popcll(a2 ^ dt[2]) + __popcll(a3 ^ dt[3]);
+        const unsigned key = ((unsigned)d << 16) | (unsigned)j;
+        if (key < k0) { k1 = k0; k0 = key; } else if (key < k1) k1 = key;
+    }
+    const unsigned b0 = wave_min_u32(k0);
+    if (k0 == b0) k0 = k1;            // the winner's lane exposes its runner-up
+    const unsigned b1 = wave_min_u32(k0);
+    if (lane == 0) {
+        const int i0 = b0 == 0xFFFFFFFFu ? -1 : (int)(b0 & 0xFFFF), i1 = b1 == 0xFFFFFFFFu ? -1 : (int)(b1 & 0xFFFF);
+        const int dd0 = i0 < 0 ? -1 : (int)(b0 >> 16), dd1 = i1 < 0 ? -1 : (int)(b1 >> 16);
+        idx0[o] = i0; idx1[o] = i1; dist0[o] = dd0; dist1[o] = dd1;
+        ratio_ok[o] = (i1 >= 0 && (double)(float)dd0 < (double)(float)dd1 * 0.7) ? 1 : 0;
+    }
+}
+
+}  // namespace orbx

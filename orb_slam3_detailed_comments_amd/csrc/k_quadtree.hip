@@ -1,0 +1,396 @@
+// k_quadtree.hip — the reference's quadtree keypoint distribution (ORBextractor::DistributeOctTree +
+// ExtractorNode::DivideNode + compareNodes, src/ORBextractor.cc:602-697, :711-1057) as ONE workgroup
+// per (image, level), bit-exact including list order and the unstable std::sort tie permutation.
+//
+// Formulation (proved equal to the reference by oracle/orb_oracle.cpp::quadtree, which is checked
+// against the reference's own source):
+//   * the std::list is an array in list order; a full pass replaces it by
+//       [children of the LAST divided node ... children of the FIRST divided node] ++ [undivided nodes]
+//     with each child block ordered n4,n3,n2,n1 (push_front order), empty children dropped;
+//   * a node's keys are a contiguous span of a key buffer; DivideNode is a *stable* 4-way partition of
+//     the span (wave ballots), so keys keep the reference's vKeys order and "first max response wins"
+//     (:1028-1053) is "first max in the span";
+//   * bNoMore <=> span length 1;
+//   * the final rounds (:940-1020) sort (size, node) pairs with a single-lane model of libstdc++'s
+//     std::sort (libstdcxx_sort_model.h), then a prefix over "non-empty children - 1" finds where
+//     `lNodes.size() >= N` breaks the loop.
+// Key buffers A/B live in HBM (L2-resident, a few KB per level); node lists live in LDS.
+#include "orbx_types.h"
+#include "orbx_block.h"
+#include "libstdcxx_sort_model.h"
+
+namespace orbx {
+
+struct SortLess {
+    __device__ __forceinline__ bool operator()(unsigned long long a, unsigned long long b) const { return (a >> 16) < (b >> 16); }
+};
+
+__device__ __forceinline__ int node_cnt(const QNode& n) { return (int)(n.cnt_buf & 0x3FFFFFFFu); }
+__device__ __forceinline__ int node_buf(const QNode& n) { return (int)((n.cnt_buf >> 30) & 1u); }
+
+// Stable 4-way partition of one node's span by one wave: src span -> dst span (same offsets), children
+// laid out n1|n2|n3|n4.  Returns the 4 child counts (valid in every lane).
+__device__ __forceinline__ void wave_partition(const QNode nd, const uint32_t* __restrict__ src,
+                                               uint32_t* __restrict__ dst, int cnt[4]) {
+    const int lane = lane_id();
+    const int c = node_cnt(nd);
+    const int s = (int)nd.start;
+    // halfX = ceil(float(w)/2) (src/ORBextractor.cc:608-609); exact in integers for w >= 0
+    const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1);
+    const int my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (c <= 64) {
+        uint32_t key = 0; int q = -1;
+        if (lane < c) {
+            key = src[s + lane];
+            const bool left = key_x(key) < mx, top = key_y(key) < my;
+            q = left ? (top ? 0 : 2) : (top ? 1 : 3);
+        }
+        const unsigned long long b0 = __ballot(q == 0), b1 = __ballot(q == 1), b2 = __ballot(q == 2), b3 = __ballot(q == 3);
+        cnt[0] = __popcll(b0); cnt[1] = __popcll(b1); cnt[2] = __popcll(b2); cnt[3] = __popcll(b3);
+        if (q >= 0) {
+            const unsigned long long bq = q == 0 ? b0 : q == 1 ? b1 : q == 2 ? b2 : b3;
+            const int base = q == 0 ? 0 : q == 1 ? cnt[0] : q == 2 ? cnt[0] + cnt[1] : cnt[0] + cnt[1] + cnt[2];
+            dst[s + base + __popcll(bq & lt)] = key;
+        }
+        return;
+    }
+    int tot[4] = {0, 0, 0, 0};
+    for (int i0 = 0; i0 < c; i0 += 64) {
+        int q = -1;
+        if (i0 + lane < c) {
+            const uint32_t key = src[s + i0 + lane];
+            const bool left = key_x(key) < mx, top = key_y(key) < my;
+            q = left ? (top ? 0 : 2) : (top ? 1 : 3);
+        }
+        tot[0] += __popcll(__ballot(q == 0)); tot[1] += __popcll(__ballot(q == 1));
+        tot[2] += __popcll(__ballot(q == 2)); tot[3] += __popcll(__ballot(q == 3));
+    }
+    int run[4] = {0, tot[0], tot[0] + tot[1], tot[0] + tot[1] + tot[2]};
+    for (int i0 = 0; i0 < c; i0 += 64) {
+        int q = -1; uint32_t key = 0;
+        if (i0 + lane < c) {
+            key = src[s + i0 + lane];
+            const bool left = key_x(key) < mx, top = key_y(key) < my;
+            q = left ? (top ? 0 : 2) : (top ? 1 : 3);
+        }
+        const unsigned long long b0 = __ballot(q == 0), b1 = __ballot(q == 1), b2 = __ballot(q == 2), b3 = __ballot(q == 3);
+        if (q >= 0) {
+            const unsigned long long bq = q == 0 ? b0 : q == 1 ? b1 : q == 2 ? b2 : b3;
+            dst[s + run[q] + __popcll(bq & lt)] = key;
+        }
+        run[0] += __popcll(b0); run[1] += __popcll(b1); run[2] += __popcll(b2); run[3] += __popcll(b3);
+    }
+    cnt[0] = tot[0]; cnt[1] = tot[1]; cnt[2] = tot[2]; cnt[3] = tot[3];
+}
+
+__device__ __forceinline__ QNode make_child(const QNode& p, int q, const int cnt[4], int newbuf) {
+    const int mx = p.x0 + ((p.x1 - p.x0 + 1) >> 1);
+    const int my = p.y0 + ((p.y1 - p.y0 + 1) >> 1);
+    QNode c;
+    c.x0 = (q & 1) ? (int16_t)mx : p.x0;  c.x1 = (q & 1) ? p.x1 : (int16_t)mx;
+    c.y0 = (q & 2) ? (int16_t)my : p.y0;  c.y1 = (q & 2) ? p.y1 : (int16_t)my;
+    int off = 0;
+    for (int k = 0; k < q; k++) off += cnt[k];
+    c.start = p.start + (uint32_t)off;
+    c.cnt_buf = (uint32_t)cnt[q] | ((uint32_t)newbuf << 30);
+    return c;
+}
+
+// grid (nlevels, B), 256 threads.  Dynamic LDS: see carve below (host passes node_cap).
+__global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ lv,
+                                                  const CellInfo* __restrict__ cells, int ncells,
+                                                  const int* __restrict__ cell_count,
+                                                  const uint32_t* __restrict__ slots, size_t slots_stride,
+                                                  uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
+                                                  uint32_t* __restrict__ lvl_keys, int kp_total_cap,
+                                                  int* __restrict__ lvl_count, int nlevels, int node_cap,
+                                                  int* __restrict__ status) {
+    ORBX_DYN_SMEM(smem);
+    __shared__ unsigned long long s_scan[20];
+    __shared__ int s_i[16];
+    const int level = (int)blockIdx.x, b = (int)blockIdx.y;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const LevelInfo L = lv[level];
+    const int N = L.quota;
+    // LDS carve: nodes[2][cap] (16 B) | childcnt[cap][4] (u32) | expand[2][cap] (u64) | erased[cap] (u8)
+    QNode* nodes0 = (QNode*)smem;
+    QNode* nodes1 = nodes0 + node_cap;
+    uint32_t* childcnt = (uint32_t*)(nodes1 + node_cap);
+    unsigned long long* exp0 = (unsigned long long*)(childcnt + 4 * (size_t)node_cap);
+    unsigned long long* exp1 = exp0 + node_cap;
+    uint8_t* erased = (uint8_t*)(exp1 + node_cap);
+    uint32_t* bufA = candA + (size_t)b * cand_stride + L.cand_off;
+    uint32_t* bufB = candB + (size_t)b * cand_stride + L.cand_off;
+    const int* ccount = cell_count + (size_t)b * ncells + L.cell_begin;
+    const uint32_t* slot_base = slots + (size_t)b * slots_stride;
+
+    // ---- P0: gather the level's candidates in the reference order (cells row-major) into bufB ----
+    int n = 0;
+    for (int c0 = 0; c0 < L.cell_count; c0 += 256) {
+        const int c = c0 + tid;
+        const int cnt = c < L.cell_count ? ccount[c] : 0;
+        unsigned long long tot;
+        const int pos = n + (int)block_excl_scan<unsigned long long>((unsigned long long)cnt, &tot, s_scan);
+        if (cnt > 0) {
+            const uint32_t* sp = slot_base + cells[L.cell_begin + c].slot_off;
+            for (int k = 0; k < cnt; k++) bufB[pos + k] = sp[k];
+        }
+        n += (int)tot;
+    }
+    __syncthreads();
+    // ---- roots (:718-764): key -> root (int)(x / hX), stable per-root compaction bufB -> bufA ----
+    int nnodes = 0;
+    {
+        int base = 0;
+        for (int r = 0; r < L.nini; r++) {
+            int rcount = 0;
+            for (int i0 = 0; i0 < n; i0 += 256) {
+                const int i = i0 + tid;
+                uint32_t key = 0; int flag = 0;
+                if (i < n) {
+                    key = bufB[i];
+                    const int root = __float2int_rz(__fdiv_rn((float)key_x(key), L.hX));
+                    flag = (root == r);
+                }
+                unsigned long long tot;
+                const int pos = (int)block_excl_scan<unsigned long long>((unsigned long long)flag, &tot, s_scan);
+                if (flag) bufA[base + rcount + pos] = key;
+                rcount += (int)tot;
+            }
+            if (rcount > 0) {
+                if (tid == 0) {
+                    QNode nd;
+                    nd.x0 = (int16_t)__float2int_rz(__fmul_rn(L.hX, (float)r));
+                    nd.x1 = (int16_t)__float2int_rz(__fmul_rn(L.hX, (float)(r + 1)));
+                    nd.y0 = 0; nd.y1 = (int16_t)L.bh;
+                    nd.start = (uint32_t)base; nd.cnt_buf = (uint32_t)rcount;   // buffer A = 0
+                    nodes0[nnodes] = nd;
+                }
+                nnodes++;
+            }
+            base += rcount;
+        }
+    }
+    __syncthreads();
+
+    QNode* cur = nodes0; QNode* nxt = nodes1;
+    unsigned long long* expc = exp0; unsigned long long* expn = exp1;
+    bool finish = (n == 0);
+    int overflow = 0;
+    while (!finish) {
+        const int prevSize = nnodes;
+        // ---- full pass: divide every node with more than one key (:790-905) ----
+        for (int i = wave; i < nnodes; i += 4) {
+            const QNode nd = cur[i];
+            if (node_cnt(nd) > 1) {
+                int cnt[4];
+                const int bsel = node_buf(nd);
+                wave_partition(nd, bsel ? bufB : bufA, bsel ? bufA : bufB, cnt);
+                if (lane < 4) childcnt[4 * i + lane] = (uint32_t)(lane == 0 ? cnt[0] : lane == 1 ? cnt[1] : lane == 2 ? cnt[2] : cnt[3]);
+            }
+        }
+        __syncthreads();
+        int T = 0, E = 0, K = 0;
+        {
+            // exclusive scans over the list of (m = non-empty children, e = children with >1 key, k = kept)
+            unsigned long long run = 0, total_all = 0;
+            // first compute totals (needed for the reversed block placement)
+            for (int i0 = 0; i0 < nnodes; i0 += 256) {
+                const int i = i0 + tid;
+                unsigned long long v = 0;
+                if (i < nnodes) {
+                    const int c = node_cnt(cur[i]);
+                    if (c > 1) {
+                        int m = 0, e = 0;
+                        for (int q = 0; q < 4; q++) { const int cq = (int)childcnt[4 * i + q]; m += cq > 0; e += cq > 1; }
+                        v = (unsigned long long)m | ((unsigned long long)e << 20);
+                    } else v = 1ull << 40;
+                }
+                unsigned long long tot;
+                (void)block_excl_scan<unsigned long long>(v, &tot, s_scan);
+                total_all += tot;
+            }
+            T = (int)(total_all & 0xFFFFF); E = (int)((total_all >> 20) & 0xFFFFF); K = (int)(total_all >> 40);
+            if (T + K > node_cap) { overflow = 1; }
+            if (!overflow) {
+                for (int i0 = 0; i0 < nnodes; i0 += 256) {
+                    const int i = i0 + tid;
+                    unsigned long long v = 0; int c = 0; int cq[4] = {0, 0, 0, 0};
+                    QNode nd;
+                    if (i < nnodes) {
+                        nd = cur[i]; c = node_cnt(nd);
+                        if (c > 1) {
+                            int m = 0, e = 0;
+                            for (int q = 0; q < 4; q++) { cq[q] = (int)childcnt[4 * i + q]; m += cq[q] > 0; e += cq[q] > 1; }
+                            v = (unsigned long long)m | ((unsigned long long)e << 20);
+                        } else v = 1ull << 40;
+                    }
+                    unsigned long long tot;
+                    const unsigned long long ex = run + block_excl_scan<unsigned long long>(v, &tot, s_scan);
+                    run += tot;
+                    if (i < nnodes) {
+                        if (c > 1) {
+                            const int Pm = (int)(ex & 0xFFFFF), Pe = (int)((ex >> 20) & 0xFFFFF);
+                            const int m = (int)(v & 0xFFFFF);
+                            const int newbuf = node_buf(nd) ^ 1;
+                            int after = 0;      // non-empty children with larger q come first in the block
+                            int erank = 0;
+                            for (int q = 3; q >= 0; q--) {
+                                if (cq[q] > 0) { nxt[T - Pm - m + after] = make_child(nd, q, cq, newbuf); after++; }
+                            }
+                            int seen = 0;
+                            for (int q = 0; q < 4; q++) {
+                                if (cq[q] > 0) {
+                                    // position of child q inside the block = number of non-empty children with q' > q
+                                    int pos_in_block = 0;
+                                    for (int q2 = q + 1; q2 < 4; q2++) pos_in_block += cq[q2] > 0;
+                                    if (cq[q] > 1) {
+                                        const int mxx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1);
+                                        const int cx0 = (q & 1) ? mxx : (int)nd.x0;
+                                        expn[Pe + erank] = ((unsigned long long)cq[q] << 32) | ((unsigned long long)(uint16_t)cx0 << 16) |
+                                                           (unsigned long long)(T - Pm - m + pos_in_block);
+                                        erank++;
+                                    }
+                                    seen++;
+                                }
+                            }
+                            (void)seen;
+                        } else {
+                            const int Pk = (int)(ex >> 40);
+                            nxt[T + Pk] = nd;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (overflow) break;
+        nnodes = T + K;
+        int nexp = E;
+        { QNode* t = cur; cur = nxt; nxt = t; }
+        { unsigned long long* t = expc; expc = expn; expn = t; }
+        if (nnodes >= N || nnodes == prevSize) { finish = true; }
+        else if (nnodes + nexp * 3 > N) {
+            // ---- final rounds (:940-1020): split largest-first until the quota is reached ----
+            while (!finish) {
+                const int prev2 = nnodes;
+                if (tid == 0) libstdcxx_sort(expc, nexp, SortLess());
+                for (int i = tid; i < nnodes; i += 256) erased[i] = 0;
+                __syncthreads();
+                // children counts of every candidate (partition into the other buffer; harmless if the
+                // node ends up not being divided: its own buffer is untouched)
+                for (int j = wave; j < nexp; j += 4) {
+                    const int idx = (int)(expc[j] & 0xFFFF);
+                    const QNode nd = cur[idx];
+                    int cnt[4];
+                    const int bsel = node_buf(nd);
+                    wave_partition(nd, bsel ? bufB : bufA, bsel ? bufA : bufB, cnt);
+                    if (lane < 4) childcnt[4 * idx + lane] = (uint32_t)(lane == 0 ? cnt[0] : lane == 1 ? cnt[1] : lane == 2 ? cnt[2] : cnt[3]);
+                }
+                __syncthreads();
+                // how many of the sorted candidates get divided before `size >= N` breaks the loop
+                if (tid == 0) {
+                    int size = prev2, ndiv = 0;
+                    for (int j = nexp - 1; j >= 0; j--) {
+                        const int idx = (int)(expc[j] & 0xFFFF);
+                        int m = 0;
+                        for (int q = 0; q < 4; q++) m += childcnt[4 * idx + q] > 0;
+                        size += m - 1; ndiv++;
+                        if (size >= N) break;
+                    }
+                    s_i[0] = ndiv;
+                }
+                __syncthreads();
+                const int ndiv = s_i[0];
+                // totals over the divided set (division order t = 0..ndiv-1 <-> sorted index nexp-1-t)
+                unsigned long long total_all = 0;
+                for (int t0 = 0; t0 < ndiv; t0 += 256) {
+                    const int t = t0 + tid;
+                    unsigned long long v = 0;
+                    if (t < ndiv) {
+                        const int idx = (int)(expc[nexp - 1 - t] & 0xFFFF);
+                        int m = 0, e = 0;
+                        for (int q = 0; q < 4; q++) { const int cq = (int)childcnt[4 * idx + q]; m += cq > 0; e += cq > 1; }
+                        v = (unsigned long long)m | ((unsigned long long)e << 20);
+                        erased[idx] = 1;
+                    }
+                    unsigned long long tot;
+                    (void)block_excl_scan<unsigned long long>(v, &tot, s_scan);
+                    total_all += tot;
+                }
+                const int T2 = (int)(total_all & 0xFFFFF), E2 = (int)((total_all >> 20) & 0xFFFFF);
+                __syncthreads();
+                if (T2 + (prev2 - ndiv) > node_cap) { overflow = 1; break; }
+                unsigned long long run = 0;
+                for (int t0 = 0; t0 < ndiv; t0 += 256) {
+                    const int t = t0 + tid;
+                    unsigned long long v = 0; int cq[4] = {0, 0, 0, 0}; QNode nd; int m = 0;
+                    if (t < ndiv) {
+                        const int idx = (int)(expc[nexp - 1 - t] & 0xFFFF);
+                        nd = cur[idx];
+                        int e = 0;
+                        for (int q = 0; q < 4; q++) { cq[q] = (int)childcnt[4 * idx + q]; m += cq[q] > 0; e += cq[q] > 1; }
+                        v = (unsigned long long)m | ((unsigned long long)e << 20);
+                    }
+                    unsigned long long tot;
+                    const unsigned long long ex = run + block_excl_scan<unsigned long long>(v, &tot, s_scan);
+                    run += tot;
+                    if (t < ndiv) {
+                        const int Pm = (int)(ex & 0xFFFFF), Pe = (int)((ex >> 20) & 0xFFFFF);
+                        const int newbuf = node_buf(nd) ^ 1;
+                        int after = 0, erank = 0;
+                        for (int q = 3; q >= 0; q--)
+                            if (cq[q] > 0) { nxt[T2 - Pm - m + after] = make_child(nd, q, cq, newbuf); after++; }
+                        for (int q = 0; q < 4; q++) {
+                            if (cq[q] > 1) {
+                                int pos_in_block = 0;
+                                for (int q2 = q + 1; q2 < 4; q2++) pos_in_block += cq[q2] > 0;
+                                const int mxx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1);
+                                const int cx0 = (q & 1) ? mxx : (int)nd.x0;
+                                expn[Pe + erank] = ((unsigned long long)cq[q] << 32) | ((unsigned long long)(uint16_t)cx0 << 16) |
+                                                   (unsigned long long)(T2 - Pm - m + pos_in_block);
+                                erank++;
+                            }
+                        }
+                    }
+                }
+                // old list minus the erased parents, in old order, after the new blocks
+                int kept_run = 0;
+                for (int i0 = 0; i0 < prev2; i0 += 256) {
+                    const int i = i0 + tid;
+                    const int keep = (i < prev2 && !erased[i]) ? 1 : 0;
+                    unsigned long long tot;
+                    const int pos = (int)block_excl_scan<unsigned long long>((unsigned long long)keep, &tot, s_scan);
+                    if (keep) nxt[T2 + kept_run + pos] = cur[i];
+                    kept_run += (int)tot;
+                }
+                __syncthreads();
+                nnodes = T2 + kept_run;
+                nexp = E2;
+                { QNode* t = cur; cur = nxt; nxt = t; }
+                { unsigned long long* t = expc; expc = expn; expn = t; }
+                if (nnodes >= N || nnodes == prev2) finish = true;
+            }
+            break;
+        }
+    }
+    __syncthreads();
+    // ---- result (:1028-1053): per node, the first key with the largest response ----
+    uint32_t* outk = lvl_keys + (size_t)b * kp_total_cap + L.kp_off;
+    if (overflow || nnodes > L.kp_cap) {
+        if (tid == 0) { atomicOr(status, 1); lvl_count[(size_t)b * nlevels + level] = 0; }
+        return;
+    }
+    for (int i = tid; i < nnodes; i += 256) {
+        const QNode nd = cur[i];
+        const uint32_t* kb = (node_buf(nd) ? bufB : bufA) + nd.start;
+        const int c = node_cnt(nd);
+        uint32_t best = kb[0];
+        for (int k = 1; k < c; k++) { const uint32_t key = kb[k]; if (key_s(key) > key_s(best)) best = key; }
+        outk[i] = best;
+    }
+    if (tid == 0) lvl_count[(size_t)b * nlevels + level] = nnodes;
+}
+
+}  // namespace orbx

@@ -1,0 +1,616 @@
+// orbx_api.cpp — host side of liborbx_hip.so: parameter tables (reference ORBextractor constructor,
+// src/ORBextractor.cc:468-571), per-resolution geometry (pyramid sizes :1691-1692, FAST cell grid
+// :1069-1129, resize coefficients of cv::resize), device memory, stream orchestration and the C ABI of
+// include/orbx.h.  Compiled by hipcc for gfx950 (product) or by g++ against tests/emu (tests only).
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/orbx.h"
+#include "orbx_kernels.h"
+#include "orbx_rt.h"
+
+using namespace orbx;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char* fmt, ...) {
+    char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf; return code;
+}
+
+inline int round_half_even_f(float v) { return (int)lrintf(v); }    // cvRound under the default FP mode
+inline int round_half_even_d(double v) { return (int)lrint(v); }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+enum Stage { ST_IMPORT = 0, ST_PYRAMID, ST_FAST, ST_QUADTREE, ST_BLUR, ST_LAYOUT, ST_DESCRIBE, ST_MATCH };
+const char* kStageNames[ORBX_NSTAGES] = {"import", "pyramid", "fast_cells", "quadtree", "blur", "layout", "orient_brief", "match"};
+
+template <typename T> struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    int ensure(size_t count) {
+        if (count <= n && p) return 0;
+        rt::dfree(p); p = (T*)rt::dmalloc(count * sizeof(T)); n = p ? count : 0;
+        return p ? 0 : -1;
+    }
+    void release() { rt::dfree(p); p = nullptr; n = 0; }
+};
+template <typename T> struct HostBuf {
+    T* p = nullptr; size_t n = 0;
+    int ensure(size_t count) {
+        if (count <= n && p) return 0;
+        rt::hfree(p); p = (T*)rt::hmalloc(count * sizeof(T)); n = p ? count : 0;
+        return p ? 0 : -1;
+    }
+    void release() { rt::hfree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct orbx_extractor {
+    // ---- reference constructor state (src/ORBextractor.cc:468-571) ----
+    int nfeatures = 0, nlevels = 0, iniTh = 0, minTh = 0, device = 0, gauss_variant = 0;
+    double scaleFactor = 1.0;   // the reference keeps the float argument in a double member (include/ORBextractor.h:96)
+    float scale[kMaxLevels], inv_scale[kMaxLevels], sigma2[kMaxLevels], inv_sigma2[kMaxLevels];
+    int quota[kMaxLevels];
+    UmaxTab umax;
+    // ---- geometry for the configured resolution ----
+    int W = 0, H = 0, maxB = 0;
+    LevelInfo lv[kMaxLevels];
+    std::vector<CellInfo> cells;
+    std::vector<ResizeTap> xtab, ytab;
+    size_t pyr_stride = 0, cand_stride = 0;
+    int ncells = 0, kp_total_cap = 0, node_cap = 0, fast_tile_bytes = 0, fast_inner_bytes = 0;
+    // ---- device state ----
+    DevBuf<LevelInfo> d_lv; DevBuf<CellInfo> d_cells; DevBuf<ResizeTap> d_xtab, d_ytab;
+    DevBuf<uint8_t> d_pyr, d_blur, d_stage;
+    DevBuf<uint32_t> d_slots, d_candA, d_candB, d_lvl_keys;
+    DevBuf<int> d_cell_count, d_lvl_count, d_final_idx, d_nm, d_status;
+    DevBuf<KeyPointRec> d_kps; DevBuf<unsigned long long> d_desc;
+    DevBuf<float> d_uRight, d_depth; DevBuf<int> d_sad, d_nmatch;
+    DevBuf<int> d_knn; DevBuf<uint8_t> d_ratio;
+    DevBuf<unsigned long long> d_hamA, d_hamB; DevBuf<int> d_hamOut;
+    HostBuf<uint8_t> h_stage;
+    HostBuf<int> h_nm;
+    rt::stream_t s0 = 0, s1 = 0;
+    rt::event_t ev_fork = 0, ev_join = 0, ev_done = 0;
+    rt::event_t ev_stage[ORBX_NSTAGES][2];
+    bool profile = false, have_streams = false;
+    int lastB = 0;
+    float stage_ms[ORBX_NSTAGES];
+};
+
+namespace {
+
+// ---- E0: tables of the reference constructor -------------------------------------------------------
+void init_tables(orbx_extractor* h) {
+    h->scale[0] = 1.0f; h->sigma2[0] = 1.0f;
+    for (int i = 1; i < h->nlevels; i++) {
+        h->scale[i] = (float)(h->scale[i - 1] * h->scaleFactor);
+        h->sigma2[i] = h->scale[i] * h->scale[i];
+    }
+    for (int i = 0; i < h->nlevels; i++) {
+        h->inv_scale[i] = 1.0f / h->scale[i];
+        h->inv_sigma2[i] = 1.0f / h->sigma2[i];
+    }
+    const float factor = (float)(1.0f / h->scaleFactor);
+    float want = h->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)h->nlevels));
+    int sum = 0;
+    for (int l = 0; l < h->nlevels - 1; l++) {
+        h->quota[l] = round_half_even_f(want);
+        sum += h->quota[l];
+        want *= factor;
+    }
+    h->quota[h->nlevels - 1] = std::max(h->nfeatures - sum, 0);
+    // circular patch row half-widths
+    int* um = h->umax.u;
+    const int vmax = (int)floor(kHalfPatch * sqrt(2.f) / 2 + 1), vmin = (int)ceil(kHalfPatch * sqrt(2.f) / 2);
+    const double hp2 = kHalfPatch * kHalfPatch;
+    for (int v = 0; v <= vmax; ++v) um[v] = round_half_even_d(sqrt(hp2 - v * v));
+    for (int v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+        while (um[v0] == um[v0 + 1]) ++v0;
+        um[v] = v0;
+        ++v0;
+    }
+}
+
+// cv::resize(INTER_LINEAR, 8U) coefficient tables for one axis
+void resize_axis(int ssize, int dsize, bool clamp_edges, std::vector<ResizeTap>& out) {
+    const double inv = (double)dsize / ssize, sc = 1.0 / inv;
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * sc - 0.5);
+        int s = (int)floorf(f);
+        f -= s;
+        if (clamp_edges) {
+            if (s < 0) { f = 0; s = 0; }
+            if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+        }
+        int a0 = round_half_even_f((1.f - f) * 2048.f), a1 = round_half_even_f(f * 2048.f);
+        a0 = std::min(std::max(a0, -32768), 32767); a1 = std::min(std::max(a1, -32768), 32767);
+        ResizeTap t; t.ofs = s; t.w = (a0 & 0xFFFF) | (a1 << 16);
+        out.push_back(t);
+    }
+}
+
+int configure(orbx_extractor* h, int W, int H, int B) {
+    if (W <= 0 || H <= 0 || B <= 0) return fail(ORBX_E_ARG, "bad size %dx%d batch %d", W, H, B);
+    const bool same_geom = (W == h->W && H == h->H);
+    if (same_geom && B <= h->maxB) return ORBX_OK;
+    if (rt::set_device(h->device)) return fail(ORBX_E_DEVICE, "hipSetDevice(%d) failed", h->device);
+    if (!same_geom) {
+        if (W - 2 * kBorder > 4095 || H - 2 * kBorder > 4095) return fail(ORBX_E_ARG, "image larger than 4127 px is not supported");
+        h->cells.clear(); h->xtab.clear(); h->ytab.clear();
+        size_t off = 0; int cand_off = 0, kp_off = 0, node_cap = 0, tile_b = 0, inner_b = 0;
+        for (int l = 0; l < h->nlevels; l++) {
+            LevelInfo& L = h->lv[l];
+            memset(&L, 0, sizeof L);
+            L.w = round_half_even_f((float)W * h->inv_scale[l]);     // src/ORBextractor.cc:1692
+            L.h = round_half_even_f((float)H * h->inv_scale[l]);
+            L.pitch = (int)align_up((size_t)L.w, 64);
+            L.off = (int)off; off += align_up((size_t)L.pitch * L.h, 256);
+            L.scale = h->scale[l]; L.inv_scale = h->inv_scale[l]; L.quota = h->quota[l];
+            L.patch = (int)(31 * h->scale[l]);                       // :1184
+            // FAST cell grid, :1069-1129
+            const float Wc = 35;
+            const int minBX = kBorder, minBY = kBorder, maxBX = L.w - kBorder, maxBY = L.h - kBorder;
+            const float width = (float)(maxBX - minBX), height = (float)(maxBY - minBY);
+            if (width < Wc || height < Wc) return fail(ORBX_E_ARG, "level %d (%dx%d) is too small for the 35-px FAST cell grid", l, L.w, L.h);
+            L.ncols = (int)(width / Wc); L.nrows = (int)(height / Wc);
+            L.wcell = (int)ceil(width / L.ncols); L.hcell = (int)ceil(height / L.nrows);
+            L.bw = maxBX - minBX; L.bh = maxBY - minBY;
+            L.nini = (int)roundf((float)L.bw / (float)L.bh);         // :718
+            if (L.nini < 1) return fail(ORBX_E_ARG, "aspect ratio < 0.5 is not supported (the reference divides by zero)");
+            L.hX = (float)L.bw / (float)L.nini;                      // :722
+            L.cell_begin = (int)h->cells.size();
+            L.cand_off = cand_off;
+            int slot = cand_off;
+            for (int i = 0; i < L.nrows; i++) {
+                const float iniY = (float)(minBY + i * L.hcell);
+                float maxY = iniY + L.hcell + 6;
+                if (iniY >= maxBY - 3) continue;
+                if (maxY > maxBY) maxY = (float)maxBY;
+                for (int j = 0; j < L.ncols; j++) {
+                    const float iniX = (float)(minBX + j * L.wcell);
+                    float maxX = iniX + L.wcell + 6;
+                    if (iniX >= maxBX - 6) continue;
+                    if (maxX > maxBX) maxX = (float)maxBX;
+                    CellInfo c; memset(&c, 0, sizeof c);
+                    c.level = (int16_t)l;
+                    c.x0 = (int16_t)((int)iniX + 3); c.x1 = (int16_t)((int)maxX - 3);
+                    c.y0 = (int16_t)((int)iniY + 3); c.y1 = (int16_t)((int)maxY - 3);
+                    c.slot_off = slot;
+                    const int iw = std::max(c.x1 - c.x0, 0), ih = std::max(c.y1 - c.y0, 0);
+                    slot += ((iw + 1) / 2) * ((ih + 1) / 2);         // max number of strict 3x3 local maxima
+                    if (iw > 0 && ih > 0) {
+                        const int wp = (iw + 6 + 3) & ~3;
+                        tile_b = std::max(tile_b, wp * (ih + 6));
+                        inner_b = std::max(inner_b, iw * ih);
+                    }
+                    h->cells.push_back(c);
+                }
+            }
+            L.cell_count = (int)h->cells.size() - L.cell_begin;
+            L.cand_cap = slot - cand_off;
+            cand_off = slot;
+            // a full pass never overshoots the quota, a final-round split adds at most 3 (:912, :1006)
+            L.kp_cap = std::max(L.quota + 3, 4 * L.nini);
+            L.kp_off = kp_off; kp_off += L.kp_cap;
+            node_cap = std::max(node_cap, L.kp_cap + 8);
+            if (l > 0) {
+                L.xtab_off = (int)h->xtab.size(); resize_axis(h->lv[l - 1].w, L.w, true, h->xtab);
+                L.ytab_off = (int)h->ytab.size(); resize_axis(h->lv[l - 1].h, L.h, false, h->ytab);
+            }
+        }
+        h->pyr_stride = off; h->cand_stride = (size_t)cand_off; h->ncells = (int)h->cells.size();
+        h->kp_total_cap = kp_off; h->node_cap = node_cap;
+        h->fast_tile_bytes = (int)align_up((size_t)tile_b, 16); h->fast_inner_bytes = (int)align_up((size_t)inner_b, 16);
+        if (h->kp_total_cap >= 65535) return fail(ORBX_E_ARG, "nfeatures too large");
+        h->W = W; h->H = H; h->maxB = 0;
+        int e = 0;
+        e |= h->d_lv.ensure(kMaxLevels); e |= h->d_cells.ensure(h->cells.size());
+        e |= h->d_xtab.ensure(std::max<size_t>(h->xtab.size(), 1)); e |= h->d_ytab.ensure(std::max<size_t>(h->ytab.size(), 1));
+        if (e) return fail(ORBX_E_DEVICE, "device allocation failed (tables)");
+        rt::copy_h2d(h->d_lv.p, h->lv, sizeof(LevelInfo) * kMaxLevels, h->s0);
+        rt::copy_h2d(h->d_cells.p, h->cells.data(), sizeof(CellInfo) * h->cells.size(), h->s0);
+        if (!h->xtab.empty()) rt::copy_h2d(h->d_xtab.p, h->xtab.data(), sizeof(ResizeTap) * h->xtab.size(), h->s0);
+        if (!h->ytab.empty()) rt::copy_h2d(h->d_ytab.p, h->ytab.data(), sizeof(ResizeTap) * h->ytab.size(), h->s0);
+        rt::stream_sync(h->s0);
+    }
+    if (B > h->maxB) {
+        const size_t b = (size_t)B, cap = (size_t)h->kp_total_cap;
+        int e = 0;
+        e |= h->d_pyr.ensure(b * h->pyr_stride + 256); e |= h->d_blur.ensure(b * h->pyr_stride + 256);
+        e |= h->d_slots.ensure(b * h->cand_stride + 4); e |= h->d_candA.ensure(b * h->cand_stride + 4); e |= h->d_candB.ensure(b * h->cand_stride + 4);
+        e |= h->d_cell_count.ensure(b * h->ncells); e |= h->d_lvl_count.ensure(b * h->nlevels);
+        e |= h->d_lvl_keys.ensure(b * cap); e |= h->d_final_idx.ensure(b * cap);
+        e |= h->d_nm.ensure(2 * b); e |= h->d_status.ensure(4);
+        e |= h->d_kps.ensure(b * cap); e |= h->d_desc.ensure(b * cap * 4);
+        e |= h->d_uRight.ensure(b * cap); e |= h->d_depth.ensure(b * cap); e |= h->d_sad.ensure(b * cap); e |= h->d_nmatch.ensure(b);
+        e |= h->d_knn.ensure(4 * b * cap); e |= h->d_ratio.ensure(b * cap);
+        e |= h->h_nm.ensure(3 * b + 4);
+        if (e) return fail(ORBX_E_DEVICE, "device allocation failed (batch %d of %dx%d)", B, W, H);
+        rt::memset_async(h->d_status.p, 0, 4 * sizeof(int), h->s0);
+        h->maxB = B;
+    }
+    return ORBX_OK;
+}
+
+void stage_begin(orbx_extractor* h, int st, rt::stream_t s) { if (h->profile) rt::event_record(h->ev_stage[st][0], s); }
+void stage_end(orbx_extractor* h, int st, rt::stream_t s) { if (h->profile) rt::event_record(h->ev_stage[st][1], s); }
+
+int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int stride, size_t image_stride, int lap0, int lap1) {
+    const int nl = h->nlevels;
+    const dim3 blk2(64, 4, 1), blk1(256, 1, 1);
+    stage_begin(h, ST_IMPORT, h->s0);
+    {
+        const LevelInfo& L0 = h->lv[0];
+        dim3 grid((L0.pitch + 255) / 256, (L0.h + 3) / 4, B);
+        ORBX_LAUNCH(k_import, grid, blk2, 0, h->s0, (const LevelInfo*)h->d_lv.p, d_images, stride, image_stride, h->d_pyr.p, h->pyr_stride);
+    }
+    stage_end(h, ST_IMPORT, h->s0);
+    stage_begin(h, ST_PYRAMID, h->s0);
+    for (int l = 1; l < nl; l++) {
+        const LevelInfo& L = h->lv[l];
+        dim3 grid((L.pitch + 255) / 256, (L.h + 3) / 4, B);
+        ORBX_LAUNCH(k_resize, grid, blk2, 0, h->s0, (const LevelInfo*)h->d_lv.p, l, (const ResizeTap*)h->d_xtab.p, (const ResizeTap*)h->d_ytab.p, h->d_pyr.p, h->pyr_stride);
+    }
+    stage_end(h, ST_PYRAMID, h->s0);
+    // fork: the blur only depends on the pyramid and runs beside FAST + quadtree on the second stream
+    rt::event_record(h->ev_fork, h->s0);
+    rt::stream_wait_event(h->s1, h->ev_fork);
+    stage_begin(h, ST_BLUR, h->s1);
+    {
+        BlurTaps taps;
+        static const int A[7] = {18, 34, 48, 56, 48, 34, 18}, Bt[7] = {18, 34, 49, 55, 49, 34, 18};
+        for (int i = 0; i < 7; i++) taps.k[i] = h->gauss_variant == 1 ? Bt[i] : A[i];
+        dim3 grid((h->lv[0].w + 63) / 64, (h->lv[0].h + 15) / 16, B * nl);
+        ORBX_LAUNCH(k_blur, grid, blk2, 0, h->s1, (const LevelInfo*)h->d_lv.p, nl, (const uint8_t*)h->d_pyr.p, h->d_blur.p, h->pyr_stride, taps);
+    }
+    stage_end(h, ST_BLUR, h->s1);
+    rt::event_record(h->ev_join, h->s1);
+    stage_begin(h, ST_FAST, h->s0);
+    {
+        dim3 grid(h->ncells, B, 1);
+        const size_t smem = (size_t)h->fast_tile_bytes + 2 * (size_t)h->fast_inner_bytes;
+        ORBX_LAUNCH(k_fast_cells, grid, blk1, smem, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
+                    (const uint8_t*)h->d_pyr.p, h->pyr_stride, h->iniTh, h->minTh, h->d_slots.p, h->cand_stride, h->d_cell_count.p,
+                    h->fast_tile_bytes, h->fast_inner_bytes);
+    }
+    stage_end(h, ST_FAST, h->s0);
+    stage_begin(h, ST_QUADTREE, h->s0);
+    {
+        dim3 grid(nl, B, 1);
+        const size_t smem = (size_t)h->node_cap * 65 + 64;
+        ORBX_LAUNCH(k_quadtree, grid, blk1, smem, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
+                    (const int*)h->d_cell_count.p, (const uint32_t*)h->d_slots.p, h->cand_stride, h->d_candA.p, h->d_candB.p, h->cand_stride,
+                    h->d_lvl_keys.p, h->kp_total_cap, h->d_lvl_count.p, nl, h->node_cap, h->d_status.p);
+    }
+    stage_end(h, ST_QUADTREE, h->s0);
+    stage_begin(h, ST_LAYOUT, h->s0);
+    {
+        dim3 grid(B, 1, 1);
+        ORBX_LAUNCH(k_layout, grid, blk1, 0, h->s0, (const LevelInfo*)h->d_lv.p, nl, (const uint32_t*)h->d_lvl_keys.p, h->kp_total_cap,
+                    (const int*)h->d_lvl_count.p, lap0, lap1, h->d_final_idx.p, h->d_nm.p, h->d_nm.p + h->maxB);
+    }
+    stage_end(h, ST_LAYOUT, h->s0);
+    rt::stream_wait_event(h->s0, h->ev_join);
+    stage_begin(h, ST_DESCRIBE, h->s0);
+    {
+        dim3 grid((h->kp_total_cap + 3) / 4, B, 1);
+        ORBX_LAUNCH(k_orient_brief, grid, blk1, 0, h->s0, (const LevelInfo*)h->d_lv.p, nl, (const uint8_t*)h->d_pyr.p, (const uint8_t*)h->d_blur.p,
+                    h->pyr_stride, (const uint32_t*)h->d_lvl_keys.p, h->kp_total_cap, (const int*)h->d_lvl_count.p, (const int*)h->d_final_idx.p,
+                    h->umax, h->d_kps.p, h->d_desc.p);
+    }
+    stage_end(h, ST_DESCRIBE, h->s0);
+    rt::event_record(h->ev_done, h->s0);
+    h->lastB = B;
+    if (rt::check_launch()) return fail(ORBX_E_DEVICE, "kernel launch failed: %s", rt::last_error());
+    return ORBX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* orbx_last_error(void) { return g_err.c_str(); }
+const char* orbx_stage_name(int i) { return (i >= 0 && i < ORBX_NSTAGES) ? kStageNames[i] : ""; }
+int orbx_device_count(void) { return rt::device_count(); }
+
+int orbx_create(orbx_extractor** out, int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, int device_id) {
+    if (!out) return fail(ORBX_E_ARG, "null out");
+    *out = nullptr;
+    if (nfeatures <= 0 || nlevels < 1 || nlevels > kMaxLevels || !(scale_factor > 1.0f) || ini_th < 0 || min_th < 0 || ini_th > 255 || min_th > 255)
+        return fail(ORBX_E_ARG, "bad extractor parameters");
+    if (rt::device_count() <= device_id || device_id < 0) return fail(ORBX_E_DEVICE, "no usable GPU %d (HIP reports %d devices)", device_id, rt::device_count());
+    if (rt::set_device(device_id)) return fail(ORBX_E_DEVICE, "hipSetDevice(%d) failed", device_id);
+    orbx_extractor* h = new orbx_extractor();
+    h->nfeatures = nfeatures; h->scaleFactor = scale_factor; h->nlevels = nlevels; h->iniTh = ini_th; h->minTh = min_th; h->device = device_id;
+    init_tables(h);
+    int e = rt::stream_create(&h->s0) | rt::stream_create(&h->s1) | rt::event_create(&h->ev_fork) | rt::event_create(&h->ev_join) | rt::event_create(&h->ev_done);
+    for (int i = 0; i < ORBX_NSTAGES; i++) { e |= rt::event_create(&h->ev_stage[i][0]); e |= rt::event_create(&h->ev_stage[i][1]); h->stage_ms[i] = 0; }
+    if (e) { delete h; return fail(ORBX_E_DEVICE, "stream/event creation failed"); }
+    h->have_streams = true;
+    *out = h;
+    return ORBX_OK;
+}
+
+void orbx_destroy(orbx_extractor* h) {
+    if (!h) return;
+    rt::set_device(h->device);
+    if (h->have_streams) {
+        rt::stream_sync(h->s0); rt::stream_sync(h->s1);
+        for (int i = 0; i < ORBX_NSTAGES; i++) { rt::event_destroy(h->ev_stage[i][0]); rt::event_destroy(h->ev_stage[i][1]); }
+        rt::event_destroy(h->ev_fork); rt::event_destroy(h->ev_join); rt::event_destroy(h->ev_done);
+        rt::stream_destroy(h->s0); rt::stream_destroy(h->s1);
+    }
+    h->d_lv.release(); h->d_cells.release(); h->d_xtab.release(); h->d_ytab.release(); h->d_pyr.release(); h->d_blur.release(); h->d_stage.release();
+    h->d_slots.release(); h->d_candA.release(); h->d_candB.release(); h->d_lvl_keys.release(); h->d_cell_count.release(); h->d_lvl_count.release();
+    h->d_final_idx.release(); h->d_nm.release(); h->d_status.release(); h->d_kps.release(); h->d_desc.release();
+    h->d_uRight.release(); h->d_depth.release(); h->d_sad.release(); h->d_nmatch.release(); h->d_knn.release(); h->d_ratio.release();
+    h->d_hamA.release(); h->d_hamB.release(); h->d_hamOut.release(); h->h_stage.release(); h->h_nm.release();
+    delete h;
+}
+
+int orbx_set_gaussian_taps(orbx_extractor* h, int variant) {
+    if (!h || (variant != 0 && variant != 1)) return fail(ORBX_E_ARG, "bad gaussian variant");
+    h->gauss_variant = variant; return ORBX_OK;
+}
+int orbx_reserve(orbx_extractor* h, int width, int height, int max_batch) { if (!h) return fail(ORBX_E_ARG, "null handle"); return configure(h, width, height, max_batch); }
+int orbx_get_levels(const orbx_extractor* h) { return h ? h->nlevels : 0; }
+float orbx_get_scale_factor(const orbx_extractor* h) { return h ? (float)h->scaleFactor : 0.f; }
+int orbx_get_level_tables(const orbx_extractor* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2, int* fpl, int* umax16) {
+    if (!h) return fail(ORBX_E_ARG, "null handle");
+    for (int i = 0; i < h->nlevels; i++) {
+        if (scale) scale[i] = h->scale[i];
+        if (inv_scale) inv_scale[i] = h->inv_scale[i];
+        if (sigma2) sigma2[i] = h->sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = h->inv_sigma2[i];
+        if (fpl) fpl[i] = h->quota[i];
+    }
+    if (umax16) for (int i = 0; i < 16; i++) umax16[i] = h->umax.u[i];
+    return ORBX_OK;
+}
+int orbx_max_keypoints(const orbx_extractor* h) {
+    if (!h) return 0;
+    if (h->kp_total_cap) return h->kp_total_cap;
+    int s = 0; for (int l = 0; l < h->nlevels; l++) s += std::max(h->quota[l] + 3, 16); return s;   // before the geometry is known
+}
+
+int orbx_extract_batch(orbx_extractor* h, int B, const uint8_t* images, int width, int height, int stride, size_t image_stride,
+                       int on_device, int lap0, int lap1) {
+    if (!h) return fail(ORBX_E_ARG, "null handle");
+    if (!images || width <= 0 || height <= 0 || B <= 0) return fail(ORBX_E_EMPTY, "empty image");
+    if (stride < width) return fail(ORBX_E_ARG, "stride < width");
+    if (B > 1 && image_stride < (size_t)stride * (height - 1) + width) return fail(ORBX_E_ARG, "image_stride too small");
+    int rc = configure(h, width, height, B);
+    if (rc) return rc;
+    rt::set_device(h->device);
+    const uint8_t* d_images = images;
+    if (!on_device) {
+        const size_t bytes = (size_t)(B - 1) * image_stride + (size_t)stride * (height - 1) + width;
+        if (h->d_stage.ensure(bytes + 16)) return fail(ORBX_E_DEVICE, "staging allocation failed");
+        if (rt::copy_h2d(h->d_stage.p, images, bytes, h->s0)) return fail(ORBX_E_DEVICE, "H2D copy failed: %s", rt::last_error());
+        d_images = h->d_stage.p;
+    }
+    return enqueue_extract(h, B, d_images, stride, image_stride, lap0, lap1);
+}
+
+int orbx_sync(orbx_extractor* h) {
+    if (!h) return fail(ORBX_E_ARG, "null handle");
+    rt::set_device(h->device);
+    if (rt::stream_sync(h->s0) || rt::stream_sync(h->s1)) return fail(ORBX_E_DEVICE, "stream sync failed: %s", rt::last_error());
+    if (h->profile) for (int i = 0; i < ORBX_NSTAGES; i++) if (i != ST_MATCH) h->stage_ms[i] = rt::event_elapsed_ms(h->ev_stage[i][0], h->ev_stage[i][1]);
+    return ORBX_OK;
+}
+
+int orbx_fetch(orbx_extractor* h, OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n_out, int* mono_out) {
+    if (!h || h->lastB <= 0) return fail(ORBX_E_ARG, "nothing to fetch");
+    rt::set_device(h->device);
+    const int B = h->lastB; const size_t tc = (size_t)h->kp_total_cap;
+    const size_t kb = (size_t)B * tc * sizeof(KeyPointRec), db = (size_t)B * tc * 32;
+    if (h->h_stage.ensure(kb + db + 64)) return fail(ORBX_E_DEVICE, "pinned allocation failed");
+    int e = rt::copy_d2h(h->h_nm.p, h->d_nm.p, sizeof(int) * 2 * h->maxB, h->s0);
+    e |= rt::copy_d2h(h->h_nm.p + 2 * h->maxB, h->d_status.p, sizeof(int), h->s0);
+    if (kps) e |= rt::copy_d2h(h->h_stage.p, h->d_kps.p, kb, h->s0);
+    if (desc) e |= rt::copy_d2h(h->h_stage.p + kb, h->d_desc.p, db, h->s0);
+    if (e || rt::stream_sync(h->s0)) return fail(ORBX_E_DEVICE, "D2H failed: %s", rt::last_error());
+    if (h->profile) orbx_sync(h);
+    if (h->h_nm.p[2 * h->maxB] != 0) return fail(ORBX_E_INTERNAL, "device quadtree capacity check tripped");
+    int rc = ORBX_OK;
+    for (int b = 0; b < B; b++) {
+        const int n = h->h_nm.p[b];
+        if (n_out) n_out[b] = n;
+        if (mono_out) mono_out[b] = h->h_nm.p[h->maxB + b];
+        if (n > cap) { rc = ORBX_E_CAPACITY; continue; }
+        if (kps) memcpy(kps + (size_t)b * cap, h->h_stage.p + (size_t)b * tc * sizeof(KeyPointRec), (size_t)n * sizeof(KeyPointRec));
+        if (desc) memcpy(desc + (size_t)b * cap * 32, h->h_stage.p + kb + (size_t)b * tc * 32, (size_t)n * 32);
+    }
+    if (rc) return fail(rc, "output capacity %d too small", cap);
+    return ORBX_OK;
+}
+
+int orbx_extract(orbx_extractor* h, const uint8_t* image, int width, int height, int stride, int lap0, int lap1,
+                 OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n_out, int* mono_out) {
+    if (n_out) *n_out = 0;
+    if (mono_out) *mono_out = -1;
+    int rc = orbx_extract_batch(h, 1, image, width, height, stride, (size_t)stride * height, 0, lap0, lap1);
+    if (rc) return rc;
+    return orbx_fetch(h, kps, desc, cap, n_out, mono_out);
+}
+
+int orbx_pyramid_level(orbx_extractor* h, int b, int level, int blurred, uint8_t* dst, int dst_stride, int* width, int* height) {
+    if (!h || level < 0 || level >= h->nlevels || b < 0 || b >= h->lastB) return fail(ORBX_E_ARG, "bad pyramid query");
+    const LevelInfo& L = h->lv[level];
+    if (width) *width = L.w;
+    if (height) *height = L.h;
+    if (!dst) return ORBX_OK;
+    if (dst_stride < L.w) return fail(ORBX_E_ARG, "dst_stride < width");
+    rt::set_device(h->device);
+    const size_t plane = (size_t)L.pitch * L.h;
+    if (h->h_stage.ensure(plane + 64)) return fail(ORBX_E_DEVICE, "pinned allocation failed");
+    rt::stream_sync(h->s1);
+    const uint8_t* src = (blurred ? h->d_blur.p : h->d_pyr.p) + (size_t)b * h->pyr_stride + L.off;
+    if (rt::copy_d2h(h->h_stage.p, src, plane, h->s0) || rt::stream_sync(h->s0)) return fail(ORBX_E_DEVICE, "D2H failed");
+    for (int y = 0; y < L.h; y++) memcpy(dst + (size_t)y * dst_stride, h->h_stage.p + (size_t)y * L.pitch, L.w);
+    return ORBX_OK;
+}
+
+int orbx_device_alloc(orbx_extractor* h, size_t bytes, void** dptr) {
+    if (!h || !dptr) return fail(ORBX_E_ARG, "null");
+    rt::set_device(h->device);
+    *dptr = rt::dmalloc(bytes);
+    return *dptr ? ORBX_OK : fail(ORBX_E_DEVICE, "hipMalloc(%zu) failed", bytes);
+}
+int orbx_device_free(orbx_extractor* h, void* dptr) { if (!h) return ORBX_E_ARG; rt::set_device(h->device); rt::dfree(dptr); return ORBX_OK; }
+int orbx_device_upload(orbx_extractor* h, void* dptr, const void* host, size_t bytes) {
+    if (!h || !dptr || !host) return fail(ORBX_E_ARG, "null");
+    rt::set_device(h->device);
+    if (rt::copy_h2d(dptr, host, bytes, h->s0) || rt::stream_sync(h->s0)) return fail(ORBX_E_DEVICE, "upload failed");
+    return ORBX_OK;
+}
+
+int orbx_profile_enable(orbx_extractor* h, int on) { if (!h) return ORBX_E_ARG; h->profile = on != 0; return ORBX_OK; }
+int orbx_profile_get(orbx_extractor* h, float ms[ORBX_NSTAGES]) {
+    if (!h) return ORBX_E_ARG;
+    for (int i = 0; i < ORBX_NSTAGES; i++) ms[i] = h->stage_ms[i];
+    return ORBX_OK;
+}
+
+// ---- stage probes -------------------------------------------------------------------------------------
+int orbx_debug_candidates(orbx_extractor* h, int b, int level, int* xys, int cap) {
+    if (!h || level < 0 || level >= h->nlevels || b < 0 || b >= h->lastB) return fail(ORBX_E_ARG, "bad probe");
+    rt::set_device(h->device);
+    rt::stream_sync(h->s0);
+    const LevelInfo& L = h->lv[level];
+    std::vector<int> counts(L.cell_count);
+    rt::copy_d2h(counts.data(), h->d_cell_count.p + (size_t)b * h->ncells + L.cell_begin, sizeof(int) * L.cell_count, h->s0);
+    std::vector<uint32_t> slots(L.cand_cap + 1);
+    rt::copy_d2h(slots.data(), h->d_slots.p + (size_t)b * h->cand_stride + L.cand_off, sizeof(uint32_t) * L.cand_cap, h->s0);
+    rt::stream_sync(h->s0);
+    int n = 0;
+    for (int c = 0; c < L.cell_count; c++) {
+        const int so = h->cells[L.cell_begin + c].slot_off - L.cand_off;
+        for (int k = 0; k < counts[c]; k++) {
+            if (n < cap) { const uint32_t key = slots[so + k]; xys[3 * n] = key_x(key); xys[3 * n + 1] = key_y(key); xys[3 * n + 2] = key_s(key); }
+            n++;
+        }
+    }
+    return n;
+}
+int orbx_debug_level_keys(orbx_extractor* h, int b, int level, int* xys, int cap) {
+    if (!h || level < 0 || level >= h->nlevels || b < 0 || b >= h->lastB) return fail(ORBX_E_ARG, "bad probe");
+    rt::set_device(h->device);
+    rt::stream_sync(h->s0);
+    const LevelInfo& L = h->lv[level];
+    int cnt = 0;
+    rt::copy_d2h(&cnt, h->d_lvl_count.p + (size_t)b * h->nlevels + level, sizeof(int), h->s0);
+    std::vector<uint32_t> keys(L.kp_cap);
+    rt::copy_d2h(keys.data(), h->d_lvl_keys.p + (size_t)b * h->kp_total_cap + L.kp_off, sizeof(uint32_t) * L.kp_cap, h->s0);
+    rt::stream_sync(h->s0);
+    for (int i = 0; i < cnt && i < cap; i++) { xys[3 * i] = key_x(keys[i]); xys[3 * i + 1] = key_y(keys[i]); xys[3 * i + 2] = key_s(keys[i]); }
+    return cnt;
+}
+
+// ---- matchers ------------------------------------------------------------------------------------------
+int orbm_hamming_matrix(orbx_extractor* h, const uint8_t* a, int na, const uint8_t* b, int nb, int* out) {
+    if (!h || !a || !b || !out || na <= 0 || nb <= 0) return fail(ORBX_E_ARG, "bad hamming arguments");
+    rt::set_device(h->device);
+    if (h->d_hamA.ensure((size_t)na * 4) || h->d_hamB.ensure((size_t)nb * 4) || h->d_hamOut.ensure((size_t)na * nb)) return fail(ORBX_E_DEVICE, "allocation failed");
+    rt::copy_h2d(h->d_hamA.p, a, (size_t)na * 32, h->s0);
+    rt::copy_h2d(h->d_hamB.p, b, (size_t)nb * 32, h->s0);
+    dim3 grid((nb + 255) / 256, na, 1), blk(256, 1, 1);
+    ORBX_LAUNCH(k_hamming_matrix, grid, blk, 0, h->s0, (const unsigned long long*)h->d_hamA.p, na, (const unsigned long long*)h->d_hamB.p, nb, h->d_hamOut.p);
+    if (rt::copy_d2h(out, h->d_hamOut.p, sizeof(int) * (size_t)na * nb, h->s0) || rt::stream_sync(h->s0)) return fail(ORBX_E_DEVICE, "hamming failed: %s", rt::last_error());
+    return ORBX_OK;
+}
+
+static int check_pair(orbx_extractor* L, int lf, orbx_extractor* R, int rf, int B) {
+    if (!L || !R || B <= 0 || lf < 0 || rf < 0) return fail(ORBX_E_ARG, "bad matcher arguments");
+    if (lf + B > L->lastB || rf + B > R->lastB) return fail(ORBX_E_ARG, "matcher range exceeds the last extracted batch");
+    if (L->W != R->W || L->H != R->H || L->nlevels != R->nlevels || L->kp_total_cap != R->kp_total_cap || L->device != R->device)
+        return fail(ORBX_E_ARG, "left/right extractors differ in geometry, parameters or device");
+    return ORBX_OK;
+}
+
+int orbm_stereo_match(orbx_extractor* L, int lf, orbx_extractor* R, int rf, int B, float bf, float bl) {
+    int rc = check_pair(L, lf, R, rf, B); if (rc) return rc;
+    rt::set_device(L->device);
+    if (L != R) rt::stream_wait_event(L->s0, R->ev_done);
+    const int cap = L->kp_total_cap;
+    StereoParams P; P.mbf = bf; P.mb = bl; P.th_high = 100; P.th_orb = (100 + 50) / 2;   // ORBmatcher::TH_HIGH/TH_LOW, src/ORBmatcher.cc:35-36
+    if (L->profile) rt::event_record(L->ev_stage[ST_MATCH][0], L->s0);
+    dim3 grid((cap + 3) / 4, B, 1), blk(256, 1, 1);
+    ORBX_LAUNCH(k_stereo_match, grid, blk, 0, L->s0, (const LevelInfo*)L->d_lv.p,
+                (const KeyPointRec*)(L->d_kps.p + (size_t)lf * cap), (const unsigned long long*)(L->d_desc.p + (size_t)lf * cap * 4), (const int*)(L->d_nm.p + lf),
+                (const KeyPointRec*)(R->d_kps.p + (size_t)rf * cap), (const unsigned long long*)(R->d_desc.p + (size_t)rf * cap * 4), (const int*)(R->d_nm.p + rf),
+                cap, (const uint8_t*)(L->d_pyr.p + (size_t)lf * L->pyr_stride), (const uint8_t*)(R->d_pyr.p + (size_t)rf * R->pyr_stride), L->pyr_stride,
+                P, L->d_uRight.p, L->d_depth.p, L->d_sad.p);
+    dim3 grid2(B, 1, 1);
+    ORBX_LAUNCH(k_stereo_median, grid2, blk, (size_t)cap * sizeof(int) + 16, L->s0, (const int*)(L->d_nm.p + lf), cap, L->d_uRight.p, L->d_depth.p,
+                (const int*)L->d_sad.p, L->d_nmatch.p);
+    if (L->profile) rt::event_record(L->ev_stage[ST_MATCH][1], L->s0);
+    if (rt::check_launch()) return fail(ORBX_E_DEVICE, "kernel launch failed: %s", rt::last_error());
+    return ORBX_OK;
+}
+
+int orbm_stereo_fetch(orbx_extractor* L, int B, float* uRight, float* depth, int cap, int* n_matches) {
+    if (!L || B <= 0 || B > L->maxB) return fail(ORBX_E_ARG, "bad fetch");
+    rt::set_device(L->device);
+    const size_t tc = (size_t)L->kp_total_cap;
+    if (L->h_stage.ensure(2 * B * tc * sizeof(float) + 64)) return fail(ORBX_E_DEVICE, "pinned allocation failed");
+    float* hu = (float*)L->h_stage.p; float* hd = hu + B * tc;
+    int e = rt::copy_d2h(hu, L->d_uRight.p, B * tc * sizeof(float), L->s0) | rt::copy_d2h(hd, L->d_depth.p, B * tc * sizeof(float), L->s0);
+    e |= rt::copy_d2h(L->h_nm.p, L->d_nmatch.p, sizeof(int) * B, L->s0);
+    if (e || rt::stream_sync(L->s0)) return fail(ORBX_E_DEVICE, "D2H failed: %s", rt::last_error());
+    if (L->profile) L->stage_ms[ST_MATCH] = rt::event_elapsed_ms(L->ev_stage[ST_MATCH][0], L->ev_stage[ST_MATCH][1]);
+    const size_t ncopy = std::min<size_t>(tc, (size_t)cap);
+    for (int b = 0; b < B; b++) {
+        if (uRight) memcpy(uRight + (size_t)b * cap, hu + b * tc, ncopy * sizeof(float));
+        if (depth) memcpy(depth + (size_t)b * cap, hd + b * tc, ncopy * sizeof(float));
+        if (n_matches) n_matches[b] = L->h_nm.p[b];
+    }
+    return ORBX_OK;
+}
+
+int orbm_knn2(orbx_extractor* L, int lf, orbx_extractor* R, int rf, int B) {
+    int rc = check_pair(L, lf, R, rf, B); if (rc) return rc;
+    rt::set_device(L->device);
+    if (L != R) rt::stream_wait_event(L->s0, R->ev_done);
+    const int cap = L->kp_total_cap; const size_t bc = (size_t)L->maxB * cap;
+    if (L->profile) rt::event_record(L->ev_stage[ST_MATCH][0], L->s0);
+    dim3 grid((cap + 3) / 4, B, 1), blk(256, 1, 1);
+    ORBX_LAUNCH(k_knn2, grid, blk, 0, L->s0,
+                (const unsigned long long*)(L->d_desc.p + (size_t)lf * cap * 4), (const int*)(L->d_nm.p + L->maxB + lf), (const int*)(L->d_nm.p + lf),
+                (const unsigned long long*)(R->d_desc.p + (size_t)rf * cap * 4), (const int*)(R->d_nm.p + R->maxB + rf), (const int*)(R->d_nm.p + rf),
+                cap, L->d_knn.p, L->d_knn.p + bc, L->d_knn.p + 2 * bc, L->d_knn.p + 3 * bc, L->d_ratio.p);
+    if (L->profile) rt::event_record(L->ev_stage[ST_MATCH][1], L->s0);
+    if (rt::check_launch()) return fail(ORBX_E_DEVICE, "kernel launch failed: %s", rt::last_error());
+    return ORBX_OK;
+}
+
+int orbm_knn2_fetch(orbx_extractor* L, int B, int* idx0, int* dist0, int* idx1, int* dist1, uint8_t* ratio_ok, int cap) {
+    if (!L || B <= 0 || B > L->maxB) return fail(ORBX_E_ARG, "bad fetch");
+    rt::set_device(L->device);
+    const size_t tc = (size_t)L->kp_total_cap, bc = (size_t)L->maxB * tc;
+    if (L->h_stage.ensure(4 * B * tc * sizeof(int) + B * tc + 64)) return fail(ORBX_E_DEVICE, "pinned allocation failed");
+    int* hk = (int*)L->h_stage.p; uint8_t* hr = L->h_stage.p + 4 * B * tc * sizeof(int);
+    int e = 0;
+    for (int k = 0; k < 4; k++) e |= rt::copy_d2h(hk + k * B * tc, L->d_knn.p + k * bc, B * tc * sizeof(int), L->s0);
+    e |= rt::copy_d2h(hr, L->d_ratio.p, B * tc, L->s0);
+    if (e || rt::stream_sync(L->s0)) return fail(ORBX_E_DEVICE, "D2H failed: %s", rt::last_error());
+    if (L->profile) L->stage_ms[ST_MATCH] = rt::event_elapsed_ms(L->ev_stage[ST_MATCH][0], L->ev_stage[ST_MATCH][1]);
+    const size_t ncopy = std::min<size_t>(tc, (size_t)cap);
+    int* outs[4] = {idx0, dist0, idx1, dist1};
+    for (int b = 0; b < B; b++) {
+        for (int k = 0; k < 4; k++) if (outs[k]) memcpy(outs[k] + (size_t)b * cap, hk + k * B * tc + b * tc, ncopy * sizeof(int));
+        if (ratio_ok) memcpy(ratio_ok + (size_t)b * cap, hr + b * tc, ncopy);
+    }
+    return ORBX_OK;
+}
+
+}  // extern "C"

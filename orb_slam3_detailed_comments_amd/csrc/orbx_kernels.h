@@ -1,0 +1,45 @@
+// orbx_kernels.h — prototypes of the __global__ kernels (defined in k_*.hip) for the host launcher.
+#pragma once
+#include "orbx_types.h"
+
+namespace orbx {
+
+__global__ void k_import(const LevelInfo* __restrict__ lv, const uint8_t* __restrict__ images, int stride,
+                         size_t image_stride, uint8_t* __restrict__ pyr, size_t pyr_stride);
+__global__ void k_resize(const LevelInfo* __restrict__ lv, int level, const ResizeTap* __restrict__ xtab,
+                         const ResizeTap* __restrict__ ytab, uint8_t* __restrict__ pyr, size_t pyr_stride);
+__global__ void k_fast_cells(const LevelInfo* __restrict__ lv, const CellInfo* __restrict__ cells, int ncells,
+                             const uint8_t* __restrict__ pyr, size_t pyr_stride, int iniTh, int minTh,
+                             uint32_t* __restrict__ slots, size_t slots_stride, int* __restrict__ cell_count,
+                             int tile_bytes, int inner_bytes);
+__global__ void k_blur(const LevelInfo* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,
+                       uint8_t* __restrict__ blur, size_t pyr_stride, BlurTaps taps);
+__global__ void k_quadtree(const LevelInfo* __restrict__ lv, const CellInfo* __restrict__ cells, int ncells,
+                           const int* __restrict__ cell_count, const uint32_t* __restrict__ slots, size_t slots_stride,
+                           uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
+                           uint32_t* __restrict__ lvl_keys, int kp_total_cap, int* __restrict__ lvl_count,
+                           int nlevels, int node_cap, int* __restrict__ status);
+__global__ void k_layout(const LevelInfo* __restrict__ lv, int nlevels, const uint32_t* __restrict__ lvl_keys,
+                         int kp_total_cap, const int* __restrict__ lvl_count, int lap0, int lap1,
+                         int* __restrict__ final_idx, int* __restrict__ n_out, int* __restrict__ mono_out);
+__global__ void k_orient_brief(const LevelInfo* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,
+                               const uint8_t* __restrict__ blur, size_t pyr_stride,
+                               const uint32_t* __restrict__ lvl_keys, int kp_total_cap,
+                               const int* __restrict__ lvl_count, const int* __restrict__ final_idx, UmaxTab umax,
+                               KeyPointRec* __restrict__ out_kps, unsigned long long* __restrict__ out_desc);
+__global__ void k_hamming_matrix(const unsigned long long* __restrict__ A, int na,
+                                 const unsigned long long* __restrict__ Bm, int nb, int* __restrict__ out);
+__global__ void k_stereo_match(const LevelInfo* __restrict__ lv, const KeyPointRec* __restrict__ kpsL,
+                               const unsigned long long* __restrict__ descL, const int* __restrict__ nL,
+                               const KeyPointRec* __restrict__ kpsR, const unsigned long long* __restrict__ descR,
+                               const int* __restrict__ nR, int cap, const uint8_t* __restrict__ pyrL,
+                               const uint8_t* __restrict__ pyrR, size_t pyr_stride, StereoParams P,
+                               float* __restrict__ uRight, float* __restrict__ depth, int* __restrict__ sad);
+__global__ void k_stereo_median(const int* __restrict__ nL, int cap, float* __restrict__ uRight,
+                                float* __restrict__ depth, const int* __restrict__ sad, int* __restrict__ n_matches);
+__global__ void k_knn2(const unsigned long long* __restrict__ descQ, const int* __restrict__ qoff, const int* __restrict__ nq,
+                       const unsigned long long* __restrict__ descT, const int* __restrict__ toff, const int* __restrict__ nt,
+                       int cap, int* __restrict__ idx0, int* __restrict__ dist0, int* __restrict__ idx1,
+                       int* __restrict__ dist1, uint8_t* __restrict__ ratio_ok);
+
+}  // namespace orbx

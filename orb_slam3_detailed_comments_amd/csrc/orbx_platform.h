@@ -1,0 +1,26 @@
+// orbx_platform.h — the one place that knows whether the kernel sources are being compiled by hipcc
+// for gfx950 (the product) or by g++ against tests/emu/hip_emu.h (CPU SIMT emulator, tests only).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#ifdef ORBX_EMU
+#include "hip_emu.h"   // tests/emu, via -I
+#define ORBX_DYN_SMEM(name) unsigned char* name = hipemu::cur().blk->dyn_smem
+#define ORBX_LAUNCH(kern, grid, block, smem, stream, ...) \
+    hipemu::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
+#define ORBX_HD
+#else
+#include <hip/hip_runtime.h>
+#define ORBX_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#define ORBX_LAUNCH(kern, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__)
+#define ORBX_HD __host__ __device__
+#endif
+
+namespace orbx {
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+}  // namespace orbx

@@ -1,0 +1,71 @@
+// orbx_rt.h — thin runtime layer: HIP (product) or plain libc (tests/emu build of the same sources).
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include "orbx_platform.h"
+
+namespace orbx { namespace rt {
+
+#ifdef ORBX_EMU
+typedef int stream_t;
+struct event_s { double t; };
+typedef event_s* event_t;
+inline double now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+inline int set_device(int) { return 0; }
+inline int device_count() { return 1; }
+inline void* dmalloc(size_t n) { return calloc(n ? n : 1, 1); }
+inline void dfree(void* p) { free(p); }
+inline void* hmalloc(size_t n) { return calloc(n ? n : 1, 1); }
+inline void hfree(void* p) { free(p); }
+inline int copy_h2d(void* d, const void* s, size_t n, stream_t) { memcpy(d, s, n); return 0; }
+inline int copy_d2h(void* d, const void* s, size_t n, stream_t) { memcpy(d, s, n); return 0; }
+inline int copy_d2d(void* d, const void* s, size_t n, stream_t) { memmove(d, s, n); return 0; }
+inline int copy2d(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, int /*kind*/, stream_t) {
+    for (size_t y = 0; y < h; y++) memcpy((char*)d + y * dp, (const char*)s + y * sp, w);
+    return 0;
+}
+inline int memset_async(void* d, int v, size_t n, stream_t) { memset(d, v, n); return 0; }
+inline int stream_create(stream_t* s) { *s = 0; return 0; }
+inline void stream_destroy(stream_t) {}
+inline int stream_sync(stream_t) { return 0; }
+inline int event_create(event_t* e) { *e = new event_s{0}; return 0; }
+inline void event_destroy(event_t e) { delete e; }
+inline int event_record(event_t e, stream_t) { e->t = now_ms(); return 0; }
+inline int stream_wait_event(stream_t, event_t) { return 0; }
+inline int event_sync(event_t) { return 0; }
+inline float event_elapsed_ms(event_t a, event_t b) { return (float)(b->t - a->t); }
+inline const char* last_error() { return "emu"; }
+inline int check_launch() { return 0; }
+#else
+typedef hipStream_t stream_t;
+typedef hipEvent_t event_t;
+#define ORBX_HIP_OK(x) ((x) == hipSuccess ? 0 : -1)
+inline int set_device(int d) { return ORBX_HIP_OK(hipSetDevice(d)); }
+inline int device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+inline void* dmalloc(size_t n) { void* p = nullptr; if (hipMalloc(&p, n ? n : 1) != hipSuccess) return nullptr; return p; }
+inline void dfree(void* p) { if (p) (void)hipFree(p); }
+inline void* hmalloc(size_t n) { void* p = nullptr; if (hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) != hipSuccess) return nullptr; return p; }
+inline void hfree(void* p) { if (p) (void)hipHostFree(p); }
+inline int copy_h2d(void* d, const void* s, size_t n, stream_t st) { return ORBX_HIP_OK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st)); }
+inline int copy_d2h(void* d, const void* s, size_t n, stream_t st) { return ORBX_HIP_OK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, st)); }
+inline int copy_d2d(void* d, const void* s, size_t n, stream_t st) { return ORBX_HIP_OK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, st)); }
+// kind: 0 host->device, 1 device->device
+inline int copy2d(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, int kind, stream_t st) {
+    return ORBX_HIP_OK(hipMemcpy2DAsync(d, dp, s, sp, w, h, kind ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+}
+inline int memset_async(void* d, int v, size_t n, stream_t st) { return ORBX_HIP_OK(hipMemsetAsync(d, v, n, st)); }
+inline int stream_create(stream_t* s) { return ORBX_HIP_OK(hipStreamCreateWithFlags(s, hipStreamNonBlocking)); }
+inline void stream_destroy(stream_t s) { (void)hipStreamDestroy(s); }
+inline int stream_sync(stream_t s) { return ORBX_HIP_OK(hipStreamSynchronize(s)); }
+inline int event_create(event_t* e) { return ORBX_HIP_OK(hipEventCreate(e)); }
+inline void event_destroy(event_t e) { (void)hipEventDestroy(e); }
+inline int event_record(event_t e, stream_t s) { return ORBX_HIP_OK(hipEventRecord(e, s)); }
+inline int stream_wait_event(stream_t s, event_t e) { return ORBX_HIP_OK(hipStreamWaitEvent(s, e, 0)); }
+inline int event_sync(event_t e) { return ORBX_HIP_OK(hipEventSynchronize(e)); }
+inline float event_elapsed_ms(event_t a, event_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
+inline const char* last_error() { return hipGetErrorString(hipGetLastError()); }
+inline int check_launch() { return ORBX_HIP_OK(hipGetLastError()); }
+#endif
+
+}}  // namespace orbx::rt

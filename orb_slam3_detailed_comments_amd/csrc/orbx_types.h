@@ -1,0 +1,61 @@
+// orbx_types.h — device-visible tables and packed record formats shared by the kernels and the host.
+#pragma once
+#include <cstdint>
+#include "orbx_platform.h"
+
+namespace orbx {
+
+constexpr int kMaxLevels = 16;
+constexpr int kEdge = 19;        // EDGE_THRESHOLD, reference src/ORBextractor.cc:78
+constexpr int kBorder = 16;      // minBorderX/Y = EDGE_THRESHOLD-3, :1076-1077
+constexpr int kHalfPatch = 15;   // HALF_PATCH_SIZE, :77
+
+// Candidate / keypoint key: x (12 bits) | y (12 bits) << 12 | score (8 bits) << 24.
+// FAST candidates carry coordinates relative to the detection border (x-16, y-16) exactly like the
+// reference's vToDistributeKeys (:1159-1160); quadtree outputs keep the same packing.
+__host__ __device__ inline uint32_t key_pack(int x, int y, int s) { return (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)s << 24); }
+__host__ __device__ inline int key_x(uint32_t k) { return (int)(k & 0xFFFu); }
+__host__ __device__ inline int key_y(uint32_t k) { return (int)((k >> 12) & 0xFFFu); }
+__host__ __device__ inline int key_s(uint32_t k) { return (int)(k >> 24); }
+
+struct LevelInfo {
+    int w, h, pitch;         // level image size and row pitch (bytes, multiple of 64)
+    int off;                 // byte offset of this level inside one image's pyramid block
+    float scale, inv_scale;  // mvScaleFactor / mvInvScaleFactor (:478-500)
+    int quota;               // mnFeaturesPerLevel (:509-526)
+    int patch;               // scaledPatchSize = int(31*scale) (:1184)
+    int kp_cap, kp_off;      // capacity / offset of this level in the per-image level-ordered keypoint arrays
+    int ncols, nrows, wcell, hcell;   // FAST cell grid (:1087-1095)
+    int cell_begin, cell_count;       // this level's cells in the flattened cell table
+    int cand_cap, cand_off;  // capacity / offset of this level in the per-image candidate arrays
+    int bw, bh;              // detection-area size (maxBorder-minBorder), the quadtree's root extent
+    int nini;                // number of quadtree roots = round(bw/bh) (:718)
+    float hX;                // root width = bw/nini (:722)
+    int xtab_off, ytab_off;  // offsets into the resize coefficient tables (levels >= 1)
+    int _pad;
+};
+
+struct CellInfo {
+    int16_t level;
+    int16_t x0, y0, x1, y1;  // detectable interior of the cell window in level coordinates
+    int16_t _pad;
+    int slot_off;            // first candidate slot of this cell inside the per-image slot array
+};
+
+// Resize coefficient entry: source index + two 11-bit fixed-point weights (a0 | a1 << 16).
+struct ResizeTap { int ofs; int w; };
+
+struct KeyPointRec { float x, y, size, angle, response; int32_t octave, class_id; };   // = OrbxKeyPoint, 28 B
+
+struct BlurTaps { int k[7]; };                       // 7-tap Gaussian, 8-bit fixed point
+struct UmaxTab { int u[16]; };                        // circular patch half-widths (src/ORBextractor.cc:542-570)
+struct StereoParams { float mbf, mb; int th_high, th_orb; };   // ORBmatcher::TH_HIGH, (TH_HIGH+TH_LOW)/2
+
+// quadtree node, 16 B, lives in LDS
+struct QNode {
+    int16_t x0, y0, x1, y1;
+    uint32_t start;     // first key of this node's span in the key buffers
+    uint32_t cnt_buf;   // bits 0..29 key count, bit 30 = which key buffer (0:A 1:B) holds the span
+};
+
+}  // namespace orbx

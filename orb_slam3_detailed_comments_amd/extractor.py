@@ -1,0 +1,157 @@
+"""Host-side mirror of ``ORB_SLAM3::ORBextractor`` (reference include/ORBextractor.h:43-109) on top of the
+HIP library: same constructor arguments, same call convention and return value (monoIndex, -1 on an empty
+image), same getters; plus the batched form that the MI355X design is built around."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KP_DTYPE
+
+
+class ORBextractor:
+    HARRIS_SCORE, FAST_SCORE = 0, 1   # include/ORBextractor.h:47 (only FAST_SCORE is ever computed)
+
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device_id=0, lib=None):
+        self._lib = lib or _lib.load_hip()
+        self._h = C.c_void_p()
+        self._lib.check(self._lib.L.orbx_create(C.byref(self._h), int(nfeatures), float(scaleFactor), int(nlevels),
+                                               int(iniThFAST), int(minThFAST), int(device_id)))
+        self.nfeatures, self.nlevels = int(nfeatures), int(nlevels)
+        self._shape = None
+        self._B = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.L.orbx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- getters (include/ORBextractor.h:61-81) ----
+    def GetLevels(self):
+        return self._lib.L.orbx_get_levels(self._h)
+
+    def GetScaleFactor(self):
+        return self._lib.L.orbx_get_scale_factor(self._h)
+
+    def _tables(self):
+        nl = self.nlevels
+        f = [np.zeros(nl, np.float32) for _ in range(4)]
+        q = np.zeros(nl, np.int32); um = np.zeros(16, np.int32)
+        self._lib.check(self._lib.L.orbx_get_level_tables(self._h, *[a.ctypes.data for a in f], q.ctypes.data, um.ctypes.data))
+        return f, q, um
+
+    def GetScaleFactors(self):
+        return self._tables()[0][0]
+
+    def GetInverseScaleFactors(self):
+        return self._tables()[0][1]
+
+    def GetScaleSigmaSquares(self):
+        return self._tables()[0][2]
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._tables()[0][3]
+
+    def features_per_level(self):
+        return self._tables()[1]
+
+    def umax(self):
+        return self._tables()[2]
+
+    def set_gaussian_taps(self, variant):
+        self._lib.check(self._lib.L.orbx_set_gaussian_taps(self._h, int(variant)))
+
+    def max_keypoints(self):
+        return self._lib.L.orbx_max_keypoints(self._h)
+
+    # ---- ORBextractor::operator() (src/ORBextractor.cc:1557) ----
+    def __call__(self, image, mask=None, vLappingArea=(0, 0)):
+        """Returns (monoIndex, keypoints[N] structured array, descriptors[N,32] uint8); monoIndex == -1 and empty
+        outputs for an empty image, like the reference.  `mask` is ignored, like the reference."""
+        if image is None or image.size == 0:
+            return -1, np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        assert image.dtype == np.uint8 and image.ndim == 2, "CV_8UC1 expected (src/ORBextractor.cc:1567)"
+        res = self.extract_batch(image[None], vLappingArea)
+        return res[0]
+
+    def enqueue(self, images, lap=(0, 0), device_ptr=None, shape=None, stride=None, image_stride=None):
+        """Asynchronous batched extraction.  images: uint8 [B,H,W] host array, or (device_ptr, shape=(B,H,W))."""
+        if device_ptr is None:
+            images = np.ascontiguousarray(images, np.uint8)
+            B, H, W = images.shape
+            ptr, st, ist, ondev = images.ctypes.data, images.strides[1], images.strides[0], 0
+            self._keep = images
+        else:
+            B, H, W = shape
+            ptr, st, ist, ondev = device_ptr, stride or W, image_stride or (stride or W) * H, 1
+        self._lib.check(self._lib.L.orbx_extract_batch(self._h, B, ptr, W, H, st, ist, ondev, int(lap[0]), int(lap[1])))
+        self._shape, self._B = (H, W), B
+        return B
+
+    def fetch(self):
+        B, cap = self._B, self.max_keypoints()
+        kps = np.zeros((B, cap), KP_DTYPE); desc = np.zeros((B, cap, 32), np.uint8)
+        n = np.zeros(B, np.int32); mono = np.zeros(B, np.int32)
+        self._lib.check(self._lib.L.orbx_fetch(self._h, kps.ctypes.data, desc.ctypes.data, cap, n.ctypes.data, mono.ctypes.data))
+        return [(int(mono[b]), kps[b, :n[b]].copy(), desc[b, :n[b]].copy()) for b in range(B)]
+
+    def extract_batch(self, images, lap=(0, 0)):
+        self.enqueue(images, lap)
+        return self.fetch()
+
+    def sync(self):
+        self._lib.check(self._lib.L.orbx_sync(self._h))
+
+    # ---- mvImagePyramid (include/ORBextractor.h:83) ----
+    def pyramid_level(self, level, image_index=0, blurred=False):
+        w, h = C.c_int(), C.c_int()
+        self._lib.check(self._lib.L.orbx_pyramid_level(self._h, image_index, level, int(blurred), None, 0, C.byref(w), C.byref(h)))
+        a = np.zeros((h.value, w.value), np.uint8)
+        self._lib.check(self._lib.L.orbx_pyramid_level(self._h, image_index, level, int(blurred), a.ctypes.data, w.value, C.byref(w), C.byref(h)))
+        return a
+
+    @property
+    def mvImagePyramid(self):
+        return [self.pyramid_level(l) for l in range(self.nlevels)]
+
+    # ---- stage probes / profiling ----
+    def debug_candidates(self, level, image_index=0):
+        cap = 1 << 18
+        a = np.zeros((cap, 3), np.int32)
+        n = self._lib.L.orbx_debug_candidates(self._h, image_index, level, a.ctypes.data, cap)
+        if n < 0:
+            self._lib.check(n)
+        return a[:n].copy()
+
+    def debug_level_keys(self, level, image_index=0):
+        cap = self.max_keypoints()
+        a = np.zeros((cap, 3), np.int32)
+        n = self._lib.L.orbx_debug_level_keys(self._h, image_index, level, a.ctypes.data, cap)
+        if n < 0:
+            self._lib.check(n)
+        return a[:n].copy()
+
+    def profile(self, on=True):
+        self._lib.check(self._lib.L.orbx_profile_enable(self._h, int(on)))
+
+    def stage_ms(self):
+        ms = np.zeros(_lib.NSTAGES, np.float32)
+        self._lib.check(self._lib.L.orbx_profile_get(self._h, ms.ctypes.data))
+        return dict(zip(self._lib.stage_names(), ms.tolist()))
+
+    # ---- device memory helpers ----
+    def device_upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = C.c_void_p()
+        self._lib.check(self._lib.L.orbx_device_alloc(self._h, arr.nbytes, C.byref(p)))
+        self._lib.check(self._lib.L.orbx_device_upload(self._h, p, arr.ctypes.data, arr.nbytes))
+        return p
+
+    def device_free(self, p):
+        self._lib.L.orbx_device_free(self._h, p)
