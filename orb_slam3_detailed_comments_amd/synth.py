@@ -42,12 +42,26 @@ def corner_field(w=752, h=480, seed=0, nrect=3000, noise=3.0, contrast_div=1.0):
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
 
-def stereo_pair(w=752, h=480, seed=0, nrect=3000, noise=3.0):
-    """Rectified stereo pair (left, right): right = per-rectangle shifted left + independent noise."""
+def stereo_pair(w=752, h=480, seed=0, nrect=3000, noise=2.0, band=48, max_disp=60):
+    """Rectified stereo pair (left, right).  One textured scene is rendered wider than the image; the left view
+    is a window of it and the right view is the same window shifted by a per-band disparity (horizontal bands
+    of `band` rows = depth layers, disparity 2..max_disp px) plus independent sensor noise.  Most keypoints
+    therefore have a true match on the same row with a near-identical descriptor, band seams give occlusions,
+    and the noise makes the SAD parabola fit non-trivial."""
     rng = np.random.default_rng(SEED0 + seed)
-    sc = _scene(rng, w, h, nrect)
-    left = _render(w, h, sc, 0, 0, 1.0) + rng.normal(0, noise, (h, w))
-    right = _render(w, h, sc, 1, 4, 1.0) + rng.normal(0, noise, (h, w))
+    pad = max_disp + 4
+    sc = _scene(rng, w + pad, h, int(nrect * (w + pad) / w))
+    scene = _render(w + pad, h, sc, 0, 0, 1.0)
+    nb = (h + band - 1) // band
+    disp = rng.integers(2, max_disp + 1, nb)
+    left = scene[:, :w].copy()
+    right = np.empty_like(left)
+    for k in range(nb):
+        y0, y1 = k * band, min((k + 1) * band, h)
+        d = int(disp[k])
+        right[y0:y1] = scene[y0:y1, d:d + w]
+    left = left + rng.normal(0, noise, (h, w))
+    right = right + rng.normal(0, noise, (h, w))
     cv = lambda a: np.clip(np.rint(a), 0, 255).astype(np.uint8)
     return cv(left), cv(right)
 

@@ -178,3 +178,31 @@ class ReferenceExtractor:
 def kps_equal(a, b):
     """Bit-exact comparison of keypoint records (angle compared as bit pattern)."""
     return a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+def oracle_stereo(oL, oR, kL, dL, kR, dR, bf, b):
+    """Frame::ComputeStereoMatches restatement on two OracleExtractor objects (their last extract() pyramids)."""
+    L = oracle()
+    kL = np.ascontiguousarray(kL); kR = np.ascontiguousarray(kR)
+    dL = np.ascontiguousarray(dL); dR = np.ascontiguousarray(dR)
+    u = np.zeros(len(kL), np.float32); d = np.zeros(len(kL), np.float32)
+    n = L.orbo_stereo_matches(oL.h, oR.h, kL.ctypes.data, len(kL), dL.ctypes.data, kR.ctypes.data, len(kR), dR.ctypes.data,
+                              float(bf), float(b), u.ctypes.data, d.ctypes.data)
+    return u, d, n
+
+
+def oracle_knn2(q, t):
+    L = oracle()
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    nq = len(q)
+    out = [np.zeros(nq, np.int32) for _ in range(4)]
+    ok = np.zeros(nq, np.uint8)
+    L.orbo_knn2(q.ctypes.data, nq, t.ctypes.data, len(t), out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data,
+                out[3].ctypes.data, ok.ctypes.data)
+    return dict(idx0=out[0], dist0=out[1], idx1=out[2], dist1=out[3], ratio_ok=ok)
+
+
+def oracle_hamming(a, b):
+    L = oracle()
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return L.orbo_descriptor_distance(a.ctypes.data, b.ctypes.data)
