@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json): stereo pairs/s of ORB extract (left+right) + ComputeStereoMatches on 752x480
+EuRoC-shaped rectified pairs, nFeatures=1200, 8 levels — config[1] of BASELINE.json — on N GPUs of one node.
+
+One "step" = one pass of the hot path over one batch of `--pairs` synthetic stereo pairs per GPU that are already
+resident in HBM: import -> pyramid -> FAST cells -> quadtree -> blur -> IC-angle + rBRIEF -> stereo row search/SAD/
+sub-pixel/median, and the results (keypoints, descriptors, uRight, depth) copied back to host memory.
+Multi-GPU: independent image streams, one process per GPU, no data-path collective (weak scaling).
+
+Prints ONE JSON line (rank 0).  See DESIGN.md §Measurement for the roofline / cpu_baseline definitions.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, NFEAT, NLEVELS, SCALE, INI, MIN = 752, 480, 1200, 8, 1.2, 20, 7     # Examples/Stereo/EuRoC.yaml:67-80
+BF, BASE = 458.654 * 0.110074, 0.110074                                    # EuRoC.yaml:23,57
+HBM_PEAK_GBS = 8000.0                                                      # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def level_pixels():
+    inv = [1.0]
+    s = np.float32(1.0)
+    for _ in range(1, NLEVELS):
+        s = np.float32(s * np.float64(np.float32(SCALE)))
+        inv.append(float(np.float32(1.0) / s))
+    return [int(np.rint(np.float32(W) * np.float32(i))) * int(np.rint(np.float32(H) * np.float32(i))) for i in inv]
+
+
+def algorithmic_bytes(n_kp, n_cand, n_right):
+    """Compulsory bytes per IMAGE of each extractor kernel and per PAIR of the matcher."""
+    px = level_pixels()
+    P, P0, P7 = sum(px), px[0], px[-1]
+    return {
+        "import": 2 * P0,
+        "pyramid": (P - P7) + (P - P0),
+        "fast_cells": P + 4 * n_cand,
+        "quadtree": 3 * 4 * n_cand + 4 * n_kp,
+        "blur": 2 * P,
+        "layout": 8 * n_kp,
+        "orient_brief": (749 + 512 + 60) * n_kp,
+        "match": 25 * 32 * n_kp + (121 + 11 * 121) * 0.7 * n_kp + 8 * n_kp,   # per pair
+    }
+
+
+def cpu_baseline(seconds_budget=15.0):
+    """Reference CPU path timed on the host cores, same workload shape: per stereo pair, the reference's own
+    ORBextractor.cc (oracle/_ref, compiled against the OpenCV shim) for left + right, then the oracle restatement of
+    Frame::ComputeStereoMatches.  One thread per pair stream, `cores` independent streams."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import threading
+    import oracle_lib as ol
+    from orb_slam3_detailed_comments_amd import synth
+    kind = "reference" if ol.reference() is not None else "port"
+    cores = min(8, os.cpu_count() or 1)
+    pairs = [synth.stereo_pair(W, H, seed=1000 + i) for i in range(cores)]
+    done = [0] * cores
+    state = []
+    for t in range(cores):          # untimed: the stereo restatement reads the pyramids held by its extractor objects
+        oL, oR = ol.OracleExtractor(NFEAT), ol.OracleExtractor(NFEAT)
+        oL.extract(pairs[t][0]); oR.extract(pairs[t][1])
+        ex = (ol.ReferenceExtractor(NFEAT), ol.ReferenceExtractor(NFEAT)) if kind == "reference" else (ol.OracleExtractor(NFEAT), ol.OracleExtractor(NFEAT))
+        state.append((oL, oR, ex))
+    t_end = time.time() + seconds_budget
+
+    def work(t):
+        oL, oR, (eL, eR) = state[t]
+        L, R = pairs[t]
+        while time.time() < t_end:
+            (mL, kL, dL), (mR, kR, dR) = eL.extract(L), eR.extract(R)
+            ol.oracle_stereo(oL, oR, kL, dL, kR, dR, BF, BASE)
+            done[t] += 1
+
+    t0 = time.time()
+    th = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    dt = time.time() - t0
+    n = sum(done)
+    sample = ("%d pairs in %.1f s on %d threads (one pair stream per thread); extractor = %s; stereo association = oracle "
+              "restatement; OpenCV primitives are the scalar shim, not SIMD OpenCV, so this under-states a real OpenCV build"
+              % (n, dt, cores, "reference src/ORBextractor.cc via oracle/_ref" if kind == "reference" else "oracle restatement"))
+    return {"value": round(n / dt, 2), "unit": "stereo pairs/s", "cores": cores, "kind": kind, "sample": sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_
+        torch.cuda.set_device(local)
+        dist_.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist = dist_
+
+    from orb_slam3_detailed_comments_amd import ORBextractor, load_hip, synth
+    lib = load_hip()
+    P = args.pairs
+    # synthetic EuRoC-shaped rectified pairs; every rank (= camera stream shard) gets its own seeds
+    ls, rs = [], []
+    for i in range(P):
+        l, r = synth.stereo_pair(W, H, seed=rank * 100003 + i)
+        ls.append(l); rs.append(r)
+    batch = np.stack(ls + rs)                                   # [2P, H, W]: lefts then rights
+    handles = [ORBextractor(NFEAT, SCALE, NLEVELS, INI, MIN, device_id=local) for _ in range(2)]
+    dptrs = [h.device_upload(batch) for h in handles]          # inputs resident in HBM before the timed region
+    cap = handles[0].max_keypoints()
+    for h in handles:
+        h.profile(True)
+    out = [dict(k=np.zeros((2 * P, cap), np.dtype("V28")), d=np.zeros((2 * P, cap, 32), np.uint8), n=np.zeros(2 * P, np.int32),
+                m=np.zeros(2 * P, np.int32), u=np.zeros((P, cap), np.float32), z=np.zeros((P, cap), np.float32), nm=np.zeros(P, np.int32))
+           for _ in handles]
+    stage_sum = {}
+    stage_cnt = [0]
+    nkp = [0, 0]
+    nmatch = [0, 0]
+
+    def enqueue(i):
+        h = handles[i]
+        h.enqueue(None, (0, 0), device_ptr=dptrs[i], shape=batch.shape)
+        lib.check(lib.L.orbm_stereo_match(h._h, 0, h._h, P, P, BF, BASE))
+
+    def fetch(i, record):
+        h, o = handles[i], out[i]
+        lib.check(lib.L.orbx_fetch(h._h, o["k"].ctypes.data, o["d"].ctypes.data, cap, o["n"].ctypes.data, o["m"].ctypes.data))
+        lib.check(lib.L.orbm_stereo_fetch(h._h, P, o["u"].ctypes.data, o["z"].ctypes.data, cap, o["nm"].ctypes.data))
+        if record:
+            for k, v in h.stage_ms().items():
+                stage_sum[k] = stage_sum.get(k, 0.0) + v
+            stage_cnt[0] += 1
+            nkp[0] += int(o["n"].sum()); nkp[1] += 2 * P
+            nmatch[0] += int(o["nm"].sum()); nmatch[1] += P
+
+    def run(nsteps, record):
+        pending = []
+        for s in range(nsteps):
+            i = s % 2
+            if len(pending) == 2:
+                fetch(pending.pop(0), record)
+            enqueue(i)
+            pending.append(i)
+        while pending:
+            fetch(pending.pop(0), record)
+
+    def sync_all():
+        for h in handles:
+            h.sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    run(args.warmup, False)
+    sync_all()
+    t0 = time.perf_counter()
+    run(args.steps, True)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_pairs = P * args.steps * world
+        value = total_pairs / dt
+        avg_kp = nkp[0] / max(nkp[1], 1)
+        stage_ms = {k: v / max(stage_cnt[0], 1) for k, v in stage_sum.items()}
+        # average FAST candidates per image (for the algorithmic-byte model): probe the last batch
+        ncand = 0
+        for l in range(NLEVELS):
+            ncand += len(handles[0].debug_candidates(l, 0))
+        ab = algorithmic_bytes(avg_kp, ncand, avg_kp)
+        units = {k: 2 * P for k in ab}
+        units["match"] = P
+        dom = max((k for k in stage_ms if stage_ms[k] > 0), key=lambda k: stage_ms[k])
+        achieved = ab[dom] * units[dom] / (stage_ms[dom] * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(dom)
+            except Exception:
+                traffic = None
+        per_pair_bytes = 2 * sum(v for k, v in ab.items() if k != "match") + ab["match"]
+        res = {
+            "metric": "stereo pairs/sec ORB extract+match, 752x480 stereo @1200 feat", "value": round(value, 1),
+            "unit": "stereo pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "EuRoC-shaped stereo 752x480, nFeatures=1200, 8 levels: extract L+R + ComputeStereoMatches (BASELINE.json configs[1])",
+                       "pairs_per_step_per_gpu": P, "images_per_step_per_gpu": 2 * P, "outputs_copied_to_host": True,
+                       "avg_keypoints_per_image": round(avg_kp, 1), "avg_stereo_matches_per_pair": round(nmatch[0] / max(nmatch[1], 1), 1),
+                       "parallelism": "independent streams, %d GPU(s), no collective" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(ab[dom] * units[dom]), "avg_launch_ms": round(stage_ms[dom], 4),
+                         "end_to_end_GBps": round(per_pair_bytes * value / world / 1e9, 2),
+                         "end_to_end_frac": round(per_pair_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5)},
+            "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                res["cpu_baseline"] = cpu_baseline()
+            except Exception as e:   # the baseline is reporting only; never fail the bench on it
+                res["cpu_baseline"] = {"value": None, "unit": "stereo pairs/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

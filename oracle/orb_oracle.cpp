@@ -507,6 +507,20 @@ void orbo_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int* idx0, in
     }
 }
 
+// ---- raw primitive entry points (tests/test_oracle_primitives.py cross-checks them against slow definitions) ----
+int orbo_prim_fast(const uint8_t* img, int w, int h, int step, int threshold, int nonmax, int* xys, int cap) {
+    std::vector<orbp::FastPoint> pts;
+    orbp::fast9_16(img, w, h, (size_t)step, threshold, nonmax != 0, pts);
+    for (size_t i = 0; i < pts.size() && (int)i < cap; i++) { xys[3 * i] = pts[i].x; xys[3 * i + 1] = pts[i].y; xys[3 * i + 2] = pts[i].score; }
+    return (int)pts.size();
+}
+int orbo_prim_is_corner(const uint8_t* p, int step, int threshold) { return orbp::fast_is_corner(p, (size_t)step, threshold) ? 1 : 0; }
+int orbo_prim_corner_score(const uint8_t* p, int step, int threshold) { return orbp::fast_corner_score(p, (size_t)step, threshold); }
+void orbo_prim_resize(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh) { orbp::resize_linear_u8(src, sw, sh, (size_t)sw, dst, dw, dh, (size_t)dw); }
+void orbo_prim_blur(const uint8_t* src, int w, int h, uint8_t* dst, int variant) { orbp::gaussian_blur7_u8(src, w, h, (size_t)w, dst, (size_t)w, variant); }
+void orbo_prim_border(const uint8_t* src, int w, int h, uint8_t* dst, int b) { orbp::make_border_reflect101(src, w, h, (size_t)w, dst, (size_t)(w + 2 * b), b, b, b, b); }
+int orbo_prim_round(double v) { return orbp::round_half_even(v); }
+
 // glibc cosf/sinf, exposed so tests can pin the device-side model (csrc/glibc_sincosf_model.h).
 float orbo_cosf(float x) { return cosf(x); }
 float orbo_sinf(float x) { return sinf(x); }

@@ -1,0 +1,25 @@
+"""Shared parity cases: (name, image factory, nfeatures, lapping area) — SURVEY.md §8d configs on synthetic inputs."""
+from orb_slam3_detailed_comments_amd import synth
+
+FULL_CASES = [
+    ("euroc_752x480_n1200", lambda: synth.corner_field(seed=0), 1200, (0, 0)),
+    ("euroc_mono_n1000_lap_all", lambda: synth.corner_field(seed=1), 1000, (0, 1000)),
+    ("low_texture", lambda: synth.corner_field(seed=2, contrast_div=6.0), 1200, (0, 0)),
+    ("sparse_corners", lambda: synth.sparse_corners(seed=0), 1200, (0, 0)),
+    ("uniform_noise_partial_lap", lambda: synth.uniform_noise(seed=0), 1200, (100, 400)),
+    ("tumvi_512_n1500_lap", lambda: synth.corner_field(512, 512, seed=3), 1500, (0, 511)),
+    ("tum_640x480_n1000", lambda: synth.corner_field(640, 480, seed=4), 1000, (0, 0)),
+    ("euroc_mono_600x350_n5000_init", lambda: synth.corner_field(600, 350, seed=5), 5000, (0, 1000)),
+]
+
+SMALL_CASES = [
+    ("small_376x240_n500", lambda: synth.corner_field(376, 240, seed=10, nrect=800), 500, (0, 0)),
+    ("small_lap_partial", lambda: synth.corner_field(376, 240, seed=11, nrect=800), 500, (100, 250)),
+    ("small_noise", lambda: synth.uniform_noise(320, 256, seed=12), 400, (0, 1000)),
+    ("small_sparse", lambda: synth.sparse_corners(376, 240, seed=13, ncorner=12), 500, (0, 0)),
+    ("small_flat_empty", lambda: __import__("numpy").full((240, 376), 77, "uint8"), 500, (0, 0)),
+    ("small_square_512", lambda: synth.corner_field(300, 300, seed=14, nrect=700), 300, (0, 299)),
+    ("small_wide_nini3", lambda: synth.corner_field(640, 250, seed=15, nrect=900), 600, (0, 0)),
+]
+
+EUROC_BF, EUROC_B = 458.654 * 0.110074, 0.110074   # Examples/Stereo/EuRoC.yaml:23,57 (fx * baseline, baseline)

@@ -1,0 +1,117 @@
+"""CPU-only CI of the *kernel sources*: orb_slam3_detailed_comments_amd/csrc/k_*.hip compiled with g++ against the
+SIMT emulator (tests/emu) must reproduce the oracle bit for bit.  This is not the product path (the package only
+loads the hipcc build); the same assertions run against the real GPU in tests/test_gpu_parity.py."""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from cases import SMALL_CASES, EUROC_BF, EUROC_B
+from orb_slam3_detailed_comments_amd import synth
+from orb_slam3_detailed_comments_amd.extractor import ORBextractor
+from orb_slam3_detailed_comments_amd import matcher as M
+
+
+def _same(a, b):
+    return a[0] == b[0] and ol.kps_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("name,factory,nf,lap", SMALL_CASES, ids=[c[0] for c in SMALL_CASES])
+def test_extractor_stagewise_and_final(emu_lib, name, factory, nf, lap):
+    img = factory()
+    ex = ORBextractor(nf, 1.2, 8, 20, 7, lib=emu_lib)
+    got = ex(img, None, lap)
+    o = ol.OracleExtractor(nf)
+    exp = o.extract(img, lap)
+    for l in range(8):
+        assert np.array_equal(ex.pyramid_level(l), o.level_image(l)), "pyramid level %d" % l
+        assert np.array_equal(ex.pyramid_level(l, blurred=True), o.level_image(l, blurred=True)), "blur level %d" % l
+        assert np.array_equal(ex.debug_candidates(l), o.level_candidates(l)), "FAST candidates level %d" % l
+        k2 = o.level_keypoints(l)
+        k2a = np.stack([k2["x"] - 16, k2["y"] - 16, k2["response"]], 1).astype(np.int32) if len(k2) else np.zeros((0, 3), np.int32)
+        assert np.array_equal(ex.debug_level_keys(l), k2a), "quadtree level %d" % l
+    assert _same(got, exp)
+
+
+def test_empty_image_and_errors(emu_lib):
+    ex = ORBextractor(500, 1.2, 8, 20, 7, lib=emu_lib)
+    mono, k, d = ex(np.zeros((0, 0), np.uint8))
+    assert mono == -1 and len(k) == 0 and d.shape == (0, 32)        # src/ORBextractor.cc:1561-1562
+    from orb_slam3_detailed_comments_amd._lib import OrbxError
+    with pytest.raises(OrbxError):                                    # too small for the 35-px cell grid
+        ex(np.zeros((60, 60), np.uint8))
+    with pytest.raises(OrbxError):
+        ORBextractor(0, 1.2, 8, 20, 7, lib=emu_lib)
+
+
+def test_other_parameters_and_gauss_variant(emu_lib):
+    img = synth.corner_field(376, 240, seed=31, nrect=800)
+    for (nf, sf, nl, ini, mn, gv) in [(300, 1.2, 8, 20, 7, 1), (250, 1.5, 4, 25, 10, 0), (40, 1.2, 8, 20, 7, 0)]:
+        ex = ORBextractor(nf, sf, nl, ini, mn, lib=emu_lib)
+        ex.set_gaussian_taps(gv)
+        assert _same(ex(img), ol.OracleExtractor(nf, sf, nl, ini, mn, gv).extract(img))
+
+
+def test_batch_and_stereo_and_knn(emu_lib):
+    L, R = synth.stereo_pair(376, 240, seed=20, nrect=800)
+    L2, R2 = synth.stereo_pair(376, 240, seed=21, nrect=800)
+    ex = ORBextractor(500, 1.2, 8, 20, 7, lib=emu_lib)
+    res = ex.extract_batch(np.stack([L, L2, R, R2]))
+    u, d, n = M.ComputeStereoMatches(ex, ex, EUROC_BF, EUROC_B, 0, 2, 2)
+    for p, (l, r) in enumerate(((L, R), (L2, R2))):
+        oL, oR = ol.OracleExtractor(500), ol.OracleExtractor(500)
+        eL, eR = oL.extract(l), oR.extract(r)
+        assert _same(res[p], eL) and _same(res[2 + p], eR)
+        uo, do, no = ol.oracle_stereo(oL, oR, eL[1], eL[2], eR[1], eR[2], EUROC_BF, EUROC_B)
+        N = len(eL[1])
+        assert n[p] == no and no > 50
+        assert u[p, :N].tobytes() == uo.tobytes() and d[p, :N].tobytes() == do.tobytes()
+        assert (u[p, N:] == -1).all()
+    # fisheye-style kNN + ratio on the lapping part
+    res = ex.extract_batch(np.stack([L, R]), (60, 300))
+    out = M.StereoFishEyeKnn(ex, ex, 0, 1, 1)
+    (mL, kL, dL), (mR, kR, dR) = res
+    ref = ol.oracle_knn2(dL[mL:], dR[mR:])
+    nq = len(dL) - mL
+    assert nq > 100 and mL > 0
+    for key in ref:
+        assert np.array_equal(out[key][0, :nq], ref[key]), key
+    # all-pairs DescriptorDistance
+    Hm = M.ORBmatcher.DescriptorDistance(ex, dL[:40], dR[:50])
+    assert np.array_equal(Hm, np.unpackbits(dL[:40, None, :] ^ dR[None, :50, :], axis=2).sum(2))
+
+
+def test_knn_ties_and_degenerate_sizes(emu_lib):
+    ex = ORBextractor(500, 1.2, 8, 20, 7, lib=emu_lib)
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, (6, 32), dtype=np.uint8)
+    dup = np.concatenate([a, a, a[:2]])             # duplicate descriptors: equal distances keep the lower index
+    Hm = M.ORBmatcher.DescriptorDistance(ex, dup, dup)
+    assert (np.diag(Hm) == 0).all() and Hm[0, 6] == 0
+    ref = ol.oracle_knn2(dup, dup)
+    assert ref["idx0"][6] == 0 and ref["idx1"][6] == 6 and ref["dist1"][6] == 0      # strict '<' insertion order
+
+
+def test_two_extractor_instances_concurrently(emu_lib):
+    """Two instances on two threads, like Frame's left/right extraction threads (src/Frame.cc:136-141)."""
+    L, R = synth.stereo_pair(376, 240, seed=22, nrect=800)
+    exL, exR = ORBextractor(500, 1.2, 8, 20, 7, lib=emu_lib), ORBextractor(500, 1.2, 8, 20, 7, lib=emu_lib)
+    out = {}
+    tl = threading.Thread(target=lambda: out.__setitem__("L", exL(L)))
+    tr = threading.Thread(target=lambda: out.__setitem__("R", exR(R)))
+    tl.start(); tr.start(); tl.join(); tr.join()
+    assert _same(out["L"], ol.OracleExtractor(500).extract(L)) and _same(out["R"], ol.OracleExtractor(500).extract(R))
+    u, d, n = M.ComputeStereoMatches(exL, exR, EUROC_BF, EUROC_B)
+    oL, oR = ol.OracleExtractor(500), ol.OracleExtractor(500)
+    eL, eR = oL.extract(L), oR.extract(R)
+    uo, do, no = ol.oracle_stereo(oL, oR, eL[1], eL[2], eR[1], eR[2], EUROC_BF, EUROC_B)
+    assert n[0] == no and u[0, :len(uo)].tobytes() == uo.tobytes()
+
+
+def test_golden_fixture(emu_lib):
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gold_376x240_n500.npz"))
+    ex = ORBextractor(500, 1.2, 8, 20, 7, lib=emu_lib)
+    mono, k, d = ex(g["image"], None, (100, 250))
+    assert mono == int(g["mono_b"]) and k.tobytes() == g["kps_b"].tobytes() and np.array_equal(d, g["desc_b"])

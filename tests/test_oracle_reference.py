@@ -1,0 +1,77 @@
+"""Pins the oracle: our C++ restatement (oracle/orb_oracle.cpp) must equal the REFERENCE's own
+src/ORBextractor.cc (compiled unmodified against the OpenCV shim into oracle/_ref), and both must equal the
+committed golden vectors that were generated from the reference build (tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from cases import FULL_CASES, SMALL_CASES
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+HAVE_REF = ol.reference() is not None
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref/libref_orb.so not built (needs /root/reference)")
+@pytest.mark.parametrize("name,factory,nf,lap", FULL_CASES + SMALL_CASES, ids=[c[0] for c in FULL_CASES + SMALL_CASES])
+def test_restatement_equals_reference(name, factory, nf, lap):
+    img = factory()
+    mo, ko, do = ol.OracleExtractor(nf).extract(img, lap)
+    mr, kr, dr = ol.ReferenceExtractor(nf).extract(img, lap)
+    assert mo == mr and ol.kps_equal(ko, kr) and np.array_equal(do, dr)
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref/libref_orb.so not built")
+def test_restatement_equals_reference_other_params():
+    from orb_slam3_detailed_comments_amd import synth
+    img = synth.corner_field(480, 360, seed=21, nrect=1200)
+    for (nf, sf, nl, ini, mn, gv) in [(800, 1.2, 8, 20, 7, 1), (600, 1.5, 4, 25, 10, 0), (700, 1.1, 6, 12, 5, 0), (50, 1.2, 8, 20, 7, 0)]:
+        mo, ko, do = ol.OracleExtractor(nf, sf, nl, ini, mn, gv).extract(img, (0, 0))
+        mr, kr, dr = ol.ReferenceExtractor(nf, sf, nl, ini, mn, gv).extract(img, (0, 0))
+        assert mo == mr and ol.kps_equal(ko, kr) and np.array_equal(do, dr), (nf, sf, nl)
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref/libref_orb.so not built")
+def test_tables_match_reference_constructor():
+    for nf in (1000, 1200, 1500, 5000):
+        q, um, scales = ol.OracleExtractor(nf).tables()
+        rq, rum, rpat, rscales = ol.ReferenceExtractor(nf).tables()
+        assert np.array_equal(q, rq) and np.array_equal(um, rum)
+        for a, b in zip(scales, rscales):
+            assert a.tobytes() == b.tobytes()
+    # the product's copy of the rBRIEF pattern equals the reference's table
+    vals = []
+    for ln in open(os.path.join(ol.ROOT, "orb_slam3_detailed_comments_amd", "csrc", "brief_pattern.inc")):
+        if ln.startswith("    "):
+            vals += [int(v) for v in ln.strip().strip(",").split(",")]
+    assert vals == rpat.tolist()
+
+
+def test_known_tables():
+    """Values derived in SURVEY.md §8 from the reference formulas (src/ORBextractor.cc:478-570)."""
+    expect = {1000: [217, 181, 151, 126, 105, 87, 73, 60], 1200: [261, 217, 181, 151, 126, 105, 87, 72],
+              1500: [326, 271, 226, 189, 157, 131, 109, 91], 5000: [1086, 905, 754, 628, 524, 436, 364, 303]}
+    for nf, q in expect.items():
+        got, um, scales = ol.OracleExtractor(nf).tables()
+        assert got.tolist() == q
+        assert um.tolist() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    o = ol.OracleExtractor(1200)
+    o.extract(np.zeros((480, 752), np.uint8))
+    assert [o.level_info(l)[:2] for l in range(8)] == [(752, 480), (627, 400), (522, 333), (435, 278), (363, 231), (302, 193), (252, 161), (210, 134)]
+
+
+@pytest.mark.parametrize("name", ["gold_376x240_n500", "gold_stereo_376x240_n500"])
+def test_golden_vectors(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    if name.startswith("gold_stereo"):
+        oL, oR = ol.OracleExtractor(500), ol.OracleExtractor(500)
+        mL, kL, dL = oL.extract(g["left"]); mR, kR, dR = oR.extract(g["right"])
+        assert kL.tobytes() == g["kps_left"].tobytes() and np.array_equal(dL, g["desc_left"])
+        assert kR.tobytes() == g["kps_right"].tobytes() and np.array_equal(dR, g["desc_right"])
+        u, d, n = ol.oracle_stereo(oL, oR, kL, dL, kR, dR, float(g["bf"]), float(g["b"]))
+        assert u.tobytes() == g["uright"].tobytes() and d.tobytes() == g["depth"].tobytes()
+    else:
+        for lap_key, lap in (("a", (0, 0)), ("b", (100, 250))):
+            mono, k, d = ol.OracleExtractor(500).extract(g["image"], lap)
+            assert mono == int(g["mono_" + lap_key]) and k.tobytes() == g["kps_" + lap_key].tobytes() and np.array_equal(d, g["desc_" + lap_key])
