@@ -124,9 +124,9 @@ def main():
     cap = handles[0].max_keypoints()
     for h in handles:
         h.profile(True)
-    out = [dict(k=np.zeros((2 * P, cap), np.dtype("V28")), d=np.zeros((2 * P, cap, 32), np.uint8), n=np.zeros(2 * P, np.int32),
-                m=np.zeros(2 * P, np.int32), u=np.zeros((P, cap), np.float32), z=np.zeros((P, cap), np.float32), nm=np.zeros(P, np.int32))
-           for _ in handles]
+    out = [dict(k=h.pinned_empty((2 * P, cap, 28), np.uint8), d=h.pinned_empty((2 * P, cap, 32), np.uint8), n=np.zeros(2 * P, np.int32),
+                m=np.zeros(2 * P, np.int32), u=h.pinned_empty((P, cap), np.float32), z=h.pinned_empty((P, cap), np.float32), nm=np.zeros(P, np.int32))
+           for h in handles]
     stage_sum = {}
     stage_cnt = [0]
     nkp = [0, 0]

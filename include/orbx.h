@@ -96,6 +96,11 @@ int orbx_device_alloc(orbx_extractor* h, size_t bytes, void** dptr);
 int orbx_device_free(orbx_extractor* h, void* dptr);
 int orbx_device_upload(orbx_extractor* h, void* dptr, const void* host, size_t bytes);
 
+/* page-locked host memory for output buffers: with cap == orbx_max_keypoints() orbx_fetch / orbm_stereo_fetch copy straight
+ * into the caller's arrays (no staging, no repacking) and pinned memory makes that copy run at PCIe speed */
+int orbx_host_alloc(orbx_extractor* h, size_t bytes, void** hptr);
+int orbx_host_free(orbx_extractor* h, void* hptr);
+
 /* Per-stage GPU time of the last batch, HIP events on the launching streams.  names is a static table. */
 #define ORBX_NSTAGES 8
 int orbx_profile_enable(orbx_extractor* h, int on);

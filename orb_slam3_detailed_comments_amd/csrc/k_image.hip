@@ -22,70 +22,103 @@ __global__ void __launch_bounds__(256) k_import(const LevelInfo* __restrict__ lv
     if (y >= D.h || x0 >= D.pitch) return;
     const uint8_t* src = images + (size_t)b * image_stride + (size_t)y * stride;
     uint32_t out = 0;
+    if ((((size_t)(src + x0)) & 3) == 0 && x0 + 3 < D.w) out = *(const uint32_t*)(src + x0);   // aligned interior dword
+    else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) if (x0 + k < D.w) out |= (uint32_t)src[x0 + k] << (8 * k);
+        for (int k = 0; k < 4; k++) if (x0 + k < D.w) out |= (uint32_t)src[x0 + k] << (8 * k);
+    }
     *(uint32_t*)(pyr + (size_t)b * pyr_stride + D.off + (size_t)y * D.pitch + x0) = out;
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Pyramid: bilinear 11-bit fixed point, 4 output pixels per thread, one dword store.
-// block (64,4): 256 output columns x 4 rows.  grid (ceil(pitch/256), ceil(h/4), B)
+// Pyramid: cv::resize INTER_LINEAR 8U, 11-bit fixed point.  A workgroup produces a 256 x 8 output tile: the source
+// rows/columns it needs (<= ~1.2x the tile for the 1.2 pyramid) are staged in LDS with aligned dword loads, each
+// thread then interpolates 4 adjacent outputs on 2 rows and stores them as dwords.
+// block (64,4); grid (ceil(pitch/256), ceil(h/8), B); dynamic LDS = lds_rows * lds_pitch bytes.
 __global__ void __launch_bounds__(256) k_resize(const LevelInfo* __restrict__ lv, int level,
                                                 const ResizeTap* __restrict__ xtab,
                                                 const ResizeTap* __restrict__ ytab,
-                                                uint8_t* __restrict__ pyr, size_t pyr_stride) {
+                                                uint8_t* __restrict__ pyr, size_t pyr_stride, int lds_pitch, int lds_rows) {
+    ORBX_DYN_SMEM(smem);
     const LevelInfo D = lv[level];
     const LevelInfo S = lv[level - 1];
     const int b = (int)blockIdx.z;
-    const int dy = (int)(blockIdx.y * 4 + threadIdx.y);
-    const int dx0 = (int)(blockIdx.x * 64 + threadIdx.x) * 4;
-    if (dy >= D.h || dx0 >= D.pitch) return;
+    const int tid = (int)(threadIdx.y * 64 + threadIdx.x);
+    const int dxb = (int)blockIdx.x * 256, dyb = (int)blockIdx.y * 8;
     const uint8_t* src = pyr + (size_t)b * pyr_stride + S.off;
     uint8_t* dst = pyr + (size_t)b * pyr_stride + D.off;
-    const ResizeTap ty = ytab[D.ytab_off + dy];
-    const int sy0 = imin(imax(ty.ofs, 0), S.h - 1), sy1 = imin(imax(ty.ofs + 1, 0), S.h - 1);
-    const int b0 = (int)(int16_t)(ty.w & 0xFFFF), b1 = ty.w >> 16;
-    const uint8_t* S0 = src + (size_t)sy0 * S.pitch;
-    const uint8_t* S1 = src + (size_t)sy1 * S.pitch;
-    uint32_t out = 0;
+    const ResizeTap* xt = xtab + D.xtab_off;
+    const ResizeTap* yt = ytab + D.ytab_off;
+    // source window of this tile (block-uniform)
+    const int dx_last = imin(dxb + 255, D.w - 1), dy_last = imin(dyb + 7, D.h - 1);
+    const int gx0 = xt[imin(dxb, D.w - 1)].ofs & ~3;
+    const int sx_hi = imin(xt[dx_last].ofs + 1, S.w - 1);
+    const int ncd = imin(((sx_hi - gx0) >> 2) + 1, lds_pitch >> 2);
+    const int sy_lo = imin(imax(yt[imin(dyb, D.h - 1)].ofs, 0), S.h - 1);
+    const int sy_hi = imin(imax(yt[dy_last].ofs + 1, 0), S.h - 1);
+    const int nrow = imin(sy_hi - sy_lo + 1, lds_rows);
+    for (int i = tid; i < nrow * ncd; i += 256) {
+        const int r = i / ncd, c = i - r * ncd;
+        *(uint32_t*)(smem + r * lds_pitch + 4 * c) = *(const uint32_t*)(src + (size_t)(sy_lo + r) * S.pitch + gx0 + 4 * c);
+    }
+    __syncthreads();
+    const int dx0 = dxb + (int)threadIdx.x * 4;
+    if (dx0 >= D.pitch) return;
+    int sxo[4], sxo1[4], a0[4], a1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int dx = dx0 + k;
-        if (dx < D.w) {
-            const ResizeTap tx = xtab[D.xtab_off + dx];
-            const int sx = tx.ofs, sx1 = imin(sx + 1, S.w - 1);
-            const int a0 = (int)(int16_t)(tx.w & 0xFFFF), a1 = tx.w >> 16;
-            const int r0 = S0[sx] * a0 + S0[sx1] * a1;
-            const int r1 = S1[sx] * a0 + S1[sx1] * a1;
-            int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-            v = imin(imax(v, 0), 255);
-            out |= (uint32_t)v << (8 * k);
-        }
+        const int dx = imin(dx0 + k, D.w - 1);
+        const ResizeTap tx = xt[dx];
+        sxo[k] = tx.ofs - gx0; sxo1[k] = imin(tx.ofs + 1, S.w - 1) - gx0;
+        a0[k] = (int)(int16_t)(tx.w & 0xFFFF); a1[k] = tx.w >> 16;
     }
-    *(uint32_t*)(dst + (size_t)dy * D.pitch + dx0) = out;
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int dy = dyb + (int)threadIdx.y + 4 * rr;
+        if (dy >= D.h) break;
+        const ResizeTap ty = yt[dy];
+        const int r0 = imin(imax(ty.ofs, 0), S.h - 1) - sy_lo, r1 = imin(imax(ty.ofs + 1, 0), S.h - 1) - sy_lo;
+        const int b0 = (int)(int16_t)(ty.w & 0xFFFF), b1 = ty.w >> 16;
+        const uint8_t* S0 = smem + r0 * lds_pitch;
+        const uint8_t* S1 = smem + r1 * lds_pitch;
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (dx0 + k < D.w) {
+                const int h0 = S0[sxo[k]] * a0[k] + S0[sxo1[k]] * a1[k];
+                const int h1 = S1[sxo[k]] * a0[k] + S1[sxo1[k]] * a1[k];
+                int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                v = imin(imax(v, 0), 255);
+                out |= (uint32_t)v << (8 * k);
+            }
+        }
+        *(uint32_t*)(dst + (size_t)dy * D.pitch + dx0) = out;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // FAST-9/16.  ring offsets (dx,dy), k = 0..15, as in OpenCV: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)
-// (0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
-// Returns OpenCV's cornerScore (largest threshold for which the pixel is still a corner) when the pixel
-// is a corner at threshold t0, else 0.   score = max over the 16 nine-arcs of min |v - ring| , minus 1.
-__device__ __forceinline__ int fast_score(const uint8_t* c, int wp, int t0) {
+// (0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3).  d[k] = v - ring[k].
+__device__ __forceinline__ void fast_ring(const uint8_t* c, int wp, int d[16]) {
     const int v = c[0];
-    int d[16];
     d[0] = v - c[3 * wp];          d[1] = v - c[3 * wp + 1];    d[2] = v - c[2 * wp + 2];    d[3] = v - c[wp + 3];
     d[4] = v - c[3];               d[5] = v - c[-wp + 3];       d[6] = v - c[-2 * wp + 2];   d[7] = v - c[-3 * wp + 1];
     d[8] = v - c[-3 * wp];         d[9] = v - c[-3 * wp - 1];   d[10] = v - c[-2 * wp - 2];  d[11] = v - c[-wp - 3];
     d[12] = v - c[-3];             d[13] = v - c[wp - 3];       d[14] = v - c[2 * wp - 2];   d[15] = v - c[3 * wp - 1];
-    // exact quick rejection: a 9-arc contains one pixel of every opposite pair (k, k+8)
+}
+// Exact quick rejection: a 9-arc contains one pixel of every opposite pair (k, k+8).
+__device__ __forceinline__ bool fast_quick(const int d[16], int t0) {
     bool dark = true, bright = true;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         dark = dark && (d[k] > t0 || d[k + 8] > t0);
         bright = bright && (d[k] < -t0 || d[k + 8] < -t0);
     }
-    if (!dark && !bright) return 0;
-    // sliding 9-window min (dark arcs) and max (bright arcs) over the circular ring by doubling
+    return dark || bright;
+}
+// OpenCV's cornerScore (largest threshold for which the pixel is still a corner) when the pixel is a corner at
+// threshold t0, else 0:  max over the 16 nine-arcs of min |v - ring| , minus 1.  Sliding 9-window min/max by doubling.
+__device__ __forceinline__ int fast_full(const int d[16], int t0) {
     int mn2[16], mx2[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) { mn2[k] = imin(d[k], d[(k + 1) & 15]); mx2[k] = imax(d[k], d[(k + 1) & 15]); }
@@ -104,9 +137,14 @@ __device__ __forceinline__ int fast_score(const uint8_t* c, int wp, int t0) {
     return m > t0 ? m - 1 : 0;
 }
 
-// One workgroup per (cell, image).  LDS: window tile | score tile | nms tile.
-// slots: per-cell candidate lists in the reference order (row-major inside the cell);
-// cell_count[b*ncells + cell] = number of candidates kept for the cell.
+// One workgroup per (cell, image).  LDS: window tile (dword-aligned columns) | score tile | candidate list (u16).
+//   A  every interior pixel: ring + exact quick rejection; survivors are appended, in row-major order, to the list
+//      of the wave that owns that quarter of the pixel range (wave ballots, no barrier)
+//   B  full corner score only for listed pixels (all lanes busy)
+//   C  cell-local strict 3x3 NMS on listed pixels; does any survivor reach iniTh?
+//   D  threshold choice of the reference (FAST at iniTh; if that yields nothing, FAST at minTh, :1135-1148) and
+//      ordered compaction into the cell's slot list.
+// slots: per-cell candidate lists in the reference order; cell_count[b*ncells + cell] = number kept.
 __global__ void __launch_bounds__(256) k_fast_cells(const LevelInfo* __restrict__ lv,
                                                     const CellInfo* __restrict__ cells, int ncells,
                                                     const uint8_t* __restrict__ pyr, size_t pyr_stride,
@@ -115,6 +153,7 @@ __global__ void __launch_bounds__(256) k_fast_cells(const LevelInfo* __restrict_
                                                     int* __restrict__ cell_count, int tile_bytes, int inner_bytes) {
     ORBX_DYN_SMEM(smem);
     __shared__ int s_flags[2];
+    __shared__ int s_cnt[4];
     __shared__ int s_wave[4];
     const int cell = (int)blockIdx.x, b = (int)blockIdx.y;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -125,28 +164,65 @@ __global__ void __launch_bounds__(256) k_fast_cells(const LevelInfo* __restrict_
         if (tid == 0) cell_count[(size_t)b * ncells + cell] = 0;
         return;
     }
-    const int ww = iw + 6, wh = ih + 6, wp = (ww + 3) & ~3;
+    const int wh = ih + 6;
+    const int gx0 = (ci.x0 - 3) & ~3, gx1 = (ci.x1 + 3 + 3) & ~3;   // dword-aligned window columns
+    const int wpd = (gx1 - gx0) >> 2, wp = wpd * 4;
+    const int xo = (ci.x0 - 3) - gx0;
     uint8_t* tile = smem;
     uint8_t* sc = smem + tile_bytes;
-    uint8_t* nm = sc + inner_bytes;
+    uint16_t* list = (uint16_t*)(sc + inner_bytes);
     const uint8_t* img = pyr + (size_t)b * pyr_stride + L.off;
-    for (int i = tid; i < wh * ww; i += 256) {
-        const int r = i / ww, c = i - r * ww;
-        tile[r * wp + c] = img[(size_t)(ci.y0 - 3 + r) * L.pitch + (ci.x0 - 3 + c)];
+    for (int i = tid; i < wh * wpd; i += 256) {
+        const int r = i / wpd, c = i - r * wpd;
+        ((uint32_t*)tile)[i] = *(const uint32_t*)(img + (size_t)(ci.y0 - 3 + r) * L.pitch + gx0 + 4 * c);
     }
-    if (tid == 0) { s_flags[0] = 0; }
+    if (tid == 0) s_flags[0] = 0;
     __syncthreads();
     const int t0 = imin(iniTh, minTh);
     const int npx = iw * ih;
-    for (int p = tid; p < npx; p += 256) {
-        const int y = p / iw, x = p - y * iw;
-        sc[p] = (uint8_t)fast_score(tile + (y + 3) * wp + (x + 3), wp, t0);
+    const int q = (npx + 3) >> 2;
+    const unsigned M = (1u << 20) / (unsigned)iw + 1u;      // p / iw == (p * M) >> 20 exactly for p < 2^13, iw <= 128
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // ---- A ----
+    {
+        const int pbeg = wave * q, pend = imin(npx, pbeg + q);
+        uint16_t* mylist = list + pbeg;
+        int cnt = 0;
+        for (int p0 = pbeg; p0 < pend; p0 += 64) {
+            const int p = p0 + lane;
+            bool pass = false;
+            if (p < pend) {
+                const int y = (int)(((unsigned)p * M) >> 20), x = p - y * iw;
+                int d[16];
+                fast_ring(tile + (y + 3) * wp + xo + x + 3, wp, d);
+                pass = fast_quick(d, t0);
+                if (!pass) sc[p] = 0;
+            }
+            const unsigned long long bal = __ballot(pass);
+            if (pass) mylist[cnt + __popcll(bal & lt)] = (uint16_t)p;
+            cnt += __popcll(bal);
+        }
+        if (lane == 0) s_cnt[wave] = cnt;
     }
     __syncthreads();
-    // cell-local strict 3x3 non-max suppression (neighbours outside the interior count as 0)
+    const int n0 = s_cnt[0], n1 = s_cnt[1], n2 = s_cnt[2], n3 = s_cnt[3];
+    const int total = n0 + n1 + n2 + n3;
+    // ---- B ----
+    for (int i = tid; i < total; i += 256) {
+        const int li = i < n0 ? i : (i < n0 + n1 ? q + i - n0 : (i < n0 + n1 + n2 ? 2 * q + i - n0 - n1 : 3 * q + i - n0 - n1 - n2));
+        const int p = list[li];
+        const int y = (int)(((unsigned)p * M) >> 20), x = p - y * iw;
+        int d[16];
+        fast_ring(tile + (y + 3) * wp + xo + x + 3, wp, d);
+        sc[p] = (uint8_t)fast_full(d, t0);
+    }
+    __syncthreads();
+    // ---- C ----
     int any_hi = 0;
-    for (int p = tid; p < npx; p += 256) {
-        const int y = p / iw, x = p - y * iw;
+    for (int i = tid; i < total; i += 256) {
+        const int li = i < n0 ? i : (i < n0 + n1 ? q + i - n0 : (i < n0 + n1 + n2 ? 2 * q + i - n0 - n1 : 3 * q + i - n0 - n1 - n2));
+        const int p = list[li];
+        const int y = (int)(((unsigned)p * M) >> 20), x = p - y * iw;
         const int s = sc[p];
         int keep = 0;
         if (s > 0) {
@@ -157,33 +233,37 @@ __global__ void __launch_bounds__(256) k_fast_cells(const LevelInfo* __restrict_
                 for (int dx = -1; dx <= 1; dx++) {
                     if (dx == 0 && dy == 0) continue;
                     const int xx = x + dx, yy = y + dy;
-                    const int q = (xx >= 0 && xx < iw && yy >= 0 && yy < ih) ? (int)sc[yy * iw + xx] : 0;
-                    keep &= (s > q);
+                    const int qv = (xx >= 0 && xx < iw && yy >= 0 && yy < ih) ? (int)sc[yy * iw + xx] : 0;
+                    keep &= (s > qv);
                 }
         }
-        nm[p] = keep ? (uint8_t)s : (uint8_t)0;
+        if (keep) list[li] = (uint16_t)(p | 0x8000);
         any_hi |= (keep && s >= iniTh);
     }
     if (any_hi) atomicOr(&s_flags[0], 1);
     __syncthreads();
-    // threshold choice of the reference: FAST at iniTh; if that yields nothing, FAST at minTh (:1135-1148)
+    // ---- D ----
     const int thr = s_flags[0] ? iniTh : minTh;
     uint32_t* out = slots + (size_t)b * slots_stride + ci.slot_off;
     int base = 0;
-    for (int p0 = 0; p0 < npx; p0 += 256) {
-        const int p = p0 + tid;
-        int s = 0;
-        if (p < npx) s = nm[p];
-        const int flag = (s > 0 && s >= thr);
+    for (int i0 = 0; i0 < total; i0 += 256) {
+        const int i = i0 + tid;
+        int flag = 0, p = 0, s = 0;
+        if (i < total) {
+            const int li = i < n0 ? i : (i < n0 + n1 ? q + i - n0 : (i < n0 + n1 + n2 ? 2 * q + i - n0 - n1 : 3 * q + i - n0 - n1 - n2));
+            const int e = list[li];
+            p = e & 0x7FFF;
+            s = sc[p];
+            flag = (e >> 15) && s >= thr;
+        }
         const unsigned long long bal = __ballot(flag);
         if (lane == 0) s_wave[wave] = __popcll(bal);
         __syncthreads();
         int wbase = 0, tot = 0;
         for (int w = 0; w < 4; w++) { const int c = s_wave[w]; if (w < wave) wbase += c; tot += c; }
         if (flag) {
-            const int y = p / iw, x = p - y * iw;
-            const int pos = base + wbase + __popcll(bal & ((1ull << lane) - 1ull));
-            out[pos] = key_pack(ci.x0 + x - kBorder, ci.y0 + y - kBorder, s);
+            const int y = (int)(((unsigned)p * M) >> 20), x = p - y * iw;
+            out[base + wbase + __popcll(bal & lt)] = key_pack(ci.x0 + x - kBorder, ci.y0 + y - kBorder, s);
         }
         base += tot;
         __syncthreads();
@@ -192,50 +272,81 @@ __global__ void __launch_bounds__(256) k_fast_cells(const LevelInfo* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 7x7 Gaussian blur, taps k[7] (sum 256 or 257), REFLECT_101, out = sat((sum_j k_j * (sum_i k_i*p) + 32768) >> 16).
-// block (64,4); tile 64 x 16 outputs.  grid (ceil(w0/64), ceil(h0/16), B*nlevels); blocks outside a level exit.
+// 7x7 Gaussian blur, taps k[7] (symmetric; sum 256 or 257), REFLECT_101,
+//   out = sat((sum_j k_j * (sum_i k_i * p) + 32768) >> 16).
+// Streaming design: a thread owns 4 adjacent columns (one dword) and walks down a strip of kBlurRows rows with the
+// last 7 horizontal sums in registers, so every input dword is fetched once per strip (+6 halo rows, L1/L2 hits) and
+// every output is one coalesced dword store.  No LDS, no barriers.
+// block (64,4): 256 columns x 4 strips.  grid (tiles over all levels, B): tile table in BlurTiles.
+constexpr int kBlurRows = 16;
+
+__device__ __forceinline__ int blur_pick(uint32_t l, uint32_t c, uint32_t r, int idx) {   // byte idx of the 12-byte window
+    const uint32_t w = idx < 4 ? l : (idx < 8 ? c : r);
+    return (int)((w >> ((idx & 3) * 8)) & 0xFFu);
+}
+
 __global__ void __launch_bounds__(256) k_blur(const LevelInfo* __restrict__ lv, int nlevels,
                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
-                                              size_t pyr_stride, BlurTaps taps) {
-    __shared__ uint8_t s_in[22][72];
-    __shared__ uint16_t s_h[22][64];
-    const int level = (int)(blockIdx.z % (unsigned)nlevels), b = (int)(blockIdx.z / (unsigned)nlevels);
+                                              size_t pyr_stride, BlurTaps taps, BlurTiles tiles) {
+    int level = 0;
+    for (int l = 1; l < nlevels; l++) if ((int)blockIdx.x >= tiles.begin[l]) level = l;
     const LevelInfo L = lv[level];
-    const int x0 = (int)blockIdx.x * 64, y0 = (int)blockIdx.y * 16;
-    if (x0 >= L.w || y0 >= L.h) return;
-    const int tid = (int)(threadIdx.y * 64 + threadIdx.x);
+    const int b = (int)blockIdx.y;
+    const int t = (int)blockIdx.x - tiles.begin[level];
+    const int tcols = (L.w + 255) >> 8;
+    const int ty = t / tcols, tx = t - ty * tcols;
+    const int x0 = (tx * 64 + (int)threadIdx.x) * 4;
+    const int ys = (ty * 4 + (int)threadIdx.y) * kBlurRows;
+    if (x0 >= L.w || ys >= L.h) return;
     const uint8_t* src = pyr + (size_t)b * pyr_stride + L.off;
     uint8_t* dst = blur + (size_t)b * pyr_stride + L.off;
-    for (int i = tid; i < 22 * 70; i += 256) {
-        const int r = i / 70, c = i - r * 70;
-        int yy = y0 + r - 3, xx = x0 + c - 3;
-        // reflect101; coordinates far outside (tile overhang past the image) are clamped after reflection
-        if (yy < 0) yy = -yy;
-        if (yy >= L.h) yy = 2 * L.h - 2 - yy;
-        if (xx < 0) xx = -xx;
-        if (xx >= L.w) xx = 2 * L.w - 2 - xx;
-        yy = imin(imax(yy, 0), L.h - 1); xx = imin(imax(xx, 0), L.w - 1);
-        s_in[r][c] = src[(size_t)yy * L.pitch + xx];
-    }
-    __syncthreads();
-    for (int i = tid; i < 22 * 64; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        int s = 0;
+    const int k0 = taps.k[0], k1 = taps.k[1], k2 = taps.k[2], k3 = taps.k[3];
+    const bool edge = (x0 == 0) || (x0 + 7 > L.w);     // some of columns x0-3..x0+6 fall outside the image
+    int h[7][4];
 #pragma unroll
-        for (int k = 0; k < 7; k++) s += taps.k[k] * s_in[r][c + k];
-        s_h[r][c] = (uint16_t)s;
-    }
-    __syncthreads();
-    const int c = (int)threadIdx.x;
+    for (int i = 0; i < 7; i++) { h[i][0] = h[i][1] = h[i][2] = h[i][3] = 0; }
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-        const int r = (int)threadIdx.y * 4 + rr;
-        unsigned s = 0;
+    for (int i = 0; i < kBlurRows + 6; i++) {
+        const int yo = ys + i - 6;                      // output row completed by this input row
+        if (yo >= L.h) break;
+        int y = ys - 3 + i;
+        if (y < 0) y = -y;
+        if (y >= L.h) y = 2 * L.h - 2 - y;
+        const uint8_t* row = src + (size_t)y * L.pitch + x0;
+        const uint32_t c = *(const uint32_t*)row;
+        const uint32_t l = x0 > 0 ? *(const uint32_t*)(row - 4) : 0u;
+        const uint32_t r = x0 + 4 < L.pitch ? *(const uint32_t*)(row + 4) : 0u;
+        int p[10];
+        if (!edge) {
+            p[0] = (int)((l >> 8) & 0xFF); p[1] = (int)((l >> 16) & 0xFF); p[2] = (int)(l >> 24);
+            p[3] = (int)(c & 0xFF); p[4] = (int)((c >> 8) & 0xFF); p[5] = (int)((c >> 16) & 0xFF); p[6] = (int)(c >> 24);
+            p[7] = (int)(r & 0xFF); p[8] = (int)((r >> 8) & 0xFF); p[9] = (int)((r >> 16) & 0xFF);
+        } else {
 #pragma unroll
-        for (int k = 0; k < 7; k++) s += (unsigned)taps.k[k] * (unsigned)s_h[r + k][c];
-        unsigned v = (s + 32768u) >> 16;
-        v = v > 255u ? 255u : v;
-        if (x0 + c < L.w && y0 + r < L.h) dst[(size_t)(y0 + r) * L.pitch + x0 + c] = (uint8_t)v;
+            for (int j = 0; j < 10; j++) {
+                int col = x0 - 3 + j;
+                if (col < 0) col = -col;
+                if (col >= L.w) col = 2 * L.w - 2 - col;
+                col = imin(imax(col, 0), L.w - 1);     // only reachable for columns that feed no stored output
+                p[j] = blur_pick(l, c, r, col - (x0 - 4));
+            }
+        }
+#pragma unroll
+        for (int t7 = 0; t7 < 6; t7++) { h[t7][0] = h[t7 + 1][0]; h[t7][1] = h[t7 + 1][1]; h[t7][2] = h[t7 + 1][2]; h[t7][3] = h[t7 + 1][3]; }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            h[6][j] = k0 * (p[j] + p[j + 6]) + k1 * (p[j + 1] + p[j + 5]) + k2 * (p[j + 2] + p[j + 4]) + k3 * p[j + 3];
+        if (i >= 6) {
+            uint32_t out = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned v = (unsigned)(k0 * (h[0][j] + h[6][j]) + k1 * (h[1][j] + h[5][j]) + k2 * (h[2][j] + h[4][j]) + k3 * h[3][j]);
+                unsigned o = (v + 32768u) >> 16;
+                o = o > 255u ? 255u : o;
+                out |= o << (8 * j);
+            }
+            *(uint32_t*)(dst + (size_t)yo * L.pitch + x0) = out;
+        }
     }
 }
 

@@ -187,8 +187,9 @@ int configure(orbx_extractor* h, int W, int H, int B) {
                     const int iw = std::max(c.x1 - c.x0, 0), ih = std::max(c.y1 - c.y0, 0);
                     slot += ((iw + 1) / 2) * ((ih + 1) / 2);         // max number of strict 3x3 local maxima
                     if (iw > 0 && ih > 0) {
-                        const int wp = (iw + 6 + 3) & ~3;
-                        tile_b = std::max(tile_b, wp * (ih + 6));
+                        if (iw > 128 || iw * ih >= 8192) return fail(ORBX_E_ARG, "FAST cell too large");   // k_fast_cells index packing
+                        const int gx0 = (c.x0 - 3) & ~3, gx1 = (c.x1 + 3 + 3) & ~3;    // dword-aligned window (k_fast_cells)
+                        tile_b = std::max(tile_b, (gx1 - gx0) * (ih + 6));
                         inner_b = std::max(inner_b, iw * ih);
                     }
                     h->cells.push_back(c);
@@ -255,9 +256,13 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int strid
     stage_end(h, ST_IMPORT, h->s0);
     stage_begin(h, ST_PYRAMID, h->s0);
     for (int l = 1; l < nl; l++) {
-        const LevelInfo& L = h->lv[l];
-        dim3 grid((L.pitch + 255) / 256, (L.h + 3) / 4, B);
-        ORBX_LAUNCH(k_resize, grid, blk2, 0, h->s0, (const LevelInfo*)h->d_lv.p, l, (const ResizeTap*)h->d_xtab.p, (const ResizeTap*)h->d_ytab.p, h->d_pyr.p, h->pyr_stride);
+        const LevelInfo& L = h->lv[l]; const LevelInfo& S = h->lv[l - 1];
+        dim3 grid((L.pitch + 255) / 256, (L.h + 7) / 8, B);
+        // LDS window: source span of a 256 x 8 output tile (+ alignment and the +1 neighbour)
+        const int lds_pitch = (int)align_up((size_t)ceil(256.0 * S.w / L.w) + 12, 4);
+        const int lds_rows = (int)ceil(8.0 * S.h / L.h) + 3;
+        ORBX_LAUNCH(k_resize, grid, blk2, (size_t)lds_pitch * lds_rows, h->s0, (const LevelInfo*)h->d_lv.p, l, (const ResizeTap*)h->d_xtab.p,
+                    (const ResizeTap*)h->d_ytab.p, h->d_pyr.p, h->pyr_stride, lds_pitch, lds_rows);
     }
     stage_end(h, ST_PYRAMID, h->s0);
     // fork: the blur only depends on the pyramid and runs beside FAST + quadtree on the second stream
@@ -268,15 +273,18 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int strid
         BlurTaps taps;
         static const int A[7] = {18, 34, 48, 56, 48, 34, 18}, Bt[7] = {18, 34, 49, 55, 49, 34, 18};
         for (int i = 0; i < 7; i++) taps.k[i] = h->gauss_variant == 1 ? Bt[i] : A[i];
-        dim3 grid((h->lv[0].w + 63) / 64, (h->lv[0].h + 15) / 16, B * nl);
-        ORBX_LAUNCH(k_blur, grid, blk2, 0, h->s1, (const LevelInfo*)h->d_lv.p, nl, (const uint8_t*)h->d_pyr.p, h->d_blur.p, h->pyr_stride, taps);
+        BlurTiles tiles; int nt = 0;
+        for (int l = 0; l < nl; l++) { tiles.begin[l] = nt; nt += ((h->lv[l].w + 255) / 256) * ((h->lv[l].h + 63) / 64); }
+        for (int l = nl; l <= kMaxLevels; l++) tiles.begin[l] = nt;
+        dim3 grid(nt, B, 1);
+        ORBX_LAUNCH(k_blur, grid, blk2, 0, h->s1, (const LevelInfo*)h->d_lv.p, nl, (const uint8_t*)h->d_pyr.p, h->d_blur.p, h->pyr_stride, taps, tiles);
     }
     stage_end(h, ST_BLUR, h->s1);
     rt::event_record(h->ev_join, h->s1);
     stage_begin(h, ST_FAST, h->s0);
     {
         dim3 grid(h->ncells, B, 1);
-        const size_t smem = (size_t)h->fast_tile_bytes + 2 * (size_t)h->fast_inner_bytes;
+        const size_t smem = (size_t)h->fast_tile_bytes + 3 * (size_t)h->fast_inner_bytes + 32;   // tile | score | u16 list
         ORBX_LAUNCH(k_fast_cells, grid, blk1, smem, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
                     (const uint8_t*)h->d_pyr.p, h->pyr_stride, h->iniTh, h->minTh, h->d_slots.p, h->cand_stride, h->d_cell_count.p,
                     h->fast_tile_bytes, h->fast_inner_bytes);
@@ -413,11 +421,12 @@ int orbx_fetch(orbx_extractor* h, OrbxKeyPoint* kps, uint8_t* desc, int cap, int
     rt::set_device(h->device);
     const int B = h->lastB; const size_t tc = (size_t)h->kp_total_cap;
     const size_t kb = (size_t)B * tc * sizeof(KeyPointRec), db = (size_t)B * tc * 32;
-    if (h->h_stage.ensure(kb + db + 64)) return fail(ORBX_E_DEVICE, "pinned allocation failed");
+    const bool direct = (cap == h->kp_total_cap);   // caller's layout == device layout: no staging, no repack
+    if (!direct && h->h_stage.ensure(kb + db + 64)) return fail(ORBX_E_DEVICE, "pinned allocation failed");
     int e = rt::copy_d2h(h->h_nm.p, h->d_nm.p, sizeof(int) * 2 * h->maxB, h->s0);
     e |= rt::copy_d2h(h->h_nm.p + 2 * h->maxB, h->d_status.p, sizeof(int), h->s0);
-    if (kps) e |= rt::copy_d2h(h->h_stage.p, h->d_kps.p, kb, h->s0);
-    if (desc) e |= rt::copy_d2h(h->h_stage.p + kb, h->d_desc.p, db, h->s0);
+    if (kps) e |= rt::copy_d2h(direct ? (void*)kps : (void*)h->h_stage.p, h->d_kps.p, kb, h->s0);
+    if (desc) e |= rt::copy_d2h(direct ? (void*)desc : (void*)(h->h_stage.p + kb), h->d_desc.p, db, h->s0);
     if (e || rt::stream_sync(h->s0)) return fail(ORBX_E_DEVICE, "D2H failed: %s", rt::last_error());
     if (h->profile) orbx_sync(h);
     if (h->h_nm.p[2 * h->maxB] != 0) return fail(ORBX_E_INTERNAL, "device quadtree capacity check tripped");
@@ -426,6 +435,7 @@ int orbx_fetch(orbx_extractor* h, OrbxKeyPoint* kps, uint8_t* desc, int cap, int
         const int n = h->h_nm.p[b];
         if (n_out) n_out[b] = n;
         if (mono_out) mono_out[b] = h->h_nm.p[h->maxB + b];
+        if (direct) continue;
         if (n > cap) { rc = ORBX_E_CAPACITY; continue; }
         if (kps) memcpy(kps + (size_t)b * cap, h->h_stage.p + (size_t)b * tc * sizeof(KeyPointRec), (size_t)n * sizeof(KeyPointRec));
         if (desc) memcpy(desc + (size_t)b * cap * 32, h->h_stage.p + kb + (size_t)b * tc * 32, (size_t)n * 32);
@@ -473,6 +483,14 @@ int orbx_device_upload(orbx_extractor* h, void* dptr, const void* host, size_t b
     if (rt::copy_h2d(dptr, host, bytes, h->s0) || rt::stream_sync(h->s0)) return fail(ORBX_E_DEVICE, "upload failed");
     return ORBX_OK;
 }
+
+int orbx_host_alloc(orbx_extractor* h, size_t bytes, void** hptr) {
+    if (!h || !hptr) return fail(ORBX_E_ARG, "null");
+    rt::set_device(h->device);
+    *hptr = rt::hmalloc(bytes);
+    return *hptr ? ORBX_OK : fail(ORBX_E_DEVICE, "pinned host allocation of %zu bytes failed", bytes);
+}
+int orbx_host_free(orbx_extractor* h, void* hptr) { if (!h) return ORBX_E_ARG; rt::set_device(h->device); rt::hfree(hptr); return ORBX_OK; }
 
 int orbx_profile_enable(orbx_extractor* h, int on) { if (!h) return ORBX_E_ARG; h->profile = on != 0; return ORBX_OK; }
 int orbx_profile_get(orbx_extractor* h, float ms[ORBX_NSTAGES]) {
@@ -562,16 +580,19 @@ int orbm_stereo_fetch(orbx_extractor* L, int B, float* uRight, float* depth, int
     if (!L || B <= 0 || B > L->maxB) return fail(ORBX_E_ARG, "bad fetch");
     rt::set_device(L->device);
     const size_t tc = (size_t)L->kp_total_cap;
-    if (L->h_stage.ensure(2 * B * tc * sizeof(float) + 64)) return fail(ORBX_E_DEVICE, "pinned allocation failed");
-    float* hu = (float*)L->h_stage.p; float* hd = hu + B * tc;
-    int e = rt::copy_d2h(hu, L->d_uRight.p, B * tc * sizeof(float), L->s0) | rt::copy_d2h(hd, L->d_depth.p, B * tc * sizeof(float), L->s0);
+    const bool direct = ((size_t)cap == tc);
+    if (!direct && L->h_stage.ensure(2 * B * tc * sizeof(float) + 64)) return fail(ORBX_E_DEVICE, "pinned allocation failed");
+    float* hu = direct ? uRight : (float*)L->h_stage.p; float* hd = direct ? depth : hu + B * tc;
+    int e = 0;
+    if (hu) e |= rt::copy_d2h(hu, L->d_uRight.p, B * tc * sizeof(float), L->s0);
+    if (hd) e |= rt::copy_d2h(hd, L->d_depth.p, B * tc * sizeof(float), L->s0);
     e |= rt::copy_d2h(L->h_nm.p, L->d_nmatch.p, sizeof(int) * B, L->s0);
     if (e || rt::stream_sync(L->s0)) return fail(ORBX_E_DEVICE, "D2H failed: %s", rt::last_error());
     if (L->profile) L->stage_ms[ST_MATCH] = rt::event_elapsed_ms(L->ev_stage[ST_MATCH][0], L->ev_stage[ST_MATCH][1]);
     const size_t ncopy = std::min<size_t>(tc, (size_t)cap);
     for (int b = 0; b < B; b++) {
-        if (uRight) memcpy(uRight + (size_t)b * cap, hu + b * tc, ncopy * sizeof(float));
-        if (depth) memcpy(depth + (size_t)b * cap, hd + b * tc, ncopy * sizeof(float));
+        if (!direct && uRight) memcpy(uRight + (size_t)b * cap, hu + b * tc, ncopy * sizeof(float));
+        if (!direct && depth) memcpy(depth + (size_t)b * cap, hd + b * tc, ncopy * sizeof(float));
         if (n_matches) n_matches[b] = L->h_nm.p[b];
     }
     return ORBX_OK;

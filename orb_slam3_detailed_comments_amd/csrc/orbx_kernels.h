@@ -7,13 +7,14 @@ namespace orbx {
 __global__ void k_import(const LevelInfo* __restrict__ lv, const uint8_t* __restrict__ images, int stride,
                          size_t image_stride, uint8_t* __restrict__ pyr, size_t pyr_stride);
 __global__ void k_resize(const LevelInfo* __restrict__ lv, int level, const ResizeTap* __restrict__ xtab,
-                         const ResizeTap* __restrict__ ytab, uint8_t* __restrict__ pyr, size_t pyr_stride);
+                         const ResizeTap* __restrict__ ytab, uint8_t* __restrict__ pyr, size_t pyr_stride,
+                         int lds_pitch, int lds_rows);
 __global__ void k_fast_cells(const LevelInfo* __restrict__ lv, const CellInfo* __restrict__ cells, int ncells,
                              const uint8_t* __restrict__ pyr, size_t pyr_stride, int iniTh, int minTh,
                              uint32_t* __restrict__ slots, size_t slots_stride, int* __restrict__ cell_count,
                              int tile_bytes, int inner_bytes);
 __global__ void k_blur(const LevelInfo* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,
-                       uint8_t* __restrict__ blur, size_t pyr_stride, BlurTaps taps);
+                       uint8_t* __restrict__ blur, size_t pyr_stride, BlurTaps taps, BlurTiles tiles);
 __global__ void k_quadtree(const LevelInfo* __restrict__ lv, const CellInfo* __restrict__ cells, int ncells,
                            const int* __restrict__ cell_count, const uint32_t* __restrict__ slots, size_t slots_stride,
                            uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,

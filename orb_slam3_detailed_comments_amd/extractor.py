@@ -153,5 +153,16 @@ class ORBextractor:
         self._lib.check(self._lib.L.orbx_device_upload(self._h, p, arr.ctypes.data, arr.nbytes))
         return p
 
+    def pinned_empty(self, shape, dtype):
+        """numpy array backed by page-locked host memory (fast D2H target for fetch())."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        self._lib.check(self._lib.L.orbx_host_alloc(self._h, max(nbytes, 1), C.byref(p)))
+        buf = (C.c_uint8 * max(nbytes, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", []) + [p]
+        return arr
+
     def device_free(self, p):
         self._lib.L.orbx_device_free(self._h, p)
