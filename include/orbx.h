@@ -101,7 +101,8 @@ int orbx_device_upload(orbx_extractor* h, void* dptr, const void* host, size_t b
 int orbx_host_alloc(orbx_extractor* h, size_t bytes, void** hptr);
 int orbx_host_free(orbx_extractor* h, void* hptr);
 
-/* Per-stage GPU time of the last batch, HIP events on the launching streams.  names is a static table. */
+/* Per-stage GPU time of the last batch, HIP events on the launching streams.  on = 1: normal two-stream schedule (the blur
+ * overlaps FAST + quadtree, so their times overlap too); on = 2: serial schedule, every kernel alone on one stream. */
 #define ORBX_NSTAGES 8
 int orbx_profile_enable(orbx_extractor* h, int on);
 int orbx_profile_get(orbx_extractor* h, float ms[ORBX_NSTAGES]);

@@ -108,13 +108,14 @@ __device__ __forceinline__ void fast_ring(const uint8_t* c, int wp, int d[16]) {
 }
 // Exact quick rejection: a 9-arc contains one pixel of every opposite pair (k, k+8).
 __device__ __forceinline__ bool fast_quick(const int d[16], int t0) {
-    bool dark = true, bright = true;
+    // branch-free: max(d[k], d[k+8]) > t0 for all k (dark) or min(d[k], d[k+8]) < -t0 for all k (bright)
+    int mnmx = 255, mxmn = -255;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        dark = dark && (d[k] > t0 || d[k + 8] > t0);
-        bright = bright && (d[k] < -t0 || d[k + 8] < -t0);
+        mnmx = imin(mnmx, imax(d[k], d[k + 8]));
+        mxmn = imax(mxmn, imin(d[k], d[k + 8]));
     }
-    return dark || bright;
+    return (mnmx > t0) | (mxmn < -t0);
 }
 // OpenCV's cornerScore (largest threshold for which the pixel is still a corner) when the pixel is a corner at
 // threshold t0, else 0:  max over the 16 nine-arcs of min |v - ring| , minus 1.  Sliding 9-window min/max by doubling.
@@ -280,9 +281,23 @@ __global__ void __launch_bounds__(256) k_fast_cells(const LevelInfo* __restrict_
 // block (64,4): 256 columns x 4 strips.  grid (tiles over all levels, B): tile table in BlurTiles.
 constexpr int kBlurRows = 16;
 
-__device__ __forceinline__ int blur_pick(uint32_t l, uint32_t c, uint32_t r, int idx) {   // byte idx of the 12-byte window
-    const uint32_t w = idx < 4 ? l : (idx < 8 ? c : r);
-    return (int)((w >> ((idx & 3) * 8)) & 0xFFu);
+// byte permute: result byte i = byte sel_i (0..7) of the 8-byte pair {hi:lo}
+__device__ __forceinline__ uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+#ifdef ORBX_EMU
+    const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; i++) r |= (uint32_t)((v >> (8 * ((sel >> (8 * i)) & 7))) & 0xFF) << (8 * i);
+    return r;
+#else
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#endif
+}
+__device__ __forceinline__ int mul24(int a, int b) {
+#ifdef ORBX_EMU
+    return a * b;
+#else
+    return __mul24(a, b);      // operands < 2^23: full-rate 24-bit multiply instead of the quarter-rate 32-bit one
+#endif
 }
 
 __global__ void __launch_bounds__(256) k_blur(const LevelInfo* __restrict__ lv, int nlevels,
@@ -301,7 +316,27 @@ __global__ void __launch_bounds__(256) k_blur(const LevelInfo* __restrict__ lv, 
     const uint8_t* src = pyr + (size_t)b * pyr_stride + L.off;
     uint8_t* dst = blur + (size_t)b * pyr_stride + L.off;
     const int k0 = taps.k[0], k1 = taps.k[1], k2 = taps.k[2], k3 = taps.k[3];
-    const bool edge = (x0 == 0) || (x0 + 7 > L.w);     // some of columns x0-3..x0+6 fall outside the image
+    // Loop-invariant REFLECT_101 column mapping: the 10 input columns x0-3..x0+6 are gathered from the 12-byte window
+    // {l = x0-4.., c = x0.., r = x0+4..} by three byte-permutes whose selectors are computed once per thread, so border
+    // lanes cost the same as interior lanes (no divergence).  Columns that only feed outputs >= w are don't-cares.
+    uint32_t sel[3]; int base[3];
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        int idx[4], mn = 11;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int col = x0 - 3 + 4 * g + j;
+            if (col < 0) col = -col;
+            if (col >= L.w) col = 2 * L.w - 2 - col;
+            idx[j] = imin(imax(col - (x0 - 4), 0), 11);
+            if (g * 4 + j < 10) mn = imin(mn, idx[j]);
+        }
+        base[g] = imin(mn >> 2, 1);
+        uint32_t sgl = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) sgl |= (uint32_t)imin(imax(idx[j] - 4 * base[g], 0), 7) << (8 * j);
+        sel[g] = sgl;
+    }
     int h[7][4];
 #pragma unroll
     for (int i = 0; i < 7; i++) { h[i][0] = h[i][1] = h[i][2] = h[i][3] = 0; }
@@ -316,31 +351,23 @@ __global__ void __launch_bounds__(256) k_blur(const LevelInfo* __restrict__ lv, 
         const uint32_t c = *(const uint32_t*)row;
         const uint32_t l = x0 > 0 ? *(const uint32_t*)(row - 4) : 0u;
         const uint32_t r = x0 + 4 < L.pitch ? *(const uint32_t*)(row + 4) : 0u;
+        const uint32_t P0 = byte_perm(base[0] ? r : c, base[0] ? c : l, sel[0]);
+        const uint32_t P1 = byte_perm(base[1] ? r : c, base[1] ? c : l, sel[1]);
+        const uint32_t P2 = byte_perm(base[2] ? r : c, base[2] ? c : l, sel[2]);
         int p[10];
-        if (!edge) {
-            p[0] = (int)((l >> 8) & 0xFF); p[1] = (int)((l >> 16) & 0xFF); p[2] = (int)(l >> 24);
-            p[3] = (int)(c & 0xFF); p[4] = (int)((c >> 8) & 0xFF); p[5] = (int)((c >> 16) & 0xFF); p[6] = (int)(c >> 24);
-            p[7] = (int)(r & 0xFF); p[8] = (int)((r >> 8) & 0xFF); p[9] = (int)((r >> 16) & 0xFF);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 10; j++) {
-                int col = x0 - 3 + j;
-                if (col < 0) col = -col;
-                if (col >= L.w) col = 2 * L.w - 2 - col;
-                col = imin(imax(col, 0), L.w - 1);     // only reachable for columns that feed no stored output
-                p[j] = blur_pick(l, c, r, col - (x0 - 4));
-            }
-        }
+        p[0] = (int)(P0 & 0xFF); p[1] = (int)((P0 >> 8) & 0xFF); p[2] = (int)((P0 >> 16) & 0xFF); p[3] = (int)(P0 >> 24);
+        p[4] = (int)(P1 & 0xFF); p[5] = (int)((P1 >> 8) & 0xFF); p[6] = (int)((P1 >> 16) & 0xFF); p[7] = (int)(P1 >> 24);
+        p[8] = (int)(P2 & 0xFF); p[9] = (int)((P2 >> 8) & 0xFF);
 #pragma unroll
         for (int t7 = 0; t7 < 6; t7++) { h[t7][0] = h[t7 + 1][0]; h[t7][1] = h[t7 + 1][1]; h[t7][2] = h[t7 + 1][2]; h[t7][3] = h[t7 + 1][3]; }
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            h[6][j] = k0 * (p[j] + p[j + 6]) + k1 * (p[j + 1] + p[j + 5]) + k2 * (p[j + 2] + p[j + 4]) + k3 * p[j + 3];
+            h[6][j] = mul24(k0, p[j] + p[j + 6]) + mul24(k1, p[j + 1] + p[j + 5]) + mul24(k2, p[j + 2] + p[j + 4]) + mul24(k3, p[j + 3]);
         if (i >= 6) {
             uint32_t out = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const unsigned v = (unsigned)(k0 * (h[0][j] + h[6][j]) + k1 * (h[1][j] + h[5][j]) + k2 * (h[2][j] + h[4][j]) + k3 * h[3][j]);
+                const unsigned v = (unsigned)(mul24(k0, h[0][j] + h[6][j]) + mul24(k1, h[1][j] + h[5][j]) + mul24(k2, h[2][j] + h[4][j]) + mul24(k3, h[3][j]));
                 unsigned o = (v + 32768u) >> 16;
                 o = o > 255u ? 255u : o;
                 out |= o << (8 * j);

@@ -80,7 +80,7 @@ struct orbx_extractor {
     rt::stream_t s0 = 0, s1 = 0;
     rt::event_t ev_fork = 0, ev_join = 0, ev_done = 0;
     rt::event_t ev_stage[ORBX_NSTAGES][2];
-    bool profile = false, have_streams = false;
+    bool profile = false, serial = false, have_streams = false;
     int lastB = 0;
     float stage_ms[ORBX_NSTAGES];
 };
@@ -266,9 +266,10 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int strid
     }
     stage_end(h, ST_PYRAMID, h->s0);
     // fork: the blur only depends on the pyramid and runs beside FAST + quadtree on the second stream
+    rt::stream_t sb = h->serial ? h->s0 : h->s1;    // serial profiling mode keeps every kernel on one stream
     rt::event_record(h->ev_fork, h->s0);
-    rt::stream_wait_event(h->s1, h->ev_fork);
-    stage_begin(h, ST_BLUR, h->s1);
+    rt::stream_wait_event(sb, h->ev_fork);
+    stage_begin(h, ST_BLUR, sb);
     {
         BlurTaps taps;
         static const int A[7] = {18, 34, 48, 56, 48, 34, 18}, Bt[7] = {18, 34, 49, 55, 49, 34, 18};
@@ -277,10 +278,10 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int strid
         for (int l = 0; l < nl; l++) { tiles.begin[l] = nt; nt += ((h->lv[l].w + 255) / 256) * ((h->lv[l].h + 63) / 64); }
         for (int l = nl; l <= kMaxLevels; l++) tiles.begin[l] = nt;
         dim3 grid(nt, B, 1);
-        ORBX_LAUNCH(k_blur, grid, blk2, 0, h->s1, (const LevelInfo*)h->d_lv.p, nl, (const uint8_t*)h->d_pyr.p, h->d_blur.p, h->pyr_stride, taps, tiles);
+        ORBX_LAUNCH(k_blur, grid, blk2, 0, sb, (const LevelInfo*)h->d_lv.p, nl, (const uint8_t*)h->d_pyr.p, h->d_blur.p, h->pyr_stride, taps, tiles);
     }
-    stage_end(h, ST_BLUR, h->s1);
-    rt::event_record(h->ev_join, h->s1);
+    stage_end(h, ST_BLUR, sb);
+    rt::event_record(h->ev_join, sb);
     stage_begin(h, ST_FAST, h->s0);
     {
         dim3 grid(h->ncells, B, 1);
@@ -492,7 +493,7 @@ int orbx_host_alloc(orbx_extractor* h, size_t bytes, void** hptr) {
 }
 int orbx_host_free(orbx_extractor* h, void* hptr) { if (!h) return ORBX_E_ARG; rt::set_device(h->device); rt::hfree(hptr); return ORBX_OK; }
 
-int orbx_profile_enable(orbx_extractor* h, int on) { if (!h) return ORBX_E_ARG; h->profile = on != 0; return ORBX_OK; }
+int orbx_profile_enable(orbx_extractor* h, int on) { if (!h) return ORBX_E_ARG; h->profile = on != 0; h->serial = on == 2; return ORBX_OK; }
 int orbx_profile_get(orbx_extractor* h, float ms[ORBX_NSTAGES]) {
     if (!h) return ORBX_E_ARG;
     for (int i = 0; i < ORBX_NSTAGES; i++) ms[i] = h->stage_ms[i];

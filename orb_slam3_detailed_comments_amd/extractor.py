@@ -137,8 +137,8 @@ class ORBextractor:
             self._lib.check(n)
         return a[:n].copy()
 
-    def profile(self, on=True):
-        self._lib.check(self._lib.L.orbx_profile_enable(self._h, int(on)))
+    def profile(self, on=True, serial=False):
+        self._lib.check(self._lib.L.orbx_profile_enable(self._h, 2 if (on and serial) else int(on)))
 
     def stage_ms(self):
         ms = np.zeros(_lib.NSTAGES, np.float32)

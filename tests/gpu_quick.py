@@ -61,7 +61,7 @@ for B in (2, 16, 64, 128):
     arr = np.stack(imgs)
     ex = ORBextractor(1200,1.2,8,20,7)
     dptr = ex.device_upload(arr)
-    ex.profile(True)
+    ex.profile(True, serial=(os.environ.get('ORBX_SERIAL','1')=='1'))
     for it in range(3):
         ex.enqueue(None, (0,0), device_ptr=dptr, shape=arr.shape)
         lib.check(lib.L.orbm_stereo_match(ex._h, 0, ex._h, B//2, B//2, bf, b))
