@@ -132,6 +132,88 @@ int orbm_knn2(orbx_extractor* left, int left_first, orbx_extractor* right, int r
 int orbm_knn2_fetch(orbx_extractor* left, int B, int* idx0, int* dist0, int* idx1, int* dist1,
                     uint8_t* ratio_ok, int cap);
 
+/* ---------------------------------------------------------------------------------------------------------- */
+/* Guided searches.  The reference methods take Frame / KeyFrame / MapPoint objects (pointer graphs with mutexes);
+ * across the C ABI they are passed as read-only structure-of-arrays VIEWS of exactly the fields the method reads.
+ * The facade (include/orb_slam3_amd/ORBmatcher.h) fills the views from the real classes and applies the results.
+ * Geometry that the reference computes with Eigen/Sophus before matching (Tcw * x3Dw, GeometricCamera::project,
+ * the fundamental matrix) stays on the caller's side and enters here as numbers, so its float op order is the
+ * reference's own.  Only the non-fisheye path (Frame::Nleft == -1, no mpCamera2) is implemented. */
+typedef struct OrbmFrameView {            /* fields of ORB_SLAM3::Frame, include/Frame.h */
+    int N;                                /* number of keypoints */
+    const OrbxKeyPoint* keys_un;          /* mvKeysUn (:232) */
+    const uint8_t* desc;                  /* mDescriptors, N x 32 (:244) */
+    const float* u_right;                 /* mvuRight, negative = monocular point (:234); NULL = all monocular */
+    const uint8_t* occupied;              /* mvpMapPoints[i] != NULL && mvpMapPoints[i]->Observations() > 0 */
+    float min_x, min_y, max_x, max_y;     /* mnMinX .. mnMaxY (:287-290) */
+    float grid_w_inv, grid_h_inv;         /* mfGridElementWidthInv / HeightInv (:250-251) */
+    float mbf;                            /* (:209) */
+    int nlevels; const float* scale_factors;   /* mvScaleFactors (:281) */
+} OrbmFrameView;
+
+typedef struct OrbmMapPointView {         /* tracking fields of ORB_SLAM3::MapPoint, include/MapPoint.h:171-179 */
+    int M;
+    const uint8_t* in_view;               /* mbTrackInView */
+    const float* proj_x; const float* proj_y; const float* proj_xr;   /* mTrackProjX / Y / XR */
+    const int* scale_level;               /* mnTrackScaleLevel */
+    const float* view_cos;                /* mTrackViewCos */
+    const float* track_depth;             /* mTrackDepth */
+    const uint8_t* is_bad;                /* isBad() */
+    const uint8_t* has_obs;               /* Observations() > 0 */
+    const uint8_t* desc;                  /* GetDescriptor(), M x 32 */
+} OrbmMapPointView;
+
+/* Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel) (src/Frame.cc:859-951): indices in the reference's order.
+ * Returns the count (>= 0) or a negative status. */
+int orbm_get_features_in_area(orbx_extractor* h, const OrbmFrameView* F, float x, float y, float r,
+                              int min_level, int max_level, int* indices, int cap);
+
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints)
+ * (src/ORBmatcher.cc:45-239).  assigned[i] = index of the map point written to F.mvpMapPoints[i], or -1 if the call
+ * leaves that entry untouched.  *nmatches = the reference's return value. */
+int orbm_search_by_projection_mappoints(orbx_extractor* h, const OrbmFrameView* F, const OrbmMapPointView* P,
+                                        float th, int far_points, float th_far_points, float nnratio,
+                                        int* assigned, int* nmatches);
+
+typedef struct OrbmLastFrameView {        /* what SearchByProjection(CurrentFrame, LastFrame, ...) reads of LastFrame */
+    int N;
+    const uint8_t* valid;                 /* mvpMapPoints[i] != NULL && !mvbOutlier[i] && invzc >= 0 && projection inside bounds */
+    const float* proj_u; const float* proj_v;   /* CurrentFrame.mpCamera->project(Tcw * pMP->GetWorldPos()) */
+    const float* inv_z;                   /* 1 / x3Dc(2) */
+    const int* octave;                    /* LastFrame.mvKeys[i].octave */
+    const float* angle;                   /* LastFrame.mvKeysUn[i].angle */
+    const uint8_t* has_obs;               /* pMP->Observations() > 0 */
+    const uint8_t* desc;                  /* pMP->GetDescriptor(), N x 32 */
+} OrbmLastFrameView;
+
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBmatcher.cc:1950-2184).
+ * forward/backward = bForward/bBackward (:1973-1975, computed from the two poses by the caller).
+ * assigned[i] = index into LastFrame of the point written to CurrentFrame.mvpMapPoints[i]; -1 untouched;
+ * -2 = written and then reset to NULL by the rotation-consistency check. */
+int orbm_search_by_projection_frame(orbx_extractor* h, const OrbmFrameView* Cur, const OrbmLastFrameView* Last,
+                                    float th, int forward, int backward, int check_orientation,
+                                    int* assigned, int* nmatches);
+
+typedef struct OrbmKeyFrameView {         /* what SearchForTriangulation reads of a KeyFrame, include/KeyFrame.h */
+    int N;
+    const OrbxKeyPoint* keys_un;          /* mvKeysUn */
+    const uint8_t* desc;                  /* mDescriptors */
+    const float* u_right;                 /* mvuRight (NULL = all monocular) */
+    const uint8_t* has_map_point;         /* GetMapPoint(i) != NULL */
+    int fv_nodes;                         /* mFeatVec (DBoW2::FeatureVector = map<NodeId, vector<unsigned>>) as CSR: */
+    const uint32_t* fv_node_id;           /*   node ids, ascending */
+    const int* fv_start;                  /*   fv_nodes + 1 offsets into fv_feat */
+    const uint32_t* fv_feat;              /*   feature indices, in each node's insertion order */
+    int nlevels; const float* scale_factors; const float* level_sigma2;
+} OrbmKeyFrameView;
+
+/* ORBmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse) (src/ORBmatcher.cc:1045-1323),
+ * pinhole / no second camera.  F12 = K1^-T [t12]x R12 K2^-1 row-major and ep = the epipole, as the reference computes them
+ * (:1061-1063, Pinhole.cpp:186-192).  matches12[i] = idx2 matched to feature i of KF1, or -1. */
+int orbm_search_for_triangulation(orbx_extractor* h, const OrbmKeyFrameView* K1, const OrbmKeyFrameView* K2,
+                                  const float F12[9], const float ep[2], int only_stereo, int coarse,
+                                  int check_orientation, int* matches12, int* nmatches);
+
 const char* orbx_last_error(void);
 
 #ifdef __cplusplus

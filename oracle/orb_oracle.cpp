@@ -521,6 +521,262 @@ void orbo_prim_blur(const uint8_t* src, int w, int h, uint8_t* dst, int variant)
 void orbo_prim_border(const uint8_t* src, int w, int h, uint8_t* dst, int b) { orbp::make_border_reflect101(src, w, h, (size_t)w, dst, (size_t)(w + 2 * b), b, b, b, b); }
 int orbo_prim_round(double v) { return orbp::round_half_even(v); }
 
+// =====================================================================================================================
+// M3-M6: guided searches, restated sequentially on structure-of-arrays views (the reference's ORBmatcher.cc / Frame.cc
+// need Eigen, Sophus, DBoW2 and Boost and cannot be compiled here, so these restatements are NOT pinned against the
+// reference build — "parity unpinned" for M3-M6).  The views are those of include/orbx.h; geometry (projection,
+// fundamental matrix) enters as numbers computed by the caller, exactly as in the product ABI.
+// =====================================================================================================================
+struct OFrame {
+    int N; const Kp* keys; const uint8_t* desc; const float* u_right; const uint8_t* occupied;
+    float min_x, min_y, max_x, max_y, gw_inv, gh_inv, mbf; int nlevels; const float* scale;
+};
+struct OMapPoints {
+    int M; const uint8_t* in_view; const float* proj_x; const float* proj_y; const float* proj_xr; const int* scale_level;
+    const float* view_cos; const float* track_depth; const uint8_t* is_bad; const uint8_t* has_obs; const uint8_t* desc;
+};
+struct OLast {
+    int N; const uint8_t* valid; const float* proj_u; const float* proj_v; const float* inv_z; const int* octave; const float* angle;
+    const uint8_t* has_obs; const uint8_t* desc;
+};
+struct OKeyFrame {
+    int N; const Kp* keys; const uint8_t* desc; const float* u_right; const uint8_t* has_mp;
+    int fv_nodes; const uint32_t* fv_node_id; const int* fv_start; const uint32_t* fv_feat; int nlevels; const float* scale; const float* sigma2;
+};
+}  // extern "C"  (helpers below are C++)
+
+namespace {
+const int GRID_COLS = 64, GRID_ROWS = 48;   // include/Frame.h:44-45
+typedef std::vector<std::vector<std::vector<int>>> Grid;
+
+// Frame::AssignFeaturesToGrid + PosInGrid, src/Frame.cc:469-504, :962-978
+Grid build_grid(const OFrame& F) {
+    Grid g(GRID_COLS, std::vector<std::vector<int>>(GRID_ROWS));
+    for (int i = 0; i < F.N; i++) {
+        const int px = (int)round((F.keys[i].x - F.min_x) * F.gw_inv), py = (int)round((F.keys[i].y - F.min_y) * F.gh_inv);
+        if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) continue;
+        g[px][py].push_back(i);
+    }
+    return g;
+}
+// Frame::GetFeaturesInArea, src/Frame.cc:859-951
+std::vector<int> features_in_area(const OFrame& F, const Grid& g, float x, float y, float r, int minLevel, int maxLevel) {
+    std::vector<int> out;
+    const float factorX = r, factorY = r;
+    const int nMinCellX = std::max(0, (int)floor((x - F.min_x - factorX) * F.gw_inv));
+    if (nMinCellX >= GRID_COLS) return out;
+    const int nMaxCellX = std::min(GRID_COLS - 1, (int)ceil((x - F.min_x + factorX) * F.gw_inv));
+    if (nMaxCellX < 0) return out;
+    const int nMinCellY = std::max(0, (int)floor((y - F.min_y - factorY) * F.gh_inv));
+    if (nMinCellY >= GRID_ROWS) return out;
+    const int nMaxCellY = std::min(GRID_ROWS - 1, (int)ceil((y - F.min_y + factorY) * F.gh_inv));
+    if (nMaxCellY < 0) return out;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const std::vector<int>& cell = g[ix][iy];
+            for (int idx : cell) {
+                const Kp& k = F.keys[idx];
+                if (bCheckLevels) {
+                    if (k.octave < minLevel) continue;
+                    if (maxLevel >= 0 && k.octave > maxLevel) continue;
+                }
+                const float dx = k.x - x, dy = k.y - y;
+                if (fabs(dx) < factorX && fabs(dy) < factorY) out.push_back(idx);
+            }
+        }
+    return out;
+}
+void three_maxima(std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3) {   // src/ORBmatcher.cc:2335-2377
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = (int)histo[i].size();
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) ind3 = -1;
+}
+}  // namespace
+
+extern "C" {
+
+int orbo_get_features_in_area(const OFrame* F, float x, float y, float r, int minLevel, int maxLevel, int* out, int cap) {
+    Grid g = build_grid(*F);
+    std::vector<int> v = features_in_area(*F, g, x, y, r, minLevel, maxLevel);
+    for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = v[i];
+    return (int)v.size();
+}
+
+// ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th, bFarPoints, thFarPoints), src/ORBmatcher.cc:45-239 (Nleft == -1)
+int orbo_search_by_projection_mappoints(const OFrame* F, const OMapPoints* P, float th, int bFarPoints, float thFarPoints, float nnratio, int* assigned) {
+    const int TH_HIGH = 100;
+    Grid g = build_grid(*F);
+    std::vector<uint8_t> occ(F->N + 1, 0);
+    if (F->occupied) memcpy(occ.data(), F->occupied, F->N);
+    for (int i = 0; i < F->N; i++) assigned[i] = -1;
+    int nmatches = 0;
+    const bool bFactor = th != 1.0;
+    for (int iMP = 0; iMP < P->M; iMP++) {
+        if (!P->in_view[iMP]) continue;
+        if (bFarPoints && P->track_depth[iMP] > thFarPoints) continue;
+        if (P->is_bad[iMP]) continue;
+        const int nPredictedLevel = P->scale_level[iMP];
+        if (nPredictedLevel < 0 || nPredictedLevel >= F->nlevels) continue;
+        float r = P->view_cos[iMP] > 0.998 ? 2.5f : 4.0f;
+        if (bFactor) r *= th;
+        const std::vector<int> vIndices = features_in_area(*F, g, P->proj_x[iMP], P->proj_y[iMP], r * F->scale[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel);
+        if (vIndices.empty()) continue;
+        const uint8_t* MPdesc = P->desc + 32 * (size_t)iMP;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int idx : vIndices) {
+            if (occ[idx]) continue;
+            if (F->u_right && F->u_right[idx] > 0) {
+                const float er = fabs(P->proj_xr[iMP] - F->u_right[idx]);
+                if (er > r * F->scale[nPredictedLevel]) continue;
+            }
+            const int dist = descriptor_distance(MPdesc, F->desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = F->keys[idx].octave; bestIdx = idx; }
+            else if (dist < bestDist2) { bestLevel2 = F->keys[idx].octave; bestDist2 = dist; }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+                assigned[bestIdx] = iMP;
+                occ[bestIdx] = P->has_obs ? P->has_obs[iMP] : 1;
+                nmatches++;
+            }
+        }
+    }
+    return nmatches;
+}
+
+// ORBmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th, bMono), src/ORBmatcher.cc:1950-2184 (Nleft == -1)
+int orbo_search_by_projection_frame(const OFrame* C, const OLast* Lf, float th, int bForward, int bBackward, int checkOri, int* assigned) {
+    const int TH_HIGH = 100, HISTO_LENGTH = 30;
+    Grid g = build_grid(*C);
+    std::vector<uint8_t> occ(C->N + 1, 0);
+    if (C->occupied) memcpy(occ.data(), C->occupied, C->N);
+    for (int i = 0; i < C->N; i++) assigned[i] = -1;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0;
+    for (int i = 0; i < Lf->N; i++) {
+        if (!Lf->valid[i]) continue;
+        const float u = Lf->proj_u[i], v = Lf->proj_v[i], invzc = Lf->inv_z[i];
+        if (u < C->min_x || u > C->max_x) continue;
+        if (v < C->min_y || v > C->max_y) continue;
+        const int nLastOctave = Lf->octave[i];
+        if (nLastOctave < 0 || nLastOctave >= C->nlevels) continue;
+        const float radius = th * C->scale[nLastOctave];
+        std::vector<int> vIndices2;
+        if (bForward) vIndices2 = features_in_area(*C, g, u, v, radius, nLastOctave, -1);
+        else if (bBackward) vIndices2 = features_in_area(*C, g, u, v, radius, 0, nLastOctave);
+        else vIndices2 = features_in_area(*C, g, u, v, radius, nLastOctave - 1, nLastOctave + 1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* dMP = Lf->desc + 32 * (size_t)i;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int i2 : vIndices2) {
+            if (occ[i2]) continue;
+            if (C->u_right && C->u_right[i2] > 0) {
+                const float ur = u - C->mbf * invzc;
+                const float er = fabs(ur - C->u_right[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = descriptor_distance(dMP, C->desc + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            assigned[bestIdx2] = i;
+            occ[bestIdx2] = Lf->has_obs ? Lf->has_obs[i] : 1;
+            nmatches++;
+            if (checkOri) {
+                float rot = Lf->angle[i] - C->keys[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int idx : rotHist[i]) { assigned[idx] = -2; nmatches--; }
+    }
+    return nmatches;
+}
+
+// ORBmatcher::SearchForTriangulation, src/ORBmatcher.cc:1045-1323 (pinhole, no second camera) + Pinhole::epipolarConstrain
+int orbo_search_for_triangulation(const OKeyFrame* K1, const OKeyFrame* K2, const float* F12, const float* ep, int bOnlyStereo, int bCoarse,
+                                  int checkOri, int* vMatches12) {
+    const int TH_LOW = 50, HISTO_LENGTH = 30;
+    for (int i = 0; i < K1->N; i++) vMatches12[i] = -1;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0, a = 0, b = 0;
+    while (a < K1->fv_nodes && b < K2->fv_nodes) {
+        if (K1->fv_node_id[a] == K2->fv_node_id[b]) {
+            for (int i1 = K1->fv_start[a]; i1 < K1->fv_start[a + 1]; i1++) {
+                const int idx1 = (int)K1->fv_feat[i1];
+                if (K1->has_mp && K1->has_mp[idx1]) continue;
+                const bool bStereo1 = K1->u_right && K1->u_right[idx1] >= 0;
+                if (bOnlyStereo && !bStereo1) continue;
+                const Kp& kp1 = K1->keys[idx1];
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int i2 = K2->fv_start[b]; i2 < K2->fv_start[b + 1]; i2++) {
+                    const int idx2 = (int)K2->fv_feat[i2];
+                    if (K2->has_mp && K2->has_mp[idx2]) continue;
+                    const bool bStereo2 = K2->u_right && K2->u_right[idx2] >= 0;
+                    if (bOnlyStereo && !bStereo2) continue;
+                    const int dist = descriptor_distance(K1->desc + 32 * (size_t)idx1, K2->desc + 32 * (size_t)idx2);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    const Kp& kp2 = K2->keys[idx2];
+                    if (!bStereo1 && !bStereo2) {
+                        const float distex = ep[0] - kp2.x, distey = ep[1] - kp2.y;
+                        if (distex * distex + distey * distey < 100 * K2->scale[kp2.octave]) continue;
+                    }
+                    bool ok = bCoarse != 0;
+                    if (!ok) {
+                        const float ea = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+                        const float eb = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+                        const float ec = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+                        const float num = ea * kp2.x + eb * kp2.y + ec;
+                        const float den = ea * ea + eb * eb;
+                        if (den != 0) { const float dsqr = num * num / den; ok = dsqr < 3.84 * K2->sigma2[kp2.octave]; }
+                    }
+                    if (ok) { bestIdx2 = idx2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    vMatches12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (checkOri) {
+                        float rot = kp1.angle - K2->keys[bestIdx2].angle;
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)round(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        rotHist[bin].push_back(idx1);
+                    }
+                }
+            }
+            a++; b++;
+        } else if (K1->fv_node_id[a] < K2->fv_node_id[b]) { while (a < K1->fv_nodes && K1->fv_node_id[a] < K2->fv_node_id[b]) a++; }
+        else { while (b < K2->fv_nodes && K2->fv_node_id[b] < K1->fv_node_id[a]) b++; }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx1 : rotHist[i]) { vMatches12[idx1] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
 // glibc cosf/sinf, exposed so tests can pin the device-side model (csrc/glibc_sincosf_model.h).
 float orbo_cosf(float x) { return cosf(x); }
 float orbo_sinf(float x) { return sinf(x); }

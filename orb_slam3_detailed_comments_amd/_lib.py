@@ -28,6 +28,8 @@ SYMBOLS = [
     "orbx_device_alloc", "orbx_device_free", "orbx_device_upload", "orbx_host_alloc", "orbx_host_free", "orbx_profile_enable",
     "orbx_profile_get", "orbx_stage_name", "orbx_debug_candidates", "orbx_debug_level_keys",
     "orbm_hamming_matrix", "orbm_stereo_match", "orbm_stereo_fetch", "orbm_knn2", "orbm_knn2_fetch",
+    "orbm_get_features_in_area", "orbm_search_by_projection_mappoints", "orbm_search_by_projection_frame",
+    "orbm_search_for_triangulation",
     "orbx_last_error",
 ]
 
@@ -77,6 +79,10 @@ class OrbxLib:
         L.orbm_stereo_fetch.argtypes = [vp, i, vp, vp, i, vp]
         L.orbm_knn2.argtypes = [vp, i, vp, i, i]
         L.orbm_knn2_fetch.argtypes = [vp, i, vp, vp, vp, vp, vp, i]
+        L.orbm_get_features_in_area.argtypes = [vp, vp, f, f, f, i, i, vp, i]
+        L.orbm_search_by_projection_mappoints.argtypes = [vp, vp, vp, f, i, f, f, vp, ip]
+        L.orbm_search_by_projection_frame.argtypes = [vp, vp, vp, f, i, i, i, vp, ip]
+        L.orbm_search_for_triangulation.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp, ip]
         L.orbx_last_error.restype = C.c_char_p
 
     def check(self, rc):

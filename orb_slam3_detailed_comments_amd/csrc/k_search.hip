@@ -1,0 +1,206 @@
+// k_search.hip — candidate generation + Hamming evaluation for the guided searches of ORBmatcher:
+//   k_grid_build   Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:469-504, :962-978): 64x48 bucket grid as CSR,
+//                  items in insertion (= index) order inside a cell
+//   k_area_search  Frame::GetFeaturesInArea (src/Frame.cc:859-951) fused with the per-candidate part of
+//                  ORBmatcher::SearchByProjection (src/ORBmatcher.cc:45-239 and :1950-2184): one wave64 per query
+//                  (map point / last-frame point); emits, in GetFeaturesInArea order (cells ix-major, iy-minor, items in
+//                  insertion order), every candidate that passes the level / box / right-coordinate gates together with
+//                  its Hamming distance and octave.  The order-dependent acceptance loop ("skip keypoints that already
+//                  hold a MapPoint with observations", best / second-best / ratio, rotation histogram) is replayed on the
+//                  host over these lists (orbm_search.cpp), because an assignment made for one map point removes that
+//                  keypoint from the candidate set of every later one (a true sequential dependency).
+//   k_bow_search   inner loops of ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:1045-1323): one wave per
+//                  unmatched feature of KF1 against the features of KF2 in the same vocabulary node.
+#include "orbx_types.h"
+#include "orbx_block.h"
+
+namespace orbx {
+
+constexpr int kGridCols = 64, kGridRows = 48;   // FRAME_GRID_COLS / FRAME_GRID_ROWS, include/Frame.h:44-45
+
+// grid (1), 256 threads.  cell_of: scratch [N] ints.  cell_start: [64*48+1].  Cell id = ix*48 + iy.
+__global__ void __launch_bounds__(256) k_grid_build(const KeyPointRec* __restrict__ kps, int N, GridParams g,
+                                                    int* __restrict__ cell_of, int* __restrict__ cell_start,
+                                                    int* __restrict__ cell_items) {
+    __shared__ int s_hist[kGridCols * kGridRows];
+    __shared__ int s_chunk[256];
+    __shared__ unsigned long long s_scan[20];
+    const int tid = (int)threadIdx.x;
+    const int ncell = kGridCols * kGridRows;
+    for (int c = tid; c < ncell; c += 256) s_hist[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) {
+        const KeyPointRec k = kps[i];
+        const int px = (int)roundf(__fmul_rn(__fsub_rn(k.x, g.min_x), g.gw_inv));
+        const int py = (int)roundf(__fmul_rn(__fsub_rn(k.y, g.min_y), g.gh_inv));
+        int c = -1;
+        if (!(px < 0 || px >= kGridCols || py < 0 || py >= kGridRows)) { c = px * kGridRows + py; atomicAdd(&s_hist[c], 1); }
+        cell_of[i] = c;
+    }
+    __syncthreads();
+    // exclusive scan of the histogram -> cell_start; s_hist becomes the running cursor of each cell
+    int run = 0;
+    for (int c0 = 0; c0 < ncell; c0 += 256) {
+        const int c = c0 + tid;
+        const int v = s_hist[c];
+        unsigned long long tot;
+        const int ex = run + (int)block_excl_scan<unsigned long long>((unsigned long long)v, &tot, s_scan);
+        cell_start[c] = ex;
+        s_hist[c] = ex;
+        run += (int)tot;
+    }
+    if (tid == 0) cell_start[ncell] = run;
+    __syncthreads();
+    // stable placement, 256 keypoints at a time in index order
+    for (int i0 = 0; i0 < N; i0 += 256) {
+        const int i = i0 + tid;
+        const int c = i < N ? cell_of[i] : -1;
+        s_chunk[tid] = c;
+        __syncthreads();
+        int before = 0, after = 0, cur = 0;
+        if (c >= 0) {
+            for (int t = 0; t < 256; t++) { const int m = (s_chunk[t] == c); before += (t < tid) & m; after += (t > tid) & m; }
+            cur = s_hist[c];
+        }
+        __syncthreads();
+        if (c >= 0) {
+            cell_items[cur + before] = i;
+            if (after == 0) s_hist[c] = cur + before + 1;     // the last lane of this cell in the chunk advances the cursor
+        }
+        __syncthreads();
+    }
+}
+
+// level filter (with the reference's bCheckLevels quirk, :908), box test (:944) and right-coordinate gate
+// (ORBmatcher.cc:107-117 / :2043-2050) of one keypoint against one query
+__device__ __forceinline__ bool area_accept(const AreaQuery& A, const KeyPointRec& k, int idx, bool check_levels,
+                                            int gate_right, const float* __restrict__ u_right) {
+    if (check_levels) {
+        if (k.octave < A.min_level) return false;
+        if (A.max_level >= 0 && k.octave > A.max_level) return false;
+    }
+    if (!(fabsf(__fsub_rn(k.x, A.x)) < A.r && fabsf(__fsub_rn(k.y, A.y)) < A.r)) return false;
+    if (gate_right && A.gate) {
+        const float ur = u_right[idx];
+        if (ur > 0 && fabsf(__fsub_rn(A.ur, ur)) > A.r) return false;
+    }
+    return true;
+}
+
+// One wave per query.  grid (ceil(Q/4)), 256 threads.  Lane l of a chunk owns window cell l (cells enumerated ix-major,
+// iy-minor like the reference's loops): pass 0 counts, one atomicAdd reserves the query's span of the entry pool, pass 1
+// re-enumerates and writes each lane's candidates at its ordered offset (wave prefix sum).
+// entries: int2 per candidate {idx, dist | octave << 16}; q_start/q_count: CSR; pool_counter: running allocation.
+__global__ void __launch_bounds__(256) k_area_search(const AreaQuery* __restrict__ queries, const unsigned long long* __restrict__ qdesc, int Q,
+                                                     const KeyPointRec* __restrict__ kps, const float* __restrict__ u_right,
+                                                     const unsigned long long* __restrict__ fdesc, GridParams g,
+                                                     const int* __restrict__ cell_start, const int* __restrict__ cell_items,
+                                                     int gate_right, int* __restrict__ pool_counter, int pool_cap,
+                                                     int* __restrict__ q_start, int* __restrict__ q_count, int2* __restrict__ entries) {
+    const int lane = lane_id();
+    const int q = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (q >= Q) return;
+    const AreaQuery A = queries[q];
+    int cnt_total = 0, start = 0;
+    // window of grid cells, src/Frame.cc:877-903
+    const int nMinX = imax(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(A.x, g.min_x), A.r), g.gw_inv)));
+    const int nMaxX = imin(kGridCols - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(A.x, g.min_x), A.r), g.gw_inv)));
+    const int nMinY = imax(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(A.y, g.min_y), A.r), g.gh_inv)));
+    const int nMaxY = imin(kGridRows - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(A.y, g.min_y), A.r), g.gh_inv)));
+    const bool window_ok = A.active && !(nMinX >= kGridCols || nMaxX < 0 || nMinY >= kGridRows || nMaxY < 0) && nMaxX >= nMinX && nMaxY >= nMinY;
+    if (window_ok) {
+        const int ny = nMaxY - nMinY + 1, ncw = (nMaxX - nMinX + 1) * ny;
+        const bool check_levels = (A.min_level > 0) || (A.max_level >= 0);
+        const unsigned long long* dq = qdesc + 4 * (size_t)q;
+        const unsigned long long d0 = dq[0], d1 = dq[1], d2 = dq[2], d3 = dq[3];
+        for (int pass = 0; pass < 2; pass++) {
+            int base = 0;
+            for (int c0 = 0; c0 < ncw; c0 += 64) {
+                const int c = c0 + lane;
+                int s = 0, e = 0;
+                if (c < ncw) {
+                    const int ix = nMinX + c / ny, iy = nMinY + c % ny;
+                    s = cell_start[ix * kGridRows + iy]; e = cell_start[ix * kGridRows + iy + 1];
+                }
+                int cnt = 0;
+                for (int j = s; j < e; j++) {
+                    const int idx = cell_items[j];
+                    cnt += area_accept(A, kps[idx], idx, check_levels, gate_right, u_right) ? 1 : 0;
+                }
+                const int incl = wave_incl_scan(cnt);
+                if (pass == 1 && start >= 0) {
+                    int pos = start + base + incl - cnt;
+                    for (int j = s; j < e; j++) {
+                        const int idx = cell_items[j];
+                        const KeyPointRec k = kps[idx];
+                        if (!area_accept(A, k, idx, check_levels, gate_right, u_right)) continue;
+                        const unsigned long long* df = fdesc + 4 * (size_t)idx;
+                        const int dist = __popcll(d0 ^ df[0]) + __popcll(d1 ^ df[1]) + __popcll(d2 ^ df[2]) + __popcll(d3 ^ df[3]);
+                        int2 ent; ent.x = idx; ent.y = dist | (k.octave << 16);
+                        entries[pos++] = ent;
+                    }
+                }
+                base += __shfl(incl, 63);
+            }
+            if (pass == 0) {
+                cnt_total = base;
+                if (cnt_total == 0) break;
+                int off = 0;
+                if (lane == 0) off = atomicAdd(pool_counter, cnt_total);
+                off = __shfl(off, 0);
+                start = (off + cnt_total <= pool_cap) ? off : -1;   // -1: pool overflow, the host retries with a bigger pool
+            }
+        }
+    }
+    if (lane == 0) { q_start[q] = start < 0 ? 0 : start; q_count[q] = cnt_total; }
+}
+
+// One wave per work item (an unmatched feature idx1 of KF1 and the feature list of KF2 in the same node).
+// best2[item] = chosen idx2 or -1.   src/ORBmatcher.cc:1117-1254
+__global__ void __launch_bounds__(256) k_bow_search(const BowItem* __restrict__ items, int nitems,
+                                                    const KeyPointRec* __restrict__ kps1, const unsigned long long* __restrict__ desc1,
+                                                    const float* __restrict__ ur1,
+                                                    const KeyPointRec* __restrict__ kps2, const unsigned long long* __restrict__ desc2,
+                                                    const float* __restrict__ ur2, const uint8_t* __restrict__ has_mp2,
+                                                    const int* __restrict__ feat2, BowParams P, int* __restrict__ best2) {
+    const int lane = lane_id();
+    const int it = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (it >= nitems) return;
+    const BowItem I = items[it];
+    const KeyPointRec k1 = kps1[I.idx1];
+    const bool stereo1 = ur1[I.idx1] >= 0;
+    const unsigned long long* da = desc1 + 4 * (size_t)I.idx1;
+    const unsigned long long a0 = da[0], a1 = da[1], a2 = da[2], a3 = da[3];
+    // epipolar line of kp1 in image 2 (Pinhole::epipolarConstrain, src/CameraModels/Pinhole.cpp:186-217)
+    const float la = __fadd_rn(__fadd_rn(__fmul_rn(k1.x, P.F12[0]), __fmul_rn(k1.y, P.F12[3])), P.F12[6]);
+    const float lb = __fadd_rn(__fadd_rn(__fmul_rn(k1.x, P.F12[1]), __fmul_rn(k1.y, P.F12[4])), P.F12[7]);
+    const float lc = __fadd_rn(__fadd_rn(__fmul_rn(k1.x, P.F12[2]), __fmul_rn(k1.y, P.F12[5])), P.F12[8]);
+    const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+    unsigned best = 0xFFFFFFFFu;   // dist << 16 | (0xFFFF - position): the LAST candidate with the smallest distance wins (:1178 '>' test)
+    for (int j = lane; j < I.cnt2; j += 64) {
+        const int idx2 = feat2[I.start2 + j];
+        if (has_mp2[idx2]) continue;
+        const bool stereo2 = ur2[idx2] >= 0;
+        if (P.only_stereo && !stereo2) continue;
+        const unsigned long long* db = desc2 + 4 * (size_t)idx2;
+        const int dist = __popcll(a0 ^ db[0]) + __popcll(a1 ^ db[1]) + __popcll(a2 ^ db[2]) + __popcll(a3 ^ db[3]);
+        if (dist > P.th_low) continue;
+        const KeyPointRec k2 = kps2[idx2];
+        if (!stereo1 && !stereo2) {
+            const float dex = __fsub_rn(P.ep[0], k2.x), dey = __fsub_rn(P.ep[1], k2.y);
+            if (__fadd_rn(__fmul_rn(dex, dex), __fmul_rn(dey, dey)) < __fmul_rn(100.f, P.scale2[k2.octave])) continue;
+        }
+        if (!P.coarse) {
+            const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, k2.x), __fmul_rn(lb, k2.y)), lc);
+            if (den == 0) continue;
+            const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+            if (!((double)dsqr < 3.84 * (double)P.sigma2_2[k2.octave])) continue;
+        }
+        const unsigned key = ((unsigned)dist << 16) | (unsigned)(0xFFFF - j);
+        best = key < best ? key : best;
+    }
+    best = wave_min_u32(best);
+    if (lane == 0) best2[it] = best == 0xFFFFFFFFu ? -1 : feat2[I.start2 + (0xFFFF - (int)(best & 0xFFFF))];
+}
+
+}  // namespace orbx

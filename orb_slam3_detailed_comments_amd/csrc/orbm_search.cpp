@@ -1,0 +1,305 @@
+// orbm_search.cpp — host side of the guided searches (include/orbx.h "Guided searches"): uploads the SoA views,
+// launches k_grid_build / k_area_search / k_bow_search, and replays the reference's *order-dependent* acceptance loops
+// over the device-computed candidate lists:
+//   SearchByProjection(Frame, MapPoints)   src/ORBmatcher.cc:45-239
+//   SearchByProjection(Frame, Frame)       src/ORBmatcher.cc:1950-2184 (+ ComputeThreeMaxima :2335-2377)
+//   SearchForTriangulation                 src/ORBmatcher.cc:1045-1323
+// All Hamming distances and all window / level / gate / epipolar tests run on the GPU; the replay below only compares
+// precomputed integers in the reference's sequence (an assignment for one map point changes the candidate set of the next).
+#include "orbx_internal.h"
+
+using namespace orbx;
+
+namespace {
+
+const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;   // src/ORBmatcher.cc:35-37
+
+struct DeviceFrame {
+    const KeyPointRec* kps; const unsigned long long* desc; const float* ur; const int* cell_start; const int* cell_items;
+    GridParams g;
+};
+
+// scratch slots in orbx_extractor::d_sr / d_si
+enum { SR_KPS = 0, SR_DESC, SR_UR, SR_QUERY, SR_QDESC, SR_ENTRIES, SR_KPS2, SR_DESC2, SR_UR2, SR_HASMP2, SR_ITEMS, SR_SPARE };
+enum { SI_CELLOF = 0, SI_CELLSTART, SI_CELLITEMS, SI_QSTART, SI_QCOUNT, SI_COUNTER, SI_FEAT2, SI_BEST };
+
+int upload(orbx_extractor* h, int slot, const void* src, size_t bytes) {
+    if (h->d_sr[slot].ensure(bytes + 16)) return -1;
+    return rt::copy_h2d(h->d_sr[slot].p, src, bytes, h->s0);
+}
+
+int upload_frame(orbx_extractor* h, const OrbmFrameView* F, DeviceFrame* D) {
+    if (!F || F->N < 0 || (F->N > 0 && (!F->keys_un || !F->desc))) return fail(ORBX_E_ARG, "bad frame view");
+    if (F->N >= 65535) return fail(ORBX_E_ARG, "too many keypoints");
+    const int N = F->N;
+    std::vector<float> ur(N > 0 ? N : 1, -1.0f);
+    if (F->u_right) memcpy(ur.data(), F->u_right, sizeof(float) * N);
+    int e = upload(h, SR_KPS, F->keys_un, sizeof(KeyPointRec) * (size_t)N) | upload(h, SR_DESC, F->desc, 32 * (size_t)N) |
+            upload(h, SR_UR, ur.data(), sizeof(float) * (size_t)(N > 0 ? N : 1));
+    e |= h->d_si[SI_CELLOF].ensure(N + 1) | h->d_si[SI_CELLSTART].ensure(64 * 48 + 2) | h->d_si[SI_CELLITEMS].ensure(N + 1);
+    if (e) return fail(ORBX_E_DEVICE, "upload/allocation failed");
+    D->kps = (const KeyPointRec*)h->d_sr[SR_KPS].p; D->desc = (const unsigned long long*)h->d_sr[SR_DESC].p; D->ur = (const float*)h->d_sr[SR_UR].p;
+    D->g.min_x = F->min_x; D->g.min_y = F->min_y; D->g.gw_inv = F->grid_w_inv; D->g.gh_inv = F->grid_h_inv;
+    dim3 one(1, 1, 1), blk(256, 1, 1);
+    ORBX_LAUNCH(k_grid_build, one, blk, 0, h->s0, D->kps, N, D->g, h->d_si[SI_CELLOF].p, h->d_si[SI_CELLSTART].p, h->d_si[SI_CELLITEMS].p);
+    D->cell_start = h->d_si[SI_CELLSTART].p; D->cell_items = h->d_si[SI_CELLITEMS].p;
+    return ORBX_OK;
+}
+
+struct Csr { std::vector<int> start, count; std::vector<int> ent; };   // ent: 2 ints per candidate {idx, dist | octave << 16}
+
+// runs k_area_search for Q queries; grows the entry pool and retries once if it overflowed
+int run_area_search(orbx_extractor* h, const DeviceFrame& D, const std::vector<AreaQuery>& qs, const uint8_t* qdesc, Csr* out) {
+    const int Q = (int)qs.size();
+    out->start.assign(Q, 0); out->count.assign(Q, 0); out->ent.clear();
+    if (Q == 0) return ORBX_OK;
+    int e = upload(h, SR_QUERY, qs.data(), sizeof(AreaQuery) * (size_t)Q) | upload(h, SR_QDESC, qdesc, 32 * (size_t)Q);
+    e |= h->d_si[SI_QSTART].ensure(Q) | h->d_si[SI_QCOUNT].ensure(Q) | h->d_si[SI_COUNTER].ensure(4);
+    if (e) return fail(ORBX_E_DEVICE, "upload/allocation failed");
+    size_t pool = std::max<size_t>(h->d_sr[SR_ENTRIES].n / 8, (size_t)Q * 48 + 1024);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (h->d_sr[SR_ENTRIES].ensure(pool * 8 + 16)) return fail(ORBX_E_DEVICE, "entry pool allocation failed");
+        rt::memset_async(h->d_si[SI_COUNTER].p, 0, sizeof(int) * 4, h->s0);
+        dim3 grid((Q + 3) / 4, 1, 1), blk(256, 1, 1);
+        ORBX_LAUNCH(k_area_search, grid, blk, 0, h->s0, (const AreaQuery*)h->d_sr[SR_QUERY].p, (const unsigned long long*)h->d_sr[SR_QDESC].p, Q,
+                    D.kps, D.ur, D.desc, D.g, D.cell_start, D.cell_items, 1, h->d_si[SI_COUNTER].p, (int)pool,
+                    h->d_si[SI_QSTART].p, h->d_si[SI_QCOUNT].p, (int2*)h->d_sr[SR_ENTRIES].p);
+        int total = 0;
+        rt::copy_d2h(&total, h->d_si[SI_COUNTER].p, sizeof(int), h->s0);
+        rt::copy_d2h(out->start.data(), h->d_si[SI_QSTART].p, sizeof(int) * Q, h->s0);
+        rt::copy_d2h(out->count.data(), h->d_si[SI_QCOUNT].p, sizeof(int) * Q, h->s0);
+        if (rt::stream_sync(h->s0) || rt::check_launch()) return fail(ORBX_E_DEVICE, "area search failed: %s", rt::last_error());
+        if ((size_t)total <= pool) {
+            out->ent.resize(2 * (size_t)total + 2);
+            if (total > 0) { rt::copy_d2h(out->ent.data(), h->d_sr[SR_ENTRIES].p, 8 * (size_t)total, h->s0); rt::stream_sync(h->s0); }
+            return ORBX_OK;
+        }
+        pool = (size_t)total + 1024;
+    }
+    return fail(ORBX_E_INTERNAL, "entry pool overflow after retry");
+}
+
+// ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:2335-2377
+void three_maxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = (int)histo[i].size();
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+int rot_bin(float a1, float a2) {    // :2118-2123; the 1/HISTO_LENGTH factor is the reference's (kept on purpose)
+    const float factor = 1.0f / HISTO_LENGTH;
+    float rot = a1 - a2;
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)round(rot * factor);
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+}  // namespace
+
+extern "C" {
+
+int orbm_get_features_in_area(orbx_extractor* h, const OrbmFrameView* F, float x, float y, float r, int min_level, int max_level, int* indices, int cap) {
+    if (!h || !indices) return fail(ORBX_E_ARG, "null");
+    rt::set_device(h->device);
+    DeviceFrame D;
+    int rc = upload_frame(h, F, &D); if (rc) return rc;
+    std::vector<AreaQuery> qs(1);
+    qs[0].x = x; qs[0].y = y; qs[0].r = r; qs[0].ur = 0; qs[0].min_level = min_level; qs[0].max_level = max_level; qs[0].active = 1; qs[0].gate = 0;
+    uint8_t zero[32] = {0};
+    Csr c;
+    rc = run_area_search(h, D, qs, zero, &c); if (rc) return rc;
+    for (int k = 0; k < c.count[0] && k < cap; k++) indices[k] = c.ent[2 * (size_t)(c.start[0] + k)];
+    return c.count[0];
+}
+
+int orbm_search_by_projection_mappoints(orbx_extractor* h, const OrbmFrameView* F, const OrbmMapPointView* P, float th, int far_points,
+                                        float th_far, float nnratio, int* assigned, int* nmatches_out) {
+    if (!h || !F || !P || !assigned) return fail(ORBX_E_ARG, "null");
+    rt::set_device(h->device);
+    DeviceFrame D;
+    int rc = upload_frame(h, F, &D); if (rc) return rc;
+    const int M = P->M, N = F->N;
+    const bool bFactor = th != 1.0;
+    std::vector<AreaQuery> qs(M);
+    for (int i = 0; i < M; i++) {
+        AreaQuery& q = qs[i]; memset(&q, 0, sizeof q);
+        // :53-60 skip tests; (the right-camera branch :170-236 needs Nleft != -1 and is not part of this path)
+        if (!P->in_view[i]) continue;
+        if (far_points && P->track_depth[i] > th_far) continue;
+        if (P->is_bad[i]) continue;
+        const int lvl = P->scale_level[i];
+        if (lvl < 0 || lvl >= F->nlevels) continue;
+        float r = P->view_cos[i] > 0.998 ? 2.5f : 4.0f;                 // RadiusByViewingCos, :242-249
+        if (bFactor) r *= th;
+        q.x = P->proj_x[i]; q.y = P->proj_y[i]; q.r = r * F->scale_factors[lvl]; q.ur = P->proj_xr[i];
+        q.min_level = lvl - 1; q.max_level = lvl; q.active = 1; q.gate = 1;
+    }
+    Csr c;
+    rc = run_area_search(h, D, qs, P->desc, &c); if (rc) return rc;
+    // ---- sequential replay of :62-166 ----
+    std::vector<uint8_t> occ(N > 0 ? N : 1, 0);
+    if (F->occupied) memcpy(occ.data(), F->occupied, N);
+    for (int i = 0; i < N; i++) assigned[i] = -1;
+    int nmatches = 0;
+    for (int i = 0; i < M; i++) {
+        if (!qs[i].active || c.count[i] == 0) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int k = 0; k < c.count[i]; k++) {
+            const int idx = c.ent[2 * (size_t)(c.start[i] + k)], dl = c.ent[2 * (size_t)(c.start[i] + k) + 1];
+            if (occ[idx]) continue;
+            const int dist = dl & 0xFFFF, level = dl >> 16;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = level; bestIdx = idx; }
+            else if (dist < bestDist2) { bestLevel2 = level; bestDist2 = dist; }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+                assigned[bestIdx] = i;
+                occ[bestIdx] = P->has_obs ? P->has_obs[i] : 1;
+                nmatches++;
+            }
+        }
+    }
+    if (nmatches_out) *nmatches_out = nmatches;
+    return ORBX_OK;
+}
+
+int orbm_search_by_projection_frame(orbx_extractor* h, const OrbmFrameView* Cur, const OrbmLastFrameView* Last, float th, int forward, int backward,
+                                    int check_ori, int* assigned, int* nmatches_out) {
+    if (!h || !Cur || !Last || !assigned) return fail(ORBX_E_ARG, "null");
+    rt::set_device(h->device);
+    DeviceFrame D;
+    int rc = upload_frame(h, Cur, &D); if (rc) return rc;
+    const int NL = Last->N, N = Cur->N;
+    std::vector<AreaQuery> qs(NL);
+    for (int i = 0; i < NL; i++) {
+        AreaQuery& q = qs[i]; memset(&q, 0, sizeof q);
+        if (!Last->valid[i]) continue;
+        const float u = Last->proj_u[i], v = Last->proj_v[i];
+        if (u < Cur->min_x || u > Cur->max_x) continue;                  // :2003-2006
+        if (v < Cur->min_y || v > Cur->max_y) continue;
+        const int oct = Last->octave[i];
+        if (oct < 0 || oct >= Cur->nlevels) continue;
+        q.x = u; q.y = v; q.r = th * Cur->scale_factors[oct];            // :2012
+        q.ur = u - Cur->mbf * Last->inv_z[i];                            // :2045
+        if (forward) { q.min_level = oct; q.max_level = -1; }            // :2018-2023
+        else if (backward) { q.min_level = 0; q.max_level = oct; }
+        else { q.min_level = oct - 1; q.max_level = oct + 1; }
+        q.active = 1; q.gate = 1;
+    }
+    Csr c;
+    rc = run_area_search(h, D, qs, Last->desc, &c); if (rc) return rc;
+    std::vector<uint8_t> occ(N > 0 ? N : 1, 0);
+    if (Cur->occupied) memcpy(occ.data(), Cur->occupied, N);
+    for (int i = 0; i < N; i++) assigned[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int nmatches = 0;
+    for (int i = 0; i < NL; i++) {
+        if (!qs[i].active || c.count[i] == 0) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int k = 0; k < c.count[i]; k++) {
+            const int i2 = c.ent[2 * (size_t)(c.start[i] + k)], dist = c.ent[2 * (size_t)(c.start[i] + k) + 1] & 0xFFFF;
+            if (occ[i2]) continue;
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            assigned[bestIdx2] = i;
+            occ[bestIdx2] = Last->has_obs ? Last->has_obs[i] : 1;
+            nmatches++;
+            if (check_ori) rotHist[rot_bin(Last->angle[i], Cur->keys_un[bestIdx2].angle)].push_back(bestIdx2);
+        }
+    }
+    if (check_ori) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int idx : rotHist[i]) { assigned[idx] = -2; nmatches--; }
+    }
+    if (nmatches_out) *nmatches_out = nmatches;
+    return ORBX_OK;
+}
+
+int orbm_search_for_triangulation(orbx_extractor* h, const OrbmKeyFrameView* K1, const OrbmKeyFrameView* K2, const float F12[9], const float ep[2],
+                                  int only_stereo, int coarse, int check_ori, int* matches12, int* nmatches_out) {
+    if (!h || !K1 || !K2 || !F12 || !ep || !matches12) return fail(ORBX_E_ARG, "null");
+    if (K1->N >= 65535 || K2->N >= 65535 || K2->nlevels > kMaxLevels) return fail(ORBX_E_ARG, "keyframe too large");
+    rt::set_device(h->device);
+    const int N1 = K1->N, N2 = K2->N;
+    for (int i = 0; i < N1; i++) matches12[i] = -1;
+    // merge-join of the two feature vectors by node id (:1105-1286); one work item per unmatched feature of KF1
+    std::vector<BowItem> items;
+    int a = 0, b = 0;
+    while (a < K1->fv_nodes && b < K2->fv_nodes) {
+        const uint32_t na = K1->fv_node_id[a], nb = K2->fv_node_id[b];
+        if (na == nb) {
+            for (int k = K1->fv_start[a]; k < K1->fv_start[a + 1]; k++) {
+                const int idx1 = (int)K1->fv_feat[k];
+                if (K1->has_map_point && K1->has_map_point[idx1]) continue;
+                const bool stereo1 = K1->u_right && K1->u_right[idx1] >= 0;
+                if (only_stereo && !stereo1) continue;
+                BowItem it; it.idx1 = idx1; it.start2 = K2->fv_start[b]; it.cnt2 = K2->fv_start[b + 1] - K2->fv_start[b];
+                if (it.cnt2 > 0xFFFF) return fail(ORBX_E_ARG, "vocabulary node with more than 65535 features");
+                items.push_back(it);
+            }
+            a++; b++;
+        } else if (na < nb) { while (a < K1->fv_nodes && K1->fv_node_id[a] < nb) a++; }
+        else { while (b < K2->fv_nodes && K2->fv_node_id[b] < na) b++; }
+    }
+    int nmatches = 0;
+    if (!items.empty()) {
+        std::vector<float> ur1(N1 > 0 ? N1 : 1, -1.0f), ur2(N2 > 0 ? N2 : 1, -1.0f);
+        if (K1->u_right) memcpy(ur1.data(), K1->u_right, sizeof(float) * N1);
+        if (K2->u_right) memcpy(ur2.data(), K2->u_right, sizeof(float) * N2);
+        std::vector<uint8_t> mp2(N2 > 0 ? N2 : 1, 0);
+        if (K2->has_map_point) memcpy(mp2.data(), K2->has_map_point, N2);
+        const int nfeat2 = K2->fv_start[K2->fv_nodes];
+        int e = upload(h, SR_KPS, K1->keys_un, sizeof(KeyPointRec) * (size_t)N1) | upload(h, SR_DESC, K1->desc, 32 * (size_t)N1) |
+                upload(h, SR_UR, ur1.data(), sizeof(float) * ur1.size()) | upload(h, SR_KPS2, K2->keys_un, sizeof(KeyPointRec) * (size_t)N2) |
+                upload(h, SR_DESC2, K2->desc, 32 * (size_t)N2) | upload(h, SR_UR2, ur2.data(), sizeof(float) * ur2.size()) |
+                upload(h, SR_HASMP2, mp2.data(), mp2.size()) | upload(h, SR_ITEMS, items.data(), sizeof(BowItem) * items.size());
+        e |= h->d_si[SI_FEAT2].ensure(nfeat2 + 1) | h->d_si[SI_BEST].ensure(items.size());
+        if (e) return fail(ORBX_E_DEVICE, "upload/allocation failed");
+        rt::copy_h2d(h->d_si[SI_FEAT2].p, K2->fv_feat, sizeof(int) * (size_t)nfeat2, h->s0);
+        BowParams P; memset(&P, 0, sizeof P);
+        for (int i = 0; i < 9; i++) P.F12[i] = F12[i];
+        P.ep[0] = ep[0]; P.ep[1] = ep[1];
+        for (int l = 0; l < K2->nlevels; l++) { P.scale2[l] = K2->scale_factors[l]; P.sigma2_2[l] = K2->level_sigma2[l]; }
+        P.only_stereo = only_stereo; P.coarse = coarse; P.th_low = TH_LOW;
+        dim3 grid(((int)items.size() + 3) / 4, 1, 1), blk(256, 1, 1);
+        ORBX_LAUNCH(k_bow_search, grid, blk, 0, h->s0, (const BowItem*)h->d_sr[SR_ITEMS].p, (int)items.size(),
+                    (const KeyPointRec*)h->d_sr[SR_KPS].p, (const unsigned long long*)h->d_sr[SR_DESC].p, (const float*)h->d_sr[SR_UR].p,
+                    (const KeyPointRec*)h->d_sr[SR_KPS2].p, (const unsigned long long*)h->d_sr[SR_DESC2].p, (const float*)h->d_sr[SR_UR2].p,
+                    (const uint8_t*)h->d_sr[SR_HASMP2].p, (const int*)h->d_si[SI_FEAT2].p, P, h->d_si[SI_BEST].p);
+        std::vector<int> best(items.size());
+        if (rt::copy_d2h(best.data(), h->d_si[SI_BEST].p, sizeof(int) * items.size(), h->s0) || rt::stream_sync(h->s0) || rt::check_launch())
+            return fail(ORBX_E_DEVICE, "bow search failed: %s", rt::last_error());
+        std::vector<int> rotHist[HISTO_LENGTH];
+        for (size_t k = 0; k < items.size(); k++) {
+            if (best[k] < 0) continue;
+            const int idx1 = items[k].idx1;
+            matches12[idx1] = best[k];
+            nmatches++;
+            if (check_ori) rotHist[rot_bin(K1->keys_un[idx1].angle, K2->keys_un[best[k]].angle)].push_back(idx1);
+        }
+        if (check_ori) {
+            int ind1 = -1, ind2 = -1, ind3 = -1;
+            three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+            for (int i = 0; i < HISTO_LENGTH; i++) {
+                if (i == ind1 || i == ind2 || i == ind3) continue;
+                for (int idx1 : rotHist[i]) { matches12[idx1] = -1; nmatches--; }
+            }
+        }
+    }
+    if (nmatches_out) *nmatches_out = nmatches;
+    return ORBX_OK;
+}
+
+}  // extern "C"

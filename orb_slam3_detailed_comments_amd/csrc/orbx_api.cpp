@@ -2,88 +2,23 @@
 // src/ORBextractor.cc:468-571), per-resolution geometry (pyramid sizes :1691-1692, FAST cell grid
 // :1069-1129, resize coefficients of cv::resize), device memory, stream orchestration and the C ABI of
 // include/orbx.h.  Compiled by hipcc for gfx950 (product) or by g++ against tests/emu (tests only).
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdint>
-#include <cstring>
 #include <mutex>
-#include <string>
-#include <vector>
-#include "../../include/orbx.h"
-#include "orbx_kernels.h"
-#include "orbx_rt.h"
+#include "orbx_internal.h"
 
 using namespace orbx;
 
-namespace {
-
-thread_local std::string g_err;
+namespace orbx {
+static thread_local std::string g_err;
 int fail(int code, const char* fmt, ...) {
     char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
     g_err = buf; return code;
 }
+const char* last_error_string() { return g_err.c_str(); }
+}  // namespace orbx
 
-inline int round_half_even_f(float v) { return (int)lrintf(v); }    // cvRound under the default FP mode
-inline int round_half_even_d(double v) { return (int)lrint(v); }
-inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-enum Stage { ST_IMPORT = 0, ST_PYRAMID, ST_FAST, ST_QUADTREE, ST_BLUR, ST_LAYOUT, ST_DESCRIBE, ST_MATCH };
+namespace {
 const char* kStageNames[ORBX_NSTAGES] = {"import", "pyramid", "fast_cells", "quadtree", "blur", "layout", "orient_brief", "match"};
-
-template <typename T> struct DevBuf {
-    T* p = nullptr; size_t n = 0;
-    int ensure(size_t count) {
-        if (count <= n && p) return 0;
-        rt::dfree(p); p = (T*)rt::dmalloc(count * sizeof(T)); n = p ? count : 0;
-        return p ? 0 : -1;
-    }
-    void release() { rt::dfree(p); p = nullptr; n = 0; }
-};
-template <typename T> struct HostBuf {
-    T* p = nullptr; size_t n = 0;
-    int ensure(size_t count) {
-        if (count <= n && p) return 0;
-        rt::hfree(p); p = (T*)rt::hmalloc(count * sizeof(T)); n = p ? count : 0;
-        return p ? 0 : -1;
-    }
-    void release() { rt::hfree(p); p = nullptr; n = 0; }
-};
-
-}  // namespace
-
-struct orbx_extractor {
-    // ---- reference constructor state (src/ORBextractor.cc:468-571) ----
-    int nfeatures = 0, nlevels = 0, iniTh = 0, minTh = 0, device = 0, gauss_variant = 0;
-    double scaleFactor = 1.0;   // the reference keeps the float argument in a double member (include/ORBextractor.h:96)
-    float scale[kMaxLevels], inv_scale[kMaxLevels], sigma2[kMaxLevels], inv_sigma2[kMaxLevels];
-    int quota[kMaxLevels];
-    UmaxTab umax;
-    // ---- geometry for the configured resolution ----
-    int W = 0, H = 0, maxB = 0;
-    LevelInfo lv[kMaxLevels];
-    std::vector<CellInfo> cells;
-    std::vector<ResizeTap> xtab, ytab;
-    size_t pyr_stride = 0, cand_stride = 0;
-    int ncells = 0, kp_total_cap = 0, node_cap = 0, fast_tile_bytes = 0, fast_inner_bytes = 0;
-    // ---- device state ----
-    DevBuf<LevelInfo> d_lv; DevBuf<CellInfo> d_cells; DevBuf<ResizeTap> d_xtab, d_ytab;
-    DevBuf<uint8_t> d_pyr, d_blur, d_stage;
-    DevBuf<uint32_t> d_slots, d_candA, d_candB, d_lvl_keys;
-    DevBuf<int> d_cell_count, d_lvl_count, d_final_idx, d_nm, d_status;
-    DevBuf<KeyPointRec> d_kps; DevBuf<unsigned long long> d_desc;
-    DevBuf<float> d_uRight, d_depth; DevBuf<int> d_sad, d_nmatch;
-    DevBuf<int> d_knn; DevBuf<uint8_t> d_ratio;
-    DevBuf<unsigned long long> d_hamA, d_hamB; DevBuf<int> d_hamOut;
-    HostBuf<uint8_t> h_stage;
-    HostBuf<int> h_nm;
-    rt::stream_t s0 = 0, s1 = 0;
-    rt::event_t ev_fork = 0, ev_join = 0, ev_done = 0;
-    rt::event_t ev_stage[ORBX_NSTAGES][2];
-    bool profile = false, serial = false, have_streams = false;
-    int lastB = 0;
-    float stage_ms[ORBX_NSTAGES];
-};
+}
 
 namespace {
 
@@ -326,7 +261,7 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int strid
 
 extern "C" {
 
-const char* orbx_last_error(void) { return g_err.c_str(); }
+const char* orbx_last_error(void) { return orbx::last_error_string(); }
 const char* orbx_stage_name(int i) { return (i >= 0 && i < ORBX_NSTAGES) ? kStageNames[i] : ""; }
 int orbx_device_count(void) { return rt::device_count(); }
 
@@ -362,6 +297,8 @@ void orbx_destroy(orbx_extractor* h) {
     h->d_final_idx.release(); h->d_nm.release(); h->d_status.release(); h->d_kps.release(); h->d_desc.release();
     h->d_uRight.release(); h->d_depth.release(); h->d_sad.release(); h->d_nmatch.release(); h->d_knn.release(); h->d_ratio.release();
     h->d_hamA.release(); h->d_hamB.release(); h->d_hamOut.release(); h->h_stage.release(); h->h_nm.release();
+    for (auto& x : h->d_sr) x.release();
+    for (auto& x : h->d_si) x.release();
     delete h;
 }
 

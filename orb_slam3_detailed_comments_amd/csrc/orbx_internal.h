@@ -1,0 +1,80 @@
+// orbx_internal.h — host-side internals shared by orbx_api.cpp (extractor + stereo) and orbm_search.cpp
+// (projection / BoW searches): error reporting, RAII-less device/pinned buffers, the handle struct.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/orbx.h"
+#include "orbx_kernels.h"
+#include "orbx_rt.h"
+
+namespace orbx {
+
+int fail(int code, const char* fmt, ...);
+
+inline int round_half_even_f(float v) { return (int)lrintf(v); }    // cvRound under the default FP mode
+inline int round_half_even_d(double v) { return (int)lrint(v); }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+enum Stage { ST_IMPORT = 0, ST_PYRAMID, ST_FAST, ST_QUADTREE, ST_BLUR, ST_LAYOUT, ST_DESCRIBE, ST_MATCH };
+
+template <typename T> struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    int ensure(size_t count) {
+        if (count <= n && p) return 0;
+        rt::dfree(p); p = (T*)rt::dmalloc(count * sizeof(T)); n = p ? count : 0;
+        return p ? 0 : -1;
+    }
+    void release() { rt::dfree(p); p = nullptr; n = 0; }
+};
+template <typename T> struct HostBuf {
+    T* p = nullptr; size_t n = 0;
+    int ensure(size_t count) {
+        if (count <= n && p) return 0;
+        rt::hfree(p); p = (T*)rt::hmalloc(count * sizeof(T)); n = p ? count : 0;
+        return p ? 0 : -1;
+    }
+    void release() { rt::hfree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace orbx
+
+struct orbx_extractor {
+    // ---- reference constructor state (src/ORBextractor.cc:468-571) ----
+    int nfeatures = 0, nlevels = 0, iniTh = 0, minTh = 0, device = 0, gauss_variant = 0;
+    double scaleFactor = 1.0;   // the reference keeps the float argument in a double member (include/ORBextractor.h:96)
+    float scale[orbx::kMaxLevels], inv_scale[orbx::kMaxLevels], sigma2[orbx::kMaxLevels], inv_sigma2[orbx::kMaxLevels];
+    int quota[orbx::kMaxLevels];
+    orbx::UmaxTab umax;
+    // ---- geometry for the configured resolution ----
+    int W = 0, H = 0, maxB = 0;
+    orbx::LevelInfo lv[orbx::kMaxLevels];
+    std::vector<orbx::CellInfo> cells;
+    std::vector<orbx::ResizeTap> xtab, ytab;
+    size_t pyr_stride = 0, cand_stride = 0;
+    int ncells = 0, kp_total_cap = 0, node_cap = 0, fast_tile_bytes = 0, fast_inner_bytes = 0;
+    // ---- device state ----
+    orbx::DevBuf<orbx::LevelInfo> d_lv; orbx::DevBuf<orbx::CellInfo> d_cells; orbx::DevBuf<orbx::ResizeTap> d_xtab, d_ytab;
+    orbx::DevBuf<uint8_t> d_pyr, d_blur, d_stage;
+    orbx::DevBuf<uint32_t> d_slots, d_candA, d_candB, d_lvl_keys;
+    orbx::DevBuf<int> d_cell_count, d_lvl_count, d_final_idx, d_nm, d_status;
+    orbx::DevBuf<orbx::KeyPointRec> d_kps; orbx::DevBuf<unsigned long long> d_desc;
+    orbx::DevBuf<float> d_uRight, d_depth; orbx::DevBuf<int> d_sad, d_nmatch;
+    orbx::DevBuf<int> d_knn; orbx::DevBuf<uint8_t> d_ratio;
+    orbx::DevBuf<unsigned long long> d_hamA, d_hamB; orbx::DevBuf<int> d_hamOut;
+    orbx::HostBuf<uint8_t> h_stage;
+    orbx::HostBuf<int> h_nm;
+    orbx::rt::stream_t s0 = 0, s1 = 0;
+    orbx::rt::event_t ev_fork = 0, ev_join = 0, ev_done = 0;
+    orbx::rt::event_t ev_stage[ORBX_NSTAGES][2];
+    bool profile = false, serial = false, have_streams = false;
+    int lastB = 0;
+    float stage_ms[ORBX_NSTAGES];
+    // scratch of the projection / BoW searches (orbm_search.cpp)
+    orbx::DevBuf<uint8_t> d_sr[12];
+    orbx::DevBuf<int> d_si[8];
+};

@@ -43,4 +43,17 @@ __global__ void k_knn2(const unsigned long long* __restrict__ descQ, const int* 
                        int cap, int* __restrict__ idx0, int* __restrict__ dist0, int* __restrict__ idx1,
                        int* __restrict__ dist1, uint8_t* __restrict__ ratio_ok);
 
+__global__ void k_grid_build(const KeyPointRec* __restrict__ kps, int N, GridParams g, int* __restrict__ cell_of,
+                             int* __restrict__ cell_start, int* __restrict__ cell_items);
+__global__ void k_area_search(const AreaQuery* __restrict__ queries, const unsigned long long* __restrict__ qdesc, int Q,
+                              const KeyPointRec* __restrict__ kps, const float* __restrict__ u_right,
+                              const unsigned long long* __restrict__ fdesc, GridParams g, const int* __restrict__ cell_start,
+                              const int* __restrict__ cell_items, int gate_right, int* __restrict__ pool_counter, int pool_cap,
+                              int* __restrict__ q_start, int* __restrict__ q_count, int2* __restrict__ entries);
+__global__ void k_bow_search(const BowItem* __restrict__ items, int nitems, const KeyPointRec* __restrict__ kps1,
+                             const unsigned long long* __restrict__ desc1, const float* __restrict__ ur1,
+                             const KeyPointRec* __restrict__ kps2, const unsigned long long* __restrict__ desc2,
+                             const float* __restrict__ ur2, const uint8_t* __restrict__ has_mp2, const int* __restrict__ feat2,
+                             BowParams P, int* __restrict__ best2);
+
 }  // namespace orbx

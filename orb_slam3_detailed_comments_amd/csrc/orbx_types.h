@@ -52,6 +52,23 @@ struct BlurTiles { int begin[kMaxLevels + 1]; };         // first tile (256 cols
 struct UmaxTab { int u[16]; };                        // circular patch half-widths (src/ORBextractor.cc:542-570)
 struct StereoParams { float mbf, mb; int th_high, th_orb; };   // ORBmatcher::TH_HIGH, (TH_HIGH+TH_LOW)/2
 
+// ---- guided searches (k_search.hip) ----
+struct GridParams { float min_x, min_y, gw_inv, gh_inv; };      // mnMinX, mnMinY, mfGridElementWidthInv/HeightInv (include/Frame.h:250-251)
+struct AreaQuery {                                                // one GetFeaturesInArea call + the right-coordinate gate
+    float x, y, r, ur;
+    int min_level, max_level, active, gate;
+};
+struct BowItem { int idx1, start2, cnt2; };
+struct BowParams {
+    float F12[9];            // fundamental matrix, row-major (Pinhole::epipolarConstrain)
+    float ep[2];             // epipole of KF1's centre in KF2
+    float scale2[kMaxLevels], sigma2_2[kMaxLevels];
+    int only_stereo, coarse, th_low;
+};
+#ifdef ORBX_EMU
+struct int2 { int x, y; };
+#endif
+
 // quadtree node, 16 B, lives in LDS
 struct QNode {
     int16_t x0, y0, x1, y1;

@@ -1,6 +1,8 @@
 """Host-side mirror of the reference's descriptor matchers on top of the HIP library:
 ``ORBmatcher::DescriptorDistance`` (src/ORBmatcher.cc:2383-2403), ``Frame::ComputeStereoMatches``
 (src/Frame.cc:1102-1358) and the kNN + ratio part of ``Frame::ComputeStereoFishEyeMatches`` (:1553-1562)."""
+import ctypes as C
+
 import numpy as np
 
 
@@ -9,6 +11,34 @@ class ORBmatcher:
 
     def __init__(self, nnratio=0.6, checkOri=True):
         self.mfNNratio, self.mbCheckOrientation = float(nnratio), bool(checkOri)
+
+    def SearchByProjection(self, ext, frame, map_points, th=1.0, bFarPoints=False, thFarPoints=50.0):
+        """ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints), src/ORBmatcher.cc:45.
+        frame / map_points: views.frame_view(...) / views.map_point_view(...).  Returns (nmatches, assigned[N]) where
+        assigned[i] is the index of the map point written to F.mvpMapPoints[i] (-1: untouched)."""
+        N = frame.view.N
+        assigned = np.full(N, -1, np.int32); nm = C.c_int()
+        ext._lib.check(ext._lib.L.orbm_search_by_projection_mappoints(ext._h, frame.ref(), map_points.ref(), float(th), int(bFarPoints),
+                                                                    float(thFarPoints), self.mfNNratio, assigned.ctypes.data, C.byref(nm)))
+        return nm.value, assigned
+
+    def SearchByProjectionFrame(self, ext, cur, last, th, bForward=False, bBackward=False):
+        """ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono), src/ORBmatcher.cc:1950.
+        Returns (nmatches, assigned[N]): index into the last frame, -1 untouched, -2 reset by the rotation check."""
+        N = cur.view.N
+        assigned = np.full(N, -1, np.int32); nm = C.c_int()
+        ext._lib.check(ext._lib.L.orbm_search_by_projection_frame(ext._h, cur.ref(), last.ref(), float(th), int(bForward), int(bBackward),
+                                                                int(self.mbCheckOrientation), assigned.ctypes.data, C.byref(nm)))
+        return nm.value, assigned
+
+    def SearchForTriangulation(self, ext, kf1, kf2, F12, ep, bOnlyStereo=False, bCoarse=False):
+        """ORBmatcher::SearchForTriangulation, src/ORBmatcher.cc:1045 (pinhole).  Returns (nmatches, vMatchedPairs [(i1,i2)...])."""
+        F12 = np.ascontiguousarray(F12, np.float32).reshape(9); ep = np.ascontiguousarray(ep, np.float32).reshape(2)
+        m12 = np.full(kf1.view.N, -1, np.int32); nm = C.c_int()
+        ext._lib.check(ext._lib.L.orbm_search_for_triangulation(ext._h, kf1.ref(), kf2.ref(), F12.ctypes.data, ep.ctypes.data, int(bOnlyStereo),
+                                                              int(bCoarse), int(self.mbCheckOrientation), m12.ctypes.data, C.byref(nm)))
+        idx = np.nonzero(m12 >= 0)[0]
+        return nm.value, [(int(i), int(m12[i])) for i in idx]
 
     @staticmethod
     def DescriptorDistance(ext, a, b):
@@ -43,3 +73,13 @@ def StereoFishEyeKnn(left, right, left_first=0, right_first=0, B=None):
     L.check(L.L.orbm_knn2_fetch(left._h, B, out["idx0"].ctypes.data, out["dist0"].ctypes.data, out["idx1"].ctypes.data,
                                 out["dist1"].ctypes.data, out["ratio_ok"].ctypes.data, cap))
     return out
+
+
+def GetFeaturesInArea(ext, frame, x, y, r, minLevel=-1, maxLevel=-1):
+    """Frame::GetFeaturesInArea (src/Frame.cc:859): keypoint indices in the reference's order."""
+    cap = max(frame.view.N, 1)
+    out = np.zeros(cap, np.int32)
+    n = ext._lib.L.orbm_get_features_in_area(ext._h, frame.ref(), float(x), float(y), float(r), int(minLevel), int(maxLevel), out.ctypes.data, cap)
+    if n < 0:
+        ext._lib.check(n)
+    return out[:n].copy()

@@ -206,3 +206,38 @@ def oracle_hamming(a, b):
     L = oracle()
     a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
     return L.orbo_descriptor_distance(a.ctypes.data, b.ctypes.data)
+
+
+# ---- guided searches (M3-M6): oracle restatements on the same views as the product ABI ----
+def oracle_features_in_area(frame, x, y, r, minLevel=-1, maxLevel=-1):
+    L = oracle()
+    L.orbo_get_features_in_area.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    out = np.zeros(max(frame.view.N, 1), np.int32)
+    n = L.orbo_get_features_in_area(frame.ref(), x, y, r, minLevel, maxLevel, out.ctypes.data, len(out))
+    return out[:n].copy()
+
+
+def oracle_search_by_projection_mappoints(frame, mps, th, bFar, thFar, nnratio):
+    L = oracle()
+    L.orbo_search_by_projection_mappoints.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p]
+    a = np.full(max(frame.view.N, 1), -1, np.int32)
+    n = L.orbo_search_by_projection_mappoints(frame.ref(), mps.ref(), th, int(bFar), thFar, nnratio, a.ctypes.data)
+    return n, a[:frame.view.N]
+
+
+def oracle_search_by_projection_frame(cur, last, th, fwd, bwd, check_ori):
+    L = oracle()
+    L.orbo_search_by_projection_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    a = np.full(max(cur.view.N, 1), -1, np.int32)
+    n = L.orbo_search_by_projection_frame(cur.ref(), last.ref(), th, int(fwd), int(bwd), int(check_ori), a.ctypes.data)
+    return n, a[:cur.view.N]
+
+
+def oracle_search_for_triangulation(k1, k2, F12, ep, only_stereo, coarse, check_ori):
+    L = oracle()
+    L.orbo_search_for_triangulation.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    F12 = np.ascontiguousarray(F12, np.float32).reshape(9); ep = np.ascontiguousarray(ep, np.float32).reshape(2)
+    m = np.full(max(k1.view.N, 1), -1, np.int32)
+    n = L.orbo_search_for_triangulation(k1.ref(), k2.ref(), F12.ctypes.data, ep.ctypes.data, int(only_stereo), int(coarse), int(check_ori), m.ctypes.data)
+    idx = np.nonzero(m[:k1.view.N] >= 0)[0]
+    return n, [(int(i), int(m[i])) for i in idx]

@@ -1,0 +1,64 @@
+"""Guided searches (GetFeaturesInArea, both SearchByProjection overloads, SearchForTriangulation): kernel sources on the
+CPU SIMT emulator + the host replay vs the sequential oracle restatement.  Same assertions on the GPU in test_gpu_search.py."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import search_scenes as sc
+from orb_slam3_detailed_comments_amd import synth
+from orb_slam3_detailed_comments_amd.extractor import ORBextractor
+from orb_slam3_detailed_comments_amd import matcher as M
+
+
+def run_all(lib, w, h, nf, M_points, seeds):
+    ex = ORBextractor(500, 1.2, 8, 20, 7, lib=lib) if lib is not None else ORBextractor(500, 1.2, 8, 20, 7)
+    for seed in seeds:
+        rng = np.random.default_rng(seed)
+        img = synth.corner_field(w, h, seed=300 + seed, nrect=int(3000 * w * h / (752 * 480)))
+        fv, k, d, u, scales = sc.frame_from_image(img, nf, rng)
+        # M3: result *sequence* of GetFeaturesInArea incl. the level-check quirk and out-of-bounds windows
+        for (x, y, r, mn, mx) in [(w / 2, h / 2, 40, -1, -1), (10, 10, 60, 0, 3), (w - 5, h - 5, 30, 2, -1), (w / 3, h / 2, 25, 0, -1),
+                                  (-50, 100, 20, -1, -1), (w + 200, 100, 20, -1, -1), (w / 2, h / 2, 1000, 1, 2), (200, 150, 0.5, -1, -1)]:
+            assert np.array_equal(M.GetFeaturesInArea(ex, fv, x, y, r, mn, mx), ol.oracle_features_in_area(fv, x, y, r, mn, mx)), (x, y, r, mn, mx)
+        # M4
+        mps = sc.map_points_for_frame(k, d, u, scales, M_points, rng, w, h)
+        for (th, far, thfar, ratio) in [(3.0, False, 0.0, 0.8), (1.0, True, 20.0, 0.8), (5.0, False, 0.0, 0.6)]:
+            n1, a1 = M.ORBmatcher(ratio).SearchByProjection(ex, fv, mps, th, far, thfar)
+            n2, a2 = ol.oracle_search_by_projection_mappoints(fv, mps, th, far, thfar, ratio)
+            assert n1 == n2 and np.array_equal(a1, a2), (th, far, ratio)
+            assert n1 > M_points // 20
+        # M5
+        last = sc.last_frame_for(k, d, scales, rng, w, h, 40.0)
+        for (th, fwd, bwd, ori) in [(7.0, False, False, True), (15.0, True, False, True), (7.0, False, True, False), (14.0, False, False, True)]:
+            n1, a1 = M.ORBmatcher(0.9, ori).SearchByProjectionFrame(ex, fv, last, th, fwd, bwd)
+            n2, a2 = ol.oracle_search_by_projection_frame(fv, last, th, fwd, bwd, ori)
+            assert n1 == n2 and np.array_equal(a1, a2), (th, fwd, bwd, ori)
+            assert n1 > 20
+        # M6
+        (kf1, kf2), F12, ep = sc.keyframe_pair(rng, nf, w, h)
+        for (only_stereo, coarse, ori) in [(False, False, False), (False, True, True), (True, False, False), (False, False, True)]:
+            n1, p1 = M.ORBmatcher(0.6, ori).SearchForTriangulation(ex, kf1[0], kf2[0], F12, ep, only_stereo, coarse)
+            n2, p2 = ol.oracle_search_for_triangulation(kf1[0], kf2[0], F12, ep, only_stereo, coarse, ori)
+            assert n1 == n2 and p1 == p2, (only_stereo, coarse, ori)
+        assert len(p2) > 5
+
+
+def test_guided_searches_emulated(emu_lib):
+    run_all(emu_lib, 480, 360, 500, 1500, seeds=(0, 1))
+
+
+def test_degenerate_views(emu_lib):
+    from orb_slam3_detailed_comments_amd import views
+    ex = ORBextractor(500, 1.2, 8, 20, 7, lib=emu_lib)
+    rng = np.random.default_rng(9)
+    img = synth.corner_field(376, 240, seed=10, nrect=800)
+    fv, k, d, u, scales = sc.frame_from_image(img, 300, rng, with_uright=False)
+    # no map point in view, and an empty frame
+    mps = views.map_point_view(np.zeros(50, np.uint8), *[np.zeros(50, np.float32)] * 3, np.zeros(50, np.int32), np.ones(50, np.float32),
+                               np.ones(50, np.float32), np.zeros(50, np.uint8), np.ones(50, np.uint8), np.zeros((50, 32), np.uint8))
+    n, a = M.ORBmatcher(0.8).SearchByProjection(ex, fv, mps, 3.0)
+    assert n == 0 and (a == -1).all()
+    empty = views.frame_view(k[:0], d[:0], scales, 376, 240)
+    mps2 = sc.map_points_for_frame(k, d, None, scales, 100, rng, 376, 240)
+    n, a = M.ORBmatcher(0.8).SearchByProjection(ex, empty, mps2, 3.0)
+    assert n == 0 and len(a) == 0
