@@ -111,6 +111,7 @@ const char* orbx_stage_name(int i);
 /* Stage probes for parity tests (level-ordered intermediate results of image `image_index`). */
 int orbx_debug_candidates(orbx_extractor* h, int image_index, int level, int* xys, int cap);       /* returns count; (x,y,score) rel. to the 16-px border, reference order */
 int orbx_debug_level_keys(orbx_extractor* h, int image_index, int level, int* xys, int cap);       /* quadtree output in list order */
+int orbx_debug_quadtree_profile(orbx_extractor* h, long long out[16]);   /* phase timestamps of one quadtree workgroup (profiling mode 2) */
 
 /* ---------------------------------------------------------------------------------------------------------- */
 /* ORBmatcher::DescriptorDistance (include/ORBmatcher.h:44, src/ORBmatcher.cc:2383-2403), all pairs:

@@ -26,7 +26,7 @@ SYMBOLS = [
     "orbx_get_levels", "orbx_get_scale_factor", "orbx_get_level_tables", "orbx_max_keypoints",
     "orbx_extract", "orbx_extract_batch", "orbx_fetch", "orbx_sync", "orbx_pyramid_level",
     "orbx_device_alloc", "orbx_device_free", "orbx_device_upload", "orbx_host_alloc", "orbx_host_free", "orbx_profile_enable",
-    "orbx_profile_get", "orbx_stage_name", "orbx_debug_candidates", "orbx_debug_level_keys",
+    "orbx_profile_get", "orbx_stage_name", "orbx_debug_candidates", "orbx_debug_level_keys", "orbx_debug_quadtree_profile",
     "orbm_hamming_matrix", "orbm_stereo_match", "orbm_stereo_fetch", "orbm_knn2", "orbm_knn2_fetch",
     "orbm_get_features_in_area", "orbm_search_by_projection_mappoints", "orbm_search_by_projection_frame",
     "orbm_search_for_triangulation",
@@ -74,6 +74,7 @@ class OrbxLib:
         L.orbx_stage_name.argtypes = [i]; L.orbx_stage_name.restype = C.c_char_p
         L.orbx_debug_candidates.argtypes = [vp, i, i, vp, i]
         L.orbx_debug_level_keys.argtypes = [vp, i, i, vp, i]
+        L.orbx_debug_quadtree_profile.argtypes = [vp, vp]
         L.orbm_hamming_matrix.argtypes = [vp, vp, i, vp, i, vp]
         L.orbm_stereo_match.argtypes = [vp, i, vp, i, i, f, f]
         L.orbm_stereo_fetch.argtypes = [vp, i, vp, vp, i, vp]

@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                                                   uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
                                                   uint32_t* __restrict__ lvl_keys, int kp_total_cap,
                                                   int* __restrict__ lvl_count, int nlevels, int node_cap,
-                                                  int* __restrict__ status) {
+                                                  int* __restrict__ status, long long* __restrict__ qt_prof) {
     ORBX_DYN_SMEM(smem);
     __shared__ unsigned long long s_scan[20];
     __shared__ int s_i[16];
@@ -113,6 +113,12 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const LevelInfo L = lv[level];
     const int N = L.quota;
+#ifdef ORBX_EMU
+#define QT_STAMP(i)
+#else
+#define QT_STAMP(i) if (qt_prof && tid == 0 && level == 0 && b == 0) qt_prof[i] = wall_clock64();
+#endif
+    QT_STAMP(0)
     // LDS carve: nodes[2][cap] (16 B) | childcnt[cap][4] (u32) | expand[2][cap] (u64) | erased[cap] (u8)
     QNode* nodes0 = (QNode*)smem;
     QNode* nodes1 = nodes0 + node_cap;
@@ -139,6 +145,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
         n += (int)tot;
     }
     __syncthreads();
+    QT_STAMP(1)
     // ---- roots (:718-764): key -> root (int)(x / hX), stable per-root compaction bufB -> bufA ----
     int nnodes = 0;
     {
@@ -174,6 +181,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
     }
     __syncthreads();
 
+    QT_STAMP(2)
     QNode* cur = nodes0; QNode* nxt = nodes1;
     unsigned long long* expc = exp0; unsigned long long* expn = exp1;
     bool finish = (n == 0);
@@ -272,10 +280,14 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
         { unsigned long long* t = expc; expc = expn; expn = t; }
         if (nnodes >= N || nnodes == prevSize) { finish = true; }
         else if (nnodes + nexp * 3 > N) {
+            QT_STAMP(3)
+            if (qt_prof && tid == 0 && level == 0 && b == 0) { qt_prof[10] = n; qt_prof[11] = nnodes; qt_prof[12] = nexp; }
             // ---- final rounds (:940-1020): split largest-first until the quota is reached ----
             while (!finish) {
                 const int prev2 = nnodes;
+                QT_STAMP(4)
                 if (tid == 0) libstdcxx_sort(expc, nexp, SortLess());
+                QT_STAMP(5)
                 for (int i = tid; i < nnodes; i += 256) erased[i] = 0;
                 __syncthreads();
                 // children counts of every candidate (partition into the other buffer; harmless if the
@@ -289,6 +301,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                     if (lane < 4) childcnt[4 * idx + lane] = (uint32_t)(lane == 0 ? cnt[0] : lane == 1 ? cnt[1] : lane == 2 ? cnt[2] : cnt[3]);
                 }
                 __syncthreads();
+                QT_STAMP(6)
                 // how many of the sorted candidates get divided before `size >= N` breaks the loop
                 if (tid == 0) {
                     int size = prev2, ndiv = 0;
@@ -302,6 +315,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                     s_i[0] = ndiv;
                 }
                 __syncthreads();
+                QT_STAMP(7)
                 const int ndiv = s_i[0];
                 // totals over the divided set (division order t = 0..ndiv-1 <-> sorted index nexp-1-t)
                 unsigned long long total_all = 0;
@@ -376,6 +390,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
         }
     }
     __syncthreads();
+    QT_STAMP(8)
     // ---- result (:1028-1053): per node, the first key with the largest response ----
     uint32_t* outk = lvl_keys + (size_t)b * kp_total_cap + L.kp_off;
     if (overflow || nnodes > L.kp_cap) {
@@ -391,6 +406,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
         outk[i] = best;
     }
     if (tid == 0) lvl_count[(size_t)b * nlevels + level] = nnodes;
+    QT_STAMP(9)
 }
 
 }  // namespace orbx

@@ -168,7 +168,7 @@ int configure(orbx_extractor* h, int W, int H, int B) {
         e |= h->d_kps.ensure(b * cap); e |= h->d_desc.ensure(b * cap * 4);
         e |= h->d_uRight.ensure(b * cap); e |= h->d_depth.ensure(b * cap); e |= h->d_sad.ensure(b * cap); e |= h->d_nmatch.ensure(b);
         e |= h->d_knn.ensure(4 * b * cap); e |= h->d_ratio.ensure(b * cap);
-        e |= h->h_nm.ensure(3 * b + 4);
+        e |= h->h_nm.ensure(3 * b + 4); e |= h->d_qtprof.ensure(32);
         if (e) return fail(ORBX_E_DEVICE, "device allocation failed (batch %d of %dx%d)", B, W, H);
         rt::memset_async(h->d_status.p, 0, 4 * sizeof(int), h->s0);
         h->maxB = B;
@@ -232,7 +232,8 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int strid
         const size_t smem = (size_t)h->node_cap * 65 + 64;
         ORBX_LAUNCH(k_quadtree, grid, blk1, smem, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
                     (const int*)h->d_cell_count.p, (const uint32_t*)h->d_slots.p, h->cand_stride, h->d_candA.p, h->d_candB.p, h->cand_stride,
-                    h->d_lvl_keys.p, h->kp_total_cap, h->d_lvl_count.p, nl, h->node_cap, h->d_status.p);
+                    h->d_lvl_keys.p, h->kp_total_cap, h->d_lvl_count.p, nl, h->node_cap, h->d_status.p,
+                    h->serial ? (long long*)h->d_qtprof.p : (long long*)nullptr);
     }
     stage_end(h, ST_QUADTREE, h->s0);
     stage_begin(h, ST_LAYOUT, h->s0);
@@ -419,6 +420,14 @@ int orbx_device_upload(orbx_extractor* h, void* dptr, const void* host, size_t b
     if (!h || !dptr || !host) return fail(ORBX_E_ARG, "null");
     rt::set_device(h->device);
     if (rt::copy_h2d(dptr, host, bytes, h->s0) || rt::stream_sync(h->s0)) return fail(ORBX_E_DEVICE, "upload failed");
+    return ORBX_OK;
+}
+
+// debug: phase timestamps (100 MHz wall clock) of the level-0 quadtree workgroup of image 0 (serial profiling mode only)
+int orbx_debug_quadtree_profile(orbx_extractor* h, long long out[16]) {
+    if (!h || !h->d_qtprof.p) return ORBX_E_ARG;
+    rt::set_device(h->device);
+    if (rt::copy_d2h(out, h->d_qtprof.p, sizeof(long long) * 16, h->s0) || rt::stream_sync(h->s0)) return ORBX_E_DEVICE;
     return ORBX_OK;
 }
 

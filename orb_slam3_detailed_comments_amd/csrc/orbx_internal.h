@@ -77,4 +77,5 @@ struct orbx_extractor {
     // scratch of the projection / BoW searches (orbm_search.cpp)
     orbx::DevBuf<uint8_t> d_sr[12];
     orbx::DevBuf<int> d_si[8];
+    orbx::DevBuf<long long> d_qtprof;
 };
