@@ -21,6 +21,11 @@
 
 namespace orbx {
 
+#ifndef ORBX_BIGSPAN
+#define ORBX_BIGSPAN 1024
+#endif
+constexpr int kBigSpan = ORBX_BIGSPAN;   // spans above this are partitioned by the whole workgroup (tests also build with 80)
+
 struct SortLess {
     __device__ __forceinline__ bool operator()(unsigned long long a, unsigned long long b) const { return (a >> 16) < (b >> 16); }
 };
@@ -84,6 +89,191 @@ __device__ __forceinline__ void wave_partition(const QNode nd, const uint32_t* _
     cnt[0] = tot[0]; cnt[1] = tot[1]; cnt[2] = tot[2]; cnt[3] = tot[3];
 }
 
+
+// Block-cooperative stable partition of the span [s, s+c) into <= 4 classes (src -> dst, same offsets): every wave owns a
+// contiguous quarter of the span, counts its classes with ballots, the four waves exchange counts through LDS once, then
+// each wave writes its keys at its ordered offsets.  Two barriers per call instead of two per 256 keys.
+// cls(key) in [0,4).  s_cnt: 16 ints of LDS.  All 256 threads must call.  cnt[] = class totals (valid in every thread).
+template <typename F>
+__device__ __forceinline__ void block_partition4(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int s, int c,
+                                                 F cls, int* s_cnt, int cnt[4]) {
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const int seg = ((c + 255) >> 8) << 6;
+    const int beg = wave * seg, end = imin(c, beg + seg);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int tot[4] = {0, 0, 0, 0};
+    for (int i0 = beg; i0 < end; i0 += 64) {
+        int q = -1;
+        if (i0 + lane < end) q = cls(src[s + i0 + lane]);
+        tot[0] += __popcll(__ballot(q == 0)); tot[1] += __popcll(__ballot(q == 1));
+        tot[2] += __popcll(__ballot(q == 2)); tot[3] += __popcll(__ballot(q == 3));
+    }
+    if (lane < 4) s_cnt[wave * 4 + lane] = lane == 0 ? tot[0] : lane == 1 ? tot[1] : lane == 2 ? tot[2] : tot[3];
+    __syncthreads();
+    int run[4], acc = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const int v = s_cnt[w * 4 + k]; total += v; before += w < wave ? v : 0; }
+        cnt[k] = total; run[k] = acc + before; acc += total;
+    }
+    for (int i0 = beg; i0 < end; i0 += 64) {
+        int q = -1; uint32_t key = 0;
+        if (i0 + lane < end) { key = src[s + i0 + lane]; q = cls(key); }
+        const unsigned long long b0 = __ballot(q == 0), b1 = __ballot(q == 1), b2 = __ballot(q == 2), b3 = __ballot(q == 3);
+        if (q >= 0) {
+            const unsigned long long bq = q == 0 ? b0 : q == 1 ? b1 : q == 2 ? b2 : b3;
+            dst[s + run[q] + __popcll(bq & lt)] = key;
+        }
+        run[0] += __popcll(b0); run[1] += __popcll(b1); run[2] += __popcll(b2); run[3] += __popcll(b3);
+    }
+    __syncthreads();
+}
+
+struct QuadCls {    // DivideNode's key -> child test (:651-661)
+    int mx, my;
+    __device__ __forceinline__ int operator()(uint32_t key) const {
+        const bool left = key_x(key) < mx, top = key_y(key) < my;
+        return left ? (top ? 0 : 2) : (top ? 1 : 3);
+    }
+};
+struct RootCls {    // vpIniNodes[kp.pt.x / hX] (:763): roots r0, r0+1, r0+2 -> classes 0..2, every later root -> class 3
+    float hX; int r0;
+    __device__ __forceinline__ int operator()(uint32_t key) const {
+        const int d = __float2int_rz(__fdiv_rn((float)key_x(key), hX)) - r0;
+        return d < 3 ? d : 3;
+    }
+};
+
+
+// std::sort(a, a+n, SortLess) by the whole workgroup, same result as libstdc++ (libstdcxx_sort_model.h) but with the
+// independent work run in parallel:
+//  * introsort's partition tree: the sub-ranges produced by one __unguarded_partition_pivot are disjoint, so each pending
+//    range is partitioned by its own thread, level by level (a range whose depth budget is exhausted is heap-sorted by
+//    its thread, exactly like the recursion would);
+//  * __final_insertion_sort never moves an element across a partition cut (left of a cut is <= pivot <= right of it) and
+//    insertion sort is stable, so it equals a stable rank-sort inside every final range of <= 16 elements: each thread
+//    ranks one element among its <= 16 range-mates.
+// seg0/seg1: two range lists (first | last << 12 | depth << 24), capacity >= n/8 + 8 each; flags: n bytes
+// (1 = a final range starts here, 2 = a heap-sorted range starts here); tmp: n elements.  All 256 threads must call.
+__device__ __forceinline__ void block_sort_libstdcxx(unsigned long long* a, unsigned long long* tmp, int n,
+                                                     uint32_t* seg0, uint32_t* seg1, uint8_t* flags, int* s_ctr) {
+    const int tid = (int)threadIdx.x;
+    SortLess less;
+    for (int i = tid; i < n; i += 256) flags[i] = 0;
+    if (tid == 0) {
+        int lg = 0;
+        for (int t = n; t > 1; t >>= 1) lg++;
+        flags[0] = 1;
+        s_ctr[0] = 0; s_ctr[1] = 0;
+        if (n > 16) { seg0[0] = 0u | ((uint32_t)n << 12) | ((uint32_t)(lg * 2) << 24); s_ctr[0] = 1; }
+    }
+    __syncthreads();
+    uint32_t* cur = seg0; uint32_t* nxt = seg1;
+    int which = 0;
+    for (;;) {
+        const int ncur = s_ctr[which];
+        if (ncur == 0) break;
+        for (int j = tid; j < ncur; j += 256) {
+            const uint32_t sg = cur[j];
+            const int first = (int)(sg & 0xFFF), last = (int)((sg >> 12) & 0xFFF);
+            int depth = (int)(sg >> 24);
+            if (depth == 0) {
+                sm_heap_sort(a, first, last, less);
+                flags[first] = 2;
+            } else {
+                --depth;
+                const int mid = first + (last - first) / 2;
+                sm_move_median_to_first(a, first, first + 1, mid, last - 1, less);
+                const int cut = sm_unguarded_partition(a, first + 1, last, first, less);
+                // right range [cut, last), left range [first, cut): both continue with the decremented budget
+                if (last - cut > 16) nxt[atomicAdd(&s_ctr[which ^ 1], 1)] = (uint32_t)cut | ((uint32_t)last << 12) | ((uint32_t)depth << 24);
+                if (cut < last) flags[cut] = flags[cut] ? flags[cut] : 1;
+                if (cut - first > 16) nxt[atomicAdd(&s_ctr[which ^ 1], 1)] = (uint32_t)first | ((uint32_t)cut << 12) | ((uint32_t)depth << 24);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_ctr[which] = 0;
+        which ^= 1;
+        { uint32_t* t = cur; cur = nxt; nxt = t; }
+        __syncthreads();
+    }
+    // final insertion sort == stable rank inside each final range
+    for (int i = tid; i < n; i += 256) {
+        int f = i;
+        while (flags[f] == 0) --f;
+        const unsigned long long v = a[i];
+        int pos = i;
+        if (flags[f] == 1) {
+            int e = i + 1;
+            while (e < n && flags[e] == 0) ++e;
+            int rank = 0;
+            for (int j = f; j < e; j++) {
+                const unsigned long long o = a[j];
+                rank += (less(o, v) || (j < i && !less(v, o))) ? 1 : 0;
+            }
+            pos = f + rank;
+        }
+        tmp[pos] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) a[i] = tmp[i];
+    __syncthreads();
+}
+
+
+// One wave partitions the nodes idx_of(j), j = wave, wave+4, ... < count, skipping spans of <= 1 key and spans above
+// kBigSpan (done cooperatively elsewhere).  Spans of <= 64 keys (the common case) are software-pipelined: the keys of
+// the next node are requested before the ballots of the current one, hiding most of the L2 latency.
+template <typename IdxFn>
+__device__ __forceinline__ void wave_partition_many(int count, IdxFn idx_of, const QNode* __restrict__ cur,
+                                                    uint32_t* __restrict__ bufA, uint32_t* __restrict__ bufB,
+                                                    uint32_t* __restrict__ childcnt) {
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int j = wave;
+    int idx = 0; QNode nd; nd.x0 = nd.y0 = nd.x1 = nd.y1 = 0; nd.start = 0; nd.cnt_buf = 0;
+    uint32_t key = 0;
+    if (j < count) {
+        idx = idx_of(j); nd = cur[idx];
+        const int c = node_cnt(nd);
+        if (c > 1 && c <= 64 && lane < c) key = (node_buf(nd) ? bufB : bufA)[nd.start + lane];
+    }
+    while (j < count) {
+        const int jn = j + 4;
+        int idxn = 0; QNode ndn = nd; uint32_t keyn = 0;
+        if (jn < count) {
+            idxn = idx_of(jn); ndn = cur[idxn];
+            const int cn = node_cnt(ndn);
+            if (cn > 1 && cn <= 64 && lane < cn) keyn = (node_buf(ndn) ? bufB : bufA)[ndn.start + lane];
+        }
+        const int c = node_cnt(nd);
+        if (c > 1 && c <= kBigSpan) {
+            int cnt[4];
+            const int bsel = node_buf(nd);
+            if (c <= 64) {
+                const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+                int q = -1;
+                if (lane < c) { const bool left = key_x(key) < mx, top = key_y(key) < my; q = left ? (top ? 0 : 2) : (top ? 1 : 3); }
+                const unsigned long long b0 = __ballot(q == 0), b1 = __ballot(q == 1), b2 = __ballot(q == 2), b3 = __ballot(q == 3);
+                cnt[0] = __popcll(b0); cnt[1] = __popcll(b1); cnt[2] = __popcll(b2); cnt[3] = __popcll(b3);
+                if (q >= 0) {
+                    const unsigned long long bq = q == 0 ? b0 : q == 1 ? b1 : q == 2 ? b2 : b3;
+                    const int base = q == 0 ? 0 : q == 1 ? cnt[0] : q == 2 ? cnt[0] + cnt[1] : cnt[0] + cnt[1] + cnt[2];
+                    (bsel ? bufA : bufB)[nd.start + base + __popcll(bq & lt)] = key;
+                }
+            } else {
+                wave_partition(nd, bsel ? bufB : bufA, bsel ? bufA : bufB, cnt);
+            }
+            if (lane < 4) childcnt[4 * idx + lane] = (uint32_t)(lane == 0 ? cnt[0] : lane == 1 ? cnt[1] : lane == 2 ? cnt[2] : cnt[3]);
+        }
+        j = jn; idx = idxn; nd = ndn; key = keyn;
+    }
+}
+struct IdentityIdx { __device__ __forceinline__ int operator()(int j) const { return j; } };
+struct ExpandIdx { const unsigned long long* e; __device__ __forceinline__ int operator()(int j) const { return (int)(e[j] & 0xFFFF); } };
+
 __device__ __forceinline__ QNode make_child(const QNode& p, int q, const int cnt[4], int newbuf) {
     const int mx = p.x0 + ((p.x1 - p.x0 + 1) >> 1);
     const int my = p.y0 + ((p.y1 - p.y0 + 1) >> 1);
@@ -146,37 +336,30 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
     }
     __syncthreads();
     QT_STAMP(1)
-    // ---- roots (:718-764): key -> root (int)(x / hX), stable per-root compaction bufB -> bufA ----
+    // ---- roots (:718-764): key -> root (int)(x / hX); stable block-cooperative partition, three roots per sweep ----
     int nnodes = 0;
     {
-        int base = 0;
-        for (int r = 0; r < L.nini; r++) {
-            int rcount = 0;
-            for (int i0 = 0; i0 < n; i0 += 256) {
-                const int i = i0 + tid;
-                uint32_t key = 0; int flag = 0;
-                if (i < n) {
-                    key = bufB[i];
-                    const int root = __float2int_rz(__fdiv_rn((float)key_x(key), L.hX));
-                    flag = (root == r);
+        int rs = 0, rc = n, sb = 1;      // the not-yet-assigned keys: span [rs, rs+rc) of buffer sb (1 = B, 0 = A)
+        for (int r0 = 0; r0 < L.nini && rc > 0; r0 += 3) {
+            int cnt[4];
+            RootCls cls; cls.hX = L.hX; cls.r0 = r0;
+            block_partition4(sb ? bufB : bufA, sb ? bufA : bufB, rs, rc, cls, s_i, cnt);
+            int off = rs;
+            for (int k = 0; k < 3 && r0 + k < L.nini; k++) {
+                if (cnt[k] > 0) {
+                    if (tid == 0) {
+                        QNode nd;
+                        nd.x0 = (int16_t)__float2int_rz(__fmul_rn(L.hX, (float)(r0 + k)));
+                        nd.x1 = (int16_t)__float2int_rz(__fmul_rn(L.hX, (float)(r0 + k + 1)));
+                        nd.y0 = 0; nd.y1 = (int16_t)L.bh;
+                        nd.start = (uint32_t)off; nd.cnt_buf = (uint32_t)cnt[k] | ((uint32_t)(sb ^ 1) << 30);
+                        nodes0[nnodes] = nd;
+                    }
+                    nnodes++;
                 }
-                unsigned long long tot;
-                const int pos = (int)block_excl_scan<unsigned long long>((unsigned long long)flag, &tot, s_scan);
-                if (flag) bufA[base + rcount + pos] = key;
-                rcount += (int)tot;
+                off += cnt[k];
             }
-            if (rcount > 0) {
-                if (tid == 0) {
-                    QNode nd;
-                    nd.x0 = (int16_t)__float2int_rz(__fmul_rn(L.hX, (float)r));
-                    nd.x1 = (int16_t)__float2int_rz(__fmul_rn(L.hX, (float)(r + 1)));
-                    nd.y0 = 0; nd.y1 = (int16_t)L.bh;
-                    nd.start = (uint32_t)base; nd.cnt_buf = (uint32_t)rcount;   // buffer A = 0
-                    nodes0[nnodes] = nd;
-                }
-                nnodes++;
-            }
-            base += rcount;
+            rs = off; rc = cnt[3]; sb ^= 1;
         }
     }
     __syncthreads();
@@ -189,15 +372,18 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
     while (!finish) {
         const int prevSize = nnodes;
         // ---- full pass: divide every node with more than one key (:790-905) ----
-        for (int i = wave; i < nnodes; i += 4) {
+        // big spans: the whole workgroup partitions them one after another; small spans: one wave each
+        for (int i = 0; i < nnodes; i++) {
             const QNode nd = cur[i];
-            if (node_cnt(nd) > 1) {
+            if (node_cnt(nd) > kBigSpan) {
                 int cnt[4];
+                QuadCls cls; cls.mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1); cls.my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
                 const int bsel = node_buf(nd);
-                wave_partition(nd, bsel ? bufB : bufA, bsel ? bufA : bufB, cnt);
-                if (lane < 4) childcnt[4 * i + lane] = (uint32_t)(lane == 0 ? cnt[0] : lane == 1 ? cnt[1] : lane == 2 ? cnt[2] : cnt[3]);
+                block_partition4(bsel ? bufB : bufA, bsel ? bufA : bufB, (int)nd.start, node_cnt(nd), cls, s_i, cnt);
+                if (tid < 4) childcnt[4 * i + tid] = (uint32_t)(tid == 0 ? cnt[0] : tid == 1 ? cnt[1] : tid == 2 ? cnt[2] : cnt[3]);
             }
         }
+        wave_partition_many(nnodes, IdentityIdx(), cur, bufA, bufB, childcnt);
         __syncthreads();
         int T = 0, E = 0, K = 0;
         {
@@ -286,20 +472,26 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
             while (!finish) {
                 const int prev2 = nnodes;
                 QT_STAMP(4)
-                if (tid == 0) libstdcxx_sort(expc, nexp, SortLess());
+                // scratch: the child-count table is not live here (range lists), `erased` doubles as the range-start flags,
+                // the other expand array is the rank-sort target
+                block_sort_libstdcxx(expc, expn, nexp, childcnt, childcnt + 2 * (size_t)node_cap, erased, s_i + 8);
                 QT_STAMP(5)
                 for (int i = tid; i < nnodes; i += 256) erased[i] = 0;
                 __syncthreads();
                 // children counts of every candidate (partition into the other buffer; harmless if the
                 // node ends up not being divided: its own buffer is untouched)
-                for (int j = wave; j < nexp; j += 4) {
+                for (int j = 0; j < nexp; j++) {           // (rare) spans too big for one wave
                     const int idx = (int)(expc[j] & 0xFFFF);
                     const QNode nd = cur[idx];
-                    int cnt[4];
-                    const int bsel = node_buf(nd);
-                    wave_partition(nd, bsel ? bufB : bufA, bsel ? bufA : bufB, cnt);
-                    if (lane < 4) childcnt[4 * idx + lane] = (uint32_t)(lane == 0 ? cnt[0] : lane == 1 ? cnt[1] : lane == 2 ? cnt[2] : cnt[3]);
+                    if (node_cnt(nd) > kBigSpan) {
+                        int cnt[4];
+                        QuadCls cls; cls.mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1); cls.my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+                        const int bsel = node_buf(nd);
+                        block_partition4(bsel ? bufB : bufA, bsel ? bufA : bufB, (int)nd.start, node_cnt(nd), cls, s_i, cnt);
+                        if (tid < 4) childcnt[4 * idx + tid] = (uint32_t)(tid == 0 ? cnt[0] : tid == 1 ? cnt[1] : tid == 2 ? cnt[2] : cnt[3]);
+                    }
                 }
+                { ExpandIdx ei; ei.e = expc; wave_partition_many(nexp, ei, cur, bufA, bufB, childcnt); }
                 __syncthreads();
                 QT_STAMP(6)
                 // how many of the sorted candidates get divided before `size >= N` breaks the loop
