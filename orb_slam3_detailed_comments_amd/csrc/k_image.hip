@@ -97,6 +97,57 @@ __global__ void __launch_bounds__(256) k_resize(const LevelInfo* __restrict__ lv
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Small CDNA byte / packed-16-bit helpers (with plain-C equivalents for the test emulator).
+// byte permute (v_perm_b32): result byte i = byte sel_i (0..7) of the 8-byte pair {hi:lo}; selector 0x0c gives 0x00
+__device__ __forceinline__ uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+#ifdef ORBX_EMU
+    const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t sb = (sel >> (8 * i)) & 0xFF;
+        const uint32_t byte = sb >= 0x0c ? 0u : (uint32_t)((v >> (8 * (sb & 7))) & 0xFF);
+        r |= byte << (8 * i);
+    }
+    return r;
+#else
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#endif
+}
+// v_alignbyte_b32: the 4 bytes starting at byte `shift` (0..3) of the 8-byte pair {hi:lo}
+__device__ __forceinline__ uint32_t align_byte(uint32_t hi, uint32_t lo, uint32_t shift) {
+#ifdef ORBX_EMU
+    return (uint32_t)(((((unsigned long long)hi) << 32) | lo) >> (8 * (shift & 3)));
+#else
+    return __builtin_amdgcn_alignbyte(hi, lo, shift);
+#endif
+}
+__device__ __forceinline__ int mul24(int a, int b) {
+#ifdef ORBX_EMU
+    return a * b;
+#else
+    return __mul24(a, b);      // operands < 2^23: full-rate 24-bit multiply instead of the quarter-rate 32-bit one
+#endif
+}
+// two signed 16-bit lanes in one VGPR (v_pk_sub_i16 / v_pk_min_i16 / v_pk_max_i16)
+#ifdef ORBX_EMU
+struct pk2 { short x, y; };
+__device__ __forceinline__ pk2 pk_make(uint32_t v) { pk2 r; r.x = (short)(v & 0xFFFF); r.y = (short)(v >> 16); return r; }
+__device__ __forceinline__ pk2 pk_sub(pk2 a, pk2 b) { pk2 r; r.x = (short)(a.x - b.x); r.y = (short)(a.y - b.y); return r; }
+__device__ __forceinline__ pk2 pk_min(pk2 a, pk2 b) { pk2 r; r.x = a.x < b.x ? a.x : b.x; r.y = a.y < b.y ? a.y : b.y; return r; }
+__device__ __forceinline__ pk2 pk_max(pk2 a, pk2 b) { pk2 r; r.x = a.x > b.x ? a.x : b.x; r.y = a.y > b.y ? a.y : b.y; return r; }
+__device__ __forceinline__ int pk_lo(pk2 a) { return a.x; }
+__device__ __forceinline__ int pk_hi(pk2 a) { return a.y; }
+#else
+typedef short pk2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk2 pk_make(uint32_t v) { return __builtin_bit_cast(pk2, v); }
+__device__ __forceinline__ pk2 pk_sub(pk2 a, pk2 b) { return a - b; }
+__device__ __forceinline__ pk2 pk_min(pk2 a, pk2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ pk2 pk_max(pk2 a, pk2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ int pk_lo(pk2 a) { return (int)a.x; }
+__device__ __forceinline__ int pk_hi(pk2 a) { return (int)a.y; }
+#endif
+
+// ---------------------------------------------------------------------------------------------------
 // FAST-9/16.  ring offsets (dx,dy), k = 0..15, as in OpenCV: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)
 // (0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3).  d[k] = v - ring[k].
 __device__ __forceinline__ void fast_ring(const uint8_t* c, int wp, int d[16]) {
@@ -166,7 +217,7 @@ __global__ void __launch_bounds__(256) k_fast_cells(const LevelInfo* __restrict_
         return;
     }
     const int wh = ih + 6;
-    const int gx0 = (ci.x0 - 3) & ~3, gx1 = (ci.x1 + 3 + 3) & ~3;   // dword-aligned window columns
+    const int gx0 = ((ci.x0 - 3) & ~3) - 4, gx1 = ((ci.x1 + 3 + 3) & ~3) + 4;   // dword-aligned window + one dword margin each side
     const int wpd = (gx1 - gx0) >> 2, wp = wpd * 4;
     const int xo = (ci.x0 - 3) - gx0;
     uint8_t* tile = smem;
@@ -181,27 +232,67 @@ __global__ void __launch_bounds__(256) k_fast_cells(const LevelInfo* __restrict_
     __syncthreads();
     const int t0 = imin(iniTh, minTh);
     const int npx = iw * ih;
-    const int q = (npx + 3) >> 2;
     const unsigned M = (1u << 20) / (unsigned)iw + 1u;      // p / iw == (p * M) >> 20 exactly for p < 2^13, iw <= 128
     const unsigned long long lt = (1ull << lane) - 1ull;
-    // ---- A ----
+    // ---- A ----  work item = (row y, dword group g): 4 adjacent pixels per lane, packed 16-bit arithmetic.
+    // The 16 ring bytes of the 4 pixels are cut out of 21 aligned LDS dwords with v_alignbyte, widened with v_perm,
+    // and the exact opposite-pair rejection runs on two pixels per instruction (v_pk_sub/min/max_i16).
+    const int g0 = (xo + 3) >> 2, ng = ((xo + 3 + iw - 1) >> 2) - g0 + 1;
+    const int nitems = ih * ng;
+    const int qi = (nitems + 3) >> 2;                      // items per wave (contiguous ranges keep the list row-major)
+    const int q = qi * 4;                                  // list capacity per wave (pixels)
     {
-        const int pbeg = wave * q, pend = imin(npx, pbeg + q);
-        uint16_t* mylist = list + pbeg;
+        const unsigned Mg = (1u << 20) / (unsigned)ng + 1u;
+        const int ibeg = wave * qi, iend = imin(nitems, ibeg + qi);
+        uint16_t* mylist = list + wave * q;
+        const uint32_t* tile32 = (const uint32_t*)tile;
         int cnt = 0;
-        for (int p0 = pbeg; p0 < pend; p0 += 64) {
-            const int p = p0 + lane;
-            bool pass = false;
-            if (p < pend) {
-                const int y = (int)(((unsigned)p * M) >> 20), x = p - y * iw;
-                int d[16];
-                fast_ring(tile + (y + 3) * wp + xo + x + 3, wp, d);
-                pass = fast_quick(d, t0);
-                if (!pass) sc[p] = 0;
+        for (int it0 = ibeg; it0 < iend; it0 += 64) {
+            const int it = it0 + lane;
+            unsigned mask = 0; int y = 0, xbase = 0;
+            if (it < iend) {
+                y = (int)(((unsigned)it * Mg) >> 20);
+                const int g = g0 + (it - y * ng);
+                xbase = 4 * g - (xo + 3);                  // interior x of this lane's first pixel (may be < 0)
+                const uint32_t* rp = tile32 + (y + 3) * wpd + g;
+                uint32_t Lw[7], Cw[7], Rw[7];
+#pragma unroll
+                for (int r = 0; r < 7; r++) { const uint32_t* pr = rp + (r - 3) * wpd; Lw[r] = pr[-1]; Cw[r] = pr[0]; Rw[r] = pr[1]; }
+                // row index r = dy + 3
+                const pk2 vlo = pk_make(byte_perm(0u, Cw[3], 0x0c010c00u)), vhi = pk_make(byte_perm(0u, Cw[3], 0x0c030c02u));
+                pk2 dlo[16], dhi[16];
+#define ORBX_RING(k, r, dx) { const uint32_t w4 = (dx) == 0 ? Cw[r] : ((dx) > 0 ? align_byte(Rw[r], Cw[r], (dx)) : align_byte(Cw[r], Lw[r], 4 + (dx))); \
+                              dlo[k] = pk_sub(vlo, pk_make(byte_perm(0u, w4, 0x0c010c00u))); dhi[k] = pk_sub(vhi, pk_make(byte_perm(0u, w4, 0x0c030c02u))); }
+                ORBX_RING(0, 6, 0)  ORBX_RING(1, 6, 1)  ORBX_RING(2, 5, 2)  ORBX_RING(3, 4, 3)
+                ORBX_RING(4, 3, 3)  ORBX_RING(5, 2, 3)  ORBX_RING(6, 1, 2)  ORBX_RING(7, 0, 1)
+                ORBX_RING(8, 0, 0)  ORBX_RING(9, 0, -1) ORBX_RING(10, 1, -2) ORBX_RING(11, 2, -3)
+                ORBX_RING(12, 3, -3) ORBX_RING(13, 4, -3) ORBX_RING(14, 5, -2) ORBX_RING(15, 6, -1)
+#undef ORBX_RING
+                pk2 mnmx_lo = pk_max(dlo[0], dlo[8]), mxmn_lo = pk_min(dlo[0], dlo[8]);
+                pk2 mnmx_hi = pk_max(dhi[0], dhi[8]), mxmn_hi = pk_min(dhi[0], dhi[8]);
+#pragma unroll
+                for (int k = 1; k < 8; k++) {
+                    mnmx_lo = pk_min(mnmx_lo, pk_max(dlo[k], dlo[k + 8])); mxmn_lo = pk_max(mxmn_lo, pk_min(dlo[k], dlo[k + 8]));
+                    mnmx_hi = pk_min(mnmx_hi, pk_max(dhi[k], dhi[k + 8])); mxmn_hi = pk_max(mxmn_hi, pk_min(dhi[k], dhi[k + 8]));
+                }
+                const int a0 = pk_lo(mnmx_lo), a1 = pk_hi(mnmx_lo), a2 = pk_lo(mnmx_hi), a3 = pk_hi(mnmx_hi);
+                const int b0 = pk_lo(mxmn_lo), b1 = pk_hi(mxmn_lo), b2 = pk_lo(mxmn_hi), b3 = pk_hi(mxmn_hi);
+                const unsigned pass = (unsigned)((a0 > t0) | (b0 < -t0)) | ((unsigned)((a1 > t0) | (b1 < -t0)) << 1) |
+                                      ((unsigned)((a2 > t0) | (b2 < -t0)) << 2) | ((unsigned)((a3 > t0) | (b3 < -t0)) << 3);
+                unsigned valid = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) valid |= (unsigned)(xbase + j >= 0 && xbase + j < iw) << j;
+                mask = pass & valid;
+                const unsigned fail = valid & ~pass;
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (fail & (1u << j)) sc[y * iw + xbase + j] = 0;
             }
-            const unsigned long long bal = __ballot(pass);
-            if (pass) mylist[cnt + __popcll(bal & lt)] = (uint16_t)p;
-            cnt += __popcll(bal);
+            const int c4 = __popc(mask);
+            const int incl = wave_incl_scan(c4);
+            int pos = cnt + incl - c4;
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (mask & (1u << j)) mylist[pos++] = (uint16_t)(y * iw + xbase + j);
+            cnt += __shfl(incl, 63);
         }
         if (lane == 0) s_cnt[wave] = cnt;
     }
@@ -280,25 +371,6 @@ __global__ void __launch_bounds__(256) k_fast_cells(const LevelInfo* __restrict_
 // every output is one coalesced dword store.  No LDS, no barriers.
 // block (64,4): 256 columns x 4 strips.  grid (tiles over all levels, B): tile table in BlurTiles.
 constexpr int kBlurRows = 16;
-
-// byte permute: result byte i = byte sel_i (0..7) of the 8-byte pair {hi:lo}
-__device__ __forceinline__ uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
-#ifdef ORBX_EMU
-    const unsigned long long v = ((unsigned long long)hi << 32) | lo;
-    uint32_t r = 0;
-    for (int i = 0; i < 4; i++) r |= (uint32_t)((v >> (8 * ((sel >> (8 * i)) & 7))) & 0xFF) << (8 * i);
-    return r;
-#else
-    return __builtin_amdgcn_perm(hi, lo, sel);
-#endif
-}
-__device__ __forceinline__ int mul24(int a, int b) {
-#ifdef ORBX_EMU
-    return a * b;
-#else
-    return __mul24(a, b);      // operands < 2^23: full-rate 24-bit multiply instead of the quarter-rate 32-bit one
-#endif
-}
 
 __global__ void __launch_bounds__(256) k_blur(const LevelInfo* __restrict__ lv, int nlevels,
                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,

@@ -102,11 +102,16 @@ __device__ __forceinline__ void block_partition4(const uint32_t* __restrict__ sr
     const int beg = wave * seg, end = imin(c, beg + seg);
     const unsigned long long lt = (1ull << lane) - 1ull;
     int tot[4] = {0, 0, 0, 0};
-    for (int i0 = beg; i0 < end; i0 += 64) {
-        int q = -1;
-        if (i0 + lane < end) q = cls(src[s + i0 + lane]);
-        tot[0] += __popcll(__ballot(q == 0)); tot[1] += __popcll(__ballot(q == 1));
-        tot[2] += __popcll(__ballot(q == 2)); tot[3] += __popcll(__ballot(q == 3));
+    for (int i0 = beg; i0 < end; i0 += 256) {          // 4 chunks per trip: the four loads are in flight together
+        uint32_t key[4]; int q[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u + lane; key[u] = i < end ? src[s + i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            q[u] = (i0 + 64 * u + lane < end) ? cls(key[u]) : -1;
+            tot[0] += __popcll(__ballot(q[u] == 0)); tot[1] += __popcll(__ballot(q[u] == 1));
+            tot[2] += __popcll(__ballot(q[u] == 2)); tot[3] += __popcll(__ballot(q[u] == 3));
+        }
     }
     if (lane < 4) s_cnt[wave * 4 + lane] = lane == 0 ? tot[0] : lane == 1 ? tot[1] : lane == 2 ? tot[2] : tot[3];
     __syncthreads();
@@ -118,15 +123,20 @@ __device__ __forceinline__ void block_partition4(const uint32_t* __restrict__ sr
         for (int w = 0; w < 4; w++) { const int v = s_cnt[w * 4 + k]; total += v; before += w < wave ? v : 0; }
         cnt[k] = total; run[k] = acc + before; acc += total;
     }
-    for (int i0 = beg; i0 < end; i0 += 64) {
-        int q = -1; uint32_t key = 0;
-        if (i0 + lane < end) { key = src[s + i0 + lane]; q = cls(key); }
-        const unsigned long long b0 = __ballot(q == 0), b1 = __ballot(q == 1), b2 = __ballot(q == 2), b3 = __ballot(q == 3);
-        if (q >= 0) {
-            const unsigned long long bq = q == 0 ? b0 : q == 1 ? b1 : q == 2 ? b2 : b3;
-            dst[s + run[q] + __popcll(bq & lt)] = key;
+    for (int i0 = beg; i0 < end; i0 += 256) {
+        uint32_t key[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u + lane; key[u] = i < end ? src[s + i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int q = (i0 + 64 * u + lane < end) ? cls(key[u]) : -1;
+            const unsigned long long b0 = __ballot(q == 0), b1 = __ballot(q == 1), b2 = __ballot(q == 2), b3 = __ballot(q == 3);
+            if (q >= 0) {
+                const unsigned long long bq = q == 0 ? b0 : q == 1 ? b1 : q == 2 ? b2 : b3;
+                dst[s + run[q] + __popcll(bq & lt)] = key[u];
+            }
+            run[0] += __popcll(b0); run[1] += __popcll(b1); run[2] += __popcll(b2); run[3] += __popcll(b3);
         }
-        run[0] += __popcll(b0); run[1] += __popcll(b1); run[2] += __popcll(b2); run[3] += __popcll(b3);
     }
     __syncthreads();
 }
@@ -234,41 +244,70 @@ __device__ __forceinline__ void wave_partition_many(int count, IdxFn idx_of, con
     const unsigned long long lt = (1ull << lane) - 1ull;
     int j = wave;
     int idx = 0; QNode nd; nd.x0 = nd.y0 = nd.x1 = nd.y1 = 0; nd.start = 0; nd.cnt_buf = 0;
-    uint32_t key = 0;
+    uint32_t key[4] = {0, 0, 0, 0};
     if (j < count) {
         idx = idx_of(j); nd = cur[idx];
         const int c = node_cnt(nd);
-        if (c > 1 && c <= 64 && lane < c) key = (node_buf(nd) ? bufB : bufA)[nd.start + lane];
+        if (c > 1 && c <= 256) {
+            const uint32_t* sp = (node_buf(nd) ? bufB : bufA) + nd.start;
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (64 * u + lane < c) key[u] = sp[64 * u + lane];
+        }
     }
     while (j < count) {
         const int jn = j + 4;
-        int idxn = 0; QNode ndn = nd; uint32_t keyn = 0;
-        if (jn < count) {
+        int idxn = 0; QNode ndn = nd; uint32_t keyn[4] = {0, 0, 0, 0};
+        if (jn < count) {           // request the next node's keys before working on this one
             idxn = idx_of(jn); ndn = cur[idxn];
             const int cn = node_cnt(ndn);
-            if (cn > 1 && cn <= 64 && lane < cn) keyn = (node_buf(ndn) ? bufB : bufA)[ndn.start + lane];
+            if (cn > 1 && cn <= 256) {
+                const uint32_t* sp = (node_buf(ndn) ? bufB : bufA) + ndn.start;
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (64 * u + lane < cn) keyn[u] = sp[64 * u + lane];
+            }
         }
         const int c = node_cnt(nd);
         if (c > 1 && c <= kBigSpan) {
             int cnt[4];
             const int bsel = node_buf(nd);
-            if (c <= 64) {
+            if (c <= 256) {
                 const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
-                int q = -1;
-                if (lane < c) { const bool left = key_x(key) < mx, top = key_y(key) < my; q = left ? (top ? 0 : 2) : (top ? 1 : 3); }
-                const unsigned long long b0 = __ballot(q == 0), b1 = __ballot(q == 1), b2 = __ballot(q == 2), b3 = __ballot(q == 3);
-                cnt[0] = __popcll(b0); cnt[1] = __popcll(b1); cnt[2] = __popcll(b2); cnt[3] = __popcll(b3);
-                if (q >= 0) {
-                    const unsigned long long bq = q == 0 ? b0 : q == 1 ? b1 : q == 2 ? b2 : b3;
-                    const int base = q == 0 ? 0 : q == 1 ? cnt[0] : q == 2 ? cnt[0] + cnt[1] : cnt[0] + cnt[1] + cnt[2];
-                    (bsel ? bufA : bufB)[nd.start + base + __popcll(bq & lt)] = key;
+                unsigned long long bal[4][4];
+                int q[4];
+                cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    q[u] = -1;
+                    if (64 * u + lane < c) { const bool left = key_x(key[u]) < mx, top = key_y(key[u]) < my; q[u] = left ? (top ? 0 : 2) : (top ? 1 : 3); }
+                    if (64 * u < c) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { bal[u][k] = __ballot(q[u] == k); cnt[k] += __popcll(bal[u][k]); }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) bal[u][k] = 0;
+                    }
+                }
+                uint32_t* dp = (bsel ? bufA : bufB) + nd.start;
+                int run[4] = {0, cnt[0], cnt[0] + cnt[1], cnt[0] + cnt[1] + cnt[2]};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (q[u] >= 0) {
+                        const int k = q[u];
+                        const unsigned long long bq = k == 0 ? bal[u][0] : k == 1 ? bal[u][1] : k == 2 ? bal[u][2] : bal[u][3];
+                        const int base = k == 0 ? run[0] : k == 1 ? run[1] : k == 2 ? run[2] : run[3];
+                        dp[base + __popcll(bq & lt)] = key[u];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) run[k] += __popcll(bal[u][k]);
                 }
             } else {
                 wave_partition(nd, bsel ? bufB : bufA, bsel ? bufA : bufB, cnt);
             }
             if (lane < 4) childcnt[4 * idx + lane] = (uint32_t)(lane == 0 ? cnt[0] : lane == 1 ? cnt[1] : lane == 2 ? cnt[2] : cnt[3]);
         }
-        j = jn; idx = idxn; nd = ndn; key = keyn;
+        j = jn; idx = idxn; nd = ndn;
+#pragma unroll
+        for (int u = 0; u < 4; u++) key[u] = keyn[u];
     }
 }
 struct IdentityIdx { __device__ __forceinline__ int operator()(int j) const { return j; } };
