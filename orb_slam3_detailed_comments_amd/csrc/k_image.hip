@@ -197,7 +197,18 @@ __device__ __forceinline__ int fast_full(const int d[16], int t0) {
 //   D  threshold choice of the reference (FAST at iniTh; if that yields nothing, FAST at minTh, :1135-1148) and
 //      ordered compaction into the cell's slot list.
 // slots: per-cell candidate lists in the reference order; cell_count[b*ncells + cell] = number kept.
-__global__ void __launch_bounds__(256) k_fast_cells(const LevelInfo* __restrict__ lv,
+constexpr int kFastWaves = 1;                       // waves per FAST workgroup (one cell per workgroup)
+constexpr int kFastThreads = 64 * kFastWaves;
+
+// position of the i-th survivor in the concatenation of the per-wave lists (wave w's list starts at w*q)
+__device__ __forceinline__ int list_index(int i, const int* s_cnt, int q) {
+    int w = 0;
+#pragma unroll
+    for (int k = 0; k < kFastWaves - 1; k++) { const int c = s_cnt[w]; if (i >= c) { i -= c; w++; } }
+    return w * q + i;
+}
+
+__global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __restrict__ lv,
                                                     const CellInfo* __restrict__ cells, int ncells,
                                                     const uint8_t* __restrict__ pyr, size_t pyr_stride,
                                                     int iniTh, int minTh,
@@ -205,8 +216,8 @@ __global__ void __launch_bounds__(256) k_fast_cells(const LevelInfo* __restrict_
                                                     int* __restrict__ cell_count, int tile_bytes, int inner_bytes) {
     ORBX_DYN_SMEM(smem);
     __shared__ int s_flags[2];
-    __shared__ int s_cnt[4];
-    __shared__ int s_wave[4];
+    __shared__ int s_cnt[kFastWaves];
+    __shared__ int s_wave[kFastWaves];
     const int cell = (int)blockIdx.x, b = (int)blockIdx.y;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const CellInfo ci = cells[cell];
@@ -224,7 +235,7 @@ __global__ void __launch_bounds__(256) k_fast_cells(const LevelInfo* __restrict_
     uint8_t* sc = smem + tile_bytes;
     uint16_t* list = (uint16_t*)(sc + inner_bytes);
     const uint8_t* img = pyr + (size_t)b * pyr_stride + L.off;
-    for (int i = tid; i < wh * wpd; i += 256) {
+    for (int i = tid; i < wh * wpd; i += kFastThreads) {
         const int r = i / wpd, c = i - r * wpd;
         ((uint32_t*)tile)[i] = *(const uint32_t*)(img + (size_t)(ci.y0 - 3 + r) * L.pitch + gx0 + 4 * c);
     }
@@ -239,7 +250,7 @@ __global__ void __launch_bounds__(256) k_fast_cells(const LevelInfo* __restrict_
     // and the exact opposite-pair rejection runs on two pixels per instruction (v_pk_sub/min/max_i16).
     const int g0 = (xo + 3) >> 2, ng = ((xo + 3 + iw - 1) >> 2) - g0 + 1;
     const int nitems = ih * ng;
-    const int qi = (nitems + 3) >> 2;                      // items per wave (contiguous ranges keep the list row-major)
+    const int qi = (nitems + kFastWaves - 1) / kFastWaves;   // items per wave (contiguous ranges keep the list row-major)
     const int q = qi * 4;                                  // list capacity per wave (pixels)
     {
         const unsigned Mg = (1u << 20) / (unsigned)ng + 1u;
@@ -297,11 +308,11 @@ __global__ void __launch_bounds__(256) k_fast_cells(const LevelInfo* __restrict_
         if (lane == 0) s_cnt[wave] = cnt;
     }
     __syncthreads();
-    const int n0 = s_cnt[0], n1 = s_cnt[1], n2 = s_cnt[2], n3 = s_cnt[3];
-    const int total = n0 + n1 + n2 + n3;
+    int total = 0;
+    for (int w = 0; w < kFastWaves; w++) total += s_cnt[w];
     // ---- B ----
-    for (int i = tid; i < total; i += 256) {
-        const int li = i < n0 ? i : (i < n0 + n1 ? q + i - n0 : (i < n0 + n1 + n2 ? 2 * q + i - n0 - n1 : 3 * q + i - n0 - n1 - n2));
+    for (int i = tid; i < total; i += kFastThreads) {
+        const int li = list_index(i, s_cnt, q);
         const int p = list[li];
         const int y = (int)(((unsigned)p * M) >> 20), x = p - y * iw;
         int d[16];
@@ -311,8 +322,8 @@ __global__ void __launch_bounds__(256) k_fast_cells(const LevelInfo* __restrict_
     __syncthreads();
     // ---- C ----
     int any_hi = 0;
-    for (int i = tid; i < total; i += 256) {
-        const int li = i < n0 ? i : (i < n0 + n1 ? q + i - n0 : (i < n0 + n1 + n2 ? 2 * q + i - n0 - n1 : 3 * q + i - n0 - n1 - n2));
+    for (int i = tid; i < total; i += kFastThreads) {
+        const int li = list_index(i, s_cnt, q);
         const int p = list[li];
         const int y = (int)(((unsigned)p * M) >> 20), x = p - y * iw;
         const int s = sc[p];
@@ -338,11 +349,11 @@ __global__ void __launch_bounds__(256) k_fast_cells(const LevelInfo* __restrict_
     const int thr = s_flags[0] ? iniTh : minTh;
     uint32_t* out = slots + (size_t)b * slots_stride + ci.slot_off;
     int base = 0;
-    for (int i0 = 0; i0 < total; i0 += 256) {
+    for (int i0 = 0; i0 < total; i0 += kFastThreads) {
         const int i = i0 + tid;
         int flag = 0, p = 0, s = 0;
         if (i < total) {
-            const int li = i < n0 ? i : (i < n0 + n1 ? q + i - n0 : (i < n0 + n1 + n2 ? 2 * q + i - n0 - n1 : 3 * q + i - n0 - n1 - n2));
+            const int li = list_index(i, s_cnt, q);
             const int e = list[li];
             p = e & 0x7FFF;
             s = sc[p];
@@ -352,7 +363,7 @@ __global__ void __launch_bounds__(256) k_fast_cells(const LevelInfo* __restrict_
         if (lane == 0) s_wave[wave] = __popcll(bal);
         __syncthreads();
         int wbase = 0, tot = 0;
-        for (int w = 0; w < 4; w++) { const int c = s_wave[w]; if (w < wave) wbase += c; tot += c; }
+        for (int w = 0; w < kFastWaves; w++) { const int c = s_wave[w]; if (w < wave) wbase += c; tot += c; }
         if (flag) {
             const int y = (int)(((unsigned)p * M) >> 20), x = p - y * iw;
             out[base + wbase + __popcll(bal & lt)] = key_pack(ci.x0 + x - kBorder, ci.y0 + y - kBorder, s);

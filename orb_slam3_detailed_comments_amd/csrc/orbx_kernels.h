@@ -9,6 +9,7 @@ __global__ void k_import(const LevelInfo* __restrict__ lv, const uint8_t* __rest
 __global__ void k_resize(const LevelInfo* __restrict__ lv, int level, const ResizeTap* __restrict__ xtab,
                          const ResizeTap* __restrict__ ytab, uint8_t* __restrict__ pyr, size_t pyr_stride,
                          int lds_pitch, int lds_rows);
+constexpr int kFastThreadsDecl = 64;   // must equal kFastThreads in k_image.hip
 __global__ void k_fast_cells(const LevelInfo* __restrict__ lv, const CellInfo* __restrict__ cells, int ncells,
                              const uint8_t* __restrict__ pyr, size_t pyr_stride, int iniTh, int minTh,
                              uint32_t* __restrict__ slots, size_t slots_stride, int* __restrict__ cell_count,
