@@ -93,19 +93,21 @@ __global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restric
     const uint8_t* raw = pyr + (size_t)b * pyr_stride + L.off + (size_t)y * L.pitch + x;
     const int half = lane >> 5, col = lane & 31, u = col - kHalfPatch;
     int m10 = 0, m01 = 0;
-    if (col < 31) {
-#pragma unroll 4
+    {
+        // all 16 row loads of this lane are issued back to back (masked lanes read the centre pixel and weigh it 0),
+        // so the gather costs one memory round trip instead of sixteen dependent ones
+        int I[16], wu[16], wv[16];
+#pragma unroll
         for (int it = 0; it < 16; it++) {
             const int v = half ? it + 1 : -it;
             const int av = v < 0 ? -v : v;
-            if (av <= kHalfPatch) {
-                const int au = u < 0 ? -u : u;
-                if (au <= umax.u[av]) {
-                    const int I = raw[(ptrdiff_t)v * L.pitch + u];
-                    m10 += u * I; m01 += v * I;
-                }
-            }
+            const int au = u < 0 ? -u : u;
+            const bool on = col < 31 && av <= kHalfPatch && au <= umax.u[av <= kHalfPatch ? av : 0];
+            I[it] = raw[on ? ((ptrdiff_t)v * L.pitch + u) : 0];
+            wu[it] = on ? u : 0; wv[it] = on ? v : 0;
         }
+#pragma unroll
+        for (int it = 0; it < 16; it++) { m10 += wu[it] * I[it]; m01 += wv[it] * I[it]; }
     }
     m10 = wave_sum(m10); m01 = wave_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
@@ -116,17 +118,21 @@ __global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restric
     const uint8_t* ctr = blur + (size_t)b * pyr_stride + L.off + (size_t)y * L.pitch + x;
     const int fi = final_idx[(size_t)b * kp_total_cap + slot];
     unsigned long long mine = 0;
+    int t0v[4], t1v[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < 4; r++) {       // 8 independent gathers in flight
         const signed char* p = &BRIEF_PATTERN[4 * (64 * r + lane)];
         const float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
         const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, bb), __fmul_rn(y0, a)));
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, bb)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, bb), __fmul_rn(y1, a)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, bb)));
-        const int t0 = ctr[(ptrdiff_t)r0 * L.pitch + c0];
-        const int t1 = ctr[(ptrdiff_t)r1 * L.pitch + c1];
-        const unsigned long long w = __ballot(t0 < t1);
+        t0v[r] = ctr[(ptrdiff_t)r0 * L.pitch + c0];
+        t1v[r] = ctr[(ptrdiff_t)r1 * L.pitch + c1];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const unsigned long long w = __ballot(t0v[r] < t1v[r]);
         if (lane == r) mine = w;
     }
     if (lane < 4) out_desc[((size_t)b * kp_total_cap + fi) * 4 + lane] = mine;

@@ -197,6 +197,26 @@ __device__ __forceinline__ int fast_full(const int d[16], int t0) {
 //   D  threshold choice of the reference (FAST at iniTh; if that yields nothing, FAST at minTh, :1135-1148) and
 //      ordered compaction into the cell's slot list.
 // slots: per-cell candidate lists in the reference order; cell_count[b*ncells + cell] = number kept.
+// fast_full for two pixels at once (packed 16-bit lanes); d[k] = (v - ring_k) of pixel A in .x and pixel B in .y
+__device__ __forceinline__ void fast_full_pk(const pk2 d[16], int t0, int& sA, int& sB) {
+    pk2 mn2[16], mx2[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn2[k] = pk_min(d[k], d[(k + 1) & 15]); mx2[k] = pk_max(d[k], d[(k + 1) & 15]); }
+    pk2 mn4[16], mx4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn4[k] = pk_min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = pk_max(mx2[k], mx2[(k + 2) & 15]); }
+    pk2 Md = pk_min(pk_min(mn4[0], mn4[4]), d[8]);          // max over arcs of the arc minimum (dark)
+    pk2 Mx = pk_max(pk_max(mx4[0], mx4[4]), d[8]);          // min over arcs of the arc maximum (bright, negated below)
+#pragma unroll
+    for (int k = 1; k < 16; k++) {
+        Md = pk_max(Md, pk_min(pk_min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]));
+        Mx = pk_min(Mx, pk_max(pk_max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]));
+    }
+    const int mA = imax(pk_lo(Md), -pk_lo(Mx)), mB = imax(pk_hi(Md), -pk_hi(Mx));
+    sA = mA > t0 ? mA - 1 : 0;
+    sB = mB > t0 ? mB - 1 : 0;
+}
+
 constexpr int kFastWaves = 1;                       // waves per FAST workgroup (one cell per workgroup)
 constexpr int kFastThreads = 64 * kFastWaves;
 
@@ -239,6 +259,7 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
         const int r = i / wpd, c = i - r * wpd;
         ((uint32_t*)tile)[i] = *(const uint32_t*)(img + (size_t)(ci.y0 - 3 + r) * L.pitch + gx0 + 4 * c);
     }
+    for (int i = tid; i < (inner_bytes >> 2); i += kFastThreads) ((uint32_t*)sc)[i] = 0u;   // scores default to 0 (not a corner)
     if (tid == 0) s_flags[0] = 0;
     __syncthreads();
     const int t0 = imin(iniTh, minTh);
@@ -253,50 +274,49 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
     const int qi = (nitems + kFastWaves - 1) / kFastWaves;   // items per wave (contiguous ranges keep the list row-major)
     const int q = qi * 4;                                  // list capacity per wave (pixels)
     {
-        const unsigned Mg = (1u << 20) / (unsigned)ng + 1u;
         const int ibeg = wave * qi, iend = imin(nitems, ibeg + qi);
         uint16_t* mylist = list + wave * q;
         const uint32_t* tile32 = (const uint32_t*)tile;
         int cnt = 0;
+        // (row, group) of this lane's item, advanced incrementally by 64 items per trip (no per-trip division)
+        int y = (ibeg + lane) / ng, gi = (ibeg + lane) - y * ng;
+        const int dq = 64 / ng, dr = 64 - dq * ng;
         for (int it0 = ibeg; it0 < iend; it0 += 64) {
             const int it = it0 + lane;
-            unsigned mask = 0; int y = 0, xbase = 0;
+            unsigned mask = 0; int xbase = 0;
             if (it < iend) {
-                y = (int)(((unsigned)it * Mg) >> 20);
-                const int g = g0 + (it - y * ng);
+                const int g = g0 + gi;
                 xbase = 4 * g - (xo + 3);                  // interior x of this lane's first pixel (may be < 0)
                 const uint32_t* rp = tile32 + (y + 3) * wpd + g;
                 uint32_t Lw[7], Cw[7], Rw[7];
 #pragma unroll
                 for (int r = 0; r < 7; r++) { const uint32_t* pr = rp + (r - 3) * wpd; Lw[r] = pr[-1]; Cw[r] = pr[0]; Rw[r] = pr[1]; }
-                // row index r = dy + 3
-                const pk2 vlo = pk_make(byte_perm(0u, Cw[3], 0x0c010c00u)), vhi = pk_make(byte_perm(0u, Cw[3], 0x0c030c02u));
-                pk2 dlo[16], dhi[16];
+                // ring bytes of the 4 pixels, widened to 2 x (2 x u16); row index r = dy + 3
+                pk2 rlo[16], rhi[16];
 #define ORBX_RING(k, r, dx) { const uint32_t w4 = (dx) == 0 ? Cw[r] : ((dx) > 0 ? align_byte(Rw[r], Cw[r], (dx)) : align_byte(Cw[r], Lw[r], 4 + (dx))); \
-                              dlo[k] = pk_sub(vlo, pk_make(byte_perm(0u, w4, 0x0c010c00u))); dhi[k] = pk_sub(vhi, pk_make(byte_perm(0u, w4, 0x0c030c02u))); }
+                              rlo[k] = pk_make(byte_perm(0u, w4, 0x0c010c00u)); rhi[k] = pk_make(byte_perm(0u, w4, 0x0c030c02u)); }
                 ORBX_RING(0, 6, 0)  ORBX_RING(1, 6, 1)  ORBX_RING(2, 5, 2)  ORBX_RING(3, 4, 3)
                 ORBX_RING(4, 3, 3)  ORBX_RING(5, 2, 3)  ORBX_RING(6, 1, 2)  ORBX_RING(7, 0, 1)
                 ORBX_RING(8, 0, 0)  ORBX_RING(9, 0, -1) ORBX_RING(10, 1, -2) ORBX_RING(11, 2, -3)
                 ORBX_RING(12, 3, -3) ORBX_RING(13, 4, -3) ORBX_RING(14, 5, -2) ORBX_RING(15, 6, -1)
 #undef ORBX_RING
-                pk2 mnmx_lo = pk_max(dlo[0], dlo[8]), mxmn_lo = pk_min(dlo[0], dlo[8]);
-                pk2 mnmx_hi = pk_max(dhi[0], dhi[8]), mxmn_hi = pk_min(dhi[0], dhi[8]);
+                // a dark 9-arc needs min(ring_k, ring_k+8) < v - t for all 8 pairs, a bright one max(..) > v + t:
+                //   M = max_k min(pair) ,  N = min_k max(pair) ;  possible corner  <=>  v - M > t  or  N - v > t
+                pk2 M_lo = pk_min(rlo[0], rlo[8]), N_lo = pk_max(rlo[0], rlo[8]);
+                pk2 M_hi = pk_min(rhi[0], rhi[8]), N_hi = pk_max(rhi[0], rhi[8]);
 #pragma unroll
                 for (int k = 1; k < 8; k++) {
-                    mnmx_lo = pk_min(mnmx_lo, pk_max(dlo[k], dlo[k + 8])); mxmn_lo = pk_max(mxmn_lo, pk_min(dlo[k], dlo[k + 8]));
-                    mnmx_hi = pk_min(mnmx_hi, pk_max(dhi[k], dhi[k + 8])); mxmn_hi = pk_max(mxmn_hi, pk_min(dhi[k], dhi[k + 8]));
+                    M_lo = pk_max(M_lo, pk_min(rlo[k], rlo[k + 8])); N_lo = pk_min(N_lo, pk_max(rlo[k], rlo[k + 8]));
+                    M_hi = pk_max(M_hi, pk_min(rhi[k], rhi[k + 8])); N_hi = pk_min(N_hi, pk_max(rhi[k], rhi[k + 8]));
                 }
-                const int a0 = pk_lo(mnmx_lo), a1 = pk_hi(mnmx_lo), a2 = pk_lo(mnmx_hi), a3 = pk_hi(mnmx_hi);
-                const int b0 = pk_lo(mxmn_lo), b1 = pk_hi(mxmn_lo), b2 = pk_lo(mxmn_hi), b3 = pk_hi(mxmn_hi);
-                const unsigned pass = (unsigned)((a0 > t0) | (b0 < -t0)) | ((unsigned)((a1 > t0) | (b1 < -t0)) << 1) |
-                                      ((unsigned)((a2 > t0) | (b2 < -t0)) << 2) | ((unsigned)((a3 > t0) | (b3 < -t0)) << 3);
-                unsigned valid = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) valid |= (unsigned)(xbase + j >= 0 && xbase + j < iw) << j;
+                const pk2 vlo = pk_make(byte_perm(0u, Cw[3], 0x0c010c00u)), vhi = pk_make(byte_perm(0u, Cw[3], 0x0c030c02u));
+                const pk2 dk_lo = pk_sub(vlo, M_lo), dk_hi = pk_sub(vhi, M_hi), br_lo = pk_sub(N_lo, vlo), br_hi = pk_sub(N_hi, vhi);
+                const pk2 best_lo = pk_max(dk_lo, br_lo), best_hi = pk_max(dk_hi, br_hi);
+                const unsigned pass = (unsigned)(pk_lo(best_lo) > t0) | ((unsigned)(pk_hi(best_lo) > t0) << 1) |
+                                      ((unsigned)(pk_lo(best_hi) > t0) << 2) | ((unsigned)(pk_hi(best_hi) > t0) << 3);
+                const int lo = imax(0, -xbase), hi = imin(4, iw - xbase);          // valid pixels j in [lo, hi)
+                const unsigned valid = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
                 mask = pass & valid;
-                const unsigned fail = valid & ~pass;
-#pragma unroll
-                for (int j = 0; j < 4; j++) if (fail & (1u << j)) sc[y * iw + xbase + j] = 0;
             }
             const int c4 = __popc(mask);
             const int incl = wave_incl_scan(c4);
@@ -304,20 +324,35 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
 #pragma unroll
             for (int j = 0; j < 4; j++) if (mask & (1u << j)) mylist[pos++] = (uint16_t)(y * iw + xbase + j);
             cnt += __shfl(incl, 63);
+            gi += dr; y += dq;
+            if (gi >= ng) { gi -= ng; y++; }
         }
         if (lane == 0) s_cnt[wave] = cnt;
     }
     __syncthreads();
     int total = 0;
     for (int w = 0; w < kFastWaves; w++) total += s_cnt[w];
-    // ---- B ----
-    for (int i = tid; i < total; i += kFastThreads) {
-        const int li = list_index(i, s_cnt, q);
-        const int p = list[li];
-        const int y = (int)(((unsigned)p * M) >> 20), x = p - y * iw;
-        int d[16];
-        fast_ring(tile + (y + 3) * wp + xo + x + 3, wp, d);
-        sc[p] = (uint8_t)fast_full(d, t0);
+    // ---- B ----  full score, two listed pixels per lane (packed lanes)
+    for (int i = 2 * tid; i < total; i += 2 * kFastThreads) {
+        const int pA = list[list_index(i, s_cnt, q)];
+        const bool hasB = i + 1 < total;
+        const int pB = hasB ? list[list_index(i + 1, s_cnt, q)] : pA;
+        const int yA = (int)(((unsigned)pA * M) >> 20), xA = pA - yA * iw;
+        const int yB = (int)(((unsigned)pB * M) >> 20), xB = pB - yB * iw;
+        const uint8_t* cA = tile + (yA + 3) * wp + xo + xA + 3;
+        const uint8_t* cB = tile + (yB + 3) * wp + xo + xB + 3;
+        const pk2 v2 = pk_make((uint32_t)cA[0] | ((uint32_t)cB[0] << 16));
+        pk2 d[16];
+#define ORBX_D(k, off) d[k] = pk_sub(v2, pk_make((uint32_t)cA[off] | ((uint32_t)cB[off] << 16)));
+        ORBX_D(0, 3 * wp)       ORBX_D(1, 3 * wp + 1)    ORBX_D(2, 2 * wp + 2)    ORBX_D(3, wp + 3)
+        ORBX_D(4, 3)            ORBX_D(5, -wp + 3)       ORBX_D(6, -2 * wp + 2)   ORBX_D(7, -3 * wp + 1)
+        ORBX_D(8, -3 * wp)      ORBX_D(9, -3 * wp - 1)   ORBX_D(10, -2 * wp - 2)  ORBX_D(11, -wp - 3)
+        ORBX_D(12, -3)          ORBX_D(13, wp - 3)       ORBX_D(14, 2 * wp - 2)   ORBX_D(15, 3 * wp - 1)
+#undef ORBX_D
+        int sA, sB;
+        fast_full_pk(d, t0, sA, sB);
+        sc[pA] = (uint8_t)sA;
+        if (hasB) sc[pB] = (uint8_t)sB;
     }
     __syncthreads();
     // ---- C ----
