@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restric
                                                       const uint32_t* __restrict__ lvl_keys, int kp_total_cap,
                                                       const int* __restrict__ lvl_count, const int* __restrict__ final_idx,
                                                       UmaxTab umax, KeyPointRec* __restrict__ out_kps,
-                                                      unsigned long long* __restrict__ out_desc) {
+                                                      unsigned long long* __restrict__ out_desc, int4* __restrict__ out_aux) {
     const int b = (int)blockIdx.y;
     const int lane = lane_id();
     const int slot = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
@@ -143,6 +143,11 @@ __global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restric
         k.x = xf; k.y = yf; k.size = (float)L.patch; k.angle = angle; k.response = (float)key_s(key);
         k.octave = level; k.class_id = -1;
         out_kps[(size_t)b * kp_total_cap + fi] = k;
+        // compact 16-byte record for the stereo row search (Frame::ComputeStereoMatches, src/Frame.cc:1141-1155): the band of
+        // image rows [floor(y - r), ceil(y + r)], r = 2 * scale, in which this keypoint is a candidate; x; octave
+        const float r = __fmul_rn(2.0f, L.scale);
+        int4 aux; aux.x = (int)floorf(__fsub_rn(yf, r)); aux.y = (int)ceilf(__fadd_rn(yf, r)); aux.z = __float_as_int(xf); aux.w = level;
+        out_aux[(size_t)b * kp_total_cap + fi] = aux;
     }
 }
 

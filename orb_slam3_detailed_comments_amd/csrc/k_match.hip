@@ -28,12 +28,10 @@ __global__ void __launch_bounds__(256) k_hamming_matrix(const unsigned long long
 // kpsL/descL/nL: left extractor outputs (stride cap); same for right; pyrL/pyrR: raw pyramids.
 __global__ void __launch_bounds__(256) k_stereo_match(const LevelInfo* __restrict__ lv,
                                                       const KeyPointRec* __restrict__ kpsL, const unsigned long long* __restrict__ descL, const int* __restrict__ nL,
-                                                      const KeyPointRec* __restrict__ kpsR, const unsigned long long* __restrict__ descR, const int* __restrict__ nR,
+                                                      const KeyPointRec* __restrict__ kpsR, const unsigned long long* __restrict__ descR,
+                                                      const int4* __restrict__ auxR, const int* __restrict__ nR,
                                                       int cap, const uint8_t* __restrict__ pyrL, const uint8_t* __restrict__ pyrR, size_t pyr_stride,
                                                       StereoParams P, float* __restrict__ uRight, float* __restrict__ depth, int* __restrict__ sad) {
-    __shared__ float s_scale[kMaxLevels];
-    if (threadIdx.x < kMaxLevels) s_scale[threadIdx.x] = lv[threadIdx.x].scale;
-    __syncthreads();
     const int b = (int)blockIdx.y, lane = lane_id();
     const int iL = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     if (iL >= cap) return;
@@ -51,23 +49,21 @@ __global__ void __launch_bounds__(256) k_stereo_match(const LevelInfo* __restric
     if (!(maxU < 0)) {
         const unsigned long long* dl = descL + 4 * o;
         const unsigned long long d0 = dl[0], d1 = dl[1], d2 = dl[2], d3 = dl[3];
-        const KeyPointRec* kr = kpsR + (size_t)b * cap;
+        const int4* ar = auxR + (size_t)b * cap;          // {first row, last row, x bits, octave}: one coalesced 16-B load per candidate
         for (int base = 0; base < nr; base += 256) {      // 4 right keypoints per lane per trip, their loads in flight together
-            float ky[4], kx[4]; int ko[4];
+            int4 a[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int iR = base + 64 * u + lane;
-                const bool in = iR < nr;
-                ky[u] = in ? kr[iR].y : 0.f; kx[u] = in ? kr[iR].x : 0.f; ko[u] = in ? kr[iR].octave : -100;
+                if (iR < nr) a[u] = ar[iR]; else { a[u].x = 1; a[u].y = 0; a[u].z = 0; a[u].w = 0; }   // empty band
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int iR = base + 64 * u + lane;
-                if (ko[u] < levelL - 1 || ko[u] > levelL + 1) continue;      // also rejects the padding lanes
-                const float r = __fmul_rn(2.0f, s_scale[ko[u]]);
-                const int maxr = (int)ceilf(__fadd_rn(ky[u], r)), minr = (int)floorf(__fsub_rn(ky[u], r));
-                if (rowL < minr || rowL > maxr) continue;
-                if (kx[u] >= minU && kx[u] <= maxU) {
+                if (rowL < a[u].x || rowL > a[u].y) continue;
+                if (a[u].w < levelL - 1 || a[u].w > levelL + 1) continue;
+                const float xr = __int_as_float(a[u].z);
+                if (xr >= minU && xr <= maxU) {
                     const unsigned long long* dr = descR + 4 * ((size_t)b * cap + iR);
                     const int dist = __popcll(d0 ^ dr[0]) + __popcll(d1 ^ dr[1]) + __popcll(d2 ^ dr[2]) + __popcll(d3 ^ dr[3]);
                     const unsigned cand = ((unsigned)dist << 16) | (unsigned)iR;

@@ -165,7 +165,7 @@ int configure(orbx_extractor* h, int W, int H, int B) {
         e |= h->d_cell_count.ensure(b * h->ncells); e |= h->d_lvl_count.ensure(b * h->nlevels);
         e |= h->d_lvl_keys.ensure(b * cap); e |= h->d_final_idx.ensure(b * cap);
         e |= h->d_nm.ensure(2 * b); e |= h->d_status.ensure(4);
-        e |= h->d_kps.ensure(b * cap); e |= h->d_desc.ensure(b * cap * 4);
+        e |= h->d_kps.ensure(b * cap); e |= h->d_desc.ensure(b * cap * 4); e |= h->d_aux.ensure(b * cap * 4);
         e |= h->d_uRight.ensure(b * cap); e |= h->d_depth.ensure(b * cap); e |= h->d_sad.ensure(b * cap); e |= h->d_nmatch.ensure(b);
         e |= h->d_knn.ensure(4 * b * cap); e |= h->d_ratio.ensure(b * cap);
         e |= h->h_nm.ensure(3 * b + 4); e |= h->d_qtprof.ensure(32);
@@ -249,7 +249,7 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int strid
         dim3 grid((h->kp_total_cap + 3) / 4, B, 1);
         ORBX_LAUNCH(k_orient_brief, grid, blk1, 0, h->s0, (const LevelInfo*)h->d_lv.p, nl, (const uint8_t*)h->d_pyr.p, (const uint8_t*)h->d_blur.p,
                     h->pyr_stride, (const uint32_t*)h->d_lvl_keys.p, h->kp_total_cap, (const int*)h->d_lvl_count.p, (const int*)h->d_final_idx.p,
-                    h->umax, h->d_kps.p, h->d_desc.p);
+                    h->umax, h->d_kps.p, h->d_desc.p, (int4*)h->d_aux.p);
     }
     stage_end(h, ST_DESCRIBE, h->s0);
     rt::event_record(h->ev_done, h->s0);
@@ -300,6 +300,7 @@ void orbx_destroy(orbx_extractor* h) {
     h->d_hamA.release(); h->d_hamB.release(); h->d_hamOut.release(); h->h_stage.release(); h->h_nm.release();
     for (auto& x : h->d_sr) x.release();
     for (auto& x : h->d_si) x.release();
+    h->d_aux.release(); h->d_qtprof.release();
     delete h;
 }
 
@@ -512,7 +513,8 @@ int orbm_stereo_match(orbx_extractor* L, int lf, orbx_extractor* R, int rf, int 
     dim3 grid((cap + 3) / 4, B, 1), blk(256, 1, 1);
     ORBX_LAUNCH(k_stereo_match, grid, blk, 0, L->s0, (const LevelInfo*)L->d_lv.p,
                 (const KeyPointRec*)(L->d_kps.p + (size_t)lf * cap), (const unsigned long long*)(L->d_desc.p + (size_t)lf * cap * 4), (const int*)(L->d_nm.p + lf),
-                (const KeyPointRec*)(R->d_kps.p + (size_t)rf * cap), (const unsigned long long*)(R->d_desc.p + (size_t)rf * cap * 4), (const int*)(R->d_nm.p + rf),
+                (const KeyPointRec*)(R->d_kps.p + (size_t)rf * cap), (const unsigned long long*)(R->d_desc.p + (size_t)rf * cap * 4),
+                (const int4*)(R->d_aux.p + (size_t)rf * cap * 4), (const int*)(R->d_nm.p + rf),
                 cap, (const uint8_t*)(L->d_pyr.p + (size_t)lf * L->pyr_stride), (const uint8_t*)(R->d_pyr.p + (size_t)rf * R->pyr_stride), L->pyr_stride,
                 P, L->d_uRight.p, L->d_depth.p, L->d_sad.p);
     dim3 grid2(B, 1, 1);

@@ -78,4 +78,5 @@ struct orbx_extractor {
     orbx::DevBuf<uint8_t> d_sr[12];
     orbx::DevBuf<int> d_si[8];
     orbx::DevBuf<long long> d_qtprof;
+    orbx::DevBuf<int> d_aux;     // int4 per keypoint: stereo row band / x / octave (k_orient_brief -> k_stereo_match)
 };

@@ -67,6 +67,7 @@ struct BowParams {
 };
 #ifdef ORBX_EMU
 struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
 #endif
 
 // quadtree node, 16 B, lives in LDS
