@@ -239,16 +239,16 @@ __device__ __forceinline__ void block_sort_libstdcxx(unsigned long long* a, unsi
 template <typename IdxFn>
 __device__ __forceinline__ void wave_partition_many(int count, IdxFn idx_of, const QNode* __restrict__ cur,
                                                     uint32_t* __restrict__ bufA, uint32_t* __restrict__ bufB,
-                                                    uint32_t* __restrict__ childcnt) {
+                                                    uint32_t* __restrict__ childcnt, int D) {
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     const unsigned long long lt = (1ull << lane) - 1ull;
     int j = wave;
-    int idx = 0; QNode nd; nd.x0 = nd.y0 = nd.x1 = nd.y1 = 0; nd.start = 0; nd.cnt_buf = 0;
+    int idx = 0; QNode nd; nd.x0 = nd.y0 = nd.x1 = nd.y1 = 0; nd.start = 0; nd.cnt_buf = 0; nd.code = 0; nd.depth = 0;
     uint32_t key[4] = {0, 0, 0, 0};
     if (j < count) {
         idx = idx_of(j); nd = cur[idx];
         const int c = node_cnt(nd);
-        if (c > 1 && c <= 256) {
+        if (c > 1 && c <= 256 && (int)nd.depth >= D) {
             const uint32_t* sp = (node_buf(nd) ? bufB : bufA) + nd.start;
 #pragma unroll
             for (int u = 0; u < 4; u++) if (64 * u + lane < c) key[u] = sp[64 * u + lane];
@@ -260,14 +260,14 @@ __device__ __forceinline__ void wave_partition_many(int count, IdxFn idx_of, con
         if (jn < count) {           // request the next node's keys before working on this one
             idxn = idx_of(jn); ndn = cur[idxn];
             const int cn = node_cnt(ndn);
-            if (cn > 1 && cn <= 256) {
+            if (cn > 1 && cn <= 256 && (int)ndn.depth >= D) {
                 const uint32_t* sp = (node_buf(ndn) ? bufB : bufA) + ndn.start;
 #pragma unroll
                 for (int u = 0; u < 4; u++) if (64 * u + lane < cn) keyn[u] = sp[64 * u + lane];
             }
         }
         const int c = node_cnt(nd);
-        if (c > 1 && c <= kBigSpan) {
+        if (c > 1 && c <= kBigSpan && (int)nd.depth >= D) {
             int cnt[4];
             const int bsel = node_buf(nd);
             if (c <= 256) {
@@ -323,7 +323,43 @@ __device__ __forceinline__ QNode make_child(const QNode& p, int q, const int cnt
     for (int k = 0; k < q; k++) off += cnt[k];
     c.start = p.start + (uint32_t)off;
     c.cnt_buf = (uint32_t)cnt[q] | ((uint32_t)newbuf << 30);
+    c.code = p.code * 4u + (uint32_t)q;
+    c.depth = p.depth + 1u;
     return c;
+}
+// Child counts of a node whose span is still ordered by its next child digit (depth < presort depth D): differences of
+// the bucket offsets of the up-front counting sort, no key is touched.  bucket id = code digits padded to D digits.
+__device__ __forceinline__ void presorted_child_counts(const QNode& nd, int D, const int* __restrict__ bucket_start, int cnt[4]) {
+    const int sh = 2 * (D - (int)nd.depth - 1);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int c0 = (int)((nd.code * 4u + (uint32_t)q) << sh), c1 = (int)((nd.code * 4u + (uint32_t)q + 1u) << sh);
+        cnt[q] = bucket_start[c1] - bucket_start[c0];
+    }
+}
+
+// position of a candidate in the reference's vToDistributeKeys: FAST cells row-major (:1097-1166), row-major inside a cell
+__device__ __forceinline__ unsigned long long vkeys_order(uint32_t key, int wcell, int hcell) {
+    const int x = key_x(key), y = key_y(key);
+    const unsigned long long ci = (unsigned long long)((y - 3) / hcell), cj = (unsigned long long)((x - 3) / wcell);
+    return (ci << 36) | (cj << 24) | ((unsigned long long)y << 12) | (unsigned long long)x;
+}
+
+// bucket of a key for the up-front counting sort: root index (int)(x / hX) (:763), then the D child digits that DivideNode
+// (:602-674) assigns on the way down (children n1..n4 = digits 0..3)
+__device__ __forceinline__ int presort_bucket(uint32_t key, float hX, int bh, int D) {
+    const int kx = key_x(key), ky = key_y(key);
+    const int r = __float2int_rz(__fdiv_rn((float)kx, hX));
+    int x0 = __float2int_rz(__fmul_rn(hX, (float)r)), x1 = __float2int_rz(__fmul_rn(hX, (float)(r + 1))), y0 = 0, y1 = bh;
+    int code = r;
+    for (int d = 0; d < D; d++) {
+        const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+        const bool left = kx < mx, top = ky < my;
+        code = code * 4 + (left ? (top ? 0 : 2) : (top ? 1 : 3));
+        if (left) x1 = mx; else x0 = mx;
+        if (top) y1 = my; else y0 = my;
+    }
+    return code;
 }
 
 // grid (nlevels, B), 256 threads.  Dynamic LDS: see carve below (host passes node_cap).
@@ -333,7 +369,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                                                   const uint32_t* __restrict__ slots, size_t slots_stride,
                                                   uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
                                                   uint32_t* __restrict__ lvl_keys, int kp_total_cap,
-                                                  int* __restrict__ lvl_count, int nlevels, int node_cap,
+                                                  int* __restrict__ lvl_count, int nlevels, int node_cap, int nb_cap,
                                                   int* __restrict__ status, long long* __restrict__ qt_prof) {
     ORBX_DYN_SMEM(smem);
     __shared__ unsigned long long s_scan[20];
@@ -348,13 +384,16 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
 #define QT_STAMP(i) if (qt_prof && tid == 0 && level == 0 && b == 0) qt_prof[i] = wall_clock64();
 #endif
     QT_STAMP(0)
-    // LDS carve: nodes[2][cap] (16 B) | childcnt[cap][4] (u32) | expand[2][cap] (u64) | erased[cap] (u8)
+    // LDS carve: nodes[2][cap] (24 B) | childcnt[cap][4] (u32) | expand[2][cap] (u64) | bucket_start[nb+1] | wcount[4][nb] | erased[cap] (u8)
     QNode* nodes0 = (QNode*)smem;
     QNode* nodes1 = nodes0 + node_cap;
     uint32_t* childcnt = (uint32_t*)(nodes1 + node_cap);
     unsigned long long* exp0 = (unsigned long long*)(childcnt + 4 * (size_t)node_cap);
     unsigned long long* exp1 = exp0 + node_cap;
-    uint8_t* erased = (uint8_t*)(exp1 + node_cap);
+    int* bucket_start = (int*)(exp1 + node_cap);
+    int* wcount = bucket_start + (nb_cap + 1);
+    uint8_t* erased = (uint8_t*)(wcount + 4 * (size_t)nb_cap);
+    const int D = L.presort_depth, NBr = 1 << (2 * D), NB = L.nini * NBr;     // buckets per root / in total
     uint32_t* bufA = candA + (size_t)b * cand_stride + L.cand_off;
     uint32_t* bufB = candB + (size_t)b * cand_stride + L.cand_off;
     const int* ccount = cell_count + (size_t)b * ncells + L.cell_begin;
@@ -375,30 +414,70 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
     }
     __syncthreads();
     QT_STAMP(1)
-    // ---- roots (:718-764): key -> root (int)(x / hX); stable block-cooperative partition, three roots per sweep ----
-    int nnodes = 0;
+    // ---- roots + first D tree levels in ONE stable counting sort (bufB -> bufA) --------------------------------------
+    // bucket(key) = root index (int)(x / hX) (:763), then the D child digits DivideNode (:602-674) would assign on the way
+    // down.  After the sort every node of depth <= D is a contiguous span, its children are laid out n1|n2|n3|n4 and keys keep
+    // their vKeys order inside a bucket (stable), which is exactly the state D partition passes would have produced.
+    for (int i = tid; i < 4 * NB; i += 256) wcount[i] = 0;
+    __syncthreads();
     {
-        int rs = 0, rc = n, sb = 1;      // the not-yet-assigned keys: span [rs, rs+rc) of buffer sb (1 = B, 0 = A)
-        for (int r0 = 0; r0 < L.nini && rc > 0; r0 += 3) {
-            int cnt[4];
-            RootCls cls; cls.hX = L.hX; cls.r0 = r0;
-            block_partition4(sb ? bufB : bufA, sb ? bufA : bufB, rs, rc, cls, s_i, cnt);
-            int off = rs;
-            for (int k = 0; k < 3 && r0 + k < L.nini; k++) {
-                if (cnt[k] > 0) {
-                    if (tid == 0) {
-                        QNode nd;
-                        nd.x0 = (int16_t)__float2int_rz(__fmul_rn(L.hX, (float)(r0 + k)));
-                        nd.x1 = (int16_t)__float2int_rz(__fmul_rn(L.hX, (float)(r0 + k + 1)));
-                        nd.y0 = 0; nd.y1 = (int16_t)L.bh;
-                        nd.start = (uint32_t)off; nd.cnt_buf = (uint32_t)cnt[k] | ((uint32_t)(sb ^ 1) << 30);
-                        nodes0[nnodes] = nd;
-                    }
-                    nnodes++;
-                }
-                off += cnt[k];
+        const int seg = ((n + 255) >> 8) << 6;                        // contiguous quarter of the keys per wave
+        const int beg = wave * seg, end = imin(n, beg + seg);
+        int* mycount = wcount + wave * NB;
+        for (int i = beg + lane; i < end; i += 64) atomicAdd(&mycount[presort_bucket(bufB[i], L.hX, L.bh, D)], 1);
+        __syncthreads();
+        // exclusive scan over buckets of the totals; wcount[w][b] becomes wave w's first output position in bucket b
+        int run = 0;
+        for (int b0 = 0; b0 < NB; b0 += 256) {
+            const int bk = b0 + tid;
+            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            if (bk < NB) { c0 = wcount[bk]; c1 = wcount[NB + bk]; c2 = wcount[2 * NB + bk]; c3 = wcount[3 * NB + bk]; }
+            unsigned long long tot;
+            const int ex = run + (int)block_excl_scan<unsigned long long>((unsigned long long)(c0 + c1 + c2 + c3), &tot, s_scan);
+            if (bk < NB) {
+                bucket_start[bk] = ex;
+                wcount[bk] = ex; wcount[NB + bk] = ex + c0; wcount[2 * NB + bk] = ex + c0 + c1; wcount[3 * NB + bk] = ex + c0 + c1 + c2;
             }
-            rs = off; rc = cnt[3]; sb ^= 1;
+            run += (int)tot;
+        }
+        if (tid == 0) bucket_start[NB] = run;
+        __syncthreads();
+        // stable scatter: within a 64-key chunk, lanes with the same bucket are ranked with a bit-wise match (ballots)
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        int nbits = 0;
+        while ((1 << nbits) < NB) nbits++;
+        for (int i0 = beg; i0 < end; i0 += 64) {
+            const int i = i0 + lane;
+            const bool in = i < end;
+            const uint32_t key = in ? bufB[i] : 0u;
+            const uint32_t code = in ? (uint32_t)presort_bucket(key, L.hX, L.bh, D) : 0xFFFFFFFFu;
+            unsigned long long same = __ballot(in);
+            for (int bit = 0; bit < nbits; bit++) {
+                const unsigned long long bb = __ballot((code >> bit) & 1u);
+                same &= ((code >> bit) & 1u) ? bb : ~bb;
+            }
+            int base = 0;
+            if (in) { base = mycount[code]; bufA[base + __popcll(same & lt)] = key; }
+            ORBX_WAVE_SYNC();           // every lane of a group has read the cursor ...
+            if (in && (same >> lane) <= 1ull) mycount[code] = base + __popcll(same);     // ... before its highest lane advances it
+            ORBX_WAVE_SYNC();
+        }
+    }
+    __syncthreads();
+    int nnodes = 0;
+    for (int r = 0; r < L.nini; r++) {
+        const int s0 = bucket_start[r * NBr], c = bucket_start[(r + 1) * NBr] - s0;
+        if (c > 0) {
+            if (tid == 0) {
+                QNode nd;
+                nd.x0 = (int16_t)__float2int_rz(__fmul_rn(L.hX, (float)r));
+                nd.x1 = (int16_t)__float2int_rz(__fmul_rn(L.hX, (float)(r + 1)));
+                nd.y0 = 0; nd.y1 = (int16_t)L.bh;
+                nd.start = (uint32_t)s0; nd.cnt_buf = (uint32_t)c;   // buffer A = 0
+                nd.code = (uint32_t)r; nd.depth = 0;
+                nodes0[nnodes] = nd;
+            }
+            nnodes++;
         }
     }
     __syncthreads();
@@ -411,10 +490,19 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
     while (!finish) {
         const int prevSize = nnodes;
         // ---- full pass: divide every node with more than one key (:790-905) ----
-        // big spans: the whole workgroup partitions them one after another; small spans: one wave each
+        // presorted depths: child counts come from the bucket offsets; deeper: big spans are partitioned by the whole
+        // workgroup one after another, small spans by one wave each
+        for (int i = tid; i < nnodes; i += 256) {
+            const QNode nd = cur[i];
+            if (node_cnt(nd) > 1 && (int)nd.depth < D) {
+                int cnt[4];
+                presorted_child_counts(nd, D, bucket_start, cnt);
+                childcnt[4 * i] = (uint32_t)cnt[0]; childcnt[4 * i + 1] = (uint32_t)cnt[1]; childcnt[4 * i + 2] = (uint32_t)cnt[2]; childcnt[4 * i + 3] = (uint32_t)cnt[3];
+            }
+        }
         for (int i = 0; i < nnodes; i++) {
             const QNode nd = cur[i];
-            if (node_cnt(nd) > kBigSpan) {
+            if (node_cnt(nd) > kBigSpan && (int)nd.depth >= D) {
                 int cnt[4];
                 QuadCls cls; cls.mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1); cls.my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
                 const int bsel = node_buf(nd);
@@ -422,7 +510,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                 if (tid < 4) childcnt[4 * i + tid] = (uint32_t)(tid == 0 ? cnt[0] : tid == 1 ? cnt[1] : tid == 2 ? cnt[2] : cnt[3]);
             }
         }
-        wave_partition_many(nnodes, IdentityIdx(), cur, bufA, bufB, childcnt);
+        wave_partition_many(nnodes, IdentityIdx(), cur, bufA, bufB, childcnt, D);
         __syncthreads();
         int T = 0, E = 0, K = 0;
         {
@@ -466,7 +554,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                         if (c > 1) {
                             const int Pm = (int)(ex & 0xFFFFF), Pe = (int)((ex >> 20) & 0xFFFFF);
                             const int m = (int)(v & 0xFFFFF);
-                            const int newbuf = node_buf(nd) ^ 1;
+                            const int newbuf = node_buf(nd) ^ ((int)nd.depth >= D ? 1 : 0);   // count-only divisions move no key
                             int after = 0;      // non-empty children with larger q come first in the block
                             int erank = 0;
                             for (int q = 3; q >= 0; q--) {
@@ -519,10 +607,19 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                 __syncthreads();
                 // children counts of every candidate (partition into the other buffer; harmless if the
                 // node ends up not being divided: its own buffer is untouched)
+                for (int j = tid; j < nexp; j += 256) {    // presorted depths: counts from the bucket offsets
+                    const int idx = (int)(expc[j] & 0xFFFF);
+                    const QNode nd = cur[idx];
+                    if ((int)nd.depth < D) {
+                        int cnt[4];
+                        presorted_child_counts(nd, D, bucket_start, cnt);
+                        childcnt[4 * idx] = (uint32_t)cnt[0]; childcnt[4 * idx + 1] = (uint32_t)cnt[1]; childcnt[4 * idx + 2] = (uint32_t)cnt[2]; childcnt[4 * idx + 3] = (uint32_t)cnt[3];
+                    }
+                }
                 for (int j = 0; j < nexp; j++) {           // (rare) spans too big for one wave
                     const int idx = (int)(expc[j] & 0xFFFF);
                     const QNode nd = cur[idx];
-                    if (node_cnt(nd) > kBigSpan) {
+                    if (node_cnt(nd) > kBigSpan && (int)nd.depth >= D) {
                         int cnt[4];
                         QuadCls cls; cls.mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1); cls.my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
                         const int bsel = node_buf(nd);
@@ -530,7 +627,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                         if (tid < 4) childcnt[4 * idx + tid] = (uint32_t)(tid == 0 ? cnt[0] : tid == 1 ? cnt[1] : tid == 2 ? cnt[2] : cnt[3]);
                     }
                 }
-                { ExpandIdx ei; ei.e = expc; wave_partition_many(nexp, ei, cur, bufA, bufB, childcnt); }
+                { ExpandIdx ei; ei.e = expc; wave_partition_many(nexp, ei, cur, bufA, bufB, childcnt, D); }
                 __syncthreads();
                 QT_STAMP(6)
                 // how many of the sorted candidates get divided before `size >= N` breaks the loop
@@ -583,7 +680,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                     run += tot;
                     if (t < ndiv) {
                         const int Pm = (int)(ex & 0xFFFFF), Pe = (int)((ex >> 20) & 0xFFFFF);
-                        const int newbuf = node_buf(nd) ^ 1;
+                        const int newbuf = node_buf(nd) ^ ((int)nd.depth >= D ? 1 : 0);
                         int after = 0, erank = 0;
                         for (int q = 3; q >= 0; q--)
                             if (cq[q] > 0) { nxt[T2 - Pm - m + after] = make_child(nd, q, cq, newbuf); after++; }
@@ -632,8 +729,18 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
         const QNode nd = cur[i];
         const uint32_t* kb = (node_buf(nd) ? bufB : bufA) + nd.start;
         const int c = node_cnt(nd);
+        // "first key with the largest response" in vKeys order (:1028-1053).  vKeys order = FAST emission order = cells
+        // row-major, then y, then x, which is a function of the key itself; spans that were never physically partitioned
+        // are ordered by bucket instead, so the order is recomputed rather than read off the position.
         uint32_t best = kb[0];
-        for (int k = 1; k < c; k++) { const uint32_t key = kb[k]; if (key_s(key) > key_s(best)) best = key; }
+        unsigned long long bo = vkeys_order(best, L.wcell, L.hcell);
+        for (int k = 1; k < c; k++) {
+            const uint32_t key = kb[k];
+            const int ds = key_s(key) - key_s(best);
+            if (ds < 0) continue;
+            const unsigned long long ko = vkeys_order(key, L.wcell, L.hcell);
+            if (ds > 0 || ko < bo) { best = key; bo = ko; }
+        }
         outk[i] = best;
     }
     if (tid == 0) lvl_count[(size_t)b * nlevels + level] = nnodes;

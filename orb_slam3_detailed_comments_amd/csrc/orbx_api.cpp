@@ -5,6 +5,10 @@
 #include <mutex>
 #include "orbx_internal.h"
 
+#ifndef ORBX_PRESORT_MAX
+#define ORBX_PRESORT_MAX 5      // deepest quadtree level resolved by the up-front counting sort (tests also build 0 and 2)
+#endif
+
 using namespace orbx;
 
 namespace orbx {
@@ -80,7 +84,7 @@ int configure(orbx_extractor* h, int W, int H, int B) {
     if (!same_geom) {
         if (W - 2 * kBorder > 4095 || H - 2 * kBorder > 4095) return fail(ORBX_E_ARG, "image larger than 4127 px is not supported");
         h->cells.clear(); h->xtab.clear(); h->ytab.clear();
-        size_t off = 0; int cand_off = 0, kp_off = 0, node_cap = 0, tile_b = 0, inner_b = 0;
+        size_t off = 0; int cand_off = 0, kp_off = 0, node_cap = 0, tile_b = 0, inner_b = 0, nb_cap = 1;
         for (int l = 0; l < h->nlevels; l++) {
             LevelInfo& L = h->lv[l];
             memset(&L, 0, sizeof L);
@@ -136,6 +140,10 @@ int configure(orbx_extractor* h, int W, int H, int B) {
             // a full pass never overshoots the quota, a final-round split adds at most 3 (:912, :1006)
             L.kp_cap = std::max(L.quota + 3, 4 * L.nini);
             L.kp_off = kp_off; kp_off += L.kp_cap;
+            // presort depth of the quadtree kernel: nini * 4^D buckets, at most 1024
+            L.presort_depth = 0;
+            while (L.presort_depth < ORBX_PRESORT_MAX && L.nini * (1 << (2 * (L.presort_depth + 1))) <= 1024) L.presort_depth++;
+            nb_cap = std::max(nb_cap, L.nini * (1 << (2 * L.presort_depth)));
             node_cap = std::max(node_cap, L.kp_cap + 8);
             if (l > 0) {
                 L.xtab_off = (int)h->xtab.size(); resize_axis(h->lv[l - 1].w, L.w, true, h->xtab);
@@ -143,7 +151,7 @@ int configure(orbx_extractor* h, int W, int H, int B) {
             }
         }
         h->pyr_stride = off; h->cand_stride = (size_t)cand_off; h->ncells = (int)h->cells.size();
-        h->kp_total_cap = kp_off; h->node_cap = node_cap;
+        h->kp_total_cap = kp_off; h->node_cap = node_cap; h->nb_cap = nb_cap;
         h->fast_tile_bytes = (int)align_up((size_t)tile_b, 16); h->fast_inner_bytes = (int)align_up((size_t)inner_b, 16);
         if (h->kp_total_cap >= 65535) return fail(ORBX_E_ARG, "nfeatures too large");
         h->W = W; h->H = H; h->maxB = 0;
@@ -229,10 +237,11 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int strid
     stage_begin(h, ST_QUADTREE, h->s0);
     {
         dim3 grid(nl, B, 1);
-        const size_t smem = (size_t)h->node_cap * 65 + 64;
+        // nodes 2x24 B + child counts 16 B + expand lists 2x8 B + flags 1 B per node; bucket offsets + 4 per-wave cursors per bucket
+        const size_t smem = (size_t)h->node_cap * 81 + (size_t)(5 * h->nb_cap + 2) * 4 + 64;
         ORBX_LAUNCH(k_quadtree, grid, blk1, smem, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
                     (const int*)h->d_cell_count.p, (const uint32_t*)h->d_slots.p, h->cand_stride, h->d_candA.p, h->d_candB.p, h->cand_stride,
-                    h->d_lvl_keys.p, h->kp_total_cap, h->d_lvl_count.p, nl, h->node_cap, h->d_status.p,
+                    h->d_lvl_keys.p, h->kp_total_cap, h->d_lvl_count.p, nl, h->node_cap, h->nb_cap, h->d_status.p,
                     h->serial ? (long long*)h->d_qtprof.p : (long long*)nullptr);
     }
     stage_end(h, ST_QUADTREE, h->s0);

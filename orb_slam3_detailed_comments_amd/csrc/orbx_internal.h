@@ -56,7 +56,7 @@ struct orbx_extractor {
     std::vector<orbx::CellInfo> cells;
     std::vector<orbx::ResizeTap> xtab, ytab;
     size_t pyr_stride = 0, cand_stride = 0;
-    int ncells = 0, kp_total_cap = 0, node_cap = 0, fast_tile_bytes = 0, fast_inner_bytes = 0;
+    int ncells = 0, kp_total_cap = 0, node_cap = 0, nb_cap = 1, fast_tile_bytes = 0, fast_inner_bytes = 0;
     // ---- device state ----
     orbx::DevBuf<orbx::LevelInfo> d_lv; orbx::DevBuf<orbx::CellInfo> d_cells; orbx::DevBuf<orbx::ResizeTap> d_xtab, d_ytab;
     orbx::DevBuf<uint8_t> d_pyr, d_blur, d_stage;

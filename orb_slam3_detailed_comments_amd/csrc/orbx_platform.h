@@ -10,12 +10,16 @@
 #define ORBX_LAUNCH(kern, grid, block, smem, stream, ...) \
     hipemu::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
 #define ORBX_HD
+// lanes of a wave run in lockstep on the GPU; the emulator's fibers do not, so code that relies on "every lane has read
+// before any lane writes" marks the point explicitly
+#define ORBX_WAVE_SYNC() hipemu::wave_barrier()
 #else
 #include <hip/hip_runtime.h>
 #define ORBX_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #define ORBX_LAUNCH(kern, grid, block, smem, stream, ...) \
     hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__)
 #define ORBX_HD __host__ __device__
+#define ORBX_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #endif
 
 namespace orbx {

@@ -32,7 +32,7 @@ struct LevelInfo {
     int nini;                // number of quadtree roots = round(bw/bh) (:718)
     float hX;                // root width = bw/nini (:722)
     int xtab_off, ytab_off;  // offsets into the resize coefficient tables (levels >= 1)
-    int _pad;
+    int presort_depth;       // quadtree: keys are counting-sorted by (root, first presort_depth child digits) up front
 };
 
 struct CellInfo {
@@ -70,11 +70,13 @@ struct int2 { int x, y; };
 struct int4 { int x, y, z, w; };
 #endif
 
-// quadtree node, 16 B, lives in LDS
+// quadtree node, 24 B, lives in LDS
 struct QNode {
     int16_t x0, y0, x1, y1;
     uint32_t start;     // first key of this node's span in the key buffers
     uint32_t cnt_buf;   // bits 0..29 key count, bit 30 = which key buffer (0:A 1:B) holds the span
+    uint32_t code;      // path from the root: root index, then one base-4 digit (child n1..n4) per level
+    uint32_t depth;     // number of digits; while depth < the level's presort depth the span is already ordered by the next digit
 };
 
 }  // namespace orbx
