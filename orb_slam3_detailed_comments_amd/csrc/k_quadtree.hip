@@ -401,16 +401,29 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
 
     // ---- P0: gather the level's candidates in the reference order (cells row-major) into bufB ----
     int n = 0;
-    for (int c0 = 0; c0 < L.cell_count; c0 += 256) {
-        const int c = c0 + tid;
-        const int cnt = c < L.cell_count ? ccount[c] : 0;
-        unsigned long long tot;
-        const int pos = n + (int)block_excl_scan<unsigned long long>((unsigned long long)cnt, &tot, s_scan);
-        if (cnt > 0) {
-            const uint32_t* sp = slot_base + cells[L.cell_begin + c].slot_off;
-            for (int k = 0; k < cnt; k++) bufB[pos + k] = sp[k];
+    {
+        int* g_pos = (int*)childcnt;            // scratch: per-cell output offset / count of the current 256-cell chunk
+        int* g_cnt = g_pos + 256;
+        for (int c0 = 0; c0 < L.cell_count; c0 += 256) {
+            const int c = c0 + tid;
+            const int cnt = c < L.cell_count ? ccount[c] : 0;
+            unsigned long long tot;
+            const int pos = n + (int)block_excl_scan<unsigned long long>((unsigned long long)cnt, &tot, s_scan);
+            g_pos[tid] = pos; g_cnt[tid] = cnt;
+            __syncthreads();
+            // one wave per cell, lanes copy the cell's keys (coalesced, several loads in flight)
+            const int ncell = imin(256, L.cell_count - c0);
+            for (int ci = wave; ci < ncell; ci += 4) {
+                const int cc = g_cnt[ci];
+                if (cc > 0) {
+                    const uint32_t* sp = slot_base + cells[L.cell_begin + c0 + ci].slot_off;
+                    uint32_t* dp = bufB + g_pos[ci];
+                    for (int k = lane; k < cc; k += 64) dp[k] = sp[k];
+                }
+            }
+            n += (int)tot;
+            __syncthreads();
         }
-        n += (int)tot;
     }
     __syncthreads();
     QT_STAMP(1)
@@ -424,7 +437,29 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
         const int seg = ((n + 255) >> 8) << 6;                        // contiguous quarter of the keys per wave
         const int beg = wave * seg, end = imin(n, beg + seg);
         int* mycount = wcount + wave * NB;
-        for (int i = beg + lane; i < end; i += 64) atomicAdd(&mycount[presort_bucket(bufB[i], L.hX, L.bh, D)], 1);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        int nbits = 0;
+        while ((1 << nbits) < NB) nbits++;
+        // histogram: lanes of a 64-key chunk that share a bucket are found with a bit-wise match (ballots) and the highest
+        // lane of each group adds the group size once — neighbouring keys usually share a bucket, so per-lane LDS atomics
+        // would serialise.  Four chunks per trip keep four key loads in flight.
+        for (int i0 = beg; i0 < end; i0 += 256) {
+            uint32_t key[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u + lane; key[u] = i < end ? bufB[i] : 0u; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool in = i0 + 64 * u + lane < end;
+                const uint32_t code = in ? (uint32_t)presort_bucket(key[u], L.hX, L.bh, D) : 0xFFFFFFFFu;
+                unsigned long long same = __ballot(in);
+                for (int bit = 0; bit < nbits; bit++) {
+                    const unsigned long long bb = __ballot((code >> bit) & 1u);
+                    same &= ((code >> bit) & 1u) ? bb : ~bb;
+                }
+                if (in && (same >> lane) <= 1ull) mycount[code] += __popcll(same);
+                ORBX_WAVE_SYNC();
+            }
+        }
         __syncthreads();
         // exclusive scan over buckets of the totals; wcount[w][b] becomes wave w's first output position in bucket b
         int run = 0;
@@ -442,25 +477,26 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
         }
         if (tid == 0) bucket_start[NB] = run;
         __syncthreads();
-        // stable scatter: within a 64-key chunk, lanes with the same bucket are ranked with a bit-wise match (ballots)
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        int nbits = 0;
-        while ((1 << nbits) < NB) nbits++;
-        for (int i0 = beg; i0 < end; i0 += 64) {
-            const int i = i0 + lane;
-            const bool in = i < end;
-            const uint32_t key = in ? bufB[i] : 0u;
-            const uint32_t code = in ? (uint32_t)presort_bucket(key, L.hX, L.bh, D) : 0xFFFFFFFFu;
-            unsigned long long same = __ballot(in);
-            for (int bit = 0; bit < nbits; bit++) {
-                const unsigned long long bb = __ballot((code >> bit) & 1u);
-                same &= ((code >> bit) & 1u) ? bb : ~bb;
+        // stable scatter: same match; rank inside the group = number of lower lanes in it
+        for (int i0 = beg; i0 < end; i0 += 256) {
+            uint32_t key[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u + lane; key[u] = i < end ? bufB[i] : 0u; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool in = i0 + 64 * u + lane < end;
+                const uint32_t code = in ? (uint32_t)presort_bucket(key[u], L.hX, L.bh, D) : 0xFFFFFFFFu;
+                unsigned long long same = __ballot(in);
+                for (int bit = 0; bit < nbits; bit++) {
+                    const unsigned long long bb = __ballot((code >> bit) & 1u);
+                    same &= ((code >> bit) & 1u) ? bb : ~bb;
+                }
+                int base = 0;
+                if (in) { base = mycount[code]; bufA[base + __popcll(same & lt)] = key[u]; }
+                ORBX_WAVE_SYNC();           // every lane of a group has read the cursor ...
+                if (in && (same >> lane) <= 1ull) mycount[code] = base + __popcll(same);     // ... before its highest lane advances it
+                ORBX_WAVE_SYNC();
             }
-            int base = 0;
-            if (in) { base = mycount[code]; bufA[base + __popcll(same & lt)] = key; }
-            ORBX_WAVE_SYNC();           // every lane of a group has read the cursor ...
-            if (in && (same >> lane) <= 1ull) mycount[code] = base + __popcll(same);     // ... before its highest lane advances it
-            ORBX_WAVE_SYNC();
         }
     }
     __syncthreads();
