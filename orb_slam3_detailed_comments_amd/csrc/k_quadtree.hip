@@ -345,23 +345,6 @@ __device__ __forceinline__ unsigned long long vkeys_order(uint32_t key, int wcel
     return (ci << 36) | (cj << 24) | ((unsigned long long)y << 12) | (unsigned long long)x;
 }
 
-// bucket of a key for the up-front counting sort: root index (int)(x / hX) (:763), then the D child digits that DivideNode
-// (:602-674) assigns on the way down (children n1..n4 = digits 0..3)
-__device__ __forceinline__ int presort_bucket(uint32_t key, float hX, int bh, int D) {
-    const int kx = key_x(key), ky = key_y(key);
-    const int r = __float2int_rz(__fdiv_rn((float)kx, hX));
-    int x0 = __float2int_rz(__fmul_rn(hX, (float)r)), x1 = __float2int_rz(__fmul_rn(hX, (float)(r + 1))), y0 = 0, y1 = bh;
-    int code = r;
-    for (int d = 0; d < D; d++) {
-        const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
-        const bool left = kx < mx, top = ky < my;
-        code = code * 4 + (left ? (top ? 0 : 2) : (top ? 1 : 3));
-        if (left) x1 = mx; else x0 = mx;
-        if (top) y1 = my; else y0 = my;
-    }
-    return code;
-}
-
 // grid (nlevels, B), 256 threads.  Dynamic LDS: see carve below (host passes node_cap).
 __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ lv,
                                                   const CellInfo* __restrict__ cells, int ncells,
@@ -369,7 +352,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                                                   const uint32_t* __restrict__ slots, size_t slots_stride,
                                                   uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
                                                   uint32_t* __restrict__ lvl_keys, int kp_total_cap,
-                                                  int* __restrict__ lvl_count, int nlevels, int node_cap, int nb_cap,
+                                                  int* __restrict__ lvl_count, int nlevels, int node_cap, int nb_cap, int lut_x, int lut_y,
                                                   int* __restrict__ status, long long* __restrict__ qt_prof) {
     ORBX_DYN_SMEM(smem);
     __shared__ unsigned long long s_scan[20];
@@ -392,7 +375,9 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
     unsigned long long* exp1 = exp0 + node_cap;
     int* bucket_start = (int*)(exp1 + node_cap);
     int* wcount = bucket_start + (nb_cap + 1);
-    uint8_t* erased = (uint8_t*)(wcount + 4 * (size_t)nb_cap);
+    uint16_t* xpart = (uint16_t*)(wcount + 4 * (size_t)nb_cap);     // bucket code = xpart[x] + ypart[y]
+    uint16_t* ypart = xpart + lut_x;
+    uint8_t* erased = (uint8_t*)(ypart + lut_y);
     const int D = L.presort_depth, NBr = 1 << (2 * D), NB = L.nini * NBr;     // buckets per root / in total
     uint32_t* bufA = candA + (size_t)b * cand_stride + L.cand_off;
     uint32_t* bufB = candB + (size_t)b * cand_stride + L.cand_off;
@@ -401,29 +386,16 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
 
     // ---- P0: gather the level's candidates in the reference order (cells row-major) into bufB ----
     int n = 0;
-    {
-        int* g_pos = (int*)childcnt;            // scratch: per-cell output offset / count of the current 256-cell chunk
-        int* g_cnt = g_pos + 256;
-        for (int c0 = 0; c0 < L.cell_count; c0 += 256) {
-            const int c = c0 + tid;
-            const int cnt = c < L.cell_count ? ccount[c] : 0;
-            unsigned long long tot;
-            const int pos = n + (int)block_excl_scan<unsigned long long>((unsigned long long)cnt, &tot, s_scan);
-            g_pos[tid] = pos; g_cnt[tid] = cnt;
-            __syncthreads();
-            // one wave per cell, lanes copy the cell's keys (coalesced, several loads in flight)
-            const int ncell = imin(256, L.cell_count - c0);
-            for (int ci = wave; ci < ncell; ci += 4) {
-                const int cc = g_cnt[ci];
-                if (cc > 0) {
-                    const uint32_t* sp = slot_base + cells[L.cell_begin + c0 + ci].slot_off;
-                    uint32_t* dp = bufB + g_pos[ci];
-                    for (int k = lane; k < cc; k += 64) dp[k] = sp[k];
-                }
-            }
-            n += (int)tot;
-            __syncthreads();
+    for (int c0 = 0; c0 < L.cell_count; c0 += 256) {       // one thread per cell: 256 independent copy streams
+        const int c = c0 + tid;
+        const int cnt = c < L.cell_count ? ccount[c] : 0;
+        unsigned long long tot;
+        const int pos = n + (int)block_excl_scan<unsigned long long>((unsigned long long)cnt, &tot, s_scan);
+        if (cnt > 0) {
+            const uint32_t* sp = slot_base + cells[L.cell_begin + c].slot_off;
+            for (int k = 0; k < cnt; k++) bufB[pos + k] = sp[k];
         }
+        n += (int)tot;
     }
     __syncthreads();
     QT_STAMP(1)
@@ -432,6 +404,30 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
     // down.  After the sort every node of depth <= D is a contiguous span, its children are laid out n1|n2|n3|n4 and keys keep
     // their vKeys order inside a bucket (stable), which is exactly the state D partition passes would have produced.
     for (int i = tid; i < 4 * NB; i += 256) wcount[i] = 0;
+    // The child digit at every depth is (right ? 1 : 0) + (bottom ? 2 : 0): the x half depends only on x (and the root the x
+    // falls in), the y half only on y, so the bucket code splits into two small LDS tables built once per workgroup.
+    for (int x = tid; x < L.bw; x += 256) {
+        const int r = __float2int_rz(__fdiv_rn((float)x, L.hX));
+        int x0 = __float2int_rz(__fmul_rn(L.hX, (float)r)), x1 = __float2int_rz(__fmul_rn(L.hX, (float)(r + 1)));
+        int code = r;
+        for (int d = 0; d < D; d++) {
+            const int mx = x0 + ((x1 - x0 + 1) >> 1);
+            const bool left = x < mx;
+            code = code * 4 + (left ? 0 : 1);
+            if (left) x1 = mx; else x0 = mx;
+        }
+        xpart[x] = (uint16_t)code;
+    }
+    for (int y = tid; y < L.bh; y += 256) {
+        int y0 = 0, y1 = L.bh, code = 0;
+        for (int d = 0; d < D; d++) {
+            const int my = y0 + ((y1 - y0 + 1) >> 1);
+            const bool top = y < my;
+            code = code * 4 + (top ? 0 : 2);
+            if (top) y1 = my; else y0 = my;
+        }
+        ypart[y] = (uint16_t)code;
+    }
     __syncthreads();
     {
         const int seg = ((n + 255) >> 8) << 6;                        // contiguous quarter of the keys per wave
@@ -450,7 +446,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const bool in = i0 + 64 * u + lane < end;
-                const uint32_t code = in ? (uint32_t)presort_bucket(key[u], L.hX, L.bh, D) : 0xFFFFFFFFu;
+                const uint32_t code = in ? ((uint32_t)xpart[key_x(key[u])] + (uint32_t)ypart[key_y(key[u])]) : 0xFFFFFFFFu;
                 unsigned long long same = __ballot(in);
                 for (int bit = 0; bit < nbits; bit++) {
                     const unsigned long long bb = __ballot((code >> bit) & 1u);
@@ -485,7 +481,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const bool in = i0 + 64 * u + lane < end;
-                const uint32_t code = in ? (uint32_t)presort_bucket(key[u], L.hX, L.bh, D) : 0xFFFFFFFFu;
+                const uint32_t code = in ? ((uint32_t)xpart[key_x(key[u])] + (uint32_t)ypart[key_y(key[u])]) : 0xFFFFFFFFu;
                 unsigned long long same = __ballot(in);
                 for (int bit = 0; bit < nbits; bit++) {
                     const unsigned long long bb = __ballot((code >> bit) & 1u);

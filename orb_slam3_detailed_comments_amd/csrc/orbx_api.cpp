@@ -238,10 +238,11 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int strid
     {
         dim3 grid(nl, B, 1);
         // nodes 2x24 B + child counts 16 B + expand lists 2x8 B + flags 1 B per node; bucket offsets + 4 per-wave cursors per bucket
-        const size_t smem = (size_t)h->node_cap * 81 + (size_t)(5 * h->nb_cap + 2) * 4 + 64;
+        const int lut_x = (int)align_up((size_t)h->lv[0].bw + 1, 8), lut_y = (int)align_up((size_t)h->lv[0].bh + 1, 8);   // level 0 is the largest
+        const size_t smem = (size_t)h->node_cap * 81 + (size_t)(5 * h->nb_cap + 2) * 4 + 2 * (size_t)(lut_x + lut_y) + 64;
         ORBX_LAUNCH(k_quadtree, grid, blk1, smem, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
                     (const int*)h->d_cell_count.p, (const uint32_t*)h->d_slots.p, h->cand_stride, h->d_candA.p, h->d_candB.p, h->cand_stride,
-                    h->d_lvl_keys.p, h->kp_total_cap, h->d_lvl_count.p, nl, h->node_cap, h->nb_cap, h->d_status.p,
+                    h->d_lvl_keys.p, h->kp_total_cap, h->d_lvl_count.p, nl, h->node_cap, h->nb_cap, lut_x, lut_y, h->d_status.p,
                     h->serial ? (long long*)h->d_qtprof.p : (long long*)nullptr);
     }
     stage_end(h, ST_QUADTREE, h->s0);

@@ -20,7 +20,7 @@ __global__ void k_quadtree(const LevelInfo* __restrict__ lv, const CellInfo* __r
                            const int* __restrict__ cell_count, const uint32_t* __restrict__ slots, size_t slots_stride,
                            uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
                            uint32_t* __restrict__ lvl_keys, int kp_total_cap, int* __restrict__ lvl_count,
-                           int nlevels, int node_cap, int nb_cap, int* __restrict__ status, long long* __restrict__ qt_prof);
+                           int nlevels, int node_cap, int nb_cap, int lut_x, int lut_y, int* __restrict__ status, long long* __restrict__ qt_prof);
 __global__ void k_layout(const LevelInfo* __restrict__ lv, int nlevels, const uint32_t* __restrict__ lvl_keys,
                          int kp_total_cap, const int* __restrict__ lvl_count, int lap0, int lap1,
                          int* __restrict__ final_idx, int* __restrict__ n_out, int* __restrict__ mono_out);
