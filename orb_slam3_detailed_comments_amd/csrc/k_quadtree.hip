@@ -345,20 +345,6 @@ __device__ __forceinline__ unsigned long long vkeys_order(uint32_t key, int wcel
     return (ci << 36) | (cj << 24) | ((unsigned long long)y << 12) | (unsigned long long)x;
 }
 
-// lanes (among those with `in`) whose code equals this lane's code.  Keys arrive cell by cell, so a 64-key chunk holds only
-// a few distinct bucket codes: one ballot per distinct code (loop is wave-uniform) instead of one per code bit.
-__device__ __forceinline__ unsigned long long match_any(uint32_t code, bool in) {
-    unsigned long long rem = __ballot(in), mine = 0;
-    while (rem) {
-        const int leader = __ffsll((unsigned long long)rem) - 1;
-        const uint32_t c = __shfl(code, leader);
-        const unsigned long long m = __ballot(in && code == c);
-        if (in && code == c) mine = m;
-        rem &= ~m;
-    }
-    return mine;
-}
-
 // grid (nlevels, B), 256 threads.  Dynamic LDS: see carve below (host passes node_cap).
 __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ lv,
                                                   const CellInfo* __restrict__ cells, int ncells,
@@ -448,6 +434,8 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
         const int beg = wave * seg, end = imin(n, beg + seg);
         int* mycount = wcount + wave * NB;
         const unsigned long long lt = (1ull << lane) - 1ull;
+        int nbits = 0;
+        while ((1 << nbits) < NB) nbits++;
         // histogram: lanes of a 64-key chunk that share a bucket are found with a bit-wise match (ballots) and the highest
         // lane of each group adds the group size once — neighbouring keys usually share a bucket, so per-lane LDS atomics
         // would serialise.  Four chunks per trip keep four key loads in flight.
@@ -459,7 +447,11 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
             for (int u = 0; u < 4; u++) {
                 const bool in = i0 + 64 * u + lane < end;
                 const uint32_t code = in ? ((uint32_t)xpart[key_x(key[u])] + (uint32_t)ypart[key_y(key[u])]) : 0xFFFFFFFFu;
-                const unsigned long long same = match_any(code, in);
+                unsigned long long same = __ballot(in);
+                for (int bit = 0; bit < nbits; bit++) {
+                    const unsigned long long bb = __ballot((code >> bit) & 1u);
+                    same &= ((code >> bit) & 1u) ? bb : ~bb;
+                }
                 if (in && (same >> lane) <= 1ull) mycount[code] += __popcll(same);
                 ORBX_WAVE_SYNC();
             }
@@ -490,7 +482,11 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
             for (int u = 0; u < 4; u++) {
                 const bool in = i0 + 64 * u + lane < end;
                 const uint32_t code = in ? ((uint32_t)xpart[key_x(key[u])] + (uint32_t)ypart[key_y(key[u])]) : 0xFFFFFFFFu;
-                const unsigned long long same = match_any(code, in);
+                unsigned long long same = __ballot(in);
+                for (int bit = 0; bit < nbits; bit++) {
+                    const unsigned long long bb = __ballot((code >> bit) & 1u);
+                    same &= ((code >> bit) & 1u) ? bb : ~bb;
+                }
                 int base = 0;
                 if (in) { base = mycount[code]; bufA[base + __popcll(same & lt)] = key[u]; }
                 ORBX_WAVE_SYNC();           // every lane of a group has read the cursor ...
