@@ -238,8 +238,13 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
     __shared__ int s_flags[2];
     __shared__ int s_cnt[kFastWaves];
     __shared__ int s_wave[kFastWaves];
-    const int cell = (int)blockIdx.x, b = (int)blockIdx.y;
+    // XCD-aware mapping: workgroup b runs on XCD b % 8 and every XCD has its own L2, so XCD k gets the k-th contiguous
+    // eighth of the cell table (whole bands of neighbouring cells): the 6-px window overlap between neighbours is then
+    // served by that XCD's L2 instead of being fetched from HBM once per XCD.
+    const int nper = (ncells + 7) >> 3;
+    const int cell = (int)(blockIdx.x & 7u) * nper + (int)(blockIdx.x >> 3), b = (int)blockIdx.y;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (cell >= ncells) return;
     const CellInfo ci = cells[cell];
     const LevelInfo L = lv[ci.level];
     const int iw = ci.x1 - ci.x0, ih = ci.y1 - ci.y0;
