@@ -238,11 +238,11 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
     __shared__ int s_flags[2];
     __shared__ int s_cnt[kFastWaves];
     __shared__ int s_wave[kFastWaves];
-    // XCD-aware mapping: workgroup b runs on XCD b % 8 and every XCD has its own L2, so XCD k gets the k-th contiguous
-    // eighth of the cell table (whole bands of neighbouring cells): the 6-px window overlap between neighbours is then
-    // served by that XCD's L2 instead of being fetched from HBM once per XCD.
-    const int nper = (ncells + 7) >> 3;
-    const int cell = (int)(blockIdx.x & 7u) * nper + (int)(blockIdx.x >> 3), b = (int)blockIdx.y;
+    // XCD-aware mapping: workgroup b runs on XCD b % 8 and every XCD has its own L2.  Runs of 16 consecutive cells (horizontal
+    // neighbours, whose windows overlap by 6 px) go to the same XCD so the overlap is served by that L2; the runs themselves are
+    // dealt round-robin so that every XCD gets the same mix of levels (dense level-0 cells cost more than coarse ones).
+    const int xj = (int)(blockIdx.x >> 3);
+    const int cell = ((((xj >> 4) << 3) + (int)(blockIdx.x & 7u)) << 4) + (xj & 15), b = (int)blockIdx.y;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (cell >= ncells) return;
     const CellInfo ci = cells[cell];
