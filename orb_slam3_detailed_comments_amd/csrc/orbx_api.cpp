@@ -227,7 +227,7 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int strid
     rt::event_record(h->ev_join, sb);
     stage_begin(h, ST_FAST, h->s0);
     {
-        dim3 grid(((h->ncells + 127) / 128) * 128, B, 1), blkf(kFastThreadsDecl, 1, 1);     // multiple of 8 x 16: see the XCD mapping in k_fast_cells
+        dim3 grid(h->ncells, B, 1), blkf(kFastThreadsDecl, 1, 1);
         const size_t smem = (size_t)h->fast_tile_bytes + 3 * (size_t)h->fast_inner_bytes + 64;   // tile | score | u16 list
         ORBX_LAUNCH(k_fast_cells, grid, blkf, smem, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
                     (const uint8_t*)h->d_pyr.p, h->pyr_stride, h->iniTh, h->minTh, h->d_slots.p, h->cand_stride, h->d_cell_count.p,
