@@ -33,6 +33,7 @@ public:
     static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b)
     {
         int d = 0;
+        std::lock_guard<std::mutex> lock(Mutex());
         Check(orbm_hamming_matrix(SharedHandle(), a.ptr(0), 1, b.ptr(0), 1, &d));
         return d;
     }
@@ -40,6 +41,7 @@ public:
     static void DescriptorDistances(const cv::Mat &A, const cv::Mat &B, std::vector<int>& out)
     {
         out.resize((size_t)A.rows * B.rows);
+        std::lock_guard<std::mutex> lock(Mutex());
         if (A.rows && B.rows) Check(orbm_hamming_matrix(SharedHandle(), A.ptr(0), A.rows, B.ptr(0), B.rows, out.data()));
     }
 
@@ -70,6 +72,7 @@ public:
         OrbmMapPointView mv = {M, inView.data(), px.data(), py.data(), pxr.data(), lvl.data(), vcos.data(), depth.data(), bad.data(), hasObs.data(), desc.data()};
         std::vector<int> assigned(N > 0 ? N : 1, -1);
         int nmatches = 0;
+        std::lock_guard<std::mutex> lock(Mutex());      // the reference's matchers are re-entrant (Tracking / LocalMapping / LoopClosing threads); one handle is not
         Check(orbm_search_by_projection_mappoints(SharedHandle(), &fv, &mv, th, bFarPoints, thFarPoints, mfNNratio, assigned.data(), &nmatches));
         for (int i = 0; i < N; i++) if (assigned[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[assigned[i]];
         return nmatches;
@@ -88,6 +91,7 @@ public:
         if (!h) throw std::runtime_error(std::string("ORBmatcher (HIP): ") + orbx_last_error());
         return h;
     }
+    static std::mutex& Mutex() { static std::mutex m; return m; }
     static void Check(int rc) { if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBmatcher (HIP): ") + orbx_last_error()); }
 
 protected:

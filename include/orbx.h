@@ -101,6 +101,10 @@ int orbx_device_upload(orbx_extractor* h, void* dptr, const void* host, size_t b
 int orbx_host_alloc(orbx_extractor* h, size_t bytes, void** hptr);
 int orbx_host_free(orbx_extractor* h, void* hptr);
 
+/* Replay the extraction pipeline as one hipGraph (captured on first use, re-captured when the batch size, geometry, input
+ * pointer or lapping area change).  Pays off at small batches, where the ~17 kernel launches are latency-bound. */
+int orbx_set_graph_replay(orbx_extractor* h, int on);
+
 /* Per-stage GPU time of the last batch, HIP events on the launching streams.  on = 1: normal two-stream schedule (the blur
  * overlaps FAST + quadtree, so their times overlap too); on = 2: serial schedule, every kernel alone on one stream. */
 #define ORBX_NSTAGES 8

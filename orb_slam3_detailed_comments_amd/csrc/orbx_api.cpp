@@ -299,6 +299,10 @@ void orbx_destroy(orbx_extractor* h) {
     rt::set_device(h->device);
     if (h->have_streams) {
         rt::stream_sync(h->s0); rt::stream_sync(h->s1);
+#ifndef ORBX_EMU
+        if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+        if (h->graph) (void)hipGraphDestroy(h->graph);
+#endif
         for (int i = 0; i < ORBX_NSTAGES; i++) { rt::event_destroy(h->ev_stage[i][0]); rt::event_destroy(h->ev_stage[i][1]); }
         rt::event_destroy(h->ev_fork); rt::event_destroy(h->ev_join); rt::event_destroy(h->ev_done);
         rt::stream_destroy(h->s0); rt::stream_destroy(h->s1);
@@ -355,6 +359,32 @@ int orbx_extract_batch(orbx_extractor* h, int B, const uint8_t* images, int widt
         if (rt::copy_h2d(h->d_stage.p, images, bytes, h->s0)) return fail(ORBX_E_DEVICE, "H2D copy failed: %s", rt::last_error());
         d_images = h->d_stage.p;
     }
+#ifndef ORBX_EMU
+    // hipGraph replay of the whole extraction (import, 7 dependent resize launches, FAST, quadtree, blur on the second stream,
+    // layout, orient+BRIEF): at small batches the ~17 launches are launch/latency-bound.  The graph is keyed on everything that
+    // is baked into the kernel arguments and re-captured when any of it changes.
+    if (h->use_graph && !h->profile) {
+        const bool same = h->graph_exec && h->g_B == B && h->g_images == d_images && h->g_stride == stride && h->g_image_stride == image_stride &&
+                          h->g_lap0 == lap0 && h->g_lap1 == lap1 && h->g_W == h->W && h->g_H == h->H && h->g_pyr == h->d_pyr.p && h->g_gauss == h->gauss_variant;
+        if (!same) {
+            if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+            if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+            if (hipStreamBeginCapture(h->s0, hipStreamCaptureModeThreadLocal) != hipSuccess) return fail(ORBX_E_DEVICE, "graph capture failed to start");
+            rc = enqueue_extract(h, B, d_images, stride, image_stride, lap0, lap1);
+            const hipError_t e = hipStreamEndCapture(h->s0, &h->graph);
+            if (rc || e != hipSuccess || hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0) != hipSuccess) {
+                h->graph_exec = nullptr;
+                return fail(ORBX_E_DEVICE, "graph capture/instantiate failed: %s", rt::last_error());
+            }
+            h->g_B = B; h->g_images = d_images; h->g_stride = stride; h->g_image_stride = image_stride; h->g_lap0 = lap0; h->g_lap1 = lap1;
+            h->g_W = h->W; h->g_H = h->H; h->g_pyr = h->d_pyr.p; h->g_gauss = h->gauss_variant;
+        }
+        if (hipGraphLaunch(h->graph_exec, h->s0) != hipSuccess) return fail(ORBX_E_DEVICE, "graph launch failed: %s", rt::last_error());
+        rt::event_record(h->ev_done, h->s0);
+        h->lastB = B;
+        return ORBX_OK;
+    }
+#endif
     return enqueue_extract(h, B, d_images, stride, image_stride, lap0, lap1);
 }
 
@@ -449,6 +479,8 @@ int orbx_host_alloc(orbx_extractor* h, size_t bytes, void** hptr) {
     return *hptr ? ORBX_OK : fail(ORBX_E_DEVICE, "pinned host allocation of %zu bytes failed", bytes);
 }
 int orbx_host_free(orbx_extractor* h, void* hptr) { if (!h) return ORBX_E_ARG; rt::set_device(h->device); rt::hfree(hptr); return ORBX_OK; }
+
+int orbx_set_graph_replay(orbx_extractor* h, int on) { if (!h) return ORBX_E_ARG; h->use_graph = on != 0; return ORBX_OK; }
 
 int orbx_profile_enable(orbx_extractor* h, int on) { if (!h) return ORBX_E_ARG; h->profile = on != 0; h->serial = on == 2; return ORBX_OK; }
 int orbx_profile_get(orbx_extractor* h, float ms[ORBX_NSTAGES]) {

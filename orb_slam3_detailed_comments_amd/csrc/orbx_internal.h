@@ -78,5 +78,12 @@ struct orbx_extractor {
     orbx::DevBuf<uint8_t> d_sr[12];
     orbx::DevBuf<int> d_si[8];
     orbx::DevBuf<long long> d_qtprof;
+    // hipGraph replay of the extraction pipeline (orbx_set_graph_replay)
+    bool use_graph = false;
+#ifndef ORBX_EMU
+    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
+#endif
+    int g_B = 0, g_stride = 0, g_lap0 = 0, g_lap1 = 0, g_W = 0, g_H = 0, g_gauss = 0; size_t g_image_stride = 0;
+    const void* g_images = nullptr; const void* g_pyr = nullptr;
     orbx::DevBuf<int> d_aux;     // int4 per keypoint: stereo row band / x / octave (k_orient_brief -> k_stereo_match)
 };

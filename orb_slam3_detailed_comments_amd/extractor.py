@@ -137,6 +137,10 @@ class ORBextractor:
             self._lib.check(n)
         return a[:n].copy()
 
+    def graph_replay(self, on=True):
+        """Replay the extraction pipeline as one hipGraph (small-batch latency)."""
+        self._lib.check(self._lib.L.orbx_set_graph_replay(self._h, int(on)))
+
     def profile(self, on=True, serial=False):
         self._lib.check(self._lib.L.orbx_profile_enable(self._h, 2 if (on and serial) else int(on)))
 

@@ -76,3 +76,19 @@ for B in (2, 16, 64, 128):
     qp = np.zeros(16, np.int64); lib.L.orbx_debug_quadtree_profile(ex._h, qp.ctypes.data)
     print('  quadtree L0 phases (us): gather %.1f roots %.1f passes %.1f [final: sort %.1f part %.1f ndiv %.1f] total %.1f  n=%d nodes=%d nexp=%d' % ((qp[1]-qp[0])/100,(qp[2]-qp[1])/100,(qp[3]-qp[2])/100,(qp[5]-qp[4])/100,(qp[6]-qp[5])/100,(qp[7]-qp[6])/100,(qp[9]-qp[0])/100,qp[10],qp[11],qp[12]))
     print('B',B,'ms/batch %.3f'%(dt*1e3),'pairs/s %.0f'%((B//2)/dt), 'stages', {k:round(v,3) for k,v in ex.stage_ms().items()}, 'matches', n[:3], flush=True)
+
+# ---- single-pair latency: eager vs hipGraph replay ----
+L, R = synth.stereo_pair(seed=100)
+pair = np.stack([L, R])
+for graph in (False, True):
+    ex = ORBextractor(1200,1.2,8,20,7)
+    ex.graph_replay(graph)
+    dptr = ex.device_upload(pair)
+    for it in range(5):
+        ex.enqueue(None, (0,0), device_ptr=dptr, shape=pair.shape); lib.check(lib.L.orbm_stereo_match(ex._h, 0, ex._h, 1, 1, bf, b)); ex.sync()
+    K = 50
+    t = time.time()
+    for it in range(K):
+        ex.enqueue(None, (0,0), device_ptr=dptr, shape=pair.shape); lib.check(lib.L.orbm_stereo_match(ex._h, 0, ex._h, 1, 1, bf, b)); ex.sync()
+    dt = (time.time() - t) / K
+    print('single pair, graph=%s: %.3f ms per pair (sync each), %.0f pairs/s' % (graph, dt * 1e3, 1 / dt), flush=True)

@@ -179,3 +179,28 @@ def test_two_instances_on_two_threads(hip_lib):
 def test_smoke_entry(hip_lib):
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_graph_replay_equals_eager(hip_lib):
+    """hipGraph replay of the extraction pipeline: same bits as eager launches, across re-use and re-capture."""
+    ex = ORBextractor(1200, 1.2, 8, 20, 7)
+    ex.graph_replay(True)
+    for seed, lap in ((80, (0, 0)), (81, (0, 0)), (82, (100, 400)), (83, (0, 0))):
+        pair = np.stack(synth.stereo_pair(seed=seed))
+        got = ex.extract_batch(pair, lap)
+        for i in range(2):
+            assert _same(got[i], ol.OracleExtractor(1200).extract(pair[i], lap)), (seed, i)
+    u, d, n = M.ComputeStereoMatches(ex, ex, EUROC_BF, EUROC_B, 0, 1, 1)
+    assert n[0] > 100
+    big = np.stack([synth.corner_field(seed=90 + i) for i in range(5)])        # other batch size -> re-capture
+    got = ex.extract_batch(big)
+    assert all(_same(got[i], ol.OracleExtractor(1200).extract(big[i])) for i in range(5))
+
+
+def test_fuzz_gpu(hip_lib):
+    from test_emu_fuzz import _case
+    for seed in range(14):
+        img, nf, sf, nl, ini, mn, lap, gv = _case(seed)
+        ex = ORBextractor(nf, sf, nl, ini, mn)
+        ex.set_gaussian_taps(gv)
+        assert _same(ex(img, None, lap), ol.OracleExtractor(nf, sf, nl, ini, mn, gv).extract(img, lap)), seed
