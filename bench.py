@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU")
+    ap.add_argument("--handles", type=int, default=2, help="extractor handles in flight per GPU (each owns two streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -119,7 +120,8 @@ def main():
         l, r = synth.stereo_pair(W, H, seed=rank * 100003 + i)
         ls.append(l); rs.append(r)
     batch = np.stack(ls + rs)                                   # [2P, H, W]: lefts then rights
-    handles = [ORBextractor(NFEAT, SCALE, NLEVELS, INI, MIN, device_id=local) for _ in range(2)]
+    NH = max(1, args.handles)
+    handles = [ORBextractor(NFEAT, SCALE, NLEVELS, INI, MIN, device_id=local) for _ in range(NH)]
     dptrs = [h.device_upload(batch) for h in handles]          # inputs resident in HBM before the timed region
     cap = handles[0].max_keypoints()
     for h in handles:
@@ -151,8 +153,8 @@ def main():
     def run(nsteps, record):
         pending = []
         for s in range(nsteps):
-            i = s % 2
-            if len(pending) == 2:
+            i = s % NH
+            if len(pending) == NH:
                 fetch(pending.pop(0), record)
             enqueue(i)
             pending.append(i)
@@ -207,7 +209,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "EuRoC-shaped stereo 752x480, nFeatures=1200, 8 levels: extract L+R + ComputeStereoMatches (BASELINE.json configs[1])",
-                       "pairs_per_step_per_gpu": P, "images_per_step_per_gpu": 2 * P, "outputs_copied_to_host": True,
+                       "pairs_per_step_per_gpu": P, "images_per_step_per_gpu": 2 * P, "outputs_copied_to_host": True, "handles_in_flight": NH,
                        "avg_keypoints_per_image": round(avg_kp, 1), "avg_stereo_matches_per_pair": round(nmatch[0] / max(nmatch[1], 1), 1),
                        "parallelism": "independent streams, %d GPU(s), no collective" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
