@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU")
-    ap.add_argument("--handles", type=int, default=2, help="extractor handles in flight per GPU (each owns two streams)")
+    ap.add_argument("--handles", type=int, default=4, help="extractor handles in flight per GPU (each owns two streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
