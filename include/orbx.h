@@ -219,6 +219,20 @@ int orbm_search_for_triangulation(orbx_extractor* h, const OrbmKeyFrameView* K1,
                                   const float F12[9], const float ep[2], int only_stereo, int coarse,
                                   int check_orientation, int* matches12, int* nmatches);
 
+/* ---- "next" rows of SURVEY.md §8f, built on the same kernels ---- */
+/* ORBmatcher::SearchByBoW.  K1 = the key frame whose map points are searched (has_map_point[i] = map point present and not bad),
+ * K2 = the other side.  th_inclusive = 1: SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (src/ORBmatcher.cc:259-493: accept
+ * bestDist1 <= TH_LOW, every frame feature is a candidate — K2->has_map_point may be NULL).  th_inclusive = 0:
+ * SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (:892-1043: bestDist1 < TH_LOW, only K2 features with a good map point).
+ * matches12[i] = index in K2 matched to feature i of K1, or -1 (after the rotation-consistency pruning). */
+int orbm_search_by_bow(orbx_extractor* h, const OrbmKeyFrameView* K1, const OrbmKeyFrameView* K2, float nnratio, int th_inclusive,
+                       int check_orientation, int* matches12, int* nmatches);
+
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (src/ORBmatcher.cc:734-880).
+ * prev_matched: N1 x 2 floats (vbPrevMatched), updated in place like the reference does (:876-878). */
+int orbm_search_for_initialization(orbx_extractor* h, const OrbmFrameView* F1, const OrbmFrameView* F2, float* prev_matched,
+                                   int window_size, float nnratio, int check_orientation, int* matches12, int* nmatches);
+
 const char* orbx_last_error(void);
 
 #ifdef __cplusplus

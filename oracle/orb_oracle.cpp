@@ -777,6 +777,102 @@ int orbo_search_for_triangulation(const OKeyFrame* K1, const OKeyFrame* K2, cons
     return nmatches;
 }
 
+// ORBmatcher::SearchByBoW, src/ORBmatcher.cc:259-493 (th_inclusive = 1: key frame vs frame) and :892-1043 (0: key frame vs key frame)
+int orbo_search_by_bow(const OKeyFrame* K1, const OKeyFrame* K2, float nnratio, int th_inclusive, int checkOri, int* m12) {
+    const int TH_LOW = 50, HISTO_LENGTH = 30;
+    for (int i = 0; i < K1->N; i++) m12[i] = -1;
+    std::vector<char> taken(K2->N + 1, 0);
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0, a = 0, b = 0;
+    while (a < K1->fv_nodes && b < K2->fv_nodes) {
+        if (K1->fv_node_id[a] == K2->fv_node_id[b]) {
+            for (int i1 = K1->fv_start[a]; i1 < K1->fv_start[a + 1]; i1++) {
+                const int idx1 = (int)K1->fv_feat[i1];
+                if (!K1->has_mp || !K1->has_mp[idx1]) continue;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int i2 = K2->fv_start[b]; i2 < K2->fv_start[b + 1]; i2++) {
+                    const int idx2 = (int)K2->fv_feat[i2];
+                    if (taken[idx2]) continue;
+                    if (K2->has_mp && !K2->has_mp[idx2]) continue;
+                    const int dist = descriptor_distance(K1->desc + 32 * (size_t)idx1, K2->desc + 32 * (size_t)idx2);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                const bool pass = th_inclusive ? (bestDist1 <= TH_LOW) : (bestDist1 < TH_LOW);
+                if (pass && static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                    m12[idx1] = bestIdx2; taken[bestIdx2] = 1; nmatches++;
+                    if (checkOri) {
+                        float rot = K1->keys[idx1].angle - K2->keys[bestIdx2].angle;
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)round(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        rotHist[bin].push_back(idx1);
+                    }
+                }
+            }
+            a++; b++;
+        } else if (K1->fv_node_id[a] < K2->fv_node_id[b]) { while (a < K1->fv_nodes && K1->fv_node_id[a] < K2->fv_node_id[b]) a++; }
+        else { while (b < K2->fv_nodes && K2->fv_node_id[b] < K1->fv_node_id[a]) b++; }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx1 : rotHist[i]) { m12[idx1] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+// ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:734-880
+int orbo_search_for_initialization(const OFrame* F1, const OFrame* F2, float* prev, int windowSize, float nnratio, int checkOri, int* m12) {
+    const int TH_LOW = 50, HISTO_LENGTH = 30;
+    Grid g = build_grid(*F2);
+    for (int i = 0; i < F1->N; i++) m12[i] = -1;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> vMatchedDistance(F2->N + 1, INT_MAX), vnMatches21(F2->N + 1, -1);
+    int nmatches = 0;
+    for (int i1 = 0; i1 < F1->N; i1++) {
+        const int level1 = F1->keys[i1].octave;
+        if (level1 > 0) continue;
+        std::vector<int> vIndices2 = features_in_area(*F2, g, prev[2 * i1], prev[2 * i1 + 1], (float)windowSize, level1, level1);
+        if (vIndices2.empty()) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int i2 : vIndices2) {
+            const int dist = descriptor_distance(F1->desc + 32 * (size_t)i1, F2->desc + 32 * (size_t)i2);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (vnMatches21[bestIdx2] >= 0) { m12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+                m12[i1] = bestIdx2; vnMatches21[bestIdx2] = i1; vMatchedDistance[bestIdx2] = bestDist; nmatches++;
+                if (checkOri) {
+                    float rot = F1->keys[i1].angle - F2->keys[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx1 : rotHist[i]) if (m12[idx1] >= 0) { m12[idx1] = -1; nmatches--; }
+        }
+    }
+    for (int i1 = 0; i1 < F1->N; i1++) if (m12[i1] >= 0) { prev[2 * i1] = F2->keys[m12[i1]].x; prev[2 * i1 + 1] = F2->keys[m12[i1]].y; }
+    return nmatches;
+}
+
 // glibc cosf/sinf, exposed so tests can pin the device-side model (csrc/glibc_sincosf_model.h).
 float orbo_cosf(float x) { return cosf(x); }
 float orbo_sinf(float x) { return sinf(x); }

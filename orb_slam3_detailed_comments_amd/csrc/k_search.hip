@@ -203,4 +203,27 @@ __global__ void __launch_bounds__(256) k_bow_search(const BowItem* __restrict__ 
     if (lane == 0) best2[it] = best == 0xFFFFFFFFu ? -1 : feat2[I.start2 + (0xFFFF - (int)(best & 0xFFFF))];
 }
 
+// All distances of one unmatched feature idx1 to the features of the other key frame / frame in the same vocabulary node, in the
+// node's order, for the sequential accept loops of ORBmatcher::SearchByBoW (src/ORBmatcher.cc:259-493 and :892-1043), which skip
+// targets taken by earlier features.  out[item.out_off + j] = Hamming distance, or -1 when the j-th target is not eligible.
+__global__ void __launch_bounds__(256) k_bow_dists(const BowItem* __restrict__ items, int nitems,
+                                                   const unsigned long long* __restrict__ desc1, const unsigned long long* __restrict__ desc2,
+                                                   const uint8_t* __restrict__ eligible2, const int* __restrict__ feat2, int* __restrict__ out) {
+    const int lane = lane_id();
+    const int it = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (it >= nitems) return;
+    const BowItem I = items[it];
+    const unsigned long long* da = desc1 + 4 * (size_t)I.idx1;
+    const unsigned long long a0 = da[0], a1 = da[1], a2 = da[2], a3 = da[3];
+    for (int j = lane; j < I.cnt2; j += 64) {
+        const int idx2 = feat2[I.start2 + j];
+        int d = -1;
+        if (eligible2[idx2]) {
+            const unsigned long long* db = desc2 + 4 * (size_t)idx2;
+            d = __popcll(a0 ^ db[0]) + __popcll(a1 ^ db[1]) + __popcll(a2 ^ db[2]) + __popcll(a3 ^ db[3]);
+        }
+        out[I.out_off + j] = d;
+    }
+}
+
 }  // namespace orbx

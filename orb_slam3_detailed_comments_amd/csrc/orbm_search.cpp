@@ -245,7 +245,7 @@ int orbm_search_for_triangulation(orbx_extractor* h, const OrbmKeyFrameView* K1,
                 if (K1->has_map_point && K1->has_map_point[idx1]) continue;
                 const bool stereo1 = K1->u_right && K1->u_right[idx1] >= 0;
                 if (only_stereo && !stereo1) continue;
-                BowItem it; it.idx1 = idx1; it.start2 = K2->fv_start[b]; it.cnt2 = K2->fv_start[b + 1] - K2->fv_start[b];
+                BowItem it; it.idx1 = idx1; it.start2 = K2->fv_start[b]; it.cnt2 = K2->fv_start[b + 1] - K2->fv_start[b]; it.out_off = 0;
                 if (it.cnt2 > 0xFFFF) return fail(ORBX_E_ARG, "vocabulary node with more than 65535 features");
                 items.push_back(it);
             }
@@ -298,6 +298,133 @@ int orbm_search_for_triangulation(orbx_extractor* h, const OrbmKeyFrameView* K1,
             }
         }
     }
+    if (nmatches_out) *nmatches_out = nmatches;
+    return ORBX_OK;
+}
+
+
+// ORBmatcher::SearchByBoW, both overloads (src/ORBmatcher.cc:259-493, :892-1043), non-fisheye path
+int orbm_search_by_bow(orbx_extractor* h, const OrbmKeyFrameView* K1, const OrbmKeyFrameView* K2, float nnratio, int th_inclusive,
+                       int check_ori, int* matches12, int* nmatches_out) {
+    if (!h || !K1 || !K2 || !matches12) return fail(ORBX_E_ARG, "null");
+    if (K1->N >= 65535 || K2->N >= 65535) return fail(ORBX_E_ARG, "keyframe too large");
+    rt::set_device(h->device);
+    const int N1 = K1->N, N2 = K2->N;
+    for (int i = 0; i < N1; i++) matches12[i] = -1;
+    std::vector<BowItem> items;
+    int a = 0, b = 0, total = 0;
+    while (a < K1->fv_nodes && b < K2->fv_nodes) {
+        const uint32_t na = K1->fv_node_id[a], nb = K2->fv_node_id[b];
+        if (na == nb) {
+            for (int k = K1->fv_start[a]; k < K1->fv_start[a + 1]; k++) {
+                const int idx1 = (int)K1->fv_feat[k];
+                if (!K1->has_map_point || !K1->has_map_point[idx1]) continue;     // !pMP || pMP->isBad()
+                BowItem it; it.idx1 = idx1; it.start2 = K2->fv_start[b]; it.cnt2 = K2->fv_start[b + 1] - K2->fv_start[b]; it.out_off = total;
+                total += it.cnt2;
+                items.push_back(it);
+            }
+            a++; b++;
+        } else if (na < nb) { while (a < K1->fv_nodes && K1->fv_node_id[a] < nb) a++; }
+        else { while (b < K2->fv_nodes && K2->fv_node_id[b] < na) b++; }
+    }
+    int nmatches = 0;
+    if (!items.empty() && total > 0) {
+        std::vector<uint8_t> elig(N2 > 0 ? N2 : 1, 1);
+        if (K2->has_map_point) memcpy(elig.data(), K2->has_map_point, N2);
+        const int nfeat2 = K2->fv_start[K2->fv_nodes];
+        int e = upload(h, SR_DESC, K1->desc, 32 * (size_t)N1) | upload(h, SR_DESC2, K2->desc, 32 * (size_t)N2) |
+                upload(h, SR_HASMP2, elig.data(), elig.size()) | upload(h, SR_ITEMS, items.data(), sizeof(BowItem) * items.size());
+        e |= h->d_si[SI_FEAT2].ensure(nfeat2 + 1) | h->d_si[SI_BEST].ensure((size_t)total + 1);
+        if (e) return fail(ORBX_E_DEVICE, "upload/allocation failed");
+        rt::copy_h2d(h->d_si[SI_FEAT2].p, K2->fv_feat, sizeof(int) * (size_t)nfeat2, h->s0);
+        dim3 grid(((int)items.size() + 3) / 4, 1, 1), blk(256, 1, 1);
+        ORBX_LAUNCH(k_bow_dists, grid, blk, 0, h->s0, (const BowItem*)h->d_sr[SR_ITEMS].p, (int)items.size(),
+                    (const unsigned long long*)h->d_sr[SR_DESC].p, (const unsigned long long*)h->d_sr[SR_DESC2].p,
+                    (const uint8_t*)h->d_sr[SR_HASMP2].p, (const int*)h->d_si[SI_FEAT2].p, h->d_si[SI_BEST].p);
+        std::vector<int> dist((size_t)total);
+        if (rt::copy_d2h(dist.data(), h->d_si[SI_BEST].p, sizeof(int) * (size_t)total, h->s0) || rt::stream_sync(h->s0) || rt::check_launch())
+            return fail(ORBX_E_DEVICE, "bow distances failed: %s", rt::last_error());
+        // sequential replay: a target taken by an earlier feature is skipped (:331 vpMapPointMatches[realIdxF], :948 vbMatched2[idx2])
+        std::vector<uint8_t> taken(N2 > 0 ? N2 : 1, 0);
+        std::vector<int> rotHist[HISTO_LENGTH];
+        for (const BowItem& it : items) {
+            int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+            for (int j = 0; j < it.cnt2; j++) {
+                const int idx2 = (int)K2->fv_feat[it.start2 + j];
+                const int d = dist[(size_t)it.out_off + j];
+                if (taken[idx2] || d < 0) continue;
+                if (d < bestDist1) { bestDist2 = bestDist1; bestDist1 = d; bestIdx2 = idx2; }
+                else if (d < bestDist2) bestDist2 = d;
+            }
+            const bool pass = th_inclusive ? (bestDist1 <= TH_LOW) : (bestDist1 < TH_LOW);
+            if (pass && static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                matches12[it.idx1] = bestIdx2;
+                taken[bestIdx2] = 1;
+                nmatches++;
+                if (check_ori) rotHist[rot_bin(K1->keys_un[it.idx1].angle, K2->keys_un[bestIdx2].angle)].push_back(it.idx1);
+            }
+        }
+        if (check_ori) {
+            int ind1 = -1, ind2 = -1, ind3 = -1;
+            three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+            for (int i = 0; i < HISTO_LENGTH; i++) {
+                if (i == ind1 || i == ind2 || i == ind3) continue;
+                for (int idx1 : rotHist[i]) { matches12[idx1] = -1; nmatches--; }
+            }
+        }
+    }
+    if (nmatches_out) *nmatches_out = nmatches;
+    return ORBX_OK;
+}
+
+// ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:734-880)
+int orbm_search_for_initialization(orbx_extractor* h, const OrbmFrameView* F1, const OrbmFrameView* F2, float* prev, int window_size,
+                                   float nnratio, int check_ori, int* matches12, int* nmatches_out) {
+    if (!h || !F1 || !F2 || !prev || !matches12) return fail(ORBX_E_ARG, "null");
+    rt::set_device(h->device);
+    DeviceFrame D;
+    int rc = upload_frame(h, F2, &D); if (rc) return rc;
+    const int N1 = F1->N, N2 = F2->N;
+    std::vector<AreaQuery> qs(N1);
+    for (int i = 0; i < N1; i++) {
+        AreaQuery& q = qs[i]; memset(&q, 0, sizeof q);
+        const int level1 = F1->keys_un[i].octave;
+        if (level1 > 0) continue;                                   // :755-757 only level-0 keypoints
+        q.x = prev[2 * i]; q.y = prev[2 * i + 1]; q.r = (float)window_size; q.min_level = level1; q.max_level = level1; q.active = 1; q.gate = 0;
+    }
+    Csr c;
+    rc = run_area_search(h, D, qs, F1->desc, &c); if (rc) return rc;
+    for (int i = 0; i < N1; i++) matches12[i] = -1;
+    std::vector<int> matched_dist(N2 > 0 ? N2 : 1, 0x7FFFFFFF), matches21(N2 > 0 ? N2 : 1, -1);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int nmatches = 0;
+    for (int i1 = 0; i1 < N1; i1++) {
+        if (!qs[i1].active || c.count[i1] == 0) continue;
+        int bestDist = 0x7FFFFFFF, bestDist2 = 0x7FFFFFFF, bestIdx2 = -1;
+        for (int k = 0; k < c.count[i1]; k++) {
+            const int i2 = c.ent[2 * (size_t)(c.start[i1] + k)], dist = c.ent[2 * (size_t)(c.start[i1] + k) + 1] & 0xFFFF;
+            if (matched_dist[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (matches21[bestIdx2] >= 0) { matches12[matches21[bestIdx2]] = -1; nmatches--; }
+                matches12[i1] = bestIdx2; matches21[bestIdx2] = i1; matched_dist[bestIdx2] = bestDist;
+                nmatches++;
+                if (check_ori) rotHist[rot_bin(F1->keys_un[i1].angle, F2->keys_un[bestIdx2].angle)].push_back(i1);
+            }
+        }
+    }
+    if (check_ori) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx1 : rotHist[i]) if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+        }
+    }
+    for (int i1 = 0; i1 < N1; i1++) if (matches12[i1] >= 0) { prev[2 * i1] = F2->keys_un[matches12[i1]].x; prev[2 * i1 + 1] = F2->keys_un[matches12[i1]].y; }
     if (nmatches_out) *nmatches_out = nmatches;
     return ORBX_OK;
 }

@@ -58,7 +58,7 @@ struct AreaQuery {                                                // one GetFeat
     float x, y, r, ur;
     int min_level, max_level, active, gate;
 };
-struct BowItem { int idx1, start2, cnt2; };
+struct BowItem { int idx1, start2, cnt2, out_off; };
 struct BowParams {
     float F12[9];            // fundamental matrix, row-major (Pinhole::epipolarConstrain)
     float ep[2];             // epipole of KF1's centre in KF2

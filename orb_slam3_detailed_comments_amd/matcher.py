@@ -40,6 +40,23 @@ class ORBmatcher:
         idx = np.nonzero(m12 >= 0)[0]
         return nm.value, [(int(i), int(m12[i])) for i in idx]
 
+    def SearchByBoW(self, ext, kf1, kf2, frame_version=True):
+        """ORBmatcher::SearchByBoW: frame_version=True is (KeyFrame*, Frame&, vpMapPointMatches), src/ORBmatcher.cc:259;
+        False is (KeyFrame*, KeyFrame*, vpMatches12), :892.  Returns (nmatches, matches12[N1])."""
+        m12 = np.full(kf1.view.N, -1, np.int32); nm = C.c_int()
+        ext._lib.check(ext._lib.L.orbm_search_by_bow(ext._h, kf1.ref(), kf2.ref(), self.mfNNratio, int(frame_version), int(self.mbCheckOrientation),
+                                                   m12.ctypes.data, C.byref(nm)))
+        return nm.value, m12
+
+    def SearchForInitialization(self, ext, f1, f2, vbPrevMatched, windowSize=10):
+        """ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:734.  vbPrevMatched [N1,2] float32 is updated in place.
+        Returns (nmatches, vnMatches12)."""
+        assert vbPrevMatched.dtype == np.float32 and vbPrevMatched.flags["C_CONTIGUOUS"]
+        m12 = np.full(f1.view.N, -1, np.int32); nm = C.c_int()
+        ext._lib.check(ext._lib.L.orbm_search_for_initialization(ext._h, f1.ref(), f2.ref(), vbPrevMatched.ctypes.data, int(windowSize), self.mfNNratio,
+                                                               int(self.mbCheckOrientation), m12.ctypes.data, C.byref(nm)))
+        return nm.value, m12
+
     @staticmethod
     def DescriptorDistance(ext, a, b):
         """All-pairs Hamming distance matrix [len(a), len(b)] of 32-byte descriptors, computed on `ext`'s GPU."""

@@ -241,3 +241,19 @@ def oracle_search_for_triangulation(k1, k2, F12, ep, only_stereo, coarse, check_
     n = L.orbo_search_for_triangulation(k1.ref(), k2.ref(), F12.ctypes.data, ep.ctypes.data, int(only_stereo), int(coarse), int(check_ori), m.ctypes.data)
     idx = np.nonzero(m[:k1.view.N] >= 0)[0]
     return n, [(int(i), int(m[i])) for i in idx]
+
+
+def oracle_search_by_bow(k1, k2, nnratio, frame_version, check_ori):
+    L = oracle()
+    L.orbo_search_by_bow.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]
+    m = np.full(max(k1.view.N, 1), -1, np.int32)
+    n = L.orbo_search_by_bow(k1.ref(), k2.ref(), nnratio, int(frame_version), int(check_ori), m.ctypes.data)
+    return n, m[:k1.view.N]
+
+
+def oracle_search_for_initialization(f1, f2, prev, window, nnratio, check_ori):
+    L = oracle()
+    L.orbo_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    m = np.full(max(f1.view.N, 1), -1, np.int32)
+    n = L.orbo_search_for_initialization(f1.ref(), f2.ref(), prev.ctypes.data, int(window), nnratio, int(check_ori), m.ctypes.data)
+    return n, m[:f1.view.N]

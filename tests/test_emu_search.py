@@ -41,6 +41,23 @@ def run_all(lib, w, h, nf, M_points, seeds):
             n2, p2 = ol.oracle_search_for_triangulation(kf1[0], kf2[0], F12, ep, only_stereo, coarse, ori)
             assert n1 == n2 and p1 == p2, (only_stereo, coarse, ori)
         assert len(p2) > 5
+        # "next" rows: SearchByBoW (both overloads) and SearchForInitialization
+        nbest = 0
+        for (frame_version, ratio, ori) in [(True, 0.7, True), (False, 0.8, False), (True, 0.9, False), (False, 0.75, True)]:
+            n1, m1 = M.ORBmatcher(ratio, ori).SearchByBoW(ex, kf1[0], kf2[0], frame_version)
+            n2, m2 = ol.oracle_search_by_bow(kf1[0], kf2[0], ratio, frame_version, ori)
+            assert n1 == n2 and np.array_equal(m1, m2), (frame_version, ratio, ori)
+            nbest = max(nbest, n2)
+        assert nbest > 5
+        f1 = sc.views.frame_view(kf1[1], kf1[2], scales, w, h); f2 = sc.views.frame_view(kf2[1], kf2[2], scales, w, h)
+        nbest = 0
+        for (win, ratio, ori) in [(100, 0.9, True), (30, 0.9, False)]:
+            pa = np.ascontiguousarray(np.stack([kf1[1]["x"], kf1[1]["y"]], 1), np.float32); pb = pa.copy()
+            n1, m1 = M.ORBmatcher(ratio, ori).SearchForInitialization(ex, f1, f2, pa, win)
+            n2, m2 = ol.oracle_search_for_initialization(f1, f2, pb, win, ratio, ori)
+            assert n1 == n2 and np.array_equal(m1, m2) and pa.tobytes() == pb.tobytes(), (win, ratio, ori)
+            nbest = max(nbest, n2)
+        assert nbest > 5
 
 
 def test_guided_searches_emulated(emu_lib):
