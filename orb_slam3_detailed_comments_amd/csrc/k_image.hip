@@ -268,7 +268,6 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
     if (tid == 0) s_flags[0] = 0;
     __syncthreads();
     const int t0 = imin(iniTh, minTh);
-    const int npx = iw * ih;
     const unsigned M = (1u << 20) / (unsigned)iw + 1u;      // p / iw == (p * M) >> 20 exactly for p < 2^13, iw <= 128
     const unsigned long long lt = (1ull << lane) - 1ull;
     // ---- A ----  work item = (row y, dword group g): 4 adjacent pixels per lane, packed 16-bit arithmetic.

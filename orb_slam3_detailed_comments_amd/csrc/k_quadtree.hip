@@ -7,14 +7,17 @@
 //   * the std::list is an array in list order; a full pass replaces it by
 //       [children of the LAST divided node ... children of the FIRST divided node] ++ [undivided nodes]
 //     with each child block ordered n4,n3,n2,n1 (push_front order), empty children dropped;
-//   * a node's keys are a contiguous span of a key buffer; DivideNode is a *stable* 4-way partition of
-//     the span (wave ballots), so keys keep the reference's vKeys order and "first max response wins"
-//     (:1028-1053) is "first max in the span";
+//   * a node's keys are a contiguous span of a key buffer, children laid out n1|n2|n3|n4.  ONE stable counting sort by
+//     (root, first D child digits) up front puts every node of depth <= D in that state at once (D <= 5, <= 1024 buckets,
+//     bucket code = xpart[x] + ypart[y] from two LDS tables); dividing such a node is a difference of bucket offsets.
+//     Deeper nodes are divided by *stable* 4-way partitions of their span (wave ballots; whole workgroup for huge spans);
+//   * "first max response wins" (:1028-1053) refers to vKeys order = FAST emission order, which is a function of the key
+//     (cell row, cell column, y, x) and is recomputed in the final selection;
 //   * bNoMore <=> span length 1;
-//   * the final rounds (:940-1020) sort (size, node) pairs with a single-lane model of libstdc++'s
-//     std::sort (libstdcxx_sort_model.h), then a prefix over "non-empty children - 1" finds where
-//     `lNodes.size() >= N` breaks the loop.
-// Key buffers A/B live in HBM (L2-resident, a few KB per level); node lists live in LDS.
+//   * the final rounds (:940-1020) sort (size, node) pairs with a workgroup-parallel model of libstdc++'s std::sort
+//     (partition tree level by level, then a stable rank inside every final range of <= 16), then a prefix over
+//     "non-empty children - 1" finds where `lNodes.size() >= N` breaks the loop.
+// Key buffers A/B live in HBM (L2-resident); node lists, bucket offsets and scratch live in LDS.
 #include "orbx_types.h"
 #include "orbx_block.h"
 #include "libstdcxx_sort_model.h"
@@ -146,13 +149,6 @@ struct QuadCls {    // DivideNode's key -> child test (:651-661)
     __device__ __forceinline__ int operator()(uint32_t key) const {
         const bool left = key_x(key) < mx, top = key_y(key) < my;
         return left ? (top ? 0 : 2) : (top ? 1 : 3);
-    }
-};
-struct RootCls {    // vpIniNodes[kp.pt.x / hX] (:763): roots r0, r0+1, r0+2 -> classes 0..2, every later root -> class 3
-    float hX; int r0;
-    __device__ __forceinline__ int operator()(uint32_t key) const {
-        const int d = __float2int_rz(__fdiv_rn((float)key_x(key), hX)) - r0;
-        return d < 3 ? d : 3;
     }
 };
 
