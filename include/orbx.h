@@ -219,6 +219,17 @@ int orbm_search_for_triangulation(orbx_extractor* h, const OrbmKeyFrameView* K1,
                                   const float F12[9], const float ep[2], int only_stereo, int coarse,
                                   int check_orientation, int* matches12, int* nmatches);
 
+/* Batched Frame::GetFeaturesInArea + Hamming distance: the building block the remaining projection-type searches of the
+ * reference (SearchByProjection(KeyFrame*, Sim3, ...) src/ORBmatcher.cc:495-732, SearchByProjection(Frame&, KeyFrame*, ...) :2196-2324,
+ * Fuse :1325-1675, SearchBySim3 :1689-1932) share: for every query (x, y, r, minLevel, maxLevel, descriptor) the keypoints
+ * of F in the window, in the reference's GetFeaturesInArea order, with their distance to the query descriptor and their octave.
+ * None of those callers has an order-dependent accept loop, so they take the minimum over their own gates on these lists.
+ * CSR output: start[Q], count[Q]; entry k of query q is idx[start[q]+k], dist[...], level[...].  `cap` = capacity of the entry
+ * arrays; returns the total number of entries (> cap: nothing is copied, call again with a larger cap). */
+typedef struct OrbmAreaQuery { float x, y, r; int min_level, max_level; } OrbmAreaQuery;
+int orbm_area_search_batch(orbx_extractor* h, const OrbmFrameView* F, const OrbmAreaQuery* queries, const uint8_t* query_desc, int Q,
+                           int* start, int* count, int* idx, int* dist, int* level, int cap);
+
 /* ---- "next" rows of SURVEY.md §8f, built on the same kernels ---- */
 /* ORBmatcher::SearchByBoW.  K1 = the key frame whose map points are searched (has_map_point[i] = map point present and not bad),
  * K2 = the other side.  th_inclusive = 1: SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (src/ORBmatcher.cc:259-493: accept

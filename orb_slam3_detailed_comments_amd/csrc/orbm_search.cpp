@@ -119,6 +119,27 @@ int orbm_get_features_in_area(orbx_extractor* h, const OrbmFrameView* F, float x
     return c.count[0];
 }
 
+int orbm_area_search_batch(orbx_extractor* h, const OrbmFrameView* F, const OrbmAreaQuery* queries, const uint8_t* query_desc, int Q,
+                           int* start, int* count, int* idx, int* dist, int* level, int cap) {
+    if (!h || !F || (Q > 0 && (!queries || !query_desc || !start || !count))) return fail(ORBX_E_ARG, "null");
+    rt::set_device(h->device);
+    DeviceFrame D;
+    int rc = upload_frame(h, F, &D); if (rc) return rc;
+    std::vector<AreaQuery> qs(Q);
+    for (int i = 0; i < Q; i++) {
+        AreaQuery& q = qs[i]; memset(&q, 0, sizeof q);
+        q.x = queries[i].x; q.y = queries[i].y; q.r = queries[i].r; q.min_level = queries[i].min_level; q.max_level = queries[i].max_level;
+        q.active = 1; q.gate = 0;
+    }
+    Csr c;
+    rc = run_area_search(h, D, qs, query_desc, &c); if (rc) return rc;
+    int total = 0;
+    for (int i = 0; i < Q; i++) { start[i] = c.start[i]; count[i] = c.count[i]; total = std::max(total, c.start[i] + c.count[i]); }
+    if (total <= cap && idx && dist && level)
+        for (int k = 0; k < total; k++) { idx[k] = c.ent[2 * (size_t)k]; dist[k] = c.ent[2 * (size_t)k + 1] & 0xFFFF; level[k] = c.ent[2 * (size_t)k + 1] >> 16; }
+    return total;
+}
+
 int orbm_search_by_projection_mappoints(orbx_extractor* h, const OrbmFrameView* F, const OrbmMapPointView* P, float th, int far_points,
                                         float th_far, float nnratio, int* assigned, int* nmatches_out) {
     if (!h || !F || !P || !assigned) return fail(ORBX_E_ARG, "null");

@@ -100,3 +100,25 @@ def GetFeaturesInArea(ext, frame, x, y, r, minLevel=-1, maxLevel=-1):
     if n < 0:
         ext._lib.check(n)
     return out[:n].copy()
+
+
+def AreaSearchBatch(ext, frame, queries, query_desc):
+    """Batched GetFeaturesInArea + Hamming distances (orbm_area_search_batch).  queries: [Q,5] float array (x, y, r, minLevel,
+    maxLevel); returns per query a list of (idx, dist, level) in the reference's GetFeaturesInArea order."""
+    q = np.zeros(len(queries), np.dtype([("x", "<f4"), ("y", "<f4"), ("r", "<f4"), ("mn", "<i4"), ("mx", "<i4")]))
+    qa = np.asarray(queries, np.float64).reshape(-1, 5)
+    q["x"], q["y"], q["r"], q["mn"], q["mx"] = qa[:, 0], qa[:, 1], qa[:, 2], qa[:, 3].astype(np.int32), qa[:, 4].astype(np.int32)
+    d = np.ascontiguousarray(query_desc, np.uint8).reshape(len(q), 32)
+    Q = len(q)
+    start = np.zeros(Q, np.int32); count = np.zeros(Q, np.int32)
+    cap = max(64 * Q, 1024)
+    for _ in range(2):
+        idx = np.zeros(cap, np.int32); dist = np.zeros(cap, np.int32); lvl = np.zeros(cap, np.int32)
+        tot = ext._lib.L.orbm_area_search_batch(ext._h, frame.ref(), q.ctypes.data, d.ctypes.data, Q, start.ctypes.data, count.ctypes.data,
+                                                idx.ctypes.data, dist.ctypes.data, lvl.ctypes.data, cap)
+        if tot < 0:
+            ext._lib.check(tot)
+        if tot <= cap:
+            break
+        cap = tot
+    return [list(zip(idx[s:s + c].tolist(), dist[s:s + c].tolist(), lvl[s:s + c].tolist())) for s, c in zip(start.tolist(), count.tolist())]

@@ -115,3 +115,24 @@ def test_golden_fixture(emu_lib):
     ex = ORBextractor(500, 1.2, 8, 20, 7, lib=emu_lib)
     mono, k, d = ex(g["image"], None, (100, 250))
     assert mono == int(g["mono_b"]) and k.tobytes() == g["kps_b"].tobytes() and np.array_equal(d, g["desc_b"])
+
+
+def test_handle_reuse_across_sizes_and_batches(emu_lib):
+    """One handle, changing resolution and batch size between calls: tables and device buffers are rebuilt transparently."""
+    ex = ORBextractor(300, 1.2, 8, 20, 7, lib=emu_lib)
+    a = synth.corner_field(376, 240, seed=40, nrect=800); b = synth.corner_field(320, 300, seed=41, nrect=800)
+    ra1 = ex(a)
+    rb = ex.extract_batch(np.stack([b, b[::-1].copy(), b]))
+    ra2 = ex(a)
+    assert _same(ra1, ra2) and _same(ra1, ol.OracleExtractor(300).extract(a))
+    assert _same(rb[0], rb[2]) and _same(rb[0], ol.OracleExtractor(300).extract(b)) and _same(rb[1], ol.OracleExtractor(300).extract(b[::-1].copy()))
+    # strided input (a view into a wider buffer), like a cv::Mat ROI
+    wide = np.zeros((240, 500), np.uint8); wide[:, 60:436] = a
+    roi = wide[:, 60:436]
+    mono = np.zeros(1, np.int32)
+    import ctypes as C
+    cap = ex.max_keypoints()
+    from orb_slam3_detailed_comments_amd._lib import KP_DTYPE
+    kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8); n = C.c_int(); m = C.c_int()
+    emu_lib.check(emu_lib.L.orbx_extract(ex._h, roi.ctypes.data, 376, 240, 500, 0, 0, kps.ctypes.data, desc.ctypes.data, cap, C.byref(n), C.byref(m)))
+    assert m.value == ra1[0] and ol.kps_equal(kps[:n.value], ra1[1]) and np.array_equal(desc[:n.value], ra1[2])

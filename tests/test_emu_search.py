@@ -20,6 +20,15 @@ def run_all(lib, w, h, nf, M_points, seeds):
         for (x, y, r, mn, mx) in [(w / 2, h / 2, 40, -1, -1), (10, 10, 60, 0, 3), (w - 5, h - 5, 30, 2, -1), (w / 3, h / 2, 25, 0, -1),
                                   (-50, 100, 20, -1, -1), (w + 200, 100, 20, -1, -1), (w / 2, h / 2, 1000, 1, 2), (200, 150, 0.5, -1, -1)]:
             assert np.array_equal(M.GetFeaturesInArea(ex, fv, x, y, r, mn, mx), ol.oracle_features_in_area(fv, x, y, r, mn, mx)), (x, y, r, mn, mx)
+        # batched window search (building block of the Sim3 / Fuse projection variants)
+        qs = [(w / 2, h / 2, 40, -1, -1), (10, 10, 60, 0, 3), (w - 5, h - 5, 30, 2, -1), (-50, 100, 20, -1, -1), (200, 150, 25, 1, 1)]
+        qd = rng.integers(0, 256, (len(qs), 32), dtype=np.uint8)
+        res = M.AreaSearchBatch(ex, fv, qs, qd)
+        for (x, y, r, mn, mx), dq, lst in zip(qs, qd, res):
+            exp_idx = ol.oracle_features_in_area(fv, x, y, r, mn, mx)
+            assert [e[0] for e in lst] == exp_idx.tolist()
+            assert [e[1] for e in lst] == [int(np.unpackbits(dq ^ d[i]).sum()) for i in exp_idx]
+            assert [e[2] for e in lst] == k["octave"][exp_idx].tolist()
         # M4
         mps = sc.map_points_for_frame(k, d, u, scales, M_points, rng, w, h)
         for (th, far, thfar, ratio) in [(3.0, False, 0.0, 0.8), (1.0, True, 20.0, 0.8), (5.0, False, 0.0, 0.6)]:
