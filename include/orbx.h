@@ -230,6 +230,46 @@ typedef struct OrbmAreaQuery { float x, y, r; int min_level, max_level; } OrbmAr
 int orbm_area_search_batch(orbx_extractor* h, const OrbmFrameView* F, const OrbmAreaQuery* queries, const uint8_t* query_desc, int Q,
                            int* start, int* count, int* idx, int* dist, int* level, int cap);
 
+/* ---- remaining projection-type searches ----
+ * The caller evaluates the geometry in front of GetFeaturesInArea with the reference's own Sophus/Eigen code (Tcw * p3Dw, project,
+ * IsInImage, min/max distance, viewing angle, PredictScale) and hands the survivors over as numbers; window search, level window,
+ * chi-square gate and every Hamming distance run on the device, the (order-dependent) accept loop is replayed in order. */
+typedef struct OrbmProjectedPointView {
+    int M;
+    const uint8_t* valid;                 /* 1 = the point reaches GetFeaturesInArea in the reference's loop */
+    const float* u; const float* v;       /* its projection */
+    const float* ur;                      /* uv(0) - bf*invz: read by the Fuse chi-square gate only (may be NULL otherwise) */
+    const int* pred_level;                /* pMP->PredictScale(dist, pKF) */
+    const float* angle;                   /* pKF->mvKeysUn[i].angle: read by orbm_search_by_projection_keyframe with check_orientation only */
+    const uint8_t* desc;                  /* pMP->GetDescriptor(), M x 32 */
+} OrbmProjectedPointView;
+
+/* ORBmatcher::SearchByProjection(KeyFrame* pKF, Sim3f& Scw, vpPoints, vpMatched, th, ratioHamming) (src/ORBmatcher.cc:495-606) and
+ * the overload that also returns the key frame of each point (:608-732; vpMatchedKF[idx] = vpPointsKFs[assigned[idx]]).
+ * KF->occupied[idx] = (vpMatched[idx] != NULL) on entry.  assigned[idx] = index of the point written to vpMatched[idx], else -1. */
+int orbm_search_by_projection_sim3(orbx_extractor* h, const OrbmFrameView* KF, const OrbmProjectedPointView* P, float th,
+                                   float ratio_hamming, int* assigned, int* nmatches);
+
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:2196-2324).
+ * Cur->occupied[i] = (CurrentFrame.mvpMapPoints[i] != NULL); P has one entry per feature of pKF.  assigned[i] = index into pKF of the
+ * map point written to CurrentFrame.mvpMapPoints[i]; -1 untouched; -2 written and reset by the rotation-consistency check. */
+int orbm_search_by_projection_keyframe(orbx_extractor* h, const OrbmFrameView* Cur, const OrbmProjectedPointView* P, float th,
+                                       int orb_dist, int check_orientation, int* assigned, int* nmatches);
+
+/* Candidate search of ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight) (src/ORBmatcher.cc:1325-1528; chi2_gate = 1, inv_level_sigma2 =
+ * pKF->mvInvLevelSigma2) and of Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (:1543-1660; chi2_gate = 0).  best_idx[i] = the key-frame
+ * feature the reference would fuse point i with (bestDist <= TH_LOW), else -1; best_dist may be NULL.  The map surgery that follows
+ * (Replace / AddObservation / AddMapPoint) mutates the caller's map and is done by the caller, in point order, from best_idx.
+ * For bRight build KF from mvKeysRight / the right descriptors and add NLeft to the returned indices. */
+int orbm_fuse_candidates(orbx_extractor* h, const OrbmFrameView* KF, const OrbmProjectedPointView* P, float th, int chi2_gate,
+                         const float* inv_level_sigma2, int* best_idx, int* best_dist);
+
+/* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, S12, th) (src/ORBmatcher.cc:1689-1932).  P1in2 has one entry per feature of KF1 (its
+ * map point transformed by S21 and projected into KF2; valid = present, good, not already matched, passes the depth / image / distance
+ * tests), P2in1 the reverse.  matches12[i1] = idx2 of the mutually consistent new match, else -1; *nfound = the reference's return value. */
+int orbm_search_by_sim3(orbx_extractor* h, const OrbmFrameView* KF1, const OrbmFrameView* KF2, const OrbmProjectedPointView* P1in2,
+                        const OrbmProjectedPointView* P2in1, float th, int* matches12, int* nfound);
+
 /* ---- "next" rows of SURVEY.md §8f, built on the same kernels ---- */
 /* ORBmatcher::SearchByBoW.  K1 = the key frame whose map points are searched (has_map_point[i] = map point present and not bad),
  * K2 = the other side.  th_inclusive = 1: SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (src/ORBmatcher.cc:259-493: accept

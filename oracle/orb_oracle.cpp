@@ -539,6 +539,9 @@ struct OLast {
     int N; const uint8_t* valid; const float* proj_u; const float* proj_v; const float* inv_z; const int* octave; const float* angle;
     const uint8_t* has_obs; const uint8_t* desc;
 };
+struct OProj {      // OrbmProjectedPointView: map points already projected by the caller
+    int M; const uint8_t* valid; const float* u; const float* v; const float* ur; const int* pred_level; const float* angle; const uint8_t* desc;
+};
 struct OKeyFrame {
     int N; const Kp* keys; const uint8_t* desc; const float* u_right; const uint8_t* has_mp;
     int fv_nodes; const uint32_t* fv_node_id; const int* fv_start; const uint32_t* fv_feat; int nlevels; const float* scale; const float* sigma2;
@@ -871,6 +874,166 @@ int orbo_search_for_initialization(const OFrame* F1, const OFrame* F2, float* pr
     }
     for (int i1 = 0; i1 < F1->N; i1++) if (m12[i1] >= 0) { prev[2 * i1] = F2->keys[m12[i1]].x; prev[2 * i1 + 1] = F2->keys[m12[i1]].y; }
     return nmatches;
+}
+
+// ---- remaining projection-type searches.  The geometric skip tests in front of GetFeaturesInArea are the
+// caller's (OProj::valid); KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:843-884) = Frame::GetFeaturesInArea without level check.
+
+// ORBmatcher::SearchByProjection(KeyFrame*, Sim3f&, vpPoints, vpMatched, th, ratioHamming), src/ORBmatcher.cc:495-606, and the
+// overload that also records the key frame of each point (:608-732).  occupied = vpMatched[idx] != NULL on entry.
+int orbo_search_by_projection_sim3(const OFrame* KF, const OProj* P, float th, float ratioHamming, int* assigned) {
+    const int TH_LOW = 50;
+    Grid g = build_grid(*KF);
+    std::vector<uint8_t> vpMatched(KF->N + 1, 0);
+    if (KF->occupied) memcpy(vpMatched.data(), KF->occupied, KF->N);
+    for (int i = 0; i < KF->N; i++) assigned[i] = -1;
+    int nmatches = 0;
+    for (int iMP = 0; iMP < P->M; iMP++) {
+        if (!P->valid[iMP]) continue;
+        const int nPredictedLevel = P->pred_level[iMP];
+        if (nPredictedLevel < 0 || nPredictedLevel >= KF->nlevels) continue;
+        const float radius = th * KF->scale[nPredictedLevel];
+        const std::vector<int> vIndices = features_in_area(*KF, g, P->u[iMP], P->v[iMP], radius, -1, -1);
+        if (vIndices.empty()) continue;
+        const uint8_t* dMP = P->desc + 32 * (size_t)iMP;
+        int bestDist = 256, bestIdx = -1;
+        for (int idx : vIndices) {
+            if (vpMatched[idx]) continue;
+            const int kpLevel = KF->keys[idx].octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            const int dist = descriptor_distance(dMP, KF->desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestIdx >= 0 && bestDist <= TH_LOW * ratioHamming) { vpMatched[bestIdx] = 1; assigned[bestIdx] = iMP; nmatches++; }
+    }
+    return nmatches;
+}
+
+// ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist), src/ORBmatcher.cc:2196-2324.
+// occupied = CurrentFrame.mvpMapPoints[i2] != NULL; P->angle[i] = pKF->mvKeysUn[i].angle.
+int orbo_search_by_projection_keyframe(const OFrame* C, const OProj* P, float th, int ORBdist, int checkOri, int* assigned) {
+    const int HISTO_LENGTH = 30;
+    Grid g = build_grid(*C);
+    std::vector<uint8_t> occ(C->N + 1, 0);
+    if (C->occupied) memcpy(occ.data(), C->occupied, C->N);
+    for (int i = 0; i < C->N; i++) assigned[i] = -1;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0;
+    for (int i = 0; i < P->M; i++) {
+        if (!P->valid[i]) continue;
+        const int nPredictedLevel = P->pred_level[i];
+        if (nPredictedLevel < 0 || nPredictedLevel >= C->nlevels) continue;
+        const float radius = th * C->scale[nPredictedLevel];
+        const std::vector<int> vIndices2 = features_in_area(*C, g, P->u[i], P->v[i], radius, nPredictedLevel - 1, nPredictedLevel + 1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* dMP = P->desc + 32 * (size_t)i;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int i2 : vIndices2) {
+            if (occ[i2]) continue;
+            const int dist = descriptor_distance(dMP, C->desc + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestIdx2 >= 0 && bestDist <= ORBdist) {
+            occ[bestIdx2] = 1; assigned[bestIdx2] = i; nmatches++;
+            if (checkOri) {
+                float rot = P->angle[i] - C->keys[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int idx : rotHist[i]) { assigned[idx] = -2; nmatches--; }
+    }
+    return nmatches;
+}
+
+// candidate search of ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight) (src/ORBmatcher.cc:1325-1528, chi2_gate = 1) and of
+// Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (:1543-1660, chi2_gate = 0): bestIdx per point, -1 when bestDist > TH_LOW.
+// The map surgery that follows (Replace / AddObservation) mutates the caller's map and stays with the caller.
+void orbo_fuse_candidates(const OFrame* KF, const OProj* P, float th, int chi2_gate, const float* invLevelSigma2, int* best_idx, int* best_dist) {
+    const int TH_LOW = 50;
+    Grid g = build_grid(*KF);
+    for (int i = 0; i < P->M; i++) {
+        best_idx[i] = -1; best_dist[i] = -1;
+        if (!P->valid[i]) continue;
+        const int nPredictedLevel = P->pred_level[i];
+        if (nPredictedLevel < 0 || nPredictedLevel >= KF->nlevels) continue;
+        const float radius = th * KF->scale[nPredictedLevel];
+        const float u = P->u[i], v = P->v[i];
+        const std::vector<int> vIndices = features_in_area(*KF, g, u, v, radius, -1, -1);
+        if (vIndices.empty()) continue;
+        const uint8_t* dMP = P->desc + 32 * (size_t)i;
+        int bestDist = 256, bestIdx = -1;
+        for (int idx : vIndices) {
+            const Kp& kp = KF->keys[idx];
+            const int kpLevel = kp.octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            if (chi2_gate) {
+                if (KF->u_right && KF->u_right[idx] >= 0) {
+                    const float kpx = kp.x, kpy = kp.y, kpr = KF->u_right[idx];
+                    const float ex = u - kpx, ey = v - kpy, er = P->ur[i] - kpr;
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * invLevelSigma2[kpLevel] > 7.8) continue;
+                } else {
+                    const float kpx = kp.x, kpy = kp.y;
+                    const float ex = u - kpx, ey = v - kpy;
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * invLevelSigma2[kpLevel] > 5.99) continue;
+                }
+            }
+            const int dist = descriptor_distance(dMP, KF->desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW) { best_idx[i] = bestIdx; best_dist[i] = bestDist; }
+    }
+}
+
+// ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, S12, th), src/ORBmatcher.cc:1689-1932.  P1in2[i1] = map point of feature i1 of
+// KF1 projected into KF2 (valid = has a good, not yet matched map point that passes the depth/image/distance tests), P2in1 likewise.
+int orbo_search_by_sim3(const OFrame* KF1, const OFrame* KF2, const OProj* P1in2, const OProj* P2in1, float th, int* matches12) {
+    const int TH_HIGH = 100;
+    const int N1 = KF1->N, N2 = KF2->N;
+    std::vector<int> vnMatch1(N1 + 1, -1), vnMatch2(N2 + 1, -1);
+    for (int dir = 0; dir < 2; dir++) {
+        const OFrame* T = dir == 0 ? KF2 : KF1; const OProj* P = dir == 0 ? P1in2 : P2in1;
+        std::vector<int>& vn = dir == 0 ? vnMatch1 : vnMatch2;
+        Grid g = build_grid(*T);
+        for (int i = 0; i < P->M; i++) {
+            if (!P->valid[i]) continue;
+            const int nPredictedLevel = P->pred_level[i];
+            if (nPredictedLevel < 0 || nPredictedLevel >= T->nlevels) continue;
+            const float radius = th * T->scale[nPredictedLevel];
+            const std::vector<int> vIndices = features_in_area(*T, g, P->u[i], P->v[i], radius, -1, -1);
+            if (vIndices.empty()) continue;
+            const uint8_t* dMP = P->desc + 32 * (size_t)i;
+            int bestDist = 0x7fffffff, bestIdx = -1;
+            for (int idx : vIndices) {
+                const Kp& kp = T->keys[idx];
+                if (kp.octave < nPredictedLevel - 1 || kp.octave > nPredictedLevel) continue;
+                const int dist = descriptor_distance(dMP, T->desc + 32 * (size_t)idx);
+                if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+            }
+            if (bestDist <= TH_HIGH) vn[i] = bestIdx;
+        }
+    }
+    int nFound = 0;
+    for (int i1 = 0; i1 < N1; i1++) {
+        matches12[i1] = -1;
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0) {
+            const int idx1 = vnMatch2[idx2];
+            if (idx1 == i1) { matches12[i1] = idx2; nFound++; }
+        }
+    }
+    return nFound;
 }
 
 // glibc cosf/sinf, exposed so tests can pin the device-side model (csrc/glibc_sincosf_model.h).

@@ -30,6 +30,7 @@ SYMBOLS = [
     "orbm_hamming_matrix", "orbm_stereo_match", "orbm_stereo_fetch", "orbm_knn2", "orbm_knn2_fetch",
     "orbm_get_features_in_area", "orbm_search_by_projection_mappoints", "orbm_search_by_projection_frame",
     "orbm_search_for_triangulation", "orbm_search_by_bow", "orbm_search_for_initialization", "orbm_area_search_batch",
+    "orbm_search_by_projection_sim3", "orbm_search_by_projection_keyframe", "orbm_fuse_candidates", "orbm_search_by_sim3",
     "orbx_last_error",
 ]
 
@@ -88,6 +89,10 @@ class OrbxLib:
         L.orbm_search_by_bow.argtypes = [vp, vp, vp, f, i, i, vp, ip]
         L.orbm_search_for_initialization.argtypes = [vp, vp, vp, vp, i, f, i, vp, ip]
         L.orbm_area_search_batch.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp, vp, i]
+        L.orbm_search_by_projection_sim3.argtypes = [vp, vp, vp, f, f, vp, ip]
+        L.orbm_search_by_projection_keyframe.argtypes = [vp, vp, vp, f, i, i, vp, ip]
+        L.orbm_fuse_candidates.argtypes = [vp, vp, vp, f, i, vp, vp, vp]
+        L.orbm_search_by_sim3.argtypes = [vp, vp, vp, vp, vp, f, vp, ip]
         L.orbx_last_error.restype = C.c_char_p
 
     def check(self, rc):

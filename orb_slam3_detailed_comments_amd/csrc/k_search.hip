@@ -86,6 +86,19 @@ __device__ __forceinline__ bool area_accept(const AreaQuery& A, const KeyPointRe
     }
     return true;
 }
+// reprojection gate of ORBmatcher::Fuse (src/ORBmatcher.cc:1437-1469): e2 * invSigma2[octave] > 7.8 (stereo keypoint, 3 dof)
+// or > 5.99 (monocular, 2 dof), float product compared as double like the reference's float-vs-double-literal comparison
+__device__ __forceinline__ bool chi2_accept(const AreaQuery& A, const KeyPointRec& k, float ur, const GridParams& g) {
+    const float ex = __fsub_rn(A.x, k.x), ey = __fsub_rn(A.y, k.y);
+    float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+    const float inv = g.inv_sigma2[k.octave & (kMaxLevels - 1)];
+    if (ur >= 0) {
+        const float er = __fsub_rn(A.ur, ur);
+        e2 = __fadd_rn(e2, __fmul_rn(er, er));
+        return !((double)__fmul_rn(e2, inv) > 7.8);
+    }
+    return !((double)__fmul_rn(e2, inv) > 5.99);
+}
 
 // One wave per query.  grid (ceil(Q/4)), 256 threads.  Lane l of a chunk owns window cell l (cells enumerated ix-major,
 // iy-minor like the reference's loops): pass 0 counts, one atomicAdd reserves the query's span of the entry pool, pass 1
@@ -125,7 +138,8 @@ __global__ void __launch_bounds__(256) k_area_search(const AreaQuery* __restrict
                 int cnt = 0;
                 for (int j = s; j < e; j++) {
                     const int idx = cell_items[j];
-                    cnt += area_accept(A, kps[idx], idx, check_levels, gate_right, u_right) ? 1 : 0;
+                    const KeyPointRec k = kps[idx];
+                    cnt += (area_accept(A, k, idx, check_levels, gate_right, u_right) && (A.gate != 2 || chi2_accept(A, k, u_right[idx], g))) ? 1 : 0;
                 }
                 const int incl = wave_incl_scan(cnt);
                 if (pass == 1 && start >= 0) {
@@ -134,6 +148,7 @@ __global__ void __launch_bounds__(256) k_area_search(const AreaQuery* __restrict
                         const int idx = cell_items[j];
                         const KeyPointRec k = kps[idx];
                         if (!area_accept(A, k, idx, check_levels, gate_right, u_right)) continue;
+                        if (A.gate == 2 && !chi2_accept(A, k, u_right[idx], g)) continue;
                         const unsigned long long* df = fdesc + 4 * (size_t)idx;
                         const int dist = __popcll(d0 ^ df[0]) + __popcll(d1 ^ df[1]) + __popcll(d2 ^ df[2]) + __popcll(d3 ^ df[3]);
                         int2 ent; ent.x = idx; ent.y = dist | (k.octave << 16);

@@ -39,6 +39,7 @@ int upload_frame(orbx_extractor* h, const OrbmFrameView* F, DeviceFrame* D) {
     e |= h->d_si[SI_CELLOF].ensure(N + 1) | h->d_si[SI_CELLSTART].ensure(64 * 48 + 2) | h->d_si[SI_CELLITEMS].ensure(N + 1);
     if (e) return fail(ORBX_E_DEVICE, "upload/allocation failed");
     D->kps = (const KeyPointRec*)h->d_sr[SR_KPS].p; D->desc = (const unsigned long long*)h->d_sr[SR_DESC].p; D->ur = (const float*)h->d_sr[SR_UR].p;
+    memset(&D->g, 0, sizeof D->g);
     D->g.min_x = F->min_x; D->g.min_y = F->min_y; D->g.gw_inv = F->grid_w_inv; D->g.gh_inv = F->grid_h_inv;
     dim3 one(1, 1, 1), blk(256, 1, 1);
     ORBX_LAUNCH(k_grid_build, one, blk, 0, h->s0, D->kps, N, D->g, h->d_si[SI_CELLOF].p, h->d_si[SI_CELLSTART].p, h->d_si[SI_CELLITEMS].p);
@@ -447,6 +448,158 @@ int orbm_search_for_initialization(orbx_extractor* h, const OrbmFrameView* F1, c
     }
     for (int i1 = 0; i1 < N1; i1++) if (matches12[i1] >= 0) { prev[2 * i1] = F2->keys_un[matches12[i1]].x; prev[2 * i1 + 1] = F2->keys_un[matches12[i1]].y; }
     if (nmatches_out) *nmatches_out = nmatches;
+    return ORBX_OK;
+}
+
+}  // extern "C"
+
+// ---- the remaining projection-type searches.  The caller evaluates the geometry (Sophus/Eigen op order
+// stays the reference's) and hands over, per map point: valid (= survived every skip test in front of GetFeaturesInArea), the
+// projection, the predicted level and the descriptor.  GetFeaturesInArea, the level window, the chi-square gate and all Hamming
+// distances run on the GPU (k_area_search); the accept logic is replayed here over the ordered candidate lists.
+namespace {
+
+// one k_area_search over P's valid points: window radius th * scale[pred], levels [pred-1, pred+hi]
+int projected_candidates(orbx_extractor* h, const OrbmFrameView* F, const OrbmProjectedPointView* P, float th, int hi, int gate,
+                         const float* inv_sigma2, std::vector<AreaQuery>* qs, Csr* c) {
+    if (!P || P->M < 0 || (P->M > 0 && (!P->valid || !P->u || !P->v || !P->pred_level || !P->desc))) return fail(ORBX_E_ARG, "bad point view");
+    if (F && F->nlevels > kMaxLevels) return fail(ORBX_E_ARG, "too many levels");
+    DeviceFrame D;
+    int rc = upload_frame(h, F, &D); if (rc) return rc;
+    if (gate == 2) {
+        if (!inv_sigma2) return fail(ORBX_E_ARG, "chi-square gate without mvInvLevelSigma2");
+        for (int l = 0; l < F->nlevels; l++) D.g.inv_sigma2[l] = inv_sigma2[l];
+    }
+    const int M = P->M;
+    qs->resize(M);
+    for (int i = 0; i < M; i++) {
+        AreaQuery& q = (*qs)[i]; memset(&q, 0, sizeof q);
+        if (!P->valid[i]) continue;
+        const int lvl = P->pred_level[i];
+        if (lvl < 0 || lvl >= F->nlevels) continue;
+        q.x = P->u[i]; q.y = P->v[i]; q.r = th * F->scale_factors[lvl];
+        q.ur = P->ur ? P->ur[i] : 0.0f;
+        q.min_level = lvl - 1; q.max_level = lvl + hi; q.active = 1; q.gate = gate;
+    }
+    return run_area_search(h, D, *qs, P->desc, c);
+}
+
+}  // namespace
+
+extern "C" {
+
+int orbm_search_by_projection_sim3(orbx_extractor* h, const OrbmFrameView* KF, const OrbmProjectedPointView* P, float th, float ratio_hamming,
+                                   int* assigned, int* nmatches_out) {
+    if (!h || !KF || !P || !assigned) return fail(ORBX_E_ARG, "null");
+    rt::set_device(h->device);
+    std::vector<AreaQuery> qs; Csr c;
+    int rc = projected_candidates(h, KF, P, th, 0, 0, nullptr, &qs, &c); if (rc) return rc;
+    const int N = KF->N;
+    std::vector<uint8_t> occ(N > 0 ? N : 1, 0);
+    if (KF->occupied) memcpy(occ.data(), KF->occupied, N);          // vpMatched[idx] != NULL
+    for (int i = 0; i < N; i++) assigned[i] = -1;
+    int nmatches = 0;
+    for (int i = 0; i < P->M; i++) {                                 // src/ORBmatcher.cc:519-606 / :640-727
+        if (!qs[i].active || c.count[i] == 0) continue;
+        int bestDist = 256, bestIdx = -1;
+        for (int k = 0; k < c.count[i]; k++) {
+            const int idx = c.ent[2 * (size_t)(c.start[i] + k)], dist = c.ent[2 * (size_t)(c.start[i] + k) + 1] & 0xFFFF;
+            if (occ[idx]) continue;
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestIdx >= 0 && bestDist <= TH_LOW * ratio_hamming) { assigned[bestIdx] = i; occ[bestIdx] = 1; nmatches++; }
+    }
+    if (nmatches_out) *nmatches_out = nmatches;
+    return ORBX_OK;
+}
+
+int orbm_search_by_projection_keyframe(orbx_extractor* h, const OrbmFrameView* Cur, const OrbmProjectedPointView* P, float th, int orb_dist,
+                                       int check_ori, int* assigned, int* nmatches_out) {
+    if (!h || !Cur || !P || !assigned) return fail(ORBX_E_ARG, "null");
+    if (check_ori && P->M > 0 && !P->angle) return fail(ORBX_E_ARG, "orientation check without key-frame angles");
+    rt::set_device(h->device);
+    std::vector<AreaQuery> qs; Csr c;
+    int rc = projected_candidates(h, Cur, P, th, 1, 0, nullptr, &qs, &c); if (rc) return rc;
+    const int N = Cur->N;
+    std::vector<uint8_t> occ(N > 0 ? N : 1, 0);
+    if (Cur->occupied) memcpy(occ.data(), Cur->occupied, N);        // CurrentFrame.mvpMapPoints[i2] != NULL
+    for (int i = 0; i < N; i++) assigned[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int nmatches = 0;
+    for (int i = 0; i < P->M; i++) {                                 // src/ORBmatcher.cc:2213-2290
+        if (!qs[i].active || c.count[i] == 0) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int k = 0; k < c.count[i]; k++) {
+            const int i2 = c.ent[2 * (size_t)(c.start[i] + k)], dist = c.ent[2 * (size_t)(c.start[i] + k) + 1] & 0xFFFF;
+            if (occ[i2]) continue;
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestIdx2 >= 0 && bestDist <= orb_dist) {
+            assigned[bestIdx2] = i; occ[bestIdx2] = 1; nmatches++;
+            if (check_ori) rotHist[rot_bin(P->angle[i], Cur->keys_un[bestIdx2].angle)].push_back(bestIdx2);
+        }
+    }
+    if (check_ori) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int idx : rotHist[i]) { assigned[idx] = -2; nmatches--; }
+    }
+    if (nmatches_out) *nmatches_out = nmatches;
+    return ORBX_OK;
+}
+
+int orbm_fuse_candidates(orbx_extractor* h, const OrbmFrameView* KF, const OrbmProjectedPointView* P, float th, int chi2_gate,
+                         const float* inv_level_sigma2, int* best_idx, int* best_dist) {
+    if (!h || !KF || !P || !best_idx) return fail(ORBX_E_ARG, "null");
+    if (chi2_gate && P->M > 0 && !P->ur) return fail(ORBX_E_ARG, "chi-square gate without projected right coordinates");
+    rt::set_device(h->device);
+    std::vector<AreaQuery> qs; Csr c;
+    int rc = projected_candidates(h, KF, P, th, 0, chi2_gate ? 2 : 0, inv_level_sigma2, &qs, &c); if (rc) return rc;
+    for (int i = 0; i < P->M; i++) {                                 // src/ORBmatcher.cc:1421-1490 / :1601-1640
+        int bestDist = 256, bestIdx = -1;
+        if (qs[i].active)
+            for (int k = 0; k < c.count[i]; k++) {
+                const int idx = c.ent[2 * (size_t)(c.start[i] + k)], dist = c.ent[2 * (size_t)(c.start[i] + k) + 1] & 0xFFFF;
+                if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+            }
+        if (bestDist > TH_LOW) bestIdx = -1;                         // :1493 / :1643
+        best_idx[i] = bestIdx;
+        if (best_dist) best_dist[i] = bestIdx >= 0 ? bestDist : -1;
+    }
+    return ORBX_OK;
+}
+
+int orbm_search_by_sim3(orbx_extractor* h, const OrbmFrameView* KF1, const OrbmFrameView* KF2, const OrbmProjectedPointView* P1in2,
+                        const OrbmProjectedPointView* P2in1, float th, int* matches12, int* nfound_out) {
+    if (!h || !KF1 || !KF2 || !P1in2 || !P2in1 || !matches12) return fail(ORBX_E_ARG, "null");
+    if (P1in2->M != KF1->N || P2in1->M != KF2->N) return fail(ORBX_E_ARG, "one projected point per key-frame feature expected");
+    rt::set_device(h->device);
+    const int N1 = KF1->N, N2 = KF2->N;
+    std::vector<int> vnMatch1(N1 > 0 ? N1 : 1, -1), vnMatch2(N2 > 0 ? N2 : 1, -1);
+    for (int dir = 0; dir < 2; dir++) {                              // src/ORBmatcher.cc:1735-1826 and :1829-1915
+        const OrbmProjectedPointView* P = dir == 0 ? P1in2 : P2in1;
+        std::vector<AreaQuery> qs; Csr c;
+        int rc = projected_candidates(h, dir == 0 ? KF2 : KF1, P, th, 0, 0, nullptr, &qs, &c); if (rc) return rc;
+        std::vector<int>& out = dir == 0 ? vnMatch1 : vnMatch2;
+        for (int i = 0; i < P->M; i++) {
+            if (!qs[i].active) continue;
+            int bestDist = 0x7fffffff, bestIdx = -1;
+            for (int k = 0; k < c.count[i]; k++) {
+                const int idx = c.ent[2 * (size_t)(c.start[i] + k)], dist = c.ent[2 * (size_t)(c.start[i] + k) + 1] & 0xFFFF;
+                if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+            }
+            if (bestDist <= TH_HIGH) out[i] = bestIdx;
+        }
+    }
+    int nfound = 0;
+    for (int i1 = 0; i1 < N1; i1++) {                                // :1918-1932
+        matches12[i1] = -1;
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0 && vnMatch2[idx2] == i1) { matches12[i1] = idx2; nfound++; }
+    }
+    if (nfound_out) *nfound_out = nfound;
     return ORBX_OK;
 }
 

@@ -53,10 +53,13 @@ struct UmaxTab { int u[16]; };                        // circular patch half-wid
 struct StereoParams { float mbf, mb; int th_high, th_orb; };   // ORBmatcher::TH_HIGH, (TH_HIGH+TH_LOW)/2
 
 // ---- guided searches (k_search.hip) ----
-struct GridParams { float min_x, min_y, gw_inv, gh_inv; };      // mnMinX, mnMinY, mfGridElementWidthInv/HeightInv (include/Frame.h:250-251)
-struct AreaQuery {                                                // one GetFeaturesInArea call + the right-coordinate gate
+struct GridParams {                                               // mnMinX, mnMinY, mfGridElementWidthInv/HeightInv (include/Frame.h:250-251)
+    float min_x, min_y, gw_inv, gh_inv;
+    float inv_sigma2[kMaxLevels];                                 // mvInvLevelSigma2, read by the chi-square gate (AreaQuery::gate == 2) only
+};
+struct AreaQuery {                                                // one GetFeaturesInArea call + the per-candidate gate
     float x, y, r, ur;
-    int min_level, max_level, active, gate;
+    int min_level, max_level, active, gate;                      // gate: 0 none, 1 right coordinate (ORBmatcher.cc:107-117), 2 Fuse chi-square (:1437-1469)
 };
 struct BowItem { int idx1, start2, cnt2, out_off; };
 struct BowParams {

@@ -57,6 +57,39 @@ class ORBmatcher:
                                                                int(self.mbCheckOrientation), m12.ctypes.data, C.byref(nm)))
         return nm.value, m12
 
+    def SearchByProjectionSim3(self, ext, kf, points, th, ratioHamming=1.0):
+        """ORBmatcher::SearchByProjection(KeyFrame*, Sim3f&, vpPoints, [vpPointsKFs,] vpMatched, [vpMatchedKF,] th, ratioHamming),
+        src/ORBmatcher.cc:495 and :608.  kf: views.frame_view with occupied = (vpMatched[idx] != NULL); points:
+        views.projected_point_view.  Returns (nmatches, assigned[N]) with assigned[idx] = index of the point put in vpMatched[idx]."""
+        assigned = np.full(kf.view.N, -1, np.int32); nm = C.c_int()
+        ext._lib.check(ext._lib.L.orbm_search_by_projection_sim3(ext._h, kf.ref(), points.ref(), float(th), float(ratioHamming),
+                                                               assigned.ctypes.data, C.byref(nm)))
+        return nm.value, assigned
+
+    def SearchByProjectionKeyFrame(self, ext, cur, points, th, ORBdist):
+        """ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist), src/ORBmatcher.cc:2196.
+        cur.occupied = (CurrentFrame.mvpMapPoints[i] != NULL).  Returns (nmatches, assigned[N]) (-2: reset by the rotation check)."""
+        assigned = np.full(cur.view.N, -1, np.int32); nm = C.c_int()
+        ext._lib.check(ext._lib.L.orbm_search_by_projection_keyframe(ext._h, cur.ref(), points.ref(), float(th), int(ORBdist),
+                                                                   int(self.mbCheckOrientation), assigned.ctypes.data, C.byref(nm)))
+        return nm.value, assigned
+
+    def FuseCandidates(self, ext, kf, points, th, invLevelSigma2=None):
+        """Candidate search of both ORBmatcher::Fuse overloads (src/ORBmatcher.cc:1325 with the chi-square gate when invLevelSigma2 is
+        given, :1543 without).  Returns (bestIdx[M], bestDist[M]); -1 where the reference would not fuse."""
+        M = points.view.M
+        bi = np.full(M, -1, np.int32); bd = np.full(M, -1, np.int32)
+        s2 = None if invLevelSigma2 is None else np.ascontiguousarray(invLevelSigma2, np.float32)
+        ext._lib.check(ext._lib.L.orbm_fuse_candidates(ext._h, kf.ref(), points.ref(), float(th), int(s2 is not None),
+                                                     None if s2 is None else s2.ctypes.data, bi.ctypes.data, bd.ctypes.data))
+        return bi, bd
+
+    def SearchBySim3(self, ext, kf1, kf2, p1in2, p2in1, th):
+        """ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, S12, th), src/ORBmatcher.cc:1689.  Returns (nFound, matches12[N1])."""
+        m12 = np.full(kf1.view.N, -1, np.int32); nf = C.c_int()
+        ext._lib.check(ext._lib.L.orbm_search_by_sim3(ext._h, kf1.ref(), kf2.ref(), p1in2.ref(), p2in1.ref(), float(th), m12.ctypes.data, C.byref(nf)))
+        return nf.value, m12
+
     @staticmethod
     def DescriptorDistance(ext, a, b):
         """All-pairs Hamming distance matrix [len(a), len(b)] of 32-byte descriptors, computed on `ext`'s GPU."""

@@ -1,5 +1,5 @@
 """ctypes mirrors of the read-only structure-of-arrays views in include/orbx.h (OrbmFrameView, OrbmMapPointView,
-OrbmLastFrameView, OrbmKeyFrameView) and helpers that build them from numpy arrays."""
+OrbmLastFrameView, OrbmKeyFrameView, OrbmProjectedPointView) and helpers that build them from numpy arrays."""
 import ctypes as C
 
 import numpy as np
@@ -29,6 +29,10 @@ class KeyFrameView(C.Structure):
     _fields_ = [("N", _i), ("keys_un", _vp), ("desc", _vp), ("u_right", _vp), ("has_map_point", _vp), ("fv_nodes", _i),
                 ("fv_node_id", _vp), ("fv_start", _vp), ("fv_feat", _vp), ("nlevels", _i), ("scale_factors", _vp),
                 ("level_sigma2", _vp)]
+
+
+class ProjectedPointView(C.Structure):
+    _fields_ = [("M", _i), ("valid", _vp), ("u", _vp), ("v", _vp), ("ur", _vp), ("pred_level", _vp), ("angle", _vp), ("desc", _vp)]
 
 
 def _arr(a, dtype):
@@ -79,3 +83,10 @@ def key_frame_view(keys_un, desc, scale_factors, level_sigma2, fv_node_id, fv_st
     u = _arr(u_right, np.float32); m = _arr(has_map_point, np.uint8)
     v = KeyFrameView(len(k), _ptr(k), _ptr(d), _ptr(u), _ptr(m), len(ni), _ptr(ni), _ptr(st), _ptr(ft), len(s), _ptr(s), _ptr(g))
     return Held(v, (k, d, s, g, ni, st, ft, u, m))
+
+
+def projected_point_view(valid, u, v, pred_level, desc, ur=None, angle=None):
+    """OrbmProjectedPointView: map points whose geometry (projection, gates, PredictScale) the caller has already evaluated."""
+    a = [_arr(valid, np.uint8), _arr(u, np.float32), _arr(v, np.float32), _arr(ur, np.float32), _arr(pred_level, np.int32),
+         _arr(angle, np.float32), _arr(desc, np.uint8)]
+    return Held(ProjectedPointView(len(a[0]), *[_ptr(x) for x in a]), a)

@@ -257,3 +257,38 @@ def oracle_search_for_initialization(f1, f2, prev, window, nnratio, check_ori):
     m = np.full(max(f1.view.N, 1), -1, np.int32)
     n = L.orbo_search_for_initialization(f1.ref(), f2.ref(), prev.ctypes.data, int(window), nnratio, int(check_ori), m.ctypes.data)
     return n, m[:f1.view.N]
+
+
+def oracle_search_by_projection_sim3(kf, pts, th, ratio):
+    L = oracle()
+    L.orbo_search_by_projection_sim3.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+    a = np.full(max(kf.view.N, 1), -1, np.int32)
+    n = L.orbo_search_by_projection_sim3(kf.ref(), pts.ref(), th, ratio, a.ctypes.data)
+    return n, a[:kf.view.N]
+
+
+def oracle_search_by_projection_keyframe(cur, pts, th, orb_dist, check_ori):
+    L = oracle()
+    L.orbo_search_by_projection_keyframe.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]
+    a = np.full(max(cur.view.N, 1), -1, np.int32)
+    n = L.orbo_search_by_projection_keyframe(cur.ref(), pts.ref(), th, int(orb_dist), int(check_ori), a.ctypes.data)
+    return n, a[:cur.view.N]
+
+
+def oracle_fuse_candidates(kf, pts, th, inv_sigma2=None):
+    L = oracle()
+    L.orbo_fuse_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orbo_fuse_candidates.restype = None
+    M = pts.view.M
+    bi = np.full(max(M, 1), -1, np.int32); bd = np.full(max(M, 1), -1, np.int32)
+    s2 = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32)
+    L.orbo_fuse_candidates(kf.ref(), pts.ref(), th, int(s2 is not None), None if s2 is None else s2.ctypes.data, bi.ctypes.data, bd.ctypes.data)
+    return bi[:M], bd[:M]
+
+
+def oracle_search_by_sim3(kf1, kf2, p12, p21, th):
+    L = oracle()
+    L.orbo_search_by_sim3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    m = np.full(max(kf1.view.N, 1), -1, np.int32)
+    n = L.orbo_search_by_sim3(kf1.ref(), kf2.ref(), p12.ref(), p21.ref(), th, m.ctypes.data)
+    return n, m[:kf1.view.N]

@@ -80,3 +80,33 @@ def keyframe_pair(rng, nf=800, w=640, h=480):
     F12 = np.array([0, 0, 0, 0, 0, -1, 0, 1, 0], np.float32)
     ep = np.array([1.0e6, h / 2.0], np.float32)
     return out, F12, ep
+
+
+def projected_points(k, d, u_right, scales, rng, w, h, M=None, maxflips=45):
+    """Map points "already projected by the caller" for the Sim3 / key-frame / Fuse searches: 70 % land within a few pixels of a
+    keypoint and carry a noisy copy of its descriptor.  M=None: one point per keypoint, in keypoint order (SearchBySim3 /
+    SearchByProjection(Frame, KeyFrame) have one map point per key-frame feature)."""
+    N = len(k)
+    src = np.arange(N) if M is None else rng.integers(0, N, M)
+    M = len(src)
+    good = rng.random(M) < 0.7
+    px = np.where(good, k["x"][src] + rng.uniform(-4, 4, M), rng.uniform(-20, w + 20, M)).astype(np.float32)
+    py = np.where(good, k["y"][src] + rng.uniform(-4, 4, M), rng.uniform(-20, h + 20, M)).astype(np.float32)
+    lvl = np.clip(k["octave"][src] + rng.integers(0, 2, M), 0, len(scales) - 1).astype(np.int32)
+    base_ur = u_right[src] if u_right is not None else px - 4.0
+    ur = (np.where(base_ur >= 0, base_ur, px - 4.0) + rng.uniform(-1.5, 1.5, M)).astype(np.float32)
+    ang = ((k["angle"][src] + np.where(rng.random(M) < 0.8, rng.uniform(-6, 6, M), rng.uniform(0, 360, M))) % 360).astype(np.float32)
+    desc = np.where(good[:, None], flip_bits(d[src], rng, maxflips), rng.integers(0, 256, (M, 32), dtype=np.uint8)).astype(np.uint8)
+    return views.projected_point_view(rng.random(M) < 0.85, px, py, lvl, desc, ur, ang)
+
+
+def shifted_keyframe(k, d, scales, rng, w, h, shift=(6.0, -3.0)):
+    """A second key frame seeing the same scene: a shuffled 85 % subset of the keypoints, moved by `shift` plus noise, descriptors
+    with up to 30 flipped bits.  Returns (frame_view, keys2, desc2, perm) with perm[j] = index in k of feature j."""
+    N = len(k)
+    perm = rng.permutation(N)[: int(0.85 * N)]
+    k2 = k[perm].copy()
+    k2["x"] = (k2["x"] + shift[0] + rng.uniform(-1, 1, len(perm))).astype(np.float32)
+    k2["y"] = (k2["y"] + shift[1] + rng.uniform(-1, 1, len(perm))).astype(np.float32)
+    d2 = flip_bits(d[perm], rng, 30)
+    return views.frame_view(k2, d2, scales, w, h), k2, d2, perm

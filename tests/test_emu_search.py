@@ -67,6 +67,47 @@ def run_all(lib, w, h, nf, M_points, seeds):
             assert n1 == n2 and np.array_equal(m1, m2) and pa.tobytes() == pb.tobytes(), (win, ratio, ori)
             nbest = max(nbest, n2)
         assert nbest > 5
+        # "next" rank 2: the remaining projection-type searches
+        occ_kf = sc.views.frame_view(k, d, scales, w, h, u, (rng.random(len(k)) < 0.2).astype(np.uint8))
+        pts = sc.projected_points(k, d, u, scales, rng, w, h, M=M_points)
+        best = 0
+        for (th, ratio) in [(3, 1.0), (8, 0.8), (1, 1.5)]:
+            n1, a1 = M.ORBmatcher().SearchByProjectionSim3(ex, occ_kf, pts, th, ratio)
+            n2, a2 = ol.oracle_search_by_projection_sim3(occ_kf, pts, th, ratio)
+            assert n1 == n2 and np.array_equal(a1, a2), (th, ratio)
+            best = max(best, n2)
+        assert best > 20
+        per_feat = sc.projected_points(k, d, u, scales, rng, w, h)
+        best = 0
+        for (th, orbdist, ori) in [(10.0, 100, True), (3.0, 64, False), (6.0, 50, True)]:
+            n1, a1 = M.ORBmatcher(0.75, ori).SearchByProjectionKeyFrame(ex, occ_kf, per_feat, th, orbdist)
+            n2, a2 = ol.oracle_search_by_projection_keyframe(occ_kf, per_feat, th, orbdist, ori)
+            assert n1 == n2 and np.array_equal(a1, a2), (th, orbdist, ori)
+            best = max(best, n2)
+        assert best > 20
+        inv_s2 = (1.0 / (np.asarray(scales, np.float32) ** 2)).astype(np.float32)
+        best = 0
+        for (th, s2) in [(3.0, inv_s2), (2.5, None), (4.0, (inv_s2 * 4).astype(np.float32))]:
+            b1, d1 = M.ORBmatcher().FuseCandidates(ex, fv, pts, th, s2)
+            b2, d2 = ol.oracle_fuse_candidates(fv, pts, th, s2)
+            assert np.array_equal(b1, b2) and np.array_equal(d1, d2), th
+            best = max(best, int((b2 >= 0).sum()))
+        assert best > 20
+        mono_kf = sc.views.frame_view(k, d, scales, w, h)                 # monocular key frame: only the 5.99 branch of the gate
+        assert np.array_equal(M.ORBmatcher().FuseCandidates(ex, mono_kf, pts, 3.0, inv_s2)[0], ol.oracle_fuse_candidates(mono_kf, pts, 3.0, inv_s2)[0])
+        kf2v, k2, d2, perm = sc.shifted_keyframe(k, d, scales, rng, w, h)
+        kf1v = sc.views.frame_view(k, d, scales, w, h)
+        p12 = sc.projected_points(k, d, None, scales, rng, w, h)
+        p12.keep[1][:] += np.float32(6.0); p12.keep[2][:] -= np.float32(3.0)   # into KF2's coordinates
+        p21 = sc.projected_points(k2, d2, None, scales, rng, w, h)
+        p21.keep[1][:] -= np.float32(6.0); p21.keep[2][:] += np.float32(3.0)
+        best = 0
+        for th in (7.5, 3.0):
+            n1, m1 = M.ORBmatcher().SearchBySim3(ex, kf1v, kf2v, p12, p21, th)
+            n2, m2 = ol.oracle_search_by_sim3(kf1v, kf2v, p12, p21, th)
+            assert n1 == n2 and np.array_equal(m1, m2), th
+            best = max(best, n2)
+        assert best > 20
 
 
 def test_guided_searches_emulated(emu_lib):
