@@ -284,6 +284,40 @@ int orbm_search_by_bow(orbx_extractor* h, const OrbmKeyFrameView* K1, const Orbm
 int orbm_search_for_initialization(orbx_extractor* h, const OrbmFrameView* F1, const OrbmFrameView* F2, float* prev_matched,
                                    int window_size, float nnratio, int check_orientation, int* matches12, int* nmatches);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:438-529) for P map points at once.  Point p owns the
+ * descriptors desc[32*start[p] .. 32*start[p+1]) — its observations' descriptors in the reference's iteration order (:451-470).
+ * best[p] = index, relative to start[p], of the descriptor the reference would keep (smallest median distance to the others, first on
+ * ties); -1 for a point without descriptors. */
+int orbm_distinctive_descriptors(orbx_extractor* h, const uint8_t* desc, const int* start, int P, int* best);
+
+/* ---- Vocabulary: the consumer right behind the extractor, Frame::ComputeBoW (src/Frame.cc:984-997) ->
+ * ORBVocabulary::transform(features, mBowVec, mFeatVec, 4) (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1195).  Produces the
+ * FeatureVector CSR that OrbmKeyFrameView (SearchByBoW / SearchForTriangulation) consumes. ---- */
+typedef struct orbv_vocabulary orbv_vocabulary;
+
+/* Vocabulary from flat arrays in ORBvoc.txt line order (loadFromTextFile, TemplatedVocabulary.h:1338-1430): entry i describes node
+ * i + 1; parent[i] (0 = root) must be an earlier node; is_leaf[i] = the file's leaf flag (word ids are handed out to flagged nodes in
+ * line order); desc[32*i..]; weight[i].  scoring / weighting = DBoW2::ScoringType / WeightingType (BowVector.h:37-56).
+ * The vocabulary lives on h's device. */
+int orbv_create(orbx_extractor* h, int k, int L, int scoring, int weighting, int n_nodes, const int* parent, const uint8_t* is_leaf,
+                const uint8_t* desc, const double* weight, orbv_vocabulary** out);
+/* ORBVocabulary::loadFromTextFile(path) */
+int orbv_load_text(orbx_extractor* h, const char* path, orbv_vocabulary** out);
+void orbv_destroy(orbv_vocabulary* v);
+int orbv_words(const orbv_vocabulary* v);                                       /* ORBVocabulary::size() */
+
+/* transform(features, BowVector&, FeatureVector&, levelsup) for n host descriptors (n x 32).  Any output pointer may be NULL.
+ * word_id/node_id [n]: per-feature word and ancestor at level L - levelsup (transform(feature, id, weight, &nid, levelsup), :1218-1259).
+ * BowVector: bow_id/bow_val (capacity n), ascending word ids, *n_bow entries.  FeatureVector as CSR: fv_node (capacity n, ascending),
+ * fv_start (capacity n + 1), fv_feat (capacity n; feature indices in insertion order), *n_fv nodes. */
+int orbv_transform(orbv_vocabulary* v, orbx_extractor* h, const uint8_t* desc, int n, int levelsup, uint32_t* word_id, uint32_t* node_id,
+                   uint32_t* bow_id, double* bow_val, int* n_bow, uint32_t* fv_node, int* fv_start, uint32_t* fv_feat, int* n_fv);
+/* The same for images [first, first + B) of h's last orbx_extract_batch, on the descriptors that are still on the device (no copy);
+ * asynchronous on h's stream.  orbv_fetch copies the vectors of image b (relative to `first`) out; capacities = orbx_max_keypoints(h). */
+int orbv_transform_extracted(orbv_vocabulary* v, orbx_extractor* h, int first, int B, int levelsup);
+int orbv_fetch(orbv_vocabulary* v, orbx_extractor* h, int b, uint32_t* word_id, uint32_t* node_id, int n_features, uint32_t* bow_id, double* bow_val,
+               int* n_bow, uint32_t* fv_node, int* fv_start, uint32_t* fv_feat, int* n_fv);
+
 const char* orbx_last_error(void);
 
 #ifdef __cplusplus

@@ -17,6 +17,10 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <string>
+#include <sstream>
+#include <iostream>
+#include <fstream>
 #include <vector>
 #include "../../orb_primitives.h"
 
@@ -163,5 +167,29 @@ struct KeyPointsFilter {   // referenced only by the reference's dead ComputeKey
         }
     }
 };
+
+// cv::FileStorage / cv::FileNode: named by DBoW2's TemplatedVocabulary.h (YAML save/load, virtual members that must compile).
+// The oracle loads vocabularies with the reference's own loadFromTextFile, so these are never-opened stubs.
+class FileNode {
+public:
+    FileNode operator[](const char*) const { return FileNode(); }
+    FileNode operator[](const std::string&) const { return FileNode(); }
+    FileNode operator[](int) const { return FileNode(); }
+    size_t size() const { return 0; }
+    operator int() const { return 0; }
+    operator double() const { return 0.0; }
+    operator std::string() const { return std::string(); }
+};
+class FileStorage {
+public:
+    enum { READ = 0, WRITE = 1 };
+    FileStorage(const char*, int) {}
+    FileStorage(const std::string&, int) {}
+    bool isOpened() const { return false; }
+    void release() {}
+    FileNode operator[](const char*) const { return FileNode(); }
+    FileNode operator[](const std::string&) const { return FileNode(); }
+};
+template <typename T> static inline FileStorage& operator<<(FileStorage& fs, const T&) { return fs; }
 
 }  // namespace cv

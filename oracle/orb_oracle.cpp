@@ -1036,6 +1036,32 @@ int orbo_search_by_sim3(const OFrame* KF1, const OFrame* KF2, const OProj* P1in2
     return nFound;
 }
 
+// MapPoint::ComputeDistinctiveDescriptors, src/MapPoint.cc:438-529, on a CSR of descriptors per map point.
+void orbo_distinctive_descriptors(const uint8_t* desc, const int* start, int P, int* best) {
+    for (int p = 0; p < P; p++) {
+        const size_t N = (size_t)(start[p + 1] - start[p]);
+        best[p] = -1;
+        if (N == 0) continue;
+        const uint8_t* D = desc + 32 * (size_t)start[p];
+        std::vector<float> Distances(N * N);
+        for (size_t i = 0; i < N; i++) {
+            Distances[i * N + i] = 0;
+            for (size_t j = i + 1; j < N; j++) {
+                const int distij = descriptor_distance(D + 32 * i, D + 32 * j);
+                Distances[i * N + j] = distij; Distances[j * N + i] = distij;
+            }
+        }
+        int BestMedian = 0x7fffffff, BestIdx = 0;
+        for (size_t i = 0; i < N; i++) {
+            std::vector<int> vDists(Distances.begin() + i * N, Distances.begin() + (i + 1) * N);
+            std::sort(vDists.begin(), vDists.end());
+            const int median = vDists[0.5 * (N - 1)];
+            if (median < BestMedian) { BestMedian = median; BestIdx = (int)i; }
+        }
+        best[p] = BestIdx;
+    }
+}
+
 // glibc cosf/sinf, exposed so tests can pin the device-side model (csrc/glibc_sincosf_model.h).
 float orbo_cosf(float x) { return cosf(x); }
 float orbo_sinf(float x) { return sinf(x); }

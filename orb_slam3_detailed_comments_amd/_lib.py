@@ -30,7 +30,8 @@ SYMBOLS = [
     "orbm_hamming_matrix", "orbm_stereo_match", "orbm_stereo_fetch", "orbm_knn2", "orbm_knn2_fetch",
     "orbm_get_features_in_area", "orbm_search_by_projection_mappoints", "orbm_search_by_projection_frame",
     "orbm_search_for_triangulation", "orbm_search_by_bow", "orbm_search_for_initialization", "orbm_area_search_batch",
-    "orbm_search_by_projection_sim3", "orbm_search_by_projection_keyframe", "orbm_fuse_candidates", "orbm_search_by_sim3",
+    "orbm_search_by_projection_sim3", "orbm_search_by_projection_keyframe", "orbm_fuse_candidates", "orbm_search_by_sim3", "orbm_distinctive_descriptors",
+    "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_words", "orbv_transform", "orbv_transform_extracted", "orbv_fetch",
     "orbx_last_error",
 ]
 
@@ -93,6 +94,14 @@ class OrbxLib:
         L.orbm_search_by_projection_keyframe.argtypes = [vp, vp, vp, f, i, i, vp, ip]
         L.orbm_fuse_candidates.argtypes = [vp, vp, vp, f, i, vp, vp, vp]
         L.orbm_search_by_sim3.argtypes = [vp, vp, vp, vp, vp, f, vp, ip]
+        L.orbm_distinctive_descriptors.argtypes = [vp, vp, vp, i, vp]
+        L.orbv_create.argtypes = [vp, i, i, i, i, i, vp, vp, vp, vp, C.POINTER(vp)]
+        L.orbv_load_text.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
+        L.orbv_destroy.argtypes = [vp]; L.orbv_destroy.restype = None
+        L.orbv_words.argtypes = [vp]
+        L.orbv_transform.argtypes = [vp, vp, vp, i, i, vp, vp, vp, vp, ip, vp, vp, vp, ip]
+        L.orbv_transform_extracted.argtypes = [vp, vp, i, i, i]
+        L.orbv_fetch.argtypes = [vp, vp, i, vp, vp, i, vp, vp, ip, vp, vp, vp, ip]
         L.orbx_last_error.restype = C.c_char_p
 
     def check(self, rc):

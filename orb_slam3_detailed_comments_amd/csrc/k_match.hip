@@ -208,4 +208,51 @@ __global__ void __launch_bounds__(256) k_knn2(const unsigned long long* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:438-529), many map points per launch: for point p with descriptors
+// D_0..D_{N-1} (its observations), row i = all N distances d(D_i, D_j) including d(i,i) = 0; median_i = sorted(row i)[0.5*(N-1)];
+// best = first i with the smallest median (strict `<`, :511).  One wave per point: a row's distances go into a 257-bin LDS histogram
+// (distances are integers in [0, 256]), a wave prefix sum over the bins locates the rank-(N-1)/2 value.  grid (ceil(P/4)), 256 threads.
+__global__ void __launch_bounds__(256) k_distinctive(const unsigned long long* __restrict__ desc, const int* __restrict__ start, int P,
+                                                     int* __restrict__ best) {
+    __shared__ int s_hist[4][320];
+    const int lane = lane_id(), w = wave_id();
+    const int p = (int)blockIdx.x * 4 + w;
+    if (p >= P) return;
+    const int s0 = start[p], N = start[p + 1] - s0;
+    int* hist = s_hist[w];
+#pragma unroll
+    for (int t = 0; t < 5; t++) hist[lane * 5 + t] = 0;
+    ORBX_WAVE_SYNC();
+    if (N <= 0) { if (lane == 0) best[p] = -1; return; }
+    const int rank = (N - 1) >> 1;                       // (size_t)(0.5 * (N - 1))
+    int bestMedian = 0x7fffffff, bestIdx = 0;
+    for (int i = 0; i < N; i++) {
+        const unsigned long long* di = desc + 4 * (size_t)(s0 + i);
+        const unsigned long long a0 = di[0], a1 = di[1], a2 = di[2], a3 = di[3];
+        for (int j = lane; j < N; j += 64) {
+            const unsigned long long* dj = desc + 4 * (size_t)(s0 + j);
+            const int d = __popcll(a0 ^ dj[0]) + __popcll(a1 ^ dj[1]) + __popcll(a2 ^ dj[2]) + __popcll(a3 ^ dj[3]);
+            atomicAdd(&hist[d], 1);
+        }
+        ORBX_WAVE_SYNC();
+        int c[5], mine = 0;
+#pragma unroll
+        for (int t = 0; t < 5; t++) { c[t] = hist[lane * 5 + t]; mine += c[t]; }
+        const int incl = wave_incl_scan(mine);
+        int before = incl - mine, median = -1;
+        if (before <= rank && rank < incl) {
+#pragma unroll
+            for (int t = 0; t < 5; t++) { if (median < 0 && rank < before + c[t]) median = lane * 5 + t; before += c[t]; }
+        }
+        const unsigned long long who = __ballot(median >= 0);
+        median = __shfl(median, __ffsll(who) - 1);
+        if (median < bestMedian) { bestMedian = median; bestIdx = i; }
+#pragma unroll
+        for (int t = 0; t < 5; t++) hist[lane * 5 + t] = 0;
+        ORBX_WAVE_SYNC();
+    }
+    if (lane == 0) best[p] = bestIdx;
+}
+
 }  // namespace orbx

@@ -603,4 +603,21 @@ int orbm_search_by_sim3(orbx_extractor* h, const OrbmFrameView* KF1, const OrbmF
     return ORBX_OK;
 }
 
+int orbm_distinctive_descriptors(orbx_extractor* h, const uint8_t* desc, const int* start, int P, int* best) {
+    if (!h || P < 0 || (P > 0 && (!start || !best))) return fail(ORBX_E_ARG, "null");
+    if (P == 0) return ORBX_OK;
+    rt::set_device(h->device);
+    const int total = start[P];
+    if (total < 0 || (total > 0 && !desc)) return fail(ORBX_E_ARG, "bad descriptor list");
+    for (int p = 0; p < P; p++) if (start[p + 1] < start[p]) return fail(ORBX_E_ARG, "start[] must be non-decreasing");
+    int e = upload(h, SR_DESC, desc, 32 * (size_t)total) | h->d_si[SI_QSTART].ensure(P + 1) | h->d_si[SI_BEST].ensure(P);
+    if (!e) e = rt::copy_h2d(h->d_si[SI_QSTART].p, start, sizeof(int) * (size_t)(P + 1), h->s0);
+    if (e) return fail(ORBX_E_DEVICE, "upload/allocation failed");
+    dim3 grid((P + 3) / 4, 1, 1), blk(256, 1, 1);
+    ORBX_LAUNCH(k_distinctive, grid, blk, 0, h->s0, (const unsigned long long*)h->d_sr[SR_DESC].p, (const int*)h->d_si[SI_QSTART].p, P, h->d_si[SI_BEST].p);
+    rt::copy_d2h(best, h->d_si[SI_BEST].p, sizeof(int) * (size_t)P, h->s0);
+    if (rt::stream_sync(h->s0) || rt::check_launch()) return fail(ORBX_E_DEVICE, "distinctive-descriptor kernel failed: %s", rt::last_error());
+    return ORBX_OK;
+}
+
 }  // extern "C"

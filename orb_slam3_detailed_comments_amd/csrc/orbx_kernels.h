@@ -60,4 +60,15 @@ __global__ void k_bow_dists(const BowItem* __restrict__ items, int nitems, const
                             const unsigned long long* __restrict__ desc2, const uint8_t* __restrict__ eligible2,
                             const int* __restrict__ feat2, int* __restrict__ out);
 
+__global__ void k_distinctive(const unsigned long long* __restrict__ desc, const int* __restrict__ start, int P, int* __restrict__ best);
+__global__ void k_voc_descend(const unsigned long long* __restrict__ fdesc, const int* __restrict__ n_feat, int n_fixed, int cap, int B,
+                              const unsigned long long* __restrict__ slot_desc, const VocSlot* __restrict__ slots,
+                              const double* __restrict__ slot_weight, int root_children, int nid_level, unsigned* __restrict__ out_word,
+                              unsigned* __restrict__ out_node, double* __restrict__ out_weight);
+__global__ void k_voc_assemble(const unsigned* __restrict__ word, const unsigned* __restrict__ node, const double* __restrict__ weight,
+                               const int* __restrict__ n_feat, int n_fixed, int cap, int P, int weighting, int norm,
+                               unsigned* __restrict__ bow_id, double* __restrict__ bow_val, int* __restrict__ bow_start,
+                               unsigned* __restrict__ fv_node, int* __restrict__ fv_start, unsigned* __restrict__ fv_feat,
+                               int* __restrict__ n_out);
+
 }  // namespace orbx

@@ -61,6 +61,7 @@ struct AreaQuery {                                                // one GetFeat
     float x, y, r, ur;
     int min_level, max_level, active, gate;                      // gate: 0 none, 1 right coordinate (ORBmatcher.cc:107-117), 2 Fuse chi-square (:1437-1469)
 };
+struct VocSlot { int node_id, child_start, child_cnt, word_id; };   // one vocabulary node; children occupy consecutive slots
 struct BowItem { int idx1, start2, cnt2, out_off; };
 struct BowParams {
     float F12[9];            // fundamental matrix, row-major (Pinhole::epipolarConstrain)

@@ -155,3 +155,13 @@ def AreaSearchBatch(ext, frame, queries, query_desc):
             break
         cap = tot
     return [list(zip(idx[s:s + c].tolist(), dist[s:s + c].tolist(), lvl[s:s + c].tolist())) for s, c in zip(start.tolist(), count.tolist())]
+
+
+def ComputeDistinctiveDescriptors(ext, desc, start):
+    """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:438) for many map points: desc [total, 32] uint8, start [P+1] offsets.
+    Returns best[P]: which of each point's descriptors becomes mDescriptor (-1: point without descriptors)."""
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); st = np.ascontiguousarray(start, np.int32)
+    P = len(st) - 1
+    best = np.full(max(P, 1), -1, np.int32)
+    ext._lib.check(ext._lib.L.orbm_distinctive_descriptors(ext._h, d.ctypes.data if len(d) else None, st.ctypes.data, P, best.ctypes.data))
+    return best[:P]

@@ -292,3 +292,64 @@ def oracle_search_by_sim3(kf1, kf2, p12, p21, th):
     m = np.full(max(kf1.view.N, 1), -1, np.int32)
     n = L.orbo_search_by_sim3(kf1.ref(), kf2.ref(), p12.ref(), p21.ref(), th, m.ctypes.data)
     return n, m[:kf1.view.N]
+
+
+# ---- the reference's own DBoW2 (oracle/_ref/libref_dbow2.so) ----
+_DBOW2 = None
+
+
+def reference_dbow2():
+    global _DBOW2
+    if _DBOW2 is None:
+        p = os.path.join(ORACLE_DIR, "_ref", "libref_dbow2.so")
+        if not os.path.exists(p):
+            build()
+        if not os.path.exists(p):
+            return None
+        L = C.CDLL(p)
+        L.ref_voc_load_text.restype = C.c_void_p; L.ref_voc_load_text.argtypes = [C.c_char_p]
+        L.ref_voc_destroy.argtypes = [C.c_void_p]
+        L.ref_voc_size.argtypes = [C.c_void_p]
+        L.ref_voc_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 2 + [C.POINTER(C.c_int)] + [C.c_void_p] * 3 + [C.POINTER(C.c_int)]
+        L.ref_voc_transform_one.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_double), C.POINTER(C.c_uint)]
+        _DBOW2 = L
+    return _DBOW2
+
+
+class RefVocabulary:
+    """ORBVocabulary of the reference, loaded with its own loadFromTextFile."""
+
+    def __init__(self, path):
+        self.L = reference_dbow2()
+        self.h = self.L.ref_voc_load_text(str(path).encode())
+        assert self.h, "reference loadFromTextFile failed"
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ref_voc_destroy(self.h)
+
+    def size(self):
+        return self.L.ref_voc_size(self.h)
+
+    def transform(self, desc, levelsup=4):
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); n = len(d); cap = max(n, 1)
+        bi = np.zeros(cap, np.uint32); bv = np.zeros(cap, np.float64); fn = np.zeros(cap, np.uint32); fs = np.zeros(cap + 1, np.int32)
+        ff = np.zeros(cap, np.uint32); nb, nf = C.c_int(), C.c_int()
+        self.L.ref_voc_transform(self.h, d.ctypes.data, n, levelsup, bi.ctypes.data, bv.ctypes.data, C.byref(nb), fn.ctypes.data, fs.ctypes.data,
+                                 ff.ctypes.data, C.byref(nf))
+        return bi[:nb.value], bv[:nb.value], fn[:nf.value], fs[:nf.value + 1], ff[:int(fs[nf.value])]
+
+    def transform_one(self, desc, levelsup=4):
+        d = np.ascontiguousarray(desc, np.uint8); w = C.c_uint(); wt = C.c_double(); nd = C.c_uint()
+        self.L.ref_voc_transform_one(self.h, d.ctypes.data, levelsup, C.byref(w), C.byref(wt), C.byref(nd))
+        return w.value, wt.value, nd.value
+
+
+def oracle_distinctive_descriptors(desc, start):
+    L = oracle()
+    L.orbo_distinctive_descriptors.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.orbo_distinctive_descriptors.restype = None
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); st = np.ascontiguousarray(start, np.int32)
+    best = np.full(max(len(st) - 1, 1), -1, np.int32)
+    L.orbo_distinctive_descriptors(d.ctypes.data, st.ctypes.data, len(st) - 1, best.ctypes.data)
+    return best[:len(st) - 1]

@@ -21,7 +21,7 @@ def _ensure_built():
 def test_header_symbols_exported():
     _ensure_built()
     hdr = open(os.path.join(ROOT, "include", "orbx.h")).read()
-    declared = set(re.findall(r"\b(orb[xm]_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(orb[xmv]_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     L = C.CDLL(_lib.HIP_LIB_PATH)
     for s in sorted(declared):

@@ -1,0 +1,74 @@
+"""Vocabulary transform (Frame::ComputeBoW -> ORBVocabulary::transform): kernel sources on the CPU SIMT emulator vs the reference's
+OWN DBoW2 (oracle/_ref/libref_dbow2.so, compiled unmodified from Thirdparty/DBoW2).  Same assertions on the GPU in test_gpu_vocab.py."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import vocab_scenes as vs
+from orb_slam3_detailed_comments_amd.extractor import ORBextractor
+from orb_slam3_detailed_comments_amd.vocabulary import ORBVocabulary
+
+CONFIGS = [  # (k, L, scoring, weighting, ragged, min_leaf_level, levelsups)
+    (10, 3, 0, 0, False, 1, (4, 2, 1, 0)),     # ORB-SLAM3's types (L1_NORM, TF_IDF); levelsup 4 > L -> node id 0
+    (6, 4, 1, 1, False, 1, (2, 3)),            # L2 norm, TF
+    (5, 4, 5, 0, False, 1, (1,)),              # DOT_PRODUCT: no normalisation, values divided by the vector size
+    (4, 5, 2, 2, False, 1, (2,)),              # CHI_SQUARE (L1), IDF: addIfNotExist
+    (3, 6, 0, 3, True, 4, (2,)),               # ragged tree, leaves at levels >= 4 = L - levelsup; BINARY
+    (20, 2, 0, 0, False, 1, (1,)),             # more children than lanes in a group
+]
+
+
+def check_vocabulary(ex, tmp_path, cfg, seed, n_desc):
+    if ol.reference_dbow2() is None:
+        pytest.skip("oracle/_ref/libref_dbow2.so not built")
+    k, L, scoring, weighting, ragged, mll, levelsups = cfg
+    rng = np.random.default_rng(seed)
+    header, parent, leaf, desc, weight = vs.make_vocabulary(rng, k, L, scoring, weighting, ragged=ragged, min_leaf_level=mll)
+    path = tmp_path / ("voc_%d_%d_%d.txt" % (k, L, seed))
+    vs.write_text(path, header, parent, leaf, desc, weight)
+    ref = ol.RefVocabulary(path)
+    for loader in ("text", "arrays"):
+        voc = ORBVocabulary.loadFromTextFile(ex, path) if loader == "text" else ORBVocabulary.from_arrays(ex, *header, parent, leaf, desc, weight)
+        assert voc.size() == ref.size() == int(leaf.sum())
+        for levelsup in levelsups:
+            for n in (n_desc, 1, 0, 37):
+                q = vs.descriptors_near(rng, desc, n)
+                r = voc.transform(q, levelsup)
+                bi, bv, fn, fs, ff = ref.transform(q, levelsup)
+                assert np.array_equal(r.bow_id, bi) and r.bow_val.tobytes() == bv.tobytes(), (cfg, levelsup, n)
+                assert np.array_equal(r.fv_node, fn) and np.array_equal(r.fv_start, fs) and np.array_equal(r.fv_feat, ff), (cfg, levelsup, n)
+                for i in range(0, n, max(1, n // 25)):          # per-feature words / nodes against the single-feature descent
+                    w, wt, nd = ref.transform_one(q[i], levelsup)
+                    assert (int(r.word_id[i]), int(r.node_id[i])) == (w, nd), (cfg, levelsup, i)
+        voc.close()
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+def test_vocabulary_transform_emulated(emu_lib, tmp_path, cfg):
+    ex = ORBextractor(500, 1.2, 8, 20, 7, lib=emu_lib)
+    check_vocabulary(ex, tmp_path, cfg, seed=11, n_desc=700)
+
+
+def test_vocabulary_on_extracted_batch_emulated(emu_lib, tmp_path):
+    """orbv_transform_extracted: the descriptors of an extracted batch, still on the device, give the same vectors as the host path."""
+    if ol.reference_dbow2() is None:
+        pytest.skip("oracle/_ref/libref_dbow2.so not built")
+    from orb_slam3_detailed_comments_amd import synth
+    ex = ORBextractor(300, 1.2, 8, 20, 7, lib=emu_lib)
+    rng = np.random.default_rng(3)
+    header, parent, leaf, desc, weight = vs.make_vocabulary(rng, 8, 3)
+    path = tmp_path / "voc.txt"
+    vs.write_text(path, header, parent, leaf, desc, weight)
+    ref = ol.RefVocabulary(path)
+    voc = ORBVocabulary.loadFromTextFile(ex, path)
+    imgs = np.stack([synth.corner_field(320, 240, seed=s, nrect=700) for s in (1, 2, 3)])
+    ex.enqueue(imgs)
+    voc.transform_extracted(ex, 0, 3, 2)
+    res = ex.fetch()
+    for b in range(3):
+        d = res[b][2]; n = len(d)
+        r = voc.fetch(ex, b, n)
+        bi, bv, fn, fs, ff = ref.transform(d, 2)
+        assert np.array_equal(r.bow_id, bi) and r.bow_val.tobytes() == bv.tobytes()
+        assert np.array_equal(r.fv_node, fn) and np.array_equal(r.fv_start, fs) and np.array_equal(r.fv_feat, ff)
+        assert len(bi) > 20

@@ -13,3 +13,9 @@ def test_guided_searches_gpu_full_size(hip_lib):
 
 def test_guided_searches_gpu_euroc_size(hip_lib):
     run_all(None, 752, 480, 1200, 3000, seeds=(5,))
+
+
+def test_distinctive_descriptors_gpu(hip_lib):
+    from test_emu_mappoint import run
+    run(None, 5000, 60, 2)          # config-4 scale: ~5000 local map points
+    run(None, 200, 400, 3)

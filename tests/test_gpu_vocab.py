@@ -1,0 +1,42 @@
+"""Vocabulary transform on the real GPU vs the reference's own DBoW2, including an ORBvoc-shaped tree (k=10, L=4 here: 11 110 nodes;
+the shipped ORBvoc.txt has L=6 but is not part of the repository) and a batch of extracted images."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import vocab_scenes as vs
+from test_emu_vocab import CONFIGS, check_vocabulary
+from orb_slam3_detailed_comments_amd import synth
+from orb_slam3_detailed_comments_amd.extractor import ORBextractor
+from orb_slam3_detailed_comments_amd.vocabulary import ORBVocabulary
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("cfg", CONFIGS + [(10, 4, 0, 0, False, 1, (4, 2))])
+def test_vocabulary_transform_gpu(hip_lib, tmp_path, cfg):
+    ex = ORBextractor(1200, 1.2, 8, 20, 7)
+    check_vocabulary(ex, tmp_path, cfg, seed=21, n_desc=5000)
+
+
+def test_vocabulary_on_extracted_batch_gpu(hip_lib, tmp_path):
+    if ol.reference_dbow2() is None:
+        pytest.skip("oracle/_ref/libref_dbow2.so not built")
+    ex = ORBextractor(1200, 1.2, 8, 20, 7)
+    rng = np.random.default_rng(5)
+    header, parent, leaf, desc, weight = vs.make_vocabulary(rng, 10, 4)
+    path = tmp_path / "voc.txt"
+    vs.write_text(path, header, parent, leaf, desc, weight)
+    ref = ol.RefVocabulary(path)
+    voc = ORBVocabulary.loadFromTextFile(ex, path)
+    imgs = np.stack([synth.corner_field(752, 480, seed=40 + s) for s in range(8)])
+    ex.enqueue(imgs)
+    voc.transform_extracted(ex, 0, 8, 2)          # levelsup 2 of L=4 ~ ORB-SLAM3's levelsup 4 of L=6
+    res = ex.fetch()
+    for b in range(8):
+        d = res[b][2]; n = len(d)
+        r = voc.fetch(ex, b, n)
+        bi, bv, fn, fs, ff = ref.transform(d, 2)
+        assert np.array_equal(r.bow_id, bi) and r.bow_val.tobytes() == bv.tobytes()
+        assert np.array_equal(r.fv_node, fn) and np.array_equal(r.fv_start, fs) and np.array_equal(r.fv_feat, ff)
+        assert n > 1000 and len(bi) > 300
