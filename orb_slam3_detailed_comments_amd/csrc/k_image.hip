@@ -260,15 +260,19 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
     uint8_t* sc = smem + tile_bytes;
     uint16_t* list = (uint16_t*)(sc + inner_bytes);
     const uint8_t* img = pyr + (size_t)b * pyr_stride + L.off;
+    const unsigned Mw = (1u << 20) / (unsigned)wpd + 1u;    // i / wpd == (i * Mw) >> 20 exactly for i < 2^13
     for (int i = tid; i < wh * wpd; i += kFastThreads) {
-        const int r = i / wpd, c = i - r * wpd;
+        const int r = (int)(((unsigned)i * Mw) >> 20), c = i - r * wpd;
         ((uint32_t*)tile)[i] = *(const uint32_t*)(img + (size_t)(ci.y0 - 3 + r) * L.pitch + gx0 + 4 * c);
     }
     for (int i = tid; i < (inner_bytes >> 2); i += kFastThreads) ((uint32_t*)sc)[i] = 0u;   // scores default to 0 (not a corner)
     if (tid == 0) s_flags[0] = 0;
     __syncthreads();
     const int t0 = imin(iniTh, minTh);
-    const unsigned M = (1u << 20) / (unsigned)iw + 1u;      // p / iw == (p * M) >> 20 exactly for p < 2^13, iw <= 128
+    // scores live in a tile with a one-pixel zero frame (pitch iw + 2), so the 3x3 NMS reads its 8 neighbours at fixed offsets
+    // without bounds tests; list entries are indices into that tile
+    const int pitch = iw + 2;
+    const unsigned M = (1u << 20) / (unsigned)pitch + 1u;   // p / pitch == (p * M) >> 20 exactly for p < 2^13, pitch <= 128
     const unsigned long long lt = (1ull << lane) - 1ull;
     // ---- A ----  work item = (row y, dword group g): 4 adjacent pixels per lane, packed 16-bit arithmetic.
     // The 16 ring bytes of the 4 pixels are cut out of 21 aligned LDS dwords with v_alignbyte, widened with v_perm,
@@ -326,7 +330,7 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
             const int incl = wave_incl_scan(c4);
             int pos = cnt + incl - c4;
 #pragma unroll
-            for (int j = 0; j < 4; j++) if (mask & (1u << j)) mylist[pos++] = (uint16_t)(y * iw + xbase + j);
+            for (int j = 0; j < 4; j++) if (mask & (1u << j)) mylist[pos++] = (uint16_t)((y + 1) * pitch + xbase + j + 1);
             cnt += __shfl(incl, 63);
             gi += dr; y += dq;
             if (gi >= ng) { gi -= ng; y++; }
@@ -341,10 +345,10 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
         const int pA = list[list_index(i, s_cnt, q)];
         const bool hasB = i + 1 < total;
         const int pB = hasB ? list[list_index(i + 1, s_cnt, q)] : pA;
-        const int yA = (int)(((unsigned)pA * M) >> 20), xA = pA - yA * iw;
-        const int yB = (int)(((unsigned)pB * M) >> 20), xB = pB - yB * iw;
-        const uint8_t* cA = tile + (yA + 3) * wp + xo + xA + 3;
-        const uint8_t* cB = tile + (yB + 3) * wp + xo + xB + 3;
+        const int yA = (int)(((unsigned)pA * M) >> 20), xA = pA - yA * pitch;     // (y + 1, x + 1)
+        const int yB = (int)(((unsigned)pB * M) >> 20), xB = pB - yB * pitch;
+        const uint8_t* cA = tile + (yA + 2) * wp + xo + xA + 2;
+        const uint8_t* cB = tile + (yB + 2) * wp + xo + xB + 2;
         const pk2 v2 = pk_make((uint32_t)cA[0] | ((uint32_t)cB[0] << 16));
         pk2 d[16];
 #define ORBX_D(k, off) d[k] = pk_sub(v2, pk_make((uint32_t)cA[off] | ((uint32_t)cB[off] << 16)));
@@ -364,21 +368,12 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
     for (int i = tid; i < total; i += kFastThreads) {
         const int li = list_index(i, s_cnt, q);
         const int p = list[li];
-        const int y = (int)(((unsigned)p * M) >> 20), x = p - y * iw;
-        const int s = sc[p];
-        int keep = 0;
-        if (s > 0) {
-            keep = 1;
-#pragma unroll
-            for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-                for (int dx = -1; dx <= 1; dx++) {
-                    if (dx == 0 && dy == 0) continue;
-                    const int xx = x + dx, yy = y + dy;
-                    const int qv = (xx >= 0 && xx < iw && yy >= 0 && yy < ih) ? (int)sc[yy * iw + xx] : 0;
-                    keep &= (s > qv);
-                }
-        }
+        const uint8_t* c = sc + p;
+        const int s = c[0];
+        // neighbours outside the cell interior are the zero frame; s == 0 (not a corner) fails every strict comparison
+        const int m0 = imax(imax((int)c[-pitch - 1], (int)c[-pitch]), imax((int)c[-pitch + 1], (int)c[-1]));
+        const int m1 = imax(imax((int)c[1], (int)c[pitch - 1]), imax((int)c[pitch], (int)c[pitch + 1]));
+        const int keep = s > imax(m0, m1);
         if (keep) list[li] = (uint16_t)(p | 0x8000);
         any_hi |= (keep && s >= iniTh);
     }
@@ -404,8 +399,8 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
         int wbase = 0, tot = 0;
         for (int w = 0; w < kFastWaves; w++) { const int c = s_wave[w]; if (w < wave) wbase += c; tot += c; }
         if (flag) {
-            const int y = (int)(((unsigned)p * M) >> 20), x = p - y * iw;
-            out[base + wbase + __popcll(bal & lt)] = key_pack(ci.x0 + x - kBorder, ci.y0 + y - kBorder, s);
+            const int y1 = (int)(((unsigned)p * M) >> 20), x1 = p - y1 * pitch;       // (y + 1, x + 1)
+            out[base + wbase + __popcll(bal & lt)] = key_pack(ci.x0 + x1 - 1 - kBorder, ci.y0 + y1 - 1 - kBorder, s);
         }
         base += tot;
         __syncthreads();

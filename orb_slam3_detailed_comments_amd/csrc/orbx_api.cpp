@@ -129,7 +129,7 @@ int configure(orbx_extractor* h, int W, int H, int B) {
                         if (iw > 128 || iw * ih >= 8192) return fail(ORBX_E_ARG, "FAST cell too large");   // k_fast_cells index packing
                         const int gx0 = ((c.x0 - 3) & ~3) - 4, gx1 = ((c.x1 + 3 + 3) & ~3) + 4;    // dword-aligned window + margins (k_fast_cells)
                         tile_b = std::max(tile_b, (gx1 - gx0) * (ih + 6));
-                        inner_b = std::max(inner_b, (iw + 8) * ih);      // score tile; the u16 survivor list holds 4 px per (row, dword) item
+                        inner_b = std::max(inner_b, std::max((iw + 8) * ih, (iw + 2) * (ih + 2)));   // score tile incl. its zero frame; the u16 survivor list holds 4 px per (row, dword) item
                     }
                     h->cells.push_back(c);
                 }
