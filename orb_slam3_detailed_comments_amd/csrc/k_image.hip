@@ -254,6 +254,8 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
     }
     const int wh = ih + 6;
     const int gx0 = ((ci.x0 - 3) & ~3) - 4, gx1 = ((ci.x1 + 3 + 3) & ~3) + 4;   // dword-aligned window + one dword margin each side
+    // (a compile-time tile pitch - 64/128 or 68/132 bytes - makes the LDS offsets immediates but measured 3-10 % slower: more LDS per
+    //  workgroup and, for 64, row-on-row bank conflicts; the runtime pitch stays)
     const int wpd = (gx1 - gx0) >> 2, wp = wpd * 4;
     const int xo = (ci.x0 - 3) - gx0;
     uint8_t* tile = smem;

@@ -19,6 +19,7 @@ SMALL_CASES = [
     ("small_sparse", lambda: synth.sparse_corners(376, 240, seed=13, ncorner=12), 500, (0, 0)),
     ("small_flat_empty", lambda: __import__("numpy").full((240, 376), 77, "uint8"), 500, (0, 0)),
     ("small_square_512", lambda: synth.corner_field(300, 300, seed=14, nrect=700), 300, (0, 299)),
+    ("small_280x260_wide_cells", lambda: synth.corner_field(280, 260, seed=16, nrect=500), 300, (0, 0)),   # upper levels: one 60-px cell (128-byte FAST tile pitch)
     ("small_wide_nini3", lambda: synth.corner_field(640, 250, seed=15, nrect=900), 600, (0, 0)),
 ]
 
