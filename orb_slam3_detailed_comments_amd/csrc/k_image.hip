@@ -220,30 +220,19 @@ __device__ __forceinline__ void fast_full_pk(const pk2 d[16], int t0, int& sA, i
 constexpr int kFastWaves = 1;                       // waves per FAST workgroup (one cell per workgroup)
 constexpr int kFastThreads = 64 * kFastWaves;
 
-// position of the i-th survivor in the concatenation of the per-wave lists (wave w's list starts at w*q)
-__device__ __forceinline__ int list_index(int i, const int* s_cnt, int q) {
-    int w = 0;
-#pragma unroll
-    for (int k = 0; k < kFastWaves - 1; k++) { const int c = s_cnt[w]; if (i >= c) { i -= c; w++; } }
-    return w * q + i;
-}
-
 __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __restrict__ lv,
                                                     const CellInfo* __restrict__ cells, int ncells,
                                                     const uint8_t* __restrict__ pyr, size_t pyr_stride,
                                                     int iniTh, int minTh,
                                                     uint32_t* __restrict__ slots, size_t slots_stride,
-                                                    int* __restrict__ cell_count, int tile_bytes, int inner_bytes) {
+                                                    int* __restrict__ cell_count, int tile_bytes, int inner_bytes, int list_bytes) {
     ORBX_DYN_SMEM(smem);
-    __shared__ int s_flags[2];
-    __shared__ int s_cnt[kFastWaves];
-    __shared__ int s_wave[kFastWaves];
     // Plain mapping (workgroup b -> cell b, i.e. neighbouring cells on different XCDs).  Two XCD-aware remaps were measured
     // (contiguous eighths of the cell table per XCD; runs of 16 cells dealt round-robin): they cut the kernel's HBM fetch from
     // 291 MB to 70 MB per 128-image launch but made it 14-27 % slower (the kernel is VALU-bound and the remaps skew the mix of
     // dense and sparse cells per XCD), so the balanced mapping stays.
     const int cell = (int)blockIdx.x, b = (int)blockIdx.y;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = (int)threadIdx.x, lane = tid & 63;
     if (cell >= ncells) return;
     const CellInfo ci = cells[cell];
     const LevelInfo L = lv[ci.level];
@@ -261,6 +250,11 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
     uint8_t* tile = smem;
     uint8_t* sc = smem + tile_bytes;
     uint16_t* list = (uint16_t*)(sc + inner_bytes);
+#ifdef ORBX_FAST_LIST_CAP                                    // tests rebuild with a tiny capacity to force the flush path
+    const int list_cap = ORBX_FAST_LIST_CAP;
+#else
+    const int list_cap = list_bytes >> 1;                    // entries
+#endif
     const uint8_t* img = pyr + (size_t)b * pyr_stride + L.off;
     const unsigned Mw = (1u << 20) / (unsigned)wpd + 1u;    // i / wpd == (i * Mw) >> 20 exactly for i < 2^13
     for (int i = tid; i < wh * wpd; i += kFastThreads) {
@@ -268,7 +262,6 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
         ((uint32_t*)tile)[i] = *(const uint32_t*)(img + (size_t)(ci.y0 - 3 + r) * L.pitch + gx0 + 4 * c);
     }
     for (int i = tid; i < (inner_bytes >> 2); i += kFastThreads) ((uint32_t*)sc)[i] = 0u;   // scores default to 0 (not a corner)
-    if (tid == 0) s_flags[0] = 0;
     __syncthreads();
     const int t0 = imin(iniTh, minTh);
     // scores live in a tile with a one-pixel zero frame (pitch iw + 2), so the 3x3 NMS reads its 8 neighbours at fixed offsets
@@ -279,20 +272,47 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
     // ---- A ----  work item = (row y, dword group g): 4 adjacent pixels per lane, packed 16-bit arithmetic.
     // The 16 ring bytes of the 4 pixels are cut out of 21 aligned LDS dwords with v_alignbyte, widened with v_perm,
     // and the exact opposite-pair rejection runs on two pixels per instruction (v_pk_sub/min/max_i16).
+    // The survivor list holds list_cap entries (half of the cell's pixels; LDS per workgroup sets the occupancy of this kernel):
+    // when the next trip would overflow it, the listed pixels are scored at once (phase B) and the list restarts.  Cells that
+    // needed such a flush (dense noise) finish with the list-free variants of phases C and D.
+    static_assert(kFastWaves == 1, "the flush logic below assumes one wave per cell");
     const int g0 = (xo + 3) >> 2, ng = ((xo + 3 + iw - 1) >> 2) - g0 + 1;
     const int nitems = ih * ng;
-    const int qi = (nitems + kFastWaves - 1) / kFastWaves;   // items per wave (contiguous ranges keep the list row-major)
-    const int q = qi * 4;                                  // list capacity per wave (pixels)
+    const uint32_t* tile32 = (const uint32_t*)tile;
+    // ---- B ----  full score of list[0, n), two listed pixels per lane (packed lanes)
+    auto score_listed = [&](int n) {
+        for (int i = 2 * lane; i < n; i += 2 * kFastThreads) {
+            const int pA = list[i];
+            const bool hasB = i + 1 < n;
+            const int pB = hasB ? list[i + 1] : pA;
+            const int yA = (int)(((unsigned)pA * M) >> 20), xA = pA - yA * pitch;     // (y + 1, x + 1)
+            const int yB = (int)(((unsigned)pB * M) >> 20), xB = pB - yB * pitch;
+            const uint8_t* cA = tile + (yA + 2) * wp + xo + xA + 2;
+            const uint8_t* cB = tile + (yB + 2) * wp + xo + xB + 2;
+            const pk2 v2 = pk_make((uint32_t)cA[0] | ((uint32_t)cB[0] << 16));
+            pk2 d[16];
+#define ORBX_D(k, off) d[k] = pk_sub(v2, pk_make((uint32_t)cA[off] | ((uint32_t)cB[off] << 16)));
+            ORBX_D(0, 3 * wp)       ORBX_D(1, 3 * wp + 1)    ORBX_D(2, 2 * wp + 2)    ORBX_D(3, wp + 3)
+            ORBX_D(4, 3)            ORBX_D(5, -wp + 3)       ORBX_D(6, -2 * wp + 2)   ORBX_D(7, -3 * wp + 1)
+            ORBX_D(8, -3 * wp)      ORBX_D(9, -3 * wp - 1)   ORBX_D(10, -2 * wp - 2)  ORBX_D(11, -wp - 3)
+            ORBX_D(12, -3)          ORBX_D(13, wp - 3)       ORBX_D(14, 2 * wp - 2)   ORBX_D(15, 3 * wp - 1)
+#undef ORBX_D
+            int sA, sB;
+            fast_full_pk(d, t0, sA, sB);
+            sc[pA] = (uint8_t)sA;
+            if (hasB) sc[pB] = (uint8_t)sB;
+        }
+        ORBX_WAVE_SYNC();
+    };
+    int cnt = 0;
+    bool flushed = false;
     {
-        const int ibeg = wave * qi, iend = imin(nitems, ibeg + qi);
-        uint16_t* mylist = list + wave * q;
-        const uint32_t* tile32 = (const uint32_t*)tile;
-        int cnt = 0;
         // (row, group) of this lane's item, advanced incrementally by 64 items per trip (no per-trip division)
-        int y = (ibeg + lane) / ng, gi = (ibeg + lane) - y * ng;
+        int y = lane / ng, gi = lane - y * ng;
         const int dq = 64 / ng, dr = 64 - dq * ng;
-        for (int it0 = ibeg; it0 < iend; it0 += 64) {
+        for (int it0 = 0; it0 < nitems; it0 += 64) {
             const int it = it0 + lane;
+            const int iend = nitems;
             unsigned mask = 0; int xbase = 0;
             if (it < iend) {
                 const int g = g0 + gi;
@@ -330,84 +350,88 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
             }
             const int c4 = __popc(mask);
             const int incl = wave_incl_scan(c4);
+            const int trip = __shfl(incl, 63);
+            if (cnt + trip > list_cap) { score_listed(cnt); cnt = 0; flushed = true; }     // wave-uniform
             int pos = cnt + incl - c4;
 #pragma unroll
-            for (int j = 0; j < 4; j++) if (mask & (1u << j)) mylist[pos++] = (uint16_t)((y + 1) * pitch + xbase + j + 1);
-            cnt += __shfl(incl, 63);
+            for (int j = 0; j < 4; j++) if (mask & (1u << j)) list[pos++] = (uint16_t)((y + 1) * pitch + xbase + j + 1);
+            cnt += trip;
             gi += dr; y += dq;
             if (gi >= ng) { gi -= ng; y++; }
         }
-        if (lane == 0) s_cnt[wave] = cnt;
     }
-    __syncthreads();
-    int total = 0;
-    for (int w = 0; w < kFastWaves; w++) total += s_cnt[w];
-    // ---- B ----  full score, two listed pixels per lane (packed lanes)
-    for (int i = 2 * tid; i < total; i += 2 * kFastThreads) {
-        const int pA = list[list_index(i, s_cnt, q)];
-        const bool hasB = i + 1 < total;
-        const int pB = hasB ? list[list_index(i + 1, s_cnt, q)] : pA;
-        const int yA = (int)(((unsigned)pA * M) >> 20), xA = pA - yA * pitch;     // (y + 1, x + 1)
-        const int yB = (int)(((unsigned)pB * M) >> 20), xB = pB - yB * pitch;
-        const uint8_t* cA = tile + (yA + 2) * wp + xo + xA + 2;
-        const uint8_t* cB = tile + (yB + 2) * wp + xo + xB + 2;
-        const pk2 v2 = pk_make((uint32_t)cA[0] | ((uint32_t)cB[0] << 16));
-        pk2 d[16];
-#define ORBX_D(k, off) d[k] = pk_sub(v2, pk_make((uint32_t)cA[off] | ((uint32_t)cB[off] << 16)));
-        ORBX_D(0, 3 * wp)       ORBX_D(1, 3 * wp + 1)    ORBX_D(2, 2 * wp + 2)    ORBX_D(3, wp + 3)
-        ORBX_D(4, 3)            ORBX_D(5, -wp + 3)       ORBX_D(6, -2 * wp + 2)   ORBX_D(7, -3 * wp + 1)
-        ORBX_D(8, -3 * wp)      ORBX_D(9, -3 * wp - 1)   ORBX_D(10, -2 * wp - 2)  ORBX_D(11, -wp - 3)
-        ORBX_D(12, -3)          ORBX_D(13, wp - 3)       ORBX_D(14, 2 * wp - 2)   ORBX_D(15, 3 * wp - 1)
-#undef ORBX_D
-        int sA, sB;
-        fast_full_pk(d, t0, sA, sB);
-        sc[pA] = (uint8_t)sA;
-        if (hasB) sc[pB] = (uint8_t)sB;
-    }
-    __syncthreads();
-    // ---- C ----
-    int any_hi = 0;
-    for (int i = tid; i < total; i += kFastThreads) {
-        const int li = list_index(i, s_cnt, q);
-        const int p = list[li];
-        const uint8_t* c = sc + p;
-        const int s = c[0];
-        // neighbours outside the cell interior are the zero frame; s == 0 (not a corner) fails every strict comparison
-        const int m0 = imax(imax((int)c[-pitch - 1], (int)c[-pitch]), imax((int)c[-pitch + 1], (int)c[-1]));
-        const int m1 = imax(imax((int)c[1], (int)c[pitch - 1]), imax((int)c[pitch], (int)c[pitch + 1]));
-        const int keep = s > imax(m0, m1);
-        if (keep) list[li] = (uint16_t)(p | 0x8000);
-        any_hi |= (keep && s >= iniTh);
-    }
-    if (any_hi) atomicOr(&s_flags[0], 1);
-    __syncthreads();
-    // ---- D ----
-    const int thr = s_flags[0] ? iniTh : minTh;
+    ORBX_WAVE_SYNC();
+    score_listed(cnt);
+    const int total = cnt;
     uint32_t* out = slots + (size_t)b * slots_stride + ci.slot_off;
     int base = 0;
-    for (int i0 = 0; i0 < total; i0 += kFastThreads) {
-        const int i = i0 + tid;
-        int flag = 0, p = 0, s = 0;
-        if (i < total) {
-            const int li = list_index(i, s_cnt, q);
-            const int e = list[li];
-            p = e & 0x7FFF;
-            s = sc[p];
-            flag = (e >> 15) && s >= thr;
+    if (!flushed) {
+        // ---- C ----  cell-local strict 3x3 NMS on the listed pixels
+        int any_hi = 0;
+        for (int i = lane; i < total; i += kFastThreads) {
+            const int p = list[i];
+            const uint8_t* c = sc + p;
+            const int s = c[0];
+            // neighbours outside the cell interior are the zero frame; s == 0 (not a corner) fails every strict comparison
+            const int m0 = imax(imax((int)c[-pitch - 1], (int)c[-pitch]), imax((int)c[-pitch + 1], (int)c[-1]));
+            const int m1 = imax(imax((int)c[1], (int)c[pitch - 1]), imax((int)c[pitch], (int)c[pitch + 1]));
+            const int keep = s > imax(m0, m1);
+            if (keep) list[i] = (uint16_t)(p | 0x8000);
+            any_hi |= (keep && s >= iniTh);
         }
-        const unsigned long long bal = __ballot(flag);
-        if (lane == 0) s_wave[wave] = __popcll(bal);
-        __syncthreads();
-        int wbase = 0, tot = 0;
-        for (int w = 0; w < kFastWaves; w++) { const int c = s_wave[w]; if (w < wave) wbase += c; tot += c; }
-        if (flag) {
-            const int y1 = (int)(((unsigned)p * M) >> 20), x1 = p - y1 * pitch;       // (y + 1, x + 1)
-            out[base + wbase + __popcll(bal & lt)] = key_pack(ci.x0 + x1 - 1 - kBorder, ci.y0 + y1 - 1 - kBorder, s);
+        ORBX_WAVE_SYNC();
+        // ---- D ----
+        const int thr = __ballot(any_hi) != 0ull ? iniTh : minTh;
+        for (int i0 = 0; i0 < total; i0 += kFastThreads) {
+            const int i = i0 + lane;
+            int flag = 0, p = 0, s = 0;
+            if (i < total) {
+                const int e = list[i];
+                p = e & 0x7FFF;
+                s = sc[p];
+                flag = (e >> 15) && s >= thr;
+            }
+            const unsigned long long bal = __ballot(flag);
+            if (flag) {
+                const int y1 = (int)(((unsigned)p * M) >> 20), x1 = p - y1 * pitch;       // (y + 1, x + 1)
+                out[base + __popcll(bal & lt)] = key_pack(ci.x0 + x1 - 1 - kBorder, ci.y0 + y1 - 1 - kBorder, s);
+            }
+            base += __popcll(bal);
         }
-        base += tot;
-        __syncthreads();
+    } else {
+        // ---- C', D' ----  the same over every interior pixel; the list region now holds one keep flag per score-tile byte
+        uint8_t* kf = (uint8_t*)list;
+        const unsigned Mi = (1u << 20) / (unsigned)iw + 1u;     // i / iw == (i * Mi) >> 20 exactly for i < 2^13
+        const int npix = iw * ih;
+        int any_hi = 0;
+        for (int i = lane; i < npix; i += kFastThreads) {
+            const int y = (int)(((unsigned)i * Mi) >> 20), x = i - y * iw;
+            const int p = (y + 1) * pitch + x + 1;
+            const uint8_t* c = sc + p;
+            const int s = c[0];
+            const int m0 = imax(imax((int)c[-pitch - 1], (int)c[-pitch]), imax((int)c[-pitch + 1], (int)c[-1]));
+            const int m1 = imax(imax((int)c[1], (int)c[pitch - 1]), imax((int)c[pitch], (int)c[pitch + 1]));
+            const int keep = s > imax(m0, m1);
+            kf[p] = (uint8_t)keep;
+            any_hi |= (keep && s >= iniTh);
+        }
+        ORBX_WAVE_SYNC();
+        const int thr = __ballot(any_hi) != 0ull ? iniTh : minTh;
+        for (int i0 = 0; i0 < npix; i0 += kFastThreads) {
+            const int i = i0 + lane;
+            int flag = 0, x = 0, y = 0, s = 0;
+            if (i < npix) {
+                y = (int)(((unsigned)i * Mi) >> 20); x = i - y * iw;
+                const int p = (y + 1) * pitch + x + 1;
+                s = sc[p];
+                flag = kf[p] && s >= thr;
+            }
+            const unsigned long long bal = __ballot(flag);
+            if (flag) out[base + __popcll(bal & lt)] = key_pack(ci.x0 + x - kBorder, ci.y0 + y - kBorder, s);
+            base += __popcll(bal);
+        }
     }
-    if (tid == 0) cell_count[(size_t)b * ncells + cell] = base;
+    if (lane == 0) cell_count[(size_t)b * ncells + cell] = base;
 }
 
 // ---------------------------------------------------------------------------------------------------

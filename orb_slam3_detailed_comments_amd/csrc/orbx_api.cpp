@@ -228,10 +228,13 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int strid
     stage_begin(h, ST_FAST, h->s0);
     {
         dim3 grid(h->ncells, B, 1), blkf(kFastThreadsDecl, 1, 1);
-        const size_t smem = (size_t)h->fast_tile_bytes + 3 * (size_t)h->fast_inner_bytes + 64;   // tile | score | u16 list
+        // tile | score | u16 survivor list for half of the cell's pixels (k_fast_cells flushes it when a denser cell would overflow);
+        // the LDS footprint of a cell sets this kernel's occupancy, which is what bounds it
+        const int list_bytes = std::max(h->fast_inner_bytes, 1024);   // also holds one flag per score-tile byte on the flush path
+        const size_t smem = (size_t)h->fast_tile_bytes + (size_t)h->fast_inner_bytes + (size_t)list_bytes + 64;
         ORBX_LAUNCH(k_fast_cells, grid, blkf, smem, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
                     (const uint8_t*)h->d_pyr.p, h->pyr_stride, h->iniTh, h->minTh, h->d_slots.p, h->cand_stride, h->d_cell_count.p,
-                    h->fast_tile_bytes, h->fast_inner_bytes);
+                    h->fast_tile_bytes, h->fast_inner_bytes, list_bytes);
     }
     stage_end(h, ST_FAST, h->s0);
     stage_begin(h, ST_QUADTREE, h->s0);

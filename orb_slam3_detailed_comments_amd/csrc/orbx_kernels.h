@@ -13,7 +13,7 @@ constexpr int kFastThreadsDecl = 64;   // must equal kFastThreads in k_image.hip
 __global__ void k_fast_cells(const LevelInfo* __restrict__ lv, const CellInfo* __restrict__ cells, int ncells,
                              const uint8_t* __restrict__ pyr, size_t pyr_stride, int iniTh, int minTh,
                              uint32_t* __restrict__ slots, size_t slots_stride, int* __restrict__ cell_count,
-                             int tile_bytes, int inner_bytes);
+                             int tile_bytes, int inner_bytes, int list_bytes);
 __global__ void k_blur(const LevelInfo* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,
                        uint8_t* __restrict__ blur, size_t pyr_stride, BlurTaps taps, BlurTiles tiles);
 __global__ void k_quadtree(const LevelInfo* __restrict__ lv, const CellInfo* __restrict__ cells, int ncells,
