@@ -310,7 +310,12 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
         // (row, group) of this lane's item, advanced incrementally by 64 items per trip (no per-trip division)
         int y = lane / ng, gi = lane - y * ng;
         const int dq = 64 / ng, dr = 64 - dq * ng;
-        for (int it0 = 0; it0 < nitems; it0 += 64) {
+        // outer loop: one turn per list fill.  The trip that would overflow the list is abandoned (nothing appended, the (row, group)
+        // cursor not advanced), the listed pixels are scored, and the same trip is redone with an empty list - one call site of
+        // phase B outside the phase-A loop keeps the register budgets of the two phases apart.
+        int it0 = 0;
+        for (;;) {
+        for (; it0 < nitems; it0 += 64) {
             const int it = it0 + lane;
             const int iend = nitems;
             unsigned mask = 0; int xbase = 0;
@@ -350,8 +355,8 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
             }
             const int c4 = __popc(mask);
             const int incl = wave_incl_scan(c4);
-            const int trip = __shfl(incl, 63);
-            if (cnt + trip > list_cap) { score_listed(cnt); cnt = 0; flushed = true; }     // wave-uniform
+            const int trip = ORBX_READLANE(incl, 63);
+            if (cnt + trip > list_cap) break;                                               // wave-uniform
             int pos = cnt + incl - c4;
 #pragma unroll
             for (int j = 0; j < 4; j++) if (mask & (1u << j)) list[pos++] = (uint16_t)((y + 1) * pitch + xbase + j + 1);
@@ -359,9 +364,12 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
             gi += dr; y += dq;
             if (gi >= ng) { gi -= ng; y++; }
         }
+        ORBX_WAVE_SYNC();
+        score_listed(cnt);
+        if (it0 >= nitems) break;
+        cnt = 0; flushed = true;
+        }
     }
-    ORBX_WAVE_SYNC();
-    score_listed(cnt);
     const int total = cnt;
     uint32_t* out = slots + (size_t)b * slots_stride + ci.slot_off;
     int base = 0;

@@ -13,6 +13,7 @@
 // lanes of a wave run in lockstep on the GPU; the emulator's fibers do not, so code that relies on "every lane has read
 // before any lane writes" marks the point explicitly
 #define ORBX_WAVE_SYNC() hipemu::wave_barrier()
+#define ORBX_READLANE(v, l) __shfl((v), (l))
 #else
 #include <hip/hip_runtime.h>
 #define ORBX_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
@@ -20,6 +21,8 @@
     hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__)
 #define ORBX_HD __host__ __device__
 #define ORBX_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+// value of lane l as a wave-uniform scalar (SGPR): keeps counters derived from it out of the vector registers
+#define ORBX_READLANE(v, l) __builtin_amdgcn_readlane((v), (l))
 #endif
 
 namespace orbx {
