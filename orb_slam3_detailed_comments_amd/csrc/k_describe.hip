@@ -1,11 +1,13 @@
 // k_describe.hip — per-keypoint kernels of the ORB extractor:
 //   k_layout        final output index of every keypoint: level scaling + lapping-area front/back
 //                   reorder of ORBextractor::operator() (src/ORBextractor.cc:1613-1681) as prefix sums
-//   k_orient_brief  one wave64 per keypoint: IC_Angle (:91-138, :580-591) on the raw level, then the
+//   k_orient_brief  a wave64 works through 8 keypoints: IC_Angle (:91-138, :580-591) on the raw level, then the
 //                   256-bit steered BRIEF (:150-203) on the blurred level; 64 lanes x 4 rounds of
-//                   __ballot assemble the four 64-bit descriptor words directly.
+//                   __ballot assemble the four 64-bit descriptor words directly; the atan2 / cos / sin of
+//                   the 8 keypoints are evaluated together, one keypoint per lane.
 #include "orbx_types.h"
 #include "orbx_block.h"
+#include "orbx_kernels.h"
 #include "glibc_sincosf_model.h"
 
 namespace orbx {
@@ -71,7 +73,15 @@ __global__ void __launch_bounds__(256) k_layout(const LevelInfo* __restrict__ lv
     if (tid == 0) { n_out[b] = total; mono_out[b] = mono_run; }
 }
 
-// grid (ceil(kp_total_cap/4), B), 256 threads = 4 keypoints.
+// grid (ceil(kp_total_cap / (4 * kKpPerWave)), B), 256 threads; a wave owns kKpPerWave consecutive keypoint slots.
+//   1  lane k prepares keypoint k (key, level, addresses, output index); the wave then walks the keypoints one at a time:
+//      IC_Angle moments with all 64 lanes (lanes 0..30 rows v = 0,-1..-15, lanes 32..62 rows v = 1..15), the sums go to lane k
+//   2  the per-keypoint transcendental work - fastAtan2 and the fp64 cosf/sinf model - runs once for the whole wave, one keypoint
+//      per lane, instead of 64-fold redundantly per keypoint
+//   3  steered BRIEF, again one keypoint at a time with all lanes (4 tests per lane, 4 ballots = 4 descriptor words)
+//   4  lane k writes the record of keypoint k
+constexpr int kKpPerWave = 8;
+static_assert(kKpPerWave == kKpPerWaveDecl, "orbx_kernels.h out of date");
 __global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restrict__ lv, int nlevels,
                                                       const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t pyr_stride,
                                                       const uint32_t* __restrict__ lvl_keys, int kp_total_cap,
@@ -80,74 +90,106 @@ __global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restric
                                                       unsigned long long* __restrict__ out_desc, int4* __restrict__ out_aux) {
     const int b = (int)blockIdx.y;
     const int lane = lane_id();
-    const int slot = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-    if (slot >= kp_total_cap) return;
-    int level = 0;
-    for (int l = 1; l < nlevels; l++) if (slot >= lv[l].kp_off) level = l;
-    const LevelInfo L = lv[level];
-    const int i = slot - L.kp_off;
-    if (i >= lvl_count[(size_t)b * nlevels + level]) return;
-    const uint32_t key = lvl_keys[(size_t)b * kp_total_cap + slot];
-    const int x = key_x(key) + kBorder, y = key_y(key) + kBorder;
-    // ---- IC_Angle: lanes 0..30 take rows v = 0,-1..-15, lanes 32..62 rows v = 1..15 ----
-    const uint8_t* raw = pyr + (size_t)b * pyr_stride + L.off + (size_t)y * L.pitch + x;
-    const int half = lane >> 5, col = lane & 31, u = col - kHalfPatch;
-    int m10 = 0, m01 = 0;
-    {
-        // all 16 row loads of this lane are issued back to back (masked lanes read the centre pixel and weigh it 0),
-        // so the gather costs one memory round trip instead of sixteen dependent ones
-        int I[16], wu[16], wv[16];
-#pragma unroll
-        for (int it = 0; it < 16; it++) {
-            const int v = half ? it + 1 : -it;
-            const int av = v < 0 ? -v : v;
-            const int au = u < 0 ? -u : u;
-            const bool on = col < 31 && av <= kHalfPatch && au <= umax.u[av <= kHalfPatch ? av : 0];
-            I[it] = raw[on ? ((ptrdiff_t)v * L.pitch + u) : 0];
-            wu[it] = on ? u : 0; wv[it] = on ? v : 0;
+    const int slot0 = ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * kKpPerWave;
+    if (slot0 >= kp_total_cap) return;
+    // ---- 1a: per-lane keypoint state (lanes >= kKpPerWave mirror lane 0 and are never read) ----
+    const int myslot = slot0 + (lane < kKpPerWave ? lane : 0);
+    int my_valid = 0, my_level = 0, my_pitch = 0, my_fi = 0;
+    uint32_t my_key = 0;
+    long long my_off = 0;                                   // byte offset of the keypoint centre inside the pyramid / blur block
+    if (myslot < kp_total_cap) {
+        for (int l = 1; l < nlevels; l++) if (myslot >= lv[l].kp_off) my_level = l;
+        const int i = myslot - lv[my_level].kp_off;
+        my_valid = i < lvl_count[(size_t)b * nlevels + my_level];
+        if (my_valid) {
+            my_key = lvl_keys[(size_t)b * kp_total_cap + myslot];
+            my_pitch = lv[my_level].pitch;
+            my_off = (long long)lv[my_level].off + (long long)(key_y(my_key) + kBorder) * my_pitch + (key_x(my_key) + kBorder);
+            my_fi = final_idx[(size_t)b * kp_total_cap + myslot];
         }
+    }
+    const unsigned long long vmask = __ballot(my_valid && lane < kKpPerWave);
+    if (vmask == 0ull) return;
+    const uint8_t* raw0 = pyr + (size_t)b * pyr_stride;
+    const uint8_t* blur0 = blur + (size_t)b * pyr_stride;
+    // ---- 1b: IC_Angle ----
+    const int half = lane >> 5, col = lane & 31, u = col - kHalfPatch;
+    // per-lane weights of the 16 (row, column) positions this lane covers; the same for every keypoint
+    int wu[16], wv[16];
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+        const int v = half ? it + 1 : -it;
+        const int av = v < 0 ? -v : v;
+        const int au = u < 0 ? -u : u;
+        const bool on = col < 31 && av <= kHalfPatch && au <= umax.u[av <= kHalfPatch ? av : 0];
+        wu[it] = on ? u : 0; wv[it] = on ? v : 0;          // masked lanes read the centre pixel and weigh it 0
+    }
+    int my_m10 = 0, my_m01 = 0;
+    for (int k = 0; k < kKpPerWave; k++) {
+        if (!((vmask >> k) & 1ull)) continue;               // wave-uniform
+        const int pitch = __shfl(my_pitch, k);
+        const uint8_t* raw = raw0 + __shfl(my_off, k);
+        // all 16 row loads of this lane are issued back to back, so the gather costs one memory round trip instead of sixteen
+        int I[16];
+#pragma unroll
+        for (int it = 0; it < 16; it++) I[it] = raw[(ptrdiff_t)wv[it] * pitch + wu[it]];
+        int m10 = 0, m01 = 0;
 #pragma unroll
         for (int it = 0; it < 16; it++) { m10 += wu[it] * I[it]; m01 += wv[it] * I[it]; }
+        m10 = wave_sum(m10); m01 = wave_sum(m01);
+        if (lane == k) { my_m10 = m10; my_m01 = m01; }
     }
-    m10 = wave_sum(m10); m01 = wave_sum(m01);
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
-    // ---- steered BRIEF on the blurred level ----
+    // ---- 2: angle, cos, sin: one keypoint per lane ----
+    const float my_angle = fast_atan2_deg((float)my_m01, (float)my_m10);
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-    const float rad = __fmul_rn(angle, factorPI);
-    const float a = glibc_cosf(rad), bb = glibc_sinf(rad);
-    const uint8_t* ctr = blur + (size_t)b * pyr_stride + L.off + (size_t)y * L.pitch + x;
-    const int fi = final_idx[(size_t)b * kp_total_cap + slot];
-    unsigned long long mine = 0;
-    int t0v[4], t1v[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {       // 8 independent gathers in flight
-        const signed char* p = &BRIEF_PATTERN[4 * (64 * r + lane)];
-        const float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, bb), __fmul_rn(y0, a)));
-        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, bb)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, bb), __fmul_rn(y1, a)));
-        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, bb)));
-        t0v[r] = ctr[(ptrdiff_t)r0 * L.pitch + c0];
-        t1v[r] = ctr[(ptrdiff_t)r1 * L.pitch + c1];
-    }
+    const float my_rad = __fmul_rn(my_angle, factorPI);
+    const float my_a = glibc_cosf(my_rad), my_b = glibc_sinf(my_rad);
+    // ---- 3: steered BRIEF on the blurred level ----
+    // this lane's 4 tests (8 pattern points), the same for every keypoint
+    float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const unsigned long long w = __ballot(t0v[r] < t1v[r]);
-        if (lane == r) mine = w;
+        const signed char* p = &BRIEF_PATTERN[4 * (64 * r + lane)];
+        px0[r] = (float)p[0]; py0[r] = (float)p[1]; px1[r] = (float)p[2]; py1[r] = (float)p[3];
     }
-    if (lane < 4) out_desc[((size_t)b * kp_total_cap + fi) * 4 + lane] = mine;
-    if (lane == 0) {
+    for (int k = 0; k < kKpPerWave; k++) {
+        if (!((vmask >> k) & 1ull)) continue;
+        const int pitch = __shfl(my_pitch, k);
+        const uint8_t* ctr = blur0 + __shfl(my_off, k);
+        const float a = __shfl(my_a, k), bb = __shfl(my_b, k);
+        const int fi = __shfl(my_fi, k);
+        int t0v[4], t1v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {       // 8 independent gathers in flight
+            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0[r], bb), __fmul_rn(py0[r], a)));
+            const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[r], a), __fmul_rn(py0[r], bb)));
+            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[r], bb), __fmul_rn(py1[r], a)));
+            const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[r], a), __fmul_rn(py1[r], bb)));
+            t0v[r] = ctr[(ptrdiff_t)r0 * pitch + c0];
+            t1v[r] = ctr[(ptrdiff_t)r1 * pitch + c1];
+        }
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const unsigned long long w = __ballot(t0v[r] < t1v[r]);
+            if (lane == r) mine = w;
+        }
+        if (lane < 4) out_desc[((size_t)b * kp_total_cap + fi) * 4 + lane] = mine;
+    }
+    // ---- 4: records ----
+    if (lane < kKpPerWave && my_valid) {
+        const LevelInfo L = lv[my_level];
         KeyPointRec k;
-        float xf = (float)x, yf = (float)y;
-        if (level != 0) { xf = __fmul_rn(xf, L.scale); yf = __fmul_rn(yf, L.scale); }
-        k.x = xf; k.y = yf; k.size = (float)L.patch; k.angle = angle; k.response = (float)key_s(key);
-        k.octave = level; k.class_id = -1;
-        out_kps[(size_t)b * kp_total_cap + fi] = k;
+        float xf = (float)(key_x(my_key) + kBorder), yf = (float)(key_y(my_key) + kBorder);
+        if (my_level != 0) { xf = __fmul_rn(xf, L.scale); yf = __fmul_rn(yf, L.scale); }
+        k.x = xf; k.y = yf; k.size = (float)L.patch; k.angle = my_angle; k.response = (float)key_s(my_key);
+        k.octave = my_level; k.class_id = -1;
+        out_kps[(size_t)b * kp_total_cap + my_fi] = k;
         // compact 16-byte record for the stereo row search (Frame::ComputeStereoMatches, src/Frame.cc:1141-1155): the band of
         // image rows [floor(y - r), ceil(y + r)], r = 2 * scale, in which this keypoint is a candidate; x; octave
         const float r = __fmul_rn(2.0f, L.scale);
-        int4 aux; aux.x = (int)floorf(__fsub_rn(yf, r)); aux.y = (int)ceilf(__fadd_rn(yf, r)); aux.z = __float_as_int(xf); aux.w = level;
-        out_aux[(size_t)b * kp_total_cap + fi] = aux;
+        int4 aux; aux.x = (int)floorf(__fsub_rn(yf, r)); aux.y = (int)ceilf(__fadd_rn(yf, r)); aux.z = __float_as_int(xf); aux.w = my_level;
+        out_aux[(size_t)b * kp_total_cap + my_fi] = aux;
     }
 }
 

@@ -24,6 +24,7 @@ __global__ void k_quadtree(const LevelInfo* __restrict__ lv, const CellInfo* __r
 __global__ void k_layout(const LevelInfo* __restrict__ lv, int nlevels, const uint32_t* __restrict__ lvl_keys,
                          int kp_total_cap, const int* __restrict__ lvl_count, int lap0, int lap1,
                          int* __restrict__ final_idx, int* __restrict__ n_out, int* __restrict__ mono_out);
+constexpr int kKpPerWaveDecl = 8;      // must equal kKpPerWave in k_describe.hip
 __global__ void k_orient_brief(const LevelInfo* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,
                                const uint8_t* __restrict__ blur, size_t pyr_stride,
                                const uint32_t* __restrict__ lvl_keys, int kp_total_cap,
