@@ -121,6 +121,23 @@ __device__ __forceinline__ uint32_t align_byte(uint32_t hi, uint32_t lo, uint32_
     return __builtin_amdgcn_alignbyte(hi, lo, shift);
 #endif
 }
+// integer dot products: v_dot4_u32_u8 (four u8 x u8 products + c) and v_dot2_u32_u16 (two u16 x u16 products + c), exact (no clamp)
+__device__ __forceinline__ uint32_t dot4_u8(uint32_t a, uint32_t b, uint32_t c) {
+#ifdef ORBX_EMU
+    for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xFFu) * ((b >> (8 * i)) & 0xFFu);
+    return c;
+#else
+    return __builtin_amdgcn_udot4(a, b, c, false);
+#endif
+}
+__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c) {
+#ifdef ORBX_EMU
+    return c + (a & 0xFFFFu) * (b & 0xFFFFu) + (a >> 16) * (b >> 16);
+#else
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
+#endif
+}
 __device__ __forceinline__ int mul24(int a, int b) {
 #ifdef ORBX_EMU
     return a * b;
@@ -488,42 +505,52 @@ __global__ void __launch_bounds__(256) k_blur(const LevelInfo* __restrict__ lv, 
         for (int j = 0; j < 4; j++) sgl |= (uint32_t)imin(imax(idx[j] - 4 * base[g], 0), 7) << (8 * j);
         sel[g] = sgl;
     }
-    int h[7][4];
+    // Horizontal pass: H_j = sum_i k_i p[j+i] as two v_dot4_u32_u8 on the byte windows p[j..j+3], p[j+4..j+7] (tap 7 = 0); H <= 65535.
+    // Vertical pass: the H of two consecutive input rows share a register (lo/hi 16 bits), so a 7-row window is four
+    // v_dot2_u32_u16 with the taps paired to match the window's parity; the rounding constant is the accumulator's start value.
+    const uint32_t Klo = (uint32_t)k0 | ((uint32_t)k1 << 8) | ((uint32_t)k2 << 16) | ((uint32_t)k3 << 24);
+    const uint32_t Khi = (uint32_t)k2 | ((uint32_t)k1 << 8) | ((uint32_t)k0 << 16);
+    const uint32_t Ke0 = (uint32_t)k0 | ((uint32_t)k1 << 16), Ke1 = (uint32_t)k2 | ((uint32_t)k3 << 16), Ke2 = (uint32_t)k2 | ((uint32_t)k1 << 16), Ke3 = (uint32_t)k0;
+    const uint32_t Ko0 = (uint32_t)k0 << 16, Ko1 = (uint32_t)k1 | ((uint32_t)k2 << 16), Ko2 = (uint32_t)k3 | ((uint32_t)k2 << 16), Ko3 = (uint32_t)k1 | ((uint32_t)k0 << 16);
+    uint32_t Q[4][4];
 #pragma unroll
-    for (int i = 0; i < 7; i++) { h[i][0] = h[i][1] = h[i][2] = h[i][3] = 0; }
+    for (int i = 0; i < 4; i++) { Q[i][0] = Q[i][1] = Q[i][2] = Q[i][3] = 0u; }
 #pragma unroll
-    for (int i = 0; i < kBlurRows + 6; i++) {
-        const int yo = ys + i - 6;                      // output row completed by this input row
-        if (yo >= L.h) break;
-        int y = ys - 3 + i;
-        if (y < 0) y = -y;
-        if (y >= L.h) y = 2 * L.h - 2 - y;
-        const uint8_t* row = src + (size_t)y * L.pitch + x0;
-        const uint32_t c = *(const uint32_t*)row;
-        const uint32_t l = x0 > 0 ? *(const uint32_t*)(row - 4) : 0u;
-        const uint32_t r = x0 + 4 < L.pitch ? *(const uint32_t*)(row + 4) : 0u;
-        const uint32_t P0 = byte_perm(base[0] ? r : c, base[0] ? c : l, sel[0]);
-        const uint32_t P1 = byte_perm(base[1] ? r : c, base[1] ? c : l, sel[1]);
-        const uint32_t P2 = byte_perm(base[2] ? r : c, base[2] ? c : l, sel[2]);
-        int p[10];
-        p[0] = (int)(P0 & 0xFF); p[1] = (int)((P0 >> 8) & 0xFF); p[2] = (int)((P0 >> 16) & 0xFF); p[3] = (int)(P0 >> 24);
-        p[4] = (int)(P1 & 0xFF); p[5] = (int)((P1 >> 8) & 0xFF); p[6] = (int)((P1 >> 16) & 0xFF); p[7] = (int)(P1 >> 24);
-        p[8] = (int)(P2 & 0xFF); p[9] = (int)((P2 >> 8) & 0xFF);
+    for (int m = 0; m < (kBlurRows + 6) / 2; m++) {
+        const int yo = ys + 2 * (m - 3);                // first of the two output rows completed by this pair of input rows
+        if (m >= 3 && yo >= L.h) break;
+        uint32_t Hr[2][4];
 #pragma unroll
-        for (int t7 = 0; t7 < 6; t7++) { h[t7][0] = h[t7 + 1][0]; h[t7][1] = h[t7 + 1][1]; h[t7][2] = h[t7 + 1][2]; h[t7][3] = h[t7 + 1][3]; }
+        for (int sub = 0; sub < 2; sub++) {
+            int y = ys - 3 + 2 * m + sub;
+            if (y < 0) y = -y;
+            if (y >= L.h) y = 2 * L.h - 2 - y;
+            y = imax(y, 0);
+            const uint8_t* row = src + (size_t)y * L.pitch + x0;
+            const uint32_t c = *(const uint32_t*)row;
+            const uint32_t l = x0 > 0 ? *(const uint32_t*)(row - 4) : 0u;
+            const uint32_t r = x0 + 4 < L.pitch ? *(const uint32_t*)(row + 4) : 0u;
+            const uint32_t P0 = byte_perm(base[0] ? r : c, base[0] ? c : l, sel[0]);      // input columns x0-3 .. x0
+            const uint32_t P1 = byte_perm(base[1] ? r : c, base[1] ? c : l, sel[1]);      //               x0+1 .. x0+4
+            const uint32_t P2 = byte_perm(base[2] ? r : c, base[2] ? c : l, sel[2]);      //               x0+5, x0+6, (unused)
+            Hr[sub][0] = dot4_u8(P0, Klo, dot4_u8(P1, Khi, 0u));
+            Hr[sub][1] = dot4_u8(align_byte(P1, P0, 1), Klo, dot4_u8(align_byte(P2, P1, 1), Khi, 0u));
+            Hr[sub][2] = dot4_u8(align_byte(P1, P0, 2), Klo, dot4_u8(align_byte(P2, P1, 2), Khi, 0u));
+            Hr[sub][3] = dot4_u8(align_byte(P1, P0, 3), Klo, dot4_u8(align_byte(P2, P1, 3), Khi, 0u));
+        }
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            h[6][j] = mul24(k0, p[j] + p[j + 6]) + mul24(k1, p[j + 1] + p[j + 5]) + mul24(k2, p[j + 2] + p[j + 4]) + mul24(k3, p[j + 3]);
-        if (i >= 6) {
-            uint32_t out = 0;
+        for (int j = 0; j < 4; j++) { Q[0][j] = Q[1][j]; Q[1][j] = Q[2][j]; Q[2][j] = Q[3][j]; Q[3][j] = Hr[0][j] | (Hr[1][j] << 16); }
+        if (m >= 3) {
+            uint32_t oe = 0, oo = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const unsigned v = (unsigned)(mul24(k0, h[0][j] + h[6][j]) + mul24(k1, h[1][j] + h[5][j]) + mul24(k2, h[2][j] + h[4][j]) + mul24(k3, h[3][j]));
-                unsigned o = (v + 32768u) >> 16;
-                o = o > 255u ? 255u : o;
-                out |= o << (8 * j);
+                uint32_t ve = dot2_u16(Q[0][j], Ke0, dot2_u16(Q[1][j], Ke1, dot2_u16(Q[2][j], Ke2, dot2_u16(Q[3][j], Ke3, 32768u)))) >> 16;
+                uint32_t vo = dot2_u16(Q[0][j], Ko0, dot2_u16(Q[1][j], Ko1, dot2_u16(Q[2][j], Ko2, dot2_u16(Q[3][j], Ko3, 32768u)))) >> 16;
+                ve = ve > 255u ? 255u : ve; vo = vo > 255u ? 255u : vo;
+                oe |= ve << (8 * j); oo |= vo << (8 * j);
             }
-            *(uint32_t*)(dst + (size_t)yo * L.pitch + x0) = out;
+            *(uint32_t*)(dst + (size_t)yo * L.pitch + x0) = oe;
+            if (yo + 1 < L.h) *(uint32_t*)(dst + (size_t)(yo + 1) * L.pitch + x0) = oo;
         }
     }
 }
