@@ -24,12 +24,48 @@ __global__ void __launch_bounds__(256) k_hamming_matrix(const unsigned long long
     out[(size_t)i * nb + j] = hamming256(A + 4 * (size_t)i, Bm + 4 * (size_t)j);
 }
 
+// Row index for the stereo search (the role of vRowIndices, src/Frame.cc:1129-1155): the right keypoints of an image bucketed by the
+// first row of their candidate band (32 rows per bucket, CSR).  A left keypoint at row v then only visits the buckets that can hold
+// bands covering v instead of every right keypoint.  Order inside a bucket is arbitrary: the search reduces (distance, index) keys.
+// grid (B), 256 threads, dynamic LDS = 2 * (nb + 1) ints.
+constexpr int kRowBucketShift = 5;
+__global__ void __launch_bounds__(256) k_stereo_rows(const int4* __restrict__ auxR, const int* __restrict__ nR, int cap, int nb,
+                                                     int* __restrict__ bucket_start, int* __restrict__ bucket_items) {
+    ORBX_DYN_SMEM(smem);
+    __shared__ unsigned long long s_scan[20];
+    int* hist = (int*)smem; int* cursor = hist + (nb + 1);
+    const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const int n = nR[b];
+    const int4* ar = auxR + (size_t)b * cap;
+    for (int i = tid; i <= nb; i += 256) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) atomicAdd(&hist[imin(imax(ar[i].x, 0) >> kRowBucketShift, nb - 1)], 1);
+    __syncthreads();
+    int run = 0;
+    for (int c0 = 0; c0 < nb; c0 += 256) {
+        const int c = c0 + tid;
+        const int v = c < nb ? hist[c] : 0;
+        unsigned long long tot;
+        const int ex = run + (int)block_excl_scan<unsigned long long>((unsigned long long)v, &tot, s_scan);
+        if (c < nb) { cursor[c] = ex; bucket_start[(size_t)b * (nb + 1) + c] = ex; }
+        run += (int)tot;
+    }
+    if (tid == 0) bucket_start[(size_t)b * (nb + 1) + nb] = run;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int pos = atomicAdd(&cursor[imin(imax(ar[i].x, 0) >> kRowBucketShift, nb - 1)], 1);
+        bucket_items[(size_t)b * cap + pos] = i;
+    }
+}
+
+
 // grid (ceil(cap/4), B); one wave per left keypoint.
 // kpsL/descL/nL: left extractor outputs (stride cap); same for right; pyrL/pyrR: raw pyramids.
 __global__ void __launch_bounds__(256) k_stereo_match(const LevelInfo* __restrict__ lv,
                                                       const KeyPointRec* __restrict__ kpsL, const unsigned long long* __restrict__ descL, const int* __restrict__ nL,
                                                       const KeyPointRec* __restrict__ kpsR, const unsigned long long* __restrict__ descR,
                                                       const int4* __restrict__ auxR, const int* __restrict__ nR,
+                                                      const int* __restrict__ bucket_start, const int* __restrict__ bucket_items, int nb, int lookback,
                                                       int cap, const uint8_t* __restrict__ pyrL, const uint8_t* __restrict__ pyrR, size_t pyr_stride,
                                                       StereoParams P, float* __restrict__ uRight, float* __restrict__ depth, int* __restrict__ sad) {
     const int b = (int)blockIdx.y, lane = lane_id();
@@ -50,16 +86,26 @@ __global__ void __launch_bounds__(256) k_stereo_match(const LevelInfo* __restric
         const unsigned long long* dl = descL + 4 * o;
         const unsigned long long d0 = dl[0], d1 = dl[1], d2 = dl[2], d3 = dl[3];
         const int4* ar = auxR + (size_t)b * cap;          // {first row, last row, x bits, octave}: one coalesced 16-B load per candidate
-        for (int base = 0; base < nr; base += 256) {      // 4 right keypoints per lane per trip, their loads in flight together
-            int4 a[4];
+        // candidates: right keypoints whose band starts in rows [rowL - lookback, rowL] (lookback >= the tallest band), i.e. a
+        // contiguous run of row buckets; the exact band / octave / column tests follow
+        const int* bs = bucket_start + (size_t)b * (nb + 1);
+        const int* items = bucket_items + (size_t)b * cap;
+        const int jbeg = bs[imin(imax(rowL - lookback, 0) >> kRowBucketShift, nb - 1)], jend = bs[imin(imax(rowL, 0) >> kRowBucketShift, nb - 1) + 1];
+        (void)nr;
+        for (int base = jbeg; base < jend; base += 128) { // 2 right keypoints per lane per trip, their loads in flight together
+            int4 a[2]; int idx[2];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int iR = base + 64 * u + lane;
-                if (iR < nr) a[u] = ar[iR]; else { a[u].x = 1; a[u].y = 0; a[u].z = 0; a[u].w = 0; }   // empty band
+            for (int u = 0; u < 2; u++) {
+                const int j = base + 64 * u + lane;
+                idx[u] = j < jend ? items[j] : -1;
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int iR = base + 64 * u + lane;
+            for (int u = 0; u < 2; u++) {
+                if (idx[u] >= 0) a[u] = ar[idx[u]]; else { a[u].x = 1; a[u].y = 0; a[u].z = 0; a[u].w = 0; }   // empty band
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int iR = idx[u];
                 if (rowL < a[u].x || rowL > a[u].y) continue;
                 if (a[u].w < levelL - 1 || a[u].w > levelL + 1) continue;
                 const float xr = __int_as_float(a[u].z);

@@ -317,7 +317,7 @@ void orbx_destroy(orbx_extractor* h) {
     h->d_hamA.release(); h->d_hamB.release(); h->d_hamOut.release(); h->h_stage.release(); h->h_nm.release();
     for (auto& x : h->d_sr) x.release();
     for (auto& x : h->d_si) x.release();
-    h->d_aux.release(); h->d_qtprof.release();
+    h->d_aux.release(); h->d_qtprof.release(); h->d_rowstart.release(); h->d_rowitems.release();
     delete h;
 }
 
@@ -556,11 +556,20 @@ int orbm_stereo_match(orbx_extractor* L, int lf, orbx_extractor* R, int rf, int 
     StereoParams P; P.mbf = bf; P.mb = bl; P.th_high = 100; P.th_orb = (100 + 50) / 2;   // ORBmatcher::TH_HIGH/TH_LOW, src/ORBmatcher.cc:35-36
     if (L->profile) rt::event_record(L->ev_stage[ST_MATCH][0], L->s0);
     dim3 grid((cap + 3) / 4, B, 1), blk(256, 1, 1);
+    // row index of the right keypoints (32-row buckets of the first row of each candidate band)
+    const int nb = (R->H >> 5) + 2;
+    const int lookback = (int)std::ceil(4.0f * R->scale[R->nlevels - 1]) + 2;     // tallest band: 2 * (2 * scale) + rounding
+    if (L->d_rowstart.ensure((size_t)B * (nb + 1)) || L->d_rowitems.ensure((size_t)B * cap)) return fail(ORBX_E_DEVICE, "allocation failed");
+    {
+        dim3 gridr(B, 1, 1);
+        ORBX_LAUNCH(k_stereo_rows, gridr, blk, 2 * (size_t)(nb + 1) * sizeof(int), L->s0, (const int4*)(R->d_aux.p + (size_t)rf * cap * 4),
+                    (const int*)(R->d_nm.p + rf), cap, nb, L->d_rowstart.p, L->d_rowitems.p);
+    }
     ORBX_LAUNCH(k_stereo_match, grid, blk, 0, L->s0, (const LevelInfo*)L->d_lv.p,
                 (const KeyPointRec*)(L->d_kps.p + (size_t)lf * cap), (const unsigned long long*)(L->d_desc.p + (size_t)lf * cap * 4), (const int*)(L->d_nm.p + lf),
                 (const KeyPointRec*)(R->d_kps.p + (size_t)rf * cap), (const unsigned long long*)(R->d_desc.p + (size_t)rf * cap * 4),
                 (const int4*)(R->d_aux.p + (size_t)rf * cap * 4), (const int*)(R->d_nm.p + rf),
-                cap, (const uint8_t*)(L->d_pyr.p + (size_t)lf * L->pyr_stride), (const uint8_t*)(R->d_pyr.p + (size_t)rf * R->pyr_stride), L->pyr_stride,
+                (const int*)L->d_rowstart.p, (const int*)L->d_rowitems.p, nb, lookback, cap, (const uint8_t*)(L->d_pyr.p + (size_t)lf * L->pyr_stride), (const uint8_t*)(R->d_pyr.p + (size_t)rf * R->pyr_stride), L->pyr_stride,
                 P, L->d_uRight.p, L->d_depth.p, L->d_sad.p);
     dim3 grid2(B, 1, 1);
     ORBX_LAUNCH(k_stereo_median, grid2, blk, (size_t)cap * sizeof(int) + 16, L->s0, (const int*)(L->d_nm.p + lf), cap, L->d_uRight.p, L->d_depth.p,

@@ -85,5 +85,6 @@ struct orbx_extractor {
 #endif
     int g_B = 0, g_stride = 0, g_lap0 = 0, g_lap1 = 0, g_W = 0, g_H = 0, g_gauss = 0; size_t g_image_stride = 0;
     const void* g_images = nullptr; const void* g_pyr = nullptr;
+    orbx::DevBuf<int> d_rowstart, d_rowitems;   // row index of the right keypoints (k_stereo_rows)
     orbx::DevBuf<int> d_aux;     // int4 per keypoint: stereo row band / x / octave (k_orient_brief -> k_stereo_match)
 };

@@ -32,10 +32,13 @@ __global__ void k_orient_brief(const LevelInfo* __restrict__ lv, int nlevels, co
                                KeyPointRec* __restrict__ out_kps, unsigned long long* __restrict__ out_desc, int4* __restrict__ out_aux);
 __global__ void k_hamming_matrix(const unsigned long long* __restrict__ A, int na,
                                  const unsigned long long* __restrict__ Bm, int nb, int* __restrict__ out);
+__global__ void k_stereo_rows(const int4* __restrict__ auxR, const int* __restrict__ nR, int cap, int nb, int* __restrict__ bucket_start,
+                              int* __restrict__ bucket_items);
 __global__ void k_stereo_match(const LevelInfo* __restrict__ lv, const KeyPointRec* __restrict__ kpsL,
                                const unsigned long long* __restrict__ descL, const int* __restrict__ nL,
                                const KeyPointRec* __restrict__ kpsR, const unsigned long long* __restrict__ descR,
-                               const int4* __restrict__ auxR, const int* __restrict__ nR, int cap, const uint8_t* __restrict__ pyrL,
+                               const int4* __restrict__ auxR, const int* __restrict__ nR, const int* __restrict__ bucket_start,
+                               const int* __restrict__ bucket_items, int nb, int lookback, int cap, const uint8_t* __restrict__ pyrL,
                                const uint8_t* __restrict__ pyrR, size_t pyr_stride, StereoParams P,
                                float* __restrict__ uRight, float* __restrict__ depth, int* __restrict__ sad);
 __global__ void k_stereo_median(const int* __restrict__ nL, int cap, float* __restrict__ uRight,
