@@ -127,8 +127,8 @@ __global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restric
     int my_m10 = 0, my_m01 = 0;
     for (int k = 0; k < kKpPerWave; k++) {
         if (!((vmask >> k) & 1ull)) continue;               // wave-uniform
-        const int pitch = __shfl(my_pitch, k);
-        const uint8_t* raw = raw0 + __shfl(my_off, k);
+        const int pitch = ORBX_READLANE(my_pitch, k);
+        const uint8_t* raw = raw0 + readlane_i64(my_off, k);
         // all 16 row loads of this lane are issued back to back, so the gather costs one memory round trip instead of sixteen
         int I[16];
 #pragma unroll
@@ -154,10 +154,10 @@ __global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restric
     }
     for (int k = 0; k < kKpPerWave; k++) {
         if (!((vmask >> k) & 1ull)) continue;
-        const int pitch = __shfl(my_pitch, k);
-        const uint8_t* ctr = blur0 + __shfl(my_off, k);
-        const float a = __shfl(my_a, k), bb = __shfl(my_b, k);
-        const int fi = __shfl(my_fi, k);
+        const int pitch = ORBX_READLANE(my_pitch, k);
+        const uint8_t* ctr = blur0 + readlane_i64(my_off, k);
+        const float a = __int_as_float(ORBX_READLANE(__float_as_int(my_a), k)), bb = __int_as_float(ORBX_READLANE(__float_as_int(my_b), k));
+        const int fi = ORBX_READLANE(my_fi, k);
         int t0v[4], t1v[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {       // 8 independent gathers in flight

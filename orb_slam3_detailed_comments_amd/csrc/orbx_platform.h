@@ -30,4 +30,13 @@ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+// lane l's 64-bit value as a wave-uniform scalar pair (base addresses then live in SGPRs and loads use 32-bit vector offsets)
+__device__ __forceinline__ long long readlane_i64(long long v, int l) {
+#ifdef ORBX_EMU
+    return __shfl(v, l);
+#else
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xFFFFFFFFll), l), hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+    return ((long long)hi << 32) | (unsigned long long)(unsigned)lo;
+#endif
+}
 }  // namespace orbx
