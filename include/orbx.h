@@ -230,6 +230,23 @@ typedef struct OrbmAreaQuery { float x, y, r; int min_level, max_level; } OrbmAr
 int orbm_area_search_batch(orbx_extractor* h, const OrbmFrameView* F, const OrbmAreaQuery* queries, const uint8_t* query_desc, int Q,
                            int* start, int* count, int* idx, int* dist, int* level, int cap);
 
+/* ---- Input pre-step: what the reference does to a camera frame between the driver and ORBextractor ----
+ * geometry 1 = cv::remap(im, imRect, M1, M2, cv::INTER_LINEAR), the stereo rectification of System::TrackStereo (src/System.cc:286-293,
+ * maps of cv::initUndistortRectifyMap(..., CV_32F, ...), src/Settings.cc:549-574); geometry 2 = cv::resize(im, imToFeed, newImSize)
+ * (src/System.cc:295-297, e.g. 752x480 -> 600x350 in Examples/Monocular/EuRoC.yaml:36-37); then, for 3/4-channel frames,
+ * cv::cvtColor(..., COLOR_RGB2GRAY | BGR2GRAY | RGBA2GRAY | BGRA2GRAY) of Tracking::GrabImage* (src/Tracking.cc:1532-1560, rgb = mbRGB).
+ * With a spec set, orbx_extract / orbx_extract_batch take the raw frames (width, height, stride of the source, `channels` bytes per
+ * pixel) and extract at out_w x out_h (geometry != 0) or at the source size.  NULL restores plain 8UC1 input. */
+typedef struct OrbxInputSpec {
+    int channels;                        /* 1, 3 or 4 */
+    int rgb;                             /* Tracking::mbRGB: 1 = red first, 0 = blue first */
+    int gray_variant;                    /* cvtColor 8U coefficients: 0 = OpenCV 4.x (9798, 19235, 3735 >> 15), 1 = 3.x (4899, 9617, 1868 >> 14) */
+    int geometry;                        /* 0 none, 1 remap, 2 resize */
+    int out_w, out_h;                    /* size fed to the extractor when geometry != 0 (map size / Settings::newImSize()) */
+    const float* map_x; const float* map_y;   /* geometry 1: M1, M2 (CV_32FC1, out_h x out_w, dense); copied to the device */
+} OrbxInputSpec;
+int orbx_set_input(orbx_extractor* h, const OrbxInputSpec* spec);
+
 /* ---- remaining projection-type searches ----
  * The caller evaluates the geometry in front of GetFeaturesInArea with the reference's own Sophus/Eigen code (Tcw * p3Dw, project,
  * IsInImage, min/max distance, viewing angle, PredictScale) and hands the survivors over as numbers; window search, level window,

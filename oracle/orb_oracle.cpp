@@ -520,6 +520,21 @@ void orbo_prim_resize(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, 
 void orbo_prim_blur(const uint8_t* src, int w, int h, uint8_t* dst, int variant) { orbp::gaussian_blur7_u8(src, w, h, (size_t)w, dst, (size_t)w, variant); }
 void orbo_prim_border(const uint8_t* src, int w, int h, uint8_t* dst, int b) { orbp::make_border_reflect101(src, w, h, (size_t)w, dst, (size_t)(w + 2 * b), b, b, b, b); }
 int orbo_prim_round(double v) { return orbp::round_half_even(v); }
+// input pre-step (System.cc:286-297, Tracking.cc:1532-1560); multi-channel resize = cv::resize per channel
+void orbo_prim_remap(const uint8_t* src, int sw, int sh, int cn, const float* mapx, const float* mapy, uint8_t* dst, int dw, int dh) {
+    orbp::remap_linear_u8(src, sw, sh, (size_t)sw * cn, cn, mapx, mapy, dst, dw, dh, (size_t)dw * cn);
+}
+void orbo_prim_gray(const uint8_t* src, int w, int h, int cn, int red_first, int variant, uint8_t* dst) {
+    orbp::cvt_gray_u8(src, w, h, (size_t)w * cn, cn, red_first, variant, dst, (size_t)w);
+}
+void orbo_prim_resize_cn(const uint8_t* src, int sw, int sh, int cn, uint8_t* dst, int dw, int dh) {
+    std::vector<uint8_t> a((size_t)sw * sh), b((size_t)dw * dh);
+    for (int c = 0; c < cn; c++) {
+        for (size_t i = 0; i < a.size(); i++) a[i] = src[i * cn + c];
+        orbp::resize_linear_u8(a.data(), sw, sh, (size_t)sw, b.data(), dw, dh, (size_t)dw);
+        for (size_t i = 0; i < b.size(); i++) dst[i * cn + c] = b[i];
+    }
+}
 
 // =====================================================================================================================
 // M3-M6: guided searches, restated sequentially on structure-of-arrays views (the reference's ORBmatcher.cc / Frame.cc

@@ -93,6 +93,46 @@ static inline void resize_linear_u8(const uint8_t* src, int sw, int sh, size_t s
     }
 }
 
+// ---- cv::remap(src, dst, map1 (CV_32FC1 x), map2 (CV_32FC1 y), INTER_LINEAR, BORDER_CONSTANT, Scalar()) for 8U, cn channels ----
+// OpenCV imgproc/remap: float maps are converted block-wise to fixed point, sx = cvRound(x * INTER_TAB_SIZE) with
+// INTER_TAB_SIZE = 32, integer part saturate_cast<short>(sx >> 5), fraction sx & 31; weights from BilinearTab_i
+// (saturate_cast<short>((1-fy)(1-fx) * 32768) ..., exact integers for 5-bit fractions; the single table entry whose sum
+// misses 32768 - fx = fy = 0, weight 32767 - gets the missing unit on tap 3, which cannot change an 8-bit result);
+// result = saturate_cast<uchar>((sum + (1 << 14)) >> 15); taps outside the source read the border value 0.
+static inline void remap_linear_u8(const uint8_t* src, int sw, int sh, size_t sstep, int cn, const float* mapx, const float* mapy,
+                                   uint8_t* dst, int dw, int dh, size_t dstep) {
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            const int fsx = round_half_even((double)(mapx[(size_t)y * dw + x] * 32.0f)), fsy = round_half_even((double)(mapy[(size_t)y * dw + x] * 32.0f));
+            const int sx = sat_short(fsx >> 5), sy = sat_short(fsy >> 5);
+            const int fx = fsx & 31, fy = fsy & 31;
+            int w[4] = {(32 - fx) * (32 - fy) * 32, fx * (32 - fy) * 32, (32 - fx) * fy * 32, fx * fy * 32};
+            if (fx == 0 && fy == 0) { w[0] = 32767; w[3] = 1; }
+            for (int c = 0; c < cn; c++) {
+                int v[4];
+                for (int k = 0; k < 4; k++) {
+                    const int xx = sx + (k & 1), yy = sy + (k >> 1);
+                    v[k] = (xx >= 0 && xx < sw && yy >= 0 && yy < sh) ? src[(size_t)yy * sstep + (size_t)xx * cn + c] : 0;
+                }
+                const int r = (v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3] + (1 << 14)) >> 15;
+                dst[(size_t)y * dstep + (size_t)x * cn + c] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+            }
+        }
+}
+
+// ---- cv::cvtColor(src, dst, COLOR_RGB2GRAY / BGR2GRAY / RGBA2GRAY / BGRA2GRAY) for 8U ----
+// variant 0: OpenCV 4.x (RY15 = 9798, GY15 = 19235, BY15 = 3735, gray_shift = 15); variant 1: OpenCV 3.x (R2Y = 4899, G2Y = 9617,
+// B2Y = 1868, yuv_shift = 14); dst = CV_DESCALE(r*RY + g*GY + b*BY, shift).
+static inline void cvt_gray_u8(const uint8_t* src, int w, int h, size_t sstep, int cn, int red_first, int variant, uint8_t* dst, size_t dstep) {
+    const int ry = variant ? 4899 : 9798, gy = variant ? 9617 : 19235, by = variant ? 1868 : 3735, shift = variant ? 14 : 15;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const uint8_t* p = src + (size_t)y * sstep + (size_t)x * cn;
+            const int r = red_first ? p[0] : p[2], g = p[1], b = red_first ? p[2] : p[0];
+            dst[(size_t)y * dstep + x] = (uint8_t)((r * ry + g * gy + b * by + (1 << (shift - 1))) >> shift);
+        }
+}
+
 // ---- cv::copyMakeBorder(BORDER_REFLECT_101) ---------------------------------------------------
 // dst is (w+left+right) x (h+top+bottom); src may alias the interior of dst.
 static inline void make_border_reflect101(const uint8_t* src, int w, int h, size_t sstep,

@@ -24,7 +24,7 @@ ORBX_OK, ORBX_E_EMPTY, ORBX_E_ARG, ORBX_E_DEVICE, ORBX_E_CAPACITY, ORBX_E_INTERN
 SYMBOLS = [
     "orbx_device_count", "orbx_create", "orbx_destroy", "orbx_set_gaussian_taps", "orbx_reserve",
     "orbx_get_levels", "orbx_get_scale_factor", "orbx_get_level_tables", "orbx_max_keypoints",
-    "orbx_extract", "orbx_extract_batch", "orbx_fetch", "orbx_sync", "orbx_pyramid_level",
+    "orbx_extract", "orbx_extract_batch", "orbx_set_input", "orbx_fetch", "orbx_sync", "orbx_pyramid_level",
     "orbx_device_alloc", "orbx_device_free", "orbx_device_upload", "orbx_host_alloc", "orbx_host_free", "orbx_set_graph_replay", "orbx_profile_enable",
     "orbx_profile_get", "orbx_stage_name", "orbx_debug_candidates", "orbx_debug_level_keys", "orbx_debug_quadtree_profile",
     "orbm_hamming_matrix", "orbm_stereo_match", "orbm_stereo_fetch", "orbm_knn2", "orbm_knn2_fetch",
@@ -63,6 +63,7 @@ class OrbxLib:
         L.orbx_max_keypoints.argtypes = [vp]
         L.orbx_extract.argtypes = [vp, vp, i, i, i, i, i, vp, vp, i, ip, ip]
         L.orbx_extract_batch.argtypes = [vp, i, vp, i, i, i, sz, i, i, i]
+        L.orbx_set_input.argtypes = [vp, vp]
         L.orbx_fetch.argtypes = [vp, vp, vp, i, vp, vp]
         L.orbx_sync.argtypes = [vp]
         L.orbx_pyramid_level.argtypes = [vp, i, i, i, vp, i, ip, ip]

@@ -187,11 +187,41 @@ int configure(orbx_extractor* h, int W, int H, int B) {
 void stage_begin(orbx_extractor* h, int st, rt::stream_t s) { if (h->profile) rt::event_record(h->ev_stage[st][0], s); }
 void stage_end(orbx_extractor* h, int st, rt::stream_t s) { if (h->profile) rt::event_record(h->ev_stage[st][1], s); }
 
-int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int stride, size_t image_stride, int lap0, int lap1) {
+// level 0 from raw camera frames: geometry (remap / resize, per channel) first, grey conversion second - the order of the reference
+// (System::TrackStereo feeds the rectified / resized frame to Tracking::GrabImage*, which converts it)
+void enqueue_input(orbx_extractor* h, int B, const uint8_t* d_images, int sw, int sh, int stride, size_t image_stride) {
+    const LevelInfo& L0 = h->lv[0];
+    const dim3 blk2(64, 4, 1);
+    const int C = h->in_channels;
+    uint8_t* lvl0 = h->d_pyr.p + L0.off;
+    const uint8_t* cur = d_images; int cur_stride = stride; size_t cur_img = image_stride;
+    if (h->in_geometry != 0) {
+        const bool direct = C == 1;                               // single channel: straight into the pyramid
+        uint8_t* dst = direct ? lvl0 : h->d_frame.p;
+        const int dpitch = direct ? L0.pitch : L0.w * C; const size_t dstride = direct ? h->pyr_stride : (size_t)L0.w * L0.h * C;
+        dim3 grid(((dpitch + C - 1) / C + 63) / 64, (L0.h + 3) / 4, B);
+        if (h->in_geometry == 1)
+            ORBX_LAUNCH(k_input_remap, grid, blk2, 0, h->s0, cur, sw, sh, cur_stride, cur_img, C, (const float*)h->d_mapx.p, (const float*)h->d_mapy.p,
+                        L0.w, L0.h, dst, dpitch, dstride);
+        else
+            ORBX_LAUNCH(k_input_resize, grid, blk2, 0, h->s0, cur, sw, sh, cur_stride, cur_img, C, (const ResizeTap*)h->d_in_xt.p,
+                        (const ResizeTap*)h->d_in_yt.p, L0.w, L0.h, dst, dpitch, dstride);
+        cur = dst; cur_stride = dpitch; cur_img = dstride;
+        if (direct) return;
+    }
+    // cv::cvtColor 8U: OpenCV 4.x (RY15, GY15, BY15, 15) or 3.x (R2Y, G2Y, B2Y, yuv_shift = 14)
+    const int ry = h->in_gray_variant ? 4899 : 9798, gy = h->in_gray_variant ? 9617 : 19235, by = h->in_gray_variant ? 1868 : 3735;
+    dim3 grid((L0.pitch + 63) / 64, (L0.h + 3) / 4, B);
+    ORBX_LAUNCH(k_input_gray, grid, blk2, 0, h->s0, cur, cur_stride, cur_img, C, h->in_rgb ? 0 : 2, ry, gy, by, h->in_gray_variant ? 14 : 15, L0.w, L0.h,
+                lvl0, L0.pitch, h->pyr_stride);
+}
+
+int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w, int src_h, int stride, size_t image_stride, int lap0, int lap1) {
     const int nl = h->nlevels;
     const dim3 blk2(64, 4, 1), blk1(256, 1, 1);
     stage_begin(h, ST_IMPORT, h->s0);
-    {
+    if (h->in_active && (h->in_channels != 1 || h->in_geometry != 0)) enqueue_input(h, B, d_images, src_w, src_h, stride, image_stride);
+    else {
         const LevelInfo& L0 = h->lv[0];
         dim3 grid((L0.pitch + 255) / 256, (L0.h + 3) / 4, B);
         ORBX_LAUNCH(k_import, grid, blk2, 0, h->s0, (const LevelInfo*)h->d_lv.p, d_images, stride, image_stride, h->d_pyr.p, h->pyr_stride);
@@ -318,6 +348,7 @@ void orbx_destroy(orbx_extractor* h) {
     for (auto& x : h->d_sr) x.release();
     for (auto& x : h->d_si) x.release();
     h->d_aux.release(); h->d_qtprof.release(); h->d_rowstart.release(); h->d_rowitems.release();
+    h->d_mapx.release(); h->d_mapy.release(); h->d_in_xt.release(); h->d_in_yt.release(); h->d_frame.release();
     delete h;
 }
 
@@ -350,14 +381,28 @@ int orbx_extract_batch(orbx_extractor* h, int B, const uint8_t* images, int widt
                        int on_device, int lap0, int lap1) {
     if (!h) return fail(ORBX_E_ARG, "null handle");
     if (!images || width <= 0 || height <= 0 || B <= 0) return fail(ORBX_E_EMPTY, "empty image");
-    if (stride < width) return fail(ORBX_E_ARG, "stride < width");
-    if (B > 1 && image_stride < (size_t)stride * (height - 1) + width) return fail(ORBX_E_ARG, "image_stride too small");
-    int rc = configure(h, width, height, B);
+    const int C = h->in_active ? h->in_channels : 1;
+    const size_t row_bytes = (size_t)width * C;
+    if ((size_t)stride < row_bytes) return fail(ORBX_E_ARG, "stride < width * channels");
+    if (B > 1 && image_stride < (size_t)stride * (height - 1) + row_bytes) return fail(ORBX_E_ARG, "image_stride too small");
+    const bool geom = h->in_active && h->in_geometry != 0;
+    int rc = configure(h, geom ? h->in_out_w : width, geom ? h->in_out_h : height, B);
     if (rc) return rc;
     rt::set_device(h->device);
+    if (h->in_active) {
+        if (h->in_geometry == 2 && (h->in_tap_w != width || h->in_tap_h != height)) {        // cv::resize taps for this source size
+            std::vector<ResizeTap> xt, yt;
+            resize_axis(width, h->in_out_w, true, xt); resize_axis(height, h->in_out_h, false, yt);
+            if (h->d_in_xt.ensure(xt.size()) || h->d_in_yt.ensure(yt.size())) return fail(ORBX_E_DEVICE, "allocation failed");
+            rt::copy_h2d(h->d_in_xt.p, xt.data(), sizeof(ResizeTap) * xt.size(), h->s0); rt::copy_h2d(h->d_in_yt.p, yt.data(), sizeof(ResizeTap) * yt.size(), h->s0);
+            rt::stream_sync(h->s0);
+            h->in_tap_w = width; h->in_tap_h = height;
+        }
+        if (geom && C > 1 && h->d_frame.ensure((size_t)B * h->W * h->H * C + 16)) return fail(ORBX_E_DEVICE, "allocation failed");
+    }
     const uint8_t* d_images = images;
     if (!on_device) {
-        const size_t bytes = (size_t)(B - 1) * image_stride + (size_t)stride * (height - 1) + width;
+        const size_t bytes = (size_t)(B - 1) * image_stride + (size_t)stride * (height - 1) + row_bytes;
         if (h->d_stage.ensure(bytes + 16)) return fail(ORBX_E_DEVICE, "staging allocation failed");
         if (rt::copy_h2d(h->d_stage.p, images, bytes, h->s0)) return fail(ORBX_E_DEVICE, "H2D copy failed: %s", rt::last_error());
         d_images = h->d_stage.p;
@@ -366,14 +411,14 @@ int orbx_extract_batch(orbx_extractor* h, int B, const uint8_t* images, int widt
     // hipGraph replay of the whole extraction (import, 7 dependent resize launches, FAST, quadtree, blur on the second stream,
     // layout, orient+BRIEF): at small batches the ~17 launches are launch/latency-bound.  The graph is keyed on everything that
     // is baked into the kernel arguments and re-captured when any of it changes.
-    if (h->use_graph && !h->profile) {
+    if (h->use_graph && !h->profile && !h->in_active) {
         const bool same = h->graph_exec && h->g_B == B && h->g_images == d_images && h->g_stride == stride && h->g_image_stride == image_stride &&
                           h->g_lap0 == lap0 && h->g_lap1 == lap1 && h->g_W == h->W && h->g_H == h->H && h->g_pyr == h->d_pyr.p && h->g_gauss == h->gauss_variant;
         if (!same) {
             if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
             if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
             if (hipStreamBeginCapture(h->s0, hipStreamCaptureModeThreadLocal) != hipSuccess) return fail(ORBX_E_DEVICE, "graph capture failed to start");
-            rc = enqueue_extract(h, B, d_images, stride, image_stride, lap0, lap1);
+            rc = enqueue_extract(h, B, d_images, width, height, stride, image_stride, lap0, lap1);
             const hipError_t e = hipStreamEndCapture(h->s0, &h->graph);
             if (rc || e != hipSuccess || hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0) != hipSuccess) {
                 h->graph_exec = nullptr;
@@ -388,7 +433,27 @@ int orbx_extract_batch(orbx_extractor* h, int B, const uint8_t* images, int widt
         return ORBX_OK;
     }
 #endif
-    return enqueue_extract(h, B, d_images, stride, image_stride, lap0, lap1);
+    return enqueue_extract(h, B, d_images, width, height, stride, image_stride, lap0, lap1);
+}
+
+int orbx_set_input(orbx_extractor* h, const OrbxInputSpec* spec) {
+    if (!h) return fail(ORBX_E_ARG, "null handle");
+    if (!spec) { h->in_active = false; return ORBX_OK; }
+    if (spec->channels != 1 && spec->channels != 3 && spec->channels != 4) return fail(ORBX_E_ARG, "channels must be 1, 3 or 4");
+    if (spec->geometry < 0 || spec->geometry > 2) return fail(ORBX_E_ARG, "unknown geometry");
+    if (spec->geometry != 0 && (spec->out_w <= 0 || spec->out_h <= 0)) return fail(ORBX_E_ARG, "output size missing");
+    if (spec->geometry == 1 && (!spec->map_x || !spec->map_y)) return fail(ORBX_E_ARG, "rectification maps missing");
+    rt::set_device(h->device);
+    if (spec->geometry == 1) {
+        const size_t n = (size_t)spec->out_w * spec->out_h;
+        if (h->d_mapx.ensure(n) || h->d_mapy.ensure(n)) return fail(ORBX_E_DEVICE, "allocation failed");
+        if (rt::copy_h2d(h->d_mapx.p, spec->map_x, n * sizeof(float), h->s0) | rt::copy_h2d(h->d_mapy.p, spec->map_y, n * sizeof(float), h->s0) | rt::stream_sync(h->s0))
+            return fail(ORBX_E_DEVICE, "map upload failed");
+    }
+    h->in_channels = spec->channels; h->in_rgb = spec->rgb ? 1 : 0; h->in_gray_variant = spec->gray_variant ? 1 : 0; h->in_geometry = spec->geometry;
+    h->in_out_w = spec->out_w; h->in_out_h = spec->out_h; h->in_tap_w = h->in_tap_h = 0;
+    h->in_active = true;
+    return ORBX_OK;
 }
 
 int orbx_sync(orbx_extractor* h) {

@@ -85,6 +85,9 @@ struct orbx_extractor {
 #endif
     int g_B = 0, g_stride = 0, g_lap0 = 0, g_lap1 = 0, g_W = 0, g_H = 0, g_gauss = 0; size_t g_image_stride = 0;
     const void* g_images = nullptr; const void* g_pyr = nullptr;
+    // input pre-step (orbx_set_input): channels / colour order / grey coefficients / geometry, device maps or taps, intermediate frame
+    bool in_active = false; int in_channels = 1, in_rgb = 1, in_gray_variant = 0, in_geometry = 0, in_out_w = 0, in_out_h = 0, in_tap_w = 0, in_tap_h = 0;
+    orbx::DevBuf<float> d_mapx, d_mapy; orbx::DevBuf<orbx::ResizeTap> d_in_xt, d_in_yt; orbx::DevBuf<uint8_t> d_frame;
     orbx::DevBuf<int> d_rowstart, d_rowitems;   // row index of the right keypoints (k_stereo_rows)
     orbx::DevBuf<int> d_aux;     // int4 per keypoint: stereo row band / x / octave (k_orient_brief -> k_stereo_match)
 };

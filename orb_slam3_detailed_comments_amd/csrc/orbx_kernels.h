@@ -75,4 +75,11 @@ __global__ void k_voc_assemble(const unsigned* __restrict__ word, const unsigned
                                unsigned* __restrict__ fv_node, int* __restrict__ fv_start, unsigned* __restrict__ fv_feat,
                                int* __restrict__ n_out);
 
+__global__ void k_input_remap(const uint8_t* __restrict__ src, int sw, int sh, int sstride, size_t simg, int C, const float* __restrict__ mapx,
+                              const float* __restrict__ mapy, int out_w, int out_h, uint8_t* __restrict__ dst, int dst_pitch, size_t dst_stride);
+__global__ void k_input_resize(const uint8_t* __restrict__ src, int sw, int sh, int sstride, size_t simg, int C, const ResizeTap* __restrict__ xt,
+                               const ResizeTap* __restrict__ yt, int out_w, int out_h, uint8_t* __restrict__ dst, int dst_pitch, size_t dst_stride);
+__global__ void k_input_gray(const uint8_t* __restrict__ src, int sstride, size_t simg, int C, int ridx, int ry, int gy, int by, int shift, int w, int h,
+                             uint8_t* __restrict__ dst, int dst_pitch, size_t dst_stride);
+
 }  // namespace orbx

@@ -70,6 +70,32 @@ class ORBextractor:
     def max_keypoints(self):
         return self._lib.L.orbx_max_keypoints(self._h)
 
+    def set_input(self, channels=1, rgb=True, gray_variant=0, remap=None, resize=None):
+        """The reference's steps between the camera driver and the extractor (orbx_set_input): `remap=(map_x, map_y)` = stereo
+        rectification cv::remap(..., INTER_LINEAR) with CV_32FC1 maps (src/System.cc:286-293); `resize=(new_w, new_h)` = cv::resize to
+        Settings::newImSize (:295-297); channels 3/4 + rgb = the cvtColor of Tracking::GrabImage* (src/Tracking.cc:1532-1560).
+        Frames are then passed as [B,H,W] (1 channel) or [B,H,W,C].  set_input(None) restores plain 8UC1 input."""
+        import ctypes as C
+
+        class Spec(C.Structure):
+            _fields_ = [("channels", C.c_int), ("rgb", C.c_int), ("gray_variant", C.c_int), ("geometry", C.c_int), ("out_w", C.c_int),
+                        ("out_h", C.c_int), ("map_x", C.c_void_p), ("map_y", C.c_void_p)]
+        if channels is None:
+            self._lib.check(self._lib.L.orbx_set_input(self._h, None)); self._in_channels = 1
+            return
+        sp = Spec(int(channels), int(bool(rgb)), int(gray_variant), 0, 0, 0, None, None)
+        keep = None
+        if remap is not None:
+            mx = np.ascontiguousarray(remap[0], np.float32); my = np.ascontiguousarray(remap[1], np.float32)
+            assert mx.shape == my.shape and mx.ndim == 2
+            sp.geometry, sp.out_w, sp.out_h, sp.map_x, sp.map_y = 1, mx.shape[1], mx.shape[0], mx.ctypes.data, my.ctypes.data
+            keep = (mx, my)
+        elif resize is not None:
+            sp.geometry, sp.out_w, sp.out_h = 2, int(resize[0]), int(resize[1])
+        self._lib.check(self._lib.L.orbx_set_input(self._h, C.byref(sp)))
+        del keep
+        self._in_channels = int(channels)
+
     # ---- ORBextractor::operator() (src/ORBextractor.cc:1557) ----
     def __call__(self, image, mask=None, vLappingArea=(0, 0)):
         """Returns (monoIndex, keypoints[N] structured array, descriptors[N,32] uint8); monoIndex == -1 and empty
@@ -84,7 +110,8 @@ class ORBextractor:
         """Asynchronous batched extraction.  images: uint8 [B,H,W] host array, or (device_ptr, shape=(B,H,W))."""
         if device_ptr is None:
             images = np.ascontiguousarray(images, np.uint8)
-            B, H, W = images.shape
+            B, H, W = images.shape[:3]
+            assert images.ndim == 3 or images.shape[3] == getattr(self, "_in_channels", 1), "channel count differs from set_input()"
             ptr, st, ist, ondev = images.ctypes.data, images.strides[1], images.strides[0], 0
             self._keep = images
         else:

@@ -353,3 +353,36 @@ def oracle_distinctive_descriptors(desc, start):
     best = np.full(max(len(st) - 1, 1), -1, np.int32)
     L.orbo_distinctive_descriptors(d.ctypes.data, st.ctypes.data, len(st) - 1, best.ctypes.data)
     return best[:len(st) - 1]
+
+
+# ---- input pre-step primitives (cv::remap / cv::resize on cn channels / cv::cvtColor) ----
+def oracle_remap(src, mapx, mapy):
+    L = oracle()
+    L.orbo_prim_remap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.orbo_prim_remap.restype = None
+    src = np.ascontiguousarray(src, np.uint8); cn = 1 if src.ndim == 2 else src.shape[2]
+    mx = np.ascontiguousarray(mapx, np.float32); my = np.ascontiguousarray(mapy, np.float32)
+    dh, dw = mx.shape
+    dst = np.zeros((dh, dw) if src.ndim == 2 else (dh, dw, cn), np.uint8)
+    L.orbo_prim_remap(src.ctypes.data, src.shape[1], src.shape[0], cn, mx.ctypes.data, my.ctypes.data, dst.ctypes.data, dw, dh)
+    return dst
+
+
+def oracle_resize_cn(src, dw, dh):
+    L = oracle()
+    L.orbo_prim_resize_cn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    L.orbo_prim_resize_cn.restype = None
+    src = np.ascontiguousarray(src, np.uint8); cn = 1 if src.ndim == 2 else src.shape[2]
+    dst = np.zeros((dh, dw) if src.ndim == 2 else (dh, dw, cn), np.uint8)
+    L.orbo_prim_resize_cn(src.ctypes.data, src.shape[1], src.shape[0], cn, dst.ctypes.data, dw, dh)
+    return dst
+
+
+def oracle_gray(src, red_first, variant):
+    L = oracle()
+    L.orbo_prim_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.orbo_prim_gray.restype = None
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros(src.shape[:2], np.uint8)
+    L.orbo_prim_gray(src.ctypes.data, src.shape[1], src.shape[0], src.shape[2], int(red_first), int(variant), dst.ctypes.data)
+    return dst
