@@ -216,6 +216,20 @@ def main():
                 traffic = json.load(open(pmc)).get(dom)
             except Exception:
                 traffic = None
+        # VALU issue view of the same kernel (the HBM fraction says little for a compute-heavy integer kernel): wave-instructions per
+        # launch from the SQ counter pass (profiles/pmc_valu.json, scaled to this launch size) against the issue peak of
+        # 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md)
+        valu = None
+        pv = os.path.join(ROOT, "profiles", "pmc_valu.json")
+        if os.path.exists(pv):
+            try:
+                n_instr = json.load(open(pv)).get(dom, 0) * (2 * P) / 128.0
+                peak = 256 * 4 * 2.4e9 / 2
+                if n_instr > 0:
+                    valu = {"wave_instr_per_launch": int(n_instr), "peak_wave_instr_per_s": peak,
+                            "frac": round(n_instr / (stage_ms[dom] * 1e-3) / peak, 4), "alone_frac": round(n_instr / (serial_sum[dom] * 1e-3) / peak, 4)}
+            except Exception:
+                valu = None
         per_pair_bytes = 2 * sum(v for k, v in ab.items() if k != "match") + ab["match"]
         res = {
             "metric": "stereo pairs/sec ORB extract+match, 752x480 stereo @1200 feat", "value": round(value, 1),
@@ -231,7 +245,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(ab[dom] * units[dom]), "avg_launch_ms": round(stage_ms[dom], 4),
                          "alone_launch_ms": round(serial_sum[dom], 4), "alone_GBps": round(ab[dom] * units[dom] / (serial_sum[dom] * 1e-3) / 1e9, 2),
                          "end_to_end_GBps": round(per_pair_bytes * value / world / 1e9, 2),
-                         "end_to_end_frac": round(per_pair_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5)},
+                         "end_to_end_frac": round(per_pair_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5), "valu_issue": valu},
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_alone": {k: round(v, 4) for k, v in serial_sum.items()},
         }

@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
     ORBX_DYN_SMEM(smem);
     // Plain mapping (workgroup b -> cell b, i.e. neighbouring cells on different XCDs).  Two XCD-aware remaps were measured
     // (contiguous eighths of the cell table per XCD; runs of 16 cells dealt round-robin): they cut the kernel's HBM fetch from
-    // 291 MB to 70 MB per 128-image launch but made it 14-27 % slower (the kernel is VALU-bound and the remaps skew the mix of
+    // 291 MB to 70 MB per 128-image launch but made it 14-27 % slower (the kernel is compute-heavy and the remaps skew the mix of
     // dense and sparse cells per XCD), so the balanced mapping stays.
     const int cell = (int)blockIdx.x, b = (int)blockIdx.y;
     const int tid = (int)threadIdx.x, lane = tid & 63;

@@ -15,3 +15,14 @@ for k, s in stage.items():
 out["_note"] = "bytes per stage launch at 128 images/step = (FETCH_SIZE+WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes; 4-B/lane loads, factor 1.0 (calibrated on k_blur)"
 json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 print(out)
+
+# optional: VALU wave-instructions per stage launch from the SQ pass (tools/gpu_pmc_round.sh) -> profiles/pmc_valu.json
+if len(sys.argv) > 5:
+    q = json.load(open(sys.argv[4]))["counters"]
+    v = {}
+    for k, s_ in stage.items():
+        mult = 7 if k == "k_resize" else 1
+        v[s_] = int(q.get(k, {}).get("SQ_INSTS_VALU", {}).get("avg", 0.0) * mult)
+    v["_note"] = "VALU wave-instructions per stage launch at 128 images/step (rocprofv3 --pmc SQ_INSTS_VALU, own pass)"
+    json.dump(v, open(sys.argv[5], "w"), indent=1, sort_keys=True)
+    print(v)
