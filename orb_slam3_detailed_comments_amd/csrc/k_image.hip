@@ -306,6 +306,7 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
             const int yB = (int)(((unsigned)pB * M) >> 20), xB = pB - yB * pitch;
             const uint8_t* cA = tile + (yA + 2) * wp + xo + xA + 2;
             const uint8_t* cB = tile + (yB + 2) * wp + xo + xB + 2;
+            // (gathering the ring with 7 unaligned ds_read_b32/b64 per pixel instead of 17 byte reads was measured 67 % slower)
             const pk2 v2 = pk_make((uint32_t)cA[0] | ((uint32_t)cB[0] << 16));
             pk2 d[16];
 #define ORBX_D(k, off) d[k] = pk_sub(v2, pk_make((uint32_t)cA[off] | ((uint32_t)cB[off] << 16)));
