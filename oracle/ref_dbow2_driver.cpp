@@ -53,6 +53,14 @@ void ref_voc_transform_one(void* h, const uint8_t* desc, int levelsup, unsigned*
     *word = w; *weight = wt; *node = nid;
 }
 
+// FORB::distance (Thirdparty/DBoW2/DBoW2/FORB.cpp:81-101), the reference's second copy of ORBmatcher::DescriptorDistance
+// (src/ORBmatcher.cc:2383-2403, identical SWAR popcount): pins the Hamming kernels to reference code.
+int ref_forb_distance(const uint8_t* a, const uint8_t* b) {
+    cv::Mat A(1, 32, CV_8U), B(1, 32, CV_8U);
+    memcpy(A.data, a, 32); memcpy(B.data, b, 32);
+    return DBoW2::FORB::distance(A, B);
+}
+
 double ref_voc_score(void* h, const unsigned* id1, const double* v1, int n1, const unsigned* id2, const double* v2, int n2) {
     ORBVocabulary* voc = (ORBVocabulary*)h;
     DBoW2::BowVector a, b;

@@ -75,3 +75,19 @@ def test_golden_vectors(name):
         for lap_key, lap in (("a", (0, 0)), ("b", (100, 250))):
             mono, k, d = ol.OracleExtractor(500).extract(g["image"], lap)
             assert mono == int(g["mono_" + lap_key]) and k.tobytes() == g["kps_" + lap_key].tobytes() and np.array_equal(d, g["desc_" + lap_key])
+
+
+def test_descriptor_distance_against_reference_forb():
+    """M0: the oracle's DescriptorDistance equals the reference's own FORB::distance (same SWAR popcount as
+    ORBmatcher::DescriptorDistance, src/ORBmatcher.cc:2383-2403) on random and structured pairs."""
+    import ctypes as C
+    L = ol.reference_dbow2()
+    if L is None:
+        pytest.skip("oracle/_ref/libref_dbow2.so not built")
+    L.ref_forb_distance.argtypes = [C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (400, 32), dtype=np.uint8); b = rng.integers(0, 256, (400, 32), dtype=np.uint8)
+    b[:50] = a[:50]; b[50:60] = 255 - a[50:60]; a[60] = 0; b[60] = 255; b[61:100] = a[61:100] ^ np.uint8(0x80)
+    for x, y in zip(a, b):
+        ref = L.ref_forb_distance(x.ctypes.data, y.ctypes.data)
+        assert ref == ol.oracle_hamming(x, y) == int(np.unpackbits(x ^ y).sum())
