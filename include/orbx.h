@@ -143,7 +143,8 @@ int orbm_knn2_fetch(orbx_extractor* left, int B, int* idx0, int* dist0, int* idx
  * The facade (include/orb_slam3_amd/ORBmatcher.h) fills the views from the real classes and applies the results.
  * Geometry that the reference computes with Eigen/Sophus before matching (Tcw * x3Dw, GeometricCamera::project,
  * the fundamental matrix) stays on the caller's side and enters here as numbers, so its float op order is the
- * reference's own.  Only the non-fisheye path (Frame::Nleft == -1, no mpCamera2) is implemented. */
+ * reference's own.  The functions below are the Frame::Nleft == -1 paths; the two-camera (fisheye rig) branches of the two
+ * SearchByProjection overloads are the *_fisheye entry points further down. */
 typedef struct OrbmFrameView {            /* fields of ORB_SLAM3::Frame, include/Frame.h */
     int N;                                /* number of keypoints */
     const OrbxKeyPoint* keys_un;          /* mvKeysUn (:232) */
@@ -246,6 +247,33 @@ typedef struct OrbxInputSpec {
     const float* map_x; const float* map_y;   /* geometry 1: M1, M2 (CV_32FC1, out_h x out_w, dense); copied to the device */
 } OrbxInputSpec;
 int orbx_set_input(orbx_extractor* h, const OrbxInputSpec* spec);
+
+/* ---- two-camera (fisheye rig, Frame::Nleft != -1) branches of the SearchByProjection overloads ----
+ * left  = the view of camera 1: keys_un = mvKeys, desc = descriptor rows [0, Nleft), occupied = mvpMapPoints[0, Nleft) (with observations);
+ * right = the view of camera 2: keys_un = mvKeysRight, desc = rows [Nleft, N), occupied = mvpMapPoints[Nleft, N); u_right is not read.
+ * Both views carry the frame's bounds / grid parameters (the right grid is mGridRight). */
+typedef struct OrbmFisheyeFrameView {
+    OrbmFrameView left, right;
+    const int* left_to_right;             /* mvLeftToRightMatch [Nleft]  (read by the map-point overload only; NULL = all -1) */
+    const int* right_to_left;             /* mvRightToLeftMatch [Nright] (read by the map-point overload only; NULL = all -1) */
+} OrbmFisheyeFrameView;
+typedef struct OrbmMapPointRightView {    /* the *R tracking fields of MapPoint, include/MapPoint.h:175-179 */
+    const uint8_t* in_view_r;             /* mbTrackInViewR */
+    const float* proj_xr; const float* proj_yr;   /* mTrackProjXR / mTrackProjYR */
+    const int* scale_level_r;             /* mnTrackScaleLevelR (-1 = not set) */
+    const float* view_cos_r;              /* mTrackViewCosR */
+} OrbmMapPointRightView;
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints) with F.Nleft != -1
+ * (src/ORBmatcher.cc:45-239 including :170-236).  assigned has Nleft + Nright entries, indexed like F.mvpMapPoints. */
+int orbm_search_by_projection_mappoints_fisheye(orbx_extractor* h, const OrbmFisheyeFrameView* F, const OrbmMapPointView* P,
+                                                const OrbmMapPointRightView* PR, float th, int far_points, float th_far_points,
+                                                float nnratio, int* assigned, int* nmatches);
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) with CurrentFrame.Nleft != -1
+ * (src/ORBmatcher.cc:1950-2184 including :2090-2150).  proj_ur / proj_vr [Last->N] = project(GetRelativePoseTrl() * x3Dc).
+ * assigned has Nleft + Nright entries (-1 untouched, -2 reset by the rotation check). */
+int orbm_search_by_projection_frame_fisheye(orbx_extractor* h, const OrbmFisheyeFrameView* Cur, const OrbmLastFrameView* Last,
+                                            const float* proj_ur, const float* proj_vr, float th, int forward, int backward,
+                                            int check_orientation, int* assigned, int* nmatches);
 
 /* ---- remaining projection-type searches ----
  * The caller evaluates the geometry in front of GetFeaturesInArea with the reference's own Sophus/Eigen code (Tcw * p3Dw, project,

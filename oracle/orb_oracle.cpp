@@ -557,6 +557,8 @@ struct OLast {
 struct OProj {      // OrbmProjectedPointView: map points already projected by the caller
     int M; const uint8_t* valid; const float* u; const float* v; const float* ur; const int* pred_level; const float* angle; const uint8_t* desc;
 };
+struct OFisheye { OFrame left, right; const int* left_to_right; const int* right_to_left; };   // OrbmFisheyeFrameView
+struct OMapPointsR { const uint8_t* in_view_r; const float* proj_xr; const float* proj_yr; const int* scale_level_r; const float* view_cos_r; };
 struct OKeyFrame {
     int N; const Kp* keys; const uint8_t* desc; const float* u_right; const uint8_t* has_mp;
     int fv_nodes; const uint32_t* fv_node_id; const int* fv_start; const uint32_t* fv_feat; int nlevels; const float* scale; const float* sigma2;
@@ -1075,6 +1077,142 @@ void orbo_distinctive_descriptors(const uint8_t* desc, const int* start, int P, 
         }
         best[p] = BestIdx;
     }
+}
+
+// ---- two-camera (F.Nleft != -1) versions.  F.mvpMapPoints / mDescriptors index i < Nleft = left camera, i >= Nleft = right camera
+// (right-relative index + Nleft); GetFeaturesInArea(..., bRight) walks mGrid / mGridRight over mvKeys / mvKeysRight.
+
+// ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th, bFarPoints, thFarPoints), src/ORBmatcher.cc:45-239, Nleft != -1
+int orbo_search_by_projection_mappoints_fisheye(const OFisheye* F, const OMapPoints* P, const OMapPointsR* PR, float th, int bFarPoints,
+                                                float thFarPoints, float mfNNratio, int* assigned) {
+    const int TH_HIGH = 100;
+    const OFrame& FL = F->left; const OFrame& FR = F->right;
+    const int Nleft = FL.N;
+    Grid gl = build_grid(FL), gr = build_grid(FR);
+    std::vector<uint8_t> occ(FL.N + FR.N + 1, 0);      // mvpMapPoints[i] && Observations() > 0
+    if (FL.occupied) memcpy(occ.data(), FL.occupied, FL.N);
+    if (FR.occupied) memcpy(occ.data() + Nleft, FR.occupied, FR.N);
+    for (int i = 0; i < FL.N + FR.N; i++) assigned[i] = -1;
+    int nmatches = 0;
+    const bool bFactor = th != 1.0;
+    for (int iMP = 0; iMP < P->M; iMP++) {
+        const uint8_t obs = P->has_obs ? P->has_obs[iMP] : 1;
+        if (!P->in_view[iMP] && !PR->in_view_r[iMP]) continue;
+        if (bFarPoints && P->track_depth[iMP] > thFarPoints) continue;
+        if (P->is_bad[iMP]) continue;
+        const uint8_t* MPdescriptor = P->desc + 32 * (size_t)iMP;
+        if (P->in_view[iMP] && P->scale_level[iMP] >= 0 && P->scale_level[iMP] < FL.nlevels) {
+            const int nPredictedLevel = P->scale_level[iMP];
+            float r = P->view_cos[iMP] > 0.998 ? 2.5f : 4.0f;
+            if (bFactor) r *= th;
+            const std::vector<int> vIndices = features_in_area(FL, gl, P->proj_x[iMP], P->proj_y[iMP], r * FL.scale[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel);
+            if (!vIndices.empty()) {
+                int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+                for (int idx : vIndices) {
+                    if (occ[idx]) continue;
+                    const int dist = descriptor_distance(MPdescriptor, FL.desc + 32 * (size_t)idx);
+                    if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = FL.keys[idx].octave; bestIdx = idx; }
+                    else if (dist < bestDist2) { bestLevel2 = FL.keys[idx].octave; bestDist2 = dist; }
+                }
+                if (bestDist <= TH_HIGH) {
+                    if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;
+                    if (bestLevel != bestLevel2 || bestDist <= mfNNratio * bestDist2) {
+                        assigned[bestIdx] = iMP; occ[bestIdx] = obs;
+                        if (F->left_to_right && F->left_to_right[bestIdx] != -1) {
+                            assigned[F->left_to_right[bestIdx] + Nleft] = iMP; occ[F->left_to_right[bestIdx] + Nleft] = obs;
+                            nmatches++;
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+        }
+        if (PR->in_view_r[iMP]) {
+            const int nPredictedLevel = PR->scale_level_r[iMP];
+            if (nPredictedLevel != -1 && nPredictedLevel >= 0 && nPredictedLevel < FR.nlevels) {
+                const float r = PR->view_cos_r[iMP] > 0.998 ? 2.5f : 4.0f;
+                const std::vector<int> vIndices = features_in_area(FR, gr, PR->proj_xr[iMP], PR->proj_yr[iMP], r * FR.scale[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel);
+                if (vIndices.empty()) continue;
+                int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+                for (int idx : vIndices) {
+                    if (occ[idx + Nleft]) continue;
+                    const int dist = descriptor_distance(MPdescriptor, FR.desc + 32 * (size_t)idx);
+                    if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = FR.keys[idx].octave; bestIdx = idx; }
+                    else if (dist < bestDist2) { bestLevel2 = FR.keys[idx].octave; bestDist2 = dist; }
+                }
+                if (bestDist <= TH_HIGH) {
+                    if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;
+                    if (F->right_to_left && F->right_to_left[bestIdx] != -1) {
+                        assigned[F->right_to_left[bestIdx]] = iMP; occ[F->right_to_left[bestIdx]] = obs;
+                        nmatches++;
+                    }
+                    assigned[bestIdx + Nleft] = iMP; occ[bestIdx + Nleft] = obs;
+                    nmatches++;
+                }
+            }
+        }
+    }
+    return nmatches;
+}
+
+// ORBmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th, bMono), src/ORBmatcher.cc:1950-2184, CurrentFrame.Nleft != -1
+int orbo_search_by_projection_frame_fisheye(const OFisheye* C, const OLast* Lf, const float* proj_ur, const float* proj_vr, float th, int bForward,
+                                            int bBackward, int checkOri, int* assigned) {
+    const int TH_HIGH = 100, HISTO_LENGTH = 30;
+    const OFrame& CL = C->left; const OFrame& CR = C->right;
+    const int Nleft = CL.N;
+    Grid gl = build_grid(CL), gr = build_grid(CR);
+    std::vector<uint8_t> occ(CL.N + CR.N + 1, 0);
+    if (CL.occupied) memcpy(occ.data(), CL.occupied, CL.N);
+    if (CR.occupied) memcpy(occ.data() + Nleft, CR.occupied, CR.N);
+    for (int i = 0; i < CL.N + CR.N; i++) assigned[i] = -1;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0;
+    for (int i = 0; i < Lf->N; i++) {
+        if (!Lf->valid[i]) continue;
+        const uint8_t obs = Lf->has_obs ? Lf->has_obs[i] : 1;
+        const float u = Lf->proj_u[i], v = Lf->proj_v[i];
+        if (u < CL.min_x || u > CL.max_x) continue;
+        if (v < CL.min_y || v > CL.max_y) continue;
+        const int nLastOctave = Lf->octave[i];
+        if (nLastOctave < 0 || nLastOctave >= CL.nlevels) continue;
+        const float radius = th * CL.scale[nLastOctave];
+        const uint8_t* dMP = Lf->desc + 32 * (size_t)i;
+        for (int cam = 0; cam < 2; cam++) {
+            const OFrame& T = cam == 0 ? CL : CR; const Grid& g = cam == 0 ? gl : gr; const int base = cam == 0 ? 0 : Nleft;
+            const float x = cam == 0 ? u : proj_ur[i], y = cam == 0 ? v : proj_vr[i];
+            std::vector<int> vIndices2;
+            if (bForward) vIndices2 = features_in_area(T, g, x, y, radius, nLastOctave, -1);
+            else if (bBackward) vIndices2 = features_in_area(T, g, x, y, radius, 0, nLastOctave);
+            else vIndices2 = features_in_area(T, g, x, y, radius, nLastOctave - 1, nLastOctave + 1);
+            if (cam == 0 && vIndices2.empty()) break;            // the `continue` of :2025-2026 also skips the right camera
+            int bestDist = 256, bestIdx2 = -1;
+            for (int i2 : vIndices2) {
+                if (occ[i2 + base]) continue;
+                const int dist = descriptor_distance(dMP, T.desc + 32 * (size_t)i2);
+                if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+            }
+            if (bestDist <= TH_HIGH) {
+                assigned[bestIdx2 + base] = i; occ[bestIdx2 + base] = obs; nmatches++;
+                if (checkOri) {
+                    float rot = Lf->angle[i] - T.keys[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(bestIdx2 + base);
+                }
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int idx : rotHist[i]) { assigned[idx] = -2; nmatches--; }
+    }
+    return nmatches;
 }
 
 // glibc cosf/sinf, exposed so tests can pin the device-side model (csrc/glibc_sincosf_model.h).

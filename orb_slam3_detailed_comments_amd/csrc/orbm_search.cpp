@@ -620,4 +620,177 @@ int orbm_distinctive_descriptors(orbx_extractor* h, const uint8_t* desc, const i
     return ORBX_OK;
 }
 
+// ---- two-camera (Frame::Nleft != -1) branches.  Each camera's window search runs on the device (one k_area_search per camera); the
+// reference interleaves the two cameras per map point and its assignments feed the occupancy test of later points, so the accept
+// logic is replayed here over both candidate lists in the reference's order.
+namespace {
+int camera_candidates(orbx_extractor* h, const OrbmFrameView* F, const std::vector<AreaQuery>& qs, const uint8_t* qdesc, Csr* c) {
+    DeviceFrame D;
+    int rc = upload_frame(h, F, &D); if (rc) return rc;
+    return run_area_search(h, D, qs, qdesc, c);
+}
+inline int cand_idx(const Csr& c, int q, int k) { return c.ent[2 * (size_t)(c.start[q] + k)]; }
+inline int cand_dl(const Csr& c, int q, int k) { return c.ent[2 * (size_t)(c.start[q] + k) + 1]; }
+}  // namespace
+
+int orbm_search_by_projection_mappoints_fisheye(orbx_extractor* h, const OrbmFisheyeFrameView* F, const OrbmMapPointView* P,
+                                                const OrbmMapPointRightView* PR, float th, int far_points, float th_far, float nnratio,
+                                                int* assigned, int* nmatches_out) {
+    if (!h || !F || !P || !PR || !assigned) return fail(ORBX_E_ARG, "null");
+    rt::set_device(h->device);
+    const int M = P->M, NL = F->left.N, NR = F->right.N;
+    const bool bFactor = th != 1.0;
+    std::vector<AreaQuery> ql(M), qr(M);
+    std::vector<uint8_t> alive(M > 0 ? M : 1, 0);
+    for (int i = 0; i < M; i++) {
+        memset(&ql[i], 0, sizeof(AreaQuery)); memset(&qr[i], 0, sizeof(AreaQuery));
+        const bool inl = P->in_view[i] != 0, inr = PR->in_view_r[i] != 0;
+        if (!inl && !inr) continue;                                       // :53-60
+        if (far_points && P->track_depth[i] > th_far) continue;
+        if (P->is_bad[i]) continue;
+        alive[i] = 1;
+        if (inl) {
+            const int lvl = P->scale_level[i];
+            if (lvl >= 0 && lvl < F->left.nlevels) {
+                float r = P->view_cos[i] > 0.998 ? 2.5f : 4.0f;
+                if (bFactor) r *= th;
+                AreaQuery& q = ql[i];
+                q.x = P->proj_x[i]; q.y = P->proj_y[i]; q.r = r * F->left.scale_factors[lvl]; q.min_level = lvl - 1; q.max_level = lvl; q.active = 1;
+            }
+        }
+        if (inr) {
+            const int lvl = PR->scale_level_r[i];
+            if (lvl != -1 && lvl >= 0 && lvl < F->right.nlevels) {            // :172-173
+                const float r = PR->view_cos_r[i] > 0.998 ? 2.5f : 4.0f;     // the right pass does not apply th (:174)
+                AreaQuery& q = qr[i];
+                q.x = PR->proj_xr[i]; q.y = PR->proj_yr[i]; q.r = r * F->right.scale_factors[lvl]; q.min_level = lvl - 1; q.max_level = lvl; q.active = 1;
+            }
+        }
+    }
+    Csr cl, cr;
+    int rc = camera_candidates(h, &F->left, ql, P->desc, &cl); if (rc) return rc;
+    rc = camera_candidates(h, &F->right, qr, P->desc, &cr); if (rc) return rc;
+    std::vector<uint8_t> occ((size_t)NL + NR + 1, 0);
+    if (F->left.occupied) memcpy(occ.data(), F->left.occupied, NL);
+    if (F->right.occupied) memcpy(occ.data() + NL, F->right.occupied, NR);
+    for (int i = 0; i < NL + NR; i++) assigned[i] = -1;
+    int nmatches = 0;
+    for (int i = 0; i < M; i++) {
+        if (!alive[i]) continue;
+        const uint8_t obs = P->has_obs ? P->has_obs[i] : 1;
+        bool skip_right = false;
+        if (ql[i].active && cl.count[i] > 0) {                               // :62-166
+            int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+            for (int k = 0; k < cl.count[i]; k++) {
+                const int idx = cand_idx(cl, i, k), dl = cand_dl(cl, i, k);
+                if (occ[idx]) continue;
+                const int dist = dl & 0xFFFF, level = dl >> 16;
+                if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = level; bestIdx = idx; }
+                else if (dist < bestDist2) { bestLevel2 = level; bestDist2 = dist; }
+            }
+            if (bestDist <= TH_HIGH) {
+                if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) skip_right = true;     // `continue` of the reference: next map point
+                else if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+                    assigned[bestIdx] = i; occ[bestIdx] = obs;
+                    const int ltr = F->left_to_right ? F->left_to_right[bestIdx] : -1;
+                    if (ltr != -1) { assigned[ltr + NL] = i; occ[ltr + NL] = obs; nmatches++; }
+                    nmatches++;
+                }
+            }
+        }
+        if (skip_right) continue;
+        if (qr[i].active) {                                                  // :170-236
+            if (cr.count[i] == 0) continue;
+            int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+            for (int k = 0; k < cr.count[i]; k++) {
+                const int idx = cand_idx(cr, i, k), dl = cand_dl(cr, i, k);
+                if (occ[idx + NL]) continue;
+                const int dist = dl & 0xFFFF, level = dl >> 16;
+                if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = level; bestIdx = idx; }
+                else if (dist < bestDist2) { bestLevel2 = level; bestDist2 = dist; }
+            }
+            if (bestDist <= TH_HIGH) {
+                if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+                const int rtl = F->right_to_left ? F->right_to_left[bestIdx] : -1;
+                if (rtl != -1) { assigned[rtl] = i; occ[rtl] = obs; nmatches++; }
+                assigned[bestIdx + NL] = i; occ[bestIdx + NL] = obs;
+                nmatches++;
+            }
+        }
+    }
+    if (nmatches_out) *nmatches_out = nmatches;
+    return ORBX_OK;
+}
+
+int orbm_search_by_projection_frame_fisheye(orbx_extractor* h, const OrbmFisheyeFrameView* Cur, const OrbmLastFrameView* Last, const float* proj_ur,
+                                            const float* proj_vr, float th, int forward, int backward, int check_ori, int* assigned, int* nmatches_out) {
+    if (!h || !Cur || !Last || !proj_ur || !proj_vr || !assigned) return fail(ORBX_E_ARG, "null");
+    rt::set_device(h->device);
+    const int NLast = Last->N, NL = Cur->left.N, NR = Cur->right.N;
+    std::vector<AreaQuery> ql(NLast), qr(NLast);
+    for (int i = 0; i < NLast; i++) {
+        memset(&ql[i], 0, sizeof(AreaQuery)); memset(&qr[i], 0, sizeof(AreaQuery));
+        if (!Last->valid[i]) continue;
+        const float u = Last->proj_u[i], v = Last->proj_v[i];
+        if (u < Cur->left.min_x || u > Cur->left.max_x) continue;          // :2003-2006
+        if (v < Cur->left.min_y || v > Cur->left.max_y) continue;
+        const int oct = Last->octave[i];
+        if (oct < 0 || oct >= Cur->left.nlevels) continue;
+        for (int cam = 0; cam < 2; cam++) {
+            AreaQuery& q = cam == 0 ? ql[i] : qr[i];
+            q.x = cam == 0 ? u : proj_ur[i]; q.y = cam == 0 ? v : proj_vr[i]; q.r = th * Cur->left.scale_factors[oct];
+            if (forward) { q.min_level = oct; q.max_level = -1; }
+            else if (backward) { q.min_level = 0; q.max_level = oct; }
+            else { q.min_level = oct - 1; q.max_level = oct + 1; }
+            q.active = 1;
+        }
+    }
+    Csr cl, cr;
+    int rc = camera_candidates(h, &Cur->left, ql, Last->desc, &cl); if (rc) return rc;
+    rc = camera_candidates(h, &Cur->right, qr, Last->desc, &cr); if (rc) return rc;
+    std::vector<uint8_t> occ((size_t)NL + NR + 1, 0);
+    if (Cur->left.occupied) memcpy(occ.data(), Cur->left.occupied, NL);
+    if (Cur->right.occupied) memcpy(occ.data() + NL, Cur->right.occupied, NR);
+    for (int i = 0; i < NL + NR; i++) assigned[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int nmatches = 0;
+    for (int i = 0; i < NLast; i++) {
+        if (!ql[i].active || cl.count[i] == 0) continue;                   // an empty left window also skips the right camera (:2025-2026)
+        const uint8_t obs = Last->has_obs ? Last->has_obs[i] : 1;
+        {
+            int bestDist = 256, bestIdx2 = -1;
+            for (int k = 0; k < cl.count[i]; k++) {
+                const int i2 = cand_idx(cl, i, k), dist = cand_dl(cl, i, k) & 0xFFFF;
+                if (occ[i2]) continue;
+                if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+            }
+            if (bestDist <= TH_HIGH) {
+                assigned[bestIdx2] = i; occ[bestIdx2] = obs; nmatches++;
+                if (check_ori) rotHist[rot_bin(Last->angle[i], Cur->left.keys_un[bestIdx2].angle)].push_back(bestIdx2);
+            }
+        }
+        {
+            int bestDist = 256, bestIdx2 = -1;
+            for (int k = 0; k < cr.count[i]; k++) {
+                const int i2 = cand_idx(cr, i, k), dist = cand_dl(cr, i, k) & 0xFFFF;
+                if (occ[i2 + NL]) continue;
+                if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+            }
+            if (bestDist <= TH_HIGH) {
+                assigned[bestIdx2 + NL] = i; occ[bestIdx2 + NL] = obs; nmatches++;
+                if (check_ori) rotHist[rot_bin(Last->angle[i], Cur->right.keys_un[bestIdx2].angle)].push_back(bestIdx2 + NL);
+            }
+        }
+    }
+    if (check_ori) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int idx : rotHist[i]) { assigned[idx] = -2; nmatches--; }
+    }
+    if (nmatches_out) *nmatches_out = nmatches;
+    return ORBX_OK;
+}
+
 }  // extern "C"

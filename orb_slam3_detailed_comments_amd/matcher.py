@@ -57,6 +57,24 @@ class ORBmatcher:
                                                                int(self.mbCheckOrientation), m12.ctypes.data, C.byref(nm)))
         return nm.value, m12
 
+    def SearchByProjectionFisheye(self, ext, frame2, map_points, map_points_r, th=1.0, bFarPoints=False, thFarPoints=50.0):
+        """SearchByProjection(Frame&, vector<MapPoint*>&, ...) for a two-camera frame (Nleft != -1), src/ORBmatcher.cc:45-239.
+        frame2: views.fisheye_frame_view; map_points_r: views.map_point_right_view.  Returns (nmatches, assigned[Nleft + Nright])."""
+        N = frame2.view.left.N + frame2.view.right.N
+        assigned = np.full(N, -1, np.int32); nm = C.c_int()
+        ext._lib.check(ext._lib.L.orbm_search_by_projection_mappoints_fisheye(ext._h, frame2.ref(), map_points.ref(), map_points_r.ref(), float(th),
+                                                                            int(bFarPoints), float(thFarPoints), self.mfNNratio, assigned.ctypes.data, C.byref(nm)))
+        return nm.value, assigned
+
+    def SearchByProjectionFrameFisheye(self, ext, cur2, last, proj_ur, proj_vr, th, bForward=False, bBackward=False):
+        """SearchByProjection(Frame& Cur, const Frame& Last, th, bMono) for a two-camera current frame, src/ORBmatcher.cc:1950-2184."""
+        N = cur2.view.left.N + cur2.view.right.N
+        ur = np.ascontiguousarray(proj_ur, np.float32); vr = np.ascontiguousarray(proj_vr, np.float32)
+        assigned = np.full(N, -1, np.int32); nm = C.c_int()
+        ext._lib.check(ext._lib.L.orbm_search_by_projection_frame_fisheye(ext._h, cur2.ref(), last.ref(), ur.ctypes.data, vr.ctypes.data, float(th),
+                                                                        int(bForward), int(bBackward), int(self.mbCheckOrientation), assigned.ctypes.data, C.byref(nm)))
+        return nm.value, assigned
+
     def SearchByProjectionSim3(self, ext, kf, points, th, ratioHamming=1.0):
         """ORBmatcher::SearchByProjection(KeyFrame*, Sim3f&, vpPoints, [vpPointsKFs,] vpMatched, [vpMatchedKF,] th, ratioHamming),
         src/ORBmatcher.cc:495 and :608.  kf: views.frame_view with occupied = (vpMatched[idx] != NULL); points:

@@ -31,6 +31,14 @@ class KeyFrameView(C.Structure):
                 ("level_sigma2", _vp)]
 
 
+class FisheyeFrameView(C.Structure):
+    _fields_ = [("left", FrameView), ("right", FrameView), ("left_to_right", _vp), ("right_to_left", _vp)]
+
+
+class MapPointRightView(C.Structure):
+    _fields_ = [("in_view_r", _vp), ("proj_xr", _vp), ("proj_yr", _vp), ("scale_level_r", _vp), ("view_cos_r", _vp)]
+
+
 class ProjectedPointView(C.Structure):
     _fields_ = [("M", _i), ("valid", _vp), ("u", _vp), ("v", _vp), ("ur", _vp), ("pred_level", _vp), ("angle", _vp), ("desc", _vp)]
 
@@ -90,3 +98,15 @@ def projected_point_view(valid, u, v, pred_level, desc, ur=None, angle=None):
     a = [_arr(valid, np.uint8), _arr(u, np.float32), _arr(v, np.float32), _arr(ur, np.float32), _arr(pred_level, np.int32),
          _arr(angle, np.float32), _arr(desc, np.uint8)]
     return Held(ProjectedPointView(len(a[0]), *[_ptr(x) for x in a]), a)
+
+
+def fisheye_frame_view(left, right, left_to_right=None, right_to_left=None):
+    """OrbmFisheyeFrameView from two frame_view() results (camera 1 / camera 2 of a Frame with Nleft != -1)."""
+    l2r = _arr(left_to_right, np.int32); r2l = _arr(right_to_left, np.int32)
+    v = FisheyeFrameView(left.view, right.view, _ptr(l2r), _ptr(r2l))
+    return Held(v, (left, right, l2r, r2l))
+
+
+def map_point_right_view(in_view_r, proj_xr, proj_yr, scale_level_r, view_cos_r):
+    a = [_arr(in_view_r, np.uint8), _arr(proj_xr, np.float32), _arr(proj_yr, np.float32), _arr(scale_level_r, np.int32), _arr(view_cos_r, np.float32)]
+    return Held(MapPointRightView(*[_ptr(x) for x in a]), a)

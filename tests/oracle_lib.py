@@ -386,3 +386,22 @@ def oracle_gray(src, red_first, variant):
     dst = np.zeros(src.shape[:2], np.uint8)
     L.orbo_prim_gray(src.ctypes.data, src.shape[1], src.shape[0], src.shape[2], int(red_first), int(variant), dst.ctypes.data)
     return dst
+
+
+def oracle_search_by_projection_mappoints_fisheye(frame2, mps, mps_r, th, bFar, thFar, nnratio):
+    L = oracle()
+    L.orbo_search_by_projection_mappoints_fisheye.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p]
+    N = frame2.view.left.N + frame2.view.right.N
+    a = np.full(max(N, 1), -1, np.int32)
+    n = L.orbo_search_by_projection_mappoints_fisheye(frame2.ref(), mps.ref(), mps_r.ref(), th, int(bFar), thFar, nnratio, a.ctypes.data)
+    return n, a[:N]
+
+
+def oracle_search_by_projection_frame_fisheye(cur2, last, proj_ur, proj_vr, th, fwd, bwd, check_ori):
+    L = oracle()
+    L.orbo_search_by_projection_frame_fisheye.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    N = cur2.view.left.N + cur2.view.right.N
+    ur = np.ascontiguousarray(proj_ur, np.float32); vr = np.ascontiguousarray(proj_vr, np.float32)
+    a = np.full(max(N, 1), -1, np.int32)
+    n = L.orbo_search_by_projection_frame_fisheye(cur2.ref(), last.ref(), ur.ctypes.data, vr.ctypes.data, th, int(fwd), int(bwd), int(check_ori), a.ctypes.data)
+    return n, a[:N]

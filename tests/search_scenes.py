@@ -110,3 +110,35 @@ def shifted_keyframe(k, d, scales, rng, w, h, shift=(6.0, -3.0)):
     k2["y"] = (k2["y"] + shift[1] + rng.uniform(-1, 1, len(perm))).astype(np.float32)
     d2 = flip_bits(d[perm], rng, 30)
     return views.frame_view(k2, d2, scales, w, h), k2, d2, perm
+
+
+def fisheye_rig(k, d, scales, rng, w, h, occupied_frac=0.1):
+    """A two-camera frame (Nleft != -1): camera 1 = (k, d); camera 2 sees the same scene shifted (shifted_keyframe).  About half of
+    the correspondences are known stereo matches (mvLeftToRightMatch / mvRightToLeftMatch), the rest -1."""
+    occL = (rng.random(len(k)) < occupied_frac).astype(np.uint8)
+    left = views.frame_view(k, d, scales, w, h, None, occL)
+    _, k2, d2, perm = shifted_keyframe(k, d, scales, rng, w, h, shift=(-9.0, 1.5))
+    occR = (rng.random(len(k2)) < occupied_frac).astype(np.uint8)
+    right = views.frame_view(k2, d2, scales, w, h, None, occR)
+    l2r = np.full(len(k), -1, np.int32); r2l = np.full(len(k2), -1, np.int32)
+    known = rng.random(len(k2)) < 0.5
+    for j in np.nonzero(known)[0]:
+        l2r[perm[j]] = j; r2l[j] = perm[j]
+    return views.fisheye_frame_view(left, right, l2r, r2l), k2, d2, perm
+
+
+def map_points_right_for(k2, d2, mps, scales, rng, w, h):
+    """The *R tracking fields for the map points of `mps`: projections near random right keypoints, some levels unset (-1)."""
+    M = mps.view.M; N2 = len(k2)
+    src = rng.integers(0, N2, M)
+    good = rng.random(M) < 0.6
+    pxr = np.where(good, k2["x"][src] + rng.uniform(-3, 3, M), rng.uniform(0, w, M)).astype(np.float32)
+    pyr = np.where(good, k2["y"][src] + rng.uniform(-3, 3, M), rng.uniform(0, h, M)).astype(np.float32)
+    lvl = np.clip(k2["octave"][src] + rng.integers(-1, 2, M), 0, len(scales) - 1).astype(np.int32)
+    lvl[rng.random(M) < 0.05] = -1
+    vc = np.where(rng.random(M) < 0.5, 0.9985, 0.99).astype(np.float32)
+    # descriptors of the points whose right projection is "good" should resemble the right keypoint: overwrite those rows of mps' descriptors
+    desc = mps.keep[9]
+    upd = good & (rng.random(M) < 0.5)
+    desc[upd] = flip_bits(d2[src[upd]], rng, 40)
+    return views.map_point_right_view(rng.random(M) < 0.7, pxr, pyr, lvl, vc)

@@ -108,6 +108,27 @@ def run_all(lib, w, h, nf, M_points, seeds):
             assert n1 == n2 and np.array_equal(m1, m2), th
             best = max(best, n2)
         assert best > 20
+        # two-camera (fisheye rig) branches of the two SearchByProjection overloads
+        rig, k2, d2, perm = sc.fisheye_rig(k, d, scales, rng, w, h)
+        mps_l = sc.map_points_for_frame(k, d, None, scales, M_points, rng, w, h)
+        mps_r = sc.map_points_right_for(k2, d2, mps_l, scales, rng, w, h)
+        best = 0
+        for (th, far, thfar, ratio) in [(3.0, False, 0.0, 0.8), (1.0, True, 20.0, 0.9), (5.0, False, 0.0, 0.6)]:
+            n1, a1 = M.ORBmatcher(ratio).SearchByProjectionFisheye(ex, rig, mps_l, mps_r, th, far, thfar)
+            n2, a2 = ol.oracle_search_by_projection_mappoints_fisheye(rig, mps_l, mps_r, th, far, thfar, ratio)
+            assert n1 == n2 and np.array_equal(a1, a2), (th, far, ratio)
+            best = max(best, n2)
+        assert best > M_points // 20 and (a2[len(k):] >= 0).sum() > 10 and (a2[:len(k)] >= 0).sum() > 10
+        last2 = sc.last_frame_for(k, d, scales, rng, w, h, 40.0)
+        pur = (last2.keep[1] - np.float32(9.0) + rng.uniform(-1, 1, len(k))).astype(np.float32)
+        pvr = (last2.keep[2] + np.float32(1.5) + rng.uniform(-1, 1, len(k))).astype(np.float32)
+        best = 0
+        for (th, fwd, bwd, ori) in [(7.0, False, False, True), (15.0, True, False, True), (7.0, False, True, False)]:
+            n1, a1 = M.ORBmatcher(0.9, ori).SearchByProjectionFrameFisheye(ex, rig, last2, pur, pvr, th, fwd, bwd)
+            n2, a2 = ol.oracle_search_by_projection_frame_fisheye(rig, last2, pur, pvr, th, fwd, bwd, ori)
+            assert n1 == n2 and np.array_equal(a1, a2), (th, fwd, bwd, ori)
+            best = max(best, n2)
+        assert best > 40 and (a2[len(k):] >= 0).sum() > 10
 
 
 def test_guided_searches_emulated(emu_lib):
