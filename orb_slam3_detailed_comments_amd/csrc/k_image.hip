@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
     const uint8_t* img = pyr + (size_t)b * pyr_stride + L.off;
     const unsigned Mw = (1u << 20) / (unsigned)wpd + 1u;    // i / wpd == (i * Mw) >> 20 exactly for i < 2^13
     for (int i = tid; i < wh * wpd; i += kFastThreads) {
-        const int r = (int)(((unsigned)i * Mw) >> 20), c = i - r * wpd;
+        const int r = (int)((unsigned)mul24(i, (int)Mw) >> 20), c = i - mul24(r, wpd);
         ((uint32_t*)tile)[i] = *(const uint32_t*)(img + (size_t)(ci.y0 - 3 + r) * L.pitch + gx0 + 4 * c);
     }
     for (int i = tid; i < (inner_bytes >> 2); i += kFastThreads) ((uint32_t*)sc)[i] = 0u;   // scores default to 0 (not a corner)
@@ -302,10 +302,11 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
             const int pA = list[i];
             const bool hasB = i + 1 < n;
             const int pB = hasB ? list[i + 1] : pA;
-            const int yA = (int)(((unsigned)pA * M) >> 20), xA = pA - yA * pitch;     // (y + 1, x + 1)
-            const int yB = (int)(((unsigned)pB * M) >> 20), xB = pB - yB * pitch;
-            const uint8_t* cA = tile + (yA + 2) * wp + xo + xA + 2;
-            const uint8_t* cB = tile + (yB + 2) * wp + xo + xB + 2;
+            // (24-bit multiplies: every operand here is far below 2^23 and the products below 2^31; v_mul_lo_u32 runs at quarter rate)
+            const int yA = (int)((unsigned)mul24(pA, (int)M) >> 20), xA = pA - mul24(yA, pitch);     // (y + 1, x + 1)
+            const int yB = (int)((unsigned)mul24(pB, (int)M) >> 20), xB = pB - mul24(yB, pitch);
+            const uint8_t* cA = tile + mul24(yA + 2, wp) + xo + xA + 2;
+            const uint8_t* cB = tile + mul24(yB + 2, wp) + xo + xB + 2;
             // (gathering the ring with 7 unaligned ds_read_b32/b64 per pixel instead of 17 byte reads was measured 67 % slower)
             const pk2 v2 = pk_make((uint32_t)cA[0] | ((uint32_t)cB[0] << 16));
             pk2 d[16];
@@ -340,7 +341,7 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
             if (it < iend) {
                 const int g = g0 + gi;
                 xbase = 4 * g - (xo + 3);                  // interior x of this lane's first pixel (may be < 0)
-                const uint32_t* rp = tile32 + (y + 3) * wpd + g;
+                const uint32_t* rp = tile32 + mul24(y + 3, wpd) + g;
                 uint32_t Lw[7], Cw[7], Rw[7];
 #pragma unroll
                 for (int r = 0; r < 7; r++) { const uint32_t* pr = rp + (r - 3) * wpd; Lw[r] = pr[-1]; Cw[r] = pr[0]; Rw[r] = pr[1]; }
@@ -377,7 +378,7 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
             if (cnt + trip > list_cap) break;                                               // wave-uniform
             int pos = cnt + incl - c4;
 #pragma unroll
-            for (int j = 0; j < 4; j++) if (mask & (1u << j)) list[pos++] = (uint16_t)((y + 1) * pitch + xbase + j + 1);
+            for (int j = 0; j < 4; j++) if (mask & (1u << j)) list[pos++] = (uint16_t)(mul24(y + 1, pitch) + xbase + j + 1);
             cnt += trip;
             gi += dr; y += dq;
             if (gi >= ng) { gi -= ng; y++; }
@@ -419,7 +420,7 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
             }
             const unsigned long long bal = __ballot(flag);
             if (flag) {
-                const int y1 = (int)(((unsigned)p * M) >> 20), x1 = p - y1 * pitch;       // (y + 1, x + 1)
+                const int y1 = (int)((unsigned)mul24(p, (int)M) >> 20), x1 = p - mul24(y1, pitch);       // (y + 1, x + 1)
                 out[base + __popcll(bal & lt)] = key_pack(ci.x0 + x1 - 1 - kBorder, ci.y0 + y1 - 1 - kBorder, s);
             }
             base += __popcll(bal);
@@ -431,8 +432,8 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
         const int npix = iw * ih;
         int any_hi = 0;
         for (int i = lane; i < npix; i += kFastThreads) {
-            const int y = (int)(((unsigned)i * Mi) >> 20), x = i - y * iw;
-            const int p = (y + 1) * pitch + x + 1;
+            const int y = (int)((unsigned)mul24(i, (int)Mi) >> 20), x = i - mul24(y, iw);
+            const int p = mul24(y + 1, pitch) + x + 1;
             const uint8_t* c = sc + p;
             const int s = c[0];
             const int m0 = imax(imax((int)c[-pitch - 1], (int)c[-pitch]), imax((int)c[-pitch + 1], (int)c[-1]));
@@ -447,8 +448,8 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
             const int i = i0 + lane;
             int flag = 0, x = 0, y = 0, s = 0;
             if (i < npix) {
-                y = (int)(((unsigned)i * Mi) >> 20); x = i - y * iw;
-                const int p = (y + 1) * pitch + x + 1;
+                y = (int)((unsigned)mul24(i, (int)Mi) >> 20); x = i - mul24(y, iw);
+                const int p = mul24(y + 1, pitch) + x + 1;
                 s = sc[p];
                 flag = kf[p] && s >= thr;
             }
