@@ -150,3 +150,39 @@ def test_degenerate_views(emu_lib):
     mps2 = sc.map_points_for_frame(k, d, None, scales, 100, rng, 376, 240)
     n, a = M.ORBmatcher(0.8).SearchByProjection(ex, empty, mps2, 3.0)
     assert n == 0 and len(a) == 0
+
+
+def concurrent_matchers(lib, w, h, nf, M_points):
+    """matcher calls from three threads (Tracking / LocalMapping / LoopClosing call ORBmatcher
+    concurrently on different objects): one handle per thread, results equal to the sequential oracle."""
+    import threading
+    scenes = []
+    for t in range(3):
+        rng = np.random.default_rng(100 + t)
+        img = synth.corner_field(w, h, seed=400 + t, nrect=int(3000 * w * h / (752 * 480)))
+        fv, k, d, u, scales = sc.frame_from_image(img, nf, rng)
+        mps = sc.map_points_for_frame(k, d, u, scales, M_points, rng, w, h)
+        last = sc.last_frame_for(k, d, scales, rng, w, h, 40.0)
+        exp = (ol.oracle_search_by_projection_mappoints(fv, mps, 3.0, False, 0.0, 0.8), ol.oracle_search_by_projection_frame(fv, last, 7.0, False, False, True))
+        scenes.append((fv, mps, last, exp))
+    errors = []
+
+    def work(t):
+        try:
+            ex = ORBextractor(500, 1.2, 8, 20, 7, lib=lib) if lib is not None else ORBextractor(500, 1.2, 8, 20, 7)
+            fv, mps, last, exp = scenes[t]
+            for _ in range(4):
+                n1, a1 = M.ORBmatcher(0.8).SearchByProjection(ex, fv, mps, 3.0)
+                n2, a2 = M.ORBmatcher(0.9, True).SearchByProjectionFrame(ex, fv, last, 7.0)
+                assert n1 == exp[0][0] and np.array_equal(a1, exp[0][1]) and n2 == exp[1][0] and np.array_equal(a2, exp[1][1])
+        except Exception as e:       # noqa: BLE001 - reported below
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(3)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errors, errors
+
+
+def test_matchers_from_three_threads_emulated(emu_lib):
+    concurrent_matchers(emu_lib, 376, 240, 400, 600)

@@ -19,3 +19,8 @@ def test_distinctive_descriptors_gpu(hip_lib):
     from test_emu_mappoint import run
     run(None, 5000, 60, 2)          # config-4 scale: ~5000 local map points
     run(None, 200, 400, 3)
+
+
+def test_matchers_from_three_threads_gpu(hip_lib):
+    from test_emu_search import concurrent_matchers
+    concurrent_matchers(None, 640, 480, 1000, 3000)
