@@ -61,3 +61,25 @@ def test_matcher_facade_emulated(tmp_path, emu_lib):
 @pytest.mark.gpu
 def test_matcher_facade_gpu(tmp_path, hip_lib):
     _run_matcher_facade(tmp_path, os.path.dirname(_lib.HIP_LIB_PATH), "orbx_hip")
+
+
+DBOW2 = "/root/reference/Thirdparty/DBoW2"
+
+
+@pytest.mark.skipif(not os.path.isdir(DBOW2), reason="needs the reference's DBoW2 sources (/root/reference)")
+def test_vocabulary_facade_emulated(tmp_path, emu_lib):
+    """include/orb_slam3_amd/ORBVocabulary.h vs the reference's DBoW2 in one binary: equal BowVector / FeatureVector objects."""
+    import vocab_scenes as vs
+    rng = np.random.default_rng(2)
+    header, parent, leaf, desc, weight = vs.make_vocabulary(rng, 10, 3)
+    voc = tmp_path / "voc.txt"
+    vs.write_text(voc, header, parent, leaf, desc, weight)
+    exe = tmp_path / "vocabulary_facade_test"
+    libdir = os.path.join(ROOT, "tests", "emu")
+    srcs = [os.path.join(DBOW2, "DBoW2", f) for f in ("FORB.cpp", "BowVector.cpp", "FeatureVector.cpp", "ScoringObject.cpp")] + [os.path.join(DBOW2, "DUtils", "Random.cpp"), os.path.join(DBOW2, "DUtils", "Timestamp.cpp")]
+    subprocess.run(["g++", "-std=c++14", "-O1", "-w", "-I" + os.path.join(ROOT, "include", "orb_slam3_amd"), "-I" + os.path.join(ROOT, "include"),
+                    "-I" + os.path.join(ROOT, "oracle", "opencv_shim"), "-I" + os.path.join(ROOT, "oracle", "boost_shim"), "-I" + DBOW2,
+                    os.path.join(ROOT, "tests", "cpp", "vocabulary_facade_test.cpp")] + srcs +
+                   ["-L" + libdir, "-lorbx_emu", "-Wl,-rpath," + libdir, "-lpthread", "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe), str(voc), "900"], capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
