@@ -10,8 +10,13 @@
 // PARITY STATUS: pinned against the reference's own extractor source for everything the reference
 // implements itself (tables, cell grid, threshold fallback, quadtree, IC-angle, steered BRIEF,
 // lapping reorder).  UNPINNED for the OpenCV primitives underneath (resize / FAST / GaussianBlur /
-// fastAtan2), because OpenCV is not vendored in the reference, not installed here, and the
-// reference ships no golden vectors.  Those live in orb_primitives.h.
+// fastAtan2 / remap / cvtColor), because OpenCV is not vendored in the reference, not installed here,
+// and the reference ships no golden vectors.  Those live in orb_primitives.h.
+// UNPINNED as well: the matcher-side restatements further down (ComputeStereoMatches, kNN + ratio, GetFeaturesInArea, every
+// SearchByProjection overload incl. the two-camera branches, SearchForTriangulation, SearchByBoW, SearchForInitialization,
+// SearchBySim3, the Fuse candidate search, ComputeDistinctiveDescriptors): src/Frame.cc, src/ORBmatcher.cc and src/MapPoint.cc
+// need Eigen / Sophus / Boost and cannot be compiled here.  PINNED separately: DescriptorDistance against the reference's
+// FORB::distance, and the vocabulary transform against the reference's own DBoW2 (oracle/ref_dbow2_driver.cpp).
 //
 // The extractor restatement deliberately uses the *derived* formulation the GPU kernels use
 // (SURVEY.md §8a row F2): one FAST score map at min(iniTh,minTh), cell-local strict 3x3 NMS, and a
