@@ -40,13 +40,18 @@ inline int check_launch() { return 0; }
 #else
 typedef hipStream_t stream_t;
 typedef hipEvent_t event_t;
-#define ORBX_HIP_OK(x) ((x) == hipSuccess ? 0 : -1)
+// A failed HIP call leaves a sticky per-thread "last error" in the runtime.  When the process shares that runtime with another
+// library (PyTorch in bench.py --gpus N), the other library's next hipGetLastError() check would trip over it, so every wrapper
+// consumes the error it has seen and keeps its own copy for last_error().
+inline hipError_t& last_code() { static thread_local hipError_t e = hipSuccess; return e; }
+inline int hip_ok(hipError_t e) { if (e == hipSuccess) return 0; last_code() = e; (void)hipGetLastError(); return -1; }
+#define ORBX_HIP_OK(x) ::orbx::rt::hip_ok(x)
 inline int set_device(int d) { return ORBX_HIP_OK(hipSetDevice(d)); }
-inline int device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
-inline void* dmalloc(size_t n) { void* p = nullptr; if (hipMalloc(&p, n ? n : 1) != hipSuccess) return nullptr; return p; }
-inline void dfree(void* p) { if (p) (void)hipFree(p); }
-inline void* hmalloc(size_t n) { void* p = nullptr; if (hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) != hipSuccess) return nullptr; return p; }
-inline void hfree(void* p) { if (p) (void)hipHostFree(p); }
+inline int device_count() { int n = 0; if (hip_ok(hipGetDeviceCount(&n))) return 0; return n; }
+inline void* dmalloc(size_t n) { void* p = nullptr; if (hip_ok(hipMalloc(&p, n ? n : 1))) return nullptr; return p; }
+inline void dfree(void* p) { if (p) (void)hip_ok(hipFree(p)); }
+inline void* hmalloc(size_t n) { void* p = nullptr; if (hip_ok(hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault))) return nullptr; return p; }
+inline void hfree(void* p) { if (p) (void)hip_ok(hipHostFree(p)); }
 inline int copy_h2d(void* d, const void* s, size_t n, stream_t st) { return ORBX_HIP_OK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st)); }
 inline int copy_d2h(void* d, const void* s, size_t n, stream_t st) { return ORBX_HIP_OK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, st)); }
 inline int copy_d2d(void* d, const void* s, size_t n, stream_t st) { return ORBX_HIP_OK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, st)); }
@@ -56,15 +61,15 @@ inline int copy2d(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t
 }
 inline int memset_async(void* d, int v, size_t n, stream_t st) { return ORBX_HIP_OK(hipMemsetAsync(d, v, n, st)); }
 inline int stream_create(stream_t* s) { return ORBX_HIP_OK(hipStreamCreateWithFlags(s, hipStreamNonBlocking)); }
-inline void stream_destroy(stream_t s) { (void)hipStreamDestroy(s); }
+inline void stream_destroy(stream_t s) { (void)hip_ok(hipStreamDestroy(s)); }
 inline int stream_sync(stream_t s) { return ORBX_HIP_OK(hipStreamSynchronize(s)); }
 inline int event_create(event_t* e) { return ORBX_HIP_OK(hipEventCreate(e)); }
-inline void event_destroy(event_t e) { (void)hipEventDestroy(e); }
+inline void event_destroy(event_t e) { (void)hip_ok(hipEventDestroy(e)); }
 inline int event_record(event_t e, stream_t s) { return ORBX_HIP_OK(hipEventRecord(e, s)); }
 inline int stream_wait_event(stream_t s, event_t e) { return ORBX_HIP_OK(hipStreamWaitEvent(s, e, 0)); }
 inline int event_sync(event_t e) { return ORBX_HIP_OK(hipEventSynchronize(e)); }
-inline float event_elapsed_ms(event_t a, event_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
-inline const char* last_error() { return hipGetErrorString(hipGetLastError()); }
+inline float event_elapsed_ms(event_t a, event_t b) { float ms = 0; if (hip_ok(hipEventElapsedTime(&ms, a, b))) ms = 0; return ms; }   // unrecorded events: 0
+inline const char* last_error() { hipError_t e = hipGetLastError(); if (e == hipSuccess) e = last_code(); return hipGetErrorString(e); }
 inline int check_launch() { return ORBX_HIP_OK(hipGetLastError()); }
 #endif
 
