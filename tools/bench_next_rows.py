@@ -1,0 +1,97 @@
+"""Measurement of the "next" rows of SURVEY.md §8f and the guided searches at BASELINE.json config-4 sizes: wall time of the device path
+(through the C ABI, host views in / results out, i.e. including uploads, the ordered host replay and downloads) next to the CPU
+oracle / reference on the same inputs.  Not the headline benchmark (bench.py); run by tools/gpu_round.sh, results go to profiles/."""
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as ol
+import search_scenes as sc
+import vocab_scenes as vs
+from orb_slam3_detailed_comments_amd import synth, ORBextractor
+from orb_slam3_detailed_comments_amd import matcher as M
+from orb_slam3_detailed_comments_amd.vocabulary import ORBVocabulary
+
+
+def best(fn, reps):
+    fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+    return min(ts) * 1e3
+
+
+def main():
+    out = {}
+    rng = np.random.default_rng(0)
+    w, h, nf, MP = 640, 480, 1000, 5000                       # BASELINE.json configs[3]: TUM RGB-D, 5000 local map points
+    ex = ORBextractor(nf, 1.2, 8, 20, 7)
+    img = synth.corner_field(w, h, seed=300, nrect=int(3000 * w * h / (752 * 480)))
+    fv, k, d, u, scales = sc.frame_from_image(img, nf, rng)
+    mps = sc.map_points_for_frame(k, d, u, scales, MP, rng, w, h)
+    last = sc.last_frame_for(k, d, scales, rng, w, h, 40.0)
+    pts = sc.projected_points(k, d, u, scales, rng, w, h, M=MP)
+    m = M.ORBmatcher(0.8)
+    rows = [
+        ("SearchByProjection(Frame, 5000 MapPoints)", lambda: m.SearchByProjection(ex, fv, mps, 3.0), lambda: ol.oracle_search_by_projection_mappoints(fv, mps, 3.0, False, 0.0, 0.8)),
+        ("SearchByProjection(Frame, LastFrame)", lambda: m.SearchByProjectionFrame(ex, fv, last, 7.0), lambda: ol.oracle_search_by_projection_frame(fv, last, 7.0, False, False, True)),
+        ("SearchByProjection(KeyFrame, Sim3, 5000 points)", lambda: m.SearchByProjectionSim3(ex, fv, pts, 8, 1.0), lambda: ol.oracle_search_by_projection_sim3(fv, pts, 8, 1.0)),
+        ("Fuse candidate search (5000 points, chi2 gate)", lambda: m.FuseCandidates(ex, fv, pts, 3.0, (1.0 / np.asarray(scales) ** 2).astype(np.float32)),
+         lambda: ol.oracle_fuse_candidates(fv, pts, 3.0, (1.0 / np.asarray(scales) ** 2).astype(np.float32))),
+    ]
+    (kf1, kf2), F12, ep = sc.keyframe_pair(rng, nf, w, h)
+    rows += [
+        ("SearchForTriangulation", lambda: M.ORBmatcher(0.6, False).SearchForTriangulation(ex, kf1[0], kf2[0], F12, ep), lambda: ol.oracle_search_for_triangulation(kf1[0], kf2[0], F12, ep, False, False, False)),
+        ("SearchByBoW(KeyFrame, Frame)", lambda: M.ORBmatcher(0.7, True).SearchByBoW(ex, kf1[0], kf2[0], True), lambda: ol.oracle_search_by_bow(kf1[0], kf2[0], 0.7, True, True)),
+    ]
+    # MapPoint::ComputeDistinctiveDescriptors for 5000 map points with ~20 observations each
+    counts = rng.integers(5, 40, MP); start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    dd = rng.integers(0, 256, (int(start[-1]), 32), dtype=np.uint8)
+    rows.append(("ComputeDistinctiveDescriptors (5000 map points, %d descriptors)" % len(dd), lambda: M.ComputeDistinctiveDescriptors(ex, dd, start), lambda: ol.oracle_distinctive_descriptors(dd, start)))
+    for name, gpu, cpu in rows:
+        out[name] = {"gpu_ms": round(best(gpu, 5), 3), "cpu_oracle_ms": round(best(cpu, 2), 3)}
+    # vocabulary transform: k=10, L=5 (111 110 nodes); 128 extracted EuRoC-size images, descriptors resident on the device
+    tmp = tempfile.mkdtemp()
+    header, parent, leaf, vdesc, weight = vs.make_vocabulary(rng, 10, 5)
+    path = os.path.join(tmp, "voc.txt"); vs.write_text(path, header, parent, leaf, vdesc, weight)
+    ex2 = ORBextractor(1200, 1.2, 8, 20, 7)
+    voc = ORBVocabulary.loadFromTextFile(ex2, path)
+    imgs = np.stack([synth.stereo_pair(752, 480, seed=100 + (i % 16))[0] for i in range(128)])
+    ex2.enqueue(imgs); res = ex2.fetch()
+
+    def gpu_voc():
+        voc.transform_extracted(ex2, 0, 128, 4); ex2.sync()
+    t_dev = best(gpu_voc, 5)
+    r = voc.fetch(ex2, 0, len(res[0][2]))
+    entry = {"gpu_ms_128_images_device_resident": round(t_dev, 3), "gpu_ms_per_image": round(t_dev / 128, 4), "nodes": int(len(parent))}
+    if ol.reference_dbow2() is not None:
+        ref = ol.RefVocabulary(path)
+        d0 = res[0][2]
+        entry["cpu_reference_dbow2_ms_per_image"] = round(best(lambda: ref.transform(d0, 4), 3), 3)
+        bi, bv, fn, fs, ff = ref.transform(d0, 4)
+        entry["parity_image0"] = bool(np.array_equal(r.bow_id, bi) and r.bow_val.tobytes() == bv.tobytes() and np.array_equal(r.fv_feat, ff))
+    out["ORBVocabulary::transform (k=10, L=5, 1213 features/image)"] = entry
+    # input pre-step: rectification of 128 EuRoC frames (inputs resident in HBM)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_emu_input import rectify_maps
+    mx, my = rectify_maps(752, 480, rng)
+    ex3 = ORBextractor(1200, 1.2, 8, 20, 7)
+    ex3.set_input(1, remap=(mx, my)); ex3.profile(True, serial=True)
+    dptr = ex3.device_upload(imgs)
+    def gpu_in():
+        ex3.enqueue(None, (0, 0), device_ptr=dptr, shape=imgs.shape); ex3.sync()
+    best(gpu_in, 3)
+    st = ex3.stage_ms()
+    out["cv::remap rectification, 128 x 752x480 (k_input_remap -> level 0)"] = {"gpu_ms": round(st["import"], 4), "GBps": round(128 * 752 * 480 * (1 + 8 + 1) / (st["import"] * 1e-3) / 1e9, 1),
+                                                                                 "cpu_oracle_ms_per_image": round(best(lambda: ol.oracle_remap(imgs[0], mx, my), 2), 2)}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
