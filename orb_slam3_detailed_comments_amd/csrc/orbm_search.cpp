@@ -28,17 +28,26 @@ int upload(orbx_extractor* h, int slot, const void* src, size_t bytes) {
     return rt::copy_h2d(h->d_sr[slot].p, src, bytes, h->s0);
 }
 
+// Per call the window searches move: frame (keypoints | descriptors | uRight) and queries (AreaQuery | descriptors) up, the candidate
+// lists down.  Each direction is ONE async copy between a pinned staging buffer and one device buffer (a call is latency-bound: with a
+// dozen small pageable copies the driver calls cost more than the kernels).
+inline size_t al16(size_t v) { return (v + 15) & ~(size_t)15; }
+
 int upload_frame(orbx_extractor* h, const OrbmFrameView* F, DeviceFrame* D) {
     if (!F || F->N < 0 || (F->N > 0 && (!F->keys_un || !F->desc))) return fail(ORBX_E_ARG, "bad frame view");
     if (F->N >= 65535) return fail(ORBX_E_ARG, "too many keypoints");
-    const int N = F->N;
-    std::vector<float> ur(N > 0 ? N : 1, -1.0f);
-    if (F->u_right) memcpy(ur.data(), F->u_right, sizeof(float) * N);
-    int e = upload(h, SR_KPS, F->keys_un, sizeof(KeyPointRec) * (size_t)N) | upload(h, SR_DESC, F->desc, 32 * (size_t)N) |
-            upload(h, SR_UR, ur.data(), sizeof(float) * (size_t)(N > 0 ? N : 1));
-    e |= h->d_si[SI_CELLOF].ensure(N + 1) | h->d_si[SI_CELLSTART].ensure(64 * 48 + 2) | h->d_si[SI_CELLITEMS].ensure(N + 1);
+    const int N = F->N, N1 = N > 0 ? N : 1;
+    const size_t okp = 0, odesc = al16(sizeof(KeyPointRec) * (size_t)N1), our = odesc + al16(32 * (size_t)N1), total = our + al16(sizeof(float) * (size_t)N1);
+    int e = h->h_packA.ensure(total + 16) | h->d_sr[SR_KPS].ensure(total + 16);
+    e |= h->d_si[SI_CELLOF].ensure(N + 1) | h->d_si[SI_CELLSTART].ensure(64 * 48 + 2) | h->d_si[SI_CELLITEMS].ensure(N + 1) | h->d_si[SI_COUNTER].ensure(4);
     if (e) return fail(ORBX_E_DEVICE, "upload/allocation failed");
-    D->kps = (const KeyPointRec*)h->d_sr[SR_KPS].p; D->desc = (const unsigned long long*)h->d_sr[SR_DESC].p; D->ur = (const float*)h->d_sr[SR_UR].p;
+    uint8_t* hp = h->h_packA.p;
+    if (N > 0) { memcpy(hp + okp, F->keys_un, sizeof(KeyPointRec) * (size_t)N); memcpy(hp + odesc, F->desc, 32 * (size_t)N); }
+    float* ur = (float*)(hp + our);
+    if (F->u_right) memcpy(ur, F->u_right, sizeof(float) * (size_t)N); else for (int i = 0; i < N1; i++) ur[i] = -1.0f;
+    if (rt::copy_h2d(h->d_sr[SR_KPS].p, hp, total, h->s0)) return fail(ORBX_E_DEVICE, "upload failed");
+    const uint8_t* dp = h->d_sr[SR_KPS].p;
+    D->kps = (const KeyPointRec*)(dp + okp); D->desc = (const unsigned long long*)(dp + odesc); D->ur = (const float*)(dp + our);
     memset(&D->g, 0, sizeof D->g);
     D->g.min_x = F->min_x; D->g.min_y = F->min_y; D->g.gw_inv = F->grid_w_inv; D->g.gh_inv = F->grid_h_inv;
     dim3 one(1, 1, 1), blk(256, 1, 1);
@@ -49,30 +58,45 @@ int upload_frame(orbx_extractor* h, const OrbmFrameView* F, DeviceFrame* D) {
 
 struct Csr { std::vector<int> start, count; std::vector<int> ent; };   // ent: 2 ints per candidate {idx, dist | octave << 16}
 
-// runs k_area_search for Q queries; grows the entry pool and retries once if it overflowed
+// runs k_area_search for Q queries.  Results come back in one copy: [total, -, -, -][start Q][count Q][entries]; the number of
+// entries fetched with the header is a guess from the previous call, a second copy follows only if it was too small, and the pool is
+// grown and the search repeated if the pool itself overflowed.
 int run_area_search(orbx_extractor* h, const DeviceFrame& D, const std::vector<AreaQuery>& qs, const uint8_t* qdesc, Csr* out) {
     const int Q = (int)qs.size();
     out->start.assign(Q, 0); out->count.assign(Q, 0); out->ent.clear();
     if (Q == 0) return ORBX_OK;
-    int e = upload(h, SR_QUERY, qs.data(), sizeof(AreaQuery) * (size_t)Q) | upload(h, SR_QDESC, qdesc, 32 * (size_t)Q);
-    e |= h->d_si[SI_QSTART].ensure(Q) | h->d_si[SI_QCOUNT].ensure(Q) | h->d_si[SI_COUNTER].ensure(4);
-    if (e) return fail(ORBX_E_DEVICE, "upload/allocation failed");
-    size_t pool = std::max<size_t>(h->d_sr[SR_ENTRIES].n / 8, (size_t)Q * 48 + 1024);
+    const size_t oq = 0, oqd = al16(sizeof(AreaQuery) * (size_t)Q), qtotal = oqd + al16(32 * (size_t)Q);
+    if (h->h_packB.ensure(qtotal + 16) || h->d_sr[SR_QUERY].ensure(qtotal + 16)) return fail(ORBX_E_DEVICE, "upload/allocation failed");
+    memcpy(h->h_packB.p + oq, qs.data(), sizeof(AreaQuery) * (size_t)Q); memcpy(h->h_packB.p + oqd, qdesc, 32 * (size_t)Q);
+    if (rt::copy_h2d(h->d_sr[SR_QUERY].p, h->h_packB.p, qtotal, h->s0)) return fail(ORBX_E_DEVICE, "upload failed");
+    const AreaQuery* dq = (const AreaQuery*)(h->d_sr[SR_QUERY].p + oq);
+    const unsigned long long* dqd = (const unsigned long long*)(h->d_sr[SR_QUERY].p + oqd);
+    const size_t hdr = 16 + 8 * (size_t)Q;                          // bytes in front of the entries
+    size_t pool = std::max<size_t>(h->area_pool, (size_t)Q * 48 + 1024);
     for (int attempt = 0; attempt < 2; attempt++) {
-        if (h->d_sr[SR_ENTRIES].ensure(pool * 8 + 16)) return fail(ORBX_E_DEVICE, "entry pool allocation failed");
-        rt::memset_async(h->d_si[SI_COUNTER].p, 0, sizeof(int) * 4, h->s0);
+        if (h->d_sr[SR_ENTRIES].ensure(hdr + pool * 8 + 16)) return fail(ORBX_E_DEVICE, "entry pool allocation failed");
+        h->area_pool = pool;
+        uint8_t* dout = h->d_sr[SR_ENTRIES].p;
+        int* d_counter = (int*)dout; int* d_start = (int*)(dout + 16); int* d_count = d_start + Q; int2* d_ent = (int2*)(dout + hdr);
+        rt::memset_async(d_counter, 0, 16, h->s0);
         dim3 grid((Q + 3) / 4, 1, 1), blk(256, 1, 1);
-        ORBX_LAUNCH(k_area_search, grid, blk, 0, h->s0, (const AreaQuery*)h->d_sr[SR_QUERY].p, (const unsigned long long*)h->d_sr[SR_QDESC].p, Q,
-                    D.kps, D.ur, D.desc, D.g, D.cell_start, D.cell_items, 1, h->d_si[SI_COUNTER].p, (int)pool,
-                    h->d_si[SI_QSTART].p, h->d_si[SI_QCOUNT].p, (int2*)h->d_sr[SR_ENTRIES].p);
-        int total = 0;
-        rt::copy_d2h(&total, h->d_si[SI_COUNTER].p, sizeof(int), h->s0);
-        rt::copy_d2h(out->start.data(), h->d_si[SI_QSTART].p, sizeof(int) * Q, h->s0);
-        rt::copy_d2h(out->count.data(), h->d_si[SI_QCOUNT].p, sizeof(int) * Q, h->s0);
+        ORBX_LAUNCH(k_area_search, grid, blk, 0, h->s0, dq, dqd, Q, D.kps, D.ur, D.desc, D.g, D.cell_start, D.cell_items, 1, d_counter, (int)pool,
+                    d_start, d_count, d_ent);
+        const size_t guess = std::min(pool, std::max<size_t>(h->area_last_total + h->area_last_total / 4 + 256, 1024));
+        if (h->h_out.ensure(hdr + pool * 8 + 16)) return fail(ORBX_E_DEVICE, "pinned allocation failed");
+        rt::copy_d2h(h->h_out.p, dout, hdr + guess * 8, h->s0);
         if (rt::stream_sync(h->s0) || rt::check_launch()) return fail(ORBX_E_DEVICE, "area search failed: %s", rt::last_error());
+        const int total = *(const int*)h->h_out.p;
         if ((size_t)total <= pool) {
+            if ((size_t)total > guess) {
+                rt::copy_d2h(h->h_out.p + hdr + guess * 8, dout + hdr + guess * 8, ((size_t)total - guess) * 8, h->s0);
+                if (rt::stream_sync(h->s0)) return fail(ORBX_E_DEVICE, "area search download failed: %s", rt::last_error());
+            }
+            h->area_last_total = (size_t)total;
+            memcpy(out->start.data(), h->h_out.p + 16, sizeof(int) * (size_t)Q);
+            memcpy(out->count.data(), h->h_out.p + 16 + sizeof(int) * (size_t)Q, sizeof(int) * (size_t)Q);
             out->ent.resize(2 * (size_t)total + 2);
-            if (total > 0) { rt::copy_d2h(out->ent.data(), h->d_sr[SR_ENTRIES].p, 8 * (size_t)total, h->s0); rt::stream_sync(h->s0); }
+            if (total > 0) memcpy(out->ent.data(), h->h_out.p + hdr, 8 * (size_t)total);
             return ORBX_OK;
         }
         pool = (size_t)total + 1024;

@@ -346,6 +346,7 @@ void orbx_destroy(orbx_extractor* h) {
     h->d_uRight.release(); h->d_depth.release(); h->d_sad.release(); h->d_nmatch.release(); h->d_knn.release(); h->d_ratio.release();
     h->d_hamA.release(); h->d_hamB.release(); h->d_hamOut.release(); h->h_stage.release(); h->h_nm.release();
     for (auto& x : h->d_sr) x.release();
+    h->h_packA.release(); h->h_packB.release(); h->h_out.release();
     for (auto& x : h->d_si) x.release();
     h->d_aux.release(); h->d_qtprof.release(); h->d_rowstart.release(); h->d_rowitems.release();
     h->d_mapx.release(); h->d_mapy.release(); h->d_in_xt.release(); h->d_in_yt.release(); h->d_frame.release();

@@ -76,6 +76,8 @@ struct orbx_extractor {
     float stage_ms[ORBX_NSTAGES];
     // scratch of the projection / BoW searches (orbm_search.cpp)
     orbx::DevBuf<uint8_t> d_sr[12];
+    orbx::HostBuf<uint8_t> h_packA, h_packB, h_out;      // pinned staging of the window searches (frame, queries, results)
+    size_t area_pool = 0, area_last_total = 0;
     orbx::DevBuf<int> d_si[8];
     orbx::DevBuf<long long> d_qtprof;
     // hipGraph replay of the extraction pipeline (orbx_set_graph_replay)
