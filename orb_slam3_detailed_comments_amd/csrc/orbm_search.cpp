@@ -33,6 +33,19 @@ int upload(orbx_extractor* h, int slot, const void* src, size_t bytes) {
 // dozen small pageable copies the driver calls cost more than the kernels).
 inline size_t al16(size_t v) { return (v + 15) & ~(size_t)15; }
 
+// several host arrays -> one pinned staging buffer -> one async copy into d_sr[SR_KPS]; add() returns the device address
+struct Packer {
+    orbx_extractor* h; std::vector<std::pair<const void*, size_t>> parts; std::vector<size_t> offs; size_t total = 0;
+    explicit Packer(orbx_extractor* hh) : h(hh) {}
+    size_t add(const void* src, size_t bytes) { offs.push_back(total); parts.emplace_back(src, bytes); total += al16(bytes ? bytes : 1); return offs.size() - 1; }
+    int flush() {
+        if (h->h_packA.ensure(total + 16) || h->d_sr[SR_KPS].ensure(total + 16)) return -1;
+        for (size_t i = 0; i < parts.size(); i++) if (parts[i].second) memcpy(h->h_packA.p + offs[i], parts[i].first, parts[i].second);
+        return rt::copy_h2d(h->d_sr[SR_KPS].p, h->h_packA.p, total, h->s0);
+    }
+    template <typename T> const T* dev(size_t part) const { return (const T*)(h->d_sr[SR_KPS].p + offs[part]); }
+};
+
 int upload_frame(orbx_extractor* h, const OrbmFrameView* F, DeviceFrame* D) {
     if (!F || F->N < 0 || (F->N > 0 && (!F->keys_un || !F->desc))) return fail(ORBX_E_ARG, "bad frame view");
     if (F->N >= 65535) return fail(ORBX_E_ARG, "too many keypoints");
@@ -307,23 +320,21 @@ int orbm_search_for_triangulation(orbx_extractor* h, const OrbmKeyFrameView* K1,
         std::vector<uint8_t> mp2(N2 > 0 ? N2 : 1, 0);
         if (K2->has_map_point) memcpy(mp2.data(), K2->has_map_point, N2);
         const int nfeat2 = K2->fv_start[K2->fv_nodes];
-        int e = upload(h, SR_KPS, K1->keys_un, sizeof(KeyPointRec) * (size_t)N1) | upload(h, SR_DESC, K1->desc, 32 * (size_t)N1) |
-                upload(h, SR_UR, ur1.data(), sizeof(float) * ur1.size()) | upload(h, SR_KPS2, K2->keys_un, sizeof(KeyPointRec) * (size_t)N2) |
-                upload(h, SR_DESC2, K2->desc, 32 * (size_t)N2) | upload(h, SR_UR2, ur2.data(), sizeof(float) * ur2.size()) |
-                upload(h, SR_HASMP2, mp2.data(), mp2.size()) | upload(h, SR_ITEMS, items.data(), sizeof(BowItem) * items.size());
-        e |= h->d_si[SI_FEAT2].ensure(nfeat2 + 1) | h->d_si[SI_BEST].ensure(items.size());
-        if (e) return fail(ORBX_E_DEVICE, "upload/allocation failed");
-        rt::copy_h2d(h->d_si[SI_FEAT2].p, K2->fv_feat, sizeof(int) * (size_t)nfeat2, h->s0);
+        Packer pk(h);
+        const size_t pk1 = pk.add(K1->keys_un, sizeof(KeyPointRec) * (size_t)N1), pd1 = pk.add(K1->desc, 32 * (size_t)N1), pu1 = pk.add(ur1.data(), sizeof(float) * ur1.size()),
+                     pk2 = pk.add(K2->keys_un, sizeof(KeyPointRec) * (size_t)N2), pd2 = pk.add(K2->desc, 32 * (size_t)N2), pu2 = pk.add(ur2.data(), sizeof(float) * ur2.size()),
+                     pm2 = pk.add(mp2.data(), mp2.size()), pit = pk.add(items.data(), sizeof(BowItem) * items.size()), pf2 = pk.add(K2->fv_feat, sizeof(int) * (size_t)nfeat2);
+        if (pk.flush() || h->d_si[SI_BEST].ensure(items.size())) return fail(ORBX_E_DEVICE, "upload/allocation failed");
         BowParams P; memset(&P, 0, sizeof P);
         for (int i = 0; i < 9; i++) P.F12[i] = F12[i];
         P.ep[0] = ep[0]; P.ep[1] = ep[1];
         for (int l = 0; l < K2->nlevels; l++) { P.scale2[l] = K2->scale_factors[l]; P.sigma2_2[l] = K2->level_sigma2[l]; }
         P.only_stereo = only_stereo; P.coarse = coarse; P.th_low = TH_LOW;
         dim3 grid(((int)items.size() + 3) / 4, 1, 1), blk(256, 1, 1);
-        ORBX_LAUNCH(k_bow_search, grid, blk, 0, h->s0, (const BowItem*)h->d_sr[SR_ITEMS].p, (int)items.size(),
-                    (const KeyPointRec*)h->d_sr[SR_KPS].p, (const unsigned long long*)h->d_sr[SR_DESC].p, (const float*)h->d_sr[SR_UR].p,
-                    (const KeyPointRec*)h->d_sr[SR_KPS2].p, (const unsigned long long*)h->d_sr[SR_DESC2].p, (const float*)h->d_sr[SR_UR2].p,
-                    (const uint8_t*)h->d_sr[SR_HASMP2].p, (const int*)h->d_si[SI_FEAT2].p, P, h->d_si[SI_BEST].p);
+        ORBX_LAUNCH(k_bow_search, grid, blk, 0, h->s0, pk.dev<BowItem>(pit), (int)items.size(),
+                    pk.dev<KeyPointRec>(pk1), pk.dev<unsigned long long>(pd1), pk.dev<float>(pu1),
+                    pk.dev<KeyPointRec>(pk2), pk.dev<unsigned long long>(pd2), pk.dev<float>(pu2),
+                    pk.dev<uint8_t>(pm2), pk.dev<int>(pf2), P, h->d_si[SI_BEST].p);
         std::vector<int> best(items.size());
         if (rt::copy_d2h(best.data(), h->d_si[SI_BEST].p, sizeof(int) * items.size(), h->s0) || rt::stream_sync(h->s0) || rt::check_launch())
             return fail(ORBX_E_DEVICE, "bow search failed: %s", rt::last_error());
@@ -378,15 +389,13 @@ int orbm_search_by_bow(orbx_extractor* h, const OrbmKeyFrameView* K1, const Orbm
         std::vector<uint8_t> elig(N2 > 0 ? N2 : 1, 1);
         if (K2->has_map_point) memcpy(elig.data(), K2->has_map_point, N2);
         const int nfeat2 = K2->fv_start[K2->fv_nodes];
-        int e = upload(h, SR_DESC, K1->desc, 32 * (size_t)N1) | upload(h, SR_DESC2, K2->desc, 32 * (size_t)N2) |
-                upload(h, SR_HASMP2, elig.data(), elig.size()) | upload(h, SR_ITEMS, items.data(), sizeof(BowItem) * items.size());
-        e |= h->d_si[SI_FEAT2].ensure(nfeat2 + 1) | h->d_si[SI_BEST].ensure((size_t)total + 1);
-        if (e) return fail(ORBX_E_DEVICE, "upload/allocation failed");
-        rt::copy_h2d(h->d_si[SI_FEAT2].p, K2->fv_feat, sizeof(int) * (size_t)nfeat2, h->s0);
+        Packer pk(h);
+        const size_t pd1 = pk.add(K1->desc, 32 * (size_t)N1), pd2 = pk.add(K2->desc, 32 * (size_t)N2), pel = pk.add(elig.data(), elig.size()),
+                     pit = pk.add(items.data(), sizeof(BowItem) * items.size()), pf2 = pk.add(K2->fv_feat, sizeof(int) * (size_t)nfeat2);
+        if (pk.flush() || h->d_si[SI_BEST].ensure((size_t)total + 1)) return fail(ORBX_E_DEVICE, "upload/allocation failed");
         dim3 grid(((int)items.size() + 3) / 4, 1, 1), blk(256, 1, 1);
-        ORBX_LAUNCH(k_bow_dists, grid, blk, 0, h->s0, (const BowItem*)h->d_sr[SR_ITEMS].p, (int)items.size(),
-                    (const unsigned long long*)h->d_sr[SR_DESC].p, (const unsigned long long*)h->d_sr[SR_DESC2].p,
-                    (const uint8_t*)h->d_sr[SR_HASMP2].p, (const int*)h->d_si[SI_FEAT2].p, h->d_si[SI_BEST].p);
+        ORBX_LAUNCH(k_bow_dists, grid, blk, 0, h->s0, pk.dev<BowItem>(pit), (int)items.size(), pk.dev<unsigned long long>(pd1), pk.dev<unsigned long long>(pd2),
+                    pk.dev<uint8_t>(pel), pk.dev<int>(pf2), h->d_si[SI_BEST].p);
         std::vector<int> dist((size_t)total);
         if (rt::copy_d2h(dist.data(), h->d_si[SI_BEST].p, sizeof(int) * (size_t)total, h->s0) || rt::stream_sync(h->s0) || rt::check_launch())
             return fail(ORBX_E_DEVICE, "bow distances failed: %s", rt::last_error());
