@@ -85,3 +85,17 @@ def test_grey_weights_sum_and_remap_table_quirk():
     for q in (0, 1, 127, 255):
         assert np.array_equal((p * 32767 + q + 16384) >> 15, (p * 32768 + 16384) >> 15)
     assert 9798 + 19235 + 3735 == 1 << 15 and 4899 + 9617 + 1868 == 1 << 14
+
+
+def test_input_error_paths(emu_lib):
+    from orb_slam3_detailed_comments_amd._lib import OrbxError
+    ex = ORBextractor(300, 1.2, 8, 20, 7, lib=emu_lib)
+    with pytest.raises(OrbxError):
+        ex.set_input(2)                                               # 2-channel frames do not exist in the reference's pipeline
+    ex.set_input(3)
+    img = synth.corner_field(376, 240, seed=1, nrect=800)
+    with pytest.raises(OrbxError):                                    # stride < width * channels
+        ex._lib.check(ex._lib.L.orbx_extract_batch(ex._h, 1, img.ctypes.data, 376, 240, 376, 376 * 240, 0, 0, 0))
+    ex.set_input(None)
+    mono, k, d = ex(img, None, (0, 0))
+    assert len(k) > 100
