@@ -150,6 +150,7 @@ __device__ __forceinline__ int mul24(int a, int b) {
 struct pk2 { short x, y; };
 __device__ __forceinline__ pk2 pk_make(uint32_t v) { pk2 r; r.x = (short)(v & 0xFFFF); r.y = (short)(v >> 16); return r; }
 __device__ __forceinline__ pk2 pk_sub(pk2 a, pk2 b) { pk2 r; r.x = (short)(a.x - b.x); r.y = (short)(a.y - b.y); return r; }
+__device__ __forceinline__ pk2 pk_mad(pk2 a, pk2 b, pk2 c) { pk2 r; r.x = (short)(a.x * b.x + c.x); r.y = (short)(a.y * b.y + c.y); return r; }
 __device__ __forceinline__ pk2 pk_min(pk2 a, pk2 b) { pk2 r; r.x = a.x < b.x ? a.x : b.x; r.y = a.y < b.y ? a.y : b.y; return r; }
 __device__ __forceinline__ pk2 pk_max(pk2 a, pk2 b) { pk2 r; r.x = a.x > b.x ? a.x : b.x; r.y = a.y > b.y ? a.y : b.y; return r; }
 __device__ __forceinline__ int pk_lo(pk2 a) { return a.x; }
@@ -158,6 +159,7 @@ __device__ __forceinline__ int pk_hi(pk2 a) { return a.y; }
 typedef short pk2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ pk2 pk_make(uint32_t v) { return __builtin_bit_cast(pk2, v); }
 __device__ __forceinline__ pk2 pk_sub(pk2 a, pk2 b) { return a - b; }
+__device__ __forceinline__ pk2 pk_mad(pk2 a, pk2 b, pk2 c) { return a * b + c; }      // v_pk_mad_i16
 __device__ __forceinline__ pk2 pk_min(pk2 a, pk2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ pk2 pk_max(pk2 a, pk2 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ int pk_lo(pk2 a) { return (int)a.x; }
@@ -234,8 +236,27 @@ __device__ __forceinline__ void fast_full_pk(const pk2 d[16], int t0, int& sA, i
     sB = mB > t0 ? mB - 1 : 0;
 }
 
+// one-sided variant: d[k] = sign * (v - ring_k) with sign = +1 for a dark candidate and -1 for a bright one, so that both become
+// "max over the 16 nine-arcs of the arc minimum"
+__device__ __forceinline__ void fast_score_pk(const pk2 d[16], int t0, int& sA, int& sB) {
+    pk2 mn2[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) mn2[k] = pk_min(d[k], d[(k + 1) & 15]);
+    pk2 mn4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) mn4[k] = pk_min(mn2[k], mn2[(k + 2) & 15]);
+    pk2 Md = pk_min(pk_min(mn4[0], mn4[4]), d[8]);
+#pragma unroll
+    for (int k = 1; k < 16; k++) Md = pk_max(Md, pk_min(pk_min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]));
+    const int mA = pk_lo(Md), mB = pk_hi(Md);
+    sA = mA > t0 ? mA - 1 : 0;
+    sB = mB > t0 ? mB - 1 : 0;
+}
+
 constexpr int kFastWaves = 1;                       // waves per FAST workgroup (one cell per workgroup)
 constexpr int kFastThreads = 64 * kFastWaves;
+// survivor-list entry: score-tile index (13 bits) | bright-candidate flag | "second entry of the same pixel" flag | NMS-keep flag
+constexpr int kListPos = 0x1FFF, kListBright = 0x2000, kListDup = 0x4000;
 
 __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __restrict__ lv,
                                                     const CellInfo* __restrict__ cells, int ncells,
@@ -299,27 +320,33 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
     // ---- B ----  full score of list[0, n), two listed pixels per lane (packed lanes)
     auto score_listed = [&](int n) {
         for (int i = 2 * lane; i < n; i += 2 * kFastThreads) {
-            const int pA = list[i];
+            const int eA = list[i];
             const bool hasB = i + 1 < n;
-            const int pB = hasB ? list[i + 1] : pA;
+            const int eB = hasB ? list[i + 1] : eA;
+            const int pA = eA & kListPos, pB = eB & kListPos;
+            // polarity of the entry: +1 dark (v - ring), -1 bright (ring - v)
+            const int sgA = (eA & kListBright) ? -1 : 1, sgB = (eB & kListBright) ? -1 : 1;
             // (24-bit multiplies: every operand here is far below 2^23 and the products below 2^31; v_mul_lo_u32 runs at quarter rate)
             const int yA = (int)((unsigned)mul24(pA, (int)M) >> 20), xA = pA - mul24(yA, pitch);     // (y + 1, x + 1)
             const int yB = (int)((unsigned)mul24(pB, (int)M) >> 20), xB = pB - mul24(yB, pitch);
             const uint8_t* cA = tile + mul24(yA + 2, wp) + xo + xA + 2;
             const uint8_t* cB = tile + mul24(yB + 2, wp) + xo + xB + 2;
             // (gathering the ring with 7 unaligned ds_read_b32/b64 per pixel instead of 17 byte reads was measured 67 % slower)
-            const pk2 v2 = pk_make((uint32_t)cA[0] | ((uint32_t)cB[0] << 16));
+            const pk2 c2 = pk_make((uint32_t)((sgA * (int)cA[0]) & 0xFFFF) | ((uint32_t)(sgB * (int)cB[0]) << 16));    // sign * v
+            const pk2 ns2 = pk_make((uint32_t)((-sgA) & 0xFFFF) | ((uint32_t)(-sgB) << 16));                            // -sign
             pk2 d[16];
-#define ORBX_D(k, off) d[k] = pk_sub(v2, pk_make((uint32_t)cA[off] | ((uint32_t)cB[off] << 16)));
+#define ORBX_D(k, off) d[k] = pk_mad(pk_make((uint32_t)cA[off] | ((uint32_t)cB[off] << 16)), ns2, c2);
             ORBX_D(0, 3 * wp)       ORBX_D(1, 3 * wp + 1)    ORBX_D(2, 2 * wp + 2)    ORBX_D(3, wp + 3)
             ORBX_D(4, 3)            ORBX_D(5, -wp + 3)       ORBX_D(6, -2 * wp + 2)   ORBX_D(7, -3 * wp + 1)
             ORBX_D(8, -3 * wp)      ORBX_D(9, -3 * wp - 1)   ORBX_D(10, -2 * wp - 2)  ORBX_D(11, -wp - 3)
             ORBX_D(12, -3)          ORBX_D(13, wp - 3)       ORBX_D(14, 2 * wp - 2)   ORBX_D(15, 3 * wp - 1)
 #undef ORBX_D
             int sA, sB;
-            fast_full_pk(d, t0, sA, sB);
-            sc[pA] = (uint8_t)sA;
-            if (hasB) sc[pB] = (uint8_t)sB;
+            fast_score_pk(d, t0, sA, sB);
+            // a pixel that passed the quick test for both polarities has two entries; it can be a corner for at most one of them
+            // (two 9-arcs of opposite sign do not fit on 16 ring pixels), so only a positive score is written
+            if (sA > 0) sc[pA] = (uint8_t)sA;
+            if (hasB && sB > 0) sc[pB] = (uint8_t)sB;
         }
         ORBX_WAVE_SYNC();
     };
@@ -365,20 +392,25 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
                 }
                 const pk2 vlo = pk_make(byte_perm(0u, Cw[3], 0x0c010c00u)), vhi = pk_make(byte_perm(0u, Cw[3], 0x0c030c02u));
                 const pk2 dk_lo = pk_sub(vlo, M_lo), dk_hi = pk_sub(vhi, M_hi), br_lo = pk_sub(N_lo, vlo), br_hi = pk_sub(N_hi, vhi);
-                const pk2 best_lo = pk_max(dk_lo, br_lo), best_hi = pk_max(dk_hi, br_hi);
-                const unsigned pass = (unsigned)(pk_lo(best_lo) > t0) | ((unsigned)(pk_hi(best_lo) > t0) << 1) |
-                                      ((unsigned)(pk_lo(best_hi) > t0) << 2) | ((unsigned)(pk_hi(best_hi) > t0) << 3);
+                const unsigned passD = (unsigned)(pk_lo(dk_lo) > t0) | ((unsigned)(pk_hi(dk_lo) > t0) << 1) |
+                                       ((unsigned)(pk_lo(dk_hi) > t0) << 2) | ((unsigned)(pk_hi(dk_hi) > t0) << 3);
+                const unsigned passB = (unsigned)(pk_lo(br_lo) > t0) | ((unsigned)(pk_hi(br_lo) > t0) << 1) |
+                                       ((unsigned)(pk_lo(br_hi) > t0) << 2) | ((unsigned)(pk_hi(br_hi) > t0) << 3);
                 const int lo = imax(0, -xbase), hi = imin(4, iw - xbase);          // valid pixels j in [lo, hi)
                 const unsigned valid = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
-                mask = pass & valid;
+                mask = (passD & valid) | ((passB & valid) << 4);                   // bits 0-3 dark candidates, 4-7 bright candidates
             }
             const int c4 = __popc(mask);
             const int incl = wave_incl_scan(c4);
             const int trip = ORBX_READLANE(incl, 63);
-            if (cnt + trip > list_cap) break;                                               // wave-uniform
+            if (cnt > 0 && cnt + trip > list_cap) break;                                    // wave-uniform (a trip adds <= 512 entries <= list_cap)
             int pos = cnt + incl - c4;
 #pragma unroll
-            for (int j = 0; j < 4; j++) if (mask & (1u << j)) list[pos++] = (uint16_t)(mul24(y + 1, pitch) + xbase + j + 1);
+            for (int j = 0; j < 4; j++) {
+                const int pj = mul24(y + 1, pitch) + xbase + j + 1;
+                if (mask & (1u << j)) list[pos++] = (uint16_t)pj;
+                if (mask & (16u << j)) list[pos++] = (uint16_t)(pj | kListBright | ((mask & (1u << j)) ? kListDup : 0));
+            }
             cnt += trip;
             gi += dr; y += dq;
             if (gi >= ng) { gi -= ng; y++; }
@@ -396,14 +428,15 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
         // ---- C ----  cell-local strict 3x3 NMS on the listed pixels
         int any_hi = 0;
         for (int i = lane; i < total; i += kFastThreads) {
-            const int p = list[i];
+            const int e = list[i];
+            const int p = e & kListPos;
             const uint8_t* c = sc + p;
-            const int s = c[0];
+            const int s = (e & kListDup) ? 0 : c[0];          // the second entry of a two-polarity pixel is not a second pixel
             // neighbours outside the cell interior are the zero frame; s == 0 (not a corner) fails every strict comparison
             const int m0 = imax(imax((int)c[-pitch - 1], (int)c[-pitch]), imax((int)c[-pitch + 1], (int)c[-1]));
             const int m1 = imax(imax((int)c[1], (int)c[pitch - 1]), imax((int)c[pitch], (int)c[pitch + 1]));
             const int keep = s > imax(m0, m1);
-            if (keep) list[i] = (uint16_t)(p | 0x8000);
+            if (keep) list[i] = (uint16_t)(e | 0x8000);
             any_hi |= (keep && s >= iniTh);
         }
         ORBX_WAVE_SYNC();
@@ -414,7 +447,7 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
             int flag = 0, p = 0, s = 0;
             if (i < total) {
                 const int e = list[i];
-                p = e & 0x7FFF;
+                p = e & kListPos;
                 s = sc[p];
                 flag = (e >> 15) && s >= thr;
             }

@@ -32,10 +32,10 @@ def test_quadtree_path_mix(tmp_path, presort_max, bigspan):
 
 def test_fast_list_flush_path(tmp_path):
     """k_fast_cells keeps survivors of the quick test in a list sized for half of a cell's pixels and flushes it when a denser cell
-    would overflow; with a 300-entry list nearly every cell of a textured image takes that path (and its list-free NMS / compaction)."""
+    would overflow; with a 520-entry list nearly every cell of a textured image takes that path (and its list-free NMS / compaction)."""
     so = str(tmp_path / "liborbx_emu_smalllist.so")
     srcs = [os.path.join(CSRC, f) for f in ("k_image.hip", "k_quadtree.hip", "k_describe.hip", "k_match.hip", "k_search.hip", "k_vocab.hip", "k_input.hip", "orbx_api.cpp", "orbm_search.cpp", "orbv_api.cpp")]
-    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-DORBX_EMU", "-DORBX_FAST_LIST_CAP=300",
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-DORBX_EMU", "-DORBX_FAST_LIST_CAP=520",
                     "-I" + os.path.join(ROOT, "tests", "emu"), "-I" + CSRC, "-fPIC", "-shared", "-w", "-x", "c++"] + srcs + ["-o", so, "-lpthread"], check=True)
     lib = _lib.OrbxLib(so)
     for name, factory, nf, lap in SMALL_CASES[:3] + FULL_CASES[:1] + FULL_CASES[4:5]:
