@@ -57,9 +57,24 @@ __global__ void __launch_bounds__(256) k_resize(const LevelInfo* __restrict__ lv
     const int sy_lo = imin(imax(yt[imin(dyb, D.h - 1)].ofs, 0), S.h - 1);
     const int sy_hi = imin(imax(yt[dy_last].ofs + 1, 0), S.h - 1);
     const int nrow = imin(sy_hi - sy_lo + 1, lds_rows);
-    for (int i = tid; i < nrow * ncd; i += 256) {
-        const int r = i / ncd, c = i - r * ncd;
-        *(uint32_t*)(smem + r * lds_pitch + 4 * c) = *(const uint32_t*)(src + (size_t)(sy_lo + r) * S.pitch + gx0 + 4 * c);
+    {   // the window is a few dwords per thread: all of a thread's global loads are issued before the first LDS store
+        const int n = nrow * ncd;
+        const unsigned Mc = (1u << 20) / (unsigned)ncd + 1u;     // i / ncd == (i * Mc) >> 20 exactly for i < 2^13
+        for (int i0 = tid; i0 < n; i0 += 1024) {
+            uint32_t v[4]; int o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = i0 + 256 * k;
+                o[k] = -1;
+                if (i < n) {
+                    const int r = (int)(((unsigned)i * Mc) >> 20), c = i - r * ncd;
+                    o[k] = r * lds_pitch + 4 * c;
+                    v[k] = *(const uint32_t*)(src + (size_t)(sy_lo + r) * S.pitch + gx0 + 4 * c);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (o[k] >= 0) *(uint32_t*)(smem + o[k]) = v[k];
+        }
     }
     __syncthreads();
     const int dx0 = dxb + (int)threadIdx.x * 4;
