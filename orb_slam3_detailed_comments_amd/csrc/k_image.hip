@@ -57,6 +57,13 @@ __global__ void __launch_bounds__(256) k_resize(const LevelInfo* __restrict__ lv
     const int sy_lo = imin(imax(yt[imin(dyb, D.h - 1)].ofs, 0), S.h - 1);
     const int sy_hi = imin(imax(yt[dy_last].ofs + 1, 0), S.h - 1);
     const int nrow = imin(sy_hi - sy_lo + 1, lds_rows);
+    // this thread's interpolation taps (4 columns, 2 rows): loaded up front so that their latency overlaps the window loads
+    const int dx0 = dxb + (int)threadIdx.x * 4;
+    ResizeTap txs[4], tys[2];
+#pragma unroll
+    for (int k = 0; k < 4; k++) txs[k] = xt[imin(dx0 + k, D.w - 1)];
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) tys[rr] = yt[imin(dyb + (int)threadIdx.y + 4 * rr, D.h - 1)];
     {   // the window is a few dwords per thread: all of a thread's global loads are issued before the first LDS store
         const int n = nrow * ncd;
         const unsigned Mc = (1u << 20) / (unsigned)ncd + 1u;     // i / ncd == (i * Mc) >> 20 exactly for i < 2^13
@@ -77,13 +84,11 @@ __global__ void __launch_bounds__(256) k_resize(const LevelInfo* __restrict__ lv
         }
     }
     __syncthreads();
-    const int dx0 = dxb + (int)threadIdx.x * 4;
     if (dx0 >= D.pitch) return;
     int sxo[4], sxo1[4], a0[4], a1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int dx = imin(dx0 + k, D.w - 1);
-        const ResizeTap tx = xt[dx];
+        const ResizeTap tx = txs[k];
         sxo[k] = tx.ofs - gx0; sxo1[k] = imin(tx.ofs + 1, S.w - 1) - gx0;
         a0[k] = (int)(int16_t)(tx.w & 0xFFFF); a1[k] = tx.w >> 16;
     }
@@ -91,7 +96,7 @@ __global__ void __launch_bounds__(256) k_resize(const LevelInfo* __restrict__ lv
     for (int rr = 0; rr < 2; rr++) {
         const int dy = dyb + (int)threadIdx.y + 4 * rr;
         if (dy >= D.h) break;
-        const ResizeTap ty = yt[dy];
+        const ResizeTap ty = tys[rr];
         const int r0 = imin(imax(ty.ofs, 0), S.h - 1) - sy_lo, r1 = imin(imax(ty.ofs + 1, 0), S.h - 1) - sy_lo;
         const int b0 = (int)(int16_t)(ty.w & 0xFFFF), b1 = ty.w >> 16;
         const uint8_t* S0 = smem + r0 * lds_pitch;
