@@ -315,9 +315,18 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
 #endif
     const uint8_t* img = pyr + (size_t)b * pyr_stride + L.off;
     const unsigned Mw = (1u << 20) / (unsigned)wpd + 1u;    // i / wpd == (i * Mw) >> 20 exactly for i < 2^13
-    for (int i = tid; i < wh * wpd; i += kFastThreads) {
-        const int r = (int)((unsigned)mul24(i, (int)Mw) >> 20), c = i - mul24(r, wpd);
-        ((uint32_t*)tile)[i] = *(const uint32_t*)(img + (size_t)(ci.y0 - 3 + r) * L.pitch + gx0 + 4 * c);
+    for (int i0 = tid; i0 < wh * wpd; i0 += 4 * kFastThreads) {          // four loads in flight per lane before the first LDS store
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = i0 + k * kFastThreads;
+            if (i < wh * wpd) {
+                const int r = (int)((unsigned)mul24(i, (int)Mw) >> 20), c = i - mul24(r, wpd);
+                v[k] = *(const uint32_t*)(img + (size_t)(ci.y0 - 3 + r) * L.pitch + gx0 + 4 * c);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int i = i0 + k * kFastThreads; if (i < wh * wpd) ((uint32_t*)tile)[i] = v[k]; }
     }
     for (int i = tid; i < (inner_bytes >> 2); i += kFastThreads) ((uint32_t*)sc)[i] = 0u;   // scores default to 0 (not a corner)
     __syncthreads();
