@@ -2,7 +2,7 @@
 # PMC pass: SQ instruction / stall counters per kernel (own run, no trace domains besides the implicit kernel dispatch)
 mkdir -p gpurun_out; R=$PWD; export TMPDIR=/tmp
 rm -rf gpurun_out/prof_sq
-(cd /tmp && rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $R/gpurun_out/prof_sq -o sq -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_sq.log 2>&1)
+(cd /tmp && rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $R/gpurun_out/prof_sq -o sq -- python $R/bench.py --steps 3 --warmup 1 --pairs 64 --no-cpu-baseline > $R/gpurun_out/prof_sq.log 2>&1)
 tail -2 gpurun_out/prof_sq.log | cut -c1-200
 python tools/pmc_summary.py gpurun_out/prof_sq gpurun_out/summary_sq > /dev/null
 python - <<'PY'

@@ -9,8 +9,8 @@ python tools/bench_next_rows.py > gpurun_out/next_rows.json 2> gpurun_out/next_r
 export TMPDIR=/tmp
 rm -rf gpurun_out/prof_trace gpurun_out/prof_fetch gpurun_out/prof_write
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trace -o trace -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/prof_trace.log 2>&1)
-(cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -o fetch -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_fetch.log 2>&1)
-(cd /tmp && rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -o write -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_write.log 2>&1)
+(cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -o fetch -- python $R/bench.py --steps 4 --warmup 2 --pairs 64 --no-cpu-baseline > $R/gpurun_out/prof_fetch.log 2>&1)
+(cd /tmp && rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -o write -- python $R/bench.py --steps 4 --warmup 2 --pairs 64 --no-cpu-baseline > $R/gpurun_out/prof_write.log 2>&1)
 python tools/pmc_summary.py gpurun_out/prof_trace gpurun_out/summary_trace > /dev/null
 python tools/pmc_summary.py gpurun_out/prof_fetch gpurun_out/summary_fetch > /dev/null
 python tools/pmc_summary.py gpurun_out/prof_write gpurun_out/summary_write > /dev/null
