@@ -7,6 +7,7 @@
 // All are HBM/LDS-bound integer kernels: no MFMA.  One launch covers every image of the batch.
 #include "orbx_types.h"
 #include "orbx_block.h"
+#include "orbx_kernels.h"
 
 namespace orbx {
 
@@ -530,7 +531,7 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
 // last 7 horizontal sums in registers, so every input dword is fetched once per strip (+6 halo rows, L1/L2 hits) and
 // every output is one coalesced dword store.  No LDS, no barriers.
 // block (64,4): 256 columns x 4 strips.  grid (tiles over all levels, B): tile table in BlurTiles.
-constexpr int kBlurRows = 16;
+static_assert(kBlurRows % 2 == 0, "rows are produced in pairs");
 
 __global__ void __launch_bounds__(256) k_blur(const LevelInfo* __restrict__ lv, int nlevels,
                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,

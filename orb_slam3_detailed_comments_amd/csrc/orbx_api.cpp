@@ -248,7 +248,7 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
         static const int A[7] = {18, 34, 48, 56, 48, 34, 18}, Bt[7] = {18, 34, 49, 55, 49, 34, 18};
         for (int i = 0; i < 7; i++) taps.k[i] = h->gauss_variant == 1 ? Bt[i] : A[i];
         BlurTiles tiles; int nt = 0;
-        for (int l = 0; l < nl; l++) { tiles.begin[l] = nt; nt += ((h->lv[l].w + 255) / 256) * ((h->lv[l].h + 63) / 64); }
+        for (int l = 0; l < nl; l++) { tiles.begin[l] = nt; nt += ((h->lv[l].w + 255) / 256) * ((h->lv[l].h + 4 * kBlurRows - 1) / (4 * kBlurRows)); }
         for (int l = nl; l <= kMaxLevels; l++) tiles.begin[l] = nt;
         dim3 grid(nt, B, 1);
         ORBX_LAUNCH(k_blur, grid, blk2, 0, sb, (const LevelInfo*)h->d_lv.p, nl, (const uint8_t*)h->d_pyr.p, h->d_blur.p, h->pyr_stride, taps, tiles);
