@@ -136,3 +136,21 @@ def test_handle_reuse_across_sizes_and_batches(emu_lib):
     kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8); n = C.c_int(); m = C.c_int()
     emu_lib.check(emu_lib.L.orbx_extract(ex._h, roi.ctypes.data, 376, 240, 500, 0, 0, kps.ctypes.data, desc.ctypes.data, cap, C.byref(n), C.byref(m)))
     assert m.value == ra1[0] and ol.kps_equal(kps[:n.value], ra1[1]) and np.array_equal(desc[:n.value], ra1[2])
+
+
+def test_unusual_pyramids_with_stereo(emu_lib):
+    """Pyramids the reference accepts but nobody ships: 11 levels (stereo row bands up to 25 rows tall), 3 levels at scale 2, one level."""
+    from orb_slam3_detailed_comments_amd import matcher as M
+    L, R = synth.stereo_pair(752, 480, seed=3)
+    for (nf, sf, nl) in [(800, 1.2, 11), (300, 2.0, 3), (2000, 1.3, 1)]:
+        ex = ORBextractor(nf, sf, nl, 20, 7, lib=emu_lib)
+        res = ex.extract_batch(np.stack([L, R]), (0, 0))
+        oL = ol.OracleExtractor(nf, sf, nl, 20, 7); oR = ol.OracleExtractor(nf, sf, nl, 20, 7)
+        eL = oL.extract(L); eR = oR.extract(R)
+        for got, exp in zip(res, (eL, eR)):
+            assert got[0] == exp[0] and ol.kps_equal(got[1], exp[1]) and np.array_equal(got[2], exp[2]), (nf, sf, nl)
+        u, d, n = M.ComputeStereoMatches(ex, ex, EUROC_BF, EUROC_B, 0, 1, 1)
+        uo, do, no = ol.oracle_stereo(oL, oR, eL[1], eL[2], eR[1], eR[2], EUROC_BF, EUROC_B)
+        N = len(eL[1])
+        assert n[0] == no and np.array_equal(u[0, :N].view(np.uint32), uo.view(np.uint32)) and np.array_equal(d[0, :N].view(np.uint32), do.view(np.uint32)), (nf, sf, nl)
+        assert no > 20
