@@ -40,3 +40,24 @@ def test_vocabulary_on_extracted_batch_gpu(hip_lib, tmp_path):
         assert np.array_equal(r.bow_id, bi) and r.bow_val.tobytes() == bv.tobytes()
         assert np.array_equal(r.fv_node, fn) and np.array_equal(r.fv_start, fs) and np.array_equal(r.fv_feat, ff)
         assert n > 1000 and len(bi) > 300
+
+
+def test_vocabulary_maximum_feature_count_gpu(hip_lib, tmp_path):
+    """16384 features in one call (128 KB of LDS for the sort) and the capacity error one above it."""
+    from orb_slam3_detailed_comments_amd._lib import OrbxError
+    if ol.reference_dbow2() is None:
+        pytest.skip("oracle/_ref/libref_dbow2.so not built")
+    ex = ORBextractor(1200, 1.2, 8, 20, 7)
+    rng = np.random.default_rng(9)
+    header, parent, leaf, desc, weight = vs.make_vocabulary(rng, 9, 3)
+    path = tmp_path / "voc.txt"
+    vs.write_text(path, header, parent, leaf, desc, weight)
+    ref = ol.RefVocabulary(path)
+    voc = ORBVocabulary.loadFromTextFile(ex, path)
+    q = vs.descriptors_near(rng, desc, 16384)
+    r = voc.transform(q, 1)
+    bi, bv, fn, fs, ff = ref.transform(q, 1)
+    assert np.array_equal(r.bow_id, bi) and r.bow_val.tobytes() == bv.tobytes()
+    assert np.array_equal(r.fv_node, fn) and np.array_equal(r.fv_start, fs) and np.array_equal(r.fv_feat, ff)
+    with pytest.raises(OrbxError):
+        voc.transform(np.zeros((16385, 32), np.uint8), 1)
