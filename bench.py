@@ -129,7 +129,7 @@ def main():
     dptrs = [h.device_upload(batch) for h in handles]          # inputs resident in HBM before the timed region
     cap = handles[0].max_keypoints()
     for h in handles:
-        h.profile(not os.environ.get("ORBX_BENCH_NOPROFILE"))
+        h.profile(not os.environ.get("ORBX_BENCH_NOPROFILE"), serial=bool(os.environ.get("ORBX_BENCH_SERIAL")))
     out = [dict(k=h.pinned_empty((2 * P, cap, 28), np.uint8), d=h.pinned_empty((2 * P, cap, 32), np.uint8), n=np.zeros(2 * P, np.int32),
                 m=np.zeros(2 * P, np.int32), u=h.pinned_empty((P, cap), np.float32), z=h.pinned_empty((P, cap), np.float32), nm=np.zeros(P, np.int32))
            for h in handles]
