@@ -6,6 +6,7 @@ python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1; tail -3 gp
 python bench.py --steps 30 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; cat gpurun_out/bench.json; tail -3 gpurun_out/bench.err
 python tests/gpu_quick.py > gpurun_out/quick.log 2>&1; grep -E "PARITY|^B " gpurun_out/quick.log
 python tools/bench_next_rows.py > gpurun_out/next_rows.json 2> gpurun_out/next_rows.err; tail -2 gpurun_out/next_rows.err
+python tools/bench_other_configs.py > gpurun_out/other_configs.json 2>/dev/null
 export TMPDIR=/tmp
 rm -rf gpurun_out/prof_trace gpurun_out/prof_fetch gpurun_out/prof_write
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trace -o trace -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/prof_trace.log 2>&1)
