@@ -123,7 +123,11 @@ class ORBextractor:
 
     def fetch(self):
         B, cap = self._B, self.max_keypoints()
-        kps = np.zeros((B, cap), KP_DTYPE); desc = np.zeros((B, cap, 32), np.uint8)
+        buf = getattr(self, "_fetch_buf", None)
+        if buf is None or buf[0] != (B, cap):      # page-locked staging, reused across calls (the device layout is [B, cap])
+            buf = ((B, cap), self.pinned_empty((B, cap), KP_DTYPE), self.pinned_empty((B, cap, 32), np.uint8))
+            self._fetch_buf = buf
+        kps, desc = buf[1], buf[2]
         n = np.zeros(B, np.int32); mono = np.zeros(B, np.int32)
         self._lib.check(self._lib.L.orbx_fetch(self._h, kps.ctypes.data, desc.ctypes.data, cap, n.ctypes.data, mono.ctypes.data))
         return [(int(mono[b]), kps[b, :n[b]].copy(), desc[b, :n[b]].copy()) for b in range(B)]
