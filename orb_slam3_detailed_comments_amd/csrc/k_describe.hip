@@ -91,6 +91,8 @@ __global__ void __launch_bounds__(256) k_layout(const LevelInfo* __restrict__ lv
 //   3  steered BRIEF, again one keypoint at a time with all lanes (4 tests per lane, 4 ballots = 4 descriptor words)
 //   4  lane k writes the record of keypoint k
 constexpr int kKpPerWave = 8;
+// window of the steered-BRIEF samples: rows / columns -18 .. +18 (the pattern's radius is 18.4), 10 dwords per row
+constexpr int kWinR = 18, kWinRows = 2 * kWinR + 1, kWinDw = 10, kWinTrips = (kWinRows * kWinDw + 63) / 64;
 static_assert(kKpPerWave == kKpPerWaveDecl, "orbx_kernels.h out of date");
 __global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restrict__ lv, int nlevels,
                                                       const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t pyr_stride,
@@ -98,6 +100,7 @@ __global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restric
                                                       const int* __restrict__ lvl_count, const int* __restrict__ final_idx,
                                                       UmaxTab umax, KeyPointRec* __restrict__ out_kps,
                                                       unsigned long long* __restrict__ out_desc, int4* __restrict__ out_aux) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[4][kWinRows * kWinDw * 4];
     const int b = (int)blockIdx.y;
     const int lane = lane_id();
     const int slot0 = ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * kKpPerWave;
@@ -172,21 +175,35 @@ __global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restric
         const signed char* p = &BRIEF_PATTERN[4 * (64 * r + lane)];
         px0[r] = (float)p[0]; py0[r] = (float)p[1]; px1[r] = (float)p[2]; py1[r] = (float)p[3];
     }
+    // The 512 sample points of a keypoint fall inside the 37 x 37 window around it (pattern radius 18.4).  The wave first copies that
+    // window into its LDS slice with six row-coalesced dword loads per lane-trip (lanes of a row read 40 contiguous bytes) and then picks
+    // the samples out of LDS: 512 scattered single-byte gathers from global memory per keypoint were what kept the texture path busy.
+    uint8_t* win = s_win[threadIdx.x >> 6];
     for (int k = 0; k < kKpPerWave; k++) {
         if (!((vmask >> k) & 1ull)) continue;
         const int pitch = ORBX_READLANE(my_pitch, k);
         const uint8_t* ctr = blur0 + readlane_i64(my_off, k);
         const float a = __int_as_float(ORBX_READLANE(__float_as_int(my_a), k)), bb = __int_as_float(ORBX_READLANE(__float_as_int(my_b), k));
         const int fi = ORBX_READLANE(my_fi, k);
+        uint32_t wv[kWinTrips];
+#pragma unroll
+        for (int t = 0; t < kWinTrips; t++) {
+            const int i = lane + 64 * t;                    // dword i of the window: row i / 10, dword column i % 10
+            if (i < kWinRows * kWinDw) __builtin_memcpy(&wv[t], ctr + (ptrdiff_t)(i / kWinDw - kWinR) * pitch + (4 * (i % kWinDw) - kWinR), 4);
+        }
+        ORBX_WAVE_SYNC();                                   // the previous keypoint's samples have been read
+#pragma unroll
+        for (int t = 0; t < kWinTrips; t++) { const int i = lane + 64 * t; if (i < kWinRows * kWinDw) ((uint32_t*)win)[i] = wv[t]; }
+        ORBX_WAVE_SYNC();
         int t0v[4], t1v[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {       // 8 independent gathers in flight
+        for (int r = 0; r < 4; r++) {
             const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0[r], bb), __fmul_rn(py0[r], a)));
             const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[r], a), __fmul_rn(py0[r], bb)));
             const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[r], bb), __fmul_rn(py1[r], a)));
             const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[r], a), __fmul_rn(py1[r], bb)));
-            t0v[r] = ctr[(ptrdiff_t)r0 * pitch + c0];
-            t1v[r] = ctr[(ptrdiff_t)r1 * pitch + c1];
+            t0v[r] = win[(r0 + kWinR) * (4 * kWinDw) + c0 + kWinR];
+            t1v[r] = win[(r1 + kWinR) * (4 * kWinDw) + c1 + kWinR];
         }
         unsigned long long mine = 0;
 #pragma unroll
