@@ -12,6 +12,11 @@ FULL_CASES = [
     ("euroc_mono_600x350_n5000_init", lambda: synth.corner_field(600, 350, seed=5), 5000, (0, 1000)),
 ]
 
+LARGE_CASES = [   # sizes outside BASELINE.json that real rigs use (KITTI, HD): GPU parity only
+    ("kitti_1241x376_n2000", lambda: synth.corner_field(1241, 376, seed=20, nrect=3900), 2000, (0, 0)),
+    ("hd_1920x1080_n3000", lambda: synth.corner_field(1920, 1080, seed=21, nrect=17000), 3000, (0, 0)),
+]
+
 SMALL_CASES = [
     ("small_376x240_n500", lambda: synth.corner_field(376, 240, seed=10, nrect=800), 500, (0, 0)),
     ("small_lap_partial", lambda: synth.corner_field(376, 240, seed=11, nrect=800), 500, (100, 250)),
