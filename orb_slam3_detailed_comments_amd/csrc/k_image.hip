@@ -190,45 +190,6 @@ __device__ __forceinline__ int pk_hi(pk2 a) { return (int)a.y; }
 // ---------------------------------------------------------------------------------------------------
 // FAST-9/16.  ring offsets (dx,dy), k = 0..15, as in OpenCV: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)
 // (0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3).  d[k] = v - ring[k].
-__device__ __forceinline__ void fast_ring(const uint8_t* c, int wp, int d[16]) {
-    const int v = c[0];
-    d[0] = v - c[3 * wp];          d[1] = v - c[3 * wp + 1];    d[2] = v - c[2 * wp + 2];    d[3] = v - c[wp + 3];
-    d[4] = v - c[3];               d[5] = v - c[-wp + 3];       d[6] = v - c[-2 * wp + 2];   d[7] = v - c[-3 * wp + 1];
-    d[8] = v - c[-3 * wp];         d[9] = v - c[-3 * wp - 1];   d[10] = v - c[-2 * wp - 2];  d[11] = v - c[-wp - 3];
-    d[12] = v - c[-3];             d[13] = v - c[wp - 3];       d[14] = v - c[2 * wp - 2];   d[15] = v - c[3 * wp - 1];
-}
-// Exact quick rejection: a 9-arc contains one pixel of every opposite pair (k, k+8).
-__device__ __forceinline__ bool fast_quick(const int d[16], int t0) {
-    // branch-free: max(d[k], d[k+8]) > t0 for all k (dark) or min(d[k], d[k+8]) < -t0 for all k (bright)
-    int mnmx = 255, mxmn = -255;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        mnmx = imin(mnmx, imax(d[k], d[k + 8]));
-        mxmn = imax(mxmn, imin(d[k], d[k + 8]));
-    }
-    return (mnmx > t0) | (mxmn < -t0);
-}
-// OpenCV's cornerScore (largest threshold for which the pixel is still a corner) when the pixel is a corner at
-// threshold t0, else 0:  max over the 16 nine-arcs of min |v - ring| , minus 1.  Sliding 9-window min/max by doubling.
-__device__ __forceinline__ int fast_full(const int d[16], int t0) {
-    int mn2[16], mx2[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { mn2[k] = imin(d[k], d[(k + 1) & 15]); mx2[k] = imax(d[k], d[(k + 1) & 15]); }
-    int mn4[16], mx4[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { mn4[k] = imin(mn2[k], mn2[(k + 2) & 15]); mx4[k] = imax(mx2[k], mx2[(k + 2) & 15]); }
-    int Md = -255, Mb = -255;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int mn9 = imin(imin(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-        const int mx9 = imax(imax(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-        Md = imax(Md, mn9);
-        Mb = imax(Mb, -mx9);
-    }
-    const int m = imax(Md, Mb);
-    return m > t0 ? m - 1 : 0;
-}
-
 // One workgroup per (cell, image).  LDS: window tile (dword-aligned columns) | score tile | candidate list (u16).
 //   A  every interior pixel: ring + exact quick rejection; survivors are appended, in row-major order, to the list
 //      of the wave that owns that quarter of the pixel range (wave ballots, no barrier)
@@ -237,26 +198,8 @@ __device__ __forceinline__ int fast_full(const int d[16], int t0) {
 //   D  threshold choice of the reference (FAST at iniTh; if that yields nothing, FAST at minTh, :1135-1148) and
 //      ordered compaction into the cell's slot list.
 // slots: per-cell candidate lists in the reference order; cell_count[b*ncells + cell] = number kept.
-// fast_full for two pixels at once (packed 16-bit lanes); d[k] = (v - ring_k) of pixel A in .x and pixel B in .y
-__device__ __forceinline__ void fast_full_pk(const pk2 d[16], int t0, int& sA, int& sB) {
-    pk2 mn2[16], mx2[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { mn2[k] = pk_min(d[k], d[(k + 1) & 15]); mx2[k] = pk_max(d[k], d[(k + 1) & 15]); }
-    pk2 mn4[16], mx4[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { mn4[k] = pk_min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = pk_max(mx2[k], mx2[(k + 2) & 15]); }
-    pk2 Md = pk_min(pk_min(mn4[0], mn4[4]), d[8]);          // max over arcs of the arc minimum (dark)
-    pk2 Mx = pk_max(pk_max(mx4[0], mx4[4]), d[8]);          // min over arcs of the arc maximum (bright, negated below)
-#pragma unroll
-    for (int k = 1; k < 16; k++) {
-        Md = pk_max(Md, pk_min(pk_min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]));
-        Mx = pk_min(Mx, pk_max(pk_max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]));
-    }
-    const int mA = imax(pk_lo(Md), -pk_lo(Mx)), mB = imax(pk_hi(Md), -pk_hi(Mx));
-    sA = mA > t0 ? mA - 1 : 0;
-    sB = mB > t0 ? mB - 1 : 0;
-}
-
+// OpenCV's cornerScore (largest threshold for which the pixel is still a corner) when the pixel is a corner at threshold t0, else 0:
+// max over the 16 nine-arcs of min |v - ring|, minus 1 - sliding 9-window minima by doubling, two pixels per instruction (packed 16-bit).
 // one-sided variant: d[k] = sign * (v - ring_k) with sign = +1 for a dark candidate and -1 for a bright one, so that both become
 // "max over the 16 nine-arcs of the arc minimum"
 __device__ __forceinline__ void fast_score_pk(const pk2 d[16], int t0, int& sA, int& sB) {
