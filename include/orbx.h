@@ -220,6 +220,12 @@ int orbm_search_for_triangulation(orbx_extractor* h, const OrbmKeyFrameView* K1,
                                   const float F12[9], const float ep[2], int only_stereo, int coarse,
                                   int check_orientation, int* matches12, int* nmatches);
 
+/* The same for one key frame against n2 neighbours in one launch (LocalMapping::CreateNewMapPoints loops over 10-30 neighbour key frames,
+ * src/LocalMapping.cc:510-540): F12s = n2 x 9, eps = n2 x 2, matches12 = n2 rows of K1->N entries, nmatches = n2 counts. */
+int orbm_search_for_triangulation_batch(orbx_extractor* h, const OrbmKeyFrameView* K1, int n2, const OrbmKeyFrameView* const* K2s,
+                                        const float* F12s, const float* eps, int only_stereo, int coarse, int check_orientation,
+                                        int* matches12, int* nmatches);
+
 /* Batched Frame::GetFeaturesInArea + Hamming distance: the building block the remaining projection-type searches of the
  * reference (SearchByProjection(KeyFrame*, Sim3, ...) src/ORBmatcher.cc:495-732, SearchByProjection(Frame&, KeyFrame*, ...) :2196-2324,
  * Fuse :1325-1675, SearchBySim3 :1689-1932) share: for every query (x, y, r, minLevel, maxLevel, descriptor) the keypoints

@@ -31,7 +31,7 @@ SYMBOLS = [
     "orbm_get_features_in_area", "orbm_search_by_projection_mappoints", "orbm_search_by_projection_frame",
     "orbm_search_for_triangulation", "orbm_search_by_bow", "orbm_search_for_initialization", "orbm_area_search_batch",
     "orbm_search_by_projection_sim3", "orbm_search_by_projection_keyframe", "orbm_fuse_candidates", "orbm_search_by_sim3", "orbm_distinctive_descriptors",
-    "orbm_search_by_projection_mappoints_fisheye", "orbm_search_by_projection_frame_fisheye",
+    "orbm_search_by_projection_mappoints_fisheye", "orbm_search_by_projection_frame_fisheye", "orbm_search_for_triangulation_batch",
     "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_words", "orbv_transform", "orbv_transform_extracted", "orbv_fetch",
     "orbx_last_error",
 ]
@@ -98,6 +98,7 @@ class OrbxLib:
         L.orbm_search_by_sim3.argtypes = [vp, vp, vp, vp, vp, f, vp, ip]
         L.orbm_search_by_projection_mappoints_fisheye.argtypes = [vp, vp, vp, vp, f, i, f, f, vp, ip]
         L.orbm_search_by_projection_frame_fisheye.argtypes = [vp, vp, vp, vp, vp, f, i, i, i, vp, ip]
+        L.orbm_search_for_triangulation_batch.argtypes = [vp, vp, i, vp, vp, vp, i, i, i, vp, vp]
         L.orbm_distinctive_descriptors.argtypes = [vp, vp, vp, i, vp]
         L.orbv_create.argtypes = [vp, i, i, i, i, i, vp, vp, vp, vp, C.POINTER(vp)]
         L.orbv_load_text.argtypes = [vp, C.c_char_p, C.POINTER(vp)]

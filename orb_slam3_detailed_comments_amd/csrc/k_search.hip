@@ -170,18 +170,19 @@ __global__ void __launch_bounds__(256) k_area_search(const AreaQuery* __restrict
     if (lane == 0) { q_start[q] = start < 0 ? 0 : start; q_count[q] = cnt_total; }
 }
 
-// One wave per work item (an unmatched feature idx1 of KF1 and the feature list of KF2 in the same node).
-// best2[item] = chosen idx2 or -1.   src/ORBmatcher.cc:1117-1254
+// One wave per work item (an unmatched feature idx1 of KF1 and the feature list of a neighbour KF2 in the same node; the arrays of
+// all neighbours of a batch are concatenated, item.out_off = neighbour).  best2[item] = chosen (global) idx2 or -1.   src/ORBmatcher.cc:1117-1254
 __global__ void __launch_bounds__(256) k_bow_search(const BowItem* __restrict__ items, int nitems,
                                                     const KeyPointRec* __restrict__ kps1, const unsigned long long* __restrict__ desc1,
                                                     const float* __restrict__ ur1,
                                                     const KeyPointRec* __restrict__ kps2, const unsigned long long* __restrict__ desc2,
                                                     const float* __restrict__ ur2, const uint8_t* __restrict__ has_mp2,
-                                                    const int* __restrict__ feat2, BowParams P, int* __restrict__ best2) {
+                                                    const int* __restrict__ feat2, const BowParams* __restrict__ Ps, int* __restrict__ best2) {
     const int lane = lane_id();
     const int it = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     if (it >= nitems) return;
     const BowItem I = items[it];
+    const BowParams& P = Ps[I.out_off];            // the neighbour key frame this item belongs to (wave-uniform)
     const KeyPointRec k1 = kps1[I.idx1];
     const bool stereo1 = ur1[I.idx1] >= 0;
     const unsigned long long* da = desc1 + 4 * (size_t)I.idx1;

@@ -286,77 +286,109 @@ int orbm_search_by_projection_frame(orbx_extractor* h, const OrbmFrameView* Cur,
     return ORBX_OK;
 }
 
-int orbm_search_for_triangulation(orbx_extractor* h, const OrbmKeyFrameView* K1, const OrbmKeyFrameView* K2, const float F12[9], const float ep[2],
-                                  int only_stereo, int coarse, int check_ori, int* matches12, int* nmatches_out) {
-    if (!h || !K1 || !K2 || !F12 || !ep || !matches12) return fail(ORBX_E_ARG, "null");
-    if (K1->N >= 65535 || K2->N >= 65535 || K2->nlevels > kMaxLevels) return fail(ORBX_E_ARG, "keyframe too large");
+// ORBmatcher::SearchForTriangulation for one key frame against n2 neighbours in a single launch (LocalMapping::CreateNewMapPoints calls
+// it for 10-30 neighbours in a row, src/LocalMapping.cc:510-540).  matches12: n2 rows of K1->N entries.
+int orbm_search_for_triangulation_batch(orbx_extractor* h, const OrbmKeyFrameView* K1, int n2, const OrbmKeyFrameView* const* K2s, const float* F12s,
+                                        const float* eps, int only_stereo, int coarse, int check_ori, int* matches12, int* nmatches_out) {
+    if (!h || !K1 || n2 < 0 || (n2 > 0 && (!K2s || !F12s || !eps || !matches12))) return fail(ORBX_E_ARG, "null");
+    if (K1->N >= 65535) return fail(ORBX_E_ARG, "keyframe too large");
     rt::set_device(h->device);
-    const int N1 = K1->N, N2 = K2->N;
-    for (int i = 0; i < N1; i++) matches12[i] = -1;
-    // merge-join of the two feature vectors by node id (:1105-1286); one work item per unmatched feature of KF1
+    const int N1 = K1->N;
+    for (size_t i = 0; i < (size_t)n2 * N1; i++) matches12[i] = -1;
+    for (int j = 0; j < n2; j++) if (nmatches_out) nmatches_out[j] = 0;
+    // merge-join of the feature vectors by node id (:1105-1286); one work item per unmatched feature of KF1 and neighbour.
+    // The neighbours' arrays are concatenated; feat2 entries and the returned indices are global (base2[j] + index in KF j).
     std::vector<BowItem> items;
-    int a = 0, b = 0;
-    while (a < K1->fv_nodes && b < K2->fv_nodes) {
-        const uint32_t na = K1->fv_node_id[a], nb = K2->fv_node_id[b];
-        if (na == nb) {
-            for (int k = K1->fv_start[a]; k < K1->fv_start[a + 1]; k++) {
-                const int idx1 = (int)K1->fv_feat[k];
-                if (K1->has_map_point && K1->has_map_point[idx1]) continue;
-                const bool stereo1 = K1->u_right && K1->u_right[idx1] >= 0;
-                if (only_stereo && !stereo1) continue;
-                BowItem it; it.idx1 = idx1; it.start2 = K2->fv_start[b]; it.cnt2 = K2->fv_start[b + 1] - K2->fv_start[b]; it.out_off = 0;
-                if (it.cnt2 > 0xFFFF) return fail(ORBX_E_ARG, "vocabulary node with more than 65535 features");
-                items.push_back(it);
-            }
-            a++; b++;
-        } else if (na < nb) { while (a < K1->fv_nodes && K1->fv_node_id[a] < nb) a++; }
-        else { while (b < K2->fv_nodes && K2->fv_node_id[b] < na) b++; }
+    std::vector<int> base2(n2 + 1, 0), fbase(n2 + 1, 0), first_item(n2 + 1, 0);
+    for (int j = 0; j < n2; j++) {
+        const OrbmKeyFrameView* K2 = K2s[j];
+        if (!K2 || K2->N >= 65535 || K2->nlevels > kMaxLevels) return fail(ORBX_E_ARG, "bad neighbour key frame %d", j);
+        base2[j + 1] = base2[j] + K2->N; fbase[j + 1] = fbase[j] + K2->fv_start[K2->fv_nodes];
+        first_item[j] = (int)items.size();
+        int a = 0, b = 0;
+        while (a < K1->fv_nodes && b < K2->fv_nodes) {
+            const uint32_t na = K1->fv_node_id[a], nb = K2->fv_node_id[b];
+            if (na == nb) {
+                for (int k = K1->fv_start[a]; k < K1->fv_start[a + 1]; k++) {
+                    const int idx1 = (int)K1->fv_feat[k];
+                    if (K1->has_map_point && K1->has_map_point[idx1]) continue;
+                    const bool stereo1 = K1->u_right && K1->u_right[idx1] >= 0;
+                    if (only_stereo && !stereo1) continue;
+                    BowItem it; it.idx1 = idx1; it.start2 = fbase[j] + K2->fv_start[b]; it.cnt2 = K2->fv_start[b + 1] - K2->fv_start[b]; it.out_off = j;
+                    if (it.cnt2 > 0xFFFF) return fail(ORBX_E_ARG, "vocabulary node with more than 65535 features");
+                    items.push_back(it);
+                }
+                a++; b++;
+            } else if (na < nb) { while (a < K1->fv_nodes && K1->fv_node_id[a] < nb) a++; }
+            else { while (b < K2->fv_nodes && K2->fv_node_id[b] < na) b++; }
+        }
     }
-    int nmatches = 0;
-    if (!items.empty()) {
-        std::vector<float> ur1(N1 > 0 ? N1 : 1, -1.0f), ur2(N2 > 0 ? N2 : 1, -1.0f);
-        if (K1->u_right) memcpy(ur1.data(), K1->u_right, sizeof(float) * N1);
-        if (K2->u_right) memcpy(ur2.data(), K2->u_right, sizeof(float) * N2);
-        std::vector<uint8_t> mp2(N2 > 0 ? N2 : 1, 0);
-        if (K2->has_map_point) memcpy(mp2.data(), K2->has_map_point, N2);
-        const int nfeat2 = K2->fv_start[K2->fv_nodes];
-        Packer pk(h);
-        const size_t pk1 = pk.add(K1->keys_un, sizeof(KeyPointRec) * (size_t)N1), pd1 = pk.add(K1->desc, 32 * (size_t)N1), pu1 = pk.add(ur1.data(), sizeof(float) * ur1.size()),
-                     pk2 = pk.add(K2->keys_un, sizeof(KeyPointRec) * (size_t)N2), pd2 = pk.add(K2->desc, 32 * (size_t)N2), pu2 = pk.add(ur2.data(), sizeof(float) * ur2.size()),
-                     pm2 = pk.add(mp2.data(), mp2.size()), pit = pk.add(items.data(), sizeof(BowItem) * items.size()), pf2 = pk.add(K2->fv_feat, sizeof(int) * (size_t)nfeat2);
-        if (pk.flush() || h->d_si[SI_BEST].ensure(items.size())) return fail(ORBX_E_DEVICE, "upload/allocation failed");
-        BowParams P; memset(&P, 0, sizeof P);
-        for (int i = 0; i < 9; i++) P.F12[i] = F12[i];
-        P.ep[0] = ep[0]; P.ep[1] = ep[1];
+    first_item[n2] = (int)items.size();
+    if (items.empty()) return ORBX_OK;
+    const int T2 = std::max(base2[n2], 1), TF = std::max(fbase[n2], 1);
+    std::vector<float> ur1(N1 > 0 ? N1 : 1, -1.0f), ur2(T2, -1.0f);
+    if (K1->u_right) memcpy(ur1.data(), K1->u_right, sizeof(float) * N1);
+    std::vector<uint8_t> mp2(T2, 0), desc2((size_t)T2 * 32);
+    std::vector<KeyPointRec> kps2(T2);
+    std::vector<int> feat2(TF);
+    std::vector<BowParams> Ps(n2);
+    for (int j = 0; j < n2; j++) {
+        const OrbmKeyFrameView* K2 = K2s[j];
+        const int N2 = K2->N, o = base2[j];
+        if (N2 > 0) { memcpy(&kps2[o], K2->keys_un, sizeof(KeyPointRec) * (size_t)N2); memcpy(&desc2[(size_t)o * 32], K2->desc, 32 * (size_t)N2); }
+        if (K2->u_right) memcpy(&ur2[o], K2->u_right, sizeof(float) * (size_t)N2);
+        if (K2->has_map_point) memcpy(&mp2[o], K2->has_map_point, N2);
+        const int nf = K2->fv_start[K2->fv_nodes];
+        for (int k = 0; k < nf; k++) feat2[fbase[j] + k] = (int)K2->fv_feat[k] + o;
+        BowParams& P = Ps[j]; memset(&P, 0, sizeof P);
+        for (int i = 0; i < 9; i++) P.F12[i] = F12s[9 * (size_t)j + i];
+        P.ep[0] = eps[2 * (size_t)j]; P.ep[1] = eps[2 * (size_t)j + 1];
         for (int l = 0; l < K2->nlevels; l++) { P.scale2[l] = K2->scale_factors[l]; P.sigma2_2[l] = K2->level_sigma2[l]; }
         P.only_stereo = only_stereo; P.coarse = coarse; P.th_low = TH_LOW;
-        dim3 grid(((int)items.size() + 3) / 4, 1, 1), blk(256, 1, 1);
-        ORBX_LAUNCH(k_bow_search, grid, blk, 0, h->s0, pk.dev<BowItem>(pit), (int)items.size(),
-                    pk.dev<KeyPointRec>(pk1), pk.dev<unsigned long long>(pd1), pk.dev<float>(pu1),
-                    pk.dev<KeyPointRec>(pk2), pk.dev<unsigned long long>(pd2), pk.dev<float>(pu2),
-                    pk.dev<uint8_t>(pm2), pk.dev<int>(pf2), P, h->d_si[SI_BEST].p);
-        std::vector<int> best(items.size());
-        if (rt::copy_d2h(best.data(), h->d_si[SI_BEST].p, sizeof(int) * items.size(), h->s0) || rt::stream_sync(h->s0) || rt::check_launch())
-            return fail(ORBX_E_DEVICE, "bow search failed: %s", rt::last_error());
+    }
+    Packer pk(h);
+    const size_t pk1 = pk.add(K1->keys_un, sizeof(KeyPointRec) * (size_t)N1), pd1 = pk.add(K1->desc, 32 * (size_t)N1), pu1 = pk.add(ur1.data(), sizeof(float) * ur1.size()),
+                 pk2 = pk.add(kps2.data(), sizeof(KeyPointRec) * kps2.size()), pd2 = pk.add(desc2.data(), desc2.size()), pu2 = pk.add(ur2.data(), sizeof(float) * ur2.size()),
+                 pm2 = pk.add(mp2.data(), mp2.size()), pit = pk.add(items.data(), sizeof(BowItem) * items.size()), pf2 = pk.add(feat2.data(), sizeof(int) * feat2.size()),
+                 pps = pk.add(Ps.data(), sizeof(BowParams) * Ps.size());
+    if (pk.flush() || h->d_si[SI_BEST].ensure(items.size())) return fail(ORBX_E_DEVICE, "upload/allocation failed");
+    dim3 grid(((int)items.size() + 3) / 4, 1, 1), blk(256, 1, 1);
+    ORBX_LAUNCH(k_bow_search, grid, blk, 0, h->s0, pk.dev<BowItem>(pit), (int)items.size(),
+                pk.dev<KeyPointRec>(pk1), pk.dev<unsigned long long>(pd1), pk.dev<float>(pu1),
+                pk.dev<KeyPointRec>(pk2), pk.dev<unsigned long long>(pd2), pk.dev<float>(pu2),
+                pk.dev<uint8_t>(pm2), pk.dev<int>(pf2), pk.dev<BowParams>(pps), h->d_si[SI_BEST].p);
+    std::vector<int> best(items.size());
+    if (rt::copy_d2h(best.data(), h->d_si[SI_BEST].p, sizeof(int) * items.size(), h->s0) || rt::stream_sync(h->s0) || rt::check_launch())
+        return fail(ORBX_E_DEVICE, "bow search failed: %s", rt::last_error());
+    for (int j = 0; j < n2; j++) {
+        const OrbmKeyFrameView* K2 = K2s[j];
+        int* m12 = matches12 + (size_t)j * N1;
+        int nmatches = 0;
         std::vector<int> rotHist[HISTO_LENGTH];
-        for (size_t k = 0; k < items.size(); k++) {
+        for (int k = first_item[j]; k < first_item[j + 1]; k++) {
             if (best[k] < 0) continue;
-            const int idx1 = items[k].idx1;
-            matches12[idx1] = best[k];
+            const int idx1 = items[k].idx1, idx2 = best[k] - base2[j];
+            m12[idx1] = idx2;
             nmatches++;
-            if (check_ori) rotHist[rot_bin(K1->keys_un[idx1].angle, K2->keys_un[best[k]].angle)].push_back(idx1);
+            if (check_ori) rotHist[rot_bin(K1->keys_un[idx1].angle, K2->keys_un[idx2].angle)].push_back(idx1);
         }
         if (check_ori) {
             int ind1 = -1, ind2 = -1, ind3 = -1;
             three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
             for (int i = 0; i < HISTO_LENGTH; i++) {
                 if (i == ind1 || i == ind2 || i == ind3) continue;
-                for (int idx1 : rotHist[i]) { matches12[idx1] = -1; nmatches--; }
+                for (int idx1 : rotHist[i]) { m12[idx1] = -1; nmatches--; }
             }
         }
+        if (nmatches_out) nmatches_out[j] = nmatches;
     }
-    if (nmatches_out) *nmatches_out = nmatches;
     return ORBX_OK;
+}
+
+int orbm_search_for_triangulation(orbx_extractor* h, const OrbmKeyFrameView* K1, const OrbmKeyFrameView* K2, const float F12[9], const float ep[2],
+                                  int only_stereo, int coarse, int check_ori, int* matches12, int* nmatches_out) {
+    if (!h || !K1 || !K2 || !F12 || !ep || !matches12) return fail(ORBX_E_ARG, "null");
+    return orbm_search_for_triangulation_batch(h, K1, 1, &K2, F12, ep, only_stereo, coarse, check_ori, matches12, nmatches_out);
 }
 
 

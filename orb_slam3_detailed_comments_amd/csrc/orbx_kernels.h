@@ -60,7 +60,7 @@ __global__ void k_bow_search(const BowItem* __restrict__ items, int nitems, cons
                              const unsigned long long* __restrict__ desc1, const float* __restrict__ ur1,
                              const KeyPointRec* __restrict__ kps2, const unsigned long long* __restrict__ desc2,
                              const float* __restrict__ ur2, const uint8_t* __restrict__ has_mp2, const int* __restrict__ feat2,
-                             BowParams P, int* __restrict__ best2);
+                             const BowParams* __restrict__ Ps, int* __restrict__ best2);
 __global__ void k_bow_dists(const BowItem* __restrict__ items, int nitems, const unsigned long long* __restrict__ desc1,
                             const unsigned long long* __restrict__ desc2, const uint8_t* __restrict__ eligible2,
                             const int* __restrict__ feat2, int* __restrict__ out);

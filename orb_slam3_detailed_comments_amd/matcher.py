@@ -40,6 +40,18 @@ class ORBmatcher:
         idx = np.nonzero(m12 >= 0)[0]
         return nm.value, [(int(i), int(m12[i])) for i in idx]
 
+    def SearchForTriangulationBatch(self, ext, kf1, kf2s, F12s, eps, bOnlyStereo=False, bCoarse=False):
+        """SearchForTriangulation of kf1 against every key frame of kf2s in one launch.  Returns a list of (nmatches, pairs) like
+        SearchForTriangulation."""
+        n2 = len(kf2s)
+        F = np.ascontiguousarray(F12s, np.float32).reshape(n2, 9); E = np.ascontiguousarray(eps, np.float32).reshape(n2, 2)
+        ptrs = (C.c_void_p * max(n2, 1))(*[C.cast(k.ref(), C.c_void_p) for k in kf2s])
+        N1 = kf1.view.N
+        m12 = np.full((max(n2, 1), max(N1, 1)), -1, np.int32); nm = np.zeros(max(n2, 1), np.int32)
+        ext._lib.check(ext._lib.L.orbm_search_for_triangulation_batch(ext._h, kf1.ref(), n2, ptrs, F.ctypes.data, E.ctypes.data, int(bOnlyStereo), int(bCoarse),
+                                                                    int(self.mbCheckOrientation), m12.ctypes.data, nm.ctypes.data))
+        return [(int(nm[j]), [(int(i), int(m12[j, i])) for i in np.nonzero(m12[j, :N1] >= 0)[0]]) for j in range(n2)]
+
     def SearchByBoW(self, ext, kf1, kf2, frame_version=True):
         """ORBmatcher::SearchByBoW: frame_version=True is (KeyFrame*, Frame&, vpMapPointMatches), src/ORBmatcher.cc:259;
         False is (KeyFrame*, KeyFrame*, vpMatches12), :892.  Returns (nmatches, matches12[N1])."""

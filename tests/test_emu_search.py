@@ -50,6 +50,15 @@ def run_all(lib, w, h, nf, M_points, seeds):
             n2, p2 = ol.oracle_search_for_triangulation(kf1[0], kf2[0], F12, ep, only_stereo, coarse, ori)
             assert n1 == n2 and p1 == p2, (only_stereo, coarse, ori)
         assert len(p2) > 5
+        # the same against several neighbours in one launch (LocalMapping::CreateNewMapPoints loops over 10-30 neighbours)
+        (kf3, kf4), F34, ep34 = sc.keyframe_pair(rng, nf, w, h)
+        neigh = [kf2[0], kf3[0], kf4[0], kf1[0]]
+        Fs = np.stack([F12, F34, F12 * np.float32(0.5), F34]); Es = np.stack([ep, ep34, np.array([w / 2, h / 2], np.float32), ep])
+        for (only_stereo, coarse, ori) in [(False, False, True), (True, True, False)]:
+            got = M.ORBmatcher(0.6, ori).SearchForTriangulationBatch(ex, kf1[0], neigh, Fs, Es, only_stereo, coarse)
+            for j, kf in enumerate(neigh):
+                assert got[j] == ol.oracle_search_for_triangulation(kf1[0], kf, Fs[j], Es[j], only_stereo, coarse, ori), (j, only_stereo, coarse, ori)
+        assert sum(g[0] for g in got) > 5
         # "next" rows: SearchByBoW (both overloads) and SearchForInitialization
         nbest = 0
         for (frame_version, ratio, ori) in [(True, 0.7, True), (False, 0.8, False), (True, 0.9, False), (False, 0.75, True)]:
