@@ -1,0 +1,56 @@
+"""Randomised differential test of the projection-type searches (kernels on the CPU SIMT emulator + host replay vs the sequential
+oracle): random thresholds, ratios, motion flags, occupancy densities, empty frames and empty point sets."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import search_scenes as sc
+from orb_slam3_detailed_comments_amd import synth, views
+from orb_slam3_detailed_comments_amd.extractor import ORBextractor
+from orb_slam3_detailed_comments_amd import matcher as M
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_projection_searches_fuzz(emu_lib, seed):
+    rng = np.random.default_rng(1000 + seed)
+    ex = ORBextractor(500, 1.2, 8, 20, 7, lib=emu_lib)
+    w, h = 376, 240
+    img = synth.corner_field(w, h, seed=500 + seed, nrect=int(rng.integers(50, 1200)))
+    nf = int(rng.integers(60, 500))
+    occ_frac = float(rng.choice([0.0, 0.1, 0.6, 1.0]))
+    fv, k, d, u, scales = sc.frame_from_image(img, nf, rng, occupied_frac=occ_frac, with_uright=bool(rng.integers(0, 2)))
+    if seed == 5:                                   # an empty frame
+        fv = views.frame_view(k[:0], d[:0], scales, w, h); k, d, u = k[:0], d[:0], None
+    N = len(k)
+    Mp = int(rng.choice([0, 1, 70, 900]))
+    for rep in range(3):
+        th = float(rng.choice([1.0, 2.0, 7.0, 15.0, 40.0])); ratio = float(rng.uniform(0.5, 1.0)); ori = bool(rng.integers(0, 2))
+        fwd, bwd = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        if N > 0:
+            mps = sc.map_points_for_frame(k, d, u, scales, max(Mp, 1), rng, w, h)
+            far = bool(rng.integers(0, 2))
+            n1, a1 = M.ORBmatcher(ratio).SearchByProjection(ex, fv, mps, th, far, 20.0)
+            n2, a2 = ol.oracle_search_by_projection_mappoints(fv, mps, th, far, 20.0, ratio)
+            assert n1 == n2 and np.array_equal(a1, a2), ("mappoints", seed, rep)
+            last = sc.last_frame_for(k, d, scales, rng, w, h, 40.0)
+            n1, a1 = M.ORBmatcher(ratio, ori).SearchByProjectionFrame(ex, fv, last, th, fwd, bwd)
+            n2, a2 = ol.oracle_search_by_projection_frame(fv, last, th, fwd, bwd, ori)
+            assert n1 == n2 and np.array_equal(a1, a2), ("frame", seed, rep)
+            pts = sc.projected_points(k, d, u, scales, rng, w, h, M=max(Mp, 1))
+            per = sc.projected_points(k, d, u, scales, rng, w, h)
+        else:
+            zero = np.zeros(max(Mp, 1), np.float32)
+            pts = views.projected_point_view(np.ones(max(Mp, 1), np.uint8), zero + 50, zero + 50, np.zeros(max(Mp, 1), np.int32),
+                                             rng.integers(0, 256, (max(Mp, 1), 32), dtype=np.uint8), zero, zero)
+            per = views.projected_point_view(np.zeros(0, np.uint8), zero[:0], zero[:0], np.zeros(0, np.int32), np.zeros((0, 32), np.uint8), zero[:0], zero[:0])
+        n1, a1 = M.ORBmatcher().SearchByProjectionSim3(ex, fv, pts, th, ratio * 2)
+        n2, a2 = ol.oracle_search_by_projection_sim3(fv, pts, th, ratio * 2)
+        assert n1 == n2 and np.array_equal(a1, a2), ("sim3", seed, rep)
+        orb_dist = int(rng.choice([30, 64, 100]))
+        n1, a1 = M.ORBmatcher(0.7, ori).SearchByProjectionKeyFrame(ex, fv, per, th, orb_dist)
+        n2, a2 = ol.oracle_search_by_projection_keyframe(fv, per, th, orb_dist, ori)
+        assert n1 == n2 and np.array_equal(a1, a2), ("keyframe", seed, rep)
+        s2 = (rng.uniform(0.05, 2.0) / (np.asarray(scales, np.float32) ** 2)).astype(np.float32) if rng.integers(0, 2) else None
+        b1, d1 = M.ORBmatcher().FuseCandidates(ex, fv, pts, th, s2)
+        b2, d2 = ol.oracle_fuse_candidates(fv, pts, th, s2)
+        assert np.array_equal(b1, b2) and np.array_equal(d1, d2), ("fuse", seed, rep)
