@@ -229,11 +229,18 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
                                                     uint32_t* __restrict__ slots, size_t slots_stride,
                                                     int* __restrict__ cell_count, int tile_bytes, int inner_bytes, int list_bytes) {
     ORBX_DYN_SMEM(smem);
-    // Plain mapping (workgroup b -> cell b, i.e. neighbouring cells on different XCDs).  Two XCD-aware remaps were measured
-    // (contiguous eighths of the cell table per XCD; runs of 16 cells dealt round-robin): they cut the kernel's HBM fetch from
-    // 291 MB to 70 MB per 128-image launch but made it 14-27 % slower (the kernel is compute-heavy and the remaps skew the mix of
-    // dense and sparse cells per XCD), so the balanced mapping stays.
+    // Plain mapping (workgroup b -> cell b, i.e. neighbouring cells on different XCDs, each with its own L2).  Keeping runs of
+    // neighbouring cells on one XCD (-DORBX_FAST_XCD_RUN=n) lets the L2 serve the 6-pixel window overlap and the dword / line padding:
+    // measured per 128-image launch n = 1 (this mapping) 305 MB fetched, 0.458 ms; n = 4: 131 MB, 0.473 ms; n = 20: 80 MB, 0.560 ms
+    // (and 62.9 k / 61.6 k / 58.2 k pairs/s end to end).  The kernel is not memory-bound and the runs skew the mix of dense and sparse
+    // cells per XCD, so the balanced mapping stays the default.
+#ifdef ORBX_FAST_XCD_RUN
+    // runs of ORBX_FAST_XCD_RUN consecutive cells on the same XCD (workgroup id % 8 picks the XCD)
+    const int bx = (int)blockIdx.x, xcd = bx & 7, jj = bx >> 3;
+    const int cell = ((jj / ORBX_FAST_XCD_RUN) * 8 + xcd) * ORBX_FAST_XCD_RUN + (jj % ORBX_FAST_XCD_RUN), b = (int)blockIdx.y;
+#else
     const int cell = (int)blockIdx.x, b = (int)blockIdx.y;
+#endif
     const int tid = (int)threadIdx.x, lane = tid & 63;
     if (cell >= ncells) return;
     const CellInfo ci = cells[cell];
