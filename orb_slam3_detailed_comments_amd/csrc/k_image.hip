@@ -229,18 +229,14 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
                                                     uint32_t* __restrict__ slots, size_t slots_stride,
                                                     int* __restrict__ cell_count, int tile_bytes, int inner_bytes, int list_bytes) {
     ORBX_DYN_SMEM(smem);
-    // Plain mapping (workgroup b -> cell b, i.e. neighbouring cells on different XCDs, each with its own L2).  Keeping runs of
-    // neighbouring cells on one XCD (-DORBX_FAST_XCD_RUN=n) lets the L2 serve the 6-pixel window overlap and the dword / line padding:
-    // measured per 128-image launch n = 1 (this mapping) 305 MB fetched, 0.458 ms; n = 4: 131 MB, 0.473 ms; n = 20: 80 MB, 0.560 ms
-    // (and 62.9 k / 61.6 k / 58.2 k pairs/s end to end).  The kernel is not memory-bound and the runs skew the mix of dense and sparse
-    // cells per XCD, so the balanced mapping stays the default.
-#ifdef ORBX_FAST_XCD_RUN
-    // runs of ORBX_FAST_XCD_RUN consecutive cells on the same XCD (workgroup id % 8 picks the XCD)
+    // Workgroup -> cell mapping.  Consecutive workgroup ids go to different XCDs (id % 8), each with its own L2; with the plain mapping
+    // (workgroup b -> cell b) neighbouring cells never share an L2 and the 6-pixel window overlap plus the dword / cache-line padding of
+    // every 43-byte window row is fetched again per cell.  Runs of kFastXcdRun neighbouring cells are therefore kept on one XCD.
+    // Measured per 128-image launch, run length 1 / 2 / 4 / 20: 305 / 186 / 131 / 80 MB fetched, 0.458 / 0.485 / 0.475 / 0.560 ms,
+    // 63.0 / 62.6 / 62.3 / 58.2 k pairs/s end to end - the kernel is not memory-bound and long runs skew the mix of dense and sparse cells
+    // per XCD, so the run stays short: 4 brings the traffic down to the algorithmic bytes for 1 % of throughput.
     const int bx = (int)blockIdx.x, xcd = bx & 7, jj = bx >> 3;
-    const int cell = ((jj / ORBX_FAST_XCD_RUN) * 8 + xcd) * ORBX_FAST_XCD_RUN + (jj % ORBX_FAST_XCD_RUN), b = (int)blockIdx.y;
-#else
-    const int cell = (int)blockIdx.x, b = (int)blockIdx.y;
-#endif
+    const int cell = ((jj / kFastXcdRun) * 8 + xcd) * kFastXcdRun + (jj % kFastXcdRun), b = (int)blockIdx.y;
     const int tid = (int)threadIdx.x, lane = tid & 63;
     if (cell >= ncells) return;
     const CellInfo ci = cells[cell];

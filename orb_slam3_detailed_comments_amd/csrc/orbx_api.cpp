@@ -257,11 +257,7 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
     rt::event_record(h->ev_join, sb);
     stage_begin(h, ST_FAST, h->s0);
     {
-#ifdef ORBX_FAST_XCD_RUN
-        dim3 grid((h->ncells + 8 * ORBX_FAST_XCD_RUN - 1) / (8 * ORBX_FAST_XCD_RUN) * (8 * ORBX_FAST_XCD_RUN), B, 1), blkf(kFastThreadsDecl, 1, 1);
-#else
-        dim3 grid(h->ncells, B, 1), blkf(kFastThreadsDecl, 1, 1);
-#endif
+        dim3 grid((h->ncells + 8 * kFastXcdRun - 1) / (8 * kFastXcdRun) * (8 * kFastXcdRun), B, 1), blkf(kFastThreadsDecl, 1, 1);   // whole XCD runs (k_fast_cells)
         // tile | score | u16 survivor list for half of the cell's pixels (k_fast_cells flushes it when a denser cell would overflow);
         // the LDS footprint of a cell sets this kernel's occupancy, which is what bounds it
         const int list_bytes = std::max(h->fast_inner_bytes, 1024);   // also holds one flag per score-tile byte on the flush path

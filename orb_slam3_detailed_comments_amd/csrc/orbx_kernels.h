@@ -9,6 +9,10 @@ __global__ void k_import(const LevelInfo* __restrict__ lv, const uint8_t* __rest
 __global__ void k_resize(const LevelInfo* __restrict__ lv, int level, const ResizeTap* __restrict__ xtab,
                          const ResizeTap* __restrict__ ytab, uint8_t* __restrict__ pyr, size_t pyr_stride,
                          int lds_pitch, int lds_rows);
+#ifndef ORBX_FAST_XCD_RUN
+#define ORBX_FAST_XCD_RUN 4
+#endif
+constexpr int kFastXcdRun = ORBX_FAST_XCD_RUN;   // neighbouring FAST cells kept on one XCD (k_fast_cells)
 constexpr int kFastThreadsDecl = 64;   // must equal kFastThreads in k_image.hip
 __global__ void k_fast_cells(const LevelInfo* __restrict__ lv, const CellInfo* __restrict__ cells, int ncells,
                              const uint8_t* __restrict__ pyr, size_t pyr_stride, int iniTh, int minTh,
