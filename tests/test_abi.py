@@ -56,3 +56,10 @@ def test_package_never_references_oracle_or_emulator():
                 assert "oracle_lib" not in txt and "liborb_oracle" not in txt and "libref_orb" not in txt, f
                 if f.endswith(".py"):
                     assert "liborbx_emu" not in txt or f == "_lib.py", f
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/orbx.h is the C ABI: it must compile as C99 with warnings as errors (no C++ types, no torch types)."""
+    src = tmp_path / "cabi.c"
+    src.write_text('#include "orbx.h"\nint main(void) { OrbxInputSpec s; OrbmFrameView f; OrbmFisheyeFrameView g; (void)s; (void)f; (void)g; return orbx_device_count() < 0; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "cabi.o")], check=True)
