@@ -2,5 +2,7 @@
 the reference's ORBextractor / ORBmatcher interfaces.  See DESIGN.md and include/orbx.h."""
 from ._lib import KP_DTYPE, OrbxError, load_hip  # noqa: F401
 from .extractor import ORBextractor  # noqa: F401
-from .matcher import ORBmatcher, ComputeStereoMatches, StereoFishEyeKnn, GetFeaturesInArea  # noqa: F401
+from .matcher import (ORBmatcher, ComputeStereoMatches, StereoFishEyeKnn, GetFeaturesInArea, AreaSearchBatch,  # noqa: F401
+                      ComputeDistinctiveDescriptors)
+from .vocabulary import ORBVocabulary  # noqa: F401
 from . import views  # noqa: F401
