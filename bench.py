@@ -111,9 +111,18 @@ def main():
     if world > 1 or os.environ.get("ORBX_BENCH_FORCE_DIST") == "1":    # the env switch lets a 1-GPU box exercise the torch.distributed path
         import torch
         import torch.distributed as dist_
+        # ORBX_BENCH_BACKEND=gloo: test switch - several ranks may then share one GPU (RCCL refuses that), which lets a 1-GPU box run the
+        # multi-process path end to end; the barrier and the max-reduce go over CPU tensors in that case
+        backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")
+        ndev = torch.cuda.device_count()
+        local = local % max(ndev, 1)
         torch.cuda.set_device(local)
-        dist_.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist_.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist_.init_process_group(backend)
         dist = dist_
+        dist_dev = "cuda" if backend == "nccl" else "cpu"
 
     from orb_slam3_detailed_comments_amd import ORBextractor, load_hip, synth
     lib = load_hip()
@@ -196,7 +205,7 @@ def main():
         sys.stderr.write("debug: run %.2f ms, closing sync %.2f ms\n" % ((ta - t0) * 1e3, (time.perf_counter() - ta) * 1e3))
     if dist is not None:
         import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=dist_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
