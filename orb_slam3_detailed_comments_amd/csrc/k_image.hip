@@ -45,13 +45,13 @@ __global__ void __launch_bounds__(256) k_resize(const LevelInfo* __restrict__ lv
     const LevelInfo S = lv[level - 1];
     const int b = (int)blockIdx.z;
     const int tid = (int)(threadIdx.y * 64 + threadIdx.x);
-    const int dxb = (int)blockIdx.x * 256, dyb = (int)blockIdx.y * 8;
+    const int dxb = (int)blockIdx.x * 256, dyb = (int)blockIdx.y * kResizeRows;
     const uint8_t* src = pyr + (size_t)b * pyr_stride + S.off;
     uint8_t* dst = pyr + (size_t)b * pyr_stride + D.off;
     const ResizeTap* xt = xtab + D.xtab_off;
     const ResizeTap* yt = ytab + D.ytab_off;
     // source window of this tile (block-uniform)
-    const int dx_last = imin(dxb + 255, D.w - 1), dy_last = imin(dyb + 7, D.h - 1);
+    const int dx_last = imin(dxb + 255, D.w - 1), dy_last = imin(dyb + kResizeRows - 1, D.h - 1);
     const int gx0 = xt[imin(dxb, D.w - 1)].ofs & ~3;
     const int sx_hi = imin(xt[dx_last].ofs + 1, S.w - 1);
     const int ncd = imin(((sx_hi - gx0) >> 2) + 1, lds_pitch >> 2);
@@ -60,11 +60,11 @@ __global__ void __launch_bounds__(256) k_resize(const LevelInfo* __restrict__ lv
     const int nrow = imin(sy_hi - sy_lo + 1, lds_rows);
     // this thread's interpolation taps (4 columns, 2 rows): loaded up front so that their latency overlaps the window loads
     const int dx0 = dxb + (int)threadIdx.x * 4;
-    ResizeTap txs[4], tys[2];
+    ResizeTap txs[4], tys[kResizeRows / 4];
 #pragma unroll
     for (int k = 0; k < 4; k++) txs[k] = xt[imin(dx0 + k, D.w - 1)];
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++) tys[rr] = yt[imin(dyb + (int)threadIdx.y + 4 * rr, D.h - 1)];
+    for (int rr = 0; rr < kResizeRows / 4; rr++) tys[rr] = yt[imin(dyb + (int)threadIdx.y + 4 * rr, D.h - 1)];
     {   // the window is a few dwords per thread: all of a thread's global loads are issued before the first LDS store
         const int n = nrow * ncd;
         const unsigned Mc = (1u << 20) / (unsigned)ncd + 1u;     // i / ncd == (i * Mc) >> 20 exactly for i < 2^13
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) k_resize(const LevelInfo* __restrict__ lv
         a0[k] = (int)(int16_t)(tx.w & 0xFFFF); a1[k] = tx.w >> 16;
     }
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
+    for (int rr = 0; rr < kResizeRows / 4; rr++) {
         const int dy = dyb + (int)threadIdx.y + 4 * rr;
         if (dy >= D.h) break;
         const ResizeTap ty = tys[rr];

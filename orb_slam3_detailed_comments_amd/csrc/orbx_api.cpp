@@ -230,10 +230,10 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
     stage_begin(h, ST_PYRAMID, h->s0);
     for (int l = 1; l < nl; l++) {
         const LevelInfo& L = h->lv[l]; const LevelInfo& S = h->lv[l - 1];
-        dim3 grid((L.pitch + 255) / 256, (L.h + 7) / 8, B);
+        dim3 grid((L.pitch + 255) / 256, (L.h + kResizeRows - 1) / kResizeRows, B);
         // LDS window: source span of a 256 x 8 output tile (+ alignment and the +1 neighbour)
         const int lds_pitch = (int)align_up((size_t)ceil(256.0 * S.w / L.w) + 12, 4);
-        const int lds_rows = (int)ceil(8.0 * S.h / L.h) + 3;
+        const int lds_rows = (int)ceil((double)kResizeRows * S.h / L.h) + 3;
         ORBX_LAUNCH(k_resize, grid, blk2, (size_t)lds_pitch * lds_rows, h->s0, (const LevelInfo*)h->d_lv.p, l, (const ResizeTap*)h->d_xtab.p,
                     (const ResizeTap*)h->d_ytab.p, h->d_pyr.p, h->pyr_stride, lds_pitch, lds_rows);
     }

@@ -18,6 +18,7 @@ __global__ void k_fast_cells(const LevelInfo* __restrict__ lv, const CellInfo* _
                              const uint8_t* __restrict__ pyr, size_t pyr_stride, int iniTh, int minTh,
                              uint32_t* __restrict__ slots, size_t slots_stride, int* __restrict__ cell_count,
                              int tile_bytes, int inner_bytes, int list_bytes);
+constexpr int kResizeRows = 8;         // output rows per k_resize tile (256 columns wide)
 constexpr int kBlurRows = 16;          // output rows per k_blur thread (a block covers 256 columns x 4 * kBlurRows rows)
 __global__ void k_blur(const LevelInfo* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,
                        uint8_t* __restrict__ blur, size_t pyr_stride, BlurTaps taps, BlurTiles tiles);
