@@ -20,6 +20,26 @@ __device__ __forceinline__ T wave_sum(T v) {
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
     return v;
 }
+#ifndef ORBX_EMU
+// 32-bit integers: the wave64 inclusive scan as seven DPP adds (row_shr 1,2,3 of the input, row_shr 4 / 8 with bank masks, row_bcast 15 /
+// 31 with row masks - the classic GCN sequence) instead of six ds_bpermute round trips through the LDS pipe; lanes that a step does not
+// feed add 0.  The sum is the last lane of the scan, read back as a wave-uniform scalar.
+__device__ __forceinline__ int wave_incl_scan_i32_dpp(int v) {
+    int x = v;
+    x += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);       // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);       // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, v, 0x113, 0xf, 0xf, false);       // row_shr:3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xe, false);       // row_shr:4, banks 1-3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xc, false);       // row_shr:8, banks 2-3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);       // row_bcast:15 -> rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);       // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+template <> __device__ __forceinline__ int wave_incl_scan<int>(int v) { return wave_incl_scan_i32_dpp(v); }
+template <> __device__ __forceinline__ unsigned wave_incl_scan<unsigned>(unsigned v) { return (unsigned)wave_incl_scan_i32_dpp((int)v); }
+template <> __device__ __forceinline__ int wave_sum<int>(int v) { return __builtin_amdgcn_readlane(wave_incl_scan_i32_dpp(v), 63); }
+template <> __device__ __forceinline__ unsigned wave_sum<unsigned>(unsigned v) { return (unsigned)__builtin_amdgcn_readlane(wave_incl_scan_i32_dpp((int)v), 63); }
+#endif
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { unsigned long long o = __shfl_xor(v, d); v = o < v ? o : v; }
