@@ -1,21 +1,32 @@
-/* ORBmatcher.h — drop-in facade for the part of ORB_SLAM3::ORBmatcher that this library accelerates
- * (/root/reference/include/ORBmatcher.h:36-103): constructor, DescriptorDistance, SearchByProjection(Frame&, vector<MapPoint*>&,...)
- * and the public TH_LOW / TH_HIGH / HISTO_LENGTH constants, plus ComputeStereoMatches (the body of Frame::ComputeStereoMatches,
- * src/Frame.cc:1102-1358, as a function of the Frame).
+/* ORBmatcher.h — drop-in facade for ORB_SLAM3::ORBmatcher (/root/reference/include/ORBmatcher.h:36-103): every public method of the
+ * reference class, with the reference's signatures, on top of the C ABI of include/orbx.h, plus ComputeStereoMatches (the body of
+ * Frame::ComputeStereoMatches, src/Frame.cc:1102-1358, as a function of the Frame).
  *
- * The methods are templates on the Frame / MapPoint types so that this header compiles both against the reference's real
- * classes (member names below are the reference's, include/Frame.h and include/MapPoint.h) and against the light mock structs of
- * tests/cpp/matcher_facade_test.cpp — the reference's Frame.h itself needs Eigen/Sophus/DBoW2, which are not available in the
- * build container.  The remaining overloads (Frame/Frame projection, SearchForTriangulation) are bound the same way from the C ABI
- * (orbm_search_by_projection_frame, orbm_search_for_triangulation); INTEGRATION.md has the snippets, since their view construction
- * needs Sophus poses.
+ * Division of labour (the same for every method): the facade runs the head of the reference's per-point loop on the host with the
+ * caller's own Sophus / Eigen / GeometricCamera code (pose * point, project, IsInImage, distance and viewing-angle gates, PredictScale) and
+ * hands the survivors to the library as numbers; window search, level gates, every Hamming distance and the accept loop run on the
+ * device; the facade then writes the result back into the caller's objects exactly where the reference would have.
+ *
+ * The methods are templates on the Frame / KeyFrame / MapPoint (and Sim3) types, and the geometric types are taken from the return types
+ * of their accessors, so this header needs neither Eigen nor Sophus itself.  It compiles against the reference's real classes (member
+ * names below are the reference's: include/Frame.h, include/KeyFrame.h, include/MapPoint.h), against the stand-in world of
+ * oracle/slam_shim (tests/cpp/matcher_world_driver.cpp drives this facade and the reference's own compiled ORBmatcher.cc with identical
+ * objects and compares every output) and against the light mocks of tests/cpp/matcher_facade_test.cpp.
+ *
+ * Not accelerated, reported with an exception instead of a silent CPU path: the two-camera (fisheye rig) branches of SearchByBoW,
+ * SearchForTriangulation and Fuse.
  */
 #ifndef ORB_SLAM3_AMD_ORBMATCHER_H
 #define ORB_SLAM3_AMD_ORBMATCHER_H
 
+#include <cmath>
+#include <cstring>
 #include <mutex>
+#include <set>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 #include <opencv2/opencv.hpp>
 #include "../orbx.h"
@@ -25,6 +36,8 @@ namespace ORB_SLAM3
 
 class ORBmatcher
 {
+    template <class X> using Decay = typename std::decay<X>::type;
+
 public:
     ORBmatcher(float nnratio=0.6, bool checkOri=true): mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
 
@@ -46,36 +59,468 @@ public:
     }
 
     // Search matches between Frame keypoints and projected MapPoints. Returns number of matches
-    // Used to track the local map (Tracking)   — src/ORBmatcher.cc:45-239, non-fisheye path (F.Nleft == -1)
+    // Used to track the local map (Tracking)   — src/ORBmatcher.cc:45-239, both the one-camera and the fisheye-rig (F.Nleft != -1) path
     template <class FrameT, class MapPointT>
     int SearchByProjection(FrameT &F, const std::vector<MapPointT*> &vpMapPoints, const float th=3, const bool bFarPoints = false, const float thFarPoints = 50.0f)
     {
-        if (F.Nleft != -1) throw std::runtime_error("ORBmatcher (HIP): the fisheye (Nleft != -1) path is not accelerated");
-        const int N = F.N, M = (int)vpMapPoints.size();
-        std::vector<OrbxKeyPoint> keys(N); std::vector<uint8_t> occ(N, 0);
-        for (int i = 0; i < N; i++) {
-            const cv::KeyPoint& k = F.mvKeysUn[i];
-            keys[i].x = k.pt.x; keys[i].y = k.pt.y; keys[i].size = k.size; keys[i].angle = k.angle; keys[i].response = k.response; keys[i].octave = k.octave; keys[i].class_id = k.class_id;
-            if (F.mvpMapPoints[i]) occ[i] = F.mvpMapPoints[i]->Observations() > 0;
-        }
-        std::vector<uint8_t> inView(M), bad(M), hasObs(M), desc((size_t)M * 32);
-        std::vector<float> px(M), py(M), pxr(M), vcos(M), depth(M); std::vector<int> lvl(M);
+        const int M = (int)vpMapPoints.size();
+        const bool rig = F.Nleft != -1;
+        std::vector<uint8_t> inView(M), bad(M), hasObs(M), desc((size_t)M * 32), inViewR(M);
+        std::vector<float> px(M), py(M), pxr(M), vcos(M), depth(M), pyr(M), vcosR(M); std::vector<int> lvl(M), lvlR(M);
         for (int i = 0; i < M; i++) {
             MapPointT* p = vpMapPoints[i];
-            inView[i] = p->mbTrackInView; bad[i] = p->isBad(); hasObs[i] = p->Observations() > 0;
-            px[i] = p->mTrackProjX; py[i] = p->mTrackProjY; pxr[i] = p->mTrackProjXR; vcos[i] = p->mTrackViewCos; depth[i] = p->mTrackDepth;
-            lvl[i] = p->mnTrackScaleLevel;
-            const cv::Mat d = p->GetDescriptor();
-            memcpy(&desc[(size_t)i * 32], d.ptr(0), 32);
+            inView[i] = p->mbTrackInView; inViewR[i] = p->mbTrackInViewR; bad[i] = p->isBad(); hasObs[i] = p->Observations() > 0;
+            px[i] = p->mTrackProjX; py[i] = p->mTrackProjY; pxr[i] = p->mTrackProjXR; pyr[i] = p->mTrackProjYR; vcos[i] = p->mTrackViewCos; vcosR[i] = p->mTrackViewCosR;
+            depth[i] = p->mTrackDepth; lvl[i] = p->mnTrackScaleLevel; lvlR[i] = p->mnTrackScaleLevelR;
+            CopyDescriptor(p, &desc[(size_t)i * 32]);
         }
-        OrbmFrameView fv; FillFrameView(F, keys, occ, fv);
         OrbmMapPointView mv = {M, inView.data(), px.data(), py.data(), pxr.data(), lvl.data(), vcos.data(), depth.data(), bad.data(), hasObs.data(), desc.data()};
-        std::vector<int> assigned(N > 0 ? N : 1, -1);
         int nmatches = 0;
-        std::lock_guard<std::mutex> lock(Mutex());      // the reference's matchers are re-entrant (Tracking / LocalMapping / LoopClosing threads); one handle is not
-        Check(orbm_search_by_projection_mappoints(SharedHandle(), &fv, &mv, th, bFarPoints, thFarPoints, mfNNratio, assigned.data(), &nmatches));
-        for (int i = 0; i < N; i++) if (assigned[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[assigned[i]];
+        std::vector<int> assigned;
+        if (!rig) {
+            FrameStore fs; FillFrame(F, fs, OccupiedWithObservations);
+            assigned.assign(F.N > 0 ? F.N : 1, -1);
+            std::lock_guard<std::mutex> lock(Mutex());      // the reference's matchers are re-entrant (Tracking / LocalMapping / LoopClosing threads); one handle is not
+            Check(orbm_search_by_projection_mappoints(SharedHandle(), &fs.v, &mv, th, bFarPoints, thFarPoints, mfNNratio, assigned.data(), &nmatches));
+        } else {
+            RigStore rs; FillRig(F, rs, OccupiedWithObservations);
+            OrbmMapPointRightView mr = {inViewR.data(), pxr.data(), pyr.data(), lvlR.data(), vcosR.data()};
+            assigned.assign(F.N > 0 ? F.N : 1, -1);
+            std::lock_guard<std::mutex> lock(Mutex());
+            Check(orbm_search_by_projection_mappoints_fisheye(SharedHandle(), &rs.v, &mv, &mr, th, bFarPoints, thFarPoints, mfNNratio, assigned.data(), &nmatches));
+        }
+        for (int i = 0; i < F.N; i++) if (assigned[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[assigned[i]];
         return nmatches;
+    }
+
+    // Project MapPoints tracked in last frame into the current frame and search matches.
+    // Used to track from previous frame (Tracking)   — src/ORBmatcher.cc:1950-2184
+    template <class FrameT>
+    int SearchByProjection(FrameT &CurrentFrame, const FrameT &LastFrame, const float th, const bool bMono)
+    {
+        const auto Tcw = CurrentFrame.GetPose();
+        typedef Decay<decltype(Tcw.translation())> Vec3;
+        typedef Decay<decltype(CurrentFrame.mpCamera->project(std::declval<Vec3>()))> Vec2;
+        const Vec3 twc = Tcw.inverse().translation();
+        const auto Tlw = LastFrame.GetPose();
+        const Vec3 tlc = Tlw * twc;
+        const bool bForward = tlc(2)>CurrentFrame.mb && !bMono;
+        const bool bBackward = -tlc(2)>CurrentFrame.mb && !bMono;
+        const bool rig = CurrentFrame.Nleft != -1;
+
+        const int NL = LastFrame.N;
+        std::vector<uint8_t> valid(NL, 0), hasObs(NL, 0), desc((size_t)NL * 32, 0);
+        std::vector<float> pu(NL, 0), pv(NL, 0), invz(NL, 0), ang(NL, 0), pur(NL, 0), pvr(NL, 0); std::vector<int> oct(NL, 0);
+        for (int i = 0; i < NL; i++) {
+            auto* pMP = LastFrame.mvpMapPoints[i];
+            if (!pMP || LastFrame.mvbOutlier[i]) continue;
+            Vec3 x3Dw = pMP->GetWorldPos();
+            Vec3 x3Dc = Tcw * x3Dw;
+            const float invzc = 1.0/x3Dc(2);
+            if (invzc<0) continue;
+            Vec2 uv = CurrentFrame.mpCamera->project(x3Dc);
+            if (uv(0)<CurrentFrame.mnMinX || uv(0)>CurrentFrame.mnMaxX) continue;
+            if (uv(1)<CurrentFrame.mnMinY || uv(1)>CurrentFrame.mnMaxY) continue;
+            valid[i] = 1; pu[i] = uv(0); pv[i] = uv(1); invz[i] = invzc;
+            oct[i] = (LastFrame.Nleft == -1 || i < LastFrame.Nleft) ? LastFrame.mvKeys[i].octave : LastFrame.mvKeysRight[i - LastFrame.Nleft].octave;
+            ang[i] = ((LastFrame.Nleft == -1) ? LastFrame.mvKeysUn[i] : (i < LastFrame.Nleft) ? LastFrame.mvKeys[i] : LastFrame.mvKeysRight[i - LastFrame.Nleft]).angle;
+            hasObs[i] = pMP->Observations() > 0;
+            CopyDescriptor(pMP, &desc[(size_t)i * 32]);
+            if (rig) {
+                Vec3 x3Dr = CurrentFrame.GetRelativePoseTrl() * x3Dc;
+                Vec2 uvr = CurrentFrame.mpCamera->project(x3Dr);
+                pur[i] = uvr(0); pvr[i] = uvr(1);
+            }
+        }
+        OrbmLastFrameView lv = {NL, valid.data(), pu.data(), pv.data(), invz.data(), oct.data(), ang.data(), hasObs.data(), desc.data()};
+        std::vector<int> assigned(CurrentFrame.N > 0 ? CurrentFrame.N : 1, -1);
+        int nmatches = 0;
+        if (!rig) {
+            FrameStore fs; FillFrame(CurrentFrame, fs, OccupiedWithObservations);
+            std::lock_guard<std::mutex> lock(Mutex());
+            Check(orbm_search_by_projection_frame(SharedHandle(), &fs.v, &lv, th, bForward, bBackward, mbCheckOrientation, assigned.data(), &nmatches));
+        } else {
+            RigStore rs; FillRig(CurrentFrame, rs, OccupiedWithObservations);
+            std::lock_guard<std::mutex> lock(Mutex());
+            Check(orbm_search_by_projection_frame_fisheye(SharedHandle(), &rs.v, &lv, pur.data(), pvr.data(), th, bForward, bBackward, mbCheckOrientation,
+                                                          assigned.data(), &nmatches));
+        }
+        for (int i = 0; i < CurrentFrame.N; i++) {
+            if (assigned[i] >= 0) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[assigned[i]];
+            else if (assigned[i] == -2) CurrentFrame.mvpMapPoints[i] = nullptr;
+        }
+        return nmatches;
+    }
+
+    // Project MapPoints seen in KeyFrame into the Frame and search matches.
+    // Used in relocalisation (Tracking)   — src/ORBmatcher.cc:2196-2324
+    template <class FrameT, class KeyFrameT, class MapPointT>
+    int SearchByProjection(FrameT &CurrentFrame, KeyFrameT* pKF, const std::set<MapPointT*> &sAlreadyFound, const float th, const int ORBdist)
+    {
+        const auto Tcw = CurrentFrame.GetPose();
+        typedef Decay<decltype(Tcw.translation())> Vec3;
+        typedef Decay<decltype(CurrentFrame.mpCamera->project(std::declval<Vec3>()))> Vec2;
+        Vec3 Ow = Tcw.inverse().translation();
+        const std::vector<MapPointT*> vpMPs = pKF->GetMapPointMatches();
+        const int M = (int)vpMPs.size();
+        ProjStore ps(M);
+        for (int i = 0; i < M; i++) {
+            MapPointT* pMP = vpMPs[i];
+            if (!pMP || pMP->isBad() || sAlreadyFound.count(pMP)) continue;
+            Vec3 x3Dw = pMP->GetWorldPos();
+            Vec3 x3Dc = Tcw * x3Dw;
+            const Vec2 uv = CurrentFrame.mpCamera->project(x3Dc);
+            if (uv(0)<CurrentFrame.mnMinX || uv(0)>CurrentFrame.mnMaxX) continue;
+            if (uv(1)<CurrentFrame.mnMinY || uv(1)>CurrentFrame.mnMaxY) continue;
+            Vec3 PO = x3Dw-Ow;
+            float dist3D = PO.norm();
+            const float maxDistance = pMP->GetMaxDistanceInvariance();
+            const float minDistance = pMP->GetMinDistanceInvariance();
+            if (dist3D<minDistance || dist3D>maxDistance) continue;
+            ps.set(i, uv(0), uv(1), 0.0f, pMP->PredictScale(dist3D,&CurrentFrame), pKF->mvKeysUn[i].angle);
+            CopyDescriptor(pMP, ps.descAt(i));
+        }
+        FrameStore fs; FillFrame(CurrentFrame, fs, OccupiedAny);
+        std::vector<int> assigned(CurrentFrame.N > 0 ? CurrentFrame.N : 1, -1);
+        int nmatches = 0;
+        {
+            std::lock_guard<std::mutex> lock(Mutex());
+            Check(orbm_search_by_projection_keyframe(SharedHandle(), &fs.v, ps.view(), th, ORBdist, mbCheckOrientation, assigned.data(), &nmatches));
+        }
+        for (int i = 0; i < CurrentFrame.N; i++) {
+            if (assigned[i] >= 0) CurrentFrame.mvpMapPoints[i] = vpMPs[assigned[i]];
+            else if (assigned[i] == -2) CurrentFrame.mvpMapPoints[i] = nullptr;
+        }
+        return nmatches;
+    }
+
+    // Project MapPoints using a Similarity Transformation and search matches.
+    // Used in loop detection (Loop Closing)   — src/ORBmatcher.cc:495-606
+    template <class KeyFrameT, class Sim3T, class MapPointT>
+    int SearchByProjection(KeyFrameT* pKF, Sim3T &Scw, const std::vector<MapPointT*> &vpPoints, std::vector<MapPointT*> &vpMatched, int th, float ratioHamming=1.0)
+    {
+        std::vector<int> assigned;
+        const int n = SearchBySim3Projection(pKF, Scw, vpPoints, vpMatched, th, ratioHamming, /*inlineProjection=*/false, assigned);
+        for (size_t idx = 0; idx < vpMatched.size(); idx++) if (assigned[idx] >= 0) vpMatched[idx] = vpPoints[assigned[idx]];
+        return n;
+    }
+
+    // Project MapPoints using a Similarity Transformation and search matches.
+    // Used in Place Recognition (Loop Closing and Merging)   — src/ORBmatcher.cc:608-732
+    template <class KeyFrameT, class Sim3T, class MapPointT>
+    int SearchByProjection(KeyFrameT* pKF, Sim3T &Scw, const std::vector<MapPointT*> &vpPoints, const std::vector<KeyFrameT*> &vpPointsKFs,
+                           std::vector<MapPointT*> &vpMatched, std::vector<KeyFrameT*> &vpMatchedKF, int th, float ratioHamming=1.0)
+    {
+        std::vector<int> assigned;
+        const int n = SearchBySim3Projection(pKF, Scw, vpPoints, vpMatched, th, ratioHamming, /*inlineProjection=*/true, assigned);
+        for (size_t idx = 0; idx < vpMatched.size(); idx++)
+            if (assigned[idx] >= 0) { vpMatched[idx] = vpPoints[assigned[idx]]; vpMatchedKF[idx] = vpPointsKFs[assigned[idx]]; }
+        return n;
+    }
+
+    // Search matches between MapPoints in a KeyFrame and ORB in a Frame.
+    // Brute force constrained to ORB that belong to the same vocabulary node (at a certain level)
+    // Used in Relocalisation and Loop Detection   — src/ORBmatcher.cc:259-493 (one camera)
+    template <class KeyFrameT, class FrameT, class MapPointT>
+    int SearchByBoW(KeyFrameT* pKF, FrameT &F, std::vector<MapPointT*> &vpMapPointMatches)
+    {
+        if (F.Nleft != -1 || pKF->mpCamera2) throw std::runtime_error("ORBmatcher (HIP): the fisheye-rig path of SearchByBoW is not accelerated");
+        const std::vector<MapPointT*> vpMapPointsKF = pKF->GetMapPointMatches();
+        vpMapPointMatches = std::vector<MapPointT*>(F.N,static_cast<MapPointT*>(NULL));
+        BowStore k1, k2;
+        FillBow(*pKF, pKF->N, k1); FillBow(F, F.N, k2);
+        k1.present.assign(pKF->N, 0);
+        for (int i = 0; i < pKF->N; i++) k1.present[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();
+        k1.v.has_map_point = k1.present.data();
+        k2.v.has_map_point = nullptr;
+        std::vector<int> m12(pKF->N > 0 ? pKF->N : 1, -1);
+        int nmatches = 0;
+        {
+            std::lock_guard<std::mutex> lock(Mutex());
+            Check(orbm_search_by_bow(SharedHandle(), &k1.v, &k2.v, mfNNratio, 1, mbCheckOrientation, m12.data(), &nmatches));
+        }
+        for (int i = 0; i < pKF->N; i++) if (m12[i] >= 0) vpMapPointMatches[m12[i]] = vpMapPointsKF[i];
+        return nmatches;
+    }
+    // src/ORBmatcher.cc:892-1043
+    template <class KeyFrameT, class MapPointT>
+    int SearchByBoW(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*> &vpMatches12)
+    {
+        if (pKF1->NLeft != -1 || pKF2->NLeft != -1) throw std::runtime_error("ORBmatcher (HIP): the fisheye-rig path of SearchByBoW is not accelerated");
+        const std::vector<MapPointT*> vpMapPoints1 = pKF1->GetMapPointMatches();
+        const std::vector<MapPointT*> vpMapPoints2 = pKF2->GetMapPointMatches();
+        vpMatches12 = std::vector<MapPointT*>(vpMapPoints1.size(),static_cast<MapPointT*>(NULL));
+        BowStore k1, k2;
+        FillBow(*pKF1, (int)vpMapPoints1.size(), k1); FillBow(*pKF2, (int)vpMapPoints2.size(), k2);
+        k1.present.assign(vpMapPoints1.size(), 0); k2.present.assign(vpMapPoints2.size(), 0);
+        for (size_t i = 0; i < vpMapPoints1.size(); i++) k1.present[i] = vpMapPoints1[i] && !vpMapPoints1[i]->isBad();
+        for (size_t i = 0; i < vpMapPoints2.size(); i++) k2.present[i] = vpMapPoints2[i] && !vpMapPoints2[i]->isBad();
+        k1.v.has_map_point = k1.present.data(); k2.v.has_map_point = k2.present.data();
+        std::vector<int> m12(vpMapPoints1.size() > 0 ? vpMapPoints1.size() : 1, -1);
+        int nmatches = 0;
+        {
+            std::lock_guard<std::mutex> lock(Mutex());
+            Check(orbm_search_by_bow(SharedHandle(), &k1.v, &k2.v, mfNNratio, 0, mbCheckOrientation, m12.data(), &nmatches));
+        }
+        for (size_t i = 0; i < vpMapPoints1.size(); i++) if (m12[i] >= 0) vpMatches12[i] = vpMapPoints2[m12[i]];
+        return nmatches;
+    }
+
+    // Matching for the Map Initialization (only used in the monocular case)   — src/ORBmatcher.cc:734-880
+    template <class FrameT>
+    int SearchForInitialization(FrameT &F1, FrameT &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize=10)
+    {
+        const int N1 = (int)F1.mvKeysUn.size();
+        vnMatches12 = std::vector<int>(N1,-1);
+        FrameStore f1, f2; FillFrame(F1, f1); FillFrame(F2, f2);
+        std::vector<float> prev((size_t)N1 * 2 + 2);
+        for (int i = 0; i < N1; i++) { prev[2 * i] = vbPrevMatched[i].x; prev[2 * i + 1] = vbPrevMatched[i].y; }
+        int nmatches = 0;
+        std::vector<int> m12(N1 > 0 ? N1 : 1, -1);
+        {
+            std::lock_guard<std::mutex> lock(Mutex());
+            Check(orbm_search_for_initialization(SharedHandle(), &f1.v, &f2.v, prev.data(), windowSize, mfNNratio, mbCheckOrientation, m12.data(), &nmatches));
+        }
+        for (int i = 0; i < N1; i++) { vnMatches12[i] = m12[i]; vbPrevMatched[i].x = prev[2 * i]; vbPrevMatched[i].y = prev[2 * i + 1]; }
+        return nmatches;
+    }
+
+    // Matching to triangulate new MapPoints. Check Epipolar Constraint.   — src/ORBmatcher.cc:1045-1323 (pinhole, one camera)
+    template <class KeyFrameT>
+    int SearchForTriangulation(KeyFrameT *pKF1, KeyFrameT* pKF2, std::vector<std::pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo, const bool bCoarse = false)
+    {
+        if (pKF1->mpCamera2 || pKF2->mpCamera2) throw std::runtime_error("ORBmatcher (HIP): the fisheye-rig path of SearchForTriangulation is not accelerated");
+        auto T1w = pKF1->GetPose();
+        auto T2w = pKF2->GetPose();
+        auto Tw2 = pKF2->GetPoseInverse();
+        typedef Decay<decltype(T1w.translation())> Vec3;
+        typedef Decay<decltype(T1w.rotationMatrix())> Mat3;
+        typedef Decay<decltype(pKF2->mpCamera->project(std::declval<Vec3>()))> Vec2;
+        Vec3 Cw = pKF1->GetCameraCenter();
+        Vec3 C2 = T2w * Cw;
+        Vec2 ep = pKF2->mpCamera->project(C2);
+        auto T12 = T1w * Tw2;
+        Mat3 R12 = T12.rotationMatrix();
+        Vec3 t12 = T12.translation();
+        // the fundamental matrix of Pinhole::epipolarConstrain (src/CameraModels/Pinhole.cpp:191-194), evaluated once instead of per pair
+        Mat3 t12x = R12;
+        t12x(0,0) = 0; t12x(0,1) = -t12(2); t12x(0,2) = t12(1); t12x(1,0) = t12(2); t12x(1,1) = 0; t12x(1,2) = -t12(0); t12x(2,0) = -t12(1); t12x(2,1) = t12(0); t12x(2,2) = 0;
+        Mat3 K1 = pKF1->mpCamera->toK_();
+        Mat3 K2 = pKF2->mpCamera->toK_();
+        Mat3 F12 = K1.transpose().inverse() * t12x * R12 * K2.inverse();
+        float f12[9], epf[2] = {ep(0), ep(1)};
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) f12[r * 3 + c] = F12(r, c);
+
+        BowStore k1, k2;
+        FillBow(*pKF1, pKF1->N, k1); FillBow(*pKF2, pKF2->N, k2);
+        k1.present.assign(pKF1->N, 0); k2.present.assign(pKF2->N, 0);
+        for (int i = 0; i < pKF1->N; i++) k1.present[i] = pKF1->GetMapPoint(i) != nullptr;
+        for (int i = 0; i < pKF2->N; i++) k2.present[i] = pKF2->GetMapPoint(i) != nullptr;
+        k1.v.has_map_point = k1.present.data(); k2.v.has_map_point = k2.present.data();
+        std::vector<int> m12(pKF1->N > 0 ? pKF1->N : 1, -1);
+        int nmatches = 0;
+        {
+            std::lock_guard<std::mutex> lock(Mutex());
+            Check(orbm_search_for_triangulation(SharedHandle(), &k1.v, &k2.v, f12, epf, bOnlyStereo, bCoarse, mbCheckOrientation, m12.data(), &nmatches));
+        }
+        vMatchedPairs.clear();
+        vMatchedPairs.reserve(nmatches);
+        for (int i = 0; i < pKF1->N; i++) if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m12[i]));
+        return nmatches;
+    }
+
+    // Search matches between MapPoints seen in KF1 and KF2 transforming by a Sim3 [s12*R12|t12]
+    // In the stereo and RGB-D case, s12=1   — src/ORBmatcher.cc:1689-1932
+    template <class KeyFrameT, class MapPointT, class Sim3T>
+    int SearchBySim3(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT *> &vpMatches12, const Sim3T &S12, const float th)
+    {
+        const float &fx = pKF1->fx;
+        const float &fy = pKF1->fy;
+        const float &cx = pKF1->cx;
+        const float &cy = pKF1->cy;
+        auto T1w = pKF1->GetPose();
+        auto T2w = pKF2->GetPose();
+        typedef Decay<decltype(T1w.translation())> Vec3;
+        Sim3T S21 = S12.inverse();
+        const std::vector<MapPointT*> vpMapPoints1 = pKF1->GetMapPointMatches();
+        const int N1 = vpMapPoints1.size();
+        const std::vector<MapPointT*> vpMapPoints2 = pKF2->GetMapPointMatches();
+        const int N2 = vpMapPoints2.size();
+        std::vector<bool> vbAlreadyMatched1(N1,false), vbAlreadyMatched2(N2,false);
+        for (int i=0; i<N1; i++) {
+            MapPointT* pMP = vpMatches12[i];
+            if (pMP) {
+                vbAlreadyMatched1[i]=true;
+                int idx2 = std::get<0>(pMP->GetIndexInKeyFrame(pKF2));
+                if (idx2>=0 && idx2<N2) vbAlreadyMatched2[idx2]=true;
+            }
+        }
+        ProjStore p1(N1), p2(N2);
+        for (int i1=0; i1<N1; i1++) {                       // map points of KF1 into KF2
+            MapPointT* pMP = vpMapPoints1[i1];
+            if (!pMP || vbAlreadyMatched1[i1] || pMP->isBad()) continue;
+            Vec3 p3Dw = pMP->GetWorldPos();
+            Vec3 p3Dc1 = T1w * p3Dw;
+            Vec3 p3Dc2 = S21 * p3Dc1;
+            if (p3Dc2(2)<0.0) continue;
+            const float invz = 1.0/p3Dc2(2);
+            const float x = p3Dc2(0)*invz;
+            const float y = p3Dc2(1)*invz;
+            const float u = fx*x+cx;
+            const float v = fy*y+cy;
+            if (!pKF2->IsInImage(u,v)) continue;
+            const float maxDistance = pMP->GetMaxDistanceInvariance();
+            const float minDistance = pMP->GetMinDistanceInvariance();
+            const float dist3D = p3Dc2.norm();
+            if (dist3D<minDistance || dist3D>maxDistance ) continue;
+            p1.set(i1, u, v, 0.0f, pMP->PredictScale(dist3D,pKF2), 0.0f);
+            CopyDescriptor(pMP, p1.descAt(i1));
+        }
+        for (int i2=0; i2<N2; i2++) {                       // map points of KF2 into KF1
+            MapPointT* pMP = vpMapPoints2[i2];
+            if (!pMP || vbAlreadyMatched2[i2] || pMP->isBad()) continue;
+            Vec3 p3Dw = pMP->GetWorldPos();
+            Vec3 p3Dc2 = T2w * p3Dw;
+            Vec3 p3Dc1 = S12 * p3Dc2;
+            if (p3Dc1(2)<0.0) continue;
+            const float invz = 1.0/p3Dc1(2);
+            const float x = p3Dc1(0)*invz;
+            const float y = p3Dc1(1)*invz;
+            const float u = fx*x+cx;
+            const float v = fy*y+cy;
+            if (!pKF1->IsInImage(u,v)) continue;
+            const float maxDistance = pMP->GetMaxDistanceInvariance();
+            const float minDistance = pMP->GetMinDistanceInvariance();
+            const float dist3D = p3Dc1.norm();
+            if (dist3D<minDistance || dist3D>maxDistance) continue;
+            p2.set(i2, u, v, 0.0f, pMP->PredictScale(dist3D,pKF1), 0.0f);
+            CopyDescriptor(pMP, p2.descAt(i2));
+        }
+        FrameStore f1, f2; FillFrame(*pKF1, f1); FillFrame(*pKF2, f2);
+        std::vector<int> m12(N1 > 0 ? N1 : 1, -1);
+        int nFound = 0;
+        {
+            std::lock_guard<std::mutex> lock(Mutex());
+            Check(orbm_search_by_sim3(SharedHandle(), &f1.v, &f2.v, p1.view(), p2.view(), th, m12.data(), &nFound));
+        }
+        for (int i1 = 0; i1 < N1; i1++) if (m12[i1] >= 0) vpMatches12[i1] = vpMapPoints2[m12[i1]];
+        return nFound;
+    }
+
+    // Project MapPoints into KeyFrame and search for duplicated MapPoints.   — src/ORBmatcher.cc:1325-1528
+    template <class KeyFrameT, class MapPointT>
+    int Fuse(KeyFrameT* pKF, const std::vector<MapPointT *> &vpMapPoints, const float th=3.0, const bool bRight = false)
+    {
+        if (bRight || pKF->NLeft != -1) throw std::runtime_error("ORBmatcher (HIP): the fisheye-rig path of Fuse is not accelerated");
+        auto Tcw = pKF->GetPose();
+        typedef Decay<decltype(Tcw.translation())> Vec3;
+        typedef Decay<decltype(pKF->mpCamera->project(std::declval<Vec3>()))> Vec2;
+        Vec3 Ow = pKF->GetCameraCenter();
+        auto* pCamera = pKF->mpCamera;
+        const float &bf = pKF->mbf;
+        const int nMPs = vpMapPoints.size();
+        // geometry of every point that could reach the window search.  Whether it does is decided again in the replay loop below: the
+        // reference's bad / IsInKeyFrame tests read state that earlier iterations of its loop may have changed (Replace, AddObservation).
+        ProjStore ps(nMPs);
+        for (int i=0; i<nMPs; i++) {
+            MapPointT* pMP = vpMapPoints[i];
+            if (!pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+            Vec3 p3Dw = pMP->GetWorldPos();
+            Vec3 p3Dc = Tcw * p3Dw;
+            if (p3Dc(2)<0.0f) continue;
+            const float invz = 1/p3Dc(2);
+            const Vec2 uv = pCamera->project(p3Dc);
+            if (!pKF->IsInImage(uv(0),uv(1))) continue;
+            const float ur = uv(0)-bf*invz;
+            const float maxDistance = pMP->GetMaxDistanceInvariance();
+            const float minDistance = pMP->GetMinDistanceInvariance();
+            Vec3 PO = p3Dw-Ow;
+            const float dist3D = PO.norm();
+            if (dist3D<minDistance || dist3D>maxDistance) continue;
+            Vec3 Pn = pMP->GetNormal();
+            if (PO.dot(Pn)<0.5*dist3D) continue;
+            ps.set(i, uv(0), uv(1), ur, pMP->PredictScale(dist3D,pKF), 0.0f);
+            CopyDescriptor(pMP, ps.descAt(i));
+        }
+        FrameStore fs; FillFrame(*pKF, fs);
+        std::vector<int> best(nMPs > 0 ? nMPs : 1, -1);
+        {
+            std::lock_guard<std::mutex> lock(Mutex());
+            Check(orbm_fuse_candidates(SharedHandle(), &fs.v, ps.view(), th, 1, pKF->mvInvLevelSigma2.data(), best.data(), nullptr));
+        }
+        int nFused=0;
+        for (int i=0; i<nMPs; i++) {                        // the map surgery of :1494-1520, in the reference's order
+            MapPointT* pMP = vpMapPoints[i];
+            if (!pMP || !ps.valid[i] || best[i] < 0) continue;
+            if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+            const int bestIdx = best[i];
+            MapPointT* pMPinKF = pKF->GetMapPoint(bestIdx);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) {
+                    if (pMPinKF->Observations()>pMP->Observations()) pMP->Replace(pMPinKF);
+                    else pMPinKF->Replace(pMP);
+                }
+            } else {
+                pMP->AddObservation(pKF,bestIdx);
+                pKF->AddMapPoint(pMP,bestIdx);
+            }
+            nFused++;
+        }
+        return nFused;
+    }
+
+    // Project MapPoints into KeyFrame using a given Sim3 and search for duplicated MapPoints.   — src/ORBmatcher.cc:1543-1660
+    template <class KeyFrameT, class Sim3T, class MapPointT>
+    int Fuse(KeyFrameT* pKF, Sim3T &Scw, const std::vector<MapPointT*> &vpPoints, float th, std::vector<MapPointT *> &vpReplacePoint)
+    {
+        typedef Decay<decltype(pKF->GetPose())> SE3;
+        SE3 Tcw = SE3(Scw.rotationMatrix(),Scw.translation()/Scw.scale());
+        typedef Decay<decltype(Tcw.translation())> Vec3;
+        typedef Decay<decltype(pKF->mpCamera->project(std::declval<Vec3>()))> Vec2;
+        Vec3 Ow = Tcw.inverse().translation();
+        const std::set<MapPointT*> spAlreadyFound = pKF->GetMapPoints();
+        const int nPoints = vpPoints.size();
+        ProjStore ps(nPoints);
+        for (int iMP=0; iMP<nPoints; iMP++) {
+            MapPointT* pMP = vpPoints[iMP];
+            if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+            Vec3 p3Dw = pMP->GetWorldPos();
+            Vec3 p3Dc = Tcw * p3Dw;
+            if (p3Dc(2)<0.0f) continue;
+            const Vec2 uv = pKF->mpCamera->project(p3Dc);
+            if (!pKF->IsInImage(uv(0),uv(1))) continue;
+            const float maxDistance = pMP->GetMaxDistanceInvariance();
+            const float minDistance = pMP->GetMinDistanceInvariance();
+            Vec3 PO = p3Dw-Ow;
+            const float dist3D = PO.norm();
+            if (dist3D<minDistance || dist3D>maxDistance) continue;
+            Vec3 Pn = pMP->GetNormal();
+            if (PO.dot(Pn)<0.5*dist3D) continue;
+            ps.set(iMP, uv(0), uv(1), 0.0f, pMP->PredictScale(dist3D,pKF), 0.0f);
+            CopyDescriptor(pMP, ps.descAt(iMP));
+        }
+        FrameStore fs; FillFrame(*pKF, fs);
+        std::vector<int> best(nPoints > 0 ? nPoints : 1, -1);
+        {
+            std::lock_guard<std::mutex> lock(Mutex());
+            Check(orbm_fuse_candidates(SharedHandle(), &fs.v, ps.view(), th, 0, nullptr, best.data(), nullptr));
+        }
+        int nFused=0;
+        for (int iMP=0; iMP<nPoints; iMP++) {               // :1640-1656
+            if (!ps.valid[iMP] || best[iMP] < 0) continue;
+            MapPointT* pMP = vpPoints[iMP];
+            if (pMP->isBad()) continue;
+            const int bestIdx = best[iMP];
+            MapPointT* pMPinKF = pKF->GetMapPoint(bestIdx);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) vpReplacePoint[iMP] = pMPinKF;
+            } else {
+                pMP->AddObservation(pKF,bestIdx);
+                pKF->AddMapPoint(pMP,bestIdx);
+            }
+            nFused++;
+        }
+        return nFused;
     }
 
 public:
@@ -95,13 +540,152 @@ public:
     static void Check(int rc) { if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBmatcher (HIP): ") + orbx_last_error()); }
 
 protected:
-    template <class FrameT>
-    static void FillFrameView(FrameT& F, const std::vector<OrbxKeyPoint>& keys, const std::vector<uint8_t>& occ, OrbmFrameView& fv)
+    enum Occupancy { OccupiedAny, OccupiedWithObservations };
+
+    struct FrameStore { std::vector<OrbxKeyPoint> keys; std::vector<uint8_t> occ; OrbmFrameView v; };
+    struct RigStore { FrameStore l, r; OrbmFisheyeFrameView v; };
+    struct BowStore {
+        std::vector<OrbxKeyPoint> keys; std::vector<uint8_t> present; std::vector<uint32_t> node, feat; std::vector<int> start; OrbmKeyFrameView v;
+    };
+    // survivors of the host-side head of a projection loop
+    struct ProjStore {
+        std::vector<uint8_t> valid, desc; std::vector<float> u, v, ur, angle; std::vector<int> level; OrbmProjectedPointView pv;
+        explicit ProjStore(int M) : valid(M > 0 ? M : 1, 0), desc((size_t)(M > 0 ? M : 1) * 32, 0), u(M > 0 ? M : 1, 0), v(M > 0 ? M : 1, 0), ur(M > 0 ? M : 1, 0),
+                                    angle(M > 0 ? M : 1, 0), level(M > 0 ? M : 1, 0) { pv.M = M; }
+        void set(int i, float uu, float vv, float r, int l, float a) { valid[i] = 1; u[i] = uu; v[i] = vv; ur[i] = r; level[i] = l; angle[i] = a; }
+        uint8_t* descAt(int i) { return &desc[(size_t)i * 32]; }
+        const OrbmProjectedPointView* view() {
+            pv.valid = valid.data(); pv.u = u.data(); pv.v = v.data(); pv.ur = ur.data(); pv.pred_level = level.data(); pv.angle = angle.data(); pv.desc = desc.data();
+            return &pv;
+        }
+    };
+
+    template <class MapPointT> static void CopyDescriptor(MapPointT* p, uint8_t* dst) { const cv::Mat d = p->GetDescriptor(); memcpy(dst, d.ptr(0), 32); }
+
+    static void ConvertKeys(const std::vector<cv::KeyPoint>& in, int n, std::vector<OrbxKeyPoint>& out)
     {
-        fv.N = F.N; fv.keys_un = keys.data(); fv.desc = F.mDescriptors.ptr(0); fv.u_right = F.mvuRight.empty() ? nullptr : F.mvuRight.data();
-        fv.occupied = occ.data(); fv.min_x = F.mnMinX; fv.min_y = F.mnMinY; fv.max_x = F.mnMaxX; fv.max_y = F.mnMaxY;
+        out.resize(n > 0 ? n : 1);
+        for (int i = 0; i < n; i++) {
+            const cv::KeyPoint& k = in[i];
+            out[i].x = k.pt.x; out[i].y = k.pt.y; out[i].size = k.size; out[i].angle = k.angle; out[i].response = k.response; out[i].octave = k.octave; out[i].class_id = k.class_id;
+        }
+    }
+    template <class H> static void FillBounds(H& F, OrbmFrameView& fv)
+    {
+        fv.min_x = F.mnMinX; fv.min_y = F.mnMinY; fv.max_x = F.mnMaxX; fv.max_y = F.mnMaxY;
         fv.grid_w_inv = F.mfGridElementWidthInv; fv.grid_h_inv = F.mfGridElementHeightInv; fv.mbf = F.mbf;
         fv.nlevels = (int)F.mvScaleFactors.size(); fv.scale_factors = F.mvScaleFactors.data();
+    }
+    // Frame::mvpMapPoints is public, KeyFrame's is not: occupancy is only ever read from Frames
+    template <class FrameT> static void FillOccupancy(FrameT& F, int first, int n, Occupancy occ, std::vector<uint8_t>& out)
+    {
+        out.assign(n > 0 ? n : 1, 0);
+        for (int i = 0; i < n; i++) if (F.mvpMapPoints[first + i]) out[i] = occ == OccupiedAny ? 1 : F.mvpMapPoints[first + i]->Observations() > 0;
+    }
+    // one-camera Frame or KeyFrame as the target of a window search (nothing occupied)
+    template <class H> static void FillFrame(H& F, FrameStore& s)
+    {
+        const int N = (int)F.mvKeysUn.size();
+        ConvertKeys(F.mvKeysUn, N, s.keys);
+        s.occ.assign(N > 0 ? N : 1, 0);
+        s.v.N = N; s.v.keys_un = s.keys.data(); s.v.desc = F.mDescriptors.ptr(0); s.v.u_right = F.mvuRight.empty() ? nullptr : F.mvuRight.data();
+        s.v.occupied = s.occ.data();
+        FillBounds(F, s.v);
+    }
+    template <class FrameT> static void FillFrame(FrameT& F, FrameStore& s, Occupancy occ)
+    {
+        FillFrame(F, s);
+        FillOccupancy(F, 0, s.v.N, occ, s.occ);
+        s.v.occupied = s.occ.data();
+    }
+    // fisheye-rig Frame: camera 1 = mvKeys / rows [0, Nleft), camera 2 = mvKeysRight / rows [Nleft, N)
+    template <class FrameT> static void FillRig(FrameT& F, RigStore& s, Occupancy occ)
+    {
+        const int NL = F.Nleft, NR = F.N - F.Nleft;
+        ConvertKeys(F.mvKeys, NL, s.l.keys); ConvertKeys(F.mvKeysRight, NR, s.r.keys);
+        FillOccupancy(F, 0, NL, occ, s.l.occ); FillOccupancy(F, NL, NR, occ, s.r.occ);
+        s.l.v.N = NL; s.l.v.keys_un = s.l.keys.data(); s.l.v.desc = F.mDescriptors.ptr(0); s.l.v.u_right = nullptr; s.l.v.occupied = s.l.occ.data();
+        s.r.v.N = NR; s.r.v.keys_un = s.r.keys.data(); s.r.v.desc = F.mDescriptors.ptr(0) + (size_t)NL * 32; s.r.v.u_right = nullptr; s.r.v.occupied = s.r.occ.data();
+        FillBounds(F, s.l.v); FillBounds(F, s.r.v);
+        s.v.left = s.l.v; s.v.right = s.r.v;
+        s.v.left_to_right = F.mvLeftToRightMatch.empty() ? nullptr : F.mvLeftToRightMatch.data();
+        s.v.right_to_left = F.mvRightToLeftMatch.empty() ? nullptr : F.mvRightToLeftMatch.data();
+    }
+    // Frame or KeyFrame with its DBoW2::FeatureVector (map<NodeId, vector<unsigned>>) flattened to CSR
+    template <class H> static void FillBow(H& K, int N, BowStore& s)
+    {
+        ConvertKeys(K.mvKeysUn, N, s.keys);
+        s.node.clear(); s.feat.clear(); s.start.assign(1, 0);
+        for (auto it = K.mFeatVec.begin(); it != K.mFeatVec.end(); ++it) {
+            s.node.push_back((uint32_t)it->first);
+            for (size_t j = 0; j < it->second.size(); j++) s.feat.push_back((uint32_t)it->second[j]);
+            s.start.push_back((int)s.feat.size());
+        }
+        if (s.node.empty()) s.node.push_back(0);
+        if (s.feat.empty()) s.feat.push_back(0);
+        s.v.N = N; s.v.keys_un = s.keys.data(); s.v.desc = K.mDescriptors.ptr(0); s.v.u_right = K.mvuRight.empty() ? nullptr : K.mvuRight.data();
+        s.v.has_map_point = nullptr;
+        s.v.fv_nodes = (int)s.start.size() - 1; s.v.fv_node_id = s.node.data(); s.v.fv_start = s.start.data(); s.v.fv_feat = s.feat.data();
+        s.v.nlevels = (int)K.mvScaleFactors.size(); s.v.scale_factors = K.mvScaleFactors.data(); s.v.level_sigma2 = K.mvLevelSigma2.data();
+    }
+
+    // common body of the two SearchByProjection(KeyFrame*, Sim3, ...) overloads; they differ in how the projection is written
+    // (:534 GeometricCamera::project, :656-660 inline pinhole arithmetic with pKF->fx ...)
+    template <class KeyFrameT, class Sim3T, class MapPointT>
+    int SearchBySim3Projection(KeyFrameT* pKF, Sim3T &Scw, const std::vector<MapPointT*> &vpPoints, std::vector<MapPointT*> &vpMatched, int th, float ratioHamming,
+                               bool inlineProjection, std::vector<int>& assigned)
+    {
+        const float &fx = pKF->fx;
+        const float &fy = pKF->fy;
+        const float &cx = pKF->cx;
+        const float &cy = pKF->cy;
+        typedef Decay<decltype(pKF->GetPose())> SE3;
+        SE3 Tcw = SE3(Scw.rotationMatrix(),Scw.translation()/Scw.scale());
+        typedef Decay<decltype(Tcw.translation())> Vec3;
+        typedef Decay<decltype(pKF->mpCamera->project(std::declval<Vec3>()))> Vec2;
+        Vec3 Ow = Tcw.inverse().translation();
+        std::set<MapPointT*> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+        spAlreadyFound.erase(static_cast<MapPointT*>(NULL));
+        const int M = (int)vpPoints.size();
+        ProjStore ps(M);
+        for (int iMP=0; iMP<M; iMP++) {
+            MapPointT* pMP = vpPoints[iMP];
+            if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+            Vec3 p3Dw = pMP->GetWorldPos();
+            Vec3 p3Dc = Tcw * p3Dw;
+            if (p3Dc(2)<0.0) continue;
+            float u, v;
+            if (inlineProjection) {
+                const float invz = 1/p3Dc(2);
+                const float x = p3Dc(0)*invz;
+                const float y = p3Dc(1)*invz;
+                u = fx*x+cx;
+                v = fy*y+cy;
+            } else {
+                const Vec2 uv = pKF->mpCamera->project(p3Dc);
+                u = uv(0); v = uv(1);
+            }
+            if (!pKF->IsInImage(u,v)) continue;
+            const float maxDistance = pMP->GetMaxDistanceInvariance();
+            const float minDistance = pMP->GetMinDistanceInvariance();
+            Vec3 PO = p3Dw-Ow;
+            const float dist = PO.norm();
+            if (dist<minDistance || dist>maxDistance) continue;
+            Vec3 Pn = pMP->GetNormal();
+            if (PO.dot(Pn)<0.5*dist) continue;
+            ps.set(iMP, u, v, 0.0f, pMP->PredictScale(dist,pKF), 0.0f);
+            CopyDescriptor(pMP, ps.descAt(iMP));
+        }
+        FrameStore fs; FillFrame(*pKF, fs);
+        const int N = (int)vpMatched.size();
+        fs.occ.assign(N > 0 ? N : 1, 0);
+        for (int i = 0; i < N; i++) fs.occ[i] = vpMatched[i] != nullptr;
+        fs.v.occupied = fs.occ.data();
+        assigned.assign(N > 0 ? N : 1, -1);
+        int nmatches = 0;
+        std::lock_guard<std::mutex> lock(Mutex());
+        Check(orbm_search_by_projection_sim3(SharedHandle(), &fs.v, ps.view(), (float)th, ratioHamming, assigned.data(), &nmatches));
+        return nmatches;
     }
 
     float mfNNratio;

@@ -10,12 +10,12 @@
 #include "ORBmatcher.h"
 
 struct MockMapPoint {
-    bool mbTrackInView = true, mbTrackInViewR = false; float mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0, mTrackViewCos = 1, mTrackDepth = 1;
-    int mnTrackScaleLevel = 0; bool bad = false; int nobs = 1; cv::Mat desc;
+    bool mbTrackInView = true, mbTrackInViewR = false; float mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0, mTrackProjYR = 0, mTrackViewCos = 1, mTrackViewCosR = 1, mTrackDepth = 1;
+    int mnTrackScaleLevel = 0, mnTrackScaleLevelR = -1; bool bad = false; int nobs = 1; cv::Mat desc;
     bool isBad() { return bad; } int Observations() { return nobs; } cv::Mat GetDescriptor() { return desc; }
 };
 struct MockFrame {
-    int N = 0, Nleft = -1; std::vector<cv::KeyPoint> mvKeysUn; cv::Mat mDescriptors; std::vector<float> mvuRight, mvDepth;
+    int N = 0, Nleft = -1; std::vector<cv::KeyPoint> mvKeysUn, mvKeys, mvKeysRight; std::vector<int> mvLeftToRightMatch, mvRightToLeftMatch; cv::Mat mDescriptors; std::vector<float> mvuRight, mvDepth;
     std::vector<MockMapPoint*> mvpMapPoints; float mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0, mfGridElementWidthInv = 0, mfGridElementHeightInv = 0, mbf = 0, mb = 0;
     std::vector<float> mvScaleFactors;
 };

@@ -1,0 +1,252 @@
+// matcher_world_driver.cpp — one source, two builds (oracle/Makefile):
+//   oracle/_ref/libmw_ref.so     with the REFERENCE's own include/ORBmatcher.h + src/ORBmatcher.cc (compiled unmodified, in place)
+//   oracle/_ref/libmw_facade.so  with include/orb_slam3_amd/ORBmatcher.h (-DMW_FACADE); its orbx_* / orbm_* symbols are left undefined and
+//                                resolve against whichever library the test loaded first (the HIP build or the CPU emulator build)
+// Both see the same stand-in world (oracle/slam_shim/slam_world.h: Frame, KeyFrame, MapPoint, cameras, poses).  The C functions below
+// build a world from flat arrays, run one ORBmatcher method on it and expose everything the method may have written, so that
+// tests/test_matcher_reference.py can feed identical scenes to both libraries and compare every output bit for bit.
+#ifdef MW_FACADE
+#include "orb_slam3_amd/ORBmatcher.h"
+#else
+#include "ORBmatcher.h"
+#endif
+#include <cstdint>
+#include <cstring>
+#include <memory>
+
+using namespace ORB_SLAM3;
+
+namespace {
+struct World {
+    std::vector<std::unique_ptr<GeometricCamera>> cams;
+    std::vector<std::unique_ptr<MapPoint>> mps;
+    std::vector<std::unique_ptr<Frame>> frames;
+    std::vector<std::unique_ptr<KeyFrame>> kfs;
+    int idOf(MapPoint* p) const { return p ? p->id : -1; }
+    MapPoint* mp(int id) const { return id < 0 ? nullptr : mps[id].get(); }
+    int kfId(KeyFrame* k) const { for (size_t i = 0; i < kfs.size(); i++) if (kfs[i].get() == k) return (int)i; return -1; }
+};
+struct KP { float x, y, size, angle, response; int32_t octave, class_id; };
+
+void fill_holder(World* w, FeatureHolder& H, int N, const KP* keys, const KP* keys_un, int n_right, const KP* keys_right, const uint8_t* desc, const float* u_right,
+                 const float* pose_R, const float* pose_t, const float* trl_R, const float* trl_t, const float* bounds, int nlevels, float scale_factor, int cam, int cam2,
+                 float mbf, float mb) {
+    H.N = N;
+    const int n_left = n_right >= 0 ? N - n_right : N;
+    H.mvKeys.resize(n_left); H.mvKeysUn.resize(n_right >= 0 ? n_left : N); H.mvKeysRight.resize(n_right >= 0 ? n_right : 0);
+    auto conv = [](const KP& k) { cv::KeyPoint c(k.x, k.y, k.size, k.angle, k.response, k.octave, k.class_id); return c; };
+    for (int i = 0; i < n_left; i++) H.mvKeys[i] = conv(keys[i]);
+    for (size_t i = 0; i < H.mvKeysUn.size(); i++) H.mvKeysUn[i] = conv(keys_un[i]);
+    for (size_t i = 0; i < H.mvKeysRight.size(); i++) H.mvKeysRight[i] = conv(keys_right[i]);
+    H.mDescriptors.create(N > 0 ? N : 1, 32, CV_8UC1);
+    if (N > 0) memcpy(H.mDescriptors.data, desc, (size_t)N * 32);
+    H.mvuRight.assign(N, -1.0f);
+    if (u_right) for (int i = 0; i < N; i++) H.mvuRight[i] = u_right[i];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { H.mTcw.R(r, c) = pose_R[r * 3 + c]; H.mTrl.R(r, c) = trl_R ? trl_R[r * 3 + c] : (r == c ? 1.0f : 0.0f); }
+    for (int r = 0; r < 3; r++) { H.mTcw.t(r) = pose_t[r]; H.mTrl.t(r) = trl_t ? trl_t[r] : 0.0f; }
+    H.mnMinX = bounds[0]; H.mnMinY = bounds[1]; H.mnMaxX = bounds[2]; H.mnMaxY = bounds[3];
+    H.mfGridElementWidthInv = static_cast<float>(FRAME_GRID_COLS) / static_cast<float>(H.mnMaxX - H.mnMinX);     // src/Frame.cc:195-196
+    H.mfGridElementHeightInv = static_cast<float>(FRAME_GRID_ROWS) / static_cast<float>(H.mnMaxY - H.mnMinY);
+    H.mnScaleLevels = nlevels; H.mfLogScaleFactor = log(scale_factor);
+    H.mvScaleFactors.resize(nlevels); H.mvLevelSigma2.resize(nlevels); H.mvInvLevelSigma2.resize(nlevels);       // src/ORBextractor.cc:480-497
+    H.mvScaleFactors[0] = 1.0f; H.mvLevelSigma2[0] = 1.0f;
+    for (int i = 1; i < nlevels; i++) { H.mvScaleFactors[i] = H.mvScaleFactors[i - 1] * scale_factor; H.mvLevelSigma2[i] = H.mvScaleFactors[i] * H.mvScaleFactors[i]; }
+    for (int i = 0; i < nlevels; i++) H.mvInvLevelSigma2[i] = 1.0f / H.mvLevelSigma2[i];
+    H.mpCamera = w->cams[cam].get(); H.mpCamera2 = cam2 >= 0 ? w->cams[cam2].get() : nullptr;
+    H.fx = H.mpCamera->mvParameters[0]; H.fy = H.mpCamera->mvParameters[1]; H.cx = H.mpCamera->mvParameters[2]; H.cy = H.mpCamera->mvParameters[3];
+    H.mbf = mbf; H.mb = mb;
+    H.AssignFeaturesToGrid(n_right >= 0 ? n_left : -1);
+}
+Sophus::Sim3f make_sim3(float s, const float* R, const float* t) {
+    Eigen::Matrix3f Rm; Eigen::Vector3f tv;
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rm(r, c) = R[r * 3 + c]; tv(r) = t[r]; }
+    return Sophus::Sim3f(s, Rm, tv);
+}
+}  // namespace
+
+extern "C" {
+
+const char* mw_flavour() {
+#ifdef MW_FACADE
+    return "facade";
+#else
+    return "reference";
+#endif
+}
+void* mw_create() { return new World(); }
+void mw_destroy(void* w) { delete (World*)w; }
+
+int mw_add_camera(void* wv, float fx, float fy, float cx, float cy) {
+    World* w = (World*)wv; w->cams.emplace_back(new GeometricCamera(fx, fy, cx, cy)); return (int)w->cams.size() - 1;
+}
+int mw_add_mappoint(void* wv, const float* pos, const float* normal, float min_dist, float max_dist, const uint8_t* desc, int bad, int n_obs) {
+    World* w = (World*)wv;
+    std::unique_ptr<MapPoint> p(new MapPoint());
+    p->id = (int)w->mps.size(); p->bad = bad != 0; p->nObs = n_obs;
+    p->pos = Eigen::Vector3f(pos[0], pos[1], pos[2]); p->normal = Eigen::Vector3f(normal[0], normal[1], normal[2]);
+    p->minDist = min_dist; p->maxDist = max_dist;
+    p->descriptor.create(1, 32, CV_8UC1); memcpy(p->descriptor.data, desc, 32);
+    w->mps.push_back(std::move(p));
+    return (int)w->mps.size() - 1;
+}
+// tracking fields written by Frame::isInFrustum (include/MapPoint.h:171-179); t = {projX, projY, projXR, viewCos, depth, projYR, viewCosR}
+void mw_set_track(void* wv, int id, int in_view, int in_view_r, int level, int level_r, const float* t) {
+    MapPoint* p = ((World*)wv)->mps[id].get();
+    p->mbTrackInView = in_view != 0; p->mbTrackInViewR = in_view_r != 0; p->mnTrackScaleLevel = level; p->mnTrackScaleLevelR = level_r;
+    p->mTrackProjX = t[0]; p->mTrackProjY = t[1]; p->mTrackProjXR = t[2]; p->mTrackViewCos = t[3]; p->mTrackDepth = t[4]; p->mTrackProjYR = t[5]; p->mTrackViewCosR = t[6];
+}
+// n_right < 0: one camera (keys = mvKeys, keys_un = mvKeysUn, both N entries); n_right >= 0: fisheye rig (keys = mvKeys [N - n_right],
+// keys_right = mvKeysRight [n_right], descriptors left rows first)
+int mw_add_frame(void* wv, int keyframe, int N, const void* keys, const void* keys_un, int n_right, const void* keys_right, const uint8_t* desc, const float* u_right,
+                 const float* pose_R, const float* pose_t, const float* trl_R, const float* trl_t, const float* bounds, int nlevels, float scale_factor, int cam, int cam2,
+                 float mbf, float mb) {
+    World* w = (World*)wv;
+    if (keyframe) {
+        std::unique_ptr<KeyFrame> k(new KeyFrame());
+        fill_holder(w, *k, N, (const KP*)keys, (const KP*)keys_un, n_right, (const KP*)keys_right, desc, u_right, pose_R, pose_t, trl_R, trl_t, bounds, nlevels, scale_factor, cam, cam2, mbf, mb);
+        if (n_right >= 0) { k->NLeft = N - n_right; k->NRight = n_right; }
+        k->mvpMapPoints.assign(N, nullptr);
+        w->kfs.push_back(std::move(k));
+        return (int)w->kfs.size() - 1;
+    }
+    std::unique_ptr<Frame> f(new Frame());
+    fill_holder(w, *f, N, (const KP*)keys, (const KP*)keys_un, n_right, (const KP*)keys_right, desc, u_right, pose_R, pose_t, trl_R, trl_t, bounds, nlevels, scale_factor, cam, cam2, mbf, mb);
+    if (n_right >= 0) { f->Nleft = N - n_right; f->Nright = n_right; f->mvLeftToRightMatch.assign(f->Nleft, -1); f->mvRightToLeftMatch.assign(n_right, -1); }
+    f->mvpMapPoints.assign(N, nullptr); f->mvbOutlier.assign(N, false);
+    w->frames.push_back(std::move(f));
+    return (int)w->frames.size() - 1;
+}
+void mw_set_map_points(void* wv, int keyframe, int id, const int* mp_ids, const uint8_t* outlier) {
+    World* w = (World*)wv;
+    if (keyframe) {
+        KeyFrame* k = w->kfs[id].get();
+        for (int i = 0; i < k->N; i++) { k->mvpMapPoints[i] = w->mp(mp_ids[i]); if (k->mvpMapPoints[i]) k->mvpMapPoints[i]->observations[k] = std::tuple<int, int>(i, -1); }
+    } else {
+        Frame* f = w->frames[id].get();
+        for (int i = 0; i < f->N; i++) { f->mvpMapPoints[i] = w->mp(mp_ids[i]); if (outlier) f->mvbOutlier[i] = outlier[i] != 0; }
+    }
+}
+void mw_get_map_points(void* wv, int keyframe, int id, int* out) {
+    World* w = (World*)wv;
+    if (keyframe) { KeyFrame* k = w->kfs[id].get(); for (int i = 0; i < k->N; i++) out[i] = w->idOf(k->mvpMapPoints[i]); }
+    else { Frame* f = w->frames[id].get(); for (int i = 0; i < f->N; i++) out[i] = w->idOf(f->mvpMapPoints[i]); }
+}
+void mw_set_feat_vec(void* wv, int keyframe, int id, int n_nodes, const uint32_t* node_ids, const int* start, const uint32_t* feat) {
+    World* w = (World*)wv;
+    DBoW2::FeatureVector& fv = keyframe ? w->kfs[id]->mFeatVec : w->frames[id]->mFeatVec;
+    fv.clear();
+    for (int n = 0; n < n_nodes; n++) for (int j = start[n]; j < start[n + 1]; j++) fv.addFeature(node_ids[n], feat[j]);
+}
+void mw_set_lr_matches(void* wv, int id, const int* l2r, const int* r2l) {
+    Frame* f = ((World*)wv)->frames[id].get();
+    for (size_t i = 0; i < f->mvLeftToRightMatch.size(); i++) f->mvLeftToRightMatch[i] = l2r[i];
+    for (size_t i = 0; i < f->mvRightToLeftMatch.size(); i++) f->mvRightToLeftMatch[i] = r2l[i];
+}
+// state a Fuse call may have changed: out = {bad, nObs, replacedBy, index of the observation in key frame kf (-1 none)}
+void mw_get_mappoint_state(void* wv, int id, int kf, int* out) {
+    World* w = (World*)wv; MapPoint* p = w->mps[id].get();
+    out[0] = p->bad; out[1] = p->nObs; out[2] = w->idOf(p->replacedBy); out[3] = std::get<0>(p->GetIndexInKeyFrame(w->kfs[kf].get()));
+}
+
+int mw_descriptor_distance(const uint8_t* a, const uint8_t* b) {
+    cv::Mat A(1, 32, CV_8UC1, (void*)a), B(1, 32, CV_8UC1, (void*)b);
+    return ORBmatcher::DescriptorDistance(A, B);
+}
+
+// ---- the methods.  Every function returns the method's return value. ----
+int mw_search_by_projection_mappoints(void* wv, int frame, const int* mp_ids, int M, float th, int far_points, float th_far, float nnratio, int check_ori) {
+    World* w = (World*)wv;
+    std::vector<MapPoint*> v(M); for (int i = 0; i < M; i++) v[i] = w->mp(mp_ids[i]);
+    ORBmatcher m(nnratio, check_ori != 0);
+    return m.SearchByProjection(*w->frames[frame], v, th, far_points != 0, th_far);
+}
+int mw_search_by_projection_frame(void* wv, int cur, int last, float th, int mono, float nnratio, int check_ori) {
+    World* w = (World*)wv;
+    ORBmatcher m(nnratio, check_ori != 0);
+    return m.SearchByProjection(*w->frames[cur], *w->frames[last], th, mono != 0);
+}
+int mw_search_by_projection_keyframe(void* wv, int cur, int kf, const int* found_ids, int n_found, float th, int orb_dist, float nnratio, int check_ori) {
+    World* w = (World*)wv;
+    std::set<MapPoint*> found; for (int i = 0; i < n_found; i++) found.insert(w->mp(found_ids[i]));
+    ORBmatcher m(nnratio, check_ori != 0);
+    return m.SearchByProjection(*w->frames[cur], w->kfs[kf].get(), found, th, orb_dist);
+}
+// matched: in/out, one map point id per key-frame feature (-1 = NULL); matched_kf (with_kfs): out, key frame id per feature
+int mw_search_by_projection_sim3(void* wv, int kf, float s, const float* R, const float* t, const int* mp_ids, int M, const int* point_kfs, int with_kfs, int* matched,
+                                 int* matched_kf, int th, float ratio_hamming) {
+    World* w = (World*)wv; KeyFrame* k = w->kfs[kf].get();
+    Sophus::Sim3f Scw = make_sim3(s, R, t);
+    std::vector<MapPoint*> pts(M); for (int i = 0; i < M; i++) pts[i] = w->mp(mp_ids[i]);
+    std::vector<MapPoint*> vm(k->N); for (int i = 0; i < k->N; i++) vm[i] = w->mp(matched[i]);
+    ORBmatcher m(0.75f, true);
+    int n;
+    if (with_kfs) {
+        std::vector<KeyFrame*> pk(M), mk(k->N, nullptr); for (int i = 0; i < M; i++) pk[i] = w->kfs[point_kfs[i]].get();
+        n = m.SearchByProjection(k, Scw, pts, pk, vm, mk, th, ratio_hamming);
+        for (int i = 0; i < k->N; i++) matched_kf[i] = w->kfId(mk[i]);
+    } else n = m.SearchByProjection(k, Scw, pts, vm, th, ratio_hamming);
+    for (int i = 0; i < k->N; i++) matched[i] = w->idOf(vm[i]);
+    return n;
+}
+int mw_search_by_bow_frame(void* wv, int kf, int frame, int* out_ids, float nnratio, int check_ori) {
+    World* w = (World*)wv;
+    std::vector<MapPoint*> vm;
+    ORBmatcher m(nnratio, check_ori != 0);
+    const int n = m.SearchByBoW(w->kfs[kf].get(), *w->frames[frame], vm);
+    for (size_t i = 0; i < vm.size(); i++) out_ids[i] = w->idOf(vm[i]);
+    return n;
+}
+int mw_search_by_bow_keyframes(void* wv, int kf1, int kf2, int* out_ids, float nnratio, int check_ori) {
+    World* w = (World*)wv;
+    std::vector<MapPoint*> vm;
+    ORBmatcher m(nnratio, check_ori != 0);
+    const int n = m.SearchByBoW(w->kfs[kf1].get(), w->kfs[kf2].get(), vm);
+    for (size_t i = 0; i < vm.size(); i++) out_ids[i] = w->idOf(vm[i]);
+    return n;
+}
+int mw_search_for_initialization(void* wv, int f1, int f2, float* prev_matched, int* matches12, int window, float nnratio, int check_ori) {
+    World* w = (World*)wv; Frame& F1 = *w->frames[f1];
+    std::vector<cv::Point2f> prev(F1.mvKeysUn.size()); for (size_t i = 0; i < prev.size(); i++) prev[i] = cv::Point2f(prev_matched[2 * i], prev_matched[2 * i + 1]);
+    std::vector<int> m12;
+    ORBmatcher m(nnratio, check_ori != 0);
+    const int n = m.SearchForInitialization(F1, *w->frames[f2], prev, m12, window);
+    for (size_t i = 0; i < m12.size(); i++) { matches12[i] = m12[i]; prev_matched[2 * i] = prev[i].x; prev_matched[2 * i + 1] = prev[i].y; }
+    return n;
+}
+// pairs: up to cap (idx1, idx2) pairs; *n_pairs = vMatchedPairs.size()
+int mw_search_for_triangulation(void* wv, int kf1, int kf2, int only_stereo, int coarse, int* pairs, int cap, int* n_pairs, float nnratio, int check_ori) {
+    World* w = (World*)wv;
+    std::vector<std::pair<size_t, size_t>> vp;
+    ORBmatcher m(nnratio, check_ori != 0);
+    const int n = m.SearchForTriangulation(w->kfs[kf1].get(), w->kfs[kf2].get(), vp, only_stereo != 0, coarse != 0);
+    *n_pairs = (int)vp.size();
+    for (size_t i = 0; i < vp.size() && (int)i < cap; i++) { pairs[2 * i] = (int)vp[i].first; pairs[2 * i + 1] = (int)vp[i].second; }
+    return n;
+}
+int mw_fuse(void* wv, int kf, const int* mp_ids, int M, float th, int right) {
+    World* w = (World*)wv;
+    std::vector<MapPoint*> v(M); for (int i = 0; i < M; i++) v[i] = w->mp(mp_ids[i]);
+    ORBmatcher m(0.8f, true);
+    return m.Fuse(w->kfs[kf].get(), v, th, right != 0);
+}
+int mw_fuse_sim3(void* wv, int kf, float s, const float* R, const float* t, const int* mp_ids, int M, float th, int* replace_ids) {
+    World* w = (World*)wv;
+    Sophus::Sim3f Scw = make_sim3(s, R, t);
+    std::vector<MapPoint*> v(M), rep(M, nullptr); for (int i = 0; i < M; i++) v[i] = w->mp(mp_ids[i]);
+    ORBmatcher m(0.8f, true);
+    const int n = m.Fuse(w->kfs[kf].get(), Scw, v, th, rep);
+    for (int i = 0; i < M; i++) replace_ids[i] = w->idOf(rep[i]);
+    return n;
+}
+// matches12: in/out, map point id per feature of kf1
+int mw_search_by_sim3(void* wv, int kf1, int kf2, int* matches12, float s, const float* R, const float* t, float th) {
+    World* w = (World*)wv; KeyFrame* k1 = w->kfs[kf1].get();
+    const Sophus::Sim3f S12 = make_sim3(s, R, t);
+    std::vector<MapPoint*> vm(k1->N); for (int i = 0; i < k1->N; i++) vm[i] = w->mp(matches12[i]);
+    ORBmatcher m(0.75f, true);
+    const int n = m.SearchBySim3(k1, w->kfs[kf2].get(), vm, S12, th);
+    for (int i = 0; i < k1->N; i++) matches12[i] = w->idOf(vm[i]);
+    return n;
+}
+
+}  // extern "C"
