@@ -12,11 +12,16 @@
 // lapping reorder).  UNPINNED for the OpenCV primitives underneath (resize / FAST / GaussianBlur /
 // fastAtan2 / remap / cvtColor), because OpenCV is not vendored in the reference, not installed here,
 // and the reference ships no golden vectors.  Those live in orb_primitives.h.
-// UNPINNED as well: the matcher-side restatements further down (ComputeStereoMatches, kNN + ratio, GetFeaturesInArea, every
-// SearchByProjection overload incl. the two-camera branches, SearchForTriangulation, SearchByBoW, SearchForInitialization,
-// SearchBySim3, the Fuse candidate search, ComputeDistinctiveDescriptors): src/Frame.cc, src/ORBmatcher.cc and src/MapPoint.cc
-// need Eigen / Sophus / Boost and cannot be compiled here.  PINNED separately: DescriptorDistance against the reference's
-// FORB::distance, and the vocabulary transform against the reference's own DBoW2 (oracle/ref_dbow2_driver.cpp).
+// PINNED against the reference's own src/ORBmatcher.cc (compiled unmodified and in place over the stand-in world of oracle/slam_shim,
+// oracle/_ref/libmw_ref.so): every ORBmatcher method — all SearchByProjection overloads incl. the two-camera branches, both SearchByBoW,
+// SearchForInitialization, SearchForTriangulation, SearchBySim3, both Fuse, DescriptorDistance — via tests/test_matcher_reference.py, which
+// drives reference and product with identical Frame / KeyFrame / MapPoint objects (the restatements below agree with the product on the same
+// views, tests/test_emu_search*.py).  What the reference's ORBmatcher.cc calls but does not contain — Frame / KeyFrame::GetFeaturesInArea,
+// the grid assignment, MapPoint::PredictScale, Pinhole::project / epipolarConstrain, the 3x3 float algebra of Eigen / Sophus — is restated in
+// slam_shim/slam_world.h and shared by both sides.  PINNED separately: DescriptorDistance against the reference's FORB::distance, and the
+// vocabulary transform against the reference's own DBoW2 (oracle/ref_dbow2_driver.cpp).
+// UNPINNED: ComputeStereoMatches, the fisheye kNN + ratio step and ComputeDistinctiveDescriptors (src/Frame.cc, src/MapPoint.cc define whole
+// classes over Eigen / Sophus / g2o / Boost and cannot be compiled here); GetFeaturesInArea as a stand-alone function.
 //
 // The extractor restatement deliberately uses the *derived* formulation the GPU kernels use
 // (SURVEY.md §8a row F2): one FAST score map at min(iniTh,minTh), cell-local strict 3x3 NMS, and a
@@ -542,10 +547,10 @@ void orbo_prim_resize_cn(const uint8_t* src, int sw, int sh, int cn, uint8_t* ds
 }
 
 // =====================================================================================================================
-// M3-M6: guided searches, restated sequentially on structure-of-arrays views (the reference's ORBmatcher.cc / Frame.cc
-// need Eigen, Sophus, DBoW2 and Boost and cannot be compiled here, so these restatements are NOT pinned against the
-// reference build — "parity unpinned" for M3-M6).  The views are those of include/orbx.h; geometry (projection,
-// fundamental matrix) enters as numbers computed by the caller, exactly as in the product ABI.
+// M3-M6: guided searches, restated sequentially on structure-of-arrays views (those of include/orbx.h; geometry - projection,
+// fundamental matrix - enters as numbers computed by the caller, exactly as in the product ABI).  The product agrees with these on
+// random views (tests/test_emu_search*.py) and with the reference's own compiled ORBmatcher.cc on whole Frame / KeyFrame / MapPoint
+// worlds (tests/test_matcher_reference.py).
 // =====================================================================================================================
 struct OFrame {
     int N; const Kp* keys; const uint8_t* desc; const float* u_right; const uint8_t* occupied;
