@@ -13,6 +13,8 @@
 #pragma once
 #include <algorithm>
 #include <cassert>
+#include <climits>
+#include <cstdlib>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -63,7 +65,7 @@ struct KeyPoint {
 
 enum { INTER_LINEAR = 1 };
 enum { BORDER_REFLECT_101 = 4, BORDER_DEFAULT = 4, BORDER_ISOLATED = 16 };
-enum { NORM_L1 = 2 };
+enum { NORM_L1 = 2, NORM_HAMMING = 6 };
 
 struct MatStep {
     size_t v; MatStep() : v(0) {} MatStep(size_t s) : v(s) {}
@@ -101,6 +103,10 @@ public:
     void copyTo(Mat&& dst) const { copyTo(dst); }   // e.g. desc.row(i).copyTo(descriptors.row(j))
     template <typename T> T& at(int y, int x) { return *(T*)(data + (size_t)y * step + (size_t)x * sizeof(T)); }
     template <typename T> const T& at(int y, int x) const { return *(const T*)(data + (size_t)y * step + (size_t)x * sizeof(T)); }
+    template <typename T> T& at(int i) { return rows == 1 ? at<T>(0, i) : at<T>(i, 0); }
+    template <typename T> const T& at(int i) const { return rows == 1 ? at<T>(0, i) : at<T>(i, 0); }
+    size_t total() const { return (size_t)rows * cols; }
+    Mat reshape(int /*cn*/) const { return *this; }             // only reached with lens distortion, which the oracle never configures
     uchar* ptr(int y = 0) { return data + (size_t)y * step; }
     const uchar* ptr(int y = 0) const { return data + (size_t)y * step; }
     template <typename T> T* ptr(int y = 0) { return (T*)(data + (size_t)y * step); }
@@ -158,6 +164,40 @@ static inline void GaussianBlur(const Mat& src, Mat& dst, Size ksize, double sx,
 static inline double norm(const Mat& a, const Mat& b, int /*NORM_L1*/) {
     return orbp::norm_l1_u8(a.data, a.step, b.data, b.step, a.cols, a.rows);
 }
+
+// Names Frame.cc needs to compile.  undistortPoints is only called with non-zero distortion coefficients (src/Frame.cc:1007, :1061), which the
+// oracle never configures; vconcat / BFMatcher serve the fisheye-rig constructor (:1514, :1553): brute-force Hamming 2-NN with strict '<'
+// insertion, equal distances keep the lower train index first (OpenCV's BFMatcher order; restated, OpenCV is not installed).
+static inline void undistortPoints(const Mat&, Mat&, const Mat&, const Mat&, const Mat&, const Mat&) { std::abort(); }
+static inline void vconcat(const Mat& a, const Mat& b, Mat& dst) {
+    Mat r(a.rows + b.rows, a.cols, CV_8UC1);
+    for (int y = 0; y < a.rows; y++) memcpy(r.ptr(y), a.ptr(y), (size_t)a.cols);
+    for (int y = 0; y < b.rows; y++) memcpy(r.ptr(a.rows + y), b.ptr(y), (size_t)b.cols);
+    dst = r;
+}
+struct DMatch {
+    int queryIdx, trainIdx, imgIdx; float distance;
+    DMatch() : queryIdx(-1), trainIdx(-1), imgIdx(-1), distance(3.4e38f) {}
+    DMatch(int q, int t, float d) : queryIdx(q), trainIdx(t), imgIdx(0), distance(d) {}
+};
+class BFMatcher {
+public:
+    BFMatcher(int /*normType*/ = NORM_HAMMING, bool /*crossCheck*/ = false) {}
+    void knnMatch(const Mat& query, const Mat& train, std::vector<std::vector<DMatch>>& matches, int k) const {
+        matches.assign(query.rows, std::vector<DMatch>());
+        for (int i = 0; i < query.rows; i++) {
+            std::vector<std::pair<int, int>> best;                  // (distance, train index), ascending, at most k
+            for (int j = 0; j < train.rows; j++) {
+                int d = 0;
+                for (int b = 0; b < query.cols; b++) d += __builtin_popcount((unsigned)(query.ptr(i)[b] ^ train.ptr(j)[b]));
+                size_t pos = best.size();
+                while (pos > 0 && d < best[pos - 1].first) pos--;
+                if ((int)pos < k) { best.insert(best.begin() + pos, std::make_pair(d, j)); if ((int)best.size() > k) best.pop_back(); }
+            }
+            for (size_t n = 0; n < best.size(); n++) matches[i].push_back(DMatch(i, best[n].second, (float)best[n].first));
+        }
+    }
+};
 
 struct KeyPointsFilter {   // referenced only by the reference's dead ComputeKeyPointsOld
     static void retainBest(std::vector<KeyPoint>& kps, int n) {

@@ -1,0 +1,75 @@
+// oracle/ref_frame_driver.cpp — TEST INFRASTRUCTURE ONLY.
+//
+// C-ABI wrapper around the REFERENCE's own ORB_SLAM3::Frame, compiled from /root/reference/src/Frame.cc + src/ORBextractor.cc (unmodified,
+// read in place; never copied into this repo) against oracle/opencv_shim and oracle/slam_shim/frame_world.h.  Built by oracle/Makefile
+// into oracle/_ref/libref_frame.so.  One entry point runs the reference's stereo Frame constructor (src/Frame.cc:105-230): two
+// ORBextractors on two threads, UndistortKeyPoints (no distortion), ComputeStereoMatches (:1102-1358), AssignFeaturesToGrid (:469-503);
+// the others read the resulting Frame and call its GetFeaturesInArea (:859-951).
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <vector>
+#include "Frame.h"          // the reference header, via -I/root/reference/include
+#include "ORBextractor.h"
+
+using namespace ORB_SLAM3;
+
+namespace {
+struct RefKp { float x, y, size, angle, response; int octave, class_id; };
+struct Holder {
+    ORBextractor *left, *right; Pinhole* cam; Frame* frame;
+    ~Holder() { delete frame; delete left; delete right; delete cam; }
+};
+void put_keys(const std::vector<cv::KeyPoint>& k, void* out) {
+    RefKp* o = (RefKp*)out;
+    for (size_t i = 0; i < k.size(); i++) o[i] = {k[i].pt.x, k[i].pt.y, k[i].size, k[i].angle, k[i].response, k[i].octave, k[i].class_id};
+}
+}  // namespace
+
+extern "C" {
+
+// Frame(imLeft, imRight, ...) with fresh extractors and a pinhole camera without distortion.  Returns a handle; *n / *n_right = keypoint counts.
+void* ref_frame_stereo(const uint8_t* L, const uint8_t* R, int w, int h, int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, int gauss_variant,
+                       float fx, float fy, float cx, float cy, float bf, float th_depth, int* n, int* n_right) {
+    cv::shim_gauss_variant() = gauss_variant;
+    Holder* H = new Holder();
+    H->left = new ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th);
+    H->right = new ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th);
+    H->cam = new Pinhole(fx, fy, cx, cy);
+    cv::Mat imL(h, w, CV_8UC1, (void*)L, (size_t)w), imR(h, w, CV_8UC1, (void*)R, (size_t)w);
+    cv::Mat K = H->cam->toK();
+    cv::Mat dist(4, 1, CV_32F); for (int i = 0; i < 4; i++) dist.at<float>(i) = 0.0f;
+    Frame::mbInitialComputations = true;                 // image bounds and grid constants are per image size (:185-203)
+    // The reference's constructor calls ComputeStereoMatches() (src/Frame.cc:164), which reads the member mb (:1163 minZ = mb), BEFORE it
+    // assigns mb = mbf / fx (:206); mb is not in the initialiser list.  In the running system every Frame is a temporary built in the same
+    // stack slot of Tracking::GrabImageStereo (src/Tracking.cc:1565-1582), so from the second frame on the value read is the one the previous
+    // frame left there, mbf / fx.  The driver reproduces that state: raw storage whose mb field already holds mbf / fx.
+    void* storage = ::operator new(sizeof(Frame));
+    memset(storage, 0, sizeof(Frame));
+    reinterpret_cast<Frame*>(storage)->mb = bf / fx;
+    H->frame = new (storage) Frame(imL, imR, 0.0, H->left, H->right, nullptr, K, dist, bf, th_depth, H->cam);
+    *n = H->frame->N; *n_right = (int)H->frame->mvKeysRight.size();
+    return H;
+}
+void ref_frame_destroy(void* h) { delete (Holder*)h; }
+
+// mvKeys, mvKeysUn, mDescriptors, mvuRight, mvDepth (N entries each) and mvKeysRight, mDescriptorsRight
+void ref_frame_get(void* h, void* keys, void* keys_un, uint8_t* desc, float* u_right, float* depth, void* keys_right, uint8_t* desc_right) {
+    Frame* F = ((Holder*)h)->frame;
+    put_keys(F->mvKeys, keys); put_keys(F->mvKeysUn, keys_un); put_keys(F->mvKeysRight, keys_right);
+    for (int i = 0; i < F->N; i++) { memcpy(desc + 32 * (size_t)i, F->mDescriptors.ptr(i), 32); u_right[i] = F->mvuRight[i]; depth[i] = F->mvDepth[i]; }
+    for (size_t i = 0; i < F->mvKeysRight.size(); i++) memcpy(desc_right + 32 * i, F->mDescriptorsRight.ptr((int)i), 32);
+}
+// out = {mnMinX, mnMinY, mnMaxX, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv, mbf, mb}
+void ref_frame_constants(void* h, float* out) {
+    Frame* F = ((Holder*)h)->frame;
+    out[0] = Frame::mnMinX; out[1] = Frame::mnMinY; out[2] = Frame::mnMaxX; out[3] = Frame::mnMaxY;
+    out[4] = Frame::mfGridElementWidthInv; out[5] = Frame::mfGridElementHeightInv; out[6] = F->mbf; out[7] = F->mb;
+}
+int ref_frame_features_in_area(void* h, float x, float y, float r, int min_level, int max_level, int* idx, int cap) {
+    const std::vector<size_t> v = ((Holder*)h)->frame->GetFeaturesInArea(x, y, r, min_level, max_level);
+    for (size_t i = 0; i < v.size() && (int)i < cap; i++) idx[i] = (int)v[i];
+    return (int)v.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,273 @@
+// slam_types.h — TEST INFRASTRUCTURE (part of oracle/; never shipped).  Stand-ins for Eigen / Sophus and for the GeometricCamera, MapPoint and
+// KeyFrame classes of the reference, shared by slam_world.h (the world the reference's ORBmatcher.cc is compiled over) and frame_world.h
+// (the world the reference's Frame.cc is compiled over).  See slam_world.h for what is restated here and why.
+#ifndef ORBX_SLAM_TYPES_H
+#define ORBX_SLAM_TYPES_H
+
+#define MAPPOINT_H
+#define KEYFRAME_H
+
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <set>
+#include <tuple>
+#include <vector>
+#include <opencv2/core/core.hpp>
+#include "Thirdparty/DBoW2/DBoW2/BowVector.h"
+#include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
+
+#define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+
+using namespace std;     // the reference's headers rely on it (include/ORBmatcher.h:78 uses an unqualified pair<>)
+
+namespace Eigen {
+struct Vector2f {
+    float d[2];
+    Vector2f() : d{0, 0} {}
+    Vector2f(float x, float y) : d{x, y} {}
+    float& operator()(int i) { return d[i]; }
+    const float& operator()(int i) const { return d[i]; }
+    float& operator[](int i) { return d[i]; }
+    const float& operator[](int i) const { return d[i]; }
+};
+struct Vector3f {
+    float d[3];
+    Vector3f() : d{0, 0, 0} {}
+    Vector3f(float x, float y, float z) : d{x, y, z} {}
+    float& operator()(int i) { return d[i]; }
+    const float& operator()(int i) const { return d[i]; }
+    float& operator[](int i) { return d[i]; }
+    const float& operator[](int i) const { return d[i]; }
+    void setZero() { d[0] = d[1] = d[2] = 0; }
+    float dot(const Vector3f& o) const { return d[0] * o.d[0] + d[1] * o.d[1] + d[2] * o.d[2]; }
+    float norm() const { return std::sqrt(dot(*this)); }
+};
+inline Vector3f operator-(const Vector3f& a, const Vector3f& b) { return Vector3f(a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2]); }
+inline Vector3f operator+(const Vector3f& a, const Vector3f& b) { return Vector3f(a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2]); }
+inline Vector3f operator-(const Vector3f& a) { return Vector3f(-a.d[0], -a.d[1], -a.d[2]); }
+inline Vector3f operator/(const Vector3f& a, float s) { return Vector3f(a.d[0] / s, a.d[1] / s, a.d[2] / s); }
+inline Vector3f operator*(const Vector3f& a, float s) { return Vector3f(a.d[0] * s, a.d[1] * s, a.d[2] * s); }
+inline Vector3f operator*(float s, const Vector3f& a) { return a * s; }
+struct Matrix3f {
+    float m[3][3];
+    Matrix3f() : m{{0, 0, 0}, {0, 0, 0}, {0, 0, 0}} {}
+    static Matrix3f Identity() { Matrix3f r; r.m[0][0] = r.m[1][1] = r.m[2][2] = 1.0f; return r; }
+    static Matrix3f Zero() { return Matrix3f(); }
+    float& operator()(int r, int c) { return m[r][c]; }
+    const float& operator()(int r, int c) const { return m[r][c]; }
+    Matrix3f transpose() const { Matrix3f r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = m[j][i]; return r; }
+    Matrix3f inverse() const {          // cofactors / determinant
+        Matrix3f r;
+        const float c00 = m[1][1] * m[2][2] - m[1][2] * m[2][1], c01 = m[1][2] * m[2][0] - m[1][0] * m[2][2], c02 = m[1][0] * m[2][1] - m[1][1] * m[2][0];
+        const float det = m[0][0] * c00 + m[0][1] * c01 + m[0][2] * c02, id = 1.0f / det;
+        r.m[0][0] = c00 * id; r.m[1][0] = c01 * id; r.m[2][0] = c02 * id;
+        r.m[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) * id; r.m[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) * id; r.m[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) * id;
+        r.m[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) * id; r.m[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) * id; r.m[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) * id;
+        return r;
+    }
+};
+inline Vector3f operator*(const Matrix3f& A, const Vector3f& v) {
+    return Vector3f(A.m[0][0] * v.d[0] + A.m[0][1] * v.d[1] + A.m[0][2] * v.d[2], A.m[1][0] * v.d[0] + A.m[1][1] * v.d[1] + A.m[1][2] * v.d[2],
+                    A.m[2][0] * v.d[0] + A.m[2][1] * v.d[1] + A.m[2][2] * v.d[2]);
+}
+inline Matrix3f operator*(const Matrix3f& A, const Matrix3f& B) {
+    Matrix3f r;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = A.m[i][0] * B.m[0][j] + A.m[i][1] * B.m[1][j] + A.m[i][2] * B.m[2][j];
+    return r;
+}
+inline Matrix3f operator*(const Matrix3f& A, float s) { Matrix3f r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = A.m[i][j] * s; return r; }
+}  // namespace Eigen
+
+namespace Sophus {
+template <typename T> struct SE3;
+template <> struct SE3<float> {
+    Eigen::Matrix3f R; Eigen::Vector3f t;
+    SE3() : R(Eigen::Matrix3f::Identity()), t() {}
+    SE3(const Eigen::Matrix3f& r, const Eigen::Vector3f& tt) : R(r), t(tt) {}
+    const Eigen::Matrix3f& rotationMatrix() const { return R; }
+    const Eigen::Vector3f& translation() const { return t; }
+    SE3 inverse() const { const Eigen::Matrix3f Rt = R.transpose(); return SE3(Rt, -(Rt * t)); }
+    SE3 operator*(const SE3& o) const { return SE3(R * o.R, R * o.t + t); }
+    Eigen::Vector3f operator*(const Eigen::Vector3f& p) const { return R * p + t; }
+};
+typedef SE3<float> SE3f;
+template <> struct SE3<double> {};     // include/Frame.h:369 holds an unused Sophus::SE3<double> member
+template <typename T> struct Sim3;
+template <> struct Sim3<float> {
+    Eigen::Matrix3f R; Eigen::Vector3f t; float s;
+    Sim3() : R(Eigen::Matrix3f::Identity()), t(), s(1.0f) {}
+    Sim3(float ss, const Eigen::Matrix3f& r, const Eigen::Vector3f& tt) : R(r), t(tt), s(ss) {}
+    const Eigen::Matrix3f& rotationMatrix() const { return R; }
+    const Eigen::Vector3f& translation() const { return t; }
+    float scale() const { return s; }
+    Sim3 inverse() const { const Eigen::Matrix3f Rt = R.transpose(); const float is = 1.0f / s; return Sim3(is, Rt, -((Rt * t) * is)); }
+    Eigen::Vector3f operator*(const Eigen::Vector3f& p) const { return (R * p) * s + t; }
+};
+typedef Sim3<float> Sim3f;
+}  // namespace Sophus
+
+namespace ORB_SLAM3 {
+
+class KeyFrame;
+class Frame;
+class MapPoint;
+
+// pinhole GeometricCamera: parameters fx, fy, cx, cy
+class GeometricCamera {
+public:
+    float mvParameters[4];
+    GeometricCamera(float fx, float fy, float cx, float cy) : mvParameters{fx, fy, cx, cy} {}
+    virtual ~GeometricCamera() {}
+    virtual Eigen::Vector2f project(const Eigen::Vector3f& v3D) {                                    // Pinhole.cpp:61-68
+        Eigen::Vector2f res;
+        res[0] = mvParameters[0] * v3D[0] / v3D[2] + mvParameters[2];
+        res[1] = mvParameters[1] * v3D[1] / v3D[2] + mvParameters[3];
+        return res;
+    }
+    virtual Eigen::Matrix3f toK_() {
+        Eigen::Matrix3f K; K(0, 0) = mvParameters[0]; K(1, 1) = mvParameters[1]; K(0, 2) = mvParameters[2]; K(1, 2) = mvParameters[3]; K(2, 2) = 1.0f; return K;
+    }
+    static Eigen::Matrix3f hat(const Eigen::Vector3f& t) {
+        Eigen::Matrix3f x; x(0, 1) = -t(2); x(0, 2) = t(1); x(1, 0) = t(2); x(1, 2) = -t(0); x(2, 0) = -t(1); x(2, 1) = t(0); return x;
+    }
+    Eigen::Matrix3f fundamental(GeometricCamera* pCamera2, const Eigen::Matrix3f& R12, const Eigen::Vector3f& t12) {   // Pinhole.cpp:191-194
+        return toK_().transpose().inverse() * hat(t12) * R12 * pCamera2->toK_().inverse();
+    }
+    virtual bool epipolarConstrain(GeometricCamera* pCamera2, const cv::KeyPoint& kp1, const cv::KeyPoint& kp2, const Eigen::Matrix3f& R12,
+                                   const Eigen::Vector3f& t12, const float sigmaLevel, const float unc) {              // Pinhole.cpp:186-216
+        const Eigen::Matrix3f F12 = fundamental(pCamera2, R12, t12);
+        const float a = kp1.pt.x * F12(0, 0) + kp1.pt.y * F12(1, 0) + F12(2, 0);
+        const float b = kp1.pt.x * F12(0, 1) + kp1.pt.y * F12(1, 1) + F12(2, 1);
+        const float c = kp1.pt.x * F12(0, 2) + kp1.pt.y * F12(1, 2) + F12(2, 2);
+        const float num = a * kp2.pt.x + b * kp2.pt.y + c;
+        const float den = a * a + b * b;
+        if (den == 0) return false;
+        const float dsqr = num * num / den;
+        return dsqr < 3.84 * unc;
+    }
+};
+
+class MapPoint {
+public:
+    // tracking fields (include/MapPoint.h:171-179)
+    float mTrackProjX = 0, mTrackProjY = 0, mTrackDepth = 0, mTrackDepthR = 0, mTrackProjXR = 0, mTrackProjYR = 0;
+    bool mbTrackInView = false, mbTrackInViewR = false;
+    int mnTrackScaleLevel = 0, mnTrackScaleLevelR = -1;
+    float mTrackViewCos = 1, mTrackViewCosR = 1;
+    // state behind the accessors
+    int id = -1;
+    bool bad = false;
+    int nObs = 1;
+    Eigen::Vector3f pos, normal;
+    float minDist = 0, maxDist = 1e9f;
+    cv::Mat descriptor;
+    std::map<KeyFrame*, std::tuple<int, int>> observations;
+    MapPoint* replacedBy = nullptr;         // log of Replace()
+
+    bool isBad() { return bad; }
+    int Observations() { return nObs; }
+    cv::Mat GetDescriptor() { return descriptor.clone(); }
+    Eigen::Vector3f GetWorldPos() { return pos; }
+    Eigen::Vector3f GetNormal() { return normal; }
+    float GetMinDistanceInvariance() { return 0.8f * minDist; }           // src/MapPoint.cc:658-671
+    float GetMaxDistanceInvariance() { return 1.2f * maxDist; }
+    template <class T> int PredictScale(const float& currentDist, T* pF) {  // src/MapPoint.cc:688-731
+        float ratio = maxDist / currentDist;
+        int nScale = ceil(log(ratio) / pF->mfLogScaleFactor);
+        if (nScale < 0) nScale = 0;
+        else if (nScale >= pF->mnScaleLevels) nScale = pF->mnScaleLevels - 1;
+        return nScale;
+    }
+    bool IsInKeyFrame(KeyFrame* pKF) { return observations.count(pKF) != 0; }
+    std::tuple<int, int> GetIndexInKeyFrame(KeyFrame* pKF) { auto it = observations.find(pKF); return it != observations.end() ? it->second : std::tuple<int, int>(-1, -1); }
+    void AddObservation(KeyFrame* pKF, int idx) { observations[pKF] = std::tuple<int, int>(idx, -1); nObs++; }
+    void Replace(MapPoint* pMP) { replacedBy = pMP; bad = true; }
+};
+
+#define FRAME_GRID_ROWS 48
+#define FRAME_GRID_COLS 64
+
+// what Frame and KeyFrame share
+class FeatureHolder {
+public:
+    int N = 0;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysUn, mvKeysRight;
+    std::vector<float> mvuRight;
+    cv::Mat mDescriptors;
+    DBoW2::BowVector mBowVec;
+    DBoW2::FeatureVector mFeatVec;
+    std::vector<float> mvScaleFactors, mvLevelSigma2, mvInvLevelSigma2;
+    int mnScaleLevels = 0;
+    float mfLogScaleFactor = 0;
+    float mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;
+    float mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
+    float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0, mb = 0;
+    GeometricCamera *mpCamera = nullptr, *mpCamera2 = nullptr;
+    std::vector<size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS], mGridRight[FRAME_GRID_COLS][FRAME_GRID_ROWS];
+    Sophus::SE3f mTcw, mTrl;             // world -> (left) camera; left -> right camera
+
+    bool PosInGrid(const cv::KeyPoint& kp, int& posX, int& posY) {       // src/Frame.cc:964-975
+        posX = round((kp.pt.x - mnMinX) * mfGridElementWidthInv);
+        posY = round((kp.pt.y - mnMinY) * mfGridElementHeightInv);
+        if (posX < 0 || posX >= FRAME_GRID_COLS || posY < 0 || posY >= FRAME_GRID_ROWS) return false;
+        return true;
+    }
+    // src/Frame.cc:469-503 (AssignFeaturesToGrid); nleft = Nleft / NLeft of the owner
+    void AssignFeaturesToGrid(int nleft) {
+        for (int i = 0; i < FRAME_GRID_COLS; i++) for (int j = 0; j < FRAME_GRID_ROWS; j++) { mGrid[i][j].clear(); mGridRight[i][j].clear(); }
+        for (int i = 0; i < N; i++) {
+            const cv::KeyPoint& kp = (nleft == -1) ? mvKeysUn[i] : (i < nleft) ? mvKeys[i] : mvKeysRight[i - nleft];
+            int x, y;
+            if (PosInGrid(kp, x, y)) {
+                if (nleft == -1 || i < nleft) mGrid[x][y].push_back(i);
+                else mGridRight[x][y].push_back(i - nleft);
+            }
+        }
+    }
+};
+
+class KeyFrame : public FeatureHolder {
+public:
+    int NLeft = -1, NRight = -1;
+    const int mnGridCols = FRAME_GRID_COLS, mnGridRows = FRAME_GRID_ROWS;
+    std::vector<MapPoint*> mvpMapPoints;
+
+    std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
+    MapPoint* GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; }
+    std::set<MapPoint*> GetMapPoints() { std::set<MapPoint*> s; for (MapPoint* p : mvpMapPoints) if (p && !p->isBad()) s.insert(p); return s; }   // src/KeyFrame.cc:370-385
+    void AddMapPoint(MapPoint* pMP, const size_t& idx) { mvpMapPoints[idx] = pMP; }
+    Sophus::SE3f GetPose() { return mTcw; }
+    Sophus::SE3f GetPoseInverse() { return mTcw.inverse(); }
+    Eigen::Vector3f GetCameraCenter() { return mTcw.inverse().translation(); }
+    Sophus::SE3f GetRightPose() { return mTrl * mTcw; }
+    Sophus::SE3f GetRightPoseInverse() { return (mTrl * mTcw).inverse(); }
+    Eigen::Vector3f GetRightCameraCenter() { return (mTrl * mTcw).inverse().translation(); }
+    bool IsInImage(const float& x, const float& y) const { return (x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY); }   // src/KeyFrame.cc:894-897
+    std::vector<size_t> GetFeaturesInArea(const float& x, const float& y, const float& r, const bool bRight = false) const {   // src/KeyFrame.cc:843-891
+        std::vector<size_t> vIndices;
+        vIndices.reserve(N);
+        float factorX = r, factorY = r;
+        const int nMinCellX = max(0, (int)floor((x - mnMinX - factorX) * mfGridElementWidthInv));
+        if (nMinCellX >= mnGridCols) return vIndices;
+        const int nMaxCellX = min((int)mnGridCols - 1, (int)ceil((x - mnMinX + factorX) * mfGridElementWidthInv));
+        if (nMaxCellX < 0) return vIndices;
+        const int nMinCellY = max(0, (int)floor((y - mnMinY - factorY) * mfGridElementHeightInv));
+        if (nMinCellY >= mnGridRows) return vIndices;
+        const int nMaxCellY = min((int)mnGridRows - 1, (int)ceil((y - mnMinY + factorY) * mfGridElementHeightInv));
+        if (nMaxCellY < 0) return vIndices;
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                const std::vector<size_t>& vCell = (!bRight) ? mGrid[ix][iy] : mGridRight[ix][iy];
+                for (size_t j = 0, jend = vCell.size(); j < jend; j++) {
+                    const cv::KeyPoint& kpUn = (NLeft == -1) ? mvKeysUn[vCell[j]] : (!bRight) ? mvKeys[vCell[j]] : mvKeysRight[vCell[j]];
+                    const float distx = kpUn.pt.x - x, disty = kpUn.pt.y - y;
+                    if (fabs(distx) < r && fabs(disty) < r) vIndices.push_back(vCell[j]);
+                }
+            }
+        return vIndices;
+    }
+};
+
+}  // namespace ORB_SLAM3
+#endif

@@ -405,3 +405,56 @@ def oracle_search_by_projection_frame_fisheye(cur2, last, proj_ur, proj_vr, th, 
     a = np.full(max(N, 1), -1, np.int32)
     n = L.orbo_search_by_projection_frame_fisheye(cur2.ref(), last.ref(), ur.ctypes.data, vr.ctypes.data, th, int(fwd), int(bwd), int(check_ori), a.ctypes.data)
     return n, a[:N]
+
+
+_REF_FRAME = None
+
+
+def reference_frame_lib():
+    """The reference's own Frame.cc + ORBextractor.cc + ORBmatcher.cc built over oracle/slam_shim/frame_world.h (oracle/_ref/libref_frame.so); None if absent."""
+    global _REF_FRAME
+    if _REF_FRAME is None:
+        p = os.path.join(ORACLE_DIR, "_ref", "libref_frame.so")
+        if not os.path.exists(p) and os.path.exists("/root/reference/src/Frame.cc"):
+            build()
+        if not os.path.exists(p):
+            return None
+        L = C.CDLL(p)
+        L.ref_frame_stereo.restype = C.c_void_p
+        L.ref_frame_stereo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_float] * 6 + [C.POINTER(C.c_int)] * 2
+        L.ref_frame_destroy.argtypes = [C.c_void_p]
+        L.ref_frame_get.argtypes = [C.c_void_p] * 8
+        L.ref_frame_constants.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_frame_features_in_area.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        _REF_FRAME = L
+    return _REF_FRAME
+
+
+class ReferenceFrame:
+    """ORB_SLAM3::Frame as built by the reference's own stereo constructor (src/Frame.cc:105-230) on a rectified pair."""
+
+    def __init__(self, left, right, nfeatures=1200, scale=1.2, nlevels=8, ini=20, mn=7, gauss_variant=0, fx=458.654, fy=457.296, cx=367.215, cy=248.375, bf=458.654 * 0.110074, th_depth=35.0):
+        L = reference_frame_lib()
+        left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
+        n = C.c_int(); nr = C.c_int()
+        self.L = L
+        self.h = L.ref_frame_stereo(left.ctypes.data, right.ctypes.data, left.shape[1], left.shape[0], nfeatures, scale, nlevels, ini, mn, gauss_variant,
+                                    fx, fy, cx, cy, bf, th_depth, C.byref(n), C.byref(nr))
+        N, NR = n.value, nr.value
+        self.N = N
+        self.keys = np.zeros(N, KP_DTYPE); self.keys_un = np.zeros(N, KP_DTYPE); self.desc = np.zeros((N, 32), np.uint8)
+        self.u_right = np.zeros(N, np.float32); self.depth = np.zeros(N, np.float32)
+        self.keys_right = np.zeros(NR, KP_DTYPE); self.desc_right = np.zeros((NR, 32), np.uint8)
+        L.ref_frame_get(self.h, self.keys.ctypes.data, self.keys_un.ctypes.data, self.desc.ctypes.data, self.u_right.ctypes.data, self.depth.ctypes.data,
+                        self.keys_right.ctypes.data, self.desc_right.ctypes.data)
+        c = np.zeros(8, np.float32); L.ref_frame_constants(self.h, c.ctypes.data)
+        self.bounds = c[:4].copy(); self.grid_inv = c[4:6].copy(); self.mbf, self.mb = float(c[6]), float(c[7])
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ref_frame_destroy(self.h); self.h = None
+
+    def features_in_area(self, x, y, r, min_level=-1, max_level=-1):
+        idx = np.zeros(max(self.N, 1), np.int32)
+        n = self.L.ref_frame_features_in_area(self.h, x, y, r, min_level, max_level, idx.ctypes.data, len(idx))
+        return idx[:n].copy()
