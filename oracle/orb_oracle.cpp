@@ -20,8 +20,10 @@
 // the grid assignment, MapPoint::PredictScale, Pinhole::project / epipolarConstrain, the 3x3 float algebra of Eigen / Sophus — is restated in
 // slam_shim/slam_world.h and shared by both sides.  PINNED separately: DescriptorDistance against the reference's FORB::distance, and the
 // vocabulary transform against the reference's own DBoW2 (oracle/ref_dbow2_driver.cpp).
-// UNPINNED: ComputeStereoMatches, the fisheye kNN + ratio step and ComputeDistinctiveDescriptors (src/Frame.cc, src/MapPoint.cc define whole
-// classes over Eigen / Sophus / g2o / Boost and cannot be compiled here); GetFeaturesInArea as a stand-alone function.
+// PINNED against the reference's own src/Frame.cc (compiled unmodified over oracle/slam_shim/frame_world.h, oracle/_ref/libref_frame.so):
+// ComputeStereoMatches - through the reference's whole stereo Frame constructor, extraction included - and Frame::GetFeaturesInArea on the
+// reference's own grid (tests/test_frame_reference.py).
+// UNPINNED: the fisheye kNN step (cv::BFMatcher is OpenCV) and ComputeDistinctiveDescriptors (src/MapPoint.cc cannot be compiled here).
 //
 // The extractor restatement deliberately uses the *derived* formulation the GPU kernels use
 // (SURVEY.md §8a row F2): one FAST score map at min(iniTh,minTh), cell-local strict 3x3 NMS, and a

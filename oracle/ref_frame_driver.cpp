@@ -6,6 +6,7 @@
 // ORBextractors on two threads, UndistortKeyPoints (no distortion), ComputeStereoMatches (:1102-1358), AssignFeaturesToGrid (:469-503);
 // the others read the resulting Frame and call its GetFeaturesInArea (:859-951).
 #include <cstdint>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -52,6 +53,36 @@ void* ref_frame_stereo(const uint8_t* L, const uint8_t* R, int w, int h, int nfe
     return H;
 }
 void ref_frame_destroy(void* h) { delete (Holder*)h; }
+
+// bench.py's cpu_baseline: the reference's steady state - two long-lived extractors (Tracking owns them), one Frame temporary per stereo
+// pair built in the same storage (the constructor itself runs the two extractions on two threads).  Returns the number of frames
+// constructed in `seconds`; *elapsed = the time they took.
+int ref_frame_stereo_repeat(const uint8_t* L, const uint8_t* R, int w, int h, int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th,
+                            float fx, float fy, float cx, float cy, float bf, float th_depth, double seconds, double* elapsed, int* matches) {
+    ORBextractor left(nfeatures, scale_factor, nlevels, ini_th, min_th), right(nfeatures, scale_factor, nlevels, ini_th, min_th);
+    Pinhole cam(fx, fy, cx, cy);
+    cv::Mat imL(h, w, CV_8UC1, (void*)L, (size_t)w), imR(h, w, CV_8UC1, (void*)R, (size_t)w);
+    cv::Mat K = cam.toK();
+    cv::Mat dist(4, 1, CV_32F); for (int i = 0; i < 4; i++) dist.at<float>(i) = 0.0f;
+    void* storage = ::operator new(sizeof(Frame));
+    memset(storage, 0, sizeof(Frame));
+    reinterpret_cast<Frame*>(storage)->mb = bf / fx;
+    const auto t0 = std::chrono::steady_clock::now();
+    int n = 0; double dt = 0;
+    do {
+        Frame* F = new (storage) Frame(imL, imR, 0.0, &left, &right, nullptr, K, dist, bf, th_depth, &cam);
+        int m = 0; for (int i = 0; i < F->N; i++) m += F->mvuRight[i] >= 0;
+        *matches = m;
+        const float mb = F->mb;
+        F->~Frame();
+        reinterpret_cast<Frame*>(storage)->mb = mb;
+        n++;
+        dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    } while (dt < seconds);
+    ::operator delete(storage);
+    *elapsed = dt;
+    return n;
+}
 
 // mvKeys, mvKeysUn, mDescriptors, mvuRight, mvDepth (N entries each) and mvKeysRight, mDescriptorsRight
 void ref_frame_get(void* h, void* keys, void* keys_un, uint8_t* desc, float* u_right, float* depth, void* keys_right, uint8_t* desc_right) {
