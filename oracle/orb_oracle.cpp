@@ -23,7 +23,8 @@
 // PINNED against the reference's own src/Frame.cc (compiled unmodified over oracle/slam_shim/frame_world.h, oracle/_ref/libref_frame.so):
 // ComputeStereoMatches - through the reference's whole stereo Frame constructor, extraction included - and Frame::GetFeaturesInArea on the
 // reference's own grid (tests/test_frame_reference.py).
-// UNPINNED: the fisheye kNN step (cv::BFMatcher is OpenCV) and ComputeDistinctiveDescriptors (src/MapPoint.cc cannot be compiled here).
+// PINNED against the reference's own src/MapPoint.cc (oracle/_ref/libref_mappoint.so): ComputeDistinctiveDescriptors (tests/test_emu_mappoint.py).
+// UNPINNED: the fisheye kNN step (cv::BFMatcher is OpenCV, not installed).
 //
 // The extractor restatement deliberately uses the *derived* formulation the GPU kernels use
 // (SURVEY.md §8a row F2): one FAST score map at min(iniTh,minTh), cell-local strict 3x3 NMS, and a

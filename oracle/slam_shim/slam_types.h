@@ -4,7 +4,9 @@
 #ifndef ORBX_SLAM_TYPES_H
 #define ORBX_SLAM_TYPES_H
 
+#ifndef ORBX_REAL_MAPPOINT
 #define MAPPOINT_H
+#endif
 #define KEYFRAME_H
 
 #include <cmath>
@@ -40,6 +42,8 @@ struct Vector3f {
     float& operator[](int i) { return d[i]; }
     const float& operator[](int i) const { return d[i]; }
     void setZero() { d[0] = d[1] = d[2] = 0; }
+    float* data() { return d; }
+    size_t size() const { return 3; }
     float dot(const Vector3f& o) const { return d[0] * o.d[0] + d[1] * o.d[1] + d[2] * o.d[2]; }
     float norm() const { return std::sqrt(dot(*this)); }
 };
@@ -112,6 +116,7 @@ namespace ORB_SLAM3 {
 class KeyFrame;
 class Frame;
 class MapPoint;
+class Map;
 
 // pinhole GeometricCamera: parameters fx, fy, cx, cy
 class GeometricCamera {
@@ -148,6 +153,7 @@ public:
     }
 };
 
+#ifndef ORBX_REAL_MAPPOINT
 class MapPoint {
 public:
     // tracking fields (include/MapPoint.h:171-179)
@@ -184,6 +190,8 @@ public:
     void AddObservation(KeyFrame* pKF, int idx) { observations[pKF] = std::tuple<int, int>(idx, -1); nObs++; }
     void Replace(MapPoint* pMP) { replacedBy = pMP; bad = true; }
 };
+
+#endif
 
 #define FRAME_GRID_ROWS 48
 #define FRAME_GRID_COLS 64
@@ -235,8 +243,20 @@ public:
 
     std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
     MapPoint* GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; }
+#ifndef ORBX_REAL_MAPPOINT
     std::set<MapPoint*> GetMapPoints() { std::set<MapPoint*> s; for (MapPoint* p : mvpMapPoints) if (p && !p->isBad()) s.insert(p); return s; }   // src/KeyFrame.cc:370-385
+#else
+    std::set<MapPoint*> GetMapPoints();            // defined where the real MapPoint is complete (oracle/ref_mappoint_driver.cpp)
+#endif
     void AddMapPoint(MapPoint* pMP, const size_t& idx) { mvpMapPoints[idx] = pMP; }
+    // what src/MapPoint.cc calls on a key frame
+    long unsigned int mnId = 0, mnFrameId = 0;
+    bool mbBadKF = false;
+    bool isBad() { return mbBadKF; }
+    Map* GetMap() { return nullptr; }
+    void EraseMapPointMatch(const int& idx) { mvpMapPoints[idx] = nullptr; }
+    void EraseMapPointMatch(MapPoint* pMP) { for (auto& p : mvpMapPoints) if (p == pMP) p = nullptr; }
+    void ReplaceMapPointMatch(const int& idx, MapPoint* pMP) { mvpMapPoints[idx] = pMP; }
     Sophus::SE3f GetPose() { return mTcw; }
     Sophus::SE3f GetPoseInverse() { return mTcw.inverse(); }
     Eigen::Vector3f GetCameraCenter() { return mTcw.inverse().translation(); }

@@ -470,3 +470,34 @@ def reference_frame_repeat(left, right, seconds, nfeatures=1200, scale=1.2, nlev
     n = L.ref_frame_stereo_repeat(left.ctypes.data, right.ctypes.data, left.shape[1], left.shape[0], nfeatures, scale, nlevels, ini, mn, fx, fy, cx, cy, bf, th_depth,
                                   float(seconds), C.byref(el), C.byref(m))
     return n, el.value, m.value
+
+
+_REF_MP = None
+
+
+def reference_mappoint_lib():
+    """The reference's own MapPoint.cc (+ Frame.cc, ORBmatcher.cc) built over oracle/slam_shim/mappoint_world.h (oracle/_ref/libref_mappoint.so); None if absent."""
+    global _REF_MP
+    if _REF_MP is None:
+        p = os.path.join(ORACLE_DIR, "_ref", "libref_mappoint.so")
+        if not os.path.exists(p) and os.path.exists("/root/reference/src/MapPoint.cc"):
+            build()
+        if not os.path.exists(p):
+            return None
+        L = C.CDLL(p)
+        L.ref_mp_distinctive.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _REF_MP = L
+    return _REF_MP
+
+
+def reference_distinctive_descriptors(desc, start, right_of_prev=None, bad_kf=None):
+    """MapPoint::ComputeDistinctiveDescriptors as the reference's own MapPoint.cc executes it.  Returns (descriptors [P,32], has [P])."""
+    L = reference_mappoint_lib()
+    desc = np.ascontiguousarray(desc, np.uint8); start = np.ascontiguousarray(start, np.int32)
+    n = len(desc); P = len(start) - 1
+    rp = np.zeros(max(n, 1), np.uint8) if right_of_prev is None else np.ascontiguousarray(right_of_prev, np.uint8)
+    bk = np.zeros(max(n, 1), np.uint8) if bad_kf is None else np.ascontiguousarray(bad_kf, np.uint8)
+    out = np.zeros((max(P, 1), 32), np.uint8); has = np.zeros(max(P, 1), np.uint8)
+    d = desc if n else np.zeros((1, 32), np.uint8)
+    L.ref_mp_distinctive(d.ctypes.data, start.ctypes.data, rp.ctypes.data, bk.ctypes.data, P, out.ctypes.data, has.ctypes.data)
+    return out[:P], has[:P]

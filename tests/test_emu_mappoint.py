@@ -34,6 +34,37 @@ def run(lib, P, nmax, seed):
     assert np.array_equal(got, exp)
     assert got[0] == -1 and got[1] == 0
     assert len(M.ComputeDistinctiveDescriptors(ex, desc[:0], np.zeros(1, np.int32))) == 0
+    if ol.reference_mappoint_lib() is not None:
+        vs_reference(ex, rng, desc, start, got)
+
+
+def vs_reference(ex, rng, desc, start, got):
+    """The reference's own src/MapPoint.cc (oracle/_ref/libref_mappoint.so): one MapPoint per point, one key frame per observation (or one
+    fisheye-rig key frame for a left/right pair), AddObservation, ComputeDistinctiveDescriptors, GetDescriptor."""
+    P = len(start) - 1
+    n = len(desc)
+    # some observations are the right-camera view of the previous observation's key frame
+    rp = (rng.random(n) < 0.15).astype(np.uint8)
+    rp[start[:-1][start[:-1] < n]] = 0
+    for o in range(1, n):
+        if rp[o] and rp[o - 1]:
+            rp[o] = 0                               # a key frame has one right-camera observation of a point at most
+    ref_desc, has = ol.reference_distinctive_descriptors(desc, start, rp)
+    for p in range(P):
+        assert bool(has[p]) == (got[p] >= 0)
+        if has[p]:
+            assert ref_desc[p].tobytes() == desc[start[p] + got[p]].tobytes(), "point %d: the reference keeps a different descriptor" % p
+    # bad key frames are skipped by the reference (:455); the caller of the C ABI leaves their observations out
+    bad = (rng.random(n) < 0.2).astype(np.uint8)
+    ref_desc, has = ol.reference_distinctive_descriptors(desc, start, None, bad)
+    keep = bad == 0
+    start2 = np.concatenate([[0], np.cumsum([int(keep[start[p]:start[p + 1]].sum()) for p in range(P)])]).astype(np.int32)
+    desc2 = np.ascontiguousarray(desc[keep])
+    got2 = M.ComputeDistinctiveDescriptors(ex, desc2, start2)
+    for p in range(P):
+        assert bool(has[p]) == (got2[p] >= 0)
+        if has[p]:
+            assert ref_desc[p].tobytes() == desc2[start2[p] + got2[p]].tobytes()
 
 
 def test_distinctive_descriptors_emulated(emu_lib):
