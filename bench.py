@@ -260,17 +260,21 @@ def main():
             except Exception:
                 traffic = None
         # VALU issue view of the same kernel (the HBM fraction says little for a compute-heavy integer kernel): wave-instructions per
-        # launch from the SQ counter pass (profiles/pmc_valu.json, scaled to this launch size) against the issue peak of
-        # 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md)
+        # launch from the SQ counter pass (profiles/pmc_valu.json, scaled to this launch size) against the issue rates MEASURED on this
+        # part with tools/valu_issue_microbench.hip (profiles/r01_final/valu_microbench.txt): v_add_u32 / v_fma_f32 issue at 937 G
+        # wave-instr/s, the classes FAST is made of (VOP3P packed 16-bit min/max/sub/mad, v_perm_b32, v_alignbyte_b32, v_min/max_i32,
+        # v_dot4) at 531-562 G wave-instr/s.  A kernel mixing both classes cannot exceed a rate between the two.
         valu = None
         pv = os.path.join(ROOT, "profiles", "pmc_valu.json")
         if os.path.exists(pv):
             try:
                 n_instr = json.load(open(pv)).get(dom, 0) * (2 * P) / 128.0
-                peak = 256 * 4 * 2.4e9 / 2
+                peak_full, peak_packed = 937e9, 545e9
                 if n_instr > 0:
-                    valu = {"wave_instr_per_launch": int(n_instr), "peak_wave_instr_per_s": peak,
-                            "frac": round(n_instr / (stage_ms[dom] * 1e-3) / peak, 4), "alone_frac": round(n_instr / (serial_sum[dom] * 1e-3) / peak, 4)}
+                    valu = {"wave_instr_per_launch": int(n_instr), "peak_wave_instr_per_s": peak_full, "packed_class_peak_wave_instr_per_s": peak_packed,
+                            "achieved_wave_instr_per_s": round(n_instr / (stage_ms[dom] * 1e-3), 0), "alone_wave_instr_per_s": round(n_instr / (serial_sum[dom] * 1e-3), 0),
+                            "frac": round(n_instr / (stage_ms[dom] * 1e-3) / peak_full, 4), "alone_frac": round(n_instr / (serial_sum[dom] * 1e-3) / peak_full, 4),
+                            "alone_frac_of_packed_class": round(n_instr / (serial_sum[dom] * 1e-3) / peak_packed, 4)}
             except Exception:
                 valu = None
         per_pair_bytes = 2 * sum(v for k, v in ab.items() if k != "match") + ab["match"]
