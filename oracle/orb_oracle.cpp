@@ -24,7 +24,8 @@
 // ComputeStereoMatches - through the reference's whole stereo Frame constructor, extraction included - and Frame::GetFeaturesInArea on the
 // reference's own grid (tests/test_frame_reference.py).
 // PINNED against the reference's own src/MapPoint.cc (oracle/_ref/libref_mappoint.so): ComputeDistinctiveDescriptors (tests/test_emu_mappoint.py).
-// UNPINNED: the fisheye kNN step (cv::BFMatcher is OpenCV, not installed).
+// The fisheye kNN + ratio decision is pinned through the reference's fisheye-rig Frame constructor, with cv::BFMatcher itself restated
+// in the shim (OpenCV is not installed) and the KB8 triangulation gate set to accept-all.
 //
 // The extractor restatement deliberately uses the *derived* formulation the GPU kernels use
 // (SURVEY.md §8a row F2): one FAST score map at min(iniTh,minTh), cell-local strict 3x3 NMS, and a

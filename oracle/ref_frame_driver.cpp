@@ -18,8 +18,8 @@ using namespace ORB_SLAM3;
 namespace {
 struct RefKp { float x, y, size, angle, response; int octave, class_id; };
 struct Holder {
-    ORBextractor *left, *right; Pinhole* cam; Frame* frame;
-    ~Holder() { delete frame; delete left; delete right; delete cam; }
+    ORBextractor *left = nullptr, *right = nullptr; Pinhole* cam = nullptr; KannalaBrandt8 *kb1 = nullptr, *kb2 = nullptr; Frame* frame = nullptr;
+    ~Holder() { delete frame; delete left; delete right; delete cam; delete kb1; delete kb2; }
 };
 void put_keys(const std::vector<cv::KeyPoint>& k, void* out) {
     RefKp* o = (RefKp*)out;
@@ -53,6 +53,36 @@ void* ref_frame_stereo(const uint8_t* L, const uint8_t* R, int w, int h, int nfe
     return H;
 }
 void ref_frame_destroy(void* h) { delete (Holder*)h; }
+
+// The fisheye-rig constructor (src/Frame.cc:1432-1528): two extractions with the cameras' lapping areas, ComputeStereoFishEyeMatches
+// (:1530-1587: BFMatcher 2-NN on the lapping parts + the 0.7 ratio test; the triangulation gate accepts everything, see frame_world.h),
+// vconcat of the descriptors, AssignFeaturesToGrid.  out = {Nleft, Nright, monoLeft, monoRight}.
+void* ref_frame_fisheye(const uint8_t* L, const uint8_t* R, int w, int h, int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, int gauss_variant,
+                        int lap_l0, int lap_l1, int lap_r0, int lap_r1, int* out) {
+    cv::shim_gauss_variant() = gauss_variant;
+    Holder* H = new Holder();
+    H->left = new ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th);
+    H->right = new ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th);
+    H->kb1 = new KannalaBrandt8(); H->kb2 = new KannalaBrandt8();
+    H->kb1->mvLappingArea[0] = lap_l0; H->kb1->mvLappingArea[1] = lap_l1; H->kb2->mvLappingArea[0] = lap_r0; H->kb2->mvLappingArea[1] = lap_r1;
+    cv::Mat imL(h, w, CV_8UC1, (void*)L, (size_t)w), imR(h, w, CV_8UC1, (void*)R, (size_t)w);
+    cv::Mat K(3, 3, CV_32F); for (int i = 0; i < 9; i++) K.at<float>(i / 3, i % 3) = (i % 4 == 0) ? 1.0f : 0.0f;
+    K.at<float>(0, 0) = 190.9f; K.at<float>(1, 1) = 190.9f; K.at<float>(0, 2) = 254.9f; K.at<float>(1, 2) = 256.9f;
+    cv::Mat dist(4, 1, CV_32F); for (int i = 0; i < 4; i++) dist.at<float>(i) = 0.0f;
+    Sophus::SE3f Tlr;
+    Frame::mbInitialComputations = true;
+    H->frame = new Frame(imL, imR, 0.0, H->left, H->right, nullptr, K, dist, 19.3f, 40.0f, H->kb1, H->kb2, Tlr);
+    out[0] = H->frame->Nleft; out[1] = H->frame->Nright; out[2] = H->frame->monoLeft; out[3] = H->frame->monoRight;
+    return H;
+}
+// mvKeys [Nleft], mvKeysRight [Nright], mDescriptors [Nleft + Nright rows: left then right], mvLeftToRightMatch [Nleft], mvRightToLeftMatch [Nright]
+void ref_frame_fisheye_get(void* h, void* keys, void* keys_right, uint8_t* desc, int* l2r, int* r2l) {
+    Frame* F = ((Holder*)h)->frame;
+    put_keys(F->mvKeys, keys); put_keys(F->mvKeysRight, keys_right);
+    for (int i = 0; i < F->N; i++) memcpy(desc + 32 * (size_t)i, F->mDescriptors.ptr(i), 32);
+    for (int i = 0; i < F->Nleft; i++) l2r[i] = F->mvLeftToRightMatch[i];
+    for (int i = 0; i < F->Nright; i++) r2l[i] = F->mvRightToLeftMatch[i];
+}
 
 // bench.py's cpu_baseline: the reference's steady state - two long-lived extractors (Tracking owns them), one Frame temporary per stereo
 // pair built in the same storage (the constructor itself runs the two extractions on two threads).  Returns the number of frames

@@ -56,7 +56,12 @@ class KannalaBrandt8 : public GeometricCamera {
 public:
     std::vector<int> mvLappingArea{0, 0};
     KannalaBrandt8() : GeometricCamera(1, 1, 0, 0) {}
-    float TriangulateMatches(GeometricCamera*, const cv::KeyPoint&, const cv::KeyPoint&, const Eigen::Matrix3f&, const Eigen::Vector3f&, const float, const float, Eigen::Vector3f&) { return -1; }
+    // The triangulation gate of ComputeStereoFishEyeMatches (src/Frame.cc:1568-1573) is host-side geometry outside the accelerated path
+    // (DESIGN.md, row M2): the stand-in accepts every pair, so that what the reference's own loop leaves in mvLeftToRightMatch /
+    // mvRightToLeftMatch is exactly its kNN + ratio decision.
+    float TriangulateMatches(GeometricCamera*, const cv::KeyPoint&, const cv::KeyPoint&, const Eigen::Matrix3f&, const Eigen::Vector3f&, const float, const float, Eigen::Vector3f& p3D) {
+        p3D = Eigen::Vector3f(0, 0, 1); return 1.0f;
+    }
 };
 }  // namespace ORB_SLAM3
 #endif

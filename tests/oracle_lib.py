@@ -423,6 +423,9 @@ def reference_frame_lib():
         L.ref_frame_stereo.restype = C.c_void_p
         L.ref_frame_stereo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_float] * 6 + [C.POINTER(C.c_int)] * 2
         L.ref_frame_destroy.argtypes = [C.c_void_p]
+        L.ref_frame_fisheye.restype = C.c_void_p
+        L.ref_frame_fisheye.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float] + [C.c_int] * 8 + [C.c_void_p]
+        L.ref_frame_fisheye_get.argtypes = [C.c_void_p] * 6
         L.ref_frame_stereo_repeat.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_float] * 6 + [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.ref_frame_get.argtypes = [C.c_void_p] * 8
         L.ref_frame_constants.argtypes = [C.c_void_p, C.c_void_p]
@@ -501,3 +504,19 @@ def reference_distinctive_descriptors(desc, start, right_of_prev=None, bad_kf=No
     d = desc if n else np.zeros((1, 32), np.uint8)
     L.ref_mp_distinctive(d.ctypes.data, start.ctypes.data, rp.ctypes.data, bk.ctypes.data, P, out.ctypes.data, has.ctypes.data)
     return out[:P], has[:P]
+
+
+def reference_fisheye_frame(left, right, lap_left, lap_right, nfeatures=1500, scale=1.2, nlevels=8, ini=20, mn=7, gauss_variant=0):
+    """The reference's fisheye-rig Frame constructor (src/Frame.cc:1432-1528) with an accept-all triangulation gate.
+    Returns dict(keys, keys_right, desc [Nleft+Nright,32], mono_left, mono_right, l2r, r2l)."""
+    L = reference_frame_lib()
+    left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
+    out = np.zeros(4, np.int32)
+    h = L.ref_frame_fisheye(left.ctypes.data, right.ctypes.data, left.shape[1], left.shape[0], nfeatures, scale, nlevels, ini, mn, gauss_variant,
+                            lap_left[0], lap_left[1], lap_right[0], lap_right[1], out.ctypes.data)
+    nl, nr, ml, mr = [int(v) for v in out]
+    keys = np.zeros(nl, KP_DTYPE); keys_r = np.zeros(nr, KP_DTYPE); desc = np.zeros((nl + nr, 32), np.uint8)
+    l2r = np.zeros(max(nl, 1), np.int32); r2l = np.zeros(max(nr, 1), np.int32)
+    L.ref_frame_fisheye_get(h, keys.ctypes.data, keys_r.ctypes.data, desc.ctypes.data, l2r.ctypes.data, r2l.ctypes.data)
+    L.ref_frame_destroy(h)
+    return dict(keys=keys, keys_right=keys_r, desc=desc, mono_left=ml, mono_right=mr, l2r=l2r[:nl], r2l=r2l[:nr])

@@ -90,3 +90,56 @@ def test_product_equals_reference_frame_emulated(emu_lib):
 @pytest.mark.gpu
 def test_product_equals_reference_frame_gpu(hip_lib):
     _product_vs_reference(hip_lib, CASES)
+
+
+# ---- the fisheye-rig constructor (src/Frame.cc:1432-1528): extraction with lapping areas + ComputeStereoFishEyeMatches (:1530-1587) ----
+RIG_CASES = [(512, 512, 5, 1500, (0, 511)), (512, 512, 6, 1000, (100, 400)), (376, 240, 20, 500, (60, 300))]
+
+
+def _expected_l2r(F, ref):
+    nl = len(F["keys"])
+    exp = np.full(nl, -1, np.int32); r2l = np.full(len(F["keys_right"]), -1, np.int32)
+    for i in range(nl - F["mono_left"]):
+        if ref["ratio_ok"][i]:                                  # (*it)[0].distance < (*it)[1].distance * 0.7  (:1556)
+            exp[i + F["mono_left"]] = ref["idx0"][i] + F["mono_right"]
+            r2l[ref["idx0"][i] + F["mono_right"]] = i + F["mono_left"]
+    return exp, r2l
+
+
+@pytest.mark.parametrize("case", RIG_CASES)
+def test_oracle_equals_reference_fisheye_frame(case):
+    w, h, seed, nf, lap = case
+    L, R = _pair(w, h, seed)
+    F = ol.reference_fisheye_frame(L, R, lap, lap, nf)
+    nl = len(F["keys"])
+    oL, oR = ol.OracleExtractor(nf), ol.OracleExtractor(nf)
+    (mL, kL, dL), (mR, kR, dR) = oL.extract(L, lap), oR.extract(R, lap)
+    assert (mL, mR) == (F["mono_left"], F["mono_right"])
+    assert kL.tobytes() == F["keys"].tobytes() and kR.tobytes() == F["keys_right"].tobytes()
+    assert np.concatenate([dL, dR]).tobytes() == F["desc"].tobytes()                 # cv::vconcat(mDescriptors, mDescriptorsRight) (:1514)
+    exp, r2l = _expected_l2r(F, ol.oracle_knn2(dL[mL:], dR[mR:]))
+    assert np.array_equal(exp, F["l2r"]) and np.array_equal(r2l, F["r2l"]) and (exp >= 0).sum() > 20
+
+
+def _product_vs_reference_rig(lib, cases):
+    for w, h, seed, nf, lap in cases:
+        L, R = _pair(w, h, seed)
+        F = ol.reference_fisheye_frame(L, R, lap, lap, nf)
+        ex = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib)
+        (mL, kL, dL), (mR, kR, dR) = ex.extract_batch(np.stack([L, R]), lap)
+        assert (mL, mR) == (F["mono_left"], F["mono_right"])
+        assert kL.tobytes() == F["keys"].tobytes() and kR.tobytes() == F["keys_right"].tobytes() and np.concatenate([dL, dR]).tobytes() == F["desc"].tobytes()
+        out = M.StereoFishEyeKnn(ex, ex, 0, 1, 1)
+        nq = len(kL) - mL
+        got = {k: out[k][0, :nq] for k in ("idx0", "ratio_ok")}
+        exp, r2l = _expected_l2r(F, got)
+        assert np.array_equal(exp, F["l2r"]) and np.array_equal(r2l, F["r2l"]), "mvLeftToRightMatch / mvRightToLeftMatch differ from the reference Frame"
+
+
+def test_product_equals_reference_fisheye_frame_emulated(emu_lib):
+    _product_vs_reference_rig(emu_lib, RIG_CASES[2:])
+
+
+@pytest.mark.gpu
+def test_product_equals_reference_fisheye_frame_gpu(hip_lib):
+    _product_vs_reference_rig(hip_lib, RIG_CASES)
