@@ -1,0 +1,52 @@
+"""Soak: many seeded worlds / image pairs, product (HIP library) vs the reference's own compiled sources (oracle/_ref).  Run on a GPU box:
+    python tools/soak_reference.py [n_seeds]
+Prints one line per family and exits non-zero on the first difference."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as ol                                     # noqa: E402
+from orb_slam3_detailed_comments_amd import _lib, ORBextractor, ComputeStereoMatches, synth   # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+REF = os.path.join(ROOT, "oracle", "_ref", "libmw_ref.so"); FAC = os.path.join(ROOT, "oracle", "_ref", "libmw_facade.so")
+RUN = os.path.join(ROOT, "tests", "matcher_world.py")
+tmp = tempfile.mkdtemp()
+bad = 0
+for seed in range(1000, 1000 + n):
+    for variant in ("base", "dense", "hard", "rig"):
+        a = os.path.join(tmp, "a.npz"); b = os.path.join(tmp, "b.npz")
+        subprocess.run([sys.executable, RUN, REF, "", str(seed), variant, a], check=True)
+        subprocess.run([sys.executable, RUN, FAC, _lib.HIP_LIB_PATH, str(seed), variant, b], check=True)
+        A, B = np.load(a), np.load(b)
+        for k in A.files:
+            if k != "flavour" and not np.array_equal(A[k], B[k]):
+                print("DIFF world seed %d %s: %s" % (seed, variant, k)); bad += 1
+print("matcher worlds: %d seeds x 4 variants, %d differences" % (n, bad))
+
+lib = _lib.load_hip()
+FX = 458.654; BF = FX * 0.110074
+bad2 = 0
+for seed in range(2000, 2000 + n):
+    w, h = [(752, 480), (640, 480), (376, 240)][seed % 3]
+    nf = [1200, 1000, 500][seed % 3]
+    kind = seed % 4
+    if kind == 3:
+        L = synth.pink_noise(w, h, seed=seed); R = np.roll(L, -7, axis=1)
+    else:
+        L, R = synth.stereo_pair(w, h, seed=seed, nrect=[2000, 800, 3000][kind])
+    F = ol.ReferenceFrame(L, R, nf, fx=FX, bf=BF)
+    ex = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib)
+    (_, kL, dL), (_, kR, dR) = ex.extract_batch(np.stack([L, R]))
+    u, d, m = ComputeStereoMatches(ex, ex, BF, F.mb, 0, 1, 1)
+    ok = (kL.tobytes() == F.keys.tobytes() and dL.tobytes() == F.desc.tobytes() and kR.tobytes() == F.keys_right.tobytes() and dR.tobytes() == F.desc_right.tobytes()
+          and u[0, :F.N].tobytes() == F.u_right.tobytes() and d[0, :F.N].tobytes() == F.depth.tobytes())
+    if not ok:
+        print("DIFF frame seed %d (%dx%d)" % (seed, w, h)); bad2 += 1
+print("stereo frames: %d pairs, %d differences" % (n, bad2))
+sys.exit(1 if bad or bad2 else 0)
