@@ -176,6 +176,8 @@ __device__ __forceinline__ pk2 pk_min(pk2 a, pk2 b) { pk2 r; r.x = a.x < b.x ? a
 __device__ __forceinline__ pk2 pk_max(pk2 a, pk2 b) { pk2 r; r.x = a.x > b.x ? a.x : b.x; r.y = a.y > b.y ? a.y : b.y; return r; }
 __device__ __forceinline__ int pk_lo(pk2 a) { return a.x; }
 __device__ __forceinline__ int pk_hi(pk2 a) { return a.y; }
+__device__ __forceinline__ pk2 pk_min3(pk2 a, pk2 b, pk2 c) { return pk_min(pk_min(a, b), c); }
+__device__ __forceinline__ pk2 pk_max3(pk2 a, pk2 b, pk2 c) { return pk_max(pk_max(a, b), c); }
 #else
 typedef short pk2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ pk2 pk_make(uint32_t v) { return __builtin_bit_cast(pk2, v); }
@@ -185,7 +187,15 @@ __device__ __forceinline__ pk2 pk_min(pk2 a, pk2 b) { return __builtin_elementwi
 __device__ __forceinline__ pk2 pk_max(pk2 a, pk2 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ int pk_lo(pk2 a) { return (int)a.x; }
 __device__ __forceinline__ int pk_hi(pk2 a) { return (int)a.y; }
+// Three-input packed min / max.  gfx950 has no 3-input packed INTEGER min/max, but it has v_pk_minimum3_f16 / v_pk_maximum3_f16, and positive
+// normal binary16 numbers are ordered exactly like their bit patterns read as integers.  Every caller keeps its operands in
+// [0x0400, 0x7BFF] (pixel values biased by 0x6400, signed differences biased by 0x4000), where the two orders coincide and neither NaN
+// nor denormal handling can interfere.  Same issue rate as the 2-input packed ops (tools/valu_issue_microbench.hip).
+__device__ __forceinline__ pk2 pk_min3(pk2 a, pk2 b, pk2 c) { pk2 d; asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ pk2 pk_max3(pk2 a, pk2 b, pk2 c) { pk2 d; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 #endif
+constexpr int kPixBias = 0x6400;     // pixel value b is carried as 0x6400 + b (binary16 1024 + b) in phase A
+constexpr int kDiffBias = 0x4000;    // a signed difference d in [-255, 255] is carried as 0x4000 + d in phase B
 
 // ---------------------------------------------------------------------------------------------------
 // FAST-9/16.  ring offsets (dx,dy), k = 0..15, as in OpenCV: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)
@@ -203,16 +213,19 @@ __device__ __forceinline__ int pk_hi(pk2 a) { return (int)a.y; }
 // one-sided variant: d[k] = sign * (v - ring_k) with sign = +1 for a dark candidate and -1 for a bright one, so that both become
 // "max over the 16 nine-arcs of the arc minimum"
 __device__ __forceinline__ void fast_score_pk(const pk2 d[16], int t0, int& sA, int& sB) {
-    pk2 mn2[16];
+    // d[k] carries kDiffBias.  9-window minima as min3 of three 3-window minima, maximum over the 16 windows by max3.
+    pk2 w3[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) mn2[k] = pk_min(d[k], d[(k + 1) & 15]);
-    pk2 mn4[16];
+    for (int k = 0; k < 16; k++) w3[k] = pk_min3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+    pk2 w9[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) mn4[k] = pk_min(mn2[k], mn2[(k + 2) & 15]);
-    pk2 Md = pk_min(pk_min(mn4[0], mn4[4]), d[8]);
+    for (int k = 0; k < 16; k++) w9[k] = pk_min3(w3[k], w3[(k + 3) & 15], w3[(k + 6) & 15]);
+    pk2 m[6];
 #pragma unroll
-    for (int k = 1; k < 16; k++) Md = pk_max(Md, pk_min(pk_min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]));
-    const int mA = pk_lo(Md), mB = pk_hi(Md);
+    for (int k = 0; k < 5; k++) m[k] = pk_max3(w9[3 * k], w9[3 * k + 1], w9[3 * k + 2]);
+    m[5] = w9[15];
+    const pk2 Md = pk_max3(pk_max3(m[0], m[1], m[2]), pk_max3(m[3], m[4], m[5]), m[5]);
+    const int mA = pk_lo(Md) - kDiffBias, mB = pk_hi(Md) - kDiffBias;
     sA = mA > t0 ? mA - 1 : 0;
     sB = mB > t0 ? mB - 1 : 0;
 }
@@ -308,7 +321,7 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
             const uint8_t* cA = tile + mul24(yA + 2, wp) + xo + xA + 2;
             const uint8_t* cB = tile + mul24(yB + 2, wp) + xo + xB + 2;
             // (gathering the ring with 7 unaligned ds_read_b32/b64 per pixel instead of 17 byte reads was measured 67 % slower)
-            const pk2 c2 = pk_make((uint32_t)((sgA * (int)cA[0]) & 0xFFFF) | ((uint32_t)(sgB * (int)cB[0]) << 16));    // sign * v
+            const pk2 c2 = pk_make((uint32_t)((sgA * (int)cA[0] + kDiffBias) & 0xFFFF) | ((uint32_t)(sgB * (int)cB[0] + kDiffBias) << 16));    // sign * v + bias
             const pk2 ns2 = pk_make((uint32_t)((-sgA) & 0xFFFF) | ((uint32_t)(-sgB) << 16));                            // -sign
             pk2 d[16];
 #define ORBX_D(k, off) d[k] = pk_mad(pk_make((uint32_t)cA[off] | ((uint32_t)cB[off] << 16)), ns2, c2);
@@ -346,12 +359,13 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
                 xbase = 4 * g - (xo + 3);                  // interior x of this lane's first pixel (may be < 0)
                 const uint32_t* rp = tile32 + mul24(y + 3, wpd) + g;
                 uint32_t Lw[7], Cw[7], Rw[7];
+                const uint32_t kBias4 = (uint32_t)(kPixBias >> 8) * 0x01010101u;          // the high byte of every widened pixel
 #pragma unroll
                 for (int r = 0; r < 7; r++) { const uint32_t* pr = rp + (r - 3) * wpd; Lw[r] = pr[-1]; Cw[r] = pr[0]; Rw[r] = pr[1]; }
                 // ring bytes of the 4 pixels, widened to 2 x (2 x u16); row index r = dy + 3
                 pk2 rlo[16], rhi[16];
 #define ORBX_RING(k, r, dx) { const uint32_t w4 = (dx) == 0 ? Cw[r] : ((dx) > 0 ? align_byte(Rw[r], Cw[r], (dx)) : align_byte(Cw[r], Lw[r], 4 + (dx))); \
-                              rlo[k] = pk_make(byte_perm(0u, w4, 0x0c010c00u)); rhi[k] = pk_make(byte_perm(0u, w4, 0x0c030c02u)); }
+                              rlo[k] = pk_make(byte_perm(kBias4, w4, 0x04010400u)); rhi[k] = pk_make(byte_perm(kBias4, w4, 0x04030402u)); }
                 ORBX_RING(0, 6, 0)  ORBX_RING(1, 6, 1)  ORBX_RING(2, 5, 2)  ORBX_RING(3, 4, 3)
                 ORBX_RING(4, 3, 3)  ORBX_RING(5, 2, 3)  ORBX_RING(6, 1, 2)  ORBX_RING(7, 0, 1)
                 ORBX_RING(8, 0, 0)  ORBX_RING(9, 0, -1) ORBX_RING(10, 1, -2) ORBX_RING(11, 2, -3)
@@ -359,14 +373,17 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
 #undef ORBX_RING
                 // a dark 9-arc needs min(ring_k, ring_k+8) < v - t for all 8 pairs, a bright one max(..) > v + t:
                 //   M = max_k min(pair) ,  N = min_k max(pair) ;  possible corner  <=>  v - M > t  or  N - v > t
-                pk2 M_lo = pk_min(rlo[0], rlo[8]), N_lo = pk_max(rlo[0], rlo[8]);
-                pk2 M_hi = pk_min(rhi[0], rhi[8]), N_hi = pk_max(rhi[0], rhi[8]);
+                pk2 mn_lo[8], mx_lo[8], mn_hi[8], mx_hi[8];
 #pragma unroll
-                for (int k = 1; k < 8; k++) {
-                    M_lo = pk_max(M_lo, pk_min(rlo[k], rlo[k + 8])); N_lo = pk_min(N_lo, pk_max(rlo[k], rlo[k + 8]));
-                    M_hi = pk_max(M_hi, pk_min(rhi[k], rhi[k + 8])); N_hi = pk_min(N_hi, pk_max(rhi[k], rhi[k + 8]));
+                for (int k = 0; k < 8; k++) {
+                    mn_lo[k] = pk_min(rlo[k], rlo[k + 8]); mx_lo[k] = pk_max(rlo[k], rlo[k + 8]);
+                    mn_hi[k] = pk_min(rhi[k], rhi[k + 8]); mx_hi[k] = pk_max(rhi[k], rhi[k + 8]);
                 }
-                const pk2 vlo = pk_make(byte_perm(0u, Cw[3], 0x0c010c00u)), vhi = pk_make(byte_perm(0u, Cw[3], 0x0c030c02u));
+                const pk2 M_lo = pk_max(pk_max3(mn_lo[0], mn_lo[1], mn_lo[2]), pk_max3(pk_max3(mn_lo[3], mn_lo[4], mn_lo[5]), mn_lo[6], mn_lo[7]));
+                const pk2 M_hi = pk_max(pk_max3(mn_hi[0], mn_hi[1], mn_hi[2]), pk_max3(pk_max3(mn_hi[3], mn_hi[4], mn_hi[5]), mn_hi[6], mn_hi[7]));
+                const pk2 N_lo = pk_min(pk_min3(mx_lo[0], mx_lo[1], mx_lo[2]), pk_min3(pk_min3(mx_lo[3], mx_lo[4], mx_lo[5]), mx_lo[6], mx_lo[7]));
+                const pk2 N_hi = pk_min(pk_min3(mx_hi[0], mx_hi[1], mx_hi[2]), pk_min3(pk_min3(mx_hi[3], mx_hi[4], mx_hi[5]), mx_hi[6], mx_hi[7]));
+                const pk2 vlo = pk_make(byte_perm(kBias4, Cw[3], 0x04010400u)), vhi = pk_make(byte_perm(kBias4, Cw[3], 0x04030402u));
                 const pk2 dk_lo = pk_sub(vlo, M_lo), dk_hi = pk_sub(vhi, M_hi), br_lo = pk_sub(N_lo, vlo), br_hi = pk_sub(N_hi, vhi);
                 const unsigned passD = (unsigned)(pk_lo(dk_lo) > t0) | ((unsigned)(pk_hi(dk_lo) > t0) << 1) |
                                        ((unsigned)(pk_lo(dk_hi) > t0) << 2) | ((unsigned)(pk_hi(dk_hi) > t0) << 3);

@@ -25,6 +25,10 @@ template <int OP> __global__ void __launch_bounds__(256) k(uint32_t* out, uint32
             if (OP == 7) ORBX_OP("v_dot4_u32_u8 %0, %0, %1, %2");
             if (OP == 8) ORBX_OP("v_pk_sub_i16 %0, %0, %1");
             if (OP == 9) ORBX_OP("v_fma_f32 %0, %0, %1, %2");
+            if (OP == 10) ORBX_OP("v_pk_maximum3_f16 %0, %0, %1, %2");
+            if (OP == 11) ORBX_OP("v_pk_min_f16 %0, %0, %1");
+            if (OP == 12) ORBX_OP("v_max3_i16 %0, %0, %1, %2");
+            if (OP == 13) ORBX_OP("v_pk_add_u16 %0, %0, %1");
         }
     }
     uint32_t r = 0;
@@ -46,6 +50,6 @@ template <int OP> void run(const char* name, uint32_t* d) {
 int main() {
     uint32_t* d; hipMalloc(&d, 256 * 8 * 256 * 4);
     run<0>("v_min_i32", d); run<1>("v_pk_min_i16", d); run<2>("v_pk_max_i16", d); run<3>("v_perm_b32", d); run<4>("v_alignbyte_b32", d);
-    run<5>("v_pk_mad_i16", d); run<6>("v_add_u32", d); run<7>("v_dot4_u32_u8", d); run<8>("v_pk_sub_i16", d); run<9>("v_fma_f32", d);
+    run<5>("v_pk_mad_i16", d); run<6>("v_add_u32", d); run<7>("v_dot4_u32_u8", d); run<8>("v_pk_sub_i16", d); run<9>("v_fma_f32", d); run<10>("v_pk_maximum3_f16", d); run<11>("v_pk_min_f16", d); run<12>("v_max3_i16", d); run<13>("v_pk_add_u16", d);
     return 0;
 }
