@@ -178,6 +178,8 @@ __device__ __forceinline__ int pk_lo(pk2 a) { return a.x; }
 __device__ __forceinline__ int pk_hi(pk2 a) { return a.y; }
 __device__ __forceinline__ pk2 pk_min3(pk2 a, pk2 b, pk2 c) { return pk_min(pk_min(a, b), c); }
 __device__ __forceinline__ pk2 pk_max3(pk2 a, pk2 b, pk2 c) { return pk_max(pk_max(a, b), c); }
+__device__ __forceinline__ pk2 pk_bytes(const uint8_t* a, const uint8_t* b) { pk2 r; r.x = (short)*a; r.y = (short)*b; return r; }
+__device__ __forceinline__ pk2 pk_xor_or(pk2 a, uint32_t x, uint32_t o) { return pk_make((((uint32_t)(uint16_t)a.x | ((uint32_t)(uint16_t)a.y << 16)) ^ x) | o); }
 #else
 typedef short pk2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ pk2 pk_make(uint32_t v) { return __builtin_bit_cast(pk2, v); }
@@ -189,13 +191,15 @@ __device__ __forceinline__ int pk_lo(pk2 a) { return (int)a.x; }
 __device__ __forceinline__ int pk_hi(pk2 a) { return (int)a.y; }
 // Three-input packed min / max.  gfx950 has no 3-input packed INTEGER min/max, but it has v_pk_minimum3_f16 / v_pk_maximum3_f16, and positive
 // normal binary16 numbers are ordered exactly like their bit patterns read as integers.  Every caller keeps its operands in
-// [0x0400, 0x7BFF] (pixel values biased by 0x6400, signed differences biased by 0x4000), where the two orders coincide and neither NaN
+// [0x0400, 0x7BFF] (pixel values biased by 0x6400), where the two orders coincide and neither NaN
 // nor denormal handling can interfere.  Same issue rate as the 2-input packed ops (tools/valu_issue_microbench.hip).
 __device__ __forceinline__ pk2 pk_min3(pk2 a, pk2 b, pk2 c) { pk2 d; asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ pk2 pk_max3(pk2 a, pk2 b, pk2 c) { pk2 d; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// two bytes from two LDS addresses as the two halves of one register; (a ^ x) | o is one v_bitop3_b32
+__device__ __forceinline__ pk2 pk_bytes(const uint8_t* a, const uint8_t* b) { pk2 r = __builtin_bit_cast(pk2, (uint32_t)*a); r.y = (short)(unsigned short)*b; return r; }
+__device__ __forceinline__ pk2 pk_xor_or(pk2 a, uint32_t x, uint32_t o) { return __builtin_bit_cast(pk2, (__builtin_bit_cast(uint32_t, a) ^ x) | o); }
 #endif
-constexpr int kPixBias = 0x6400;     // pixel value b is carried as 0x6400 + b (binary16 1024 + b) in phase A
-constexpr int kDiffBias = 0x4000;    // a signed difference d in [-255, 255] is carried as 0x4000 + d in phase B
+constexpr int kPixBias = 0x6400;     // pixel value b is carried as 0x6400 + b (binary16 1024 + b)
 
 // ---------------------------------------------------------------------------------------------------
 // FAST-9/16.  ring offsets (dx,dy), k = 0..15, as in OpenCV: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)
@@ -212,20 +216,24 @@ constexpr int kDiffBias = 0x4000;    // a signed difference d in [-255, 255] is 
 // max over the 16 nine-arcs of min |v - ring|, minus 1 - sliding 9-window minima by doubling, two pixels per instruction (packed 16-bit).
 // one-sided variant: d[k] = sign * (v - ring_k) with sign = +1 for a dark candidate and -1 for a bright one, so that both become
 // "max over the 16 nine-arcs of the arc minimum"
-__device__ __forceinline__ void fast_score_pk(const pk2 d[16], int t0, int& sA, int& sB) {
-    // d[k] carries kDiffBias.  9-window minima as min3 of three 3-window minima, maximum over the 16 windows by max3.
+// x[k] = ring value of a dark candidate, 255 - ring value of a bright one (+ kPixBias), vp = the centre treated the same way:
+//   dark   max over 9-arcs of min (v - r)  =  v - min over arcs of max r
+//   bright max over 9-arcs of min (r - v)  = (255 - v) - min over arcs of max (255 - r)
+// so both polarities are "centre minus the smallest 9-arc maximum": 9-arc maxima as max3 of three 3-arc maxima, the minimum over the 16
+// arcs by min3.
+__device__ __forceinline__ void fast_score_pk(const pk2 x[16], pk2 vp, int t0, int& sA, int& sB) {
     pk2 w3[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) w3[k] = pk_min3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+    for (int k = 0; k < 16; k++) w3[k] = pk_max3(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
     pk2 w9[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) w9[k] = pk_min3(w3[k], w3[(k + 3) & 15], w3[(k + 6) & 15]);
-    pk2 m[6];
+    for (int k = 0; k < 16; k++) w9[k] = pk_max3(w3[k], w3[(k + 3) & 15], w3[(k + 6) & 15]);
+    pk2 m[5];
 #pragma unroll
-    for (int k = 0; k < 5; k++) m[k] = pk_max3(w9[3 * k], w9[3 * k + 1], w9[3 * k + 2]);
-    m[5] = w9[15];
-    const pk2 Md = pk_max3(pk_max3(m[0], m[1], m[2]), pk_max3(m[3], m[4], m[5]), m[5]);
-    const int mA = pk_lo(Md) - kDiffBias, mB = pk_hi(Md) - kDiffBias;
+    for (int k = 0; k < 5; k++) m[k] = pk_min3(w9[3 * k], w9[3 * k + 1], w9[3 * k + 2]);
+    const pk2 W = pk_min3(pk_min3(m[0], m[1], m[2]), pk_min3(m[3], m[4], w9[15]), w9[15]);
+    const pk2 df = pk_sub(vp, W);
+    const int mA = pk_lo(df), mB = pk_hi(df);
     sA = mA > t0 ? mA - 1 : 0;
     sB = mB > t0 ? mB - 1 : 0;
 }
@@ -313,25 +321,28 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
             const bool hasB = i + 1 < n;
             const int eB = hasB ? list[i + 1] : eA;
             const int pA = eA & kListPos, pB = eB & kListPos;
-            // polarity of the entry: +1 dark (v - ring), -1 bright (ring - v)
-            const int sgA = (eA & kListBright) ? -1 : 1, sgB = (eB & kListBright) ? -1 : 1;
+            // polarity of the entry: a bright candidate is scored on the inverted image (x ^ 0xFF), see fast_score_pk
+            const uint32_t xm = ((eA & kListBright) ? 0x000000FFu : 0u) | ((eB & kListBright) ? 0x00FF0000u : 0u);
+            const uint32_t bias2 = (uint32_t)kPixBias * 0x00010001u;
             // (24-bit multiplies: every operand here is far below 2^23 and the products below 2^31; v_mul_lo_u32 runs at quarter rate)
             const int yA = (int)((unsigned)mul24(pA, (int)M) >> 20), xA = pA - mul24(yA, pitch);     // (y + 1, x + 1)
             const int yB = (int)((unsigned)mul24(pB, (int)M) >> 20), xB = pB - mul24(yB, pitch);
             const uint8_t* cA = tile + mul24(yA + 2, wp) + xo + xA + 2;
             const uint8_t* cB = tile + mul24(yB + 2, wp) + xo + xB + 2;
+            // one pointer per window row and pixel, so that the 16 ring reads are immediate offsets from them
             // (gathering the ring with 7 unaligned ds_read_b32/b64 per pixel instead of 17 byte reads was measured 67 % slower)
-            const pk2 c2 = pk_make((uint32_t)((sgA * (int)cA[0] + kDiffBias) & 0xFFFF) | ((uint32_t)(sgB * (int)cB[0] + kDiffBias) << 16));    // sign * v + bias
-            const pk2 ns2 = pk_make((uint32_t)((-sgA) & 0xFFFF) | ((uint32_t)(-sgB) << 16));                            // -sign
+            const uint8_t *a0 = cA - 3 * wp, *a1 = cA - 2 * wp, *a2 = cA - wp, *a4 = cA + wp, *a5 = cA + 2 * wp, *a6 = cA + 3 * wp;
+            const uint8_t *b0 = cB - 3 * wp, *b1 = cB - 2 * wp, *b2 = cB - wp, *b4 = cB + wp, *b5 = cB + 2 * wp, *b6 = cB + 3 * wp;
+            const pk2 vp = pk_xor_or(pk_bytes(cA, cB), xm, bias2);
             pk2 d[16];
-#define ORBX_D(k, off) d[k] = pk_mad(pk_make((uint32_t)cA[off] | ((uint32_t)cB[off] << 16)), ns2, c2);
-            ORBX_D(0, 3 * wp)       ORBX_D(1, 3 * wp + 1)    ORBX_D(2, 2 * wp + 2)    ORBX_D(3, wp + 3)
-            ORBX_D(4, 3)            ORBX_D(5, -wp + 3)       ORBX_D(6, -2 * wp + 2)   ORBX_D(7, -3 * wp + 1)
-            ORBX_D(8, -3 * wp)      ORBX_D(9, -3 * wp - 1)   ORBX_D(10, -2 * wp - 2)  ORBX_D(11, -wp - 3)
-            ORBX_D(12, -3)          ORBX_D(13, wp - 3)       ORBX_D(14, 2 * wp - 2)   ORBX_D(15, 3 * wp - 1)
+#define ORBX_D(k, ra, rb, dx) d[k] = pk_xor_or(pk_bytes(ra + (dx), rb + (dx)), xm, bias2);
+            ORBX_D(0, a6, b6, 0)    ORBX_D(1, a6, b6, 1)    ORBX_D(2, a5, b5, 2)    ORBX_D(3, a4, b4, 3)
+            ORBX_D(4, cA, cB, 3)    ORBX_D(5, a2, b2, 3)    ORBX_D(6, a1, b1, 2)    ORBX_D(7, a0, b0, 1)
+            ORBX_D(8, a0, b0, 0)    ORBX_D(9, a0, b0, -1)   ORBX_D(10, a1, b1, -2)  ORBX_D(11, a2, b2, -3)
+            ORBX_D(12, cA, cB, -3)  ORBX_D(13, a4, b4, -3)  ORBX_D(14, a5, b5, -2)  ORBX_D(15, a6, b6, -1)
 #undef ORBX_D
             int sA, sB;
-            fast_score_pk(d, t0, sA, sB);
+            fast_score_pk(d, vp, t0, sA, sB);
             // a pixel that passed the quick test for both polarities has two entries; it can be a corner for at most one of them
             // (two 9-arcs of opposite sign do not fit on 16 ring pixels), so only a positive score is written
             if (sA > 0) sc[pA] = (uint8_t)sA;
@@ -353,7 +364,10 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
         for (; it0 < nitems; it0 += 64) {
             const int it = it0 + lane;
             const int iend = nitems;
-            unsigned mask = 0; int xbase = 0;
+            // survivor predicates of this lane's 4 pixels (dark / bright): kept as eight lane masks, so that the appends below run under them
+            // directly instead of re-testing bits of a per-lane bit mask
+            bool pd0 = false, pd1 = false, pd2 = false, pd3 = false, pb0 = false, pb1 = false, pb2 = false, pb3 = false;
+            int xbase = 0;
             if (it < iend) {
                 const int g = g0 + gi;
                 xbase = 4 * g - (xo + 3);                  // interior x of this lane's first pixel (may be < 0)
@@ -385,25 +399,22 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
                 const pk2 N_hi = pk_min(pk_min3(mx_hi[0], mx_hi[1], mx_hi[2]), pk_min3(pk_min3(mx_hi[3], mx_hi[4], mx_hi[5]), mx_hi[6], mx_hi[7]));
                 const pk2 vlo = pk_make(byte_perm(kBias4, Cw[3], 0x04010400u)), vhi = pk_make(byte_perm(kBias4, Cw[3], 0x04030402u));
                 const pk2 dk_lo = pk_sub(vlo, M_lo), dk_hi = pk_sub(vhi, M_hi), br_lo = pk_sub(N_lo, vlo), br_hi = pk_sub(N_hi, vhi);
-                const unsigned passD = (unsigned)(pk_lo(dk_lo) > t0) | ((unsigned)(pk_hi(dk_lo) > t0) << 1) |
-                                       ((unsigned)(pk_lo(dk_hi) > t0) << 2) | ((unsigned)(pk_hi(dk_hi) > t0) << 3);
-                const unsigned passB = (unsigned)(pk_lo(br_lo) > t0) | ((unsigned)(pk_hi(br_lo) > t0) << 1) |
-                                       ((unsigned)(pk_lo(br_hi) > t0) << 2) | ((unsigned)(pk_hi(br_hi) > t0) << 3);
                 const int lo = imax(0, -xbase), hi = imin(4, iw - xbase);          // valid pixels j in [lo, hi)
-                const unsigned valid = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
-                mask = (passD & valid) | ((passB & valid) << 4);                   // bits 0-3 dark candidates, 4-7 bright candidates
+                const bool v0 = lo <= 0 && hi > 0, v1 = lo <= 1 && hi > 1, v2 = lo <= 2 && hi > 2, v3 = hi > 3 && lo <= 3;
+                pd0 = v0 && pk_lo(dk_lo) > t0; pd1 = v1 && pk_hi(dk_lo) > t0; pd2 = v2 && pk_lo(dk_hi) > t0; pd3 = v3 && pk_hi(dk_hi) > t0;
+                pb0 = v0 && pk_lo(br_lo) > t0; pb1 = v1 && pk_hi(br_lo) > t0; pb2 = v2 && pk_lo(br_hi) > t0; pb3 = v3 && pk_hi(br_hi) > t0;
             }
-            const int c4 = __popc(mask);
+            const int c4 = (int)pd0 + (int)pd1 + (int)pd2 + (int)pd3 + (int)pb0 + (int)pb1 + (int)pb2 + (int)pb3;
             const int incl = wave_incl_scan(c4);
             const int trip = ORBX_READLANE(incl, 63);
             if (cnt > 0 && cnt + trip > list_cap) break;                                    // wave-uniform (a trip adds <= 512 entries <= list_cap)
             int pos = cnt + incl - c4;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int pj = mul24(y + 1, pitch) + xbase + j + 1;
-                if (mask & (1u << j)) list[pos++] = (uint16_t)pj;
-                if (mask & (16u << j)) list[pos++] = (uint16_t)(pj | kListBright | ((mask & (1u << j)) ? kListDup : 0));
-            }
+            const int pj0 = mul24(y + 1, pitch) + xbase + 1;
+#define ORBX_APPEND(j, pd, pb) \
+            if (pd) list[pos++] = (uint16_t)(pj0 + (j)); \
+            if (pb) list[pos++] = (uint16_t)((pj0 + (j)) | kListBright | ((pd) ? kListDup : 0));
+            ORBX_APPEND(0, pd0, pb0) ORBX_APPEND(1, pd1, pb1) ORBX_APPEND(2, pd2, pb2) ORBX_APPEND(3, pd3, pb3)
+#undef ORBX_APPEND
             cnt += trip;
             gi += dr; y += dq;
             if (gi >= ng) { gi -= ng; y++; }
