@@ -330,7 +330,8 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
             const uint8_t* cA = tile + mul24(yA + 2, wp) + xo + xA + 2;
             const uint8_t* cB = tile + mul24(yB + 2, wp) + xo + xB + 2;
             // one pointer per window row and pixel, so that the 16 ring reads are immediate offsets from them
-            // (gathering the ring with 7 unaligned ds_read_b32/b64 per pixel instead of 17 byte reads was measured 67 % slower)
+            // (gathering the ring with 7 unaligned ds_read_b32/b64 per pixel instead of 17 byte reads was measured 67 % slower; packing the two
+            //  pixels' bytes with ds_read_u8_d16 / _d16_hi does not work on this part: with SRAM ECC enabled the d16 loads clear the other half)
             const uint8_t *a0 = cA - 3 * wp, *a1 = cA - 2 * wp, *a2 = cA - wp, *a4 = cA + wp, *a5 = cA + 2 * wp, *a6 = cA + 3 * wp;
             const uint8_t *b0 = cB - 3 * wp, *b1 = cB - 2 * wp, *b2 = cB - wp, *b4 = cB + wp, *b5 = cB + 2 * wp, *b6 = cB + 3 * wp;
             const pk2 vp = pk_xor_or(pk_bytes(cA, cB), xm, bias2);
