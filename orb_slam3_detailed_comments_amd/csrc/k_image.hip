@@ -196,7 +196,7 @@ __device__ __forceinline__ int pk_hi(pk2 a) { return (int)a.y; }
 __device__ __forceinline__ pk2 pk_min3(pk2 a, pk2 b, pk2 c) { pk2 d; asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ pk2 pk_max3(pk2 a, pk2 b, pk2 c) { pk2 d; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 // two bytes from two LDS addresses as the two halves of one register; (a ^ x) | o is one v_bitop3_b32
-__device__ __forceinline__ pk2 pk_bytes(const uint8_t* a, const uint8_t* b) { pk2 r = __builtin_bit_cast(pk2, (uint32_t)*a); r.y = (short)(unsigned short)*b; return r; }
+__device__ __forceinline__ pk2 pk_bytes(const uint8_t* a, const uint8_t* b) { return __builtin_bit_cast(pk2, (uint32_t)*a | ((uint32_t)*b << 16)); }   // v_lshl_or_b32 (full rate; v_perm_b32 is not)
 __device__ __forceinline__ pk2 pk_xor_or(pk2 a, uint32_t x, uint32_t o) { return __builtin_bit_cast(pk2, (__builtin_bit_cast(uint32_t, a) ^ x) | o); }
 #endif
 constexpr int kPixBias = 0x6400;     // pixel value b is carried as 0x6400 + b (binary16 1024 + b)
