@@ -373,32 +373,34 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
                 const int g = g0 + gi;
                 xbase = 4 * g - (xo + 3);                  // interior x of this lane's first pixel (may be < 0)
                 const uint32_t* rp = tile32 + mul24(y + 3, wpd) + g;
-                uint32_t Lw[7], Cw[7], Rw[7];
                 const uint32_t kBias4 = (uint32_t)(kPixBias >> 8) * 0x01010101u;          // the high byte of every widened pixel
-#pragma unroll
-                for (int r = 0; r < 7; r++) { const uint32_t* pr = rp + (r - 3) * wpd; Lw[r] = pr[-1]; Cw[r] = pr[0]; Rw[r] = pr[1]; }
-                // ring bytes of the 4 pixels, widened to 2 x (2 x u16); row index r = dy + 3
-                pk2 rlo[16], rhi[16];
-#define ORBX_RING(k, r, dx) { const uint32_t w4 = (dx) == 0 ? Cw[r] : ((dx) > 0 ? align_byte(Rw[r], Cw[r], (dx)) : align_byte(Cw[r], Lw[r], 4 + (dx))); \
-                              rlo[k] = pk_make(byte_perm(kBias4, w4, 0x04010400u)); rhi[k] = pk_make(byte_perm(kBias4, w4, 0x04030402u)); }
-                ORBX_RING(0, 6, 0)  ORBX_RING(1, 6, 1)  ORBX_RING(2, 5, 2)  ORBX_RING(3, 4, 3)
-                ORBX_RING(4, 3, 3)  ORBX_RING(5, 2, 3)  ORBX_RING(6, 1, 2)  ORBX_RING(7, 0, 1)
-                ORBX_RING(8, 0, 0)  ORBX_RING(9, 0, -1) ORBX_RING(10, 1, -2) ORBX_RING(11, 2, -3)
-                ORBX_RING(12, 3, -3) ORBX_RING(13, 4, -3) ORBX_RING(14, 5, -2) ORBX_RING(15, 6, -1)
+                // Only the four opposite pairs (0,8) (2,10) (4,12) (6,14) are tested here: still a necessary condition (every 9-arc holds one
+                // point of each opposite pair), it lets 34 % instead of 31 % of the pixels through to the exact score of phase B, and it costs
+                // half the ring extraction and pair arithmetic of the full eight-pair test (8 ring points from 11 LDS dwords instead of 16 from 21).
+                const uint32_t* r0 = rp - 3 * wpd; const uint32_t* r1 = rp - 2 * wpd; const uint32_t* r5 = rp + 2 * wpd; const uint32_t* r6 = rp + 3 * wpd;
+                const uint32_t C0 = r0[0], C6 = r6[0], L1 = r1[-1], C1 = r1[0], R1 = r1[1], L3 = rp[-1], C3 = rp[0], R3 = rp[1], L5 = r5[-1], C5 = r5[0], R5 = r5[1];
+                pk2 rlo[8], rhi[8];          // index = k / 2 for k = 0, 2, .., 14
+#define ORBX_RING(i, w4) { const uint32_t w = (w4); rlo[i] = pk_make(byte_perm(kBias4, w, 0x04010400u)); rhi[i] = pk_make(byte_perm(kBias4, w, 0x04030402u)); }
+                ORBX_RING(0, C6)                          // k = 0   ( 0, +3)
+                ORBX_RING(1, align_byte(R5, C5, 2))       // k = 2   (+2, +2)
+                ORBX_RING(2, align_byte(R3, C3, 3))       // k = 4   (+3,  0)
+                ORBX_RING(3, align_byte(R1, C1, 2))       // k = 6   (+2, -2)
+                ORBX_RING(4, C0)                          // k = 8   ( 0, -3)
+                ORBX_RING(5, align_byte(C1, L1, 2))       // k = 10  (-2, -2)
+                ORBX_RING(6, align_byte(C3, L3, 1))       // k = 12  (-3,  0)
+                ORBX_RING(7, align_byte(C5, L5, 2))       // k = 14  (-2, +2)
 #undef ORBX_RING
-                // a dark 9-arc needs min(ring_k, ring_k+8) < v - t for all 8 pairs, a bright one max(..) > v + t:
-                //   M = max_k min(pair) ,  N = min_k max(pair) ;  possible corner  <=>  v - M > t  or  N - v > t
-                pk2 mn_lo[8], mx_lo[8], mn_hi[8], mx_hi[8];
+                // a dark 9-arc needs min(ring_k, ring_k+8) < v - t for every opposite pair, a bright one max(..) > v + t:
+                //   M = max_k min(pair) ,  N = min_k max(pair) ;  possible corner  =>  v - M > t  or  N - v > t
+                pk2 mn_lo[4], mx_lo[4], mn_hi[4], mx_hi[4];
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    mn_lo[k] = pk_min(rlo[k], rlo[k + 8]); mx_lo[k] = pk_max(rlo[k], rlo[k + 8]);
-                    mn_hi[k] = pk_min(rhi[k], rhi[k + 8]); mx_hi[k] = pk_max(rhi[k], rhi[k + 8]);
+                for (int k = 0; k < 4; k++) {
+                    mn_lo[k] = pk_min(rlo[k], rlo[k + 4]); mx_lo[k] = pk_max(rlo[k], rlo[k + 4]);
+                    mn_hi[k] = pk_min(rhi[k], rhi[k + 4]); mx_hi[k] = pk_max(rhi[k], rhi[k + 4]);
                 }
-                const pk2 M_lo = pk_max(pk_max3(mn_lo[0], mn_lo[1], mn_lo[2]), pk_max3(pk_max3(mn_lo[3], mn_lo[4], mn_lo[5]), mn_lo[6], mn_lo[7]));
-                const pk2 M_hi = pk_max(pk_max3(mn_hi[0], mn_hi[1], mn_hi[2]), pk_max3(pk_max3(mn_hi[3], mn_hi[4], mn_hi[5]), mn_hi[6], mn_hi[7]));
-                const pk2 N_lo = pk_min(pk_min3(mx_lo[0], mx_lo[1], mx_lo[2]), pk_min3(pk_min3(mx_lo[3], mx_lo[4], mx_lo[5]), mx_lo[6], mx_lo[7]));
-                const pk2 N_hi = pk_min(pk_min3(mx_hi[0], mx_hi[1], mx_hi[2]), pk_min3(pk_min3(mx_hi[3], mx_hi[4], mx_hi[5]), mx_hi[6], mx_hi[7]));
-                const pk2 vlo = pk_make(byte_perm(kBias4, Cw[3], 0x04010400u)), vhi = pk_make(byte_perm(kBias4, Cw[3], 0x04030402u));
+                const pk2 M_lo = pk_max(pk_max3(mn_lo[0], mn_lo[1], mn_lo[2]), mn_lo[3]), M_hi = pk_max(pk_max3(mn_hi[0], mn_hi[1], mn_hi[2]), mn_hi[3]);
+                const pk2 N_lo = pk_min(pk_min3(mx_lo[0], mx_lo[1], mx_lo[2]), mx_lo[3]), N_hi = pk_min(pk_min3(mx_hi[0], mx_hi[1], mx_hi[2]), mx_hi[3]);
+                const pk2 vlo = pk_make(byte_perm(kBias4, C3, 0x04010400u)), vhi = pk_make(byte_perm(kBias4, C3, 0x04030402u));
                 const pk2 dk_lo = pk_sub(vlo, M_lo), dk_hi = pk_sub(vhi, M_hi), br_lo = pk_sub(N_lo, vlo), br_hi = pk_sub(N_hi, vhi);
                 const int lo = imax(0, -xbase), hi = imin(4, iw - xbase);          // valid pixels j in [lo, hi)
                 const bool v0 = lo <= 0 && hi > 0, v1 = lo <= 1 && hi > 1, v2 = lo <= 2 && hi > 2, v3 = hi > 3 && lo <= 3;
