@@ -377,6 +377,7 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
                 // Only the four opposite pairs (0,8) (2,10) (4,12) (6,14) are tested here: still a necessary condition (every 9-arc holds one
                 // point of each opposite pair), it lets 34 % instead of 31 % of the pixels through to the exact score of phase B, and it costs
                 // half the ring extraction and pair arithmetic of the full eight-pair test (8 ring points from 11 LDS dwords instead of 16 from 21).
+                // Measured per 128 images: eight pairs 0.415 ms, four 0.396 ms, the two compass pairs alone 0.409 ms (41 % survivors).
                 const uint32_t* r0 = rp - 3 * wpd; const uint32_t* r1 = rp - 2 * wpd; const uint32_t* r5 = rp + 2 * wpd; const uint32_t* r6 = rp + 3 * wpd;
                 const uint32_t C0 = r0[0], C6 = r6[0], L1 = r1[-1], C1 = r1[0], R1 = r1[1], L3 = rp[-1], C3 = rp[0], R3 = rp[1], L5 = r5[-1], C5 = r5[0], R5 = r5[1];
                 pk2 rlo[8], rhi[8];          // index = k / 2 for k = 0, 2, .., 14
