@@ -548,13 +548,20 @@ __global__ void __launch_bounds__(256) k_blur(const LevelInfo* __restrict__ lv, 
         for (int j = 0; j < 4; j++) sgl |= (uint32_t)imin(imax(idx[j] - 4 * base[g], 0), 7) << (8 * j);
         sel[g] = sgl;
     }
-    // Horizontal pass: H_j = sum_i k_i p[j+i] as two v_dot4_u32_u8 on the byte windows p[j..j+3], p[j+4..j+7] (tap 7 = 0); H <= 65535.
+    // Horizontal pass: H_j = sum_i k_i p[j+i], j = 0..3, on the three byte windows P0 = p[0..3], P1 = p[4..7], P2 = p[8..9]: instead of
+    // shifting the data to each j (v_alignbyte) the taps are shifted - ten v_dot4_u32_u8 with constant tap words; H <= 65535.
     // Vertical pass: the H of two consecutive input rows share a register (lo/hi 16 bits), so a 7-row window is four
     // v_dot2_u32_u16 with the taps paired to match the window's parity; the rounding constant is the accumulator's start value.
-    const uint32_t Klo = (uint32_t)k0 | ((uint32_t)k1 << 8) | ((uint32_t)k2 << 16) | ((uint32_t)k3 << 24);
-    const uint32_t Khi = (uint32_t)k2 | ((uint32_t)k1 << 8) | ((uint32_t)k0 << 16);
+    const uint32_t uk0 = (uint32_t)k0, uk1 = (uint32_t)k1, uk2 = (uint32_t)k2, uk3 = (uint32_t)k3;
+    const uint32_t T00 = uk0 | (uk1 << 8) | (uk2 << 16) | (uk3 << 24), T01 = uk2 | (uk1 << 8) | (uk0 << 16);                     // j = 0
+    const uint32_t T10 = (uk0 << 8) | (uk1 << 16) | (uk2 << 24), T11 = uk3 | (uk2 << 8) | (uk1 << 16) | (uk0 << 24);             // j = 1
+    const uint32_t T20 = (uk0 << 16) | (uk1 << 24), T21 = uk2 | (uk3 << 8) | (uk2 << 16) | (uk1 << 24), T22 = uk0;               // j = 2
+    const uint32_t T30 = uk0 << 24, T31 = uk1 | (uk2 << 8) | (uk3 << 16) | (uk2 << 24), T32 = uk1 | (uk0 << 8);                  // j = 3
     const uint32_t Ke0 = (uint32_t)k0 | ((uint32_t)k1 << 16), Ke1 = (uint32_t)k2 | ((uint32_t)k3 << 16), Ke2 = (uint32_t)k2 | ((uint32_t)k1 << 16), Ke3 = (uint32_t)k0;
     const uint32_t Ko0 = (uint32_t)k0 << 16, Ko1 = (uint32_t)k1 | ((uint32_t)k2 << 16), Ko2 = (uint32_t)k3 | ((uint32_t)k2 << 16), Ko3 = (uint32_t)k1 | ((uint32_t)k0 << 16);
+    // taps that sum to 256 cannot exceed 255 after the final shift ((255 * 65536 + 32768) >> 16 = 255): the four result bytes are then
+    // cut out of the accumulators with two byte-permutes instead of shift + clamp + insert per output (wave-uniform choice)
+    const bool exact256 = 2 * (k0 + k1 + k2) + k3 <= 256;
     uint32_t Q[4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++) { Q[i][0] = Q[i][1] = Q[i][2] = Q[i][3] = 0u; }
@@ -576,21 +583,31 @@ __global__ void __launch_bounds__(256) k_blur(const LevelInfo* __restrict__ lv, 
             const uint32_t P0 = byte_perm(base[0] ? r : c, base[0] ? c : l, sel[0]);      // input columns x0-3 .. x0
             const uint32_t P1 = byte_perm(base[1] ? r : c, base[1] ? c : l, sel[1]);      //               x0+1 .. x0+4
             const uint32_t P2 = byte_perm(base[2] ? r : c, base[2] ? c : l, sel[2]);      //               x0+5, x0+6, (unused)
-            Hr[sub][0] = dot4_u8(P0, Klo, dot4_u8(P1, Khi, 0u));
-            Hr[sub][1] = dot4_u8(align_byte(P1, P0, 1), Klo, dot4_u8(align_byte(P2, P1, 1), Khi, 0u));
-            Hr[sub][2] = dot4_u8(align_byte(P1, P0, 2), Klo, dot4_u8(align_byte(P2, P1, 2), Khi, 0u));
-            Hr[sub][3] = dot4_u8(align_byte(P1, P0, 3), Klo, dot4_u8(align_byte(P2, P1, 3), Khi, 0u));
+            Hr[sub][0] = dot4_u8(P0, T00, dot4_u8(P1, T01, 0u));
+            Hr[sub][1] = dot4_u8(P0, T10, dot4_u8(P1, T11, 0u));
+            Hr[sub][2] = dot4_u8(P0, T20, dot4_u8(P1, T21, dot4_u8(P2, T22, 0u)));
+            Hr[sub][3] = dot4_u8(P0, T30, dot4_u8(P1, T31, dot4_u8(P2, T32, 0u)));
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) { Q[0][j] = Q[1][j]; Q[1][j] = Q[2][j]; Q[2][j] = Q[3][j]; Q[3][j] = Hr[0][j] | (Hr[1][j] << 16); }
         if (m >= 3) {
-            uint32_t oe = 0, oo = 0;
+            uint32_t ae[4], ao[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                uint32_t ve = dot2_u16(Q[0][j], Ke0, dot2_u16(Q[1][j], Ke1, dot2_u16(Q[2][j], Ke2, dot2_u16(Q[3][j], Ke3, 32768u)))) >> 16;
-                uint32_t vo = dot2_u16(Q[0][j], Ko0, dot2_u16(Q[1][j], Ko1, dot2_u16(Q[2][j], Ko2, dot2_u16(Q[3][j], Ko3, 32768u)))) >> 16;
-                ve = ve > 255u ? 255u : ve; vo = vo > 255u ? 255u : vo;
-                oe |= ve << (8 * j); oo |= vo << (8 * j);
+                ae[j] = dot2_u16(Q[0][j], Ke0, dot2_u16(Q[1][j], Ke1, dot2_u16(Q[2][j], Ke2, dot2_u16(Q[3][j], Ke3, 32768u))));
+                ao[j] = dot2_u16(Q[0][j], Ko0, dot2_u16(Q[1][j], Ko1, dot2_u16(Q[2][j], Ko2, dot2_u16(Q[3][j], Ko3, 32768u))));
+            }
+            uint32_t oe = 0, oo = 0;
+            if (exact256) {                            // byte 2 of each accumulator is the output
+                oe = byte_perm(ae[1], ae[0], 0x0c0c0602u) | byte_perm(ae[3], ae[2], 0x06020c0cu);
+                oo = byte_perm(ao[1], ao[0], 0x0c0c0602u) | byte_perm(ao[3], ao[2], 0x06020c0cu);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    uint32_t ve = ae[j] >> 16, vo = ao[j] >> 16;
+                    ve = ve > 255u ? 255u : ve; vo = vo > 255u ? 255u : vo;
+                    oe |= ve << (8 * j); oo |= vo << (8 * j);
+                }
             }
             *(uint32_t*)(dst + (size_t)yo * L.pitch + x0) = oe;
             if (yo + 1 < L.h) *(uint32_t*)(dst + (size_t)(yo + 1) * L.pitch + x0) = oo;
