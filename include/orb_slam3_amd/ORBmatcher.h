@@ -13,8 +13,8 @@
  * oracle/slam_shim (tests/cpp/matcher_world_driver.cpp drives this facade and the reference's own compiled ORBmatcher.cc with identical
  * objects and compares every output) and against the light mocks of tests/cpp/matcher_facade_test.cpp.
  *
- * Not accelerated, reported with an exception instead of a silent CPU path: the two-camera (fisheye rig) branches of SearchByBoW,
- * SearchForTriangulation and Fuse.
+ * Not accelerated, reported with an exception instead of a silent CPU path: the two-camera (fisheye rig) branches of SearchByBoW
+ * and SearchForTriangulation (the latter needs the KB8 camera model's epipolar test).
  */
 #ifndef ORB_SLAM3_AMD_ORBMATCHER_H
 #define ORB_SLAM3_AMD_ORBMATCHER_H
@@ -411,12 +411,13 @@ public:
     template <class KeyFrameT, class MapPointT>
     int Fuse(KeyFrameT* pKF, const std::vector<MapPointT *> &vpMapPoints, const float th=3.0, const bool bRight = false)
     {
-        if (bRight || pKF->NLeft != -1) throw std::runtime_error("ORBmatcher (HIP): the fisheye-rig path of Fuse is not accelerated");
-        auto Tcw = pKF->GetPose();
+        const bool rig = pKF->NLeft != -1;
+        if (bRight && !rig) throw std::runtime_error("ORBmatcher (HIP): Fuse(bRight) on a key frame without a second camera");
+        auto Tcw = bRight ? pKF->GetRightPose() : pKF->GetPose();
         typedef Decay<decltype(Tcw.translation())> Vec3;
         typedef Decay<decltype(pKF->mpCamera->project(std::declval<Vec3>()))> Vec2;
-        Vec3 Ow = pKF->GetCameraCenter();
-        auto* pCamera = pKF->mpCamera;
+        Vec3 Ow = bRight ? pKF->GetRightCameraCenter() : pKF->GetCameraCenter();
+        auto* pCamera = bRight ? pKF->mpCamera2 : pKF->mpCamera;
         const float &bf = pKF->mbf;
         const int nMPs = vpMapPoints.size();
         // geometry of every point that could reach the window search.  Whether it does is decided again in the replay loop below: the
@@ -442,12 +443,22 @@ public:
             ps.set(i, uv(0), uv(1), ur, pMP->PredictScale(dist3D,pKF), 0.0f);
             CopyDescriptor(pMP, ps.descAt(i));
         }
-        FrameStore fs; FillFrame(*pKF, fs);
+        FrameStore fs;
+        if (!rig) FillFrame(*pKF, fs);
+        else {                                              // one camera of the rig: its own keypoints, descriptor rows and grid (:1432-1434, :1468)
+            const int n = bRight ? pKF->N - pKF->NLeft : pKF->NLeft;
+            ConvertKeys(bRight ? pKF->mvKeysRight : pKF->mvKeys, n, fs.keys);
+            fs.occ.assign(n > 0 ? n : 1, 0);
+            fs.v.N = n; fs.v.keys_un = fs.keys.data(); fs.v.desc = pKF->mDescriptors.ptr(0) + (bRight ? (size_t)pKF->NLeft * 32 : 0); fs.v.u_right = nullptr;
+            fs.v.occupied = fs.occ.data();
+            FillBounds(*pKF, fs.v);
+        }
         std::vector<int> best(nMPs > 0 ? nMPs : 1, -1);
         {
             std::lock_guard<std::mutex> lock(Mutex());
             Check(orbm_fuse_candidates(SharedHandle(), &fs.v, ps.view(), th, 1, pKF->mvInvLevelSigma2.data(), best.data(), nullptr));
         }
+        if (bRight) for (int i = 0; i < nMPs; i++) if (best[i] >= 0) best[i] += pKF->NLeft;       // :1488
         int nFused=0;
         for (int i=0; i<nMPs; i++) {                        // the map surgery of :1494-1520, in the reference's order
             MapPointT* pMP = vpMapPoints[i];

@@ -318,12 +318,16 @@ def build_and_run_rig(drv, seed):
     mp_ids = np.array(mp_ids)
     trl = (rot(0.0, 0.02, 0.0), np.array([-0.11, 0.0, 0.0], np.float32))
 
-    def make_rig(pose, rot_off, assoc_frac):
+    def make_rig(pose, rot_off, assoc_frac, keyframe=False):
         R, t = pose
         kl, dl, _, ptl, _ = sc.observe(R, t, clutter=150, rot_off=rot_off)
         Rr = (trl[0] @ R).astype(np.float32); tr = (trl[0] @ t + trl[1]).astype(np.float32)
         kr, dr, _, ptr, _ = sc.observe(Rr, tr, clutter=150, rot_off=rot_off)
-        fid = drv.frame(False, kl, np.concatenate([dl, dr]), None, R, t, cam, cam2, keys_right=kr, trl=trl)
+        fid = drv.frame(keyframe, kl, np.concatenate([dl, dr]), None, R, t, cam, cam2, keys_right=kr, trl=trl)
+        if keyframe:
+            pt = np.concatenate([ptl, ptr])
+            ids = np.where((pt >= 0) & (rng.uniform(size=len(pt)) < assoc_frac), mp_ids[np.maximum(pt, 0)], -1).astype(np.int32)
+            return fid, len(kl), len(kr), ids, (R, t, Rr, tr)
         pt = np.concatenate([ptl, ptr])
         ids = np.where((pt >= 0) & (rng.uniform(size=len(pt)) < assoc_frac), mp_ids[np.maximum(pt, 0)], -1).astype(np.int32)
         # stereo correspondences between the two cameras of the rig
@@ -361,6 +365,21 @@ def build_and_run_rig(drv, seed):
             drv.set_map_points(False, fc, idsc)
             n = L.mw_search_by_projection_frame(drv.w, fc, fl, C.c_float(10.0), 0, C.c_float(0.9), ori)
             out["rig_sbp_frame_%s_%d" % (tag, ori)] = np.concatenate([[n], drv.get_map_points(False, fc, nlc + nrc)])
+
+    # ---- Fuse(pKF, vpMapPoints, th, bRight) on a rig key frame: left camera, then right camera (LocalMapping::SearchInNeighbors) ----
+    kF, nlF, nrF, idsF, _ = make_rig(pose, 0.0, 0.4, keyframe=True)
+    drv.set_map_points(True, kF, idsF)
+    dup = []
+    for i in rng.permutation(len(sc.X))[:500]:
+        d = float(np.linalg.norm(sc.X[i])); maxd = d * SCALE ** int(sc.level0[i])
+        dup.append(drv.mappoint(sc.X[i] + rng.normal(0, 0.01, 3), sc.X[i] / d, maxd / SCALE ** (NLEVELS - 1), maxd, sc.noisy_desc(np.array([i]), 25)[0], bad=rng.uniform() < 0.03,
+                                n_obs=int(rng.integers(0, 6))))
+    cand = np.concatenate([np.array(dup), idsF[idsF >= 0][:30], [-1]]).astype(np.int32)
+    rng.shuffle(cand)
+    for right in (0, 1):
+        n = L.mw_fuse(drv.w, kF, _p(cand), len(cand), C.c_float(3.0), right)
+        st = np.array([drv.mappoint_state(int(c), kF) for c in cand if c >= 0]).ravel()
+        out["rig_fuse_%d" % right] = np.concatenate([[n], drv.get_map_points(True, kF, nlF + nrF), st])
     return out
 
 
