@@ -13,8 +13,8 @@
  * oracle/slam_shim (tests/cpp/matcher_world_driver.cpp drives this facade and the reference's own compiled ORBmatcher.cc with identical
  * objects and compares every output) and against the light mocks of tests/cpp/matcher_facade_test.cpp.
  *
- * Not accelerated, reported with an exception instead of a silent CPU path: the two-camera (fisheye rig) branches of SearchByBoW
- * and SearchForTriangulation (the latter needs the KB8 camera model's epipolar test).
+ * Not accelerated, reported with an exception instead of a silent CPU path: the two-camera (fisheye rig) branch of
+ * SearchForTriangulation (it needs the KB8 camera model's epipolar test).
  */
 #ifndef ORB_SLAM3_AMD_ORBMATCHER_H
 #define ORB_SLAM3_AMD_ORBMATCHER_H
@@ -224,37 +224,50 @@ public:
     template <class KeyFrameT, class FrameT, class MapPointT>
     int SearchByBoW(KeyFrameT* pKF, FrameT &F, std::vector<MapPointT*> &vpMapPointMatches)
     {
-        if (F.Nleft != -1 || pKF->mpCamera2) throw std::runtime_error("ORBmatcher (HIP): the fisheye-rig path of SearchByBoW is not accelerated");
         const std::vector<MapPointT*> vpMapPointsKF = pKF->GetMapPointMatches();
         vpMapPointMatches = std::vector<MapPointT*>(F.N,static_cast<MapPointT*>(NULL));
+        const bool rig = F.Nleft != -1;
         BowStore k1, k2;
-        FillBow(*pKF, pKF->N, k1); FillBow(F, F.N, k2);
-        k1.present.assign(pKF->N, 0);
+        if (!rig && !pKF->mpCamera2) { FillBow(*pKF, pKF->N, k1); FillBow(F, F.N, k2); }
+        else {                                              // keypoints by feature index: camera 1 (mvKeys), then camera 2 (mvKeysRight) (:392-396, :399-402)
+            FillBow(*pKF, pKF->N, k1); FillBow(F, F.N, k2);
+            FillAllKeys(*pKF, pKF->NLeft, pKF->N, k1); FillAllKeys(F, F.Nleft, F.N, k2);
+        }
+        k1.present.assign(pKF->N > 0 ? pKF->N : 1, 0);
         for (int i = 0; i < pKF->N; i++) k1.present[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();
         k1.v.has_map_point = k1.present.data();
         k2.v.has_map_point = nullptr;
-        std::vector<int> m12(pKF->N > 0 ? pKF->N : 1, -1);
         int nmatches = 0;
-        {
-            std::lock_guard<std::mutex> lock(Mutex());
-            Check(orbm_search_by_bow(SharedHandle(), &k1.v, &k2.v, mfNNratio, 1, mbCheckOrientation, m12.data(), &nmatches));
+        if (!rig) {
+            std::vector<int> m12(pKF->N > 0 ? pKF->N : 1, -1);
+            {
+                std::lock_guard<std::mutex> lock(Mutex());
+                Check(orbm_search_by_bow(SharedHandle(), &k1.v, &k2.v, mfNNratio, 1, mbCheckOrientation, m12.data(), &nmatches));
+            }
+            for (int i = 0; i < pKF->N; i++) if (m12[i] >= 0) vpMapPointMatches[m12[i]] = vpMapPointsKF[i];
+        } else {
+            std::vector<int> a2(F.N > 0 ? F.N : 1, -1);
+            {
+                std::lock_guard<std::mutex> lock(Mutex());
+                Check(orbm_search_by_bow_fisheye(SharedHandle(), &k1.v, &k2.v, F.Nleft, mfNNratio, mbCheckOrientation, a2.data(), &nmatches));
+            }
+            for (int j = 0; j < F.N; j++) if (a2[j] >= 0) vpMapPointMatches[j] = vpMapPointsKF[a2[j]];
         }
-        for (int i = 0; i < pKF->N; i++) if (m12[i] >= 0) vpMapPointMatches[m12[i]] = vpMapPointsKF[i];
         return nmatches;
     }
-    // src/ORBmatcher.cc:892-1043
+    // src/ORBmatcher.cc:892-1043; on fisheye-rig key frames only the features of camera 1 take part (:930, :953)
     template <class KeyFrameT, class MapPointT>
     int SearchByBoW(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*> &vpMatches12)
     {
-        if (pKF1->NLeft != -1 || pKF2->NLeft != -1) throw std::runtime_error("ORBmatcher (HIP): the fisheye-rig path of SearchByBoW is not accelerated");
         const std::vector<MapPointT*> vpMapPoints1 = pKF1->GetMapPointMatches();
         const std::vector<MapPointT*> vpMapPoints2 = pKF2->GetMapPointMatches();
         vpMatches12 = std::vector<MapPointT*>(vpMapPoints1.size(),static_cast<MapPointT*>(NULL));
         BowStore k1, k2;
         FillBow(*pKF1, (int)vpMapPoints1.size(), k1); FillBow(*pKF2, (int)vpMapPoints2.size(), k2);
-        k1.present.assign(vpMapPoints1.size(), 0); k2.present.assign(vpMapPoints2.size(), 0);
-        for (size_t i = 0; i < vpMapPoints1.size(); i++) k1.present[i] = vpMapPoints1[i] && !vpMapPoints1[i]->isBad();
-        for (size_t i = 0; i < vpMapPoints2.size(); i++) k2.present[i] = vpMapPoints2[i] && !vpMapPoints2[i]->isBad();
+        k1.present.assign(vpMapPoints1.size() > 0 ? vpMapPoints1.size() : 1, 0); k2.present.assign(vpMapPoints2.size() > 0 ? vpMapPoints2.size() : 1, 0);
+        const size_t lim1 = pKF1->NLeft != -1 ? pKF1->mvKeysUn.size() : vpMapPoints1.size(), lim2 = pKF2->NLeft != -1 ? pKF2->mvKeysUn.size() : vpMapPoints2.size();
+        for (size_t i = 0; i < vpMapPoints1.size() && i < lim1; i++) k1.present[i] = vpMapPoints1[i] && !vpMapPoints1[i]->isBad();
+        for (size_t i = 0; i < vpMapPoints2.size() && i < lim2; i++) k2.present[i] = vpMapPoints2[i] && !vpMapPoints2[i]->isBad();
         k1.v.has_map_point = k1.present.data(); k2.v.has_map_point = k2.present.data();
         std::vector<int> m12(vpMapPoints1.size() > 0 ? vpMapPoints1.size() : 1, -1);
         int nmatches = 0;
@@ -623,9 +636,21 @@ protected:
         s.v.right_to_left = F.mvRightToLeftMatch.empty() ? nullptr : F.mvRightToLeftMatch.data();
     }
     // Frame or KeyFrame with its DBoW2::FeatureVector (map<NodeId, vector<unsigned>>) flattened to CSR
+    // keypoints of a rig Frame / KeyFrame by feature index (mvKeys, then mvKeysRight); a one-camera holder keeps mvKeysUn
+    template <class H> static void FillAllKeys(H& K, int nleft, int N, BowStore& s)
+    {
+        if (nleft == -1) return;
+        std::vector<OrbxKeyPoint> r;
+        ConvertKeys(K.mvKeys, nleft, s.keys); s.keys.resize(nleft);
+        ConvertKeys(K.mvKeysRight, N - nleft, r); r.resize(N - nleft);
+        s.keys.insert(s.keys.end(), r.begin(), r.end());
+        if (s.keys.empty()) s.keys.resize(1);
+        s.v.keys_un = s.keys.data();
+    }
     template <class H> static void FillBow(H& K, int N, BowStore& s)
     {
-        ConvertKeys(K.mvKeysUn, N, s.keys);
+        ConvertKeys(K.mvKeysUn, (int)K.mvKeysUn.size() < N ? (int)K.mvKeysUn.size() : N, s.keys);
+        if ((int)s.keys.size() < N) s.keys.resize(N);
         s.node.clear(); s.feat.clear(); s.start.assign(1, 0);
         for (auto it = K.mFeatVec.begin(); it != K.mFeatVec.end(); ++it) {
             s.node.push_back((uint32_t)it->first);

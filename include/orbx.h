@@ -330,6 +330,12 @@ int orbm_search_by_sim3(orbx_extractor* h, const OrbmFrameView* KF1, const OrbmF
 int orbm_search_by_bow(orbx_extractor* h, const OrbmKeyFrameView* K1, const OrbmKeyFrameView* K2, float nnratio, int th_inclusive,
                        int check_orientation, int* matches12, int* nmatches);
 
+/* SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) for a fisheye-rig frame (F.Nleft != -1; src/ORBmatcher.cc:259-493 incl. :343-372, :414-446).
+ * K1 / K2 list ALL features by index (camera 1 first: keys = mvKeys followed by mvKeysRight, descriptor rows as stored); nleft2 = F.Nleft.
+ * assigned2[j] = feature of K1 whose map point is written to vpMapPointMatches[j], -1 = NULL (after the rotation-consistency pruning). */
+int orbm_search_by_bow_fisheye(orbx_extractor* h, const OrbmKeyFrameView* K1, const OrbmKeyFrameView* K2, int nleft2, float nnratio,
+                               int check_orientation, int* assigned2, int* nmatches);
+
 /* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (src/ORBmatcher.cc:734-880).
  * prev_matched: N1 x 2 floats (vbPrevMatched), updated in place like the reference does (:876-878). */
 int orbm_search_for_initialization(orbx_extractor* h, const OrbmFrameView* F1, const OrbmFrameView* F2, float* prev_matched,

@@ -464,6 +464,88 @@ int orbm_search_by_bow(orbx_extractor* h, const OrbmKeyFrameView* K1, const Orbm
     return ORBX_OK;
 }
 
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) for a fisheye-rig frame (F.Nleft != -1, src/ORBmatcher.cc:259-493 incl.
+// :343-372 and :414-446): best / second best are kept separately for the features of camera 1 (index < nleft2) and of camera 2, the
+// camera-2 match is only considered when the camera-1 best passed TH_LOW (:378, :414 nest that way) and takes no ratio test (":417 || true").
+// assigned2[j] = feature of K1 whose map point goes to vpMapPointMatches[j], or -1.
+int orbm_search_by_bow_fisheye(orbx_extractor* h, const OrbmKeyFrameView* K1, const OrbmKeyFrameView* K2, int nleft2, float nnratio, int check_ori,
+                               int* assigned2, int* nmatches_out) {
+    if (!h || !K1 || !K2 || !assigned2) return fail(ORBX_E_ARG, "null");
+    if (K1->N >= 65535 || K2->N >= 65535 || nleft2 < 0 || nleft2 > K2->N) return fail(ORBX_E_ARG, "bad key frame / frame sizes");
+    rt::set_device(h->device);
+    const int N1 = K1->N, N2 = K2->N;
+    for (int i = 0; i < N2; i++) assigned2[i] = -1;
+    std::vector<BowItem> items;
+    int a = 0, b = 0, total = 0;
+    while (a < K1->fv_nodes && b < K2->fv_nodes) {
+        const uint32_t na = K1->fv_node_id[a], nb = K2->fv_node_id[b];
+        if (na == nb) {
+            for (int k = K1->fv_start[a]; k < K1->fv_start[a + 1]; k++) {
+                const int idx1 = (int)K1->fv_feat[k];
+                if (!K1->has_map_point || !K1->has_map_point[idx1]) continue;     // !pMP || pMP->isBad()
+                BowItem it; it.idx1 = idx1; it.start2 = K2->fv_start[b]; it.cnt2 = K2->fv_start[b + 1] - K2->fv_start[b]; it.out_off = total;
+                total += it.cnt2;
+                items.push_back(it);
+            }
+            a++; b++;
+        } else if (na < nb) { while (a < K1->fv_nodes && K1->fv_node_id[a] < nb) a++; }
+        else { while (b < K2->fv_nodes && K2->fv_node_id[b] < na) b++; }
+    }
+    int nmatches = 0;
+    if (!items.empty() && total > 0) {
+        std::vector<uint8_t> elig(N2 > 0 ? N2 : 1, 1);
+        const int nfeat2 = K2->fv_start[K2->fv_nodes];
+        Packer pk(h);
+        const size_t pd1 = pk.add(K1->desc, 32 * (size_t)N1), pd2 = pk.add(K2->desc, 32 * (size_t)N2), pel = pk.add(elig.data(), elig.size()),
+                     pit = pk.add(items.data(), sizeof(BowItem) * items.size()), pf2 = pk.add(K2->fv_feat, sizeof(int) * (size_t)nfeat2);
+        if (pk.flush() || h->d_si[SI_BEST].ensure((size_t)total + 1)) return fail(ORBX_E_DEVICE, "upload/allocation failed");
+        dim3 grid(((int)items.size() + 3) / 4, 1, 1), blk(256, 1, 1);
+        ORBX_LAUNCH(k_bow_dists, grid, blk, 0, h->s0, pk.dev<BowItem>(pit), (int)items.size(), pk.dev<unsigned long long>(pd1), pk.dev<unsigned long long>(pd2),
+                    pk.dev<uint8_t>(pel), pk.dev<int>(pf2), h->d_si[SI_BEST].p);
+        std::vector<int> dist((size_t)total);
+        if (rt::copy_d2h(dist.data(), h->d_si[SI_BEST].p, sizeof(int) * (size_t)total, h->s0) || rt::stream_sync(h->s0) || rt::check_launch())
+            return fail(ORBX_E_DEVICE, "bow distances failed: %s", rt::last_error());
+        std::vector<int> rotHist[HISTO_LENGTH];
+        for (const BowItem& it : items) {
+            int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256, bestDist1R = 256, bestIdxFR = -1, bestDist2R = 256;
+            for (int j = 0; j < it.cnt2; j++) {
+                const int idx2 = (int)K2->fv_feat[it.start2 + j];
+                const int d = dist[(size_t)it.out_off + j];
+                if (assigned2[idx2] >= 0) continue;                               // vpMapPointMatches[realIdxF] already set (:346)
+                if (idx2 < nleft2) {
+                    if (d < bestDist1) { bestDist2 = bestDist1; bestDist1 = d; bestIdxF = idx2; }
+                    else if (d < bestDist2) bestDist2 = d;
+                } else {
+                    if (d < bestDist1R) { bestDist2R = bestDist1R; bestDist1R = d; bestIdxFR = idx2; }
+                    else if (d < bestDist2R) bestDist2R = d;
+                }
+            }
+            if (bestDist1 <= TH_LOW) {
+                if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                    assigned2[bestIdxF] = it.idx1;
+                    nmatches++;
+                    if (check_ori) rotHist[rot_bin(K1->keys_un[it.idx1].angle, K2->keys_un[bestIdxF].angle)].push_back(bestIdxF);
+                }
+                if (bestDist1R <= TH_LOW) {
+                    assigned2[bestIdxFR] = it.idx1;
+                    nmatches++;
+                    if (check_ori) rotHist[rot_bin(K1->keys_un[it.idx1].angle, K2->keys_un[bestIdxFR].angle)].push_back(bestIdxFR);
+                }
+            }
+        }
+        if (check_ori) {
+            int ind1 = -1, ind2 = -1, ind3 = -1;
+            three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+            for (int i = 0; i < HISTO_LENGTH; i++) {
+                if (i == ind1 || i == ind2 || i == ind3) continue;
+                for (int idx2 : rotHist[i]) { assigned2[idx2] = -1; nmatches--; }
+            }
+        }
+    }
+    if (nmatches_out) *nmatches_out = nmatches;
+    return ORBX_OK;
+}
+
 // ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:734-880)
 int orbm_search_for_initialization(orbx_extractor* h, const OrbmFrameView* F1, const OrbmFrameView* F2, float* prev, int window_size,
                                    float nnratio, int check_ori, int* matches12, int* nmatches_out) {

@@ -60,6 +60,14 @@ class ORBmatcher:
                                                    m12.ctypes.data, C.byref(nm)))
         return nm.value, m12
 
+    def SearchByBoWFisheye(self, ext, kf, frame, nleft):
+        """SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) for a fisheye-rig frame (F.Nleft = nleft != -1), src/ORBmatcher.cc:259-493.
+        Both views list all features by index (camera 1 first).  Returns (nmatches, assigned[N_frame] = key-frame feature or -1)."""
+        a2 = np.full(max(frame.view.N, 1), -1, np.int32); nm = C.c_int()
+        ext._lib.check(ext._lib.L.orbm_search_by_bow_fisheye(ext._h, kf.ref(), frame.ref(), int(nleft), self.mfNNratio, int(self.mbCheckOrientation),
+                                                           a2.ctypes.data, C.byref(nm)))
+        return nm.value, a2[:frame.view.N]
+
     def SearchForInitialization(self, ext, f1, f2, vbPrevMatched, windowSize=10):
         """ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:734.  vbPrevMatched [N1,2] float32 is updated in place.
         Returns (nmatches, vnMatches12)."""

@@ -320,10 +320,11 @@ def build_and_run_rig(drv, seed):
 
     def make_rig(pose, rot_off, assoc_frac, keyframe=False):
         R, t = pose
-        kl, dl, _, ptl, _ = sc.observe(R, t, clutter=150, rot_off=rot_off)
+        kl, dl, _, ptl, nodel = sc.observe(R, t, clutter=150, rot_off=rot_off)
         Rr = (trl[0] @ R).astype(np.float32); tr = (trl[0] @ t + trl[1]).astype(np.float32)
-        kr, dr, _, ptr, _ = sc.observe(Rr, tr, clutter=150, rot_off=rot_off)
+        kr, dr, _, ptr, noder = sc.observe(Rr, tr, clutter=150, rot_off=rot_off)
         fid = drv.frame(keyframe, kl, np.concatenate([dl, dr]), None, R, t, cam, cam2, keys_right=kr, trl=trl)
+        drv.set_feat_vec(keyframe, fid, np.concatenate([nodel, noder]))
         if keyframe:
             pt = np.concatenate([ptl, ptr])
             ids = np.where((pt >= 0) & (rng.uniform(size=len(pt)) < assoc_frac), mp_ids[np.maximum(pt, 0)], -1).astype(np.int32)
@@ -380,6 +381,18 @@ def build_and_run_rig(drv, seed):
         n = L.mw_fuse(drv.w, kF, _p(cand), len(cand), C.c_float(3.0), right)
         st = np.array([drv.mappoint_state(int(c), kF) for c in cand if c >= 0]).ravel()
         out["rig_fuse_%d" % right] = np.concatenate([[n], drv.get_map_points(True, kF, nlF + nrF), st])
+
+    # ---- SearchByBoW on rig objects: key frame -> rig frame (both cameras), key frame -> key frame (camera 1 only) ----
+    kA, nlA, nrA, idsA, _ = make_rig((np.eye(3, dtype=np.float32), np.zeros(3, np.float32)), 0.0, 0.7, keyframe=True)
+    drv.set_map_points(True, kA, idsA)
+    fb, nlb, nrb, _, _ = make_rig(pose, 15.0, 0.0)
+    for ori in (1, 0):
+        o = np.full(nlb + nrb, -1, np.int32)
+        n = L.mw_search_by_bow_frame(drv.w, kA, fb, _p(o), C.c_float(0.75), ori)
+        out["rig_bow_frame_%d" % ori] = np.concatenate([[n], o])
+        o = np.full(nlA + nrA, -1, np.int32)
+        n = L.mw_search_by_bow_keyframes(drv.w, kA, kF, _p(o), C.c_float(0.8), ori)
+        out["rig_bow_keyframes_%d" % ori] = np.concatenate([[n], o])
     return out
 
 
