@@ -34,7 +34,14 @@
 namespace ORB_SLAM3
 {
 
-class ORBmatcher
+// TH_LOW / TH_HIGH / HISTO_LENGTH (src/ORBmatcher.cc:35-37) as static members of a class template: their definitions may then live in this
+// header and still be merged to one object when several translation units (Frame.cc, MapPoint.cc, Tracking.cc, ...) include it.
+template <class Unused> struct ORBmatcherConstants { static const int TH_LOW; static const int TH_HIGH; static const int HISTO_LENGTH; };
+template <class Unused> const int ORBmatcherConstants<Unused>::TH_HIGH = 100;
+template <class Unused> const int ORBmatcherConstants<Unused>::TH_LOW = 50;
+template <class Unused> const int ORBmatcherConstants<Unused>::HISTO_LENGTH = 30;
+
+class ORBmatcher : public ORBmatcherConstants<void>
 {
     template <class X> using Decay = typename std::decay<X>::type;
 
@@ -548,10 +555,6 @@ public:
     }
 
 public:
-    static const int TH_LOW;
-    static const int TH_HIGH;
-    static const int HISTO_LENGTH;
-
     static orbx_extractor* SharedHandle()
     {
         static orbx_extractor* h = nullptr;
@@ -727,10 +730,6 @@ protected:
     float mfNNratio;
     bool mbCheckOrientation;
 };
-
-const int ORBmatcher::TH_HIGH = 100;
-const int ORBmatcher::TH_LOW = 50;
-const int ORBmatcher::HISTO_LENGTH = 30;
 
 // Frame::ComputeStereoMatches (src/Frame.cc:1102-1358) for a Frame whose two extractors are the HIP facades: runs on the
 // device-resident pyramids/descriptors of the LAST call of each extractor and fills F.mvuRight / F.mvDepth.

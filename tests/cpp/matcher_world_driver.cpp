@@ -5,6 +5,12 @@
 // Both see the same stand-in world (oracle/slam_shim/slam_world.h: Frame, KeyFrame, MapPoint, cameras, poses).  The C functions below
 // build a world from flat arrays, run one ORBmatcher method on it and expose everything the method may have written, so that
 // tests/test_matcher_reference.py can feed identical scenes to both libraries and compare every output bit for bit.
+// With -DMW_REAL (oracle/slam_shim/real_world.h; libmw_ref_real.so / libmw_facade_real.so) the Frame and MapPoint objects are the reference's
+// own classes (Frame.cc and MapPoint.cc are linked in); KeyFrame stays the stand-in.
+#ifdef MW_REAL
+#include "Frame.h"
+#include "MapPoint.h"
+#endif
 #ifdef MW_FACADE
 #include "orb_slam3_amd/ORBmatcher.h"
 #else
@@ -16,19 +22,35 @@
 
 using namespace ORB_SLAM3;
 
+#ifdef MW_REAL
+std::set<MapPoint*> KeyFrame::GetMapPoints() { std::set<MapPoint*> s; for (MapPoint* p : mvpMapPoints) if (p && !p->isBad()) s.insert(p); return s; }   // src/KeyFrame.cc:370-385
+#endif
+
 namespace {
 struct World {
     std::vector<std::unique_ptr<GeometricCamera>> cams;
     std::vector<std::unique_ptr<MapPoint>> mps;
     std::vector<std::unique_ptr<Frame>> frames;
     std::vector<std::unique_ptr<KeyFrame>> kfs;
+#ifdef MW_REAL
+    Map map; KeyFrame ref_kf;
+    std::map<MapPoint*, int> ids;
+    int idOf(MapPoint* p) const { if (!p) return -1; auto it = ids.find(p); return it == ids.end() ? -2 : it->second; }
+#else
     int idOf(MapPoint* p) const { return p ? p->id : -1; }
+#endif
     MapPoint* mp(int id) const { return id < 0 ? nullptr : mps[id].get(); }
     int kfId(KeyFrame* k) const { for (size_t i = 0; i < kfs.size(); i++) if (kfs[i].get() == k) return (int)i; return -1; }
 };
 struct KP { float x, y, size, angle, response; int32_t octave, class_id; };
 
-void fill_holder(World* w, FeatureHolder& H, int N, const KP* keys, const KP* keys_un, int n_right, const KP* keys_right, const uint8_t* desc, const float* u_right,
+void set_poses(FeatureHolder& H, const Sophus::SE3f& Tcw, const Sophus::SE3f& Trl) { H.mTcw = Tcw; H.mTrl = Trl; }
+void assign_grid(FeatureHolder& H, int nleft) { H.AssignFeaturesToGrid(nleft); }
+#ifdef MW_REAL
+void set_poses(Frame& F, const Sophus::SE3f& Tcw, const Sophus::SE3f& Trl) { F.SetPose(Tcw); F.mTrl = Trl; F.mTlr = Trl.inverse(); }
+void assign_grid(Frame& F, int nleft) { F.Nleft = nleft; F.AssignFeaturesToGrid(); }           // the reference's own grid assignment (src/Frame.cc:469-503)
+#endif
+template <class HolderT> void fill_holder(World* w, HolderT& H, int N, const KP* keys, const KP* keys_un, int n_right, const KP* keys_right, const uint8_t* desc, const float* u_right,
                  const float* pose_R, const float* pose_t, const float* trl_R, const float* trl_t, const float* bounds, int nlevels, float scale_factor, int cam, int cam2,
                  float mbf, float mb) {
     H.N = N;
@@ -42,8 +64,10 @@ void fill_holder(World* w, FeatureHolder& H, int N, const KP* keys, const KP* ke
     if (N > 0) memcpy(H.mDescriptors.data, desc, (size_t)N * 32);
     H.mvuRight.assign(N, -1.0f);
     if (u_right) for (int i = 0; i < N; i++) H.mvuRight[i] = u_right[i];
-    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { H.mTcw.R(r, c) = pose_R[r * 3 + c]; H.mTrl.R(r, c) = trl_R ? trl_R[r * 3 + c] : (r == c ? 1.0f : 0.0f); }
-    for (int r = 0; r < 3; r++) { H.mTcw.t(r) = pose_t[r]; H.mTrl.t(r) = trl_t ? trl_t[r] : 0.0f; }
+    Sophus::SE3f Tcw, Trl;
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { Tcw.R(r, c) = pose_R[r * 3 + c]; Trl.R(r, c) = trl_R ? trl_R[r * 3 + c] : (r == c ? 1.0f : 0.0f); }
+    for (int r = 0; r < 3; r++) { Tcw.t(r) = pose_t[r]; Trl.t(r) = trl_t ? trl_t[r] : 0.0f; }
+    set_poses(H, Tcw, Trl);
     H.mnMinX = bounds[0]; H.mnMinY = bounds[1]; H.mnMaxX = bounds[2]; H.mnMaxY = bounds[3];
     H.mfGridElementWidthInv = static_cast<float>(FRAME_GRID_COLS) / static_cast<float>(H.mnMaxX - H.mnMinX);     // src/Frame.cc:195-196
     H.mfGridElementHeightInv = static_cast<float>(FRAME_GRID_ROWS) / static_cast<float>(H.mnMaxY - H.mnMinY);
@@ -55,7 +79,7 @@ void fill_holder(World* w, FeatureHolder& H, int N, const KP* keys, const KP* ke
     H.mpCamera = w->cams[cam].get(); H.mpCamera2 = cam2 >= 0 ? w->cams[cam2].get() : nullptr;
     H.fx = H.mpCamera->mvParameters[0]; H.fy = H.mpCamera->mvParameters[1]; H.cx = H.mpCamera->mvParameters[2]; H.cy = H.mpCamera->mvParameters[3];
     H.mbf = mbf; H.mb = mb;
-    H.AssignFeaturesToGrid(n_right >= 0 ? n_left : -1);
+    assign_grid(H, n_right >= 0 ? n_left : -1);
 }
 Sophus::Sim3f make_sim3(float s, const float* R, const float* t) {
     Eigen::Matrix3f Rm; Eigen::Vector3f tv;
@@ -73,6 +97,13 @@ const char* mw_flavour() {
     return "reference";
 #endif
 }
+int mw_real_classes() {
+#ifdef MW_REAL
+    return 1;
+#else
+    return 0;
+#endif
+}
 void* mw_create() { return new World(); }
 void mw_destroy(void* w) { delete (World*)w; }
 
@@ -81,11 +112,20 @@ int mw_add_camera(void* wv, float fx, float fy, float cx, float cy) {
 }
 int mw_add_mappoint(void* wv, const float* pos, const float* normal, float min_dist, float max_dist, const uint8_t* desc, int bad, int n_obs) {
     World* w = (World*)wv;
+#ifdef MW_REAL
+    std::unique_ptr<MapPoint> p(new MapPoint(Eigen::Vector3f(pos[0], pos[1], pos[2]), &w->ref_kf, &w->map));
+    p->mbBad = bad != 0; p->nObs = n_obs;
+    p->SetNormalVector(Eigen::Vector3f(normal[0], normal[1], normal[2]));
+    p->mfMinDistance = min_dist; p->mfMaxDistance = max_dist;
+    p->mDescriptor.create(1, 32, CV_8UC1); memcpy(p->mDescriptor.data, desc, 32);
+    w->ids[p.get()] = (int)w->mps.size();
+#else
     std::unique_ptr<MapPoint> p(new MapPoint());
     p->id = (int)w->mps.size(); p->bad = bad != 0; p->nObs = n_obs;
     p->pos = Eigen::Vector3f(pos[0], pos[1], pos[2]); p->normal = Eigen::Vector3f(normal[0], normal[1], normal[2]);
     p->minDist = min_dist; p->maxDist = max_dist;
     p->descriptor.create(1, 32, CV_8UC1); memcpy(p->descriptor.data, desc, 32);
+#endif
     w->mps.push_back(std::move(p));
     return (int)w->mps.size() - 1;
 }
@@ -112,6 +152,7 @@ int mw_add_frame(void* wv, int keyframe, int N, const void* keys, const void* ke
     std::unique_ptr<Frame> f(new Frame());
     fill_holder(w, *f, N, (const KP*)keys, (const KP*)keys_un, n_right, (const KP*)keys_right, desc, u_right, pose_R, pose_t, trl_R, trl_t, bounds, nlevels, scale_factor, cam, cam2, mbf, mb);
     if (n_right >= 0) { f->Nleft = N - n_right; f->Nright = n_right; f->mvLeftToRightMatch.assign(f->Nleft, -1); f->mvRightToLeftMatch.assign(n_right, -1); }
+    else { f->Nleft = -1; f->Nright = -1; }
     f->mvpMapPoints.assign(N, nullptr); f->mvbOutlier.assign(N, false);
     w->frames.push_back(std::move(f));
     return (int)w->frames.size() - 1;
@@ -120,7 +161,15 @@ void mw_set_map_points(void* wv, int keyframe, int id, const int* mp_ids, const 
     World* w = (World*)wv;
     if (keyframe) {
         KeyFrame* k = w->kfs[id].get();
-        for (int i = 0; i < k->N; i++) { k->mvpMapPoints[i] = w->mp(mp_ids[i]); if (k->mvpMapPoints[i]) k->mvpMapPoints[i]->observations[k] = std::tuple<int, int>(i, -1); }
+        for (int i = 0; i < k->N; i++) {
+            k->mvpMapPoints[i] = w->mp(mp_ids[i]);
+            if (!k->mvpMapPoints[i]) continue;
+#ifdef MW_REAL
+            MapPoint* p = k->mvpMapPoints[i]; const int n = p->nObs; p->AddObservation(k, i); p->nObs = n;      // the observation, not its count
+#else
+            k->mvpMapPoints[i]->observations[k] = std::tuple<int, int>(i, -1);
+#endif
+        }
     } else {
         Frame* f = w->frames[id].get();
         for (int i = 0; i < f->N; i++) { f->mvpMapPoints[i] = w->mp(mp_ids[i]); if (outlier) f->mvbOutlier[i] = outlier[i] != 0; }
@@ -145,7 +194,11 @@ void mw_set_lr_matches(void* wv, int id, const int* l2r, const int* r2l) {
 // state a Fuse call may have changed: out = {bad, nObs, replacedBy, index of the observation in key frame kf (-1 none)}
 void mw_get_mappoint_state(void* wv, int id, int kf, int* out) {
     World* w = (World*)wv; MapPoint* p = w->mps[id].get();
+    #ifdef MW_REAL
+    out[0] = p->mbBad; out[1] = p->nObs; out[2] = w->idOf(p->mpReplaced); out[3] = std::get<0>(p->GetIndexInKeyFrame(w->kfs[kf].get()));
+#else
     out[0] = p->bad; out[1] = p->nObs; out[2] = w->idOf(p->replacedBy); out[3] = std::get<0>(p->GetIndexInKeyFrame(w->kfs[kf].get()));
+#endif
 }
 
 int mw_descriptor_distance(const uint8_t* a, const uint8_t* b) {

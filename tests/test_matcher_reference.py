@@ -22,11 +22,15 @@ from orb_slam3_detailed_comments_amd import _lib
 ROOT = ol.ROOT
 REF = os.path.join(ROOT, "oracle", "_ref", "libmw_ref.so")
 FACADE = os.path.join(ROOT, "oracle", "_ref", "libmw_facade.so")
+# the same driver over the reference's OWN Frame and MapPoint classes (Frame.cc / MapPoint.cc linked in, and in the facade build compiled
+# against the drop-in ORBmatcher.h); only KeyFrame, Map, the camera and the Eigen / Sophus algebra are stand-ins there
+REF_REAL = os.path.join(ROOT, "oracle", "_ref", "libmw_ref_real.so")
+FACADE_REAL = os.path.join(ROOT, "oracle", "_ref", "libmw_facade_real.so")
 RUNNER = os.path.join(ROOT, "tests", "matcher_world.py")
 pytestmark = pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(FACADE)), reason="oracle/_ref/libmw_*.so not built (needs /root/reference)")
 
 MIN_MATCHES = {"sbp_mappoints_0": 100, "sbp_frame_fwd_7": 100, "sbp_keyframe_100": 100, "sbp_sim3_100_0": 100, "bow_frame_1": 80, "bow_keyframes_1": 60,
-               "init_0": 30, "triang_0_0": 10, "sim3_100": 60, "fuse": 100, "fuse_sim3": 100, "rig_sbp_mappoints_1": 200, "rig_sbp_frame_fwd_1": 300, "rig_fuse_0": 50, "rig_fuse_1": 25, "rig_bow_frame_1": 80, "rig_bow_keyframes_1": 40}
+               "init_0": 30, "triang_0_0": 10, "sim3_100": 60, "fuse": 100, "fuse_sim3": 60, "rig_sbp_mappoints_1": 200, "rig_sbp_frame_fwd_1": 300, "rig_fuse_0": 50, "rig_fuse_1": 25, "rig_bow_frame_1": 80, "rig_bow_keyframes_1": 40}
 
 
 def _run(tmp_path, driver, orbx, seed, variant, tag):
@@ -36,10 +40,10 @@ def _run(tmp_path, driver, orbx, seed, variant, tag):
     return np.load(dst)
 
 
-def _compare(tmp_path, orbx, cases):
+def _compare(tmp_path, orbx, cases, ref=REF, facade=FACADE):
     for seed, variant in cases:
-        a = _run(tmp_path, REF, "", seed, variant, "ref")
-        b = _run(tmp_path, FACADE, orbx, seed, variant, "facade")
+        a = _run(tmp_path, ref, "", seed, variant, "ref")
+        b = _run(tmp_path, facade, orbx, seed, variant, "facade")
         assert bytes(a["flavour"]) == b"reference" and bytes(b["flavour"]) == b"facade"
         assert set(a.files) == set(b.files) and len(a.files) > 5
         for k in a.files:
@@ -58,3 +62,28 @@ def test_matcher_facade_equals_reference_emulated(tmp_path, emu_lib):
 @pytest.mark.gpu
 def test_matcher_facade_equals_reference_gpu(tmp_path, hip_lib):
     _compare(tmp_path, _lib.HIP_LIB_PATH, [(1, "base"), (2, "dense"), (3, "hard"), (4, "rig"), (11, "base"), (12, "dense"), (13, "rig")])
+
+
+real = pytest.mark.skipif(not (os.path.exists(REF_REAL) and os.path.exists(FACADE_REAL)), reason="oracle/_ref/libmw_*_real.so not built (needs /root/reference)")
+
+
+@real
+def test_real_classes_agree_with_standins(tmp_path):
+    """The reference's ORBmatcher.cc gives the same search results over its own Frame / MapPoint classes as over the stand-ins of
+    oracle/slam_shim (Fuse excluded: the real Replace / AddObservation change more state than the stand-in log records)."""
+    a = _run(tmp_path, REF_REAL, "", 1, "base", "real")
+    b = _run(tmp_path, REF, "", 1, "base", "standin")
+    for k in a.files:
+        if k != "flavour" and not k.startswith("fuse"):
+            assert np.array_equal(a[k], b[k]), k
+
+
+@real
+def test_matcher_facade_equals_reference_real_classes_emulated(tmp_path, emu_lib):
+    _compare(tmp_path, os.path.join(ROOT, "tests", "emu", "liborbx_emu.so"), [(1, "base"), (3, "hard"), (4, "rig")], REF_REAL, FACADE_REAL)
+
+
+@real
+@pytest.mark.gpu
+def test_matcher_facade_equals_reference_real_classes_gpu(tmp_path, hip_lib):
+    _compare(tmp_path, _lib.HIP_LIB_PATH, [(1, "base"), (2, "dense"), (3, "hard"), (4, "rig"), (21, "base"), (22, "rig")], REF_REAL, FACADE_REAL)
