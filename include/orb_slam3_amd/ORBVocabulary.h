@@ -13,7 +13,7 @@
 #include <opencv2/core/core.hpp>
 #include "DBoW2/BowVector.h"
 #include "DBoW2/FeatureVector.h"
-#include "orbx.h"
+#include "../orbx.h"
 
 namespace ORB_SLAM3 {
 

@@ -83,3 +83,19 @@ def test_vocabulary_facade_emulated(tmp_path, emu_lib):
                    ["-L" + libdir, "-lorbx_emu", "-Wl,-rpath," + libdir, "-lpthread", "-o", str(exe)], check=True)
     r = subprocess.run([str(exe), str(voc), "900"], capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_facade_headers_link_from_several_translation_units(tmp_path, emu_lib):
+    """Tracking.cc, Frame.cc, MapPoint.cc, LocalMapping.cc ... all include ORBmatcher.h / ORBextractor.h: the drop-in headers must not define
+    anything that collides at link time (they once defined TH_LOW / TH_HIGH / HISTO_LENGTH at namespace scope)."""
+    voc = os.path.isdir(DBOW2)
+    inc = '#include "ORBextractor.h"\n#include "ORBmatcher.h"\n' + ('#include "ORBVocabulary.h"\n' if voc else "")
+    (tmp_path / "a.cpp").write_text(inc + "int fa() { ORB_SLAM3::ORBmatcher m(0.7f, true); const int& r = ORB_SLAM3::ORBmatcher::TH_LOW; return r; }\n")
+    (tmp_path / "b.cpp").write_text(inc + "int fa();\nint main() { const int& r = ORB_SLAM3::ORBmatcher::TH_HIGH; return fa() + r + ORB_SLAM3::ORBmatcher::HISTO_LENGTH == 180 ? 0 : 1; }\n")
+    libdir = os.path.join(ROOT, "tests", "emu")
+    cmd = ["g++", "-std=c++14", "-w", "-I" + os.path.join(ROOT, "include", "orb_slam3_amd"), "-I" + os.path.join(ROOT, "oracle", "opencv_shim")]
+    if voc:
+        cmd += ["-I" + DBOW2, "-I/root/reference", "-I" + os.path.join(ROOT, "oracle", "boost_shim")]
+    exe = tmp_path / "two_tu"
+    subprocess.run(cmd + [str(tmp_path / "a.cpp"), str(tmp_path / "b.cpp"), "-L" + libdir, "-lorbx_emu", "-Wl,-rpath," + libdir, "-lpthread", "-o", str(exe)], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
