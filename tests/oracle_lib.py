@@ -410,16 +410,7 @@ def oracle_search_by_projection_frame_fisheye(cur2, last, proj_ur, proj_vr, th, 
 _REF_FRAME = None
 
 
-def reference_frame_lib():
-    """The reference's own Frame.cc + ORBextractor.cc + ORBmatcher.cc built over oracle/slam_shim/frame_world.h (oracle/_ref/libref_frame.so); None if absent."""
-    global _REF_FRAME
-    if _REF_FRAME is None:
-        p = os.path.join(ORACLE_DIR, "_ref", "libref_frame.so")
-        if not os.path.exists(p) and os.path.exists("/root/reference/src/Frame.cc"):
-            build()
-        if not os.path.exists(p):
-            return None
-        L = C.CDLL(p)
+def _bind_frame_lib(L):
         L.ref_frame_stereo.restype = C.c_void_p
         L.ref_frame_stereo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_float] * 6 + [C.POINTER(C.c_int)] * 2
         L.ref_frame_destroy.argtypes = [C.c_void_p]
@@ -430,15 +421,35 @@ def reference_frame_lib():
         L.ref_frame_get.argtypes = [C.c_void_p] * 8
         L.ref_frame_constants.argtypes = [C.c_void_p, C.c_void_p]
         L.ref_frame_features_in_area.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
-        _REF_FRAME = L
+        return L
+
+
+def reference_frame_lib():
+    """The reference's own Frame.cc + ORBextractor.cc + ORBmatcher.cc built over oracle/slam_shim/frame_world.h (oracle/_ref/libref_frame.so); None if absent."""
+    global _REF_FRAME
+    if _REF_FRAME is None:
+        p = os.path.join(ORACLE_DIR, "_ref", "libref_frame.so")
+        if not os.path.exists(p) and os.path.exists("/root/reference/src/Frame.cc"):
+            build()
+        if not os.path.exists(p):
+            return None
+        _REF_FRAME = _bind_frame_lib(C.CDLL(p))
     return _REF_FRAME
+
+
+def dropin_frame_lib(orbx_path):
+    """oracle/_ref/libref_frame_dropin.so: the reference's own Frame.cc compiled against the drop-in ORBextractor.h, i.e. the
+    reference's stereo Frame constructor running on the product library `orbx_path` (HIP or emulator build).  Load once per process."""
+    C.CDLL(orbx_path, mode=C.RTLD_GLOBAL)
+    return _bind_frame_lib(C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libref_frame_dropin.so")))
 
 
 class ReferenceFrame:
     """ORB_SLAM3::Frame as built by the reference's own stereo constructor (src/Frame.cc:105-230) on a rectified pair."""
 
-    def __init__(self, left, right, nfeatures=1200, scale=1.2, nlevels=8, ini=20, mn=7, gauss_variant=0, fx=458.654, fy=457.296, cx=367.215, cy=248.375, bf=458.654 * 0.110074, th_depth=35.0):
-        L = reference_frame_lib()
+    def __init__(self, left, right, nfeatures=1200, scale=1.2, nlevels=8, ini=20, mn=7, gauss_variant=0, fx=458.654, fy=457.296, cx=367.215, cy=248.375, bf=458.654 * 0.110074, th_depth=35.0,
+                 lib=None):
+        L = lib or reference_frame_lib()
         left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
         n = C.c_int(); nr = C.c_int()
         self.L = L

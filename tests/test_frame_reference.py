@@ -143,3 +143,36 @@ def test_product_equals_reference_fisheye_frame_emulated(emu_lib):
 @pytest.mark.gpu
 def test_product_equals_reference_fisheye_frame_gpu(hip_lib):
     _product_vs_reference_rig(hip_lib, RIG_CASES)
+
+
+# ---- the reference's own Frame.cc compiled against the drop-in ORBextractor.h: "zero source changes" for the extractor, end to end ----
+DROPIN = os.path.join(ol.ROOT, "oracle", "_ref", "libref_frame_dropin.so")
+
+
+def _dropin_vs_reference(tmp_path, orbx, cases):
+    import subprocess, sys
+    for case in cases:
+        w, h, seed, nf, sf, nl, ini, mn, gv = case
+        if gv != 0:
+            continue                                    # the facade constructor keeps the library's default taps
+        dst = str(tmp_path / ("dropin_%d.npz" % seed))
+        env = dict(os.environ); env["PYTHONPATH"] = ol.ROOT + os.pathsep + os.path.join(ol.ROOT, "tests")
+        r = subprocess.run([sys.executable, os.path.join(ol.ROOT, "tests", "frame_dropin_runner.py"), orbx] + [str(v) for v in case] + [dst], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        D = np.load(dst)
+        _, _, F = _ref(case)
+        for k, ref in (("keys", F.keys), ("keys_un", F.keys_un), ("desc", F.desc), ("keys_right", F.keys_right), ("desc_right", F.desc_right), ("u_right", F.u_right), ("depth", F.depth)):
+            assert D[k].tobytes() == ref.tobytes(), "Frame::%s differs when the reference's Frame.cc runs on the drop-in extractor" % k
+        assert list(D["probe"]) == [len(F.features_in_area(300.0, 200.0, 40.0)), len(F.features_in_area(100.0, 100.0, 25.0, 1, 3))]
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/libref_frame_dropin.so not built (needs /root/reference)")
+def test_reference_frame_on_dropin_extractor_emulated(tmp_path, emu_lib):
+    _dropin_vs_reference(tmp_path, os.path.join(ol.ROOT, "tests", "emu", "liborbx_emu.so"), CASES[2:3])
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/libref_frame_dropin.so not built")
+def test_reference_frame_on_dropin_extractor_gpu(tmp_path, hip_lib):
+    from orb_slam3_detailed_comments_amd import _lib
+    _dropin_vs_reference(tmp_path, _lib.HIP_LIB_PATH, CASES)
