@@ -12,7 +12,7 @@ assert KP_DTYPE.itemsize == 28
 
 
 def build():
-    subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-j8", "-C", ORACLE_DIR, "-s"], check=True, stdout=subprocess.DEVNULL)
 
 
 def _load(path):
