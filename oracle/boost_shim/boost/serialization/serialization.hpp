@@ -4,4 +4,5 @@
 namespace boost { namespace serialization {
 class access;
 template <class Base, class Derived> Base& base_object(Derived& d) { return static_cast<Base&>(d); }
+template <class T> int make_array(T*, unsigned long) { return 0; }          // include/KeyFrame.h:146, include/MapPoint.h:86 (inside serialize() templates)
 } }

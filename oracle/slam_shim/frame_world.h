@@ -27,6 +27,7 @@ template <typename T, int R, int C> struct MatrixSel;
 template <> struct MatrixSel<float, 3, 1> { typedef Vector3f type; };
 template <> struct MatrixSel<float, 3, 3> { typedef Matrix3f type; };
 template <> struct MatrixSel<float, 2, 1> { typedef Vector2f type; };
+template <> struct MatrixSel<float, 1, 3> { typedef Vector3f type; };
 template <typename T, int R, int C> using Matrix = typename MatrixSel<T, R, C>::type;
 }
 
@@ -34,7 +35,7 @@ namespace ORB_SLAM3 {
 namespace IMU {
 struct Bias { float bax = 0, bay = 0, baz = 0, bwx = 0, bwy = 0, bwz = 0; };
 struct Calib { Sophus::SE3f mTcb, mTbc; bool mbIsSet = false; };
-struct Preintegrated { void SetNewBias(const Bias&) {} };
+struct Preintegrated { void SetNewBias(const Bias&) {} void CopyFrom(Preintegrated*) {} };
 }
 class ConstraintPoseImu {};
 class Converter {

@@ -7,7 +7,9 @@
 #ifndef ORBX_REAL_MAPPOINT
 #define MAPPOINT_H
 #endif
+#ifndef ORBX_REAL_KEYFRAME
 #define KEYFRAME_H
+#endif
 
 #include <cmath>
 #include <map>
@@ -60,6 +62,9 @@ struct Matrix3f {
     static Matrix3f Zero() { return Matrix3f(); }
     float& operator()(int r, int c) { return m[r][c]; }
     const float& operator()(int r, int c) const { return m[r][c]; }
+    float* data() { return &m[0][0]; }
+    size_t size() const { return 9; }
+    Vector3f row(int r) const { return Vector3f(m[r][0], m[r][1], m[r][2]); }
     Matrix3f transpose() const { Matrix3f r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = m[j][i]; return r; }
     Matrix3f inverse() const {          // cofactors / determinant
         Matrix3f r;
@@ -84,6 +89,11 @@ inline Matrix3f operator*(const Matrix3f& A, float s) { Matrix3f r; for (int i =
 }  // namespace Eigen
 
 namespace Sophus {
+struct SO3f {
+    Eigen::Matrix3f R;
+    SO3f operator*(const SO3f& o) const { SO3f r; r.R = R * o.R; return r; }
+    const Eigen::Matrix3f& matrix() const { return R; }
+};
 template <typename T> struct SE3;
 template <> struct SE3<float> {
     Eigen::Matrix3f R; Eigen::Vector3f t;
@@ -91,6 +101,7 @@ template <> struct SE3<float> {
     SE3(const Eigen::Matrix3f& r, const Eigen::Vector3f& tt) : R(r), t(tt) {}
     const Eigen::Matrix3f& rotationMatrix() const { return R; }
     const Eigen::Vector3f& translation() const { return t; }
+    SO3f so3() const { SO3f r; r.R = R; return r; }
     SE3 inverse() const { const Eigen::Matrix3f Rt = R.transpose(); return SE3(Rt, -(Rt * t)); }
     SE3 operator*(const SE3& o) const { return SE3(R * o.R, R * o.t + t); }
     Eigen::Vector3f operator*(const Eigen::Vector3f& p) const { return R * p + t; }
@@ -124,6 +135,7 @@ public:
     float mvParameters[4];
     GeometricCamera(float fx, float fy, float cx, float cy) : mvParameters{fx, fy, cx, cy} {}
     virtual ~GeometricCamera() {}
+    unsigned int GetId() { return 0; }
     virtual Eigen::Vector2f project(const Eigen::Vector3f& v3D) {                                    // Pinhole.cpp:61-68
         Eigen::Vector2f res;
         res[0] = mvParameters[0] * v3D[0] / v3D[2] + mvParameters[2];
@@ -235,6 +247,7 @@ public:
     }
 };
 
+#ifndef ORBX_REAL_KEYFRAME
 class KeyFrame : public FeatureHolder {
 public:
     int NLeft = -1, NRight = -1;
@@ -288,6 +301,8 @@ public:
         return vIndices;
     }
 };
+
+#endif
 
 }  // namespace ORB_SLAM3
 #endif

@@ -5,8 +5,13 @@
 // Both see the same stand-in world (oracle/slam_shim/slam_world.h: Frame, KeyFrame, MapPoint, cameras, poses).  The C functions below
 // build a world from flat arrays, run one ORBmatcher method on it and expose everything the method may have written, so that
 // tests/test_matcher_reference.py can feed identical scenes to both libraries and compare every output bit for bit.
-// With -DMW_REAL (oracle/slam_shim/real_world.h; libmw_ref_real.so / libmw_facade_real.so) the Frame and MapPoint objects are the reference's
-// own classes (Frame.cc and MapPoint.cc are linked in); KeyFrame stays the stand-in.
+// With -DMW_FULL (oracle/slam_shim/full_world.h; libmw_ref_full.so / libmw_facade_full.so) Frame, KeyFrame and MapPoint are the reference's own
+// classes (Frame.cc, KeyFrame.cc and MapPoint.cc are linked in; a key frame is built by the reference's KeyFrame(Frame&, Map*, KeyFrameDatabase*)
+// constructor from a real Frame).  MW_REAL marks the code shared by every variant with real Frame / MapPoint objects.
+#ifdef MW_FULL
+#define MW_REAL
+#include "KeyFrame.h"
+#endif
 #ifdef MW_REAL
 #include "Frame.h"
 #include "MapPoint.h"
@@ -22,7 +27,7 @@
 
 using namespace ORB_SLAM3;
 
-#ifdef MW_REAL
+#if defined(MW_REAL) && !defined(MW_FULL)
 std::set<MapPoint*> KeyFrame::GetMapPoints() { std::set<MapPoint*> s; for (MapPoint* p : mvpMapPoints) if (p && !p->isBad()) s.insert(p); return s; }   // src/KeyFrame.cc:370-385
 #endif
 
@@ -34,6 +39,9 @@ struct World {
     std::vector<std::unique_ptr<KeyFrame>> kfs;
 #ifdef MW_REAL
     Map map; KeyFrame ref_kf;
+#ifdef MW_FULL
+    KeyFrameDatabase db;
+#endif
     std::map<MapPoint*, int> ids;
     int idOf(MapPoint* p) const { if (!p) return -1; auto it = ids.find(p); return it == ids.end() ? -2 : it->second; }
 #else
@@ -141,6 +149,19 @@ int mw_add_frame(void* wv, int keyframe, int N, const void* keys, const void* ke
                  const float* pose_R, const float* pose_t, const float* trl_R, const float* trl_t, const float* bounds, int nlevels, float scale_factor, int cam, int cam2,
                  float mbf, float mb) {
     World* w = (World*)wv;
+#ifdef MW_FULL
+    if (keyframe) {                                        // a real Frame first, then the reference's KeyFrame(Frame&, Map*, KeyFrameDatabase*)
+        std::unique_ptr<Frame> f(new Frame());
+        fill_holder(w, *f, N, (const KP*)keys, (const KP*)keys_un, n_right, (const KP*)keys_right, desc, u_right, pose_R, pose_t, trl_R, trl_t, bounds, nlevels, scale_factor, cam, cam2, mbf, mb);
+        if (n_right >= 0) { f->Nleft = N - n_right; f->Nright = n_right; f->mvLeftToRightMatch.assign(f->Nleft, -1); f->mvRightToLeftMatch.assign(n_right, -1); }
+        else { f->Nleft = -1; f->Nright = -1; }
+        f->mvpMapPoints.assign(N, nullptr); f->mvbOutlier.assign(N, false);
+        f->mfScaleFactor = scale_factor; f->mThDepth = 35.0f; f->mTimeStamp = 0; f->mnId = 0; f->mpORBvocabulary = nullptr; f->mpImuPreintegrated = nullptr; f->mnDataset = 0;
+        f->invfx = 1.0f / f->fx; f->invfy = 1.0f / f->fy;
+        w->kfs.emplace_back(new KeyFrame(*f, &w->map, &w->db));
+        return (int)w->kfs.size() - 1;
+    }
+#else
     if (keyframe) {
         std::unique_ptr<KeyFrame> k(new KeyFrame());
         fill_holder(w, *k, N, (const KP*)keys, (const KP*)keys_un, n_right, (const KP*)keys_right, desc, u_right, pose_R, pose_t, trl_R, trl_t, bounds, nlevels, scale_factor, cam, cam2, mbf, mb);
@@ -149,6 +170,7 @@ int mw_add_frame(void* wv, int keyframe, int N, const void* keys, const void* ke
         w->kfs.push_back(std::move(k));
         return (int)w->kfs.size() - 1;
     }
+#endif
     std::unique_ptr<Frame> f(new Frame());
     fill_holder(w, *f, N, (const KP*)keys, (const KP*)keys_un, n_right, (const KP*)keys_right, desc, u_right, pose_R, pose_t, trl_R, trl_t, bounds, nlevels, scale_factor, cam, cam2, mbf, mb);
     if (n_right >= 0) { f->Nleft = N - n_right; f->Nright = n_right; f->mvLeftToRightMatch.assign(f->Nleft, -1); f->mvRightToLeftMatch.assign(n_right, -1); }
