@@ -24,6 +24,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <new>
 
 using namespace ORB_SLAM3;
 
@@ -41,6 +42,8 @@ struct World {
     Map map; KeyFrame ref_kf;
 #ifdef MW_FULL
     KeyFrameDatabase db;
+    static const size_t kMaxKeyFrames = 64;
+    char* kf_arena = nullptr;
 #endif
     std::map<MapPoint*, int> ids;
     int idOf(MapPoint* p) const { if (!p) return -1; auto it = ids.find(p); return it == ids.end() ? -2 : it->second; }
@@ -113,7 +116,12 @@ int mw_real_classes() {
 #endif
 }
 void* mw_create() { return new World(); }
-void mw_destroy(void* w) { delete (World*)w; }
+void mw_destroy(void* w) {
+#ifdef MW_FULL
+    for (auto& k : ((World*)w)->kfs) k.release();      // arena objects (never freed: a test process)
+#endif
+    delete (World*)w;
+}
 
 int mw_add_camera(void* wv, float fx, float fy, float cx, float cy) {
     World* w = (World*)wv; w->cams.emplace_back(new GeometricCamera(fx, fy, cx, cy)); return (int)w->cams.size() - 1;
@@ -158,7 +166,11 @@ int mw_add_frame(void* wv, int keyframe, int N, const void* keys, const void* ke
         f->mvpMapPoints.assign(N, nullptr); f->mvbOutlier.assign(N, false);
         f->mfScaleFactor = scale_factor; f->mThDepth = 35.0f; f->mTimeStamp = 0; f->mnId = 0; f->mpORBvocabulary = nullptr; f->mpImuPreintegrated = nullptr; f->mnDataset = 0;
         f->invfx = 1.0f / f->fx; f->invfy = 1.0f / f->fy;
-        w->kfs.emplace_back(new KeyFrame(*f, &w->map, &w->db));
+        // MapPoint keeps its observations in a std::map<KeyFrame*, ...> and iterates it (Replace, ComputeDistinctiveDescriptors), so the reference's
+        // results depend on the ADDRESS order of the key frames.  Both builds therefore place them in one arena, in creation order.
+        if (!w->kf_arena) w->kf_arena = (char*)::operator new(sizeof(KeyFrame) * World::kMaxKeyFrames);
+        if (w->kfs.size() >= World::kMaxKeyFrames) return -1;
+        w->kfs.emplace_back(new (w->kf_arena + sizeof(KeyFrame) * w->kfs.size()) KeyFrame(*f, &w->map, &w->db));
         return (int)w->kfs.size() - 1;
     }
 #else

@@ -14,11 +14,14 @@ import oracle_lib as ol                                     # noqa: E402
 from orb_slam3_detailed_comments_amd import _lib, ORBextractor, ComputeStereoMatches, synth   # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-REF = os.path.join(ROOT, "oracle", "_ref", "libmw_ref.so"); FAC = os.path.join(ROOT, "oracle", "_ref", "libmw_facade.so")
+# even seeds: stand-in Frame / KeyFrame / MapPoint world; odd seeds: the reference's own classes (Frame.cc, KeyFrame.cc, MapPoint.cc compiled in place)
+WORLDS = [(os.path.join(ROOT, "oracle", "_ref", "libmw_ref.so"), os.path.join(ROOT, "oracle", "_ref", "libmw_facade.so")),
+          (os.path.join(ROOT, "oracle", "_ref", "libmw_ref_full.so"), os.path.join(ROOT, "oracle", "_ref", "libmw_facade_full.so"))]
 RUN = os.path.join(ROOT, "tests", "matcher_world.py")
 tmp = tempfile.mkdtemp()
 bad = 0
 for seed in range(1000, 1000 + n):
+    REF, FAC = WORLDS[seed & 1]
     for variant in ("base", "dense", "hard", "rig"):
         a = os.path.join(tmp, "a.npz"); b = os.path.join(tmp, "b.npz")
         subprocess.run([sys.executable, RUN, REF, "", str(seed), variant, a], check=True)
