@@ -31,6 +31,21 @@ __global__ void __launch_bounds__(256) k_import(const LevelInfo* __restrict__ lv
     *(uint32_t*)(pyr + (size_t)b * pyr_stride + D.off + (size_t)y * D.pitch + x0) = out;
 }
 
+__device__ __forceinline__ int mul24(int a, int b) {
+#ifdef ORBX_EMU
+    return a * b;
+#else
+    return __mul24(a, b);      // operands < 2^23: full-rate 24-bit multiply instead of the quarter-rate 32-bit one
+#endif
+}
+// the same, but immune to the compiler turning it back into v_mul_lo_u32 (it does where it has proven narrower operand ranges)
+__device__ __forceinline__ int mul24_forced(int a, int b) {
+#ifdef ORBX_EMU
+    return a * b;
+#else
+    int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+#endif
+}
 // ---------------------------------------------------------------------------------------------------
 // Pyramid: cv::resize INTER_LINEAR 8U, 11-bit fixed point.  A workgroup produces a 256 x 8 output tile: the source
 // rows/columns it needs (<= ~1.2x the tile for the 1.2 pyramid) are staged in LDS with aligned dword loads, each
@@ -75,9 +90,9 @@ __global__ void __launch_bounds__(256) k_resize(const LevelInfo* __restrict__ lv
                 const int i = i0 + 256 * k;
                 o[k] = -1;
                 if (i < n) {
-                    const int r = (int)(((unsigned)i * Mc) >> 20), c = i - r * ncd;
-                    o[k] = r * lds_pitch + 4 * c;
-                    v[k] = *(const uint32_t*)(src + (size_t)(sy_lo + r) * S.pitch + gx0 + 4 * c);
+                    const int r = (int)((unsigned)mul24(i, (int)Mc) >> 20), c = i - mul24(r, ncd);
+                    o[k] = mul24(r, lds_pitch) + 4 * c;
+                    v[k] = *(const uint32_t*)(src + mul24(sy_lo + r, S.pitch) + gx0 + 4 * c);
                 }
             }
 #pragma unroll
@@ -100,20 +115,22 @@ __global__ void __launch_bounds__(256) k_resize(const LevelInfo* __restrict__ lv
         const ResizeTap ty = tys[rr];
         const int r0 = imin(imax(ty.ofs, 0), S.h - 1) - sy_lo, r1 = imin(imax(ty.ofs + 1, 0), S.h - 1) - sy_lo;
         const int b0 = (int)(int16_t)(ty.w & 0xFFFF), b1 = ty.w >> 16;
-        const uint8_t* S0 = smem + r0 * lds_pitch;
-        const uint8_t* S1 = smem + r1 * lds_pitch;
+        const uint8_t* S0 = smem + mul24(r0, lds_pitch);
+        const uint8_t* S1 = smem + mul24(r1, lds_pitch);
         uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (dx0 + k < D.w) {
-                const int h0 = S0[sxo[k]] * a0[k] + S0[sxo1[k]] * a1[k];
-                const int h1 = S1[sxo[k]] * a0[k] + S1[sxo1[k]] * a1[k];
-                int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                // every factor is below 2^23 and every product below 2^31 (pixel < 2^8, tap <= 2^11, h >> 4 < 2^16): 24-bit multiplies,
+                // the 32-bit v_mul_lo_u32 runs at a quarter of their rate
+                const int h0 = mul24((int)S0[sxo[k]], a0[k]) + mul24((int)S0[sxo1[k]], a1[k]);
+                const int h1 = mul24((int)S1[sxo[k]], a0[k]) + mul24((int)S1[sxo1[k]], a1[k]);
+                int v = ((mul24_forced(b0, h0 >> 4) >> 16) + (mul24_forced(b1, h1 >> 4) >> 16) + 2) >> 2;
                 v = imin(imax(v, 0), 255);
                 out |= (uint32_t)v << (8 * k);
             }
         }
-        *(uint32_t*)(dst + (size_t)dy * D.pitch + dx0) = out;
+        *(uint32_t*)(dst + mul24(dy, D.pitch) + dx0) = out;
     }
 }
 
@@ -157,13 +174,6 @@ __device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c)
 #else
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
-#endif
-}
-__device__ __forceinline__ int mul24(int a, int b) {
-#ifdef ORBX_EMU
-    return a * b;
-#else
-    return __mul24(a, b);      // operands < 2^23: full-rate 24-bit multiply instead of the quarter-rate 32-bit one
 #endif
 }
 // two signed 16-bit lanes in one VGPR (v_pk_sub_i16 / v_pk_min_i16 / v_pk_max_i16)
@@ -576,7 +586,7 @@ __global__ void __launch_bounds__(256) k_blur(const LevelInfo* __restrict__ lv, 
             if (y < 0) y = -y;
             if (y >= L.h) y = 2 * L.h - 2 - y;
             y = imax(y, 0);
-            const uint8_t* row = src + (size_t)y * L.pitch + x0;
+            const uint8_t* row = src + (uint32_t)(mul24(y, L.pitch) + x0);      // uniform base + 32-bit offset: no 64-bit multiply-add per row
             const uint32_t c = *(const uint32_t*)row;
             const uint32_t l = x0 > 0 ? *(const uint32_t*)(row - 4) : 0u;
             const uint32_t r = x0 + 4 < L.pitch ? *(const uint32_t*)(row + 4) : 0u;
@@ -609,8 +619,9 @@ __global__ void __launch_bounds__(256) k_blur(const LevelInfo* __restrict__ lv, 
                     oe |= ve << (8 * j); oo |= vo << (8 * j);
                 }
             }
-            *(uint32_t*)(dst + (size_t)yo * L.pitch + x0) = oe;
-            if (yo + 1 < L.h) *(uint32_t*)(dst + (size_t)(yo + 1) * L.pitch + x0) = oo;
+            const uint32_t oofs = (uint32_t)(mul24(yo, L.pitch) + x0);
+            *(uint32_t*)(dst + oofs) = oe;
+            if (yo + 1 < L.h) *(uint32_t*)(dst + (oofs + (uint32_t)L.pitch)) = oo;
         }
     }
 }
