@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restric
         uint32_t I4[4];
 #pragma unroll
         for (int trip = 0; trip < 4; trip++)                // issued back to back: one memory round trip
-            __builtin_memcpy(&I4[trip], raw + (ptrdiff_t)(-kHalfPatch + 8 * trip + r8) * pitch, 4);
+            __builtin_memcpy(&I4[trip], raw + (ptrdiff_t)__mul24(-kHalfPatch + 8 * trip + r8, pitch), 4);      // 24-bit multiply, not a 64-bit multiply-add
         uint32_t du = 0, dv = 0, ds = 0;
 #pragma unroll
         for (int trip = 0; trip < 4; trip++) { du = dot4_u8(I4[trip], wu4[trip], du); dv = dot4_u8(I4[trip], wv4[trip], dv); ds = dot4_u8(I4[trip], on4[trip], ds); }
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restric
 #pragma unroll
         for (int t = 0; t < kWinTrips; t++) {
             const int i = lane + 64 * t;                    // dword i of the window: row i / 10, dword column i % 10
-            if (i < kWinRows * kWinDw) __builtin_memcpy(&wv[t], ctr + (ptrdiff_t)(i / kWinDw - kWinR) * pitch + (4 * (i % kWinDw) - kWinR), 4);
+            if (i < kWinRows * kWinDw) __builtin_memcpy(&wv[t], ctr + (ptrdiff_t)(__mul24(i / kWinDw - kWinR, pitch) + (4 * (i % kWinDw) - kWinR)), 4);
         }
         ORBX_WAVE_SYNC();                                   // the previous keypoint's samples have been read
 #pragma unroll

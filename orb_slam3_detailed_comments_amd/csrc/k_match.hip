@@ -143,8 +143,9 @@ __global__ void __launch_bounds__(256) k_stereo_match(const LevelInfo* __restric
                 const int idx = lane + 64 * rep;
                 if (idx < 121) {
                     const int row = idx / 11, col = idx - row * 11;
-                    const int a = IL[(size_t)(cv - w + row) * Lv.pitch + (cu - w + col)];
-                    const uint8_t* rp = IR + (size_t)(cv - w + row) * Lv.pitch + (cr - w - Lh + col);
+                    const int rofs = __mul24(cv - w + row, Lv.pitch);                                 // rows and pitches are far below 2^23
+                    const int a = IL[(uint32_t)(rofs + (cu - w + col))];
+                    const uint8_t* rp = IR + (uint32_t)(rofs + (cr - w - Lh + col));
 #pragma unroll
                     for (int k = 0; k < 11; k++) { const int d = a - (int)rp[k]; acc[k] += d < 0 ? -d : d; }
                 }
