@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
             const int i = i0 + k * kFastThreads;
             if (i < wh * wpd) {
                 const int r = (int)((unsigned)mul24(i, (int)Mw) >> 20), c = i - mul24(r, wpd);
-                v[k] = *(const uint32_t*)(img + (size_t)(ci.y0 - 3 + r) * L.pitch + gx0 + 4 * c);
+                v[k] = *(const uint32_t*)(img + (uint32_t)(mul24(ci.y0 - 3 + r, L.pitch) + gx0 + 4 * c));      // uniform base + 32-bit offset
             }
         }
 #pragma unroll
