@@ -279,7 +279,7 @@ def main():
                 valu = None
         per_pair_bytes = 2 * sum(v for k, v in ab.items() if k != "match") + ab["match"]
         res = {
-            "metric": "stereo pairs/sec ORB extract+match, 752x480 stereo @1200 feat", "value": round(value, 1),
+            "metric": "frames/sec ORB extract+match, 752x480 stereo @1200 feat (1 frame = 1 stereo pair; BASELINE.json configs[1])", "value": round(value, 1),
             "unit": "stereo pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
