@@ -322,7 +322,6 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
     // needed such a flush (dense noise) finish with the list-free variants of phases C and D.
     static_assert(kFastWaves == 1, "the flush logic below assumes one wave per cell");
     const int g0 = (xo + 3) >> 2, ng = ((xo + 3 + iw - 1) >> 2) - g0 + 1;
-    const int nitems = ih * ng;
     const uint32_t* tile32 = (const uint32_t*)tile;
     // ---- B ----  full score of list[0, n), two listed pixels per lane (packed lanes)
     auto score_listed = [&](int n) {
@@ -364,25 +363,30 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
     int cnt = 0;
     bool flushed = false;
     {
-        // (row, group) of this lane's item, advanced incrementally by 64 items per trip (no per-trip division)
-        int y = lane / ng, gi = lane - y * ng;
-        const int dq = 64 / ng, dr = 64 - dq * ng;
+        // A trip covers rpt = 64 / ng whole rows: lane = (row within the trip) * ng + (dword group), so a lane keeps its group - and with it
+        // its x position, the validity of its four pixels and its tile column - for the whole cell, and only the row advances.  Row-major
+        // order of the lanes is row-major order of the pixels.  (ng <= 11 for the cell sizes in use: at most 14 % of the lanes idle.)
+        const int rpt = imax(64 / ng, 1);                          // (a row of more than 64 groups = 256 pixels does not occur: cells are < 70 px wide)
+        const int yl = lane / ng, gi = lane - yl * ng;
+        const bool lane_used = yl < rpt;
+        const int g = g0 + gi;
+        const int xbase = 4 * g - (xo + 3);                    // interior x of this lane's first pixel (may be < 0)
+        const int vlo_ = imax(0, -xbase), vhi_ = imin(4, iw - xbase);          // valid pixels j in [vlo_, vhi_)
+        const bool v0 = lane_used && vlo_ <= 0 && vhi_ > 0, v1 = lane_used && vlo_ <= 1 && vhi_ > 1, v2 = lane_used && vlo_ <= 2 && vhi_ > 2, v3 = lane_used && vhi_ > 3 && vlo_ <= 3;
+        const uint32_t* rp_lane = tile32 + mul24(yl + 3, wpd) + g;
+        const int pj_lane = mul24(yl + 1, pitch) + xbase + 1;
         // outer loop: one turn per list fill.  The trip that would overflow the list is abandoned (nothing appended, the (row, group)
         // cursor not advanced), the listed pixels are scored, and the same trip is redone with an empty list - one call site of
         // phase B outside the phase-A loop keeps the register budgets of the two phases apart.
-        int it0 = 0;
+        int it0 = 0;                                               // first row of the current trip
         for (;;) {
-        for (; it0 < nitems; it0 += 64) {
-            const int it = it0 + lane;
-            const int iend = nitems;
+        for (; it0 < ih; it0 += rpt) {
+            const int y = it0 + yl;
             // survivor predicates of this lane's 4 pixels (dark / bright): kept as eight lane masks, so that the appends below run under them
             // directly instead of re-testing bits of a per-lane bit mask
             bool pd0 = false, pd1 = false, pd2 = false, pd3 = false, pb0 = false, pb1 = false, pb2 = false, pb3 = false;
-            int xbase = 0;
-            if (it < iend) {
-                const int g = g0 + gi;
-                xbase = 4 * g - (xo + 3);                  // interior x of this lane's first pixel (may be < 0)
-                const uint32_t* rp = tile32 + mul24(y + 3, wpd) + g;
+            if (lane_used && y < ih) {
+                const uint32_t* rp = rp_lane + mul24(it0, wpd);
                 const uint32_t kBias4 = (uint32_t)(kPixBias >> 8) * 0x01010101u;          // the high byte of every widened pixel
                 // Only the four opposite pairs (0,8) (2,10) (4,12) (6,14) are tested here: still a necessary condition (every 9-arc holds one
                 // point of each opposite pair), it lets 34 % instead of 31 % of the pixels through to the exact score of phase B, and it costs
@@ -413,8 +417,6 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
                 const pk2 N_lo = pk_min(pk_min3(mx_lo[0], mx_lo[1], mx_lo[2]), mx_lo[3]), N_hi = pk_min(pk_min3(mx_hi[0], mx_hi[1], mx_hi[2]), mx_hi[3]);
                 const pk2 vlo = pk_make(byte_perm(kBias4, C3, 0x04010400u)), vhi = pk_make(byte_perm(kBias4, C3, 0x04030402u));
                 const pk2 dk_lo = pk_sub(vlo, M_lo), dk_hi = pk_sub(vhi, M_hi), br_lo = pk_sub(N_lo, vlo), br_hi = pk_sub(N_hi, vhi);
-                const int lo = imax(0, -xbase), hi = imin(4, iw - xbase);          // valid pixels j in [lo, hi)
-                const bool v0 = lo <= 0 && hi > 0, v1 = lo <= 1 && hi > 1, v2 = lo <= 2 && hi > 2, v3 = hi > 3 && lo <= 3;
                 pd0 = v0 && pk_lo(dk_lo) > t0; pd1 = v1 && pk_hi(dk_lo) > t0; pd2 = v2 && pk_lo(dk_hi) > t0; pd3 = v3 && pk_hi(dk_hi) > t0;
                 pb0 = v0 && pk_lo(br_lo) > t0; pb1 = v1 && pk_hi(br_lo) > t0; pb2 = v2 && pk_lo(br_hi) > t0; pb3 = v3 && pk_hi(br_hi) > t0;
             }
@@ -423,19 +425,17 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
             const int trip = ORBX_READLANE(incl, 63);
             if (cnt > 0 && cnt + trip > list_cap) break;                                    // wave-uniform (a trip adds <= 512 entries <= list_cap)
             int pos = cnt + incl - c4;
-            const int pj0 = mul24(y + 1, pitch) + xbase + 1;
+            const int pj0 = pj_lane + mul24(it0, pitch);
 #define ORBX_APPEND(j, pd, pb) \
             if (pd) list[pos++] = (uint16_t)(pj0 + (j)); \
             if (pb) list[pos++] = (uint16_t)((pj0 + (j)) | kListBright | ((pd) ? kListDup : 0));
             ORBX_APPEND(0, pd0, pb0) ORBX_APPEND(1, pd1, pb1) ORBX_APPEND(2, pd2, pb2) ORBX_APPEND(3, pd3, pb3)
 #undef ORBX_APPEND
             cnt += trip;
-            gi += dr; y += dq;
-            if (gi >= ng) { gi -= ng; y++; }
         }
         ORBX_WAVE_SYNC();
         score_listed(cnt);
-        if (it0 >= nitems) break;
+        if (it0 >= ih) break;
         cnt = 0; flushed = true;
         }
     }
