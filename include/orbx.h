@@ -330,6 +330,11 @@ int orbm_search_by_sim3(orbx_extractor* h, const OrbmFrameView* KF1, const OrbmF
 int orbm_search_by_bow(orbx_extractor* h, const OrbmKeyFrameView* K1, const OrbmKeyFrameView* K2, float nnratio, int th_inclusive,
                        int check_orientation, int* matches12, int* nmatches);
 
+/* n independent (K1s[p], K2s[p]) pairs in one launch: every relocalisation candidate against the current frame (src/Tracking.cc:4360-4380),
+ * a key frame against its loop / merge candidates (src/LoopClosing.cc:840-850).  matches12[p] has K1s[p]->N entries, nmatches n entries. */
+int orbm_search_by_bow_batch(orbx_extractor* h, int n, const OrbmKeyFrameView* const* K1s, const OrbmKeyFrameView* const* K2s, float nnratio,
+                             int th_inclusive, int check_orientation, int* const* matches12, int* nmatches);
+
 /* SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) for a fisheye-rig frame (F.Nleft != -1; src/ORBmatcher.cc:259-493 incl. :343-372, :414-446).
  * K1 / K2 list ALL features by index (camera 1 first: keys = mvKeys followed by mvKeysRight, descriptor rows as stored); nleft2 = F.Nleft.
  * assigned2[j] = feature of K1 whose map point is written to vpMapPointMatches[j], -1 = NULL (after the rotation-consistency pruning). */

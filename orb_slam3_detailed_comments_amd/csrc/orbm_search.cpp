@@ -392,52 +392,78 @@ int orbm_search_for_triangulation(orbx_extractor* h, const OrbmKeyFrameView* K1,
 }
 
 
-// ORBmatcher::SearchByBoW, both overloads (src/ORBmatcher.cc:259-493, :892-1043), non-fisheye path
-int orbm_search_by_bow(orbx_extractor* h, const OrbmKeyFrameView* K1, const OrbmKeyFrameView* K2, float nnratio, int th_inclusive,
-                       int check_ori, int* matches12, int* nmatches_out) {
-    if (!h || !K1 || !K2 || !matches12) return fail(ORBX_E_ARG, "null");
-    if (K1->N >= 65535 || K2->N >= 65535) return fail(ORBX_E_ARG, "keyframe too large");
+// ORBmatcher::SearchByBoW, both overloads (src/ORBmatcher.cc:259-493, :892-1043), non-fisheye path, for n independent (K1, K2) pairs in one
+// launch: Tracking::Relocalization matches every candidate key frame against the current frame (src/Tracking.cc:4360-4380), loop / merge
+// detection one key frame against its candidates' covisible key frames (src/LoopClosing.cc:840-850).  The pairs' descriptors and feature
+// lists are concatenated (indices made global), one k_bow_dists launch computes every node-bucket distance, the order-dependent selection
+// is replayed per pair on the host.
+int orbm_search_by_bow_batch(orbx_extractor* h, int n, const OrbmKeyFrameView* const* K1s, const OrbmKeyFrameView* const* K2s, float nnratio, int th_inclusive,
+                             int check_ori, int* const* matches12, int* nmatches_out) {
+    if (!h || n < 0 || (n > 0 && (!K1s || !K2s || !matches12))) return fail(ORBX_E_ARG, "null");
     rt::set_device(h->device);
-    const int N1 = K1->N, N2 = K2->N;
-    for (int i = 0; i < N1; i++) matches12[i] = -1;
     std::vector<BowItem> items;
-    int a = 0, b = 0, total = 0;
-    while (a < K1->fv_nodes && b < K2->fv_nodes) {
-        const uint32_t na = K1->fv_node_id[a], nb = K2->fv_node_id[b];
-        if (na == nb) {
-            for (int k = K1->fv_start[a]; k < K1->fv_start[a + 1]; k++) {
-                const int idx1 = (int)K1->fv_feat[k];
-                if (!K1->has_map_point || !K1->has_map_point[idx1]) continue;     // !pMP || pMP->isBad()
-                BowItem it; it.idx1 = idx1; it.start2 = K2->fv_start[b]; it.cnt2 = K2->fv_start[b + 1] - K2->fv_start[b]; it.out_off = total;
-                total += it.cnt2;
-                items.push_back(it);
-            }
-            a++; b++;
-        } else if (na < nb) { while (a < K1->fv_nodes && K1->fv_node_id[a] < nb) a++; }
-        else { while (b < K2->fv_nodes && K2->fv_node_id[b] < na) b++; }
+    std::vector<int> first_item(n + 1, 0), base1(n + 1, 0), base2(n + 1, 0), fbase2(n + 1, 0), obase(n + 1, 0);
+    int total = 0;
+    for (int p = 0; p < n; p++) {
+        const OrbmKeyFrameView *K1 = K1s[p], *K2 = K2s[p];
+        if (!K1 || !K2 || !matches12[p] || K1->N >= 65535 || K2->N >= 65535) return fail(ORBX_E_ARG, "bad key frame pair %d", p);
+        for (int i = 0; i < K1->N; i++) matches12[p][i] = -1;
+        if (nmatches_out) nmatches_out[p] = 0;
+        first_item[p] = (int)items.size(); obase[p] = total;
+        base1[p + 1] = base1[p] + K1->N; base2[p + 1] = base2[p] + K2->N; fbase2[p + 1] = fbase2[p] + K2->fv_start[K2->fv_nodes];
+        int a = 0, b = 0;
+        while (a < K1->fv_nodes && b < K2->fv_nodes) {
+            const uint32_t na = K1->fv_node_id[a], nb = K2->fv_node_id[b];
+            if (na == nb) {
+                for (int k = K1->fv_start[a]; k < K1->fv_start[a + 1]; k++) {
+                    const int idx1 = (int)K1->fv_feat[k];
+                    if (!K1->has_map_point || !K1->has_map_point[idx1]) continue;     // !pMP || pMP->isBad()
+                    BowItem it; it.idx1 = base1[p] + idx1; it.start2 = fbase2[p] + K2->fv_start[b]; it.cnt2 = K2->fv_start[b + 1] - K2->fv_start[b]; it.out_off = total;
+                    total += it.cnt2;
+                    items.push_back(it);
+                }
+                a++; b++;
+            } else if (na < nb) { while (a < K1->fv_nodes && K1->fv_node_id[a] < nb) a++; }
+            else { while (b < K2->fv_nodes && K2->fv_node_id[b] < na) b++; }
+        }
     }
-    int nmatches = 0;
-    if (!items.empty() && total > 0) {
-        std::vector<uint8_t> elig(N2 > 0 ? N2 : 1, 1);
-        if (K2->has_map_point) memcpy(elig.data(), K2->has_map_point, N2);
-        const int nfeat2 = K2->fv_start[K2->fv_nodes];
-        Packer pk(h);
-        const size_t pd1 = pk.add(K1->desc, 32 * (size_t)N1), pd2 = pk.add(K2->desc, 32 * (size_t)N2), pel = pk.add(elig.data(), elig.size()),
-                     pit = pk.add(items.data(), sizeof(BowItem) * items.size()), pf2 = pk.add(K2->fv_feat, sizeof(int) * (size_t)nfeat2);
-        if (pk.flush() || h->d_si[SI_BEST].ensure((size_t)total + 1)) return fail(ORBX_E_DEVICE, "upload/allocation failed");
-        dim3 grid(((int)items.size() + 3) / 4, 1, 1), blk(256, 1, 1);
-        ORBX_LAUNCH(k_bow_dists, grid, blk, 0, h->s0, pk.dev<BowItem>(pit), (int)items.size(), pk.dev<unsigned long long>(pd1), pk.dev<unsigned long long>(pd2),
-                    pk.dev<uint8_t>(pel), pk.dev<int>(pf2), h->d_si[SI_BEST].p);
-        std::vector<int> dist((size_t)total);
-        if (rt::copy_d2h(dist.data(), h->d_si[SI_BEST].p, sizeof(int) * (size_t)total, h->s0) || rt::stream_sync(h->s0) || rt::check_launch())
-            return fail(ORBX_E_DEVICE, "bow distances failed: %s", rt::last_error());
+    first_item[n] = (int)items.size(); obase[n] = total;
+    if (items.empty() || total == 0) return ORBX_OK;
+    const int T1 = std::max(base1[n], 1), T2 = std::max(base2[n], 1), TF = std::max(fbase2[n], 1);
+    std::vector<uint8_t> desc1((size_t)T1 * 32), desc2((size_t)T2 * 32), elig(T2, 1);
+    std::vector<int> feat2(TF);
+    for (int p = 0; p < n; p++) {
+        const OrbmKeyFrameView *K1 = K1s[p], *K2 = K2s[p];
+        if (K1->N > 0) memcpy(&desc1[(size_t)base1[p] * 32], K1->desc, 32 * (size_t)K1->N);
+        if (K2->N > 0) memcpy(&desc2[(size_t)base2[p] * 32], K2->desc, 32 * (size_t)K2->N);
+        if (K2->has_map_point) memcpy(&elig[base2[p]], K2->has_map_point, K2->N);
+        const int nf = K2->fv_start[K2->fv_nodes];
+        for (int k = 0; k < nf; k++) feat2[fbase2[p] + k] = (int)K2->fv_feat[k] + base2[p];
+    }
+    Packer pk(h);
+    const size_t pd1 = pk.add(desc1.data(), desc1.size()), pd2 = pk.add(desc2.data(), desc2.size()), pel = pk.add(elig.data(), elig.size()),
+                 pit = pk.add(items.data(), sizeof(BowItem) * items.size()), pf2 = pk.add(feat2.data(), sizeof(int) * feat2.size());
+    if (pk.flush() || h->d_si[SI_BEST].ensure((size_t)total + 1)) return fail(ORBX_E_DEVICE, "upload/allocation failed");
+    dim3 grid(((int)items.size() + 3) / 4, 1, 1), blk(256, 1, 1);
+    ORBX_LAUNCH(k_bow_dists, grid, blk, 0, h->s0, pk.dev<BowItem>(pit), (int)items.size(), pk.dev<unsigned long long>(pd1), pk.dev<unsigned long long>(pd2),
+                pk.dev<uint8_t>(pel), pk.dev<int>(pf2), h->d_si[SI_BEST].p);
+    std::vector<int> dist((size_t)total);
+    if (rt::copy_d2h(dist.data(), h->d_si[SI_BEST].p, sizeof(int) * (size_t)total, h->s0) || rt::stream_sync(h->s0) || rt::check_launch())
+        return fail(ORBX_E_DEVICE, "bow distances failed: %s", rt::last_error());
+    for (int p = 0; p < n; p++) {
+        const OrbmKeyFrameView *K1 = K1s[p], *K2 = K2s[p];
+        const int N2 = K2->N;
+        int* m12 = matches12[p];
+        int nmatches = 0;
         // sequential replay: a target taken by an earlier feature is skipped (:331 vpMapPointMatches[realIdxF], :948 vbMatched2[idx2])
         std::vector<uint8_t> taken(N2 > 0 ? N2 : 1, 0);
         std::vector<int> rotHist[HISTO_LENGTH];
-        for (const BowItem& it : items) {
+        for (int q = first_item[p]; q < first_item[p + 1]; q++) {
+            const BowItem& it = items[q];
+            const int idx1 = it.idx1 - base1[p];
             int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
             for (int j = 0; j < it.cnt2; j++) {
-                const int idx2 = (int)K2->fv_feat[it.start2 + j];
+                const int idx2 = feat2[it.start2 + j] - base2[p];
                 const int d = dist[(size_t)it.out_off + j];
                 if (taken[idx2] || d < 0) continue;
                 if (d < bestDist1) { bestDist2 = bestDist1; bestDist1 = d; bestIdx2 = idx2; }
@@ -445,10 +471,10 @@ int orbm_search_by_bow(orbx_extractor* h, const OrbmKeyFrameView* K1, const Orbm
             }
             const bool pass = th_inclusive ? (bestDist1 <= TH_LOW) : (bestDist1 < TH_LOW);
             if (pass && static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
-                matches12[it.idx1] = bestIdx2;
+                m12[idx1] = bestIdx2;
                 taken[bestIdx2] = 1;
                 nmatches++;
-                if (check_ori) rotHist[rot_bin(K1->keys_un[it.idx1].angle, K2->keys_un[bestIdx2].angle)].push_back(it.idx1);
+                if (check_ori) rotHist[rot_bin(K1->keys_un[idx1].angle, K2->keys_un[bestIdx2].angle)].push_back(idx1);
             }
         }
         if (check_ori) {
@@ -456,12 +482,21 @@ int orbm_search_by_bow(orbx_extractor* h, const OrbmKeyFrameView* K1, const Orbm
             three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
             for (int i = 0; i < HISTO_LENGTH; i++) {
                 if (i == ind1 || i == ind2 || i == ind3) continue;
-                for (int idx1 : rotHist[i]) { matches12[idx1] = -1; nmatches--; }
+                for (int idx1 : rotHist[i]) { m12[idx1] = -1; nmatches--; }
             }
         }
+        if (nmatches_out) nmatches_out[p] = nmatches;
     }
-    if (nmatches_out) *nmatches_out = nmatches;
     return ORBX_OK;
+}
+
+int orbm_search_by_bow(orbx_extractor* h, const OrbmKeyFrameView* K1, const OrbmKeyFrameView* K2, float nnratio, int th_inclusive,
+                       int check_ori, int* matches12, int* nmatches_out) {
+    if (!h || !K1 || !K2 || !matches12) return fail(ORBX_E_ARG, "null");
+    int nm = 0;
+    const int rc = orbm_search_by_bow_batch(h, 1, &K1, &K2, nnratio, th_inclusive, check_ori, &matches12, &nm);
+    if (nmatches_out) *nmatches_out = nm;
+    return rc;
 }
 
 // ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) for a fisheye-rig frame (F.Nleft != -1, src/ORBmatcher.cc:259-493 incl.

@@ -60,6 +60,16 @@ class ORBmatcher:
                                                    m12.ctypes.data, C.byref(nm)))
         return nm.value, m12
 
+    def SearchByBoWBatch(self, ext, kf1s, kf2s, frame_version=True):
+        """SearchByBoW for the pairs (kf1s[p], kf2s[p]) in one launch (relocalisation candidates vs the current frame, a key frame vs its loop
+        candidates).  Returns a list of (nmatches, matches12) like SearchByBoW."""
+        n = len(kf1s)
+        p1 = (C.c_void_p * max(n, 1))(*[C.cast(k.ref(), C.c_void_p) for k in kf1s]); p2 = (C.c_void_p * max(n, 1))(*[C.cast(k.ref(), C.c_void_p) for k in kf2s])
+        outs = [np.full(max(k.view.N, 1), -1, np.int32) for k in kf1s]
+        po = (C.c_void_p * max(n, 1))(*[o.ctypes.data for o in outs]); nm = np.zeros(max(n, 1), np.int32)
+        ext._lib.check(ext._lib.L.orbm_search_by_bow_batch(ext._h, n, p1, p2, self.mfNNratio, int(frame_version), int(self.mbCheckOrientation), po, nm.ctypes.data))
+        return [(int(nm[p]), outs[p][:kf1s[p].view.N]) for p in range(n)]
+
     def SearchByBoWFisheye(self, ext, kf, frame, nleft):
         """SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) for a fisheye-rig frame (F.Nleft = nleft != -1), src/ORBmatcher.cc:259-493.
         Both views list all features by index (camera 1 first).  Returns (nmatches, assigned[N_frame] = key-frame feature or -1)."""

@@ -67,6 +67,14 @@ def run_all(lib, w, h, nf, M_points, seeds):
             assert n1 == n2 and np.array_equal(m1, m2), (frame_version, ratio, ori)
             nbest = max(nbest, n2)
         assert nbest > 5
+        # the same searches for several pairs in one launch (relocalisation candidates, loop candidates)
+        for (frame_version, ratio, ori) in [(True, 0.7, True), (False, 0.8, False)]:
+            k1s = [kf1[0], kf3[0], kf2[0], kf1[0]]; k2s = [kf2[0], kf4[0], kf1[0], kf4[0]]
+            got = M.ORBmatcher(ratio, ori).SearchByBoWBatch(ex, k1s, k2s, frame_version)
+            for p in range(len(k1s)):
+                n2, m2 = ol.oracle_search_by_bow(k1s[p], k2s[p], ratio, frame_version, ori)
+                assert got[p][0] == n2 and np.array_equal(got[p][1], m2), (p, frame_version, ratio, ori)
+        assert M.ORBmatcher(0.7, True).SearchByBoWBatch(ex, [], [], True) == []
         f1 = sc.views.frame_view(kf1[1], kf1[2], scales, w, h); f2 = sc.views.frame_view(kf2[1], kf2[2], scales, w, h)
         nbest = 0
         for (win, ratio, ori) in [(100, 0.9, True), (30, 0.9, False)]:

@@ -55,6 +55,8 @@ def main():
     Fs = np.tile(np.asarray(F12, np.float32), (20, 1)); Es = np.tile(np.asarray(ep, np.float32), (20, 1))
     rows.append(("SearchForTriangulation x 20 neighbours (one batched launch)", lambda: M.ORBmatcher(0.6, False).SearchForTriangulationBatch(ex, kf1[0], neigh, Fs, Es),
                  lambda: [ol.oracle_search_for_triangulation(kf1[0], kf2[0], F12, ep, False, False, False) for _ in range(20)]))
+    rows.append(("SearchByBoW x 10 relocalisation candidates (one batched launch)", lambda: M.ORBmatcher(0.7, True).SearchByBoWBatch(ex, [kf1[0]] * 10, [kf2[0]] * 10, True),
+                 lambda: [ol.oracle_search_by_bow(kf1[0], kf2[0], 0.7, True, True) for _ in range(10)]))
     # MapPoint::ComputeDistinctiveDescriptors for 5000 map points with ~20 observations each
     counts = rng.integers(5, 40, MP); start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
     dd = rng.integers(0, 256, (int(start[-1]), 32), dtype=np.uint8)
