@@ -115,6 +115,9 @@ const char* orbx_stage_name(int i);
 /* Stage probes for parity tests (level-ordered intermediate results of image `image_index`). */
 int orbx_debug_candidates(orbx_extractor* h, int image_index, int level, int* xys, int cap);       /* returns count; (x,y,score) rel. to the 16-px border, reference order */
 int orbx_debug_level_keys(orbx_extractor* h, int image_index, int level, int* xys, int cap);       /* quadtree output in list order */
+/* test switches of the stereo row search (orbm_stereo_match): bit 0 visits the candidates of a row band in the opposite order (the result
+ * must not change), bit 1 restores the distance-only tie rule of an earlier revision (the tie tests must then fail) */
+int orbx_debug_stereo_flags(orbx_extractor* h, int flags);
 int orbx_debug_quadtree_profile(orbx_extractor* h, long long out[16]);   /* phase timestamps of one quadtree workgroup (profiling mode 2) */
 
 /* ---------------------------------------------------------------------------------------------------------- */

@@ -26,7 +26,8 @@ __global__ void __launch_bounds__(256) k_hamming_matrix(const unsigned long long
 
 // Row index for the stereo search (the role of vRowIndices, src/Frame.cc:1129-1155): the right keypoints of an image bucketed by the
 // first row of their candidate band (32 rows per bucket, CSR).  A left keypoint at row v then only visits the buckets that can hold
-// bands covering v instead of every right keypoint.  Order inside a bucket is arbitrary: the search reduces (distance, index) keys.
+// bands covering v instead of every right keypoint.  Order inside a bucket is arbitrary (atomics): the search reduces full
+// (distance << 16 | index) keys, in the lanes as well as across them, so the visiting order never shows in the result.
 // grid (B), 256 threads, dynamic LDS = 2 * (nb + 1) ints.
 constexpr int kRowBucketShift = 5;
 __global__ void __launch_bounds__(256) k_stereo_rows(const int4* __restrict__ auxR, const int* __restrict__ nR, int cap, int nb,
@@ -81,7 +82,9 @@ __global__ void __launch_bounds__(256) k_stereo_match(const LevelInfo* __restric
     float out_u = -1.0f, out_d = -1.0f; int out_sad = -1;
     const int rowL = __float2int_rz(vL);
     const int nr = nR[b];
-    unsigned best = ((unsigned)P.th_high << 16) | 0xFFFFu;
+    // key = distance << 16 | iR.  The reference starts from bestDist = TH_HIGH, bestIdxR = 0 and replaces on a strictly smaller distance
+    // while it walks vRowIndices[vL] in ascending iR (src/Frame.cc:1195-1226): the winner is the smallest key below TH_HIGH << 16.
+    unsigned best = (unsigned)P.th_high << 16;
     if (!(maxU < 0)) {
         const unsigned long long* dl = descL + 4 * o;
         const unsigned long long d0 = dl[0], d1 = dl[1], d2 = dl[2], d3 = dl[3];
@@ -91,13 +94,14 @@ __global__ void __launch_bounds__(256) k_stereo_match(const LevelInfo* __restric
         const int* bs = bucket_start + (size_t)b * (nb + 1);
         const int* items = bucket_items + (size_t)b * cap;
         const int jbeg = bs[imin(imax(rowL - lookback, 0) >> kRowBucketShift, nb - 1)], jend = bs[imin(imax(rowL, 0) >> kRowBucketShift, nb - 1) + 1];
-        (void)nr;
         for (int base = jbeg; base < jend; base += 128) { // 2 right keypoints per lane per trip, their loads in flight together
             int4 a[2]; int idx[2];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                const int j = base + 64 * u + lane;
-                idx[u] = j < jend ? items[j] : -1;
+                int j = base + 64 * u + lane;
+                const bool in = j < jend;
+                if (P.debug_flags & 1) j = jend - 1 - (j - jbeg);    // test switch: visit the candidates in the opposite order
+                idx[u] = in ? items[j] : -1;
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) {
@@ -113,14 +117,16 @@ __global__ void __launch_bounds__(256) k_stereo_match(const LevelInfo* __restric
                     const unsigned long long* dr = descR + 4 * ((size_t)b * cap + iR);
                     const int dist = __popcll(d0 ^ dr[0]) + __popcll(d1 ^ dr[1]) + __popcll(d2 ^ dr[2]) + __popcll(d3 ^ dr[3]);
                     const unsigned cand = ((unsigned)dist << 16) | (unsigned)iR;
-                    if (dist < (int)(best >> 16)) best = cand;   // strict '<': first (lowest iR) minimum wins
+                    // full-key compare: lowest distance, then lowest iR, whatever the visiting order.  (Test switch bit 1 = the
+                    // distance-only compare this kernel had in round 1, kept so that the tie tests can show they would catch it.)
+                    if ((P.debug_flags & 2) ? dist < (int)(best >> 16) : cand < best) best = cand;
                 }
             }
         }
     }
     best = wave_min_u32(best);   // lowest distance, then lowest right index == sequential first-min
     const int bestDist = (int)(best >> 16);
-    if (bestDist < P.th_orb && (best & 0xFFFFu) != 0xFFFFu) {
+    if (bestDist < P.th_orb && nr > 0) {
         const int bestIdxR = (int)(best & 0xFFFFu);
         const float uR0 = kpsR[(size_t)b * cap + bestIdxR].x;
         const LevelInfo Lv = lv[levelL];

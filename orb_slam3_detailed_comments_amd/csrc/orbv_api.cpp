@@ -45,6 +45,9 @@ int run(orbv_vocabulary* v, orbx_extractor* h, const unsigned long long* fdesc, 
     if (cap > 16384) return fail(ORBX_E_CAPACITY, "more than 16384 features per image");
     if (reserve(v, cap, B)) return fail(ORBX_E_DEVICE, "vocabulary scratch allocation failed");
     int P = 64; while (P < cap) P <<= 1;
+    // k_voc_assemble sorts one image's (id, feature) keys in LDS: 8 bytes per key slot (+ its static scan scratch)
+    if ((size_t)P * 8 + 1024 > rt::lds_limit(h->device))
+        return fail(ORBX_E_CAPACITY, "%d features per image need %zu bytes of LDS for the vocabulary transform, the device allows %zu per workgroup", cap, (size_t)P * 8 + 1024, rt::lds_limit(h->device));
     const long groups = (long)cap * B;
     dim3 g1((unsigned)((groups * 16 + 255) / 256), 1, 1), blk(256, 1, 1);
     ORBX_LAUNCH(k_voc_descend, g1, blk, 0, h->s0, fdesc, n_feat, n_fixed, cap, B, (const unsigned long long*)v->d_desc.p,

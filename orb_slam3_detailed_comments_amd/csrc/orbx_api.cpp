@@ -83,6 +83,9 @@ int configure(orbx_extractor* h, int W, int H, int B) {
     if (rt::set_device(h->device)) return fail(ORBX_E_DEVICE, "hipSetDevice(%d) failed", h->device);
     if (!same_geom) {
         if (W - 2 * kBorder > 4095 || H - 2 * kBorder > 4095) return fail(ORBX_E_ARG, "image larger than 4127 px is not supported");
+        // the tables below are rebuilt in place; until they are complete (and uploaded) the handle has no geometry, so a rejected size
+        // cannot leave host tables of one resolution beside device tables of another
+        h->W = h->H = 0; h->maxB = 0; h->lastB = 0; h->ncells = 0; h->kp_total_cap = 0;
         h->cells.clear(); h->xtab.clear(); h->ytab.clear();
         size_t off = 0; int cand_off = 0, kp_off = 0, node_cap = 0, tile_b = 0, inner_b = 0, nb_cap = 1;
         for (int l = 0; l < h->nlevels; l++) {
@@ -153,8 +156,7 @@ int configure(orbx_extractor* h, int W, int H, int B) {
         h->pyr_stride = off; h->cand_stride = (size_t)cand_off; h->ncells = (int)h->cells.size();
         h->kp_total_cap = kp_off; h->node_cap = node_cap; h->nb_cap = nb_cap;
         h->fast_tile_bytes = (int)align_up((size_t)tile_b, 16); h->fast_inner_bytes = (int)align_up((size_t)inner_b, 16);
-        if (h->kp_total_cap >= 65535) return fail(ORBX_E_ARG, "nfeatures too large");
-        h->W = W; h->H = H; h->maxB = 0;
+        if (h->kp_total_cap >= 65535) { h->kp_total_cap = 0; return fail(ORBX_E_ARG, "nfeatures too large"); }
         int e = 0;
         e |= h->d_lv.ensure(kMaxLevels); e |= h->d_cells.ensure(h->cells.size());
         e |= h->d_xtab.ensure(std::max<size_t>(h->xtab.size(), 1)); e |= h->d_ytab.ensure(std::max<size_t>(h->ytab.size(), 1));
@@ -163,7 +165,8 @@ int configure(orbx_extractor* h, int W, int H, int B) {
         rt::copy_h2d(h->d_cells.p, h->cells.data(), sizeof(CellInfo) * h->cells.size(), h->s0);
         if (!h->xtab.empty()) rt::copy_h2d(h->d_xtab.p, h->xtab.data(), sizeof(ResizeTap) * h->xtab.size(), h->s0);
         if (!h->ytab.empty()) rt::copy_h2d(h->d_ytab.p, h->ytab.data(), sizeof(ResizeTap) * h->ytab.size(), h->s0);
-        rt::stream_sync(h->s0);
+        if (rt::stream_sync(h->s0)) return fail(ORBX_E_DEVICE, "table upload failed: %s", rt::last_error());
+        h->W = W; h->H = H;                                        // commit
     }
     if (B > h->maxB) {
         const size_t b = (size_t)B, cap = (size_t)h->kp_total_cap;
@@ -219,6 +222,7 @@ void enqueue_input(orbx_extractor* h, int B, const uint8_t* d_images, int sw, in
 int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w, int src_h, int stride, size_t image_stride, int lap0, int lap1) {
     const int nl = h->nlevels;
     const dim3 blk2(64, 4, 1), blk1(256, 1, 1);
+    rt::memset_async(h->d_status.p, 0, 4 * sizeof(int), h->s0);     // the quadtree's capacity flag is per batch, not per handle
     stage_begin(h, ST_IMPORT, h->s0);
     if (h->in_active && (h->in_channels != 1 || h->in_geometry != 0)) enqueue_input(h, B, d_images, src_w, src_h, stride, image_stride);
     else {
@@ -273,6 +277,8 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
         // nodes 2x24 B + child counts 16 B + expand lists 2x8 B + flags 1 B per node; bucket offsets + 4 per-wave cursors per bucket
         const int lut_x = (int)align_up((size_t)h->lv[0].bw + 1, 8), lut_y = (int)align_up((size_t)h->lv[0].bh + 1, 8);   // level 0 is the largest
         const size_t smem = (size_t)h->node_cap * 81 + (size_t)(5 * h->nb_cap + 2) * 4 + 2 * (size_t)(lut_x + lut_y) + 64;
+        if (smem + 2048 > rt::lds_limit(h->device))
+            return fail(ORBX_E_CAPACITY, "nfeatures %d at %dx%d needs %zu bytes of LDS per quadtree workgroup, the device allows %zu", h->nfeatures, h->W, h->H, smem + 2048, rt::lds_limit(h->device));
         ORBX_LAUNCH(k_quadtree, grid, blk1, smem, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
                     (const int*)h->d_cell_count.p, (const uint32_t*)h->d_slots.p, h->cand_stride, h->d_candA.p, h->d_candB.p, h->cand_stride,
                     h->d_lvl_keys.p, h->kp_total_cap, h->d_lvl_count.p, nl, h->node_cap, h->nb_cap, lut_x, lut_y, h->d_status.p,
@@ -549,6 +555,8 @@ int orbx_host_alloc(orbx_extractor* h, size_t bytes, void** hptr) {
 }
 int orbx_host_free(orbx_extractor* h, void* hptr) { if (!h) return ORBX_E_ARG; rt::set_device(h->device); rt::hfree(hptr); return ORBX_OK; }
 
+int orbx_debug_stereo_flags(orbx_extractor* h, int flags) { if (!h) return ORBX_E_ARG; h->debug_stereo_flags = flags; return ORBX_OK; }
+
 int orbx_set_graph_replay(orbx_extractor* h, int on) { if (!h) return ORBX_E_ARG; h->use_graph = on != 0; return ORBX_OK; }
 
 int orbx_profile_enable(orbx_extractor* h, int on) { if (!h) return ORBX_E_ARG; h->profile = on != 0; h->serial = on == 2; return ORBX_OK; }
@@ -620,6 +628,7 @@ int orbm_stereo_match(orbx_extractor* L, int lf, orbx_extractor* R, int rf, int 
     if (L != R) rt::stream_wait_event(L->s0, R->ev_done);
     const int cap = L->kp_total_cap;
     StereoParams P; P.mbf = bf; P.mb = bl; P.th_high = 100; P.th_orb = (100 + 50) / 2;   // ORBmatcher::TH_HIGH/TH_LOW, src/ORBmatcher.cc:35-36
+    P.debug_flags = L->debug_stereo_flags;
     if (L->profile) rt::event_record(L->ev_stage[ST_MATCH][0], L->s0);
     dim3 grid((cap + 3) / 4, B, 1), blk(256, 1, 1);
     // row index of the right keypoints (32-row buckets of the first row of each candidate band)

@@ -37,6 +37,7 @@ inline int event_sync(event_t) { return 0; }
 inline float event_elapsed_ms(event_t a, event_t b) { return (float)(b->t - a->t); }
 inline const char* last_error() { return "emu"; }
 inline int check_launch() { return 0; }
+inline size_t lds_limit(int) { return (size_t)1 << 30; }
 #else
 typedef hipStream_t stream_t;
 typedef hipEvent_t event_t;
@@ -71,6 +72,12 @@ inline int event_sync(event_t e) { return ORBX_HIP_OK(hipEventSynchronize(e)); }
 inline float event_elapsed_ms(event_t a, event_t b) { float ms = 0; if (hip_ok(hipEventElapsedTime(&ms, a, b))) ms = 0; return ms; }   // unrecorded events: 0
 inline const char* last_error() { hipError_t e = hipGetLastError(); if (e == hipSuccess) e = last_code(); return hipGetErrorString(e); }
 inline int check_launch() { return ORBX_HIP_OK(hipGetLastError()); }
+// largest LDS allocation (static + dynamic) one workgroup may ask for on this device
+inline size_t lds_limit(int dev) {
+    static thread_local int cached_dev = -1; static thread_local size_t cached = 0;
+    if (dev != cached_dev) { int v = 0; if (hip_ok(hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev))) v = 65536; cached = (size_t)v; cached_dev = dev; }
+    return cached;
+}
 #endif
 
 }}  // namespace orbx::rt

@@ -50,7 +50,7 @@ struct KeyPointRec { float x, y, size, angle, response; int32_t octave, class_id
 struct BlurTaps { int k[7]; };                       // 7-tap Gaussian, 8-bit fixed point
 struct BlurTiles { int begin[kMaxLevels + 1]; };         // first tile (256 cols x 64 rows) of each level in k_blur's grid
 struct UmaxTab { int u[16]; };                        // circular patch half-widths (src/ORBextractor.cc:542-570)
-struct StereoParams { float mbf, mb; int th_high, th_orb; };   // ORBmatcher::TH_HIGH, (TH_HIGH+TH_LOW)/2
+struct StereoParams { float mbf, mb; int th_high, th_orb; int debug_flags; };   // ORBmatcher::TH_HIGH, (TH_HIGH+TH_LOW)/2
 
 // ---- guided searches (k_search.hip) ----
 struct GridParams {                                               // mnMinX, mnMinY, mfGridElementWidthInv/HeightInv (include/Frame.h:250-251)

@@ -23,6 +23,10 @@ class ORBextractor:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
+            self._fetch_buf = None
+            for p in getattr(self, "_pinned", []):          # page-locked buffers handed out by pinned_empty()
+                self._lib.L.orbx_host_free(self._h, p)
+            self._pinned = []
             self._lib.L.orbx_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -125,6 +129,10 @@ class ORBextractor:
         B, cap = self._B, self.max_keypoints()
         buf = getattr(self, "_fetch_buf", None)
         if buf is None or buf[0] != (B, cap):      # page-locked staging, reused across calls (the device layout is [B, cap])
+            if buf is not None:                    # a new batch shape replaces the staging pair: give the old pages back
+                self._fetch_buf = None
+                for a in buf[1:]:
+                    self.pinned_free(a)
             buf = ((B, cap), self.pinned_empty((B, cap), KP_DTYPE), self.pinned_empty((B, cap, 32), np.uint8))
             self._fetch_buf = buf
         kps, desc = buf[1], buf[2]
@@ -168,6 +176,10 @@ class ORBextractor:
             self._lib.check(n)
         return a[:n].copy()
 
+    def debug_stereo_flags(self, flags):
+        """Test switches of the stereo row search (orbx_debug_stereo_flags)."""
+        self._lib.check(self._lib.L.orbx_debug_stereo_flags(self._h, int(flags)))
+
     def graph_replay(self, on=True):
         """Replay the extraction pipeline as one hipGraph (small-batch latency)."""
         self._lib.check(self._lib.L.orbx_set_graph_replay(self._h, int(on)))
@@ -198,6 +210,15 @@ class ORBextractor:
         arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
         self._pinned = getattr(self, "_pinned", []) + [p]
         return arr
+
+    def pinned_free(self, arr):
+        """Release a pinned_empty() array (the caller must not touch `arr` afterwards); close() releases whatever is left."""
+        addr = arr.ctypes.data
+        for p in getattr(self, "_pinned", []):
+            if p.value == addr:
+                self._pinned.remove(p)
+                self._lib.L.orbx_host_free(self._h, p)
+                return
 
     def device_free(self, p):
         self._lib.L.orbx_device_free(self._h, p)

@@ -93,3 +93,23 @@ def pink_noise(w=752, h=480, seed=0, beta=1.6, contrast=60.0):
     img = np.fft.irfft2(spec, s=(h, w))
     img = (img - img.mean()) / (img.std() + 1e-12)
     return np.clip(128.0 + contrast * img, 0, 255).astype(np.uint8)
+
+
+def periodic_stereo_pair(w=752, h=480, seed=0, period=(48, 240), disparity=17, nrect=40):
+    """Adversarial input for the stereo row search: a noise-free texture that repeats every `period[0]` columns (and `period[1]` rows),
+    right view = left view shifted by `disparity`.  Every keypoint of the right image then has exact copies - identical descriptors - on the
+    same row at every multiple of the period, so a left keypoint sees several candidates with the same minimal Hamming distance and the
+    result depends on the tie rule alone (reference src/Frame.cc:1195-1226: the lowest right index wins)."""
+    rng = np.random.default_rng(0x7E5 + seed)
+    px, py = period
+    tile = np.full((py, px), 110.0)
+    for _ in range(nrect):
+        x0, y0 = int(rng.integers(0, px)), int(rng.integers(0, py))
+        rw, rh = int(rng.integers(4, max(px // 2, 6))), int(rng.integers(4, 30))
+        c = float(rng.integers(25, 110)) * (1 if rng.random() < 0.5 else -1)
+        ys = (np.arange(y0, y0 + rh) % py)[:, None]; xs = (np.arange(x0, x0 + rw) % px)[None, :]
+        tile[ys, xs] += c
+    reps = ((h + py - 1) // py + 1, (w + disparity + px - 1) // px + 1)
+    scene = np.tile(tile, reps)
+    cv = lambda a: np.clip(np.rint(a), 0, 255).astype(np.uint8)
+    return cv(scene[:h, :w]), cv(scene[:h, disparity:disparity + w])

@@ -1,0 +1,64 @@
+"""Tie rule of the stereo row search (Frame::ComputeStereoMatches, reference src/Frame.cc:1195-1226).
+
+The reference walks vRowIndices[vL] in ascending right index and replaces its best on a strictly smaller distance: among right keypoints
+with the same minimal Hamming distance the LOWEST index wins.  The device search visits the candidates of a row band in whatever order the
+row buckets were filled (atomics), so it has to reduce full (distance, index) keys.  These tests feed noise-free periodic textures - the
+right image holds exact copies of every descriptor along the row - and require mvuRight / mvDepth bit-equal to the reference's own Frame
+constructor (oracle/_ref/libref_frame.so) for the normal and for the reversed visiting order (orbx_debug_stereo_flags bit 0).  Bit 1
+restores the distance-only compare of round 1: with it the reversed order MUST produce a different result, which shows that the inputs
+really exercise the rule."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from orb_slam3_detailed_comments_amd import ORBextractor, ComputeStereoMatches, synth
+
+pytestmark = pytest.mark.skipif(ol.reference_frame_lib() is None, reason="oracle/_ref/libref_frame.so not built (needs /root/reference)")
+FX = 458.654
+BF = FX * 0.110074
+
+
+def _tied_left_keypoints(F):
+    """left keypoints whose smallest descriptor distance over ALL right keypoints is reached more than once (an upper bound of the ties
+    the row search sees; only used to show the input is adversarial)"""
+    a = np.unpackbits(F.desc, axis=1).astype(np.int16); b = np.unpackbits(F.desc_right, axis=1).astype(np.int16)
+    d = a @ (1 - b).T + (1 - a) @ b.T
+    return int(((d == d.min(1, keepdims=True)).sum(1) > 1).sum())
+
+
+def _run(lib, w, h, nf, seeds, repeats, period):
+    differs_with_round1_rule = 0
+    for seed in seeds:
+        L, R = synth.periodic_stereo_pair(w, h, seed=seed, period=period)
+        F = ol.ReferenceFrame(L, R, nf, 1.2, 8, 20, 7, 0, fx=FX, bf=BF)
+        assert (F.u_right >= 0).sum() > 50 and _tied_left_keypoints(F) > 30, "input is not adversarial"
+        ex = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib)
+        (_, kL, dL), (_, kR, dR) = ex.extract_batch(np.stack([L, R]))
+        assert kL.tobytes() == F.keys.tobytes() and dL.tobytes() == F.desc.tobytes() and kR.tobytes() == F.keys_right.tobytes() and dR.tobytes() == F.desc_right.tobytes()
+        N = F.N
+        for flags in (0, 1):
+            ex.debug_stereo_flags(flags)
+            for rep in range(repeats):
+                u, d, n = ComputeStereoMatches(ex, ex, BF, F.mb, 0, 1, 1)
+                assert u[0, :N].tobytes() == F.u_right.tobytes() and d[0, :N].tobytes() == F.depth.tobytes(), \
+                    "seed %d flags %d repeat %d: mvuRight / mvDepth differ from the reference Frame" % (seed, flags, rep)
+        ex.debug_stereo_flags(3)        # reversed order + the distance-only compare of round 1
+        u, d, n = ComputeStereoMatches(ex, ex, BF, F.mb, 0, 1, 1)
+        differs_with_round1_rule += u[0, :N].tobytes() != F.u_right.tobytes()
+        ex.debug_stereo_flags(0)
+        ex.close()
+    return differs_with_round1_rule
+
+
+def test_stereo_tie_rule_emulated(emu_lib):
+    caught = _run(emu_lib, 752, 480, 1200, seeds=(1,), repeats=1, period=(48, 240))
+    assert caught > 0, "the distance-only tie rule went unnoticed: the test input does not exercise the tie rule"
+
+
+@pytest.mark.gpu
+def test_stereo_tie_rule_gpu(hip_lib):
+    # atomics fill the row buckets in a scheduling-dependent order on hardware: every pair is matched 100 times per visiting order
+    caught = _run(hip_lib, 752, 480, 1200, seeds=(1, 2, 3), repeats=100, period=(48, 240))
+    assert caught > 0, "the distance-only tie rule went unnoticed: the test inputs do not exercise the tie rule"
+    _run(hip_lib, 752, 480, 1200, seeds=(4,), repeats=100, period=(32, 480))
+    _run(hip_lib, 376, 240, 500, seeds=(5, 6), repeats=100, period=(24, 60))

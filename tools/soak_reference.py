@@ -1,5 +1,5 @@
 """Soak: many seeded worlds / image pairs, product (HIP library) vs the reference's own compiled sources (oracle/_ref).  Run on a GPU box:
-    python tools/soak_reference.py [n_seeds]
+    python tools/soak_reference.py [n_world_seeds [n_stereo_pairs]]
 Prints one line per family and exits non-zero on the first difference."""
 import os
 import subprocess
@@ -14,6 +14,7 @@ import oracle_lib as ol                                     # noqa: E402
 from orb_slam3_detailed_comments_amd import _lib, ORBextractor, ComputeStereoMatches, synth   # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+npairs = int(sys.argv[2]) if len(sys.argv) > 2 else n
 # even seeds: stand-in Frame / KeyFrame / MapPoint world; odd seeds: the reference's own classes (Frame.cc, KeyFrame.cc, MapPoint.cc compiled in place)
 WORLDS = [(os.path.join(ROOT, "oracle", "_ref", "libmw_ref.so"), os.path.join(ROOT, "oracle", "_ref", "libmw_facade.so")),
           (os.path.join(ROOT, "oracle", "_ref", "libmw_ref_full.so"), os.path.join(ROOT, "oracle", "_ref", "libmw_facade_full.so"))]
@@ -35,21 +36,24 @@ print("matcher worlds: %d seeds x 4 variants, %d differences" % (n, bad))
 lib = _lib.load_hip()
 FX = 458.654; BF = FX * 0.110074
 bad2 = 0
-for seed in range(2000, 2000 + n):
-    w, h = [(752, 480), (640, 480), (376, 240)][seed % 3]
-    nf = [1200, 1000, 500][seed % 3]
-    kind = seed % 4
+exs = {}
+for seed in range(2000, 2000 + npairs):
+    w, h = [(752, 480), (640, 480), (376, 240), (376, 240)][seed % 4]
+    nf = [1200, 1000, 500, 500][seed % 4]
+    kind = seed % 5
     if kind == 3:
         L = synth.pink_noise(w, h, seed=seed); R = np.roll(L, -7, axis=1)
+    elif kind == 4:                                             # exact descriptor copies along the rows: the tie rule of the row search
+        L, R = synth.periodic_stereo_pair(w, h, seed=seed, period=[(48, 240), (32, 120), (64, 480)][seed % 3], disparity=5 + seed % 40)
     else:
         L, R = synth.stereo_pair(w, h, seed=seed, nrect=[2000, 800, 3000][kind])
     F = ol.ReferenceFrame(L, R, nf, fx=FX, bf=BF)
-    ex = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib)
+    ex = exs.get(nf) or exs.setdefault(nf, ORBextractor(nf, 1.2, 8, 20, 7, lib=lib))
     (_, kL, dL), (_, kR, dR) = ex.extract_batch(np.stack([L, R]))
     u, d, m = ComputeStereoMatches(ex, ex, BF, F.mb, 0, 1, 1)
     ok = (kL.tobytes() == F.keys.tobytes() and dL.tobytes() == F.desc.tobytes() and kR.tobytes() == F.keys_right.tobytes() and dR.tobytes() == F.desc_right.tobytes()
           and u[0, :F.N].tobytes() == F.u_right.tobytes() and d[0, :F.N].tobytes() == F.depth.tobytes())
     if not ok:
         print("DIFF frame seed %d (%dx%d)" % (seed, w, h)); bad2 += 1
-print("stereo frames: %d pairs, %d differences" % (n, bad2))
+print("stereo frames: %d pairs, %d differences" % (npairs, bad2))
 sys.exit(1 if bad or bad2 else 0)
