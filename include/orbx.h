@@ -116,7 +116,8 @@ const char* orbx_stage_name(int i);
 int orbx_debug_candidates(orbx_extractor* h, int image_index, int level, int* xys, int cap);       /* returns count; (x,y,score) rel. to the 16-px border, reference order */
 int orbx_debug_level_keys(orbx_extractor* h, int image_index, int level, int* xys, int cap);       /* quadtree output in list order */
 /* test switches of the stereo row search (orbm_stereo_match): bit 0 visits the candidates of a row band in the opposite order (the result
- * must not change), bit 1 restores the distance-only tie rule of an earlier revision (the tie tests must then fail) */
+ * must not change), bit 2 makes every lane walk all candidates from the last to the first (every tie then meets inside one lane; the
+ * result must not change either), bit 1 restores the distance-only tie rule of an earlier revision (the tie tests must then fail) */
 int orbx_debug_stereo_flags(orbx_extractor* h, int flags);
 int orbx_debug_quadtree_profile(orbx_extractor* h, long long out[16]);   /* phase timestamps of one quadtree workgroup (profiling mode 2) */
 

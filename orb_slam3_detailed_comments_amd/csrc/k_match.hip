@@ -94,6 +94,24 @@ __global__ void __launch_bounds__(256) k_stereo_match(const LevelInfo* __restric
         const int* bs = bucket_start + (size_t)b * (nb + 1);
         const int* items = bucket_items + (size_t)b * cap;
         const int jbeg = bs[imin(imax(rowL - lookback, 0) >> kRowBucketShift, nb - 1)], jend = bs[imin(imax(rowL, 0) >> kRowBucketShift, nb - 1) + 1];
+        // one candidate: exact band / octave / column tests, then the (distance, index) key
+        auto visit = [&](int iR, const int4& a) {
+            if (rowL < a.x || rowL > a.y) return;
+            if (a.w < levelL - 1 || a.w > levelL + 1) return;
+            const float xr = __int_as_float(a.z);
+            if (xr >= minU && xr <= maxU) {
+                const unsigned long long* dr = descR + 4 * ((size_t)b * cap + iR);
+                const int dist = __popcll(d0 ^ dr[0]) + __popcll(d1 ^ dr[1]) + __popcll(d2 ^ dr[2]) + __popcll(d3 ^ dr[3]);
+                const unsigned cand = ((unsigned)dist << 16) | (unsigned)iR;
+                // full-key compare: lowest distance, then lowest iR, whatever the visiting order.  (Test switch bit 1 = the
+                // distance-only compare this kernel had in round 1, kept so that the tie tests can show they would catch it.)
+                if ((P.debug_flags & 2) ? dist < (int)(best >> 16) : cand < best) best = cand;
+            }
+        };
+        if (P.debug_flags & 4) {
+            // test switch: every lane walks ALL candidates, last to first - every tie then meets in one lane, the higher position first
+            for (int j = jend - 1; j >= jbeg; j--) { const int iR = items[j]; visit(iR, ar[iR]); }
+        } else
         for (int base = jbeg; base < jend; base += 128) { // 2 right keypoints per lane per trip, their loads in flight together
             int4 a[2]; int idx[2];
 #pragma unroll
@@ -108,20 +126,7 @@ __global__ void __launch_bounds__(256) k_stereo_match(const LevelInfo* __restric
                 if (idx[u] >= 0) a[u] = ar[idx[u]]; else { a[u].x = 1; a[u].y = 0; a[u].z = 0; a[u].w = 0; }   // empty band
             }
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int iR = idx[u];
-                if (rowL < a[u].x || rowL > a[u].y) continue;
-                if (a[u].w < levelL - 1 || a[u].w > levelL + 1) continue;
-                const float xr = __int_as_float(a[u].z);
-                if (xr >= minU && xr <= maxU) {
-                    const unsigned long long* dr = descR + 4 * ((size_t)b * cap + iR);
-                    const int dist = __popcll(d0 ^ dr[0]) + __popcll(d1 ^ dr[1]) + __popcll(d2 ^ dr[2]) + __popcll(d3 ^ dr[3]);
-                    const unsigned cand = ((unsigned)dist << 16) | (unsigned)iR;
-                    // full-key compare: lowest distance, then lowest iR, whatever the visiting order.  (Test switch bit 1 = the
-                    // distance-only compare this kernel had in round 1, kept so that the tie tests can show they would catch it.)
-                    if ((P.debug_flags & 2) ? dist < (int)(best >> 16) : cand < best) best = cand;
-                }
-            }
+            for (int u = 0; u < 2; u++) visit(idx[u], a[u]);
         }
     }
     best = wave_min_u32(best);   // lowest distance, then lowest right index == sequential first-min

@@ -5,6 +5,9 @@
 #include <mutex>
 #include "orbx_internal.h"
 
+#ifndef ORBX_FAST_LIST_BYTES
+#define ORBX_FAST_LIST_BYTES 2048   // k_fast_cells: 1024 list entries (corners of the cell so far + survivors waiting for their score)
+#endif
 #ifndef ORBX_PRESORT_MAX
 #define ORBX_PRESORT_MAX 5      // deepest quadtree level resolved by the up-front counting sort (tests also build 0 and 2)
 #endif
@@ -129,10 +132,11 @@ int configure(orbx_extractor* h, int W, int H, int B) {
                     const int iw = std::max(c.x1 - c.x0, 0), ih = std::max(c.y1 - c.y0, 0);
                     slot += ((iw + 1) / 2) * ((ih + 1) / 2);         // max number of strict 3x3 local maxima
                     if (iw > 0 && ih > 0) {
-                        if (iw > 128 || iw * ih >= 8192) return fail(ORBX_E_ARG, "FAST cell too large");   // k_fast_cells index packing
-                        const int gx0 = ((c.x0 - 3) & ~3) - 4, gx1 = ((c.x1 + 3 + 3) & ~3) + 4;    // dword-aligned window + margins (k_fast_cells)
-                        tile_b = std::max(tile_b, (gx1 - gx0) * (ih + 6));
-                        inner_b = std::max(inner_b, std::max((iw + 8) * ih, (iw + 2) * (ih + 2)));   // score tile incl. its zero frame; the u16 survivor list holds 4 px per (row, dword) item
+                        const int gx0 = (c.x0 - 3) & ~3, gx1 = (c.x1 + 3 + 3) & ~3;                 // dword-aligned window (k_fast_cells)
+                        const int wp = gx1 - gx0 <= kFastPitch ? kFastPitch : gx1 - gx0;             // LDS pitch of the window tile
+                        if (iw > 240 || iw * ih >= 8192 || wp * (ih + 6) > 16384) return fail(ORBX_E_ARG, "FAST cell too large");   // k_fast_cells: one row per trip, 14-bit tile offsets
+                        tile_b = std::max(tile_b, wp * (ih + 6));
+                        inner_b = std::max(inner_b, wp * (ih + 2));                                  // score tile
                     }
                     h->cells.push_back(c);
                 }
@@ -262,13 +266,12 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
     stage_begin(h, ST_FAST, h->s0);
     {
         dim3 grid((h->ncells + 8 * kFastXcdRun - 1) / (8 * kFastXcdRun) * (8 * kFastXcdRun), B, 1), blkf(kFastThreadsDecl, 1, 1);   // whole XCD runs (k_fast_cells)
-        // tile | score | u16 survivor list for half of the cell's pixels (k_fast_cells flushes it when a denser cell would overflow);
-        // the LDS footprint of a cell sets this kernel's occupancy, which is what bounds it
-        const int list_bytes = std::max(h->fast_inner_bytes, 1024);   // also holds one flag per score-tile byte on the flush path
-        const size_t smem = (size_t)h->fast_tile_bytes + (size_t)h->fast_inner_bytes + (size_t)list_bytes + 64;
+        // pad | window tile | score tile | u16 list: corners found so far + pending survivors of the quick test (scored whenever it fills up)
+        const int list_bytes = ORBX_FAST_LIST_BYTES;
+        const size_t smem = 16 + (size_t)h->fast_tile_bytes + (size_t)h->fast_inner_bytes + (size_t)list_bytes + 64;
         ORBX_LAUNCH(k_fast_cells, grid, blkf, smem, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
                     (const uint8_t*)h->d_pyr.p, h->pyr_stride, h->iniTh, h->minTh, h->d_slots.p, h->cand_stride, h->d_cell_count.p,
-                    h->fast_tile_bytes, h->fast_inner_bytes, list_bytes);
+                    h->fast_tile_bytes, list_bytes);
     }
     stage_end(h, ST_FAST, h->s0);
     stage_begin(h, ST_QUADTREE, h->s0);

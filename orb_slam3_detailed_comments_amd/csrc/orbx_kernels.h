@@ -13,11 +13,12 @@ __global__ void k_resize(const LevelInfo* __restrict__ lv, int level, const Resi
 #define ORBX_FAST_XCD_RUN 4
 #endif
 constexpr int kFastXcdRun = ORBX_FAST_XCD_RUN;   // neighbouring FAST cells kept on one XCD (k_fast_cells)
-constexpr int kFastThreadsDecl = 64;   // must equal kFastThreads in k_image.hip
+constexpr int kFastThreadsDecl = 64;   // must equal kFastThreads in k_fast.hip
+constexpr int kFastPitch = 48;         // LDS pitch of the FAST window tile for cells whose dword-aligned window fits in it (cells up to 39 px wide)
 __global__ void k_fast_cells(const LevelInfo* __restrict__ lv, const CellInfo* __restrict__ cells, int ncells,
                              const uint8_t* __restrict__ pyr, size_t pyr_stride, int iniTh, int minTh,
                              uint32_t* __restrict__ slots, size_t slots_stride, int* __restrict__ cell_count,
-                             int tile_bytes, int inner_bytes, int list_bytes);
+                             int tile_bytes, int list_bytes);
 constexpr int kResizeRows = 8;         // output rows per k_resize tile (256 columns wide)
 constexpr int kBlurRows = 16;          // output rows per k_blur thread (a block covers 256 columns x 4 * kBlurRows rows)
 __global__ void k_blur(const LevelInfo* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,

@@ -1,0 +1,102 @@
+// orbx_simd.h — small CDNA byte / packed-16-bit helpers shared by the image kernels (k_image.hip, k_fast.hip), with plain-C equivalents
+// for the test emulator (tests/emu).
+#pragma once
+#include "orbx_types.h"
+
+namespace orbx {
+
+__device__ __forceinline__ int mul24(int a, int b) {
+#ifdef ORBX_EMU
+    return a * b;
+#else
+    return __mul24(a, b);      // operands < 2^23: full-rate 24-bit multiply instead of the quarter-rate 32-bit one
+#endif
+}
+// the same, but immune to the compiler turning it back into v_mul_lo_u32 (it does where it has proven narrower operand ranges)
+__device__ __forceinline__ int mul24_forced(int a, int b) {
+#ifdef ORBX_EMU
+    return a * b;
+#else
+    int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+#endif
+}
+// ---------------------------------------------------------------------------------------------------
+// Small CDNA byte / packed-16-bit helpers (with plain-C equivalents for the test emulator).
+// byte permute (v_perm_b32): result byte i = byte sel_i (0..7) of the 8-byte pair {hi:lo}; selector 0x0c gives 0x00
+__device__ __forceinline__ uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+#ifdef ORBX_EMU
+    const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t sb = (sel >> (8 * i)) & 0xFF;
+        const uint32_t byte = sb >= 0x0c ? 0u : (uint32_t)((v >> (8 * (sb & 7))) & 0xFF);
+        r |= byte << (8 * i);
+    }
+    return r;
+#else
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#endif
+}
+// v_alignbyte_b32: the 4 bytes starting at byte `shift` (0..3) of the 8-byte pair {hi:lo}
+__device__ __forceinline__ uint32_t align_byte(uint32_t hi, uint32_t lo, uint32_t shift) {
+#ifdef ORBX_EMU
+    return (uint32_t)(((((unsigned long long)hi) << 32) | lo) >> (8 * (shift & 3)));
+#else
+    return __builtin_amdgcn_alignbyte(hi, lo, shift);
+#endif
+}
+// integer dot products: v_dot4_u32_u8 (four u8 x u8 products + c) and v_dot2_u32_u16 (two u16 x u16 products + c), exact (no clamp)
+__device__ __forceinline__ uint32_t dot4_u8(uint32_t a, uint32_t b, uint32_t c) {
+#ifdef ORBX_EMU
+    for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xFFu) * ((b >> (8 * i)) & 0xFFu);
+    return c;
+#else
+    return __builtin_amdgcn_udot4(a, b, c, false);
+#endif
+}
+__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c) {
+#ifdef ORBX_EMU
+    return c + (a & 0xFFFFu) * (b & 0xFFFFu) + (a >> 16) * (b >> 16);
+#else
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
+#endif
+}
+// two signed 16-bit lanes in one VGPR (v_pk_sub_i16 / v_pk_min_i16 / v_pk_max_i16)
+#ifdef ORBX_EMU
+struct pk2 { short x, y; };
+__device__ __forceinline__ pk2 pk_make(uint32_t v) { pk2 r; r.x = (short)(v & 0xFFFF); r.y = (short)(v >> 16); return r; }
+__device__ __forceinline__ pk2 pk_sub(pk2 a, pk2 b) { pk2 r; r.x = (short)(a.x - b.x); r.y = (short)(a.y - b.y); return r; }
+__device__ __forceinline__ pk2 pk_mad(pk2 a, pk2 b, pk2 c) { pk2 r; r.x = (short)(a.x * b.x + c.x); r.y = (short)(a.y * b.y + c.y); return r; }
+__device__ __forceinline__ pk2 pk_min(pk2 a, pk2 b) { pk2 r; r.x = a.x < b.x ? a.x : b.x; r.y = a.y < b.y ? a.y : b.y; return r; }
+__device__ __forceinline__ pk2 pk_max(pk2 a, pk2 b) { pk2 r; r.x = a.x > b.x ? a.x : b.x; r.y = a.y > b.y ? a.y : b.y; return r; }
+__device__ __forceinline__ int pk_lo(pk2 a) { return a.x; }
+__device__ __forceinline__ int pk_hi(pk2 a) { return a.y; }
+__device__ __forceinline__ pk2 pk_min3(pk2 a, pk2 b, pk2 c) { return pk_min(pk_min(a, b), c); }
+__device__ __forceinline__ pk2 pk_max3(pk2 a, pk2 b, pk2 c) { return pk_max(pk_max(a, b), c); }
+__device__ __forceinline__ pk2 pk_bytes(const uint8_t* a, const uint8_t* b) { pk2 r; r.x = (short)*a; r.y = (short)*b; return r; }
+__device__ __forceinline__ pk2 pk_xor_or(pk2 a, uint32_t x, uint32_t o) { return pk_make((((uint32_t)(uint16_t)a.x | ((uint32_t)(uint16_t)a.y << 16)) ^ x) | o); }
+__device__ __forceinline__ pk2 pk_xor(pk2 a, uint32_t x) { return pk_make(((uint32_t)(uint16_t)a.x | ((uint32_t)(uint16_t)a.y << 16)) ^ x); }
+#else
+typedef short pk2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk2 pk_make(uint32_t v) { return __builtin_bit_cast(pk2, v); }
+__device__ __forceinline__ pk2 pk_sub(pk2 a, pk2 b) { return a - b; }
+__device__ __forceinline__ pk2 pk_mad(pk2 a, pk2 b, pk2 c) { return a * b + c; }      // v_pk_mad_i16
+__device__ __forceinline__ pk2 pk_min(pk2 a, pk2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ pk2 pk_max(pk2 a, pk2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ int pk_lo(pk2 a) { return (int)a.x; }
+__device__ __forceinline__ int pk_hi(pk2 a) { return (int)a.y; }
+// Three-input packed min / max.  gfx950 has no 3-input packed INTEGER min/max, but it has v_pk_minimum3_f16 / v_pk_maximum3_f16, and positive
+// normal binary16 numbers are ordered exactly like their bit patterns read as integers.  Every caller keeps its operands in
+// [0x0400, 0x7BFF] (pixel values biased by 0x6400), where the two orders coincide and neither NaN
+// nor denormal handling can interfere.  Same issue rate as the 2-input packed ops (tools/valu_issue_microbench.hip).
+__device__ __forceinline__ pk2 pk_min3(pk2 a, pk2 b, pk2 c) { pk2 d; asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ pk2 pk_max3(pk2 a, pk2 b, pk2 c) { pk2 d; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// two bytes from two LDS addresses as the two halves of one register; (a ^ x) | o is one v_bitop3_b32
+__device__ __forceinline__ pk2 pk_bytes(const uint8_t* a, const uint8_t* b) { return __builtin_bit_cast(pk2, (uint32_t)*a | ((uint32_t)*b << 16)); }   // v_lshl_or_b32 (full rate; v_perm_b32 is not)
+__device__ __forceinline__ pk2 pk_xor_or(pk2 a, uint32_t x, uint32_t o) { return __builtin_bit_cast(pk2, (__builtin_bit_cast(uint32_t, a) ^ x) | o); }
+__device__ __forceinline__ pk2 pk_xor(pk2 a, uint32_t x) { return __builtin_bit_cast(pk2, __builtin_bit_cast(uint32_t, a) ^ x); }
+#endif
+constexpr int kPixBias = 0x6400;     // pixel value b is carried as 0x6400 + b (binary16 1024 + b)
+
+}  // namespace orbx

@@ -19,7 +19,7 @@ CSRC = os.path.join(ROOT, "orb_slam3_detailed_comments_amd", "csrc")
 @pytest.mark.parametrize("presort_max,bigspan", [(1, 80), (0, 1024)])
 def test_quadtree_path_mix(tmp_path, presort_max, bigspan):
     so = str(tmp_path / "liborbx_emu_variant.so")
-    srcs = [os.path.join(CSRC, f) for f in ("k_image.hip", "k_quadtree.hip", "k_describe.hip", "k_match.hip", "k_search.hip", "k_vocab.hip", "k_input.hip", "orbx_api.cpp", "orbm_search.cpp", "orbv_api.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("k_image.hip", "k_fast.hip", "k_quadtree.hip", "k_describe.hip", "k_match.hip", "k_search.hip", "k_vocab.hip", "k_input.hip", "orbx_api.cpp", "orbm_search.cpp", "orbv_api.cpp")]
     subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-DORBX_EMU", "-DORBX_PRESORT_MAX=%d" % presort_max, "-DORBX_BIGSPAN=%d" % bigspan,
                     "-I" + os.path.join(ROOT, "tests", "emu"), "-I" + CSRC, "-fPIC", "-shared", "-w", "-x", "c++"] + srcs + ["-o", so, "-lpthread"], check=True)
     lib = _lib.OrbxLib(so)
@@ -30,12 +30,14 @@ def test_quadtree_path_mix(tmp_path, presort_max, bigspan):
         assert got[0] == exp[0] and ol.kps_equal(got[1], exp[1]) and np.array_equal(got[2], exp[2]), name
 
 
-def test_fast_list_flush_path(tmp_path):
-    """k_fast_cells keeps survivors of the quick test in a list sized for half of a cell's pixels and flushes it when a denser cell
-    would overflow; with a 520-entry list nearly every cell of a textured image takes that path (and its list-free NMS / compaction)."""
+@pytest.mark.parametrize("cap", [200, 600])
+def test_fast_list_flush_path(tmp_path, cap):
+    """k_fast_cells keeps the corners found so far and the survivors of the quick test that wait for their score in one list; when it fills
+    up the pending ones are scored, and a cell whose corners alone fill it (noise) falls back to NMS / compaction scans of the score tile.
+    With 600 entries most cells of a textured image score in several batches, with 200 nearly all of them also give the corner list up."""
     so = str(tmp_path / "liborbx_emu_smalllist.so")
-    srcs = [os.path.join(CSRC, f) for f in ("k_image.hip", "k_quadtree.hip", "k_describe.hip", "k_match.hip", "k_search.hip", "k_vocab.hip", "k_input.hip", "orbx_api.cpp", "orbm_search.cpp", "orbv_api.cpp")]
-    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-DORBX_EMU", "-DORBX_FAST_LIST_CAP=520",
+    srcs = [os.path.join(CSRC, f) for f in ("k_image.hip", "k_fast.hip", "k_quadtree.hip", "k_describe.hip", "k_match.hip", "k_search.hip", "k_vocab.hip", "k_input.hip", "orbx_api.cpp", "orbm_search.cpp", "orbv_api.cpp")]
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-DORBX_EMU", "-DORBX_FAST_LIST_CAP=%d" % cap,
                     "-I" + os.path.join(ROOT, "tests", "emu"), "-I" + CSRC, "-fPIC", "-shared", "-w", "-x", "c++"] + srcs + ["-o", so, "-lpthread"], check=True)
     lib = _lib.OrbxLib(so)
     for name, factory, nf, lap in SMALL_CASES[:3] + FULL_CASES[:1] + FULL_CASES[4:5]:

@@ -4,9 +4,9 @@ The reference walks vRowIndices[vL] in ascending right index and replaces its be
 with the same minimal Hamming distance the LOWEST index wins.  The device search visits the candidates of a row band in whatever order the
 row buckets were filled (atomics), so it has to reduce full (distance, index) keys.  These tests feed noise-free periodic textures - the
 right image holds exact copies of every descriptor along the row - and require mvuRight / mvDepth bit-equal to the reference's own Frame
-constructor (oracle/_ref/libref_frame.so) for the normal and for the reversed visiting order (orbx_debug_stereo_flags bit 0).  Bit 1
-restores the distance-only compare of round 1: with it the reversed order MUST produce a different result, which shows that the inputs
-really exercise the rule."""
+constructor (oracle/_ref/libref_frame.so) for the normal and the reversed visiting order (orbx_debug_stereo_flags bit 0) and for a walk in
+which every lane sees every candidate, last to first (bit 2).  Bit 1 restores the distance-only compare of round 1: with it at least one of
+those orders MUST produce a different result, which shows that the inputs really exercise the rule."""
 import numpy as np
 import pytest
 
@@ -36,14 +36,14 @@ def _run(lib, w, h, nf, seeds, repeats, period):
         (_, kL, dL), (_, kR, dR) = ex.extract_batch(np.stack([L, R]))
         assert kL.tobytes() == F.keys.tobytes() and dL.tobytes() == F.desc.tobytes() and kR.tobytes() == F.keys_right.tobytes() and dR.tobytes() == F.desc_right.tobytes()
         N = F.N
-        for flags in (0, 1):
+        for flags in (0, 1, 4):
             ex.debug_stereo_flags(flags)
             for rep in range(repeats):
                 u, d, n = ComputeStereoMatches(ex, ex, BF, F.mb, 0, 1, 1)
                 assert u[0, :N].tobytes() == F.u_right.tobytes() and d[0, :N].tobytes() == F.depth.tobytes(), \
                     "seed %d flags %d repeat %d: mvuRight / mvDepth differ from the reference Frame" % (seed, flags, rep)
-        for flags in (2, 3):            # the distance-only compare of round 1, in both visiting orders (whichever order the hardware's
-            ex.debug_stereo_flags(flags)    # atomics produce, one of the two shows a lane the higher index first)
+        for flags in (2, 3, 6):         # the distance-only compare of round 1: in both lane-strided visiting orders, and with every lane walking
+            ex.debug_stereo_flags(flags)    # all candidates backwards (every tie then meets in one lane, the later bucket position first)
             u, d, n = ComputeStereoMatches(ex, ex, BF, F.mb, 0, 1, 1)
             differs_with_round1_rule += u[0, :N].tobytes() != F.u_right.tobytes()
         ex.debug_stereo_flags(0)

@@ -1,0 +1,54 @@
+"""Experimental builds of liborbx_hip.so with parts of k_fast_cells cut out (timing attribution on the GPU; results are wrong by construction).
+   python tools/build_fast_variants.py  ->  build/variants/liborbx_hip_<name>.so"""
+import os, shutil, subprocess, sys, tempfile
+from concurrent.futures import ThreadPoolExecutor
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "orb_slam3_detailed_comments_amd", "csrc")
+OUT = os.path.join(ROOT, "build", "variants")
+SRCS = "k_image.hip k_fast.hip k_quadtree.hip k_describe.hip k_match.hip k_search.hip k_vocab.hip k_input.hip orbx_api.cpp orbm_search.cpp orbv_api.cpp".split()
+
+def patch(src, name):
+    if name == "base":
+        return src
+    if name == "load_only":        # return after the tile load
+        return src.replace("    const int t0 = imin(iniTh, minTh);\n", "    const int t0 = imin(iniTh, minTh);\n    if (lane < 64) { if (lane == 0) *count_out = 0; return; }\n", 1)
+    if name == "no_score":         # phase A only: pending entries are dropped instead of scored
+        return src.replace("        for (int i0 = pbeg; i0 < cnt; i0 += 2 * kFastThreads) {", "        for (int i0 = pbeg; i0 < cnt && iniTh < 0; i0 += 2 * kFastThreads) {", 1)
+    if name == "no_cd":            # no NMS / output
+        return src.replace("    if (corners_listed) {\n        // ---- C ----", "    if (iniTh < 0) {\n        // ---- C ----", 1).replace("    } else {\n        // ---- C', D' ----", "    } else if (iniTh < 0) {\n        // ---- C', D' ----", 1)
+    if name == "no_gather":        # phase B without the LDS ring gather: ring values made up from the entry
+        return src.replace("#define ORBX_D(k, dx, dy) d[k] = pk_xor(pk_bytes(qa + ((dy) + 3) * wp + (dx) + 3, qb + ((dy) + 3) * wp + (dx) + 3), X);",
+                           "#define ORBX_D(k, dx, dy) d[k] = pk_xor(pk_make((uint32_t)((eA * (k + 3)) & 0xFF) | ((uint32_t)((eB * (k + 5)) & 0xFF) << 16)), X);", 1)
+    if name == "no_network":       # phase B with the gather but without the min/max network
+        return src.replace("        fast_score_pk(d, vp, t0, sA, sB);\n    };", "        { pk2 acc = d[0]; for (int k = 1; k < 16; k++) acc = pk_xor(acc, __builtin_bit_cast(uint32_t, d[k])); const pk2 df = pk_sub(vp, acc); sA = pk_lo(df) & 31; sB = pk_hi(df) & 31; }\n    };", 1)
+    raise SystemExit("unknown variant " + name)
+
+def build(name, extra=()):
+    d = tempfile.mkdtemp(prefix="orbx_" + name)
+    for f in os.listdir(CSRC):
+        shutil.copy(os.path.join(CSRC, f), d)
+    p = os.path.join(d, "k_fast.hip")
+    s = open(p).read(); t = patch(s, name.split("+")[0])
+    assert name.startswith("base") or t != s, name
+    open(p, "w").write(t)
+    os.makedirs(os.path.join(d, "..", "..", "include"), exist_ok=True)
+    out = os.path.join(OUT, "liborbx_hip_%s.so" % name.replace("+", "_"))
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-w", "-shared", "-x", "hip",
+           "-I" + CSRC, "-include", os.path.join(ROOT, "include", "orbx.h")] + list(extra) + [os.path.join(d, f) for f in SRCS] + ["-o", out]
+    # the sources include "../../include/orbx.h" relative to csrc: compile inside a mirror of the tree
+    mirror = os.path.join(d, "m", "a", "b"); os.makedirs(mirror)
+    for f in os.listdir(d):
+        if os.path.isfile(os.path.join(d, f)): shutil.copy(os.path.join(d, f), mirror)
+    os.makedirs(os.path.join(d, "m", "include")); shutil.copy(os.path.join(ROOT, "include", "orbx.h"), os.path.join(d, "m", "include"))
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-w", "-shared", "-x", "hip"] + list(extra) + [os.path.join(mirror, f) for f in SRCS] + ["-o", out]
+    subprocess.run(cmd, check=True)
+    shutil.rmtree(d)
+    return out
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    jobs = [("base", ()), ("load_only", ()), ("no_score", ()), ("no_cd", ()), ("no_gather", ()), ("no_network", ()),
+            ("base+list1k", ("-DORBX_FAST_LIST_BYTES=1024",)), ("base+list3k", ("-DORBX_FAST_LIST_BYTES=3072",)), ("base+xcd1", ("-DORBX_FAST_XCD_RUN=1",))]
+    if len(sys.argv) > 1: jobs = [j for j in jobs if j[0] in sys.argv[1:]]
+    with ThreadPoolExecutor(4) as ex:
+        for o in ex.map(lambda j: build(*j), jobs): print(o)
