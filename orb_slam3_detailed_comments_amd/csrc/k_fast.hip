@@ -133,8 +133,14 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
         // a bright candidate is scored on the inverted image (byte ^ 0xFF); the bias that makes every operand a positive binary16 pattern
         // does not overlap the pixel bits, so one xor applies both
         const uint32_t X = (uint32_t)kPixBias * 0x00010001u | ((eA & kEntBright) ? 0x000000FFu : 0u) | ((eB & kEntBright) ? 0x00FF0000u : 0u);
-        const uint8_t* qa = tile + (eA & kEntOff) - 3 * wp - 3;      // window pixel (-3, -3) of the candidate: every ring offset is >= 0
-        const uint8_t* qb = tile + (eB & kEntOff) - 3 * wp - 3;
+        // window pixel (-3, -3) of the candidate: every ring offset from it is >= 0 and fits the ds_read offset field (the offsets are made
+        // opaque so that the compiler keeps this one base per candidate instead of re-deriving bases for the rows above the centre)
+        int ofa = (eA & kEntOff) - 3 * wp - 3, ofb = (eB & kEntOff) - 3 * wp - 3;
+#ifndef ORBX_EMU
+        asm volatile("" : "+v"(ofa), "+v"(ofb));
+#endif
+        const uint8_t* qa = tile + ofa;
+        const uint8_t* qb = tile + ofb;
         pk2 d[16];
 #define ORBX_D(k, dx, dy) d[k] = pk_xor(pk_bytes(qa + ((dy) + 3) * wp + (dx) + 3, qb + ((dy) + 3) * wp + (dx) + 3), X);
         ORBX_D(0, 0, 3)     ORBX_D(1, 1, 3)     ORBX_D(2, 2, 2)     ORBX_D(3, 3, 1)

@@ -120,6 +120,81 @@ __global__ void __launch_bounds__(256) k_resize(const LevelInfo* __restrict__ lv
 
 
 // ---------------------------------------------------------------------------------------------------
+// Pyramid, streaming form (the common case: scale factor <= 2).  A thread owns 4 adjacent output columns and walks down kResizeStrip
+// output rows.  Per source row it loads the 8 source bytes its columns need (one unaligned 8-byte load; neighbouring threads overlap in
+// L1), cuts the two taps of every column out with one v_perm_b32 (as a u16 pair) and forms the horizontal sum with one v_dot2_u32_u16
+// against the column's weight pair; consecutive output rows share a source row (5 times out of 6 at scale 1.2), so about 1.2 horizontal
+// rows are computed per output row.  Vertical pass as in cv::resize: ((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2.
+// No LDS, no barriers, ~15 VALU instructions per output pixel (the tile-staged k_resize above needs ~50).
+// block (64, 4): 256 columns x 4 strips; grid (ceil(pitch / 256), ceil(h / (4 * strip_rows)), B).
+__global__ void __launch_bounds__(256) k_resize_rows(const LevelInfo* __restrict__ lv, int level,
+                                                     const ResizeTap* __restrict__ xtab, const ResizeTap* __restrict__ ytab,
+                                                     uint8_t* __restrict__ pyr, size_t pyr_stride, int strip_rows) {
+    const LevelInfo D = lv[level];
+    const LevelInfo S = lv[level - 1];
+    const int b = (int)blockIdx.z;
+    const int dx0 = ((int)blockIdx.x * 64 + (int)threadIdx.x) * 4;
+#ifdef ORBX_EMU
+    const int strip = (int)blockIdx.y * 4 + (int)threadIdx.y;
+#else
+    const int strip = __builtin_amdgcn_readfirstlane((int)blockIdx.y * 4 + (int)threadIdx.y);     // one strip per wave: row bookkeeping stays scalar
+#endif
+    const int ys = strip * strip_rows;
+    if (dx0 >= D.pitch || ys >= D.h) return;
+    const uint8_t* src = pyr + (size_t)b * pyr_stride + S.off;
+    uint8_t* dst = pyr + (size_t)b * pyr_stride + D.off;
+    const ResizeTap* xt = xtab + D.xtab_off;
+    const ResizeTap* yt = ytab + D.ytab_off;
+    // per-column constants: byte selectors into the 8-byte source window that starts at the first column's left tap, and the weight pairs
+    uint32_t sel[4], wgt[4];
+    const int sx0 = xt[imin(dx0, D.w - 1)].ofs;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const ResizeTap tx = xt[imin(dx0 + k, D.w - 1)];
+        const int i0 = tx.ofs - sx0, i1 = imin(tx.ofs + 1, S.w - 1) - sx0;              // 0..7 (checked on the host for every level that uses this kernel)
+        sel[k] = (uint32_t)i0 | 0x0c00u | ((uint32_t)i1 << 16) | 0x0c000000u;           // bytes (tap0, 0, tap1, 0)
+        wgt[k] = dx0 + k < D.w ? (uint32_t)tx.w : 0u;                                   // a0 | a1 << 16; columns in the row padding come out 0
+    }
+    const uint8_t* col = src + sx0;
+    struct Win { uint32_t lo, hi; };
+    auto load_row = [&](int r) { Win w; __builtin_memcpy(&w, col + (uint32_t)mul24(imin(r, S.h - 1), S.pitch), 8); return w; };   // one (unaligned) 8-byte load
+    // The strip's source rows are walked once, in order, with the loads two rows ahead of their use; an output row is emitted when its
+    // second source row arrives (its first one is the previous row, or the same row where cv::resize clamps at the image border).
+    const int ye = imin(ys + strip_rows, D.h);
+    int dy = ys;
+    // the strip's vertical taps: lane i holds those of row ys + i, the row loop reads them back as wave-uniform scalars (no loads in the loop
+    // besides the source rows)
+    const ResizeTap tyl = yt[imin(ys + ((int)threadIdx.x & 63), D.h - 1)];                 // strip_rows <= 64
+    ResizeTap ty; ty.ofs = ORBX_READLANE(tyl.ofs, 0); ty.w = ORBX_READLANE(tyl.w, 0);
+    const int r_first = imin(imax(ty.ofs, 0), S.h - 1), r_last = imin(imax(ORBX_READLANE(tyl.ofs, ye - 1 - ys) + 1, 0), S.h - 1);
+    Win w0 = load_row(r_first), w1 = load_row(r_first + 1);
+    uint32_t Hp[4] = {0u, 0u, 0u, 0u}, Hc[4];
+    for (int r = r_first; r <= r_last; r++) {
+        const Win wn = load_row(r + 2);
+#pragma unroll
+        for (int k = 0; k < 4; k++) Hc[k] = dot2_u16(byte_perm(w0.hi, w0.lo, sel[k]), wgt[k], 0u) >> 4;
+        while (dy < ye && imin(imax(ty.ofs + 1, 0), S.h - 1) == r) {
+            const bool same = imin(imax(ty.ofs, 0), S.h - 1) == r;             // both taps on this row (border clamp)
+            const int b0 = (int)(int16_t)(ty.w & 0xFFFF), b1 = ty.w >> 16;
+            uint32_t out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                // every factor is below 2^23 and every product below 2^31: 24-bit multiplies.  The result cannot exceed 255 (weights sum to
+                // 2048 +- 1), so no clamp
+                const int v = ((mul24_forced(b0, (int)(same ? Hc[k] : Hp[k])) >> 16) + (mul24_forced(b1, (int)Hc[k]) >> 16) + 2) >> 2;
+                out |= (uint32_t)v << (8 * k);
+            }
+            *(uint32_t*)(dst + (uint32_t)(mul24(dy, D.pitch) + dx0)) = out;
+            dy++;
+            if (dy < ye) { ty.ofs = ORBX_READLANE(tyl.ofs, dy - ys); ty.w = ORBX_READLANE(tyl.w, dy - ys); }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) Hp[k] = Hc[k];
+        w0 = w1; w1 = wn;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 7x7 Gaussian blur, taps k[7] (symmetric; sum 256 or 257), REFLECT_101,
 //   out = sat((sum_j k_j * (sum_i k_i * p) + 32768) >> 16).
 // Streaming design: a thread owns 4 adjacent columns (one dword) and walks down a strip of kBlurRows rows with the

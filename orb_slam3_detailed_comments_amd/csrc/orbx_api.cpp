@@ -5,6 +5,9 @@
 #include <mutex>
 #include "orbx_internal.h"
 
+#ifndef ORBX_RESIZE_STRIP
+#define ORBX_RESIZE_STRIP 16        // k_resize_rows: output rows per wave for large batches
+#endif
 #ifndef ORBX_FAST_LIST_BYTES
 #define ORBX_FAST_LIST_BYTES 2048   // k_fast_cells: 1024 list entries (corners of the cell so far + survivors waiting for their score)
 #endif
@@ -155,6 +158,12 @@ int configure(orbx_extractor* h, int W, int H, int B) {
             if (l > 0) {
                 L.xtab_off = (int)h->xtab.size(); resize_axis(h->lv[l - 1].w, L.w, true, h->xtab);
                 L.ytab_off = (int)h->ytab.size(); resize_axis(h->lv[l - 1].h, L.h, false, h->ytab);
+                // k_resize_rows: both taps of output columns x .. x+3 (x a multiple of 4) within 8 bytes of the first one's left tap
+                bool ok = true;
+                const ResizeTap* xt = h->xtab.data() + L.xtab_off;
+                for (int x = 0; x < L.w && ok; x += 4)
+                    for (int k = 0; k < 4; k++) { const int xx = std::min(x + k, L.w - 1); if (std::min(xt[xx].ofs + 1, h->lv[l - 1].w - 1) - xt[x].ofs > 7 || xt[xx].ofs < xt[x].ofs) ok = false; }
+                h->resize_rows_ok[l] = ok;
             }
         }
         h->pyr_stride = off; h->cand_stride = (size_t)cand_off; h->ncells = (int)h->cells.size();
@@ -238,6 +247,16 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
     stage_begin(h, ST_PYRAMID, h->s0);
     for (int l = 1; l < nl; l++) {
         const LevelInfo& L = h->lv[l]; const LevelInfo& S = h->lv[l - 1];
+        if (h->resize_rows_ok[l]) {          // streaming form: the taps of 4 adjacent output columns fit an 8-byte source window
+            // rows per wave: long strips share more source rows (a strip of n rows computes ~1.2 n + 1 horizontal rows), short ones give
+            // small batches enough waves to hide the row loads
+            int strip = ORBX_RESIZE_STRIP;
+            while (strip > 4 && (long)((L.pitch + 255) / 256) * ((L.h + 4 * strip - 1) / (4 * strip)) * B < 2048) strip >>= 1;
+            dim3 gridr((L.pitch + 255) / 256, (L.h + 4 * strip - 1) / (4 * strip), B);
+            ORBX_LAUNCH(k_resize_rows, gridr, blk2, 0, h->s0, (const LevelInfo*)h->d_lv.p, l, (const ResizeTap*)h->d_xtab.p, (const ResizeTap*)h->d_ytab.p,
+                        h->d_pyr.p, h->pyr_stride, strip);
+            continue;
+        }
         dim3 grid((L.pitch + 255) / 256, (L.h + kResizeRows - 1) / kResizeRows, B);
         // LDS window: source span of a 256 x 8 output tile (+ alignment and the +1 neighbour)
         const int lds_pitch = (int)align_up((size_t)ceil(256.0 * S.w / L.w) + 12, 4);

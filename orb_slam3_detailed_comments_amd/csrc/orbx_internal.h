@@ -55,6 +55,7 @@ struct orbx_extractor {
     orbx::LevelInfo lv[orbx::kMaxLevels];
     std::vector<orbx::CellInfo> cells;
     std::vector<orbx::ResizeTap> xtab, ytab;
+    bool resize_rows_ok[orbx::kMaxLevels] = {};     // level l can use k_resize_rows (scale factor <= 2)
     size_t pyr_stride = 0, cand_stride = 0;
     int ncells = 0, kp_total_cap = 0, node_cap = 0, nb_cap = 1, fast_tile_bytes = 0, fast_inner_bytes = 0;
     // ---- device state ----

@@ -9,6 +9,9 @@ __global__ void k_import(const LevelInfo* __restrict__ lv, const uint8_t* __rest
 __global__ void k_resize(const LevelInfo* __restrict__ lv, int level, const ResizeTap* __restrict__ xtab,
                          const ResizeTap* __restrict__ ytab, uint8_t* __restrict__ pyr, size_t pyr_stride,
                          int lds_pitch, int lds_rows);
+// strip_rows (<= 64): output rows per wave; a block covers 256 columns x 4 strips
+__global__ void k_resize_rows(const LevelInfo* __restrict__ lv, int level, const ResizeTap* __restrict__ xtab,
+                              const ResizeTap* __restrict__ ytab, uint8_t* __restrict__ pyr, size_t pyr_stride, int strip_rows);
 #ifndef ORBX_FAST_XCD_RUN
 #define ORBX_FAST_XCD_RUN 4
 #endif

@@ -21,6 +21,24 @@ def patch(src, name):
                            "#define ORBX_D(k, dx, dy) d[k] = pk_xor(pk_make((uint32_t)((eA * (k + 3)) & 0xFF) | ((uint32_t)((eB * (k + 5)) & 0xFF) << 16)), X);", 1)
     if name == "no_network":       # phase B with the gather but without the min/max network
         return src.replace("        fast_score_pk(d, vp, t0, sA, sB);\n    };", "        { pk2 acc = d[0]; for (int k = 1; k < 16; k++) acc = pk_xor(acc, __builtin_bit_cast(uint32_t, d[k])); const pk2 df = pk_sub(vp, acc); sA = pk_lo(df) & 31; sB = pk_hi(df) & 31; }\n    };", 1)
+    NS = ("        for (int i0 = pbeg; i0 < cnt; i0 += 2 * kFastThreads) {", "        for (int i0 = pbeg; i0 < cnt && iniTh < 0; i0 += 2 * kFastThreads) {")
+    if name == "A_nowrite":        # phase A without the list writes (no scoring either)
+        t = src.replace(*NS, 1)
+        t = t.replace("if (pj[j]) list[cnt + lanes_below(bal[j])] = ", "if (pj[j] && iniTh < 0) list[cnt + lanes_below(bal[j])] = ", 1)
+        return t
+    if name == "A_noread":         # phase A without its LDS reads
+        t = src.replace(*NS, 1)
+        a = "const uint32_t C0 = hb[1], L1 = hb[wpd], C1 = hb[wpd + 1], R1 = hb[wpd + 2], L3 = hb[3 * wpd], C3 = hb[3 * wpd + 1], R3 = hb[3 * wpd + 2],"
+        assert a in t
+        t = t.replace(a, "const uint32_t hv = (uint32_t)(size_t)hb * 2654435761u; const uint32_t C0 = hv, L1 = hv >> 1, C1 = hv * 3, R1 = hv ^ 77, L3 = hv + 5, C3 = hv >> 3, R3 = hv * 7,", 1)
+        t = t.replace("L5 = hb[5 * wpd], C5 = hb[5 * wpd + 1], R5 = hb[5 * wpd + 2], C6 = hb[6 * wpd + 1];", "L5 = hv * 11, C5 = hv >> 5, R5 = hv * 13, C6 = hv ^ 0x5555;", 1)
+        return t
+    if name == "A_noappend":       # phase A: compute only, flags folded into one store per lane
+        t = src.replace(*NS, 1)
+        a = "            const uint32_t ANY = SD | SB, BOTH = SD & SB;\n"
+        assert a in t
+        t = t.replace(a, "            const uint32_t ANY = SD | SB, BOTH = SD & SB;\n            if (iniTh >= 0) { ((uint32_t*)list)[lane] ^= ANY + BOTH; continue; }\n", 1)
+        return t
     raise SystemExit("unknown variant " + name)
 
 def build(name, extra=()):
@@ -48,7 +66,9 @@ def build(name, extra=()):
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     jobs = [("base", ()), ("load_only", ()), ("no_score", ()), ("no_cd", ()), ("no_gather", ()), ("no_network", ()),
-            ("base+list1k", ("-DORBX_FAST_LIST_BYTES=1024",)), ("base+list3k", ("-DORBX_FAST_LIST_BYTES=3072",)), ("base+xcd1", ("-DORBX_FAST_XCD_RUN=1",))]
+            ("base+list1k", ("-DORBX_FAST_LIST_BYTES=1024",)), ("base+list3k", ("-DORBX_FAST_LIST_BYTES=3072",)), ("base+xcd1", ("-DORBX_FAST_XCD_RUN=1",)),
+            ("A_nowrite", ()), ("A_noread", ()), ("A_noappend", ()),
+            ("base+strip4", ("-DORBX_RESIZE_STRIP=4",)), ("base+strip8", ("-DORBX_RESIZE_STRIP=8",)), ("base+strip32", ("-DORBX_RESIZE_STRIP=32",))]
     if len(sys.argv) > 1: jobs = [j for j in jobs if j[0] in sys.argv[1:]]
     with ThreadPoolExecutor(4) as ex:
         for o in ex.map(lambda j: build(*j), jobs): print(o)
