@@ -13,8 +13,8 @@
  * oracle/slam_shim (tests/cpp/matcher_world_driver.cpp drives this facade and the reference's own compiled ORBmatcher.cc with identical
  * objects and compares every output) and against the light mocks of tests/cpp/matcher_facade_test.cpp.
  *
- * Not accelerated, reported with an exception instead of a silent CPU path: the two-camera (fisheye rig) branch of
- * SearchForTriangulation (it needs the KB8 camera model's epipolar test).
+ * The fisheye branches of SearchForTriangulation (KannalaBrandt8::epipolarConstrain = the triangulation test) run on the device as well;
+ * the 4x4 null vector of the triangulation is an fp64 eigen-decomposition there instead of Eigen's fp32 JacobiSVD (see kb8_model.h).
  */
 #ifndef ORB_SLAM3_AMD_ORBMATCHER_H
 #define ORB_SLAM3_AMD_ORBMATCHER_H
@@ -309,7 +309,6 @@ public:
     template <class KeyFrameT>
     int SearchForTriangulation(KeyFrameT *pKF1, KeyFrameT* pKF2, std::vector<std::pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo, const bool bCoarse = false)
     {
-        if (pKF1->mpCamera2 || pKF2->mpCamera2) throw std::runtime_error("ORBmatcher (HIP): the fisheye-rig path of SearchForTriangulation is not accelerated");
         auto T1w = pKF1->GetPose();
         auto T2w = pKF2->GetPose();
         auto Tw2 = pKF2->GetPoseInverse();
@@ -319,6 +318,9 @@ public:
         Vec3 Cw = pKF1->GetCameraCenter();
         Vec3 C2 = T2w * Cw;
         Vec2 ep = pKF2->mpCamera->project(C2);
+        if (pKF1->mpCamera->GetType() == 1 /* GeometricCamera::CAM_FISHEYE */)
+            return SearchForTriangulationFisheye(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse, ep(0), ep(1));
+        if (pKF1->mpCamera2 || pKF2->mpCamera2) throw std::runtime_error("ORBmatcher (HIP): SearchForTriangulation on a rig of pinhole cameras is not supported (the reference only builds rigs of Kannala-Brandt cameras)");
         auto T12 = T1w * Tw2;
         Mat3 R12 = T12.rotationMatrix();
         Vec3 t12 = T12.translation();
@@ -342,6 +344,53 @@ public:
         {
             std::lock_guard<std::mutex> lock(Mutex());
             Check(orbm_search_for_triangulation(SharedHandle(), &k1.v, &k2.v, f12, epf, bOnlyStereo, bCoarse, mbCheckOrientation, m12.data(), &nmatches));
+        }
+        vMatchedPairs.clear();
+        vMatchedPairs.reserve(nmatches);
+        for (int i = 0; i < pKF1->N; i++) if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m12[i]));
+        return nmatches;
+    }
+
+    // Kannala-Brandt cameras (one fisheye camera, or the two-camera rig): the epipolar test is KannalaBrandt8::epipolarConstrain =
+    // TriangulateMatches > 1e-4 with the relative pose of the pair of cameras the two features belong to (src/ORBmatcher.cc:1067-1083, :1203-1240)
+    template <class KeyFrameT>
+    int SearchForTriangulationFisheye(KeyFrameT *pKF1, KeyFrameT* pKF2, std::vector<std::pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo, const bool bCoarse, float epx, float epy)
+    {
+        const bool rig = pKF1->mpCamera2 && pKF2->mpCamera2;
+        OrbmKB8Pair kb; memset(&kb, 0, sizeof kb);
+        kb.nleft1 = rig ? pKF1->NLeft : -1; kb.nleft2 = rig ? pKF2->NLeft : -1;
+        for (int i = 0; i < 8; i++) {
+            kb.cam1[0][i] = pKF1->mpCamera->getParameter(i); kb.cam2[0][i] = pKF2->mpCamera->getParameter(i);
+            if (rig) { kb.cam1[1][i] = pKF1->mpCamera2->getParameter(i); kb.cam2[1][i] = pKF2->mpCamera2->getParameter(i); }
+        }
+        auto put = [&](int k, const decltype(pKF1->GetPose())& T) {
+            const auto R = T.rotationMatrix(); const auto t = T.translation();
+            for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) kb.R[k][3 * r + c] = R(r, c); kb.t[k][r] = t(r); }
+        };
+        auto T1w = pKF1->GetPose();
+        auto Tw2 = pKF2->GetPoseInverse();
+        if (!rig) put(0, T1w * Tw2);
+        else {
+            auto Tr1w = pKF1->GetRightPose();
+            auto Twr2 = pKF2->GetRightPoseInverse();
+            put(0, T1w * Tw2); put(1, T1w * Twr2); put(2, Tr1w * Tw2); put(3, Tr1w * Twr2);       // Tll, Tlr, Trl, Trr
+        }
+        BowStore k1, k2;
+        FillBow(*pKF1, pKF1->N, k1); FillBow(*pKF2, pKF2->N, k2);
+        if (pKF1->NLeft != -1) FillAllKeys(*pKF1, pKF1->NLeft, pKF1->N, k1);
+        if (pKF2->NLeft != -1) FillAllKeys(*pKF2, pKF2->NLeft, pKF2->N, k2);
+        if (pKF1->mpCamera2) k1.v.u_right = nullptr;                    // bStereo1 = !mpCamera2 && mvuRight[idx1] >= 0 (:1126)
+        if (pKF2->mpCamera2) k2.v.u_right = nullptr;
+        k1.present.assign(pKF1->N > 0 ? pKF1->N : 1, 0); k2.present.assign(pKF2->N > 0 ? pKF2->N : 1, 0);
+        for (int i = 0; i < pKF1->N; i++) k1.present[i] = pKF1->GetMapPoint(i) != nullptr;
+        for (int i = 0; i < pKF2->N; i++) k2.present[i] = pKF2->GetMapPoint(i) != nullptr;
+        k1.v.has_map_point = k1.present.data(); k2.v.has_map_point = k2.present.data();
+        std::vector<int> m12(pKF1->N > 0 ? pKF1->N : 1, -1);
+        const float epf[2] = {epx, epy};
+        int nmatches = 0;
+        {
+            std::lock_guard<std::mutex> lock(Mutex());
+            Check(orbm_search_for_triangulation_kb8(SharedHandle(), &k1.v, &k2.v, &kb, epf, bOnlyStereo, bCoarse, mbCheckOrientation, m12.data(), &nmatches));
         }
         vMatchedPairs.clear();
         vMatchedPairs.reserve(nmatches);
@@ -743,6 +792,33 @@ void ComputeStereoMatches(FrameT& F, ExtractorT* pLeft, ExtractorT* pRight)
     ORBmatcher::Check(orbm_stereo_fetch(pLeft->Handle(), 1, u.data(), d.data(), cap, &n));
     F.mvuRight.assign(u.begin(), u.begin() + F.N);
     F.mvDepth.assign(d.begin(), d.begin() + F.N);
+}
+
+// Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1530-1587) for a fisheye-rig Frame whose two extractors are the HIP facades: 2-NN + ratio
+// test on the lapping keypoints and the triangulation gate (KannalaBrandt8::TriangulateMatches) on the device-resident results of the LAST
+// call of each extractor (both made with the cameras' lapping areas, as ExtractORB does).  Fills mvLeftToRightMatch, mvRightToLeftMatch,
+// mvDepth, mvuRight, mvStereo3Dpoints and resets mnCloseMPs, like the member function.  Call it where the reference calls the member:
+//   Frame.cc:1511   ComputeStereoFishEyeMatches();   ->   ORB_SLAM3::ComputeStereoFishEyeMatches(*this, mpORBextractorLeft, mpORBextractorRight);
+template <class FrameT, class ExtractorT>
+void ComputeStereoFishEyeMatches(FrameT& F, ExtractorT* pLeft, ExtractorT* pRight)
+{
+    OrbmKB8Stereo cams;
+    for (int i = 0; i < 8; i++) { cams.cam1[i] = F.mpCamera->getParameter(i); cams.cam2[i] = F.mpCamera2->getParameter(i); }
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) cams.R12[3 * r + c] = F.mRlr(r, c); cams.t12[r] = F.mtlr(r); }
+    const int cap = orbx_max_keypoints(pLeft->Handle());
+    std::vector<int> l2r(cap, -1), r2l(cap, -1);
+    std::vector<float> depth(cap, -1.0f), p3d((size_t)cap * 3, 0.0f);
+    int n = 0;
+    ORBmatcher::Check(orbm_stereo_fisheye(pLeft->Handle(), 0, pRight->Handle(), 0, 1, &cams));
+    ORBmatcher::Check(orbm_stereo_fisheye_fetch(pLeft->Handle(), 1, l2r.data(), r2l.data(), depth.data(), p3d.data(), &n, cap));
+    F.mvLeftToRightMatch.assign(l2r.begin(), l2r.begin() + F.Nleft);
+    F.mvRightToLeftMatch.assign(r2l.begin(), r2l.begin() + F.Nright);
+    F.mvDepth.assign(depth.begin(), depth.begin() + F.Nleft);
+    F.mvuRight = std::vector<float>(F.Nleft, -1);
+    typedef typename std::decay<decltype(F.mvStereo3Dpoints[0])>::type Vec3;
+    F.mvStereo3Dpoints = std::vector<Vec3>(F.Nleft);
+    for (int i = 0; i < F.Nleft; i++) if (l2r[i] >= 0) F.mvStereo3Dpoints[i] = Vec3(p3d[3 * (size_t)i], p3d[3 * (size_t)i + 1], p3d[3 * (size_t)i + 2]);
+    F.mnCloseMPs = 0;
 }
 
 } // namespace ORB_SLAM

@@ -141,6 +141,19 @@ int orbm_knn2(orbx_extractor* left, int left_first, orbx_extractor* right, int r
 int orbm_knn2_fetch(orbx_extractor* left, int B, int* idx0, int* dist0, int* idx1, int* dist1,
                     uint8_t* ratio_ok, int cap);
 
+/* Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1530-1587) for B fisheye pairs whose two images were extracted with the cameras' lapping
+ * areas: brute-force 2-NN + ratio test on the lapping keypoints, then KannalaBrandt8::TriangulateMatches (parallax, DLT triangulation,
+ * positive depth in both cameras, reprojection chi-square; src/CameraModels/KannalaBrandt8.cpp:439-523) on every survivor; accepted when
+ * the depth is > 1e-4.  Asynchronous; orbm_stereo_fisheye_fetch returns, per pair, mvLeftToRightMatch [cap], mvRightToLeftMatch [cap],
+ * mvDepth [cap] (-1 = none), mvStereo3Dpoints [cap][3] and the number of matches.  The null vector of the triangulation matrix is computed
+ * in fp64 instead of Eigen's fp32 JacobiSVD: depths agree with the reference to ~1e-6 relative, not bit for bit. */
+typedef struct OrbmKB8Stereo {
+    float cam1[8], cam2[8];               /* KannalaBrandt8::mvParameters (fx, fy, cx, cy, k0..k3) of mpCamera and mpCamera2 */
+    float R12[9], t12[3];                 /* Frame::mRlr (row-major), mtlr */
+} OrbmKB8Stereo;
+int orbm_stereo_fisheye(orbx_extractor* left, int left_first, orbx_extractor* right, int right_first, int B, const OrbmKB8Stereo* cams);
+int orbm_stereo_fisheye_fetch(orbx_extractor* left, int B, int* l2r, int* r2l, float* depth, float* p3d, int* n_matches, int cap);
+
 /* ---------------------------------------------------------------------------------------------------------- */
 /* Guided searches.  The reference methods take Frame / KeyFrame / MapPoint objects (pointer graphs with mutexes);
  * across the C ABI they are passed as read-only structure-of-arrays VIEWS of exactly the fields the method reads.
@@ -229,6 +242,19 @@ int orbm_search_for_triangulation(orbx_extractor* h, const OrbmKeyFrameView* K1,
 int orbm_search_for_triangulation_batch(orbx_extractor* h, const OrbmKeyFrameView* K1, int n2, const OrbmKeyFrameView* const* K2s,
                                         const float* F12s, const float* eps, int only_stereo, int coarse, int check_orientation,
                                         int* matches12, int* nmatches);
+
+/* The same for key frames with Kannala-Brandt cameras - one fisheye camera, or a fisheye rig (mpCamera2 != NULL, features [0, NLeft) from
+ * camera 1 and [NLeft, N) from camera 2): the epipolar test is KannalaBrandt8::epipolarConstrain = TriangulateMatches > 1e-4
+ * (src/CameraModels/KannalaBrandt8.cpp:322-328), with the relative pose chosen per pair of cameras (src/ORBmatcher.cc:1203-1240).
+ * K1 / K2->keys_un hold mvKeys followed by mvKeysRight for a rig (mvKeysUn for one camera), u_right = NULL for a rig. */
+typedef struct OrbmKB8Pair {
+    int nleft1, nleft2;                   /* KeyFrame::NLeft of KF1 / KF2, -1 = one camera */
+    float cam1[2][8], cam2[2][8];         /* mvParameters of mpCamera, mpCamera2 of KF1 and of KF2 (the second is ignored for one camera) */
+    float R[4][9], t[4][3];               /* [bRight1 * 2 + bRight2]: rotation (row-major) / translation of Tll, Tlr, Trl, Trr (:1067-1083);
+                                             one camera: entry 0 = T12 = T1w * Tw2 */
+} OrbmKB8Pair;
+int orbm_search_for_triangulation_kb8(orbx_extractor* h, const OrbmKeyFrameView* K1, const OrbmKeyFrameView* K2, const OrbmKB8Pair* cams,
+                                      const float ep[2], int only_stereo, int coarse, int check_orientation, int* matches12, int* nmatches);
 
 /* Batched Frame::GetFeaturesInArea + Hamming distance: the building block the remaining projection-type searches of the
  * reference (SearchByProjection(KeyFrame*, Sim3, ...) src/ORBmatcher.cc:495-732, SearchByProjection(Frame&, KeyFrame*, ...) :2196-2324,

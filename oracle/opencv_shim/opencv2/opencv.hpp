@@ -51,6 +51,7 @@ template <typename T> struct Point_ {
 typedef Point_<int> Point2i;
 typedef Point2i Point;
 typedef Point_<float> Point2f;
+struct Point3f { float x, y, z; Point3f() : x(0), y(0), z(0) {} Point3f(float a, float b, float c) : x(a), y(b), z(c) {} };
 static inline Point2f& operator*=(Point2f& p, float s) { p.x = p.x * s; p.y = p.y * s; return p; }
 
 struct Size { int width, height; Size() : width(0), height(0) {} Size(int w, int h) : width(w), height(h) {} };

@@ -57,19 +57,29 @@ void ref_frame_destroy(void* h) { delete (Holder*)h; }
 // The fisheye-rig constructor (src/Frame.cc:1432-1528): two extractions with the cameras' lapping areas, ComputeStereoFishEyeMatches
 // (:1530-1587: BFMatcher 2-NN on the lapping parts + the 0.7 ratio test; the triangulation gate accepts everything, see frame_world.h),
 // vconcat of the descriptors, AssignFeaturesToGrid.  out = {Nleft, Nright, monoLeft, monoRight}.
+// cams == NULL: a camera whose triangulation gate accepts every pair, so that what the reference's loop leaves in mvLeftToRightMatch /
+// mvRightToLeftMatch is exactly its kNN + ratio decision; else cams = {cam1[8], cam2[8], Rlr[9] row-major, tlr[3]} and the gate is
+// KannalaBrandt8::TriangulateMatches (restated, oracle/slam_shim/kb8_camera.h).
+struct KB8AcceptAll : KannalaBrandt8 {
+    float TriangulateMatches(GeometricCamera*, const cv::KeyPoint&, const cv::KeyPoint&, const Eigen::Matrix3f&, const Eigen::Vector3f&, const float, const float, Eigen::Vector3f& p3D) override {
+        p3D = Eigen::Vector3f(0, 0, 1); return 1.0f;
+    }
+};
 void* ref_frame_fisheye(const uint8_t* L, const uint8_t* R, int w, int h, int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, int gauss_variant,
-                        int lap_l0, int lap_l1, int lap_r0, int lap_r1, int* out) {
+                        int lap_l0, int lap_l1, int lap_r0, int lap_r1, const float* cams, int* out) {
     cv::shim_gauss_variant() = gauss_variant;
     Holder* H = new Holder();
     H->left = new ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th);
     H->right = new ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th);
-    H->kb1 = new KannalaBrandt8(); H->kb2 = new KannalaBrandt8();
+    if (cams) { H->kb1 = new KannalaBrandt8(cams); H->kb2 = new KannalaBrandt8(cams + 8); }
+    else { H->kb1 = new KB8AcceptAll(); H->kb2 = new KB8AcceptAll(); }
     H->kb1->mvLappingArea[0] = lap_l0; H->kb1->mvLappingArea[1] = lap_l1; H->kb2->mvLappingArea[0] = lap_r0; H->kb2->mvLappingArea[1] = lap_r1;
     cv::Mat imL(h, w, CV_8UC1, (void*)L, (size_t)w), imR(h, w, CV_8UC1, (void*)R, (size_t)w);
     cv::Mat K(3, 3, CV_32F); for (int i = 0; i < 9; i++) K.at<float>(i / 3, i % 3) = (i % 4 == 0) ? 1.0f : 0.0f;
     K.at<float>(0, 0) = 190.9f; K.at<float>(1, 1) = 190.9f; K.at<float>(0, 2) = 254.9f; K.at<float>(1, 2) = 256.9f;
     cv::Mat dist(4, 1, CV_32F); for (int i = 0; i < 4; i++) dist.at<float>(i) = 0.0f;
     Sophus::SE3f Tlr;
+    if (cams) { for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Tlr.R(i, j) = cams[16 + 3 * i + j]; Tlr.t[i] = cams[25 + i]; } }
     Frame::mbInitialComputations = true;
     H->frame = new Frame(imL, imR, 0.0, H->left, H->right, nullptr, K, dist, 19.3f, 40.0f, H->kb1, H->kb2, Tlr);
     out[0] = H->frame->Nleft; out[1] = H->frame->Nright; out[2] = H->frame->monoLeft; out[3] = H->frame->monoRight;
@@ -82,6 +92,11 @@ void ref_frame_fisheye_get(void* h, void* keys, void* keys_right, uint8_t* desc,
     for (int i = 0; i < F->N; i++) memcpy(desc + 32 * (size_t)i, F->mDescriptors.ptr(i), 32);
     for (int i = 0; i < F->Nleft; i++) l2r[i] = F->mvLeftToRightMatch[i];
     for (int i = 0; i < F->Nright; i++) r2l[i] = F->mvRightToLeftMatch[i];
+}
+// mvDepth [Nleft], mvStereo3Dpoints [Nleft][3]
+void ref_frame_fisheye_get3d(void* h, float* depth, float* p3d) {
+    Frame* F = ((Holder*)h)->frame;
+    for (int i = 0; i < F->Nleft; i++) { depth[i] = F->mvDepth[i]; for (int k = 0; k < 3; k++) p3d[3 * i + k] = F->mvStereo3Dpoints[i][k]; }
 }
 
 // bench.py's cpu_baseline: the reference's steady state - two long-lived extractors (Tracking owns them), one Frame temporary per stereo

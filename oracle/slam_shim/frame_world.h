@@ -53,16 +53,6 @@ public:
     cv::Mat toK() { cv::Mat K(3, 3, CV_32F); for (int i = 0; i < 9; i++) K.at<float>(i / 3, i % 3) = 0; K.at<float>(0, 0) = mvParameters[0]; K.at<float>(1, 1) = mvParameters[1];
                     K.at<float>(0, 2) = mvParameters[2]; K.at<float>(1, 2) = mvParameters[3]; K.at<float>(2, 2) = 1; return K; }
 };
-class KannalaBrandt8 : public GeometricCamera {
-public:
-    std::vector<int> mvLappingArea{0, 0};
-    KannalaBrandt8() : GeometricCamera(1, 1, 0, 0) {}
-    // The triangulation gate of ComputeStereoFishEyeMatches (src/Frame.cc:1568-1573) is host-side geometry outside the accelerated path
-    // (DESIGN.md, row M2): the stand-in accepts every pair, so that what the reference's own loop leaves in mvLeftToRightMatch /
-    // mvRightToLeftMatch is exactly its kNN + ratio decision.
-    float TriangulateMatches(GeometricCamera*, const cv::KeyPoint&, const cv::KeyPoint&, const Eigen::Matrix3f&, const Eigen::Vector3f&, const float, const float, Eigen::Vector3f& p3D) {
-        p3D = Eigen::Vector3f(0, 0, 1); return 1.0f;
-    }
-};
+// KannalaBrandt8: the restated camera of kb8_camera.h (slam_types.h), triangulation gate included
 }  // namespace ORB_SLAM3
 #endif

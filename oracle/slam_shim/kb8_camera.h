@@ -1,0 +1,139 @@
+// kb8_camera.h — TEST INFRASTRUCTURE (part of oracle/; never shipped).  The reference's Kannala-Brandt camera restated for the stand-in worlds
+// (slam_world.h, frame_world.h): src/CameraModels/KannalaBrandt8.cpp project (:87-104), unproject / unprojectEig (:142-146, :180-216),
+// epipolarConstrain (:322-328), TriangulateMatches (:439-523), Triangulate (:553-573), statement by statement over the stand-in Eigen types.
+// KannalaBrandt8.cpp itself cannot be compiled here: it needs Eigen (Matrix<float,3,4>, comma initialisers, JacobiSVD), Sophus and
+// cv::fisheye, none of which exist in this image.  PARITY UNPINNED for this file: in particular Eigen::JacobiSVD<Matrix4f> is replaced by a
+// one-sided (Hestenes) Jacobi SVD in fp32 - a different algorithm from the product's (fp64 eigenvectors of A^T A,
+// orb_slam3_detailed_comments_amd/csrc/kb8_model.h), so that the comparison of the two is a real cross-check (tolerance 1e-4 relative depth).
+#ifndef ORBX_KB8_CAMERA_H
+#define ORBX_KB8_CAMERA_H
+#include <cmath>
+
+namespace ORB_SLAM3 {
+
+// last column of V of a 4x4 SVD (singular values in descending order): the right singular vector of the smallest singular value
+inline void StandInJacobiSVD_V3(const float A[4][4], float x[4]) {
+    float U[4][4], V[4][4];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { U[i][j] = A[i][j]; V[i][j] = i == j ? 1.f : 0.f; }
+    for (int sweep = 0; sweep < 40; sweep++) {
+        bool rotated = false;
+        for (int p = 0; p < 3; p++)
+            for (int q = p + 1; q < 4; q++) {
+                float alpha = 0, beta = 0, gamma = 0;
+                for (int k = 0; k < 4; k++) { alpha += U[k][p] * U[k][p]; beta += U[k][q] * U[k][q]; gamma += U[k][p] * U[k][q]; }
+                if (std::fabs(gamma) <= 1e-9f * std::sqrt(alpha * beta) || gamma == 0.f) continue;
+                rotated = true;
+                const float zeta = (beta - alpha) / (2.f * gamma);
+                const float t = (zeta >= 0 ? 1.f : -1.f) / (std::fabs(zeta) + std::sqrt(1.f + zeta * zeta));
+                const float c = 1.f / std::sqrt(1.f + t * t), s = c * t;
+                for (int k = 0; k < 4; k++) { const float a = U[k][p], b = U[k][q]; U[k][p] = c * a - s * b; U[k][q] = s * a + c * b; }
+                for (int k = 0; k < 4; k++) { const float a = V[k][p], b = V[k][q]; V[k][p] = c * a - s * b; V[k][q] = s * a + c * b; }
+            }
+        if (!rotated) break;
+    }
+    int m = 0; float best = -1;
+    for (int j = 0; j < 4; j++) { float n = 0; for (int k = 0; k < 4; k++) n += U[k][j] * U[k][j]; if (best < 0 || n < best) { best = n; m = j; } }
+    for (int k = 0; k < 4; k++) x[k] = V[k][m];
+}
+
+class KannalaBrandt8 : public GeometricCamera {
+public:
+    float k[4];                                  // mvParameters[4..7]
+    const float precision = 1e-6f;               // include/CameraModels/KannalaBrandt8.h:45
+    std::vector<int> mvLappingArea{0, 0};
+    KannalaBrandt8() : GeometricCamera(1, 1, 0, 0), k{0, 0, 0, 0} {}
+    KannalaBrandt8(const float p[8]) : GeometricCamera(p[0], p[1], p[2], p[3]), k{p[4], p[5], p[6], p[7]} {}
+    unsigned int GetType() override { return CAM_FISHEYE; }
+    float getParameter(const int i) override { return i < 4 ? mvParameters[i] : k[i - 4]; }
+
+    Eigen::Vector2f project(const Eigen::Vector3f& v3D) override {                                    // :87-104
+        const float x2_plus_y2 = v3D[0] * v3D[0] + v3D[1] * v3D[1];
+        const float theta = atan2f(sqrtf(x2_plus_y2), v3D[2]);
+        const float psi = atan2f(v3D[1], v3D[0]);
+        const float theta2 = theta * theta;
+        const float theta3 = theta * theta2;
+        const float theta5 = theta3 * theta2;
+        const float theta7 = theta5 * theta2;
+        const float theta9 = theta7 * theta2;
+        const float r = theta + k[0] * theta3 + k[1] * theta5 + k[2] * theta7 + k[3] * theta9;
+        Eigen::Vector2f res;
+        res[0] = mvParameters[0] * r * cos((double)psi) + mvParameters[2];
+        res[1] = mvParameters[1] * r * sin((double)psi) + mvParameters[3];
+        return res;
+    }
+    cv::Point3f unproject(const cv::Point2f& p2D) {                                                   // :180-216
+        cv::Point2f pw((p2D.x - mvParameters[2]) / mvParameters[0], (p2D.y - mvParameters[3]) / mvParameters[1]);
+        float scale = 1.f;
+        float theta_d = sqrtf(pw.x * pw.x + pw.y * pw.y);
+        theta_d = fminf(fmaxf(-CV_PI / 2.f, theta_d), CV_PI / 2.f);
+        if (theta_d > 1e-8) {
+            float theta = theta_d;
+            for (int j = 0; j < 10; j++) {
+                float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+                float k0_theta2 = k[0] * theta2, k1_theta4 = k[1] * theta4;
+                float k2_theta6 = k[2] * theta6, k3_theta8 = k[3] * theta8;
+                float theta_fix = (theta * (1 + k0_theta2 + k1_theta4 + k2_theta6 + k3_theta8) - theta_d) /
+                                  (1 + 3 * k0_theta2 + 5 * k1_theta4 + 7 * k2_theta6 + 9 * k3_theta8);
+                theta = theta - theta_fix;
+                if (fabsf(theta_fix) < precision) break;
+            }
+            scale = std::tan(theta) / theta_d;
+        }
+        return cv::Point3f(pw.x * scale, pw.y * scale, 1.f);
+    }
+    Eigen::Vector3f unprojectEig(const cv::Point2f& p2D) override { cv::Point3f ray = this->unproject(p2D); return Eigen::Vector3f(ray.x, ray.y, ray.z); }   // :142-146
+
+    bool epipolarConstrain(GeometricCamera* pCamera2, const cv::KeyPoint& kp1, const cv::KeyPoint& kp2, const Eigen::Matrix3f& R12, const Eigen::Vector3f& t12,
+                           const float sigmaLevel, const float unc) override {                       // :322-328
+        Eigen::Vector3f p3D;
+        return this->TriangulateMatches(pCamera2, kp1, kp2, R12, t12, sigmaLevel, unc, p3D) > 0.0001f;
+    }
+    virtual float TriangulateMatches(GeometricCamera* pCamera2, const cv::KeyPoint& kp1, const cv::KeyPoint& kp2, const Eigen::Matrix3f& R12, const Eigen::Vector3f& t12,
+                             const float sigmaLevel, const float unc, Eigen::Vector3f& p3D) {        // :439-523
+        Eigen::Vector3f r1 = this->unprojectEig(kp1.pt);
+        Eigen::Vector3f r2 = pCamera2->unprojectEig(kp2.pt);
+        Eigen::Vector3f r21 = R12 * r2;
+        const float cosParallaxRays = r1.dot(r21) / (r1.norm() * r21.norm());
+        if (cosParallaxRays > 0.9998) return -1;
+        cv::Point2f p11, p22;
+        p11.x = r1[0]; p11.y = r1[1];
+        p22.x = r2[0]; p22.y = r2[1];
+        Eigen::Vector3f x3D;
+        float Tcw1[3][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}};                                // << Matrix3f::Identity(), Vector3f::Zero()
+        float Tcw2[3][4];
+        Eigen::Matrix3f R21 = R12.transpose();
+        const Eigen::Vector3f mt = -(R21 * t12);                                                      // << R21, -R21 * t12
+        for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Tcw2[i][j] = R21(i, j); Tcw2[i][3] = mt[i]; }
+        Triangulate(p11, p22, Tcw1, Tcw2, x3D);
+        float z1 = x3D(2);
+        if (z1 <= 0) return -2;
+        float z2 = R21.row(2).dot(x3D) + Tcw2[2][3];
+        if (z2 <= 0) return -3;
+        Eigen::Vector2f uv1 = this->project(x3D);
+        float errX1 = uv1(0) - kp1.pt.x;
+        float errY1 = uv1(1) - kp1.pt.y;
+        if ((errX1 * errX1 + errY1 * errY1) > 5.991 * sigmaLevel) return -4;
+        Eigen::Vector3f x3D2 = R21 * x3D + Eigen::Vector3f(Tcw2[0][3], Tcw2[1][3], Tcw2[2][3]);
+        Eigen::Vector2f uv2 = pCamera2->project(x3D2);
+        float errX2 = uv2(0) - kp2.pt.x;
+        float errY2 = uv2(1) - kp2.pt.y;
+        if ((errX2 * errX2 + errY2 * errY2) > 5.991 * unc) return -5;
+        p3D = x3D;
+        return z1;
+    }
+    void Triangulate(const cv::Point2f& p1, const cv::Point2f& p2, const float Tcw1[3][4], const float Tcw2[3][4], Eigen::Vector3f& x3D) {   // :553-573
+        float A[4][4];
+        for (int j = 0; j < 4; j++) {
+            A[0][j] = p1.x * Tcw1[2][j] - Tcw1[0][j];
+            A[1][j] = p1.y * Tcw1[2][j] - Tcw1[1][j];
+            A[2][j] = p2.x * Tcw2[2][j] - Tcw2[0][j];
+            A[3][j] = p2.y * Tcw2[2][j] - Tcw2[1][j];
+        }
+        float x3Dh[4];
+        StandInJacobiSVD_V3(A, x3Dh);
+        x3D = Eigen::Vector3f(x3Dh[0], x3Dh[1], x3Dh[2]) / x3Dh[3];
+    }
+};
+
+}  // namespace ORB_SLAM3
+#endif

@@ -133,9 +133,15 @@ class Map;
 class GeometricCamera {
 public:
     float mvParameters[4];
+    const static unsigned int CAM_PINHOLE = 0, CAM_FISHEYE = 1;                                      // include/CameraModels/GeometricCamera.h:93-94
     GeometricCamera(float fx, float fy, float cx, float cy) : mvParameters{fx, fy, cx, cy} {}
     virtual ~GeometricCamera() {}
     unsigned int GetId() { return 0; }
+    virtual unsigned int GetType() { return CAM_PINHOLE; }
+    virtual float getParameter(const int i) { return mvParameters[i]; }
+    virtual Eigen::Vector3f unprojectEig(const cv::Point2f& p2D) {                                  // Pinhole.cpp:85-89
+        return Eigen::Vector3f((p2D.x - mvParameters[2]) / mvParameters[0], (p2D.y - mvParameters[3]) / mvParameters[1], 1.f);
+    }
     virtual Eigen::Vector2f project(const Eigen::Vector3f& v3D) {                                    // Pinhole.cpp:61-68
         Eigen::Vector2f res;
         res[0] = mvParameters[0] * v3D[0] / v3D[2] + mvParameters[2];
@@ -164,6 +170,10 @@ public:
         return dsqr < 3.84 * unc;
     }
 };
+
+}  // namespace ORB_SLAM3
+#include "kb8_camera.h"
+namespace ORB_SLAM3 {
 
 #ifndef ORBX_REAL_MAPPOINT
 class MapPoint {

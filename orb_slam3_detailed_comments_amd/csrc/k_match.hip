@@ -8,6 +8,7 @@
 // Descriptors are read as 4 x u64 (the reference reads 8 x int32; the popcount sum is identical).
 #include "orbx_types.h"
 #include "orbx_block.h"
+#include "kb8_model.h"
 
 namespace orbx {
 
@@ -264,6 +265,41 @@ __global__ void __launch_bounds__(256) k_knn2(const unsigned long long* __restri
         idx0[o] = i0; idx1[o] = i1; dist0[o] = dd0; dist1[o] = dd1;
         ratio_ok[o] = (i1 >= 0 && (double)(float)dd0 < (double)(float)dd1 * 0.7) ? 1 : 0;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The rest of Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1556-1586) after k_knn2: every query (left lapping keypoint) whose best
+// match passed the ratio test is triangulated with KannalaBrandt8::TriangulateMatches; depth > 1e-4 accepts.  One thread per query.
+// l2r / depth / p3d are indexed by left keypoint, r2l by right keypoint (the loop runs over ascending left index, so the last writer of
+// mvRightToLeftMatch[j] is the largest left index: atomicMax).  grid (ceil(cap/256), B).  r2l must be pre-filled with -1.
+__global__ void __launch_bounds__(256) k_kb8_stereo(const KeyPointRec* __restrict__ kpsL, const int* __restrict__ monoL, const int* __restrict__ nL,
+                                                    const KeyPointRec* __restrict__ kpsR, const int* __restrict__ monoR, int cap,
+                                                    const int* __restrict__ idx0, const uint8_t* __restrict__ ratio_ok, KB8StereoParams P,
+                                                    int* __restrict__ l2r, int* __restrict__ r2l, float* __restrict__ depth, float* __restrict__ p3d,
+                                                    int* __restrict__ nmatches) {
+    const int b = (int)blockIdx.y, i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= cap) return;
+    const size_t o = (size_t)b * cap + i;
+    int match = -1; float d = -1.0f, X[3] = {0.f, 0.f, 0.f};
+    const int q = i - monoL[b];                                  // query row of the kNN (lapping keypoints start at monoLeft)
+    if (i < nL[b] && q >= 0 && ratio_ok[(size_t)b * cap + q]) {
+        const int j = idx0[(size_t)b * cap + q] + monoR[b];
+        const KeyPointRec kl = kpsL[o], kr = kpsR[(size_t)b * cap + j];
+        KB8Cam c1, c2;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { c1.p[k] = P.cam1[k]; c2.p[k] = P.cam2[k]; }
+        float r1[3], r2[3], p[3];
+        kb8_unproject(c1, kl.x, kl.y, r1);
+        kb8_unproject(c2, kr.x, kr.y, r2);
+        const float z = kb8_triangulate_matches(c1, c2, r1, r2, kl.x, kl.y, kr.x, kr.y, P.R12, P.t12, P.sigma2[kl.octave], P.sigma2[kr.octave], p);
+        if (z > 0.0001f) {
+            match = j; d = z; X[0] = p[0]; X[1] = p[1]; X[2] = p[2];
+            atomicMax(&r2l[(size_t)b * cap + j], i);
+            atomicAdd(&nmatches[b], 1);
+        }
+    }
+    l2r[o] = match; depth[o] = d;
+    p3d[3 * o] = X[0]; p3d[3 * o + 1] = X[1]; p3d[3 * o + 2] = X[2];
 }
 
 // ---------------------------------------------------------------------------------------------------

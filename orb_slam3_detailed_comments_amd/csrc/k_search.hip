@@ -13,6 +13,7 @@
 //                  unmatched feature of KF1 against the features of KF2 in the same vocabulary node.
 #include "orbx_types.h"
 #include "orbx_block.h"
+#include "kb8_model.h"
 
 namespace orbx {
 
@@ -172,7 +173,8 @@ __global__ void __launch_bounds__(256) k_area_search(const AreaQuery* __restrict
 
 // One wave per work item (an unmatched feature idx1 of KF1 and the feature list of a neighbour KF2 in the same node; the arrays of
 // all neighbours of a batch are concatenated, item.out_off = neighbour).  best2[item] = chosen (global) idx2 or -1.   src/ORBmatcher.cc:1117-1254
-__global__ void __launch_bounds__(256) k_bow_search(const BowItem* __restrict__ items, int nitems,
+template <bool KB8>
+__device__ __forceinline__ void bow_search_body(const BowItem* __restrict__ items, int nitems,
                                                     const KeyPointRec* __restrict__ kps1, const unsigned long long* __restrict__ desc1,
                                                     const float* __restrict__ ur1,
                                                     const KeyPointRec* __restrict__ kps2, const unsigned long long* __restrict__ desc2,
@@ -192,6 +194,15 @@ __global__ void __launch_bounds__(256) k_bow_search(const BowItem* __restrict__ 
     const float lb = __fadd_rn(__fadd_rn(__fmul_rn(k1.x, P.F12[1]), __fmul_rn(k1.y, P.F12[4])), P.F12[7]);
     const float lc = __fadd_rn(__fadd_rn(__fmul_rn(k1.x, P.F12[2]), __fmul_rn(k1.y, P.F12[5])), P.F12[8]);
     const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+    // Kannala-Brandt cameras: which camera of a rig the feature belongs to (:1136-1141), its ray (unprojected once per feature)
+    const bool rig = KB8 && P.nleft1 >= 0 && P.nleft2 >= 0;                          // pKF1->mpCamera2 && pKF2->mpCamera2 (:1203)
+    const int right1 = (KB8 && P.nleft1 >= 0 && I.idx1 >= P.nleft1) ? 1 : 0;
+    KB8Cam c1; float ray1[3] = {0.f, 0.f, 1.f};
+    if (KB8) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) c1.p[i] = P.cam1[rig ? right1 : 0][i];
+        kb8_unproject(c1, k1.x, k1.y, ray1);
+    }
     unsigned best = 0xFFFFFFFFu;   // dist << 16 | (0xFFFF - position): the LAST candidate with the smallest distance wins (:1178 '>' test)
     for (int j = lane; j < I.cnt2; j += 64) {
         const int idx2 = feat2[I.start2 + j];
@@ -202,11 +213,22 @@ __global__ void __launch_bounds__(256) k_bow_search(const BowItem* __restrict__ 
         const int dist = __popcll(a0 ^ db[0]) + __popcll(a1 ^ db[1]) + __popcll(a2 ^ db[2]) + __popcll(a3 ^ db[3]);
         if (dist > P.th_low) continue;
         const KeyPointRec k2 = kps2[idx2];
-        if (!stereo1 && !stereo2) {
+        if (!stereo1 && !stereo2 && !(KB8 && P.nleft1 >= 0)) {                       // ... && !pKF1->mpCamera2 (:1189)
             const float dex = __fsub_rn(P.ep[0], k2.x), dey = __fsub_rn(P.ep[1], k2.y);
             if (__fadd_rn(__fmul_rn(dex, dex), __fmul_rn(dey, dey)) < __fmul_rn(100.f, P.scale2[k2.octave])) continue;
         }
-        if (!P.coarse) {
+        if (KB8) {
+            if (!P.coarse) {
+                const int right2 = (P.nleft2 >= 0 && idx2 >= P.nleft2) ? 1 : 0;
+                const int sel = rig ? right1 * 2 + right2 : 0;
+                KB8Cam c2; float ray2[3], p3D[3];
+#pragma unroll
+                for (int i = 0; i < 8; i++) c2.p[i] = P.cam2[rig ? right2 : 0][i];
+                kb8_unproject(c2, k2.x, k2.y, ray2);
+                const float z = kb8_triangulate_matches(c1, c2, ray1, ray2, k1.x, k1.y, k2.x, k2.y, P.R[sel], P.t[sel], P.sigma2_1[k1.octave], P.sigma2_2[k2.octave], p3D);
+                if (!(z > 0.0001f)) continue;                                            // KannalaBrandt8::epipolarConstrain (:322-328)
+            }
+        } else if (!P.coarse) {
             const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, k2.x), __fmul_rn(lb, k2.y)), lc);
             if (den == 0) continue;
             const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
@@ -217,6 +239,22 @@ __global__ void __launch_bounds__(256) k_bow_search(const BowItem* __restrict__ 
     }
     best = wave_min_u32(best);
     if (lane == 0) best2[it] = best == 0xFFFFFFFFu ? -1 : feat2[I.start2 + (0xFFFF - (int)(best & 0xFFFF))];
+}
+
+__global__ void __launch_bounds__(256) k_bow_search(const BowItem* __restrict__ items, int nitems, const KeyPointRec* __restrict__ kps1,
+                                                    const unsigned long long* __restrict__ desc1, const float* __restrict__ ur1,
+                                                    const KeyPointRec* __restrict__ kps2, const unsigned long long* __restrict__ desc2,
+                                                    const float* __restrict__ ur2, const uint8_t* __restrict__ has_mp2,
+                                                    const int* __restrict__ feat2, const BowParams* __restrict__ Ps, int* __restrict__ best2) {
+    bow_search_body<false>(items, nitems, kps1, desc1, ur1, kps2, desc2, ur2, has_mp2, feat2, Ps, best2);
+}
+// the same with Kannala-Brandt cameras (the triangulation test needs ~200 registers: its own kernel keeps the pinhole one slim)
+__global__ void __launch_bounds__(256) k_bow_search_kb8(const BowItem* __restrict__ items, int nitems, const KeyPointRec* __restrict__ kps1,
+                                                        const unsigned long long* __restrict__ desc1, const float* __restrict__ ur1,
+                                                        const KeyPointRec* __restrict__ kps2, const unsigned long long* __restrict__ desc2,
+                                                        const float* __restrict__ ur2, const uint8_t* __restrict__ has_mp2,
+                                                        const int* __restrict__ feat2, const BowParams* __restrict__ Ps, int* __restrict__ best2) {
+    bow_search_body<true>(items, nitems, kps1, desc1, ur1, kps2, desc2, ur2, has_mp2, feat2, Ps, best2);
 }
 
 // All distances of one unmatched feature idx1 to the features of the other key frame / frame in the same vocabulary node, in the

@@ -288,9 +288,9 @@ int orbm_search_by_projection_frame(orbx_extractor* h, const OrbmFrameView* Cur,
 
 // ORBmatcher::SearchForTriangulation for one key frame against n2 neighbours in a single launch (LocalMapping::CreateNewMapPoints calls
 // it for 10-30 neighbours in a row, src/LocalMapping.cc:510-540).  matches12: n2 rows of K1->N entries.
-int orbm_search_for_triangulation_batch(orbx_extractor* h, const OrbmKeyFrameView* K1, int n2, const OrbmKeyFrameView* const* K2s, const float* F12s,
-                                        const float* eps, int only_stereo, int coarse, int check_ori, int* matches12, int* nmatches_out) {
-    if (!h || !K1 || n2 < 0 || (n2 > 0 && (!K2s || !F12s || !eps || !matches12))) return fail(ORBX_E_ARG, "null");
+static int search_for_triangulation_impl(orbx_extractor* h, const OrbmKeyFrameView* K1, int n2, const OrbmKeyFrameView* const* K2s, const float* F12s,
+                                         const float* eps, const OrbmKB8Pair* kb8, int only_stereo, int coarse, int check_ori, int* matches12, int* nmatches_out) {
+    if (!h || !K1 || n2 < 0 || (n2 > 0 && (!K2s || (!F12s && !kb8) || !eps || !matches12))) return fail(ORBX_E_ARG, "null");
     if (K1->N >= 65535) return fail(ORBX_E_ARG, "keyframe too large");
     rt::set_device(h->device);
     const int N1 = K1->N;
@@ -341,7 +341,13 @@ int orbm_search_for_triangulation_batch(orbx_extractor* h, const OrbmKeyFrameVie
         const int nf = K2->fv_start[K2->fv_nodes];
         for (int k = 0; k < nf; k++) feat2[fbase[j] + k] = (int)K2->fv_feat[k] + o;
         BowParams& P = Ps[j]; memset(&P, 0, sizeof P);
-        for (int i = 0; i < 9; i++) P.F12[i] = F12s[9 * (size_t)j + i];
+        if (F12s) for (int i = 0; i < 9; i++) P.F12[i] = F12s[9 * (size_t)j + i];
+        if (kb8) {                               // Kannala-Brandt cameras: one OrbmKB8Pair per neighbour
+            const OrbmKB8Pair& C = kb8[j];
+            P.kb8 = 1; P.nleft1 = C.nleft1; P.nleft2 = C.nleft2;
+            memcpy(P.cam1, C.cam1, sizeof P.cam1); memcpy(P.cam2, C.cam2, sizeof P.cam2); memcpy(P.R, C.R, sizeof P.R); memcpy(P.t, C.t, sizeof P.t);
+            for (int l = 0; l < K1->nlevels && l < kMaxLevels; l++) P.sigma2_1[l] = K1->level_sigma2[l];
+        }
         P.ep[0] = eps[2 * (size_t)j]; P.ep[1] = eps[2 * (size_t)j + 1];
         for (int l = 0; l < K2->nlevels; l++) { P.scale2[l] = K2->scale_factors[l]; P.sigma2_2[l] = K2->level_sigma2[l]; }
         P.only_stereo = only_stereo; P.coarse = coarse; P.th_low = TH_LOW;
@@ -353,6 +359,12 @@ int orbm_search_for_triangulation_batch(orbx_extractor* h, const OrbmKeyFrameVie
                  pps = pk.add(Ps.data(), sizeof(BowParams) * Ps.size());
     if (pk.flush() || h->d_si[SI_BEST].ensure(items.size())) return fail(ORBX_E_DEVICE, "upload/allocation failed");
     dim3 grid(((int)items.size() + 3) / 4, 1, 1), blk(256, 1, 1);
+    if (kb8)
+        ORBX_LAUNCH(k_bow_search_kb8, grid, blk, 0, h->s0, pk.dev<BowItem>(pit), (int)items.size(),
+                    pk.dev<KeyPointRec>(pk1), pk.dev<unsigned long long>(pd1), pk.dev<float>(pu1),
+                    pk.dev<KeyPointRec>(pk2), pk.dev<unsigned long long>(pd2), pk.dev<float>(pu2),
+                    pk.dev<uint8_t>(pm2), pk.dev<int>(pf2), pk.dev<BowParams>(pps), h->d_si[SI_BEST].p);
+    else
     ORBX_LAUNCH(k_bow_search, grid, blk, 0, h->s0, pk.dev<BowItem>(pit), (int)items.size(),
                 pk.dev<KeyPointRec>(pk1), pk.dev<unsigned long long>(pd1), pk.dev<float>(pu1),
                 pk.dev<KeyPointRec>(pk2), pk.dev<unsigned long long>(pd2), pk.dev<float>(pu2),
@@ -383,6 +395,18 @@ int orbm_search_for_triangulation_batch(orbx_extractor* h, const OrbmKeyFrameVie
         if (nmatches_out) nmatches_out[j] = nmatches;
     }
     return ORBX_OK;
+}
+
+int orbm_search_for_triangulation_batch(orbx_extractor* h, const OrbmKeyFrameView* K1, int n2, const OrbmKeyFrameView* const* K2s, const float* F12s,
+                                        const float* eps, int only_stereo, int coarse, int check_ori, int* matches12, int* nmatches_out) {
+    if (n2 > 0 && !F12s) return fail(ORBX_E_ARG, "null");
+    return search_for_triangulation_impl(h, K1, n2, K2s, F12s, eps, nullptr, only_stereo, coarse, check_ori, matches12, nmatches_out);
+}
+
+int orbm_search_for_triangulation_kb8(orbx_extractor* h, const OrbmKeyFrameView* K1, const OrbmKeyFrameView* K2, const OrbmKB8Pair* cams, const float ep[2],
+                                      int only_stereo, int coarse, int check_ori, int* matches12, int* nmatches_out) {
+    if (!h || !K1 || !K2 || !cams || !ep || !matches12) return fail(ORBX_E_ARG, "null");
+    return search_for_triangulation_impl(h, K1, 1, &K2, nullptr, ep, cams, only_stereo, coarse, check_ori, matches12, nmatches_out);
 }
 
 int orbm_search_for_triangulation(orbx_extractor* h, const OrbmKeyFrameView* K1, const OrbmKeyFrameView* K2, const float F12[9], const float ep[2],

@@ -372,7 +372,7 @@ void orbx_destroy(orbx_extractor* h) {
     h->d_slots.release(); h->d_candA.release(); h->d_candB.release(); h->d_lvl_keys.release(); h->d_cell_count.release(); h->d_lvl_count.release();
     h->d_final_idx.release(); h->d_nm.release(); h->d_status.release(); h->d_kps.release(); h->d_desc.release();
     h->d_uRight.release(); h->d_depth.release(); h->d_sad.release(); h->d_nmatch.release(); h->d_knn.release(); h->d_ratio.release();
-    h->d_hamA.release(); h->d_hamB.release(); h->d_hamOut.release(); h->h_stage.release(); h->h_nm.release();
+    h->d_l2r.release(); h->d_r2l.release(); h->d_p3d.release(); h->d_hamA.release(); h->d_hamB.release(); h->d_hamOut.release(); h->h_stage.release(); h->h_nm.release();
     for (auto& x : h->d_sr) x.release();
     h->h_packA.release(); h->h_packB.release(); h->h_out.release();
     for (auto& x : h->d_si) x.release();
@@ -711,6 +711,51 @@ int orbm_knn2(orbx_extractor* L, int lf, orbx_extractor* R, int rf, int B) {
                 cap, L->d_knn.p, L->d_knn.p + bc, L->d_knn.p + 2 * bc, L->d_knn.p + 3 * bc, L->d_ratio.p);
     if (L->profile) rt::event_record(L->ev_stage[ST_MATCH][1], L->s0);
     if (rt::check_launch()) return fail(ORBX_E_DEVICE, "kernel launch failed: %s", rt::last_error());
+    return ORBX_OK;
+}
+
+// Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1530-1587) for B fisheye pairs: 2-NN + ratio test (k_knn2), then the triangulation gate
+// KannalaBrandt8::TriangulateMatches (src/CameraModels/KannalaBrandt8.cpp:439-523) on the device.
+int orbm_stereo_fisheye(orbx_extractor* L, int lf, orbx_extractor* R, int rf, int B, const OrbmKB8Stereo* S) {
+    if (!S) return fail(ORBX_E_ARG, "null camera parameters");
+    int rc = orbm_knn2(L, lf, R, rf, B); if (rc) return rc;
+    const int cap = L->kp_total_cap; const size_t bc = (size_t)L->maxB * cap;
+    if (L->d_l2r.ensure(bc) || L->d_r2l.ensure(bc) || L->d_p3d.ensure(3 * bc)) return fail(ORBX_E_DEVICE, "allocation failed");
+    KB8StereoParams P; memset(&P, 0, sizeof P);
+    for (int i = 0; i < 8; i++) { P.cam1[i] = S->cam1[i]; P.cam2[i] = S->cam2[i]; }
+    for (int i = 0; i < 9; i++) P.R12[i] = S->R12[i];
+    for (int i = 0; i < 3; i++) P.t12[i] = S->t12[i];
+    for (int l = 0; l < L->nlevels; l++) P.sigma2[l] = L->sigma2[l];
+    rt::memset_async(L->d_r2l.p, 0xFF, sizeof(int) * (size_t)B * cap, L->s0);
+    rt::memset_async(L->d_nmatch.p, 0, sizeof(int) * (size_t)B, L->s0);
+    dim3 grid((cap + 255) / 256, B, 1), blk(256, 1, 1);
+    ORBX_LAUNCH(k_kb8_stereo, grid, blk, 0, L->s0, (const KeyPointRec*)(L->d_kps.p + (size_t)lf * cap), (const int*)(L->d_nm.p + L->maxB + lf), (const int*)(L->d_nm.p + lf),
+                (const KeyPointRec*)(R->d_kps.p + (size_t)rf * cap), (const int*)(R->d_nm.p + R->maxB + rf), cap, (const int*)L->d_knn.p, (const uint8_t*)L->d_ratio.p, P,
+                L->d_l2r.p, L->d_r2l.p, L->d_depth.p, L->d_p3d.p, L->d_nmatch.p);
+    if (L->profile) rt::event_record(L->ev_stage[ST_MATCH][1], L->s0);
+    if (rt::check_launch()) return fail(ORBX_E_DEVICE, "kernel launch failed: %s", rt::last_error());
+    return ORBX_OK;
+}
+
+int orbm_stereo_fisheye_fetch(orbx_extractor* L, int B, int* l2r, int* r2l, float* depth, float* p3d, int* n_matches, int cap) {
+    if (!L || B <= 0 || B > L->maxB || !L->d_l2r.p) return fail(ORBX_E_ARG, "bad fetch");
+    rt::set_device(L->device);
+    const size_t tc = (size_t)L->kp_total_cap, n = (size_t)B * tc;
+    if (L->h_stage.ensure(n * (2 * sizeof(int) + 4 * sizeof(float)) + 64)) return fail(ORBX_E_DEVICE, "pinned allocation failed");
+    int* hl = (int*)L->h_stage.p; int* hr = hl + n; float* hd = (float*)(hr + n); float* hp = hd + n;
+    int e = rt::copy_d2h(hl, L->d_l2r.p, n * sizeof(int), L->s0) | rt::copy_d2h(hr, L->d_r2l.p, n * sizeof(int), L->s0) |
+            rt::copy_d2h(hd, L->d_depth.p, n * sizeof(float), L->s0) | rt::copy_d2h(hp, L->d_p3d.p, 3 * n * sizeof(float), L->s0) |
+            rt::copy_d2h(L->h_nm.p, L->d_nmatch.p, sizeof(int) * B, L->s0);
+    if (e || rt::stream_sync(L->s0)) return fail(ORBX_E_DEVICE, "D2H failed: %s", rt::last_error());
+    if (L->profile) L->stage_ms[ST_MATCH] = rt::event_elapsed_ms(L->ev_stage[ST_MATCH][0], L->ev_stage[ST_MATCH][1]);
+    const size_t ncopy = std::min<size_t>(tc, (size_t)cap);
+    for (int b = 0; b < B; b++) {
+        if (l2r) memcpy(l2r + (size_t)b * cap, hl + b * tc, ncopy * sizeof(int));
+        if (r2l) memcpy(r2l + (size_t)b * cap, hr + b * tc, ncopy * sizeof(int));
+        if (depth) memcpy(depth + (size_t)b * cap, hd + b * tc, ncopy * sizeof(float));
+        if (p3d) memcpy(p3d + 3 * (size_t)b * cap, hp + 3 * b * tc, 3 * ncopy * sizeof(float));
+        if (n_matches) n_matches[b] = L->h_nm.p[b];
+    }
     return ORBX_OK;
 }
 

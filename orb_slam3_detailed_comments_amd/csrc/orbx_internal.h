@@ -66,6 +66,7 @@ struct orbx_extractor {
     orbx::DevBuf<orbx::KeyPointRec> d_kps; orbx::DevBuf<unsigned long long> d_desc;
     orbx::DevBuf<float> d_uRight, d_depth; orbx::DevBuf<int> d_sad, d_nmatch;
     orbx::DevBuf<int> d_knn; orbx::DevBuf<uint8_t> d_ratio;
+    orbx::DevBuf<int> d_l2r, d_r2l; orbx::DevBuf<float> d_p3d;     // fisheye stereo (orbm_stereo_fisheye)
     orbx::DevBuf<unsigned long long> d_hamA, d_hamB; orbx::DevBuf<int> d_hamOut;
     orbx::HostBuf<uint8_t> h_stage;
     orbx::HostBuf<int> h_nm;

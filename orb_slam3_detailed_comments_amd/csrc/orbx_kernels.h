@@ -53,6 +53,10 @@ __global__ void k_stereo_match(const LevelInfo* __restrict__ lv, const KeyPointR
                                float* __restrict__ uRight, float* __restrict__ depth, int* __restrict__ sad);
 __global__ void k_stereo_median(const int* __restrict__ nL, int cap, float* __restrict__ uRight,
                                 float* __restrict__ depth, const int* __restrict__ sad, int* __restrict__ n_matches);
+__global__ void k_kb8_stereo(const KeyPointRec* __restrict__ kpsL, const int* __restrict__ monoL, const int* __restrict__ nL,
+                             const KeyPointRec* __restrict__ kpsR, const int* __restrict__ monoR, int cap, const int* __restrict__ idx0,
+                             const uint8_t* __restrict__ ratio_ok, KB8StereoParams P, int* __restrict__ l2r, int* __restrict__ r2l,
+                             float* __restrict__ depth, float* __restrict__ p3d, int* __restrict__ nmatches);
 __global__ void k_knn2(const unsigned long long* __restrict__ descQ, const int* __restrict__ qoff, const int* __restrict__ nq,
                        const unsigned long long* __restrict__ descT, const int* __restrict__ toff, const int* __restrict__ nt,
                        int cap, int* __restrict__ idx0, int* __restrict__ dist0, int* __restrict__ idx1,
@@ -66,6 +70,11 @@ __global__ void k_area_search(const AreaQuery* __restrict__ queries, const unsig
                               const int* __restrict__ cell_items, int gate_right, int* __restrict__ pool_counter, int pool_cap,
                               int* __restrict__ q_start, int* __restrict__ q_count, int2* __restrict__ entries);
 __global__ void k_bow_search(const BowItem* __restrict__ items, int nitems, const KeyPointRec* __restrict__ kps1,
+                             const unsigned long long* __restrict__ desc1, const float* __restrict__ ur1,
+                             const KeyPointRec* __restrict__ kps2, const unsigned long long* __restrict__ desc2,
+                             const float* __restrict__ ur2, const uint8_t* __restrict__ has_mp2, const int* __restrict__ feat2,
+                             const BowParams* __restrict__ Ps, int* __restrict__ best2);
+__global__ void k_bow_search_kb8(const BowItem* __restrict__ items, int nitems, const KeyPointRec* __restrict__ kps1,
                              const unsigned long long* __restrict__ desc1, const float* __restrict__ ur1,
                              const KeyPointRec* __restrict__ kps2, const unsigned long long* __restrict__ desc2,
                              const float* __restrict__ ur2, const uint8_t* __restrict__ has_mp2, const int* __restrict__ feat2,

@@ -68,6 +68,16 @@ struct BowParams {
     float ep[2];             // epipole of KF1's centre in KF2
     float scale2[kMaxLevels], sigma2_2[kMaxLevels];
     int only_stereo, coarse, th_low;
+    // Kannala-Brandt cameras (KannalaBrandt8::epipolarConstrain = TriangulateMatches > 1e-4): kb8 != 0
+    int kb8, nleft1, nleft2;                 // NLeft of the two key frames (-1: one camera)
+    float sigma2_1[kMaxLevels];              // mvLevelSigma2 of KF1
+    float cam1[2][8], cam2[2][8];            // mvParameters of mpCamera / mpCamera2 of KF1 and KF2
+    float R[4][9], t[4][3];                  // relative pose by [bRight1 * 2 + bRight2] (Tll, Tlr, Trl, Trr); one camera: entry 0
+};
+struct KB8StereoParams {                     // Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1530-1587)
+    float cam1[8], cam2[8];                  // mpCamera, mpCamera2
+    float R12[9], t12[3];                    // mRlr, mtlr
+    float sigma2[kMaxLevels];                // mvLevelSigma2
 };
 #ifdef ORBX_EMU
 struct int2 { int x, y; };

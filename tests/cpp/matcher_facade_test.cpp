@@ -70,6 +70,29 @@ int main(int argc, char** argv) {
     int bad_assign = 0;
     for (int i = 0; i < F.N; i++) { MockMapPoint* e = exp[i] >= 0 ? vp[exp[i]] : nullptr; bad_assign += F.mvpMapPoints[i] != e; }
     const int dd = ORB_SLAM3::ORBmatcher::DescriptorDistance(F.mDescriptors.row(0), dR.row(0));
+    // ---- ComputeStereoFishEyeMatches through the facade helper: a mock fisheye-rig Frame with the member names of include/Frame.h ----
+    struct MockCam { float p[8]; float getParameter(int i) { return p[i]; } };
+    struct M3 { float m[9]; float operator()(int r, int c) const { return m[3 * r + c]; } };
+    struct V3 { float d[3]; V3() : d{0, 0, 0} {} V3(float a, float b, float c) : d{a, b, c} {} float operator()(int i) const { return d[i]; } };
+    struct MockRigFrame {
+        int Nleft = 0, Nright = 0, mnCloseMPs = 7; MockCam *mpCamera, *mpCamera2; M3 mRlr; V3 mtlr;
+        std::vector<int> mvLeftToRightMatch, mvRightToLeftMatch; std::vector<float> mvDepth, mvuRight; std::vector<V3> mvStereo3Dpoints;
+    } RF;
+    MockCam c1{{190.98f, 190.97f, 254.93f, 256.90f, 0.0034f, 0.0007f, -0.0020f, 0.0002f}}, c2{{190.44f, 190.43f, 252.60f, 254.92f, 0.0034f, 0.0018f, -0.0027f, 0.0003f}};
+    RF.mpCamera = &c1; RF.mpCamera2 = &c2; RF.mRlr = M3{{1, 0, 0, 0, 1, 0, 0, 0, 1}}; RF.mtlr = V3(0.101f, 0.0f, 0.0f);
+    std::vector<cv::KeyPoint> kl2, kr2; cv::Mat dl2, dr2; std::vector<int> lap2 = {0, w - 1};
+    exL(imL, cv::Mat(), kl2, dl2, lap2); exR(imR, cv::Mat(), kr2, dr2, lap2);
+    RF.Nleft = (int)kl2.size(); RF.Nright = (int)kr2.size();
+    ORB_SLAM3::ComputeStereoFishEyeMatches(RF, &exL, &exR);
+    int nfish = 0, fish_bad = RF.mnCloseMPs != 0 || (int)RF.mvDepth.size() != RF.Nleft || (int)RF.mvRightToLeftMatch.size() != RF.Nright;
+    for (int i = 0; i < RF.Nleft && !fish_bad; i++) {
+        const int j = RF.mvLeftToRightMatch[i];
+        if (j < 0) { fish_bad |= RF.mvDepth[i] != -1.0f; continue; }
+        nfish++;
+        fish_bad |= !(RF.mvDepth[i] > 0.0001f) || RF.mvStereo3Dpoints[i](2) != RF.mvDepth[i] || j >= RF.Nright || RF.mvRightToLeftMatch[j] < i;
+    }
+    printf("fisheye helper: %d of %d left keypoints matched, consistent=%d\n", nfish, RF.Nleft, !fish_bad);
+    if (fish_bad) return 1;
     const int de = orbo_descriptor_distance(F.mDescriptors.ptr(0), dR.ptr(0));
     printf("N=%d stereo=%d matches facade=%d oracle=%d mismatched_assignments=%d dist %d %d TH %d %d %d\n", F.N, nstereo, ngot, nexp, bad_assign, dd, de,
            ORB_SLAM3::ORBmatcher::TH_LOW, ORB_SLAM3::ORBmatcher::TH_HIGH, ORB_SLAM3::ORBmatcher::HISTO_LENGTH);

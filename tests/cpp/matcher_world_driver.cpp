@@ -126,6 +126,9 @@ void mw_destroy(void* w) {
 int mw_add_camera(void* wv, float fx, float fy, float cx, float cy) {
     World* w = (World*)wv; w->cams.emplace_back(new GeometricCamera(fx, fy, cx, cy)); return (int)w->cams.size() - 1;
 }
+int mw_add_camera_kb8(void* wv, const float* p8) {
+    World* w = (World*)wv; w->cams.emplace_back(new KannalaBrandt8(p8)); return (int)w->cams.size() - 1;
+}
 int mw_add_mappoint(void* wv, const float* pos, const float* normal, float min_dist, float max_dist, const uint8_t* desc, int bad, int n_obs) {
     World* w = (World*)wv;
 #ifdef MW_REAL

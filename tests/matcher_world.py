@@ -106,12 +106,15 @@ class Scene:
                 d[r, b >> 3] ^= np.uint8(1 << (b & 7))
         return d
 
-    def observe(self, R, t, frac=0.8, clutter=250, px_noise=1.5, maxflips=45, rot_off=0.0, stereo_frac=0.6, angle_outliers=0.08, level0_frac=0.0):
-        """Returns keys (KP array), desc, u_right, point index per feature (-1 clutter), node per feature."""
+    def observe(self, R, t, frac=0.8, clutter=250, px_noise=1.5, maxflips=45, rot_off=0.0, stereo_frac=0.6, angle_outliers=0.08, level0_frac=0.0, proj=None):
+        """Returns keys (KP array), desc, u_right, point index per feature (-1 clutter), node per feature.  proj: camera projection of the
+        camera-frame points (default: the pinhole FX, FY, CX, CY)."""
         rng = self.rng
         Xc = (R.astype(np.float64) @ self.X.T.astype(np.float64)).T + t.astype(np.float64)
         z = Xc[:, 2]
         u = FX * Xc[:, 0] / z + CX; v = FY * Xc[:, 1] / z + CY
+        if proj is not None:
+            u, v = proj(Xc)
         vis = (z > 0.5) & (u > 8) & (u < W - 8) & (v > 8) & (v < H - 8) & (rng.uniform(size=len(z)) < frac)
         idx = np.nonzero(vis)[0]
         rng.shuffle(idx)
@@ -396,9 +399,64 @@ def build_and_run_rig(drv, seed):
     return out
 
 
+def kb8_project(p8, Xc):
+    """KannalaBrandt8::project (src/CameraModels/KannalaBrandt8.cpp:87-104) in fp64, for building scenes"""
+    x, y, z = Xc[:, 0], Xc[:, 1], Xc[:, 2]
+    theta = np.arctan2(np.sqrt(x * x + y * y), z); psi = np.arctan2(y, x)
+    r = theta + p8[4] * theta ** 3 + p8[5] * theta ** 5 + p8[6] * theta ** 7 + p8[7] * theta ** 9
+    return p8[0] * r * np.cos(psi) + p8[2], p8[1] * r * np.sin(psi) + p8[3]
+
+
+def build_and_run_kb8(drv, seed):
+    """ORBmatcher::SearchForTriangulation on key frames with Kannala-Brandt cameras (src/ORBmatcher.cc:1045-1323, the branches of :1067-1083,
+    :1126-1141, :1189, :1203-1240): one fisheye camera per key frame, and the two-camera rig (features of both cameras in one key frame)."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    L = drv.L
+    sc = Scene(rng)
+    # a 640 x 480 fisheye pair in the style of Examples/Stereo/TUM-VI.yaml, scaled to the world's image size
+    P1 = np.array([FX * 0.62, FY * 0.62, CX + 1.5, CY - 2.0, 0.0035, 0.0007, -0.0020, 0.0002], np.float32)
+    P2 = np.array([FX * 0.618, FY * 0.621, CX - 2.0, CY + 1.0, 0.0034, 0.0018, -0.0027, 0.0003], np.float32)
+    L.mw_add_camera_kb8.restype = C.c_int
+    c1 = L.mw_add_camera_kb8(drv.w, _p(P1)); c2 = L.mw_add_camera_kb8(drv.w, _p(P2))
+    trl = (rot(0.0, 0.03, 0.001), np.array([-0.101, 0.0006, 0.001], np.float32))
+    mp_ids = []
+    for i in range(len(sc.X)):
+        d = float(np.linalg.norm(sc.X[i])); maxd = d * SCALE ** int(sc.level0[i])
+        mp_ids.append(drv.mappoint(sc.X[i], sc.X[i] / d, maxd / SCALE ** (NLEVELS - 1), maxd, sc.noisy_desc(np.array([i]), 20)[0], bad=0, n_obs=2))
+    mp_ids = np.array(mp_ids)
+
+    def make(pose, rig, assoc_frac):
+        R, t = pose
+        kl, dl, url, ptl, nodel = sc.observe(R, t, clutter=120, px_noise=0.6, maxflips=35, proj=lambda X: kb8_project(P1.astype(np.float64), X))
+        if not rig:
+            kid = drv.frame(True, kl, dl, None, R, t, c1)
+            drv.set_feat_vec(True, kid, nodel)
+            pt = ptl
+        else:
+            Rr = (trl[0] @ R).astype(np.float32); tr = (trl[0] @ t + trl[1]).astype(np.float32)
+            kr, dr, _, ptr, noder = sc.observe(Rr, tr, clutter=120, px_noise=0.6, maxflips=35, proj=lambda X: kb8_project(P2.astype(np.float64), X))
+            kid = drv.frame(True, kl, np.concatenate([dl, dr]), None, R, t, c1, c2, keys_right=kr, trl=trl)
+            drv.set_feat_vec(True, kid, np.concatenate([nodel, noder]))
+            pt = np.concatenate([ptl, ptr])
+        ids = np.where((pt >= 0) & (rng.uniform(size=len(pt)) < assoc_frac), mp_ids[np.maximum(pt, 0)], -1).astype(np.int32)
+        drv.set_map_points(True, kid, ids)
+        return kid, len(pt)
+
+    poseA = (np.eye(3, dtype=np.float32), np.zeros(3, np.float32))
+    poseB = (rot(0.01, -0.03, 0.02), np.array([0.45, -0.05, 0.12], np.float32))
+    for rig in (0, 1):
+        kA, nA = make(poseA, rig, 0.3); kB, nB = make(poseB, rig, 0.3)
+        for (only_stereo, coarse, ori) in ((0, 0, 1), (0, 0, 0), (0, 1, 1), (1, 0, 0)):
+            pairs = np.full((max(nA, 1), 2), -1, np.int32); npairs = C.c_int(0)
+            n = L.mw_search_for_triangulation(drv.w, kA, kB, only_stereo, coarse, _p(pairs), len(pairs), C.byref(npairs), C.c_float(0.6), ori)
+            out["kb8_triangulation_rig%d_%d%d%d" % (rig, only_stereo, coarse, ori)] = np.concatenate([[n, npairs.value], pairs[:npairs.value].ravel()])
+    return out
+
+
 if __name__ == "__main__":
     drv_path, orbx_path, seed, variant, dst = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
     d = Driver(drv_path, orbx_path or None)
-    res = build_and_run_rig(d, seed) if variant == "rig" else build_and_run(d, seed, variant)
+    res = build_and_run_rig(d, seed) if variant == "rig" else build_and_run_kb8(d, seed) if variant == "kb8" else build_and_run(d, seed, variant)
     np.savez(dst, flavour=np.frombuffer(d.L.mw_flavour(), np.uint8), **res)
     d.close()

@@ -415,7 +415,8 @@ def _bind_frame_lib(L):
         L.ref_frame_stereo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_float] * 6 + [C.POINTER(C.c_int)] * 2
         L.ref_frame_destroy.argtypes = [C.c_void_p]
         L.ref_frame_fisheye.restype = C.c_void_p
-        L.ref_frame_fisheye.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float] + [C.c_int] * 8 + [C.c_void_p]
+        L.ref_frame_fisheye.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p]
+        L.ref_frame_fisheye_get3d.argtypes = [C.c_void_p] * 3
         L.ref_frame_fisheye_get.argtypes = [C.c_void_p] * 6
         L.ref_frame_stereo_repeat.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_float] * 6 + [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.ref_frame_get.argtypes = [C.c_void_p] * 8
@@ -517,17 +518,23 @@ def reference_distinctive_descriptors(desc, start, right_of_prev=None, bad_kf=No
     return out[:P], has[:P]
 
 
-def reference_fisheye_frame(left, right, lap_left, lap_right, nfeatures=1500, scale=1.2, nlevels=8, ini=20, mn=7, gauss_variant=0):
-    """The reference's fisheye-rig Frame constructor (src/Frame.cc:1432-1528) with an accept-all triangulation gate.
-    Returns dict(keys, keys_right, desc [Nleft+Nright,32], mono_left, mono_right, l2r, r2l)."""
+def reference_fisheye_frame(left, right, lap_left, lap_right, nfeatures=1500, scale=1.2, nlevels=8, ini=20, mn=7, gauss_variant=0, cams=None):
+    """The reference's fisheye-rig Frame constructor (src/Frame.cc:1432-1528).  cams = None: accept-all triangulation gate (the result is the
+    kNN + ratio decision); cams = (cam1[8], cam2[8], Rlr[3,3], tlr[3]): gate = KannalaBrandt8::TriangulateMatches (restated camera).
+    Returns dict(keys, keys_right, desc [Nleft+Nright,32], mono_left, mono_right, l2r, r2l, depth, p3d)."""
     L = reference_frame_lib()
     left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
     out = np.zeros(4, np.int32)
+    cp = None
+    if cams is not None:
+        cp = np.concatenate([np.asarray(c, np.float32).ravel() for c in cams]).astype(np.float32); assert cp.size == 28
     h = L.ref_frame_fisheye(left.ctypes.data, right.ctypes.data, left.shape[1], left.shape[0], nfeatures, scale, nlevels, ini, mn, gauss_variant,
-                            lap_left[0], lap_left[1], lap_right[0], lap_right[1], out.ctypes.data)
+                            lap_left[0], lap_left[1], lap_right[0], lap_right[1], None if cp is None else cp.ctypes.data, out.ctypes.data)
     nl, nr, ml, mr = [int(v) for v in out]
     keys = np.zeros(nl, KP_DTYPE); keys_r = np.zeros(nr, KP_DTYPE); desc = np.zeros((nl + nr, 32), np.uint8)
     l2r = np.zeros(max(nl, 1), np.int32); r2l = np.zeros(max(nr, 1), np.int32)
     L.ref_frame_fisheye_get(h, keys.ctypes.data, keys_r.ctypes.data, desc.ctypes.data, l2r.ctypes.data, r2l.ctypes.data)
+    depth = np.zeros(max(nl, 1), np.float32); p3d = np.zeros((max(nl, 1), 3), np.float32)
+    L.ref_frame_fisheye_get3d(h, depth.ctypes.data, p3d.ctypes.data)
     L.ref_frame_destroy(h)
-    return dict(keys=keys, keys_right=keys_r, desc=desc, mono_left=ml, mono_right=mr, l2r=l2r[:nl], r2l=r2l[:nr])
+    return dict(keys=keys, keys_right=keys_r, desc=desc, mono_left=ml, mono_right=mr, l2r=l2r[:nl], r2l=r2l[:nr], depth=depth[:nl], p3d=p3d[:nl])

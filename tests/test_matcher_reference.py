@@ -31,7 +31,8 @@ RUNNER = os.path.join(ROOT, "tests", "matcher_world.py")
 pytestmark = pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(FACADE)), reason="oracle/_ref/libmw_*.so not built (needs /root/reference)")
 
 MIN_MATCHES = {"sbp_mappoints_0": 100, "sbp_frame_fwd_7": 100, "sbp_keyframe_100": 100, "sbp_sim3_100_0": 100, "bow_frame_1": 80, "bow_keyframes_1": 60,
-               "init_0": 30, "triang_0_0": 10, "sim3_100": 60, "fuse": 100, "fuse_sim3": 60, "rig_sbp_mappoints_1": 200, "rig_sbp_frame_fwd_1": 300, "rig_fuse_0": 50, "rig_fuse_1": 25, "rig_bow_frame_1": 80, "rig_bow_keyframes_1": 40}
+               "init_0": 30, "triang_0_0": 10, "sim3_100": 60, "fuse": 100, "fuse_sim3": 60, "rig_sbp_mappoints_1": 200, "rig_sbp_frame_fwd_1": 300, "rig_fuse_0": 50, "rig_fuse_1": 25, "rig_bow_frame_1": 80, "rig_bow_keyframes_1": 40,
+               "kb8_triangulation_rig0_001": 40, "kb8_triangulation_rig1_001": 60, "kb8_triangulation_rig1_011": 60}
 
 
 def _run(tmp_path, driver, orbx, seed, variant, tag):
@@ -57,12 +58,12 @@ def _compare(tmp_path, orbx, cases, ref=REF, facade=FACADE):
 
 
 def test_matcher_facade_equals_reference_emulated(tmp_path, emu_lib):
-    _compare(tmp_path, os.path.join(ROOT, "tests", "emu", "liborbx_emu.so"), [(1, "base"), (2, "dense"), (3, "hard"), (4, "rig"), (5, "rig")])
+    _compare(tmp_path, os.path.join(ROOT, "tests", "emu", "liborbx_emu.so"), [(1, "base"), (2, "dense"), (3, "hard"), (4, "rig"), (5, "rig"), (6, "kb8"), (7, "kb8")])
 
 
 @pytest.mark.gpu
 def test_matcher_facade_equals_reference_gpu(tmp_path, hip_lib):
-    _compare(tmp_path, _lib.HIP_LIB_PATH, [(1, "base"), (2, "dense"), (3, "hard"), (4, "rig"), (11, "base"), (12, "dense"), (13, "rig")])
+    _compare(tmp_path, _lib.HIP_LIB_PATH, [(1, "base"), (2, "dense"), (3, "hard"), (4, "rig"), (11, "base"), (12, "dense"), (13, "rig"), (6, "kb8"), (14, "kb8"), (15, "kb8")])
 
 
 real = pytest.mark.skipif(not (os.path.exists(REF_REAL) and os.path.exists(FACADE_REAL)), reason="oracle/_ref/libmw_*_full.so not built (needs /root/reference)")
@@ -81,10 +82,10 @@ def test_real_classes_agree_with_standins(tmp_path):
 
 @real
 def test_matcher_facade_equals_reference_real_classes_emulated(tmp_path, emu_lib):
-    _compare(tmp_path, os.path.join(ROOT, "tests", "emu", "liborbx_emu.so"), [(1, "base"), (3, "hard"), (4, "rig")], REF_REAL, FACADE_REAL)
+    _compare(tmp_path, os.path.join(ROOT, "tests", "emu", "liborbx_emu.so"), [(1, "base"), (3, "hard"), (4, "rig"), (6, "kb8")], REF_REAL, FACADE_REAL)
 
 
 @real
 @pytest.mark.gpu
 def test_matcher_facade_equals_reference_real_classes_gpu(tmp_path, hip_lib):
-    _compare(tmp_path, _lib.HIP_LIB_PATH, [(1, "base"), (2, "dense"), (3, "hard"), (4, "rig"), (21, "base"), (22, "rig")], REF_REAL, FACADE_REAL)
+    _compare(tmp_path, _lib.HIP_LIB_PATH, [(1, "base"), (2, "dense"), (3, "hard"), (4, "rig"), (21, "base"), (22, "rig"), (23, "kb8")], REF_REAL, FACADE_REAL)
