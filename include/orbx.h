@@ -209,6 +209,37 @@ typedef struct OrbmLastFrameView {        /* what SearchByProjection(CurrentFram
     const uint8_t* desc;                  /* pMP->GetDescriptor(), N x 32 */
 } OrbmLastFrameView;
 
+/* C1 on the device: Frame::isInFrustum (src/Frame.cc:667-773, one camera) + Pinhole / KannalaBrandt8::project + MapPoint::PredictScale
+ * (src/MapPoint.cc:688-731) for M map points at once, in the reference's fp32 operation order (Eigen's 3x3 * 3x1 product summed left to
+ * right, no fused multiply-adds; the double log of PredictScale is the device's).  The outputs are the fields the reference stores in the
+ * MapPoint: mbTrackInView, mTrackProjX / Y / XR, mTrackDepth, mTrackViewCos, mnTrackScaleLevel (any pointer may be NULL). */
+typedef struct OrbmFrustumView {
+    float Rcw[9], tcw[3], Ow[3];          /* Frame::mRcw (row-major), mtcw, mOw */
+    int camera_type;                      /* GeometricCamera::GetType(): 0 pinhole (cam = fx, fy, cx, cy), 1 Kannala-Brandt (8 parameters) */
+    float cam[8];
+    float min_x, max_x, min_y, max_y;     /* mnMinX .. mnMaxY */
+    float mbf, log_scale_factor;          /* mbf, mfLogScaleFactor */
+    int nlevels; const float* scale_factors;
+} OrbmFrustumView;
+typedef struct OrbmWorldPointView {       /* map points by position */
+    int M;
+    const float* pos;                     /* GetWorldPos(), M x 3 */
+    const float* normal;                  /* GetNormal(), M x 3 */
+    const float* min_distance;            /* mfMinDistance (GetMinDistanceInvariance() / 0.8) */
+    const float* max_distance;            /* mfMaxDistance (GetMaxDistanceInvariance() / 1.2) */
+    const uint8_t* is_bad;                /* isBad() (NULL = none) */
+    const uint8_t* has_obs;               /* Observations() > 0 (NULL = all) */
+    const uint8_t* desc;                  /* GetDescriptor(), M x 32 (searches only) */
+} OrbmWorldPointView;
+typedef struct OrbmTrackOut { uint8_t* in_view; float *proj_x, *proj_y, *proj_xr, *depth, *view_cos; int* scale_level; } OrbmTrackOut;
+int orbm_is_in_frustum(orbx_extractor* h, const OrbmFrustumView* frame, const OrbmWorldPointView* points, float viewing_cos_limit, const OrbmTrackOut* out);
+/* isInFrustum for every point, then ORBmatcher::SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints) (src/ORBmatcher.cc:45-167)
+ * on the points in view, as Tracking::SearchLocalPoints does (src/Tracking.cc:4009-4067): the window queries are produced and consumed on
+ * the device.  assigned[i] = index of the map point given to keypoint i, or -1; out (may be NULL) receives the tracking fields. */
+int orbm_search_local_points(orbx_extractor* h, const OrbmFrameView* F, const OrbmFrustumView* frame, const OrbmWorldPointView* points,
+                             float viewing_cos_limit, float th, int far_points, float th_far, float nnratio, const OrbmTrackOut* out,
+                             int* assigned, int* nmatches);
+
 /* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBmatcher.cc:1950-2184).
  * forward/backward = bForward/bBackward (:1973-1975, computed from the two poses by the caller).
  * assigned[i] = index into LastFrame of the point written to CurrentFrame.mvpMapPoints[i]; -1 untouched;

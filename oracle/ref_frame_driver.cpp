@@ -12,6 +12,7 @@
 #include <vector>
 #include "Frame.h"          // the reference header, via -I/root/reference/include
 #include "ORBextractor.h"
+#include "ORBmatcher.h"
 
 using namespace ORB_SLAM3;
 
@@ -97,6 +98,37 @@ void ref_frame_fisheye_get(void* h, void* keys, void* keys_right, uint8_t* desc,
 void ref_frame_fisheye_get3d(void* h, float* depth, float* p3d) {
     Frame* F = ((Holder*)h)->frame;
     for (int i = 0; i < F->Nleft; i++) { depth[i] = F->mvDepth[i]; for (int k = 0; k < 3; k++) p3d[3 * i + k] = F->mvStereo3Dpoints[i][k]; }
+}
+
+// Tracking::SearchLocalPoints' two steps on the reference's own code (src/Tracking.cc:4009-4067): Frame::SetPose, Frame::isInFrustum
+// (src/Frame.cc:667-773, with the stand-in MapPoint's PredictScale restated from src/MapPoint.cc:688-731) for M points, then - when `assigned`
+// is given - ORBmatcher::SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints) (src/ORBmatcher.cc:45-167).
+// track: 7 arrays of M entries (in_view, proj_x, proj_y, proj_xr, depth, view_cos, scale_level as floats).
+int ref_frame_search_local_points(void* h, const float* R, const float* t, int M, const float* pos, const float* normal, const float* min_dist, const float* max_dist,
+                                  const uint8_t* bad, const uint8_t* has_obs, const uint8_t* desc, float cos_limit, float* track, int do_search, float th, int far_points,
+                                  float th_far, float nnratio, int* assigned) {
+    Frame* F = ((Holder*)h)->frame;
+    Sophus::SE3f Tcw;
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Tcw.R(i, j) = R[3 * i + j]; Tcw.t[i] = t[i]; }
+    F->SetPose(Tcw);
+    std::vector<MapPoint> mps(M);
+    std::vector<MapPoint*> vp(M);
+    for (int i = 0; i < M; i++) {
+        MapPoint& p = mps[i];
+        p.pos = Eigen::Vector3f(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]); p.normal = Eigen::Vector3f(normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]);
+        p.minDist = min_dist[i]; p.maxDist = max_dist[i]; p.bad = bad && bad[i]; p.nObs = has_obs ? (has_obs[i] ? 2 : 0) : 1;
+        p.descriptor = cv::Mat(1, 32, CV_8U); memcpy(p.descriptor.ptr(0), desc + 32 * (size_t)i, 32);
+        vp[i] = &p;
+        const bool in = F->isInFrustum(&p, cos_limit);
+        track[i] = in && p.mbTrackInView ? 1.0f : 0.0f; track[M + i] = p.mTrackProjX; track[2 * (size_t)M + i] = p.mTrackProjY; track[3 * (size_t)M + i] = p.mTrackProjXR;
+        track[4 * (size_t)M + i] = p.mTrackDepth; track[5 * (size_t)M + i] = p.mTrackViewCos; track[6 * (size_t)M + i] = (float)p.mnTrackScaleLevel;
+    }
+    if (!do_search) return 0;
+    std::fill(F->mvpMapPoints.begin(), F->mvpMapPoints.end(), (MapPoint*)nullptr);
+    ORBmatcher matcher(nnratio);
+    const int n = matcher.SearchByProjection(*F, vp, th, far_points != 0, th_far);
+    for (int i = 0; i < F->N; i++) assigned[i] = F->mvpMapPoints[i] ? (int)(F->mvpMapPoints[i] - mps.data()) : -1;
+    return n;
 }
 
 // bench.py's cpu_baseline: the reference's steady state - two long-lived extractors (Tracking owns them), one Frame temporary per stereo

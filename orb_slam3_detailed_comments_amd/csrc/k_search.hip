@@ -171,6 +171,71 @@ __global__ void __launch_bounds__(256) k_area_search(const AreaQuery* __restrict
     if (lane == 0) { q_start[q] = start < 0 ? 0 : start; q_count[q] = cnt_total; }
 }
 
+// Frame::isInFrustum (src/Frame.cc:667-773, one camera) + MapPoint::PredictScale (src/MapPoint.cc:688-731) for M map points, one thread each,
+// in the reference's fp32 operation order (Eigen's 3x3 * 3x1 is sum-of-products left to right; no fused multiply-adds).  Writes the tracking
+// fields the reference stores in the MapPoint (mbTrackInView, mTrackProjX / Y / XR, mTrackDepth, mnTrackScaleLevel, mTrackViewCos) and,
+// when `queries` is given, the window query of ORBmatcher::SearchByProjection(Frame, MapPoints) for that point (src/ORBmatcher.cc:53-82).
+__global__ void __launch_bounds__(256) k_frustum(FrustumParams F, int M, const float* __restrict__ pos, const float* __restrict__ normal,
+                                                 const float* __restrict__ min_dist, const float* __restrict__ max_dist, const uint8_t* __restrict__ is_bad,
+                                                 uint8_t* __restrict__ in_view, float* __restrict__ track /* [6][M]: x, y, xr, depth, cos, - */,
+                                                 int* __restrict__ scale_level, AreaQuery* __restrict__ queries) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= M) return;
+    const float P0 = pos[3 * i], P1 = pos[3 * i + 1], P2 = pos[3 * i + 2];
+    bool ok = true;
+    float u = -1.0f, v = -1.0f, xr = 0.0f, depth = 0.0f, vcos = 0.0f; int lvl = 0;
+    // Pc = mRcw * P + mtcw
+    const float x = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(F.Rcw[0], P0), __fmul_rn(F.Rcw[1], P1)), __fmul_rn(F.Rcw[2], P2)), F.tcw[0]);
+    const float y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(F.Rcw[3], P0), __fmul_rn(F.Rcw[4], P1)), __fmul_rn(F.Rcw[5], P2)), F.tcw[1]);
+    const float z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(F.Rcw[6], P0), __fmul_rn(F.Rcw[7], P1)), __fmul_rn(F.Rcw[8], P2)), F.tcw[2]);
+    const float Pc_dist = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+    const float invz = __fdiv_rn(1.0f, z);
+    if (z < 0.0f) ok = false;
+    float uu = 0.f, vv = 0.f;
+    if (ok) {
+        if (F.kb8) { KB8Cam c; for (int k = 0; k < 8; k++) c.p[k] = F.cam[k]; const float pc[3] = {x, y, z}; float uv[2]; kb8_project(c, pc, uv); uu = uv[0]; vv = uv[1]; }
+        else {                                                        // Pinhole::project, src/CameraModels/Pinhole.cpp:61-68
+            uu = __fadd_rn(__fdiv_rn(__fmul_rn(F.cam[0], x), z), F.cam[2]);
+            vv = __fadd_rn(__fdiv_rn(__fmul_rn(F.cam[1], y), z), F.cam[3]);
+        }
+        if (uu < F.min_x || uu > F.max_x) ok = false;
+        if (ok && (vv < F.min_y || vv > F.max_y)) ok = false;
+    }
+    if (ok) {
+        u = uu; v = vv;                                               // mTrackProjX / Y are set before the distance tests (:705-706)
+        const float maxDistance = __fmul_rn(1.2f, max_dist[i]), minDistance = __fmul_rn(0.8f, min_dist[i]);     // MapPoint.cc:658-671
+        const float o0 = __fsub_rn(P0, F.Ow[0]), o1 = __fsub_rn(P1, F.Ow[1]), o2 = __fsub_rn(P2, F.Ow[2]);
+        const float dist = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(o0, o0), __fmul_rn(o1, o1)), __fmul_rn(o2, o2)));
+        if (dist < minDistance || dist > maxDistance) ok = false;
+        if (ok) {
+            const float dot = __fadd_rn(__fadd_rn(__fmul_rn(o0, normal[3 * i]), __fmul_rn(o1, normal[3 * i + 1])), __fmul_rn(o2, normal[3 * i + 2]));
+            vcos = __fdiv_rn(dot, dist);
+            if (vcos < F.cos_limit) ok = false;
+        }
+        if (ok) {
+            const float ratio = __fdiv_rn(max_dist[i], dist);                                                      // PredictScale
+            int n = (int)ceil(log((double)ratio) / (double)F.log_scale_factor);
+            if (n < 0) n = 0; else if (n >= F.nlevels) n = F.nlevels - 1;
+            lvl = n;
+            xr = __fsub_rn(uu, __fmul_rn(F.mbf, invz));
+            depth = Pc_dist;
+        }
+    }
+    in_view[i] = ok ? 1 : 0;
+    track[i] = u; track[M + i] = v; track[2 * (size_t)M + i] = xr; track[3 * (size_t)M + i] = depth; track[4 * (size_t)M + i] = vcos;
+    scale_level[i] = ok ? lvl : 0;
+    if (queries) {
+        AreaQuery q; q.x = 0; q.y = 0; q.r = 0; q.ur = 0; q.min_level = 0; q.max_level = 0; q.active = 0; q.gate = 0;
+        if (ok && !(F.far_points && depth > F.th_far) && !(is_bad && is_bad[i])) {
+            float r = (double)vcos > 0.998 ? 2.5f : 4.0f;             // RadiusByViewingCos, src/ORBmatcher.cc:242-249
+            if (F.th != 1.0f) r = __fmul_rn(r, F.th);
+            q.x = u; q.y = v; q.r = __fmul_rn(r, F.scale_factors[lvl]); q.ur = xr;
+            q.min_level = lvl - 1; q.max_level = lvl; q.active = 1; q.gate = 1;
+        }
+        queries[i] = q;
+    }
+}
+
 // One wave per work item (an unmatched feature idx1 of KF1 and the feature list of a neighbour KF2 in the same node; the arrays of
 // all neighbours of a batch are concatenated, item.out_off = neighbour).  best2[item] = chosen (global) idx2 or -1.   src/ORBmatcher.cc:1117-1254
 template <bool KB8>

@@ -74,6 +74,7 @@ struct Csr { std::vector<int> start, count; std::vector<int> ent; };   // ent: 2
 // runs k_area_search for Q queries.  Results come back in one copy: [total, -, -, -][start Q][count Q][entries]; the number of
 // entries fetched with the header is a guess from the previous call, a second copy follows only if it was too small, and the pool is
 // grown and the search repeated if the pool itself overflowed.
+int run_area_search_dev(orbx_extractor* h, const DeviceFrame& D, int Q, const AreaQuery* dq, const unsigned long long* dqd, Csr* out);
 int run_area_search(orbx_extractor* h, const DeviceFrame& D, const std::vector<AreaQuery>& qs, const uint8_t* qdesc, Csr* out) {
     const int Q = (int)qs.size();
     out->start.assign(Q, 0); out->count.assign(Q, 0); out->ent.clear();
@@ -82,8 +83,12 @@ int run_area_search(orbx_extractor* h, const DeviceFrame& D, const std::vector<A
     if (h->h_packB.ensure(qtotal + 16) || h->d_sr[SR_QUERY].ensure(qtotal + 16)) return fail(ORBX_E_DEVICE, "upload/allocation failed");
     memcpy(h->h_packB.p + oq, qs.data(), sizeof(AreaQuery) * (size_t)Q); memcpy(h->h_packB.p + oqd, qdesc, 32 * (size_t)Q);
     if (rt::copy_h2d(h->d_sr[SR_QUERY].p, h->h_packB.p, qtotal, h->s0)) return fail(ORBX_E_DEVICE, "upload failed");
-    const AreaQuery* dq = (const AreaQuery*)(h->d_sr[SR_QUERY].p + oq);
-    const unsigned long long* dqd = (const unsigned long long*)(h->d_sr[SR_QUERY].p + oqd);
+    return run_area_search_dev(h, D, Q, (const AreaQuery*)(h->d_sr[SR_QUERY].p + oq), (const unsigned long long*)(h->d_sr[SR_QUERY].p + oqd), out);
+}
+// the same with the queries and their descriptors already on the device
+int run_area_search_dev(orbx_extractor* h, const DeviceFrame& D, int Q, const AreaQuery* dq, const unsigned long long* dqd, Csr* out) {
+    out->start.assign(Q, 0); out->count.assign(Q, 0); out->ent.clear();
+    if (Q == 0) return ORBX_OK;
     const size_t hdr = 16 + 8 * (size_t)Q;                          // bytes in front of the entries
     size_t pool = std::max<size_t>(h->area_pool, (size_t)Q * 48 + 1024);
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -209,6 +214,118 @@ int orbm_search_by_projection_mappoints(orbx_extractor* h, const OrbmFrameView* 
     int nmatches = 0;
     for (int i = 0; i < M; i++) {
         if (!qs[i].active || c.count[i] == 0) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int k = 0; k < c.count[i]; k++) {
+            const int idx = c.ent[2 * (size_t)(c.start[i] + k)], dl = c.ent[2 * (size_t)(c.start[i] + k) + 1];
+            if (occ[idx]) continue;
+            const int dist = dl & 0xFFFF, level = dl >> 16;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = level; bestIdx = idx; }
+            else if (dist < bestDist2) { bestLevel2 = level; bestDist2 = dist; }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+                assigned[bestIdx] = i;
+                occ[bestIdx] = P->has_obs ? P->has_obs[i] : 1;
+                nmatches++;
+            }
+        }
+    }
+    if (nmatches_out) *nmatches_out = nmatches;
+    return ORBX_OK;
+}
+
+// ---- C1 on the device: Frame::isInFrustum + MapPoint::PredictScale (k_frustum), alone or in front of SearchByProjection(Frame, MapPoints) ----
+namespace {
+struct FrustumDev { uint8_t* in_view; float* track; int* level; AreaQuery* queries; const unsigned long long* qdesc; };
+int enqueue_frustum(orbx_extractor* h, const OrbmFrustumView* V, const OrbmWorldPointView* P, float cos_limit, bool with_queries, float th, int far_points, float th_far,
+                    FrustumDev* out) {
+    if (!V || !P || P->M < 0 || (P->M > 0 && (!P->pos || !P->normal || !P->min_distance || !P->max_distance))) return fail(ORBX_E_ARG, "bad frustum arguments");
+    if (V->nlevels < 1 || V->nlevels > kMaxLevels || !V->scale_factors) return fail(ORBX_E_ARG, "bad scale levels");
+    const int M = P->M; const size_t M1 = M > 0 ? M : 1;
+    // inputs -> d_sr[SR_QUERY]: [queries][descriptors][pos][normal][min][max][bad]; outputs -> d_sr[SR_SPARE]: [track 5 M][level M][in_view M]
+    const size_t oq = 0, od = oq + al16(sizeof(AreaQuery) * M1), op = od + al16(32 * M1), on = op + al16(12 * M1), omn = on + al16(12 * M1), omx = omn + al16(4 * M1),
+                 ob = omx + al16(4 * M1), total = ob + al16(M1);
+    const size_t ot = 0, ol = ot + al16(20 * M1), ov = ol + al16(4 * M1), ototal = ov + al16(M1);
+    if (h->h_packB.ensure(total + 16) || h->d_sr[SR_QUERY].ensure(total + 16) || h->d_sr[SR_SPARE].ensure(ototal + 16)) return fail(ORBX_E_DEVICE, "upload/allocation failed");
+    uint8_t* hp = h->h_packB.p;
+    if (M > 0) {
+        if (P->desc) memcpy(hp + od, P->desc, 32 * (size_t)M); else if (with_queries) return fail(ORBX_E_ARG, "map point descriptors missing");
+        memcpy(hp + op, P->pos, 12 * (size_t)M); memcpy(hp + on, P->normal, 12 * (size_t)M);
+        memcpy(hp + omn, P->min_distance, 4 * (size_t)M); memcpy(hp + omx, P->max_distance, 4 * (size_t)M);
+        if (P->is_bad) memcpy(hp + ob, P->is_bad, M); else memset(hp + ob, 0, M);
+    }
+    if (rt::copy_h2d(h->d_sr[SR_QUERY].p + od, hp + od, total - od, h->s0)) return fail(ORBX_E_DEVICE, "upload failed");
+    FrustumParams F; memset(&F, 0, sizeof F);
+    memcpy(F.Rcw, V->Rcw, sizeof F.Rcw); memcpy(F.tcw, V->tcw, sizeof F.tcw); memcpy(F.Ow, V->Ow, sizeof F.Ow);
+    memcpy(F.cam, V->cam, sizeof F.cam); F.kb8 = V->camera_type == 1;
+    F.min_x = V->min_x; F.max_x = V->max_x; F.min_y = V->min_y; F.max_y = V->max_y; F.mbf = V->mbf; F.log_scale_factor = V->log_scale_factor; F.nlevels = V->nlevels;
+    for (int l = 0; l < V->nlevels; l++) F.scale_factors[l] = V->scale_factors[l];
+    F.cos_limit = cos_limit; F.th = th; F.th_far = th_far; F.far_points = far_points;
+    uint8_t* di = h->d_sr[SR_QUERY].p; uint8_t* dout = h->d_sr[SR_SPARE].p;
+    out->in_view = dout + ov; out->track = (float*)(dout + ot); out->level = (int*)(dout + ol);
+    out->queries = with_queries ? (AreaQuery*)(di + oq) : nullptr; out->qdesc = (const unsigned long long*)(di + od);
+    if (M > 0) {
+        dim3 grid((M + 255) / 256, 1, 1), blk(256, 1, 1);
+        ORBX_LAUNCH(k_frustum, grid, blk, 0, h->s0, F, M, (const float*)(di + op), (const float*)(di + on), (const float*)(di + omn), (const float*)(di + omx),
+                    (const uint8_t*)(di + ob), out->in_view, out->track, out->level, out->queries);
+    }
+    return ORBX_OK;
+}
+// copies the tracking fields back (whatever the caller asked for); in_view always comes back through `inv`
+int fetch_frustum(orbx_extractor* h, int M, const FrustumDev& D, const OrbmTrackOut* out, std::vector<uint8_t>* inv) {
+    if (M <= 0) return ORBX_OK;
+    const size_t M1 = M;
+    std::vector<float> tr(5 * M1); std::vector<int> lv(M1);
+    inv->assign(M1, 0);
+    int e = rt::copy_d2h(inv->data(), D.in_view, M1, h->s0);
+    const bool want = out && (out->proj_x || out->proj_y || out->proj_xr || out->depth || out->view_cos || out->scale_level);
+    if (want) e |= rt::copy_d2h(tr.data(), D.track, 20 * M1, h->s0) | rt::copy_d2h(lv.data(), D.level, 4 * M1, h->s0);
+    if (e || rt::stream_sync(h->s0) || rt::check_launch()) return fail(ORBX_E_DEVICE, "frustum kernel failed: %s", rt::last_error());
+    if (out) {
+        if (out->in_view) memcpy(out->in_view, inv->data(), M1);
+        if (out->proj_x) memcpy(out->proj_x, &tr[0], 4 * M1);
+        if (out->proj_y) memcpy(out->proj_y, &tr[M1], 4 * M1);
+        if (out->proj_xr) memcpy(out->proj_xr, &tr[2 * M1], 4 * M1);
+        if (out->depth) memcpy(out->depth, &tr[3 * M1], 4 * M1);
+        if (out->view_cos) memcpy(out->view_cos, &tr[4 * M1], 4 * M1);
+        if (out->scale_level) memcpy(out->scale_level, lv.data(), 4 * M1);
+    }
+    return ORBX_OK;
+}
+}  // namespace
+
+int orbm_is_in_frustum(orbx_extractor* h, const OrbmFrustumView* V, const OrbmWorldPointView* P, float cos_limit, const OrbmTrackOut* out) {
+    if (!h || !out) return fail(ORBX_E_ARG, "null");
+    rt::set_device(h->device);
+    FrustumDev D;
+    int rc = enqueue_frustum(h, V, P, cos_limit, false, 1.0f, 0, 0.0f, &D); if (rc) return rc;
+    std::vector<uint8_t> inv;
+    return fetch_frustum(h, P->M, D, out, &inv);
+}
+
+// Tracking::SearchLocalPoints' device part (src/Tracking.cc:4009-4067): Frame::isInFrustum for every candidate map point, then
+// ORBmatcher::SearchByProjection(Frame, MapPoints, th, bFarPoints, thFarPoints) on the points in view - the window queries never leave the device.
+int orbm_search_local_points(orbx_extractor* h, const OrbmFrameView* F, const OrbmFrustumView* V, const OrbmWorldPointView* P, float cos_limit, float th,
+                             int far_points, float th_far, float nnratio, const OrbmTrackOut* out, int* assigned, int* nmatches_out) {
+    if (!h || !F || !V || !P || !assigned) return fail(ORBX_E_ARG, "null");
+    rt::set_device(h->device);
+    DeviceFrame D;
+    int rc = upload_frame(h, F, &D); if (rc) return rc;
+    FrustumDev Q;
+    rc = enqueue_frustum(h, V, P, cos_limit, true, th, far_points, th_far, &Q); if (rc) return rc;
+    const int M = P->M, N = F->N;
+    Csr c;
+    rc = run_area_search_dev(h, D, M, Q.queries, Q.qdesc, &c); if (rc) return rc;
+    std::vector<uint8_t> inv;
+    rc = fetch_frustum(h, M, Q, out, &inv); if (rc) return rc;
+    // ---- sequential replay of src/ORBmatcher.cc:62-166 (a query without candidates - not in view, far, bad - has count 0) ----
+    std::vector<uint8_t> occ(N > 0 ? N : 1, 0);
+    if (F->occupied) memcpy(occ.data(), F->occupied, N);
+    for (int i = 0; i < N; i++) assigned[i] = -1;
+    int nmatches = 0;
+    for (int i = 0; i < M; i++) {
+        if (c.count[i] == 0) continue;
         int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
         for (int k = 0; k < c.count[i]; k++) {
             const int idx = c.ent[2 * (size_t)(c.start[i] + k)], dl = c.ent[2 * (size_t)(c.start[i] + k) + 1];

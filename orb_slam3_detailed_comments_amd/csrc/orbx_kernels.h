@@ -69,6 +69,9 @@ __global__ void k_area_search(const AreaQuery* __restrict__ queries, const unsig
                               const unsigned long long* __restrict__ fdesc, GridParams g, const int* __restrict__ cell_start,
                               const int* __restrict__ cell_items, int gate_right, int* __restrict__ pool_counter, int pool_cap,
                               int* __restrict__ q_start, int* __restrict__ q_count, int2* __restrict__ entries);
+__global__ void k_frustum(FrustumParams F, int M, const float* __restrict__ pos, const float* __restrict__ normal, const float* __restrict__ min_dist,
+                          const float* __restrict__ max_dist, const uint8_t* __restrict__ is_bad, uint8_t* __restrict__ in_view, float* __restrict__ track,
+                          int* __restrict__ scale_level, AreaQuery* __restrict__ queries);
 __global__ void k_bow_search(const BowItem* __restrict__ items, int nitems, const KeyPointRec* __restrict__ kps1,
                              const unsigned long long* __restrict__ desc1, const float* __restrict__ ur1,
                              const KeyPointRec* __restrict__ kps2, const unsigned long long* __restrict__ desc2,

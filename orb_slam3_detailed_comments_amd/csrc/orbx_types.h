@@ -61,6 +61,16 @@ struct AreaQuery {                                                // one GetFeat
     float x, y, r, ur;
     int min_level, max_level, active, gate;                      // gate: 0 none, 1 right coordinate (ORBmatcher.cc:107-117), 2 Fuse chi-square (:1437-1469)
 };
+struct FrustumParams {                                            // what Frame::isInFrustum reads of the Frame (src/Frame.cc:667-773)
+    float Rcw[9], tcw[3], Ow[3];                                  // mRcw (row-major), mtcw, mOw
+    float cam[8]; int kb8;                                        // mpCamera: pinhole fx, fy, cx, cy or the 8 Kannala-Brandt parameters
+    float min_x, max_x, min_y, max_y, mbf;
+    float log_scale_factor; int nlevels;                          // mfLogScaleFactor, mnScaleLevels (MapPoint::PredictScale)
+    float scale_factors[kMaxLevels];
+    float cos_limit;                                              // viewingCosLimit
+    // SearchByProjection(Frame, MapPoints) query parameters when the queries are produced on the device
+    float th, th_far; int far_points;
+};
 struct VocSlot { int node_id, child_start, child_cnt, word_id; };   // one vocabulary node; children occupy consecutive slots
 struct BowItem { int idx1, start2, cnt2, out_off; };
 struct BowParams {

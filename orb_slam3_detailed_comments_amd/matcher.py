@@ -195,6 +195,61 @@ def ComputeStereoFishEyeMatches(left, right, cam1, cam2, R12, t12, left_first=0,
     return out
 
 
+class _FrustumView(C.Structure):
+    _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("camera_type", C.c_int), ("cam", C.c_float * 8),
+                ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float), ("mbf", C.c_float), ("log_scale_factor", C.c_float),
+                ("nlevels", C.c_int), ("scale_factors", C.c_void_p)]
+
+
+class _WorldPointView(C.Structure):
+    _fields_ = [("M", C.c_int), ("pos", C.c_void_p), ("normal", C.c_void_p), ("min_distance", C.c_void_p), ("max_distance", C.c_void_p), ("is_bad", C.c_void_p),
+                ("has_obs", C.c_void_p), ("desc", C.c_void_p)]
+
+
+class _TrackOut(C.Structure):
+    _fields_ = [("in_view", C.c_void_p), ("proj_x", C.c_void_p), ("proj_y", C.c_void_p), ("proj_xr", C.c_void_p), ("depth", C.c_void_p), ("view_cos", C.c_void_p),
+                ("scale_level", C.c_void_p)]
+
+
+def SearchLocalPoints(ext, frame, Rcw, tcw, cam, bounds, mbf, scale_factors, pos, normal, min_distance, max_distance, is_bad=None, has_obs=None, desc=None,
+                      viewing_cos_limit=0.5, th=1.0, far_points=False, th_far=50.0, nnratio=0.8, search=True):
+    """Frame::isInFrustum (src/Frame.cc:667-773) for M map points and, with search=True, ORBmatcher::SearchByProjection(F, points, th, ...)
+    (src/ORBmatcher.cc:45-167) on those in view - Tracking::SearchLocalPoints (src/Tracking.cc:4009-4067) on the device.
+    cam: (fx, fy, cx, cy) or the 8 Kannala-Brandt parameters; bounds = (min_x, max_x, min_y, max_y); frame: views.frame_view(...).
+    Returns (track dict, assigned[N] or None, nmatches)."""
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    Rcw, tcw, pos, normal, mn, mx, sf = f32(Rcw).reshape(3, 3), f32(tcw).reshape(3), f32(pos).reshape(-1, 3), f32(normal).reshape(-1, 3), f32(min_distance), f32(max_distance), f32(scale_factors)
+    M = len(pos)
+    V = _FrustumView()
+    V.Rcw[:] = Rcw.ravel().tolist(); V.tcw[:] = tcw.tolist()
+    # mOw = Twc.translation() = -(Rcw^T tcw) in the reference's fp32 order (Sophus stand-in: R^T * t summed left to right, then negated)
+    Rt = Rcw.T.copy()
+    ow = [-np.float32(np.float32(np.float32(Rt[i, 0] * tcw[0]) + np.float32(Rt[i, 1] * tcw[1])) + np.float32(Rt[i, 2] * tcw[2])) for i in range(3)]
+    V.Ow[:] = [float(v) for v in ow]
+    cam = [float(v) for v in cam]
+    V.camera_type = 1 if len(cam) == 8 else 0
+    V.cam[:] = cam + [0.0] * (8 - len(cam))
+    V.min_x, V.max_x, V.min_y, V.max_y = [float(v) for v in bounds]
+    V.mbf = float(mbf); V.log_scale_factor = float(np.float32(np.log(np.float64(sf[1])))) if len(sf) > 1 else 1.0
+    V.nlevels = len(sf); V.scale_factors = sf.ctypes.data
+    P = _WorldPointView()
+    bad = None if is_bad is None else np.ascontiguousarray(is_bad, np.uint8); obs = None if has_obs is None else np.ascontiguousarray(has_obs, np.uint8)
+    d = None if desc is None else np.ascontiguousarray(desc, np.uint8)
+    P.M = M; P.pos = pos.ctypes.data; P.normal = normal.ctypes.data; P.min_distance = mn.ctypes.data; P.max_distance = mx.ctypes.data
+    P.is_bad = None if bad is None else bad.ctypes.data; P.has_obs = None if obs is None else obs.ctypes.data; P.desc = None if d is None else d.ctypes.data
+    tr = dict(in_view=np.zeros(max(M, 1), np.uint8), proj_x=np.zeros(max(M, 1), np.float32), proj_y=np.zeros(max(M, 1), np.float32), proj_xr=np.zeros(max(M, 1), np.float32),
+              depth=np.zeros(max(M, 1), np.float32), view_cos=np.zeros(max(M, 1), np.float32), scale_level=np.zeros(max(M, 1), np.int32))
+    T = _TrackOut(*[tr[k].ctypes.data for k in ("in_view", "proj_x", "proj_y", "proj_xr", "depth", "view_cos", "scale_level")])
+    L = ext._lib
+    if not search:
+        L.check(L.L.orbm_is_in_frustum(ext._h, C.byref(V), C.byref(P), float(viewing_cos_limit), C.byref(T)))
+        return {k: v[:M] for k, v in tr.items()}, None, 0
+    assigned = np.full(max(frame.view.N, 1), -1, np.int32); n = C.c_int(0)
+    L.check(L.L.orbm_search_local_points(ext._h, frame.ref(), C.byref(V), C.byref(P), float(viewing_cos_limit), float(th), int(far_points), float(th_far), float(nnratio),
+                                         C.byref(T), assigned.ctypes.data, C.byref(n)))
+    return {k: v[:M] for k, v in tr.items()}, assigned[:frame.view.N], n.value
+
+
 def GetFeaturesInArea(ext, frame, x, y, r, minLevel=-1, maxLevel=-1):
     """Frame::GetFeaturesInArea (src/Frame.cc:859): keypoint indices in the reference's order."""
     cap = max(frame.view.N, 1)

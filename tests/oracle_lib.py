@@ -470,6 +470,23 @@ class ReferenceFrame:
         if getattr(self, "h", None):
             self.L.ref_frame_destroy(self.h); self.h = None
 
+    def search_local_points(self, R, t, pos, normal, min_dist, max_dist, bad, has_obs, desc, cos_limit=0.5, search=True, th=1.0, far_points=False, th_far=50.0, nnratio=0.8):
+        """Frame::SetPose + Frame::isInFrustum for every point + ORBmatcher::SearchByProjection(F, points, th, bFarPoints, thFarPoints) on the
+        reference's own code.  Returns (track dict, assigned[N], nmatches)."""
+        M = len(pos)
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        R, t, pos, normal, min_dist, max_dist = f32(R), f32(t), f32(pos), f32(normal), f32(min_dist), f32(max_dist)
+        bad = np.ascontiguousarray(bad, np.uint8); has_obs = np.ascontiguousarray(has_obs, np.uint8); desc = np.ascontiguousarray(desc, np.uint8)
+        track = np.zeros((7, max(M, 1)), np.float32); assigned = np.full(max(self.N, 1), -1, np.int32)
+        self.L.ref_frame_search_local_points.restype = C.c_int
+        self.L.ref_frame_search_local_points.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 7 + [C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        n = self.L.ref_frame_search_local_points(self.h, R.ctypes.data, t.ctypes.data, M, pos.ctypes.data, normal.ctypes.data, min_dist.ctypes.data, max_dist.ctypes.data,
+                                                 bad.ctypes.data, has_obs.ctypes.data, desc.ctypes.data, cos_limit, track.ctypes.data, int(search), th, int(far_points), th_far, nnratio,
+                                                 assigned.ctypes.data)
+        tr = dict(in_view=track[0, :M] > 0, proj_x=track[1, :M], proj_y=track[2, :M], proj_xr=track[3, :M], depth=track[4, :M], view_cos=track[5, :M],
+                  scale_level=track[6, :M].astype(np.int32))
+        return tr, assigned[:self.N], n
+
     def features_in_area(self, x, y, r, min_level=-1, max_level=-1):
         idx = np.zeros(max(self.N, 1), np.int32)
         n = self.L.ref_frame_features_in_area(self.h, x, y, r, min_level, max_level, idx.ctypes.data, len(idx))
