@@ -1,16 +1,16 @@
 #!/usr/bin/env python
 """Headline benchmark (BASELINE.json): stereo pairs/s of ORB extract (left+right) + ComputeStereoMatches on 752x480
-EuRoC-shaped rectified pairs, nFeatures=1200, 8 levels — config[1] of BASELINE.json — on N GPUs of one node.
+EuRoC-shaped rectified pairs, nFeatures=1200, 8 levels — configs[1] of BASELINE.json — on N GPUs of one node.
 
 One "step" = one pass of the hot path over one batch of `--pairs` synthetic stereo pairs per GPU that are already
 resident in HBM: import -> pyramid -> FAST cells -> quadtree -> blur -> IC-angle + rBRIEF -> stereo row search/SAD/
 sub-pixel/median, and the results (keypoints, descriptors, uRight, depth) copied back to host memory.
 Multi-GPU: independent image streams, one process per GPU, no data-path collective (weak scaling).
 
+`--config` selects another BASELINE.json configuration (mono / fisheye / rgbd: parity cases, not the headline metric).
 Prints ONE JSON line (rank 0).  See DESIGN.md §Measurement for the roofline / cpu_baseline definitions.
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -21,12 +21,37 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W, H, NFEAT, NLEVELS, SCALE, INI, MIN = 752, 480, 1200, 8, 1.2, 20, 7     # Examples/Stereo/EuRoC.yaml:67-80
+NLEVELS, SCALE, INI, MIN = 8, 1.2, 20, 7                                   # Examples/*/*.yaml ORBextractor.*
+FX, FY, CX, CY = 458.654, 457.296, 367.215, 248.375                         # Examples/Stereo/EuRoC.yaml:17-20
 BF, BASE = 458.654 * 0.110074, 0.110074                                    # EuRoC.yaml:23,57
 HBM_PEAK_GBS = 8000.0                                                      # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 2                              # 1024 SIMD-32 x 2.4 GHz, one wave64 instruction per 2 clk
+# Examples/Stereo/TUM-VI.yaml:11-32
+KB_CAM1 = [190.978477, 190.973307, 254.931706, 256.897442, 0.003482389402, 0.000715034845, -0.002053236141, 0.000202936736]
+KB_CAM2 = [190.442369, 190.434438, 252.598711, 254.917238, 0.003400603976, 0.001766924711, -0.002663898171, 0.000329921072]
+KB_RLR = np.array([[0.999999445773493, 0.000791687752817, 0.000694034010224], [-0.000823363992158, 0.998899461915674, 0.046895490788700],
+                   [-0.000656143613422, -0.046896036240590, 0.998899559977407]], np.float32)
+KB_TLR = np.array([0.100931237881590, 0.000570764538347, 0.001046438762054], np.float32)
+
+CONFIGS = {
+    "stereo": dict(W=752, H=480, nf=1200, lap=(0, 0), kind="stereo", unit="stereo pairs/s",
+                   metric="frames/sec ORB extract+match, 752x480 stereo @1200 feat (1 frame = 1 stereo pair; BASELINE.json configs[1])",
+                   workload="EuRoC-shaped stereo 752x480, nFeatures=1200, 8 levels: extract L+R + ComputeStereoMatches (BASELINE.json configs[1])"),
+    "mono": dict(W=752, H=480, nf=1000, lap=(0, 1000), kind="mono", unit="frames/s",
+                 metric="frames/sec ORB extraction, 752x480 mono @1000 feat (BASELINE.json configs[0])",
+                 workload="EuRoC-shaped mono 752x480, nFeatures=1000, 8 levels, lapping {0,1000}: ORBextractor::operator() (BASELINE.json configs[0])"),
+    "fisheye": dict(W=512, H=512, nf=1500, lap=(0, 511), kind="fisheye", unit="stereo pairs/s",
+                    metric="frames/sec ORB extract+match, 512x512 fisheye stereo @1500 feat (1 frame = 1 stereo pair; BASELINE.json configs[2])",
+                    workload="TUM-VI-shaped fisheye stereo 512x512 (Kannala-Brandt), nFeatures=1500, lapping {0,511}: extract L+R + ComputeStereoFishEyeMatches "
+                             "(2-NN + ratio + triangulation gate) (BASELINE.json configs[2])"),
+    "rgbd": dict(W=640, H=480, nf=1000, lap=(0, 0), kind="rgbd", unit="frames/s",
+                 metric="frames/sec ORB extract + SearchLocalPoints, 640x480 RGB-D @1000 feat, 5000 map points (BASELINE.json configs[3])",
+                 workload="TUM-RGB-D-shaped 640x480 RGB frames, nFeatures=1000: cvtColor + extraction on the device, then per frame isInFrustum + "
+                          "SearchByProjection against a 5000-point local map (BASELINE.json configs[3])"),
+}
 
 
-def level_pixels():
+def level_pixels(W, H):
     inv = [1.0]
     s = np.float32(1.0)
     for _ in range(1, NLEVELS):
@@ -35,9 +60,9 @@ def level_pixels():
     return [int(np.rint(np.float32(W) * np.float32(i))) * int(np.rint(np.float32(H) * np.float32(i))) for i in inv]
 
 
-def algorithmic_bytes(n_kp, n_cand, n_right):
-    """Compulsory bytes per IMAGE of each extractor kernel and per PAIR of the matcher."""
-    px = level_pixels()
+def algorithmic_bytes(W, H, n_kp, n_cand):
+    """Compulsory bytes per IMAGE of each extractor kernel and per PAIR of the stereo matcher."""
+    px = level_pixels(W, H)
     P, P0, P7 = sum(px), px[0], px[-1]
     return {
         "import": 2 * P0,
@@ -51,40 +76,58 @@ def algorithmic_bytes(n_kp, n_cand, n_right):
     }
 
 
-def cpu_baseline(seconds_budget=15.0):
-    """Reference CPU path timed on the host cores on the same workload: per stereo pair the reference's OWN stereo Frame constructor
-    (src/Frame.cc:105-230, compiled unmodified into oracle/_ref/libref_frame.so: two ORBextractor calls on two threads, then
-    Frame::ComputeStereoMatches and the grid assignment), with long-lived extractors as Tracking holds them.  `cores` threads = cores / 2
-    independent pair streams x the constructor's two extraction threads.  Without oracle/_ref the oracle restatement is timed ("port")."""
+def cpu_baseline(seconds_budget=6.0):
+    """The reference CPU path on the host cores, same workload, same run: per stereo pair the reference's OWN stereo Frame constructor
+    (src/Frame.cc:105-230, compiled unmodified into oracle/_ref/libref_frame.so with REGISTER_TIMES: two ORBextractor calls on two
+    threads, Frame::ComputeStereoMatches, the grid assignment), long-lived extractors as Tracking holds them.  Three settings
+    (SURVEY.md §8d): the process pinned to one core, to two cores (left || right as the reference runs them), and every core with
+    cores / 2 independent pair streams; `value` is the last one.  The two stage times are the reference's own timers
+    ("ORB Extraction" src/Frame.cc:132-146, "Stereo Matching" :158-170, printed at src/Tracking.cc:324-334).
+    Without oracle/_ref the oracle restatement is timed ("port")."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import threading
     import oracle_lib as ol
     from orb_slam3_detailed_comments_amd import synth
-    cores = min(8, os.cpu_count() or 1)
+    c = CONFIGS["stereo"]
+    W, H, NFEAT = c["W"], c["H"], c["nf"]
+    avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    cores = len(avail)
     if ol.reference_frame_lib() is not None:
-        streams = max(1, cores // 2)
-        pairs = [synth.stereo_pair(W, H, seed=1000 + i) for i in range(streams)]
-        out = [None] * streams
+        def run(streams, secs):
+            pairs = [synth.stereo_pair(W, H, seed=1000 + i) for i in range(streams)]
+            out = [None] * streams
 
-        def work(t):
-            out[t] = ol.reference_frame_repeat(pairs[t][0], pairs[t][1], seconds_budget, NFEAT, fx=458.654, bf=BF)
+            def work(t):
+                out[t] = ol.reference_frame_repeat(pairs[t][0], pairs[t][1], secs, NFEAT, fx=FX, bf=BF)
+            t0 = time.time()
+            th = [threading.Thread(target=work, args=(t,)) for t in range(streams)]
+            [x.start() for x in th]
+            [x.join() for x in th]
+            dt = time.time() - t0
+            n = sum(o[0] for o in out)
+            ext = sum(o[3] for o in out) / max(n, 1); st = sum(o[4] for o in out) / max(n, 1)
+            return n, dt, out[0][2], ext, st
 
-        t0 = time.time()
-        th = [threading.Thread(target=work, args=(t,)) for t in range(streams)]
-        [x.start() for x in th]
-        [x.join() for x in th]
-        dt = time.time() - t0
-        n = sum(o[0] for o in out)
-        sample = ("%d pairs in %.1f s: %d concurrent streams of the reference's own stereo Frame constructor (src/Frame.cc:105-230 = 2 extractor threads "
-                  "+ ComputeStereoMatches + grid), %d stereo matches on the last pair; OpenCV primitives are the scalar shim, not SIMD OpenCV, so this "
-                  "under-states a real OpenCV build" % (n, dt, streams, out[0][2]))
-        return {"value": round(n / dt, 2), "unit": "stereo pairs/s", "cores": 2 * streams, "kind": "reference", "sample": sample}
+        res = {}
+        settings = [("one_core", avail[:1], 1), ("two_cores", avail[:2], 1), ("all_cores", avail, max(1, cores // 2))]
+        for name, cpus, streams in settings:
+            if hasattr(os, "sched_setaffinity"):
+                os.sched_setaffinity(0, set(cpus))
+            n, dt, matches, ext, st = run(streams, seconds_budget)
+            res[name] = {"value": round(n / dt, 2), "cores": len(cpus), "pair_streams": streams, "pairs": n, "seconds": round(dt, 2),
+                         "stage_ms": {"ORB Extraction": round(ext, 3), "Stereo Matching": round(st, 3)}, "stereo_matches_last_pair": matches}
+        if hasattr(os, "sched_setaffinity"):
+            os.sched_setaffinity(0, set(avail))
+        a = res["all_cores"]
+        sample = ("%d pairs in %.1f s: %d concurrent streams of the reference's own stereo Frame constructor (src/Frame.cc:105-230 = 2 extractor threads + "
+                  "ComputeStereoMatches + grid) on %d cores; one_core / two_cores = one stream with the process pinned to 1 / 2 cores; OpenCV primitives are the "
+                  "scalar shim, not SIMD OpenCV, so this under-states a real OpenCV build" % (a["pairs"], a["seconds"], a["pair_streams"], a["cores"]))
+        return {"value": a["value"], "unit": "stereo pairs/s", "cores": a["cores"], "kind": "reference", "sample": sample,
+                "one_core": res["one_core"], "two_cores": res["two_cores"], "all_cores": a, "stage_ms": a["stage_ms"]}
     pairs = [synth.stereo_pair(W, H, seed=1000 + i) for i in range(cores)]
     done = [0] * cores
-    state = []
-    for t in range(cores):
-        state.append((ol.OracleExtractor(NFEAT), ol.OracleExtractor(NFEAT)))
-    t_end = time.time() + seconds_budget
+    state = [(ol.OracleExtractor(NFEAT), ol.OracleExtractor(NFEAT)) for _ in range(cores)]
+    t_end = time.time() + 2.5 * seconds_budget
 
     def work(t):
         oL, oR = state[t]
@@ -107,16 +150,20 @@ def cpu_baseline(seconds_budget=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=128, help="stereo pairs per step per GPU (one step = one batch through the whole path; "
-                    "32 -> 52 k, 64 -> 57 k, 96 -> 59 k, 128 -> 60 k pairs/s measured)")
-    ap.add_argument("--handles", type=int, default=3, help="extractor handles in flight per GPU (each owns two streams); three independent "
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="stereo", choices=sorted(CONFIGS), help="BASELINE.json configuration (stereo = configs[1] = the headline metric)")
+    ap.add_argument("--pairs", type=int, default=128, help="units (stereo pairs, or frames for mono / rgbd) per step per GPU: one step = one batch through the "
+                    "whole path (32 -> 52 k, 64 -> 57 k, 96 -> 59 k, 128 -> 60 k pairs/s measured in round 1)")
+    ap.add_argument("--handles", type=int, default=3, help="extractor handles in flight per GPU (each owns its streams); three independent "
                     "kernel chains measured best and, unlike four, insensitive to how the HIP runtime maps streams to hardware queues")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--h2d", action="store_true", help="PCIe-inclusive variant (NOT the headline value): upload the input images from pinned "
-                    "host memory inside the timed region")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the second, PCIe-inclusive measurement (never `value`)")
+    ap.add_argument("--h2d", action="store_true", help="make the PCIe-inclusive variant the timed loop (NOT the headline value)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    W, H, NFEAT, LAP, kind = cfg["W"], cfg["H"], cfg["nf"], cfg["lap"], cfg["kind"]
+    paired = kind in ("stereo", "fisheye")
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -124,74 +171,145 @@ def main():
     if world > 1 or os.environ.get("ORBX_BENCH_FORCE_DIST") == "1":    # the env switch lets a 1-GPU box exercise the torch.distributed path
         import torch
         import torch.distributed as dist_
-        # ORBX_BENCH_BACKEND=gloo: test switch - several ranks may then share one GPU (RCCL refuses that), which lets a 1-GPU box run the
-        # multi-process path end to end; the barrier and the max-reduce go over CPU tensors in that case
+        # ORBX_BENCH_BACKEND=gloo: test switch - several ranks may then share one GPU (RCCL refuses that) or run without one (ORBX_BENCH_LIB), which
+        # lets a box without 8 GPUs run the multi-process path end to end; the barrier and the max-reduce go over CPU tensors in that case
         backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")
-        ndev = torch.cuda.device_count()
-        local = local % max(ndev, 1)
-        torch.cuda.set_device(local)
         if backend == "nccl":
+            ndev = torch.cuda.device_count()
+            local = local % max(ndev, 1)
+            torch.cuda.set_device(local)
             dist_.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
+            local = 0
             dist_.init_process_group(backend)
         dist = dist_
         dist_dev = "cuda" if backend == "nccl" else "cpu"
 
-    from orb_slam3_detailed_comments_amd import ORBextractor, load_hip, synth
-    lib = load_hip()
+    from orb_slam3_detailed_comments_amd import ORBextractor, load_hip, synth, _lib
+    from orb_slam3_detailed_comments_amd import matcher as M
+    # ORBX_BENCH_LIB: test switch (tests/test_multi_gloo.py runs this file's distributed path on the CPU emulator build of the kernels)
+    lib = _lib.OrbxLib(os.environ["ORBX_BENCH_LIB"]) if os.environ.get("ORBX_BENCH_LIB") else load_hip()
     P = args.pairs
-    # synthetic EuRoC-shaped rectified pairs; every rank (= camera stream shard) gets its own seeds
-    ls, rs = [], []
-    for i in range(P):
-        l, r = synth.stereo_pair(W, H, seed=rank * 100003 + i)
-        ls.append(l); rs.append(r)
-    batch = np.stack(ls + rs)                                   # [2P, H, W]: lefts then rights
+    # synthetic inputs shaped like the configuration's dataset; every rank (= camera stream shard) gets its own seeds
+    if paired:
+        ls, rs = [], []
+        for i in range(P):
+            l, r = synth.stereo_pair(W, H, seed=rank * 100003 + i) if kind == "stereo" else synth.stereo_pair(W, H, seed=rank * 100003 + i, nrect=2000, max_disp=24, band=64)
+            ls.append(l); rs.append(r)
+        batch = np.stack(ls + rs)                               # [2P, H, W]: lefts then rights
+    elif kind == "mono":
+        batch = np.stack([synth.corner_field(W, H, seed=rank * 100003 + i) for i in range(P)])
+    else:
+        nrect = int(3000 * W * H / (752 * 480))
+        batch = np.stack([np.stack([synth.corner_field(W, H, seed=rank * 100003 + i + 7 * c, nrect=nrect) for c in range(3)], axis=2) for i in range(P)])
+    NIMG = 2 * P if paired else P
     NH = max(1, args.handles)
-    handles = [ORBextractor(NFEAT, SCALE, NLEVELS, INI, MIN, device_id=local) for _ in range(NH)]
+    handles = [ORBextractor(NFEAT, SCALE, NLEVELS, INI, MIN, device_id=local, lib=lib) for _ in range(NH)]
+    if kind == "rgbd":
+        for h in handles:
+            h.set_input(3, rgb=True)
     dptrs = [h.device_upload(batch) for h in handles]          # inputs resident in HBM before the timed region
+    shape3 = batch.shape[:3]; stride = batch.strides[1]
     cap = handles[0].max_keypoints()
     for h in handles:
         h.profile(not os.environ.get("ORBX_BENCH_NOPROFILE"), serial=bool(os.environ.get("ORBX_BENCH_SERIAL")))
-    out = [dict(k=h.pinned_empty((2 * P, cap, 28), np.uint8), d=h.pinned_empty((2 * P, cap, 32), np.uint8), n=np.zeros(2 * P, np.int32),
-                m=np.zeros(2 * P, np.int32), u=h.pinned_empty((P, cap), np.float32), z=h.pinned_empty((P, cap), np.float32), nm=np.zeros(P, np.int32))
+    out = [dict(k=h.pinned_empty((NIMG, cap, 28), np.uint8), d=h.pinned_empty((NIMG, cap, 32), np.uint8), n=np.zeros(NIMG, np.int32),
+                m=np.zeros(NIMG, np.int32), u=h.pinned_empty((P, cap), np.float32), z=h.pinned_empty((P, cap), np.float32), nm=np.zeros(P, np.int32),
+                l2r=np.zeros((P, cap), np.int32), r2l=np.zeros((P, cap), np.int32), p3=np.zeros((P, cap, 3), np.float32))
            for h in handles]
     stage_sum = {}
     stage_cnt = [0]
     nkp = [0, 0]
     nmatch = [0, 0]
+    step_end = []
 
-    host_in = None
-    if args.h2d:
-        host_in = []
-        for h in handles:
-            b = h.pinned_empty(batch.shape, np.uint8); b[...] = batch; host_in.append(b)
+    import ctypes as C
+    kb = None
+    if kind == "fisheye":
+        class Cams(C.Structure):
+            _fields_ = [("cam1", C.c_float * 8), ("cam2", C.c_float * 8), ("R12", C.c_float * 9), ("t12", C.c_float * 3)]
+        kb = Cams()
+        kb.cam1[:] = KB_CAM1; kb.cam2[:] = KB_CAM2; kb.R12[:] = KB_RLR.ravel().tolist(); kb.t12[:] = KB_TLR.tolist()
+    local_map = None
+    if kind == "rgbd":
+        # 50 key frames' worth of local map: 5000 points in front of the camera, descriptors of random keypoints of the first frame
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        rng = np.random.default_rng(7 + rank)
+        handles[0].enqueue(None, LAP, device_ptr=dptrs[0], shape=shape3, stride=stride); r0 = handles[0].fetch()[0]
+        k0, d0 = r0[1], r0[2]
+        Mp = 5000
+        src = rng.integers(0, len(k0), Mp); z = rng.uniform(0.5, 8.0, Mp)
+        X = np.stack([(k0["x"][src] + rng.normal(0, 1.0, Mp) - CX) / FX * z, (k0["y"][src] + rng.normal(0, 1.0, Mp) - CY) / FY * z, z], 1).astype(np.float32)
+        dn = np.linalg.norm(X, axis=1); nrm = (X / dn[:, None]).astype(np.float32)
+        maxd = (dn * 1.2 ** k0["octave"][src]).astype(np.float32); mind = (maxd / 1.2 ** 7).astype(np.float32)
+        dsc = d0[src].copy(); flip = rng.uniform(size=Mp) < 0.6
+        for i in np.nonzero(flip)[0]:
+            for b in rng.choice(256, int(rng.integers(0, 41)), replace=False):
+                dsc[i, b >> 3] ^= np.uint8(1 << (b & 7))
+        dsc[~flip] = rng.integers(0, 256, ((~flip).sum(), 32), dtype=np.uint8)
+        local_map = dict(pos=X, normal=nrm, mind=mind, maxd=maxd, desc=dsc, sfs=handles[0].GetScaleFactors())
 
-    def enqueue(i):
+    # PCIe-inclusive variant: page-locked host copies of the inputs and two device buffers per handle (upload of the next batch beside the kernels)
+    host_in, dbuf, dsel = None, None, None
+
+    def setup_h2d():
+        nonlocal host_in, dbuf, dsel
+        if host_in is None:
+            host_in, dbuf, dsel = [], [], [0] * NH
+            for h in handles:
+                b = h.pinned_empty(batch.shape, np.uint8); b[...] = batch; host_in.append(b)
+                dbuf.append([h.device_alloc(batch.nbytes), h.device_alloc(batch.nbytes)])
+
+    def enqueue(i, h2d=False):
         h = handles[i]
-        if host_in is not None:
-            h.enqueue(host_in[i], (0, 0))
+        if h2d:
+            # the upload of this batch was issued when the previous one of this handle was enqueued (or just now, the first time)
+            if not getattr(h, "_primed", False):
+                h.device_upload_async(dbuf[i][dsel[i]], host_in[i]); h._primed = True
+            h.enqueue(None, LAP, device_ptr=dbuf[i][dsel[i]], shape=shape3, stride=stride)
+            dsel[i] ^= 1
+            h.device_upload_async(dbuf[i][dsel[i]], host_in[i])        # next batch of this handle, into the other buffer
         else:
-            h.enqueue(None, (0, 0), device_ptr=dptrs[i], shape=batch.shape)
-        lib.check(lib.L.orbm_stereo_match(h._h, 0, h._h, P, P, BF, BASE))
+            h.enqueue(None, LAP, device_ptr=dptrs[i], shape=shape3, stride=stride)
+        if kind == "stereo":
+            lib.check(lib.L.orbm_stereo_match(h._h, 0, h._h, P, P, BF, BASE))
+        elif kind == "fisheye":
+            lib.check(lib.L.orbm_stereo_fisheye(h._h, 0, h._h, P, P, C.byref(kb)))
 
     def fetch(i, record):
         h, o = handles[i], out[i]
         lib.check(lib.L.orbx_fetch(h._h, o["k"].ctypes.data, o["d"].ctypes.data, cap, o["n"].ctypes.data, o["m"].ctypes.data))
-        lib.check(lib.L.orbm_stereo_fetch(h._h, P, o["u"].ctypes.data, o["z"].ctypes.data, cap, o["nm"].ctypes.data))
+        if kind == "stereo":
+            lib.check(lib.L.orbm_stereo_fetch(h._h, P, o["u"].ctypes.data, o["z"].ctypes.data, cap, o["nm"].ctypes.data))
+        elif kind == "fisheye":
+            lib.check(lib.L.orbm_stereo_fisheye_fetch(h._h, P, o["l2r"].ctypes.data, o["r2l"].ctypes.data, o["z"].ctypes.data, o["p3"].ctypes.data, o["nm"].ctypes.data, cap))
+        elif kind == "rgbd":
+            from orb_slam3_detailed_comments_amd import views
+            from orb_slam3_detailed_comments_amd._lib import KP_DTYPE
+            lm = local_map; tot = 0
+            kview = o["k"].view(KP_DTYPE).reshape(NIMG, cap)
+            for b in range(NIMG):
+                n = int(o["n"][b])
+                fv = views.frame_view(kview[b, :n], o["d"][b, :n], lm["sfs"], W, H)
+                _, asg, nm = M.SearchLocalPoints(h, fv, np.eye(3, dtype=np.float32), np.zeros(3, np.float32), (FX, FY, CX, CY), (0.0, float(W), 0.0, float(H)), 0.0, lm["sfs"],
+                                                 lm["pos"], lm["normal"], lm["mind"], lm["maxd"], None, None, lm["desc"], 0.5, 3.0, False, 50.0, 0.8)
+                tot += nm
+            o["nm"][0] = tot
         if record:
+            step_end.append(time.perf_counter())
             for k, v in h.stage_ms().items():
                 stage_sum[k] = stage_sum.get(k, 0.0) + v
             stage_cnt[0] += 1
-            nkp[0] += int(o["n"].sum()); nkp[1] += 2 * P
-            nmatch[0] += int(o["nm"].sum()); nmatch[1] += P
+            nkp[0] += int(o["n"].sum()); nkp[1] += NIMG
+            nmatch[0] += int(o["nm"].sum()) if kind != "rgbd" else int(o["nm"][0]); nmatch[1] += P
 
-    def run(nsteps, record):
+    def run(nsteps, record, h2d=False):
         pending = []
         for s in range(nsteps):
             i = s % NH
             if len(pending) == NH:
                 fetch(pending.pop(0), record)
-            enqueue(i)
+            enqueue(i, h2d)
             pending.append(i)
         while pending:
             fetch(pending.pop(0), record)
@@ -200,22 +318,29 @@ def main():
         for h in handles:
             h.sync()
         if dist is not None:
-            import torch
-            torch.cuda.synchronize()
+            if dist_dev == "cuda":
+                import torch
+                torch.cuda.synchronize()
             dist.barrier()
+
+    def timed(nsteps, h2d):
+        run(min(args.warmup, nsteps) if not h2d else min(6, nsteps), False, h2d)
+        sync_all()
+        del step_end[:]
+        t0 = time.perf_counter()
+        run(nsteps, True, h2d)
+        sync_all()
+        dt = time.perf_counter() - t0
+        ends = [t0] + list(step_end)
+        per = np.diff(np.array(ends)) * 1e3
+        return dt, per
 
     # setup, not a warm-up step: every handle allocates its device buffers and uploads its tables on first use
     for i in range(NH):
         enqueue(i); fetch(i, False)
-    run(args.warmup, False)
-    sync_all()
-    t0 = time.perf_counter()
-    run(args.steps, True)
-    ta = time.perf_counter()
-    sync_all()
-    dt = time.perf_counter() - t0
-    if os.environ.get("ORBX_BENCH_DEBUG"):
-        sys.stderr.write("debug: run %.2f ms, closing sync %.2f ms\n" % ((ta - t0) * 1e3, (time.perf_counter() - ta) * 1e3))
+    if args.h2d:
+        setup_h2d()
+    dt, per_step = timed(args.steps, args.h2d)
     if dist is not None:
         import torch
         t = torch.tensor([dt], dtype=torch.float64, device=dist_dev)
@@ -223,16 +348,18 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        total_pairs = P * args.steps * world
-        value = total_pairs / dt
+        total_units = P * args.steps * world
+        value = total_units / dt
         avg_kp = nkp[0] / max(nkp[1], 1)
         stage_ms = {k: v / max(stage_cnt[0], 1) for k, v in stage_sum.items()}
+        n_timed_records = stage_cnt[0]
+        avg_matches = nmatch[0] / max(nmatch[1], 1)
         # average FAST candidates per image (for the algorithmic-byte model): probe the last batch
         ncand = 0
         for l in range(NLEVELS):
             ncand += len(handles[0].debug_candidates(l, 0))
-        ab = algorithmic_bytes(avg_kp, ncand, avg_kp)
-        units = {k: 2 * P for k in ab}
+        ab = algorithmic_bytes(W, H, avg_kp, ncand)
+        units = {k: NIMG for k in ab}
         units["match"] = P
         # Which kernel dominates is decided on a clean schedule: a few extra steps on ONE handle with every kernel alone on one
         # stream (with several handles in flight an event pair also brackets the time a launch waits for CUs that another
@@ -242,62 +369,80 @@ def main():
         h0.profile(True, serial=True)
         serial_sum = {}
         for _ in range(3):
-            h0.enqueue(None, (0, 0), device_ptr=dptrs[0], shape=batch.shape)
-            lib.check(lib.L.orbm_stereo_match(h0._h, 0, h0._h, P, P, BF, BASE))
-            lib.check(lib.L.orbm_stereo_fetch(h0._h, P, out[0]["u"].ctypes.data, out[0]["z"].ctypes.data, cap, out[0]["nm"].ctypes.data))
+            enqueue(0)
+            if kind in ("stereo", "fisheye"):
+                fetch(0, False)
             h0.sync()
             for k, v in h0.stage_ms().items():
                 serial_sum[k] = serial_sum.get(k, 0.0) + v / 3.0
-        dom = max((k for k in serial_sum if serial_sum[k] > 0), key=lambda k: serial_sum[k])
+        ext_stages = ("import", "pyramid", "fast_cells", "quadtree", "blur", "layout", "orient_brief")
+        dom = max((k for k in serial_sum if serial_sum[k] > 0 and k in ab), key=lambda k: serial_sum[k])
         achieved = ab[dom] * units[dom] / (stage_ms[dom] * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and kind == "stereo":
             try:
                 traffic = json.load(open(pmc)).get(dom)
                 if traffic is not None:
-                    traffic = int(traffic * (2 * P) / 128.0)      # the PMC passes ran at 128 images per launch
+                    traffic = int(traffic * NIMG / 128.0)          # the PMC passes ran at 128 images per launch
             except Exception:
                 traffic = None
-        # VALU issue view of the same kernel (the HBM fraction says little for a compute-heavy integer kernel): wave-instructions per
-        # launch from the SQ counter pass (profiles/pmc_valu.json, scaled to this launch size) against the issue rates MEASURED on this
-        # part with tools/valu_issue_microbench.hip (profiles/r01_final/valu_microbench.txt): v_add_u32 / v_fma_f32 issue at 937 G
-        # wave-instr/s, the classes FAST is made of (VOP3P packed 16-bit min/max/sub/mad, v_perm_b32, v_alignbyte_b32, v_min/max_i32,
-        # v_dot4) at 531-562 G wave-instr/s.  A kernel mixing both classes cannot exceed a rate between the two.
+        # VALU issue view of the same kernel (the HBM fraction says little for a compute-heavy integer kernel): wave-instructions per launch
+        # from the SQ counter pass (profiles/pmc_valu.json, scaled to this launch size) against the SIMD-32 issue peak of one wave64
+        # instruction per 2 clk (1024 SIMDs x 2.4 GHz / 2 = 1228.8 G wave-instr/s; profiles/r02/valu_survey.txt: only the VOP2 integer forms
+        # reach ~2.5 clk, every VOP3 form takes ~4.4 clk, so a kernel built from both classes sits between 45 % and 80 % of that peak at best)
         valu = None
         pv = os.path.join(ROOT, "profiles", "pmc_valu.json")
-        if os.path.exists(pv):
+        if os.path.exists(pv) and kind == "stereo":
             try:
-                n_instr = json.load(open(pv)).get(dom, 0) * (2 * P) / 128.0
-                peak_full, peak_packed = 937e9, 545e9
+                n_instr = json.load(open(pv)).get(dom, 0) * NIMG / 128.0
                 if n_instr > 0:
-                    valu = {"wave_instr_per_launch": int(n_instr), "peak_wave_instr_per_s": peak_full, "packed_class_peak_wave_instr_per_s": peak_packed,
+                    valu = {"wave_instr_per_launch": int(n_instr), "peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR_PER_S,
                             "achieved_wave_instr_per_s": round(n_instr / (stage_ms[dom] * 1e-3), 0), "alone_wave_instr_per_s": round(n_instr / (serial_sum[dom] * 1e-3), 0),
-                            "frac": round(n_instr / (stage_ms[dom] * 1e-3) / peak_full, 4), "alone_frac": round(n_instr / (serial_sum[dom] * 1e-3) / peak_full, 4),
-                            "alone_frac_of_packed_class": round(n_instr / (serial_sum[dom] * 1e-3) / peak_packed, 4)}
+                            "frac": round(n_instr / (stage_ms[dom] * 1e-3) / VALU_PEAK_WAVE_INSTR_PER_S, 4),
+                            "alone_frac": round(n_instr / (serial_sum[dom] * 1e-3) / VALU_PEAK_WAVE_INSTR_PER_S, 4)}
             except Exception:
                 valu = None
-        per_pair_bytes = 2 * sum(v for k, v in ab.items() if k != "match") + ab["match"]
+        per_unit_bytes = (2 if paired else 1) * sum(v for k, v in ab.items() if k != "match") + (ab["match"] if kind == "stereo" else 0)
+        pct = lambda a, q: float(np.percentile(a, q)) if len(a) else None
         res = {
-            "metric": "frames/sec ORB extract+match, 752x480 stereo @1200 feat (1 frame = 1 stereo pair; BASELINE.json configs[1])", "value": round(value, 1),
-            "unit": "stereo pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": cfg["metric"], "value": round(value, 1),
+            "unit": cfg["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "EuRoC-shaped stereo 752x480, nFeatures=1200, 8 levels: extract L+R + ComputeStereoMatches (BASELINE.json configs[1])",
-                       "pairs_per_step_per_gpu": P, "images_per_step_per_gpu": 2 * P, "outputs_copied_to_host": True, "handles_in_flight": NH,
+            "config": {"workload": cfg["workload"], "name": args.config,
+                       "units_per_step_per_gpu": P, "images_per_step_per_gpu": NIMG, "outputs_copied_to_host": True, "handles_in_flight": NH,
                        "inputs": "uploaded from pinned host memory inside the timed region (PCIe-inclusive variant)" if args.h2d else "resident in HBM",
-                       "avg_keypoints_per_image": round(avg_kp, 1), "avg_stereo_matches_per_pair": round(nmatch[0] / max(nmatch[1], 1), 1),
+                       "avg_keypoints_per_image": round(avg_kp, 1), "avg_matches_per_unit": round(avg_matches, 1),
                        "parallelism": "independent streams, %d GPU(s), no collective" % world},
+            # per-step completion intervals of the timed region (rank 0; with several handles in flight a step completes every ms_per_step on average)
+            "step_ms": {"median": round(pct(per_step, 50), 4), "p10": round(pct(per_step, 10), 4), "p90": round(pct(per_step, 90), 4), "n": int(len(per_step))},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(ab[dom] * units[dom]), "avg_launch_ms": round(stage_ms[dom], 4),
                          "alone_launch_ms": round(serial_sum[dom], 4), "alone_GBps": round(ab[dom] * units[dom] / (serial_sum[dom] * 1e-3) / 1e9, 2),
-                         "end_to_end_GBps": round(per_pair_bytes * value / world / 1e9, 2),
-                         "end_to_end_frac": round(per_pair_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5), "valu_issue": valu},
+                         "end_to_end_GBps": round(per_unit_bytes * value / world / 1e9, 2),
+                         "end_to_end_frac": round(per_unit_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5), "valu_issue": valu},
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_alone": {k: round(v, 4) for k, v in serial_sum.items()},
+            # the reference's two instrumented regions (src/Frame.cc:132-146 / :158-170, printed by Tracking::PrintTimeStats), per step, each kernel alone
+            "reference_stage_ms_alone": {"ORB Extraction": round(sum(serial_sum.get(k, 0.0) for k in ext_stages), 4), "Stereo Matching": round(serial_sum.get("match", 0.0), 4)},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if kind == "stereo" and not args.h2d and not args.no_h2d and world == 1 and dist is None:
+            # second measurement, never `value`: the same steps with every input batch uploaded from page-locked host memory inside the timed
+            # region, on each handle's copy stream, double-buffered (upload of batch i + 1 beside the kernels of batch i)
+            try:
+                setup_h2d()
+                for h in handles:
+                    h.profile(False)
+                n2 = max(min(args.steps, 100), 10)
+                dt2, per2 = timed(n2, True)
+                res["h2d_inclusive"] = {"value": round(P * n2 / dt2, 1), "unit": cfg["unit"], "steps": n2, "ms_per_step": round(dt2 / n2 * 1e3, 4),
+                                        "input_MB_per_step": round(batch.nbytes / 1e6, 1), "PCIe_GBps": round(batch.nbytes * n2 / dt2 / 1e9, 1),
+                                        "step_ms": {"median": round(pct(per2, 50), 4), "p10": round(pct(per2, 10), 4), "p90": round(pct(per2, 90), 4)}}
+            except Exception as e:
+                res["h2d_inclusive"] = {"value": None, "error": repr(e)}
+        if kind == "stereo" and not args.no_cpu_baseline and world == 1:
             try:
                 res["cpu_baseline"] = cpu_baseline()
             except Exception as e:   # the baseline is reporting only; never fail the bench on it

@@ -95,6 +95,10 @@ int orbx_pyramid_level(orbx_extractor* h, int image_index, int level, int blurre
 int orbx_device_alloc(orbx_extractor* h, size_t bytes, void** dptr);
 int orbx_device_free(orbx_extractor* h, void* dptr);
 int orbx_device_upload(orbx_extractor* h, void* dptr, const void* host, size_t bytes);
+/* the same on the handle's copy stream, without waiting: the next orbx_extract_batch(..., on_device = 1) of this handle waits for it on the
+ * device, and the copy itself waits until the previous extraction has read its input (upload batch i + 1 while batch i is processed;
+ * `host` should be page-locked, orbx_host_alloc) */
+int orbx_device_upload_async(orbx_extractor* h, void* dptr, const void* host, size_t bytes);
 
 /* page-locked host memory for output buffers: with cap == orbx_max_keypoints() orbx_fetch / orbm_stereo_fetch copy straight
  * into the caller's arrays (no staging, no repacking) and pinned memory makes that copy run at PCIe speed */

@@ -135,7 +135,7 @@ int ref_frame_search_local_points(void* h, const float* R, const float* t, int M
 // pair built in the same storage (the constructor itself runs the two extractions on two threads).  Returns the number of frames
 // constructed in `seconds`; *elapsed = the time they took.
 int ref_frame_stereo_repeat(const uint8_t* L, const uint8_t* R, int w, int h, int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th,
-                            float fx, float fy, float cx, float cy, float bf, float th_depth, double seconds, double* elapsed, int* matches) {
+                            float fx, float fy, float cx, float cy, float bf, float th_depth, double seconds, double* elapsed, int* matches, double* stage_ms) {
     ORBextractor left(nfeatures, scale_factor, nlevels, ini_th, min_th), right(nfeatures, scale_factor, nlevels, ini_th, min_th);
     Pinhole cam(fx, fy, cx, cy);
     cv::Mat imL(h, w, CV_8UC1, (void*)L, (size_t)w), imR(h, w, CV_8UC1, (void*)R, (size_t)w);
@@ -150,6 +150,9 @@ int ref_frame_stereo_repeat(const uint8_t* L, const uint8_t* R, int w, int h, in
         Frame* F = new (storage) Frame(imL, imR, 0.0, &left, &right, nullptr, K, dist, bf, th_depth, &cam);
         int m = 0; for (int i = 0; i < F->N; i++) m += F->mvuRight[i] >= 0;
         *matches = m;
+#ifdef REGISTER_TIMES                          // the reference's own timers (src/Frame.cc:132-146 "ORB Extraction", :158-170 "Stereo Matching")
+        if (stage_ms) { stage_ms[0] += F->mTimeORB_Ext; stage_ms[1] += F->mTimeStereoMatch; }
+#endif
         const float mb = F->mb;
         F->~Frame();
         reinterpret_cast<Frame*>(storage)->mb = mb;

@@ -3,7 +3,7 @@
 // epipolarConstrain (:322-328), TriangulateMatches (:439-523), Triangulate (:553-573), statement by statement over the stand-in Eigen types.
 // KannalaBrandt8.cpp itself cannot be compiled here: it needs Eigen (Matrix<float,3,4>, comma initialisers, JacobiSVD), Sophus and
 // cv::fisheye, none of which exist in this image.  PARITY UNPINNED for this file: in particular Eigen::JacobiSVD<Matrix4f> is replaced by a
-// one-sided (Hestenes) Jacobi SVD in fp32 - a different algorithm from the product's (fp64 eigenvectors of A^T A,
+// one-sided (Hestenes) Jacobi SVD of A (fp64 inside) - a different algorithm from the product's (fp64 eigenvectors of A^T A,
 // orb_slam3_detailed_comments_amd/csrc/kb8_model.h), so that the comparison of the two is a real cross-check (tolerance 1e-4 relative depth).
 #ifndef ORBX_KB8_CAMERA_H
 #define ORBX_KB8_CAMERA_H
@@ -13,27 +13,29 @@ namespace ORB_SLAM3 {
 
 // last column of V of a 4x4 SVD (singular values in descending order): the right singular vector of the smallest singular value
 inline void StandInJacobiSVD_V3(const float A[4][4], float x[4]) {
-    float U[4][4], V[4][4];
-    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { U[i][j] = A[i][j]; V[i][j] = i == j ? 1.f : 0.f; }
-    for (int sweep = 0; sweep < 40; sweep++) {
+    // fp64 inside: an fp32 SVD (Eigen's included) leaves a relative error of ~eps32 / (1 - cos parallax) in the null vector, i.e. up to a few
+    // 1e-4 in the depth of low-parallax pairs - more than the 1e-4 the tests allow between the two implementations
+    double U[4][4], V[4][4];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { U[i][j] = A[i][j]; V[i][j] = i == j ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 60; sweep++) {
         bool rotated = false;
         for (int p = 0; p < 3; p++)
             for (int q = p + 1; q < 4; q++) {
-                float alpha = 0, beta = 0, gamma = 0;
+                double alpha = 0, beta = 0, gamma = 0;
                 for (int k = 0; k < 4; k++) { alpha += U[k][p] * U[k][p]; beta += U[k][q] * U[k][q]; gamma += U[k][p] * U[k][q]; }
-                if (std::fabs(gamma) <= 1e-9f * std::sqrt(alpha * beta) || gamma == 0.f) continue;
+                if (std::fabs(gamma) <= 1e-18 * std::sqrt(alpha * beta) || gamma == 0.0) continue;
                 rotated = true;
-                const float zeta = (beta - alpha) / (2.f * gamma);
-                const float t = (zeta >= 0 ? 1.f : -1.f) / (std::fabs(zeta) + std::sqrt(1.f + zeta * zeta));
-                const float c = 1.f / std::sqrt(1.f + t * t), s = c * t;
-                for (int k = 0; k < 4; k++) { const float a = U[k][p], b = U[k][q]; U[k][p] = c * a - s * b; U[k][q] = s * a + c * b; }
-                for (int k = 0; k < 4; k++) { const float a = V[k][p], b = V[k][q]; V[k][p] = c * a - s * b; V[k][q] = s * a + c * b; }
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
+                for (int k = 0; k < 4; k++) { const double a = U[k][p], b = U[k][q]; U[k][p] = c * a - s * b; U[k][q] = s * a + c * b; }
+                for (int k = 0; k < 4; k++) { const double a = V[k][p], b = V[k][q]; V[k][p] = c * a - s * b; V[k][q] = s * a + c * b; }
             }
         if (!rotated) break;
     }
-    int m = 0; float best = -1;
-    for (int j = 0; j < 4; j++) { float n = 0; for (int k = 0; k < 4; k++) n += U[k][j] * U[k][j]; if (best < 0 || n < best) { best = n; m = j; } }
-    for (int k = 0; k < 4; k++) x[k] = V[k][m];
+    int m = 0; double best = -1;
+    for (int j = 0; j < 4; j++) { double n = 0; for (int k = 0; k < 4; k++) n += U[k][j] * U[k][j]; if (best < 0 || n < best) { best = n; m = j; } }
+    for (int k = 0; k < 4; k++) x[k] = (float)V[k][m];
 }
 
 class KannalaBrandt8 : public GeometricCamera {

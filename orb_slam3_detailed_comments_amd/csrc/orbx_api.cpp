@@ -236,6 +236,7 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
     const int nl = h->nlevels;
     const dim3 blk2(64, 4, 1), blk1(256, 1, 1);
     rt::memset_async(h->d_status.p, 0, 4 * sizeof(int), h->s0);     // the quadtree's capacity flag is per batch, not per handle
+    if (h->copy_pending) { rt::stream_wait_event(h->s0, h->ev_copy); h->copy_pending = false; }   // input uploaded by orbx_device_upload_async
     stage_begin(h, ST_IMPORT, h->s0);
     if (h->in_active && (h->in_channels != 1 || h->in_geometry != 0)) enqueue_input(h, B, d_images, src_w, src_h, stride, image_stride);
     else {
@@ -244,6 +245,7 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
         ORBX_LAUNCH(k_import, grid, blk2, 0, h->s0, (const LevelInfo*)h->d_lv.p, d_images, stride, image_stride, h->d_pyr.p, h->pyr_stride);
     }
     stage_end(h, ST_IMPORT, h->s0);
+    rt::event_record(h->ev_import, h->s0);                          // the input images have been consumed
     stage_begin(h, ST_PYRAMID, h->s0);
     for (int l = 1; l < nl; l++) {
         const LevelInfo& L = h->lv[l]; const LevelInfo& S = h->lv[l - 1];
@@ -347,7 +349,8 @@ int orbx_create(orbx_extractor** out, int nfeatures, float scale_factor, int nle
     orbx_extractor* h = new orbx_extractor();
     h->nfeatures = nfeatures; h->scaleFactor = scale_factor; h->nlevels = nlevels; h->iniTh = ini_th; h->minTh = min_th; h->device = device_id;
     init_tables(h);
-    int e = rt::stream_create(&h->s0) | rt::stream_create(&h->s1) | rt::event_create(&h->ev_fork) | rt::event_create(&h->ev_join) | rt::event_create(&h->ev_done);
+    int e = rt::stream_create(&h->s0) | rt::stream_create(&h->s1) | rt::stream_create(&h->s_copy) | rt::event_create(&h->ev_fork) | rt::event_create(&h->ev_join) |
+            rt::event_create(&h->ev_done) | rt::event_create(&h->ev_copy) | rt::event_create(&h->ev_import);
     for (int i = 0; i < ORBX_NSTAGES; i++) { e |= rt::event_create(&h->ev_stage[i][0]); e |= rt::event_create(&h->ev_stage[i][1]); h->stage_ms[i] = 0; }
     if (e) { delete h; return fail(ORBX_E_DEVICE, "stream/event creation failed"); }
     h->have_streams = true;
@@ -365,8 +368,9 @@ void orbx_destroy(orbx_extractor* h) {
         if (h->graph) (void)hipGraphDestroy(h->graph);
 #endif
         for (int i = 0; i < ORBX_NSTAGES; i++) { rt::event_destroy(h->ev_stage[i][0]); rt::event_destroy(h->ev_stage[i][1]); }
-        rt::event_destroy(h->ev_fork); rt::event_destroy(h->ev_join); rt::event_destroy(h->ev_done);
-        rt::stream_destroy(h->s0); rt::stream_destroy(h->s1);
+        rt::stream_sync(h->s_copy);
+        rt::event_destroy(h->ev_fork); rt::event_destroy(h->ev_join); rt::event_destroy(h->ev_done); rt::event_destroy(h->ev_copy); rt::event_destroy(h->ev_import);
+        rt::stream_destroy(h->s0); rt::stream_destroy(h->s1); rt::stream_destroy(h->s_copy);
     }
     h->d_lv.release(); h->d_cells.release(); h->d_xtab.release(); h->d_ytab.release(); h->d_pyr.release(); h->d_blur.release(); h->d_stage.release();
     h->d_slots.release(); h->d_candA.release(); h->d_candB.release(); h->d_lvl_keys.release(); h->d_cell_count.release(); h->d_lvl_count.release();
@@ -440,7 +444,7 @@ int orbx_extract_batch(orbx_extractor* h, int B, const uint8_t* images, int widt
     // hipGraph replay of the whole extraction (import, 7 dependent resize launches, FAST, quadtree, blur on the second stream,
     // layout, orient+BRIEF): at small batches the ~17 launches are launch/latency-bound.  The graph is keyed on everything that
     // is baked into the kernel arguments and re-captured when any of it changes.
-    if (h->use_graph && !h->profile && !h->in_active) {
+    if (h->use_graph && !h->profile && !h->in_active && !h->copy_pending) {      // (a pending async upload is a dependency outside the graph)
         const bool same = h->graph_exec && h->g_B == B && h->g_images == d_images && h->g_stride == stride && h->g_image_stride == image_stride &&
                           h->g_lap0 == lap0 && h->g_lap1 == lap1 && h->g_W == h->W && h->g_H == h->H && h->g_pyr == h->d_pyr.p && h->g_gauss == h->gauss_variant;
         if (!same) {
@@ -558,6 +562,18 @@ int orbx_device_upload(orbx_extractor* h, void* dptr, const void* host, size_t b
     if (!h || !dptr || !host) return fail(ORBX_E_ARG, "null");
     rt::set_device(h->device);
     if (rt::copy_h2d(dptr, host, bytes, h->s0) || rt::stream_sync(h->s0)) return fail(ORBX_E_DEVICE, "upload failed");
+    return ORBX_OK;
+}
+
+// Asynchronous input upload on the handle's copy stream: returns at once; the next orbx_extract_batch(on_device = 1) of this handle waits
+// for it on the device.  With two device buffers a caller uploads batch i + 1 while batch i is being processed; an upload into the buffer
+// the previous extraction read from waits (on the device) until that extraction has imported its level 0.
+int orbx_device_upload_async(orbx_extractor* h, void* dptr, const void* host, size_t bytes) {
+    if (!h || !dptr || !host) return fail(ORBX_E_ARG, "null");
+    rt::set_device(h->device);
+    rt::stream_wait_event(h->s_copy, h->ev_import);
+    if (rt::copy_h2d(dptr, host, bytes, h->s_copy) || rt::event_record(h->ev_copy, h->s_copy)) return fail(ORBX_E_DEVICE, "upload failed: %s", rt::last_error());
+    h->copy_pending = true;
     return ORBX_OK;
 }
 

@@ -70,8 +70,9 @@ struct orbx_extractor {
     orbx::DevBuf<unsigned long long> d_hamA, d_hamB; orbx::DevBuf<int> d_hamOut;
     orbx::HostBuf<uint8_t> h_stage;
     orbx::HostBuf<int> h_nm;
-    orbx::rt::stream_t s0 = 0, s1 = 0;
-    orbx::rt::event_t ev_fork = 0, ev_join = 0, ev_done = 0;
+    orbx::rt::stream_t s0 = 0, s1 = 0, s_copy = 0;          // s_copy: orbx_device_upload_async (input uploads beside the kernels of the previous batch)
+    orbx::rt::event_t ev_fork = 0, ev_join = 0, ev_done = 0, ev_copy = 0, ev_import = 0;
+    bool copy_pending = false;
     orbx::rt::event_t ev_stage[ORBX_NSTAGES][2];
     bool profile = false, serial = false, have_streams = false;
     int lastB = 0;

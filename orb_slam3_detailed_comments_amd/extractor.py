@@ -200,6 +200,16 @@ class ORBextractor:
         self._lib.check(self._lib.L.orbx_device_upload(self._h, p, arr.ctypes.data, arr.nbytes))
         return p
 
+    def device_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._lib.check(self._lib.L.orbx_device_alloc(self._h, int(nbytes), C.byref(p)))
+        return p
+
+    def device_upload_async(self, dptr, arr):
+        """Upload `arr` (page-locked: pinned_empty) into the device buffer on the handle's copy stream; the next enqueue(device_ptr=...)
+        waits for it on the device."""
+        self._lib.check(self._lib.L.orbx_device_upload_async(self._h, dptr, arr.ctypes.data, arr.nbytes))
+
     def pinned_empty(self, shape, dtype):
         """numpy array backed by page-locked host memory (fast D2H target for fetch())."""
         dtype = np.dtype(dtype)

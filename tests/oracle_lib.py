@@ -418,7 +418,7 @@ def _bind_frame_lib(L):
         L.ref_frame_fisheye.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p]
         L.ref_frame_fisheye_get3d.argtypes = [C.c_void_p] * 3
         L.ref_frame_fisheye_get.argtypes = [C.c_void_p] * 6
-        L.ref_frame_stereo_repeat.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_float] * 6 + [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.ref_frame_stereo_repeat.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_float] * 6 + [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p]
         L.ref_frame_get.argtypes = [C.c_void_p] * 8
         L.ref_frame_constants.argtypes = [C.c_void_p, C.c_void_p]
         L.ref_frame_features_in_area.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -495,13 +495,14 @@ class ReferenceFrame:
 
 def reference_frame_repeat(left, right, seconds, nfeatures=1200, scale=1.2, nlevels=8, ini=20, mn=7, fx=458.654, fy=457.296, cx=367.215, cy=248.375, bf=458.654 * 0.110074, th_depth=35.0):
     """Constructs the reference's stereo Frame on (left, right) over and over for `seconds` (long-lived extractors, as Tracking holds them).
-    Returns (frames, elapsed seconds, stereo matches of the last frame).  Releases the GIL."""
+    Returns (frames, elapsed seconds, stereo matches of the last frame, sum of "ORB Extraction" ms, sum of "Stereo Matching" ms).  Releases the GIL."""
     L = reference_frame_lib()
     left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
     el = C.c_double(); m = C.c_int()
+    st = np.zeros(2, np.float64)          # sums of the reference's own timers: mTimeORB_Ext, mTimeStereoMatch (ms; REGISTER_TIMES build)
     n = L.ref_frame_stereo_repeat(left.ctypes.data, right.ctypes.data, left.shape[1], left.shape[0], nfeatures, scale, nlevels, ini, mn, fx, fy, cx, cy, bf, th_depth,
-                                  float(seconds), C.byref(el), C.byref(m))
-    return n, el.value, m.value
+                                  float(seconds), C.byref(el), C.byref(m), st.ctypes.data)
+    return n, el.value, m.value, float(st[0]), float(st[1])
 
 
 _REF_MP = None

@@ -1,0 +1,32 @@
+"""bench.py's multi-process path (rendezvous, barrier, max-over-ranks timing, aggregated value) without GPUs: two ranks under
+torch.distributed.run with the gloo backend, the kernels running in the CPU emulator build (ORBX_BENCH_LIB).  The numbers mean nothing; the
+protocol is what is tested: one JSON line from rank 0, n_gpus = 2, value = units of BOTH ranks / the slowest rank's time."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_bench_two_ranks_gloo(emu_lib):
+    env = dict(os.environ)
+    env.update(ORBX_BENCH_BACKEND="gloo", ORBX_BENCH_LIB=os.path.join(ROOT, "tests", "emu", "liborbx_emu.so"), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "1", "--handles", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0): %r" % r.stdout[-1000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["warmup"] == 1 and res["scaling"] == "weak" and res["unit"] == "stereo pairs/s"
+    # whole-job aggregate: 2 ranks x 1 pair x 2 steps over the (max over ranks) time
+    assert abs(res["value"] - 2 * 1 * 2 / (res["ms_per_step"] * 2 * 1e-3)) < 0.06            # (value is rounded to 0.1)
+    assert res["roofline"]["kernel"] in res["stage_ms_alone"] and res["roofline"]["achieved"] > 0
+    assert "cpu_baseline" not in res and "h2d_inclusive" not in res          # rank-0 / N = 1 extras only
+    assert res["config"]["parallelism"].startswith("independent streams, 2 GPU")

@@ -4,7 +4,8 @@ KannalaBrandt8::TriangulateMatches, src/CameraModels/KannalaBrandt8.cpp:439-523)
 
 The checker is the reference's own Frame.cc / ORBmatcher.cc compiled in place over the stand-in world, with the Kannala-Brandt camera restated
 in oracle/slam_shim/kb8_camera.h (KannalaBrandt8.cpp needs Eigen, which is not available: parity of the camera arithmetic itself is unpinned;
-its 4x4 SVD is a one-sided fp32 Jacobi there and an fp64 eigen-decomposition in the product, so the comparison is a cross-check of two
+its 4x4 SVD is a one-sided Jacobi iteration on A there and an eigen-decomposition of A^T A in the product (both fp64 inside: an fp32 SVD,
+Eigen's included, is only accurate to ~eps32 / (1 - cos parallax), which exceeds 1e-4 in depth for low-parallax pairs), so the comparison is a cross-check of two
 implementations).  Bar: identical accept sets / match pairs, depths within 1e-4 relative."""
 import numpy as np
 import pytest

@@ -63,6 +63,24 @@ def main():
     rows.append(("ComputeDistinctiveDescriptors (5000 map points, %d descriptors)" % len(dd), lambda: M.ComputeDistinctiveDescriptors(ex, dd, start), lambda: ol.oracle_distinctive_descriptors(dd, start)))
     for name, gpu, cpu in rows:
         out[name] = {"gpu_ms": round(best(gpu, 5), 3), "cpu_oracle_ms": round(best(cpu, 2), 3)}
+    # Tracking::SearchLocalPoints: Frame::isInFrustum for 5000 map points + SearchByProjection on those in view, device vs the reference's own
+    # Frame.cc / ORBmatcher.cc (oracle/_ref/libref_frame.so)
+    if ol.reference_frame_lib() is not None:
+        import test_local_points as tlp
+        from orb_slam3_detailed_comments_amd import ComputeStereoMatches, views
+        Ls, Rs = synth.stereo_pair(640, 480, seed=7)
+        RF = ol.ReferenceFrame(Ls, Rs, 1000, fx=tlp.FX, fy=tlp.FY, cx=tlp.CX, cy=tlp.CY, bf=tlp.BF)
+        ex4 = ORBextractor(1000, 1.2, 8, 20, 7)
+        (_, kL, dL), _ = ex4.extract_batch(np.stack([Ls, Rs]))
+        uu, _, _ = ComputeStereoMatches(ex4, ex4, tlp.BF, RF.mb, 0, 1, 1)
+        sfs = ex4.GetScaleFactors()
+        fv4 = views.frame_view(kL, dL, sfs, 640, 480, u_right=uu[0, :RF.N], mbf=tlp.BF)
+        Rcw = tlp._rot(0.02, -0.03, 0.01); tcw = np.array([0.3, -0.1, 0.25], np.float32)
+        sp = tlp._scene(RF, rng, Rcw, tcw, MP)
+        g = lambda: M.SearchLocalPoints(ex4, fv4, Rcw, tcw, (tlp.FX, tlp.FY, tlp.CX, tlp.CY), (0.0, 640.0, 0.0, 480.0), tlp.BF, sfs, *sp, 0.5, 3.0, False, 50.0, 0.8)
+        c = lambda: RF.search_local_points(Rcw, tcw, *sp, 0.5, True, 3.0, False, 50.0, 0.8)
+        same = np.array_equal(g()[1], c()[1])
+        out["Tracking::SearchLocalPoints: isInFrustum + SearchByProjection, 5000 map points"] = {"gpu_ms": round(best(g, 5), 3), "cpu_reference_ms": round(best(c, 2), 3), "identical": bool(same)}
     # vocabulary transform: k=10, L=5 (111 110 nodes); 128 extracted EuRoC-size images, descriptors resident on the device
     tmp = tempfile.mkdtemp()
     header, parent, leaf, vdesc, weight = vs.make_vocabulary(rng, 10, 5)
