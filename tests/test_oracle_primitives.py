@@ -168,3 +168,93 @@ def test_descriptor_distance_known_answers():
     a = rng.integers(0, 256, (300, 32), dtype=np.uint8); b = rng.integers(0, 256, (300, 32), dtype=np.uint8)
     exp = np.unpackbits(a ^ b, axis=1).sum(1)
     assert [ol.oracle_hamming(a[i], b[i]) for i in range(300)] == exp.tolist()
+
+
+# ---- the input pre-step: cv::remap / cv::resize on colour frames / cv::cvtColor ------------------------------
+# Call sites in the reference: System.cc:286-293 (cv::remap(im, imRect, M1, M2, cv::INTER_LINEAR) with the CV_32F maps of Settings.cc:549-574),
+# System.cc:295-297 (cv::resize to Settings::newImSize), Tracking.cc:1532-1560 (cv::cvtColor RGB/BGR/RGBA/BGRA -> GRAY).  OpenCV is not
+# installed, so each restatement in oracle/orb_primitives.h is checked here against an independent slow definition in exact rational
+# arithmetic (fractions.Fraction), written from the operators' published definitions:
+#   remap INTER_LINEAR, 8U (OpenCV 3.x and 4.x, imgproc/src/imgwarp.cpp / remap.cpp: the same fixed-point scheme in both): source
+#     coordinates are quantised to 1/32 pixel (INTER_BITS = 5, cvRound(x * 32)), the four neighbours are blended with the bilinear weights
+#     of that quantised position, the sum is rounded half up, taps outside the image read the constant border value 0;
+#   cvtColor to grey, 8U: Y = (R * cR + G * cG + B * cB + half) >> shift with (cR, cG, cB, shift) = (9798, 19235, 3735, 15) in OpenCV 4.x
+#     (variant 0) and (4899, 9617, 1868, 14) in OpenCV 3.x (variant 1) - 0.299 / 0.587 / 0.114 in 15 / 14 bits.
+def _slow_remap(src, mapx, mapy):
+    from fractions import Fraction
+    sh, sw = src.shape[:2]
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    s3 = src.reshape(sh, sw, cn)
+    dh, dw = mapx.shape
+    out = np.zeros((dh, dw, cn), np.uint8)
+
+    def rne(v):                       # cvRound: round half to even
+        f = int(np.floor(v)); d = v - f
+        return f + 1 if d > 0.5 or (d == 0.5 and f % 2 == 1) else f
+    for y in range(dh):
+        for x in range(dw):
+            qx = rne(float(np.float32(mapx[y, x]) * np.float32(32.0))); qy = rne(float(np.float32(mapy[y, x]) * np.float32(32.0)))
+            ix, iy = qx >> 5, qy >> 5
+            fx, fy = Fraction(qx & 31, 32), Fraction(qy & 31, 32)
+            for c in range(cn):
+                acc = Fraction(0)
+                for (dx, dy, wgt) in ((0, 0, (1 - fx) * (1 - fy)), (1, 0, fx * (1 - fy)), (0, 1, (1 - fx) * fy), (1, 1, fx * fy)):
+                    xx, yy = ix + dx, iy + dy
+                    if 0 <= xx < sw and 0 <= yy < sh:
+                        acc += wgt * int(s3[yy, xx, c])
+                out[y, x, c] = min(255, int(np.floor(acc + Fraction(1, 2))))
+    return out.reshape((dh, dw) if src.ndim == 2 else (dh, dw, cn))
+
+
+def test_remap_vs_exact_bilinear_definition():
+    rng = np.random.default_rng(11)
+    for cn in (1, 3):
+        src = rng.integers(0, 256, (19, 23) if cn == 1 else (19, 23, cn), dtype=np.uint8)
+        # a rectification-like map (smooth warp) plus adversarial entries: exact integers, exact 1/64 ties of the 1/32 grid, positions
+        # left / right / above / below the image (constant border), one pixel outside (half-covered taps)
+        yy, xx = np.mgrid[0:17, 0:21].astype(np.float32)
+        mx = (xx + 1.3 + 0.04 * yy + 0.8 * np.sin(yy / 5.0)).astype(np.float32); my = (yy + 0.7 - 0.03 * xx + 0.6 * np.cos(xx / 4.0)).astype(np.float32)
+        mx[0, :6] = [0.0, 5.0, 22.0, -1.0, 23.0, -0.5]; my[0, :6] = [0.0, 3.0, 18.0, 4.0, 4.0, 18.5]
+        mx[1, :5] = [2.015625, 2.046875, 7.5, 21.984375, -0.015625]; my[1, :5] = [3.015625, 3.046875, 9.5, 17.984375, -0.015625]
+        mx[2, :3] = [-40.0, 1000.0, 4.0]; my[2, :3] = [5.0, 5.0, -300.0]
+        got = ol.oracle_remap(src, mx, my)
+        assert np.array_equal(got, _slow_remap(src, mx, my))
+    # properties: the identity map is the identity, an integer shift is a shift with a zero border
+    img = rng.integers(0, 256, (12, 14), dtype=np.uint8)
+    yy, xx = np.mgrid[0:12, 0:14].astype(np.float32)
+    assert np.array_equal(ol.oracle_remap(img, xx, yy), img)
+    sh = ol.oracle_remap(img, xx + 3, yy - 2)
+    assert np.array_equal(sh[2:, :11], img[:10, 3:]) and (sh[:2] == 0).all() and (sh[:, 11:] == 0).all()
+
+
+def test_cvtcolor_vs_definition_and_known_answers():
+    from fractions import Fraction
+    rng = np.random.default_rng(12)
+    coef = {0: (9798, 19235, 3735, 15), 1: (4899, 9617, 1868, 14)}
+    for variant, (cr, cg, cb, shift) in coef.items():
+        assert cr + cg + cb == 1 << shift                      # white stays 255, grey stays grey
+        for cn in (3, 4):
+            img = rng.integers(0, 256, (9, 11, cn), dtype=np.uint8)
+            img[0, 0, :3] = (255, 255, 255); img[0, 1, :3] = (255, 0, 0); img[0, 2, :3] = (0, 255, 0); img[0, 3, :3] = (0, 0, 255); img[0, 4, :3] = (128, 128, 128)
+            for red_first in (1, 0):
+                got = ol.oracle_gray(img, red_first, variant)
+                exp = np.zeros((9, 11), np.uint8)
+                for y in range(9):
+                    for x in range(11):
+                        r, g, b = (img[y, x, 0], img[y, x, 1], img[y, x, 2]) if red_first else (img[y, x, 2], img[y, x, 1], img[y, x, 0])
+                        exp[y, x] = int(np.floor(Fraction(int(r) * cr + int(g) * cg + int(b) * cb, 1 << shift) + Fraction(1, 2)))
+                assert np.array_equal(got, exp)
+                # ITU-R BT.601 luma of the primaries: 0.299, 0.587, 0.114 of 255
+                first, third = (76, 29) if red_first else (29, 76)
+                assert [int(v) for v in got[0, :5]] == [255, first, 150, third, 128]
+
+
+def test_resize_colour_is_per_channel_resize():
+    """cv::resize on a CV_8UC3 frame interpolates every channel independently with the coefficients of the single-channel case (the
+    horizontal / vertical tables depend on the geometry only); the single-channel primitive is pinned above."""
+    rng = np.random.default_rng(13)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    for (dw, dh) in ((41, 29), (53, 37), (60, 44), (26, 18)):
+        got = ol.oracle_resize_cn(img, dw, dh)
+        for c in range(3):
+            assert np.array_equal(got[:, :, c], ol.oracle_resize_cn(np.ascontiguousarray(img[:, :, c]), dw, dh))
