@@ -100,6 +100,10 @@ int orbx_device_upload(orbx_extractor* h, void* dptr, const void* host, size_t b
  * `host` should be page-locked, orbx_host_alloc) */
 int orbx_device_upload_async(orbx_extractor* h, void* dptr, const void* host, size_t bytes);
 
+/* device addresses of the results of the last batch: keypoints [B][cap] (28-byte records), descriptors [B][cap][32] (rows beyond n[b] are
+ * zero), n [B], monoIndex [B]; valid until the next extraction / reconfiguration of the handle (synchronise with orbx_sync first).  For
+ * consumers that stay on the device, e.g. an RCCL all-gather of the descriptor blocks (orb_slam3_detailed_comments_amd/multi.py). */
+int orbx_device_outputs(orbx_extractor* h, void** kps, void** desc, void** n, void** mono, int* cap, int* B);
 /* page-locked host memory for output buffers: with cap == orbx_max_keypoints() orbx_fetch / orbm_stereo_fetch copy straight
  * into the caller's arrays (no staging, no repacking) and pinned memory makes that copy run at PCIe speed */
 int orbx_host_alloc(orbx_extractor* h, size_t bytes, void** hptr);

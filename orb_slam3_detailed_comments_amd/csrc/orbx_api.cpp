@@ -237,6 +237,7 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
     const dim3 blk2(64, 4, 1), blk1(256, 1, 1);
     rt::memset_async(h->d_status.p, 0, 4 * sizeof(int), h->s0);     // the quadtree's capacity flag is per batch, not per handle
     if (h->copy_pending) { rt::stream_wait_event(h->s0, h->ev_copy); h->copy_pending = false; }   // input uploaded by orbx_device_upload_async
+    rt::memset_async(h->d_desc.p, 0, (size_t)B * h->kp_total_cap * 32, h->s0);   // descriptor rows beyond n[b] read as zero (fixed-shape blocks for collectives)
     stage_begin(h, ST_IMPORT, h->s0);
     if (h->in_active && (h->in_channels != 1 || h->in_geometry != 0)) enqueue_input(h, B, d_images, src_w, src_h, stride, image_stride);
     else {
@@ -594,6 +595,19 @@ int orbx_host_alloc(orbx_extractor* h, size_t bytes, void** hptr) {
 int orbx_host_free(orbx_extractor* h, void* hptr) { if (!h) return ORBX_E_ARG; rt::set_device(h->device); rt::hfree(hptr); return ORBX_OK; }
 
 int orbx_debug_stereo_flags(orbx_extractor* h, int flags) { if (!h) return ORBX_E_ARG; h->debug_stereo_flags = flags; return ORBX_OK; }
+
+// device addresses of the results of the last batch (layout [B][cap]...; valid until the handle is reconfigured or destroyed), for consumers
+// that stay on the device: RCCL collectives over the descriptor blocks, a global matcher
+int orbx_device_outputs(orbx_extractor* h, void** kps, void** desc, void** n, void** mono, int* cap, int* B) {
+    if (!h || h->lastB <= 0) return fail(ORBX_E_ARG, "nothing extracted yet");
+    if (kps) *kps = h->d_kps.p;
+    if (desc) *desc = h->d_desc.p;
+    if (n) *n = h->d_nm.p;
+    if (mono) *mono = h->d_nm.p + h->maxB;
+    if (cap) *cap = h->kp_total_cap;
+    if (B) *B = h->lastB;
+    return ORBX_OK;
+}
 
 int orbx_set_graph_replay(orbx_extractor* h, int on) { if (!h) return ORBX_E_ARG; h->use_graph = on != 0; return ORBX_OK; }
 

@@ -28,6 +28,16 @@ def _worker(rank, world, port, q):
     results = [mine[s] for s in sorted(mine)] + [(0, np.zeros(0), np.zeros((0, 32), np.uint8))] * (per_rank - len(mine))
     desc, cnt = multi.pack_descriptors(results, cap)
     dall, call = multi.all_gather_descriptors(desc, cnt)
+    # the same exchange straight from the extractor's device-resident blocks (no host packing): every rank extracts per_rank frames so that
+    # the blocks have one shape, then one collective per array
+    own = [frames[s] for s in sorted(mine)]
+    ex.extract_batch(np.stack(own + [own[0]] * (per_rank - len(own))))
+    dev_all, dev_cnt, works = multi.all_gather_extracted(ex)
+    [w.wait() for w in works]
+    dev_all = dev_all.cpu().numpy(); dev_cnt = dev_cnt.cpu().numpy()
+    for r in range(world):
+        for j, s in enumerate(multi.shard_streams(len(frames), r, world)):
+            assert dev_cnt[r, j] == call[r, j] and dev_all[r, j].tobytes() == dall[r, j].tobytes(), "device-resident gather differs from the packed one"
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, sorted(mine), {s: (mine[s][0], mine[s][1].tobytes(), mine[s][2].tobytes()) for s in mine}, dall.tobytes(), call.tolist()))
