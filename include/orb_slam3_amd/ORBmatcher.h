@@ -48,14 +48,14 @@ class ORBmatcher : public ORBmatcherConstants<void>
 public:
     ORBmatcher(float nnratio=0.6, bool checkOri=true): mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
 
-    // Computes the Hamming distance between two ORB descriptors (src/ORBmatcher.cc:2383).  One pair per call is a GPU round
-    // trip: hot N^2 callers should use DescriptorDistances.
+    // Computes the Hamming distance between two ORB descriptors (src/ORBmatcher.cc:2383).
     static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b)
     {
-        int d = 0;
-        std::lock_guard<std::mutex> lock(Mutex());
-        Check(orbm_hamming_matrix(SharedHandle(), a.ptr(0), 1, b.ptr(0), 1, &d));
-        return d;
+        // one pair = four 64-bit popcounts: done where the caller is (MapPoint::ComputeDistinctiveDescriptors calls this N^2 times,
+        // src/MapPoint.cc:496; Frame::ComputeStereoMatches once per candidate, src/Frame.cc:1219); the batched forms run on the device
+        unsigned long long x[4], y[4];
+        memcpy(x, a.ptr(0), 32); memcpy(y, b.ptr(0), 32);
+        return __builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) + __builtin_popcountll(x[2] ^ y[2]) + __builtin_popcountll(x[3] ^ y[3]);
     }
     // all pairs: out[i*B.rows + j] = distance(A.row(i), B.row(j))
     static void DescriptorDistances(const cv::Mat &A, const cv::Mat &B, std::vector<int>& out)
@@ -87,7 +87,7 @@ public:
         if (!rig) {
             FrameStore fs; FillFrame(F, fs, OccupiedWithObservations);
             assigned.assign(F.N > 0 ? F.N : 1, -1);
-            std::lock_guard<std::mutex> lock(Mutex());      // the reference's matchers are re-entrant (Tracking / LocalMapping / LoopClosing threads); one handle is not
+            std::lock_guard<std::mutex> lock(Mutex());
             Check(orbm_search_by_projection_mappoints(SharedHandle(), &fs.v, &mv, th, bFarPoints, thFarPoints, mfNNratio, assigned.data(), &nmatches));
         } else {
             RigStore rs; FillRig(F, rs, OccupiedWithObservations);
@@ -604,15 +604,17 @@ public:
     }
 
 public:
+    // One library handle (HIP streams + device scratch) per calling THREAD: the reference's matchers are stateless and are called
+    // concurrently from the Tracking, LocalMapping and LoopClosing threads; with a handle of its own each of them runs
+    // its searches on its own stream without waiting for the others.  The handle lives as long as its thread.
     static orbx_extractor* SharedHandle()
     {
-        static orbx_extractor* h = nullptr;
-        static std::once_flag once;
-        std::call_once(once, [](){ if (orbx_create(&h, 1000, 1.2f, 8, 20, 7, 0) != ORBX_OK) h = nullptr; });
-        if (!h) throw std::runtime_error(std::string("ORBmatcher (HIP): ") + orbx_last_error());
-        return h;
+        struct Holder { orbx_extractor* h = nullptr; ~Holder() { if (h) orbx_destroy(h); } };
+        static thread_local Holder t;
+        if (!t.h && orbx_create(&t.h, 1000, 1.2f, 8, 20, 7, 0) != ORBX_OK) { t.h = nullptr; throw std::runtime_error(std::string("ORBmatcher (HIP): ") + orbx_last_error()); }
+        return t.h;
     }
-    static std::mutex& Mutex() { static std::mutex m; return m; }
+    static std::mutex& Mutex() { static thread_local std::mutex m; return m; }      // per thread as well: never contended
     static void Check(int rc) { if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBmatcher (HIP): ") + orbx_last_error()); }
 
 protected:

@@ -54,6 +54,26 @@ def _run_matcher_facade(tmp_path, libdir, libname):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def _run_matcher_threads(tmp_path, libdir, libname):
+    """Three threads call the ORBmatcher facade concurrently (one library handle per thread): the same results as one after the other."""
+    L, _ = synth.stereo_pair(376, 240, seed=21, nrect=800)
+    (tmp_path / "t.raw").write_bytes(L.tobytes())
+    exe = tmp_path / "matcher_threads_test"
+    subprocess.run(["g++", "-std=c++14", "-O1", "-w", "-I" + os.path.join(ROOT, "include", "orb_slam3_amd"), "-I" + os.path.join(ROOT, "oracle", "opencv_shim"),
+                    os.path.join(ROOT, "tests", "cpp", "matcher_threads_test.cpp"), "-L" + libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-lpthread", "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe), str(tmp_path / "t.raw"), "376", "240"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_matcher_facade_three_threads_emulated(tmp_path, emu_lib):
+    _run_matcher_threads(tmp_path, os.path.join(ROOT, "tests", "emu"), "orbx_emu")
+
+
+@pytest.mark.gpu
+def test_matcher_facade_three_threads_gpu(tmp_path, hip_lib):
+    _run_matcher_threads(tmp_path, os.path.dirname(_lib.HIP_LIB_PATH), "orbx_hip")
+
+
 def test_matcher_facade_emulated(tmp_path, emu_lib):
     _run_matcher_facade(tmp_path, os.path.join(ROOT, "tests", "emu"), "orbx_emu")
 
