@@ -155,8 +155,9 @@ def main():
     ap.add_argument("--config", default="stereo", choices=sorted(CONFIGS), help="BASELINE.json configuration (stereo = configs[1] = the headline metric)")
     ap.add_argument("--pairs", type=int, default=128, help="units (stereo pairs, or frames for mono / rgbd) per step per GPU: one step = one batch through the "
                     "whole path (32 -> 52 k, 64 -> 57 k, 96 -> 59 k, 128 -> 60 k pairs/s measured in round 1)")
-    ap.add_argument("--handles", type=int, default=3, help="extractor handles in flight per GPU (each owns its streams); three independent "
-                    "kernel chains measured best and, unlike four, insensitive to how the HIP runtime maps streams to hardware queues")
+    ap.add_argument("--handles", type=int, default=0, help="extractor handles in flight per GPU (each owns its streams).  Default: 4 as a plain process "
+                    "(2 / 3 / 4 / 5 / 6 handles: 68.0 / 75.7 / 80.3 / 70.2 / 69.0 k pairs/s), 3 inside a torch.distributed process, where PyTorch's own "
+                    "streams share the hardware queues and four chains were measured unstable (37-48 k) in round 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the second, PCIe-inclusive measurement (never `value`)")
     ap.add_argument("--h2d", action="store_true", help="make the PCIe-inclusive variant the timed loop (NOT the headline value)")
@@ -203,7 +204,7 @@ def main():
         nrect = int(3000 * W * H / (752 * 480))
         batch = np.stack([np.stack([synth.corner_field(W, H, seed=rank * 100003 + i + 7 * c, nrect=nrect) for c in range(3)], axis=2) for i in range(P)])
     NIMG = 2 * P if paired else P
-    NH = max(1, args.handles)
+    NH = args.handles if args.handles > 0 else (3 if dist is not None else 4)
     handles = [ORBextractor(NFEAT, SCALE, NLEVELS, INI, MIN, device_id=local, lib=lib) for _ in range(NH)]
     if kind == "rgbd":
         for h in handles:

@@ -341,7 +341,7 @@ __device__ __forceinline__ unsigned long long vkeys_order(uint32_t key, int wcel
     return (ci << 36) | (cj << 24) | ((unsigned long long)y << 12) | (unsigned long long)x;
 }
 
-// grid (nlevels, B), 256 threads.  Dynamic LDS: see carve below (host passes node_cap).
+// grid (B, nlevels), 256 threads.  Dynamic LDS: see carve below (host passes node_cap).
 __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ lv,
                                                   const CellInfo* __restrict__ cells, int ncells,
                                                   const int* __restrict__ cell_count,
@@ -353,7 +353,9 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
     ORBX_DYN_SMEM(smem);
     __shared__ unsigned long long s_scan[20];
     __shared__ int s_i[16];
-    const int level = (int)blockIdx.x, b = (int)blockIdx.y;
+    // grid (B, nlevels): workgroups are dispatched image-fastest, i.e. every image's level 0 (the longest tree by far) starts first and the
+    // short trees of the small levels fill the remaining slots
+    const int level = (int)blockIdx.y, b = (int)blockIdx.x;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const LevelInfo L = lv[level];
     const int N = L.quota;

@@ -298,7 +298,7 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
     stage_end(h, ST_FAST, h->s0);
     stage_begin(h, ST_QUADTREE, h->s0);
     {
-        dim3 grid(nl, B, 1);
+        dim3 grid(B, nl, 1);
         // nodes 2x24 B + child counts 16 B + expand lists 2x8 B + flags 1 B per node; bucket offsets + 4 per-wave cursors per bucket
         const int lut_x = (int)align_up((size_t)h->lv[0].bw + 1, 8), lut_y = (int)align_up((size_t)h->lv[0].bh + 1, 8);   // level 0 is the largest
         const size_t smem = (size_t)h->node_cap * 81 + (size_t)(5 * h->nb_cap + 2) * 4 + 2 * (size_t)(lut_x + lut_y) + 64;
