@@ -98,15 +98,21 @@ protected:
     void ExportPyramid()
     {
         const int EDGE_THRESHOLD = 19;
+        std::vector<uint8_t*> dst(mnLevels); std::vector<int> stride(mnLevels);
+        std::vector<cv::Mat> framed(mnLevels);
         for (int level = 0; level < mnLevels; ++level) {
             int w = 0, h = 0;
-            orbx_pyramid_level(mpHandle, 0, level, 0, nullptr, 0, &w, &h);
-            cv::Mat temp(cv::Size(w + EDGE_THRESHOLD*2, h + EDGE_THRESHOLD*2), CV_8UC1);
-            mvImagePyramid[level] = temp(cv::Rect(EDGE_THRESHOLD, EDGE_THRESHOLD, w, h));
-            orbx_pyramid_level(mpHandle, 0, level, 0, mvImagePyramid[level].data, (int)mvImagePyramid[level].step, &w, &h);
-            cv::copyMakeBorder(mvImagePyramid[level], temp, EDGE_THRESHOLD, EDGE_THRESHOLD, EDGE_THRESHOLD, EDGE_THRESHOLD,
-                               cv::BORDER_REFLECT_101+cv::BORDER_ISOLATED);
+            orbx_pyramid_level(mpHandle, 0, level, 0, nullptr, 0, &w, &h);           // sizes only (no copy)
+            framed[level] = cv::Mat(cv::Size(w + EDGE_THRESHOLD*2, h + EDGE_THRESHOLD*2), CV_8UC1);
+            mvImagePyramid[level] = framed[level](cv::Rect(EDGE_THRESHOLD, EDGE_THRESHOLD, w, h));
+            dst[level] = mvImagePyramid[level].data; stride[level] = (int)mvImagePyramid[level].step;
         }
+        // one device-to-host copy for the whole pyramid, then the reference's borders (src/ORBextractor.cc:1712-1736)
+        if (orbx_pyramid_fetch(mpHandle, 0, 0, dst.data(), stride.data()) != ORBX_OK)
+            throw std::runtime_error(std::string("ORBextractor (HIP): ") + orbx_last_error());
+        for (int level = 0; level < mnLevels; ++level)
+            cv::copyMakeBorder(mvImagePyramid[level], framed[level], EDGE_THRESHOLD, EDGE_THRESHOLD, EDGE_THRESHOLD, EDGE_THRESHOLD,
+                               cv::BORDER_REFLECT_101+cv::BORDER_ISOLATED);
     }
 
     orbx_extractor* mpHandle;

@@ -90,6 +90,8 @@ int orbx_sync(orbx_extractor* h);
  * GaussianBlur'ed level used for the descriptors.  dst may be NULL to query the size. */
 int orbx_pyramid_level(orbx_extractor* h, int image_index, int level, int blurred, uint8_t* dst,
                        int dst_stride, int* width, int* height);
+/* all levels of one image with a single device-to-host copy: dst[l] receives level l (width x height of orbx_pyramid_level) with row pitch dst_stride[l] */
+int orbx_pyramid_fetch(orbx_extractor* h, int image_index, int blurred, uint8_t* const* dst, const int* dst_stride);
 
 /* device memory helpers so a caller can keep inputs resident (bench, multi-camera rigs) */
 int orbx_device_alloc(orbx_extractor* h, size_t bytes, void** dptr);

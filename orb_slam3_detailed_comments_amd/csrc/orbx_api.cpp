@@ -552,6 +552,22 @@ int orbx_pyramid_level(orbx_extractor* h, int b, int level, int blurred, uint8_t
     return ORBX_OK;
 }
 
+// every level of one image in ONE device-to-host copy (the levels of an image are contiguous on the device): dst[l] / dst_stride[l] per level
+int orbx_pyramid_fetch(orbx_extractor* h, int b, int blurred, uint8_t* const* dst, const int* dst_stride) {
+    if (!h || !dst || !dst_stride || b < 0 || b >= h->lastB) return fail(ORBX_E_ARG, "bad pyramid query");
+    for (int l = 0; l < h->nlevels; l++) if (!dst[l] || dst_stride[l] < h->lv[l].w) return fail(ORBX_E_ARG, "level %d: destination missing or too narrow", l);
+    rt::set_device(h->device);
+    if (h->h_stage.ensure(h->pyr_stride + 64)) return fail(ORBX_E_DEVICE, "pinned allocation failed");
+    rt::stream_sync(h->s1);
+    const uint8_t* src = (blurred ? h->d_blur.p : h->d_pyr.p) + (size_t)b * h->pyr_stride;
+    if (rt::copy_d2h(h->h_stage.p, src, h->pyr_stride, h->s0) || rt::stream_sync(h->s0)) return fail(ORBX_E_DEVICE, "D2H failed");
+    for (int l = 0; l < h->nlevels; l++) {
+        const LevelInfo& L = h->lv[l];
+        for (int y = 0; y < L.h; y++) memcpy(dst[l] + (size_t)y * dst_stride[l], h->h_stage.p + L.off + (size_t)y * L.pitch, L.w);
+    }
+    return ORBX_OK;
+}
+
 int orbx_device_alloc(orbx_extractor* h, size_t bytes, void** dptr) {
     if (!h || !dptr) return fail(ORBX_E_ARG, "null");
     rt::set_device(h->device);
