@@ -153,6 +153,57 @@ struct QuadCls {    // DivideNode's key -> child test (:651-661)
 };
 
 
+#ifndef ORBX_WAVE_SORT_RANGE
+#define ORBX_WAVE_SORT_RANGE 40
+#endif
+constexpr int kWaveSortRange = ORBX_WAVE_SORT_RANGE;     // ranges longer than this are partitioned by a wave instead of one thread
+
+// libstdc++'s __unguarded_partition (sm_unguarded_partition) of a[lo, hi) around a[pivot] by one wave, same result and same array state.
+// The sequential loop alternates "first walks up to the next element >= pivot" and "last walks down to the next element <= pivot" and
+// swaps the two while first < last.  A walk never revisits a swapped position except the most recent one, so with
+//   L_0 < L_1 < ..   the positions of the elements >= pivot (initial values),     R_0 > R_1 > ..  those of the elements <= pivot,
+// swap k exchanges a[L_k] and a[R_k], K = #{k : L_k < R_k} swaps happen (the predicate is monotone in k), and the walk of `first` that
+// ends the loop stops at L_K or at R_(K-1) (which holds an element >= pivot since swap K-1), whichever comes first.
+// scratch: 4 * (hi - lo) uint16.  Returns the cut in every lane.
+__device__ __forceinline__ int wave_unguarded_partition(unsigned long long* a, int lo, int hi, int pivot, uint16_t* scratch) {
+    const int lane = lane_id();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    SortLess less;
+    const unsigned long long pv = a[pivot];
+    const int m = hi - lo;
+    uint16_t* Lpos = scratch;
+    uint16_t* Rasc = scratch + 2 * m;        // positions of the elements <= pivot in ascending order: R_k = Rasc[nR - 1 - k]
+    int nL = 0, nR = 0;
+    for (int c0 = 0; c0 < m; c0 += 64) {
+        const int i = lo + c0 + lane;
+        const bool valid = c0 + lane < m;
+        const unsigned long long v = valid ? a[i] : 0ull;
+        const bool isL = valid && !less(v, pv), isR = valid && !less(pv, v);
+        const unsigned long long bL = __ballot(isL), bR = __ballot(isR);
+        if (isL) Lpos[nL + __popcll(bL & lt)] = (uint16_t)i;
+        if (isR) Rasc[nR + __popcll(bR & lt)] = (uint16_t)i;
+        nL += __popcll(bL); nR += __popcll(bR);
+    }
+    ORBX_WAVE_SYNC();
+    const int mn = nL < nR ? nL : nR;
+    int K = 0;
+    for (int k0 = 0; k0 < mn; k0 += 64) {
+        const int k = k0 + lane;
+        int pl = 0, pr = 0;
+        bool ok = false;
+        if (k < mn) { pl = Lpos[k]; pr = Rasc[nR - 1 - k]; ok = pl < pr; }
+        const unsigned long long bal = __ballot(ok);
+        if (ok) { const unsigned long long t = a[pl]; a[pl] = a[pr]; a[pr] = t; }
+        K += __popcll(bal);
+        if (bal != ~0ull) break;
+    }
+    ORBX_WAVE_SYNC();
+    int cut = 0x7FFFFFFF;
+    if (K < nL) cut = Lpos[K];
+    if (K >= 1) { const int r = Rasc[nR - K]; cut = r < cut ? r : cut; }
+    return cut;
+}
+
 // std::sort(a, a+n, SortLess) by the whole workgroup, same result as libstdc++ (libstdcxx_sort_model.h) but with the
 // independent work run in parallel:
 //  * introsort's partition tree: the sub-ranges produced by one __unguarded_partition_pivot are disjoint, so each pending
@@ -167,7 +218,7 @@ __device__ __forceinline__ void block_sort_libstdcxx(unsigned long long* a, unsi
                                                      uint32_t* seg0, uint32_t* seg1, uint8_t* flags, int* s_ctr) {
     const int tid = (int)threadIdx.x;
     SortLess less;
-    for (int i = tid; i < n; i += 256) flags[i] = 0;
+    for (int i = tid; i < n; i += (int)blockDim.x) flags[i] = 0;
     if (tid == 0) {
         int lg = 0;
         for (int t = n; t > 1; t >>= 1) lg++;
@@ -178,17 +229,34 @@ __device__ __forceinline__ void block_sort_libstdcxx(unsigned long long* a, unsi
     __syncthreads();
     uint32_t* cur = seg0; uint32_t* nxt = seg1;
     int which = 0;
+    const int lane = lane_id(), wave = tid >> 6, nwaves = (int)(blockDim.x >> 6);
     for (;;) {
         const int ncur = s_ctr[which];
         if (ncur == 0) break;
-        for (int j = tid; j < ncur; j += 256) {
+        // long ranges (the first levels of the partition tree): one wave each, wave_unguarded_partition
+        for (int j = wave; j < ncur; j += nwaves) {
+            const uint32_t sg = cur[j];
+            const int first = (int)(sg & 0xFFF), last = (int)((sg >> 12) & 0xFFF);
+            int depth = (int)(sg >> 24);
+            if (depth == 0 || last - first <= kWaveSortRange) continue;
+            --depth;
+            if (lane == 0) sm_move_median_to_first(a, first, first + 1, first + (last - first) / 2, last - 1, less);
+            ORBX_WAVE_SYNC();
+            const int cut = wave_unguarded_partition(a, first + 1, last, first, (uint16_t*)(tmp + first));
+            if (lane == 0) {
+                if (last - cut > 16) nxt[atomicAdd(&s_ctr[which ^ 1], 1)] = (uint32_t)cut | ((uint32_t)last << 12) | ((uint32_t)depth << 24);
+                if (cut < last) flags[cut] = flags[cut] ? flags[cut] : 1;
+                if (cut - first > 16) nxt[atomicAdd(&s_ctr[which ^ 1], 1)] = (uint32_t)first | ((uint32_t)cut << 12) | ((uint32_t)depth << 24);
+            }
+        }
+        for (int j = tid; j < ncur; j += (int)blockDim.x) {
             const uint32_t sg = cur[j];
             const int first = (int)(sg & 0xFFF), last = (int)((sg >> 12) & 0xFFF);
             int depth = (int)(sg >> 24);
             if (depth == 0) {
                 sm_heap_sort(a, first, last, less);
                 flags[first] = 2;
-            } else {
+            } else if (last - first <= kWaveSortRange) {
                 --depth;
                 const int mid = first + (last - first) / 2;
                 sm_move_median_to_first(a, first, first + 1, mid, last - 1, less);
@@ -306,6 +374,7 @@ __device__ __forceinline__ void wave_partition_many(int count, IdxFn idx_of, con
         for (int u = 0; u < 4; u++) key[u] = keyn[u];
     }
 }
+constexpr int kDeepSmall = 1, kDeepBig = 2;       // a node below the presorted depths with > 1 key: one wave partitions it / the workgroup does
 struct IdentityIdx { __device__ __forceinline__ int operator()(int j) const { return j; } };
 struct ExpandIdx { const unsigned long long* e; __device__ __forceinline__ int operator()(int j) const { return (int)(e[j] & 0xFFFF); } };
 
@@ -352,7 +421,8 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                                                   int* __restrict__ status, long long* __restrict__ qt_prof) {
     ORBX_DYN_SMEM(smem);
     __shared__ unsigned long long s_scan[20];
-    __shared__ int s_i[16];
+    __shared__ int s_i[24];
+    int* s_kinds = s_i + 23;                            // kinds of deep nodes met in the current pass (kDeepSmall | kDeepBig)
     // grid (B, nlevels): workgroups are dispatched image-fastest, i.e. every image's level 0 (the longest tree by far) starts first and the
     // short trees of the small levels fill the remaining slots
     const int level = (int)blockIdx.y, b = (int)blockIdx.x;
@@ -365,6 +435,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
 #define QT_STAMP(i) if (qt_prof && tid == 0 && level == 0 && b == 0) qt_prof[i] = wall_clock64();
 #endif
     QT_STAMP(0)
+    if (tid == 0) *s_kinds = 0;
     // LDS carve: nodes[2][cap] (24 B) | childcnt[cap][4] (u32) | expand[2][cap] (u64) | bucket_start[nb+1] | wcount[4][nb] | erased[cap] (u8)
     QNode* nodes0 = (QNode*)smem;
     QNode* nodes1 = nodes0 + node_cap;
@@ -522,26 +593,39 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
         // ---- full pass: divide every node with more than one key (:790-905) ----
         // presorted depths: child counts come from the bucket offsets; deeper: big spans are partitioned by the whole
         // workgroup one after another, small spans by one wave each
-        for (int i = tid; i < nnodes; i += 256) {
-            const QNode nd = cur[i];
-            if (node_cnt(nd) > 1 && (int)nd.depth < D) {
-                int cnt[4];
-                presorted_child_counts(nd, D, bucket_start, cnt);
-                childcnt[4 * i] = (uint32_t)cnt[0]; childcnt[4 * i + 1] = (uint32_t)cnt[1]; childcnt[4 * i + 2] = (uint32_t)cnt[2]; childcnt[4 * i + 3] = (uint32_t)cnt[3];
+        // (which kinds of deep nodes exist is found on the way: most passes of a level move no key at all and skip the partition loops)
+        {
+            int kinds = 0;
+            for (int i = tid; i < nnodes; i += 256) {
+                const QNode nd = cur[i];
+                const int c = node_cnt(nd);
+                if (c > 1) {
+                    if ((int)nd.depth < D) {
+                        int cnt[4];
+                        presorted_child_counts(nd, D, bucket_start, cnt);
+                        childcnt[4 * i] = (uint32_t)cnt[0]; childcnt[4 * i + 1] = (uint32_t)cnt[1]; childcnt[4 * i + 2] = (uint32_t)cnt[2]; childcnt[4 * i + 3] = (uint32_t)cnt[3];
+                    } else kinds |= c > kBigSpan ? kDeepBig : kDeepSmall;
+                }
             }
+            if (kinds) atomicOr(s_kinds, kinds);
         }
-        for (int i = 0; i < nnodes; i++) {
-            const QNode nd = cur[i];
-            if (node_cnt(nd) > kBigSpan && (int)nd.depth >= D) {
-                int cnt[4];
-                QuadCls cls; cls.mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1); cls.my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
-                const int bsel = node_buf(nd);
-                block_partition4(bsel ? bufB : bufA, bsel ? bufA : bufB, (int)nd.start, node_cnt(nd), cls, s_i, cnt);
-                if (tid < 4) childcnt[4 * i + tid] = (uint32_t)(tid == 0 ? cnt[0] : tid == 1 ? cnt[1] : tid == 2 ? cnt[2] : cnt[3]);
-            }
-        }
-        wave_partition_many(nnodes, IdentityIdx(), cur, bufA, bufB, childcnt, D);
         __syncthreads();
+        const int kinds = *s_kinds;
+        if (kinds & kDeepBig) {
+            for (int i = 0; i < nnodes; i++) {
+                const QNode nd = cur[i];
+                if (node_cnt(nd) > kBigSpan && (int)nd.depth >= D) {
+                    int cnt[4];
+                    QuadCls cls; cls.mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1); cls.my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+                    const int bsel = node_buf(nd);
+                    block_partition4(bsel ? bufB : bufA, bsel ? bufA : bufB, (int)nd.start, node_cnt(nd), cls, s_i, cnt);
+                    if (tid < 4) childcnt[4 * i + tid] = (uint32_t)(tid == 0 ? cnt[0] : tid == 1 ? cnt[1] : tid == 2 ? cnt[2] : cnt[3]);
+                }
+            }
+        }
+        if (kinds & kDeepSmall) wave_partition_many(nnodes, IdentityIdx(), cur, bufA, bufB, childcnt, D);
+        __syncthreads();
+        if (tid == 0) *s_kinds = 0;
         int T = 0, E = 0, K = 0;
         {
             // exclusive scans over the list of (m = non-empty children, e = children with >1 key, k = kept)
@@ -634,43 +718,61 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                 block_sort_libstdcxx(expc, expn, nexp, childcnt, childcnt + 2 * (size_t)node_cap, erased, s_i + 8);
                 QT_STAMP(5)
                 for (int i = tid; i < nnodes; i += 256) erased[i] = 0;
-                __syncthreads();
+                if (tid == 0) s_i[0] = nexp;
                 // children counts of every candidate (partition into the other buffer; harmless if the
                 // node ends up not being divided: its own buffer is untouched)
-                for (int j = tid; j < nexp; j += 256) {    // presorted depths: counts from the bucket offsets
-                    const int idx = (int)(expc[j] & 0xFFFF);
-                    const QNode nd = cur[idx];
-                    if ((int)nd.depth < D) {
-                        int cnt[4];
-                        presorted_child_counts(nd, D, bucket_start, cnt);
-                        childcnt[4 * idx] = (uint32_t)cnt[0]; childcnt[4 * idx + 1] = (uint32_t)cnt[1]; childcnt[4 * idx + 2] = (uint32_t)cnt[2]; childcnt[4 * idx + 3] = (uint32_t)cnt[3];
-                    }
-                }
-                for (int j = 0; j < nexp; j++) {           // (rare) spans too big for one wave
-                    const int idx = (int)(expc[j] & 0xFFFF);
-                    const QNode nd = cur[idx];
-                    if (node_cnt(nd) > kBigSpan && (int)nd.depth >= D) {
-                        int cnt[4];
-                        QuadCls cls; cls.mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1); cls.my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
-                        const int bsel = node_buf(nd);
-                        block_partition4(bsel ? bufB : bufA, bsel ? bufA : bufB, (int)nd.start, node_cnt(nd), cls, s_i, cnt);
-                        if (tid < 4) childcnt[4 * idx + tid] = (uint32_t)(tid == 0 ? cnt[0] : tid == 1 ? cnt[1] : tid == 2 ? cnt[2] : cnt[3]);
-                    }
-                }
-                { ExpandIdx ei; ei.e = expc; wave_partition_many(nexp, ei, cur, bufA, bufB, childcnt, D); }
-                __syncthreads();
-                QT_STAMP(6)
-                // how many of the sorted candidates get divided before `size >= N` breaks the loop
-                if (tid == 0) {
-                    int size = prev2, ndiv = 0;
-                    for (int j = nexp - 1; j >= 0; j--) {
+                {
+                    int kinds = 0;
+                    for (int j = tid; j < nexp; j += 256) {    // presorted depths: counts from the bucket offsets
                         const int idx = (int)(expc[j] & 0xFFFF);
-                        int m = 0;
-                        for (int q = 0; q < 4; q++) m += childcnt[4 * idx + q] > 0;
-                        size += m - 1; ndiv++;
-                        if (size >= N) break;
+                        const QNode nd = cur[idx];
+                        if ((int)nd.depth < D) {
+                            int cnt[4];
+                            presorted_child_counts(nd, D, bucket_start, cnt);
+                            childcnt[4 * idx] = (uint32_t)cnt[0]; childcnt[4 * idx + 1] = (uint32_t)cnt[1]; childcnt[4 * idx + 2] = (uint32_t)cnt[2]; childcnt[4 * idx + 3] = (uint32_t)cnt[3];
+                        } else kinds |= node_cnt(nd) > kBigSpan ? kDeepBig : kDeepSmall;
                     }
-                    s_i[0] = ndiv;
+                    if (kinds) atomicOr(s_kinds, kinds);
+                }
+                __syncthreads();
+                const int kinds = *s_kinds;
+                if (kinds & kDeepBig) {
+                    for (int j = 0; j < nexp; j++) {           // (rare) spans too big for one wave
+                        const int idx = (int)(expc[j] & 0xFFFF);
+                        const QNode nd = cur[idx];
+                        if (node_cnt(nd) > kBigSpan && (int)nd.depth >= D) {
+                            int cnt[4];
+                            QuadCls cls; cls.mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1); cls.my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+                            const int bsel = node_buf(nd);
+                            block_partition4(bsel ? bufB : bufA, bsel ? bufA : bufB, (int)nd.start, node_cnt(nd), cls, s_i + 1, cnt);
+                            if (tid < 4) childcnt[4 * idx + tid] = (uint32_t)(tid == 0 ? cnt[0] : tid == 1 ? cnt[1] : tid == 2 ? cnt[2] : cnt[3]);
+                        }
+                    }
+                }
+                if (kinds & kDeepSmall) { ExpandIdx ei; ei.e = expc; wave_partition_many(nexp, ei, cur, bufA, bufB, childcnt, D); }
+                __syncthreads();
+                if (tid == 0) *s_kinds = 0;
+                QT_STAMP(6)
+                // how many of the sorted candidates get divided before `size >= N` breaks the loop (:995-1012): candidate t (sorted index
+                // nexp - 1 - t) leaves the list with prev2 + sum over t' <= t of (non-empty children - 1) nodes; the first t that reaches N
+                // is the last one divided
+                {
+                    int run = prev2;
+                    for (int t0 = 0; t0 < nexp; t0 += 256) {
+                        const int t = t0 + tid;
+                        int v = 0;
+                        if (t < nexp) {
+                            const int idx = (int)(expc[nexp - 1 - t] & 0xFFFF);
+                            int m = 0;
+                            for (int q = 0; q < 4; q++) m += childcnt[4 * idx + q] > 0;
+                            v = m - 1;
+                        }
+                        unsigned long long tot;
+                        const int incl = run + (int)block_excl_scan<unsigned long long>((unsigned long long)v, &tot, s_scan) + v;
+                        if (t < nexp && incl >= N) atomicMin(&s_i[0], t + 1);
+                        run += (int)tot;
+                        if (run >= N) break;            // uniform
+                    }
                 }
                 __syncthreads();
                 QT_STAMP(7)
@@ -755,23 +857,37 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
         if (tid == 0) { atomicOr(status, 1); lvl_count[(size_t)b * nlevels + level] = 0; }
         return;
     }
-    for (int i = tid; i < nnodes; i += 256) {
-        const QNode nd = cur[i];
-        const uint32_t* kb = (node_buf(nd) ? bufB : bufA) + nd.start;
-        const int c = node_cnt(nd);
-        // "first key with the largest response" in vKeys order (:1028-1053).  vKeys order = FAST emission order = cells
-        // row-major, then y, then x, which is a function of the key itself; spans that were never physically partitioned
-        // are ordered by bucket instead, so the order is recomputed rather than read off the position.
-        uint32_t best = kb[0];
-        unsigned long long bo = vkeys_order(best, L.wcell, L.hcell);
-        for (int k = 1; k < c; k++) {
-            const uint32_t key = kb[k];
-            const int ds = key_s(key) - key_s(best);
-            if (ds < 0) continue;
-            const unsigned long long ko = vkeys_order(key, L.wcell, L.hcell);
-            if (ds > 0 || ko < bo) { best = key; bo = ko; }
+    // "first key with the largest response" in vKeys order (:1028-1053).  vKeys order = FAST emission order = cells row-major, then y, then
+    // x, which is a function of the key itself; spans that were never physically partitioned are ordered by bucket instead, so the order is
+    // recomputed rather than read off the position.  Four lanes share a node (keys k = r, r + 4, ..; four loads in flight per lane) and
+    // combine their candidates with the same rule.
+    for (int i0 = 0; i0 < nnodes; i0 += 64) {
+        const int i = i0 + (tid >> 2), r = tid & 3;
+        uint32_t best = 0; int bs = -1; unsigned long long bo = ~0ull;
+        if (i < nnodes) {
+            const QNode nd = cur[i];
+            const uint32_t* kb = (node_buf(nd) ? bufB : bufA) + nd.start;
+            const int c = node_cnt(nd);
+            for (int k0 = r; k0 < c; k0 += 16) {
+                uint32_t key[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) key[u] = k0 + 4 * u < c ? kb[k0 + 4 * u] : 0u;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (k0 + 4 * u >= c) continue;
+                    const int ds = key_s(key[u]) - bs;
+                    if (ds < 0) continue;
+                    const unsigned long long ko = vkeys_order(key[u], L.wcell, L.hcell);
+                    if (ds > 0 || ko < bo) { best = key[u]; bs = key_s(key[u]); bo = ko; }
+                }
+            }
         }
-        outk[i] = best;
+#pragma unroll
+        for (int d = 1; d <= 2; d <<= 1) {
+            const uint32_t ob = __shfl_xor(best, d); const int os = __shfl_xor(bs, d); const unsigned long long oo = __shfl_xor(bo, d);
+            if (os > bs || (os == bs && oo < bo)) { best = ob; bs = os; bo = oo; }
+        }
+        if (i < nnodes && r == 0) outk[i] = best;
     }
     if (tid == 0) lvl_count[(size_t)b * nlevels + level] = nnodes;
     QT_STAMP(9)

@@ -106,9 +106,31 @@ ORBX_HD inline int sm_unguarded_partition(T* a, int first, int last, int pivot, 
     }
 }
 
-// std::sort(a, a+n, less)
+// The same partition in the data-parallel form the quadtree kernel uses for long ranges (wave_unguarded_partition in k_quadtree.hip):
+// L_0 < L_1 < .. = positions of the elements >= pivot, R_0 > R_1 > .. = positions of the elements <= pivot (initial values); swap k
+// exchanges a[L_k], a[R_k]; K = #{k : L_k < R_k} swaps happen; the cut is min(L_K, R_(K-1)).  Host-only (tests compare it with the loop above).
+#if !defined(__HIP_DEVICE_COMPILE__)
 template <typename T, typename Less>
-ORBX_HD inline void libstdcxx_sort(T* a, int n, Less less) {
+inline int sm_unguarded_partition_lists(T* a, int lo, int hi, int pivot, Less less) {
+    const int m = hi - lo;
+    int* Lp = new int[2 * (m > 0 ? m : 1)];
+    int* Rp = Lp + (m > 0 ? m : 1);
+    int nL = 0, nR = 0;
+    for (int i = lo; i < hi; i++) if (!less(a[i], a[pivot])) Lp[nL++] = i;
+    for (int i = hi - 1; i >= lo; i--) if (!less(a[pivot], a[i])) Rp[nR++] = i;
+    int K = 0;
+    while (K < nL && K < nR && Lp[K] < Rp[K]) { T t = a[Lp[K]]; a[Lp[K]] = a[Rp[K]]; a[Rp[K]] = t; K++; }
+    int cut = 0x7FFFFFFF;
+    if (K < nL) cut = Lp[K];
+    if (K >= 1 && Rp[K - 1] < cut) cut = Rp[K - 1];
+    delete[] Lp;
+    return cut;
+}
+#endif
+
+// std::sort(a, a+n, less); LISTS selects the data-parallel form of the partition step (host tests)
+template <typename T, typename Less>
+ORBX_HD inline void libstdcxx_sort(T* a, int n, Less less, bool lists = false) {
     if (n <= 0) return;
     int lg = 0;
     for (int t = n; t > 1; t >>= 1) lg++;
@@ -125,7 +147,11 @@ ORBX_HD inline void libstdcxx_sort(T* a, int n, Less less) {
             --depth;
             const int mid = first + (last - first) / 2;
             sm_move_median_to_first(a, first, first + 1, mid, last - 1, less);
+#if !defined(__HIP_DEVICE_COMPILE__)
+            const int cut = lists ? sm_unguarded_partition_lists(a, first + 1, last, first, less) : sm_unguarded_partition(a, first + 1, last, first, less);
+#else
             const int cut = sm_unguarded_partition(a, first + 1, last, first, less);
+#endif
             stk_first[sp] = cut; stk_last[sp] = last; stk_depth[sp] = depth; sp++;
             last = cut;
         }

@@ -41,6 +41,10 @@ int main() {
             orbx::libstdcxx_sort(b.data(), n, lessE);
             cases++;
             for (int i = 0; i < n; i++) if (a[i].id != b[i].id) { bad++; break; }
+            // the data-parallel form of the partition step (what the quadtree kernel's waves execute)
+            std::vector<E> c = v;
+            orbx::libstdcxx_sort(c.data(), n, lessE, true);
+            for (int i = 0; i < n; i++) if (a[i].id != c[i].id) { bad++; break; }
         }
     }
     printf("cases %ld bad %ld\n", cases, bad);

@@ -74,7 +74,7 @@ for B in (2, 16, 64, 128):
     ex.sync(); dt=(time.time()-t)/K
     u,dd,n = M.ComputeStereoMatches(ex, ex, bf, b, 0, B//2, B//2)
     qp = np.zeros(16, np.int64); lib.L.orbx_debug_quadtree_profile(ex._h, qp.ctypes.data)
-    print('  quadtree L0 phases (us): gather %.1f roots %.1f passes %.1f [final: sort %.1f part %.1f ndiv %.1f] total %.1f  n=%d nodes=%d nexp=%d' % ((qp[1]-qp[0])/100,(qp[2]-qp[1])/100,(qp[3]-qp[2])/100,(qp[5]-qp[4])/100,(qp[6]-qp[5])/100,(qp[7]-qp[6])/100,(qp[9]-qp[0])/100,qp[10],qp[11],qp[12]))
+    print('  quadtree L0 phases (us): gather %.1f roots %.1f passes %.1f [last final round: sort %.1f part %.1f ndiv %.1f rebuild %.1f] select %.1f total %.1f  n=%d nodes=%d nexp=%d' % ((qp[1]-qp[0])/100,(qp[2]-qp[1])/100,(qp[3]-qp[2])/100,(qp[5]-qp[4])/100,(qp[6]-qp[5])/100,(qp[7]-qp[6])/100,(qp[8]-qp[7])/100,(qp[9]-qp[8])/100,(qp[9]-qp[0])/100,qp[10],qp[11],qp[12]))
     print('B',B,'ms/batch %.3f'%(dt*1e3),'pairs/s %.0f'%((B//2)/dt), 'stages', {k:round(v,3) for k,v in ex.stage_ms().items()}, 'matches', n[:3], flush=True)
 
 # ---- single-pair latency: eager vs hipGraph replay ----

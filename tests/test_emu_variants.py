@@ -16,11 +16,13 @@ ROOT = ol.ROOT
 CSRC = os.path.join(ROOT, "orb_slam3_detailed_comments_amd", "csrc")
 
 
-@pytest.mark.parametrize("presort_max,bigspan", [(1, 80), (0, 1024)])
-def test_quadtree_path_mix(tmp_path, presort_max, bigspan):
+@pytest.mark.parametrize("presort_max,bigspan,wave_sort_range", [(1, 80, 16), (0, 1024, 100000)])
+def test_quadtree_path_mix(tmp_path, presort_max, bigspan, wave_sort_range):
+    # wave_sort_range: ranges of the final rounds' std::sort model above this length are partitioned by a wave (16 = every range,
+    # 100000 = none: the one-thread loop)
     so = str(tmp_path / "liborbx_emu_variant.so")
     srcs = [os.path.join(CSRC, f) for f in ("k_image.hip", "k_fast.hip", "k_quadtree.hip", "k_describe.hip", "k_match.hip", "k_search.hip", "k_vocab.hip", "k_input.hip", "orbx_api.cpp", "orbm_search.cpp", "orbv_api.cpp")]
-    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-DORBX_EMU", "-DORBX_PRESORT_MAX=%d" % presort_max, "-DORBX_BIGSPAN=%d" % bigspan,
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-DORBX_EMU", "-DORBX_PRESORT_MAX=%d" % presort_max, "-DORBX_BIGSPAN=%d" % bigspan, "-DORBX_WAVE_SORT_RANGE=%d" % wave_sort_range,
                     "-I" + os.path.join(ROOT, "tests", "emu"), "-I" + CSRC, "-fPIC", "-shared", "-w", "-x", "c++"] + srcs + ["-o", so, "-lpthread"], check=True)
     lib = _lib.OrbxLib(so)
     for name, factory, nf, lap in SMALL_CASES + FULL_CASES[:1] + FULL_CASES[4:5]:
