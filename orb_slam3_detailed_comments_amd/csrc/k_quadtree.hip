@@ -20,6 +20,7 @@
 // Key buffers A/B live in HBM (L2-resident); node lists, bucket offsets and scratch live in LDS.
 #include "orbx_types.h"
 #include "orbx_block.h"
+#include "orbx_kernels.h"
 #include "libstdcxx_sort_model.h"
 
 namespace orbx {
@@ -27,6 +28,10 @@ namespace orbx {
 #ifndef ORBX_BIGSPAN
 #define ORBX_BIGSPAN 1024
 #endif
+#ifndef ORBX_PRESORT_U16_MAX
+#define ORBX_PRESORT_U16_MAX 65535
+#endif
+constexpr int kPresortU16Max = ORBX_PRESORT_U16_MAX;     // levels with more keys count in 32-bit counters (tests lower it to force that path)
 constexpr int kBigSpan = ORBX_BIGSPAN;   // spans above this are partitioned by the whole workgroup (tests also build with 80)
 
 struct SortLess {
@@ -94,14 +99,14 @@ __device__ __forceinline__ void wave_partition(const QNode nd, const uint32_t* _
 
 
 // Block-cooperative stable partition of the span [s, s+c) into <= 4 classes (src -> dst, same offsets): every wave owns a
-// contiguous quarter of the span, counts its classes with ballots, the four waves exchange counts through LDS once, then
+// contiguous 1/nw of the span, counts its classes with ballots, the waves exchange counts through LDS once, then
 // each wave writes its keys at its ordered offsets.  Two barriers per call instead of two per 256 keys.
-// cls(key) in [0,4).  s_cnt: 16 ints of LDS.  All 256 threads must call.  cnt[] = class totals (valid in every thread).
+// cls(key) in [0,4).  s_cnt: 4 << lgnw ints of LDS.  All (64 << lgnw) threads must call.  cnt[] = class totals (valid in every thread).
 template <typename F>
 __device__ __forceinline__ void block_partition4(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int s, int c,
-                                                 F cls, int* s_cnt, int cnt[4]) {
-    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-    const int seg = ((c + 255) >> 8) << 6;
+                                                 F cls, int* s_cnt, int cnt[4], int lgnw) {
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6), nw = 1 << lgnw;
+    const int seg = ((c + (64 << lgnw) - 1) >> (6 + lgnw)) << 6;
     const int beg = wave * seg, end = imin(c, beg + seg);
     const unsigned long long lt = (1ull << lane) - 1ull;
     int tot[4] = {0, 0, 0, 0};
@@ -122,8 +127,7 @@ __device__ __forceinline__ void block_partition4(const uint32_t* __restrict__ sr
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         int before = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < 4; w++) { const int v = s_cnt[w * 4 + k]; total += v; before += w < wave ? v : 0; }
+        for (int w = 0; w < nw; w++) { const int v = s_cnt[w * 4 + k]; total += v; before += w < wave ? v : 0; }
         cnt[k] = total; run[k] = acc + before; acc += total;
     }
     for (int i0 = beg; i0 < end; i0 += 256) {
@@ -213,12 +217,12 @@ __device__ __forceinline__ int wave_unguarded_partition(unsigned long long* a, i
 //    insertion sort is stable, so it equals a stable rank-sort inside every final range of <= 16 elements: each thread
 //    ranks one element among its <= 16 range-mates.
 // seg0/seg1: two range lists (first | last << 12 | depth << 24), capacity >= n/8 + 8 each; flags: n bytes
-// (1 = a final range starts here, 2 = a heap-sorted range starts here); tmp: n elements.  All 256 threads must call.
+// (1 = a final range starts here, 2 = a heap-sorted range starts here); tmp: n elements.  All NT threads of the workgroup must call.
 __device__ __forceinline__ void block_sort_libstdcxx(unsigned long long* a, unsigned long long* tmp, int n,
-                                                     uint32_t* seg0, uint32_t* seg1, uint8_t* flags, int* s_ctr) {
+                                                     uint32_t* seg0, uint32_t* seg1, uint8_t* flags, int* s_ctr, int NT) {
     const int tid = (int)threadIdx.x;
     SortLess less;
-    for (int i = tid; i < n; i += (int)blockDim.x) flags[i] = 0;
+    for (int i = tid; i < n; i += NT) flags[i] = 0;
     if (tid == 0) {
         int lg = 0;
         for (int t = n; t > 1; t >>= 1) lg++;
@@ -229,7 +233,7 @@ __device__ __forceinline__ void block_sort_libstdcxx(unsigned long long* a, unsi
     __syncthreads();
     uint32_t* cur = seg0; uint32_t* nxt = seg1;
     int which = 0;
-    const int lane = lane_id(), wave = tid >> 6, nwaves = (int)(blockDim.x >> 6);
+    const int lane = lane_id(), wave = tid >> 6, nwaves = NT >> 6;
     for (;;) {
         const int ncur = s_ctr[which];
         if (ncur == 0) break;
@@ -249,7 +253,7 @@ __device__ __forceinline__ void block_sort_libstdcxx(unsigned long long* a, unsi
                 if (cut - first > 16) nxt[atomicAdd(&s_ctr[which ^ 1], 1)] = (uint32_t)first | ((uint32_t)cut << 12) | ((uint32_t)depth << 24);
             }
         }
-        for (int j = tid; j < ncur; j += (int)blockDim.x) {
+        for (int j = tid; j < ncur; j += NT) {
             const uint32_t sg = cur[j];
             const int first = (int)(sg & 0xFFF), last = (int)((sg >> 12) & 0xFFF);
             int depth = (int)(sg >> 24);
@@ -274,7 +278,7 @@ __device__ __forceinline__ void block_sort_libstdcxx(unsigned long long* a, unsi
         __syncthreads();
     }
     // final insertion sort == stable rank inside each final range
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += NT) {
         int f = i;
         while (flags[f] == 0) --f;
         const unsigned long long v = a[i];
@@ -292,18 +296,18 @@ __device__ __forceinline__ void block_sort_libstdcxx(unsigned long long* a, unsi
         tmp[pos] = v;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 256) a[i] = tmp[i];
+    for (int i = tid; i < n; i += NT) a[i] = tmp[i];
     __syncthreads();
 }
 
 
-// One wave partitions the nodes idx_of(j), j = wave, wave+4, ... < count, skipping spans of <= 1 key and spans above
+// One wave partitions the nodes idx_of(j), j = wave, wave+nw, ... < count, skipping spans of <= 1 key and spans above
 // kBigSpan (done cooperatively elsewhere).  Spans of <= 64 keys (the common case) are software-pipelined: the keys of
 // the next node are requested before the ballots of the current one, hiding most of the L2 latency.
 template <typename IdxFn>
 __device__ __forceinline__ void wave_partition_many(int count, IdxFn idx_of, const QNode* __restrict__ cur,
                                                     uint32_t* __restrict__ bufA, uint32_t* __restrict__ bufB,
-                                                    uint32_t* __restrict__ childcnt, int D) {
+                                                    uint32_t* __restrict__ childcnt, int D, int nw) {
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     const unsigned long long lt = (1ull << lane) - 1ull;
     int j = wave;
@@ -319,7 +323,7 @@ __device__ __forceinline__ void wave_partition_many(int count, IdxFn idx_of, con
         }
     }
     while (j < count) {
-        const int jn = j + 4;
+        const int jn = j + nw;
         int idxn = 0; QNode ndn = nd; uint32_t keyn[4] = {0, 0, 0, 0};
         if (jn < count) {           // request the next node's keys before working on this one
             idxn = idx_of(jn); ndn = cur[idxn];
@@ -410,24 +414,106 @@ __device__ __forceinline__ unsigned long long vkeys_order(uint32_t key, int wcel
     return (ci << 36) | (cj << 24) | ((unsigned long long)y << 12) | (unsigned long long)x;
 }
 
-// grid (B, nlevels), 256 threads.  Dynamic LDS: see carve below (host passes node_cap).
-__global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ lv,
+// The up-front stable counting sort of a level's keys (bufB -> bufA) by bucket code = xpart[x] + ypart[y]: the keys are cut into nseg
+// contiguous segments of whole 64-key chunks, wave w < nseg owns segment w.  counts[w][b] (CT = uint16_t when the level has < 65536 keys,
+// else uint32_t with fewer segments in the same LDS) first holds the segment's histogram, then the number of keys of bucket b in the
+// segments before w, i.e. the wave's cursor relative to bucket_start[b].
+template <typename CT>
+__device__ __forceinline__ void presort_keys(const uint32_t* __restrict__ bufB, uint32_t* __restrict__ bufA, int n, int NB, int nseg, CT* counts,
+                                             int* bucket_start, const uint16_t* xpart, const uint16_t* ypart, unsigned long long* s_scan, int NT) {
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < nseg * NB; i += NT) counts[i] = 0;
+    __syncthreads();
+    const int seg = ((n + 64 * nseg - 1) / (64 * nseg)) << 6;
+    const int beg = imin(n, wave * seg), end = wave < nseg ? imin(n, beg + seg) : beg;
+    CT* mycount = counts + (wave < nseg ? wave : 0) * NB;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int nbits = 0;
+    while ((1 << nbits) < NB) nbits++;
+    // histogram: lanes of a 64-key chunk that share a bucket are found with a bit-wise match (ballots) and the highest
+    // lane of each group adds the group size once — neighbouring keys usually share a bucket, so per-lane LDS atomics
+    // would serialise.  Four chunks per trip keep four key loads in flight.
+    for (int i0 = beg; i0 < end; i0 += 256) {
+        uint32_t key[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u + lane; key[u] = i < end ? bufB[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool in = i0 + 64 * u + lane < end;
+            const uint32_t code = in ? ((uint32_t)xpart[key_x(key[u])] + (uint32_t)ypart[key_y(key[u])]) : 0xFFFFFFFFu;
+            unsigned long long same = __ballot(in);
+            for (int bit = 0; bit < nbits; bit++) {
+                const unsigned long long bb = __ballot((code >> bit) & 1u);
+                same &= ((code >> bit) & 1u) ? bb : ~bb;
+            }
+            if (in && (same >> lane) <= 1ull) mycount[code] = (CT)(mycount[code] + __popcll(same));
+            ORBX_WAVE_SYNC();
+        }
+    }
+    __syncthreads();
+    // exclusive scan over buckets of the totals
+    int run = 0;
+    for (int b0 = 0; b0 < NB; b0 += NT) {
+        const int bk = b0 + tid;
+        int tot_b = 0;
+        if (bk < NB)
+            for (int w = 0; w < nseg; w++) { const int c = (int)counts[w * NB + bk]; counts[w * NB + bk] = (CT)tot_b; tot_b += c; }
+        unsigned long long tot;
+        const int ex = run + (int)block_excl_scan_n<unsigned long long>((unsigned long long)tot_b, &tot, s_scan, NT >> 6);
+        if (bk < NB) bucket_start[bk] = ex;
+        run += (int)tot;
+    }
+    if (tid == 0) bucket_start[NB] = run;
+    __syncthreads();
+    // stable scatter: same match; rank inside the group = number of lower lanes in it
+    for (int i0 = beg; i0 < end; i0 += 256) {
+        uint32_t key[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u + lane; key[u] = i < end ? bufB[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool in = i0 + 64 * u + lane < end;
+            const uint32_t code = in ? ((uint32_t)xpart[key_x(key[u])] + (uint32_t)ypart[key_y(key[u])]) : 0xFFFFFFFFu;
+            unsigned long long same = __ballot(in);
+            for (int bit = 0; bit < nbits; bit++) {
+                const unsigned long long bb = __ballot((code >> bit) & 1u);
+                same &= ((code >> bit) & 1u) ? bb : ~bb;
+            }
+            int cursor = 0;
+            if (in) { cursor = (int)mycount[code]; bufA[bucket_start[code] + cursor + __popcll(same & lt)] = key[u]; }
+            ORBX_WAVE_SYNC();           // every lane of a group has read the cursor ...
+            if (in && (same >> lane) <= 1ull) mycount[code] = (CT)(cursor + __popcll(same));     // ... before its highest lane advances it
+            ORBX_WAVE_SYNC();
+        }
+    }
+}
+
+// grid (B, nlevels), kQuadtreeThreads threads of which the first L.qt_threads (256 or 1024, by the size of the level) work on the level
+// and the rest exits at once.  Dynamic LDS: see carve below (host passes node_cap).
+__global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* __restrict__ lv,
                                                   const CellInfo* __restrict__ cells, int ncells,
                                                   const int* __restrict__ cell_count,
                                                   const uint32_t* __restrict__ slots, size_t slots_stride,
                                                   uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
                                                   uint32_t* __restrict__ lvl_keys, int kp_total_cap,
                                                   int* __restrict__ lvl_count, int nlevels, int node_cap, int nb_cap, int lut_x, int lut_y,
-                                                  int* __restrict__ status, long long* __restrict__ qt_prof) {
+                                                  int* __restrict__ status, long long* __restrict__ qt_prof, int wide, int counter_bytes) {
     ORBX_DYN_SMEM(smem);
     __shared__ unsigned long long s_scan[20];
-    __shared__ int s_i[24];
-    int* s_kinds = s_i + 23;                            // kinds of deep nodes met in the current pass (kDeepSmall | kDeepBig)
+    __shared__ int s_i[80];
+    int* s_part = s_i;                                  // block_partition4: 4 counts per wave
+    int* s_ndiv = s_i + 64;
+    int* s_sortctr = s_i + 66;
+    int* s_kinds = s_i + 68;                            // kinds of deep nodes met in the current pass (kDeepSmall | kDeepBig)
     // grid (B, nlevels): workgroups are dispatched image-fastest, i.e. every image's level 0 (the longest tree by far) starts first and the
     // short trees of the small levels fill the remaining slots
     const int level = (int)blockIdx.y, b = (int)blockIdx.x;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = (int)threadIdx.x, lane = tid & 63;
     const LevelInfo L = lv[level];
+    // wide: the large levels get L.qt_threads threads (small batches: the latency of one tree is what counts); otherwise every level runs on
+    // four waves, which packs more trees on a CU (large batches)
+    const int NT = wide ? L.qt_threads : 256, NW = NT >> 6, lgNW = NT == 256 ? 2 : NT == 512 ? 3 : 4;
+    if (tid >= NT) return;
     const int N = L.quota;
 #ifdef ORBX_EMU
 #define QT_STAMP(i)
@@ -436,15 +522,16 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
 #endif
     QT_STAMP(0)
     if (tid == 0) *s_kinds = 0;
-    // LDS carve: nodes[2][cap] (24 B) | childcnt[cap][4] (u32) | expand[2][cap] (u64) | bucket_start[nb+1] | wcount[4][nb] | erased[cap] (u8)
+    // LDS carve: nodes[2][cap] (24 B) | childcnt[cap][4] (u32) | expand[2][cap] (u64) | bucket_start[nb+1] | counts (counter_bytes per bucket: u16 or u32 per
+    // segment) | code LUTs | erased[cap] (u8)
     QNode* nodes0 = (QNode*)smem;
     QNode* nodes1 = nodes0 + node_cap;
     uint32_t* childcnt = (uint32_t*)(nodes1 + node_cap);
     unsigned long long* exp0 = (unsigned long long*)(childcnt + 4 * (size_t)node_cap);
     unsigned long long* exp1 = exp0 + node_cap;
     int* bucket_start = (int*)(exp1 + node_cap);
-    int* wcount = bucket_start + (nb_cap + 1);
-    uint16_t* xpart = (uint16_t*)(wcount + 4 * (size_t)nb_cap);     // bucket code = xpart[x] + ypart[y]
+    int* counts = bucket_start + (nb_cap + 2);
+    uint16_t* xpart = (uint16_t*)(counts + (size_t)(counter_bytes >> 2) * nb_cap);     // bucket code = xpart[x] + ypart[y]
     uint16_t* ypart = xpart + lut_x;
     uint8_t* erased = (uint8_t*)(ypart + lut_y);
     const int D = L.presort_depth, NBr = 1 << (2 * D), NB = L.nini * NBr;     // buckets per root / in total
@@ -454,17 +541,30 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
     const uint32_t* slot_base = slots + (size_t)b * slots_stride;
 
     // ---- P0: gather the level's candidates in the reference order (cells row-major) into bufB ----
+    // NT / 256 lanes per cell, 256 cells per trip
     int n = 0;
-    for (int c0 = 0; c0 < L.cell_count; c0 += 256) {       // one thread per cell: 256 independent copy streams
-        const int c = c0 + tid;
-        const int cnt = c < L.cell_count ? ccount[c] : 0;
-        unsigned long long tot;
-        const int pos = n + (int)block_excl_scan<unsigned long long>((unsigned long long)cnt, &tot, s_scan);
-        if (cnt > 0) {
-            const uint32_t* sp = slot_base + cells[L.cell_begin + c].slot_off;
-            for (int k = 0; k < cnt; k++) bufB[pos + k] = sp[k];
+    {
+        const int lgt = lgNW - 2, sub = tid & ((1 << lgt) - 1), tpc = 1 << lgt;
+        for (int c0 = 0; c0 < L.cell_count; c0 += 256) {
+            const int c = c0 + (tid >> lgt);
+            const int cnt = c < L.cell_count ? ccount[c] : 0;
+            unsigned long long tot;
+            int pos = n + (int)block_excl_scan_n<unsigned long long>((unsigned long long)(sub == 0 ? cnt : 0), &tot, s_scan, NW);
+            pos = __shfl(pos, lane & ~(tpc - 1));
+            if (cnt > 0) {
+                const uint32_t* sp = slot_base + cells[L.cell_begin + c].slot_off;
+                int k = sub;
+                for (; k + 7 * tpc < cnt; k += 8 * tpc) {          // eight loads in flight
+                    uint32_t v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) v[u] = sp[k + u * tpc];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) bufB[pos + k + u * tpc] = v[u];
+                }
+                for (; k < cnt; k += tpc) bufB[pos + k] = sp[k];
+            }
+            n += (int)tot;
         }
-        n += (int)tot;
     }
     __syncthreads();
     QT_STAMP(1)
@@ -472,10 +572,9 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
     // bucket(key) = root index (int)(x / hX) (:763), then the D child digits DivideNode (:602-674) would assign on the way
     // down.  After the sort every node of depth <= D is a contiguous span, its children are laid out n1|n2|n3|n4 and keys keep
     // their vKeys order inside a bucket (stable), which is exactly the state D partition passes would have produced.
-    for (int i = tid; i < 4 * NB; i += 256) wcount[i] = 0;
     // The child digit at every depth is (right ? 1 : 0) + (bottom ? 2 : 0): the x half depends only on x (and the root the x
     // falls in), the y half only on y, so the bucket code splits into two small LDS tables built once per workgroup.
-    for (int x = tid; x < L.bw; x += 256) {
+    for (int x = tid; x < L.bw; x += NT) {
         const int r = __float2int_rz(__fdiv_rn((float)x, L.hX));
         int x0 = __float2int_rz(__fmul_rn(L.hX, (float)r)), x1 = __float2int_rz(__fmul_rn(L.hX, (float)(r + 1)));
         int code = r;
@@ -487,7 +586,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
         }
         xpart[x] = (uint16_t)code;
     }
-    for (int y = tid; y < L.bh; y += 256) {
+    for (int y = tid; y < L.bh; y += NT) {
         int y0 = 0, y1 = L.bh, code = 0;
         for (int d = 0; d < D; d++) {
             const int my = y0 + ((y1 - y0 + 1) >> 1);
@@ -497,73 +596,8 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
         }
         ypart[y] = (uint16_t)code;
     }
-    __syncthreads();
-    {
-        const int seg = ((n + 255) >> 8) << 6;                        // contiguous quarter of the keys per wave
-        const int beg = wave * seg, end = imin(n, beg + seg);
-        int* mycount = wcount + wave * NB;
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        int nbits = 0;
-        while ((1 << nbits) < NB) nbits++;
-        // histogram: lanes of a 64-key chunk that share a bucket are found with a bit-wise match (ballots) and the highest
-        // lane of each group adds the group size once — neighbouring keys usually share a bucket, so per-lane LDS atomics
-        // would serialise.  Four chunks per trip keep four key loads in flight.
-        for (int i0 = beg; i0 < end; i0 += 256) {
-            uint32_t key[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u + lane; key[u] = i < end ? bufB[i] : 0u; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const bool in = i0 + 64 * u + lane < end;
-                const uint32_t code = in ? ((uint32_t)xpart[key_x(key[u])] + (uint32_t)ypart[key_y(key[u])]) : 0xFFFFFFFFu;
-                unsigned long long same = __ballot(in);
-                for (int bit = 0; bit < nbits; bit++) {
-                    const unsigned long long bb = __ballot((code >> bit) & 1u);
-                    same &= ((code >> bit) & 1u) ? bb : ~bb;
-                }
-                if (in && (same >> lane) <= 1ull) mycount[code] += __popcll(same);
-                ORBX_WAVE_SYNC();
-            }
-        }
-        __syncthreads();
-        // exclusive scan over buckets of the totals; wcount[w][b] becomes wave w's first output position in bucket b
-        int run = 0;
-        for (int b0 = 0; b0 < NB; b0 += 256) {
-            const int bk = b0 + tid;
-            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-            if (bk < NB) { c0 = wcount[bk]; c1 = wcount[NB + bk]; c2 = wcount[2 * NB + bk]; c3 = wcount[3 * NB + bk]; }
-            unsigned long long tot;
-            const int ex = run + (int)block_excl_scan<unsigned long long>((unsigned long long)(c0 + c1 + c2 + c3), &tot, s_scan);
-            if (bk < NB) {
-                bucket_start[bk] = ex;
-                wcount[bk] = ex; wcount[NB + bk] = ex + c0; wcount[2 * NB + bk] = ex + c0 + c1; wcount[3 * NB + bk] = ex + c0 + c1 + c2;
-            }
-            run += (int)tot;
-        }
-        if (tid == 0) bucket_start[NB] = run;
-        __syncthreads();
-        // stable scatter: same match; rank inside the group = number of lower lanes in it
-        for (int i0 = beg; i0 < end; i0 += 256) {
-            uint32_t key[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u + lane; key[u] = i < end ? bufB[i] : 0u; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const bool in = i0 + 64 * u + lane < end;
-                const uint32_t code = in ? ((uint32_t)xpart[key_x(key[u])] + (uint32_t)ypart[key_y(key[u])]) : 0xFFFFFFFFu;
-                unsigned long long same = __ballot(in);
-                for (int bit = 0; bit < nbits; bit++) {
-                    const unsigned long long bb = __ballot((code >> bit) & 1u);
-                    same &= ((code >> bit) & 1u) ? bb : ~bb;
-                }
-                int base = 0;
-                if (in) { base = mycount[code]; bufA[base + __popcll(same & lt)] = key[u]; }
-                ORBX_WAVE_SYNC();           // every lane of a group has read the cursor ...
-                if (in && (same >> lane) <= 1ull) mycount[code] = base + __popcll(same);     // ... before its highest lane advances it
-                ORBX_WAVE_SYNC();
-            }
-        }
-    }
+    if (n <= kPresortU16Max) presort_keys<uint16_t>(bufB, bufA, n, NB, imin(NW, counter_bytes >> 1), (uint16_t*)counts, bucket_start, xpart, ypart, s_scan, NT);
+    else presort_keys<uint32_t>(bufB, bufA, n, NB, imin(NW, counter_bytes >> 2), (uint32_t*)counts, bucket_start, xpart, ypart, s_scan, NT);
     __syncthreads();
     int nnodes = 0;
     for (int r = 0; r < L.nini; r++) {
@@ -596,7 +630,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
         // (which kinds of deep nodes exist is found on the way: most passes of a level move no key at all and skip the partition loops)
         {
             int kinds = 0;
-            for (int i = tid; i < nnodes; i += 256) {
+            for (int i = tid; i < nnodes; i += NT) {
                 const QNode nd = cur[i];
                 const int c = node_cnt(nd);
                 if (c > 1) {
@@ -618,12 +652,12 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                     int cnt[4];
                     QuadCls cls; cls.mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1); cls.my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
                     const int bsel = node_buf(nd);
-                    block_partition4(bsel ? bufB : bufA, bsel ? bufA : bufB, (int)nd.start, node_cnt(nd), cls, s_i, cnt);
+                    block_partition4(bsel ? bufB : bufA, bsel ? bufA : bufB, (int)nd.start, node_cnt(nd), cls, s_part, cnt, lgNW);
                     if (tid < 4) childcnt[4 * i + tid] = (uint32_t)(tid == 0 ? cnt[0] : tid == 1 ? cnt[1] : tid == 2 ? cnt[2] : cnt[3]);
                 }
             }
         }
-        if (kinds & kDeepSmall) wave_partition_many(nnodes, IdentityIdx(), cur, bufA, bufB, childcnt, D);
+        if (kinds & kDeepSmall) wave_partition_many(nnodes, IdentityIdx(), cur, bufA, bufB, childcnt, D, NW);
         __syncthreads();
         if (tid == 0) *s_kinds = 0;
         int T = 0, E = 0, K = 0;
@@ -631,7 +665,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
             // exclusive scans over the list of (m = non-empty children, e = children with >1 key, k = kept)
             unsigned long long run = 0, total_all = 0;
             // first compute totals (needed for the reversed block placement)
-            for (int i0 = 0; i0 < nnodes; i0 += 256) {
+            for (int i0 = 0; i0 < nnodes; i0 += NT) {
                 const int i = i0 + tid;
                 unsigned long long v = 0;
                 if (i < nnodes) {
@@ -643,13 +677,13 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                     } else v = 1ull << 40;
                 }
                 unsigned long long tot;
-                (void)block_excl_scan<unsigned long long>(v, &tot, s_scan);
+                (void)block_excl_scan_n<unsigned long long>(v, &tot, s_scan, NW);
                 total_all += tot;
             }
             T = (int)(total_all & 0xFFFFF); E = (int)((total_all >> 20) & 0xFFFFF); K = (int)(total_all >> 40);
             if (T + K > node_cap) { overflow = 1; }
             if (!overflow) {
-                for (int i0 = 0; i0 < nnodes; i0 += 256) {
+                for (int i0 = 0; i0 < nnodes; i0 += NT) {
                     const int i = i0 + tid;
                     unsigned long long v = 0; int c = 0; int cq[4] = {0, 0, 0, 0};
                     QNode nd;
@@ -662,7 +696,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                         } else v = 1ull << 40;
                     }
                     unsigned long long tot;
-                    const unsigned long long ex = run + block_excl_scan<unsigned long long>(v, &tot, s_scan);
+                    const unsigned long long ex = run + block_excl_scan_n<unsigned long long>(v, &tot, s_scan, NW);
                     run += tot;
                     if (i < nnodes) {
                         if (c > 1) {
@@ -715,15 +749,15 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                 QT_STAMP(4)
                 // scratch: the child-count table is not live here (range lists), `erased` doubles as the range-start flags,
                 // the other expand array is the rank-sort target
-                block_sort_libstdcxx(expc, expn, nexp, childcnt, childcnt + 2 * (size_t)node_cap, erased, s_i + 8);
+                block_sort_libstdcxx(expc, expn, nexp, childcnt, childcnt + 2 * (size_t)node_cap, erased, s_sortctr, NT);
                 QT_STAMP(5)
-                for (int i = tid; i < nnodes; i += 256) erased[i] = 0;
-                if (tid == 0) s_i[0] = nexp;
+                for (int i = tid; i < nnodes; i += NT) erased[i] = 0;
+                if (tid == 0) *s_ndiv = nexp;
                 // children counts of every candidate (partition into the other buffer; harmless if the
                 // node ends up not being divided: its own buffer is untouched)
                 {
                     int kinds = 0;
-                    for (int j = tid; j < nexp; j += 256) {    // presorted depths: counts from the bucket offsets
+                    for (int j = tid; j < nexp; j += NT) {    // presorted depths: counts from the bucket offsets
                         const int idx = (int)(expc[j] & 0xFFFF);
                         const QNode nd = cur[idx];
                         if ((int)nd.depth < D) {
@@ -744,12 +778,12 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                             int cnt[4];
                             QuadCls cls; cls.mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1); cls.my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
                             const int bsel = node_buf(nd);
-                            block_partition4(bsel ? bufB : bufA, bsel ? bufA : bufB, (int)nd.start, node_cnt(nd), cls, s_i + 1, cnt);
+                            block_partition4(bsel ? bufB : bufA, bsel ? bufA : bufB, (int)nd.start, node_cnt(nd), cls, s_part, cnt, lgNW);
                             if (tid < 4) childcnt[4 * idx + tid] = (uint32_t)(tid == 0 ? cnt[0] : tid == 1 ? cnt[1] : tid == 2 ? cnt[2] : cnt[3]);
                         }
                     }
                 }
-                if (kinds & kDeepSmall) { ExpandIdx ei; ei.e = expc; wave_partition_many(nexp, ei, cur, bufA, bufB, childcnt, D); }
+                if (kinds & kDeepSmall) { ExpandIdx ei; ei.e = expc; wave_partition_many(nexp, ei, cur, bufA, bufB, childcnt, D, NW); }
                 __syncthreads();
                 if (tid == 0) *s_kinds = 0;
                 QT_STAMP(6)
@@ -758,7 +792,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                 // is the last one divided
                 {
                     int run = prev2;
-                    for (int t0 = 0; t0 < nexp; t0 += 256) {
+                    for (int t0 = 0; t0 < nexp; t0 += NT) {
                         const int t = t0 + tid;
                         int v = 0;
                         if (t < nexp) {
@@ -768,18 +802,18 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                             v = m - 1;
                         }
                         unsigned long long tot;
-                        const int incl = run + (int)block_excl_scan<unsigned long long>((unsigned long long)v, &tot, s_scan) + v;
-                        if (t < nexp && incl >= N) atomicMin(&s_i[0], t + 1);
+                        const int incl = run + (int)block_excl_scan_n<unsigned long long>((unsigned long long)v, &tot, s_scan, NW) + v;
+                        if (t < nexp && incl >= N) atomicMin(s_ndiv, t + 1);
                         run += (int)tot;
                         if (run >= N) break;            // uniform
                     }
                 }
                 __syncthreads();
                 QT_STAMP(7)
-                const int ndiv = s_i[0];
+                const int ndiv = *s_ndiv;
                 // totals over the divided set (division order t = 0..ndiv-1 <-> sorted index nexp-1-t)
                 unsigned long long total_all = 0;
-                for (int t0 = 0; t0 < ndiv; t0 += 256) {
+                for (int t0 = 0; t0 < ndiv; t0 += NT) {
                     const int t = t0 + tid;
                     unsigned long long v = 0;
                     if (t < ndiv) {
@@ -790,14 +824,14 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                         erased[idx] = 1;
                     }
                     unsigned long long tot;
-                    (void)block_excl_scan<unsigned long long>(v, &tot, s_scan);
+                    (void)block_excl_scan_n<unsigned long long>(v, &tot, s_scan, NW);
                     total_all += tot;
                 }
                 const int T2 = (int)(total_all & 0xFFFFF), E2 = (int)((total_all >> 20) & 0xFFFFF);
                 __syncthreads();
                 if (T2 + (prev2 - ndiv) > node_cap) { overflow = 1; break; }
                 unsigned long long run = 0;
-                for (int t0 = 0; t0 < ndiv; t0 += 256) {
+                for (int t0 = 0; t0 < ndiv; t0 += NT) {
                     const int t = t0 + tid;
                     unsigned long long v = 0; int cq[4] = {0, 0, 0, 0}; QNode nd; int m = 0;
                     if (t < ndiv) {
@@ -808,7 +842,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                         v = (unsigned long long)m | ((unsigned long long)e << 20);
                     }
                     unsigned long long tot;
-                    const unsigned long long ex = run + block_excl_scan<unsigned long long>(v, &tot, s_scan);
+                    const unsigned long long ex = run + block_excl_scan_n<unsigned long long>(v, &tot, s_scan, NW);
                     run += tot;
                     if (t < ndiv) {
                         const int Pm = (int)(ex & 0xFFFFF), Pe = (int)((ex >> 20) & 0xFFFFF);
@@ -831,11 +865,11 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
                 }
                 // old list minus the erased parents, in old order, after the new blocks
                 int kept_run = 0;
-                for (int i0 = 0; i0 < prev2; i0 += 256) {
+                for (int i0 = 0; i0 < prev2; i0 += NT) {
                     const int i = i0 + tid;
                     const int keep = (i < prev2 && !erased[i]) ? 1 : 0;
                     unsigned long long tot;
-                    const int pos = (int)block_excl_scan<unsigned long long>((unsigned long long)keep, &tot, s_scan);
+                    const int pos = (int)block_excl_scan_n<unsigned long long>((unsigned long long)keep, &tot, s_scan, NW);
                     if (keep) nxt[T2 + kept_run + pos] = cur[i];
                     kept_run += (int)tot;
                 }
@@ -861,7 +895,7 @@ __global__ void __launch_bounds__(256) k_quadtree(const LevelInfo* __restrict__ 
     // x, which is a function of the key itself; spans that were never physically partitioned are ordered by bucket instead, so the order is
     // recomputed rather than read off the position.  Four lanes share a node (keys k = r, r + 4, ..; four loads in flight per lane) and
     // combine their candidates with the same rule.
-    for (int i0 = 0; i0 < nnodes; i0 += 64) {
+    for (int i0 = 0; i0 < nnodes; i0 += NT >> 2) {
         const int i = i0 + (tid >> 2), r = tid & 3;
         uint32_t best = 0; int bs = -1; unsigned long long bo = ~0ull;
         if (i < nnodes) {

@@ -11,6 +11,12 @@
 #ifndef ORBX_FAST_LIST_BYTES
 #define ORBX_FAST_LIST_BYTES 2048   // k_fast_cells: 1024 list entries (corners of the cell so far + survivors waiting for their score)
 #endif
+#ifndef ORBX_QT_BIG_PIXELS
+#define ORBX_QT_BIG_PIXELS 150000    // levels whose detection area has at least this many pixels get 1024 quadtree threads (tests also build 0)
+#endif
+#ifndef ORBX_QT_WIDE_BATCH
+#define ORBX_QT_WIDE_BATCH 32        // batches of up to this many images run the quadtree of their large levels on 1024 threads
+#endif
 #ifndef ORBX_PRESORT_MAX
 #define ORBX_PRESORT_MAX 5      // deepest quadtree level resolved by the up-front counting sort (tests also build 0 and 2)
 #endif
@@ -154,6 +160,7 @@ int configure(orbx_extractor* h, int W, int H, int B) {
             L.presort_depth = 0;
             while (L.presort_depth < ORBX_PRESORT_MAX && L.nini * (1 << (2 * (L.presort_depth + 1))) <= 1024) L.presort_depth++;
             nb_cap = std::max(nb_cap, L.nini * (1 << (2 * L.presort_depth)));
+            L.qt_threads = (long long)L.bw * L.bh >= ORBX_QT_BIG_PIXELS ? kQuadtreeThreads : 256;
             node_cap = std::max(node_cap, L.kp_cap + 8);
             if (l > 0) {
                 L.xtab_off = (int)h->xtab.size(); resize_axis(h->lv[l - 1].w, L.w, true, h->xtab);
@@ -299,15 +306,20 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
     stage_begin(h, ST_QUADTREE, h->s0);
     {
         dim3 grid(B, nl, 1);
-        // nodes 2x24 B + child counts 16 B + expand lists 2x8 B + flags 1 B per node; bucket offsets + 4 per-wave cursors per bucket
+        // nodes 2x24 B + child counts 16 B + expand lists 2x8 B + flags 1 B per node; bucket offsets + 32 B of per-wave cursors per bucket
         const int lut_x = (int)align_up((size_t)h->lv[0].bw + 1, 8), lut_y = (int)align_up((size_t)h->lv[0].bh + 1, 8);   // level 0 is the largest
-        const size_t smem = (size_t)h->node_cap * 81 + (size_t)(5 * h->nb_cap + 2) * 4 + 2 * (size_t)(lut_x + lut_y) + 64;
+        // small batches: the large levels run on 1024 threads (half the latency of one tree); large batches: four waves per tree, more trees per CU
+        int qt_block = 256;
+        if (B <= ORBX_QT_WIDE_BATCH) for (int l = 0; l < nl; l++) qt_block = std::max(qt_block, h->lv[l].qt_threads);
+        const int wide = qt_block > 256, counter_bytes = wide ? 32 : 16;
+        const size_t smem = (size_t)h->node_cap * 81 + (size_t)(h->nb_cap + 2) * 4 + (size_t)counter_bytes * h->nb_cap + 2 * (size_t)(lut_x + lut_y) + 64;
+        const dim3 blkq(qt_block, 1, 1);
         if (smem + 2048 > rt::lds_limit(h->device))
             return fail(ORBX_E_CAPACITY, "nfeatures %d at %dx%d needs %zu bytes of LDS per quadtree workgroup, the device allows %zu", h->nfeatures, h->W, h->H, smem + 2048, rt::lds_limit(h->device));
-        ORBX_LAUNCH(k_quadtree, grid, blk1, smem, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
+        ORBX_LAUNCH(k_quadtree, grid, blkq, smem, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
                     (const int*)h->d_cell_count.p, (const uint32_t*)h->d_slots.p, h->cand_stride, h->d_candA.p, h->d_candB.p, h->cand_stride,
                     h->d_lvl_keys.p, h->kp_total_cap, h->d_lvl_count.p, nl, h->node_cap, h->nb_cap, lut_x, lut_y, h->d_status.p,
-                    h->serial ? (long long*)h->d_qtprof.p : (long long*)nullptr);
+                    h->serial ? (long long*)h->d_qtprof.p : (long long*)nullptr, wide, counter_bytes);
     }
     stage_end(h, ST_QUADTREE, h->s0);
     stage_begin(h, ST_LAYOUT, h->s0);

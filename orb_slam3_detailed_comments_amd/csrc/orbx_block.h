@@ -69,4 +69,19 @@ __device__ __forceinline__ T block_excl_scan(T v, T* total, T* scratch) {
     return base + inc - v;
 }
 
+// The same over the first nw waves of a workgroup whose other waves have exited.
+template <typename T>
+__device__ __forceinline__ T block_excl_scan_n(T v, T* total, T* scratch, int nw) {
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    const T inc = wave_incl_scan(v);
+    if (lane == 63) scratch[wave] = inc;
+    __syncthreads();
+    T base = 0, tot = 0;
+    for (int w = 0; w < nw; w++) { const T s = scratch[w]; if (w < wave) base += s; tot += s; }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
 }  // namespace orbx

@@ -26,11 +26,13 @@ constexpr int kResizeRows = 8;         // output rows per k_resize tile (256 col
 constexpr int kBlurRows = 16;          // output rows per k_blur thread (a block covers 256 columns x 4 * kBlurRows rows)
 __global__ void k_blur(const LevelInfo* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,
                        uint8_t* __restrict__ blur, size_t pyr_stride, BlurTaps taps, BlurTiles tiles);
+constexpr int kQuadtreeThreads = 1024; // workgroup size of k_quadtree; a level uses its first LevelInfo::qt_threads threads
 __global__ void k_quadtree(const LevelInfo* __restrict__ lv, const CellInfo* __restrict__ cells, int ncells,
                            const int* __restrict__ cell_count, const uint32_t* __restrict__ slots, size_t slots_stride,
                            uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
                            uint32_t* __restrict__ lvl_keys, int kp_total_cap, int* __restrict__ lvl_count,
-                           int nlevels, int node_cap, int nb_cap, int lut_x, int lut_y, int* __restrict__ status, long long* __restrict__ qt_prof);
+                           int nlevels, int node_cap, int nb_cap, int lut_x, int lut_y, int* __restrict__ status, long long* __restrict__ qt_prof,
+                           int wide, int counter_bytes);
 __global__ void k_layout(const LevelInfo* __restrict__ lv, int nlevels, const uint32_t* __restrict__ lvl_keys,
                          int kp_total_cap, const int* __restrict__ lvl_count, int lap0, int lap1,
                          int* __restrict__ final_idx, int* __restrict__ n_out, int* __restrict__ mono_out);

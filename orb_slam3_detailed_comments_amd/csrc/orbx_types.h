@@ -33,6 +33,7 @@ struct LevelInfo {
     float hX;                // root width = bw/nini (:722)
     int xtab_off, ytab_off;  // offsets into the resize coefficient tables (levels >= 1)
     int presort_depth;       // quadtree: keys are counting-sorted by (root, first presort_depth child digits) up front
+    int qt_threads;          // quadtree: threads of the workgroup that work on this level (256, or 1024 for the large levels)
 };
 
 struct CellInfo {

@@ -16,13 +16,17 @@ ROOT = ol.ROOT
 CSRC = os.path.join(ROOT, "orb_slam3_detailed_comments_amd", "csrc")
 
 
-@pytest.mark.parametrize("presort_max,bigspan,wave_sort_range", [(1, 80, 16), (0, 1024, 100000)])
-def test_quadtree_path_mix(tmp_path, presort_max, bigspan, wave_sort_range):
+@pytest.mark.parametrize("presort_max,bigspan,wave_sort_range,big_pixels,u16_max", [(1, 80, 16, 0, 65535), (0, 1024, 100000, 150000, 0), (5, 1024, 40, 0, 0)])
+def test_quadtree_path_mix(tmp_path, presort_max, bigspan, wave_sort_range, big_pixels, u16_max):
+    # big_pixels: levels with at least this many pixels run the quadtree with 1024 threads (0 = every level);
+    # the second build also never widens (every level on 256 threads, as large batches run); u16_max: levels with more keys
+    # count their buckets in 32-bit counters and fewer segments (0 = every level);
+    # the second build also never widens (every level on 256 threads, as large batches run)
     # wave_sort_range: ranges of the final rounds' std::sort model above this length are partitioned by a wave (16 = every range,
     # 100000 = none: the one-thread loop)
     so = str(tmp_path / "liborbx_emu_variant.so")
     srcs = [os.path.join(CSRC, f) for f in ("k_image.hip", "k_fast.hip", "k_quadtree.hip", "k_describe.hip", "k_match.hip", "k_search.hip", "k_vocab.hip", "k_input.hip", "orbx_api.cpp", "orbm_search.cpp", "orbv_api.cpp")]
-    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-DORBX_EMU", "-DORBX_PRESORT_MAX=%d" % presort_max, "-DORBX_BIGSPAN=%d" % bigspan, "-DORBX_WAVE_SORT_RANGE=%d" % wave_sort_range,
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-DORBX_EMU", "-DORBX_PRESORT_MAX=%d" % presort_max, "-DORBX_BIGSPAN=%d" % bigspan, "-DORBX_WAVE_SORT_RANGE=%d" % wave_sort_range, "-DORBX_QT_BIG_PIXELS=%d" % big_pixels, "-DORBX_PRESORT_U16_MAX=%d" % u16_max, "-DORBX_QT_WIDE_BATCH=%d" % (0 if big_pixels == 150000 else 32),
                     "-I" + os.path.join(ROOT, "tests", "emu"), "-I" + CSRC, "-fPIC", "-shared", "-w", "-x", "c++"] + srcs + ["-o", so, "-lpthread"], check=True)
     lib = _lib.OrbxLib(so)
     for name, factory, nf, lap in SMALL_CASES + FULL_CASES[:1] + FULL_CASES[4:5]:
