@@ -48,37 +48,54 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
-// grid (B), 256 threads.
+// grid (B), 256 threads.  The level-ordered keypoint slots of an image (level l owns [kp_off, kp_off + kp_cap), the first lvl_count of them
+// are in use) are walked in slot order = output order of the reference: a thread takes kLayoutPer consecutive slots, so that one workgroup
+// scan per 256 * kLayoutPer slots (one in all for the usual feature counts) places every keypoint, with all key loads in flight at once.
+constexpr int kLayoutPer = 8;
 __global__ void __launch_bounds__(256) k_layout(const LevelInfo* __restrict__ lv, int nlevels,
                                                 const uint32_t* __restrict__ lvl_keys, int kp_total_cap,
                                                 const int* __restrict__ lvl_count, int lap0, int lap1,
                                                 int* __restrict__ final_idx, int* __restrict__ n_out, int* __restrict__ mono_out) {
     __shared__ unsigned long long s_scan[20];
+    __shared__ int s_cnt[kMaxLevels], s_off[kMaxLevels + 1];
+    __shared__ float s_scale[kMaxLevels];
     const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
+    if (tid < nlevels) { s_cnt[tid] = lvl_count[(size_t)b * nlevels + tid]; s_off[tid] = lv[tid].kp_off; s_scale[tid] = lv[tid].scale; }
+    if (tid == 0) s_off[nlevels] = kp_total_cap;
+    __syncthreads();
     int total = 0;
-    for (int l = 0; l < nlevels; l++) total += lvl_count[(size_t)b * nlevels + l];
+    for (int l = 0; l < nlevels; l++) total += s_cnt[l];
     int mono_run = 0, lap_run = 0;
-    for (int l = 0; l < nlevels; l++) {
-        const LevelInfo L = lv[l];
-        const int cnt = lvl_count[(size_t)b * nlevels + l];
-        for (int i0 = 0; i0 < cnt; i0 += 256) {
-            const int i = i0 + tid;
-            int lap = 0, valid = 0;
-            if (i < cnt) {
-                valid = 1;
-                float xf = (float)(key_x(lvl_keys[(size_t)b * kp_total_cap + L.kp_off + i]) + kBorder);
-                if (l != 0) xf = __fmul_rn(xf, L.scale);
-                lap = (xf >= (float)lap0 && xf <= (float)lap1) ? 1 : 0;
-            }
-            const unsigned long long v = (unsigned long long)(valid && !lap) | ((unsigned long long)lap << 32);
-            unsigned long long tot;
-            const unsigned long long ex = block_excl_scan<unsigned long long>(v, &tot, s_scan);
-            if (valid) {
-                const int idx = lap ? (total - 1 - (lap_run + (int)(ex >> 32))) : (mono_run + (int)(ex & 0xFFFFFFFFu));
-                final_idx[(size_t)b * kp_total_cap + L.kp_off + i] = idx;
-            }
-            mono_run += (int)(tot & 0xFFFFFFFFu); lap_run += (int)(tot >> 32);
+    for (int base = 0; base < kp_total_cap; base += 256 * kLayoutPer) {
+        const int s0 = base + tid * kLayoutPer;
+        int valid[kLayoutPer], lvl[kLayoutPer];
+        uint32_t key[kLayoutPer];
+        int l = 0;
+        while (l + 1 < nlevels && s_off[l + 1] <= s0) l++;
+#pragma unroll
+        for (int k = 0; k < kLayoutPer; k++) {
+            const int s = s0 + k;
+            while (l + 1 < nlevels && s_off[l + 1] <= s) l++;
+            lvl[k] = l;
+            valid[k] = s < kp_total_cap && s - s_off[l] < s_cnt[l];
+            key[k] = valid[k] ? lvl_keys[(size_t)b * kp_total_cap + s] : 0u;
         }
+        int lapf[kLayoutPer], nm = 0, nl = 0;
+#pragma unroll
+        for (int k = 0; k < kLayoutPer; k++) {
+            float xf = (float)(key_x(key[k]) + kBorder);
+            if (lvl[k] != 0) xf = __fmul_rn(xf, s_scale[lvl[k]]);
+            lapf[k] = valid[k] && xf >= (float)lap0 && xf <= (float)lap1;
+            nm += valid[k] && !lapf[k]; nl += lapf[k];
+        }
+        unsigned long long tot;
+        const unsigned long long ex = block_excl_scan<unsigned long long>((unsigned long long)nm | ((unsigned long long)nl << 32), &tot, s_scan);
+        int pm = mono_run + (int)(ex & 0xFFFFFFFFu), pl = lap_run + (int)(ex >> 32);
+#pragma unroll
+        for (int k = 0; k < kLayoutPer; k++) {
+            if (valid[k]) final_idx[(size_t)b * kp_total_cap + s0 + k] = lapf[k] ? total - 1 - pl++ : pm++;
+        }
+        mono_run += (int)(tot & 0xFFFFFFFFu); lap_run += (int)(tot >> 32);
     }
     if (tid == 0) { n_out[b] = total; mono_out[b] = mono_run; }
 }
