@@ -21,6 +21,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <set>
 #include <stdexcept>
@@ -47,6 +48,38 @@ class ORBmatcher : public ORBmatcherConstants<void>
 
 public:
     ORBmatcher(float nnratio=0.6, bool checkOri=true): mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+    // Device-resident key frames (orbm_keyframe, include/orbx.h): what the vocabulary-bucket searches read of a key frame - mvKeysUn,
+    // mDescriptors, mvuRight, mFeatVec - is fixed once ComputeBoW has run, so it is uploaded on first use and kept until Erase (call it where
+    // the map erases the key frame, src/Map.cc:106-124) or the end of the cache.  One cache per thread that owns key frames' searches
+    // (LocalMapping, LoopClosing); the device objects can be used from any thread's handle.
+    template <class KeyFrameT>
+    class ResidentKeyFrames
+    {
+    public:
+        ResidentKeyFrames() {}
+        ~ResidentKeyFrames() { Clear(); }
+        orbm_keyframe* Get(KeyFrameT* pKF)
+        {
+            auto it = m.find(pKF);
+            if (it != m.end()) return it->second;
+            BowStore k; FillBow(*pKF, pKF->N, k);
+            orbm_keyframe* r = nullptr;
+            {
+                std::lock_guard<std::mutex> lock(Mutex());
+                Check(orbm_keyframe_create(SharedHandle(), &k.v, &r));
+            }
+            m[pKF] = r;
+            return r;
+        }
+        void Erase(KeyFrameT* pKF) { auto it = m.find(pKF); if (it != m.end()) { orbm_keyframe_destroy(it->second); m.erase(it); } }
+        void Clear() { for (auto& e : m) orbm_keyframe_destroy(e.second); m.clear(); }
+        size_t size() const { return m.size(); }
+    private:
+        ResidentKeyFrames(const ResidentKeyFrames&);
+        ResidentKeyFrames& operator=(const ResidentKeyFrames&);
+        std::map<KeyFrameT*, orbm_keyframe*> m;
+    };
 
     // Computes the Hamming distance between two ORB descriptors (src/ORBmatcher.cc:2383).
     static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b)
@@ -305,33 +338,48 @@ public:
         return nmatches;
     }
 
-    // Matching to triangulate new MapPoints. Check Epipolar Constraint.   — src/ORBmatcher.cc:1045-1323 (pinhole, one camera)
+    // epipole of pKF1's centre in pKF2 (src/ORBmatcher.cc:1056-1063)
     template <class KeyFrameT>
-    int SearchForTriangulation(KeyFrameT *pKF1, KeyFrameT* pKF2, std::vector<std::pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo, const bool bCoarse = false)
+    static void Epipole(KeyFrameT* pKF1, KeyFrameT* pKF2, float epf[2])
     {
-        auto T1w = pKF1->GetPose();
         auto T2w = pKF2->GetPose();
+        typedef Decay<decltype(T2w.translation())> Vec3;
+        Vec3 Cw = pKF1->GetCameraCenter();
+        Vec3 C2 = T2w * Cw;
+        auto ep = pKF2->mpCamera->project(C2);
+        epf[0] = ep(0); epf[1] = ep(1);
+    }
+    // ... and the fundamental matrix of Pinhole::epipolarConstrain (src/CameraModels/Pinhole.cpp:191-194), evaluated once instead of per pair
+    template <class KeyFrameT>
+    static void FundamentalAndEpipole(KeyFrameT* pKF1, KeyFrameT* pKF2, float f12[9], float epf[2])
+    {
+        Epipole(pKF1, pKF2, epf);
+        auto T1w = pKF1->GetPose();
         auto Tw2 = pKF2->GetPoseInverse();
         typedef Decay<decltype(T1w.translation())> Vec3;
         typedef Decay<decltype(T1w.rotationMatrix())> Mat3;
-        typedef Decay<decltype(pKF2->mpCamera->project(std::declval<Vec3>()))> Vec2;
-        Vec3 Cw = pKF1->GetCameraCenter();
-        Vec3 C2 = T2w * Cw;
-        Vec2 ep = pKF2->mpCamera->project(C2);
-        if (pKF1->mpCamera->GetType() == 1 /* GeometricCamera::CAM_FISHEYE */)
-            return SearchForTriangulationFisheye(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse, ep(0), ep(1));
-        if (pKF1->mpCamera2 || pKF2->mpCamera2) throw std::runtime_error("ORBmatcher (HIP): SearchForTriangulation on a rig of pinhole cameras is not supported (the reference only builds rigs of Kannala-Brandt cameras)");
         auto T12 = T1w * Tw2;
         Mat3 R12 = T12.rotationMatrix();
         Vec3 t12 = T12.translation();
-        // the fundamental matrix of Pinhole::epipolarConstrain (src/CameraModels/Pinhole.cpp:191-194), evaluated once instead of per pair
         Mat3 t12x = R12;
         t12x(0,0) = 0; t12x(0,1) = -t12(2); t12x(0,2) = t12(1); t12x(1,0) = t12(2); t12x(1,1) = 0; t12x(1,2) = -t12(0); t12x(2,0) = -t12(1); t12x(2,1) = t12(0); t12x(2,2) = 0;
         Mat3 K1 = pKF1->mpCamera->toK_();
         Mat3 K2 = pKF2->mpCamera->toK_();
         Mat3 F12 = K1.transpose().inverse() * t12x * R12 * K2.inverse();
-        float f12[9], epf[2] = {ep(0), ep(1)};
         for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) f12[r * 3 + c] = F12(r, c);
+    }
+
+    // Matching to triangulate new MapPoints. Check Epipolar Constraint.   — src/ORBmatcher.cc:1045-1323 (pinhole, one camera)
+    template <class KeyFrameT>
+    int SearchForTriangulation(KeyFrameT *pKF1, KeyFrameT* pKF2, std::vector<std::pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo, const bool bCoarse = false)
+    {
+        float f12[9], epf[2];
+        if (pKF1->mpCamera->GetType() == 1 /* GeometricCamera::CAM_FISHEYE */) {
+            Epipole(pKF1, pKF2, epf);
+            return SearchForTriangulationFisheye(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse, epf[0], epf[1]);
+        }
+        if (pKF1->mpCamera2 || pKF2->mpCamera2) throw std::runtime_error("ORBmatcher (HIP): SearchForTriangulation on a rig of pinhole cameras is not supported (the reference only builds rigs of Kannala-Brandt cameras)");
+        FundamentalAndEpipole(pKF1, pKF2, f12, epf);
 
         BowStore k1, k2;
         FillBow(*pKF1, pKF1->N, k1); FillBow(*pKF2, pKF2->N, k2);
@@ -349,6 +397,47 @@ public:
         vMatchedPairs.reserve(nmatches);
         for (int i = 0; i < pKF1->N; i++) if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m12[i]));
         return nmatches;
+    }
+
+    // The same for every neighbour of pKF1 in one call over device-resident key frames (LocalMapping::CreateNewMapPoints runs
+    // SearchForTriangulation against 10-30 neighbours in a row, src/LocalMapping.cc:510-540; what a neighbour contributes - keys, descriptors,
+    // mvuRight, mFeatVec - does not change while it lives and is uploaded once, into `cache`).  vvMatchedPairs[j] / the returned counts [j] are
+    // what SearchForTriangulation(pKF1, vpNeighKFs[j], ...) gives.  Pinhole key frames with one camera.
+    template <class KeyFrameT>
+    std::vector<int> SearchForTriangulation(KeyFrameT* pKF1, const std::vector<KeyFrameT*>& vpNeighKFs, ResidentKeyFrames<KeyFrameT>& cache,
+                                            std::vector<std::vector<std::pair<size_t, size_t> > >& vvMatchedPairs, const bool bOnlyStereo, const bool bCoarse = false)
+    {
+        const int n2 = (int)vpNeighKFs.size(), N1 = pKF1->N;
+        vvMatchedPairs.assign(n2, std::vector<std::pair<size_t, size_t> >());
+        std::vector<int> counts(n2, 0);
+        if (n2 == 0 || N1 == 0) return counts;
+        std::vector<float> f12s((size_t)n2 * 9), eps((size_t)n2 * 2);
+        std::vector<orbm_keyframe*> k2(n2);
+        std::vector<std::vector<uint8_t> > mp2(n2);
+        std::vector<const uint8_t*> mp2p(n2);
+        std::vector<uint8_t> mp1(N1);
+        for (int i = 0; i < N1; i++) mp1[i] = pKF1->GetMapPoint(i) != nullptr;
+        for (int j = 0; j < n2; j++) {
+            KeyFrameT* pKF2 = vpNeighKFs[j];
+            if (pKF1->mpCamera->GetType() == 1 || pKF1->mpCamera2 || pKF2->mpCamera2) throw std::runtime_error("ORBmatcher (HIP): the resident SearchForTriangulation covers pinhole key frames with one camera");
+            FundamentalAndEpipole(pKF1, pKF2, &f12s[(size_t)j * 9], &eps[(size_t)j * 2]);
+            k2[j] = cache.Get(pKF2);
+            mp2[j].resize(pKF2->N > 0 ? pKF2->N : 1);
+            for (int i = 0; i < pKF2->N; i++) mp2[j][i] = pKF2->GetMapPoint(i) != nullptr;
+            mp2p[j] = mp2[j].data();
+        }
+        orbm_keyframe* k1 = cache.Get(pKF1);
+        std::vector<int> m12((size_t)n2 * N1, -1);
+        {
+            std::lock_guard<std::mutex> lock(Mutex());
+            Check(orbm_search_for_triangulation_resident(SharedHandle(), k1, mp1.data(), n2, k2.data(), mp2p.data(), f12s.data(), eps.data(), bOnlyStereo, bCoarse,
+                                                         mbCheckOrientation, m12.data(), counts.data()));
+        }
+        for (int j = 0; j < n2; j++) {
+            vvMatchedPairs[j].reserve(counts[j]);
+            for (int i = 0; i < N1; i++) if (m12[(size_t)j * N1 + i] >= 0) vvMatchedPairs[j].push_back(std::make_pair((size_t)i, (size_t)m12[(size_t)j * N1 + i]));
+        }
+        return counts;
     }
 
     // Kannala-Brandt cameras (one fisheye camera, or the two-camera rig): the epipolar test is KannalaBrandt8::epipolarConstrain =

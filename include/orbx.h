@@ -406,6 +406,26 @@ int orbm_search_by_bow(orbx_extractor* h, const OrbmKeyFrameView* K1, const Orbm
 int orbm_search_by_bow_batch(orbx_extractor* h, int n, const OrbmKeyFrameView* const* K1s, const OrbmKeyFrameView* const* K2s, float nnratio,
                              int th_inclusive, int check_orientation, int* const* matches12, int* nmatches);
 
+/* Device-resident key frames.  What the vocabulary-bucket searches read of a key frame or frame - mvKeysUn, mDescriptors, mvuRight, mFeatVec
+ * (include/KeyFrame.h:  the fields of OrbmKeyFrameView) - is uploaded once by orbm_keyframe_create (has_map_point of the view is ignored:
+ * map points change while a key frame lives, the searches take the flags per call).  The resident searches give the same results as
+ * orbm_search_for_triangulation_batch / orbm_search_by_bow_batch and move only flags, poses and results across the bus; the accept loop of
+ * SearchByBoW runs on the device (one wave per vocabulary node).  Pinhole / single-camera key frames.  A key frame may be used with any
+ * extractor handle of the device it was created on.  Limit: at most 2048 features of one key frame per vocabulary node (ORBX_E_CAPACITY). */
+typedef struct orbm_keyframe orbm_keyframe;
+int orbm_keyframe_create(orbx_extractor* h, const OrbmKeyFrameView* K, orbm_keyframe** out);
+void orbm_keyframe_destroy(orbm_keyframe* kf);
+/* SearchForTriangulation of K1 against n2 neighbours (src/ORBmatcher.cc:1045-1323).  has_map_point1 [K1 N] / has_map_point2[j] [K2s[j] N]:
+ * GetMapPoint(i) != NULL at call time (NULL = none).  Other arguments and results as orbm_search_for_triangulation_batch. */
+int orbm_search_for_triangulation_resident(orbx_extractor* h, orbm_keyframe* K1, const uint8_t* has_map_point1, int n2, orbm_keyframe* const* K2s,
+                                           const uint8_t* const* has_map_point2, const float* F12s, const float* eps, int only_stereo, int coarse,
+                                           int check_orientation, int* matches12, int* nmatches);
+/* SearchByBoW for n pairs (src/ORBmatcher.cc:259-493, :892-1043).  has_map_point1[p]: K1s[p] features with a good map point (NULL = none, no
+ * matches); eligible2[p]: K2s[p] features that may be matched (NULL = all: the Frame overload).  Results as orbm_search_by_bow_batch. */
+int orbm_search_by_bow_resident(orbx_extractor* h, int n, orbm_keyframe* const* K1s, const uint8_t* const* has_map_point1, orbm_keyframe* const* K2s,
+                                const uint8_t* const* eligible2, float nnratio, int th_inclusive, int check_orientation, int* const* matches12,
+                                int* nmatches);
+
 /* SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) for a fisheye-rig frame (F.Nleft != -1; src/ORBmatcher.cc:259-493 incl. :343-372, :414-446).
  * K1 / K2 list ALL features by index (camera 1 first: keys = mvKeys followed by mvKeysRight, descriptor rows as stored); nleft2 = F.Nleft.
  * assigned2[j] = feature of K1 whose map point is written to vpMapPointMatches[j], -1 = NULL (after the rotation-consistency pruning). */

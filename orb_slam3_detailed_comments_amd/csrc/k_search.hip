@@ -238,22 +238,15 @@ __global__ void __launch_bounds__(256) k_frustum(FrustumParams F, int M, const f
 
 // One wave per work item (an unmatched feature idx1 of KF1 and the feature list of a neighbour KF2 in the same node; the arrays of
 // all neighbours of a batch are concatenated, item.out_off = neighbour).  best2[item] = chosen (global) idx2 or -1.   src/ORBmatcher.cc:1117-1254
+// The best candidate for feature idx1 of KF1 (record k1, descriptor a0..a3) among cnt2 features of KF2 listed in feat2 (one vocabulary
+// node): src/ORBmatcher.cc:1117-1254.  Returns the chosen entry of feat2 or -1.  One wave; every lane gets the result.
 template <bool KB8>
-__device__ __forceinline__ void bow_search_body(const BowItem* __restrict__ items, int nitems,
-                                                    const KeyPointRec* __restrict__ kps1, const unsigned long long* __restrict__ desc1,
-                                                    const float* __restrict__ ur1,
-                                                    const KeyPointRec* __restrict__ kps2, const unsigned long long* __restrict__ desc2,
-                                                    const float* __restrict__ ur2, const uint8_t* __restrict__ has_mp2,
-                                                    const int* __restrict__ feat2, const BowParams* __restrict__ Ps, int* __restrict__ best2) {
+__device__ __forceinline__ int bow_search_core(int idx1, const KeyPointRec k1, bool stereo1, unsigned long long a0, unsigned long long a1,
+                                               unsigned long long a2, unsigned long long a3, const BowParams& P,
+                                               const KeyPointRec* __restrict__ kps2, const unsigned long long* __restrict__ desc2,
+                                               const float* __restrict__ ur2, const uint8_t* __restrict__ has_mp2,
+                                               const int* __restrict__ feat2, int cnt2) {
     const int lane = lane_id();
-    const int it = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-    if (it >= nitems) return;
-    const BowItem I = items[it];
-    const BowParams& P = Ps[I.out_off];            // the neighbour key frame this item belongs to (wave-uniform)
-    const KeyPointRec k1 = kps1[I.idx1];
-    const bool stereo1 = ur1[I.idx1] >= 0;
-    const unsigned long long* da = desc1 + 4 * (size_t)I.idx1;
-    const unsigned long long a0 = da[0], a1 = da[1], a2 = da[2], a3 = da[3];
     // epipolar line of kp1 in image 2 (Pinhole::epipolarConstrain, src/CameraModels/Pinhole.cpp:186-217)
     const float la = __fadd_rn(__fadd_rn(__fmul_rn(k1.x, P.F12[0]), __fmul_rn(k1.y, P.F12[3])), P.F12[6]);
     const float lb = __fadd_rn(__fadd_rn(__fmul_rn(k1.x, P.F12[1]), __fmul_rn(k1.y, P.F12[4])), P.F12[7]);
@@ -261,7 +254,7 @@ __device__ __forceinline__ void bow_search_body(const BowItem* __restrict__ item
     const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
     // Kannala-Brandt cameras: which camera of a rig the feature belongs to (:1136-1141), its ray (unprojected once per feature)
     const bool rig = KB8 && P.nleft1 >= 0 && P.nleft2 >= 0;                          // pKF1->mpCamera2 && pKF2->mpCamera2 (:1203)
-    const int right1 = (KB8 && P.nleft1 >= 0 && I.idx1 >= P.nleft1) ? 1 : 0;
+    const int right1 = (KB8 && P.nleft1 >= 0 && idx1 >= P.nleft1) ? 1 : 0;
     KB8Cam c1; float ray1[3] = {0.f, 0.f, 1.f};
     if (KB8) {
 #pragma unroll
@@ -269,8 +262,8 @@ __device__ __forceinline__ void bow_search_body(const BowItem* __restrict__ item
         kb8_unproject(c1, k1.x, k1.y, ray1);
     }
     unsigned best = 0xFFFFFFFFu;   // dist << 16 | (0xFFFF - position): the LAST candidate with the smallest distance wins (:1178 '>' test)
-    for (int j = lane; j < I.cnt2; j += 64) {
-        const int idx2 = feat2[I.start2 + j];
+    for (int j = lane; j < cnt2; j += 64) {
+        const int idx2 = feat2[j];
         if (has_mp2[idx2]) continue;
         const bool stereo2 = ur2[idx2] >= 0;
         if (P.only_stereo && !stereo2) continue;
@@ -303,7 +296,115 @@ __device__ __forceinline__ void bow_search_body(const BowItem* __restrict__ item
         best = key < best ? key : best;
     }
     best = wave_min_u32(best);
-    if (lane == 0) best2[it] = best == 0xFFFFFFFFu ? -1 : feat2[I.start2 + (0xFFFF - (int)(best & 0xFFFF))];
+    return best == 0xFFFFFFFFu ? -1 : feat2[0xFFFF - (int)(best & 0xFFFF)];
+}
+
+// One wave per work item (an unmatched feature idx1 of KF1 and the feature list of a neighbour KF2 in the same node; the arrays of
+// all neighbours of a batch are concatenated, item.out_off = neighbour).  best2[item] = chosen (global) idx2 or -1.
+template <bool KB8>
+__device__ __forceinline__ void bow_search_body(const BowItem* __restrict__ items, int nitems,
+                                                    const KeyPointRec* __restrict__ kps1, const unsigned long long* __restrict__ desc1,
+                                                    const float* __restrict__ ur1,
+                                                    const KeyPointRec* __restrict__ kps2, const unsigned long long* __restrict__ desc2,
+                                                    const float* __restrict__ ur2, const uint8_t* __restrict__ has_mp2,
+                                                    const int* __restrict__ feat2, const BowParams* __restrict__ Ps, int* __restrict__ best2) {
+    const int lane = lane_id();
+    const int it = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (it >= nitems) return;
+    const BowItem I = items[it];
+    const BowParams& P = Ps[I.out_off];            // the neighbour key frame this item belongs to (wave-uniform)
+    const unsigned long long* da = desc1 + 4 * (size_t)I.idx1;
+    const int r = bow_search_core<KB8>(I.idx1, kps1[I.idx1], ur1[I.idx1] >= 0, da[0], da[1], da[2], da[3], P, kps2, desc2, ur2, has_mp2, feat2 + I.start2, I.cnt2);
+    if (lane == 0) best2[it] = r;
+}
+
+// Position of `id` in the ascending list ids[0, n), or -1: two 64-way probes by the whole wave instead of a dependent binary search.
+__device__ __forceinline__ int wave_find_node(const uint32_t* __restrict__ ids, int n, uint32_t id) {
+    const int lane = lane_id();
+    int lo = 0, len = n;
+    while (len > 64) {
+        const int stride = (len + 63) >> 6;
+        const int pos = lo + lane * stride;
+        const unsigned long long le = __ballot(pos < lo + len && ids[pos] <= id);
+        if (le == 0ull) return -1;
+        const int seg = 63 - __clzll((long long)le);          // last probe <= id
+        const int nlo = lo + seg * stride;
+        len = imin(stride, lo + len - nlo); lo = nlo;
+    }
+    const unsigned long long eq = __ballot(lane < len && ids[lo + lane] == id);
+    return eq ? lo + (__ffsll((long long)eq) - 1) : -1;
+}
+
+// ORBmatcher::SearchForTriangulation over device-resident key frames: one wave per (feature idx1 of KF1, neighbour j), no work list - the
+// wave finds the neighbour's feature list of idx1's vocabulary node itself.  best[j * N1 + idx1] = index in neighbour j or -1.
+// grid (ceil(N1 / 4), n2).  flags: call-time map point flags, KF1's at offset 0, neighbour j's at nb[j].mp2_off.
+__global__ void __launch_bounds__(256) k_sft_resident(ResidentKF k1, const uint8_t* __restrict__ flags, const SftNeighbour* __restrict__ nb,
+                                                      int* __restrict__ best) {
+    const int lane = lane_id();
+    const int idx1 = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), j = (int)blockIdx.y;
+    if (idx1 >= k1.N) return;
+    int r = -1;
+    const SftNeighbour& S = nb[j];
+    const int a = k1.node_of_feat[idx1];
+    const bool stereo1 = k1.ur[idx1] >= 0;
+    if (a >= 0 && !flags[idx1] && !(S.P.only_stereo && !stereo1)) {
+        const int b = wave_find_node(S.k2.node_id, S.k2.fv_nodes, k1.node_id[a]);
+        if (b >= 0) {
+            const int s2 = S.k2.fv_start[b], c2 = S.k2.fv_start[b + 1] - s2;
+            const unsigned long long* da = k1.desc + 4 * (size_t)idx1;
+            r = bow_search_core<false>(idx1, k1.kps[idx1], stereo1, da[0], da[1], da[2], da[3], S.P, S.k2.kps, S.k2.desc, S.k2.ur, flags + S.mp2_off,
+                                       S.k2.fv_feat + s2, c2);
+        }
+    }
+    if (lane == 0) best[(size_t)j * k1.N + idx1] = r;
+}
+
+// ORBmatcher::SearchByBoW (src/ORBmatcher.cc:259-493 and :892-1043, non-fisheye) over device-resident key frames, the sequential accept
+// loop included: a target taken by an earlier feature is skipped (:331, :948), and since a feature of K2 belongs to exactly one vocabulary
+// node, that dependence never leaves a node - one wave per (node of K1, pair) walks the node's K1 features in order.
+// A lane owns the candidates (positions in K2's list of the node) lane, lane + 64, ..; bit r of `taken` = position lane + 64 r is taken.
+// m12[p * N1cap + idx1] = matched index in K2 (pre-set to -1).  Nodes with more than 2048 features in K2 set status bit 2.
+// grid (ceil(max fv_nodes / 4), n)
+__global__ void __launch_bounds__(256) k_bow_match_resident(const BowPairResident* __restrict__ pairs, const uint8_t* __restrict__ flags,
+                                                            float nnratio, int th_low, int th_inclusive, int* __restrict__ m12, int N1cap,
+                                                            int* __restrict__ status) {
+    const int lane = lane_id();
+    const int a = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), p = (int)blockIdx.y;
+    const BowPairResident& B = pairs[p];
+    if (a >= B.k1.fv_nodes || B.mp1_off < 0) return;
+    const int b = wave_find_node(B.k2.node_id, B.k2.fv_nodes, B.k1.node_id[a]);
+    if (b < 0) return;
+    const int s2 = B.k2.fv_start[b], c2 = B.k2.fv_start[b + 1] - s2;
+    if (c2 > 2048) { if (lane == 0) atomicOr(status, 4); return; }
+    const uint8_t* mp1 = flags + B.mp1_off;
+    const uint8_t* el2 = B.elig2_off >= 0 ? flags + B.elig2_off : nullptr;
+    // this lane's candidates: index in K2 and eligibility, fetched once
+    unsigned taken = 0;
+    for (int k = B.k1.fv_start[a]; k < B.k1.fv_start[a + 1]; k++) {
+        const int idx1 = B.k1.fv_feat[k];
+        if (!mp1[idx1]) continue;                                                      // !pMP || pMP->isBad()
+        const unsigned long long* da = B.k1.desc + 4 * (size_t)idx1;
+        const unsigned long long a0 = da[0], a1 = da[1], a2 = da[2], a3 = da[3];
+        unsigned k1key = (256u << 16) | 0xFFFFu, k2key = k1key;                        // this lane's two smallest (distance << 16 | position)
+        for (int j = lane, r = 0; j < c2; j += 64, r++) {
+            if ((taken >> r) & 1u) continue;
+            const int idx2 = B.k2.fv_feat[s2 + j];
+            if (el2 && !el2[idx2]) continue;
+            const unsigned long long* db = B.k2.desc + 4 * (size_t)idx2;
+            const unsigned d = (unsigned)(__popcll(a0 ^ db[0]) + __popcll(a1 ^ db[1]) + __popcll(a2 ^ db[2]) + __popcll(a3 ^ db[3]));
+            const unsigned key = (d << 16) | (unsigned)j;
+            if (key < k1key) { k2key = k1key; k1key = key; } else if (key < k2key) k2key = key;
+        }
+        // sequential rule: bestDist1 = smallest distance (first position that attains it), bestDist2 = second smallest of the multiset
+        const unsigned m1 = wave_min_u32(k1key);
+        const unsigned m2 = wave_min_u32(k1key == m1 ? k2key : k1key);
+        const int bestDist1 = (int)(m1 >> 16), bestDist2 = (int)(m2 >> 16);
+        const bool pass = th_inclusive ? bestDist1 <= th_low : bestDist1 < th_low;
+        if (pass && (float)bestDist1 < __fmul_rn(nnratio, (float)bestDist2)) {
+            const int j1 = (int)(m1 & 0xFFFFu);
+            if (lane == (j1 & 63)) { taken |= 1u << (j1 >> 6); m12[(size_t)p * N1cap + idx1] = B.k2.fv_feat[s2 + j1]; }
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) k_bow_search(const BowItem* __restrict__ items, int nitems, const KeyPointRec* __restrict__ kps1,

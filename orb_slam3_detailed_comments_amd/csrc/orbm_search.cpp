@@ -631,6 +631,171 @@ int orbm_search_by_bow_batch(orbx_extractor* h, int n, const OrbmKeyFrameView* c
     return ORBX_OK;
 }
 
+// ---- device-resident key frames ------------------------------------------------------------------------------------------------
+// What the vocabulary-bucket searches read of a key frame (keys, descriptors, mvuRight, mFeatVec) is uploaded once; the searches then move
+// only their call-time state (map point flags, poses) to the device and their result back.  The host keeps the angles for the
+// rotation-consistency histograms and the per-level scales.
+struct orbm_keyframe {
+    int device = 0, N = 0, fv_nodes = 0, nlevels = 0;
+    uint8_t* dmem = nullptr;
+    ResidentKF dev;
+    std::vector<float> angle;
+    float scale[kMaxLevels], sigma2[kMaxLevels];
+};
+
+int orbm_keyframe_create(orbx_extractor* h, const OrbmKeyFrameView* K, orbm_keyframe** out) {
+    if (!h || !K || !out || K->N < 0 || K->fv_nodes < 0 || (K->N > 0 && (!K->keys_un || !K->desc))) return fail(ORBX_E_ARG, "bad key frame view");
+    if (K->N >= 65535 || K->nlevels > kMaxLevels) return fail(ORBX_E_ARG, "key frame too large");
+    if (K->fv_nodes > 0 && (!K->fv_node_id || !K->fv_start || !K->fv_feat)) return fail(ORBX_E_ARG, "bad feature vector");
+    rt::set_device(h->device);
+    const int N = K->N, N1 = std::max(N, 1), nn = K->fv_nodes, nf = nn > 0 ? K->fv_start[nn] : 0;
+    const size_t okp = 0, odesc = okp + al16(sizeof(KeyPointRec) * (size_t)N1), our = odesc + al16(32 * (size_t)N1), onid = our + al16(4 * (size_t)N1),
+                 ost = onid + al16(4 * (size_t)(nn + 1)), oft = ost + al16(4 * (size_t)(nn + 1)), onof = oft + al16(4 * (size_t)(nf + 1)),
+                 total = onof + al16(4 * (size_t)N1);
+    std::vector<uint8_t> stage(total, 0);
+    if (N > 0) { memcpy(&stage[okp], K->keys_un, sizeof(KeyPointRec) * (size_t)N); memcpy(&stage[odesc], K->desc, 32 * (size_t)N); }
+    float* ur = (float*)&stage[our];
+    for (int i = 0; i < N1; i++) ur[i] = (K->u_right && i < N) ? K->u_right[i] : -1.0f;
+    int* nof = (int*)&stage[onof];
+    for (int i = 0; i < N1; i++) nof[i] = -1;
+    if (nn > 0) {
+        memcpy(&stage[onid], K->fv_node_id, 4 * (size_t)nn); memcpy(&stage[ost], K->fv_start, 4 * (size_t)(nn + 1));
+        int* ft = (int*)&stage[oft];
+        for (int a = 0; a < nn; a++) {
+            if (a > 0 && K->fv_node_id[a] <= K->fv_node_id[a - 1]) return fail(ORBX_E_ARG, "feature vector node ids not ascending");
+            for (int k = K->fv_start[a]; k < K->fv_start[a + 1]; k++) {
+                const int f = (int)K->fv_feat[k];
+                if (f < 0 || f >= N) return fail(ORBX_E_ARG, "feature vector entry out of range");
+                ft[k] = f; nof[f] = a;
+            }
+        }
+    }
+    orbm_keyframe* kf = new orbm_keyframe();
+    kf->device = h->device; kf->N = N; kf->fv_nodes = nn; kf->nlevels = K->nlevels;
+    kf->dmem = (uint8_t*)rt::dmalloc(total);
+    if (!kf->dmem || rt::copy_h2d(kf->dmem, stage.data(), total, h->s0) || rt::stream_sync(h->s0)) { rt::dfree(kf->dmem); delete kf; return fail(ORBX_E_DEVICE, "key frame upload failed"); }
+    kf->dev.kps = (const KeyPointRec*)(kf->dmem + okp); kf->dev.desc = (const unsigned long long*)(kf->dmem + odesc); kf->dev.ur = (const float*)(kf->dmem + our);
+    kf->dev.node_id = (const uint32_t*)(kf->dmem + onid); kf->dev.fv_start = (const int*)(kf->dmem + ost); kf->dev.fv_feat = (const int*)(kf->dmem + oft);
+    kf->dev.node_of_feat = (const int*)(kf->dmem + onof); kf->dev.N = N; kf->dev.fv_nodes = nn;
+    kf->angle.resize(N1);
+    for (int i = 0; i < N; i++) kf->angle[i] = K->keys_un[i].angle;
+    for (int l = 0; l < kMaxLevels; l++) { kf->scale[l] = l < K->nlevels && K->scale_factors ? K->scale_factors[l] : 1.0f; kf->sigma2[l] = l < K->nlevels && K->level_sigma2 ? K->level_sigma2[l] : 1.0f; }
+    *out = kf;
+    return ORBX_OK;
+}
+
+void orbm_keyframe_destroy(orbm_keyframe* kf) {
+    if (!kf) return;
+    rt::set_device(kf->device);
+    rt::dfree(kf->dmem);
+    delete kf;
+}
+
+// rotation-consistency pruning shared by the resident searches: m12 entries outside the three strongest bins of the angle-difference
+// histogram are reset (src/ORBmatcher.cc:1270-1286); returns the number of matches left
+static int prune_by_rotation(const orbm_keyframe* K1, const orbm_keyframe* K2, int* m12, bool check_ori) {
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    for (int i = 0; i < K1->N; i++) {
+        if (m12[i] < 0) continue;
+        nmatches++;
+        if (check_ori) rotHist[rot_bin(K1->angle[i], K2->angle[m12[i]])].push_back(i);
+    }
+    if (check_ori) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx1 : rotHist[i]) { m12[idx1] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+int orbm_search_for_triangulation_resident(orbx_extractor* h, orbm_keyframe* K1, const uint8_t* has_mp1, int n2, orbm_keyframe* const* K2s,
+                                           const uint8_t* const* has_mp2, const float* F12s, const float* eps, int only_stereo, int coarse, int check_ori,
+                                           int* matches12, int* nmatches_out) {
+    if (!h || !K1 || n2 < 0 || (n2 > 0 && (!K2s || !F12s || !eps || !matches12))) return fail(ORBX_E_ARG, "null");
+    if (K1->device != h->device) return fail(ORBX_E_ARG, "key frame lives on another device");
+    rt::set_device(h->device);
+    const int N1 = K1->N;
+    if (n2 == 0 || N1 == 0) { for (int j = 0; j < n2; j++) if (nmatches_out) nmatches_out[j] = 0; return ORBX_OK; }
+    // call-time flags: KF1's map point flags at 0, then each neighbour's
+    size_t ftotal = al16((size_t)N1);
+    std::vector<SftNeighbour> nb(n2);
+    for (int j = 0; j < n2; j++) {
+        const orbm_keyframe* K2 = K2s[j];
+        if (!K2 || K2->device != h->device) return fail(ORBX_E_ARG, "bad neighbour key frame %d", j);
+        SftNeighbour& S = nb[j]; memset(&S, 0, sizeof S);
+        S.k2 = K2->dev; S.mp2_off = (int)ftotal; ftotal += al16((size_t)std::max(K2->N, 1));
+        BowParams& P = S.P;
+        for (int i = 0; i < 9; i++) P.F12[i] = F12s[9 * (size_t)j + i];
+        P.ep[0] = eps[2 * (size_t)j]; P.ep[1] = eps[2 * (size_t)j + 1];
+        for (int l = 0; l < kMaxLevels; l++) { P.scale2[l] = K2->scale[l]; P.sigma2_2[l] = K2->sigma2[l]; }
+        P.only_stereo = only_stereo; P.coarse = coarse; P.th_low = TH_LOW; P.nleft1 = P.nleft2 = -1;
+    }
+    std::vector<uint8_t> flags(ftotal, 0);
+    if (has_mp1) memcpy(flags.data(), has_mp1, (size_t)N1);
+    for (int j = 0; j < n2; j++) if (has_mp2 && has_mp2[j] && K2s[j]->N > 0) memcpy(&flags[nb[j].mp2_off], has_mp2[j], (size_t)K2s[j]->N);
+    Packer pk(h);
+    const size_t pf = pk.add(flags.data(), flags.size()), pn = pk.add(nb.data(), sizeof(SftNeighbour) * nb.size());
+    if (pk.flush() || h->d_si[SI_BEST].ensure((size_t)n2 * N1)) return fail(ORBX_E_DEVICE, "upload/allocation failed");
+    dim3 grid((N1 + 3) / 4, n2, 1), blk(256, 1, 1);
+    ORBX_LAUNCH(k_sft_resident, grid, blk, 0, h->s0, K1->dev, pk.dev<uint8_t>(pf), pk.dev<SftNeighbour>(pn), h->d_si[SI_BEST].p);
+    if (rt::copy_d2h(matches12, h->d_si[SI_BEST].p, sizeof(int) * (size_t)n2 * N1, h->s0) || rt::stream_sync(h->s0) || rt::check_launch())
+        return fail(ORBX_E_DEVICE, "resident triangulation search failed: %s", rt::last_error());
+    for (int j = 0; j < n2; j++) {
+        const int nm = prune_by_rotation(K1, K2s[j], matches12 + (size_t)j * N1, check_ori != 0);
+        if (nmatches_out) nmatches_out[j] = nm;
+    }
+    return ORBX_OK;
+}
+
+int orbm_search_by_bow_resident(orbx_extractor* h, int n, orbm_keyframe* const* K1s, const uint8_t* const* has_mp1, orbm_keyframe* const* K2s,
+                                const uint8_t* const* eligible2, float nnratio, int th_inclusive, int check_ori, int* const* matches12, int* nmatches_out) {
+    if (!h || n < 0 || (n > 0 && (!K1s || !K2s || !matches12))) return fail(ORBX_E_ARG, "null");
+    rt::set_device(h->device);
+    if (n == 0) return ORBX_OK;
+    size_t ftotal = 0; int N1cap = 1, maxnodes = 1;
+    std::vector<BowPairResident> pairs(n);
+    for (int p = 0; p < n; p++) {
+        const orbm_keyframe *K1 = K1s[p], *K2 = K2s[p];
+        if (!K1 || !K2 || !matches12[p] || K1->device != h->device || K2->device != h->device) return fail(ORBX_E_ARG, "bad key frame pair %d", p);
+        BowPairResident& B = pairs[p];
+        B.k1 = K1->dev; B.k2 = K2->dev;
+        B.mp1_off = -1; B.elig2_off = -1;
+        if (has_mp1 && has_mp1[p] && K1->N > 0) { B.mp1_off = (int)ftotal; ftotal += al16((size_t)K1->N); }
+        if (eligible2 && eligible2[p] && K2->N > 0) { B.elig2_off = (int)ftotal; ftotal += al16((size_t)K2->N); }
+        N1cap = std::max(N1cap, K1->N); maxnodes = std::max(maxnodes, K1->fv_nodes);
+    }
+    std::vector<uint8_t> flags(std::max<size_t>(ftotal, 16), 0);
+    for (int p = 0; p < n; p++) {
+        if (pairs[p].mp1_off >= 0) memcpy(&flags[pairs[p].mp1_off], has_mp1[p], (size_t)K1s[p]->N);
+        if (pairs[p].elig2_off >= 0) memcpy(&flags[pairs[p].elig2_off], eligible2[p], (size_t)K2s[p]->N);
+    }
+    Packer pk(h);
+    const size_t pf = pk.add(flags.data(), flags.size()), pp = pk.add(pairs.data(), sizeof(BowPairResident) * pairs.size());
+    const size_t nout = (size_t)n * N1cap;
+    if (pk.flush() || h->d_si[SI_BEST].ensure(nout + 4)) return fail(ORBX_E_DEVICE, "upload/allocation failed");
+    // results pre-set to -1, the status word behind them to 0
+    if (rt::memset_async(h->d_si[SI_BEST].p, 0xFF, sizeof(int) * nout, h->s0) || rt::memset_async(h->d_si[SI_BEST].p + nout, 0, sizeof(int) * 4, h->s0))
+        return fail(ORBX_E_DEVICE, "memset failed");
+    dim3 grid((maxnodes + 3) / 4, n, 1), blk(256, 1, 1);
+    ORBX_LAUNCH(k_bow_match_resident, grid, blk, 0, h->s0, pk.dev<BowPairResident>(pp), pk.dev<uint8_t>(pf), nnratio, TH_LOW, th_inclusive,
+                h->d_si[SI_BEST].p, N1cap, h->d_si[SI_BEST].p + nout);
+    std::vector<int> res(nout + 4);
+    if (rt::copy_d2h(res.data(), h->d_si[SI_BEST].p, sizeof(int) * (nout + 4), h->s0) || rt::stream_sync(h->s0) || rt::check_launch())
+        return fail(ORBX_E_DEVICE, "resident bow search failed: %s", rt::last_error());
+    if (res[nout] & 4) return fail(ORBX_E_CAPACITY, "a vocabulary node holds more than 2048 features of one key frame");
+    for (int p = 0; p < n; p++) {
+        const int N1 = K1s[p]->N;
+        if (N1 > 0) memcpy(matches12[p], &res[(size_t)p * N1cap], sizeof(int) * (size_t)N1);
+        const int nm = prune_by_rotation(K1s[p], K2s[p], matches12[p], check_ori != 0);
+        if (nmatches_out) nmatches_out[p] = nm;
+    }
+    return ORBX_OK;
+}
+
 int orbm_search_by_bow(orbx_extractor* h, const OrbmKeyFrameView* K1, const OrbmKeyFrameView* K2, float nnratio, int th_inclusive,
                        int check_ori, int* matches12, int* nmatches_out) {
     if (!h || !K1 || !K2 || !matches12) return fail(ORBX_E_ARG, "null");

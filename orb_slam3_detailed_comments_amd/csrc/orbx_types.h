@@ -85,6 +85,16 @@ struct BowParams {
     float cam1[2][8], cam2[2][8];            // mvParameters of mpCamera / mpCamera2 of KF1 and KF2
     float R[4][9], t[4][3];                  // relative pose by [bRight1 * 2 + bRight2] (Tll, Tlr, Trl, Trr); one camera: entry 0
 };
+// Device-resident arrays of one key frame / frame (orbm_keyframe): what the vocabulary-bucket searches read of it, uploaded once.
+struct ResidentKF {
+    const KeyPointRec* kps; const unsigned long long* desc; const float* ur;
+    const uint32_t* node_id;     // mFeatVec as CSR: node ids (ascending), fv_nodes + 1 offsets, feature indices
+    const int* fv_start; const int* fv_feat;
+    const int* node_of_feat;     // feature -> index of its node in node_id (-1: in no node)
+    int N, fv_nodes;
+};
+struct SftNeighbour { ResidentKF k2; BowParams P; int mp2_off; int _pad; };        // one neighbour of orbm_search_for_triangulation_resident
+struct BowPairResident { ResidentKF k1, k2; int mp1_off, elig2_off; };             // one pair of orbm_search_by_bow_resident (offsets into the flag block, -1 = none / all)
 struct KB8StereoParams {                     // Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1530-1587)
     float cam1[8], cam2[8];                  // mpCamera, mpCamera2
     float R12[9], t12[3];                    // mRlr, mtlr

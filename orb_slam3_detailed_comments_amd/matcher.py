@@ -70,6 +70,35 @@ class ORBmatcher:
         ext._lib.check(ext._lib.L.orbm_search_by_bow_batch(ext._h, n, p1, p2, self.mfNNratio, int(frame_version), int(self.mbCheckOrientation), po, nm.ctypes.data))
         return [(int(nm[p]), outs[p][:kf1s[p].view.N]) for p in range(n)]
 
+    def SearchForTriangulationResident(self, ext, kf1, mp1, kf2s, mp2s, F12s, eps, bOnlyStereo=False, bCoarse=False):
+        """SearchForTriangulationBatch over ResidentKeyFrame objects: mp1 / mp2s[j] = uint8 flags "feature has a map point" at call time (None =
+        none).  Returns the same list of (nmatches, pairs)."""
+        n2 = len(kf2s)
+        F = np.ascontiguousarray(F12s, np.float32).reshape(n2, 9); E = np.ascontiguousarray(eps, np.float32).reshape(n2, 2)
+        ptrs = (C.c_void_p * max(n2, 1))(*[k._kf for k in kf2s])
+        m1 = None if mp1 is None else np.ascontiguousarray(mp1, np.uint8)
+        m2 = [None if m is None else np.ascontiguousarray(m, np.uint8) for m in mp2s]
+        pm2 = (C.c_void_p * max(n2, 1))(*[None if m is None else m.ctypes.data for m in m2])
+        N1 = kf1.N
+        m12 = np.full((max(n2, 1), max(N1, 1)), -1, np.int32); nm = np.zeros(max(n2, 1), np.int32)
+        ext._lib.check(ext._lib.L.orbm_search_for_triangulation_resident(ext._h, kf1._kf, None if m1 is None else m1.ctypes.data, n2, ptrs, pm2, F.ctypes.data,
+                                                                       E.ctypes.data, int(bOnlyStereo), int(bCoarse), int(self.mbCheckOrientation), m12.ctypes.data,
+                                                                       nm.ctypes.data))
+        m12 = m12.reshape(-1)[:n2 * N1].reshape(n2, N1) if N1 > 0 else m12[:n2, :0]
+        return [(int(nm[j]), [(int(i), int(m12[j, i])) for i in np.nonzero(m12[j] >= 0)[0]]) for j in range(n2)]
+
+    def SearchByBoWResident(self, ext, kf1s, mp1s, kf2s, elig2s, frame_version=True):
+        """SearchByBoWBatch over ResidentKeyFrame objects: mp1s[p] = uint8 flags "feature of kf1s[p] has a good map point", elig2s[p] = flags of the
+        features of kf2s[p] that may be matched (None = all).  Returns the same list of (nmatches, matches12)."""
+        n = len(kf1s)
+        p1 = (C.c_void_p * max(n, 1))(*[k._kf for k in kf1s]); p2 = (C.c_void_p * max(n, 1))(*[k._kf for k in kf2s])
+        a1 = [None if m is None else np.ascontiguousarray(m, np.uint8) for m in mp1s]; a2 = [None if m is None else np.ascontiguousarray(m, np.uint8) for m in elig2s]
+        q1 = (C.c_void_p * max(n, 1))(*[None if m is None else m.ctypes.data for m in a1]); q2 = (C.c_void_p * max(n, 1))(*[None if m is None else m.ctypes.data for m in a2])
+        outs = [np.full(max(k.N, 1), -1, np.int32) for k in kf1s]
+        po = (C.c_void_p * max(n, 1))(*[o.ctypes.data for o in outs]); nm = np.zeros(max(n, 1), np.int32)
+        ext._lib.check(ext._lib.L.orbm_search_by_bow_resident(ext._h, n, p1, q1, p2, q2, self.mfNNratio, int(frame_version), int(self.mbCheckOrientation), po, nm.ctypes.data))
+        return [(int(nm[p]), outs[p][:kf1s[p].N]) for p in range(n)]
+
     def SearchByBoWFisheye(self, ext, kf, frame, nleft):
         """SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) for a fisheye-rig frame (F.Nleft = nleft != -1), src/ORBmatcher.cc:259-493.
         Both views list all features by index (camera 1 first).  Returns (nmatches, assigned[N_frame] = key-frame feature or -1)."""
@@ -145,6 +174,27 @@ class ORBmatcher:
         out = np.zeros((len(a), len(b)), np.int32)
         ext._lib.check(ext._lib.L.orbm_hamming_matrix(ext._h, a.ctypes.data, len(a), b.ctypes.data, len(b), out.ctypes.data))
         return out
+
+
+class ResidentKeyFrame:
+    """orbm_keyframe: the parts of a key frame / frame the vocabulary-bucket searches read (keys, descriptors, mvuRight, mFeatVec), uploaded
+    once from a views.key_frame_view.  Usable with every extractor handle of the same device."""
+
+    def __init__(self, ext, kf_view):
+        self._lib = ext._lib; self.N = kf_view.view.N
+        h = C.c_void_p()
+        self._lib.check(self._lib.L.orbm_keyframe_create(ext._h, kf_view.ref(), C.byref(h)))
+        self._kf = h
+
+    def close(self):
+        if self._kf:
+            self._lib.L.orbm_keyframe_destroy(self._kf); self._kf = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def ComputeStereoMatches(left, right, bf, b, left_first=0, right_first=0, B=None):

@@ -313,6 +313,30 @@ int mw_search_for_triangulation(void* wv, int kf1, int kf2, int only_stereo, int
     for (size_t i = 0; i < vp.size() && (int)i < cap; i++) { pairs[2 * i] = (int)vp[i].first; pairs[2 * i + 1] = (int)vp[i].second; }
     return n;
 }
+// the same against n2 neighbours: the facade's one-call form over device-resident key frames, the reference's method once per neighbour.
+// pairs: n2 blocks of cap (idx1, idx2) pairs; n_pairs / nmatches: n2 entries.  `rounds` repeats the call (the facade's cache is reused).
+int mw_search_for_triangulation_neighbours(void* wv, int kf1, int n2, const int* kf2s, int only_stereo, int coarse, int* pairs, int cap, int* n_pairs, int* nmatches,
+                                           float nnratio, int check_ori, int rounds) {
+    World* w = (World*)wv;
+    ORBmatcher m(nnratio, check_ori != 0);
+    std::vector<std::vector<std::pair<size_t, size_t>>> vv(n2);
+    std::vector<int> counts(n2, 0);
+#ifdef MW_FACADE
+    ORBmatcher::ResidentKeyFrames<KeyFrame> cache;
+    std::vector<KeyFrame*> neigh(n2);
+    for (int j = 0; j < n2; j++) neigh[j] = w->kfs[kf2s[j]].get();
+    for (int r = 0; r < rounds; r++) counts = m.SearchForTriangulation(w->kfs[kf1].get(), neigh, cache, vv, only_stereo != 0, coarse != 0);
+    if ((int)cache.size() > n2 + 1) return -1;
+#else
+    for (int r = 0; r < rounds; r++)
+        for (int j = 0; j < n2; j++) counts[j] = m.SearchForTriangulation(w->kfs[kf1].get(), w->kfs[kf2s[j]].get(), vv[j], only_stereo != 0, coarse != 0);
+#endif
+    for (int j = 0; j < n2; j++) {
+        n_pairs[j] = (int)vv[j].size(); nmatches[j] = counts[j];
+        for (size_t i = 0; i < vv[j].size() && (int)i < cap; i++) { pairs[2 * ((size_t)j * cap + i)] = (int)vv[j][i].first; pairs[2 * ((size_t)j * cap + i) + 1] = (int)vv[j][i].second; }
+    }
+    return 0;
+}
 int mw_fuse(void* wv, int kf, const int* mp_ids, int M, float th, int right) {
     World* w = (World*)wv;
     std::vector<MapPoint*> v(M); for (int i = 0; i < M; i++) v[i] = w->mp(mp_ids[i]);

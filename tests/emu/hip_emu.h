@@ -196,6 +196,7 @@ static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v
 
 static inline int __mul24(int a, int b) { return a * b; }     // device: v_mul_i32_i24; the callers keep both factors below 2^23
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 
 template <typename T> static inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }

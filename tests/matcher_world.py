@@ -268,6 +268,16 @@ def build_and_run(drv, seed, variant):
     n = L.mw_search_for_triangulation(drv.w, kA, kB, 0, 0, _p(pairs), len(kkA), C.byref(npairs), C.c_float(0.6), 0)
     out["triang_noori"] = np.concatenate([[n, npairs.value], pairs])
 
+    # the same against several neighbours: the facade answers them in one call over device-resident key frames (twice: the second round
+    # reuses the cached uploads), the reference is called once per neighbour
+    if hasattr(L, "mw_search_for_triangulation_neighbours"):
+        neigh = np.array([kB, kB, kB], np.int32); cap = len(kkA)
+        for only_stereo, coarse, ori in ((0, 0, 1), (1, 1, 0)):
+            pairs = i32(2 * cap * len(neigh)); npairs = i32(len(neigh)); nms = i32(len(neigh))
+            rc = L.mw_search_for_triangulation_neighbours(drv.w, kA, len(neigh), _p(neigh), only_stereo, coarse, _p(pairs), cap, _p(npairs), _p(nms), C.c_float(0.6), ori, 2)
+            assert rc == 0
+            out["triang_neighbours_%d_%d" % (only_stereo, coarse)] = np.concatenate([npairs, nms, pairs])
+
     # ---- SearchBySim3 -----------------------------------------------------------------------------------------------
     R1, t1 = poses[0]; R2, t2 = poses[1]                    # S12 = T1w * Tw2 (scale 1) with a small perturbation
     R12 = (R1 @ R2.T).astype(np.float32); t12 = (t1 - R12 @ t2 + np.array([0.01, -0.01, 0.02])).astype(np.float32)

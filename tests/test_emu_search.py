@@ -75,6 +75,23 @@ def run_all(lib, w, h, nf, M_points, seeds):
                 n2, m2 = ol.oracle_search_by_bow(k1s[p], k2s[p], ratio, frame_version, ori)
                 assert got[p][0] == n2 and np.array_equal(got[p][1], m2), (p, frame_version, ratio, ori)
         assert M.ORBmatcher(0.7, True).SearchByBoWBatch(ex, [], [], True) == []
+        # device-resident key frames: uploaded once, the searches take the call-time map point flags; the SearchByBoW accept loop runs on the device
+        rk = {id(kf): M.ResidentKeyFrame(ex, kf) for kf in (kf1[0], kf2[0], kf3[0], kf4[0])}
+        flags = lambda kf: kf.keep[8]
+        for (frame_version, ratio, ori) in [(True, 0.7, True), (False, 0.8, False), (True, 0.95, False)]:
+            k1s = [kf1[0], kf3[0], kf2[0], kf1[0]]; k2s = [kf2[0], kf4[0], kf1[0], kf4[0]]
+            got = M.ORBmatcher(ratio, ori).SearchByBoWResident(ex, [rk[id(k)] for k in k1s], [flags(k) for k in k1s], [rk[id(k)] for k in k2s],
+                                                               [flags(k) for k in k2s], frame_version)
+            for p in range(len(k1s)):
+                n2, m2 = ol.oracle_search_by_bow(k1s[p], k2s[p], ratio, frame_version, ori)
+                assert got[p][0] == n2 and np.array_equal(got[p][1], m2), (p, frame_version, ratio, ori)
+        for (only_stereo, coarse, ori) in [(False, False, True), (True, True, False), (False, True, True)]:
+            got = M.ORBmatcher(0.6, ori).SearchForTriangulationResident(ex, rk[id(kf1[0])], flags(kf1[0]), [rk[id(k)] for k in neigh], [flags(k) for k in neigh],
+                                                                       Fs, Es, only_stereo, coarse)
+            for j, kf in enumerate(neigh):
+                assert got[j] == ol.oracle_search_for_triangulation(kf1[0], kf, Fs[j], Es[j], only_stereo, coarse, ori), (j, only_stereo, coarse, ori)
+        for r in rk.values():
+            r.close()
         f1 = sc.views.frame_view(kf1[1], kf1[2], scales, w, h); f2 = sc.views.frame_view(kf2[1], kf2[2], scales, w, h)
         nbest = 0
         for (win, ratio, ori) in [(100, 0.9, True), (30, 0.9, False)]:

@@ -57,12 +57,50 @@ def main():
                  lambda: [ol.oracle_search_for_triangulation(kf1[0], kf2[0], F12, ep, False, False, False) for _ in range(20)]))
     rows.append(("SearchByBoW x 10 relocalisation candidates (one batched launch)", lambda: M.ORBmatcher(0.7, True).SearchByBoWBatch(ex, [kf1[0]] * 10, [kf2[0]] * 10, True),
                  lambda: [ol.oracle_search_by_bow(kf1[0], kf2[0], 0.7, True, True) for _ in range(10)]))
+    # the same two with device-resident key frames (orbm_keyframe): uploaded once, a call moves flags, poses and results only; the SearchByBoW
+    # accept loop runs on the device
+    rk1, rk2 = M.ResidentKeyFrame(ex, kf1[0]), M.ResidentKeyFrame(ex, kf2[0])
+    f1, f2 = kf1[0].keep[8], kf2[0].keep[8]
+    rows.append(("SearchForTriangulation x 20 neighbours, device-resident key frames", lambda: M.ORBmatcher(0.6, False).SearchForTriangulationResident(ex, rk1, f1, [rk2] * 20, [f2] * 20, Fs, Es),
+                 lambda: [ol.oracle_search_for_triangulation(kf1[0], kf2[0], F12, ep, False, False, False) for _ in range(20)]))
+    rows.append(("SearchByBoW x 10 relocalisation candidates, device-resident key frames", lambda: M.ORBmatcher(0.7, True).SearchByBoWResident(ex, [rk1] * 10, [f1] * 10, [rk2] * 10, [f2] * 10, True),
+                 lambda: [ol.oracle_search_by_bow(kf1[0], kf2[0], 0.7, True, True) for _ in range(10)]))
+    rows.append(("SearchByBoW(KeyFrame, Frame), device-resident key frames", lambda: M.ORBmatcher(0.7, True).SearchByBoWResident(ex, [rk1], [f1], [rk2], [f2], True),
+                 lambda: ol.oracle_search_by_bow(kf1[0], kf2[0], 0.7, True, True)))
     # MapPoint::ComputeDistinctiveDescriptors for 5000 map points with ~20 observations each
     counts = rng.integers(5, 40, MP); start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
     dd = rng.integers(0, 256, (int(start[-1]), 32), dtype=np.uint8)
     rows.append(("ComputeDistinctiveDescriptors (5000 map points, %d descriptors)" % len(dd), lambda: M.ComputeDistinctiveDescriptors(ex, dd, start), lambda: ol.oracle_distinctive_descriptors(dd, start)))
     for name, gpu, cpu in rows:
         out[name] = {"gpu_ms": round(best(gpu, 5), 3), "cpu_oracle_ms": round(best(cpu, 2), 3)}
+    # The four batched rows again at the C ABI, without the Python wrappers (argument arrays prebuilt, results left in their int arrays): a wrapper
+    # costs 20-600 us per call (the list of matched pairs of 20 neighbours is built in Python), as much as the searches themselves.
+    import ctypes as C
+    L = ex._lib.L; OL = ol.oracle()
+    N1 = kf1[0].view.N
+    m20 = np.full((20, N1), -1, np.int32); nm20 = np.zeros(20, np.int32); m10 = [np.full(N1, -1, np.int32) for _ in range(10)]; nm10 = np.zeros(10, np.int32)
+    vp = lambda xs: (C.c_void_p * len(xs))(*xs)
+    k2v = vp([C.cast(kf2[0].ref(), C.c_void_p)] * 20); k1v10 = vp([C.cast(kf1[0].ref(), C.c_void_p)] * 10); k2v10 = vp([C.cast(kf2[0].ref(), C.c_void_p)] * 10)
+    r2v = vp([rk2._kf] * 20); r1v10 = vp([rk1._kf] * 10); r2v10 = vp([rk2._kf] * 10)
+    f2v = vp([f2.ctypes.data] * 20); f1v10 = vp([f1.ctypes.data] * 10); f2v10 = vp([f2.ctypes.data] * 10); po10 = vp([m.ctypes.data for m in m10])
+    F9 = np.ascontiguousarray(F12, np.float32).reshape(9); E2 = np.ascontiguousarray(ep, np.float32).reshape(2); mo = np.full(N1, -1, np.int32)
+    OL.orbo_search_for_triangulation.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    OL.orbo_search_by_bow.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]
+
+    def cpu_sft20():
+        for _ in range(20): OL.orbo_search_for_triangulation(kf1[0].ref(), kf2[0].ref(), F9.ctypes.data, E2.ctypes.data, 0, 0, 0, mo.ctypes.data)
+
+    def cpu_bow10():
+        for _ in range(10): OL.orbo_search_by_bow(kf1[0].ref(), kf2[0].ref(), 0.7, 1, 1, mo.ctypes.data)
+    raw = [
+        ("SearchForTriangulation x 20 neighbours", lambda: L.orbm_search_for_triangulation_batch(ex._h, kf1[0].ref(), 20, k2v, Fs.ctypes.data, Es.ctypes.data, 0, 0, 0, m20.ctypes.data, nm20.ctypes.data),
+         lambda: L.orbm_search_for_triangulation_resident(ex._h, rk1._kf, f1.ctypes.data, 20, r2v, f2v, Fs.ctypes.data, Es.ctypes.data, 0, 0, 0, m20.ctypes.data, nm20.ctypes.data), cpu_sft20),
+        ("SearchByBoW x 10 relocalisation candidates", lambda: L.orbm_search_by_bow_batch(ex._h, 10, k1v10, k2v10, 0.7, 1, 1, po10, nm10.ctypes.data),
+         lambda: L.orbm_search_by_bow_resident(ex._h, 10, r1v10, f1v10, r2v10, f2v10, 0.7, 1, 1, po10, nm10.ctypes.data), cpu_bow10),
+    ]
+    for name, host_views, resident, cpu in raw:
+        out[name + " (C ABI, no Python wrapper)"] = {"gpu_ms_host_views": round(best(host_views, 10), 3), "gpu_ms_resident_key_frames": round(best(resident, 10), 3),
+                                                       "cpu_oracle_ms": round(best(cpu, 3), 3)}
     # Tracking::SearchLocalPoints: Frame::isInFrustum for 5000 map points + SearchByProjection on those in view, device vs the reference's own
     # Frame.cc / ORBmatcher.cc (oracle/_ref/libref_frame.so)
     if ol.reference_frame_lib() is not None:
