@@ -74,7 +74,8 @@ struct Csr { std::vector<int> start, count; std::vector<int> ent; };   // ent: 2
 // runs k_area_search for Q queries.  Results come back in one copy: [total, -, -, -][start Q][count Q][entries]; the number of
 // entries fetched with the header is a guess from the previous call, a second copy follows only if it was too small, and the pool is
 // grown and the search repeated if the pool itself overflowed.
-int run_area_search_dev(orbx_extractor* h, const DeviceFrame& D, int Q, const AreaQuery* dq, const unsigned long long* dqd, Csr* out);
+int run_area_search_dev(orbx_extractor* h, const DeviceFrame& D, int Q, const AreaQuery* dq, const unsigned long long* dqd, Csr* out, const void* extra_src = nullptr,
+                        size_t extra_bytes = 0, const uint8_t** extra_host = nullptr);
 int run_area_search(orbx_extractor* h, const DeviceFrame& D, const std::vector<AreaQuery>& qs, const uint8_t* qdesc, Csr* out) {
     const int Q = (int)qs.size();
     out->start.assign(Q, 0); out->count.assign(Q, 0); out->ent.clear();
@@ -85,8 +86,10 @@ int run_area_search(orbx_extractor* h, const DeviceFrame& D, const std::vector<A
     if (rt::copy_h2d(h->d_sr[SR_QUERY].p, h->h_packB.p, qtotal, h->s0)) return fail(ORBX_E_DEVICE, "upload failed");
     return run_area_search_dev(h, D, Q, (const AreaQuery*)(h->d_sr[SR_QUERY].p + oq), (const unsigned long long*)(h->d_sr[SR_QUERY].p + oqd), out);
 }
-// the same with the queries and their descriptors already on the device
-int run_area_search_dev(orbx_extractor* h, const DeviceFrame& D, int Q, const AreaQuery* dq, const unsigned long long* dqd, Csr* out) {
+// the same with the queries and their descriptors already on the device.  extra_src / extra_bytes: another device block to bring back with the
+// same synchronisation (the tracking fields of SearchLocalPoints); *extra_host points at its pinned copy afterwards.
+int run_area_search_dev(orbx_extractor* h, const DeviceFrame& D, int Q, const AreaQuery* dq, const unsigned long long* dqd, Csr* out, const void* extra_src,
+                        size_t extra_bytes, const uint8_t** extra_host) {
     out->start.assign(Q, 0); out->count.assign(Q, 0); out->ent.clear();
     if (Q == 0) return ORBX_OK;
     const size_t hdr = 16 + 8 * (size_t)Q;                          // bytes in front of the entries
@@ -101,8 +104,10 @@ int run_area_search_dev(orbx_extractor* h, const DeviceFrame& D, int Q, const Ar
         ORBX_LAUNCH(k_area_search, grid, blk, 0, h->s0, dq, dqd, Q, D.kps, D.ur, D.desc, D.g, D.cell_start, D.cell_items, 1, d_counter, (int)pool,
                     d_start, d_count, d_ent);
         const size_t guess = std::min(pool, std::max<size_t>(h->area_last_total + h->area_last_total / 4 + 256, 1024));
-        if (h->h_out.ensure(hdr + pool * 8 + 16)) return fail(ORBX_E_DEVICE, "pinned allocation failed");
+        const size_t oextra = al16(hdr + pool * 8 + 16);
+        if (h->h_out.ensure(oextra + extra_bytes + 16)) return fail(ORBX_E_DEVICE, "pinned allocation failed");
         rt::copy_d2h(h->h_out.p, dout, hdr + guess * 8, h->s0);
+        if (extra_bytes) { rt::copy_d2h(h->h_out.p + oextra, extra_src, extra_bytes, h->s0); if (extra_host) *extra_host = h->h_out.p + oextra; }
         if (rt::stream_sync(h->s0) || rt::check_launch()) return fail(ORBX_E_DEVICE, "area search failed: %s", rt::last_error());
         const int total = *(const int*)h->h_out.p;
         if ((size_t)total <= pool) {
@@ -272,25 +277,27 @@ int enqueue_frustum(orbx_extractor* h, const OrbmFrustumView* V, const OrbmWorld
     }
     return ORBX_OK;
 }
-// copies the tracking fields back (whatever the caller asked for); in_view always comes back through `inv`
-int fetch_frustum(orbx_extractor* h, int M, const FrustumDev& D, const OrbmTrackOut* out, std::vector<uint8_t>* inv) {
+// hands the tracking fields (host copy of the frustum kernel's output block: [track 5 M][level M][in_view M]) to the caller's arrays
+void scatter_track(const uint8_t* blk, int M, const OrbmTrackOut* out) {
+    if (!out || M <= 0) return;
+    const size_t M1 = M, ol = al16(20 * M1), ov = ol + al16(4 * M1);
+    const float* tr = (const float*)blk;
+    if (out->in_view) memcpy(out->in_view, blk + ov, M1);
+    if (out->proj_x) memcpy(out->proj_x, tr, 4 * M1);
+    if (out->proj_y) memcpy(out->proj_y, tr + M1, 4 * M1);
+    if (out->proj_xr) memcpy(out->proj_xr, tr + 2 * M1, 4 * M1);
+    if (out->depth) memcpy(out->depth, tr + 3 * M1, 4 * M1);
+    if (out->view_cos) memcpy(out->view_cos, tr + 4 * M1, 4 * M1);
+    if (out->scale_level) memcpy(out->scale_level, blk + ol, 4 * M1);
+}
+size_t track_block_bytes(int M) { const size_t M1 = M > 0 ? M : 1; return al16(20 * M1) + al16(4 * M1) + al16(M1); }
+// brings the block back (one copy into pinned memory) and scatters it
+int fetch_frustum(orbx_extractor* h, int M, const FrustumDev& D, const OrbmTrackOut* out) {
     if (M <= 0) return ORBX_OK;
-    const size_t M1 = M;
-    std::vector<float> tr(5 * M1); std::vector<int> lv(M1);
-    inv->assign(M1, 0);
-    int e = rt::copy_d2h(inv->data(), D.in_view, M1, h->s0);
-    const bool want = out && (out->proj_x || out->proj_y || out->proj_xr || out->depth || out->view_cos || out->scale_level);
-    if (want) e |= rt::copy_d2h(tr.data(), D.track, 20 * M1, h->s0) | rt::copy_d2h(lv.data(), D.level, 4 * M1, h->s0);
-    if (e || rt::stream_sync(h->s0) || rt::check_launch()) return fail(ORBX_E_DEVICE, "frustum kernel failed: %s", rt::last_error());
-    if (out) {
-        if (out->in_view) memcpy(out->in_view, inv->data(), M1);
-        if (out->proj_x) memcpy(out->proj_x, &tr[0], 4 * M1);
-        if (out->proj_y) memcpy(out->proj_y, &tr[M1], 4 * M1);
-        if (out->proj_xr) memcpy(out->proj_xr, &tr[2 * M1], 4 * M1);
-        if (out->depth) memcpy(out->depth, &tr[3 * M1], 4 * M1);
-        if (out->view_cos) memcpy(out->view_cos, &tr[4 * M1], 4 * M1);
-        if (out->scale_level) memcpy(out->scale_level, lv.data(), 4 * M1);
-    }
+    const size_t n = track_block_bytes(M);
+    if (h->h_out.ensure(n + 16)) return fail(ORBX_E_DEVICE, "pinned allocation failed");
+    if (rt::copy_d2h(h->h_out.p, D.track, n, h->s0) || rt::stream_sync(h->s0) || rt::check_launch()) return fail(ORBX_E_DEVICE, "frustum kernel failed: %s", rt::last_error());
+    scatter_track(h->h_out.p, M, out);
     return ORBX_OK;
 }
 }  // namespace
@@ -300,8 +307,7 @@ int orbm_is_in_frustum(orbx_extractor* h, const OrbmFrustumView* V, const OrbmWo
     rt::set_device(h->device);
     FrustumDev D;
     int rc = enqueue_frustum(h, V, P, cos_limit, false, 1.0f, 0, 0.0f, &D); if (rc) return rc;
-    std::vector<uint8_t> inv;
-    return fetch_frustum(h, P->M, D, out, &inv);
+    return fetch_frustum(h, P->M, D, out);
 }
 
 // Tracking::SearchLocalPoints' device part (src/Tracking.cc:4009-4067): Frame::isInFrustum for every candidate map point, then
@@ -316,9 +322,9 @@ int orbm_search_local_points(orbx_extractor* h, const OrbmFrameView* F, const Or
     rc = enqueue_frustum(h, V, P, cos_limit, true, th, far_points, th_far, &Q); if (rc) return rc;
     const int M = P->M, N = F->N;
     Csr c;
-    rc = run_area_search_dev(h, D, M, Q.queries, Q.qdesc, &c); if (rc) return rc;
-    std::vector<uint8_t> inv;
-    rc = fetch_frustum(h, M, Q, out, &inv); if (rc) return rc;
+    const uint8_t* track_blk = nullptr;
+    rc = run_area_search_dev(h, D, M, Q.queries, Q.qdesc, &c, Q.track, out ? track_block_bytes(M) : 0, &track_blk); if (rc) return rc;
+    if (track_blk) scatter_track(track_blk, M, out);
     // ---- sequential replay of src/ORBmatcher.cc:62-166 (a query without candidates - not in view, far, bad - has count 0) ----
     std::vector<uint8_t> occ(N > 0 ? N : 1, 0);
     if (F->occupied) memcpy(occ.data(), F->occupied, N);

@@ -262,7 +262,7 @@ class _TrackOut(C.Structure):
 
 
 def SearchLocalPoints(ext, frame, Rcw, tcw, cam, bounds, mbf, scale_factors, pos, normal, min_distance, max_distance, is_bad=None, has_obs=None, desc=None,
-                      viewing_cos_limit=0.5, th=1.0, far_points=False, th_far=50.0, nnratio=0.8, search=True):
+                      viewing_cos_limit=0.5, th=1.0, far_points=False, th_far=50.0, nnratio=0.8, search=True, prepared=False):
     """Frame::isInFrustum (src/Frame.cc:667-773) for M map points and, with search=True, ORBmatcher::SearchByProjection(F, points, th, ...)
     (src/ORBmatcher.cc:45-167) on those in view - Tracking::SearchLocalPoints (src/Tracking.cc:4009-4067) on the device.
     cam: (fx, fy, cx, cy) or the 8 Kannala-Brandt parameters; bounds = (min_x, max_x, min_y, max_y); frame: views.frame_view(...).
@@ -295,8 +295,15 @@ def SearchLocalPoints(ext, frame, Rcw, tcw, cam, bounds, mbf, scale_factors, pos
         L.check(L.L.orbm_is_in_frustum(ext._h, C.byref(V), C.byref(P), float(viewing_cos_limit), C.byref(T)))
         return {k: v[:M] for k, v in tr.items()}, None, 0
     assigned = np.full(max(frame.view.N, 1), -1, np.int32); n = C.c_int(0)
-    L.check(L.L.orbm_search_local_points(ext._h, frame.ref(), C.byref(V), C.byref(P), float(viewing_cos_limit), float(th), int(far_points), float(th_far), float(nnratio),
-                                         C.byref(T), assigned.ctypes.data, C.byref(n)))
+    keep = (V, P, T, sf, pos, normal, mn, mx, bad, obs, d, tr)
+
+    def call(_keep=keep):
+        """the C ABI call alone (arguments prebuilt): what a C++ caller pays"""
+        return L.L.orbm_search_local_points(ext._h, frame.ref(), C.byref(V), C.byref(P), float(viewing_cos_limit), float(th), int(far_points), float(th_far), float(nnratio),
+                                            C.byref(T), assigned.ctypes.data, C.byref(n))
+    if prepared:
+        return call
+    L.check(call())
     return {k: v[:M] for k, v in tr.items()}, assigned[:frame.view.N], n.value
 
 
