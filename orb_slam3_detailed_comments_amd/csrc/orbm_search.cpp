@@ -316,15 +316,32 @@ int orbm_search_local_points(orbx_extractor* h, const OrbmFrameView* F, const Or
                              int far_points, float th_far, float nnratio, const OrbmTrackOut* out, int* assigned, int* nmatches_out) {
     if (!h || !F || !V || !P || !assigned) return fail(ORBX_E_ARG, "null");
     rt::set_device(h->device);
+#ifdef ORBX_TRACE_TIMING
+    timespec ts_; auto now_us = [&]() { clock_gettime(CLOCK_MONOTONIC, &ts_); return ts_.tv_sec * 1e6 + ts_.tv_nsec * 1e-3; };
+    const double t0 = now_us();
+#endif
     DeviceFrame D;
     int rc = upload_frame(h, F, &D); if (rc) return rc;
+#ifdef ORBX_TRACE_TIMING
+    const double t1 = now_us();
+#endif
     FrustumDev Q;
     rc = enqueue_frustum(h, V, P, cos_limit, true, th, far_points, th_far, &Q); if (rc) return rc;
+#ifdef ORBX_TRACE_TIMING
+    const double t2 = now_us();
+#endif
     const int M = P->M, N = F->N;
     Csr c;
     const uint8_t* track_blk = nullptr;
     rc = run_area_search_dev(h, D, M, Q.queries, Q.qdesc, &c, Q.track, out ? track_block_bytes(M) : 0, &track_blk); if (rc) return rc;
+#ifdef ORBX_TRACE_TIMING
+    const double t3 = now_us();
+#endif
     if (track_blk) scatter_track(track_blk, M, out);
+#ifdef ORBX_TRACE_TIMING
+    const double t4 = now_us();
+    struct Fin { double t0, t1, t2, t3, t4; decltype(now_us)& f; size_t ents; ~Fin() { const double t5 = f(); fprintf(stderr, "[search_local_points] frame upload %.1f  frustum enqueue %.1f  area search + wait + copy-out %.1f  scatter %.1f  replay %.1f us (%zu entries)\n", t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, ents); } } fin{t0, t1, t2, t3, t4, now_us, c.ent.size() / 2};
+#endif
     // ---- sequential replay of src/ORBmatcher.cc:62-166 (a query without candidates - not in view, far, bad - has count 0) ----
     std::vector<uint8_t> occ(N > 0 ? N : 1, 0);
     if (F->occupied) memcpy(occ.data(), F->occupied, N);
