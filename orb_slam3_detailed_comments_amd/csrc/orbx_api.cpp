@@ -332,10 +332,11 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
     rt::stream_wait_event(h->s0, h->ev_join);
     stage_begin(h, ST_DESCRIBE, h->s0);
     {
-        dim3 grid((h->kp_total_cap + 4 * kKpPerWaveDecl - 1) / (4 * kKpPerWaveDecl), B, 1);
+        const int gpi = (h->kp_total_cap + 4 * kKpPerWaveDecl - 1) / (4 * kKpPerWaveDecl);
+        dim3 grid(gpi * 8 * ((B + 7) / 8), 1, 1);                  // an image's workgroups on one XCD (k_orient_brief)
         ORBX_LAUNCH(k_orient_brief, grid, blk1, 0, h->s0, (const LevelInfo*)h->d_lv.p, nl, (const uint8_t*)h->d_pyr.p, (const uint8_t*)h->d_blur.p,
                     h->pyr_stride, (const uint32_t*)h->d_lvl_keys.p, h->kp_total_cap, (const int*)h->d_lvl_count.p, (const int*)h->d_final_idx.p,
-                    h->umax, h->d_kps.p, h->d_desc.p, (int4*)h->d_aux.p);
+                    h->umax, h->d_kps.p, h->d_desc.p, (int4*)h->d_aux.p, B, gpi);
     }
     stage_end(h, ST_DESCRIBE, h->s0);
     rt::event_record(h->ev_done, h->s0);

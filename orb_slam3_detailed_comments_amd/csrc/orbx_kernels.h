@@ -41,7 +41,8 @@ __global__ void k_orient_brief(const LevelInfo* __restrict__ lv, int nlevels, co
                                const uint8_t* __restrict__ blur, size_t pyr_stride,
                                const uint32_t* __restrict__ lvl_keys, int kp_total_cap,
                                const int* __restrict__ lvl_count, const int* __restrict__ final_idx, UmaxTab umax,
-                               KeyPointRec* __restrict__ out_kps, unsigned long long* __restrict__ out_desc, int4* __restrict__ out_aux);
+                               KeyPointRec* __restrict__ out_kps, unsigned long long* __restrict__ out_desc, int4* __restrict__ out_aux,
+                               int B, int groups_per_image);
 __global__ void k_hamming_matrix(const unsigned long long* __restrict__ A, int na,
                                  const unsigned long long* __restrict__ Bm, int nb, int* __restrict__ out);
 __global__ void k_stereo_rows(const int4* __restrict__ auxR, const int* __restrict__ nR, int cap, int nb, int* __restrict__ bucket_start,
