@@ -13,6 +13,7 @@
 //                  unmatched feature of KF1 against the features of KF2 in the same vocabulary node.
 #include "orbx_types.h"
 #include "orbx_block.h"
+#include "orbx_kernels.h"
 #include "kb8_model.h"
 
 namespace orbx {
@@ -101,33 +102,36 @@ __device__ __forceinline__ bool chi2_accept(const AreaQuery& A, const KeyPointRe
     return !((double)__fmul_rn(e2, inv) > 5.99);
 }
 
-// One wave per query.  grid (ceil(Q/4)), 256 threads.  Lane l of a chunk owns window cell l (cells enumerated ix-major,
-// iy-minor like the reference's loops): pass 0 counts, one atomicAdd reserves the query's span of the entry pool, pass 1
-// re-enumerates and writes each lane's candidates at its ordered offset (wave prefix sum).
+// One wave per query.  grid (ceil(Q / kAreaWaves)), 64 * kAreaWaves threads.  Lane l of a chunk owns window cell l (cells enumerated ix-major,
+// iy-minor like the reference's loops): pass 0 counts, the workgroup reserves the spans of its queries in the entry pool with ONE atomicAdd
+// (thousands of same-address atomics, one per query, were most of this kernel's time), pass 1 re-enumerates and writes each lane's
+// candidates at its ordered offset (wave prefix sum).
 // entries: int2 per candidate {idx, dist | octave << 16}; q_start/q_count: CSR; pool_counter: running allocation.
-__global__ void __launch_bounds__(256) k_area_search(const AreaQuery* __restrict__ queries, const unsigned long long* __restrict__ qdesc, int Q,
+__global__ void __launch_bounds__(64 * kAreaWaves) k_area_search(const AreaQuery* __restrict__ queries, const unsigned long long* __restrict__ qdesc, int Q,
                                                      const KeyPointRec* __restrict__ kps, const float* __restrict__ u_right,
                                                      const unsigned long long* __restrict__ fdesc, GridParams g,
                                                      const int* __restrict__ cell_start, const int* __restrict__ cell_items,
                                                      int gate_right, int* __restrict__ pool_counter, int pool_cap,
                                                      int* __restrict__ q_start, int* __restrict__ q_count, int2* __restrict__ entries) {
-    const int lane = lane_id();
-    const int q = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-    if (q >= Q) return;
-    const AreaQuery A = queries[q];
+    __shared__ int s_cnt[kAreaWaves], s_base;
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const int q = (int)blockIdx.x * kAreaWaves + wave;
+    AreaQuery A{};
+    if (q < Q) A = queries[q];
     int cnt_total = 0, start = 0;
     // window of grid cells, src/Frame.cc:877-903
     const int nMinX = imax(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(A.x, g.min_x), A.r), g.gw_inv)));
     const int nMaxX = imin(kGridCols - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(A.x, g.min_x), A.r), g.gw_inv)));
     const int nMinY = imax(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(A.y, g.min_y), A.r), g.gh_inv)));
     const int nMaxY = imin(kGridRows - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(A.y, g.min_y), A.r), g.gh_inv)));
-    const bool window_ok = A.active && !(nMinX >= kGridCols || nMaxX < 0 || nMinY >= kGridRows || nMaxY < 0) && nMaxX >= nMinX && nMaxY >= nMinY;
-    if (window_ok) {
-        const int ny = nMaxY - nMinY + 1, ncw = (nMaxX - nMinX + 1) * ny;
-        const bool check_levels = (A.min_level > 0) || (A.max_level >= 0);
-        const unsigned long long* dq = qdesc + 4 * (size_t)q;
-        const unsigned long long d0 = dq[0], d1 = dq[1], d2 = dq[2], d3 = dq[3];
+    const bool window_ok = q < Q && A.active && !(nMinX >= kGridCols || nMaxX < 0 || nMinY >= kGridRows || nMaxY < 0) && nMaxX >= nMinX && nMaxY >= nMinY;
+    const int ny = nMaxY - nMinY + 1, ncw = window_ok ? (nMaxX - nMinX + 1) * ny : 0;
+    const bool check_levels = (A.min_level > 0) || (A.max_level >= 0);
+    unsigned long long d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+    if (window_ok) { const unsigned long long* dq = qdesc + 4 * (size_t)q; d0 = dq[0]; d1 = dq[1]; d2 = dq[2]; d3 = dq[3]; }
+    {
         for (int pass = 0; pass < 2; pass++) {
+            if (pass == 1 && cnt_total == 0) break;
             int base = 0;
             for (int c0 = 0; c0 < ncw; c0 += 64) {
                 const int c = c0 + lane;
@@ -160,15 +164,22 @@ __global__ void __launch_bounds__(256) k_area_search(const AreaQuery* __restrict
             }
             if (pass == 0) {
                 cnt_total = base;
-                if (cnt_total == 0) break;
-                int off = 0;
-                if (lane == 0) off = atomicAdd(pool_counter, cnt_total);
-                off = __shfl(off, 0);
+                // one reservation per workgroup: the waves' spans follow each other in wave order
+                if (lane == 0) s_cnt[wave] = cnt_total;
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    int tot = 0;
+                    for (int w = 0; w < kAreaWaves; w++) tot += s_cnt[w];
+                    s_base = tot > 0 ? atomicAdd(pool_counter, tot) : 0;
+                }
+                __syncthreads();
+                int off = s_base;
+                for (int w = 0; w < wave; w++) off += s_cnt[w];
                 start = (off + cnt_total <= pool_cap) ? off : -1;   // -1: pool overflow, the host retries with a bigger pool
             }
         }
     }
-    if (lane == 0) { q_start[q] = start < 0 ? 0 : start; q_count[q] = cnt_total; }
+    if (lane == 0 && q < Q) { q_start[q] = start < 0 ? 0 : start; q_count[q] = cnt_total; }
 }
 
 // Frame::isInFrustum (src/Frame.cc:667-773, one camera) + MapPoint::PredictScale (src/MapPoint.cc:688-731) for M map points, one thread each,

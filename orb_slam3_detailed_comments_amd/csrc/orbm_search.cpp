@@ -100,7 +100,7 @@ int run_area_search_dev(orbx_extractor* h, const DeviceFrame& D, int Q, const Ar
         uint8_t* dout = h->d_sr[SR_ENTRIES].p;
         int* d_counter = (int*)dout; int* d_start = (int*)(dout + 16); int* d_count = d_start + Q; int2* d_ent = (int2*)(dout + hdr);
         rt::memset_async(d_counter, 0, 16, h->s0);
-        dim3 grid((Q + 3) / 4, 1, 1), blk(256, 1, 1);
+        dim3 grid((Q + kAreaWaves - 1) / kAreaWaves, 1, 1), blk(64 * kAreaWaves, 1, 1);
         ORBX_LAUNCH(k_area_search, grid, blk, 0, h->s0, dq, dqd, Q, D.kps, D.ur, D.desc, D.g, D.cell_start, D.cell_items, 1, d_counter, (int)pool,
                     d_start, d_count, d_ent);
         const size_t guess = std::min(pool, std::max<size_t>(h->area_last_total + h->area_last_total / 4 + 256, 1024));

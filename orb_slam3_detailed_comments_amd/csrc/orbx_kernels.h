@@ -67,6 +67,7 @@ __global__ void k_knn2(const unsigned long long* __restrict__ descQ, const int* 
 
 __global__ void k_grid_build(const KeyPointRec* __restrict__ kps, int N, GridParams g, int* __restrict__ cell_of,
                              int* __restrict__ cell_start, int* __restrict__ cell_items);
+constexpr int kAreaWaves = 16;         // queries (waves) per k_area_search workgroup
 __global__ void k_area_search(const AreaQuery* __restrict__ queries, const unsigned long long* __restrict__ qdesc, int Q,
                               const KeyPointRec* __restrict__ kps, const float* __restrict__ u_right,
                               const unsigned long long* __restrict__ fdesc, GridParams g, const int* __restrict__ cell_start,
