@@ -18,6 +18,7 @@
 
 namespace orbx {
 
+constexpr int kGridSmallCell = 16;                 // k_grid_build: cells up to this size are ordered by their own thread
 constexpr int kGridCols = 64, kGridRows = 48;   // FRAME_GRID_COLS / FRAME_GRID_ROWS, include/Frame.h:44-45
 
 // grid (1), 256 threads.  cell_of: scratch [N] ints.  cell_start: [64*48+1].  Cell id = ix*48 + iy.
@@ -30,6 +31,7 @@ __global__ void __launch_bounds__(256) k_grid_build(const KeyPointRec* __restric
     const int tid = (int)threadIdx.x;
     const int ncell = kGridCols * kGridRows;
     for (int c = tid; c < ncell; c += 256) s_hist[c] = 0;
+    if (tid == 0) s_chunk[0] = 0;                                 // set when a cell is crowded (the ordered chunk placement below then runs)
     __syncthreads();
     for (int i = tid; i < N; i += 256) {
         const KeyPointRec k = kps[i];
@@ -41,17 +43,41 @@ __global__ void __launch_bounds__(256) k_grid_build(const KeyPointRec* __restric
     }
     __syncthreads();
     // exclusive scan of the histogram -> cell_start; s_hist becomes the running cursor of each cell
-    int run = 0;
-    for (int c0 = 0; c0 < ncell; c0 += 256) {
-        const int c = c0 + tid;
-        const int v = s_hist[c];
+    // (a thread takes ncell / 256 = 12 consecutive cells, so one workgroup scan does)
+    {
+        constexpr int kPer = kGridCols * kGridRows / 256;
+        static_assert(kPer * 256 == kGridCols * kGridRows, "grid cells per thread");
+        int loc[kPer], sum = 0, mx = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; k++) { const int v = s_hist[tid * kPer + k]; loc[k] = sum; sum += v; mx = v > mx ? v : mx; }
+        if (mx > kGridSmallCell) s_chunk[0] = 1;                  // (benign race: every writer stores 1)
         unsigned long long tot;
-        const int ex = run + (int)block_excl_scan<unsigned long long>((unsigned long long)v, &tot, s_scan);
-        cell_start[c] = ex;
-        s_hist[c] = ex;
-        run += (int)tot;
+        const int ex = (int)block_excl_scan<unsigned long long>((unsigned long long)sum, &tot, s_scan);
+#pragma unroll
+        for (int k = 0; k < kPer; k++) { cell_start[tid * kPer + k] = ex + loc[k]; s_hist[tid * kPer + k] = ex + loc[k]; }
+        if (tid == 0) cell_start[ncell] = (int)tot;
+        __syncthreads();
+        if (s_chunk[0] == 0) {
+            // the usual frame: no cell holds more than kGridSmallCell keypoints.  Unordered placement through the LDS cursors, then every
+            // thread puts the (few) items of each of its cells into index order = the order of the reference's push_back loop (src/Frame.cc:488-503)
+            for (int i = tid; i < N; i += 256) {
+                const int c = cell_of[i];
+                if (c >= 0) cell_items[atomicAdd(&s_hist[c], 1)] = i;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
+                const int st = ex + loc[k], cnt = s_hist[tid * kPer + k] - st;
+                for (int a2 = 1; a2 < cnt; a2++) {                // insertion sort of <= kGridSmallCell indices
+                    const int v = cell_items[st + a2];
+                    int j = a2 - 1;
+                    while (j >= 0 && cell_items[st + j] > v) { cell_items[st + j + 1] = cell_items[st + j]; j--; }
+                    cell_items[st + j + 1] = v;
+                }
+            }
+            return;
+        }
     }
-    if (tid == 0) cell_start[ncell] = run;
     __syncthreads();
     // stable placement, 256 keypoints at a time in index order
     for (int i0 = 0; i0 < N; i0 += 256) {
