@@ -21,32 +21,48 @@ namespace orbx {
 constexpr int kGridSmallCell = 16;                 // k_grid_build: cells up to this size are ordered by their own thread
 constexpr int kGridCols = 64, kGridRows = 48;   // FRAME_GRID_COLS / FRAME_GRID_ROWS, include/Frame.h:44-45
 
-// grid (1), 256 threads.  cell_of: scratch [N] ints.  cell_start: [64*48+1].  Cell id = ix*48 + iy.
-__global__ void __launch_bounds__(256) k_grid_build(const KeyPointRec* __restrict__ kps, int N, GridParams g,
-                                                    int* __restrict__ cell_of, int* __restrict__ cell_start,
-                                                    int* __restrict__ cell_items) {
+// grid (1), kGridThreads threads.  cell_of: scratch [N] ints.  cell_start: [64*48+1].  Cell id = ix*48 + iy.
+// One workgroup because the histogram and the cursors live in LDS; 1024 threads so that a frame's keypoints take one trip per step (the
+// kernel is a chain of dependent round trips, not work).
+__global__ void __launch_bounds__(kGridThreads) k_grid_build(const KeyPointRec* __restrict__ kps, int N, GridParams g,
+                                                             int* __restrict__ cell_of, int* __restrict__ cell_start,
+                                                             int* __restrict__ cell_items) {
     __shared__ int s_hist[kGridCols * kGridRows];
     __shared__ int s_chunk[256];
     __shared__ unsigned long long s_scan[20];
     const int tid = (int)threadIdx.x;
-    const int ncell = kGridCols * kGridRows;
-    for (int c = tid; c < ncell; c += 256) s_hist[c] = 0;
+    constexpr int ncell = kGridCols * kGridRows, NT = kGridThreads, kKeep = 4;
+    for (int c = tid; c < ncell; c += NT) s_hist[c] = 0;
     if (tid == 0) s_chunk[0] = 0;                                 // set when a cell is crowded (the ordered chunk placement below then runs)
     __syncthreads();
-    for (int i = tid; i < N; i += 256) {
-        const KeyPointRec k = kps[i];
-        const int px = (int)roundf(__fmul_rn(__fsub_rn(k.x, g.min_x), g.gw_inv));
-        const int py = (int)roundf(__fmul_rn(__fsub_rn(k.y, g.min_y), g.gh_inv));
+    int myc[kKeep];                                               // cells of this thread's first keypoints (tid, tid + NT, ..)
+#pragma unroll
+    for (int k = 0; k < kKeep; k++) myc[k] = -1;
+#pragma unroll
+    for (int k = 0; k < kKeep; k++) {
+        const int i = tid + k * NT;
+        if (i < N) {
+            const KeyPointRec kp = kps[i];
+            const int px = (int)roundf(__fmul_rn(__fsub_rn(kp.x, g.min_x), g.gw_inv));
+            const int py = (int)roundf(__fmul_rn(__fsub_rn(kp.y, g.min_y), g.gh_inv));
+            if (!(px < 0 || px >= kGridCols || py < 0 || py >= kGridRows)) { myc[k] = px * kGridRows + py; atomicAdd(&s_hist[myc[k]], 1); }
+            cell_of[i] = myc[k];
+        }
+    }
+    for (int i = tid + kKeep * NT; i < N; i += NT) {
+        const KeyPointRec kp = kps[i];
+        const int px = (int)roundf(__fmul_rn(__fsub_rn(kp.x, g.min_x), g.gw_inv));
+        const int py = (int)roundf(__fmul_rn(__fsub_rn(kp.y, g.min_y), g.gh_inv));
         int c = -1;
         if (!(px < 0 || px >= kGridCols || py < 0 || py >= kGridRows)) { c = px * kGridRows + py; atomicAdd(&s_hist[c], 1); }
         cell_of[i] = c;
     }
     __syncthreads();
     // exclusive scan of the histogram -> cell_start; s_hist becomes the running cursor of each cell
-    // (a thread takes ncell / 256 = 12 consecutive cells, so one workgroup scan does)
+    // (a thread takes ncell / NT = 3 consecutive cells, so one workgroup scan does)
     {
-        constexpr int kPer = kGridCols * kGridRows / 256;
-        static_assert(kPer * 256 == kGridCols * kGridRows, "grid cells per thread");
+        constexpr int kPer = ncell / NT;
+        static_assert(kPer * NT == ncell, "grid cells per thread");
         int loc[kPer], sum = 0, mx = 0;
 #pragma unroll
         for (int k = 0; k < kPer; k++) { const int v = s_hist[tid * kPer + k]; loc[k] = sum; sum += v; mx = v > mx ? v : mx; }
@@ -60,7 +76,9 @@ __global__ void __launch_bounds__(256) k_grid_build(const KeyPointRec* __restric
         if (s_chunk[0] == 0) {
             // the usual frame: no cell holds more than kGridSmallCell keypoints.  Unordered placement through the LDS cursors, then every
             // thread puts the (few) items of each of its cells into index order = the order of the reference's push_back loop (src/Frame.cc:488-503)
-            for (int i = tid; i < N; i += 256) {
+#pragma unroll
+            for (int k = 0; k < kKeep; k++) if (myc[k] >= 0) cell_items[atomicAdd(&s_hist[myc[k]], 1)] = tid + k * NT;
+            for (int i = tid + kKeep * NT; i < N; i += NT) {
                 const int c = cell_of[i];
                 if (c >= 0) cell_items[atomicAdd(&s_hist[c], 1)] = i;
             }
@@ -79,11 +97,11 @@ __global__ void __launch_bounds__(256) k_grid_build(const KeyPointRec* __restric
         }
     }
     __syncthreads();
-    // stable placement, 256 keypoints at a time in index order
+    // crowded cells: stable placement, 256 keypoints at a time in index order (the first four waves work, the others keep the barriers company)
     for (int i0 = 0; i0 < N; i0 += 256) {
         const int i = i0 + tid;
-        const int c = i < N ? cell_of[i] : -1;
-        s_chunk[tid] = c;
+        const int c = (tid < 256 && i < N) ? cell_of[i] : -1;
+        if (tid < 256) s_chunk[tid] = c;
         __syncthreads();
         int before = 0, after = 0, cur = 0;
         if (c >= 0) {

@@ -23,7 +23,10 @@ __global__ void k_fast_cells(const LevelInfo* __restrict__ lv, const CellInfo* _
                              uint32_t* __restrict__ slots, size_t slots_stride, int* __restrict__ cell_count,
                              int tile_bytes, int list_bytes);
 constexpr int kResizeRows = 8;         // output rows per k_resize tile (256 columns wide)
-constexpr int kBlurRows = 16;          // output rows per k_blur thread (a block covers 256 columns x 4 * kBlurRows rows)
+#ifndef ORBX_BLUR_ROWS
+#define ORBX_BLUR_ROWS 16
+#endif
+constexpr int kBlurRows = ORBX_BLUR_ROWS;   // output rows per k_blur thread (a block covers 256 columns x 4 * kBlurRows rows)
 __global__ void k_blur(const LevelInfo* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,
                        uint8_t* __restrict__ blur, size_t pyr_stride, BlurTaps taps, BlurTiles tiles);
 constexpr int kQuadtreeThreads = 1024; // workgroup size of k_quadtree; a level uses its first LevelInfo::qt_threads threads
@@ -65,6 +68,7 @@ __global__ void k_knn2(const unsigned long long* __restrict__ descQ, const int* 
                        int cap, int* __restrict__ idx0, int* __restrict__ dist0, int* __restrict__ idx1,
                        int* __restrict__ dist1, uint8_t* __restrict__ ratio_ok);
 
+constexpr int kGridThreads = 1024;     // workgroup size of k_grid_build (3 grid cells per thread)
 __global__ void k_grid_build(const KeyPointRec* __restrict__ kps, int N, GridParams g, int* __restrict__ cell_of,
                              int* __restrict__ cell_start, int* __restrict__ cell_items);
 constexpr int kAreaWaves = 16;         // queries (waves) per k_area_search workgroup
