@@ -250,6 +250,18 @@ int orbm_search_local_points(orbx_extractor* h, const OrbmFrameView* F, const Or
                              float viewing_cos_limit, float th, int far_points, float th_far, float nnratio, const OrbmTrackOut* out,
                              int* assigned, int* nmatches);
 
+/* The same with the map points resident on the device: Tracking::SearchLocalPoints visits the local map (2 000 - 6 000 points,
+ * Tracking::UpdateLocalPoints, src/Tracking.cc:4070-4110) every frame, and a map point's position, normal, distance limits and descriptor
+ * change only when LocalMapping / LoopClosing touch it.  orbm_points_create uploads those fields of a point set once (is_bad / has_obs of the
+ * view are ignored: they are call-time state); orbm_search_local_points_resident then moves the frame, the two flag arrays (NULL: no point bad /
+ * every point observed) and the results only.  Same results as orbm_search_local_points. */
+typedef struct orbm_points orbm_points;
+int orbm_points_create(orbx_extractor* h, const OrbmWorldPointView* points, orbm_points** out);
+void orbm_points_destroy(orbm_points* p);
+int orbm_search_local_points_resident(orbx_extractor* h, const OrbmFrameView* F, const OrbmFrustumView* frame, const orbm_points* points,
+                                      const uint8_t* is_bad, const uint8_t* has_obs, float viewing_cos_limit, float th, int far_points, float th_far,
+                                      float nnratio, const OrbmTrackOut* out, int* assigned, int* nmatches);
+
 /* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBmatcher.cc:1950-2184).
  * forward/backward = bForward/bBackward (:1973-1975, computed from the two poses by the caller).
  * assigned[i] = index into LastFrame of the point written to CurrentFrame.mvpMapPoints[i]; -1 untouched;

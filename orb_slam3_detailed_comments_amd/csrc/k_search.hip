@@ -233,8 +233,9 @@ __global__ void __launch_bounds__(64 * kAreaWaves) k_area_search(const AreaQuery
 __global__ void __launch_bounds__(256) k_frustum(FrustumParams F, int M, const float* __restrict__ pos, const float* __restrict__ normal,
                                                  const float* __restrict__ min_dist, const float* __restrict__ max_dist, const uint8_t* __restrict__ is_bad,
                                                  uint8_t* __restrict__ in_view, float* __restrict__ track /* [6][M]: x, y, xr, depth, cos, - */,
-                                                 int* __restrict__ scale_level, AreaQuery* __restrict__ queries) {
+                                                 int* __restrict__ scale_level, AreaQuery* __restrict__ queries, int* __restrict__ zero4) {
     const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (zero4 && i < 4) zero4[i] = 0;                             // the pool counter of the window search that follows (saves a fill launch)
     if (i >= M) return;
     const float P0 = pos[3 * i], P1 = pos[3 * i + 1], P2 = pos[3 * i + 2];
     bool ok = true;

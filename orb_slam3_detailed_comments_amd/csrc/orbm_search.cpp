@@ -274,7 +274,7 @@ int enqueue_frustum(orbx_extractor* h, const OrbmFrustumView* V, const OrbmWorld
     if (M > 0) {
         dim3 grid((M + 255) / 256, 1, 1), blk(256, 1, 1);
         ORBX_LAUNCH(k_frustum, grid, blk, 0, h->s0, F, M, (const float*)(di + op), (const float*)(di + on), (const float*)(di + omn), (const float*)(di + omx),
-                    (const uint8_t*)(di + ob), out->in_view, out->track, out->level, out->queries);
+                    (const uint8_t*)(di + ob), out->in_view, out->track, out->level, out->queries, (int*)nullptr);
     }
     return ORBX_OK;
 }
@@ -311,48 +311,132 @@ int orbm_is_in_frustum(orbx_extractor* h, const OrbmFrustumView* V, const OrbmWo
     return fetch_frustum(h, P->M, D, out);
 }
 
-// Tracking::SearchLocalPoints' device part (src/Tracking.cc:4009-4067): Frame::isInFrustum for every candidate map point, then
-// ORBmatcher::SearchByProjection(Frame, MapPoints, th, bFarPoints, thFarPoints) on the points in view - the window queries never leave the device.
-int orbm_search_local_points(orbx_extractor* h, const OrbmFrameView* F, const OrbmFrustumView* V, const OrbmWorldPointView* P, float cos_limit, float th,
-                             int far_points, float th_far, float nnratio, const OrbmTrackOut* out, int* assigned, int* nmatches_out) {
-    if (!h || !F || !V || !P || !assigned) return fail(ORBX_E_ARG, "null");
+// ---- map points that stay on the device (the local map changes slowly; Tracking::SearchLocalPoints visits it every frame) ----
+struct orbm_points {
+    int device = 0, M = 0;
+    uint8_t* dmem = nullptr;
+    const unsigned long long* desc = nullptr; const float *pos = nullptr, *normal = nullptr, *min_d = nullptr, *max_d = nullptr;
+};
+
+int orbm_points_create(orbx_extractor* h, const OrbmWorldPointView* P, orbm_points** out) {
+    if (!h || !P || !out || P->M < 0 || (P->M > 0 && (!P->pos || !P->normal || !P->min_distance || !P->max_distance || !P->desc))) return fail(ORBX_E_ARG, "bad map point view");
     rt::set_device(h->device);
-#ifdef ORBX_TRACE_TIMING
-    timespec ts_; auto now_us = [&]() { clock_gettime(CLOCK_MONOTONIC, &ts_); return ts_.tv_sec * 1e6 + ts_.tv_nsec * 1e-3; };
-    const double t0 = now_us();
-#endif
-    DeviceFrame D;
-    int rc = upload_frame(h, F, &D); if (rc) return rc;
-#ifdef ORBX_TRACE_TIMING
-    const double t1 = now_us();
-#endif
-    FrustumDev Q;
-    rc = enqueue_frustum(h, V, P, cos_limit, true, th, far_points, th_far, &Q); if (rc) return rc;
-#ifdef ORBX_TRACE_TIMING
-    const double t2 = now_us();
-#endif
-    const int M = P->M, N = F->N;
-    Csr c;
-    const uint8_t* track_blk = nullptr;
-    rc = run_area_search_dev(h, D, M, Q.queries, Q.qdesc, &c, Q.track, out ? track_block_bytes(M) : 0, &track_blk); if (rc) return rc;
-#ifdef ORBX_TRACE_TIMING
-    const double t3 = now_us();
-#endif
-    if (track_blk) scatter_track(track_blk, M, out);
-#ifdef ORBX_TRACE_TIMING
-    const double t4 = now_us();
-    struct Fin { double t0, t1, t2, t3, t4; decltype(now_us)& f; size_t ents; ~Fin() { const double t5 = f(); fprintf(stderr, "[search_local_points] frame upload %.1f  frustum enqueue %.1f  area search + wait + copy-out %.1f  scatter %.1f  replay %.1f us (%zu entries)\n", t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, ents); } } fin{t0, t1, t2, t3, t4, now_us, c.ent.size() / 2};
-#endif
-    // ---- sequential replay of src/ORBmatcher.cc:62-166 (a query without candidates - not in view, far, bad - has count 0) ----
-    std::vector<uint8_t> occ(N > 0 ? N : 1, 0);
-    if (F->occupied) memcpy(occ.data(), F->occupied, N);
+    const size_t M1 = P->M > 0 ? P->M : 1;
+    const size_t od = 0, op = od + al16(32 * M1), on = op + al16(12 * M1), omn = on + al16(12 * M1), omx = omn + al16(4 * M1), total = omx + al16(4 * M1);
+    std::vector<uint8_t> st(total, 0);
+    if (P->M > 0) {
+        memcpy(&st[od], P->desc, 32 * (size_t)P->M); memcpy(&st[op], P->pos, 12 * (size_t)P->M); memcpy(&st[on], P->normal, 12 * (size_t)P->M);
+        memcpy(&st[omn], P->min_distance, 4 * (size_t)P->M); memcpy(&st[omx], P->max_distance, 4 * (size_t)P->M);
+    }
+    orbm_points* r = new orbm_points();
+    r->device = h->device; r->M = P->M; r->dmem = (uint8_t*)rt::dmalloc(total);
+    if (!r->dmem || rt::copy_h2d(r->dmem, st.data(), total, h->s0) || rt::stream_sync(h->s0)) { rt::dfree(r->dmem); delete r; return fail(ORBX_E_DEVICE, "map point upload failed"); }
+    r->desc = (const unsigned long long*)(r->dmem + od); r->pos = (const float*)(r->dmem + op); r->normal = (const float*)(r->dmem + on);
+    r->min_d = (const float*)(r->dmem + omn); r->max_d = (const float*)(r->dmem + omx);
+    *out = r;
+    return ORBX_OK;
+}
+
+void orbm_points_destroy(orbm_points* p) {
+    if (!p) return;
+    rt::set_device(p->device);
+    rt::dfree(p->dmem);
+    delete p;
+}
+
+namespace {
+// Tracking::SearchLocalPoints' device part (src/Tracking.cc:4009-4067): Frame::isInFrustum for every candidate map point, then
+// ORBmatcher::SearchByProjection(Frame, MapPoints, th, bFarPoints, thFarPoints) on the points in view.  One upload (the frame, the call-time
+// flags and - unless the points are resident - the points), three launches (grid, frustum + window queries, window search), one download
+// (tracking fields, candidate lists), then the ordered replay of src/ORBmatcher.cc:62-166 on the host.
+int search_local_points_core(orbx_extractor* h, const OrbmFrameView* F, const OrbmFrustumView* V, int M, const OrbmWorldPointView* P, const orbm_points* R,
+                             const uint8_t* is_bad, const uint8_t* has_obs, float cos_limit, float th, int far_points, float th_far, float nnratio,
+                             const OrbmTrackOut* out, int* assigned, int* nmatches_out) {
+    if (!F || F->N < 0 || (F->N > 0 && (!F->keys_un || !F->desc))) return fail(ORBX_E_ARG, "bad frame view");
+    if (F->N >= 65535) return fail(ORBX_E_ARG, "too many keypoints");
+    if (!V || V->nlevels < 1 || V->nlevels > kMaxLevels || !V->scale_factors) return fail(ORBX_E_ARG, "bad scale levels");
+    const int N = F->N;
     for (int i = 0; i < N; i++) assigned[i] = -1;
+    if (nmatches_out) *nmatches_out = 0;
+    if (M <= 0) return ORBX_OK;
+    const size_t N1 = N > 0 ? N : 1, M1 = M;
+    // input block: frame [keys | descriptors | uRight] | bad flags | (host points: descriptors | pos | normal | min | max)
+    const size_t okp = 0, odesc = okp + al16(sizeof(KeyPointRec) * N1), our = odesc + al16(32 * N1), ob = our + al16(4 * N1), opd = ob + al16(M1),
+                 opp = opd + (R ? 0 : al16(32 * M1)), opn = opp + (R ? 0 : al16(12 * M1)), opmn = opn + (R ? 0 : al16(12 * M1)), opmx = opmn + (R ? 0 : al16(4 * M1)),
+                 in_total = opmx + (R ? 0 : al16(4 * M1));
+    // output block: [counter 16 | start M | count M] | tracking fields | candidate entries
+    const size_t hdr = al16(16 + 8 * M1), trk = track_block_bytes(M), oent = hdr + trk;
+    const size_t pool = std::max<size_t>(h->area_pool, M1 * 48 + 1024);
+    int e = h->h_packA.ensure(in_total + 16) | h->d_sr[SR_KPS].ensure(in_total + 16) | h->d_sr[SR_QUERY].ensure(sizeof(AreaQuery) * M1 + 16) |
+            h->d_sr[SR_ENTRIES].ensure(oent + pool * 8 + 16) | h->h_out.ensure(oent + pool * 8 + 16);
+    e |= h->d_si[SI_CELLOF].ensure(N + 1) | h->d_si[SI_CELLSTART].ensure(64 * 48 + 2) | h->d_si[SI_CELLITEMS].ensure(N + 1);
+    if (e) return fail(ORBX_E_DEVICE, "upload/allocation failed");
+    h->area_pool = pool;
+    uint8_t* hp = h->h_packA.p;
+    if (N > 0) { memcpy(hp + okp, F->keys_un, sizeof(KeyPointRec) * (size_t)N); memcpy(hp + odesc, F->desc, 32 * (size_t)N); }
+    float* ur = (float*)(hp + our);
+    if (F->u_right) memcpy(ur, F->u_right, sizeof(float) * (size_t)N); else for (size_t i = 0; i < N1; i++) ur[i] = -1.0f;
+    if (is_bad) memcpy(hp + ob, is_bad, M1); else memset(hp + ob, 0, M1);
+    if (!R) {
+        memcpy(hp + opd, P->desc, 32 * M1); memcpy(hp + opp, P->pos, 12 * M1); memcpy(hp + opn, P->normal, 12 * M1);
+        memcpy(hp + opmn, P->min_distance, 4 * M1); memcpy(hp + opmx, P->max_distance, 4 * M1);
+    }
+    if (rt::copy_h2d(h->d_sr[SR_KPS].p, hp, in_total, h->s0)) return fail(ORBX_E_DEVICE, "upload failed");
+    const uint8_t* di = h->d_sr[SR_KPS].p;
+    DeviceFrame D;
+    D.kps = (const KeyPointRec*)(di + okp); D.desc = (const unsigned long long*)(di + odesc); D.ur = (const float*)(di + our);
+    memset(&D.g, 0, sizeof D.g);
+    D.g.min_x = F->min_x; D.g.min_y = F->min_y; D.g.gw_inv = F->grid_w_inv; D.g.gh_inv = F->grid_h_inv;
+    D.cell_start = h->d_si[SI_CELLSTART].p; D.cell_items = h->d_si[SI_CELLITEMS].p;
+    const dim3 one(1, 1, 1), blkg(kGridThreads, 1, 1), blk(256, 1, 1);
+    ORBX_LAUNCH(k_grid_build, one, blkg, 0, h->s0, D.kps, N, D.g, h->d_si[SI_CELLOF].p, h->d_si[SI_CELLSTART].p, h->d_si[SI_CELLITEMS].p);
+    FrustumParams Fp; memset(&Fp, 0, sizeof Fp);
+    memcpy(Fp.Rcw, V->Rcw, sizeof Fp.Rcw); memcpy(Fp.tcw, V->tcw, sizeof Fp.tcw); memcpy(Fp.Ow, V->Ow, sizeof Fp.Ow);
+    memcpy(Fp.cam, V->cam, sizeof Fp.cam); Fp.kb8 = V->camera_type == 1;
+    Fp.min_x = V->min_x; Fp.max_x = V->max_x; Fp.min_y = V->min_y; Fp.max_y = V->max_y; Fp.mbf = V->mbf; Fp.log_scale_factor = V->log_scale_factor; Fp.nlevels = V->nlevels;
+    for (int l = 0; l < V->nlevels; l++) Fp.scale_factors[l] = V->scale_factors[l];
+    Fp.cos_limit = cos_limit; Fp.th = th; Fp.th_far = th_far; Fp.far_points = far_points;
+    uint8_t* dout = h->d_sr[SR_ENTRIES].p;
+    int* d_counter = (int*)dout; int* d_start = (int*)(dout + 16); int* d_count = d_start + M; int2* d_ent = (int2*)(dout + oent);
+    uint8_t* dtrk = dout + hdr;
+    const size_t ol = al16(20 * M1), ov = ol + al16(4 * M1);                        // track block: [track 5 M][level M][in_view M] (scatter_track)
+    AreaQuery* dq = (AreaQuery*)h->d_sr[SR_QUERY].p;
+    const unsigned long long* dqd = R ? R->desc : (const unsigned long long*)(di + opd);
+    {
+        dim3 grid((M + 255) / 256, 1, 1);
+        ORBX_LAUNCH(k_frustum, grid, blk, 0, h->s0, Fp, M, R ? R->pos : (const float*)(di + opp), R ? R->normal : (const float*)(di + opn),
+                    R ? R->min_d : (const float*)(di + opmn), R ? R->max_d : (const float*)(di + opmx), (const uint8_t*)(di + ob),
+                    dtrk + ov, (float*)dtrk, (int*)(dtrk + ol), dq, d_counter);
+    }
+    {
+        dim3 grid((M + kAreaWaves - 1) / kAreaWaves, 1, 1), blka(64 * kAreaWaves, 1, 1);
+        ORBX_LAUNCH(k_area_search, grid, blka, 0, h->s0, (const AreaQuery*)dq, dqd, M, D.kps, D.ur, D.desc, D.g, D.cell_start, D.cell_items, 1, d_counter, (int)pool,
+                    d_start, d_count, d_ent);
+    }
+    const size_t guess = std::min(pool, std::max<size_t>(h->area_last_total + h->area_last_total / 4 + 256, 1024));
+    rt::copy_d2h(h->h_out.p, dout, oent + guess * 8, h->s0);
+    if (rt::stream_sync(h->s0) || rt::check_launch()) return fail(ORBX_E_DEVICE, "local point search failed: %s", rt::last_error());
+    const int total = *(const int*)h->h_out.p;
+    if ((size_t)total > pool) {                                     // pool overflow (the first call of a much denser scene): grow and run again
+        h->area_pool = (size_t)total + 1024;
+        return search_local_points_core(h, F, V, M, P, R, is_bad, has_obs, cos_limit, th, far_points, th_far, nnratio, out, assigned, nmatches_out);
+    }
+    if ((size_t)total > guess) {
+        rt::copy_d2h(h->h_out.p + oent + guess * 8, dout + oent + guess * 8, ((size_t)total - guess) * 8, h->s0);
+        if (rt::stream_sync(h->s0)) return fail(ORBX_E_DEVICE, "local point search download failed: %s", rt::last_error());
+    }
+    h->area_last_total = (size_t)total;
+    scatter_track(h->h_out.p + hdr, M, out);
+    const int* q_start = (const int*)(h->h_out.p + 16); const int* q_count = q_start + M; const int* ent = (const int*)(h->h_out.p + oent);
+    // ---- sequential replay of src/ORBmatcher.cc:62-166 (a query without candidates - not in view, far, bad - has count 0) ----
+    std::vector<uint8_t> occ(N1, 0);
+    if (F->occupied) memcpy(occ.data(), F->occupied, N);
     int nmatches = 0;
     for (int i = 0; i < M; i++) {
-        if (c.count[i] == 0) continue;
+        if (q_count[i] == 0) continue;
         int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
-        for (int k = 0; k < c.count[i]; k++) {
-            const int idx = c.ent[2 * (size_t)(c.start[i] + k)], dl = c.ent[2 * (size_t)(c.start[i] + k) + 1];
+        for (int k = 0; k < q_count[i]; k++) {
+            const int idx = ent[2 * (size_t)(q_start[i] + k)], dl = ent[2 * (size_t)(q_start[i] + k) + 1];
             if (occ[idx]) continue;
             const int dist = dl & 0xFFFF, level = dl >> 16;
             if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = level; bestIdx = idx; }
@@ -362,13 +446,31 @@ int orbm_search_local_points(orbx_extractor* h, const OrbmFrameView* F, const Or
             if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
             if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
                 assigned[bestIdx] = i;
-                occ[bestIdx] = P->has_obs ? P->has_obs[i] : 1;
+                occ[bestIdx] = has_obs ? has_obs[i] : 1;
                 nmatches++;
             }
         }
     }
     if (nmatches_out) *nmatches_out = nmatches;
     return ORBX_OK;
+}
+}  // namespace
+
+int orbm_search_local_points(orbx_extractor* h, const OrbmFrameView* F, const OrbmFrustumView* V, const OrbmWorldPointView* P, float cos_limit, float th,
+                             int far_points, float th_far, float nnratio, const OrbmTrackOut* out, int* assigned, int* nmatches_out) {
+    if (!h || !F || !V || !P || !assigned) return fail(ORBX_E_ARG, "null");
+    if (P->M < 0 || (P->M > 0 && (!P->pos || !P->normal || !P->min_distance || !P->max_distance || !P->desc))) return fail(ORBX_E_ARG, "bad map point view");
+    rt::set_device(h->device);
+    return search_local_points_core(h, F, V, P->M, P, nullptr, P->is_bad, P->has_obs, cos_limit, th, far_points, th_far, nnratio, out, assigned, nmatches_out);
+}
+
+int orbm_search_local_points_resident(orbx_extractor* h, const OrbmFrameView* F, const OrbmFrustumView* V, const orbm_points* points, const uint8_t* is_bad,
+                                      const uint8_t* has_obs, float cos_limit, float th, int far_points, float th_far, float nnratio, const OrbmTrackOut* out,
+                                      int* assigned, int* nmatches_out) {
+    if (!h || !F || !V || !points || !assigned) return fail(ORBX_E_ARG, "null");
+    if (points->device != h->device) return fail(ORBX_E_ARG, "map points live on another device");
+    rt::set_device(h->device);
+    return search_local_points_core(h, F, V, points->M, nullptr, points, is_bad, has_obs, cos_limit, th, far_points, th_far, nnratio, out, assigned, nmatches_out);
 }
 
 int orbm_search_by_projection_frame(orbx_extractor* h, const OrbmFrameView* Cur, const OrbmLastFrameView* Last, float th, int forward, int backward,

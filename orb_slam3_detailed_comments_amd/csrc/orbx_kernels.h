@@ -79,7 +79,7 @@ __global__ void k_area_search(const AreaQuery* __restrict__ queries, const unsig
                               int* __restrict__ q_start, int* __restrict__ q_count, int2* __restrict__ entries);
 __global__ void k_frustum(FrustumParams F, int M, const float* __restrict__ pos, const float* __restrict__ normal, const float* __restrict__ min_dist,
                           const float* __restrict__ max_dist, const uint8_t* __restrict__ is_bad, uint8_t* __restrict__ in_view, float* __restrict__ track,
-                          int* __restrict__ scale_level, AreaQuery* __restrict__ queries);
+                          int* __restrict__ scale_level, AreaQuery* __restrict__ queries, int* __restrict__ zero4);
 __global__ void k_bow_search(const BowItem* __restrict__ items, int nitems, const KeyPointRec* __restrict__ kps1,
                              const unsigned long long* __restrict__ desc1, const float* __restrict__ ur1,
                              const KeyPointRec* __restrict__ kps2, const unsigned long long* __restrict__ desc2,

@@ -261,8 +261,32 @@ class _TrackOut(C.Structure):
                 ("scale_level", C.c_void_p)]
 
 
+class ResidentPoints:
+    """orbm_points: position, normal, distance limits and descriptor of a set of map points, uploaded once (the local map)."""
+
+    def __init__(self, ext, pos, normal, min_distance, max_distance, desc):
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        self._lib = ext._lib
+        pos, normal, mn, mx, d = f32(pos).reshape(-1, 3), f32(normal).reshape(-1, 3), f32(min_distance), f32(max_distance), np.ascontiguousarray(desc, np.uint8)
+        P = _WorldPointView(); P.M = len(pos)
+        P.pos, P.normal, P.min_distance, P.max_distance, P.desc = pos.ctypes.data, normal.ctypes.data, mn.ctypes.data, mx.ctypes.data, d.ctypes.data
+        h = C.c_void_p()
+        self._lib.check(self._lib.L.orbm_points_create(ext._h, C.byref(P), C.byref(h)))
+        self._p, self.M = h, len(pos)
+
+    def close(self):
+        if self._p:
+            self._lib.L.orbm_points_destroy(self._p); self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def SearchLocalPoints(ext, frame, Rcw, tcw, cam, bounds, mbf, scale_factors, pos, normal, min_distance, max_distance, is_bad=None, has_obs=None, desc=None,
-                      viewing_cos_limit=0.5, th=1.0, far_points=False, th_far=50.0, nnratio=0.8, search=True, prepared=False):
+                      viewing_cos_limit=0.5, th=1.0, far_points=False, th_far=50.0, nnratio=0.8, search=True, prepared=False, resident=None):
     """Frame::isInFrustum (src/Frame.cc:667-773) for M map points and, with search=True, ORBmatcher::SearchByProjection(F, points, th, ...)
     (src/ORBmatcher.cc:45-167) on those in view - Tracking::SearchLocalPoints (src/Tracking.cc:4009-4067) on the device.
     cam: (fx, fy, cx, cy) or the 8 Kannala-Brandt parameters; bounds = (min_x, max_x, min_y, max_y); frame: views.frame_view(...).
@@ -298,7 +322,10 @@ def SearchLocalPoints(ext, frame, Rcw, tcw, cam, bounds, mbf, scale_factors, pos
     keep = (V, P, T, sf, pos, normal, mn, mx, bad, obs, d, tr)
 
     def call(_keep=keep):
-        """the C ABI call alone (arguments prebuilt): what a C++ caller pays"""
+        """the C ABI call alone (arguments prebuilt): what a C++ caller pays.  resident: a ResidentPoints made from the same points"""
+        if resident is not None:
+            return L.L.orbm_search_local_points_resident(ext._h, frame.ref(), C.byref(V), resident._p, P.is_bad, P.has_obs, float(viewing_cos_limit), float(th), int(far_points),
+                                                         float(th_far), float(nnratio), C.byref(T), assigned.ctypes.data, C.byref(n))
         return L.L.orbm_search_local_points(ext._h, frame.ref(), C.byref(V), C.byref(P), float(viewing_cos_limit), float(th), int(far_points), float(th_far), float(nnratio),
                                             C.byref(T), assigned.ctypes.data, C.byref(n))
     if prepared:

@@ -60,6 +60,7 @@ def _check(lib, seeds, npts=5000):
         fv = views.frame_view(kL, dL, sfs, w, h, u_right=u[0, :F.N], mbf=BF)
         Rcw = _rot(0.02, -0.03, 0.01); tcw = np.array([0.3, -0.1, 0.25], np.float32)
         pos, normal, mind, maxd, bad, obs, desc = _scene(F, rng, Rcw, tcw, npts)
+        rp = M.ResidentPoints(ex, pos, normal, mind, maxd, desc)
         for th, far in ((1.0, False), (3.0, True)):
             ref_tr, ref_as, ref_n = F.search_local_points(Rcw, tcw, pos, normal, mind, maxd, bad, obs, desc, 0.5, True, th, far, 9.0, 0.8)
             tr, asg, n = M.SearchLocalPoints(ex, fv, Rcw, tcw, (FX, FY, CX, CY), (0.0, float(w), 0.0, float(h)), BF, sfs, pos, normal, mind, maxd, bad, obs, desc,
@@ -74,10 +75,14 @@ def _check(lib, seeds, npts=5000):
                 assert tr[k][inv].tobytes() == ref_tr[k][inv].tobytes(), k
             assert np.array_equal(tr["scale_level"][inv], ref_tr["scale_level"][inv]), "mnTrackScaleLevel"
             assert n == ref_n and ref_n > npts // 10 and np.array_equal(asg, ref_as), "SearchByProjection assignment differs (%d vs %d matches)" % (n, ref_n)
+            # the same with the points resident on the device (orbm_points): only the frame and the flags travel
+            tr3, asg3, n3 = M.SearchLocalPoints(ex, fv, Rcw, tcw, (FX, FY, CX, CY), (0.0, float(w), 0.0, float(h)), BF, sfs, pos, normal, mind, maxd, bad, obs, desc,
+                                                0.5, th, far, 9.0, 0.8, resident=rp)
+            assert n3 == n and np.array_equal(asg3, asg) and all(tr3[k].tobytes() == tr[k].tobytes() for k in tr), "resident points"
             # the producer alone
             tr2, _, _ = M.SearchLocalPoints(ex, fv, Rcw, tcw, (FX, FY, CX, CY), (0.0, float(w), 0.0, float(h)), BF, sfs, pos, normal, mind, maxd, search=False)
             assert np.array_equal(tr2["in_view"], tr["in_view"]) and tr2["proj_x"].tobytes() == tr["proj_x"].tobytes()
-        ex.close()
+        rp.close(); ex.close()
 
 
 def test_local_points_emulated(emu_lib):

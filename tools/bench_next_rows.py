@@ -119,8 +119,12 @@ def main():
         c = lambda: RF.search_local_points(Rcw, tcw, *sp, 0.5, True, 3.0, False, 50.0, 0.8)
         same = np.array_equal(g()[1], c()[1])
         graw = M.SearchLocalPoints(ex4, fv4, Rcw, tcw, (tlp.FX, tlp.FY, tlp.CX, tlp.CY), (0.0, 640.0, 0.0, 480.0), tlp.BF, sfs, *sp, 0.5, 3.0, False, 50.0, 0.8, prepared=True)
+        rp = M.ResidentPoints(ex4, sp[0], sp[1], sp[2], sp[3], sp[6])
+        gres = M.SearchLocalPoints(ex4, fv4, Rcw, tcw, (tlp.FX, tlp.FY, tlp.CX, tlp.CY), (0.0, 640.0, 0.0, 480.0), tlp.BF, sfs, *sp, 0.5, 3.0, False, 50.0, 0.8, prepared=True, resident=rp)
+        same_res = np.array_equal(M.SearchLocalPoints(ex4, fv4, Rcw, tcw, (tlp.FX, tlp.FY, tlp.CX, tlp.CY), (0.0, 640.0, 0.0, 480.0), tlp.BF, sfs, *sp, 0.5, 3.0, False, 50.0, 0.8, resident=rp)[1], c()[1])
         out["Tracking::SearchLocalPoints: isInFrustum + SearchByProjection, 5000 map points"] = {"gpu_ms": round(best(g, 5), 3), "gpu_ms_c_abi": round(best(graw, 10), 3),
-                                                                                                  "cpu_reference_ms": round(best(c, 2), 3), "identical": bool(same)}
+                                                                                                  "gpu_ms_c_abi_resident_points": round(best(gres, 10), 3),
+                                                                                                  "cpu_reference_ms": round(best(c, 2), 3), "identical": bool(same and same_res)}
     # vocabulary transform: k=10, L=5 (111 110 nodes); 128 extracted EuRoC-size images, descriptors resident on the device
     tmp = tempfile.mkdtemp()
     header, parent, leaf, vdesc, weight = vs.make_vocabulary(rng, 10, 5)
