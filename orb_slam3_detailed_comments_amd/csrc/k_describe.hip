@@ -108,11 +108,13 @@ __global__ void __launch_bounds__(256) k_layout(const LevelInfo* __restrict__ lv
 //      per lane, instead of 64-fold redundantly per keypoint
 //   3  steered BRIEF, again one keypoint at a time with all lanes (4 tests per lane, 4 ballots = 4 descriptor words)
 //   4  lane k writes the record of keypoint k
-constexpr int kKpPerWave = 8;
+constexpr int kKpPerWave = 8;                       // large batches; small ones use kKpPerWaveSmall (more, shorter waves: latency)
 // window of the steered-BRIEF samples: rows / columns -18 .. +18 (the pattern's radius is 18.4), 10 dwords per row
 constexpr int kWinR = 18, kWinRows = 2 * kWinR + 1, kWinDw = 10, kWinTrips = (kWinRows * kWinDw + 63) / 64;
 static_assert(kKpPerWave == kKpPerWaveDecl, "orbx_kernels.h out of date");
-__global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restrict__ lv, int nlevels,
+constexpr int kKpPerWaveSmall = kKpPerWaveSmallDecl;
+template <int KPW>
+__device__ __forceinline__ void orient_brief_impl(const LevelInfo* __restrict__ lv, int nlevels,
                                                       const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t pyr_stride,
                                                       const uint32_t* __restrict__ lvl_keys, int kp_total_cap,
                                                       const int* __restrict__ lvl_count, const int* __restrict__ final_idx,
@@ -127,10 +129,10 @@ __global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restric
     const int b = 8 * (id / (8 * nx)) + (id & 7), gx = (id >> 3) % nx;
     if (b >= B) return;
     const int lane = lane_id();
-    const int slot0 = (gx * 4 + (int)(threadIdx.x >> 6)) * kKpPerWave;
+    const int slot0 = (gx * 4 + (int)(threadIdx.x >> 6)) * KPW;
     if (slot0 >= kp_total_cap) return;
-    // ---- 1a: per-lane keypoint state (lanes >= kKpPerWave mirror lane 0 and are never read) ----
-    const int myslot = slot0 + (lane < kKpPerWave ? lane : 0);
+    // ---- 1a: per-lane keypoint state (lanes >= KPW mirror lane 0 and are never read) ----
+    const int myslot = slot0 + (lane < KPW ? lane : 0);
     int my_valid = 0, my_level = 0, my_pitch = 0, my_fi = 0;
     uint32_t my_key = 0;
     long long my_off = 0;                                   // byte offset of the keypoint centre inside the pyramid / blur block
@@ -145,7 +147,7 @@ __global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restric
             my_fi = final_idx[(size_t)b * kp_total_cap + myslot];
         }
     }
-    const unsigned long long vmask = __ballot(my_valid && lane < kKpPerWave);
+    const unsigned long long vmask = __ballot(my_valid && lane < KPW);
     if (vmask == 0ull) return;
     const uint8_t* raw0 = pyr + (size_t)b * pyr_stride;
     const uint8_t* blur0 = blur + (size_t)b * pyr_stride;
@@ -171,7 +173,7 @@ __global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restric
         wu4[trip] = pu; wv4[trip] = pv; on4[trip] = po;
     }
     int my_m10 = 0, my_m01 = 0;
-    for (int k = 0; k < kKpPerWave; k++) {
+    for (int k = 0; k < KPW; k++) {
         if (!((vmask >> k) & 1ull)) continue;               // wave-uniform
         const int pitch = ORBX_READLANE(my_pitch, k);
         const uint8_t* raw = raw0 + readlane_i64(my_off, k) + (-kHalfPatch + 4 * cg);
@@ -203,7 +205,7 @@ __global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restric
     // window into its LDS slice with six row-coalesced dword loads per lane-trip (lanes of a row read 40 contiguous bytes) and then picks
     // the samples out of LDS: 512 scattered single-byte gathers from global memory per keypoint were what kept the texture path busy.
     uint8_t* win = s_win[threadIdx.x >> 6];
-    for (int k = 0; k < kKpPerWave; k++) {
+    for (int k = 0; k < KPW; k++) {
         if (!((vmask >> k) & 1ull)) continue;
         const int pitch = ORBX_READLANE(my_pitch, k);
         const uint8_t* ctr = blur0 + readlane_i64(my_off, k);
@@ -238,7 +240,7 @@ __global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restric
         if (lane < 4) out_desc[((size_t)b * kp_total_cap + fi) * 4 + lane] = mine;
     }
     // ---- 4: records ----
-    if (lane < kKpPerWave && my_valid) {
+    if (lane < KPW && my_valid) {
         const LevelInfo L = lv[my_level];
         KeyPointRec k;
         float xf = (float)(key_x(my_key) + kBorder), yf = (float)(key_y(my_key) + kBorder);
@@ -252,6 +254,24 @@ __global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restric
         int4 aux; aux.x = (int)floorf(__fsub_rn(yf, r)); aux.y = (int)ceilf(__fadd_rn(yf, r)); aux.z = __float_as_int(xf); aux.w = my_level;
         out_aux[(size_t)b * kp_total_cap + my_fi] = aux;
     }
+}
+
+__global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restrict__ lv, int nlevels,
+                                                      const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t pyr_stride,
+                                                      const uint32_t* __restrict__ lvl_keys, int kp_total_cap,
+                                                      const int* __restrict__ lvl_count, const int* __restrict__ final_idx,
+                                                      UmaxTab umax, KeyPointRec* __restrict__ out_kps,
+                                                      unsigned long long* __restrict__ out_desc, int4* __restrict__ out_aux, int B, int groups_per_image) {
+    orient_brief_impl<kKpPerWave>(lv, nlevels, pyr, blur, pyr_stride, lvl_keys, kp_total_cap, lvl_count, final_idx, umax, out_kps, out_desc, out_aux, B, groups_per_image);
+}
+// the same with fewer keypoints per wave: four times as many, shorter waves (small batches, where one wave's chain of keypoints is the stage time)
+__global__ void __launch_bounds__(256) k_orient_brief_small(const LevelInfo* __restrict__ lv, int nlevels,
+                                                      const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t pyr_stride,
+                                                      const uint32_t* __restrict__ lvl_keys, int kp_total_cap,
+                                                      const int* __restrict__ lvl_count, const int* __restrict__ final_idx,
+                                                      UmaxTab umax, KeyPointRec* __restrict__ out_kps,
+                                                      unsigned long long* __restrict__ out_desc, int4* __restrict__ out_aux, int B, int groups_per_image) {
+    orient_brief_impl<kKpPerWaveSmall>(lv, nlevels, pyr, blur, pyr_stride, lvl_keys, kp_total_cap, lvl_count, final_idx, umax, out_kps, out_desc, out_aux, B, groups_per_image);
 }
 
 }  // namespace orbx

@@ -332,9 +332,14 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
     rt::stream_wait_event(h->s0, h->ev_join);
     stage_begin(h, ST_DESCRIBE, h->s0);
     {
-        const int gpi = (h->kp_total_cap + 4 * kKpPerWaveDecl - 1) / (4 * kKpPerWaveDecl);
+        const bool small = B <= ORBX_QT_WIDE_BATCH;                 // latency-tuned variant: 2 keypoints per wave instead of 8
+        const int kpw = small ? kKpPerWaveSmallDecl : kKpPerWaveDecl;
+        const int gpi = (h->kp_total_cap + 4 * kpw - 1) / (4 * kpw);
         dim3 grid(gpi * 8 * ((B + 7) / 8), 1, 1);                  // an image's workgroups on one XCD (k_orient_brief)
-        ORBX_LAUNCH(k_orient_brief, grid, blk1, 0, h->s0, (const LevelInfo*)h->d_lv.p, nl, (const uint8_t*)h->d_pyr.p, (const uint8_t*)h->d_blur.p,
+        if (small) ORBX_LAUNCH(k_orient_brief_small, grid, blk1, 0, h->s0, (const LevelInfo*)h->d_lv.p, nl, (const uint8_t*)h->d_pyr.p, (const uint8_t*)h->d_blur.p,
+                    h->pyr_stride, (const uint32_t*)h->d_lvl_keys.p, h->kp_total_cap, (const int*)h->d_lvl_count.p, (const int*)h->d_final_idx.p,
+                    h->umax, h->d_kps.p, h->d_desc.p, (int4*)h->d_aux.p, B, gpi);
+        else ORBX_LAUNCH(k_orient_brief, grid, blk1, 0, h->s0, (const LevelInfo*)h->d_lv.p, nl, (const uint8_t*)h->d_pyr.p, (const uint8_t*)h->d_blur.p,
                     h->pyr_stride, (const uint32_t*)h->d_lvl_keys.p, h->kp_total_cap, (const int*)h->d_lvl_count.p, (const int*)h->d_final_idx.p,
                     h->umax, h->d_kps.p, h->d_desc.p, (int4*)h->d_aux.p, B, gpi);
     }

@@ -40,7 +40,14 @@ __global__ void k_layout(const LevelInfo* __restrict__ lv, int nlevels, const ui
                          int kp_total_cap, const int* __restrict__ lvl_count, int lap0, int lap1,
                          int* __restrict__ final_idx, int* __restrict__ n_out, int* __restrict__ mono_out);
 constexpr int kKpPerWaveDecl = 8;      // must equal kKpPerWave in k_describe.hip
+constexpr int kKpPerWaveSmallDecl = 2; // keypoints per wave of k_orient_brief_small
 __global__ void k_orient_brief(const LevelInfo* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,
+                               const uint8_t* __restrict__ blur, size_t pyr_stride,
+                               const uint32_t* __restrict__ lvl_keys, int kp_total_cap,
+                               const int* __restrict__ lvl_count, const int* __restrict__ final_idx, UmaxTab umax,
+                               KeyPointRec* __restrict__ out_kps, unsigned long long* __restrict__ out_desc, int4* __restrict__ out_aux,
+                               int B, int groups_per_image);
+__global__ void k_orient_brief_small(const LevelInfo* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,
                                const uint8_t* __restrict__ blur, size_t pyr_stride,
                                const uint32_t* __restrict__ lvl_keys, int kp_total_cap,
                                const int* __restrict__ lvl_count, const int* __restrict__ final_idx, UmaxTab umax,
