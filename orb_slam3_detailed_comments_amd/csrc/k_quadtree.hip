@@ -158,7 +158,7 @@ struct QuadCls {    // DivideNode's key -> child test (:651-661)
 
 
 #ifndef ORBX_WAVE_SORT_RANGE
-#define ORBX_WAVE_SORT_RANGE 40
+#define ORBX_WAVE_SORT_RANGE 16
 #endif
 constexpr int kWaveSortRange = ORBX_WAVE_SORT_RANGE;     // ranges longer than this are partitioned by a wave instead of one thread
 
