@@ -414,6 +414,49 @@ __device__ __forceinline__ unsigned long long vkeys_order(uint32_t key, int wcel
     return (ci << 36) | (cj << 24) | ((unsigned long long)y << 12) | (unsigned long long)x;
 }
 
+// One full pass (src/ORBextractor.cc:790-905) over <= 64 nodes whose divisible members all sit at a presorted depth, by one wave: lane i owns
+// node i, child counts come from the bucket offsets, the three prefix sums (non-empty children, children with > 1 key, kept nodes) are
+// wave scans.  Same placement as the workgroup pass: blocks of children in reverse node order, n4..n1 inside a block, kept nodes behind.
+// res: {T, E, K, overflow}.
+__device__ __forceinline__ void solo_full_pass(const QNode* __restrict__ cur, QNode* __restrict__ nxt, unsigned long long* __restrict__ expn, int nnodes,
+                                               int D, const int* __restrict__ bucket_start, int node_cap, int* res) {
+    const int lane = lane_id();
+    QNode nd; nd.x0 = nd.y0 = nd.x1 = nd.y1 = 0; nd.start = 0; nd.cnt_buf = 0; nd.code = 0; nd.depth = 0;
+    int c = 0, cq[4] = {0, 0, 0, 0}, m = 0, e = 0;
+    unsigned long long v = 0;
+    if (lane < nnodes) {
+        nd = cur[lane]; c = node_cnt(nd);
+        if (c > 1) {
+            presorted_child_counts(nd, D, bucket_start, cq);
+            for (int q = 0; q < 4; q++) { m += cq[q] > 0; e += cq[q] > 1; }
+            v = (unsigned long long)m | ((unsigned long long)e << 20);
+        } else v = 1ull << 40;
+    }
+    const unsigned long long incl = wave_incl_scan(v), tot = __shfl(incl, 63), ex = incl - v;
+    const int T = (int)(tot & 0xFFFFF), E = (int)((tot >> 20) & 0xFFFFF), K = (int)(tot >> 40);
+    const int overflow = T + K > node_cap;
+    if (!overflow && lane < nnodes) {
+        if (c > 1) {
+            const int Pm = (int)(ex & 0xFFFFF), Pe = (int)((ex >> 20) & 0xFFFFF);
+            const int newbuf = node_buf(nd);                      // count-only divisions move no key
+            int after = 0, erank = 0;
+            for (int q = 3; q >= 0; q--)
+                if (cq[q] > 0) { nxt[T - Pm - m + after] = make_child(nd, q, cq, newbuf); after++; }
+            for (int q = 0; q < 4; q++) {
+                if (cq[q] > 1) {
+                    int pos_in_block = 0;                         // position of child q inside the block = number of non-empty children with q' > q
+                    for (int q2 = q + 1; q2 < 4; q2++) pos_in_block += cq[q2] > 0;
+                    const int mxx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1);
+                    const int cx0 = (q & 1) ? mxx : (int)nd.x0;
+                    expn[Pe + erank] = ((unsigned long long)cq[q] << 32) | ((unsigned long long)(uint16_t)cx0 << 16) | (unsigned long long)(T - Pm - m + pos_in_block);
+                    erank++;
+                }
+            }
+        } else nxt[T + (int)(ex >> 40)] = nd;
+    }
+    if (lane == 0) { res[0] = T; res[1] = E; res[2] = K; res[3] = overflow; }
+}
+
 // The up-front stable counting sort of a level's keys (bufB -> bufA) by bucket code = xpart[x] + ypart[y]: the keys are cut into nseg
 // contiguous segments of whole 64-key chunks, wave w < nseg owns segment w.  counts[w][b] (CT = uint16_t when the level has < 65536 keys,
 // else uint32_t with fewer segments in the same LDS) first holds the segment's histogram, then the number of keys of bucket b in the
@@ -508,7 +551,7 @@ __global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* 
     // grid (B, nlevels): workgroups are dispatched image-fastest, i.e. every image's level 0 (the longest tree by far) starts first and the
     // short trees of the small levels fill the remaining slots
     const int level = (int)blockIdx.y, b = (int)blockIdx.x;
-    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const LevelInfo L = lv[level];
     // wide: the large levels get L.qt_threads threads (small batches: the latency of one tree is what counts); otherwise every level runs on
     // four waves, which packs more trees on a CU (large batches)
@@ -622,9 +665,19 @@ __global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* 
     unsigned long long* expc = exp0; unsigned long long* expn = exp1;
     bool finish = (n == 0);
     int overflow = 0;
+    int passno = 0;
     while (!finish) {
         const int prevSize = nnodes;
+        int T = 0, E = 0, K = 0;
         // ---- full pass: divide every node with more than one key (:790-905) ----
+        // The first passes of a level - few nodes, every divisible node at depth passno < D, so that child counts are differences of bucket
+        // offsets and no key moves - are run by ONE wave with wave scans: a workgroup pass costs eight barriers for a microsecond of work.
+        if (nnodes <= 64 && passno < D) {
+            int* res = s_i + 72 + 4 * (passno & 1);
+            if (wave == 0) solo_full_pass(cur, nxt, expn, nnodes, D, bucket_start, node_cap, res);
+            __syncthreads();
+            T = res[0]; E = res[1]; K = res[2]; overflow = res[3];
+        } else {
         // presorted depths: child counts come from the bucket offsets; deeper: big spans are partitioned by the whole
         // workgroup one after another, small spans by one wave each
         // (which kinds of deep nodes exist is found on the way: most passes of a level move no key at all and skip the partition loops)
@@ -660,7 +713,6 @@ __global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* 
         if (kinds & kDeepSmall) wave_partition_many(nnodes, IdentityIdx(), cur, bufA, bufB, childcnt, D, NW);
         __syncthreads();
         if (tid == 0) *s_kinds = 0;
-        int T = 0, E = 0, K = 0;
         {
             // exclusive scans over the list of (m = non-empty children, e = children with >1 key, k = kept)
             unsigned long long run = 0, total_all = 0;
@@ -733,8 +785,10 @@ __global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* 
                 }
             }
         }
+        }
         __syncthreads();
         if (overflow) break;
+        passno++;
         nnodes = T + K;
         int nexp = E;
         { QNode* t = cur; cur = nxt; nxt = t; }
