@@ -458,42 +458,21 @@ __device__ __forceinline__ void solo_full_pass(const QNode* __restrict__ cur, QN
 }
 
 // The up-front stable counting sort of a level's keys (bufB -> bufA) by bucket code = xpart[x] + ypart[y]: the keys are cut into nseg
-// contiguous segments of whole 64-key chunks, wave w < nseg owns segment w.  counts[w][b] (CT = uint16_t when the level has < 65536 keys,
-// else uint32_t with fewer segments in the same LDS) first holds the segment's histogram, then the number of keys of bucket b in the
-// segments before w, i.e. the wave's cursor relative to bucket_start[b].
+// contiguous segments of `seg` keys (whole 64-key chunks), wave w < nseg owns segment w.  counts[w][b] (CT = uint16_t when the level has
+// < 65536 keys, else uint32_t with fewer segments in the same LDS) comes in as the segment's histogram - counted by the gather with LDS
+// atomics, the order of the counts does not matter - and becomes the number of keys of bucket b in the segments before w, i.e. the wave's
+// cursor relative to bucket_start[b].  The scatter finds the lanes of a 64-key chunk that share a bucket with a bit-wise match (ballots):
+// rank inside the group = number of lower lanes in it.
 template <typename CT>
-__device__ __forceinline__ void presort_keys(const uint32_t* __restrict__ bufB, uint32_t* __restrict__ bufA, int n, int NB, int nseg, CT* counts,
+__device__ __forceinline__ void presort_keys(const uint32_t* __restrict__ bufB, uint32_t* __restrict__ bufA, int n, int NB, int nseg, int seg, CT* counts,
                                              int* bucket_start, const uint16_t* xpart, const uint16_t* ypart, unsigned long long* s_scan, int NT) {
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < nseg * NB; i += NT) counts[i] = 0;
-    __syncthreads();
-    const int seg = ((n + 64 * nseg - 1) / (64 * nseg)) << 6;
     const int beg = imin(n, wave * seg), end = wave < nseg ? imin(n, beg + seg) : beg;
     CT* mycount = counts + (wave < nseg ? wave : 0) * NB;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int nbits = 0;
     while ((1 << nbits) < NB) nbits++;
-    // histogram: lanes of a 64-key chunk that share a bucket are found with a bit-wise match (ballots) and the highest
-    // lane of each group adds the group size once — neighbouring keys usually share a bucket, so per-lane LDS atomics
-    // would serialise.  Four chunks per trip keep four key loads in flight.
-    for (int i0 = beg; i0 < end; i0 += 256) {
-        uint32_t key[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u + lane; key[u] = i < end ? bufB[i] : 0u; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const bool in = i0 + 64 * u + lane < end;
-            const uint32_t code = in ? ((uint32_t)xpart[key_x(key[u])] + (uint32_t)ypart[key_y(key[u])]) : 0xFFFFFFFFu;
-            unsigned long long same = __ballot(in);
-            for (int bit = 0; bit < nbits; bit++) {
-                const unsigned long long bb = __ballot((code >> bit) & 1u);
-                same &= ((code >> bit) & 1u) ? bb : ~bb;
-            }
-            if (in && (same >> lane) <= 1ull) mycount[code] = (CT)(mycount[code] + __popcll(same));
-            ORBX_WAVE_SYNC();
-        }
-    }
-    __syncthreads();
+    __syncthreads();                                               // the histogram (counted by the gather) is complete
     // exclusive scan over buckets of the totals
     int run = 0;
     for (int b0 = 0; b0 < NB; b0 += NT) {
@@ -583,40 +562,11 @@ __global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* 
     const int* ccount = cell_count + (size_t)b * ncells + L.cell_begin;
     const uint32_t* slot_base = slots + (size_t)b * slots_stride;
 
-    // ---- P0: gather the level's candidates in the reference order (cells row-major) into bufB ----
-    // NT / 256 lanes per cell, 256 cells per trip
-    int n = 0;
-    {
-        const int lgt = lgNW - 2, sub = tid & ((1 << lgt) - 1), tpc = 1 << lgt;
-        for (int c0 = 0; c0 < L.cell_count; c0 += 256) {
-            const int c = c0 + (tid >> lgt);
-            const int cnt = c < L.cell_count ? ccount[c] : 0;
-            unsigned long long tot;
-            int pos = n + (int)block_excl_scan_n<unsigned long long>((unsigned long long)(sub == 0 ? cnt : 0), &tot, s_scan, NW);
-            pos = __shfl(pos, lane & ~(tpc - 1));
-            if (cnt > 0) {
-                const uint32_t* sp = slot_base + cells[L.cell_begin + c].slot_off;
-                int k = sub;
-                for (; k + 7 * tpc < cnt; k += 8 * tpc) {          // eight loads in flight
-                    uint32_t v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) v[u] = sp[k + u * tpc];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) bufB[pos + k + u * tpc] = v[u];
-                }
-                for (; k < cnt; k += tpc) bufB[pos + k] = sp[k];
-            }
-            n += (int)tot;
-        }
-    }
-    __syncthreads();
-    QT_STAMP(1)
-    // ---- roots + first D tree levels in ONE stable counting sort (bufB -> bufA) --------------------------------------
-    // bucket(key) = root index (int)(x / hX) (:763), then the D child digits DivideNode (:602-674) would assign on the way
-    // down.  After the sort every node of depth <= D is a contiguous span, its children are laid out n1|n2|n3|n4 and keys keep
-    // their vKeys order inside a bucket (stable), which is exactly the state D partition passes would have produced.
-    // The child digit at every depth is (right ? 1 : 0) + (bottom ? 2 : 0): the x half depends only on x (and the root the x
-    // falls in), the y half only on y, so the bucket code splits into two small LDS tables built once per workgroup.
+    // ---- P0: gather the level's candidates in the reference order (cells row-major) into bufB, and count them per (sort segment, bucket) on
+    // the way (the histogram pass of the counting sort below would read every key again) ----
+    // bucket(key) = root index (int)(x / hX) (:763), then the D child digits DivideNode (:602-674) would assign on the way down.  The child
+    // digit at every depth is (right ? 1 : 0) + (bottom ? 2 : 0): the x half depends only on x (and the root the x falls in), the y half only
+    // on y, so the bucket code splits into two small LDS tables built once per workgroup.
     for (int x = tid; x < L.bw; x += NT) {
         const int r = __float2int_rz(__fdiv_rn((float)x, L.hX));
         int x0 = __float2int_rz(__fmul_rn(L.hX, (float)r)), x1 = __float2int_rz(__fmul_rn(L.hX, (float)(r + 1)));
@@ -639,8 +589,58 @@ __global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* 
         }
         ypart[y] = (uint16_t)code;
     }
-    if (n <= kPresortU16Max) presort_keys<uint16_t>(bufB, bufA, n, NB, imin(NW, counter_bytes >> 1), (uint16_t*)counts, bucket_start, xpart, ypart, s_scan, NT);
-    else presort_keys<uint32_t>(bufB, bufA, n, NB, imin(NW, counter_bytes >> 2), (uint32_t*)counts, bucket_start, xpart, ypart, s_scan, NT);
+    // number of keys first: it decides the counter width and the segment length
+    int n = 0;
+    for (int c0 = 0; c0 < L.cell_count; c0 += NT) {
+        const int c = c0 + tid;
+        unsigned long long tot;
+        (void)block_excl_scan_n<unsigned long long>((unsigned long long)(c < L.cell_count ? ccount[c] : 0), &tot, s_scan, NW);
+        n += (int)tot;
+    }
+    const bool narrow_counters = n <= kPresortU16Max;
+    const int nseg = narrow_counters ? imin(NW, counter_bytes >> 1) : imin(NW, counter_bytes >> 2);
+    const int seg = ((n + 64 * nseg - 1) / (64 * nseg)) << 6;     // keys per sort segment (whole 64-key chunks)
+    for (int i = tid; i < (narrow_counters ? (nseg * NB + 1) >> 1 : nseg * NB); i += NT) counts[i] = 0;
+    __syncthreads();
+    // NT / 256 lanes per cell, 256 cells per trip
+    {
+        const int lgt = lgNW - 2, sub = tid & ((1 << lgt) - 1), tpc = 1 << lgt;
+        int run = 0;
+        for (int c0 = 0; c0 < L.cell_count; c0 += 256) {
+            const int c = c0 + (tid >> lgt);
+            const int cnt = c < L.cell_count ? ccount[c] : 0;
+            unsigned long long tot;
+            int pos = run + (int)block_excl_scan_n<unsigned long long>((unsigned long long)(sub == 0 ? cnt : 0), &tot, s_scan, NW);
+            pos = __shfl(pos, lane & ~(tpc - 1));
+            if (cnt > 0) {
+                const uint32_t* sp = slot_base + cells[L.cell_begin + c].slot_off;
+                int sidx = (pos + sub) / seg, send = (sidx + 1) * seg;       // segment of this lane's first key, and where it ends
+                auto count_key = [&](uint32_t key, int p) {
+                    while (p >= send) { sidx++; send += seg; }
+                    const int slot = sidx * NB + (int)xpart[key_x(key)] + (int)ypart[key_y(key)];
+                    if (narrow_counters) atomicAdd((unsigned*)counts + (slot >> 1), 1u << (16 * (slot & 1)));
+                    else atomicAdd(counts + slot, 1);
+                };
+                int k = sub;
+                for (; k + 7 * tpc < cnt; k += 8 * tpc) {          // eight loads in flight
+                    uint32_t v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) v[u] = sp[k + u * tpc];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { bufB[pos + k + u * tpc] = v[u]; count_key(v[u], pos + k + u * tpc); }
+                }
+                for (; k < cnt; k += tpc) { const uint32_t v = sp[k]; bufB[pos + k] = v; count_key(v, pos + k); }
+            }
+            run += (int)tot;
+        }
+    }
+    __syncthreads();
+    QT_STAMP(1)
+    // ---- roots + first D tree levels in ONE stable counting sort (bufB -> bufA) --------------------------------------
+    // After the sort every node of depth <= D is a contiguous span, its children are laid out n1|n2|n3|n4 and keys keep
+    // their vKeys order inside a bucket (stable), which is exactly the state D partition passes would have produced.
+    if (narrow_counters) presort_keys<uint16_t>(bufB, bufA, n, NB, nseg, seg, (uint16_t*)counts, bucket_start, xpart, ypart, s_scan, NT);
+    else presort_keys<uint32_t>(bufB, bufA, n, NB, nseg, seg, (uint32_t*)counts, bucket_start, xpart, ypart, s_scan, NT);
     __syncthreads();
     int nnodes = 0;
     for (int r = 0; r < L.nini; r++) {

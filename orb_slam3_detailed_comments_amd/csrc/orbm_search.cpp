@@ -63,8 +63,7 @@ int upload_frame(orbx_extractor* h, const OrbmFrameView* F, DeviceFrame* D) {
     D->kps = (const KeyPointRec*)(dp + okp); D->desc = (const unsigned long long*)(dp + odesc); D->ur = (const float*)(dp + our);
     memset(&D->g, 0, sizeof D->g);
     D->g.min_x = F->min_x; D->g.min_y = F->min_y; D->g.gw_inv = F->grid_w_inv; D->g.gh_inv = F->grid_h_inv;
-    dim3 one(1, 1, 1), blk(256, 1, 1);
-    const dim3 blkg(kGridThreads, 1, 1);
+    const dim3 one(1, 1, 1), blkg(kGridThreads, 1, 1);
     ORBX_LAUNCH(k_grid_build, one, blkg, 0, h->s0, D->kps, N, D->g, h->d_si[SI_CELLOF].p, h->d_si[SI_CELLSTART].p, h->d_si[SI_CELLITEMS].p);
     D->cell_start = h->d_si[SI_CELLSTART].p; D->cell_items = h->d_si[SI_CELLITEMS].p;
     return ORBX_OK;
