@@ -194,21 +194,19 @@ __global__ void __launch_bounds__(256) k_stereo_median(const int* __restrict__ n
                                                        const int* __restrict__ sad, int* __restrict__ n_matches) {
     ORBX_DYN_SMEM(smem);
     __shared__ unsigned long long s_scan[20];
-    __shared__ int s_med[1];
+    __shared__ int s_med[2];
     int* list = (int*)smem;
     const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
     const int n = nL[b];
-    int cnt = 0;
-    for (int i0 = 0; i0 < n; i0 += 256) {
-        const int i = i0 + tid;
-        const int s = i < n ? sad[(size_t)b * cap + i] : -1;
-        unsigned long long tot;
-        const int pos = (int)block_excl_scan<unsigned long long>((unsigned long long)(s >= 0), &tot, s_scan);
-        if (s >= 0) list[cnt + pos] = s;
-        cnt += (int)tot;
-    }
-    if (tid == 0) s_med[0] = -1;
+    // the SADs of the matched keypoints, in any order (the median is found by rank, not by position)
+    if (tid == 0) { s_med[0] = -1; s_med[1] = 0; }
     __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int s = sad[(size_t)b * cap + i];
+        if (s >= 0) list[atomicAdd(&s_med[1], 1)] = s;
+    }
+    __syncthreads();
+    const int cnt = s_med[1];
     if (cnt == 0) { if (tid == 0) n_matches[b] = 0; return; }
     const int k = cnt / 2;
     for (int i = tid; i < cnt; i += 256) {

@@ -204,6 +204,7 @@ template <typename T> static inline T atomicOr(T* p, T v) { return __atomic_fetc
 template <typename T> static inline T atomicMax(T* p, T v) { T o = __atomic_load_n(p, __ATOMIC_RELAXED); while (o < v && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return o; }
 template <typename T> static inline T atomicMin(T* p, T v) { T o = __atomic_load_n(p, __ATOMIC_RELAXED); while (o > v && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return o; }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 // IEEE single/double ops with explicit rounding (the emulator is compiled -ffp-contract=off)
 static inline float __fmul_rn(float a, float b) { return a * b; }
