@@ -1,6 +1,6 @@
 """Measurement of the "next" rows of SURVEY.md §8f and the guided searches at BASELINE.json config-4 sizes: wall time of the device path
 (through the C ABI, host views in / results out, i.e. including uploads, the ordered host replay and downloads) next to the CPU
-oracle / reference on the same inputs.  Not the headline benchmark (bench.py); run by tools/gpu_round.sh, results go to profiles/."""
+oracle / reference on the same inputs.  Not the headline benchmark (bench.py); run by tools/gpu_round2.sh, results go to profiles/."""
 import json
 import os
 import sys

@@ -16,7 +16,7 @@ out["_note"] = "bytes per stage launch at 128 images/step = (FETCH_SIZE+WRITE_SI
 json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 print(out)
 
-# optional: VALU wave-instructions per stage launch from the SQ pass (tools/gpu_pmc_round.sh) -> profiles/pmc_valu.json
+# optional: VALU wave-instructions per stage launch from the SQ pass (tools/gpu_round2.sh) -> profiles/pmc_valu.json
 if len(sys.argv) > 5:
     q = json.load(open(sys.argv[4]))["counters"]
     v = {}
