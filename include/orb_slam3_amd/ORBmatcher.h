@@ -64,6 +64,8 @@ public:
             auto it = m.find(pKF);
             if (it != m.end()) return it->second;
             BowStore k; FillBow(*pKF, pKF->N, k);
+            if (pKF->NLeft != -1) FillAllKeys(*pKF, pKF->NLeft, pKF->N, k);      // a rig: mvKeys followed by mvKeysRight (:1136-1141)
+            if (pKF->mpCamera2) k.v.u_right = nullptr;                            // bStereo = !mpCamera2 && mvuRight[idx] >= 0 (:1126)
             orbm_keyframe* r = nullptr;
             {
                 std::lock_guard<std::mutex> lock(Mutex());
@@ -402,7 +404,7 @@ public:
     // The same for every neighbour of pKF1 in one call over device-resident key frames (LocalMapping::CreateNewMapPoints runs
     // SearchForTriangulation against 10-30 neighbours in a row, src/LocalMapping.cc:510-540; what a neighbour contributes - keys, descriptors,
     // mvuRight, mFeatVec - does not change while it lives and is uploaded once, into `cache`).  vvMatchedPairs[j] / the returned counts [j] are
-    // what SearchForTriangulation(pKF1, vpNeighKFs[j], ...) gives.  Pinhole key frames with one camera.
+    // what SearchForTriangulation(pKF1, vpNeighKFs[j], ...) gives (pinhole key frames, one Kannala-Brandt camera, or the Kannala-Brandt rig).
     template <class KeyFrameT>
     std::vector<int> SearchForTriangulation(KeyFrameT* pKF1, const std::vector<KeyFrameT*>& vpNeighKFs, ResidentKeyFrames<KeyFrameT>& cache,
                                             std::vector<std::vector<std::pair<size_t, size_t> > >& vvMatchedPairs, const bool bOnlyStereo, const bool bCoarse = false)
@@ -411,7 +413,9 @@ public:
         vvMatchedPairs.assign(n2, std::vector<std::pair<size_t, size_t> >());
         std::vector<int> counts(n2, 0);
         if (n2 == 0 || N1 == 0) return counts;
+        const bool fisheye = pKF1->mpCamera->GetType() == 1 /* GeometricCamera::CAM_FISHEYE */;
         std::vector<float> f12s((size_t)n2 * 9), eps((size_t)n2 * 2);
+        std::vector<OrbmKB8Pair> kbs(fisheye ? n2 : 0);
         std::vector<orbm_keyframe*> k2(n2);
         std::vector<std::vector<uint8_t> > mp2(n2);
         std::vector<const uint8_t*> mp2p(n2);
@@ -419,8 +423,11 @@ public:
         for (int i = 0; i < N1; i++) mp1[i] = pKF1->GetMapPoint(i) != nullptr;
         for (int j = 0; j < n2; j++) {
             KeyFrameT* pKF2 = vpNeighKFs[j];
-            if (pKF1->mpCamera->GetType() == 1 || pKF1->mpCamera2 || pKF2->mpCamera2) throw std::runtime_error("ORBmatcher (HIP): the resident SearchForTriangulation covers pinhole key frames with one camera");
-            FundamentalAndEpipole(pKF1, pKF2, &f12s[(size_t)j * 9], &eps[(size_t)j * 2]);
+            if (fisheye) { Epipole(pKF1, pKF2, &eps[(size_t)j * 2]); FillKB8Pair(pKF1, pKF2, kbs[j]); }
+            else {
+                if (pKF1->mpCamera2 || pKF2->mpCamera2) throw std::runtime_error("ORBmatcher (HIP): SearchForTriangulation on a rig of pinhole cameras is not supported (the reference only builds rigs of Kannala-Brandt cameras)");
+                FundamentalAndEpipole(pKF1, pKF2, &f12s[(size_t)j * 9], &eps[(size_t)j * 2]);
+            }
             k2[j] = cache.Get(pKF2);
             mp2[j].resize(pKF2->N > 0 ? pKF2->N : 1);
             for (int i = 0; i < pKF2->N; i++) mp2[j][i] = pKF2->GetMapPoint(i) != nullptr;
@@ -430,8 +437,10 @@ public:
         std::vector<int> m12((size_t)n2 * N1, -1);
         {
             std::lock_guard<std::mutex> lock(Mutex());
-            Check(orbm_search_for_triangulation_resident(SharedHandle(), k1, mp1.data(), n2, k2.data(), mp2p.data(), f12s.data(), eps.data(), bOnlyStereo, bCoarse,
-                                                         mbCheckOrientation, m12.data(), counts.data()));
+            if (fisheye) Check(orbm_search_for_triangulation_resident_kb8(SharedHandle(), k1, mp1.data(), n2, k2.data(), mp2p.data(), kbs.data(), eps.data(), bOnlyStereo, bCoarse,
+                                                                          mbCheckOrientation, m12.data(), counts.data()));
+            else Check(orbm_search_for_triangulation_resident(SharedHandle(), k1, mp1.data(), n2, k2.data(), mp2p.data(), f12s.data(), eps.data(), bOnlyStereo, bCoarse,
+                                                              mbCheckOrientation, m12.data(), counts.data()));
         }
         for (int j = 0; j < n2; j++) {
             vvMatchedPairs[j].reserve(counts[j]);
@@ -440,13 +449,12 @@ public:
         return counts;
     }
 
-    // Kannala-Brandt cameras (one fisheye camera, or the two-camera rig): the epipolar test is KannalaBrandt8::epipolarConstrain =
-    // TriangulateMatches > 1e-4 with the relative pose of the pair of cameras the two features belong to (src/ORBmatcher.cc:1067-1083, :1203-1240)
+    // cameras and relative poses of a pair of Kannala-Brandt key frames (src/ORBmatcher.cc:1067-1083)
     template <class KeyFrameT>
-    int SearchForTriangulationFisheye(KeyFrameT *pKF1, KeyFrameT* pKF2, std::vector<std::pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo, const bool bCoarse, float epx, float epy)
+    static void FillKB8Pair(KeyFrameT* pKF1, KeyFrameT* pKF2, OrbmKB8Pair& kb)
     {
         const bool rig = pKF1->mpCamera2 && pKF2->mpCamera2;
-        OrbmKB8Pair kb; memset(&kb, 0, sizeof kb);
+        memset(&kb, 0, sizeof kb);
         kb.nleft1 = rig ? pKF1->NLeft : -1; kb.nleft2 = rig ? pKF2->NLeft : -1;
         for (int i = 0; i < 8; i++) {
             kb.cam1[0][i] = pKF1->mpCamera->getParameter(i); kb.cam2[0][i] = pKF2->mpCamera->getParameter(i);
@@ -464,6 +472,14 @@ public:
             auto Twr2 = pKF2->GetRightPoseInverse();
             put(0, T1w * Tw2); put(1, T1w * Twr2); put(2, Tr1w * Tw2); put(3, Tr1w * Twr2);       // Tll, Tlr, Trl, Trr
         }
+    }
+
+    // Kannala-Brandt cameras (one fisheye camera, or the two-camera rig): the epipolar test is KannalaBrandt8::epipolarConstrain =
+    // TriangulateMatches > 1e-4 with the relative pose of the pair of cameras the two features belong to (src/ORBmatcher.cc:1067-1083, :1203-1240)
+    template <class KeyFrameT>
+    int SearchForTriangulationFisheye(KeyFrameT *pKF1, KeyFrameT* pKF2, std::vector<std::pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo, const bool bCoarse, float epx, float epy)
+    {
+        OrbmKB8Pair kb; FillKB8Pair(pKF1, pKF2, kb);
         BowStore k1, k2;
         FillBow(*pKF1, pKF1->N, k1); FillBow(*pKF2, pKF2->N, k2);
         if (pKF1->NLeft != -1) FillAllKeys(*pKF1, pKF1->NLeft, pKF1->N, k1);

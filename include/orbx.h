@@ -422,7 +422,7 @@ int orbm_search_by_bow_batch(orbx_extractor* h, int n, const OrbmKeyFrameView* c
  * (include/KeyFrame.h:  the fields of OrbmKeyFrameView) - is uploaded once by orbm_keyframe_create (has_map_point of the view is ignored:
  * map points change while a key frame lives, the searches take the flags per call).  The resident searches give the same results as
  * orbm_search_for_triangulation_batch / orbm_search_by_bow_batch and move only flags, poses and results across the bus; the accept loop of
- * SearchByBoW runs on the device (one wave per vocabulary node).  Pinhole / single-camera key frames.  A key frame may be used with any
+ * SearchByBoW runs on the device (one wave per vocabulary node).  A key frame may be used with any
  * extractor handle of the device it was created on.  Limit: at most 2048 features of one key frame per vocabulary node (ORBX_E_CAPACITY). */
 typedef struct orbm_keyframe orbm_keyframe;
 int orbm_keyframe_create(orbx_extractor* h, const OrbmKeyFrameView* K, orbm_keyframe** out);
@@ -432,6 +432,11 @@ void orbm_keyframe_destroy(orbm_keyframe* kf);
 int orbm_search_for_triangulation_resident(orbx_extractor* h, orbm_keyframe* K1, const uint8_t* has_map_point1, int n2, orbm_keyframe* const* K2s,
                                            const uint8_t* const* has_map_point2, const float* F12s, const float* eps, int only_stereo, int coarse,
                                            int check_orientation, int* matches12, int* nmatches);
+/* The same for key frames with Kannala-Brandt cameras (one fisheye camera or the rig; the views given to orbm_keyframe_create list mvKeys followed
+ * by mvKeysRight and no u_right for a rig, as for orbm_search_for_triangulation_kb8): cams[j] describes the pair (K1, K2s[j]). */
+int orbm_search_for_triangulation_resident_kb8(orbx_extractor* h, orbm_keyframe* K1, const uint8_t* has_map_point1, int n2, orbm_keyframe* const* K2s,
+                                               const uint8_t* const* has_map_point2, const OrbmKB8Pair* cams, const float* eps, int only_stereo, int coarse,
+                                               int check_orientation, int* matches12, int* nmatches);
 /* SearchByBoW for n pairs (src/ORBmatcher.cc:259-493, :892-1043).  has_map_point1[p]: K1s[p] features with a good map point (NULL = none, no
  * matches); eligible2[p]: K2s[p] features that may be matched (NULL = all: the Frame overload).  Results as orbm_search_by_bow_batch. */
 int orbm_search_by_bow_resident(orbx_extractor* h, int n, orbm_keyframe* const* K1s, const uint8_t* const* has_map_point1, orbm_keyframe* const* K2s,

@@ -394,8 +394,8 @@ __device__ __forceinline__ int wave_find_node(const uint32_t* __restrict__ ids, 
 // ORBmatcher::SearchForTriangulation over device-resident key frames: one wave per (feature idx1 of KF1, neighbour j), no work list - the
 // wave finds the neighbour's feature list of idx1's vocabulary node itself.  best[j * N1 + idx1] = index in neighbour j or -1.
 // grid (ceil(N1 / 4), n2).  flags: call-time map point flags, KF1's at offset 0, neighbour j's at nb[j].mp2_off.
-__global__ void __launch_bounds__(256) k_sft_resident(ResidentKF k1, const uint8_t* __restrict__ flags, const SftNeighbour* __restrict__ nb,
-                                                      int* __restrict__ best) {
+template <bool KB8>
+__device__ __forceinline__ void sft_resident_body(const ResidentKF& k1, const uint8_t* __restrict__ flags, const SftNeighbour* __restrict__ nb, int* __restrict__ best) {
     const int lane = lane_id();
     const int idx1 = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), j = (int)blockIdx.y;
     if (idx1 >= k1.N) return;
@@ -408,11 +408,20 @@ __global__ void __launch_bounds__(256) k_sft_resident(ResidentKF k1, const uint8
         if (b >= 0) {
             const int s2 = S.k2.fv_start[b], c2 = S.k2.fv_start[b + 1] - s2;
             const unsigned long long* da = k1.desc + 4 * (size_t)idx1;
-            r = bow_search_core<false>(idx1, k1.kps[idx1], stereo1, da[0], da[1], da[2], da[3], S.P, S.k2.kps, S.k2.desc, S.k2.ur, flags + S.mp2_off,
-                                       S.k2.fv_feat + s2, c2);
+            r = bow_search_core<KB8>(idx1, k1.kps[idx1], stereo1, da[0], da[1], da[2], da[3], S.P, S.k2.kps, S.k2.desc, S.k2.ur, flags + S.mp2_off,
+                                     S.k2.fv_feat + s2, c2);
         }
     }
     if (lane == 0) best[(size_t)j * k1.N + idx1] = r;
+}
+__global__ void __launch_bounds__(256) k_sft_resident(ResidentKF k1, const uint8_t* __restrict__ flags, const SftNeighbour* __restrict__ nb,
+                                                      int* __restrict__ best) {
+    sft_resident_body<false>(k1, flags, nb, best);
+}
+// Kannala-Brandt cameras (its own kernel for the same reason as k_bow_search_kb8)
+__global__ void __launch_bounds__(256) k_sft_resident_kb8(ResidentKF k1, const uint8_t* __restrict__ flags, const SftNeighbour* __restrict__ nb,
+                                                          int* __restrict__ best) {
+    sft_resident_body<true>(k1, flags, nb, best);
 }
 
 // ORBmatcher::SearchByBoW (src/ORBmatcher.cc:259-493 and :892-1043, non-fisheye) over device-resident key frames, the sequential accept

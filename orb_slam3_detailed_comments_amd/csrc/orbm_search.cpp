@@ -837,10 +837,10 @@ static int prune_by_rotation(const orbm_keyframe* K1, const orbm_keyframe* K2, i
     return nmatches;
 }
 
-int orbm_search_for_triangulation_resident(orbx_extractor* h, orbm_keyframe* K1, const uint8_t* has_mp1, int n2, orbm_keyframe* const* K2s,
-                                           const uint8_t* const* has_mp2, const float* F12s, const float* eps, int only_stereo, int coarse, int check_ori,
-                                           int* matches12, int* nmatches_out) {
-    if (!h || !K1 || n2 < 0 || (n2 > 0 && (!K2s || !F12s || !eps || !matches12))) return fail(ORBX_E_ARG, "null");
+static int sft_resident_impl(orbx_extractor* h, orbm_keyframe* K1, const uint8_t* has_mp1, int n2, orbm_keyframe* const* K2s,
+                             const uint8_t* const* has_mp2, const float* F12s, const OrbmKB8Pair* kb8, const float* eps, int only_stereo, int coarse, int check_ori,
+                             int* matches12, int* nmatches_out) {
+    if (!h || !K1 || n2 < 0 || (n2 > 0 && (!K2s || (!F12s && !kb8) || !eps || !matches12))) return fail(ORBX_E_ARG, "null");
     if (K1->device != h->device) return fail(ORBX_E_ARG, "key frame lives on another device");
     rt::set_device(h->device);
     const int N1 = K1->N;
@@ -854,10 +854,16 @@ int orbm_search_for_triangulation_resident(orbx_extractor* h, orbm_keyframe* K1,
         SftNeighbour& S = nb[j]; memset(&S, 0, sizeof S);
         S.k2 = K2->dev; S.mp2_off = (int)ftotal; ftotal += al16((size_t)std::max(K2->N, 1));
         BowParams& P = S.P;
-        for (int i = 0; i < 9; i++) P.F12[i] = F12s[9 * (size_t)j + i];
+        if (F12s) for (int i = 0; i < 9; i++) P.F12[i] = F12s[9 * (size_t)j + i];
         P.ep[0] = eps[2 * (size_t)j]; P.ep[1] = eps[2 * (size_t)j + 1];
         for (int l = 0; l < kMaxLevels; l++) { P.scale2[l] = K2->scale[l]; P.sigma2_2[l] = K2->sigma2[l]; }
         P.only_stereo = only_stereo; P.coarse = coarse; P.th_low = TH_LOW; P.nleft1 = P.nleft2 = -1;
+        if (kb8) {                               // Kannala-Brandt cameras: one OrbmKB8Pair per neighbour (as orbm_search_for_triangulation_kb8)
+            const OrbmKB8Pair& C = kb8[j];
+            P.kb8 = 1; P.nleft1 = C.nleft1; P.nleft2 = C.nleft2;
+            memcpy(P.cam1, C.cam1, sizeof P.cam1); memcpy(P.cam2, C.cam2, sizeof P.cam2); memcpy(P.R, C.R, sizeof P.R); memcpy(P.t, C.t, sizeof P.t);
+            for (int l = 0; l < kMaxLevels; l++) P.sigma2_1[l] = K1->sigma2[l];
+        }
     }
     std::vector<uint8_t> flags(ftotal, 0);
     if (has_mp1) memcpy(flags.data(), has_mp1, (size_t)N1);
@@ -866,7 +872,8 @@ int orbm_search_for_triangulation_resident(orbx_extractor* h, orbm_keyframe* K1,
     const size_t pf = pk.add(flags.data(), flags.size()), pn = pk.add(nb.data(), sizeof(SftNeighbour) * nb.size());
     if (pk.flush() || h->d_si[SI_BEST].ensure((size_t)n2 * N1)) return fail(ORBX_E_DEVICE, "upload/allocation failed");
     dim3 grid((N1 + 3) / 4, n2, 1), blk(256, 1, 1);
-    ORBX_LAUNCH(k_sft_resident, grid, blk, 0, h->s0, K1->dev, pk.dev<uint8_t>(pf), pk.dev<SftNeighbour>(pn), h->d_si[SI_BEST].p);
+    if (kb8) ORBX_LAUNCH(k_sft_resident_kb8, grid, blk, 0, h->s0, K1->dev, pk.dev<uint8_t>(pf), pk.dev<SftNeighbour>(pn), h->d_si[SI_BEST].p);
+    else ORBX_LAUNCH(k_sft_resident, grid, blk, 0, h->s0, K1->dev, pk.dev<uint8_t>(pf), pk.dev<SftNeighbour>(pn), h->d_si[SI_BEST].p);
     if (rt::copy_d2h(matches12, h->d_si[SI_BEST].p, sizeof(int) * (size_t)n2 * N1, h->s0) || rt::stream_sync(h->s0) || rt::check_launch())
         return fail(ORBX_E_DEVICE, "resident triangulation search failed: %s", rt::last_error());
     for (int j = 0; j < n2; j++) {
@@ -874,6 +881,20 @@ int orbm_search_for_triangulation_resident(orbx_extractor* h, orbm_keyframe* K1,
         if (nmatches_out) nmatches_out[j] = nm;
     }
     return ORBX_OK;
+}
+
+int orbm_search_for_triangulation_resident(orbx_extractor* h, orbm_keyframe* K1, const uint8_t* has_mp1, int n2, orbm_keyframe* const* K2s,
+                                           const uint8_t* const* has_mp2, const float* F12s, const float* eps, int only_stereo, int coarse, int check_ori,
+                                           int* matches12, int* nmatches_out) {
+    if (n2 > 0 && !F12s) return fail(ORBX_E_ARG, "null");
+    return sft_resident_impl(h, K1, has_mp1, n2, K2s, has_mp2, F12s, nullptr, eps, only_stereo, coarse, check_ori, matches12, nmatches_out);
+}
+
+int orbm_search_for_triangulation_resident_kb8(orbx_extractor* h, orbm_keyframe* K1, const uint8_t* has_mp1, int n2, orbm_keyframe* const* K2s,
+                                               const uint8_t* const* has_mp2, const OrbmKB8Pair* cams, const float* eps, int only_stereo, int coarse, int check_ori,
+                                               int* matches12, int* nmatches_out) {
+    if (n2 > 0 && !cams) return fail(ORBX_E_ARG, "null");
+    return sft_resident_impl(h, K1, has_mp1, n2, K2s, has_mp2, nullptr, cams, eps, only_stereo, coarse, check_ori, matches12, nmatches_out);
 }
 
 int orbm_search_by_bow_resident(orbx_extractor* h, int n, orbm_keyframe* const* K1s, const uint8_t* const* has_mp1, orbm_keyframe* const* K2s,

@@ -98,6 +98,7 @@ __global__ void k_bow_search_kb8(const BowItem* __restrict__ items, int nitems, 
                              const float* __restrict__ ur2, const uint8_t* __restrict__ has_mp2, const int* __restrict__ feat2,
                              const BowParams* __restrict__ Ps, int* __restrict__ best2);
 __global__ void k_sft_resident(ResidentKF k1, const uint8_t* __restrict__ flags, const SftNeighbour* __restrict__ nb, int* __restrict__ best);
+__global__ void k_sft_resident_kb8(ResidentKF k1, const uint8_t* __restrict__ flags, const SftNeighbour* __restrict__ nb, int* __restrict__ best);
 __global__ void k_bow_match_resident(const BowPairResident* __restrict__ pairs, const uint8_t* __restrict__ flags, float nnratio, int th_low,
                                      int th_inclusive, int* __restrict__ m12, int N1cap, int* __restrict__ status);
 __global__ void k_bow_dists(const BowItem* __restrict__ items, int nitems, const unsigned long long* __restrict__ desc1,

@@ -461,6 +461,15 @@ def build_and_run_kb8(drv, seed):
             pairs = np.full((max(nA, 1), 2), -1, np.int32); npairs = C.c_int(0)
             n = L.mw_search_for_triangulation(drv.w, kA, kB, only_stereo, coarse, _p(pairs), len(pairs), C.byref(npairs), C.c_float(0.6), ori)
             out["kb8_triangulation_rig%d_%d%d%d" % (rig, only_stereo, coarse, ori)] = np.concatenate([[n, npairs.value], pairs[:npairs.value].ravel()])
+        # several neighbours at once: the facade's one call over device-resident key frames (its Kannala-Brandt kernel), the reference once per neighbour
+        if hasattr(L, "mw_search_for_triangulation_neighbours"):
+            kC, nC = make((rot(-0.02, 0.02, 0.01), np.array([-0.3, 0.04, 0.08], np.float32)), rig, 0.3)
+            neigh = np.array([kB, kC, kB], np.int32); cap = max(nA, 1)
+            for (only_stereo, coarse, ori) in ((0, 0, 1), (1, 1, 0)):
+                pairs = np.full(2 * cap * len(neigh), -1, np.int32); npairs = np.full(len(neigh), -1, np.int32); nms = np.full(len(neigh), -1, np.int32)
+                rc = L.mw_search_for_triangulation_neighbours(drv.w, kA, len(neigh), _p(neigh), only_stereo, coarse, _p(pairs), cap, _p(npairs), _p(nms), C.c_float(0.6), ori, 2)
+                assert rc == 0
+                out["kb8_triangulation_neighbours_rig%d_%d%d%d" % (rig, only_stereo, coarse, ori)] = np.concatenate([npairs, nms, pairs])
     return out
 
 
