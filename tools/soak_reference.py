@@ -56,4 +56,23 @@ for seed in range(2000, 2000 + npairs):
     if not ok:
         print("DIFF frame seed %d (%dx%d)" % (seed, w, h)); bad2 += 1
 print("stereo frames: %d pairs, %d differences" % (npairs, bad2))
-sys.exit(1 if bad or bad2 else 0)
+
+# Batch-size dependent code paths (quadtree threads per tree, keypoints per wave in the describe kernel, ...): batches of 40 and 96 images of one
+# size must give, image by image, what pairs of two give (which the loop above has compared with the reference).
+bad3 = 0; nb = 0
+for rep in range(max(1, npairs // 100)):
+    w, h, nf = [(752, 480, 1200), (640, 480, 1000)][rep % 2]
+    B = [40, 96][rep % 2]
+    imgs = []
+    for i in range(B // 2):
+        L, R = synth.stereo_pair(w, h, seed=9000 + 100 * rep + i, nrect=[2000, 800, 3000][i % 3]); imgs += [L, R]
+    ex = exs.get(nf) or exs.setdefault(nf, ORBextractor(nf, 1.2, 8, 20, 7, lib=lib))
+    big = ex.extract_batch(np.stack(imgs))
+    for i in range(0, B, 2):
+        small = ex.extract_batch(np.stack(imgs[i:i + 2]))
+        for a2, b2 in zip(big[i:i + 2], small):
+            nb += 1
+            if not (a2[0] == b2[0] and a2[1].tobytes() == b2[1].tobytes() and a2[2].tobytes() == b2[2].tobytes()):
+                print("DIFF batch rep %d image %d" % (rep, i)); bad3 += 1
+print("batched vs pairwise extraction: %d images, %d differences" % (nb, bad3))
+sys.exit(1 if bad or bad2 or bad3 else 0)
