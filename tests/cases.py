@@ -16,6 +16,9 @@ FULL_CASES = [
 LARGE_CASES = [   # sizes outside BASELINE.json that real rigs use (KITTI, HD): GPU parity only
     ("kitti_1241x376_n2000", lambda: synth.corner_field(1241, 376, seed=20, nrect=3900), 2000, (0, 0)),
     ("hd_1920x1080_n3000", lambda: synth.corner_field(1920, 1080, seed=21, nrect=17000), 3000, (0, 0)),
+    # 226 k FAST candidates on level 0: the quadtree's 32-bit sort counters (levels with >= 65 536 keys) and its workgroup-wide partitions
+    ("noise_1920x1200_n3000", lambda: synth.uniform_noise(1920, 1200, seed=22), 3000, (0, 0)),
+    ("noise_1600x1200_n1500", lambda: synth.uniform_noise(1600, 1200, seed=23), 1500, (0, 1000)),
 ]
 
 SMALL_CASES = [
