@@ -195,6 +195,29 @@ __global__ void __launch_bounds__(256) k_resize_rows(const LevelInfo* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Self-test of the instruction wrappers of orbx_simd.h (orbx_debug_simd_selftest): out[op * n + i] = op(a[i], b[i], c[i]).  The CPU tests
+// run the kernels on plain-C stand-ins of these instructions; this entry lets the tests compare instruction and stand-in with an independent
+// definition, operand by operand.  ops: 0 mul24, 1 mul24_forced, 2 byte_perm, 3 align_byte, 4 dot4_u8, 5 dot2_u16, 6 pk_max3, 7 pk_min3,
+// 8 pk_sub, 9 pk_xor(a, c) (kSimdSelftestOps in all).
+__global__ void __launch_bounds__(256) k_simd_selftest(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ c, int n,
+                                                       uint32_t* __restrict__ out) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= n) return;
+    const uint32_t x = a[i], y = b[i], z = c[i];
+    auto bits = [](pk2 v) { return (uint32_t)(uint16_t)pk_lo(v) | ((uint32_t)(uint16_t)pk_hi(v) << 16); };
+    out[0 * (size_t)n + i] = (uint32_t)mul24((int)x, (int)y);
+    out[1 * (size_t)n + i] = (uint32_t)mul24_forced((int)x, (int)y);
+    out[2 * (size_t)n + i] = byte_perm(x, y, z);
+    out[3 * (size_t)n + i] = align_byte(x, y, z);
+    out[4 * (size_t)n + i] = dot4_u8(x, y, z);
+    out[5 * (size_t)n + i] = dot2_u16(x, y, z);
+    out[6 * (size_t)n + i] = bits(pk_max3(pk_make(x), pk_make(y), pk_make(z)));
+    out[7 * (size_t)n + i] = bits(pk_min3(pk_make(x), pk_make(y), pk_make(z)));
+    out[8 * (size_t)n + i] = bits(pk_sub(pk_make(x), pk_make(y)));
+    out[9 * (size_t)n + i] = bits(pk_xor(pk_make(x), z));
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 7x7 Gaussian blur, taps k[7] (symmetric; sum 256 or 257), REFLECT_101,
 //   out = sat((sum_j k_j * (sum_i k_i * p) + 32768) >> 16).
 // Streaming design: a thread owns 4 adjacent columns (one dword) and walks down a strip of kBlurRows rows with the

@@ -620,6 +620,22 @@ int orbx_debug_quadtree_profile(orbx_extractor* h, long long out[16]) {
     return ORBX_OK;
 }
 
+// debug: the instruction wrappers of csrc/orbx_simd.h applied to n operand triples; out: 10 x n results (see k_simd_selftest)
+int orbx_debug_simd_selftest(orbx_extractor* h, const uint32_t* a, const uint32_t* b, const uint32_t* c, int n, uint32_t* out) {
+    if (!h || !a || !b || !c || !out || n <= 0) return fail(ORBX_E_ARG, "bad arguments");
+    rt::set_device(h->device);
+    orbx::DevBuf<uint32_t> d;
+    const size_t N = (size_t)n;
+    if (d.ensure((3 + kSimdSelftestOps) * N)) return fail(ORBX_E_DEVICE, "allocation failed");
+    int e = rt::copy_h2d(d.p, a, 4 * N, h->s0) | rt::copy_h2d(d.p + N, b, 4 * N, h->s0) | rt::copy_h2d(d.p + 2 * N, c, 4 * N, h->s0);
+    dim3 grid((n + 255) / 256, 1, 1), blk(256, 1, 1);
+    ORBX_LAUNCH(k_simd_selftest, grid, blk, 0, h->s0, (const uint32_t*)d.p, (const uint32_t*)(d.p + N), (const uint32_t*)(d.p + 2 * N), n, d.p + 3 * N);
+    e |= rt::copy_d2h(out, d.p + 3 * N, 4 * N * kSimdSelftestOps, h->s0);
+    if (e || rt::stream_sync(h->s0) || rt::check_launch()) { d.release(); return fail(ORBX_E_DEVICE, "self-test failed: %s", rt::last_error()); }
+    d.release();
+    return ORBX_OK;
+}
+
 int orbx_host_alloc(orbx_extractor* h, size_t bytes, void** hptr) {
     if (!h || !hptr) return fail(ORBX_E_ARG, "null");
     rt::set_device(h->device);

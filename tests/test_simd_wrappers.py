@@ -1,0 +1,89 @@
+"""The byte / packed-16-bit instruction wrappers of csrc/orbx_simd.h (v_mul_i32_i24, v_perm_b32, v_alignbyte_b32, v_dot4_u32_u8, v_dot2_u32_u16,
+v_pk_maximum3_f16 / v_pk_minimum3_f16 on biased pixel patterns, v_pk_sub_i16) against independent numpy definitions, operand by operand:
+on the GPU the instructions themselves, in the CPU suite the plain-C stand-ins the SIMT emulator runs instead of them.  The operand ranges are
+those the kernels use (24-bit factors, selectors 0..7 and 0x0c, pixel patterns 0x6400 + byte in both halves for the 3-input min / max)."""
+import numpy as np
+import pytest
+
+from orb_slam3_detailed_comments_amd.extractor import ORBextractor
+
+N = 1 << 16
+
+
+def _operands(rng):
+    u32 = lambda: rng.integers(0, 1 << 32, N, dtype=np.uint64).astype(np.uint32)
+    sets = {}
+    # signed 24-bit factors (mul24): the kernels multiply row indices, pitches, fixed-point weights
+    s24 = lambda: rng.integers(-(1 << 23), 1 << 23, N).astype(np.int32).view(np.uint32)
+    sets["mul"] = (s24(), s24(), u32())
+    sel = rng.choice(np.array([0, 1, 2, 3, 4, 5, 6, 7, 0x0c], np.uint32), (N, 4))
+    sets["perm"] = (u32(), u32(), (sel[:, 0] | sel[:, 1] << 8 | sel[:, 2] << 16 | sel[:, 3] << 24).astype(np.uint32))
+    sets["align"] = (u32(), u32(), rng.integers(0, 4, N).astype(np.uint32))
+    sets["dot"] = (u32(), u32(), rng.integers(0, 1 << 24, N).astype(np.uint32))
+    pix = lambda: (0x6400 + rng.integers(0, 256, N) | (0x6400 + rng.integers(0, 256, N)) << 16).astype(np.uint32)
+    sets["pk3"] = (pix(), pix(), pix())
+    i16 = lambda: (rng.integers(0, 1 << 15, N) | rng.integers(0, 1 << 15, N) << 16).astype(np.uint32)
+    sets["pk"] = (i16(), i16(), rng.choice(np.array([0x64006400, 0x640064FF, 0x64FF6400, 0x64FF64FF], np.uint32), N))
+    for k in sets:                                              # edge operands in front
+        a, b, c = sets[k]
+        a[:4] = [0, 0xFFFFFFFF if k in ("perm", "align", "dot") else a[0], a[1], a[2]]
+    return sets
+
+
+def _run(ex, a, b, c):
+    out = np.zeros((10, N), np.uint32)
+    a, b, c = (np.ascontiguousarray(x, np.uint32) for x in (a, b, c))
+    ex._lib.check(ex._lib.L.orbx_debug_simd_selftest(ex._h, a.ctypes.data, b.ctypes.data, c.ctypes.data, N, out.ctypes.data))
+    return out
+
+
+def _bytes(x):
+    return np.stack([(x >> (8 * i)) & 0xFF for i in range(4)], 1).astype(np.uint64)
+
+
+def _halves(x):
+    return (x & 0xFFFF).astype(np.int64), (x >> 16).astype(np.int64)
+
+
+def _check(ex):
+    S = _operands(np.random.default_rng(2024))
+    # mul24: product of the sign-extended low 24 bits, low 32 bits
+    a, b, c = S["mul"]; out = _run(ex, a, b, c)
+    exp = ((a.view(np.int32).astype(np.int64) * b.view(np.int32).astype(np.int64)) & 0xFFFFFFFF).astype(np.uint32)
+    assert np.array_equal(out[0], exp) and np.array_equal(out[1], exp), "mul24"
+    # v_perm_b32: result byte i = byte sel_i of {hi:lo} (lo = bytes 0..3), selector 0x0c = 0
+    a, b, c = S["perm"]; out = _run(ex, a, b, c)
+    src = np.concatenate([_bytes(b), _bytes(a), np.zeros((N, 8), np.uint64)], 1)            # index 12 -> 0
+    selb = _bytes(c).astype(np.int64)
+    exp = sum(src[np.arange(N), selb[:, i]] << np.uint64(8 * i) for i in range(4)).astype(np.uint32)
+    assert np.array_equal(out[2], exp), "byte_perm"
+    # v_alignbyte_b32
+    a, b, c = S["align"]; out = _run(ex, a, b, c)
+    v = (a.astype(np.uint64) << np.uint64(32)) | b.astype(np.uint64)
+    assert np.array_equal(out[3], ((v >> (np.uint64(8) * c.astype(np.uint64))) & np.uint64(0xFFFFFFFF)).astype(np.uint32)), "align_byte"
+    # dot products (no clamp, 32-bit wrap)
+    a, b, c = S["dot"]; out = _run(ex, a, b, c)
+    exp4 = ((_bytes(a) * _bytes(b)).sum(1) + c.astype(np.uint64)) & np.uint64(0xFFFFFFFF)
+    assert np.array_equal(out[4], exp4.astype(np.uint32)), "dot4_u8"
+    al, ah = _halves(a); bl, bh = _halves(b)
+    assert np.array_equal(out[5], ((al * bl + ah * bh + c.astype(np.int64)) & 0xFFFFFFFF).astype(np.uint32)), "dot2_u16"
+    # packed three-input max / min on biased pixel patterns (positive binary16 numbers order like their bit patterns)
+    a, b, c = S["pk3"]; out = _run(ex, a, b, c)
+    hs = [_halves(x) for x in (a, b, c)]
+    mx = np.maximum.reduce([h[0] for h in hs]) | np.maximum.reduce([h[1] for h in hs]) << 16
+    mn = np.minimum.reduce([h[0] for h in hs]) | np.minimum.reduce([h[1] for h in hs]) << 16
+    assert np.array_equal(out[6], mx.astype(np.uint32)) and np.array_equal(out[7], mn.astype(np.uint32)), "pk_max3 / pk_min3"
+    # packed 16-bit subtract (wraps per half), packed xor
+    a, b, c = S["pk"]; out = _run(ex, a, b, c)
+    al, ah = _halves(a); bl, bh = _halves(b)
+    assert np.array_equal(out[8], (((al - bl) & 0xFFFF) | ((ah - bh) & 0xFFFF) << 16).astype(np.uint32)), "pk_sub"
+    assert np.array_equal(out[9], a ^ c), "pk_xor"
+
+
+def test_simd_wrappers_emulated(emu_lib):
+    _check(ORBextractor(500, 1.2, 8, 20, 7, lib=emu_lib))
+
+
+@pytest.mark.gpu
+def test_simd_wrappers_gpu(hip_lib):
+    _check(ORBextractor(500, 1.2, 8, 20, 7, lib=hip_lib))
