@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(256) k_resize_rows(const LevelInfo* __restrict
 // Self-test of the instruction wrappers of orbx_simd.h (orbx_debug_simd_selftest): out[op * n + i] = op(a[i], b[i], c[i]).  The CPU tests
 // run the kernels on plain-C stand-ins of these instructions; this entry lets the tests compare instruction and stand-in with an independent
 // definition, operand by operand.  ops: 0 mul24, 1 mul24_forced, 2 byte_perm, 3 align_byte, 4 dot4_u8, 5 dot2_u16, 6 pk_max3, 7 pk_min3,
-// 8 pk_sub, 9 pk_xor(a, c) (kSimdSelftestOps in all).
+// 8 pk_sub, 9 pk_xor(a, c), 10 wave_incl_scan, 11 wave_sum (both of a & 0xFFFF), 12 wave_min_u32(b) (kSimdSelftestOps in all).
 __global__ void __launch_bounds__(256) k_simd_selftest(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ c, int n,
                                                        uint32_t* __restrict__ out) {
     const int i = (int)(blockIdx.x * 256 + threadIdx.x);
@@ -215,6 +215,11 @@ __global__ void __launch_bounds__(256) k_simd_selftest(const uint32_t* __restric
     out[7 * (size_t)n + i] = bits(pk_min3(pk_make(x), pk_make(y), pk_make(z)));
     out[8 * (size_t)n + i] = bits(pk_sub(pk_make(x), pk_make(y)));
     out[9 * (size_t)n + i] = bits(pk_xor(pk_make(x), z));
+    // wave primitives of orbx_block.h (on the GPU the inclusive scan of 32-bit integers is a DPP sequence): per wave of 64 consecutive elements
+    // (n is a multiple of 256: every lane is active)
+    out[10 * (size_t)n + i] = (uint32_t)wave_incl_scan<int>((int)(x & 0xFFFFu));
+    out[11 * (size_t)n + i] = (uint32_t)wave_sum<int>((int)(x & 0xFFFFu));
+    out[12 * (size_t)n + i] = wave_min_u32(y);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -31,7 +31,7 @@ def _operands(rng):
 
 
 def _run(ex, a, b, c):
-    out = np.zeros((10, N), np.uint32)
+    out = np.zeros((13, N), np.uint32)
     a, b, c = (np.ascontiguousarray(x, np.uint32) for x in (a, b, c))
     ex._lib.check(ex._lib.L.orbx_debug_simd_selftest(ex._h, a.ctypes.data, b.ctypes.data, c.ctypes.data, N, out.ctypes.data))
     return out
@@ -78,6 +78,11 @@ def _check(ex):
     al, ah = _halves(a); bl, bh = _halves(b)
     assert np.array_equal(out[8], (((al - bl) & 0xFFFF) | ((ah - bh) & 0xFFFF) << 16).astype(np.uint32)), "pk_sub"
     assert np.array_equal(out[9], a ^ c), "pk_xor"
+    # wave primitives (orbx_block.h): inclusive scan / sum of a & 0xFFFF and minimum of b over every 64 consecutive elements
+    v = (a & 0xFFFF).astype(np.int64).reshape(-1, 64)
+    assert np.array_equal(out[10], np.cumsum(v, 1).reshape(-1).astype(np.uint32)), "wave_incl_scan"
+    assert np.array_equal(out[11], np.repeat(v.sum(1), 64).astype(np.uint32)), "wave_sum"
+    assert np.array_equal(out[12], np.repeat(b.reshape(-1, 64).min(1), 64)), "wave_min_u32"
 
 
 def test_simd_wrappers_emulated(emu_lib):
