@@ -14,6 +14,23 @@ from orb_slam3_detailed_comments_amd.extractor import ORBextractor
 
 ROOT = ol.ROOT
 CSRC = os.path.join(ROOT, "orb_slam3_detailed_comments_amd", "csrc")
+SOURCES = ("k_image.hip", "k_fast.hip", "k_quadtree.hip", "k_describe.hip", "k_match.hip", "k_search.hip", "k_vocab.hip", "k_input.hip", "orbx_api.cpp", "orbm_search.cpp",
+           "orbv_api.cpp")
+
+
+def build_emu_variant(so, defines):
+    """the kernel sources for the CPU SIMT emulator with extra -D switches; the translation units are compiled side by side"""
+    from concurrent.futures import ThreadPoolExecutor
+    d = os.path.dirname(so)
+    flags = ["-O2", "-std=c++17", "-ffp-contract=off", "-DORBX_EMU"] + list(defines) + ["-I" + os.path.join(ROOT, "tests", "emu"), "-I" + CSRC, "-fPIC", "-w"]
+
+    def one(f):
+        o = os.path.join(d, f + ".o")
+        subprocess.run(["g++"] + flags + ["-c", "-x", "c++", os.path.join(CSRC, f), "-o", o], check=True)
+        return o
+    with ThreadPoolExecutor(6) as ex:
+        objs = list(ex.map(one, SOURCES))
+    subprocess.run(["g++", "-shared"] + objs + ["-o", so, "-lpthread"], check=True)
 
 
 @pytest.mark.parametrize("presort_max,bigspan,wave_sort_range,big_pixels,u16_max", [(1, 80, 16, 0, 65535), (0, 1024, 100000, 150000, 0), (5, 1024, 40, 0, 0)])
@@ -25,9 +42,8 @@ def test_quadtree_path_mix(tmp_path, presort_max, bigspan, wave_sort_range, big_
     # wave_sort_range: ranges of the final rounds' std::sort model above this length are partitioned by a wave (16 = every range,
     # 100000 = none: the one-thread loop)
     so = str(tmp_path / "liborbx_emu_variant.so")
-    srcs = [os.path.join(CSRC, f) for f in ("k_image.hip", "k_fast.hip", "k_quadtree.hip", "k_describe.hip", "k_match.hip", "k_search.hip", "k_vocab.hip", "k_input.hip", "orbx_api.cpp", "orbm_search.cpp", "orbv_api.cpp")]
-    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-DORBX_EMU", "-DORBX_PRESORT_MAX=%d" % presort_max, "-DORBX_BIGSPAN=%d" % bigspan, "-DORBX_WAVE_SORT_RANGE=%d" % wave_sort_range, "-DORBX_QT_BIG_PIXELS=%d" % big_pixels, "-DORBX_PRESORT_U16_MAX=%d" % u16_max, "-DORBX_QT_WIDE_BATCH=%d" % (0 if big_pixels == 150000 else 32),
-                    "-I" + os.path.join(ROOT, "tests", "emu"), "-I" + CSRC, "-fPIC", "-shared", "-w", "-x", "c++"] + srcs + ["-o", so, "-lpthread"], check=True)
+    build_emu_variant(so, ["-DORBX_PRESORT_MAX=%d" % presort_max, "-DORBX_BIGSPAN=%d" % bigspan, "-DORBX_WAVE_SORT_RANGE=%d" % wave_sort_range, "-DORBX_QT_BIG_PIXELS=%d" % big_pixels,
+                           "-DORBX_PRESORT_U16_MAX=%d" % u16_max, "-DORBX_QT_WIDE_BATCH=%d" % (0 if big_pixels == 150000 else 32)])
     lib = _lib.OrbxLib(so)
     for name, factory, nf, lap in SMALL_CASES + FULL_CASES[:1] + FULL_CASES[4:5]:
         img = factory()
@@ -42,9 +58,7 @@ def test_fast_list_flush_path(tmp_path, cap):
     up the pending ones are scored, and a cell whose corners alone fill it (noise) falls back to NMS / compaction scans of the score tile.
     With 600 entries most cells of a textured image score in several batches, with 200 nearly all of them also give the corner list up."""
     so = str(tmp_path / "liborbx_emu_smalllist.so")
-    srcs = [os.path.join(CSRC, f) for f in ("k_image.hip", "k_fast.hip", "k_quadtree.hip", "k_describe.hip", "k_match.hip", "k_search.hip", "k_vocab.hip", "k_input.hip", "orbx_api.cpp", "orbm_search.cpp", "orbv_api.cpp")]
-    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-DORBX_EMU", "-DORBX_FAST_LIST_CAP=%d" % cap,
-                    "-I" + os.path.join(ROOT, "tests", "emu"), "-I" + CSRC, "-fPIC", "-shared", "-w", "-x", "c++"] + srcs + ["-o", so, "-lpthread"], check=True)
+    build_emu_variant(so, ["-DORBX_FAST_LIST_CAP=%d" % cap])
     lib = _lib.OrbxLib(so)
     for name, factory, nf, lap in SMALL_CASES[:3] + FULL_CASES[:1] + FULL_CASES[4:5]:
         img = factory()
