@@ -297,6 +297,49 @@ public:
         }
         return nmatches;
     }
+    // The same for several candidate key frames against one frame in one call over device-resident key frames (Tracking::Relocalization
+    // calls SearchByBoW(pKF, mCurrentFrame, vvpMapPointMatches[i]) for every candidate, src/Tracking.cc:4360-4380): the frame is uploaded once
+    // for all candidates, the key frames come from `cache`, the accept loop runs on the device.  One camera (F.Nleft == -1).
+    // Returns the match counts; vvpMapPointMatches[i] is what SearchByBoW(vpKFs[i], F, ...) gives.
+    template <class KeyFrameT, class FrameT, class MapPointT>
+    std::vector<int> SearchByBoW(const std::vector<KeyFrameT*>& vpKFs, FrameT &F, ResidentKeyFrames<KeyFrameT>& cache,
+                                 std::vector<std::vector<MapPointT*> > &vvpMapPointMatches)
+    {
+        const int n = (int)vpKFs.size();
+        vvpMapPointMatches.assign(n, std::vector<MapPointT*>(F.N, static_cast<MapPointT*>(NULL)));
+        std::vector<int> counts(n, 0);
+        if (n == 0) return counts;
+        if (F.Nleft != -1) throw std::runtime_error("ORBmatcher (HIP): the batched SearchByBoW covers frames of one camera");
+        BowStore kf; FillBow(F, F.N, kf);
+        orbm_keyframe* rf = nullptr;
+        std::vector<orbm_keyframe*> k1(n), k2(n);
+        std::vector<std::vector<MapPointT*> > mps(n);
+        std::vector<std::vector<uint8_t> > good(n);
+        std::vector<const uint8_t*> goodp(n);
+        std::vector<std::vector<int> > m12(n);
+        std::vector<int*> m12p(n);
+        for (int i = 0; i < n; i++) {
+            KeyFrameT* pKF = vpKFs[i];
+            if (pKF->mpCamera2) throw std::runtime_error("ORBmatcher (HIP): the batched SearchByBoW covers key frames of one camera");
+            k1[i] = cache.Get(pKF);
+            mps[i] = pKF->GetMapPointMatches();
+            good[i].assign(pKF->N > 0 ? pKF->N : 1, 0);
+            for (int j = 0; j < pKF->N; j++) good[i][j] = mps[i][j] && !mps[i][j]->isBad();
+            goodp[i] = good[i].data();
+            m12[i].assign(pKF->N > 0 ? pKF->N : 1, -1); m12p[i] = m12[i].data();
+        }
+        {
+            std::lock_guard<std::mutex> lock(Mutex());
+            Check(orbm_keyframe_create(SharedHandle(), &kf.v, &rf));
+            for (int i = 0; i < n; i++) k2[i] = rf;
+            const int rc = orbm_search_by_bow_resident(SharedHandle(), n, k1.data(), goodp.data(), k2.data(), nullptr, mfNNratio, 1, mbCheckOrientation, m12p.data(), counts.data());
+            orbm_keyframe_destroy(rf);
+            Check(rc);
+        }
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < vpKFs[i]->N; j++) if (m12[i][j] >= 0) vvpMapPointMatches[i][m12[i][j]] = mps[i][j];
+        return counts;
+    }
     // src/ORBmatcher.cc:892-1043; on fisheye-rig key frames only the features of camera 1 take part (:930, :953)
     template <class KeyFrameT, class MapPointT>
     int SearchByBoW(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*> &vpMatches12)

@@ -286,6 +286,25 @@ int mw_search_by_bow_frame(void* wv, int kf, int frame, int* out_ids, float nnra
     for (size_t i = 0; i < vm.size(); i++) out_ids[i] = w->idOf(vm[i]);
     return n;
 }
+// several candidate key frames against one frame (relocalisation): the facade's one call over device-resident key frames, the reference once per
+// candidate.  out_ids: n blocks of `frame_n` map point ids; counts: n entries.
+int mw_search_by_bow_frame_many(void* wv, int n, const int* kfs, int frame, int frame_n, int* out_ids, int* counts, float nnratio, int check_ori) {
+    World* w = (World*)wv;
+    ORBmatcher m(nnratio, check_ori != 0);
+    std::vector<std::vector<MapPoint*>> vv(n);
+#ifdef MW_FACADE
+    ORBmatcher::ResidentKeyFrames<KeyFrame> cache;
+    std::vector<KeyFrame*> cand(n);
+    for (int i = 0; i < n; i++) cand[i] = w->kfs[kfs[i]].get();
+    const std::vector<int> c = m.SearchByBoW(cand, *w->frames[frame], cache, vv);
+    for (int i = 0; i < n; i++) counts[i] = c[i];
+#else
+    for (int i = 0; i < n; i++) counts[i] = m.SearchByBoW(w->kfs[kfs[i]].get(), *w->frames[frame], vv[i]);
+#endif
+    for (int i = 0; i < n; i++)
+        for (size_t j = 0; j < vv[i].size() && (int)j < frame_n; j++) out_ids[(size_t)i * frame_n + j] = w->idOf(vv[i][j]);
+    return 0;
+}
 int mw_search_by_bow_keyframes(void* wv, int kf1, int kf2, int* out_ids, float nnratio, int check_ori) {
     World* w = (World*)wv;
     std::vector<MapPoint*> vm;

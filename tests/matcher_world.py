@@ -249,6 +249,10 @@ def build_and_run(drv, seed, variant):
         o = i32(len(kkA))
         n = L.mw_search_by_bow_keyframes(drv.w, kA, kB, _p(o), C.c_float(0.8), ori)
         out["bow_keyframes_%d" % ori] = np.concatenate([[n], o])
+        if hasattr(L, "mw_search_by_bow_frame_many"):        # relocalisation: several candidates against the frame at once
+            cand = np.array([kA, kB, kA], np.int32); oo = i32(len(cand) * len(kb)); cc = i32(len(cand))
+            assert L.mw_search_by_bow_frame_many(drv.w, len(cand), _p(cand), fb, len(kb), _p(oo), _p(cc), C.c_float(0.75), ori) == 0
+            out["bow_frame_many_%d" % ori] = np.concatenate([cc, oo])
 
     # ---- SearchForInitialization ---------------------------------------------------------------------------------
     fi1, ki1, di1, ui1, pti1, _ = make(False, poses[0], 0.0, 0.0, px_noise=0.5, level0_frac=0.6)
