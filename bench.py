@@ -147,6 +147,24 @@ def cpu_baseline(seconds_budget=6.0):
     return {"value": round(n / dt, 2), "unit": "stereo pairs/s", "cores": cores, "kind": "port", "sample": sample}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks (one process per GPU) under torch.distributed.run on
+    127.0.0.1 and pass its output and exit code through.  (The round driver starts the ranks itself; WORLD_SIZE is then set and this is skipped.)"""
+    import socket
+    import subprocess
+    if os.environ.get("ORBX_BENCH_BACKEND", "nccl") == "nccl":
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py --gpus %d: this node shows %d GPU(s); one process per GPU needs %d (ORBX_BENCH_BACKEND=gloo lets ranks share a GPU for "
+                             "protocol tests)\n" % (n, have, n))
+            return 2
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,10 +176,20 @@ def main():
     ap.add_argument("--handles", type=int, default=0, help="extractor handles in flight per GPU (each owns its streams).  Default: 4 as a plain process "
                     "(2 / 3 / 4 / 5 / 6 handles: 68.0 / 75.7 / 80.3 / 70.2 / 69.0 k pairs/s), 3 inside a torch.distributed process, where PyTorch's own "
                     "streams share the hardware queues and four chains were measured unstable (37-48 k) in round 1")
+    ap.add_argument("--workload", default="corner_field", choices=["corner_field", "natural"], help="synthetic image generator: corner_field = the headline "
+                    "workload (random rectangles, 24-52 %% of the pixels are FAST corners at t = 7); natural = 1/f^2 spectrum + sparse edges (1-5 %% corners, "
+                    "camera-like statistics) - a second reported line, never the headline")
+    ap.add_argument("--allgather", action="store_true", help="BASELINE.json configs[4]: after every batch all-gather the descriptor blocks [B, cap, 32] + counts "
+                    "of all ranks (RCCL over xGMI) inside the timed region, on a side stream beside the next extraction; the line then also carries the "
+                    "collective's own time per batch")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="the timed region repeats whole blocks of --steps steps until it lasts at least this long "
+                    "(`repeats` in the output; value = all timed units / the whole timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the second, PCIe-inclusive measurement (never `value`)")
     ap.add_argument("--h2d", action="store_true", help="make the PCIe-inclusive variant the timed loop (NOT the headline value)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)
     cfg = CONFIGS[args.config]
     W, H, NFEAT, LAP, kind = cfg["W"], cfg["H"], cfg["nf"], cfg["lap"], cfg["kind"]
     paired = kind in ("stereo", "fisheye")
@@ -169,20 +197,28 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1 or os.environ.get("ORBX_BENCH_FORCE_DIST") == "1":    # the env switch lets a 1-GPU box exercise the torch.distributed path
+    if world > 1 or args.allgather or os.environ.get("ORBX_BENCH_FORCE_DIST") == "1":    # the env switch lets a 1-GPU box exercise the torch.distributed path
         import torch
         import torch.distributed as dist_
         # ORBX_BENCH_BACKEND=gloo: test switch - several ranks may then share one GPU (RCCL refuses that) or run without one (ORBX_BENCH_LIB), which
         # lets a box without 8 GPUs run the multi-process path end to end; the barrier and the max-reduce go over CPU tensors in that case
         backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")
+        kw = {}
+        if "WORLD_SIZE" not in os.environ:              # --allgather in a plain process: a one-rank group on a free local port
+            import socket
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1])); sk.close()
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            kw = dict(rank=0, world_size=1)
         if backend == "nccl":
             ndev = torch.cuda.device_count()
-            local = local % max(ndev, 1)
-            torch.cuda.set_device(local)
-            dist_.init_process_group("nccl", device_id=torch.device("cuda", local))
+            if ndev < world:
+                raise SystemExit("bench.py: %d ranks but %d visible GPU(s); one process per GPU (ORBX_BENCH_BACKEND=gloo lets ranks share a device in "
+                                 "protocol tests)" % (world, ndev))
+            torch.cuda.set_device(local)                # rank -> GPU: LOCAL_RANK
+            dist_.init_process_group("nccl", device_id=torch.device("cuda", local), **kw)
         else:
             local = 0
-            dist_.init_process_group(backend)
+            dist_.init_process_group(backend, **kw)
         dist = dist_
         dist_dev = "cuda" if backend == "nccl" else "cpu"
 
@@ -192,17 +228,26 @@ def main():
     lib = _lib.OrbxLib(os.environ["ORBX_BENCH_LIB"]) if os.environ.get("ORBX_BENCH_LIB") else load_hip()
     P = args.pairs
     # synthetic inputs shaped like the configuration's dataset; every rank (= camera stream shard) gets its own seeds
+    nat = args.workload == "natural"
     if paired:
         ls, rs = [], []
         for i in range(P):
-            l, r = synth.stereo_pair(W, H, seed=rank * 100003 + i) if kind == "stereo" else synth.stereo_pair(W, H, seed=rank * 100003 + i, nrect=2000, max_disp=24, band=64)
+            sd = rank * 100003 + i
+            if nat:
+                l, r = synth.natural_stereo_pair(W, H, seed=sd) if kind == "stereo" else synth.natural_stereo_pair(W, H, seed=sd, max_disp=24, band=64)
+            else:
+                l, r = synth.stereo_pair(W, H, seed=sd) if kind == "stereo" else synth.stereo_pair(W, H, seed=sd, nrect=2000, max_disp=24, band=64)
             ls.append(l); rs.append(r)
         batch = np.stack(ls + rs)                               # [2P, H, W]: lefts then rights
     elif kind == "mono":
-        batch = np.stack([synth.corner_field(W, H, seed=rank * 100003 + i) for i in range(P)])
+        batch = np.stack([(synth.natural(W, H, seed=rank * 100003 + i) if nat else synth.corner_field(W, H, seed=rank * 100003 + i)) for i in range(P)])
     else:
         nrect = int(3000 * W * H / (752 * 480))
-        batch = np.stack([np.stack([synth.corner_field(W, H, seed=rank * 100003 + i + 7 * c, nrect=nrect) for c in range(3)], axis=2) for i in range(P)])
+        gen = (lambda sd: synth.natural(W, H, seed=sd)) if nat else (lambda sd: synth.corner_field(W, H, seed=sd, nrect=nrect))
+        batch = np.stack([np.stack([gen(rank * 100003 + i + 7 * c) for c in range(3)], axis=2) for i in range(P)])
+    # the statistic the FAST kernel's cost depends on: share of level-0 pixels that are FAST-9/16 corners at minThFAST (first images of the batch)
+    probe = [batch[i] if batch.ndim == 3 else batch[i][..., 1] for i in range(min(4, len(batch)))]
+    fast_density = float(np.mean([synth.fast_corner_density(im, MIN) for im in probe]))
     NIMG = 2 * P if paired else P
     NH = args.handles if args.handles > 0 else (3 if dist is not None else 4)
     handles = [ORBextractor(NFEAT, SCALE, NLEVELS, INI, MIN, device_id=local, lib=lib) for _ in range(NH)]
@@ -277,9 +322,28 @@ def main():
         elif kind == "fisheye":
             lib.check(lib.L.orbm_stereo_fisheye(h._h, 0, h._h, P, P, C.byref(kb)))
 
-    def fetch(i, record):
+    # --allgather (BASELINE.json configs[4]): the descriptor blocks of every finished batch go to all ranks; the collective of batch i runs on a
+    # side stream beside the extraction of the following batches and is waited for when its handle comes round again
+    ag_works = [None] * NH
+    ag_stream = None
+    if args.allgather:
+        from orb_slam3_detailed_comments_amd import multi
+        if dist_dev == "cuda":
+            import torch
+            ag_stream = torch.cuda.Stream()
+
+    def ag_wait(i):
+        if ag_works[i] is not None:
+            for w in ag_works[i][2]:
+                w.wait()
+            ag_works[i] = None
+
+    def fetch(i, record, gather=True):
         h, o = handles[i], out[i]
         lib.check(lib.L.orbx_fetch(h._h, o["k"].ctypes.data, o["d"].ctypes.data, cap, o["n"].ctypes.data, o["m"].ctypes.data))
+        if args.allgather and gather:            # (collective: every rank calls it the same number of times)
+            ag_wait(i)
+            ag_works[i] = multi.all_gather_extracted(h, ag_stream)
         if kind == "stereo":
             lib.check(lib.L.orbm_stereo_fetch(h._h, P, o["u"].ctypes.data, o["z"].ctypes.data, cap, o["nm"].ctypes.data))
         elif kind == "fisheye":
@@ -314,6 +378,8 @@ def main():
             pending.append(i)
         while pending:
             fetch(pending.pop(0), record)
+        for i in range(NH):
+            ag_wait(i)
 
     def sync_all():
         for h in handles:
@@ -324,33 +390,71 @@ def main():
                 torch.cuda.synchronize()
             dist.barrier()
 
-    def timed(nsteps, h2d):
-        run(min(args.warmup, nsteps) if not h2d else min(6, nsteps), False, h2d)
+    def timed(nsteps, h2d, min_seconds=0.0):
+        """W untimed warm-up steps, then ONE timed region of `repeats` whole blocks of nsteps steps between two barriers (repeats = 1 unless the
+        warm-up predicts a region shorter than min_seconds: 20 steps last 30 ms, and four handles' completions bunch differently from run to run).
+        Returns (seconds, completion intervals in ms, repeats)."""
+        nwarm = args.warmup if not h2d else min(6, nsteps)
         sync_all()
+        tw = time.perf_counter()
+        run(nwarm, False, h2d)
+        sync_all()
+        tw = time.perf_counter() - tw
+        repeats = 1
+        if nwarm > 0 and min_seconds > 0:
+            repeats = int(min(max(1, np.ceil(min_seconds / max(tw / nwarm * nsteps, 1e-6))), 10000))
+        if dist is not None:                       # every rank times the same number of steps
+            import torch
+            t = torch.tensor([repeats], dtype=torch.int64, device=dist_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            repeats = int(t.item())
+            sync_all()
         del step_end[:]
         t0 = time.perf_counter()
-        run(nsteps, True, h2d)
+        run(nsteps * repeats, True, h2d)
         sync_all()
         dt = time.perf_counter() - t0
         ends = [t0] + list(step_end)
         per = np.diff(np.array(ends)) * 1e3
-        return dt, per
+        return dt, per, repeats
 
     # setup, not a warm-up step: every handle allocates its device buffers and uploads its tables on first use
     for i in range(NH):
         enqueue(i); fetch(i, False)
     if args.h2d:
         setup_h2d()
-    dt, per_step = timed(args.steps, args.h2d)
+    dt, per_step, repeats = timed(args.steps, args.h2d, args.min_seconds)
     if dist is not None:
         import torch
         t = torch.tensor([dt], dtype=torch.float64, device=dist_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    ag_alone = None
+    if args.allgather:
+        # the exchange by itself: snapshot + both collectives + wait, nothing else running, barrier-bracketed (max over ranks)
+        import torch
+        nrep = 20
+        sync_all()
+        ta = time.perf_counter()
+        for _ in range(nrep):
+            _, _, ws = multi.all_gather_extracted(handles[0], None)
+            for w in ws:
+                w.wait()
+        sync_all()
+        ta = (time.perf_counter() - ta) / nrep
+        t = torch.tensor([ta], dtype=torch.float64, device=dist_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        blk_bytes = NIMG * cap * 32 + NIMG * 4
+        ag_alone = {"ms_per_batch_alone": round(float(t.item()) * 1e3, 4), "bytes_per_rank": blk_bytes, "bytes_gathered_per_rank": blk_bytes * world,
+                    "bus_GBps_per_rank": round(blk_bytes * (world - 1) / max(float(t.item()), 1e-9) / 1e9, 2), "backend": backend,
+                    "where": "side stream, overlapping the next extractions; included in the timed region"}
     if rank == 0:
-        total_units = P * args.steps * world
+        total_units = P * args.steps * repeats * world
         value = total_units / dt
+        # per-block rates of rank 0 (a block = --steps steps): how much `value` depends on where the region starts and ends
+        cum = np.concatenate([[0.0], np.cumsum(per_step)]) * 1e-3          # completion time of step k since the start of the region
+        block_values = [round(P * args.steps / max(cum[(b + 1) * args.steps] - cum[b * args.steps], 1e-9), 1) for b in range(repeats)] if len(per_step) == repeats * args.steps else []
         avg_kp = nkp[0] / max(nkp[1], 1)
         stage_ms = {k: v / max(stage_cnt[0], 1) for k, v in stage_sum.items()}
         n_timed_records = stage_cnt[0]
@@ -372,7 +476,7 @@ def main():
         for _ in range(3):
             enqueue(0)
             if kind in ("stereo", "fisheye"):
-                fetch(0, False)
+                fetch(0, False, gather=False)
             h0.sync()
             for k, v in h0.stage_ms().items():
                 serial_sum[k] = serial_sum.get(k, 0.0) + v / 3.0
@@ -409,13 +513,19 @@ def main():
         res = {
             "metric": cfg["metric"], "value": round(value, 1),
             "unit": cfg["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / (args.steps * repeats) * 1e3, 4), "repeats": repeats, "timed_steps": args.steps * repeats, "timed_seconds": round(dt, 4),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": cfg["workload"], "name": args.config,
                        "units_per_step_per_gpu": P, "images_per_step_per_gpu": NIMG, "outputs_copied_to_host": True, "handles_in_flight": NH,
                        "inputs": "uploaded from pinned host memory inside the timed region (PCIe-inclusive variant)" if args.h2d else "resident in HBM",
                        "avg_keypoints_per_image": round(avg_kp, 1), "avg_matches_per_unit": round(avg_matches, 1),
-                       "parallelism": "independent streams, %d GPU(s), no collective" % world},
+                       "generator": args.workload, "fast_corner_density_t%d" % MIN: round(fast_density, 4),
+                       "library": os.path.basename(lib.path) + (" (ORBX_BENCH_LIB override)" if os.environ.get("ORBX_BENCH_LIB") else ""),
+                       "parallelism": "independent streams, %d GPU(s), one process per GPU, %s" % (world, "all-gather of the descriptor blocks per batch (RCCL)" if args.allgather
+                                                                                                 else "no collective")},
+            "block_values": {"per_block": block_values if len(block_values) <= 64 else block_values[:64], "min": min(block_values) if block_values else None,
+                             "max": max(block_values) if block_values else None},
             # per-step completion intervals of the timed region (rank 0; with several handles in flight a step completes every ms_per_step on average)
             "step_ms": {"median": round(pct(per_step, 50), 4), "p10": round(pct(per_step, 10), 4), "p90": round(pct(per_step, 90), 4), "n": int(len(per_step))},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -424,6 +534,7 @@ def main():
                          "alone_launch_ms": round(serial_sum[dom], 4), "alone_GBps": round(ab[dom] * units[dom] / (serial_sum[dom] * 1e-3) / 1e9, 2),
                          "end_to_end_GBps": round(per_unit_bytes * value / world / 1e9, 2),
                          "end_to_end_frac": round(per_unit_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5), "valu_issue": valu},
+            "allgather": ag_alone,
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_alone": {k: round(v, 4) for k, v in serial_sum.items()},
             # the reference's two instrumented regions (src/Frame.cc:132-146 / :158-170, printed by Tracking::PrintTimeStats), per step, each kernel alone
@@ -437,7 +548,7 @@ def main():
                 for h in handles:
                     h.profile(False)
                 n2 = max(min(args.steps, 100), 10)
-                dt2, per2 = timed(n2, True)
+                dt2, per2, _ = timed(n2, True)
                 res["h2d_inclusive"] = {"value": round(P * n2 / dt2, 1), "unit": cfg["unit"], "steps": n2, "ms_per_step": round(dt2 / n2 * 1e3, 4),
                                         "input_MB_per_step": round(batch.nbytes / 1e6, 1), "PCIe_GBps": round(batch.nbytes * n2 / dt2 / 1e9, 1),
                                         "step_ms": {"median": round(pct(per2, 50), 4), "p10": round(pct(per2, 10), 4), "p90": round(pct(per2, 90), 4)}}
@@ -455,4 +566,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

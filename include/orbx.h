@@ -106,6 +106,14 @@ int orbx_device_upload_async(orbx_extractor* h, void* dptr, const void* host, si
  * zero), n [B], monoIndex [B]; valid until the next extraction / reconfiguration of the handle (synchronise with orbx_sync first).  For
  * consumers that stay on the device, e.g. an RCCL all-gather of the descriptor blocks (orb_slam3_detailed_comments_amd/multi.py). */
 int orbx_device_outputs(orbx_extractor* h, void** kps, void** desc, void** n, void** mono, int* cap, int* B);
+/* A SNAPSHOT of the descriptor blocks and counts of the last batch in device memory the CALLER owns (desc_dst: B * cap * 32 bytes, n_dst: B ints,
+ * either may be NULL): device-to-device copies on the handle's stream behind the extraction, complete when the call returns.  The handle's own
+ * buffers are rewritten by its next extraction, so a consumer that overlaps that extraction (an asynchronous collective) works on a snapshot. */
+int orbx_device_snapshot(orbx_extractor* h, void* desc_dst, void* n_dst);
+/* GPU index the handle was created on; ORBX_DEVICE_HOST when the library's "device" memory is plain host memory (only the CPU emulator build of
+ * the kernel sources that the tests use - the product library never returns it) */
+#define ORBX_DEVICE_HOST (-1)
+int orbx_device_id(const orbx_extractor* h);
 /* page-locked host memory for output buffers: with cap == orbx_max_keypoints() orbx_fetch / orbm_stereo_fetch copy straight
  * into the caller's arrays (no staging, no repacking) and pinned memory makes that copy run at PCIe speed */
 int orbx_host_alloc(orbx_extractor* h, size_t bytes, void** hptr);

@@ -243,7 +243,6 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
     const int nl = h->nlevels;
     const dim3 blk2(64, 4, 1), blk1(256, 1, 1);
     rt::memset_async(h->d_status.p, 0, 4 * sizeof(int), h->s0);     // the quadtree's capacity flag is per batch, not per handle
-    if (h->copy_pending) { rt::stream_wait_event(h->s0, h->ev_copy); h->copy_pending = false; }   // input uploaded by orbx_device_upload_async
     rt::memset_async(h->d_desc.p, 0, (size_t)B * h->kp_total_cap * 32, h->s0);   // descriptor rows beyond n[b] read as zero (fixed-shape blocks for collectives)
     stage_begin(h, ST_IMPORT, h->s0);
     if (h->in_active && (h->in_channels != 1 || h->in_geometry != 0)) enqueue_input(h, B, d_images, src_w, src_h, stride, image_stride);
@@ -459,11 +458,16 @@ int orbx_extract_batch(orbx_extractor* h, int B, const uint8_t* images, int widt
         if (rt::copy_h2d(h->d_stage.p, images, bytes, h->s0)) return fail(ORBX_E_DEVICE, "H2D copy failed: %s", rt::last_error());
         d_images = h->d_stage.p;
     }
+    // input uploaded by orbx_device_upload_async: the extraction (eager or replayed) starts behind it
+    if (h->copy_pending) {
+        if (rt::stream_wait_event(h->s0, h->ev_copy)) return fail(ORBX_E_DEVICE, "extraction could not be ordered behind the input upload: %s", rt::last_error());
+        h->copy_pending = false;
+    }
 #ifndef ORBX_EMU
     // hipGraph replay of the whole extraction (import, 7 dependent resize launches, FAST, quadtree, blur on the second stream,
     // layout, orient+BRIEF): at small batches the ~17 launches are launch/latency-bound.  The graph is keyed on everything that
     // is baked into the kernel arguments and re-captured when any of it changes.
-    if (h->use_graph && !h->profile && !h->in_active && !h->copy_pending) {      // (a pending async upload is a dependency outside the graph)
+    if (h->use_graph && !h->profile && !h->in_active) {
         const bool same = h->graph_exec && h->g_B == B && h->g_images == d_images && h->g_stride == stride && h->g_image_stride == image_stride &&
                           h->g_lap0 == lap0 && h->g_lap1 == lap1 && h->g_W == h->W && h->g_H == h->H && h->g_pyr == h->d_pyr.p && h->g_gauss == h->gauss_variant;
         if (!same) {
@@ -480,6 +484,9 @@ int orbx_extract_batch(orbx_extractor* h, int B, const uint8_t* images, int widt
             h->g_W = h->W; h->g_H = h->H; h->g_pyr = h->d_pyr.p; h->g_gauss = h->gauss_variant;
         }
         if (hipGraphLaunch(h->graph_exec, h->s0) != hipSuccess) return fail(ORBX_E_DEVICE, "graph launch failed: %s", rt::last_error());
+        // the records inside the capture belong to the graph; these are the ones other streams can wait on (an upload into the input buffer
+        // waits for ev_import: after a replay that is the end of the whole graph, which is later than needed but never too early)
+        rt::event_record(h->ev_import, h->s0);
         rt::event_record(h->ev_done, h->s0);
         h->lastB = B;
         return ORBX_OK;
@@ -606,7 +613,7 @@ int orbx_device_upload(orbx_extractor* h, void* dptr, const void* host, size_t b
 int orbx_device_upload_async(orbx_extractor* h, void* dptr, const void* host, size_t bytes) {
     if (!h || !dptr || !host) return fail(ORBX_E_ARG, "null");
     rt::set_device(h->device);
-    rt::stream_wait_event(h->s_copy, h->ev_import);
+    if (h->lastB > 0 && rt::stream_wait_event(h->s_copy, h->ev_import)) return fail(ORBX_E_DEVICE, "upload could not be ordered behind the previous extraction: %s", rt::last_error());
     if (rt::copy_h2d(dptr, host, bytes, h->s_copy) || rt::event_record(h->ev_copy, h->s_copy)) return fail(ORBX_E_DEVICE, "upload failed: %s", rt::last_error());
     h->copy_pending = true;
     return ORBX_OK;
@@ -658,6 +665,17 @@ int orbx_device_outputs(orbx_extractor* h, void** kps, void** desc, void** n, vo
     if (B) *B = h->lastB;
     return ORBX_OK;
 }
+
+int orbx_device_snapshot(orbx_extractor* h, void* desc_dst, void* n_dst) {
+    if (!h || h->lastB <= 0) return fail(ORBX_E_ARG, "nothing extracted yet");
+    rt::set_device(h->device);
+    int e = 0;
+    if (desc_dst) e |= rt::copy_d2d(desc_dst, h->d_desc.p, (size_t)h->lastB * h->kp_total_cap * 32, h->s0);
+    if (n_dst) e |= rt::copy_d2d(n_dst, h->d_nm.p, sizeof(int) * (size_t)h->lastB, h->s0);
+    if (e || rt::stream_sync(h->s0)) return fail(ORBX_E_DEVICE, "snapshot failed: %s", rt::last_error());
+    return ORBX_OK;
+}
+int orbx_device_id(const orbx_extractor* h) { return h ? (rt::memory_is_host() ? ORBX_DEVICE_HOST : h->device) : ORBX_E_ARG; }
 
 int orbx_set_graph_replay(orbx_extractor* h, int on) { if (!h) return ORBX_E_ARG; h->use_graph = on != 0; return ORBX_OK; }
 

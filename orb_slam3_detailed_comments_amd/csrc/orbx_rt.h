@@ -13,6 +13,7 @@ struct event_s { double t; };
 typedef event_s* event_t;
 inline double now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 inline int set_device(int) { return 0; }
+inline bool memory_is_host() { return true; }
 inline int device_count() { return 1; }
 inline void* dmalloc(size_t n) { return calloc(n ? n : 1, 1); }
 inline void dfree(void* p) { free(p); }
@@ -48,6 +49,7 @@ inline hipError_t& last_code() { static thread_local hipError_t e = hipSuccess; 
 inline int hip_ok(hipError_t e) { if (e == hipSuccess) return 0; last_code() = e; (void)hipGetLastError(); return -1; }
 #define ORBX_HIP_OK(x) ::orbx::rt::hip_ok(x)
 inline int set_device(int d) { return ORBX_HIP_OK(hipSetDevice(d)); }
+inline bool memory_is_host() { return false; }
 inline int device_count() { int n = 0; if (hip_ok(hipGetDeviceCount(&n))) return 0; return n; }
 inline void* dmalloc(size_t n) { void* p = nullptr; if (hip_ok(hipMalloc(&p, n ? n : 1))) return nullptr; return p; }
 inline void dfree(void* p) { if (p) (void)hip_ok(hipFree(p)); }

@@ -2,8 +2,6 @@
 s % world, no collective on the data path.  The only exchange is the OPTIONAL all-gather of fixed-shape descriptor blocks
 ([B, cap, 32] u8 + [B] counts) for a global matcher; it goes through torch.distributed (backend "nccl" = RCCL over xGMI on the
 GPUs, "gloo" in the CPU tests)."""
-import os
-
 import numpy as np
 
 
@@ -35,38 +33,33 @@ def all_gather_descriptors(desc, counts, device=None):
     return torch.stack(dl).cpu().numpy(), torch.stack(cl).cpu().numpy()
 
 
-class _DevArray:
-    """__cuda_array_interface__ view of device memory owned by an extractor handle (zero-copy into torch)"""
-
-    def __init__(self, ptr, shape, typestr):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
-
-
 def extracted_blocks(extractor):
-    """The extractor's device-resident results of the last batch as tensors WITHOUT a copy: (desc [B, cap, 32] u8 with zero rows beyond the
-    count, counts [B] i32).  On the GPU build these alias HBM (torch.as_tensor over __cuda_array_interface__); on the CPU emulator build of
-    the tests they alias host memory."""
+    """A snapshot of the extractor's device-resident results of the last batch as tensors the CALLER owns: (desc [B, cap, 32] u8 with zero
+    rows beyond the count, counts [B] i32), on the extractor's own GPU (orbx_device_id - not torch's current device).  The copy is device to
+    device on the handle's stream behind the extraction and complete on return (orbx_device_snapshot), so the handle may start its next
+    extraction - which clears and rewrites its descriptor buffer - while a collective still reads these tensors.  (The library of the CPU tests
+    reports ORBX_DEVICE_HOST: its "device" memory is host memory and the tensors are CPU tensors.)"""
     import ctypes as C
     import torch
     L = extractor._lib
-    desc = C.c_void_p(); n = C.c_void_p(); cap = C.c_int(); B = C.c_int()
-    L.check(L.L.orbx_device_outputs(extractor._h, None, C.byref(desc), C.byref(n), None, C.byref(cap), C.byref(B)))
-    extractor.sync()
-    if "emu" in os.path.basename(L.path):
-        d = np.ctypeslib.as_array(C.cast(desc.value, C.POINTER(C.c_uint8)), shape=(B.value, cap.value, 32))
-        c = np.ctypeslib.as_array(C.cast(n.value, C.POINTER(C.c_int32)), shape=(B.value,))
-        return torch.from_numpy(d), torch.from_numpy(c)
-    dev = torch.device("cuda", torch.cuda.current_device())
-    return (torch.as_tensor(_DevArray(desc.value, (B.value, cap.value, 32), "|u1"), device=dev),
-            torch.as_tensor(_DevArray(n.value, (B.value,), "<i4"), device=dev))
+    cap = C.c_int(); B = C.c_int()
+    L.check(L.L.orbx_device_outputs(extractor._h, None, None, None, None, C.byref(cap), C.byref(B)))
+    dev_id = L.L.orbx_device_id(extractor._h)
+    dev = torch.device("cpu") if dev_id < 0 else torch.device("cuda", dev_id)
+    d = torch.empty((B.value, cap.value, 32), dtype=torch.uint8, device=dev)
+    c = torch.empty((B.value,), dtype=torch.int32, device=dev)
+    if dev_id >= 0:
+        torch.cuda.current_stream(dev).synchronize()        # the allocator may hand out memory that work queued on torch's stream still uses
+    L.check(L.L.orbx_device_snapshot(extractor._h, d.data_ptr(), c.data_ptr()))
+    return d, c
 
 
 def all_gather_extracted(extractor, side_stream=None):
-    """All-gather of the descriptor blocks of the last batch straight from the extractor's device buffers: one collective for the
-    descriptors, one for the counts (RCCL over xGMI with backend "nccl"), no host bounce.  Returns (desc_all [world, B, cap, 32], counts_all
-    [world, B]) as tensors on the extractor's device and the work handles; with `side_stream` (a torch.cuda.Stream) the collectives are
-    issued there with async_op=True so that the next extraction - which runs on the handle's own HIP streams - overlaps them; call
-    .wait() on the handles before reading."""
+    """All-gather of the descriptor blocks of the last batch from the device: a device-to-device snapshot (extracted_blocks), then one collective
+    for the descriptors and one for the counts (RCCL over xGMI with backend "nccl"), no host bounce.  Returns (desc_all [world, B, cap, 32],
+    counts_all [world, B]) as tensors on the extractor's device and the work handles; with `side_stream` (a torch.cuda.Stream) the collectives
+    are issued there with async_op=True so that the next extraction - which runs on the handle's own HIP streams and rewrites the handle's
+    buffers - overlaps them; call .wait() on the handles before reading."""
     import contextlib
     import torch
     import torch.distributed as dist
@@ -76,8 +69,10 @@ def all_gather_extracted(extractor, side_stream=None):
     dall = torch.empty((world * B,) + tuple(d.shape[1:]), dtype=d.dtype, device=d.device); call = torch.empty((world * B,), dtype=c.dtype, device=c.device)
     ctx = torch.cuda.stream(side_stream) if (side_stream is not None and d.is_cuda) else contextlib.nullcontext()
     with ctx:
-        w1 = dist.all_gather_into_tensor(dall, d.contiguous(), async_op=True)      # rank r's block lands at rows [r * B, (r + 1) * B)
-        w2 = dist.all_gather_into_tensor(call, c.contiguous(), async_op=True)
+        if side_stream is not None and d.is_cuda:
+            d.record_stream(side_stream); c.record_stream(side_stream); dall.record_stream(side_stream); call.record_stream(side_stream)
+        w1 = dist.all_gather_into_tensor(dall, d, async_op=True)      # rank r's block lands at rows [r * B, (r + 1) * B)
+        w2 = dist.all_gather_into_tensor(call, c, async_op=True)
     return dall.view((world, B) + tuple(d.shape[1:])), call.view(world, B), (w1, w2)
 
 

@@ -113,3 +113,74 @@ def periodic_stereo_pair(w=752, h=480, seed=0, period=(48, 240), disparity=17, n
     scene = np.tile(tile, reps)
     cv = lambda a: np.clip(np.rint(a), 0, 255).astype(np.uint8)
     return cv(scene[:h, :w]), cv(scene[:h, disparity:disparity + w])
+
+
+def _natural_scene(rng, w, h, beta, contrast, nedge, noise):
+    """float scene: 1/f^beta Gaussian field + a sparse set of occluding polygons (step edges with corners, like furniture / window frames)
+    + sensor noise"""
+    fy = np.fft.fftfreq(h)[:, None]; fx = np.fft.rfftfreq(w)[None, :]
+    f = np.sqrt(fx * fx + fy * fy); f[0, 0] = 1.0
+    spec = (rng.standard_normal((h, w // 2 + 1)) + 1j * rng.standard_normal((h, w // 2 + 1))) / f ** beta
+    spec[0, 0] = 0.0
+    img = np.fft.irfft2(spec, s=(h, w))
+    img = 120.0 + contrast * (img - img.mean()) / (img.std() + 1e-12)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for _ in range(nedge):
+        # a rotated rectangle with its own brightness offset and a little texture of its own
+        cx, cy = rng.uniform(0, w), rng.uniform(0, h)
+        a, b = rng.uniform(10, 90), rng.uniform(10, 90)
+        th = rng.uniform(0, np.pi)
+        u = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th); v = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+        m = (np.abs(u) < a) & (np.abs(v) < b)
+        img[m] += rng.choice([-1.0, 1.0]) * rng.uniform(12, 70)
+    return img + rng.normal(0, noise, (h, w))
+
+
+def natural(w=752, h=480, seed=0, beta=2.0, contrast=38.0, nedge=100, noise=1.5):
+    """Camera-like image: 1/f^2 amplitude spectrum (power spectrum 1/f^4 is too smooth; natural images sit near amplitude 1/f - 1/f^2 over the
+    band FAST looks at), sparse occluding rectangles at random orientations, mild sensor noise.  1-5 % of the pixels are FAST-9/16 corners at
+    t = 7 (synth.fast_corner_density), an order of magnitude fewer than corner_field - the density regime of EuRoC-like imagery."""
+    rng = np.random.default_rng(0x4A70 + seed)
+    return np.clip(np.rint(_natural_scene(rng, w, h, beta, contrast, int(nedge * w * h / (752 * 480)), noise)), 0, 255).astype(np.uint8)
+
+
+def natural_stereo_pair(w=752, h=480, seed=0, band=48, max_disp=60, **kw):
+    """Rectified pair with natural() statistics: one wider scene, the right view shifted by a per-band disparity, independent noise per view."""
+    rng = np.random.default_rng(0x4A71 + seed)
+    pad = max_disp + 4
+    noise = kw.pop("noise", 1.5)
+    scene = _natural_scene(rng, w + pad, h, kw.pop("beta", 2.0), kw.pop("contrast", 38.0), int(kw.pop("nedge", 100) * (w + pad) * h / (752 * 480)), 0.0)
+    nb = (h + band - 1) // band
+    disp = rng.integers(2, max_disp + 1, nb)
+    left = scene[:, :w].copy(); right = np.empty_like(left)
+    for k in range(nb):
+        y0, y1 = k * band, min((k + 1) * band, h)
+        d = int(disp[k])
+        right[y0:y1] = scene[y0:y1, d:d + w]
+    cv = lambda a: np.clip(np.rint(a + rng.normal(0, noise, a.shape)), 0, 255).astype(np.uint8)
+    return cv(left), cv(right)
+
+
+_RING = ((0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3))
+
+
+def fast_corner_density(img, t=7):
+    """Fraction of the pixels (3-px border excluded) that are FAST-9/16 corners at threshold t, before non-maximum suppression: the workload
+    statistic the FAST kernel's cost depends on (numpy, the segment test as defined; not used by any product path)."""
+    a = img.astype(np.int16)
+    h, w = a.shape
+    c = a[3:h - 3, 3:w - 3]
+    br = np.stack([a[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx] > c + t for dx, dy in _RING])
+    dk = np.stack([a[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx] < c - t for dx, dy in _RING])
+
+    def arc9(m):
+        m2 = np.concatenate([m, m[:8]])
+        run = np.ones_like(m[0])
+        acc = np.zeros_like(m[0])
+        for s in range(16):
+            run = m2[s].copy()
+            for k in range(1, 9):
+                run &= m2[s + k]
+            acc |= run
+        return acc
+    return float((arc9(br) | arc9(dk)).mean())

@@ -30,3 +30,35 @@ def test_bench_two_ranks_gloo(emu_lib):
     assert res["roofline"]["kernel"] in res["stage_ms_alone"] and res["roofline"]["avg_launch_ms"] > 0
     assert "cpu_baseline" not in res and "h2d_inclusive" not in res          # rank-0 / N = 1 extras only
     assert res["config"]["parallelism"].startswith("independent streams, 2 GPU")
+
+
+def test_bench_launches_its_own_ranks(emu_lib):
+    """`python bench.py --gpus 2` WITHOUT a launcher must start two ranks itself (round-2 review: the flag was parsed and ignored), print
+    n_gpus = 2, say which library produced the line, and with --allgather carry the collective's own time (BASELINE.json configs[4])."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(ORBX_BENCH_BACKEND="gloo", ORBX_BENCH_LIB=os.path.join(ROOT, "tests", "emu", "liborbx_emu.so"), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "1", "--handles", "1", "--no-cpu-baseline",
+           "--allgather", "--min-seconds", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0): %r" % r.stdout[-1000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["repeats"] == 1 and res["timed_steps"] == 2
+    assert res["config"]["library"].startswith("liborbx_emu.so") and "override" in res["config"]["library"]
+    ag = res["allgather"]
+    assert ag["backend"] == "gloo" and ag["ms_per_batch_alone"] > 0 and ag["bytes_gathered_per_rank"] == 2 * ag["bytes_per_rank"]
+    assert "all-gather" in res["config"]["parallelism"] and 0.0 < res["config"]["fast_corner_density_t7"] < 1.0
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """with the RCCL backend one process per GPU is the rule: asking for more GPUs than the node shows is an error, not a silent 1-GPU run"""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "ORBX_BENCH_BACKEND"):
+        env.pop(k, None)
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(max(n, 2))], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert r.returncode != 0 and "one process per GPU" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())
