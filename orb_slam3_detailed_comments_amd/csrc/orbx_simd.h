@@ -77,6 +77,7 @@ __device__ __forceinline__ pk2 pk_max3(pk2 a, pk2 b, pk2 c) { return pk_max(pk_m
 __device__ __forceinline__ pk2 pk_bytes(const uint8_t* a, const uint8_t* b) { pk2 r; r.x = (short)*a; r.y = (short)*b; return r; }
 __device__ __forceinline__ pk2 pk_xor_or(pk2 a, uint32_t x, uint32_t o) { return pk_make((((uint32_t)(uint16_t)a.x | ((uint32_t)(uint16_t)a.y << 16)) ^ x) | o); }
 __device__ __forceinline__ pk2 pk_xor(pk2 a, uint32_t x) { return pk_make(((uint32_t)(uint16_t)a.x | ((uint32_t)(uint16_t)a.y << 16)) ^ x); }
+__device__ __forceinline__ uint32_t pk_bits(pk2 a) { return (uint32_t)(uint16_t)a.x | ((uint32_t)(uint16_t)a.y << 16); }
 #else
 typedef short pk2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ pk2 pk_make(uint32_t v) { return __builtin_bit_cast(pk2, v); }
@@ -96,6 +97,7 @@ __device__ __forceinline__ pk2 pk_max3(pk2 a, pk2 b, pk2 c) { pk2 d; asm("v_pk_m
 __device__ __forceinline__ pk2 pk_bytes(const uint8_t* a, const uint8_t* b) { return __builtin_bit_cast(pk2, (uint32_t)*a | ((uint32_t)*b << 16)); }   // v_lshl_or_b32 (full rate; v_perm_b32 is not)
 __device__ __forceinline__ pk2 pk_xor_or(pk2 a, uint32_t x, uint32_t o) { return __builtin_bit_cast(pk2, (__builtin_bit_cast(uint32_t, a) ^ x) | o); }
 __device__ __forceinline__ pk2 pk_xor(pk2 a, uint32_t x) { return __builtin_bit_cast(pk2, __builtin_bit_cast(uint32_t, a) ^ x); }
+__device__ __forceinline__ uint32_t pk_bits(pk2 a) { return __builtin_bit_cast(uint32_t, a); }
 #endif
 constexpr int kPixBias = 0x6400;     // pixel value b is carried as 0x6400 + b (binary16 1024 + b)
 

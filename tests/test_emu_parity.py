@@ -154,3 +154,14 @@ def test_unusual_pyramids_with_stereo(emu_lib):
         N = len(eL[1])
         assert n[0] == no and np.array_equal(u[0, :N].view(np.uint32), uo.view(np.uint32)) and np.array_equal(d[0, :N].view(np.uint32), do.view(np.uint32)), (nf, sf, nl)
         assert no > 20
+
+
+@pytest.mark.parametrize("ini,mn", [(0, 0), (1, 1), (20, 0), (7, 20), (2, 1), (130, 128), (254, 1), (255, 255), (90, 89)])
+def test_extreme_fast_thresholds(emu_lib, ini, mn):
+    """thresholds at the ends of the byte range, minTh above iniTh, threshold 0 (every pixel takes both polarities in k_fast_cells) - against the
+    oracle and the reference build"""
+    for img in (synth.uniform_noise(200, 180, seed=77), synth.corner_field(260, 200, seed=78, nrect=300)):
+        got = ORBextractor(200, 1.2, 4, ini, mn, lib=emu_lib)(img)
+        assert _same(got, ol.OracleExtractor(200, 1.2, 4, ini, mn, 0).extract(img)), (ini, mn)
+        if ol.reference() is not None:
+            assert _same(got, ol.ReferenceExtractor(200, 1.2, 4, ini, mn, 0).extract(img)), (ini, mn)
