@@ -274,6 +274,29 @@ int orbm_search_local_points_resident(orbx_extractor* h, const OrbmFrameView* F,
                                       const uint8_t* is_bad, const uint8_t* has_obs, float viewing_cos_limit, float th, int far_points, float th_far,
                                       float nnratio, const OrbmTrackOut* out, int* assigned, int* nmatches);
 
+/* Frame::ComputeStereoFromRGBD (src/Frame.cc:1361-1391) for frames [first, first + B) of the handle's last extraction: mvDepth[i] = the depth
+ * image (CV_32F, already scaled by Tracking::mDepthMapFactor, src/Tracking.cc:1617-1618) at the keypoint, mvuRight[i] = x - mbf / d where d > 0,
+ * both -1 elsewhere.  depth image b at depth + b * image_stride, rows `stride` floats apart (host memory, or device memory of this GPU).
+ * Keypoints are taken as undistorted (mvKeysUn = mvKeys: rectified / distortion-free input).  Results like orbm_stereo_match's: fetch with
+ * orbm_stereo_fetch (n_matches = keypoints with a depth), or leave them on the device for orbm_search_local_points_batch.  Asynchronous. */
+int orbm_stereo_from_depth(orbx_extractor* h, int first, int B, const float* depth, int stride, size_t image_stride, int depth_on_device, float mbf);
+
+/* Tracking::SearchLocalPoints (src/Tracking.cc:3979-4067 -> Frame::isInFrustum src/Frame.cc:667-773 + ORBmatcher::SearchByProjection
+ * src/ORBmatcher.cc:45-167) for a BATCH of frames without leaving the device: frames = images [first, first + B) of the handle's last
+ * extraction, read where the extractor left them (mvKeysUn = the extracted keypoints, mDescriptors; mvuRight = the results of
+ * orbm_stereo_match / orbm_stereo_from_depth for the same range when use_u_right != 0, else every keypoint is monocular); frames[b] = pose,
+ * camera and bounds of frame b (the grid constants are derived from the bounds as Frame does, src/Frame.cc:190-191); the local map is resident
+ * (orbm_points); is_bad / has_obs: call-time flags of the M points (NULL = none bad / all observed); occupied: [B][orbx_max_keypoints()] bytes,
+ * keypoints that already hold a map point with observations (NULL = none).  The sequential accept loop of the reference (a keypoint that has
+ * received a point is skipped by every later point) runs on the device, one wave per frame.  Asynchronous; orbm_search_local_points_fetch
+ * returns assigned [B][cap] (index of the map point written to F.mvpMapPoints[i], -1 = untouched), the reference's return value per frame
+ * and - when requested here - mbTrackInView [B][M].  ORBX_E_CAPACITY from the fetch = the candidate pool was too small for this scene: it has
+ * been enlarged, enqueue the same call again. */
+int orbm_search_local_points_batch(orbx_extractor* h, int first, int B, const OrbmFrustumView* frames, const orbm_points* points,
+                                   const uint8_t* is_bad, const uint8_t* has_obs, const uint8_t* occupied, int use_u_right,
+                                   float viewing_cos_limit, float th, int far_points, float th_far, float nnratio, int want_in_view);
+int orbm_search_local_points_fetch(orbx_extractor* h, int* assigned, int cap, int* nmatches, uint8_t* in_view);
+
 /* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBmatcher.cc:1950-2184).
  * forward/backward = bForward/bBackward (:1973-1975, computed from the two poses by the caller).
  * assigned[i] = index into LastFrame of the point written to CurrentFrame.mvpMapPoints[i]; -1 untouched;

@@ -6,7 +6,12 @@
 #include <cstdint>
 #include <cstring>
 #include <vector>
+#include <map>
+#include <mutex>
+#include <set>
+#define protected public    // the driver sets MapPoint::mfMaxDistance for the PredictScale probe (access specifiers do not change the layout)
 #include "MapPoint.h"       // the reference header, via -I/root/reference/include
+#undef protected
 
 using namespace ORB_SLAM3;
 
@@ -50,6 +55,21 @@ void ref_mp_distinctive(const uint8_t* desc, const int* start, const uint8_t* ri
         delete mp;
         delete[] kfs;
     }
+}
+
+// MapPoint::PredictScale(currentDist, Frame*) of the reference's own src/MapPoint.cc:714-731 for n (max_distance, distance) pairs: pins which
+// log the reference calls (std::log(float): the translation unit is `using namespace std`) for the device's k_frustum / k_project_points.
+void ref_mp_predict_scale(const float* max_dist, const float* dist, int n, float log_scale_factor, int nlevels, int* out) {
+    Map map;
+    KeyFrame ref_kf;
+    Frame F;
+    F.mfLogScaleFactor = log_scale_factor; F.mnScaleLevels = nlevels;
+    MapPoint* mp = new MapPoint(Eigen::Vector3f(0, 0, 1), &ref_kf, &map);
+    for (int i = 0; i < n; i++) {
+        mp->mfMaxDistance = max_dist[i];
+        out[i] = mp->PredictScale(dist[i], &F);
+    }
+    delete mp;
 }
 
 }  // extern "C"

@@ -202,7 +202,9 @@ public:
     float GetMaxDistanceInvariance() { return 1.2f * maxDist; }
     template <class T> int PredictScale(const float& currentDist, T* pF) {  // src/MapPoint.cc:688-731
         float ratio = maxDist / currentDist;
-        int nScale = ceil(log(ratio) / pF->mfLogScaleFactor);
+        // the reference's translation unit is `using namespace std`: log(float) is std::log(float) = logf, the division and ceil are float
+        // (pinned against the reference's own MapPoint.cc by tests/test_models.py::test_predict_scale_uses_float_log)
+        int nScale = std::ceil(std::log(ratio) / pF->mfLogScaleFactor);
         if (nScale < 0) nScale = 0;
         else if (nScale >= pF->mnScaleLevels) nScale = pF->mnScaleLevels - 1;
         return nScale;

@@ -15,6 +15,7 @@
 #include "orbx_block.h"
 #include "orbx_kernels.h"
 #include "kb8_model.h"
+#include "glibc_logf_model.h"
 
 namespace orbx {
 
@@ -24,9 +25,16 @@ constexpr int kGridCols = 64, kGridRows = 48;   // FRAME_GRID_COLS / FRAME_GRID_
 // grid (1), kGridThreads threads.  cell_of: scratch [N] ints.  cell_start: [64*48+1].  Cell id = ix*48 + iy.
 // One workgroup because the histogram and the cursors live in LDS; 1024 threads so that a frame's keypoints take one trip per step (the
 // kernel is a chain of dependent round trips, not work).
+// Batched form (grid = B frames of an extractor's device-resident outputs): n_per_frame != NULL gives N per frame and frame b's arrays sit at
+// kps + b * frame_stride, cell_of / cell_items + b * frame_stride, cell_start + b * kGridCellStride.
 __global__ void __launch_bounds__(kGridThreads) k_grid_build(const KeyPointRec* __restrict__ kps, int N, GridParams g,
                                                              int* __restrict__ cell_of, int* __restrict__ cell_start,
-                                                             int* __restrict__ cell_items) {
+                                                             int* __restrict__ cell_items, const int* __restrict__ n_per_frame, int frame_stride) {
+    if (n_per_frame) {
+        const size_t b = blockIdx.x;
+        N = n_per_frame[b]; kps += b * (size_t)frame_stride; cell_of += b * (size_t)frame_stride; cell_items += b * (size_t)frame_stride;
+        cell_start += b * (size_t)kGridCellStride;
+    }
     __shared__ int s_hist[kGridCols * kGridRows];
     __shared__ int s_chunk[256];
     __shared__ unsigned long long s_scan[20];
@@ -156,10 +164,18 @@ __global__ void __launch_bounds__(64 * kAreaWaves) k_area_search(const AreaQuery
                                                      const unsigned long long* __restrict__ fdesc, GridParams g,
                                                      const int* __restrict__ cell_start, const int* __restrict__ cell_items,
                                                      int gate_right, int* __restrict__ pool_counter, int pool_cap,
-                                                     int* __restrict__ q_start, int* __restrict__ q_count, int2* __restrict__ entries) {
+                                                     int* __restrict__ q_start, int* __restrict__ q_count, int2* __restrict__ entries, int frame_stride) {
     __shared__ int s_cnt[kAreaWaves], s_base;
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     const int q = (int)blockIdx.x * kAreaWaves + wave;
+    if (frame_stride > 0) {
+        // batched form: blockIdx.y = frame; every frame has its own Q queries against its own keypoints / grid; the query descriptors (map
+        // points) and the entry pool are shared
+        const size_t b = blockIdx.y;
+        queries += b * (size_t)Q; q_start += b * (size_t)Q; q_count += b * (size_t)Q;
+        kps += b * (size_t)frame_stride; u_right += b * (size_t)frame_stride; fdesc += 4 * b * (size_t)frame_stride;
+        cell_start += b * (size_t)kGridCellStride; cell_items += b * (size_t)frame_stride;
+    }
     AreaQuery A{};
     if (q < Q) A = queries[q];
     int cnt_total = 0, start = 0;
@@ -230,13 +246,23 @@ __global__ void __launch_bounds__(64 * kAreaWaves) k_area_search(const AreaQuery
 // in the reference's fp32 operation order (Eigen's 3x3 * 3x1 is sum-of-products left to right; no fused multiply-adds).  Writes the tracking
 // fields the reference stores in the MapPoint (mbTrackInView, mTrackProjX / Y / XR, mTrackDepth, mnTrackScaleLevel, mTrackViewCos) and,
 // when `queries` is given, the window query of ORBmatcher::SearchByProjection(Frame, MapPoints) for that point (src/ORBmatcher.cc:53-82).
+// Batched form: Fbatch != NULL -> blockIdx.y = frame, frame b uses Fbatch[b] and writes at offsets b * M (track: b * 5 * M).
+// F.rig_mode (Frame::isInFrustumChecks, src/Frame.cc:1592-1650, one camera of a two-camera rig; the caller passes that camera's mR, mt, twc
+// and parameters): nothing is stored unless the point passes every test, and the level of a rejected point is -1 (:756-757).
 __global__ void __launch_bounds__(256) k_frustum(FrustumParams F, int M, const float* __restrict__ pos, const float* __restrict__ normal,
                                                  const float* __restrict__ min_dist, const float* __restrict__ max_dist, const uint8_t* __restrict__ is_bad,
                                                  uint8_t* __restrict__ in_view, float* __restrict__ track /* [6][M]: x, y, xr, depth, cos, - */,
-                                                 int* __restrict__ scale_level, AreaQuery* __restrict__ queries, int* __restrict__ zero4) {
+                                                 int* __restrict__ scale_level, AreaQuery* __restrict__ queries, int* __restrict__ zero4,
+                                                 const FrustumParams* __restrict__ Fbatch) {
     const int i = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (zero4 && i < 4) zero4[i] = 0;                             // the pool counter of the window search that follows (saves a fill launch)
+    if (zero4 && i < 4 && blockIdx.y == 0) zero4[i] = 0;          // the pool counter of the window search that follows (saves a fill launch)
     if (i >= M) return;
+    if (Fbatch) {
+        const size_t b = blockIdx.y;
+        F = Fbatch[b];
+        in_view += b * (size_t)M; track += 5 * b * (size_t)M; scale_level += b * (size_t)M;
+        if (queries) queries += b * (size_t)M;
+    }
     const float P0 = pos[3 * i], P1 = pos[3 * i + 1], P2 = pos[3 * i + 2];
     bool ok = true;
     float u = -1.0f, v = -1.0f, xr = 0.0f, depth = 0.0f, vcos = 0.0f; int lvl = 0;
@@ -258,7 +284,7 @@ __global__ void __launch_bounds__(256) k_frustum(FrustumParams F, int M, const f
         if (ok && (vv < F.min_y || vv > F.max_y)) ok = false;
     }
     if (ok) {
-        u = uu; v = vv;                                               // mTrackProjX / Y are set before the distance tests (:705-706)
+        if (!F.rig_mode) { u = uu; v = vv; }                          // mTrackProjX / Y are set before the distance tests (:705-706)
         const float maxDistance = __fmul_rn(1.2f, max_dist[i]), minDistance = __fmul_rn(0.8f, min_dist[i]);     // MapPoint.cc:658-671
         const float o0 = __fsub_rn(P0, F.Ow[0]), o1 = __fsub_rn(P1, F.Ow[1]), o2 = __fsub_rn(P2, F.Ow[2]);
         const float dist = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(o0, o0), __fmul_rn(o1, o1)), __fmul_rn(o2, o2)));
@@ -269,17 +295,20 @@ __global__ void __launch_bounds__(256) k_frustum(FrustumParams F, int M, const f
             if (vcos < F.cos_limit) ok = false;
         }
         if (ok) {
-            const float ratio = __fdiv_rn(max_dist[i], dist);                                                      // PredictScale
-            int n = (int)ceil(log((double)ratio) / (double)F.log_scale_factor);
+            // MapPoint::PredictScale (src/MapPoint.cc:714-731): ceil(log(ratio) / mfLogScaleFactor) in FLOAT - std::log(float) = glibc's logf
+            // (glibc_logf_model.h, checked against the live libm for every positive float), float division, ceil(float)
+            const float ratio = __fdiv_rn(max_dist[i], dist);
+            int n = (int)ceilf(__fdiv_rn(glibc_logf_model<false>(ratio), F.log_scale_factor));
             if (n < 0) n = 0; else if (n >= F.nlevels) n = F.nlevels - 1;
             lvl = n;
+            u = uu; v = vv;
             xr = __fsub_rn(uu, __fmul_rn(F.mbf, invz));
             depth = Pc_dist;
         }
     }
     in_view[i] = ok ? 1 : 0;
     track[i] = u; track[M + i] = v; track[2 * (size_t)M + i] = xr; track[3 * (size_t)M + i] = depth; track[4 * (size_t)M + i] = vcos;
-    scale_level[i] = ok ? lvl : 0;
+    scale_level[i] = ok ? lvl : (F.rig_mode ? -1 : 0);
     if (queries) {
         AreaQuery q; q.x = 0; q.y = 0; q.r = 0; q.ur = 0; q.min_level = 0; q.max_level = 0; q.active = 0; q.gate = 0;
         if (ok && !(F.far_points && depth > F.th_far) && !(is_bad && is_bad[i])) {
@@ -290,6 +319,92 @@ __global__ void __launch_bounds__(256) k_frustum(FrustumParams F, int M, const f
         }
         queries[i] = q;
     }
+}
+
+// ORBmatcher::SearchByProjection(Frame, MapPoints) accept loop (src/ORBmatcher.cc:62-166) on the device, one wave per frame of a batch: the
+// loop is sequential over the map points (a keypoint that has received a map point WITH observations is skipped by every later point), so a
+// frame is one wave that walks its queries in order; the lanes share a query's candidates (best / second best = two wave minima over
+// (distance << 16 | position): the FIRST candidate with the smallest distance wins, the second best is the smallest among the others, as the
+// strict `<` tests of the reference leave them).  Frames are independent: the batch supplies the parallelism.
+// occupied0: [B][cap] bytes or NULL (Frame::mvpMapPoints[i] with observations before the call); has_obs: [M] or NULL (all observed).
+// assigned: [B][cap] = index of the map point given to the keypoint, -1 = untouched; nmatches: [B].
+__global__ void __launch_bounds__(64) k_local_accept(int M, int cap, const int* __restrict__ n_per_frame, const int* __restrict__ q_start,
+                                                     const int* __restrict__ q_count, const int2* __restrict__ entries, const uint8_t* __restrict__ occupied0,
+                                                     const uint8_t* __restrict__ has_obs, float nnratio, int th_high, int* __restrict__ assigned,
+                                                     int* __restrict__ nmatches) {
+    __shared__ uint32_t s_occ[2048];                               // one bit per keypoint (cap <= 65535)
+    const int lane = lane_id();
+    const size_t b = blockIdx.x;
+    const int N = n_per_frame[b];
+    q_start += b * (size_t)M; q_count += b * (size_t)M; assigned += b * (size_t)cap;
+    for (int w = lane; w < (cap + 31) / 32; w += 64) {
+        uint32_t bits = 0;
+        if (occupied0) for (int k = 0; k < 32; k++) { const int i = 32 * w + k; if (i < N && occupied0[b * (size_t)cap + i]) bits |= 1u << k; }
+        s_occ[w] = bits;
+    }
+    for (int i = lane; i < cap; i += 64) assigned[i] = -1;
+    ORBX_WAVE_SYNC();
+    int nm = 0;
+    for (int i0 = 0; i0 < M; i0 += 64) {
+        const int qi = i0 + lane;
+        const int myc = qi < M ? q_count[qi] : 0, mys = qi < M ? q_start[qi] : 0;
+        unsigned long long todo = __ballot(myc > 0);
+        while (todo) {
+            const int l = __ffsll(todo) - 1; todo &= todo - 1ull;
+            const int cnt = __shfl(myc, l), st = __shfl(mys, l);
+            // lane-local two smallest keys among the candidates that are still free
+            unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+            for (int k = lane; k < cnt; k += 64) {
+                const int2 e = entries[st + k];
+                if ((s_occ[e.x >> 5] >> (e.x & 31)) & 1u) continue;
+                const unsigned key = ((unsigned)(e.y & 0xFFFF) << 16) | (unsigned)k;
+                if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+            }
+            const unsigned best = wave_min_u32(k1);
+            if (best == 0xFFFFFFFFu) continue;                        // every candidate is taken
+            const unsigned second = wave_min_u32(k1 == best ? k2 : k1);
+            const int bestDist = (int)(best >> 16);
+            if (bestDist > th_high) continue;
+            const int2 eb = entries[st + (int)(best & 0xFFFFu)];
+            const int bestLevel = eb.y >> 16, bestIdx = eb.x;
+            int bestDist2 = 256, bestLevel2 = -1;
+            if (second != 0xFFFFFFFFu) { bestDist2 = (int)(second >> 16); bestLevel2 = entries[st + (int)(second & 0xFFFFu)].y >> 16; }
+            // :146-166  (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) -> no match
+            if (bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2)) continue;
+            if (lane == 0) {
+                assigned[bestIdx] = i0 + l;
+                if (!has_obs || has_obs[i0 + l]) s_occ[bestIdx >> 5] |= 1u << (bestIdx & 31);
+            }
+            nm++;
+            ORBX_WAVE_SYNC();
+        }
+    }
+    if (lane == 0) nmatches[b] = nm;
+}
+
+// Frame::ComputeStereoFromRGBD (src/Frame.cc:1361-1391) for B frames: mvDepth[i] = imDepth.at<float>(v, u) at the (distorted) keypoint, truncated
+// to integers like cv::Mat::at(int, int) with float arguments, and mvuRight[i] = kpU.pt.x - mbf / d where d > 0, else both -1.  keys_un == NULL:
+// no distortion (mvKeysUn = mvKeys).  depth image b at depth + b * image_stride (floats), rows `stride` floats apart.
+__global__ void __launch_bounds__(256) k_stereo_from_depth(const KeyPointRec* __restrict__ kps, const KeyPointRec* __restrict__ kps_un, const int* __restrict__ n_per_frame,
+                                                           int cap, const float* __restrict__ depth, int stride, size_t image_stride, int w, int h, float mbf,
+                                                           float* __restrict__ u_right, float* __restrict__ depth_out, int* __restrict__ n_valid) {
+    const size_t b = blockIdx.y;
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= cap) return;
+    float ur = -1.0f, d_out = -1.0f;
+    if (i < n_per_frame[b]) {
+        const KeyPointRec kp = kps[b * (size_t)cap + i];
+        const int u = (int)kp.x, v = (int)kp.y;
+        if (u >= 0 && u < w && v >= 0 && v < h) {
+            const float d = depth[b * image_stride + (size_t)v * stride + u];
+            if (d > 0) {
+                const float xu = kps_un ? kps_un[b * (size_t)cap + i].x : kp.x;
+                d_out = d; ur = __fsub_rn(xu, __fdiv_rn(mbf, d));
+                atomicAdd(&n_valid[b], 1);
+            }
+        }
+    }
+    u_right[b * (size_t)cap + i] = ur; depth_out[b * (size_t)cap + i] = d_out;
 }
 
 // One wave per work item (an unmatched feature idx1 of KF1 and the feature list of a neighbour KF2 in the same node; the arrays of

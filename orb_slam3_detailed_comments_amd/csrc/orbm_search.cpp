@@ -13,6 +13,7 @@ using namespace orbx;
 namespace {
 
 const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;   // src/ORBmatcher.cc:35-37
+const int kGridColsHost = 64, kGridRowsHost = 48;          // FRAME_GRID_COLS / FRAME_GRID_ROWS, include/Frame.h:44-45
 
 struct DeviceFrame {
     const KeyPointRec* kps; const unsigned long long* desc; const float* ur; const int* cell_start; const int* cell_items;
@@ -64,7 +65,7 @@ int upload_frame(orbx_extractor* h, const OrbmFrameView* F, DeviceFrame* D) {
     memset(&D->g, 0, sizeof D->g);
     D->g.min_x = F->min_x; D->g.min_y = F->min_y; D->g.gw_inv = F->grid_w_inv; D->g.gh_inv = F->grid_h_inv;
     const dim3 one(1, 1, 1), blkg(kGridThreads, 1, 1);
-    ORBX_LAUNCH(k_grid_build, one, blkg, 0, h->s0, D->kps, N, D->g, h->d_si[SI_CELLOF].p, h->d_si[SI_CELLSTART].p, h->d_si[SI_CELLITEMS].p);
+    ORBX_LAUNCH(k_grid_build, one, blkg, 0, h->s0, D->kps, N, D->g, h->d_si[SI_CELLOF].p, h->d_si[SI_CELLSTART].p, h->d_si[SI_CELLITEMS].p, (const int*)nullptr, 0);
     D->cell_start = h->d_si[SI_CELLSTART].p; D->cell_items = h->d_si[SI_CELLITEMS].p;
     return ORBX_OK;
 }
@@ -102,7 +103,7 @@ int run_area_search_dev(orbx_extractor* h, const DeviceFrame& D, int Q, const Ar
         rt::memset_async(d_counter, 0, 16, h->s0);
         dim3 grid((Q + kAreaWaves - 1) / kAreaWaves, 1, 1), blk(64 * kAreaWaves, 1, 1);
         ORBX_LAUNCH(k_area_search, grid, blk, 0, h->s0, dq, dqd, Q, D.kps, D.ur, D.desc, D.g, D.cell_start, D.cell_items, 1, d_counter, (int)pool,
-                    d_start, d_count, d_ent);
+                    d_start, d_count, d_ent, 0);
         const size_t guess = std::min(pool, std::max<size_t>(h->area_last_total + h->area_last_total / 4 + 256, 1024));
         const size_t oextra = al16(hdr + pool * 8 + 16);
         if (h->h_out.ensure(oextra + extra_bytes + 16)) return fail(ORBX_E_DEVICE, "pinned allocation failed");
@@ -273,7 +274,7 @@ int enqueue_frustum(orbx_extractor* h, const OrbmFrustumView* V, const OrbmWorld
     if (M > 0) {
         dim3 grid((M + 255) / 256, 1, 1), blk(256, 1, 1);
         ORBX_LAUNCH(k_frustum, grid, blk, 0, h->s0, F, M, (const float*)(di + op), (const float*)(di + on), (const float*)(di + omn), (const float*)(di + omx),
-                    (const uint8_t*)(di + ob), out->in_view, out->track, out->level, out->queries, (int*)nullptr);
+                    (const uint8_t*)(di + ob), out->in_view, out->track, out->level, out->queries, (int*)nullptr, (const FrustumParams*)nullptr);
     }
     return ORBX_OK;
 }
@@ -388,7 +389,7 @@ int search_local_points_core(orbx_extractor* h, const OrbmFrameView* F, const Or
     D.g.min_x = F->min_x; D.g.min_y = F->min_y; D.g.gw_inv = F->grid_w_inv; D.g.gh_inv = F->grid_h_inv;
     D.cell_start = h->d_si[SI_CELLSTART].p; D.cell_items = h->d_si[SI_CELLITEMS].p;
     const dim3 one(1, 1, 1), blkg(kGridThreads, 1, 1), blk(256, 1, 1);
-    ORBX_LAUNCH(k_grid_build, one, blkg, 0, h->s0, D.kps, N, D.g, h->d_si[SI_CELLOF].p, h->d_si[SI_CELLSTART].p, h->d_si[SI_CELLITEMS].p);
+    ORBX_LAUNCH(k_grid_build, one, blkg, 0, h->s0, D.kps, N, D.g, h->d_si[SI_CELLOF].p, h->d_si[SI_CELLSTART].p, h->d_si[SI_CELLITEMS].p, (const int*)nullptr, 0);
     FrustumParams Fp; memset(&Fp, 0, sizeof Fp);
     memcpy(Fp.Rcw, V->Rcw, sizeof Fp.Rcw); memcpy(Fp.tcw, V->tcw, sizeof Fp.tcw); memcpy(Fp.Ow, V->Ow, sizeof Fp.Ow);
     memcpy(Fp.cam, V->cam, sizeof Fp.cam); Fp.kb8 = V->camera_type == 1;
@@ -405,12 +406,12 @@ int search_local_points_core(orbx_extractor* h, const OrbmFrameView* F, const Or
         dim3 grid((M + 255) / 256, 1, 1);
         ORBX_LAUNCH(k_frustum, grid, blk, 0, h->s0, Fp, M, R ? R->pos : (const float*)(di + opp), R ? R->normal : (const float*)(di + opn),
                     R ? R->min_d : (const float*)(di + opmn), R ? R->max_d : (const float*)(di + opmx), (const uint8_t*)(di + ob),
-                    dtrk + ov, (float*)dtrk, (int*)(dtrk + ol), dq, d_counter);
+                    dtrk + ov, (float*)dtrk, (int*)(dtrk + ol), dq, d_counter, (const FrustumParams*)nullptr);
     }
     {
         dim3 grid((M + kAreaWaves - 1) / kAreaWaves, 1, 1), blka(64 * kAreaWaves, 1, 1);
         ORBX_LAUNCH(k_area_search, grid, blka, 0, h->s0, (const AreaQuery*)dq, dqd, M, D.kps, D.ur, D.desc, D.g, D.cell_start, D.cell_items, 1, d_counter, (int)pool,
-                    d_start, d_count, d_ent);
+                    d_start, d_count, d_ent, 0);
     }
     const size_t guess = std::min(pool, std::max<size_t>(h->area_last_total + h->area_last_total / 4 + 256, 1024));
     rt::copy_d2h(h->h_out.p, dout, oent + guess * 8, h->s0);
@@ -470,6 +471,139 @@ int orbm_search_local_points_resident(orbx_extractor* h, const OrbmFrameView* F,
     if (points->device != h->device) return fail(ORBX_E_ARG, "map points live on another device");
     rt::set_device(h->device);
     return search_local_points_core(h, F, V, points->M, nullptr, points, is_bad, has_obs, cos_limit, th, far_points, th_far, nnratio, out, assigned, nmatches_out);
+}
+
+// ---- the batched, device-resident form of Tracking::SearchLocalPoints ----------------------------------------------
+// Frames = images [first, first + B) of the handle's last extraction, read where the extractor left them (keypoints, descriptors, counts; uRight
+// from orbm_stereo_match / orbm_stereo_from_depth); map points resident (orbm_points); one pose per frame.  Five launches for the whole batch:
+// grid build (B workgroups), frustum + window queries (B x M threads), window search (B x M waves), accept loop (one wave per frame) - nothing
+// visits the host between them; one upload (poses + call-time flags), one download (assignments, match counts, optionally mbTrackInView).
+namespace {
+void fill_frustum_params(const OrbmFrustumView* V, float cos_limit, float th, int far_points, float th_far, FrustumParams* Fp) {
+    memset(Fp, 0, sizeof *Fp);
+    memcpy(Fp->Rcw, V->Rcw, sizeof Fp->Rcw); memcpy(Fp->tcw, V->tcw, sizeof Fp->tcw); memcpy(Fp->Ow, V->Ow, sizeof Fp->Ow);
+    memcpy(Fp->cam, V->cam, sizeof Fp->cam); Fp->kb8 = V->camera_type == 1;
+    Fp->min_x = V->min_x; Fp->max_x = V->max_x; Fp->min_y = V->min_y; Fp->max_y = V->max_y; Fp->mbf = V->mbf; Fp->log_scale_factor = V->log_scale_factor; Fp->nlevels = V->nlevels;
+    for (int l = 0; l < V->nlevels; l++) Fp->scale_factors[l] = V->scale_factors[l];
+    Fp->cos_limit = cos_limit; Fp->th = th; Fp->th_far = th_far; Fp->far_points = far_points;
+}
+}  // namespace
+
+int orbm_stereo_from_depth(orbx_extractor* h, int first, int B, const float* depth, int stride, size_t image_stride, int on_device, float mbf) {
+    if (!h || !depth || B <= 0 || first < 0 || first + B > h->lastB) return fail(ORBX_E_ARG, "bad frame range");
+    if (stride < h->W || (B > 1 && image_stride < (size_t)stride * (h->H - 1) + h->W)) return fail(ORBX_E_ARG, "depth stride too small");
+    rt::set_device(h->device);
+    const float* d_depth = depth;
+    if (!on_device) {
+        const size_t n = (size_t)(B - 1) * image_stride + (size_t)stride * (h->H - 1) + h->W;
+        if (h->d_depth_in.ensure(n * sizeof(float) + 16) || rt::copy_h2d(h->d_depth_in.p, depth, n * sizeof(float), h->s0)) return fail(ORBX_E_DEVICE, "depth upload failed");
+        d_depth = (const float*)h->d_depth_in.p;
+    }
+    const int cap = h->kp_total_cap;
+    rt::memset_async(h->d_nmatch.p, 0, sizeof(int) * (size_t)B, h->s0);
+    dim3 grid((cap + 255) / 256, B, 1), blk(256, 1, 1);
+    ORBX_LAUNCH(k_stereo_from_depth, grid, blk, 0, h->s0, (const KeyPointRec*)(h->d_kps.p + (size_t)first * cap), (const KeyPointRec*)nullptr, (const int*)(h->d_nm.p + first), cap,
+                d_depth, stride, image_stride, h->W, h->H, mbf, h->d_uRight.p, h->d_depth.p, h->d_nmatch.p);
+    if (rt::check_launch()) return fail(ORBX_E_DEVICE, "kernel launch failed: %s", rt::last_error());
+    return ORBX_OK;
+}
+
+int orbm_search_local_points_batch(orbx_extractor* h, int first, int B, const OrbmFrustumView* frames, const orbm_points* points, const uint8_t* is_bad,
+                                   const uint8_t* has_obs, const uint8_t* occupied, int use_u_right, float cos_limit, float th, int far_points, float th_far,
+                                   float nnratio, int want_in_view) {
+    if (!h || !frames || !points || B <= 0 || first < 0 || first + B > h->lastB) return fail(ORBX_E_ARG, "bad frame range / null");
+    if (points->device != h->device) return fail(ORBX_E_ARG, "map points live on another device");
+    for (int b = 0; b < B; b++) if (frames[b].nlevels < 1 || frames[b].nlevels > kMaxLevels || !frames[b].scale_factors) return fail(ORBX_E_ARG, "bad scale levels (frame %d)", b);
+    rt::set_device(h->device);
+    const int M = points->M, cap = h->kp_total_cap;
+    const size_t B1 = B, M1 = M > 0 ? M : 1, C1 = cap;
+    if (h->lp_pending) { rt::event_sync(h->ev_lp); }            // the staging block of the previous enqueue has been consumed
+    // upload block: poses | bad flags | has-observation flags | occupancy
+    const size_t u_f = 0, u_bad = u_f + al16(sizeof(FrustumParams) * B1), u_obs = u_bad + al16(M1), u_occ = u_obs + al16(M1), u_total = u_occ + (occupied ? al16(B1 * C1) : 0);
+    // device block: upload | uRight of "no stereo" | grid (cell_of, cell_start, cell_items) | queries | track | level | in_view | q_start | q_count |
+    // result [counter 16 | nmatches B | assigned B * cap] | entry pool
+    size_t o = al16(u_total);
+    const size_t o_ur = o; o += use_u_right ? 0 : al16(4 * B1 * C1);
+    const size_t o_cof = o; o += al16(4 * B1 * C1);
+    const size_t o_cst = o; o += al16(4 * B1 * kGridCellStride);
+    const size_t o_cit = o; o += al16(4 * B1 * C1);
+    const size_t o_q = o; o += al16(sizeof(AreaQuery) * B1 * M1);
+    const size_t o_trk = o; o += al16(20 * B1 * M1);
+    const size_t o_lvl = o; o += al16(4 * B1 * M1);
+    const size_t o_view = o; o += al16(B1 * M1);
+    const size_t o_qs = o; o += al16(4 * B1 * M1);
+    const size_t o_qc = o; o += al16(4 * B1 * M1);
+    const size_t o_res = o; const size_t res_bytes = 16 + al16(4 * B1) + 4 * B1 * C1; o += al16(res_bytes);
+    const size_t o_pool = o;
+    size_t pool = std::max<size_t>(h->lp_pool, B1 * M1 * 6 + 4096);
+    if (pool > 0x7fffffff / 2) pool = 0x7fffffff / 2;
+    if (h->d_lp.ensure(o_pool + pool * 8 + 64) || h->h_lp_in.ensure(u_total + 16) || h->h_lp_out.ensure(al16(res_bytes) + (want_in_view ? B1 * M1 : 0) + 64))
+        return fail(ORBX_E_DEVICE, "allocation failed (batched local point search, %d frames x %d points)", B, M);
+    h->lp_pool = pool;
+    uint8_t* hp = h->h_lp_in.p; uint8_t* dp = h->d_lp.p;
+    FrustumParams* Fp = (FrustumParams*)(hp + u_f);
+    for (int b = 0; b < B; b++) fill_frustum_params(&frames[b], cos_limit, th, far_points, th_far, &Fp[b]);
+    if (is_bad) memcpy(hp + u_bad, is_bad, M1); else memset(hp + u_bad, 0, M1);
+    if (has_obs) memcpy(hp + u_obs, has_obs, M1); else memset(hp + u_obs, 1, M1);
+    if (occupied) memcpy(hp + u_occ, occupied, B1 * C1);
+    if (rt::copy_h2d(dp, hp, u_total, h->s0) || rt::event_record(h->ev_lp, h->s0)) return fail(ORBX_E_DEVICE, "upload failed: %s", rt::last_error());
+    h->lp_pending = true;
+    const KeyPointRec* kps = h->d_kps.p + (size_t)first * cap;
+    const unsigned long long* fdesc = h->d_desc.p + (size_t)first * cap * 4;
+    const int* nper = h->d_nm.p + first;
+    const float* ur = h->d_uRight.p;
+    if (!use_u_right) { rt::memset_async(dp + o_ur, 0xBF, 4 * B1 * C1, h->s0); ur = (const float*)(dp + o_ur); }   // 0xBFBFBFBF = -1.498...: a negative uRight = monocular keypoint
+    GridParams g; memset(&g, 0, sizeof g);
+    g.min_x = frames[0].min_x; g.min_y = frames[0].min_y;
+    g.gw_inv = (float)kGridColsHost / (frames[0].max_x - frames[0].min_x); g.gh_inv = (float)kGridRowsHost / (frames[0].max_y - frames[0].min_y);   // src/Frame.cc:190-191
+    int* d_counter = (int*)(dp + o_res); int* d_nmatch = (int*)(dp + o_res + 16); int* d_assigned = (int*)(dp + o_res + 16 + al16(4 * B1));
+    {
+        dim3 grid(B, 1, 1), blkg(kGridThreads, 1, 1);
+        ORBX_LAUNCH(k_grid_build, grid, blkg, 0, h->s0, kps, 0, g, (int*)(dp + o_cof), (int*)(dp + o_cst), (int*)(dp + o_cit), nper, cap);
+    }
+    if (M > 0) {
+        FrustumParams dummy; memset(&dummy, 0, sizeof dummy);
+        dim3 grid((M + 255) / 256, B, 1), blk(256, 1, 1);
+        ORBX_LAUNCH(k_frustum, grid, blk, 0, h->s0, dummy, M, points->pos, points->normal, points->min_d, points->max_d, (const uint8_t*)(dp + u_bad),
+                    dp + o_view, (float*)(dp + o_trk), (int*)(dp + o_lvl), (AreaQuery*)(dp + o_q), d_counter, (const FrustumParams*)(dp + u_f));
+        dim3 grida((M + kAreaWaves - 1) / kAreaWaves, B, 1), blka(64 * kAreaWaves, 1, 1);
+        ORBX_LAUNCH(k_area_search, grida, blka, 0, h->s0, (const AreaQuery*)(dp + o_q), points->desc, M, kps, ur, fdesc, g, (const int*)(dp + o_cst), (const int*)(dp + o_cit), 1,
+                    d_counter, (int)pool, (int*)(dp + o_qs), (int*)(dp + o_qc), (int2*)(dp + o_pool), cap);
+    } else rt::memset_async(d_counter, 0, 16, h->s0);
+    {
+        dim3 grid(B, 1, 1), blk(64, 1, 1);
+        ORBX_LAUNCH(k_local_accept, grid, blk, 0, h->s0, M, cap, nper, (const int*)(dp + o_qs), (const int*)(dp + o_qc), (const int2*)(dp + o_pool),
+                    occupied ? (const uint8_t*)(dp + u_occ) : (const uint8_t*)nullptr, (const uint8_t*)(dp + u_obs), nnratio, TH_HIGH, d_assigned, d_nmatch);
+    }
+    if (rt::check_launch()) return fail(ORBX_E_DEVICE, "kernel launch failed: %s", rt::last_error());
+    h->lp_B = B; h->lp_M = M; h->lp_first = first; h->lp_o_counter = o_res; h->lp_o_view = o_view; h->lp_want_view = want_in_view != 0;
+    return ORBX_OK;
+}
+
+int orbm_search_local_points_fetch(orbx_extractor* h, int* assigned, int cap, int* nmatches, uint8_t* in_view) {
+    if (!h || h->lp_B <= 0) return fail(ORBX_E_ARG, "no batched local point search is pending");
+    if (assigned && cap < h->kp_total_cap) return fail(ORBX_E_CAPACITY, "assigned rows need %d entries", h->kp_total_cap);
+    rt::set_device(h->device);
+    const size_t B1 = h->lp_B, M1 = h->lp_M > 0 ? h->lp_M : 1, C1 = h->kp_total_cap;
+    const size_t res_bytes = 16 + al16(4 * B1) + 4 * B1 * C1;
+    uint8_t* hp = h->h_lp_out.p;
+    int e = rt::copy_d2h(hp, h->d_lp.p + h->lp_o_counter, res_bytes, h->s0);
+    if (in_view && h->lp_want_view && h->lp_M > 0) e |= rt::copy_d2h(hp + al16(res_bytes), h->d_lp.p + h->lp_o_view, B1 * M1, h->s0);
+    if (e || rt::stream_sync(h->s0) || rt::check_launch()) return fail(ORBX_E_DEVICE, "batched local point search failed: %s", rt::last_error());
+    h->lp_pending = false;
+    const int total = *(const int*)hp;
+    if (h->lp_M > 0 && (size_t)total > h->lp_pool) {                // the candidate pool was too small: the caller enqueues again (the pool has grown)
+        h->lp_pool = (size_t)total + (size_t)total / 8 + 4096;
+        return fail(ORBX_E_CAPACITY, "candidate pool overflow (%d entries): enqueue the search again, the pool has been enlarged", total);
+    }
+    if (nmatches) memcpy(nmatches, hp + 16, 4 * B1);
+    if (assigned) {
+        const int* src = (const int*)(hp + 16 + al16(4 * B1));
+        if ((size_t)cap == C1) memcpy(assigned, src, 4 * B1 * C1);
+        else for (size_t b = 0; b < B1; b++) memcpy(assigned + b * (size_t)cap, src + b * C1, 4 * C1);
+    }
+    if (in_view) { if (h->lp_want_view && h->lp_M > 0) memcpy(in_view, hp + al16(res_bytes), B1 * M1); else return fail(ORBX_E_ARG, "in_view was not requested at enqueue time"); }
+    return ORBX_OK;
 }
 
 int orbm_search_by_projection_frame(orbx_extractor* h, const OrbmFrameView* Cur, const OrbmLastFrameView* Last, float th, int forward, int backward,

@@ -368,7 +368,7 @@ int orbx_create(orbx_extractor** out, int nfeatures, float scale_factor, int nle
     h->nfeatures = nfeatures; h->scaleFactor = scale_factor; h->nlevels = nlevels; h->iniTh = ini_th; h->minTh = min_th; h->device = device_id;
     init_tables(h);
     int e = rt::stream_create(&h->s0) | rt::stream_create(&h->s1) | rt::stream_create(&h->s_copy) | rt::event_create(&h->ev_fork) | rt::event_create(&h->ev_join) |
-            rt::event_create(&h->ev_done) | rt::event_create(&h->ev_copy) | rt::event_create(&h->ev_import);
+            rt::event_create(&h->ev_done) | rt::event_create(&h->ev_copy) | rt::event_create(&h->ev_import) | rt::event_create(&h->ev_lp);
     for (int i = 0; i < ORBX_NSTAGES; i++) { e |= rt::event_create(&h->ev_stage[i][0]); e |= rt::event_create(&h->ev_stage[i][1]); h->stage_ms[i] = 0; }
     if (e) { delete h; return fail(ORBX_E_DEVICE, "stream/event creation failed"); }
     h->have_streams = true;
@@ -387,7 +387,7 @@ void orbx_destroy(orbx_extractor* h) {
 #endif
         for (int i = 0; i < ORBX_NSTAGES; i++) { rt::event_destroy(h->ev_stage[i][0]); rt::event_destroy(h->ev_stage[i][1]); }
         rt::stream_sync(h->s_copy);
-        rt::event_destroy(h->ev_fork); rt::event_destroy(h->ev_join); rt::event_destroy(h->ev_done); rt::event_destroy(h->ev_copy); rt::event_destroy(h->ev_import);
+        rt::event_destroy(h->ev_fork); rt::event_destroy(h->ev_join); rt::event_destroy(h->ev_done); rt::event_destroy(h->ev_copy); rt::event_destroy(h->ev_import); rt::event_destroy(h->ev_lp);
         rt::stream_destroy(h->s0); rt::stream_destroy(h->s1); rt::stream_destroy(h->s_copy);
     }
     h->d_lv.release(); h->d_cells.release(); h->d_xtab.release(); h->d_ytab.release(); h->d_pyr.release(); h->d_blur.release(); h->d_stage.release();
@@ -398,6 +398,7 @@ void orbx_destroy(orbx_extractor* h) {
     for (auto& x : h->d_sr) x.release();
     h->h_packA.release(); h->h_packB.release(); h->h_out.release();
     for (auto& x : h->d_si) x.release();
+    h->d_lp.release(); h->d_depth_in.release(); h->h_lp_in.release(); h->h_lp_out.release();
     h->d_aux.release(); h->d_qtprof.release(); h->d_rowstart.release(); h->d_rowitems.release();
     h->d_mapx.release(); h->d_mapy.release(); h->d_in_xt.release(); h->d_in_yt.release(); h->d_frame.release();
     delete h;

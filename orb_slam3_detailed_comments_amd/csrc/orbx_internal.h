@@ -95,5 +95,9 @@ struct orbx_extractor {
     bool in_active = false; int in_channels = 1, in_rgb = 1, in_gray_variant = 0, in_geometry = 0, in_out_w = 0, in_out_h = 0, in_tap_w = 0, in_tap_h = 0;
     orbx::DevBuf<float> d_mapx, d_mapy; orbx::DevBuf<orbx::ResizeTap> d_in_xt, d_in_yt; orbx::DevBuf<uint8_t> d_frame;
     orbx::DevBuf<int> d_rowstart, d_rowitems;   // row index of the right keypoints (k_stereo_rows)
+    // batched SearchLocalPoints (orbm_search_local_points_batch): one device block, one pinned result block, the size of the last enqueue
+    orbx::DevBuf<uint8_t> d_lp, d_depth_in; orbx::HostBuf<uint8_t> h_lp_in, h_lp_out;
+    size_t lp_pool = 0; int lp_B = 0, lp_M = 0, lp_first = 0; size_t lp_o_counter = 0, lp_o_view = 0; bool lp_pending = false, lp_want_view = false;
+    orbx::rt::event_t ev_lp = 0;
     orbx::DevBuf<int> d_aux;     // int4 per keypoint: stereo row band / x / octave (k_orient_brief -> k_stereo_match)
 };

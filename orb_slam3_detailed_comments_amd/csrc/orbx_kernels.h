@@ -78,17 +78,24 @@ __global__ void k_knn2(const unsigned long long* __restrict__ descQ, const int* 
                        int* __restrict__ dist1, uint8_t* __restrict__ ratio_ok);
 
 constexpr int kGridThreads = 1024;     // workgroup size of k_grid_build (3 grid cells per thread)
+constexpr int kGridCellStride = 64 * 48 + 2;   // ints per frame of the batched cell_start arrays
 __global__ void k_grid_build(const KeyPointRec* __restrict__ kps, int N, GridParams g, int* __restrict__ cell_of,
-                             int* __restrict__ cell_start, int* __restrict__ cell_items);
+                             int* __restrict__ cell_start, int* __restrict__ cell_items, const int* __restrict__ n_per_frame, int frame_stride);
 constexpr int kAreaWaves = 16;         // queries (waves) per k_area_search workgroup
 __global__ void k_area_search(const AreaQuery* __restrict__ queries, const unsigned long long* __restrict__ qdesc, int Q,
                               const KeyPointRec* __restrict__ kps, const float* __restrict__ u_right,
                               const unsigned long long* __restrict__ fdesc, GridParams g, const int* __restrict__ cell_start,
                               const int* __restrict__ cell_items, int gate_right, int* __restrict__ pool_counter, int pool_cap,
-                              int* __restrict__ q_start, int* __restrict__ q_count, int2* __restrict__ entries);
+                              int* __restrict__ q_start, int* __restrict__ q_count, int2* __restrict__ entries, int frame_stride);
 __global__ void k_frustum(FrustumParams F, int M, const float* __restrict__ pos, const float* __restrict__ normal, const float* __restrict__ min_dist,
                           const float* __restrict__ max_dist, const uint8_t* __restrict__ is_bad, uint8_t* __restrict__ in_view, float* __restrict__ track,
-                          int* __restrict__ scale_level, AreaQuery* __restrict__ queries, int* __restrict__ zero4);
+                          int* __restrict__ scale_level, AreaQuery* __restrict__ queries, int* __restrict__ zero4, const FrustumParams* __restrict__ Fbatch);
+__global__ void k_local_accept(int M, int cap, const int* __restrict__ n_per_frame, const int* __restrict__ q_start, const int* __restrict__ q_count,
+                               const int2* __restrict__ entries, const uint8_t* __restrict__ occupied0, const uint8_t* __restrict__ has_obs, float nnratio,
+                               int th_high, int* __restrict__ assigned, int* __restrict__ nmatches);
+__global__ void k_stereo_from_depth(const KeyPointRec* __restrict__ kps, const KeyPointRec* __restrict__ kps_un, const int* __restrict__ n_per_frame, int cap,
+                                    const float* __restrict__ depth, int stride, size_t image_stride, int w, int h, float mbf, float* __restrict__ u_right,
+                                    float* __restrict__ depth_out, int* __restrict__ n_valid);
 __global__ void k_bow_search(const BowItem* __restrict__ items, int nitems, const KeyPointRec* __restrict__ kps1,
                              const unsigned long long* __restrict__ desc1, const float* __restrict__ ur1,
                              const KeyPointRec* __restrict__ kps2, const unsigned long long* __restrict__ desc2,

@@ -71,6 +71,7 @@ struct FrustumParams {                                            // what Frame:
     float cos_limit;                                              // viewingCosLimit
     // SearchByProjection(Frame, MapPoints) query parameters when the queries are produced on the device
     float th, th_far; int far_points;
+    int rig_mode;                                                 // Frame::isInFrustumChecks: store nothing unless every test passes, level -1 when rejected
 };
 struct VocSlot { int node_id, child_start, child_cnt, word_id; };   // one vocabulary node; children occupy consecutive slots
 struct BowItem { int idx1, start2, cnt2, out_off; };

@@ -285,18 +285,14 @@ class ResidentPoints:
             pass
 
 
-def SearchLocalPoints(ext, frame, Rcw, tcw, cam, bounds, mbf, scale_factors, pos, normal, min_distance, max_distance, is_bad=None, has_obs=None, desc=None,
-                      viewing_cos_limit=0.5, th=1.0, far_points=False, th_far=50.0, nnratio=0.8, search=True, prepared=False, resident=None):
-    """Frame::isInFrustum (src/Frame.cc:667-773) for M map points and, with search=True, ORBmatcher::SearchByProjection(F, points, th, ...)
-    (src/ORBmatcher.cc:45-167) on those in view - Tracking::SearchLocalPoints (src/Tracking.cc:4009-4067) on the device.
-    cam: (fx, fy, cx, cy) or the 8 Kannala-Brandt parameters; bounds = (min_x, max_x, min_y, max_y); frame: views.frame_view(...).
-    Returns (track dict, assigned[N] or None, nmatches)."""
+def frustum_view(Rcw, tcw, cam, bounds, mbf, scale_factors, into=None):
+    """OrbmFrustumView of one frame: pose (mRcw, mtcw and mOw = -(Rcw^T tcw) in the reference's fp32 order: the Sophus stand-in sums R^T * t left
+    to right, then negates), camera (4 pinhole or 8 Kannala-Brandt parameters), image bounds (min_x, max_x, min_y, max_y), mbf, the scale
+    factors.  Returns (view, the float32 scale-factor array the view points into - keep it alive)."""
     f32 = lambda a: np.ascontiguousarray(a, np.float32)
-    Rcw, tcw, pos, normal, mn, mx, sf = f32(Rcw).reshape(3, 3), f32(tcw).reshape(3), f32(pos).reshape(-1, 3), f32(normal).reshape(-1, 3), f32(min_distance), f32(max_distance), f32(scale_factors)
-    M = len(pos)
-    V = _FrustumView()
+    Rcw, tcw, sf = f32(Rcw).reshape(3, 3), f32(tcw).reshape(3), f32(scale_factors)
+    V = into if into is not None else _FrustumView()
     V.Rcw[:] = Rcw.ravel().tolist(); V.tcw[:] = tcw.tolist()
-    # mOw = Twc.translation() = -(Rcw^T tcw) in the reference's fp32 order (Sophus stand-in: R^T * t summed left to right, then negated)
     Rt = Rcw.T.copy()
     ow = [-np.float32(np.float32(np.float32(Rt[i, 0] * tcw[0]) + np.float32(Rt[i, 1] * tcw[1])) + np.float32(Rt[i, 2] * tcw[2])) for i in range(3)]
     V.Ow[:] = [float(v) for v in ow]
@@ -306,6 +302,78 @@ def SearchLocalPoints(ext, frame, Rcw, tcw, cam, bounds, mbf, scale_factors, pos
     V.min_x, V.max_x, V.min_y, V.max_y = [float(v) for v in bounds]
     V.mbf = float(mbf); V.log_scale_factor = float(np.float32(np.log(np.float64(sf[1])))) if len(sf) > 1 else 1.0
     V.nlevels = len(sf); V.scale_factors = sf.ctypes.data
+    return V, sf
+
+
+def ComputeStereoFromRGBD(ext, depth, mbf, first=0, device_ptr=None, shape=None):
+    """Frame::ComputeStereoFromRGBD (src/Frame.cc:1361-1391) for the frames [first, first + B) of ext's last batch: depth [B, H, W] float32 (CV_32F,
+    already multiplied by the depth map factor), host array or (device_ptr, shape).  Asynchronous; fetch with StereoFetch(ext, B) or keep on the
+    device for SearchLocalPointsBatch."""
+    L = ext._lib
+    if device_ptr is None:
+        depth = np.ascontiguousarray(depth, np.float32)
+        B, H, W = depth.shape
+        ext._keep_depth = depth
+        L.check(L.L.orbm_stereo_from_depth(ext._h, int(first), B, depth.ctypes.data, W, H * W, 0, float(mbf)))
+    else:
+        B, H, W = shape
+        L.check(L.L.orbm_stereo_from_depth(ext._h, int(first), B, device_ptr, W, H * W, 1, float(mbf)))
+    return B
+
+
+def StereoFetch(ext, B):
+    """(mvuRight [B, cap], mvDepth [B, cap], matches [B]) of the last orbm_stereo_match / orbm_stereo_from_depth of `ext`."""
+    cap = ext.max_keypoints()
+    u = np.zeros((B, cap), np.float32); d = np.zeros((B, cap), np.float32); n = np.zeros(B, np.int32)
+    ext._lib.check(ext._lib.L.orbm_stereo_fetch(ext._h, B, u.ctypes.data, d.ctypes.data, cap, n.ctypes.data))
+    return u, d, n
+
+
+class LocalPointsBatch:
+    """Tracking::SearchLocalPoints for a batch of frames that stay on the device (orbm_search_local_points_batch): the frames are images
+    [first, first + B) of ext's last extraction, the local map is a ResidentPoints, poses = B x (Rcw, tcw).  enqueue() is asynchronous, fetch()
+    returns (assigned [B, cap], nmatches [B], in_view [B, M] or None)."""
+
+    def __init__(self, ext, resident, B, cam, bounds, mbf, scale_factors):
+        self.ext, self.res, self.B = ext, resident, B
+        self.cam, self.bounds, self.mbf = cam, bounds, mbf
+        self.sf = np.ascontiguousarray(scale_factors, np.float32)
+        self.views = (_FrustumView * B)()
+        self.cap = ext.max_keypoints()
+        self.assigned = np.full((B, self.cap), -1, np.int32); self.nm = np.zeros(B, np.int32)
+        self.in_view = np.zeros((B, max(resident.M, 1)), np.uint8)
+
+    def set_poses(self, poses):
+        for b, (R, t) in enumerate(poses):
+            frustum_view(R, t, self.cam, self.bounds, self.mbf, self.sf, into=self.views[b])
+            self.views[b].scale_factors = self.sf.ctypes.data
+
+    def enqueue(self, first=0, is_bad=None, has_obs=None, occupied=None, use_u_right=True, viewing_cos_limit=0.5, th=1.0, far_points=False, th_far=50.0, nnratio=0.8,
+                want_in_view=False):
+        L = self.ext._lib
+        u8 = lambda a: None if a is None else np.ascontiguousarray(a, np.uint8)
+        self._keep = (u8(is_bad), u8(has_obs), u8(occupied))
+        ptr = lambda a: None if a is None else a.ctypes.data
+        self._want = bool(want_in_view)
+        L.check(L.L.orbm_search_local_points_batch(self.ext._h, int(first), self.B, self.views, self.res._p, ptr(self._keep[0]), ptr(self._keep[1]), ptr(self._keep[2]),
+                                                   int(bool(use_u_right)), float(viewing_cos_limit), float(th), int(far_points), float(th_far), float(nnratio), int(self._want)))
+
+    def fetch(self):
+        L = self.ext._lib
+        L.check(L.L.orbm_search_local_points_fetch(self.ext._h, self.assigned.ctypes.data, self.cap, self.nm.ctypes.data, self.in_view.ctypes.data if self._want else None))
+        return self.assigned, self.nm, (self.in_view if self._want else None)
+
+
+def SearchLocalPoints(ext, frame, Rcw, tcw, cam, bounds, mbf, scale_factors, pos, normal, min_distance, max_distance, is_bad=None, has_obs=None, desc=None,
+                      viewing_cos_limit=0.5, th=1.0, far_points=False, th_far=50.0, nnratio=0.8, search=True, prepared=False, resident=None):
+    """Frame::isInFrustum (src/Frame.cc:667-773) for M map points and, with search=True, ORBmatcher::SearchByProjection(F, points, th, ...)
+    (src/ORBmatcher.cc:45-167) on those in view - Tracking::SearchLocalPoints (src/Tracking.cc:4009-4067) on the device.
+    cam: (fx, fy, cx, cy) or the 8 Kannala-Brandt parameters; bounds = (min_x, max_x, min_y, max_y); frame: views.frame_view(...).
+    Returns (track dict, assigned[N] or None, nmatches)."""
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    pos, normal, mn, mx = f32(pos).reshape(-1, 3), f32(normal).reshape(-1, 3), f32(min_distance), f32(max_distance)
+    M = len(pos)
+    V, sf = frustum_view(Rcw, tcw, cam, bounds, mbf, scale_factors)
     P = _WorldPointView()
     bad = None if is_bad is None else np.ascontiguousarray(is_bad, np.uint8); obs = None if has_obs is None else np.ascontiguousarray(has_obs, np.uint8)
     d = None if desc is None else np.ascontiguousarray(desc, np.uint8)

@@ -414,6 +414,8 @@ def _bind_frame_lib(L):
         L.ref_frame_stereo.restype = C.c_void_p
         L.ref_frame_stereo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_float] * 6 + [C.POINTER(C.c_int)] * 2
         L.ref_frame_destroy.argtypes = [C.c_void_p]
+        L.ref_frame_rgbd.restype = C.c_void_p
+        L.ref_frame_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_float] * 6 + [C.POINTER(C.c_int)]
         L.ref_frame_fisheye.restype = C.c_void_p
         L.ref_frame_fisheye.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p]
         L.ref_frame_fisheye_get3d.argtypes = [C.c_void_p] * 3
@@ -449,13 +451,20 @@ class ReferenceFrame:
     """ORB_SLAM3::Frame as built by the reference's own stereo constructor (src/Frame.cc:105-230) on a rectified pair."""
 
     def __init__(self, left, right, nfeatures=1200, scale=1.2, nlevels=8, ini=20, mn=7, gauss_variant=0, fx=458.654, fy=457.296, cx=367.215, cy=248.375, bf=458.654 * 0.110074, th_depth=35.0,
-                 lib=None):
+                 lib=None, depth=None):
+        """depth given (float32 [H, W]): the RGB-D constructor (src/Frame.cc:235-345) on (left = grey image, depth); `right` is ignored"""
         L = lib or reference_frame_lib()
-        left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
+        left = np.ascontiguousarray(left, np.uint8)
         n = C.c_int(); nr = C.c_int()
         self.L = L
-        self.h = L.ref_frame_stereo(left.ctypes.data, right.ctypes.data, left.shape[1], left.shape[0], nfeatures, scale, nlevels, ini, mn, gauss_variant,
-                                    fx, fy, cx, cy, bf, th_depth, C.byref(n), C.byref(nr))
+        if depth is not None:
+            depth = np.ascontiguousarray(depth, np.float32)
+            self.h = L.ref_frame_rgbd(left.ctypes.data, depth.ctypes.data, left.shape[1], left.shape[0], nfeatures, scale, nlevels, ini, mn, gauss_variant,
+                                      fx, fy, cx, cy, bf, th_depth, C.byref(n))
+        else:
+            right = np.ascontiguousarray(right, np.uint8)
+            self.h = L.ref_frame_stereo(left.ctypes.data, right.ctypes.data, left.shape[1], left.shape[0], nfeatures, scale, nlevels, ini, mn, gauss_variant,
+                                        fx, fy, cx, cy, bf, th_depth, C.byref(n), C.byref(nr))
         N, NR = n.value, nr.value
         self.N = N
         self.keys = np.zeros(N, KP_DTYPE); self.keys_un = np.zeros(N, KP_DTYPE); self.desc = np.zeros((N, 32), np.uint8)
