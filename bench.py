@@ -46,8 +46,9 @@ CONFIGS = {
                              "(2-NN + ratio + triangulation gate) (BASELINE.json configs[2])"),
     "rgbd": dict(W=640, H=480, nf=1000, lap=(0, 0), kind="rgbd", unit="frames/s",
                  metric="frames/sec ORB extract + SearchLocalPoints, 640x480 RGB-D @1000 feat, 5000 map points (BASELINE.json configs[3])",
-                 workload="TUM-RGB-D-shaped 640x480 RGB frames, nFeatures=1000: cvtColor + extraction on the device, then per frame isInFrustum + "
-                          "SearchByProjection against a 5000-point local map (BASELINE.json configs[3])"),
+                 workload="TUM-RGB-D-shaped 640x480 RGB frames, nFeatures=1000: cvtColor + extraction, ComputeStereoFromRGBD (uRight from the depth image), then per "
+                          "frame isInFrustum + SearchByProjection (right-coordinate gate active, accept loop on the device) against a resident 5000-point local map, "
+                          "one pose per frame, all frames of a step in one batch (BASELINE.json configs[3])"),
 }
 
 
@@ -278,22 +279,47 @@ def main():
         kb.cam1[:] = KB_CAM1; kb.cam2[:] = KB_CAM2; kb.R12[:] = KB_RLR.ravel().tolist(); kb.t12[:] = KB_TLR.tolist()
     local_map = None
     if kind == "rgbd":
-        # 50 key frames' worth of local map: 5000 points in front of the camera, descriptors of random keypoints of the first frame
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        # BASELINE.json configs[3]: per frame ComputeStereoFromRGBD (uRight from the depth image) + Tracking::SearchLocalPoints against a local map
+        # of 5000 points (50 key frames' worth), all of it on the device (orbm_stereo_from_depth + orbm_search_local_points_batch): the frames are
+        # read where the extractor left them, the local map is resident, every frame has its own pose; mvuRight / mvDepth, the keypoint -> map
+        # point assignments and the match counts come back to the host inside the timed region.
+        RGBD_BF = 40.0                                              # Examples/RGB-D/TUM1.yaml Camera.bf
         rng = np.random.default_rng(7 + rank)
-        handles[0].enqueue(None, LAP, device_ptr=dptrs[0], shape=shape3, stride=stride); r0 = handles[0].fetch()[0]
-        k0, d0 = r0[1], r0[2]
+        yy, xx = np.mgrid[0:H, 0:W]
+        depth = (2.5 + 1.5 * np.sin(xx / 57.0) * np.cos(yy / 43.0)).astype(np.float32)      # the scene's depth (m), the same for every frame
+        depth[rng.uniform(size=(H, W)) < 0.1] = 0.0                                          # missing readings
+        handles[0].enqueue(None, LAP, device_ptr=dptrs[0], shape=shape3, stride=stride); r_all = handles[0].fetch()
         Mp = 5000
-        src = rng.integers(0, len(k0), Mp); z = rng.uniform(0.5, 8.0, Mp)
-        X = np.stack([(k0["x"][src] + rng.normal(0, 1.0, Mp) - CX) / FX * z, (k0["y"][src] + rng.normal(0, 1.0, Mp) - CY) / FY * z, z], 1).astype(np.float32)
+        fsrc = rng.integers(0, P, Mp)                                # the key frame (here: batch frame) a map point was created from
+        X = np.zeros((Mp, 3), np.float32); dsc = np.zeros((Mp, 32), np.uint8); octv = np.zeros(Mp, np.int64)
+        for i in range(Mp):
+            k0, d0 = r_all[fsrc[i]][1], r_all[fsrc[i]][2]
+            j = int(rng.integers(0, len(k0)))
+            u, v = float(k0["x"][j]), float(k0["y"][j])
+            z = float(depth[int(v), int(u)]) or float(rng.uniform(1.0, 4.0))
+            z *= float(rng.uniform(0.97, 1.03))
+            X[i] = ((u + rng.normal(0, 0.7) - CX) / FX * z, (v + rng.normal(0, 0.7) - CY) / FY * z, z)
+            dsc[i] = d0[j]; octv[i] = k0["octave"][j]
+            if rng.uniform() < 0.6:
+                for bit in rng.choice(256, int(rng.integers(0, 41)), replace=False):
+                    dsc[i, bit >> 3] ^= np.uint8(1 << (bit & 7))
+            else:
+                dsc[i] = rng.integers(0, 256, 32, dtype=np.uint8)
         dn = np.linalg.norm(X, axis=1); nrm = (X / dn[:, None]).astype(np.float32)
-        maxd = (dn * 1.2 ** k0["octave"][src]).astype(np.float32); mind = (maxd / 1.2 ** 7).astype(np.float32)
-        dsc = d0[src].copy(); flip = rng.uniform(size=Mp) < 0.6
-        for i in np.nonzero(flip)[0]:
-            for b in rng.choice(256, int(rng.integers(0, 41)), replace=False):
-                dsc[i, b >> 3] ^= np.uint8(1 << (b & 7))
-        dsc[~flip] = rng.integers(0, 256, ((~flip).sum(), 32), dtype=np.uint8)
-        local_map = dict(pos=X, normal=nrm, mind=mind, maxd=maxd, desc=dsc, sfs=handles[0].GetScaleFactors())
+        maxd = (dn * 1.2 ** octv).astype(np.float32); mind = (maxd / 1.2 ** 7).astype(np.float32)
+        sfs = handles[0].GetScaleFactors()
+        poses = []
+        for b in range(P):                                           # small per-frame motion around the map's reference pose
+            a = rng.normal(0, 0.004, 3); t = rng.normal(0, 0.01, 3).astype(np.float32)
+            Rx = np.array([[1, -a[2], a[1]], [a[2], 1, -a[0]], [-a[1], a[0], 1]], np.float64)
+            uu, _, vv = np.linalg.svd(Rx)
+            poses.append(((uu @ vv).astype(np.float32), t))
+        local_map = []
+        for h in handles:
+            rp = M.ResidentPoints(h, X, nrm, mind, maxd, dsc)
+            lp = M.LocalPointsBatch(h, rp, P, (FX, FY, CX, CY), (0.0, float(W), 0.0, float(H)), RGBD_BF, sfs)
+            lp.set_poses(poses)
+            local_map.append(dict(rp=rp, lp=lp, depth=h.device_upload(np.broadcast_to(depth, (P, H, W)).copy()), bf=RGBD_BF))
 
     # PCIe-inclusive variant: page-locked host copies of the inputs and two device buffers per handle (upload of the next batch beside the kernels)
     host_in, dbuf, dsel = None, None, None
@@ -321,6 +347,10 @@ def main():
             lib.check(lib.L.orbm_stereo_match(h._h, 0, h._h, P, P, BF, BASE))
         elif kind == "fisheye":
             lib.check(lib.L.orbm_stereo_fisheye(h._h, 0, h._h, P, P, C.byref(kb)))
+        elif kind == "rgbd":
+            lm = local_map[i]
+            M.ComputeStereoFromRGBD(h, None, lm["bf"], device_ptr=lm["depth"], shape=(P, H, W))
+            lm["lp"].enqueue(0, use_u_right=True, viewing_cos_limit=0.5, th=3.0, far_points=False, nnratio=0.8)     # th = 3: the RGB-D setting, src/Tracking.cc:4038-4039
 
     # --allgather (BASELINE.json configs[4]): the descriptor blocks of every finished batch go to all ranks; the collective of batch i runs on a
     # side stream beside the extraction of the following batches and is waited for when its handle comes round again
@@ -349,17 +379,9 @@ def main():
         elif kind == "fisheye":
             lib.check(lib.L.orbm_stereo_fisheye_fetch(h._h, P, o["l2r"].ctypes.data, o["r2l"].ctypes.data, o["z"].ctypes.data, o["p3"].ctypes.data, o["nm"].ctypes.data, cap))
         elif kind == "rgbd":
-            from orb_slam3_detailed_comments_amd import views
-            from orb_slam3_detailed_comments_amd._lib import KP_DTYPE
-            lm = local_map; tot = 0
-            kview = o["k"].view(KP_DTYPE).reshape(NIMG, cap)
-            for b in range(NIMG):
-                n = int(o["n"][b])
-                fv = views.frame_view(kview[b, :n], o["d"][b, :n], lm["sfs"], W, H)
-                _, asg, nm = M.SearchLocalPoints(h, fv, np.eye(3, dtype=np.float32), np.zeros(3, np.float32), (FX, FY, CX, CY), (0.0, float(W), 0.0, float(H)), 0.0, lm["sfs"],
-                                                 lm["pos"], lm["normal"], lm["mind"], lm["maxd"], None, None, lm["desc"], 0.5, 3.0, False, 50.0, 0.8)
-                tot += nm
-            o["nm"][0] = tot
+            lib.check(lib.L.orbm_stereo_fetch(h._h, P, o["u"].ctypes.data, o["z"].ctypes.data, cap, o["nm"].ctypes.data))
+            _, nm_frames, _ = local_map[i]["lp"].fetch()
+            o["nm"][0] = int(nm_frames.sum())
         if record:
             step_end.append(time.perf_counter())
             for k, v in h.stage_ms().items():

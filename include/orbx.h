@@ -233,8 +233,9 @@ typedef struct OrbmLastFrameView {        /* what SearchByProjection(CurrentFram
 
 /* C1 on the device: Frame::isInFrustum (src/Frame.cc:667-773, one camera) + Pinhole / KannalaBrandt8::project + MapPoint::PredictScale
  * (src/MapPoint.cc:688-731) for M map points at once, in the reference's fp32 operation order (Eigen's 3x3 * 3x1 product summed left to
- * right, no fused multiply-adds; the double log of PredictScale is the device's).  The outputs are the fields the reference stores in the
- * MapPoint: mbTrackInView, mTrackProjX / Y / XR, mTrackDepth, mTrackViewCos, mnTrackScaleLevel (any pointer may be NULL). */
+ * right, no fused multiply-adds).  The outputs are the fields the reference stores in the
+ * MapPoint: mbTrackInView, mTrackProjX / Y / XR, mTrackDepth, mTrackViewCos, mnTrackScaleLevel (`out` itself is required; any array pointer in
+ * it may be NULL).  MapPoint::PredictScale's log is glibc's logf (the reference's std::log(float)), reproduced bit for bit on the device. */
 typedef struct OrbmFrustumView {
     float Rcw[9], tcw[3], Ow[3];          /* Frame::mRcw (row-major), mtcw, mOw */
     int camera_type;                      /* GeometricCamera::GetType(): 0 pinhole (cam = fx, fy, cx, cy), 1 Kannala-Brandt (8 parameters) */
@@ -392,6 +393,27 @@ typedef struct OrbmMapPointRightView {    /* the *R tracking fields of MapPoint,
 int orbm_search_by_projection_mappoints_fisheye(orbx_extractor* h, const OrbmFisheyeFrameView* F, const OrbmMapPointView* P,
                                                 const OrbmMapPointRightView* PR, float th, int far_points, float th_far_points,
                                                 float nnratio, int* assigned, int* nmatches);
+/* Frame::isInFrustum for a two-camera rig (Nleft != -1, src/Frame.cc:754-766): Frame::isInFrustumChecks (:1592-1650) once per camera on the
+ * device.  `left` = camera 1 as in OrbmFrustumView (mRcw, mtcw, mOw, mpCamera, the image bounds); camera 2 is derived exactly as the reference
+ * derives it: mR = Rrl * mRcw, mt = Rrl * mtcw + trl, twc = mRwc * tlr + mOw (3-term sums left to right), projected with mpCamera2.  A point
+ * that fails any test of a camera leaves that camera's fields untouched in the reference; here its in-view flag is 0, its level -1 and the
+ * other fields unspecified. */
+typedef struct OrbmFrustumRigView {
+    OrbmFrustumView left;                 /* camera 1 */
+    float Rrl[9], trl[3];                 /* mTrl.rotationMatrix() (row-major), mTrl.translation() */
+    float tlr[3];                         /* mTlr.translation() */
+    float Rwc[9];                         /* mRwc (row-major) */
+    int camera2_type; float cam2[8];      /* mpCamera2: GetType(), parameters */
+} OrbmFrustumRigView;
+typedef struct OrbmTrackOutRight { uint8_t* in_view_r; float *proj_xr, *proj_yr, *depth_r, *view_cos_r; int* scale_level_r; } OrbmTrackOutRight;   /* the *R fields, include/MapPoint.h:175-179 */
+int orbm_is_in_frustum_rig(orbx_extractor* h, const OrbmFrustumRigView* frame, const OrbmWorldPointView* points, float viewing_cos_limit,
+                           const OrbmTrackOut* left, const OrbmTrackOutRight* right);
+/* Tracking::SearchLocalPoints for a rig frame (src/Tracking.cc:3979-4067 with Nleft != -1): the two-camera isInFrustum on the device, then
+ * ORBmatcher::SearchByProjection(F, points, th, bFarPoints, thFarPoints) with its right-camera branch (src/ORBmatcher.cc:45-239).  assigned has
+ * Nleft + Nright entries; left / right (may be NULL) receive the tracking fields. */
+int orbm_search_local_points_fisheye(orbx_extractor* h, const OrbmFisheyeFrameView* F, const OrbmFrustumRigView* frame, const OrbmWorldPointView* points,
+                                     float viewing_cos_limit, float th, int far_points, float th_far, float nnratio, const OrbmTrackOut* left,
+                                     const OrbmTrackOutRight* right, int* assigned, int* nmatches);
 /* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) with CurrentFrame.Nleft != -1
  * (src/ORBmatcher.cc:1950-2184 including :2090-2150).  proj_ur / proj_vr [Last->N] = project(GetRelativePoseTrl() * x3Dc).
  * assigned has Nleft + Nright entries (-1 untouched, -2 reset by the rotation check). */

@@ -148,6 +148,49 @@ int ref_frame_search_local_points(void* h, const float* R, const float* t, int M
     return n;
 }
 
+// The same for a two-camera rig frame (ref_frame_fisheye): Frame::isInFrustum takes its Nleft != -1 branch (src/Frame.cc:754-766 ->
+// isInFrustumChecks :1592-1650 once per camera) and SearchByProjection its right-camera branch (src/ORBmatcher.cc:170-236).
+// track: 13 arrays of M entries: in_view, proj_x, proj_y, depth, view_cos, scale_level, in_view_r, proj_xr, proj_yr, depth_r, view_cos_r,
+// scale_level_r, (unused).  The fields of a camera whose checks fail keep the sentinels the driver wrote (-7).
+// pose_out (45 floats): mRcw 9, mtcw 3, mOw 3, mRwc 9, Trl rotation 9, Trl translation 3, Tlr translation 3, then 6 unused - what the product's
+// OrbmFrustumRigView takes, read from the reference Frame itself after SetPose.
+int ref_frame_search_local_points_rig(void* h, const float* R, const float* t, int M, const float* pos, const float* normal, const float* min_dist, const float* max_dist,
+                                      const uint8_t* bad, const uint8_t* has_obs, const uint8_t* desc, float cos_limit, float* track, int do_search, float th, int far_points,
+                                      float th_far, float nnratio, int* assigned, float* pose_out) {
+    Frame* F = ((Holder*)h)->frame;
+    Sophus::SE3f Tcw;
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Tcw.R(i, j) = R[3 * i + j]; Tcw.t[i] = t[i]; }
+    F->SetPose(Tcw);
+    {
+        const Eigen::Matrix3f Rcw = F->GetPose().rotationMatrix(), Rwc = F->GetRwc(), Rrl = F->GetRelativePoseTrl().rotationMatrix();
+        const Eigen::Vector3f tcw = F->GetPose().translation(), Ow = F->GetOw(), trl = F->GetRelativePoseTrl().translation(), tlr = F->GetRelativePoseTlr().translation();
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { pose_out[3 * i + j] = Rcw(i, j); pose_out[15 + 3 * i + j] = Rwc(i, j); pose_out[24 + 3 * i + j] = Rrl(i, j); }
+        for (int i = 0; i < 3; i++) { pose_out[9 + i] = tcw(i); pose_out[12 + i] = Ow(i); pose_out[33 + i] = trl(i); pose_out[36 + i] = tlr(i); }
+    }
+    std::vector<MapPoint> mps(M);
+    std::vector<MapPoint*> vp(M);
+    const size_t Ms = (size_t)M;
+    for (int i = 0; i < M; i++) {
+        MapPoint& p = mps[i];
+        p.pos = Eigen::Vector3f(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]); p.normal = Eigen::Vector3f(normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]);
+        p.minDist = min_dist[i]; p.maxDist = max_dist[i]; p.bad = bad && bad[i]; p.nObs = has_obs ? (has_obs[i] ? 2 : 0) : 1;
+        p.descriptor = cv::Mat(1, 32, CV_8U); memcpy(p.descriptor.ptr(0), desc + 32 * (size_t)i, 32);
+        p.mTrackProjX = p.mTrackProjY = p.mTrackDepth = p.mTrackViewCos = p.mTrackProjXR = p.mTrackProjYR = p.mTrackDepthR = p.mTrackViewCosR = -7.0f;
+        vp[i] = &p;
+        F->isInFrustum(&p, cos_limit);
+        track[i] = p.mbTrackInView; track[Ms + i] = p.mTrackProjX; track[2 * Ms + i] = p.mTrackProjY; track[3 * Ms + i] = p.mTrackDepth; track[4 * Ms + i] = p.mTrackViewCos;
+        track[5 * Ms + i] = (float)p.mnTrackScaleLevel;
+        track[6 * Ms + i] = p.mbTrackInViewR; track[7 * Ms + i] = p.mTrackProjXR; track[8 * Ms + i] = p.mTrackProjYR; track[9 * Ms + i] = p.mTrackDepthR; track[10 * Ms + i] = p.mTrackViewCosR;
+        track[11 * Ms + i] = (float)p.mnTrackScaleLevelR;
+    }
+    if (!do_search) return 0;
+    std::fill(F->mvpMapPoints.begin(), F->mvpMapPoints.end(), (MapPoint*)nullptr);
+    ORBmatcher matcher(nnratio);
+    const int n = matcher.SearchByProjection(*F, vp, th, far_points != 0, th_far);
+    for (int i = 0; i < F->N; i++) assigned[i] = F->mvpMapPoints[i] ? (int)(F->mvpMapPoints[i] - mps.data()) : -1;
+    return n;
+}
+
 // bench.py's cpu_baseline: the reference's steady state - two long-lived extractors (Tracking owns them), one Frame temporary per stereo
 // pair built in the same storage (the constructor itself runs the two extractions on two threads).  Returns the number of frames
 // constructed in `seconds`; *elapsed = the time they took.

@@ -27,7 +27,7 @@ SYMBOLS = [
     "orbx_extract", "orbx_extract_batch", "orbx_set_input", "orbx_fetch", "orbx_sync", "orbx_pyramid_level", "orbx_pyramid_fetch",
     "orbx_device_alloc", "orbx_device_free", "orbx_device_upload", "orbx_device_upload_async", "orbx_device_outputs", "orbx_device_snapshot", "orbx_device_id", "orbx_host_alloc", "orbx_host_free", "orbx_set_graph_replay", "orbx_profile_enable",
     "orbx_profile_get", "orbx_stage_name", "orbx_debug_candidates", "orbx_debug_level_keys", "orbx_debug_quadtree_profile", "orbx_debug_simd_selftest", "orbx_debug_stereo_flags",
-    "orbm_hamming_matrix", "orbm_stereo_match", "orbm_stereo_fetch", "orbm_knn2", "orbm_knn2_fetch", "orbm_stereo_fisheye", "orbm_stereo_fisheye_fetch", "orbm_search_for_triangulation_kb8", "orbm_is_in_frustum", "orbm_search_local_points",
+    "orbm_hamming_matrix", "orbm_stereo_match", "orbm_stereo_fetch", "orbm_knn2", "orbm_knn2_fetch", "orbm_stereo_fisheye", "orbm_stereo_fisheye_fetch", "orbm_search_for_triangulation_kb8", "orbm_is_in_frustum", "orbm_is_in_frustum_rig", "orbm_search_local_points_fisheye", "orbm_search_local_points",
     "orbm_get_features_in_area", "orbm_search_by_projection_mappoints", "orbm_search_by_projection_frame",
     "orbm_search_for_triangulation", "orbm_search_by_bow", "orbm_search_by_bow_batch", "orbm_keyframe_create", "orbm_points_create", "orbm_points_destroy", "orbm_search_local_points_resident", "orbm_stereo_from_depth", "orbm_search_local_points_batch", "orbm_search_local_points_fetch", "orbm_keyframe_destroy", "orbm_search_for_triangulation_resident", "orbm_search_for_triangulation_resident_kb8", "orbm_search_by_bow_resident", "orbm_search_by_bow_fisheye", "orbm_search_for_initialization", "orbm_area_search_batch",
     "orbm_search_by_projection_sim3", "orbm_search_by_projection_keyframe", "orbm_fuse_candidates", "orbm_search_by_sim3", "orbm_distinctive_descriptors",
@@ -96,6 +96,8 @@ class OrbxLib:
         L.orbm_stereo_fisheye_fetch.argtypes = [vp, i, vp, vp, vp, vp, vp, i]
         L.orbm_search_for_triangulation_kb8.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp, ip]
         L.orbm_is_in_frustum.argtypes = [vp, vp, vp, f, vp]
+        L.orbm_is_in_frustum_rig.argtypes = [vp, vp, vp, f, vp, vp]
+        L.orbm_search_local_points_fisheye.argtypes = [vp, vp, vp, vp, f, f, i, f, f, vp, vp, vp, ip]
         L.orbm_search_local_points.argtypes = [vp, vp, vp, vp, f, f, i, f, f, vp, vp, ip]
         L.orbm_get_features_in_area.argtypes = [vp, vp, f, f, f, i, i, vp, i]
         L.orbm_search_by_projection_mappoints.argtypes = [vp, vp, vp, f, i, f, f, vp, ip]

@@ -71,6 +71,14 @@ int upload_frame(orbx_extractor* h, const OrbmFrameView* F, DeviceFrame* D) {
 }
 
 struct Csr { std::vector<int> start, count; std::vector<int> ent; };   // ent: 2 ints per candidate {idx, dist | octave << 16}
+void fill_frustum_params(const OrbmFrustumView* V, float cos_limit, float th, int far_points, float th_far, FrustumParams* Fp) {
+    memset(Fp, 0, sizeof *Fp);
+    memcpy(Fp->Rcw, V->Rcw, sizeof Fp->Rcw); memcpy(Fp->tcw, V->tcw, sizeof Fp->tcw); memcpy(Fp->Ow, V->Ow, sizeof Fp->Ow);
+    memcpy(Fp->cam, V->cam, sizeof Fp->cam); Fp->kb8 = V->camera_type == 1;
+    Fp->min_x = V->min_x; Fp->max_x = V->max_x; Fp->min_y = V->min_y; Fp->max_y = V->max_y; Fp->mbf = V->mbf; Fp->log_scale_factor = V->log_scale_factor; Fp->nlevels = V->nlevels;
+    for (int l = 0; l < V->nlevels; l++) Fp->scale_factors[l] = V->scale_factors[l];
+    Fp->cos_limit = cos_limit; Fp->th = th; Fp->th_far = th_far; Fp->far_points = far_points;
+}
 
 // runs k_area_search for Q queries.  Results come back in one copy: [total, -, -, -][start Q][count Q][entries]; the number of
 // entries fetched with the header is a guess from the previous call, a second copy follows only if it was too small, and the pool is
@@ -245,7 +253,7 @@ int orbm_search_by_projection_mappoints(orbx_extractor* h, const OrbmFrameView* 
 namespace {
 struct FrustumDev { uint8_t* in_view; float* track; int* level; AreaQuery* queries; const unsigned long long* qdesc; };
 int enqueue_frustum(orbx_extractor* h, const OrbmFrustumView* V, const OrbmWorldPointView* P, float cos_limit, bool with_queries, float th, int far_points, float th_far,
-                    FrustumDev* out) {
+                    FrustumDev* out, const FrustumParams* second = nullptr, FrustumDev* out2 = nullptr) {
     if (!V || !P || P->M < 0 || (P->M > 0 && (!P->pos || !P->normal || !P->min_distance || !P->max_distance))) return fail(ORBX_E_ARG, "bad frustum arguments");
     if (V->nlevels < 1 || V->nlevels > kMaxLevels || !V->scale_factors) return fail(ORBX_E_ARG, "bad scale levels");
     const int M = P->M; const size_t M1 = M > 0 ? M : 1;
@@ -253,7 +261,7 @@ int enqueue_frustum(orbx_extractor* h, const OrbmFrustumView* V, const OrbmWorld
     const size_t oq = 0, od = oq + al16(sizeof(AreaQuery) * M1), op = od + al16(32 * M1), on = op + al16(12 * M1), omn = on + al16(12 * M1), omx = omn + al16(4 * M1),
                  ob = omx + al16(4 * M1), total = ob + al16(M1);
     const size_t ot = 0, ol = ot + al16(20 * M1), ov = ol + al16(4 * M1), ototal = ov + al16(M1);
-    if (h->h_packB.ensure(total + 16) || h->d_sr[SR_QUERY].ensure(total + 16) || h->d_sr[SR_SPARE].ensure(ototal + 16)) return fail(ORBX_E_DEVICE, "upload/allocation failed");
+    if (h->h_packB.ensure(total + 16) || h->d_sr[SR_QUERY].ensure(total + 16) || h->d_sr[SR_SPARE].ensure(2 * ototal + 16)) return fail(ORBX_E_DEVICE, "upload/allocation failed");
     uint8_t* hp = h->h_packB.p;
     if (M > 0) {
         if (P->desc) memcpy(hp + od, P->desc, 32 * (size_t)M); else if (with_queries) return fail(ORBX_E_ARG, "map point descriptors missing");
@@ -268,6 +276,7 @@ int enqueue_frustum(orbx_extractor* h, const OrbmFrustumView* V, const OrbmWorld
     F.min_x = V->min_x; F.max_x = V->max_x; F.min_y = V->min_y; F.max_y = V->max_y; F.mbf = V->mbf; F.log_scale_factor = V->log_scale_factor; F.nlevels = V->nlevels;
     for (int l = 0; l < V->nlevels; l++) F.scale_factors[l] = V->scale_factors[l];
     F.cos_limit = cos_limit; F.th = th; F.th_far = th_far; F.far_points = far_points;
+    F.rig_mode = second ? 1 : 0;
     uint8_t* di = h->d_sr[SR_QUERY].p; uint8_t* dout = h->d_sr[SR_SPARE].p;
     out->in_view = dout + ov; out->track = (float*)(dout + ot); out->level = (int*)(dout + ol);
     out->queries = with_queries ? (AreaQuery*)(di + oq) : nullptr; out->qdesc = (const unsigned long long*)(di + od);
@@ -275,6 +284,15 @@ int enqueue_frustum(orbx_extractor* h, const OrbmFrustumView* V, const OrbmWorld
         dim3 grid((M + 255) / 256, 1, 1), blk(256, 1, 1);
         ORBX_LAUNCH(k_frustum, grid, blk, 0, h->s0, F, M, (const float*)(di + op), (const float*)(di + on), (const float*)(di + omn), (const float*)(di + omx),
                     (const uint8_t*)(di + ob), out->in_view, out->track, out->level, out->queries, (int*)nullptr, (const FrustumParams*)nullptr);
+    }
+    if (second && out2) {                                           // the second camera of a rig: the same points, its own block behind the first one
+        F.rig_mode = 1;                                             // (both cameras of a rig store nothing for a rejected point; the caller passed V with rig semantics)
+        out2->in_view = dout + ototal + ov; out2->track = (float*)(dout + ototal + ot); out2->level = (int*)(dout + ototal + ol); out2->queries = nullptr; out2->qdesc = out->qdesc;
+        if (M > 0) {
+            dim3 grid((M + 255) / 256, 1, 1), blk(256, 1, 1);
+            ORBX_LAUNCH(k_frustum, grid, blk, 0, h->s0, *second, M, (const float*)(di + op), (const float*)(di + on), (const float*)(di + omn), (const float*)(di + omx),
+                        (const uint8_t*)(di + ob), out2->in_view, out2->track, out2->level, (AreaQuery*)nullptr, (int*)nullptr, (const FrustumParams*)nullptr);
+        }
     }
     return ORBX_OK;
 }
@@ -309,6 +327,48 @@ int orbm_is_in_frustum(orbx_extractor* h, const OrbmFrustumView* V, const OrbmWo
     FrustumDev D;
     int rc = enqueue_frustum(h, V, P, cos_limit, false, 1.0f, 0, 0.0f, &D); if (rc) return rc;
     return fetch_frustum(h, P->M, D, out);
+}
+
+// ---- Frame::isInFrustum with two cameras (Nleft != -1, src/Frame.cc:754-766): isInFrustumChecks (:1592-1650) once per camera ----
+namespace {
+inline float dot3(const float* a, int sa, const float* b, int sb) { return (a[0] * b[0] + a[sa] * b[sb]) + a[2 * sa] * b[2 * sb]; }   // the reference's 3-term sums, left to right
+// camera 2 of the rig as isInFrustumChecks(pMP, cos, bRight = true) sets it up: mR = Rrl * mRcw, mt = Rrl * mtcw + trl, twc = mRwc * tlr + mOw
+void right_camera_params(const OrbmFrustumRigView* V, float cos_limit, FrustumParams* Fp) {
+    OrbmFrustumView R = V->left;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R.Rcw[3 * i + j] = dot3(V->Rrl + 3 * i, 1, V->left.Rcw + j, 3);
+    for (int i = 0; i < 3; i++) R.tcw[i] = dot3(V->Rrl + 3 * i, 1, V->left.tcw, 1) + V->trl[i];
+    for (int i = 0; i < 3; i++) R.Ow[i] = dot3(V->Rwc + 3 * i, 1, V->tlr, 1) + V->left.Ow[i];
+    R.camera_type = V->camera2_type; memcpy(R.cam, V->cam2, sizeof R.cam);
+    fill_frustum_params(&R, cos_limit, 1.0f, 0, 0.0f, Fp);
+    Fp->rig_mode = 1;
+}
+void scatter_track_right(const uint8_t* blk, int M, const OrbmTrackOutRight* out) {
+    if (!out || M <= 0) return;
+    const size_t M1 = M, ol = al16(20 * M1), ov = ol + al16(4 * M1);
+    const float* tr = (const float*)blk;
+    if (out->in_view_r) memcpy(out->in_view_r, blk + ov, M1);
+    if (out->proj_xr) memcpy(out->proj_xr, tr, 4 * M1);
+    if (out->proj_yr) memcpy(out->proj_yr, tr + M1, 4 * M1);
+    if (out->depth_r) memcpy(out->depth_r, tr + 3 * M1, 4 * M1);
+    if (out->view_cos_r) memcpy(out->view_cos_r, tr + 4 * M1, 4 * M1);
+    if (out->scale_level_r) memcpy(out->scale_level_r, blk + ol, 4 * M1);
+}
+}  // namespace
+
+int orbm_is_in_frustum_rig(orbx_extractor* h, const OrbmFrustumRigView* V, const OrbmWorldPointView* P, float cos_limit, const OrbmTrackOut* left, const OrbmTrackOutRight* right) {
+    if (!h || !V || !P || !left || !right) return fail(ORBX_E_ARG, "null");
+    rt::set_device(h->device);
+    FrustumParams Fr; right_camera_params(V, cos_limit, &Fr);
+    FrustumDev D, D2;
+    int rc = enqueue_frustum(h, &V->left, P, cos_limit, false, 1.0f, 0, 0.0f, &D, &Fr, &D2); if (rc) return rc;
+    const int M = P->M;
+    if (M <= 0) return ORBX_OK;
+    const size_t n = track_block_bytes(M);
+    if (h->h_out.ensure(2 * n + 16)) return fail(ORBX_E_DEVICE, "pinned allocation failed");
+    if (rt::copy_d2h(h->h_out.p, D.track, 2 * n, h->s0) || rt::stream_sync(h->s0) || rt::check_launch()) return fail(ORBX_E_DEVICE, "frustum kernel failed: %s", rt::last_error());
+    scatter_track(h->h_out.p, M, left);
+    scatter_track_right(h->h_out.p + n, M, right);
+    return ORBX_OK;
 }
 
 // ---- map points that stay on the device (the local map changes slowly; Tracking::SearchLocalPoints visits it every frame) ----
@@ -478,16 +538,6 @@ int orbm_search_local_points_resident(orbx_extractor* h, const OrbmFrameView* F,
 // from orbm_stereo_match / orbm_stereo_from_depth); map points resident (orbm_points); one pose per frame.  Five launches for the whole batch:
 // grid build (B workgroups), frustum + window queries (B x M threads), window search (B x M waves), accept loop (one wave per frame) - nothing
 // visits the host between them; one upload (poses + call-time flags), one download (assignments, match counts, optionally mbTrackInView).
-namespace {
-void fill_frustum_params(const OrbmFrustumView* V, float cos_limit, float th, int far_points, float th_far, FrustumParams* Fp) {
-    memset(Fp, 0, sizeof *Fp);
-    memcpy(Fp->Rcw, V->Rcw, sizeof Fp->Rcw); memcpy(Fp->tcw, V->tcw, sizeof Fp->tcw); memcpy(Fp->Ow, V->Ow, sizeof Fp->Ow);
-    memcpy(Fp->cam, V->cam, sizeof Fp->cam); Fp->kb8 = V->camera_type == 1;
-    Fp->min_x = V->min_x; Fp->max_x = V->max_x; Fp->min_y = V->min_y; Fp->max_y = V->max_y; Fp->mbf = V->mbf; Fp->log_scale_factor = V->log_scale_factor; Fp->nlevels = V->nlevels;
-    for (int l = 0; l < V->nlevels; l++) Fp->scale_factors[l] = V->scale_factors[l];
-    Fp->cos_limit = cos_limit; Fp->th = th; Fp->th_far = th_far; Fp->far_points = far_points;
-}
-}  // namespace
 
 int orbm_stereo_from_depth(orbx_extractor* h, int first, int B, const float* depth, int stride, size_t image_stride, int on_device, float mbf) {
     if (!h || !depth || B <= 0 || first < 0 || first + B > h->lastB) return fail(ORBX_E_ARG, "bad frame range");
@@ -557,6 +607,7 @@ int orbm_search_local_points_batch(orbx_extractor* h, int first, int B, const Or
     g.min_x = frames[0].min_x; g.min_y = frames[0].min_y;
     g.gw_inv = (float)kGridColsHost / (frames[0].max_x - frames[0].min_x); g.gh_inv = (float)kGridRowsHost / (frames[0].max_y - frames[0].min_y);   // src/Frame.cc:190-191
     int* d_counter = (int*)(dp + o_res); int* d_nmatch = (int*)(dp + o_res + 16); int* d_assigned = (int*)(dp + o_res + 16 + al16(4 * B1));
+    if (h->profile) rt::event_record(h->ev_stage[ST_MATCH][0], h->s0);
     {
         dim3 grid(B, 1, 1), blkg(kGridThreads, 1, 1);
         ORBX_LAUNCH(k_grid_build, grid, blkg, 0, h->s0, kps, 0, g, (int*)(dp + o_cof), (int*)(dp + o_cst), (int*)(dp + o_cit), nper, cap);
@@ -575,6 +626,7 @@ int orbm_search_local_points_batch(orbx_extractor* h, int first, int B, const Or
         ORBX_LAUNCH(k_local_accept, grid, blk, 0, h->s0, M, cap, nper, (const int*)(dp + o_qs), (const int*)(dp + o_qc), (const int2*)(dp + o_pool),
                     occupied ? (const uint8_t*)(dp + u_occ) : (const uint8_t*)nullptr, (const uint8_t*)(dp + u_obs), nnratio, TH_HIGH, d_assigned, d_nmatch);
     }
+    if (h->profile) rt::event_record(h->ev_stage[ST_MATCH][1], h->s0);
     if (rt::check_launch()) return fail(ORBX_E_DEVICE, "kernel launch failed: %s", rt::last_error());
     h->lp_B = B; h->lp_M = M; h->lp_first = first; h->lp_o_counter = o_res; h->lp_o_view = o_view; h->lp_want_view = want_in_view != 0;
     return ORBX_OK;
@@ -591,6 +643,7 @@ int orbm_search_local_points_fetch(orbx_extractor* h, int* assigned, int cap, in
     if (in_view && h->lp_want_view && h->lp_M > 0) e |= rt::copy_d2h(hp + al16(res_bytes), h->d_lp.p + h->lp_o_view, B1 * M1, h->s0);
     if (e || rt::stream_sync(h->s0) || rt::check_launch()) return fail(ORBX_E_DEVICE, "batched local point search failed: %s", rt::last_error());
     h->lp_pending = false;
+    if (h->profile) h->stage_ms[ST_MATCH] = rt::event_elapsed_ms(h->ev_stage[ST_MATCH][0], h->ev_stage[ST_MATCH][1]);
     const int total = *(const int*)hp;
     if (h->lp_M > 0 && (size_t)total > h->lp_pool) {                // the candidate pool was too small: the caller enqueues again (the pool has grown)
         h->lp_pool = (size_t)total + (size_t)total / 8 + 4096;
@@ -1487,6 +1540,37 @@ int orbm_search_by_projection_mappoints_fisheye(orbx_extractor* h, const OrbmFis
         }
     }
     if (nmatches_out) *nmatches_out = nmatches;
+    return ORBX_OK;
+}
+
+int orbm_search_local_points_fisheye(orbx_extractor* h, const OrbmFisheyeFrameView* F, const OrbmFrustumRigView* V, const OrbmWorldPointView* P, float cos_limit, float th,
+                                     int far_points, float th_far, float nnratio, const OrbmTrackOut* left, const OrbmTrackOutRight* right, int* assigned, int* nmatches_out) {
+    if (!h || !F || !V || !P || !assigned) return fail(ORBX_E_ARG, "null");
+    if (P->M < 0 || (P->M > 0 && (!P->pos || !P->normal || !P->min_distance || !P->max_distance || !P->desc))) return fail(ORBX_E_ARG, "bad map point view");
+    const size_t M1 = P->M > 0 ? P->M : 1;
+    // the tracking fields of both cameras come back once (they are the reference's MapPoint members; the searches read them as views)
+    std::vector<uint8_t> inl(M1), inr(M1), zero(M1, 0), one(M1, 1);
+    std::vector<float> f(9 * M1);
+    std::vector<int> ll(M1), lr(M1);
+    OrbmTrackOut L = {inl.data(), f.data(), f.data() + M1, f.data() + 2 * M1, f.data() + 3 * M1, f.data() + 4 * M1, ll.data()};
+    OrbmTrackOutRight R = {inr.data(), f.data() + 5 * M1, f.data() + 6 * M1, f.data() + 7 * M1, f.data() + 8 * M1, lr.data()};
+    int rc = orbm_is_in_frustum_rig(h, V, P, cos_limit, &L, &R); if (rc) return rc;
+    OrbmMapPointView PV; memset(&PV, 0, sizeof PV);
+    PV.M = P->M; PV.in_view = L.in_view; PV.proj_x = L.proj_x; PV.proj_y = L.proj_y; PV.proj_xr = L.proj_xr; PV.scale_level = L.scale_level; PV.view_cos = L.view_cos;
+    PV.track_depth = L.depth; PV.is_bad = P->is_bad ? P->is_bad : zero.data(); PV.has_obs = P->has_obs ? P->has_obs : one.data(); PV.desc = P->desc;
+    OrbmMapPointRightView PR; PR.in_view_r = R.in_view_r; PR.proj_xr = R.proj_xr; PR.proj_yr = R.proj_yr; PR.scale_level_r = R.scale_level_r; PR.view_cos_r = R.view_cos_r;
+    rc = orbm_search_by_projection_mappoints_fisheye(h, F, &PV, &PR, th, far_points, th_far, nnratio, assigned, nmatches_out); if (rc) return rc;
+    const size_t n = (size_t)(P->M > 0 ? P->M : 0);
+    if (left) {
+        if (left->in_view) memcpy(left->in_view, L.in_view, n); if (left->proj_x) memcpy(left->proj_x, L.proj_x, 4 * n); if (left->proj_y) memcpy(left->proj_y, L.proj_y, 4 * n);
+        if (left->depth) memcpy(left->depth, L.depth, 4 * n); if (left->view_cos) memcpy(left->view_cos, L.view_cos, 4 * n); if (left->scale_level) memcpy(left->scale_level, L.scale_level, 4 * n);
+        if (left->proj_xr) memcpy(left->proj_xr, L.proj_xr, 4 * n);
+    }
+    if (right) {
+        if (right->in_view_r) memcpy(right->in_view_r, R.in_view_r, n); if (right->proj_xr) memcpy(right->proj_xr, R.proj_xr, 4 * n); if (right->proj_yr) memcpy(right->proj_yr, R.proj_yr, 4 * n);
+        if (right->depth_r) memcpy(right->depth_r, R.depth_r, 4 * n); if (right->view_cos_r) memcpy(right->view_cos_r, R.view_cos_r, 4 * n);
+        if (right->scale_level_r) memcpy(right->scale_level_r, R.scale_level_r, 4 * n);
+    }
     return ORBX_OK;
 }
 

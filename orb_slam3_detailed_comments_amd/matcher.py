@@ -261,6 +261,56 @@ class _TrackOut(C.Structure):
                 ("scale_level", C.c_void_p)]
 
 
+class _FrustumRigView(C.Structure):
+    _fields_ = [("left", _FrustumView), ("Rrl", C.c_float * 9), ("trl", C.c_float * 3), ("tlr", C.c_float * 3), ("Rwc", C.c_float * 9), ("camera2_type", C.c_int),
+                ("cam2", C.c_float * 8)]
+
+
+class _TrackOutRight(C.Structure):
+    _fields_ = [("in_view_r", C.c_void_p), ("proj_xr", C.c_void_p), ("proj_yr", C.c_void_p), ("depth_r", C.c_void_p), ("view_cos_r", C.c_void_p), ("scale_level_r", C.c_void_p)]
+
+
+def SearchLocalPointsRig(ext, frame2, pose, cam1, cam2, bounds, scale_factors, pos, normal, min_distance, max_distance, is_bad=None, has_obs=None, desc=None,
+                         viewing_cos_limit=0.5, th=1.0, far_points=False, th_far=50.0, nnratio=0.8, search=True):
+    """Tracking::SearchLocalPoints for a two-camera (fisheye rig) frame: Frame::isInFrustum with Nleft != -1 (src/Frame.cc:754-766 ->
+    isInFrustumChecks :1592-1650 per camera) on the device and, with search=True, ORBmatcher::SearchByProjection including its right-camera
+    branch (src/ORBmatcher.cc:45-239).  pose = dict(Rcw, tcw, Ow, Rwc, Rrl, trl, tlr) exactly as the Frame holds them; frame2 =
+    views.fisheye_frame_view(...) (None with search=False).  Returns (left dict, right dict, assigned [Nleft + Nright] or None, nmatches)."""
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    pos, normal, mn, mx, sf = f32(pos).reshape(-1, 3), f32(normal).reshape(-1, 3), f32(min_distance), f32(max_distance), f32(scale_factors)
+    M = len(pos)
+    V = _FrustumRigView()
+    frustum_view(pose["Rcw"], pose["tcw"], cam1, bounds, 0.0, sf, into=V.left)
+    V.left.Ow[:] = [float(v) for v in f32(pose["Ow"])]
+    V.left.scale_factors = sf.ctypes.data
+    V.Rrl[:] = f32(pose["Rrl"]).ravel().tolist(); V.trl[:] = f32(pose["trl"]).tolist(); V.tlr[:] = f32(pose["tlr"]).tolist(); V.Rwc[:] = f32(pose["Rwc"]).ravel().tolist()
+    cam2 = [float(v) for v in cam2]
+    V.camera2_type = 1 if len(cam2) == 8 else 0
+    V.cam2[:] = cam2 + [0.0] * (8 - len(cam2))
+    P = _WorldPointView()
+    bad = None if is_bad is None else np.ascontiguousarray(is_bad, np.uint8); obs = None if has_obs is None else np.ascontiguousarray(has_obs, np.uint8)
+    d = None if desc is None else np.ascontiguousarray(desc, np.uint8)
+    P.M = M; P.pos = pos.ctypes.data; P.normal = normal.ctypes.data; P.min_distance = mn.ctypes.data; P.max_distance = mx.ctypes.data
+    P.is_bad = None if bad is None else bad.ctypes.data; P.has_obs = None if obs is None else obs.ctypes.data; P.desc = None if d is None else d.ctypes.data
+    M1 = max(M, 1)
+    tl = dict(in_view=np.zeros(M1, np.uint8), proj_x=np.zeros(M1, np.float32), proj_y=np.zeros(M1, np.float32), proj_xr=np.zeros(M1, np.float32), depth=np.zeros(M1, np.float32),
+              view_cos=np.zeros(M1, np.float32), scale_level=np.zeros(M1, np.int32))
+    tr = dict(in_view_r=np.zeros(M1, np.uint8), proj_xr=np.zeros(M1, np.float32), proj_yr=np.zeros(M1, np.float32), depth_r=np.zeros(M1, np.float32),
+              view_cos_r=np.zeros(M1, np.float32), scale_level_r=np.zeros(M1, np.int32))
+    TL = _TrackOut(*[tl[k].ctypes.data for k in ("in_view", "proj_x", "proj_y", "proj_xr", "depth", "view_cos", "scale_level")])
+    TR = _TrackOutRight(*[tr[k].ctypes.data for k in ("in_view_r", "proj_xr", "proj_yr", "depth_r", "view_cos_r", "scale_level_r")])
+    L = ext._lib
+    cut = lambda dct: {k: v[:M] for k, v in dct.items()}
+    if not search:
+        L.check(L.L.orbm_is_in_frustum_rig(ext._h, C.byref(V), C.byref(P), float(viewing_cos_limit), C.byref(TL), C.byref(TR)))
+        return cut(tl), cut(tr), None, 0
+    N = frame2.view.left.N + frame2.view.right.N
+    assigned = np.full(max(N, 1), -1, np.int32); n = C.c_int(0)
+    L.check(L.L.orbm_search_local_points_fisheye(ext._h, frame2.ref(), C.byref(V), C.byref(P), float(viewing_cos_limit), float(th), int(far_points), float(th_far), float(nnratio),
+                                                 C.byref(TL), C.byref(TR), assigned.ctypes.data, C.byref(n)))
+    return cut(tl), cut(tr), assigned[:N], n.value
+
+
 class ResidentPoints:
     """orbm_points: position, normal, distance limits and descriptor of a set of map points, uploaded once (the local map)."""
 

@@ -545,6 +545,45 @@ def reference_distinctive_descriptors(desc, start, right_of_prev=None, bad_kf=No
     return out[:P], has[:P]
 
 
+class ReferenceRigFrame:
+    """The reference's fisheye-rig Frame (src/Frame.cc:1432-1528) kept alive for Frame::isInFrustum (two cameras) and
+    ORBmatcher::SearchByProjection(F, points, ...) with its right-camera branch.  cams = (cam1[8], cam2[8], Rlr[3,3], tlr[3])."""
+
+    def __init__(self, left, right, lap_left, lap_right, nfeatures, cams, scale=1.2, nlevels=8, ini=20, mn=7):
+        L = self.L = reference_frame_lib()
+        left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
+        out = np.zeros(4, np.int32)
+        cp = np.concatenate([np.asarray(c, np.float32).ravel() for c in cams]).astype(np.float32); assert cp.size == 28
+        self.h = L.ref_frame_fisheye(left.ctypes.data, right.ctypes.data, left.shape[1], left.shape[0], nfeatures, scale, nlevels, ini, mn, 0,
+                                     lap_left[0], lap_left[1], lap_right[0], lap_right[1], cp.ctypes.data, out.ctypes.data)
+        self.nl, self.nr, self.mono_left, self.mono_right = [int(v) for v in out]
+        self.keys = np.zeros(self.nl, KP_DTYPE); self.keys_right = np.zeros(self.nr, KP_DTYPE); self.desc = np.zeros((self.nl + self.nr, 32), np.uint8)
+        self.l2r = np.zeros(max(self.nl, 1), np.int32); self.r2l = np.zeros(max(self.nr, 1), np.int32)
+        L.ref_frame_fisheye_get(self.h, self.keys.ctypes.data, self.keys_right.ctypes.data, self.desc.ctypes.data, self.l2r.ctypes.data, self.r2l.ctypes.data)
+        self.l2r = self.l2r[:self.nl]; self.r2l = self.r2l[:self.nr]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ref_frame_destroy(self.h); self.h = None
+
+    def search_local_points(self, R, t, pos, normal, min_dist, max_dist, bad, has_obs, desc, cos_limit=0.5, search=True, th=1.0, far_points=False, th_far=50.0, nnratio=0.8):
+        """Returns (left dict, right dict, assigned [Nleft + Nright], nmatches, pose dict as the Frame holds it after SetPose)."""
+        M = len(pos)
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        R, t, pos, normal, min_dist, max_dist = f32(R), f32(t), f32(pos), f32(normal), f32(min_dist), f32(max_dist)
+        bad = np.ascontiguousarray(bad, np.uint8); has_obs = np.ascontiguousarray(has_obs, np.uint8); desc = np.ascontiguousarray(desc, np.uint8)
+        track = np.zeros((13, max(M, 1)), np.float32); assigned = np.full(max(self.nl + self.nr, 1), -1, np.int32); pose = np.zeros(45, np.float32)
+        fn = self.L.ref_frame_search_local_points_rig
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 7 + [C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        n = fn(self.h, R.ctypes.data, t.ctypes.data, M, pos.ctypes.data, normal.ctypes.data, min_dist.ctypes.data, max_dist.ctypes.data, bad.ctypes.data, has_obs.ctypes.data,
+               desc.ctypes.data, cos_limit, track.ctypes.data, int(search), th, int(far_points), th_far, nnratio, assigned.ctypes.data, pose.ctypes.data)
+        left = dict(in_view=track[0, :M] > 0, proj_x=track[1, :M], proj_y=track[2, :M], depth=track[3, :M], view_cos=track[4, :M], scale_level=track[5, :M].astype(np.int32))
+        right = dict(in_view_r=track[6, :M] > 0, proj_xr=track[7, :M], proj_yr=track[8, :M], depth_r=track[9, :M], view_cos_r=track[10, :M], scale_level_r=track[11, :M].astype(np.int32))
+        p = dict(Rcw=pose[0:9].reshape(3, 3), tcw=pose[9:12], Ow=pose[12:15], Rwc=pose[15:24].reshape(3, 3), Rrl=pose[24:33].reshape(3, 3), trl=pose[33:36], tlr=pose[36:39])
+        return left, right, assigned[:self.nl + self.nr], n, p
+
+
 def reference_fisheye_frame(left, right, lap_left, lap_right, nfeatures=1500, scale=1.2, nlevels=8, ini=20, mn=7, gauss_variant=0, cams=None):
     """The reference's fisheye-rig Frame constructor (src/Frame.cc:1432-1528).  cams = None: accept-all triangulation gate (the result is the
     kNN + ratio decision); cams = (cam1[8], cam2[8], Rlr[3,3], tlr[3]): gate = KannalaBrandt8::TriangulateMatches (restated camera).
