@@ -321,61 +321,151 @@ __global__ void __launch_bounds__(256) k_frustum(FrustumParams F, int M, const f
     }
 }
 
-// ORBmatcher::SearchByProjection(Frame, MapPoints) accept loop (src/ORBmatcher.cc:62-166) on the device, one wave per frame of a batch: the
-// loop is sequential over the map points (a keypoint that has received a map point WITH observations is skipped by every later point), so a
-// frame is one wave that walks its queries in order; the lanes share a query's candidates (best / second best = two wave minima over
-// (distance << 16 | position): the FIRST candidate with the smallest distance wins, the second best is the smallest among the others, as the
-// strict `<` tests of the reference leave them).  Frames are independent: the batch supplies the parallelism.
-// occupied0: [B][cap] bytes or NULL (Frame::mvpMapPoints[i] with observations before the call); has_obs: [M] or NULL (all observed).
-// assigned: [B][cap] = index of the map point given to the keypoint, -1 = untouched; nmatches: [B].
+// The window search of a BATCH of frames, one THREAD per query (k_area_search spends a wave on a query: right for one frame's few thousand
+// queries, which must finish in microseconds; a batch has hundreds of thousands and wants throughput).  A thread walks its window cells in the
+// reference's order (ix-major, iy-minor, items in insertion order), counts, the workgroup reserves its span of the entry pool with one
+// atomicAdd, and a second walk writes {idx, dist | octave << 16} at the thread's offset.  Same gates as k_area_search.  blockIdx.y = frame.
+// On pool overflow nothing is written and the counts are 0 (the host sees the counter, enlarges the pool and repeats).
+__global__ void __launch_bounds__(256) k_area_search_threads(const AreaQuery* __restrict__ queries, const unsigned long long* __restrict__ qdesc, int Q,
+                                                             const KeyPointRec* __restrict__ kps, const float* __restrict__ u_right,
+                                                             const unsigned long long* __restrict__ fdesc, GridParams g, const int* __restrict__ cell_start,
+                                                             const int* __restrict__ cell_items, int gate_right, int* __restrict__ pool_counter, int pool_cap,
+                                                             int* __restrict__ q_start, int* __restrict__ q_count, int2* __restrict__ entries, int frame_stride) {
+    __shared__ int s_scan[20];
+    __shared__ int s_base;
+    const size_t b = blockIdx.y;
+    const int q = (int)(blockIdx.x * 256 + threadIdx.x);
+    queries += b * (size_t)Q; q_start += b * (size_t)Q; q_count += b * (size_t)Q;
+    kps += b * (size_t)frame_stride; u_right += b * (size_t)frame_stride; fdesc += 4 * b * (size_t)frame_stride;
+    cell_start += b * (size_t)kGridCellStride; cell_items += b * (size_t)frame_stride;
+    AreaQuery A{};
+    if (q < Q) A = queries[q];
+    const int nMinX = imax(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(A.x, g.min_x), A.r), g.gw_inv)));
+    const int nMaxX = imin(kGridCols - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(A.x, g.min_x), A.r), g.gw_inv)));
+    const int nMinY = imax(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(A.y, g.min_y), A.r), g.gh_inv)));
+    const int nMaxY = imin(kGridRows - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(A.y, g.min_y), A.r), g.gh_inv)));
+    const bool window_ok = q < Q && A.active && !(nMinX >= kGridCols || nMaxX < 0 || nMinY >= kGridRows || nMaxY < 0) && nMaxX >= nMinX && nMaxY >= nMinY;
+    const bool check_levels = (A.min_level > 0) || (A.max_level >= 0);
+    int cnt = 0;
+    if (window_ok) {
+        for (int ix = nMinX; ix <= nMaxX; ix++) {
+            const int s = cell_start[ix * kGridRows + nMinY], e = cell_start[ix * kGridRows + nMaxY + 1];    // the cells of one column are consecutive
+            for (int j = s; j < e; j++) {
+                const int idx = cell_items[j];
+                const KeyPointRec k = kps[idx];
+                cnt += (area_accept(A, k, idx, check_levels, gate_right, u_right) && (A.gate != 2 || chi2_accept(A, k, u_right[idx], g))) ? 1 : 0;
+            }
+        }
+    }
+    int total;
+    const int excl = block_excl_scan<int>(cnt, &total, s_scan);
+    if (threadIdx.x == 0) s_base = total > 0 ? atomicAdd(pool_counter, total) : 0;
+    __syncthreads();
+    const bool fits = s_base + total <= pool_cap;
+    const int start = s_base + excl;
+    if (window_ok && cnt > 0 && fits) {
+        const unsigned long long* dq = qdesc + 4 * (size_t)q;
+        const unsigned long long d0 = dq[0], d1 = dq[1], d2 = dq[2], d3 = dq[3];
+        int pos = start;
+        for (int ix = nMinX; ix <= nMaxX; ix++) {
+            const int s = cell_start[ix * kGridRows + nMinY], e = cell_start[ix * kGridRows + nMaxY + 1];
+            for (int j = s; j < e; j++) {
+                const int idx = cell_items[j];
+                const KeyPointRec k = kps[idx];
+                if (!area_accept(A, k, idx, check_levels, gate_right, u_right)) continue;
+                if (A.gate == 2 && !chi2_accept(A, k, u_right[idx], g)) continue;
+                const unsigned long long* df = fdesc + 4 * (size_t)idx;
+                const int dist = __popcll(d0 ^ df[0]) + __popcll(d1 ^ df[1]) + __popcll(d2 ^ df[2]) + __popcll(d3 ^ df[3]);
+                int2 ent; ent.x = idx; ent.y = dist | (k.octave << 16);
+                entries[pos++] = ent;
+            }
+        }
+    }
+    if (q < Q) { q_start[q] = fits ? start : 0; q_count[q] = fits ? cnt : 0; }
+}
+
+// ORBmatcher::SearchByProjection(Frame, MapPoints) accept loop (src/ORBmatcher.cc:62-166) on the device, one wave per frame of a batch.
+// The loop is sequential over the map points: a keypoint that has received a map point WITH observations is skipped by every later point.
+// Conflicts are rare, so the wave works on 64 consecutive map points at a time, one per lane, optimistically:
+//   1. every pending lane walks its candidates against the current occupancy: best / second best exactly as the strict `<` tests of the
+//      reference leave them (the FIRST candidate with the smallest distance; the second best is the smallest among the others), decision;
+//   2. lanes whose decision occupies a keypoint publish the claim (LDS, minimum lane per keypoint);
+//   3. a lane is DIRTY if an earlier lane of this round claims one of its free candidates - its decision may not stand;
+//   4. the lanes before the first dirty one commit (their decisions are what the sequential loop produces: nothing earlier touches their
+//      candidates), the others repeat from 1 with the new occupancy.  The first pending lane is never dirty, so every round commits.
+// F.mvpMapPoints[idx] = pMP without observations does not occupy; a later point may overwrite it: assignments are merged with atomicMax on
+// the map point index (the sequential last writer is the largest index).
+// occupied0: [B][cap] bytes or NULL; has_obs: [M] or NULL (all observed).  assigned: [B][cap], -1 = untouched; nmatches: [B].
+// dynamic LDS: occupancy bitmap ((cap + 31) / 32 words) | claiming lane per keypoint (cap words).
 __global__ void __launch_bounds__(64) k_local_accept(int M, int cap, const int* __restrict__ n_per_frame, const int* __restrict__ q_start,
                                                      const int* __restrict__ q_count, const int2* __restrict__ entries, const uint8_t* __restrict__ occupied0,
                                                      const uint8_t* __restrict__ has_obs, float nnratio, int th_high, int* __restrict__ assigned,
                                                      int* __restrict__ nmatches) {
-    __shared__ uint32_t s_occ[2048];                               // one bit per keypoint (cap <= 65535)
+    ORBX_DYN_SMEM(smem);
+    const int nwords = (cap + 31) / 32;
+    uint32_t* s_occ = (uint32_t*)smem;
+    unsigned* s_claim = (unsigned*)(smem + 4 * (size_t)nwords);
     const int lane = lane_id();
     const size_t b = blockIdx.x;
     const int N = n_per_frame[b];
     q_start += b * (size_t)M; q_count += b * (size_t)M; assigned += b * (size_t)cap;
-    for (int w = lane; w < (cap + 31) / 32; w += 64) {
+    for (int w = lane; w < nwords; w += 64) {
         uint32_t bits = 0;
         if (occupied0) for (int k = 0; k < 32; k++) { const int i = 32 * w + k; if (i < N && occupied0[b * (size_t)cap + i]) bits |= 1u << k; }
         s_occ[w] = bits;
     }
-    for (int i = lane; i < cap; i += 64) assigned[i] = -1;
+    for (int i = lane; i < cap; i += 64) { assigned[i] = -1; s_claim[i] = 0xFFu; }
     ORBX_WAVE_SYNC();
     int nm = 0;
     for (int i0 = 0; i0 < M; i0 += 64) {
         const int qi = i0 + lane;
-        const int myc = qi < M ? q_count[qi] : 0, mys = qi < M ? q_start[qi] : 0;
-        unsigned long long todo = __ballot(myc > 0);
-        while (todo) {
-            const int l = __ffsll(todo) - 1; todo &= todo - 1ull;
-            const int cnt = __shfl(myc, l), st = __shfl(mys, l);
-            // lane-local two smallest keys among the candidates that are still free
-            unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
-            for (int k = lane; k < cnt; k += 64) {
-                const int2 e = entries[st + k];
-                if ((s_occ[e.x >> 5] >> (e.x & 31)) & 1u) continue;
-                const unsigned key = ((unsigned)(e.y & 0xFFFF) << 16) | (unsigned)k;
-                if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+        const int cnt = qi < M ? q_count[qi] : 0, st = qi < M ? q_start[qi] : 0;
+        const bool obs = qi < M && (!has_obs || has_obs[qi]);
+        bool pending = cnt > 0;
+        while (__ballot(pending) != 0ull) {
+            // 1. decision against the current occupancy
+            unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu; int e1 = 0, e2 = 0, idx1 = -1;      // keys (dist << 16 | position), packed dist | level << 16 of both, index of the best
+            if (pending) {
+                for (int k = 0; k < cnt; k++) {
+                    const int2 e = entries[st + k];
+                    if ((s_occ[e.x >> 5] >> (e.x & 31)) & 1u) continue;
+                    const unsigned key = ((unsigned)(e.y & 0xFFFF) << 16) | (unsigned)k;
+                    if (key < k1) { k2 = k1; e2 = e1; k1 = key; e1 = e.y; idx1 = e.x; } else if (key < k2) { k2 = key; e2 = e.y; }
+                }
             }
-            const unsigned best = wave_min_u32(k1);
-            if (best == 0xFFFFFFFFu) continue;                        // every candidate is taken
-            const unsigned second = wave_min_u32(k1 == best ? k2 : k1);
-            const int bestDist = (int)(best >> 16);
-            if (bestDist > th_high) continue;
-            const int2 eb = entries[st + (int)(best & 0xFFFFu)];
-            const int bestLevel = eb.y >> 16, bestIdx = eb.x;
-            int bestDist2 = 256, bestLevel2 = -1;
-            if (second != 0xFFFFFFFFu) { bestDist2 = (int)(second >> 16); bestLevel2 = entries[st + (int)(second & 0xFFFFu)].y >> 16; }
-            // :146-166  (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) -> no match
-            if (bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2)) continue;
-            if (lane == 0) {
-                assigned[bestIdx] = i0 + l;
-                if (!has_obs || has_obs[i0 + l]) s_occ[bestIdx >> 5] |= 1u << (bestIdx & 31);
+            bool accept = false;
+            if (pending && k1 != 0xFFFFFFFFu) {
+                const int bestDist = e1 & 0xFFFF, bestLevel = e1 >> 16;
+                int bestDist2 = 256, bestLevel2 = -1;
+                if (k2 != 0xFFFFFFFFu) { bestDist2 = e2 & 0xFFFF; bestLevel2 = e2 >> 16; }
+                // :146-166  bestDist <= TH_HIGH, and not (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2)
+                accept = bestDist <= th_high && !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2));
             }
-            nm++;
+            // 2. claims that occupy
+            const bool claims = accept && obs;
+            if (claims) atomicMin(&s_claim[idx1], (unsigned)lane);
+            ORBX_WAVE_SYNC();
+            // 3. dirty: an earlier lane claims one of my free candidates
+            bool dirty = false;
+            if (pending) {
+                for (int k = 0; k < cnt; k++) {
+                    const int idx = entries[st + k].x;
+                    if (s_claim[idx] < (unsigned)lane) { dirty = true; break; }
+                }
+            }
+            const unsigned long long dmask = __ballot(dirty);
+            const int first_dirty = dmask ? __ffsll(dmask) - 1 : 64;
+            ORBX_WAVE_SYNC();
+            if (claims) s_claim[idx1] = 0xFFu;                         // (every claimer of a slot restores it: the slot is 0xFF again for the next round)
+            ORBX_WAVE_SYNC();
+            // 4. commit the lanes before the first dirty one
+            const bool commit = pending && lane < first_dirty;
+            if (commit && accept) {
+                atomicMax(&assigned[idx1], qi);
+                if (obs) atomicOr(&s_occ[idx1 >> 5], 1u << (idx1 & 31));
+            }
+            nm += __popcll(__ballot(commit && accept));
+            if (commit) pending = false;
             ORBX_WAVE_SYNC();
         }
     }

@@ -8,6 +8,7 @@
 #pragma once
 #include <cmath>
 #include "orbx_platform.h"
+#include "glibc_atan2f_model.h"
 
 namespace orbx {
 
@@ -35,11 +36,12 @@ ORBX_HD inline void kb8_unproject(const KB8Cam& c, float u, float v, float r[3])
     r[0] = pwx * scale; r[1] = pwy * scale; r[2] = 1.f;
 }
 
-// camera point -> pixel (:87-104)
+// camera point -> pixel (:87-104).  atan2f = glibc's (glibc_atan2f_model.h: bit for bit, every platform); the double cos / sin of psi are the
+// platform's: a last-bit difference in double disappears in the rounding of the products to float (probability ~2^-29 per call)
 ORBX_HD inline void kb8_project(const KB8Cam& c, const float p[3], float uv[2]) {
     const float x2_plus_y2 = p[0] * p[0] + p[1] * p[1];
-    const float theta = atan2f(sqrtf(x2_plus_y2), p[2]);
-    const float psi = atan2f(p[1], p[0]);
+    const float theta = glibc_atan2f_model(sqrtf(x2_plus_y2), p[2]);
+    const float psi = glibc_atan2f_model(p[1], p[0]);
     const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2, theta9 = theta7 * theta2;
     const float r = theta + c.p[4] * theta3 + c.p[5] * theta5 + c.p[6] * theta7 + c.p[7] * theta9;
     uv[0] = (float)((double)(c.p[0] * r) * cos((double)psi) + (double)c.p[2]);

@@ -617,13 +617,15 @@ int orbm_search_local_points_batch(orbx_extractor* h, int first, int B, const Or
         dim3 grid((M + 255) / 256, B, 1), blk(256, 1, 1);
         ORBX_LAUNCH(k_frustum, grid, blk, 0, h->s0, dummy, M, points->pos, points->normal, points->min_d, points->max_d, (const uint8_t*)(dp + u_bad),
                     dp + o_view, (float*)(dp + o_trk), (int*)(dp + o_lvl), (AreaQuery*)(dp + o_q), d_counter, (const FrustumParams*)(dp + u_f));
-        dim3 grida((M + kAreaWaves - 1) / kAreaWaves, B, 1), blka(64 * kAreaWaves, 1, 1);
-        ORBX_LAUNCH(k_area_search, grida, blka, 0, h->s0, (const AreaQuery*)(dp + o_q), points->desc, M, kps, ur, fdesc, g, (const int*)(dp + o_cst), (const int*)(dp + o_cit), 1,
+        dim3 grida((M + 255) / 256, B, 1);
+        ORBX_LAUNCH(k_area_search_threads, grida, blk, 0, h->s0, (const AreaQuery*)(dp + o_q), points->desc, M, kps, ur, fdesc, g, (const int*)(dp + o_cst), (const int*)(dp + o_cit), 1,
                     d_counter, (int)pool, (int*)(dp + o_qs), (int*)(dp + o_qc), (int2*)(dp + o_pool), cap);
     } else rt::memset_async(d_counter, 0, 16, h->s0);
     {
         dim3 grid(B, 1, 1), blk(64, 1, 1);
-        ORBX_LAUNCH(k_local_accept, grid, blk, 0, h->s0, M, cap, nper, (const int*)(dp + o_qs), (const int*)(dp + o_qc), (const int2*)(dp + o_pool),
+        const size_t smem = 4 * (size_t)((cap + 31) / 32) + 4 * (size_t)cap + 64;
+        if (smem + 1024 > rt::lds_limit(h->device)) return fail(ORBX_E_CAPACITY, "%d keypoints per frame need %zu bytes of LDS in the accept kernel", cap, smem);
+        ORBX_LAUNCH(k_local_accept, grid, blk, smem, h->s0, M, cap, nper, (const int*)(dp + o_qs), (const int*)(dp + o_qc), (const int2*)(dp + o_pool),
                     occupied ? (const uint8_t*)(dp + u_occ) : (const uint8_t*)nullptr, (const uint8_t*)(dp + u_obs), nnratio, TH_HIGH, d_assigned, d_nmatch);
     }
     if (h->profile) rt::event_record(h->ev_stage[ST_MATCH][1], h->s0);

@@ -90,6 +90,11 @@ __global__ void k_area_search(const AreaQuery* __restrict__ queries, const unsig
 __global__ void k_frustum(FrustumParams F, int M, const float* __restrict__ pos, const float* __restrict__ normal, const float* __restrict__ min_dist,
                           const float* __restrict__ max_dist, const uint8_t* __restrict__ is_bad, uint8_t* __restrict__ in_view, float* __restrict__ track,
                           int* __restrict__ scale_level, AreaQuery* __restrict__ queries, int* __restrict__ zero4, const FrustumParams* __restrict__ Fbatch);
+__global__ void k_area_search_threads(const AreaQuery* __restrict__ queries, const unsigned long long* __restrict__ qdesc, int Q,
+                                      const KeyPointRec* __restrict__ kps, const float* __restrict__ u_right,
+                                      const unsigned long long* __restrict__ fdesc, GridParams g, const int* __restrict__ cell_start,
+                                      const int* __restrict__ cell_items, int gate_right, int* __restrict__ pool_counter, int pool_cap,
+                                      int* __restrict__ q_start, int* __restrict__ q_count, int2* __restrict__ entries, int frame_stride);
 __global__ void k_local_accept(int M, int cap, const int* __restrict__ n_per_frame, const int* __restrict__ q_start, const int* __restrict__ q_count,
                                const int2* __restrict__ entries, const uint8_t* __restrict__ occupied0, const uint8_t* __restrict__ has_obs, float nnratio,
                                int th_high, int* __restrict__ assigned, int* __restrict__ nmatches);

@@ -51,6 +51,13 @@ def _run(lib, w, h, nf, P, npts, rgbd):
     poses = [(_rot(0.02, -0.03, 0.01), np.array([0.3, -0.1, 0.25], np.float32)), (_rot(0.021, -0.028, 0.012), np.array([0.28, -0.11, 0.27], np.float32)),
              (_rot(-0.01, 0.02, 0.0), np.array([-0.2, 0.05, 0.1], np.float32))][:P]
     pos, normal, mind, maxd, bad, obs, desc = _scene(refs[0], rng, poses[0][0], poses[0][1], npts)
+    # duplicated map points compete for one keypoint - next to each other (inside one group of 64 of the accept kernel: the optimistic decisions
+    # collide and are redone) and far apart; some of the winners have no observations (they do not occupy, a later point overwrites them)
+    for i in rng.choice(npts - 70, npts // 4, replace=False):
+        j = i + int(rng.choice([1, 2, 5, 63, 64, 65]))
+        pos[j] = pos[i]; normal[j] = normal[i]; mind[j] = mind[i]; maxd[j] = maxd[i]; desc[j] = desc[i]
+        if rng.uniform() < 0.5:
+            desc[j, int(rng.integers(0, 32))] ^= np.uint8(1 << int(rng.integers(0, 8)))
     rp = M.ResidentPoints(ex, pos, normal, mind, maxd, desc)
     occupied = np.zeros((P, cap), np.uint8)
     for p in range(P):
