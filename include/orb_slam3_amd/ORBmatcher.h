@@ -2,10 +2,12 @@
  * reference class, with the reference's signatures, on top of the C ABI of include/orbx.h, plus ComputeStereoMatches (the body of
  * Frame::ComputeStereoMatches, src/Frame.cc:1102-1358, as a function of the Frame).
  *
- * Division of labour (the same for every method): the facade runs the head of the reference's per-point loop on the host with the
- * caller's own Sophus / Eigen / GeometricCamera code (pose * point, project, IsInImage, distance and viewing-angle gates, PredictScale) and
- * hands the survivors to the library as numbers; window search, level gates, every Hamming distance and the accept loop run on the
- * device; the facade then writes the result back into the caller's objects exactly where the reference would have.
+ * Division of labour (the same for every method): the facade reads the raw fields the method needs through the caller's own accessors
+ * (GetWorldPos, GetNormal, the distance limits, descriptors, poses, camera parameters) and applies the method's object-level tests (bad,
+ * already matched, ...); the geometry in front of the window search - pose * point, projection, image test, distance and viewing-angle gates -
+ * runs on the device for all points at once (orbm_project_points, PointBatch below), as do the window search, the level gates, every
+ * Hamming distance and the accept loop; MapPoint::PredictScale is asked of the caller's MapPoint for the survivors (it reads a protected
+ * member); the facade then writes the result back into the caller's objects exactly where the reference would have.
  *
  * The methods are templates on the Frame / KeyFrame / MapPoint (and Sim3) types, and the geometric types are taken from the return types
  * of their accessors, so this header needs neither Eigen nor Sophus itself.  It compiles against the reference's real classes (member
@@ -140,51 +142,49 @@ public:
     template <class FrameT>
     int SearchByProjection(FrameT &CurrentFrame, const FrameT &LastFrame, const float th, const bool bMono)
     {
-        const auto Tcw = CurrentFrame.GetPose();
-        typedef Decay<decltype(Tcw.translation())> Vec3;
-        typedef Decay<decltype(CurrentFrame.mpCamera->project(std::declval<Vec3>()))> Vec2;
-        const Vec3 twc = Tcw.inverse().translation();
-        const auto Tlw = LastFrame.GetPose();
-        const Vec3 tlc = Tlw * twc;
-        const bool bForward = tlc(2)>CurrentFrame.mb && !bMono;
-        const bool bBackward = -tlc(2)>CurrentFrame.mb && !bMono;
-        const bool rig = CurrentFrame.Nleft != -1;
+        // motion along the optical axis between the two frames picks the pyramid levels to search (:1973-1975)
+        const auto poseCur = CurrentFrame.GetPose();
+        const float zLastOfCurCentre = (LastFrame.GetPose() * poseCur.inverse().translation())(2);
+        const bool towards = !bMono && zLastOfCurCentre > CurrentFrame.mb, away = !bMono && -zLastOfCurCentre > CurrentFrame.mb;
+        const bool twoCameras = CurrentFrame.Nleft != -1;
 
         const int NL = LastFrame.N;
-        std::vector<uint8_t> valid(NL, 0), hasObs(NL, 0), desc((size_t)NL * 32, 0);
-        std::vector<float> pu(NL, 0), pv(NL, 0), invz(NL, 0), ang(NL, 0), pur(NL, 0), pvr(NL, 0); std::vector<int> oct(NL, 0);
+        PointBatch pts(NL);
+        std::vector<uint8_t> seen(NL > 0 ? NL : 1, 0), desc((size_t)(NL > 0 ? NL : 1) * 32, 0);
+        std::vector<float> ang(NL > 0 ? NL : 1, 0); std::vector<int> oct(NL > 0 ? NL : 1, 0);
         for (int i = 0; i < NL; i++) {
             auto* pMP = LastFrame.mvpMapPoints[i];
             if (!pMP || LastFrame.mvbOutlier[i]) continue;
-            Vec3 x3Dw = pMP->GetWorldPos();
-            Vec3 x3Dc = Tcw * x3Dw;
-            const float invzc = 1.0/x3Dc(2);
-            if (invzc<0) continue;
-            Vec2 uv = CurrentFrame.mpCamera->project(x3Dc);
-            if (uv(0)<CurrentFrame.mnMinX || uv(0)>CurrentFrame.mnMaxX) continue;
-            if (uv(1)<CurrentFrame.mnMinY || uv(1)>CurrentFrame.mnMaxY) continue;
-            valid[i] = 1; pu[i] = uv(0); pv[i] = uv(1); invz[i] = invzc;
-            oct[i] = (LastFrame.Nleft == -1 || i < LastFrame.Nleft) ? LastFrame.mvKeys[i].octave : LastFrame.mvKeysRight[i - LastFrame.Nleft].octave;
-            ang[i] = ((LastFrame.Nleft == -1) ? LastFrame.mvKeysUn[i] : (i < LastFrame.Nleft) ? LastFrame.mvKeys[i] : LastFrame.mvKeysRight[i - LastFrame.Nleft]).angle;
-            hasObs[i] = pMP->Observations() > 0;
+            pts.take(i, pMP, false);
+            const bool cam1 = LastFrame.Nleft == -1 || i < LastFrame.Nleft;
+            oct[i] = cam1 ? LastFrame.mvKeys[i].octave : LastFrame.mvKeysRight[i - LastFrame.Nleft].octave;
+            ang[i] = (LastFrame.Nleft == -1 ? LastFrame.mvKeysUn[i] : cam1 ? LastFrame.mvKeys[i] : LastFrame.mvKeysRight[i - LastFrame.Nleft]).angle;
+            seen[i] = pMP->Observations() > 0;
             CopyDescriptor(pMP, &desc[(size_t)i * 32]);
-            if (rig) {
-                Vec3 x3Dr = CurrentFrame.GetRelativePoseTrl() * x3Dc;
-                Vec2 uvr = CurrentFrame.mpCamera->project(x3Dr);
-                pur[i] = uvr(0); pvr[i] = uvr(1);
-            }
         }
-        OrbmLastFrameView lv = {NL, valid.data(), pu.data(), pv.data(), invz.data(), oct.data(), ang.data(), hasObs.data(), desc.data()};
+        OrbmProjection spec = Spec(poseCur, CurrentFrame.mpCamera, CurrentFrame, /*frameBounds*/ 0);
+        spec.depth_test = 2;                                  // 1 / z < 0 rejects (:1997-2000)
+        pts.project(spec);
+        std::vector<float> uR, vR;
+        if (twoCameras) {                                     // the same points through the left-to-right transform, camera-1 model (:2092-2094)
+            OrbmProjection right = spec;
+            right.depth_test = 0; right.bounds_mode = 2;
+            SpecSecond(right, CurrentFrame.GetRelativePoseTrl());
+            PointBatch again = pts;
+            again.project(right);
+            uR.swap(again.u); vR.swap(again.v);
+        }
+        OrbmLastFrameView lv = {NL, pts.valid.data(), pts.u.data(), pts.v.data(), pts.invz.data(), oct.data(), ang.data(), seen.data(), desc.data()};
         std::vector<int> assigned(CurrentFrame.N > 0 ? CurrentFrame.N : 1, -1);
         int nmatches = 0;
-        if (!rig) {
+        if (!twoCameras) {
             FrameStore fs; FillFrame(CurrentFrame, fs, OccupiedWithObservations);
             std::lock_guard<std::mutex> lock(Mutex());
-            Check(orbm_search_by_projection_frame(SharedHandle(), &fs.v, &lv, th, bForward, bBackward, mbCheckOrientation, assigned.data(), &nmatches));
+            Check(orbm_search_by_projection_frame(SharedHandle(), &fs.v, &lv, th, towards, away, mbCheckOrientation, assigned.data(), &nmatches));
         } else {
             RigStore rs; FillRig(CurrentFrame, rs, OccupiedWithObservations);
             std::lock_guard<std::mutex> lock(Mutex());
-            Check(orbm_search_by_projection_frame_fisheye(SharedHandle(), &rs.v, &lv, pur.data(), pvr.data(), th, bForward, bBackward, mbCheckOrientation,
+            Check(orbm_search_by_projection_frame_fisheye(SharedHandle(), &rs.v, &lv, uR.data(), vR.data(), th, towards, away, mbCheckOrientation,
                                                           assigned.data(), &nmatches));
         }
         for (int i = 0; i < CurrentFrame.N; i++) {
@@ -199,28 +199,23 @@ public:
     template <class FrameT, class KeyFrameT, class MapPointT>
     int SearchByProjection(FrameT &CurrentFrame, KeyFrameT* pKF, const std::set<MapPointT*> &sAlreadyFound, const float th, const int ORBdist)
     {
-        const auto Tcw = CurrentFrame.GetPose();
-        typedef Decay<decltype(Tcw.translation())> Vec3;
-        typedef Decay<decltype(CurrentFrame.mpCamera->project(std::declval<Vec3>()))> Vec2;
-        Vec3 Ow = Tcw.inverse().translation();
-        const std::vector<MapPointT*> vpMPs = pKF->GetMapPointMatches();
-        const int M = (int)vpMPs.size();
+        const auto pose = CurrentFrame.GetPose();
+        const std::vector<MapPointT*> kfPoints = pKF->GetMapPointMatches();
+        const int M = (int)kfPoints.size();
+        PointBatch pts(M);
+        for (int i = 0; i < M; i++) {
+            MapPointT* pMP = kfPoints[i];
+            if (pMP && !pMP->isBad() && !sAlreadyFound.count(pMP)) pts.take(i, pMP, false);
+        }
+        OrbmProjection spec = Spec(pose, CurrentFrame.mpCamera, CurrentFrame, /*frameBounds*/ 0);
+        SpecCentre(spec, pose.inverse().translation());
+        spec.distance_test = 1;                               // no depth test, no viewing angle in this method (:2228-2256)
+        pts.project(spec);
         ProjStore ps(M);
         for (int i = 0; i < M; i++) {
-            MapPointT* pMP = vpMPs[i];
-            if (!pMP || pMP->isBad() || sAlreadyFound.count(pMP)) continue;
-            Vec3 x3Dw = pMP->GetWorldPos();
-            Vec3 x3Dc = Tcw * x3Dw;
-            const Vec2 uv = CurrentFrame.mpCamera->project(x3Dc);
-            if (uv(0)<CurrentFrame.mnMinX || uv(0)>CurrentFrame.mnMaxX) continue;
-            if (uv(1)<CurrentFrame.mnMinY || uv(1)>CurrentFrame.mnMaxY) continue;
-            Vec3 PO = x3Dw-Ow;
-            float dist3D = PO.norm();
-            const float maxDistance = pMP->GetMaxDistanceInvariance();
-            const float minDistance = pMP->GetMinDistanceInvariance();
-            if (dist3D<minDistance || dist3D>maxDistance) continue;
-            ps.set(i, uv(0), uv(1), 0.0f, pMP->PredictScale(dist3D,&CurrentFrame), pKF->mvKeysUn[i].angle);
-            CopyDescriptor(pMP, ps.descAt(i));
+            if (!pts.valid[i]) continue;
+            ps.set(i, pts.u[i], pts.v[i], 0.0f, kfPoints[i]->PredictScale(pts.dist[i], &CurrentFrame), pKF->mvKeysUn[i].angle);
+            CopyDescriptor(kfPoints[i], ps.descAt(i));
         }
         FrameStore fs; FillFrame(CurrentFrame, fs, OccupiedAny);
         std::vector<int> assigned(CurrentFrame.N > 0 ? CurrentFrame.N : 1, -1);
@@ -230,7 +225,7 @@ public:
             Check(orbm_search_by_projection_keyframe(SharedHandle(), &fs.v, ps.view(), th, ORBdist, mbCheckOrientation, assigned.data(), &nmatches));
         }
         for (int i = 0; i < CurrentFrame.N; i++) {
-            if (assigned[i] >= 0) CurrentFrame.mvpMapPoints[i] = vpMPs[assigned[i]];
+            if (assigned[i] >= 0) CurrentFrame.mvpMapPoints[i] = kfPoints[assigned[i]];
             else if (assigned[i] == -2) CurrentFrame.mvpMapPoints[i] = nullptr;
         }
         return nmatches;
@@ -551,76 +546,47 @@ public:
     template <class KeyFrameT, class MapPointT, class Sim3T>
     int SearchBySim3(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT *> &vpMatches12, const Sim3T &S12, const float th)
     {
-        const float &fx = pKF1->fx;
-        const float &fy = pKF1->fy;
-        const float &cx = pKF1->cx;
-        const float &cy = pKF1->cy;
-        auto T1w = pKF1->GetPose();
-        auto T2w = pKF2->GetPose();
-        typedef Decay<decltype(T1w.translation())> Vec3;
-        Sim3T S21 = S12.inverse();
-        const std::vector<MapPointT*> vpMapPoints1 = pKF1->GetMapPointMatches();
-        const int N1 = vpMapPoints1.size();
-        const std::vector<MapPointT*> vpMapPoints2 = pKF2->GetMapPointMatches();
-        const int N2 = vpMapPoints2.size();
-        std::vector<bool> vbAlreadyMatched1(N1,false), vbAlreadyMatched2(N2,false);
-        for (int i=0; i<N1; i++) {
-            MapPointT* pMP = vpMatches12[i];
-            if (pMP) {
-                vbAlreadyMatched1[i]=true;
-                int idx2 = std::get<0>(pMP->GetIndexInKeyFrame(pKF2));
-                if (idx2>=0 && idx2<N2) vbAlreadyMatched2[idx2]=true;
+        KeyFrameT* kf[2] = {pKF1, pKF2};
+        const std::vector<MapPointT*> own[2] = {pKF1->GetMapPointMatches(), pKF2->GetMapPointMatches()};
+        const int n[2] = {(int)own[0].size(), (int)own[1].size()};
+        // points that already have a partner on either side take no part (:1718-1735)
+        std::vector<uint8_t> paired[2] = {std::vector<uint8_t>(n[0] > 0 ? n[0] : 1, 0), std::vector<uint8_t>(n[1] > 0 ? n[1] : 1, 0)};
+        for (int i = 0; i < n[0]; i++) {
+            MapPointT* partner = vpMatches12[i];
+            if (!partner) continue;
+            paired[0][i] = 1;
+            const int j = std::get<0>(partner->GetIndexInKeyFrame(pKF2));
+            if (j >= 0 && j < n[1]) paired[1][j] = 1;
+        }
+        const Sim3T across[2] = {S12.inverse(), S12};          // KF1's points enter KF2 through S21, KF2's enter KF1 through S12
+        ProjStore proj[2] = {ProjStore(n[0]), ProjStore(n[1])};
+        for (int side = 0; side < 2; side++) {
+            KeyFrameT* from = kf[side]; KeyFrameT* into = kf[1 - side];
+            PointBatch pts(n[side]);
+            for (int i = 0; i < n[side]; i++) {
+                MapPointT* pMP = own[side][i];
+                if (pMP && !paired[side][i] && !pMP->isBad()) pts.take(i, pMP, false);
+            }
+            // both directions use KF1's intrinsics, written out as x = X / Z, u = fx x + cx (:1760-1766, :1845-1851); the range is |p_c| (:1771)
+            OrbmProjection spec = Spec(from->GetPose(), pKF1->mpCamera, *into, /*IsInImage*/ 1);
+            spec.camera_type = 0; spec.cam[0] = pKF1->fx; spec.cam[1] = pKF1->fy; spec.cam[2] = pKF1->cx; spec.cam[3] = pKF1->cy; spec.inline_pinhole = 1;
+            SpecSecond(spec, across[side]);
+            spec.depth_test = 1; spec.dist_mode = 1; spec.distance_test = 1;
+            pts.project(spec);
+            for (int i = 0; i < n[side]; i++) {
+                if (!pts.valid[i]) continue;
+                proj[side].set(i, pts.u[i], pts.v[i], 0.0f, own[side][i]->PredictScale(pts.dist[i], into), 0.0f);
+                CopyDescriptor(own[side][i], proj[side].descAt(i));
             }
         }
-        ProjStore p1(N1), p2(N2);
-        for (int i1=0; i1<N1; i1++) {                       // map points of KF1 into KF2
-            MapPointT* pMP = vpMapPoints1[i1];
-            if (!pMP || vbAlreadyMatched1[i1] || pMP->isBad()) continue;
-            Vec3 p3Dw = pMP->GetWorldPos();
-            Vec3 p3Dc1 = T1w * p3Dw;
-            Vec3 p3Dc2 = S21 * p3Dc1;
-            if (p3Dc2(2)<0.0) continue;
-            const float invz = 1.0/p3Dc2(2);
-            const float x = p3Dc2(0)*invz;
-            const float y = p3Dc2(1)*invz;
-            const float u = fx*x+cx;
-            const float v = fy*y+cy;
-            if (!pKF2->IsInImage(u,v)) continue;
-            const float maxDistance = pMP->GetMaxDistanceInvariance();
-            const float minDistance = pMP->GetMinDistanceInvariance();
-            const float dist3D = p3Dc2.norm();
-            if (dist3D<minDistance || dist3D>maxDistance ) continue;
-            p1.set(i1, u, v, 0.0f, pMP->PredictScale(dist3D,pKF2), 0.0f);
-            CopyDescriptor(pMP, p1.descAt(i1));
-        }
-        for (int i2=0; i2<N2; i2++) {                       // map points of KF2 into KF1
-            MapPointT* pMP = vpMapPoints2[i2];
-            if (!pMP || vbAlreadyMatched2[i2] || pMP->isBad()) continue;
-            Vec3 p3Dw = pMP->GetWorldPos();
-            Vec3 p3Dc2 = T2w * p3Dw;
-            Vec3 p3Dc1 = S12 * p3Dc2;
-            if (p3Dc1(2)<0.0) continue;
-            const float invz = 1.0/p3Dc1(2);
-            const float x = p3Dc1(0)*invz;
-            const float y = p3Dc1(1)*invz;
-            const float u = fx*x+cx;
-            const float v = fy*y+cy;
-            if (!pKF1->IsInImage(u,v)) continue;
-            const float maxDistance = pMP->GetMaxDistanceInvariance();
-            const float minDistance = pMP->GetMinDistanceInvariance();
-            const float dist3D = p3Dc1.norm();
-            if (dist3D<minDistance || dist3D>maxDistance) continue;
-            p2.set(i2, u, v, 0.0f, pMP->PredictScale(dist3D,pKF1), 0.0f);
-            CopyDescriptor(pMP, p2.descAt(i2));
-        }
         FrameStore f1, f2; FillFrame(*pKF1, f1); FillFrame(*pKF2, f2);
-        std::vector<int> m12(N1 > 0 ? N1 : 1, -1);
+        std::vector<int> m12(n[0] > 0 ? n[0] : 1, -1);
         int nFound = 0;
         {
             std::lock_guard<std::mutex> lock(Mutex());
-            Check(orbm_search_by_sim3(SharedHandle(), &f1.v, &f2.v, p1.view(), p2.view(), th, m12.data(), &nFound));
+            Check(orbm_search_by_sim3(SharedHandle(), &f1.v, &f2.v, proj[0].view(), proj[1].view(), th, m12.data(), &nFound));
         }
-        for (int i1 = 0; i1 < N1; i1++) if (m12[i1] >= 0) vpMatches12[i1] = vpMapPoints2[m12[i1]];
+        for (int i = 0; i < n[0]; i++) if (m12[i] >= 0) vpMatches12[i] = own[1][m12[i]];
         return nFound;
     }
 
@@ -630,35 +596,23 @@ public:
     {
         const bool rig = pKF->NLeft != -1;
         if (bRight && !rig) throw std::runtime_error("ORBmatcher (HIP): Fuse(bRight) on a key frame without a second camera");
-        auto Tcw = bRight ? pKF->GetRightPose() : pKF->GetPose();
-        typedef Decay<decltype(Tcw.translation())> Vec3;
-        typedef Decay<decltype(pKF->mpCamera->project(std::declval<Vec3>()))> Vec2;
-        Vec3 Ow = bRight ? pKF->GetRightCameraCenter() : pKF->GetCameraCenter();
-        auto* pCamera = bRight ? pKF->mpCamera2 : pKF->mpCamera;
-        const float &bf = pKF->mbf;
         const int nMPs = vpMapPoints.size();
         // geometry of every point that could reach the window search.  Whether it does is decided again in the replay loop below: the
         // reference's bad / IsInKeyFrame tests read state that earlier iterations of its loop may have changed (Replace, AddObservation).
-        ProjStore ps(nMPs);
-        for (int i=0; i<nMPs; i++) {
+        PointBatch pts(nMPs);
+        for (int i = 0; i < nMPs; i++) {
             MapPointT* pMP = vpMapPoints[i];
-            if (!pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
-            Vec3 p3Dw = pMP->GetWorldPos();
-            Vec3 p3Dc = Tcw * p3Dw;
-            if (p3Dc(2)<0.0f) continue;
-            const float invz = 1/p3Dc(2);
-            const Vec2 uv = pCamera->project(p3Dc);
-            if (!pKF->IsInImage(uv(0),uv(1))) continue;
-            const float ur = uv(0)-bf*invz;
-            const float maxDistance = pMP->GetMaxDistanceInvariance();
-            const float minDistance = pMP->GetMinDistanceInvariance();
-            Vec3 PO = p3Dw-Ow;
-            const float dist3D = PO.norm();
-            if (dist3D<minDistance || dist3D>maxDistance) continue;
-            Vec3 Pn = pMP->GetNormal();
-            if (PO.dot(Pn)<0.5*dist3D) continue;
-            ps.set(i, uv(0), uv(1), ur, pMP->PredictScale(dist3D,pKF), 0.0f);
-            CopyDescriptor(pMP, ps.descAt(i));
+            if (pMP && !pMP->isBad() && !pMP->IsInKeyFrame(pKF)) pts.take(i, pMP, true);
+        }
+        OrbmProjection spec = bRight ? Spec(pKF->GetRightPose(), pKF->mpCamera2, *pKF, /*IsInImage*/ 1) : Spec(pKF->GetPose(), pKF->mpCamera, *pKF, 1);
+        if (bRight) SpecCentre(spec, pKF->GetRightCameraCenter()); else SpecCentre(spec, pKF->GetCameraCenter());
+        spec.depth_test = 1; spec.distance_test = 1; spec.angle_test = 1; spec.bf = pKF->mbf;
+        pts.project(spec);
+        ProjStore ps(nMPs);
+        for (int i = 0; i < nMPs; i++) {
+            if (!pts.valid[i]) continue;
+            ps.set(i, pts.u[i], pts.v[i], pts.ur[i], vpMapPoints[i]->PredictScale(pts.dist[i], pKF), 0.0f);
+            CopyDescriptor(vpMapPoints[i], ps.descAt(i));
         }
         FrameStore fs;
         if (!rig) FillFrame(*pKF, fs);
@@ -701,31 +655,23 @@ public:
     template <class KeyFrameT, class Sim3T, class MapPointT>
     int Fuse(KeyFrameT* pKF, Sim3T &Scw, const std::vector<MapPointT*> &vpPoints, float th, std::vector<MapPointT *> &vpReplacePoint)
     {
-        typedef Decay<decltype(pKF->GetPose())> SE3;
-        SE3 Tcw = SE3(Scw.rotationMatrix(),Scw.translation()/Scw.scale());
-        typedef Decay<decltype(Tcw.translation())> Vec3;
-        typedef Decay<decltype(pKF->mpCamera->project(std::declval<Vec3>()))> Vec2;
-        Vec3 Ow = Tcw.inverse().translation();
-        const std::set<MapPointT*> spAlreadyFound = pKF->GetMapPoints();
+        const auto pose = RigidPart<Decay<decltype(pKF->GetPose())> >(Scw);
+        const std::set<MapPointT*> inKeyFrame = pKF->GetMapPoints();
         const int nPoints = vpPoints.size();
+        PointBatch pts(nPoints);
+        for (int i = 0; i < nPoints; i++) {
+            MapPointT* pMP = vpPoints[i];
+            if (!pMP->isBad() && !inKeyFrame.count(pMP)) pts.take(i, pMP, true);
+        }
+        OrbmProjection spec = Spec(pose, pKF->mpCamera, *pKF, /*IsInImage*/ 1);
+        SpecCentre(spec, pose.inverse().translation());
+        spec.depth_test = 1; spec.distance_test = 1; spec.angle_test = 1;
+        pts.project(spec);
         ProjStore ps(nPoints);
-        for (int iMP=0; iMP<nPoints; iMP++) {
-            MapPointT* pMP = vpPoints[iMP];
-            if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
-            Vec3 p3Dw = pMP->GetWorldPos();
-            Vec3 p3Dc = Tcw * p3Dw;
-            if (p3Dc(2)<0.0f) continue;
-            const Vec2 uv = pKF->mpCamera->project(p3Dc);
-            if (!pKF->IsInImage(uv(0),uv(1))) continue;
-            const float maxDistance = pMP->GetMaxDistanceInvariance();
-            const float minDistance = pMP->GetMinDistanceInvariance();
-            Vec3 PO = p3Dw-Ow;
-            const float dist3D = PO.norm();
-            if (dist3D<minDistance || dist3D>maxDistance) continue;
-            Vec3 Pn = pMP->GetNormal();
-            if (PO.dot(Pn)<0.5*dist3D) continue;
-            ps.set(iMP, uv(0), uv(1), 0.0f, pMP->PredictScale(dist3D,pKF), 0.0f);
-            CopyDescriptor(pMP, ps.descAt(iMP));
+        for (int i = 0; i < nPoints; i++) {
+            if (!pts.valid[i]) continue;
+            ps.set(i, pts.u[i], pts.v[i], 0.0f, vpPoints[i]->PredictScale(pts.dist[i], pKF), 0.0f);
+            CopyDescriptor(vpPoints[i], ps.descAt(i));
         }
         FrameStore fs; FillFrame(*pKF, fs);
         std::vector<int> best(nPoints > 0 ? nPoints : 1, -1);
@@ -785,6 +731,54 @@ protected:
             return &pv;
         }
     };
+
+    // ---- the geometry in front of the window searches, on the device (orbm_project_points) ----
+    // raw fields of the map points of one call, read through the caller's accessors; entries never taken stay skipped
+    struct PointBatch {
+        int M;
+        std::vector<float> pos, normal, minInv, maxInv, u, v, ur, invz, dist; std::vector<uint8_t> skip, valid;
+        explicit PointBatch(int m) : M(m), pos(3 * (size_t)(m > 0 ? m : 1), 0.f), normal(3 * (size_t)(m > 0 ? m : 1), 0.f), minInv(m > 0 ? m : 1, 0.f), maxInv(m > 0 ? m : 1, 0.f),
+                                     u(m > 0 ? m : 1, 0.f), v(m > 0 ? m : 1, 0.f), ur(m > 0 ? m : 1, 0.f), invz(m > 0 ? m : 1, 0.f), dist(m > 0 ? m : 1, 0.f), skip(m > 0 ? m : 1, 1),
+                                     valid(m > 0 ? m : 1, 0) {}
+        template <class MapPointT> void take(int i, MapPointT* p, bool withNormal)
+        {
+            const auto w = p->GetWorldPos();
+            for (int k = 0; k < 3; k++) pos[3 * (size_t)i + k] = w(k);
+            if (withNormal) { const auto nrm = p->GetNormal(); for (int k = 0; k < 3; k++) normal[3 * (size_t)i + k] = nrm(k); }
+            minInv[i] = p->GetMinDistanceInvariance(); maxInv[i] = p->GetMaxDistanceInvariance();
+            skip[i] = 0;
+        }
+        void project(const OrbmProjection& spec)
+        {
+            OrbmProjectIn in = {M, pos.data(), normal.data(), minInv.data(), maxInv.data(), skip.data()};
+            OrbmProjectOut out = {valid.data(), u.data(), v.data(), ur.data(), invz.data(), dist.data()};
+            std::lock_guard<std::mutex> lock(Mutex());
+            Check(orbm_project_points(SharedHandle(), &spec, &in, &out));
+        }
+    };
+    // pose, camera and image test of a projection; the tests a method applies are switched on by the method
+    template <class PoseT, class CameraT, class HolderT> static OrbmProjection Spec(const PoseT& T, CameraT* camera, HolderT& image, int boundsMode)
+    {
+        OrbmProjection s; memset(&s, 0, sizeof s);
+        const auto R = T.rotationMatrix(); const auto t = T.translation();
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) s.R[3 * r + c] = R(r, c); s.t[r] = t(r); }
+        s.camera_type = camera->GetType() == 1 ? 1 : 0;
+        for (int i = 0; i < (s.camera_type ? 8 : 4); i++) s.cam[i] = camera->getParameter(i);
+        s.min_x = image.mnMinX; s.max_x = image.mnMaxX; s.min_y = image.mnMinY; s.max_y = image.mnMaxY; s.bounds_mode = boundsMode;
+        return s;
+    }
+    template <class Vec3T> static void SpecCentre(OrbmProjection& s, const Vec3T& c) { for (int k = 0; k < 3; k++) s.Ow[k] = c(k); }
+    // a second transform behind the pose: a Sim3 (R, t, s) or an SE3 (scale 1)
+    template <class T> static auto ScaleOf(const T& x, int) -> decltype((float)x.scale()) { return (float)x.scale(); }
+    template <class T> static float ScaleOf(const T&, long) { return 1.0f; }
+    template <class TransformT> static void SpecSecond(OrbmProjection& s, const TransformT& X)
+    {
+        const auto R = X.rotationMatrix(); const auto t = X.translation();
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) s.R2[3 * r + c] = R(r, c); s.t2[r] = t(r); }
+        s.s2 = ScaleOf(X, 0); s.has_sim3 = 1;
+    }
+    // the rigid transform a similarity moves points with up to scale: [R | t / s] (:508, :1559)
+    template <class SE3T, class Sim3T> static SE3T RigidPart(const Sim3T& S) { return SE3T(S.rotationMatrix(), S.translation() / S.scale()); }
 
     template <class MapPointT> static void CopyDescriptor(MapPointT* p, uint8_t* dst) { const cv::Mat d = p->GetDescriptor(); memcpy(dst, d.ptr(0), 32); }
 
@@ -873,46 +867,25 @@ protected:
     int SearchBySim3Projection(KeyFrameT* pKF, Sim3T &Scw, const std::vector<MapPointT*> &vpPoints, std::vector<MapPointT*> &vpMatched, int th, float ratioHamming,
                                bool inlineProjection, std::vector<int>& assigned)
     {
-        const float &fx = pKF->fx;
-        const float &fy = pKF->fy;
-        const float &cx = pKF->cx;
-        const float &cy = pKF->cy;
-        typedef Decay<decltype(pKF->GetPose())> SE3;
-        SE3 Tcw = SE3(Scw.rotationMatrix(),Scw.translation()/Scw.scale());
-        typedef Decay<decltype(Tcw.translation())> Vec3;
-        typedef Decay<decltype(pKF->mpCamera->project(std::declval<Vec3>()))> Vec2;
-        Vec3 Ow = Tcw.inverse().translation();
-        std::set<MapPointT*> spAlreadyFound(vpMatched.begin(), vpMatched.end());
-        spAlreadyFound.erase(static_cast<MapPointT*>(NULL));
+        const auto pose = RigidPart<Decay<decltype(pKF->GetPose())> >(Scw);
+        std::set<MapPointT*> taken(vpMatched.begin(), vpMatched.end());
+        taken.erase(static_cast<MapPointT*>(NULL));
         const int M = (int)vpPoints.size();
+        PointBatch pts(M);
+        for (int i = 0; i < M; i++) {
+            MapPointT* pMP = vpPoints[i];
+            if (!pMP->isBad() && !taken.count(pMP)) pts.take(i, pMP, true);
+        }
+        OrbmProjection spec = Spec(pose, pKF->mpCamera, *pKF, /*IsInImage*/ 1);
+        if (inlineProjection) { spec.camera_type = 0; spec.cam[0] = pKF->fx; spec.cam[1] = pKF->fy; spec.cam[2] = pKF->cx; spec.cam[3] = pKF->cy; spec.inline_pinhole = 1; }
+        SpecCentre(spec, pose.inverse().translation());
+        spec.depth_test = 1; spec.distance_test = 1; spec.angle_test = 1;
+        pts.project(spec);
         ProjStore ps(M);
-        for (int iMP=0; iMP<M; iMP++) {
-            MapPointT* pMP = vpPoints[iMP];
-            if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
-            Vec3 p3Dw = pMP->GetWorldPos();
-            Vec3 p3Dc = Tcw * p3Dw;
-            if (p3Dc(2)<0.0) continue;
-            float u, v;
-            if (inlineProjection) {
-                const float invz = 1/p3Dc(2);
-                const float x = p3Dc(0)*invz;
-                const float y = p3Dc(1)*invz;
-                u = fx*x+cx;
-                v = fy*y+cy;
-            } else {
-                const Vec2 uv = pKF->mpCamera->project(p3Dc);
-                u = uv(0); v = uv(1);
-            }
-            if (!pKF->IsInImage(u,v)) continue;
-            const float maxDistance = pMP->GetMaxDistanceInvariance();
-            const float minDistance = pMP->GetMinDistanceInvariance();
-            Vec3 PO = p3Dw-Ow;
-            const float dist = PO.norm();
-            if (dist<minDistance || dist>maxDistance) continue;
-            Vec3 Pn = pMP->GetNormal();
-            if (PO.dot(Pn)<0.5*dist) continue;
-            ps.set(iMP, u, v, 0.0f, pMP->PredictScale(dist,pKF), 0.0f);
-            CopyDescriptor(pMP, ps.descAt(iMP));
+        for (int i = 0; i < M; i++) {
+            if (!pts.valid[i]) continue;
+            ps.set(i, pts.u[i], pts.v[i], 0.0f, vpPoints[i]->PredictScale(pts.dist[i], pKF), 0.0f);
+            CopyDescriptor(vpPoints[i], ps.descAt(i));
         }
         FrameStore fs; FillFrame(*pKF, fs);
         const int N = (int)vpMatched.size();

@@ -421,6 +421,36 @@ int orbm_search_by_projection_frame_fisheye(orbx_extractor* h, const OrbmFisheye
                                             const float* proj_ur, const float* proj_vr, float th, int forward, int backward,
                                             int check_orientation, int* assigned, int* nmatches);
 
+/* ---- the geometry in front of the projection-type searches, on the device ----
+ * SearchByProjection(Frame, LastFrame) (src/ORBmatcher.cc:1993-2010), (Frame, KeyFrame) (:2228-2256), (KeyFrame, Sim3, ...) x2 (:525-560, :640-690),
+ * Fuse x2 (:1388-1430, :1590-1625) and SearchBySim3 (:1745-1790, :1830-1875) all start with the same per-map-point chain: transform, depth test,
+ * projection, image test, distance range, viewing angle.  orbm_project_points evaluates it for M points at once in the reference's fp32
+ * operation order (a rigid transform is R * p + t with 3-term sums left to right - the order of a matrix product; no fused multiply-adds).
+ * The spec says which tests the method at hand applies and how it writes its projection.  MapPoint::PredictScale stays with the caller's
+ * MapPoint (it reads a protected member): `dist` is its argument.  Blocking. */
+typedef struct OrbmProjection {
+    float R[9], t[3];                     /* p1 = R * p_w + t: the SE3 pose in front (Tcw, T1w, ...) */
+    int has_sim3; float R2[9], t2[3], s2; /* SearchBySim3: p_c = (R2 * p1) * s2 + t2 (Sim3 S21 / S12); else p_c = p1 */
+    float Ow[3];                          /* camera centre for the distance / angle tests (dist_mode 0) */
+    int dist_mode;                        /* 0: dist = |p_w - Ow|, 1: dist = |p_c| (SearchBySim3, :1771) */
+    int depth_test;                       /* 0 none (:2228-2256), 1: p_c.z < 0 rejects, 2: 1 / p_c.z < 0 rejects (:1997-2000) */
+    int camera_type; float cam[8];        /* GeometricCamera::GetType(): 0 pinhole (fx, fy, cx, cy), 1 Kannala-Brandt */
+    int inline_pinhole;                   /* 1: x = X * (1 / Z), u = fx * x + cx as written out in :656-660 / :1760-1766 instead of mpCamera->project */
+    float min_x, max_x, min_y, max_y;     /* mnMinX .. mnMaxY */
+    int bounds_mode;                      /* 0: the Frame test (u < min || u > max rejects), 1: KeyFrame::IsInImage (u >= min && u < max), 2: none */
+    int distance_test;                    /* dist outside [min_inv, max_inv] rejects */
+    int angle_test;                       /* PO . Pn < 0.5 dist rejects (:551, :1416, :1612) */
+    float bf;                             /* ur = u - bf / z (Fuse, :1400); 0 otherwise */
+} OrbmProjection;
+typedef struct OrbmProjectIn {
+    int M;
+    const float* pos; const float* normal;            /* GetWorldPos(), GetNormal(): M x 3 (normal may be NULL without the angle test) */
+    const float* min_inv; const float* max_inv;       /* GetMinDistanceInvariance(), GetMaxDistanceInvariance() (NULL without the distance test) */
+    const uint8_t* skip;                              /* 1 = rejected by the caller's own tests (NULL = none) */
+} OrbmProjectIn;
+typedef struct OrbmProjectOut { uint8_t* valid; float *u, *v, *ur, *inv_z, *dist; } OrbmProjectOut;   /* any array may be NULL */
+int orbm_project_points(orbx_extractor* h, const OrbmProjection* spec, const OrbmProjectIn* in, const OrbmProjectOut* out);
+
 /* ---- remaining projection-type searches ----
  * The caller evaluates the geometry in front of GetFeaturesInArea with the reference's own Sophus/Eigen code (Tcw * p3Dw, project,
  * IsInImage, min/max distance, viewing angle, PredictScale) and hands the survivors over as numbers; window search, level window,

@@ -30,7 +30,7 @@ SYMBOLS = [
     "orbm_hamming_matrix", "orbm_stereo_match", "orbm_stereo_fetch", "orbm_knn2", "orbm_knn2_fetch", "orbm_stereo_fisheye", "orbm_stereo_fisheye_fetch", "orbm_search_for_triangulation_kb8", "orbm_is_in_frustum", "orbm_is_in_frustum_rig", "orbm_search_local_points_fisheye", "orbm_search_local_points",
     "orbm_get_features_in_area", "orbm_search_by_projection_mappoints", "orbm_search_by_projection_frame",
     "orbm_search_for_triangulation", "orbm_search_by_bow", "orbm_search_by_bow_batch", "orbm_keyframe_create", "orbm_points_create", "orbm_points_destroy", "orbm_search_local_points_resident", "orbm_stereo_from_depth", "orbm_search_local_points_batch", "orbm_search_local_points_fetch", "orbm_keyframe_destroy", "orbm_search_for_triangulation_resident", "orbm_search_for_triangulation_resident_kb8", "orbm_search_by_bow_resident", "orbm_search_by_bow_fisheye", "orbm_search_for_initialization", "orbm_area_search_batch",
-    "orbm_search_by_projection_sim3", "orbm_search_by_projection_keyframe", "orbm_fuse_candidates", "orbm_search_by_sim3", "orbm_distinctive_descriptors",
+    "orbm_project_points", "orbm_search_by_projection_sim3", "orbm_search_by_projection_keyframe", "orbm_fuse_candidates", "orbm_search_by_sim3", "orbm_distinctive_descriptors",
     "orbm_search_by_projection_mappoints_fisheye", "orbm_search_by_projection_frame_fisheye", "orbm_search_for_triangulation_batch",
     "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_words", "orbv_transform", "orbv_transform_extracted", "orbv_fetch",
     "orbx_last_error",
@@ -119,6 +119,7 @@ class OrbxLib:
         L.orbm_search_by_bow_resident.argtypes = [vp, i, vp, vp, vp, vp, f, i, i, vp, vp]
         L.orbm_search_for_initialization.argtypes = [vp, vp, vp, vp, i, f, i, vp, ip]
         L.orbm_area_search_batch.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp, vp, i]
+        L.orbm_project_points.argtypes = [vp, vp, vp, vp]
         L.orbm_search_by_projection_sim3.argtypes = [vp, vp, vp, f, f, vp, ip]
         L.orbm_search_by_projection_keyframe.argtypes = [vp, vp, vp, f, i, i, vp, ip]
         L.orbm_fuse_candidates.argtypes = [vp, vp, vp, f, i, vp, vp, vp]

@@ -321,6 +321,62 @@ __global__ void __launch_bounds__(256) k_frustum(FrustumParams F, int M, const f
     }
 }
 
+// The head of the projection-type searches of ORBmatcher (SearchByProjection(Frame, LastFrame) src/ORBmatcher.cc:1993-2010, (Frame, KeyFrame)
+// :2228-2256, (KeyFrame, Sim3, ...) :525-560 / :640-690, Fuse :1388-1430 / :1590-1625, SearchBySim3 :1745-1790 / :1830-1875): transform the map
+// point, depth test, projection, image test, distance range, viewing angle - one thread per point, the reference's fp32 operation order
+// (3-term sums left to right, no fused multiply-adds).  Which tests run and how the projection is written differ between the reference's
+// methods; P says which.  Outputs: valid, u, v, ur = u - bf / z, 1 / z, dist (the argument of MapPoint::PredictScale, which stays with the
+// caller's MapPoint).  skip[i] != 0: the caller's own tests (bad, already matched, ...) have rejected the point.
+__global__ void __launch_bounds__(256) k_project_points(ProjectParams P, int M, const float* __restrict__ pos, const float* __restrict__ normal,
+                                                        const float* __restrict__ min_inv, const float* __restrict__ max_inv, const uint8_t* __restrict__ skip,
+                                                        uint8_t* __restrict__ valid, float* __restrict__ out /* [5][M]: u, v, ur, 1/z, dist */) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= M) return;
+    bool ok = !(skip && skip[i]);
+    float u = 0.f, v = 0.f, ur = 0.f, invz = 0.f, dist = 0.f;
+    if (ok) {
+        const float P0 = pos[3 * i], P1 = pos[3 * i + 1], P2 = pos[3 * i + 2];
+        float x = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.R[0], P0), __fmul_rn(P.R[1], P1)), __fmul_rn(P.R[2], P2)), P.t[0]);
+        float y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.R[3], P0), __fmul_rn(P.R[4], P1)), __fmul_rn(P.R[5], P2)), P.t[1]);
+        float z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.R[6], P0), __fmul_rn(P.R[7], P1)), __fmul_rn(P.R[8], P2)), P.t[2]);
+        if (P.has_sim3) {                                             // Sim3 * p = (R * p) * s + t
+            const float a = __fadd_rn(__fadd_rn(__fmul_rn(P.R2[0], x), __fmul_rn(P.R2[1], y)), __fmul_rn(P.R2[2], z));
+            const float b = __fadd_rn(__fadd_rn(__fmul_rn(P.R2[3], x), __fmul_rn(P.R2[4], y)), __fmul_rn(P.R2[5], z));
+            const float c = __fadd_rn(__fadd_rn(__fmul_rn(P.R2[6], x), __fmul_rn(P.R2[7], y)), __fmul_rn(P.R2[8], z));
+            x = __fadd_rn(__fmul_rn(a, P.s2), P.t2[0]); y = __fadd_rn(__fmul_rn(b, P.s2), P.t2[1]); z = __fadd_rn(__fmul_rn(c, P.s2), P.t2[2]);
+        }
+        invz = __fdiv_rn(1.0f, z);
+        if (P.depth_test == 1 && z < 0.0f) ok = false;
+        if (P.depth_test == 2 && invz < 0.0f) ok = false;
+        if (ok) {
+            if (P.camera_type == 1) { KB8Cam c; for (int k = 0; k < 8; k++) c.p[k] = P.cam[k]; const float pc[3] = {x, y, z}; float uv[2]; kb8_project(c, pc, uv); u = uv[0]; v = uv[1]; }
+            else if (P.inline_pinhole) {                              // x = X * invz; u = fx * x + cx (the hand-written form, e.g. :656-660)
+                u = __fadd_rn(__fmul_rn(P.cam[0], __fmul_rn(x, invz)), P.cam[2]);
+                v = __fadd_rn(__fmul_rn(P.cam[1], __fmul_rn(y, invz)), P.cam[3]);
+            } else {                                                  // Pinhole::project, src/CameraModels/Pinhole.cpp:61-68
+                u = __fadd_rn(__fdiv_rn(__fmul_rn(P.cam[0], x), z), P.cam[2]);
+                v = __fadd_rn(__fdiv_rn(__fmul_rn(P.cam[1], y), z), P.cam[3]);
+            }
+            if (P.bounds_mode == 0) { if (u < P.min_x || u > P.max_x || v < P.min_y || v > P.max_y) ok = false; }        // Frame: :2003-2006
+            else if (P.bounds_mode == 1 && !(u >= P.min_x && u < P.max_x && v >= P.min_y && v < P.max_y)) ok = false;      // KeyFrame::IsInImage; 2: no image test
+        }
+        if (ok) {
+            ur = __fsub_rn(u, __fmul_rn(P.bf, invz));
+            const float o0 = __fsub_rn(P0, P.Ow[0]), o1 = __fsub_rn(P1, P.Ow[1]), o2 = __fsub_rn(P2, P.Ow[2]);
+            if (P.dist_mode == 0) dist = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(o0, o0), __fmul_rn(o1, o1)), __fmul_rn(o2, o2)));
+            else dist = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+            if (P.distance_test && (dist < min_inv[i] || dist > max_inv[i])) ok = false;
+            if (ok && P.angle_test) {                                 // PO.dot(Pn) < 0.5 * dist3D
+                const float dot = __fadd_rn(__fadd_rn(__fmul_rn(o0, normal[3 * i]), __fmul_rn(o1, normal[3 * i + 1])), __fmul_rn(o2, normal[3 * i + 2]));
+                if (dot < __fmul_rn(0.5f, dist)) ok = false;
+            }
+        }
+    }
+    valid[i] = ok ? 1 : 0;
+    const size_t Ms = (size_t)M;
+    out[i] = u; out[Ms + i] = v; out[2 * Ms + i] = ur; out[3 * Ms + i] = invz; out[4 * Ms + i] = dist;
+}
+
 // The window search of a BATCH of frames, one THREAD per query (k_area_search spends a wave on a query: right for one frame's few thousand
 // queries, which must finish in microseconds; a batch has hundreds of thousands and wants throughput).  A thread walks its window cells in the
 // reference's order (ix-major, iy-minor, items in insertion order), counts, the workgroup reserves its span of the entry pool with one

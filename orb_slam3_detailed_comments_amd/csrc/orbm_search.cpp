@@ -1311,6 +1311,41 @@ int projected_candidates(orbx_extractor* h, const OrbmFrameView* F, const OrbmPr
 
 extern "C" {
 
+int orbm_project_points(orbx_extractor* h, const OrbmProjection* S, const OrbmProjectIn* in, const OrbmProjectOut* out) {
+    if (!h || !S || !in || !out || in->M < 0) return fail(ORBX_E_ARG, "null");
+    const int M = in->M;
+    if (M == 0) return ORBX_OK;
+    if (!in->pos || (S->angle_test && !in->normal) || (S->distance_test && (!in->min_inv || !in->max_inv))) return fail(ORBX_E_ARG, "projection inputs missing");
+    static_assert(sizeof(ProjectParams) == sizeof(OrbmProjection), "OrbmProjection and ProjectParams describe the same record");
+    rt::set_device(h->device);
+    const size_t M1 = M;
+    const size_t op = 0, on = op + al16(12 * M1), omn = on + al16(12 * M1), omx = omn + al16(4 * M1), os = omx + al16(4 * M1), in_total = os + al16(M1);
+    const size_t ov = 0, oo = al16(M1), out_total = oo + al16(20 * M1);
+    if (h->h_packB.ensure(in_total + 16) || h->d_sr[SR_QUERY].ensure(in_total + 16) || h->d_sr[SR_SPARE].ensure(out_total + 16) || h->h_out.ensure(out_total + 16))
+        return fail(ORBX_E_DEVICE, "allocation failed");
+    uint8_t* hp = h->h_packB.p;
+    memcpy(hp + op, in->pos, 12 * M1);
+    if (in->normal) memcpy(hp + on, in->normal, 12 * M1);
+    if (in->min_inv) memcpy(hp + omn, in->min_inv, 4 * M1);
+    if (in->max_inv) memcpy(hp + omx, in->max_inv, 4 * M1);
+    if (in->skip) memcpy(hp + os, in->skip, M1); else memset(hp + os, 0, M1);
+    if (rt::copy_h2d(h->d_sr[SR_QUERY].p, hp, in_total, h->s0)) return fail(ORBX_E_DEVICE, "upload failed");
+    ProjectParams P; memcpy(&P, S, sizeof P);
+    const uint8_t* di = h->d_sr[SR_QUERY].p; uint8_t* dout = h->d_sr[SR_SPARE].p;
+    dim3 grid((M + 255) / 256, 1, 1), blk(256, 1, 1);
+    ORBX_LAUNCH(k_project_points, grid, blk, 0, h->s0, P, M, (const float*)(di + op), (const float*)(di + on), (const float*)(di + omn), (const float*)(di + omx),
+                (const uint8_t*)(di + os), dout + ov, (float*)(dout + oo));
+    if (rt::copy_d2h(h->h_out.p, dout, out_total, h->s0) || rt::stream_sync(h->s0) || rt::check_launch()) return fail(ORBX_E_DEVICE, "projection kernel failed: %s", rt::last_error());
+    const float* f = (const float*)(h->h_out.p + oo);
+    if (out->valid) memcpy(out->valid, h->h_out.p + ov, M1);
+    if (out->u) memcpy(out->u, f, 4 * M1);
+    if (out->v) memcpy(out->v, f + M1, 4 * M1);
+    if (out->ur) memcpy(out->ur, f + 2 * M1, 4 * M1);
+    if (out->inv_z) memcpy(out->inv_z, f + 3 * M1, 4 * M1);
+    if (out->dist) memcpy(out->dist, f + 4 * M1, 4 * M1);
+    return ORBX_OK;
+}
+
 int orbm_search_by_projection_sim3(orbx_extractor* h, const OrbmFrameView* KF, const OrbmProjectedPointView* P, float th, float ratio_hamming,
                                    int* assigned, int* nmatches_out) {
     if (!h || !KF || !P || !assigned) return fail(ORBX_E_ARG, "null");

@@ -73,6 +73,17 @@ struct FrustumParams {                                            // what Frame:
     float th, th_far; int far_points;
     int rig_mode;                                                 // Frame::isInFrustumChecks: store nothing unless every test passes, level -1 when rejected
 };
+// orbm_project_points: the geometry in front of GetFeaturesInArea in the projection-type searches (ORBmatcher.cc:495-732, :1325-1675, :1689-1932,
+// :1950-2030, :2196-2260) - see OrbmProjection in include/orbx.h (same fields)
+struct ProjectParams {
+    float R[9], t[3];
+    int has_sim3; float R2[9], t2[3], s2;
+    float Ow[3];
+    int dist_mode, depth_test, camera_type; float cam[8]; int inline_pinhole;
+    float min_x, max_x, min_y, max_y; int bounds_mode;
+    int distance_test, angle_test;
+    float bf;
+};
 struct VocSlot { int node_id, child_start, child_cnt, word_id; };   // one vocabulary node; children occupy consecutive slots
 struct BowItem { int idx1, start2, cnt2, out_off; };
 struct BowParams {
