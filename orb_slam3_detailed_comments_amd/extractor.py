@@ -200,6 +200,17 @@ class ORBextractor:
         self._lib.check(self._lib.L.orbx_device_upload(self._h, p, arr.ctypes.data, arr.nbytes))
         return p
 
+    def input_upload(self, images):
+        """Zero-copy input: writes the host batch [B, H, W] straight into pyramid level 0 of this handle (orbx_input_buffer / orbx_input_upload) and
+        returns (device_ptr, shape, stride, image_stride) for enqueue(device_ptr=...): the extraction then reads level 0 in place, without the
+        import pass.  The frames stay resident (level 0 is never written by the extraction)."""
+        images = np.ascontiguousarray(images, np.uint8)
+        B, H, W = images.shape
+        self._lib.check(self._lib.L.orbx_input_upload(self._h, B, images.ctypes.data, W, H, images.strides[1], images.strides[0]))
+        p = C.c_void_p(); st = C.c_int(); ist = C.c_size_t()
+        self._lib.check(self._lib.L.orbx_input_buffer(self._h, W, H, B, C.byref(p), C.byref(st), C.byref(ist)))
+        return p, (B, H, W), st.value, ist.value
+
     def device_alloc(self, nbytes):
         p = C.c_void_p()
         self._lib.check(self._lib.L.orbx_device_alloc(self._h, int(nbytes), C.byref(p)))

@@ -165,3 +165,30 @@ def test_extreme_fast_thresholds(emu_lib, ini, mn):
         assert _same(got, ol.OracleExtractor(200, 1.2, 4, ini, mn, 0).extract(img)), (ini, mn)
         if ol.reference() is not None:
             assert _same(got, ol.ReferenceExtractor(200, 1.2, 4, ini, mn, 0).extract(img)), (ini, mn)
+
+
+def _zero_copy_case(lib, w, h, nf):
+    """frames written straight into pyramid level 0 (orbx_input_buffer / orbx_input_upload) and extracted in place give what the import path gives"""
+    imgs = np.stack([synth.corner_field(w, h, seed=90 + s, nrect=max(200, w * h // 200)) for s in range(3)])
+    a = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib); b = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib)
+    ref = a.extract_batch(imgs)
+    ptr, shape, stride, istride = b.input_upload(imgs)
+    assert stride >= w and stride % 64 == 0
+    for _ in range(2):                                   # the frames stay resident: a second extraction reads the same level 0
+        b.enqueue(None, (0, 0), device_ptr=ptr, shape=shape, stride=stride, image_stride=istride)
+        got = b.fetch()
+        for x, y in zip(got, ref):
+            assert _same(x, y)
+    assert np.array_equal(b.pyramid_level(0, 1), imgs[1]) and np.array_equal(b.pyramid_level(3, 2), a.pyramid_level(3, 2))
+    a.close(); b.close()
+
+
+def test_zero_copy_input_emulated(emu_lib):
+    _zero_copy_case(emu_lib, 376, 240, 400)
+    _zero_copy_case(emu_lib, 320, 256, 300)               # width = pitch (no row padding)
+
+
+@pytest.mark.gpu
+def test_zero_copy_input_gpu(hip_lib):
+    _zero_copy_case(hip_lib, 752, 480, 1200)
+    _zero_copy_case(hip_lib, 512, 512, 1500)

@@ -90,3 +90,32 @@ def test_vocabulary_error_paths(emu_lib, tmp_path):
     voc = ORBVocabulary.from_arrays(ex, 10, 3, 0, 0, np.zeros(0, np.int32), np.zeros(0, np.uint8), np.zeros((0, 32), np.uint8), np.zeros(0))
     r = voc.transform(np.zeros((5, 32), np.uint8), 4)
     assert voc.size() == 0 and len(r.bow_id) == 0 and len(r.fv_node) == 0
+
+
+def check_orbvoc_scale(ex, tmp_path, n_desc, seed=3):
+    """A vocabulary of the shipped ORBvoc.txt's shape - k = 10, L = 6, 1 111 110 nodes, 10^6 words, a 154 MB text file, 36 MB of node
+    descriptors on the device - loaded by the reference's own loadFromTextFile and by the product; levelsup = 4 as ORB-SLAM3 calls it
+    (src/Frame.cc:992).  Returns (vocabulary, reference vocabulary, node descriptors, rng) for timing by the caller."""
+    if ol.reference_dbow2() is None:
+        pytest.skip("oracle/_ref/libref_dbow2.so not built")
+    rng = np.random.default_rng(seed)
+    header, parent, leaf, desc, weight = vs.make_vocabulary_fast(rng, 10, 6)
+    assert len(parent) == 1111110
+    path = tmp_path / "orbvoc_scale.txt"
+    vs.write_text_fast(path, header, parent, leaf, desc, weight)
+    ref = ol.RefVocabulary(path)
+    voc = ORBVocabulary.loadFromTextFile(ex, path)
+    assert voc.size() == ref.size() == 1000000
+    for levelsup, n in ((4, n_desc), (4, 1), (0, n_desc // 2), (6, 50)):
+        q = vs.descriptors_near(rng, desc, n)
+        r = voc.transform(q, levelsup)
+        bi, bv, fn, fs, ff = ref.transform(q, levelsup)
+        assert np.array_equal(r.bow_id, bi) and r.bow_val.tobytes() == bv.tobytes(), (levelsup, n)
+        assert np.array_equal(r.fv_node, fn) and np.array_equal(r.fv_start, fs) and np.array_equal(r.fv_feat, ff), (levelsup, n)
+    return voc, ref, desc, rng
+
+
+def test_vocabulary_orbvoc_scale_emulated(emu_lib, tmp_path):
+    ex = ORBextractor(500, 1.2, 8, 20, 7, lib=emu_lib)
+    voc, _, _, _ = check_orbvoc_scale(ex, tmp_path, 600)
+    voc.close()

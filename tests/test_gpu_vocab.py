@@ -61,3 +61,21 @@ def test_vocabulary_maximum_feature_count_gpu(hip_lib, tmp_path):
     assert np.array_equal(r.fv_node, fn) and np.array_equal(r.fv_start, fs) and np.array_equal(r.fv_feat, ff)
     with pytest.raises(OrbxError):
         voc.transform(np.zeros((16385, 32), np.uint8), 1)
+
+
+def test_vocabulary_orbvoc_scale_gpu(hip_lib, tmp_path):
+    """ORBvoc.txt's shape (k = 10, L = 6, 1.1 M nodes) on the GPU: parity with the reference's DBoW2, and the time of a batch of 128 images'
+    descriptors (the 36 MB of node descriptors no longer fit one XCD's L2; they live in the MALL / HBM)."""
+    import time
+    from test_emu_vocab import check_orbvoc_scale
+    ex = ORBextractor(1200, 1.2, 8, 20, 7)
+    voc, ref, desc, rng = check_orbvoc_scale(ex, tmp_path, 5000)
+    q = vs.descriptors_near(rng, desc, 128 * 1213)
+    voc.transform(q[:1213], 4)
+    t0 = time.perf_counter()
+    for b in range(0, 128 * 1213, 16384 - 16384 % 1213):
+        voc.transform(q[b:b + 16384 - 16384 % 1213], 4)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter(); ref.transform(q[:1213], 4); dr = time.perf_counter() - t1
+    print("ORBvoc-scale transform: %.3f ms per image of 1213 features (host arrays in, vectors out), reference DBoW2 %.3f ms per image" % (dt * 1e3 / 128, dr * 1e3))
+    voc.close()
