@@ -498,6 +498,10 @@ def main():
         ab = algorithmic_bytes(W, H, avg_kp, ncand)
         if zero_copy and not args.h2d:
             ab["import"] = 0                                   # level 0 is read where the producer wrote it
+        if kind == "rgbd":
+            # the batched local-point search per frame: 5000 points x (88 B resident point + 32 B query written and read) + ~4 candidates per point
+            # x (28 B keypoint + 32 B descriptor + 4 B uRight read, 8 B entry written and read)
+            ab["match"] = 5000 * (88 + 64) + 4 * 5000 * (64 + 16)
         units = {k: NIMG for k in ab}
         units["match"] = P
         # Which kernel dominates is decided on a clean schedule: a few extra steps on ONE handle with every kernel alone on one

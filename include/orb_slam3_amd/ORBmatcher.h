@@ -930,6 +930,23 @@ void ComputeStereoMatches(FrameT& F, ExtractorT* pLeft, ExtractorT* pRight)
     F.mvDepth.assign(d.begin(), d.begin() + F.N);
 }
 
+// Frame::ComputeStereoFromRGBD (src/Frame.cc:1361-1391) for a Frame whose extractor is the HIP facade: mvDepth / mvuRight of the keypoints of the
+// LAST call of the extractor from the depth image (CV_32F, already scaled by the depth map factor); mvKeysUn is taken to equal mvKeys (no
+// distortion), as the device never sees UndistortKeyPoints.  Call it where the reference calls the member:
+//   Frame.cc:270   ComputeStereoFromRGBD(imDepth);   ->   ORB_SLAM3::ComputeStereoFromRGBD(*this, mpORBextractorLeft, imDepth);
+template <class FrameT, class ExtractorT>
+void ComputeStereoFromRGBD(FrameT& F, ExtractorT* pExtractor, const cv::Mat& imDepth)
+{
+    const int cap = orbx_max_keypoints(pExtractor->Handle());
+    std::vector<float> u(cap, -1.0f), d(cap, -1.0f);
+    int n = 0;
+    ORBmatcher::Check(orbm_stereo_from_depth(pExtractor->Handle(), 0, 1, imDepth.template ptr<float>(0), (int)(imDepth.step / sizeof(float)),
+                                             (size_t)(imDepth.step / sizeof(float)) * imDepth.rows, 0, F.mbf));
+    ORBmatcher::Check(orbm_stereo_fetch(pExtractor->Handle(), 1, u.data(), d.data(), cap, &n));
+    F.mvuRight.assign(u.begin(), u.begin() + F.N);
+    F.mvDepth.assign(d.begin(), d.begin() + F.N);
+}
+
 // Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1530-1587) for a fisheye-rig Frame whose two extractors are the HIP facades: 2-NN + ratio
 // test on the lapping keypoints and the triangulation gate (KannalaBrandt8::TriangulateMatches) on the device-resident results of the LAST
 // call of each extractor (both made with the cameras' lapping areas, as ExtractORB does).  Fills mvLeftToRightMatch, mvRightToLeftMatch,

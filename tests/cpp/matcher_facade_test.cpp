@@ -93,6 +93,25 @@ int main(int argc, char** argv) {
     }
     printf("fisheye helper: %d of %d left keypoints matched, consistent=%d\n", nfish, RF.Nleft, !fish_bad);
     if (fish_bad) return 1;
+    // ---- ComputeStereoFromRGBD through the facade helper, against the definition (src/Frame.cc:1361-1391) ----
+    {
+        MockFrame G;
+        exL(imL, cv::Mat(), G.mvKeysUn, G.mDescriptors, lap);
+        G.N = (int)G.mvKeysUn.size(); G.mbf = 40.0f;
+        std::vector<float> depth((size_t)w * h);
+        for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) depth[(size_t)y * w + x] = ((x * 7 + y * 3) % 11 == 0) ? 0.0f : 1.0f + 0.01f * (float)((x * 13 + y * 5) % 300);
+        cv::Mat imD(h, w, CV_32F, depth.data());
+        ORB_SLAM3::ComputeStereoFromRGBD(G, &exL, imD);
+        int rgbd_bad = (int)G.mvuRight.size() != G.N || (int)G.mvDepth.size() != G.N, with_depth = 0;
+        for (int i = 0; i < G.N && !rgbd_bad; i++) {
+            const cv::KeyPoint& kp = G.mvKeysUn[i];
+            const float d = depth[(size_t)(int)kp.pt.y * w + (int)kp.pt.x];
+            const float eu = d > 0 ? kp.pt.x - G.mbf / d : -1.0f, ed = d > 0 ? d : -1.0f;
+            rgbd_bad |= G.mvuRight[i] != eu || G.mvDepth[i] != ed; with_depth += d > 0;
+        }
+        printf("rgbd helper: %d of %d keypoints with depth, consistent=%d\n", with_depth, G.N, !rgbd_bad);
+        if (rgbd_bad || with_depth < G.N / 2) return 1;
+    }
     const int de = orbo_descriptor_distance(F.mDescriptors.ptr(0), dR.ptr(0));
     printf("N=%d stereo=%d matches facade=%d oracle=%d mismatched_assignments=%d dist %d %d TH %d %d %d\n", F.N, nstereo, ngot, nexp, bad_assign, dd, de,
            ORB_SLAM3::ORBmatcher::TH_LOW, ORB_SLAM3::ORBmatcher::TH_HIGH, ORB_SLAM3::ORBmatcher::HISTO_LENGTH);

@@ -220,3 +220,49 @@ def concurrent_matchers(lib, w, h, nf, M_points):
 
 def test_matchers_from_three_threads_emulated(emu_lib):
     concurrent_matchers(emu_lib, 376, 240, 400, 600)
+
+
+def test_round3_entry_points_reject_bad_arguments(emu_lib):
+    """error behaviour of the batched / rig / projection entry points: status codes, never a crash or a silent CPU path"""
+    import ctypes as C
+    from orb_slam3_detailed_comments_amd._lib import OrbxError, ORBX_E_ARG
+    L = emu_lib
+    ex = ORBextractor(300, 1.2, 8, 20, 7, lib=L)
+    img = synth.corner_field(320, 240, seed=5, nrect=600)
+    # nothing extracted yet: no frames to search, no snapshot, no pending batch
+    assert L.L.orbm_stereo_from_depth(ex._h, 0, 1, np.zeros((240, 320), np.float32).ctypes.data, 320, 320 * 240, 0, 40.0) == ORBX_E_ARG
+    assert L.L.orbm_search_local_points_fetch(ex._h, None, 0, None, None) == ORBX_E_ARG
+    assert L.L.orbx_device_snapshot(ex._h, None, None) == ORBX_E_ARG
+    ex.extract_batch(img[None])
+    pos = np.array([[0, 0, 2]], np.float32)
+    rp = M.ResidentPoints(ex, pos, pos, np.ones(1, np.float32), np.full(1, 5, np.float32), np.zeros((1, 32), np.uint8))
+    lp = M.LocalPointsBatch(ex, rp, 1, (300.0, 300.0, 160.0, 120.0), (0.0, 320.0, 0.0, 240.0), 40.0, ex.GetScaleFactors())
+    lp.set_poses([(np.eye(3, dtype=np.float32), np.zeros(3, np.float32))])
+    with pytest.raises(OrbxError):
+        lp.enqueue(first=1)                                    # frames [1, 2) of a batch of one
+    lp.enqueue(first=0, use_u_right=False, want_in_view=False)
+    assert L.L.orbm_search_local_points_fetch(ex._h, lp.assigned.ctypes.data, 3, lp.nm.ctypes.data, None) < 0        # rows too short
+    lp.enqueue(first=0, use_u_right=False, want_in_view=False)
+    assert L.L.orbm_search_local_points_fetch(ex._h, lp.assigned.ctypes.data, lp.cap, lp.nm.ctypes.data, lp.in_view.ctypes.data) == ORBX_E_ARG   # in_view not requested
+    # stereo from depth: stride smaller than the image
+    assert L.L.orbm_stereo_from_depth(ex._h, 0, 1, np.zeros((240, 320), np.float32).ctypes.data, 100, 320 * 240, 0, 40.0) == ORBX_E_ARG
+    # projection: the distance test without distance limits
+    class Spec(C.Structure):
+        _fields_ = [("R", C.c_float * 9), ("t", C.c_float * 3), ("has_sim3", C.c_int), ("R2", C.c_float * 9), ("t2", C.c_float * 3), ("s2", C.c_float), ("Ow", C.c_float * 3),
+                    ("dist_mode", C.c_int), ("depth_test", C.c_int), ("camera_type", C.c_int), ("cam", C.c_float * 8), ("inline_pinhole", C.c_int), ("min_x", C.c_float),
+                    ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float), ("bounds_mode", C.c_int), ("distance_test", C.c_int), ("angle_test", C.c_int), ("bf", C.c_float)]
+    class PIn(C.Structure):
+        _fields_ = [("M", C.c_int), ("pos", C.c_void_p), ("normal", C.c_void_p), ("min_inv", C.c_void_p), ("max_inv", C.c_void_p), ("skip", C.c_void_p)]
+    class POut(C.Structure):
+        _fields_ = [("valid", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("ur", C.c_void_p), ("inv_z", C.c_void_p), ("dist", C.c_void_p)]
+    sp = Spec(); sp.R[:] = [1, 0, 0, 0, 1, 0, 0, 0, 1]; sp.cam[:] = [300, 300, 160, 120, 0, 0, 0, 0]; sp.max_x, sp.max_y = 320.0, 240.0; sp.distance_test = 1
+    pin = PIn(1, pos.ctypes.data, None, None, None, None); valid = np.zeros(1, np.uint8); u = np.zeros(1, np.float32)
+    pout = POut(valid.ctypes.data, u.ctypes.data, None, None, None, None)
+    assert L.L.orbm_project_points(ex._h, C.byref(sp), C.byref(pin), C.byref(pout)) == ORBX_E_ARG
+    sp.distance_test = 0
+    assert L.L.orbm_project_points(ex._h, C.byref(sp), C.byref(pin), C.byref(pout)) == 0 and valid[0] == 1 and u[0] == 160.0
+    # zero-copy input is refused while a colour / geometry pre-step is configured
+    ex.set_input(3, rgb=True)
+    p = C.c_void_p(); st = C.c_int(); ist = C.c_size_t()
+    assert L.L.orbx_input_buffer(ex._h, 320, 240, 1, C.byref(p), C.byref(st), C.byref(ist)) == ORBX_E_ARG
+    rp.close(); ex.close()
