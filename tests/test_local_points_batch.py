@@ -105,3 +105,54 @@ def test_local_points_batch_emulated(emu_lib, rgbd):
 def test_local_points_batch_gpu(hip_lib, rgbd):
     _run(hip_lib, 640, 480, 1000, 3, 5000, rgbd)
     _run(hip_lib, 752, 480, 1200, 3, 3000, rgbd)
+
+
+def _large_batch(lib, w, h, nf, B, npts, nscenes):
+    """B frames x npts points in one batch (the bench's shape) against the single-frame product call, which is pinned to the reference Frame above:
+    per-frame offsets of the grid, the queries, the candidate pool and the accept kernel at a size where every workgroup row is populated"""
+    from orb_slam3_detailed_comments_amd import views
+    rng = np.random.default_rng(77)
+    imgs = np.stack([synth.corner_field(w, h, seed=500 + (b % nscenes), nrect=int(2500 * w * h / (640 * 480))) for b in range(B)])      # nscenes distinct scenes, several poses each
+    ex = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib)
+    res = ex.extract_batch(imgs)
+    depth = (2.0 + np.sin(np.arange(w)[None, :] / 50.0) + np.cos(np.arange(h)[:, None] / 40.0)).astype(np.float32)
+    depth[rng.uniform(size=(h, w)) < 0.1] = 0
+    M.ComputeStereoFromRGBD(ex, np.broadcast_to(depth, (B, h, w)).copy(), 40.0)
+    u, dep, _ = M.StereoFetch(ex, B)
+    sfs = ex.GetScaleFactors()
+    cam, bounds = (FX, FY, CX, CY), (0.0, float(w), 0.0, float(h))
+    # map points on the rays of keypoints of the 12 scenes, at the depth the depth image gives them
+    pos = np.zeros((npts, 3), np.float32); desc = np.zeros((npts, 32), np.uint8); octv = np.zeros(npts)
+    for i in range(npts):
+        k, d = res[i % nscenes][1], res[i % nscenes][2]
+        j = int(rng.integers(0, len(k)))
+        z = float(depth[int(k["y"][j]), int(k["x"][j])]) or 3.0
+        pos[i] = ((k["x"][j] - CX) / FX * z, (k["y"][j] - CY) / FY * z, z); desc[i] = d[j]; octv[i] = k["octave"][j]
+        desc[i, int(rng.integers(0, 32))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+    dn = np.linalg.norm(pos, axis=1); normal = (pos / dn[:, None]).astype(np.float32)
+    maxd = (dn * 1.2 ** octv).astype(np.float32); mind = (maxd / 1.2 ** 7).astype(np.float32)
+    obs = rng.uniform(size=npts) < 0.9; bad = rng.uniform(size=npts) < 0.03
+    poses = [(_rot(*(rng.normal(0, 0.004, 3))), rng.normal(0, 0.01, 3).astype(np.float32)) for _ in range(B)]
+    rp = M.ResidentPoints(ex, pos, normal, mind, maxd, desc)
+    lp = M.LocalPointsBatch(ex, rp, B, cam, bounds, 40.0, sfs)
+    lp.set_poses(poses)
+    lp.enqueue(0, is_bad=bad, has_obs=obs, use_u_right=True, th=3.0, want_in_view=True)
+    asg, nm, inv = lp.fetch()
+    total = 0
+    for b in range(B):
+        n = len(res[b][1])
+        fv = views.frame_view(res[b][1], res[b][2], sfs, w, h, u_right=u[b, :n], mbf=40.0)
+        tr, ref_as, ref_n = M.SearchLocalPoints(ex, fv, poses[b][0], poses[b][1], cam, bounds, 40.0, sfs, pos, normal, mind, maxd, bad, obs, desc, 0.5, 3.0, False, 50.0, 0.8)
+        assert nm[b] == ref_n and np.array_equal(asg[b, :n], ref_as) and np.array_equal(inv[b], tr["in_view"]), "frame %d" % b
+        total += ref_n
+    assert total > 20 * B
+    rp.close(); ex.close()
+
+
+def test_local_points_many_frames_emulated(emu_lib):
+    _large_batch(emu_lib, 320, 240, 300, 7, 800, 3)
+
+
+@pytest.mark.gpu
+def test_local_points_large_batch_gpu(hip_lib):
+    _large_batch(hip_lib, 640, 480, 1000, 48, 5000, 12)
