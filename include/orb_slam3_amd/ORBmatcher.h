@@ -643,25 +643,19 @@ public:
             Check(orbm_fuse_candidates(SharedHandle(), &fs.v, ps.view(), th, 1, pKF->mvInvLevelSigma2.data(), best.data(), nullptr));
         }
         if (bRight) for (int i = 0; i < nMPs; i++) if (best[i] >= 0) best[i] += pKF->NLeft;       // :1488
-        int nFused=0;
-        for (int i=0; i<nMPs; i++) {                        // the map surgery of :1494-1520, in the reference's order
-            MapPointT* pMP = vpMapPoints[i];
-            if (!pMP || !ps.valid[i] || best[i] < 0) continue;
-            if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
-            const int bestIdx = best[i];
-            MapPointT* pMPinKF = pKF->GetMapPoint(bestIdx);
-            if (pMPinKF) {
-                if (!pMPinKF->isBad()) {
-                    if (pMPinKF->Observations()>pMP->Observations()) pMP->Replace(pMPinKF);
-                    else pMPinKF->Replace(pMP);
-                }
-            } else {
-                pMP->AddObservation(pKF,bestIdx);
-                pKF->AddMapPoint(pMP,bestIdx);
+        // the map surgery of :1494-1520, one candidate after the other (an earlier merge can make a later point bad or put it into the key frame)
+        int merged = 0;
+        for (int i = 0; i < nMPs; i++) {
+            MapPointT* incoming = vpMapPoints[i];
+            if (!incoming || !ps.valid[i] || best[i] < 0 || incoming->isBad() || incoming->IsInKeyFrame(pKF)) continue;
+            MapPointT* resident = Attach(pKF, incoming, best[i]);
+            if (resident && !resident->isBad()) {           // two points for one keypoint: the one with more observations survives
+                MapPointT* keep = resident->Observations() > incoming->Observations() ? resident : incoming;
+                (keep == resident ? incoming : resident)->Replace(keep);
             }
-            nFused++;
+            merged++;
         }
-        return nFused;
+        return merged;
     }
 
     // Project MapPoints into KeyFrame using a given Sim3 and search for duplicated MapPoints.   — src/ORBmatcher.cc:1543-1660
@@ -692,22 +686,14 @@ public:
             std::lock_guard<std::mutex> lock(Mutex());
             Check(orbm_fuse_candidates(SharedHandle(), &fs.v, ps.view(), th, 0, nullptr, best.data(), nullptr));
         }
-        int nFused=0;
-        for (int iMP=0; iMP<nPoints; iMP++) {               // :1640-1656
-            if (!ps.valid[iMP] || best[iMP] < 0) continue;
-            MapPointT* pMP = vpPoints[iMP];
-            if (pMP->isBad()) continue;
-            const int bestIdx = best[iMP];
-            MapPointT* pMPinKF = pKF->GetMapPoint(bestIdx);
-            if (pMPinKF) {
-                if (!pMPinKF->isBad()) vpReplacePoint[iMP] = pMPinKF;
-            } else {
-                pMP->AddObservation(pKF,bestIdx);
-                pKF->AddMapPoint(pMP,bestIdx);
-            }
-            nFused++;
+        int merged = 0;                                     // :1640-1656: here a keypoint that already has a point only reports it
+        for (int i = 0; i < nPoints; i++) {
+            if (!ps.valid[i] || best[i] < 0 || vpPoints[i]->isBad()) continue;
+            MapPointT* resident = Attach(pKF, vpPoints[i], best[i]);
+            if (resident && !resident->isBad()) vpReplacePoint[i] = resident;
+            merged++;
         }
-        return nFused;
+        return merged;
     }
 
 public:
@@ -792,6 +778,14 @@ protected:
     }
     // the rigid transform a similarity moves points with up to scale: [R | t / s] (:508, :1559)
     template <class SE3T, class Sim3T> static SE3T RigidPart(const Sim3T& S) { return SE3T(S.rotationMatrix(), S.translation() / S.scale()); }
+
+    // gives keypoint `slot` of the key frame the map point unless it has one already; returns the point that is there (NULL: `point` went in)
+    template <class KeyFrameT, class MapPointT> static MapPointT* Attach(KeyFrameT* kf, MapPointT* point, int slot)
+    {
+        MapPointT* there = kf->GetMapPoint(slot);
+        if (!there) { point->AddObservation(kf, slot); kf->AddMapPoint(point, slot); }
+        return there;
+    }
 
     template <class MapPointT> static void CopyDescriptor(MapPointT* p, uint8_t* dst) { const cv::Mat d = p->GetDescriptor(); memcpy(dst, d.ptr(0), 32); }
 

@@ -563,7 +563,13 @@ int orbm_search_local_points_batch(orbx_extractor* h, int first, int B, const Or
                                    float nnratio, int want_in_view) {
     if (!h || !frames || !points || B <= 0 || first < 0 || first + B > h->lastB) return fail(ORBX_E_ARG, "bad frame range / null");
     if (points->device != h->device) return fail(ORBX_E_ARG, "map points live on another device");
-    for (int b = 0; b < B; b++) if (frames[b].nlevels < 1 || frames[b].nlevels > kMaxLevels || !frames[b].scale_factors) return fail(ORBX_E_ARG, "bad scale levels (frame %d)", b);
+    for (int b = 0; b < B; b++) {
+        if (frames[b].nlevels < 1 || frames[b].nlevels > kMaxLevels || !frames[b].scale_factors) return fail(ORBX_E_ARG, "bad scale levels (frame %d)", b);
+        // one grid geometry per batch (the frames of a batch come from one extraction: one image size)
+        if (frames[b].min_x != frames[0].min_x || frames[b].max_x != frames[0].max_x || frames[b].min_y != frames[0].min_y || frames[b].max_y != frames[0].max_y)
+            return fail(ORBX_E_ARG, "frame %d has other image bounds than frame 0", b);
+    }
+    if (!(frames[0].max_x > frames[0].min_x) || !(frames[0].max_y > frames[0].min_y)) return fail(ORBX_E_ARG, "empty image bounds");
     rt::set_device(h->device);
     const int M = points->M, cap = h->kp_total_cap;
     const size_t B1 = B, M1 = M > 0 ? M : 1, C1 = cap;
