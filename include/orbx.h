@@ -102,6 +102,15 @@ int orbx_device_upload(orbx_extractor* h, void* dptr, const void* host, size_t b
  * `host` should be page-locked, orbx_host_alloc) */
 int orbx_device_upload_async(orbx_extractor* h, void* dptr, const void* host, size_t bytes);
 
+/* Frame::UndistortKeyPoints (src/Frame.cc:1003-1034) on the device: with K = (fx, fy, cx, cy) and dist = mDistCoef (k1, k2, p1, p2[, k3]; ndist 4 or 5)
+ * every extraction also produces mvKeysUn - cv::undistortPoints(keys, K, dist, R = empty, P = K) in OpenCV's double arithmetic (restated;
+ * opencv_variant 0 = OpenCV >= 3.4.2, 1 = 3.2) - for orbx_fetch_undistorted and for the device-resident consumers (orbm_stereo_from_depth,
+ * orbm_search_local_points_batch).  dist == NULL or dist[0] == 0: mvKeysUn = mvKeys, as the reference decides (:1005-1009).
+ * orbx_undistorted_bounds = Frame::ComputeImageBounds (:1043-1075): out = mnMinX, mnMaxX, mnMinY, mnMaxY. */
+int orbx_set_undistort(orbx_extractor* h, const float K[4], const float* dist, int ndist, int opencv_variant);
+int orbx_fetch_undistorted(orbx_extractor* h, OrbxKeyPoint* kps_un, int cap);       /* [B][cap], blocking */
+int orbx_undistorted_bounds(const orbx_extractor* h, int width, int height, float out[4]);
+
 /* Zero-copy input: the address and layout of pyramid level 0 inside the handle, for B images of width x height (reserves like orbx_reserve).
  * A producer that can write there - a camera DMA, a decoder, orbx_input_upload below - hands its frames over without the import pass
  * (one read and one write of every pixel): call orbx_extract_batch(h, B, *dptr, width, height, *stride, *image_stride, 1, ...) with exactly
@@ -288,13 +297,13 @@ int orbm_search_local_points_resident(orbx_extractor* h, const OrbmFrameView* F,
 /* Frame::ComputeStereoFromRGBD (src/Frame.cc:1361-1391) for frames [first, first + B) of the handle's last extraction: mvDepth[i] = the depth
  * image (CV_32F, already scaled by Tracking::mDepthMapFactor, src/Tracking.cc:1617-1618) at the keypoint, mvuRight[i] = x - mbf / d where d > 0,
  * both -1 elsewhere.  depth image b at depth + b * image_stride, rows `stride` floats apart (host memory, or device memory of this GPU).
- * Keypoints are taken as undistorted (mvKeysUn = mvKeys: rectified / distortion-free input).  Results like orbm_stereo_match's: fetch with
+ * uRight uses mvKeysUn (orbx_set_undistort; mvKeys without distortion), the depth is read at mvKeys, as the reference does.  Results like orbm_stereo_match's: fetch with
  * orbm_stereo_fetch (n_matches = keypoints with a depth), or leave them on the device for orbm_search_local_points_batch.  Asynchronous. */
 int orbm_stereo_from_depth(orbx_extractor* h, int first, int B, const float* depth, int stride, size_t image_stride, int depth_on_device, float mbf);
 
 /* Tracking::SearchLocalPoints (src/Tracking.cc:3979-4067 -> Frame::isInFrustum src/Frame.cc:667-773 + ORBmatcher::SearchByProjection
  * src/ORBmatcher.cc:45-167) for a BATCH of frames without leaving the device: frames = images [first, first + B) of the handle's last
- * extraction, read where the extractor left them (mvKeysUn = the extracted keypoints, mDescriptors; mvuRight = the results of
+ * extraction, read where the extractor left them (mvKeysUn - undistorted on the device when orbx_set_undistort is set -, mDescriptors; mvuRight = the results of
  * orbm_stereo_match / orbm_stereo_from_depth for the same range when use_u_right != 0, else every keypoint is monocular); frames[b] = pose,
  * camera and bounds of frame b (the grid constants are derived from the bounds as Frame does, src/Frame.cc:190-191); the local map is resident
  * (orbm_points); is_bad / has_obs: call-time flags of the M points (NULL = none bad / all observed); occupied: [B][orbx_max_keypoints()] bytes,

@@ -166,10 +166,20 @@ static inline double norm(const Mat& a, const Mat& b, int /*NORM_L1*/) {
     return orbp::norm_l1_u8(a.data, a.step, b.data, b.step, a.cols, a.rows);
 }
 
-// Names Frame.cc needs to compile.  undistortPoints is only called with non-zero distortion coefficients (src/Frame.cc:1007, :1061), which the
-// oracle never configures; vconcat / BFMatcher serve the fisheye-rig constructor (:1514, :1553): brute-force Hamming 2-NN with strict '<'
+// Names Frame.cc needs to compile.  undistortPoints (src/Frame.cc:1019, :1061; CV_32FC2 points in place, R empty, P = K) is the restated
+// primitive of orb_primitives.h; vconcat / BFMatcher serve the fisheye-rig constructor (:1514, :1553): brute-force Hamming 2-NN with strict '<'
 // insertion, equal distances keep the lower train index first (OpenCV's BFMatcher order; restated, OpenCV is not installed).
-static inline void undistortPoints(const Mat&, Mat&, const Mat&, const Mat&, const Mat&, const Mat&) { std::abort(); }
+inline int& shim_undistort_variant() { static int v = 0; return v; }
+static inline void undistortPoints(const Mat& src, Mat& dst, const Mat& K, const Mat& dist, const Mat&, const Mat&) {
+    const float k4[4] = {K.at<float>(0, 0), K.at<float>(1, 1), K.at<float>(0, 2), K.at<float>(1, 2)};
+    float d[5] = {0, 0, 0, 0, 0};
+    const int nd = dist.rows * dist.cols;
+    for (int i = 0; i < nd && i < 5; i++) d[i] = ((const float*)dist.data)[i];
+    std::vector<float> out((size_t)2 * src.rows + 2);
+    orbp::undistort_points_f32((const float*)src.data, src.rows, k4, d, nd < 5 ? nd : 5, shim_undistort_variant(), out.data());
+    if (dst.data != src.data) dst.create(src.rows, src.cols, src.type());
+    memcpy(dst.data, out.data(), sizeof(float) * 2 * (size_t)src.rows);
+}
 static inline void vconcat(const Mat& a, const Mat& b, Mat& dst) {
     Mat r(a.rows + b.rows, a.cols, CV_8UC1);
     for (int y = 0; y < a.rows; y++) memcpy(r.ptr(y), a.ptr(y), (size_t)a.cols);

@@ -534,6 +534,7 @@ void orbo_prim_resize(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, 
 void orbo_prim_blur(const uint8_t* src, int w, int h, uint8_t* dst, int variant) { orbp::gaussian_blur7_u8(src, w, h, (size_t)w, dst, (size_t)w, variant); }
 void orbo_prim_border(const uint8_t* src, int w, int h, uint8_t* dst, int b) { orbp::make_border_reflect101(src, w, h, (size_t)w, dst, (size_t)(w + 2 * b), b, b, b, b); }
 int orbo_prim_round(double v) { return orbp::round_half_even(v); }
+void orbo_prim_undistort(const float* src, int n, const float* K, const float* dist, int ndist, int variant, float* dst) { orbp::undistort_points_f32(src, n, K, dist, ndist, variant, dst); }
 // input pre-step (System.cc:286-297, Tracking.cc:1532-1560); multi-channel resize = cv::resize per channel
 void orbo_prim_remap(const uint8_t* src, int sw, int sh, int cn, const float* mapx, const float* mapy, uint8_t* dst, int dw, int dh) {
     orbp::remap_linear_u8(src, sw, sh, (size_t)sw * cn, cn, mapx, mapy, dst, dw, dh, (size_t)dw * cn);

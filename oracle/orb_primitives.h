@@ -133,6 +133,34 @@ static inline void cvt_gray_u8(const uint8_t* src, int w, int h, size_t sstep, i
         }
 }
 
+// ---- cv::undistortPoints(src, dst, K, distCoeffs, R = empty, P = K) for CV_32FC2 points (Frame::UndistortKeyPoints, src/Frame.cc:1003-1034) ----
+// OpenCV calib3d/undistort (cvUndistortPointsInternal), the (k1, k2, p1, p2[, k3]) model the reference configures: everything in double,
+// x = (u - cx) / fx with ifx = 1. / fx, five fixed-point iterations (the public overload's TermCriteria(MAX_ITER, 5, 0.01): count only)
+//   r2 = x x + y y; icdist = (1 + ((k[7] r2 + k[6]) r2 + k[5]) r2) / (1 + ((k[4] r2 + k[1]) r2 + k[0]) r2)      (k[5..7] = 0 here: numerator 1)
+//   dX = 2 k[2] x y + k[3] (r2 + 2 x x); dY = k[2] (r2 + 2 y y) + 2 k[3] x y; x = (x0 - dX) icdist; y = (y0 - dY) icdist
+// (OpenCV >= 3.4.2 leaves the loop with the undistorted start value when icdist < 0: variant 0; 3.2 does not: variant 1), then the new
+// projection xx = P00 x + P01 y + P02, yy = ..., ww = 1 / (P20 x + P21 y + P22) with P = K, and the result is stored as float.
+static inline void undistort_points_f32(const float* src, int n, const float K[4], const float* dist, int ndist, int variant, float* dst) {
+    const double fx = K[0], fy = K[1], cx = K[2], cy = K[3], ifx = 1. / fx, ify = 1. / fy;
+    double k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < ndist && i < 5; i++) k[i] = dist[i];
+    for (int i = 0; i < n; i++) {
+        const double u = src[2 * i], v = src[2 * i + 1];
+        double x = (u - cx) * ifx, y = (v - cy) * ify;
+        const double x0 = x, y0 = y;
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            if (variant == 0 && icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+            x = (x0 - deltaX) * icdist; y = (y0 - deltaY) * icdist;
+        }
+        const double xx = fx * x + 0.0 * y + cx, yy = 0.0 * x + fy * y + cy, ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+        dst[2 * i] = (float)(xx * ww); dst[2 * i + 1] = (float)(yy * ww);
+    }
+}
+
 // ---- cv::copyMakeBorder(BORDER_REFLECT_101) ---------------------------------------------------
 // dst is (w+left+right) x (h+top+bottom); src may alias the interior of dst.
 static inline void make_border_reflect101(const uint8_t* src, int w, int h, size_t sstep,

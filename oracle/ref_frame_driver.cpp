@@ -58,14 +58,16 @@ void ref_frame_destroy(void* h) { delete (Holder*)h; }
 // Frame(imGray, imDepth, ...) - the RGB-D constructor (src/Frame.cc:235-345): one extraction, UndistortKeyPoints (no distortion),
 // ComputeStereoFromRGBD (:1361-1391), AssignFeaturesToGrid.  depth: CV_32F, w x h (already scaled by the depth map factor).
 void* ref_frame_rgbd(const uint8_t* gray, const float* depth, int w, int h, int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, int gauss_variant,
-                     float fx, float fy, float cx, float cy, float bf, float th_depth, int* n) {
+                     float fx, float fy, float cx, float cy, float bf, float th_depth, const float* dist5, int* n) {
     cv::shim_gauss_variant() = gauss_variant;
     Holder* H = new Holder();
     H->left = new ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th);
     H->cam = new Pinhole(fx, fy, cx, cy);
     cv::Mat im(h, w, CV_8UC1, (void*)gray, (size_t)w), imD(h, w, CV_32F, (void*)depth, (size_t)w * sizeof(float));
     cv::Mat K = H->cam->toK();
-    cv::Mat dist(4, 1, CV_32F); for (int i = 0; i < 4; i++) dist.at<float>(i) = 0.0f;
+    // dist5 = (k1, k2, p1, p2, k3) as Examples/RGB-D/TUM1.yaml gives them: UndistortKeyPoints (:1003-1034) and ComputeImageBounds (:1043-1075) then
+    // go through cv::undistortPoints (restated in the shim); NULL = no distortion
+    cv::Mat dist(dist5 ? 5 : 4, 1, CV_32F); for (int i = 0; i < dist.rows; i++) dist.at<float>(i) = dist5 ? dist5[i] : 0.0f;
     Frame::mbInitialComputations = true;
     H->frame = new Frame(im, imD, 0.0, H->left, nullptr, K, dist, bf, th_depth, H->cam);
     *n = H->frame->N;

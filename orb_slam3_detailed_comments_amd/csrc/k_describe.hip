@@ -8,6 +8,7 @@
 #include "orbx_types.h"
 #include "orbx_block.h"
 #include "orbx_kernels.h"
+#include "undistort_model.h"
 #include "glibc_sincosf_model.h"
 
 namespace orbx {
@@ -272,6 +273,20 @@ __global__ void __launch_bounds__(256) k_orient_brief_small(const LevelInfo* __r
                                                       UmaxTab umax, KeyPointRec* __restrict__ out_kps,
                                                       unsigned long long* __restrict__ out_desc, int4* __restrict__ out_aux, int B, int groups_per_image) {
     orient_brief_impl<kKpPerWaveSmall>(lv, nlevels, pyr, blur, pyr_stride, lvl_keys, kp_total_cap, lvl_count, final_idx, umax, out_kps, out_desc, out_aux, B, groups_per_image);
+}
+
+// Frame::UndistortKeyPoints (src/Frame.cc:1003-1034) for the keypoints of a batch: the records of `kps` with x, y replaced by cv::undistortPoints'
+// result (undistort_model.h), everything else copied.  grid (ceil(cap / 256), B).
+__global__ void __launch_bounds__(256) k_undistort(const KeyPointRec* __restrict__ kps, const int* __restrict__ n_per_frame, int cap, UndistortParams U,
+                                                   KeyPointRec* __restrict__ kps_un) {
+    const size_t b = blockIdx.y;
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= cap || i >= n_per_frame[b]) return;
+    KeyPointRec k = kps[b * (size_t)cap + i];
+    float x, y;
+    undistort_point(U, k.x, k.y, &x, &y);
+    k.x = x; k.y = y;
+    kps_un[b * (size_t)cap + i] = k;
 }
 
 }  // namespace orbx

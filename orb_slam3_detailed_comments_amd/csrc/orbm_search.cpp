@@ -552,7 +552,8 @@ int orbm_stereo_from_depth(orbx_extractor* h, int first, int B, const float* dep
     const int cap = h->kp_total_cap;
     rt::memset_async(h->d_nmatch.p, 0, sizeof(int) * (size_t)B, h->s0);
     dim3 grid((cap + 255) / 256, B, 1), blk(256, 1, 1);
-    ORBX_LAUNCH(k_stereo_from_depth, grid, blk, 0, h->s0, (const KeyPointRec*)(h->d_kps.p + (size_t)first * cap), (const KeyPointRec*)nullptr, (const int*)(h->d_nm.p + first), cap,
+    ORBX_LAUNCH(k_stereo_from_depth, grid, blk, 0, h->s0, (const KeyPointRec*)(h->d_kps.p + (size_t)first * cap),
+                h->undist.active ? (const KeyPointRec*)(h->d_kps_un.p + (size_t)first * cap) : (const KeyPointRec*)nullptr, (const int*)(h->d_nm.p + first), cap,
                 d_depth, stride, image_stride, h->W, h->H, mbf, h->d_uRight.p, h->d_depth.p, h->d_nmatch.p);
     if (rt::check_launch()) return fail(ORBX_E_DEVICE, "kernel launch failed: %s", rt::last_error());
     return ORBX_OK;
@@ -604,7 +605,7 @@ int orbm_search_local_points_batch(orbx_extractor* h, int first, int B, const Or
     if (occupied) memcpy(hp + u_occ, occupied, B1 * C1);
     if (rt::copy_h2d(dp, hp, u_total, h->s0) || rt::event_record(h->ev_lp, h->s0)) return fail(ORBX_E_DEVICE, "upload failed: %s", rt::last_error());
     h->lp_pending = true;
-    const KeyPointRec* kps = h->d_kps.p + (size_t)first * cap;
+    const KeyPointRec* kps = (h->undist.active ? h->d_kps_un.p : h->d_kps.p) + (size_t)first * cap;     // mvKeysUn
     const unsigned long long* fdesc = h->d_desc.p + (size_t)first * cap * 4;
     const int* nper = h->d_nm.p + first;
     const float* ur = h->d_uRight.p;

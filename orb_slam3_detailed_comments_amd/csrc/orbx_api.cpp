@@ -345,6 +345,10 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
                     h->pyr_stride, (const uint32_t*)h->d_lvl_keys.p, h->kp_total_cap, (const int*)h->d_lvl_count.p, (const int*)h->d_final_idx.p,
                     h->umax, h->d_kps.p, h->d_desc.p, (int4*)h->d_aux.p, B, gpi);
     }
+    if (h->undist.active) {                                         // mvKeysUn (Frame::UndistortKeyPoints)
+        dim3 grid((h->kp_total_cap + 255) / 256, B, 1);
+        ORBX_LAUNCH(k_undistort, grid, blk1, 0, h->s0, (const KeyPointRec*)h->d_kps.p, (const int*)h->d_nm.p, h->kp_total_cap, h->undist, h->d_kps_un.p);
+    }
     stage_end(h, ST_DESCRIBE, h->s0);
     rt::event_record(h->ev_done, h->s0);
     h->lastB = B;
@@ -401,6 +405,7 @@ void orbx_destroy(orbx_extractor* h) {
     for (auto& x : h->d_sr) x.release();
     h->h_packA.release(); h->h_packB.release(); h->h_out.release();
     for (auto& x : h->d_si) x.release();
+    h->d_kps_un.release();
     h->d_lp.release(); h->d_depth_in.release(); h->h_lp_in.release(); h->h_lp_out.release();
     h->d_aux.release(); h->d_qtprof.release(); h->d_rowstart.release(); h->d_rowitems.release();
     h->d_mapx.release(); h->d_mapy.release(); h->d_in_xt.release(); h->d_in_yt.release(); h->d_frame.release();
@@ -444,6 +449,7 @@ int orbx_extract_batch(orbx_extractor* h, int B, const uint8_t* images, int widt
     int rc = configure(h, geom ? h->in_out_w : width, geom ? h->in_out_h : height, B);
     if (rc) return rc;
     rt::set_device(h->device);
+    if (h->undist.active && h->d_kps_un.ensure((size_t)h->maxB * h->kp_total_cap)) return fail(ORBX_E_DEVICE, "allocation failed (undistorted keypoints)");
     if (h->in_active) {
         if (h->in_geometry == 2 && (h->in_tap_w != width || h->in_tap_h != height)) {        // cv::resize taps for this source size
             std::vector<ResizeTap> xt, yt;
@@ -473,7 +479,7 @@ int orbx_extract_batch(orbx_extractor* h, int B, const uint8_t* images, int widt
     // is baked into the kernel arguments and re-captured when any of it changes.
     if (h->use_graph && !h->profile && !h->in_active) {
         const bool same = h->graph_exec && h->g_B == B && h->g_images == d_images && h->g_stride == stride && h->g_image_stride == image_stride &&
-                          h->g_lap0 == lap0 && h->g_lap1 == lap1 && h->g_W == h->W && h->g_H == h->H && h->g_pyr == h->d_pyr.p && h->g_gauss == h->gauss_variant;
+                          h->g_lap0 == lap0 && h->g_lap1 == lap1 && h->g_W == h->W && h->g_H == h->H && h->g_pyr == h->d_pyr.p && h->g_gauss == h->gauss_variant && h->g_undist_gen == h->undist_gen;
         if (!same) {
             if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
             if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
@@ -485,7 +491,7 @@ int orbx_extract_batch(orbx_extractor* h, int B, const uint8_t* images, int widt
                 return fail(ORBX_E_DEVICE, "graph capture/instantiate failed: %s", rt::last_error());
             }
             h->g_B = B; h->g_images = d_images; h->g_stride = stride; h->g_image_stride = image_stride; h->g_lap0 = lap0; h->g_lap1 = lap1;
-            h->g_W = h->W; h->g_H = h->H; h->g_pyr = h->d_pyr.p; h->g_gauss = h->gauss_variant;
+            h->g_W = h->W; h->g_H = h->H; h->g_pyr = h->d_pyr.p; h->g_gauss = h->gauss_variant; h->g_undist_gen = h->undist_gen;
         }
         if (hipGraphLaunch(h->graph_exec, h->s0) != hipSuccess) return fail(ORBX_E_DEVICE, "graph launch failed: %s", rt::last_error());
         // the records inside the capture belong to the graph; these are the ones other streams can wait on (an upload into the input buffer
@@ -667,6 +673,41 @@ int orbx_device_outputs(orbx_extractor* h, void** kps, void** desc, void** n, vo
     if (mono) *mono = h->d_nm.p + h->maxB;
     if (cap) *cap = h->kp_total_cap;
     if (B) *B = h->lastB;
+    return ORBX_OK;
+}
+
+int orbx_set_undistort(orbx_extractor* h, const float K[4], const float* dist, int ndist, int opencv_variant) {
+    if (!h) return fail(ORBX_E_ARG, "null handle");
+    h->undist_gen++;
+    memset(&h->undist, 0, sizeof h->undist);
+    if (!K || !dist || ndist <= 0 || dist[0] == 0.0f) return ORBX_OK;           // mDistCoef.at<float>(0) == 0.0: mvKeysUn = mvKeys (src/Frame.cc:1005-1009)
+    if (ndist != 4 && ndist != 5) return fail(ORBX_E_ARG, "distortion coefficients: k1, k2, p1, p2[, k3]");
+    if (opencv_variant != 0 && opencv_variant != 1) return fail(ORBX_E_ARG, "bad OpenCV variant");
+    UndistortParams& U = h->undist;
+    U.fx = K[0]; U.fy = K[1]; U.cx = K[2]; U.cy = K[3]; U.ifx = 1. / U.fx; U.ify = 1. / U.fy;
+    for (int i = 0; i < ndist; i++) U.k[i] = dist[i];
+    U.variant = opencv_variant; U.active = 1;
+    return ORBX_OK;
+}
+int orbx_fetch_undistorted(orbx_extractor* h, OrbxKeyPoint* kps_un, int cap) {
+    if (!h || !kps_un || h->lastB <= 0) return fail(ORBX_E_ARG, "nothing to fetch");
+    if (cap < h->kp_total_cap) return fail(ORBX_E_CAPACITY, "rows need %d entries", h->kp_total_cap);
+    rt::set_device(h->device);
+    const size_t tc = (size_t)h->kp_total_cap;
+    const KeyPointRec* src = h->undist.active ? h->d_kps_un.p : h->d_kps.p;      // without distortion mvKeysUn is mvKeys
+    int e = 0;
+    if ((size_t)cap == tc) e = rt::copy_d2h(kps_un, src, (size_t)h->lastB * tc * sizeof(KeyPointRec), h->s0);
+    else for (int b = 0; b < h->lastB; b++) e |= rt::copy_d2h(kps_un + (size_t)b * cap, src + (size_t)b * tc, tc * sizeof(KeyPointRec), h->s0);
+    if (e || rt::stream_sync(h->s0)) return fail(ORBX_E_DEVICE, "D2H failed: %s", rt::last_error());
+    return ORBX_OK;
+}
+int orbx_undistorted_bounds(const orbx_extractor* h, int width, int height, float out[4]) {
+    if (!h || !out) return fail(ORBX_E_ARG, "null");
+    if (!h->undist.active) { out[0] = 0.0f; out[1] = (float)width; out[2] = 0.0f; out[3] = (float)height; return ORBX_OK; }     // src/Frame.cc:1068-1074
+    float x[4], y[4];
+    const float cu[4] = {0.0f, (float)width, 0.0f, (float)width}, cv[4] = {0.0f, 0.0f, (float)height, (float)height};
+    for (int i = 0; i < 4; i++) undistort_point(h->undist, cu[i], cv[i], &x[i], &y[i]);
+    out[0] = std::min(x[0], x[2]); out[1] = std::max(x[1], x[3]); out[2] = std::min(y[0], y[1]); out[3] = std::max(y[2], y[3]);              // :1062-1065
     return ORBX_OK;
 }
 

@@ -99,5 +99,7 @@ struct orbx_extractor {
     orbx::DevBuf<uint8_t> d_lp, d_depth_in; orbx::HostBuf<uint8_t> h_lp_in, h_lp_out;
     size_t lp_pool = 0; int lp_B = 0, lp_M = 0, lp_first = 0; size_t lp_o_counter = 0, lp_o_view = 0; bool lp_pending = false, lp_want_view = false;
     orbx::rt::event_t ev_lp = 0;
+    // Frame::UndistortKeyPoints on the device (orbx_set_undistort): mvKeysUn of the last batch
+    orbx::UndistortParams undist = {}; int undist_gen = 0, g_undist_gen = 0; orbx::DevBuf<orbx::KeyPointRec> d_kps_un;
     orbx::DevBuf<int> d_aux;     // int4 per keypoint: stereo row band / x / octave (k_orient_brief -> k_stereo_match)
 };

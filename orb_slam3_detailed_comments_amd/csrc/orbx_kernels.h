@@ -1,6 +1,7 @@
 // orbx_kernels.h — prototypes of the __global__ kernels (defined in k_*.hip) for the host launcher.
 #pragma once
 #include "orbx_types.h"
+#include "undistort_model.h"
 
 namespace orbx {
 
@@ -55,6 +56,7 @@ __global__ void k_orient_brief_small(const LevelInfo* __restrict__ lv, int nleve
                                const int* __restrict__ lvl_count, const int* __restrict__ final_idx, UmaxTab umax,
                                KeyPointRec* __restrict__ out_kps, unsigned long long* __restrict__ out_desc, int4* __restrict__ out_aux,
                                int B, int groups_per_image);
+__global__ void k_undistort(const KeyPointRec* __restrict__ kps, const int* __restrict__ n_per_frame, int cap, UndistortParams U, KeyPointRec* __restrict__ kps_un);
 __global__ void k_hamming_matrix(const unsigned long long* __restrict__ A, int na,
                                  const unsigned long long* __restrict__ Bm, int nb, int* __restrict__ out);
 __global__ void k_stereo_rows(const int4* __restrict__ auxR, const int* __restrict__ nR, int cap, int nb, int* __restrict__ bucket_start,

@@ -200,6 +200,26 @@ class ORBextractor:
         self._lib.check(self._lib.L.orbx_device_upload(self._h, p, arr.ctypes.data, arr.nbytes))
         return p
 
+    def set_undistort(self, K=None, dist=None, opencv_variant=0):
+        """Frame::UndistortKeyPoints on the device (orbx_set_undistort): K = (fx, fy, cx, cy), dist = (k1, k2, p1, p2[, k3]); None switches it off."""
+        if K is None or dist is None:
+            self._lib.check(self._lib.L.orbx_set_undistort(self._h, None, None, 0, 0)); return
+        k = np.ascontiguousarray(K, np.float32); d = np.ascontiguousarray(dist, np.float32)
+        self._lib.check(self._lib.L.orbx_set_undistort(self._h, k.ctypes.data, d.ctypes.data, len(d), int(opencv_variant)))
+
+    def fetch_undistorted(self):
+        """mvKeysUn of the last batch: [B, cap] keypoint records (rows beyond the count of a frame are unspecified)"""
+        cap = self.max_keypoints()
+        a = np.zeros((self._B, cap), KP_DTYPE)
+        self._lib.check(self._lib.L.orbx_fetch_undistorted(self._h, a.ctypes.data, cap))
+        return a
+
+    def undistorted_bounds(self, width, height):
+        """Frame::ComputeImageBounds: (mnMinX, mnMaxX, mnMinY, mnMaxY)"""
+        o = np.zeros(4, np.float32)
+        self._lib.check(self._lib.L.orbx_undistorted_bounds(self._h, int(width), int(height), o.ctypes.data))
+        return tuple(float(v) for v in o)
+
     def input_upload(self, images):
         """Zero-copy input: writes the host batch [B, H, W] straight into pyramid level 0 of this handle (orbx_input_buffer / orbx_input_upload) and
         returns (device_ptr, shape, stride, image_stride) for enqueue(device_ptr=...): the extraction then reads level 0 in place, without the

@@ -378,6 +378,17 @@ def oracle_resize_cn(src, dw, dh):
     return dst
 
 
+def oracle_undistort(points, K, dist, variant=0):
+    """cv::undistortPoints(points, K, dist, R = empty, P = K) for float32 [n, 2] points (oracle/orb_primitives.h)"""
+    L = oracle()
+    L.orbo_prim_undistort.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.orbo_prim_undistort.restype = None
+    p = np.ascontiguousarray(points, np.float32).reshape(-1, 2); k = np.ascontiguousarray(K, np.float32); d = np.ascontiguousarray(dist, np.float32)
+    out = np.zeros_like(p)
+    L.orbo_prim_undistort(p.ctypes.data, len(p), k.ctypes.data, d.ctypes.data, len(d), int(variant), out.ctypes.data)
+    return out
+
+
 def oracle_gray(src, red_first, variant):
     L = oracle()
     L.orbo_prim_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -415,7 +426,7 @@ def _bind_frame_lib(L):
         L.ref_frame_stereo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_float] * 6 + [C.POINTER(C.c_int)] * 2
         L.ref_frame_destroy.argtypes = [C.c_void_p]
         L.ref_frame_rgbd.restype = C.c_void_p
-        L.ref_frame_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_float] * 6 + [C.POINTER(C.c_int)]
+        L.ref_frame_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_float] * 6 + [C.c_void_p, C.POINTER(C.c_int)]
         L.ref_frame_fisheye.restype = C.c_void_p
         L.ref_frame_fisheye.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p]
         L.ref_frame_fisheye_get3d.argtypes = [C.c_void_p] * 3
@@ -451,16 +462,19 @@ class ReferenceFrame:
     """ORB_SLAM3::Frame as built by the reference's own stereo constructor (src/Frame.cc:105-230) on a rectified pair."""
 
     def __init__(self, left, right, nfeatures=1200, scale=1.2, nlevels=8, ini=20, mn=7, gauss_variant=0, fx=458.654, fy=457.296, cx=367.215, cy=248.375, bf=458.654 * 0.110074, th_depth=35.0,
-                 lib=None, depth=None):
-        """depth given (float32 [H, W]): the RGB-D constructor (src/Frame.cc:235-345) on (left = grey image, depth); `right` is ignored"""
+                 lib=None, depth=None, dist=None):
+        """depth given (float32 [H, W]): the RGB-D constructor (src/Frame.cc:235-345) on (left = grey image, depth); `right` is ignored;
+        dist = (k1, k2, p1, p2, k3): lens distortion (UndistortKeyPoints / ComputeImageBounds through the restated cv::undistortPoints)"""
         L = lib or reference_frame_lib()
         left = np.ascontiguousarray(left, np.uint8)
         n = C.c_int(); nr = C.c_int()
         self.L = L
         if depth is not None:
             depth = np.ascontiguousarray(depth, np.float32)
+            d5 = None if dist is None else np.ascontiguousarray(dist, np.float32)
+            assert d5 is None or d5.size == 5
             self.h = L.ref_frame_rgbd(left.ctypes.data, depth.ctypes.data, left.shape[1], left.shape[0], nfeatures, scale, nlevels, ini, mn, gauss_variant,
-                                      fx, fy, cx, cy, bf, th_depth, C.byref(n))
+                                      fx, fy, cx, cy, bf, th_depth, None if d5 is None else d5.ctypes.data, C.byref(n))
         else:
             right = np.ascontiguousarray(right, np.uint8)
             self.h = L.ref_frame_stereo(left.ctypes.data, right.ctypes.data, left.shape[1], left.shape[0], nfeatures, scale, nlevels, ini, mn, gauss_variant,
