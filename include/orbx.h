@@ -317,6 +317,29 @@ int orbm_search_local_points_batch(orbx_extractor* h, int first, int B, const Or
                                    float viewing_cos_limit, float th, int far_points, float th_far, float nnratio, int want_in_view);
 int orbm_search_local_points_fetch(orbx_extractor* h, int* assigned, int cap, int* nmatches, uint8_t* in_view);
 
+/* ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (src/ORBmatcher.cc:1950-2184, one camera) - the search of
+ * Tracking::TrackWithMotionModel - for a BATCH of frames on the device: current frames = images [first, first + B) of the handle's last
+ * extraction (mvKeysUn, mDescriptors, mvuRight as in orbm_search_local_points_batch); cur[b] = pose, camera, bounds, mbf and scale factors of
+ * current frame b; `last` = per frame the map points of ITS last frame, cap_last rows per frame: world position, valid
+ * (mvpMapPoints[i] != NULL && !mvbOutlier[i]), octave and angle of the last frame's keypoint i, Observations() > 0, descriptor.
+ * forward / backward: [B] bytes, bForward / bBackward of each pair of poses (:1973-1975).  Projection, image test, level window, window search,
+ * right-coordinate gate, Hamming distances, the sequential accept loop and the rotation histogram with its three maxima all run on the
+ * device.  Asynchronous; orbm_search_local_points_fetch returns assigned [B][cap] (index into the last frame's points, -1 untouched, -2 reset
+ * to NULL by the rotation check) and the return value per frame. */
+typedef struct OrbmLastFrameBatch {
+    int cap_last;                          /* rows per frame in the arrays below */
+    const int* n;                          /* [B] LastFrame.N */
+    const float* pos;                      /* [B][cap_last][3] pMP->GetWorldPos() */
+    const uint8_t* valid;                  /* [B][cap_last] */
+    const int* octave;                     /* [B][cap_last] */
+    const float* angle;                    /* [B][cap_last] */
+    const uint8_t* has_obs;                /* [B][cap_last] (NULL = all observed) */
+    const uint8_t* desc;                   /* [B][cap_last][32] */
+} OrbmLastFrameBatch;
+int orbm_search_by_projection_lastframe_batch(orbx_extractor* h, int first, int B, const OrbmFrustumView* cur, const OrbmLastFrameBatch* last,
+                                              float th, const uint8_t* forward, const uint8_t* backward, int check_orientation,
+                                              const uint8_t* occupied, int use_u_right);
+
 /* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBmatcher.cc:1950-2184).
  * forward/backward = bForward/bBackward (:1973-1975, computed from the two poses by the caller).
  * assigned[i] = index into LastFrame of the point written to CurrentFrame.mvpMapPoints[i]; -1 untouched;

@@ -377,6 +377,42 @@ __global__ void __launch_bounds__(256) k_project_points(ProjectParams P, int M, 
     out[i] = u; out[Ms + i] = v; out[2 * Ms + i] = ur; out[3 * Ms + i] = invz; out[4 * Ms + i] = dist;
 }
 
+// The head of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (src/ORBmatcher.cc:1970-2023) for a batch of frames: map point
+// i of frame b's last frame -> camera (Tcw * x3Dw), 1 / z < 0 rejects, projection, the Frame's image test, radius = th * mvScaleFactors[octave
+// of the LAST frame's keypoint], the level window by bForward / bBackward, ur = u - mbf / z for the right-coordinate gate.  grid (capL / 256, B).
+__global__ void __launch_bounds__(256) k_lastframe_queries(const FrustumParams* __restrict__ Fb, int capL, const int* __restrict__ n_last, const float* __restrict__ pos,
+                                                           const uint8_t* __restrict__ valid, const int* __restrict__ octave, AreaQuery* __restrict__ queries,
+                                                           int* __restrict__ zero4) {
+    const size_t b = blockIdx.y;
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (zero4 && i < 4 && b == 0) zero4[i] = 0;
+    if (i >= capL) return;
+    const FrustumParams F = Fb[b];
+    const size_t o = b * (size_t)capL + i;
+    AreaQuery q; q.x = 0; q.y = 0; q.r = 0; q.ur = 0; q.min_level = 0; q.max_level = 0; q.active = 0; q.gate = 0;
+    if (i < n_last[b] && valid[o]) {
+        const float P0 = pos[3 * o], P1 = pos[3 * o + 1], P2 = pos[3 * o + 2];
+        const float x = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(F.Rcw[0], P0), __fmul_rn(F.Rcw[1], P1)), __fmul_rn(F.Rcw[2], P2)), F.tcw[0]);
+        const float y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(F.Rcw[3], P0), __fmul_rn(F.Rcw[4], P1)), __fmul_rn(F.Rcw[5], P2)), F.tcw[1]);
+        const float z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(F.Rcw[6], P0), __fmul_rn(F.Rcw[7], P1)), __fmul_rn(F.Rcw[8], P2)), F.tcw[2]);
+        const float invz = __fdiv_rn(1.0f, z);
+        const int oct = octave[o];
+        if (!(invz < 0.0f) && oct >= 0 && oct < F.nlevels) {
+            float u, v;
+            if (F.kb8) { KB8Cam c; for (int k = 0; k < 8; k++) c.p[k] = F.cam[k]; const float pc[3] = {x, y, z}; float uv[2]; kb8_project(c, pc, uv); u = uv[0]; v = uv[1]; }
+            else { u = __fadd_rn(__fdiv_rn(__fmul_rn(F.cam[0], x), z), F.cam[2]); v = __fadd_rn(__fdiv_rn(__fmul_rn(F.cam[1], y), z), F.cam[3]); }
+            if (!(u < F.min_x || u > F.max_x || v < F.min_y || v > F.max_y)) {
+                q.x = u; q.y = v; q.r = __fmul_rn(F.th, F.scale_factors[oct]); q.ur = __fsub_rn(u, __fmul_rn(F.mbf, invz));
+                if (F.forward) { q.min_level = oct; q.max_level = -1; }
+                else if (F.backward) { q.min_level = 0; q.max_level = oct; }
+                else { q.min_level = oct - 1; q.max_level = oct + 1; }
+                q.active = 1; q.gate = 1;
+            }
+        }
+    }
+    queries[o] = q;
+}
+
 // The window search of a BATCH of frames, one THREAD per query (k_area_search spends a wave on a query: right for one frame's few thousand
 // queries, which must finish in microseconds; a batch has hundreds of thousands and wants throughput).  A thread walks its window cells in the
 // reference's order (ix-major, iy-minor, items in insertion order), counts, the workgroup reserves its span of the entry pool with one
@@ -386,12 +422,14 @@ __global__ void __launch_bounds__(256) k_area_search_threads(const AreaQuery* __
                                                              const KeyPointRec* __restrict__ kps, const float* __restrict__ u_right,
                                                              const unsigned long long* __restrict__ fdesc, GridParams g, const int* __restrict__ cell_start,
                                                              const int* __restrict__ cell_items, int gate_right, int* __restrict__ pool_counter, int pool_cap,
-                                                             int* __restrict__ q_start, int* __restrict__ q_count, int2* __restrict__ entries, int frame_stride) {
+                                                             int* __restrict__ q_start, int* __restrict__ q_count, int2* __restrict__ entries, int frame_stride,
+                                                             int qdesc_per_frame) {
     __shared__ int s_scan[20];
     __shared__ int s_base;
     const size_t b = blockIdx.y;
     const int q = (int)(blockIdx.x * 256 + threadIdx.x);
     queries += b * (size_t)Q; q_start += b * (size_t)Q; q_count += b * (size_t)Q;
+    if (qdesc_per_frame) qdesc += 4 * b * (size_t)Q;               // every frame brings its own query descriptors (the map points of ITS last frame)
     kps += b * (size_t)frame_stride; u_right += b * (size_t)frame_stride; fdesc += 4 * b * (size_t)frame_stride;
     cell_start += b * (size_t)kGridCellStride; cell_items += b * (size_t)frame_stride;
     AreaQuery A{};
@@ -453,18 +491,26 @@ __global__ void __launch_bounds__(256) k_area_search_threads(const AreaQuery* __
 // the map point index (the sequential last writer is the largest index).
 // occupied0: [B][cap] bytes or NULL; has_obs: [M] or NULL (all observed).  assigned: [B][cap], -1 = untouched; nmatches: [B].
 // dynamic LDS: occupancy bitmap ((cap + 31) / 32 words) | claiming lane per keypoint (cap words).
-__global__ void __launch_bounds__(64) k_local_accept(int M, int cap, const int* __restrict__ n_per_frame, const int* __restrict__ q_start,
-                                                     const int* __restrict__ q_count, const int2* __restrict__ entries, const uint8_t* __restrict__ occupied0,
-                                                     const uint8_t* __restrict__ has_obs, float nnratio, int th_high, int* __restrict__ assigned,
-                                                     int* __restrict__ nmatches) {
+// LASTFRAME = the accept loop of SearchByProjection(CurrentFrame, LastFrame) (src/ORBmatcher.cc:2025-2150): the best candidate alone decides
+// (bestDist <= TH_HIGH, no ratio test), has_obs / the query arrays are per frame, and every accepted pair goes into the rotation histogram
+// (:2118-2126, ComputeThreeMaxima :2335-2377): after the loop the pairs outside the three fullest bins are taken back (assigned = -2 = reset to
+// NULL, nmatches--) - per accept EVENT, as the reference's rotHist lists are (a keypoint that was given twice has two entries).
+template <bool LASTFRAME>
+__device__ __forceinline__ void local_accept_body(int M, int cap, const int* __restrict__ n_per_frame, const int* __restrict__ q_start,
+                                                  const int* __restrict__ q_count, const int2* __restrict__ entries, const uint8_t* __restrict__ occupied0,
+                                                  const uint8_t* __restrict__ has_obs, float nnratio, int th_high, int* __restrict__ assigned,
+                                                  int* __restrict__ nmatches, const float* __restrict__ last_angle, const KeyPointRec* __restrict__ cur_kps,
+                                                  int check_ori, int* __restrict__ events) {
     ORBX_DYN_SMEM(smem);
     const int nwords = (cap + 31) / 32;
     uint32_t* s_occ = (uint32_t*)smem;
     unsigned* s_claim = (unsigned*)(smem + 4 * (size_t)nwords);
+    __shared__ int s_hist[32];
     const int lane = lane_id();
     const size_t b = blockIdx.x;
     const int N = n_per_frame[b];
     q_start += b * (size_t)M; q_count += b * (size_t)M; assigned += b * (size_t)cap;
+    if (LASTFRAME) { if (has_obs) has_obs += b * (size_t)M; last_angle += b * (size_t)M; cur_kps += b * (size_t)cap; events += b * (size_t)M; if (lane < 32) s_hist[lane] = 0; }
     for (int w = lane; w < nwords; w += 64) {
         uint32_t bits = 0;
         if (occupied0) for (int k = 0; k < 32; k++) { const int i = 32 * w + k; if (i < N && occupied0[b * (size_t)cap + i]) bits |= 1u << k; }
@@ -478,6 +524,7 @@ __global__ void __launch_bounds__(64) k_local_accept(int M, int cap, const int* 
         const int cnt = qi < M ? q_count[qi] : 0, st = qi < M ? q_start[qi] : 0;
         const bool obs = qi < M && (!has_obs || has_obs[qi]);
         bool pending = cnt > 0;
+        if (LASTFRAME && qi < M) events[qi] = -1;
         while (__ballot(pending) != 0ull) {
             // 1. decision against the current occupancy
             unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu; int e1 = 0, e2 = 0, idx1 = -1;      // keys (dist << 16 | position), packed dist | level << 16 of both, index of the best
@@ -494,8 +541,8 @@ __global__ void __launch_bounds__(64) k_local_accept(int M, int cap, const int* 
                 const int bestDist = e1 & 0xFFFF, bestLevel = e1 >> 16;
                 int bestDist2 = 256, bestLevel2 = -1;
                 if (k2 != 0xFFFFFFFFu) { bestDist2 = e2 & 0xFFFF; bestLevel2 = e2 >> 16; }
-                // :146-166  bestDist <= TH_HIGH, and not (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2)
-                accept = bestDist <= th_high && !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2));
+                // :146-166  bestDist <= TH_HIGH, and not (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2);  LastFrame (:2103): bestDist <= TH_HIGH
+                accept = bestDist <= th_high && (LASTFRAME || !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2)));
             }
             // 2. claims that occupy
             const bool claims = accept && obs;
@@ -519,13 +566,56 @@ __global__ void __launch_bounds__(64) k_local_accept(int M, int cap, const int* 
             if (commit && accept) {
                 atomicMax(&assigned[idx1], qi);
                 if (obs) atomicOr(&s_occ[idx1 >> 5], 1u << (idx1 & 31));
+                if (LASTFRAME && check_ori) {                          // rot = angle(last) - angle(current), bin = round(rot / 30) (:2118-2125, the reference's 1 / HISTO_LENGTH factor)
+                    float rot = __fsub_rn(last_angle[qi], cur_kps[idx1].angle);
+                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                    int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+                    if (bin == 30) bin = 0;
+                    atomicAdd(&s_hist[bin & 31], 1);
+                    events[qi] = idx1 | (bin << 16);
+                }
             }
             nm += __popcll(__ballot(commit && accept));
             if (commit) pending = false;
             ORBX_WAVE_SYNC();
         }
     }
+    if (LASTFRAME && check_ori) {
+        ORBX_WAVE_SYNC();
+        // ComputeThreeMaxima (src/ORBmatcher.cc:2335-2377) over the 30 bin sizes, every lane alike
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < 30; i++) {
+            const int sz = s_hist[i];
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) ind3 = -1;
+        int taken_back = 0;
+        for (int qi = lane; qi < M; qi += 64) {
+            const int ev = events[qi];
+            if (ev < 0) continue;
+            const int bin = ev >> 16;
+            if (bin != ind1 && bin != ind2 && bin != ind3) { assigned[ev & 0xFFFF] = -2; taken_back++; }
+        }
+        nm -= wave_sum(taken_back);
+    }
     if (lane == 0) nmatches[b] = nm;
+}
+
+__global__ void __launch_bounds__(64) k_local_accept(int M, int cap, const int* __restrict__ n_per_frame, const int* __restrict__ q_start,
+                                                     const int* __restrict__ q_count, const int2* __restrict__ entries, const uint8_t* __restrict__ occupied0,
+                                                     const uint8_t* __restrict__ has_obs, float nnratio, int th_high, int* __restrict__ assigned,
+                                                     int* __restrict__ nmatches) {
+    local_accept_body<false>(M, cap, n_per_frame, q_start, q_count, entries, occupied0, has_obs, nnratio, th_high, assigned, nmatches, nullptr, nullptr, 0, nullptr);
+}
+__global__ void __launch_bounds__(64) k_lastframe_accept(int M, int cap, const int* __restrict__ n_per_frame, const int* __restrict__ q_start,
+                                                         const int* __restrict__ q_count, const int2* __restrict__ entries, const uint8_t* __restrict__ occupied0,
+                                                         const uint8_t* __restrict__ has_obs, int th_high, int* __restrict__ assigned, int* __restrict__ nmatches,
+                                                         const float* __restrict__ last_angle, const KeyPointRec* __restrict__ cur_kps, int check_ori,
+                                                         int* __restrict__ events) {
+    local_accept_body<true>(M, cap, n_per_frame, q_start, q_count, entries, occupied0, has_obs, 0.0f, th_high, assigned, nmatches, last_angle, cur_kps, check_ori, events);
 }
 
 // Frame::ComputeStereoFromRGBD (src/Frame.cc:1361-1391) for B frames: mvDepth[i] = imDepth.at<float>(v, u) at the (distorted) keypoint, truncated

@@ -626,7 +626,7 @@ int orbm_search_local_points_batch(orbx_extractor* h, int first, int B, const Or
                     dp + o_view, (float*)(dp + o_trk), (int*)(dp + o_lvl), (AreaQuery*)(dp + o_q), d_counter, (const FrustumParams*)(dp + u_f));
         dim3 grida((M + 255) / 256, B, 1);
         ORBX_LAUNCH(k_area_search_threads, grida, blk, 0, h->s0, (const AreaQuery*)(dp + o_q), points->desc, M, kps, ur, fdesc, g, (const int*)(dp + o_cst), (const int*)(dp + o_cit), 1,
-                    d_counter, (int)pool, (int*)(dp + o_qs), (int*)(dp + o_qc), (int2*)(dp + o_pool), cap);
+                    d_counter, (int)pool, (int*)(dp + o_qs), (int*)(dp + o_qc), (int2*)(dp + o_pool), cap, 0);
     } else rt::memset_async(d_counter, 0, 16, h->s0);
     {
         dim3 grid(B, 1, 1), blk(64, 1, 1);
@@ -638,6 +638,91 @@ int orbm_search_local_points_batch(orbx_extractor* h, int first, int B, const Or
     if (h->profile) rt::event_record(h->ev_stage[ST_MATCH][1], h->s0);
     if (rt::check_launch()) return fail(ORBX_E_DEVICE, "kernel launch failed: %s", rt::last_error());
     h->lp_B = B; h->lp_M = M; h->lp_first = first; h->lp_o_counter = o_res; h->lp_o_view = o_view; h->lp_want_view = want_in_view != 0;
+    return ORBX_OK;
+}
+
+int orbm_search_by_projection_lastframe_batch(orbx_extractor* h, int first, int B, const OrbmFrustumView* cur, const OrbmLastFrameBatch* last, float th,
+                                              const uint8_t* forward, const uint8_t* backward, int check_ori, const uint8_t* occupied, int use_u_right) {
+    if (!h || !cur || !last || B <= 0 || first < 0 || first + B > h->lastB) return fail(ORBX_E_ARG, "bad frame range / null");
+    const int M = last->cap_last;
+    if (M <= 0 || !last->n || !last->pos || !last->valid || !last->octave || !last->angle || !last->desc) return fail(ORBX_E_ARG, "bad last-frame batch");
+    for (int b = 0; b < B; b++) {
+        if (cur[b].nlevels < 1 || cur[b].nlevels > kMaxLevels || !cur[b].scale_factors) return fail(ORBX_E_ARG, "bad scale levels (frame %d)", b);
+        if (cur[b].min_x != cur[0].min_x || cur[b].max_x != cur[0].max_x || cur[b].min_y != cur[0].min_y || cur[b].max_y != cur[0].max_y)
+            return fail(ORBX_E_ARG, "frame %d has other image bounds than frame 0", b);
+        if (last->n[b] < 0 || last->n[b] > M) return fail(ORBX_E_ARG, "last frame %d: %d points in %d rows", b, last->n[b], M);
+    }
+    if (!(cur[0].max_x > cur[0].min_x) || !(cur[0].max_y > cur[0].min_y)) return fail(ORBX_E_ARG, "empty image bounds");
+    rt::set_device(h->device);
+    const int cap = h->kp_total_cap;
+    const size_t B1 = B, M1 = M, C1 = cap;
+    if (h->lp_pending) rt::event_sync(h->ev_lp);
+    // upload block: poses | n_last | pos | valid | octave | angle | has_obs | descriptors | occupancy
+    const size_t u_f = 0, u_n = u_f + al16(sizeof(FrustumParams) * B1), u_pos = u_n + al16(4 * B1), u_val = u_pos + al16(12 * B1 * M1), u_oct = u_val + al16(B1 * M1),
+                 u_ang = u_oct + al16(4 * B1 * M1), u_obs = u_ang + al16(4 * B1 * M1), u_desc = u_obs + al16(B1 * M1), u_occ = u_desc + al16(32 * B1 * M1),
+                 u_total = u_occ + (occupied ? al16(B1 * C1) : 0);
+    size_t o = al16(u_total);
+    const size_t o_ur = o; o += use_u_right ? 0 : al16(4 * B1 * C1);
+    const size_t o_cof = o; o += al16(4 * B1 * C1);
+    const size_t o_cst = o; o += al16(4 * B1 * kGridCellStride);
+    const size_t o_cit = o; o += al16(4 * B1 * C1);
+    const size_t o_q = o; o += al16(sizeof(AreaQuery) * B1 * M1);
+    const size_t o_ev = o; o += al16(4 * B1 * M1);
+    const size_t o_qs = o; o += al16(4 * B1 * M1);
+    const size_t o_qc = o; o += al16(4 * B1 * M1);
+    const size_t o_res = o; const size_t res_bytes = 16 + al16(4 * B1) + 4 * B1 * C1; o += al16(res_bytes);
+    const size_t o_pool = o;
+    size_t pool = std::max<size_t>(h->lp_pool, B1 * M1 * 16 + 4096);           // th = 7 .. 15 px windows: a dozen candidates per point
+    if (pool > 0x7fffffff / 2) pool = 0x7fffffff / 2;
+    if (h->d_lp.ensure(o_pool + pool * 8 + 64) || h->h_lp_in.ensure(u_total + 16) || h->h_lp_out.ensure(al16(res_bytes) + 64))
+        return fail(ORBX_E_DEVICE, "allocation failed (batched last-frame search, %d frames x %d points)", B, M);
+    h->lp_pool = pool;
+    uint8_t* hp = h->h_lp_in.p; uint8_t* dp = h->d_lp.p;
+    FrustumParams* Fp = (FrustumParams*)(hp + u_f);
+    for (int b = 0; b < B; b++) {
+        fill_frustum_params(&cur[b], 0.0f, th, 0, 0.0f, &Fp[b]);
+        Fp[b].forward = forward ? forward[b] != 0 : 0; Fp[b].backward = backward ? backward[b] != 0 : 0;
+    }
+    memcpy(hp + u_n, last->n, 4 * B1); memcpy(hp + u_pos, last->pos, 12 * B1 * M1); memcpy(hp + u_val, last->valid, B1 * M1); memcpy(hp + u_oct, last->octave, 4 * B1 * M1);
+    memcpy(hp + u_ang, last->angle, 4 * B1 * M1);
+    if (last->has_obs) memcpy(hp + u_obs, last->has_obs, B1 * M1); else memset(hp + u_obs, 1, B1 * M1);
+    memcpy(hp + u_desc, last->desc, 32 * B1 * M1);
+    if (occupied) memcpy(hp + u_occ, occupied, B1 * C1);
+    if (rt::copy_h2d(dp, hp, u_total, h->s0) || rt::event_record(h->ev_lp, h->s0)) return fail(ORBX_E_DEVICE, "upload failed: %s", rt::last_error());
+    h->lp_pending = true;
+    const KeyPointRec* kps = (h->undist.active ? h->d_kps_un.p : h->d_kps.p) + (size_t)first * cap;
+    const unsigned long long* fdesc = h->d_desc.p + (size_t)first * cap * 4;
+    const int* nper = h->d_nm.p + first;
+    const float* ur = h->d_uRight.p;
+    if (!use_u_right) { rt::memset_async(dp + o_ur, 0xBF, 4 * B1 * C1, h->s0); ur = (const float*)(dp + o_ur); }
+    GridParams g; memset(&g, 0, sizeof g);
+    g.min_x = cur[0].min_x; g.min_y = cur[0].min_y;
+    g.gw_inv = (float)kGridColsHost / (cur[0].max_x - cur[0].min_x); g.gh_inv = (float)kGridRowsHost / (cur[0].max_y - cur[0].min_y);
+    int* d_counter = (int*)(dp + o_res); int* d_nmatch = (int*)(dp + o_res + 16); int* d_assigned = (int*)(dp + o_res + 16 + al16(4 * B1));
+    if (h->profile) rt::event_record(h->ev_stage[ST_MATCH][0], h->s0);
+    const dim3 blk(256, 1, 1);
+    {
+        dim3 grid(B, 1, 1), blkg(kGridThreads, 1, 1);
+        ORBX_LAUNCH(k_grid_build, grid, blkg, 0, h->s0, kps, 0, g, (int*)(dp + o_cof), (int*)(dp + o_cst), (int*)(dp + o_cit), nper, cap);
+    }
+    {
+        dim3 grid((M + 255) / 256, B, 1);
+        ORBX_LAUNCH(k_lastframe_queries, grid, blk, 0, h->s0, (const FrustumParams*)(dp + u_f), M, (const int*)(dp + u_n), (const float*)(dp + u_pos), (const uint8_t*)(dp + u_val),
+                    (const int*)(dp + u_oct), (AreaQuery*)(dp + o_q), d_counter);
+        ORBX_LAUNCH(k_area_search_threads, grid, blk, 0, h->s0, (const AreaQuery*)(dp + o_q), (const unsigned long long*)(dp + u_desc), M, kps, ur, fdesc, g, (const int*)(dp + o_cst),
+                    (const int*)(dp + o_cit), 1, d_counter, (int)pool, (int*)(dp + o_qs), (int*)(dp + o_qc), (int2*)(dp + o_pool), cap, 1);
+    }
+    {
+        dim3 grid(B, 1, 1), blka(64, 1, 1);
+        const size_t smem = 4 * (size_t)((cap + 31) / 32) + 4 * (size_t)cap + 64;
+        if (smem + 1024 > rt::lds_limit(h->device)) return fail(ORBX_E_CAPACITY, "%d keypoints per frame need %zu bytes of LDS in the accept kernel", cap, smem);
+        ORBX_LAUNCH(k_lastframe_accept, grid, blka, smem, h->s0, M, cap, nper, (const int*)(dp + o_qs), (const int*)(dp + o_qc), (const int2*)(dp + o_pool),
+                    occupied ? (const uint8_t*)(dp + u_occ) : (const uint8_t*)nullptr, (const uint8_t*)(dp + u_obs), TH_HIGH, d_assigned, d_nmatch,
+                    (const float*)(dp + u_ang), kps, check_ori, (int*)(dp + o_ev));
+    }
+    if (h->profile) rt::event_record(h->ev_stage[ST_MATCH][1], h->s0);
+    if (rt::check_launch()) return fail(ORBX_E_DEVICE, "kernel launch failed: %s", rt::last_error());
+    h->lp_B = B; h->lp_M = M; h->lp_first = first; h->lp_o_counter = o_res; h->lp_o_view = 0; h->lp_want_view = false;
     return ORBX_OK;
 }
 

@@ -72,6 +72,7 @@ struct FrustumParams {                                            // what Frame:
     // SearchByProjection(Frame, MapPoints) query parameters when the queries are produced on the device
     float th, th_far; int far_points;
     int rig_mode;                                                 // Frame::isInFrustumChecks: store nothing unless every test passes, level -1 when rejected
+    int forward, backward;                                        // SearchByProjection(Frame, LastFrame): bForward / bBackward (k_lastframe_queries)
 };
 // orbm_project_points: the geometry in front of GetFeaturesInArea in the projection-type searches (ORBmatcher.cc:495-732, :1325-1675, :1689-1932,
 // :1950-2030, :2196-2260) - see OrbmProjection in include/orbx.h (same fields)

@@ -311,6 +311,95 @@ def SearchLocalPointsRig(ext, frame2, pose, cam1, cam2, bounds, scale_factors, p
     return cut(tl), cut(tr), assigned[:N], n.value
 
 
+class _Projection(C.Structure):
+    _fields_ = [("R", C.c_float * 9), ("t", C.c_float * 3), ("has_sim3", C.c_int), ("R2", C.c_float * 9), ("t2", C.c_float * 3), ("s2", C.c_float), ("Ow", C.c_float * 3),
+                ("dist_mode", C.c_int), ("depth_test", C.c_int), ("camera_type", C.c_int), ("cam", C.c_float * 8), ("inline_pinhole", C.c_int), ("min_x", C.c_float),
+                ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float), ("bounds_mode", C.c_int), ("distance_test", C.c_int), ("angle_test", C.c_int), ("bf", C.c_float)]
+
+
+class _ProjectIn(C.Structure):
+    _fields_ = [("M", C.c_int), ("pos", C.c_void_p), ("normal", C.c_void_p), ("min_inv", C.c_void_p), ("max_inv", C.c_void_p), ("skip", C.c_void_p)]
+
+
+class _ProjectOut(C.Structure):
+    _fields_ = [("valid", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("ur", C.c_void_p), ("inv_z", C.c_void_p), ("dist", C.c_void_p)]
+
+
+def ProjectPoints(ext, R, t, cam, bounds, pos, normal=None, min_inv=None, max_inv=None, skip=None, Ow=None, sim3=None, depth_test=1, bounds_mode=0, inline_pinhole=False,
+                  dist_mode=0, angle_test=False, bf=0.0):
+    """orbm_project_points: the geometry in front of the projection-type searches (transform, depth test, projection, image test, distance
+    range, viewing angle) for M map points on the device.  sim3 = (R2, t2, s2) appends a similarity behind the pose (SearchBySim3).
+    Returns dict(valid, u, v, ur, inv_z, dist)."""
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    pos = f32(pos).reshape(-1, 3); M = len(pos)
+    S = _Projection()
+    S.R[:] = f32(R).ravel().tolist(); S.t[:] = f32(t).tolist()
+    if sim3 is not None:
+        S.has_sim3 = 1; S.R2[:] = f32(sim3[0]).ravel().tolist(); S.t2[:] = f32(sim3[1]).tolist(); S.s2 = float(sim3[2])
+    if Ow is not None:
+        S.Ow[:] = f32(Ow).tolist()
+    cam = [float(v) for v in cam]
+    S.camera_type = 1 if len(cam) == 8 else 0; S.cam[:] = cam + [0.0] * (8 - len(cam)); S.inline_pinhole = int(inline_pinhole)
+    S.min_x, S.max_x, S.min_y, S.max_y = [float(v) for v in bounds]
+    S.dist_mode, S.depth_test, S.bounds_mode, S.angle_test, S.bf = int(dist_mode), int(depth_test), int(bounds_mode), int(angle_test), float(bf)
+    S.distance_test = int(min_inv is not None and max_inv is not None)
+    keep = [pos] + [None if a is None else (f32(a) if i < 3 else np.ascontiguousarray(a, np.uint8)) for i, a in enumerate((normal, min_inv, max_inv, skip))]
+    ptr = lambda a: None if a is None else a.ctypes.data
+    I = _ProjectIn(M, ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), ptr(keep[4]))
+    M1 = max(M, 1)
+    out = dict(valid=np.zeros(M1, np.uint8), u=np.zeros(M1, np.float32), v=np.zeros(M1, np.float32), ur=np.zeros(M1, np.float32), inv_z=np.zeros(M1, np.float32),
+               dist=np.zeros(M1, np.float32))
+    O = _ProjectOut(*[out[k].ctypes.data for k in ("valid", "u", "v", "ur", "inv_z", "dist")])
+    ext._lib.check(ext._lib.L.orbm_project_points(ext._h, C.byref(S), C.byref(I), C.byref(O)))
+    return {k: v[:M] for k, v in out.items()}
+
+
+class _LastFrameBatch(C.Structure):
+    _fields_ = [("cap_last", C.c_int), ("n", C.c_void_p), ("pos", C.c_void_p), ("valid", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p), ("has_obs", C.c_void_p),
+                ("desc", C.c_void_p)]
+
+
+class LastFrameBatch:
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) for a batch of frames on the device
+    (orbm_search_by_projection_lastframe_batch): current frames = images [first, first + B) of ext's last extraction; per frame the map points
+    of its last frame.  enqueue() is asynchronous, fetch() returns (assigned [B, cap], nmatches [B])."""
+
+    def __init__(self, ext, B, cam, bounds, mbf, scale_factors):
+        self.ext, self.B = ext, B
+        self.cam, self.bounds, self.mbf = cam, bounds, mbf
+        self.sf = np.ascontiguousarray(scale_factors, np.float32)
+        self.views = (_FrustumView * B)()
+        self.cap = ext.max_keypoints()
+        self.assigned = np.full((B, self.cap), -1, np.int32); self.nm = np.zeros(B, np.int32)
+
+    def set_poses(self, poses):
+        for b, (R, t) in enumerate(poses):
+            frustum_view(R, t, self.cam, self.bounds, self.mbf, self.sf, into=self.views[b])
+            self.views[b].scale_factors = self.sf.ctypes.data
+
+    def enqueue(self, n, pos, valid, octave, angle, has_obs, desc, th, forward=None, backward=None, check_orientation=True, occupied=None, use_u_right=True, first=0):
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        u8 = lambda a: None if a is None else np.ascontiguousarray(a, np.uint8)
+        self._again = lambda: self.enqueue(n, pos, valid, octave, angle, has_obs, desc, th, forward, backward, check_orientation, occupied, use_u_right, first)
+        pos = f32(pos); capL = pos.shape[1]
+        self._keep = (np.ascontiguousarray(n, np.int32), pos, u8(valid), np.ascontiguousarray(octave, np.int32), f32(angle), u8(has_obs), u8(desc), u8(forward), u8(backward), u8(occupied))
+        k = self._keep
+        ptr = lambda a: None if a is None else a.ctypes.data
+        lb = _LastFrameBatch(capL, ptr(k[0]), ptr(k[1]), ptr(k[2]), ptr(k[3]), ptr(k[4]), ptr(k[5]), ptr(k[6]))
+        L = self.ext._lib
+        L.check(L.L.orbm_search_by_projection_lastframe_batch(self.ext._h, int(first), self.B, self.views, C.byref(lb), float(th), ptr(k[7]), ptr(k[8]), int(bool(check_orientation)),
+                                                              ptr(k[9]), int(bool(use_u_right))))
+
+    def fetch(self):
+        L = self.ext._lib
+        rc = L.L.orbm_search_local_points_fetch(self.ext._h, self.assigned.ctypes.data, self.cap, self.nm.ctypes.data, None)
+        if rc == -4:                 # ORBX_E_CAPACITY: pool enlarged, run the batch again
+            self._again()
+            rc = L.L.orbm_search_local_points_fetch(self.ext._h, self.assigned.ctypes.data, self.cap, self.nm.ctypes.data, None)
+        L.check(rc)
+        return self.assigned, self.nm
+
+
 class ResidentPoints:
     """orbm_points: position, normal, distance limits and descriptor of a set of map points, uploaded once (the local map)."""
 
@@ -402,6 +491,7 @@ class LocalPointsBatch:
                 want_in_view=False):
         L = self.ext._lib
         u8 = lambda a: None if a is None else np.ascontiguousarray(a, np.uint8)
+        self._again = lambda: self.enqueue(first, is_bad, has_obs, occupied, use_u_right, viewing_cos_limit, th, far_points, th_far, nnratio, want_in_view)
         self._keep = (u8(is_bad), u8(has_obs), u8(occupied))
         ptr = lambda a: None if a is None else a.ctypes.data
         self._want = bool(want_in_view)
@@ -410,7 +500,11 @@ class LocalPointsBatch:
 
     def fetch(self):
         L = self.ext._lib
-        L.check(L.L.orbm_search_local_points_fetch(self.ext._h, self.assigned.ctypes.data, self.cap, self.nm.ctypes.data, self.in_view.ctypes.data if self._want else None))
+        rc = L.L.orbm_search_local_points_fetch(self.ext._h, self.assigned.ctypes.data, self.cap, self.nm.ctypes.data, self.in_view.ctypes.data if self._want else None)
+        if rc == -4:                 # ORBX_E_CAPACITY: the candidate pool was too small for this scene and has been enlarged - run the batch again
+            self._again()
+            rc = L.L.orbm_search_local_points_fetch(self.ext._h, self.assigned.ctypes.data, self.cap, self.nm.ctypes.data, self.in_view.ctypes.data if self._want else None)
+        L.check(rc)
         return self.assigned, self.nm, (self.in_view if self._want else None)
 
 

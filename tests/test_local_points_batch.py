@@ -156,3 +156,37 @@ def test_local_points_many_frames_emulated(emu_lib):
 @pytest.mark.gpu
 def test_local_points_large_batch_gpu(hip_lib):
     _large_batch(hip_lib, 640, 480, 1000, 48, 5000, 12)
+
+
+def test_candidate_pool_overflow_is_retried(emu_lib):
+    """a search window so wide that the candidate pool of a fresh handle overflows: the fetch reports ORBX_E_CAPACITY once (the pool is enlarged),
+    the wrapper runs the batch again, and the results are those of the single-frame call"""
+    import ctypes as C
+    from orb_slam3_detailed_comments_amd import views
+    w, h, nf, npts = 320, 240, 300, 400
+    rng = np.random.default_rng(11)
+    imgs = np.stack([synth.corner_field(w, h, seed=40 + b, nrect=700) for b in range(2)])
+    ex = ORBextractor(nf, 1.2, 8, 20, 7, lib=emu_lib)
+    res = ex.extract_batch(imgs)
+    k, d = res[0][1], res[0][2]
+    src = rng.integers(0, len(k), npts); z = rng.uniform(1, 6, npts)
+    pos = np.stack([(k["x"][src] - CX) / FX * z, (k["y"][src] - CY) / FY * z, z], 1).astype(np.float32)
+    dn = np.linalg.norm(pos, axis=1); normal = (pos / dn[:, None]).astype(np.float32)
+    maxd = (dn * 1.2 ** k["octave"][src]).astype(np.float32); mind = (maxd / 1.2 ** 7).astype(np.float32)
+    desc = d[src].copy()
+    sfs = ex.GetScaleFactors(); cam, bounds = (FX, FY, CX, CY), (0.0, float(w), 0.0, float(h))
+    rp = M.ResidentPoints(ex, pos, normal, mind, maxd, desc)
+    lp = M.LocalPointsBatch(ex, rp, 2, cam, bounds, 0.0, sfs)
+    poses = [(np.eye(3, dtype=np.float32), np.zeros(3, np.float32))] * 2
+    lp.set_poses(poses)
+    lp.enqueue(0, use_u_right=False, th=30.0)
+    rc = emu_lib.L.orbm_search_local_points_fetch(ex._h, lp.assigned.ctypes.data, lp.cap, lp.nm.ctypes.data, None)
+    assert rc == -4                                         # ORBX_E_CAPACITY: tens of thousands of candidates against a pool sized for six per point
+    lp.enqueue(0, use_u_right=False, th=30.0)
+    asg, nm, _ = lp.fetch()
+    for b in range(2):
+        fv = views.frame_view(res[b][1], res[b][2], sfs, w, h)
+        _, ref_as, ref_n = M.SearchLocalPoints(ex, fv, poses[b][0], poses[b][1], cam, bounds, 0.0, sfs, pos, normal, mind, maxd, None, None, desc, 0.5, 30.0)
+        assert nm[b] == ref_n and np.array_equal(asg[b, :len(res[b][1])], ref_as)
+    assert nm[0] > 50
+    rp.close(); ex.close()
