@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 3, visit A: GPU parity of the dense FAST kernel, A/B against the round-2 kernel (build/variants), both workloads
+# round 3, visit A (produced profiles/r03/fast_dense_vs_list_ab.txt): GPU parity of the dense FAST kernel of DESIGN.md section 4c, A/B against the list kernel
+# (build/variants/liborbx_hip_prev.so = the list kernel, _new.so = the dense one), both workloads
 O=gpurun_out/r03a
 mkdir -p $O
 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
