@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(256) k_area_search_threads(const AreaQuery* __
 // F.mvpMapPoints[idx] = pMP without observations does not occupy; a later point may overwrite it: assignments are merged with atomicMax on
 // the map point index (the sequential last writer is the largest index).
 // occupied0: [B][cap] bytes or NULL; has_obs: [M] or NULL (all observed).  assigned: [B][cap], -1 = untouched; nmatches: [B].
-// dynamic LDS: occupancy bitmap ((cap + 31) / 32 words) | claiming lane per keypoint (cap words).
+// dynamic LDS: occupancy bitmap ((cap + 31) / 32 words) | claiming lane per keypoint (cap words) | LASTFRAME: one accept event per query (M words).
 // LASTFRAME = the accept loop of SearchByProjection(CurrentFrame, LastFrame) (src/ORBmatcher.cc:2025-2150): the best candidate alone decides
 // (bestDist <= TH_HIGH, no ratio test), has_obs / the query arrays are per frame, and every accepted pair goes into the rotation histogram
 // (:2118-2126, ComputeThreeMaxima :2335-2377): after the loop the pairs outside the three fullest bins are taken back (assigned = -2 = reset to
@@ -500,7 +500,8 @@ __device__ __forceinline__ void local_accept_body(int M, int cap, const int* __r
                                                   const int* __restrict__ q_count, const int2* __restrict__ entries, const uint8_t* __restrict__ occupied0,
                                                   const uint8_t* __restrict__ has_obs, float nnratio, int th_high, int* __restrict__ assigned,
                                                   int* __restrict__ nmatches, const float* __restrict__ last_angle, const KeyPointRec* __restrict__ cur_kps,
-                                                  int check_ori, int* __restrict__ events) {
+                                                  int check_ori) {
+    int* events = nullptr;
     ORBX_DYN_SMEM(smem);
     const int nwords = (cap + 31) / 32;
     uint32_t* s_occ = (uint32_t*)smem;
@@ -510,7 +511,12 @@ __device__ __forceinline__ void local_accept_body(int M, int cap, const int* __r
     const size_t b = blockIdx.x;
     const int N = n_per_frame[b];
     q_start += b * (size_t)M; q_count += b * (size_t)M; assigned += b * (size_t)cap;
-    if (LASTFRAME) { if (has_obs) has_obs += b * (size_t)M; last_angle += b * (size_t)M; cur_kps += b * (size_t)cap; events += b * (size_t)M; if (lane < 32) s_hist[lane] = 0; }
+    if (LASTFRAME) {
+        if (has_obs) has_obs += b * (size_t)M;
+        last_angle += b * (size_t)M; cur_kps += b * (size_t)cap;
+        events = (int*)(s_claim + cap);                               // in LDS: written and read by different lanes of this wave, in program order
+        if (lane < 32) s_hist[lane] = 0;
+    }
     for (int w = lane; w < nwords; w += 64) {
         uint32_t bits = 0;
         if (occupied0) for (int k = 0; k < 32; k++) { const int i = 32 * w + k; if (i < N && occupied0[b * (size_t)cap + i]) bits |= 1u << k; }
@@ -608,14 +614,13 @@ __global__ void __launch_bounds__(64) k_local_accept(int M, int cap, const int* 
                                                      const int* __restrict__ q_count, const int2* __restrict__ entries, const uint8_t* __restrict__ occupied0,
                                                      const uint8_t* __restrict__ has_obs, float nnratio, int th_high, int* __restrict__ assigned,
                                                      int* __restrict__ nmatches) {
-    local_accept_body<false>(M, cap, n_per_frame, q_start, q_count, entries, occupied0, has_obs, nnratio, th_high, assigned, nmatches, nullptr, nullptr, 0, nullptr);
+    local_accept_body<false>(M, cap, n_per_frame, q_start, q_count, entries, occupied0, has_obs, nnratio, th_high, assigned, nmatches, nullptr, nullptr, 0);
 }
 __global__ void __launch_bounds__(64) k_lastframe_accept(int M, int cap, const int* __restrict__ n_per_frame, const int* __restrict__ q_start,
                                                          const int* __restrict__ q_count, const int2* __restrict__ entries, const uint8_t* __restrict__ occupied0,
                                                          const uint8_t* __restrict__ has_obs, int th_high, int* __restrict__ assigned, int* __restrict__ nmatches,
-                                                         const float* __restrict__ last_angle, const KeyPointRec* __restrict__ cur_kps, int check_ori,
-                                                         int* __restrict__ events) {
-    local_accept_body<true>(M, cap, n_per_frame, q_start, q_count, entries, occupied0, has_obs, 0.0f, th_high, assigned, nmatches, last_angle, cur_kps, check_ori, events);
+                                                         const float* __restrict__ last_angle, const KeyPointRec* __restrict__ cur_kps, int check_ori) {
+    local_accept_body<true>(M, cap, n_per_frame, q_start, q_count, entries, occupied0, has_obs, 0.0f, th_high, assigned, nmatches, last_angle, cur_kps, check_ori);
 }
 
 // Frame::ComputeStereoFromRGBD (src/Frame.cc:1361-1391) for B frames: mvDepth[i] = imDepth.at<float>(v, u) at the (distorted) keypoint, truncated

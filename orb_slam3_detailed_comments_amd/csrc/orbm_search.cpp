@@ -667,7 +667,6 @@ int orbm_search_by_projection_lastframe_batch(orbx_extractor* h, int first, int 
     const size_t o_cst = o; o += al16(4 * B1 * kGridCellStride);
     const size_t o_cit = o; o += al16(4 * B1 * C1);
     const size_t o_q = o; o += al16(sizeof(AreaQuery) * B1 * M1);
-    const size_t o_ev = o; o += al16(4 * B1 * M1);
     const size_t o_qs = o; o += al16(4 * B1 * M1);
     const size_t o_qc = o; o += al16(4 * B1 * M1);
     const size_t o_res = o; const size_t res_bytes = 16 + al16(4 * B1) + 4 * B1 * C1; o += al16(res_bytes);
@@ -714,11 +713,11 @@ int orbm_search_by_projection_lastframe_batch(orbx_extractor* h, int first, int 
     }
     {
         dim3 grid(B, 1, 1), blka(64, 1, 1);
-        const size_t smem = 4 * (size_t)((cap + 31) / 32) + 4 * (size_t)cap + 64;
+        const size_t smem = 4 * (size_t)((cap + 31) / 32) + 4 * (size_t)cap + 4 * (size_t)M + 64;
         if (smem + 1024 > rt::lds_limit(h->device)) return fail(ORBX_E_CAPACITY, "%d keypoints per frame need %zu bytes of LDS in the accept kernel", cap, smem);
         ORBX_LAUNCH(k_lastframe_accept, grid, blka, smem, h->s0, M, cap, nper, (const int*)(dp + o_qs), (const int*)(dp + o_qc), (const int2*)(dp + o_pool),
                     occupied ? (const uint8_t*)(dp + u_occ) : (const uint8_t*)nullptr, (const uint8_t*)(dp + u_obs), TH_HIGH, d_assigned, d_nmatch,
-                    (const float*)(dp + u_ang), kps, check_ori, (int*)(dp + o_ev));
+                    (const float*)(dp + u_ang), kps, check_ori);
     }
     if (h->profile) rt::event_record(h->ev_stage[ST_MATCH][1], h->s0);
     if (rt::check_launch()) return fail(ORBX_E_DEVICE, "kernel launch failed: %s", rt::last_error());

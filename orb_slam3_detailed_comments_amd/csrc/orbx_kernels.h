@@ -104,7 +104,7 @@ __global__ void k_lastframe_queries(const FrustumParams* __restrict__ Fb, int ca
 __global__ void k_lastframe_accept(int M, int cap, const int* __restrict__ n_per_frame, const int* __restrict__ q_start, const int* __restrict__ q_count,
                                    const int2* __restrict__ entries, const uint8_t* __restrict__ occupied0, const uint8_t* __restrict__ has_obs, int th_high,
                                    int* __restrict__ assigned, int* __restrict__ nmatches, const float* __restrict__ last_angle,
-                                   const KeyPointRec* __restrict__ cur_kps, int check_ori, int* __restrict__ events);
+                                   const KeyPointRec* __restrict__ cur_kps, int check_ori);
 __global__ void k_local_accept(int M, int cap, const int* __restrict__ n_per_frame, const int* __restrict__ q_start, const int* __restrict__ q_count,
                                const int2* __restrict__ entries, const uint8_t* __restrict__ occupied0, const uint8_t* __restrict__ has_obs, float nnratio,
                                int th_high, int* __restrict__ assigned, int* __restrict__ nmatches);

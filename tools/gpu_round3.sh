@@ -14,6 +14,7 @@ for c in mono fisheye rgbd; do python bench.py --config $c --steps 60 --warmup 6
 python tests/gpu_quick.py > $O/serial_stage_times_and_parity.log 2>&1; grep -E "PARITY|^B |single" $O/serial_stage_times_and_parity.log
 python tools/bench_next_rows.py > $O/next_rows.json 2> $O/next_rows.err; tail -2 $O/next_rows.err
 python tools/soak_reference.py 4 300 > $O/soak_vs_reference.txt 2>&1; tail -2 $O/soak_vs_reference.txt
+python tools/soak_round3.py 12 > $O/soak_round3.txt 2>&1; tail -5 $O/soak_round3.txt
 export TMPDIR=/tmp
 PROF="--steps 12 --warmup 3 --no-cpu-baseline --no-h2d --min-seconds 0"
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_trace -o trace -- python $R/bench.py $PROF > $R/$O/prof_trace.log 2>&1)
