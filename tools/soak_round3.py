@@ -21,7 +21,7 @@ t_rig._check(lib, tuple(range(200, 200 + n)), 5000)
 print("rig isInFrustum + rig SearchByProjection vs the reference rig Frame: %d frames x 5000 points x 2 settings, 0 differences" % n, flush=True)
 for i in range(max(1, n // 3)):
     for rgbd in (False, True):
-        t_batch._run(lib, [640, 752][i % 2], 480, [1000, 1200][i % 2], 3 + (i % 2), 3000 + 500 * i, rgbd)
+        t_batch._run(lib, [640, 752][i % 2], 480, [1000, 1200][i % 2], 3 - (i % 2), 3000 + 500 * i, rgbd)      # the helper has three poses
 print("batched SearchLocalPoints vs the reference Frame per frame: %d batches (stereo + RGB-D), 0 differences" % (2 * max(1, n // 3)), flush=True)
 for i in range(max(1, n // 4)):
     t_batch._large_batch(lib, 640, 480, 1000, 32 + 16 * (i % 2), 5000, 8 + i)
