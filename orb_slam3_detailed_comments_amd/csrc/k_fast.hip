@@ -174,10 +174,10 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
             }
             if (corners_listed) {
                 const bool cA = sA > 0, cB = hasB && sB > 0;
-                const unsigned long long balA = __ballot(cA), balB = __ballot(cB);
+                const unsigned long long balA = ORBX_BALLOT(cA), balB = ORBX_BALLOT(cB);
                 const int nA = __popcll(balA);
-                if (cA) list[nc + lanes_below(balA)] = (uint16_t)oA;
-                if (cB) list[nc + nA + lanes_below(balB)] = (uint16_t)oB;
+                if (ORBX_IN_BALLOT(balA)) list[nc + lanes_below(balA)] = (uint16_t)oA;
+                if (ORBX_IN_BALLOT(balB)) list[nc + nA + lanes_below(balB)] = (uint16_t)oB;
                 nc += nA + __popcll(balB);
             }
         }
@@ -241,11 +241,13 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
             bool pj[4], pdj[4];                                  // lane predicates, kept so that the appends run under the same masks
             int trip = 0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) { pj[j] = (ANY & (0x80u << (8 * j))) != 0u; bal[j] = __ballot(pj[j]); trip += __popcll(bal[j]); }
-            const bool dups = __ballot(BOTH != 0u) != 0ull;      // a pixel that passes for both polarities gets a second (dark) entry: rare
+            // (the appends below are guarded by ORBX_IN_BALLOT(bal[j]), not by pj[j]: the compiler tested every bit twice otherwise, as and + cmp for
+            // the branch and as bfe + cmp for the ballot)
+            for (int j = 0; j < 4; j++) { pj[j] = (ANY & (0x80u << (8 * j))) != 0u; bal[j] = ORBX_BALLOT(pj[j]); trip += __popcll(bal[j]); }
+            const bool dups = ORBX_BALLOT(BOTH != 0u) != 0ull;      // a pixel that passes for both polarities gets a second (dark) entry: rare
             if (dups) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) { pdj[j] = (BOTH & (0x80u << (8 * j))) != 0u; bald[j] = __ballot(pdj[j]); trip += __popcll(bald[j]); }
+                for (int j = 0; j < 4; j++) { pdj[j] = (BOTH & (0x80u << (8 * j))) != 0u; bald[j] = ORBX_BALLOT(pdj[j]); trip += __popcll(bald[j]); }
             }
             if (cnt + trip > list_cap) {                         // wave-uniform: score what is pending, then append behind the corners
                 score_pending();
@@ -254,13 +256,13 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
             const int toff = toff_lane + it0 * wp;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                if (pj[j]) list[cnt + lanes_below(bal[j])] = (uint16_t)((toff + j) | ((SB & (0x80u << (8 * j))) ? kEntBright : 0));
+                if (ORBX_IN_BALLOT(bal[j])) list[cnt + lanes_below(bal[j])] = (uint16_t)((toff + j) | ((SB & (0x80u << (8 * j))) ? kEntBright : 0));
                 cnt += __popcll(bal[j]);
             }
             if (dups) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    if (pdj[j]) list[cnt + lanes_below(bald[j])] = (uint16_t)(toff + j);
+                    if (ORBX_IN_BALLOT(bald[j])) list[cnt + lanes_below(bald[j])] = (uint16_t)(toff + j);
                     cnt += __popcll(bald[j]);
                 }
             }
@@ -294,7 +296,7 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
         ORBX_WAVE_SYNC();
         // ---- D ----  threshold choice of the reference (FAST at iniTh; if that yields nothing, FAST at minTh, :1135-1148), output in
         // bitmap order = row-major order of the pixels
-        const uint32_t* bm = __ballot(any_hi) != 0ull ? bm_hi : bm_lo;
+        const uint32_t* bm = ORBX_BALLOT(any_hi) != 0ull ? bm_hi : bm_lo;
         for (int w0 = 0; w0 < nwords; w0 += kFastThreads) {
             const int w = w0 + lane;
             uint32_t bits = w < nwords ? bm[w] : 0u;
@@ -327,7 +329,7 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
             any_hi |= (keep && s >= iniTh);
         }
         ORBX_WAVE_SYNC();
-        const int thr = __ballot(any_hi) != 0ull ? iniTh : minTh;
+        const int thr = ORBX_BALLOT(any_hi) != 0ull ? iniTh : minTh;
         for (int i0 = 0; i0 < npix; i0 += kFastThreads) {
             const int i = i0 + lane;
             int flag = 0, x = 0, y = 0, s = 0;
@@ -337,7 +339,7 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
                 s = sc[o];
                 flag = kf[o] && s >= thr;
             }
-            const unsigned long long bal = __ballot(flag);
+            const unsigned long long bal = ORBX_BALLOT(flag);
             if (flag) out[base + __popcll(bal & lt)] = key_pack(ci.x0 + x - kBorder, ci.y0 + y - kBorder, s);
             base += __popcll(bal);
         }

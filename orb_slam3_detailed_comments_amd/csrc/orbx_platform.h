@@ -14,6 +14,8 @@
 // before any lane writes" marks the point explicitly
 #define ORBX_WAVE_SYNC() hipemu::wave_barrier()
 #define ORBX_READLANE(v, l) __shfl((v), (l))
+#define ORBX_BALLOT(pred) __ballot((pred) ? 1 : 0)
+#define ORBX_IN_BALLOT(mask) ((((mask) >> (threadIdx.x & 63u)) & 1ull) != 0ull)
 #else
 #include <hip/hip_runtime.h>
 #define ORBX_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
@@ -23,6 +25,13 @@
 #define ORBX_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 // value of lane l as a wave-uniform scalar (SGPR): keeps counters derived from it out of the vector registers
 #define ORBX_READLANE(v, l) __builtin_amdgcn_readlane((v), (l))
+// wave64 ballot of a PREDICATE: llvm.amdgcn.ballot.i64 takes the i1 itself, so the comparison that produces the predicate writes the SGPR mask
+// directly.  HIP's __ballot(int) compares a materialised integer with zero: the predicate is first turned into 0 / 1 (v_bfe / v_cndmask) and then
+// compared again - two VOP3 instructions per ballot on top of the test itself (seen in k_fast_cells' append code: 16 of them per trip).
+#define ORBX_BALLOT(pred) __builtin_amdgcn_ballot_w64((bool)(pred))
+// "is my lane in this ballot": the SGPR mask itself becomes the exec mask of the guarded code (llvm.amdgcn.inverse.ballot) - one test serves
+// the ballot, its popcount, the mbcnt ranks and the branch
+#define ORBX_IN_BALLOT(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
 #endif
 
 namespace orbx {
