@@ -242,32 +242,35 @@ __global__ void __launch_bounds__(256) k_blur(const LevelInfo* __restrict__ lv, 
     const int tcols = (L.w + 255) >> 8;
     const int ty = t / tcols, tx = t - ty * tcols;
     const int x0 = (tx * 64 + (int)threadIdx.x) * 4;
-    const int ys = (ty * 4 + (int)threadIdx.y) * kBlurRows;
+    const int ys = ORBX_UNIFORM((ty * 4 + (int)threadIdx.y) * kBlurRows);      // one strip per wave: the row bookkeeping (reflection, row offsets) is scalar
     if (x0 >= L.w || ys >= L.h) return;
-    const uint8_t* src = pyr + (size_t)b * pyr_stride + L.off;
-    uint8_t* dst = blur + (size_t)b * pyr_stride + L.off;
+    const BufRsrc src = buf_make(pyr + (size_t)b * pyr_stride + L.off);
+    const BufRsrc dst = buf_make(blur + (size_t)b * pyr_stride + L.off);
     const int k0 = taps.k[0], k1 = taps.k[1], k2 = taps.k[2], k3 = taps.k[3];
-    // Loop-invariant REFLECT_101 column mapping: the 10 input columns x0-3..x0+6 are gathered from the 12-byte window
-    // {l = x0-4.., c = x0.., r = x0+4..} by three byte-permutes whose selectors are computed once per thread, so border
-    // lanes cost the same as interior lanes (no divergence).  Columns that only feed outputs >= w are don't-cares.
-    uint32_t sel[3]; int base[3];
+    // Loop-invariant REFLECT_101 column mapping: the 10 input columns x0-3..x0+6 are gathered from three dwords L, C, R of the row by three
+    // byte-permutes over the fixed register pairs (C,L), (R,C), (R,C).  C is the thread's own dword; L is the dword to its left (the own one
+    // again in the first column, whose reflected columns all lie in C); R is the dword to its right - or, in the last dwords of a row
+    // (w - x0 <= 4), where every column right of the image reflects to the left, the dword to the LEFT (w - x0 = 4 needs neither).  The
+    // dword offsets and the selectors are per-thread constants, so border lanes run the same instructions as interior lanes and no load is
+    // predicated.  Columns that only feed outputs >= w are don't-cares.
+    const int oL = x0 > 0 ? -4 : 0;
+    const int oR = L.w - x0 > 4 ? 4 : oL;
+    uint32_t sel[3];
 #pragma unroll
     for (int g = 0; g < 3; g++) {
-        int idx[4], mn = 11;
+        const int hi0 = g == 0 ? x0 : x0 + oR, lo0 = g == 0 ? x0 + oL : x0;     // first columns of the pair's high / low dword
+        uint32_t sgl = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             int col = x0 - 3 + 4 * g + j;
             if (col < 0) col = -col;
             if (col >= L.w) col = 2 * L.w - 2 - col;
-            idx[j] = imin(imax(col - (x0 - 4), 0), 11);
-            if (g * 4 + j < 10) mn = imin(mn, idx[j]);
+            const int dl = col - lo0, dh = col - hi0;
+            sgl |= ((unsigned)dl < 4u ? (uint32_t)dl : (unsigned)dh < 4u ? (uint32_t)(4 + dh) : 0u) << (8 * j);
         }
-        base[g] = imin(mn >> 2, 1);
-        uint32_t sgl = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) sgl |= (uint32_t)imin(imax(idx[j] - 4 * base[g], 0), 7) << (8 * j);
         sel[g] = sgl;
     }
+    const int xl = x0 + oL, xr = x0 + oR;
     // Horizontal pass: H_j = sum_i k_i p[j+i], j = 0..3, on the three byte windows P0 = p[0..3], P1 = p[4..7], P2 = p[8..9]: instead of
     // shifting the data to each j (v_alignbyte) the taps are shifted - ten v_dot4_u32_u8 with constant tap words; H <= 65535.
     // Vertical pass: the H of two consecutive input rows share a register (lo/hi 16 bits), so a 7-row window is four
@@ -296,13 +299,13 @@ __global__ void __launch_bounds__(256) k_blur(const LevelInfo* __restrict__ lv, 
             if (y < 0) y = -y;
             if (y >= L.h) y = 2 * L.h - 2 - y;
             y = imax(y, 0);
-            const uint8_t* row = src + (uint32_t)(mul24(y, L.pitch) + x0);      // uniform base + 32-bit offset: no 64-bit multiply-add per row
-            const uint32_t c = *(const uint32_t*)row;
-            const uint32_t l = x0 > 0 ? *(const uint32_t*)(row - 4) : 0u;
-            const uint32_t r = x0 + 4 < L.pitch ? *(const uint32_t*)(row + 4) : 0u;
-            const uint32_t P0 = byte_perm(base[0] ? r : c, base[0] ? c : l, sel[0]);      // input columns x0-3 .. x0
-            const uint32_t P1 = byte_perm(base[1] ? r : c, base[1] ? c : l, sel[1]);      //               x0+1 .. x0+4
-            const uint32_t P2 = byte_perm(base[2] ? r : c, base[2] ? c : l, sel[2]);      //               x0+5, x0+6, (unused)
+            const uint32_t ro = (uint32_t)(y * L.pitch);                        // scalar row offset + per-thread column offsets: no vector address arithmetic
+            const uint32_t c = buf_load_u32(src, (uint32_t)x0, ro);
+            const uint32_t l = buf_load_u32(src, (uint32_t)xl, ro);
+            const uint32_t r = buf_load_u32(src, (uint32_t)xr, ro);
+            const uint32_t P0 = byte_perm(c, l, sel[0]);      // input columns x0-3 .. x0
+            const uint32_t P1 = byte_perm(r, c, sel[1]);      //               x0+1 .. x0+4
+            const uint32_t P2 = byte_perm(r, c, sel[2]);      //               x0+5, x0+6, (unused)
             Hr[sub][0] = dot4_u8(P0, T00, dot4_u8(P1, T01, 0u));
             Hr[sub][1] = dot4_u8(P0, T10, dot4_u8(P1, T11, 0u));
             Hr[sub][2] = dot4_u8(P0, T20, dot4_u8(P1, T21, dot4_u8(P2, T22, 0u)));
@@ -329,9 +332,9 @@ __global__ void __launch_bounds__(256) k_blur(const LevelInfo* __restrict__ lv, 
                     oe |= ve << (8 * j); oo |= vo << (8 * j);
                 }
             }
-            const uint32_t oofs = (uint32_t)(mul24(yo, L.pitch) + x0);
-            *(uint32_t*)(dst + oofs) = oe;
-            if (yo + 1 < L.h) *(uint32_t*)(dst + (oofs + (uint32_t)L.pitch)) = oo;
+            const uint32_t oo_ = (uint32_t)(yo * L.pitch);
+            buf_store_u32(oe, dst, (uint32_t)x0, oo_);
+            if (yo + 1 < L.h) buf_store_u32(oo, dst, (uint32_t)x0, oo_ + (uint32_t)L.pitch);
         }
     }
 }

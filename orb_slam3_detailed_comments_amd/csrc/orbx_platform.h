@@ -14,6 +14,7 @@
 // before any lane writes" marks the point explicitly
 #define ORBX_WAVE_SYNC() hipemu::wave_barrier()
 #define ORBX_READLANE(v, l) __shfl((v), (l))
+#define ORBX_UNIFORM(v) (v)
 #define ORBX_BALLOT(pred) __ballot((pred) ? 1 : 0)
 #define ORBX_IN_BALLOT(mask) ((((mask) >> (threadIdx.x & 63u)) & 1ull) != 0ull)
 #else
@@ -25,6 +26,9 @@
 #define ORBX_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 // value of lane l as a wave-uniform scalar (SGPR): keeps counters derived from it out of the vector registers
 #define ORBX_READLANE(v, l) __builtin_amdgcn_readlane((v), (l))
+// a value the code knows to be the same in every lane of the wave (e.g. derived from threadIdx.y of a (64, n) block), moved to an SGPR so that
+// what is computed from it runs on the scalar unit
+#define ORBX_UNIFORM(v) __builtin_amdgcn_readfirstlane(v)
 // wave64 ballot of a PREDICATE: llvm.amdgcn.ballot.i64 takes the i1 itself, so the comparison that produces the predicate writes the SGPR mask
 // directly.  HIP's __ballot(int) compares a materialised integer with zero: the predicate is first turned into 0 / 1 (v_bfe / v_cndmask) and then
 // compared again - two VOP3 instructions per ballot on top of the test itself (seen in k_fast_cells' append code: 16 of them per trip).
