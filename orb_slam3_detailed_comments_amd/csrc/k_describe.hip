@@ -7,21 +7,12 @@
 //                   the 8 keypoints are evaluated together, one keypoint per lane.
 #include "orbx_types.h"
 #include "orbx_block.h"
+#include "orbx_simd.h"
 #include "orbx_kernels.h"
 #include "undistort_model.h"
 #include "glibc_sincosf_model.h"
 
 namespace orbx {
-
-// v_dot4_u32_u8: four u8 x u8 products + c (exact)
-__device__ __forceinline__ uint32_t dot4_u8(uint32_t a, uint32_t b, uint32_t c) {
-#ifdef ORBX_EMU
-    for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xFFu) * ((b >> (8 * i)) & 0xFFu);
-    return c;
-#else
-    return __builtin_amdgcn_udot4(a, b, c, false);
-#endif
-}
 
 // rBRIEF pattern (data table of the reference, src/ORBextractor.cc:206-464), read through the scalar/L1 path
 __device__ const signed char d_brief_pattern[1024] = {
@@ -136,7 +127,7 @@ __device__ __forceinline__ void orient_brief_impl(const LevelInfo* __restrict__ 
     const int myslot = slot0 + (lane < KPW ? lane : 0);
     int my_valid = 0, my_level = 0, my_pitch = 0, my_fi = 0;
     uint32_t my_key = 0;
-    long long my_off = 0;                                   // byte offset of the keypoint centre inside the pyramid / blur block
+    int my_off = 0;                                         // byte offset of the keypoint centre inside the image's pyramid / blur block (< 2^31)
     if (myslot < kp_total_cap) {
         for (int l = 1; l < nlevels; l++) if (myslot >= lv[l].kp_off) my_level = l;
         const int i = myslot - lv[my_level].kp_off;
@@ -144,14 +135,14 @@ __device__ __forceinline__ void orient_brief_impl(const LevelInfo* __restrict__ 
         if (my_valid) {
             my_key = lvl_keys[(size_t)b * kp_total_cap + myslot];
             my_pitch = lv[my_level].pitch;
-            my_off = (long long)lv[my_level].off + (long long)(key_y(my_key) + kBorder) * my_pitch + (key_x(my_key) + kBorder);
+            my_off = (int)lv[my_level].off + (key_y(my_key) + kBorder) * my_pitch + (key_x(my_key) + kBorder);
             my_fi = final_idx[(size_t)b * kp_total_cap + myslot];
         }
     }
     const unsigned long long vmask = __ballot(my_valid && lane < KPW);
     if (vmask == 0ull) return;
-    const uint8_t* raw0 = pyr + (size_t)b * pyr_stride;
-    const uint8_t* blur0 = blur + (size_t)b * pyr_stride;
+    const BufRsrc raw0 = buf_make(pyr + (size_t)b * pyr_stride);
+    const BufRsrc blur0 = buf_make(blur + (size_t)b * pyr_stride);
     // ---- 1b: IC_Angle ----
     // The 31 x 31 patch is read as dwords: lane = (row r8 = lane >> 3, column group c = lane & 7) covers columns u = -15 + 4c .. +3 of
     // rows v = -15 + 8 * trip + r8, four trips (the 32nd row / column carries weight 0), i.e. 4 load instructions per keypoint instead
@@ -177,11 +168,12 @@ __device__ __forceinline__ void orient_brief_impl(const LevelInfo* __restrict__ 
     for (int k = 0; k < KPW; k++) {
         if (!((vmask >> k) & 1ull)) continue;               // wave-uniform
         const int pitch = ORBX_READLANE(my_pitch, k);
-        const uint8_t* raw = raw0 + readlane_i64(my_off, k) + (-kHalfPatch + 4 * cg);
+        // scalar offset of the patch's first row / column + per-lane (row, dword) offset: buffer addressing, no 64-bit vector arithmetic
+        const uint32_t so = (uint32_t)(ORBX_READLANE(my_off, k) - kHalfPatch * pitch - kHalfPatch);
         uint32_t I4[4];
 #pragma unroll
         for (int trip = 0; trip < 4; trip++)                // issued back to back: one memory round trip
-            __builtin_memcpy(&I4[trip], raw + (ptrdiff_t)__mul24(-kHalfPatch + 8 * trip + r8, pitch), 4);      // 24-bit multiply, not a 64-bit multiply-add
+            I4[trip] = buf_load_u32(raw0, (uint32_t)(__mul24(8 * trip + r8, pitch) + 4 * cg), so);
         uint32_t du = 0, dv = 0, ds = 0;
 #pragma unroll
         for (int trip = 0; trip < 4; trip++) { du = dot4_u8(I4[trip], wu4[trip], du); dv = dot4_u8(I4[trip], wv4[trip], dv); ds = dot4_u8(I4[trip], on4[trip], ds); }
@@ -209,33 +201,38 @@ __device__ __forceinline__ void orient_brief_impl(const LevelInfo* __restrict__ 
     for (int k = 0; k < KPW; k++) {
         if (!((vmask >> k) & 1ull)) continue;
         const int pitch = ORBX_READLANE(my_pitch, k);
-        const uint8_t* ctr = blur0 + readlane_i64(my_off, k);
+        const uint32_t so = (uint32_t)(ORBX_READLANE(my_off, k) - kWinR * pitch - kWinR);      // first row / column of the window
         const float a = __int_as_float(ORBX_READLANE(__float_as_int(my_a), k)), bb = __int_as_float(ORBX_READLANE(__float_as_int(my_b), k));
         const int fi = ORBX_READLANE(my_fi, k);
         uint32_t wv[kWinTrips];
 #pragma unroll
         for (int t = 0; t < kWinTrips; t++) {
             const int i = lane + 64 * t;                    // dword i of the window: row i / 10, dword column i % 10
-            if (i < kWinRows * kWinDw) __builtin_memcpy(&wv[t], ctr + (ptrdiff_t)(__mul24(i / kWinDw - kWinR, pitch) + (4 * (i % kWinDw) - kWinR)), 4);
+            if (i < kWinRows * kWinDw) wv[t] = buf_load_u32(blur0, (uint32_t)(__mul24(i / kWinDw, pitch) + 4 * (i % kWinDw)), so);
         }
         ORBX_WAVE_SYNC();                                   // the previous keypoint's samples have been read
 #pragma unroll
         for (int t = 0; t < kWinTrips; t++) { const int i = lane + 64 * t; if (i < kWinRows * kWinDw) ((uint32_t*)win)[i] = wv[t]; }
         ORBX_WAVE_SYNC();
+        // cvRound(x) for |x| < 2^22: x + 1.5 * 2^23 is rounded (to nearest, ties to even) at integer granularity, and its bit pattern is
+        // 0x4B400000 + round(x).  The low 24 bits (0x400000 + r) feed the 24-bit multiply by the row pitch directly; all the constants are
+        // folded into one subtraction per sample: offset = 40 * (r + 18) + (c + 18).
+        constexpr float kRoundMagic = 12582912.0f;
+        constexpr uint32_t kRoundFold = 0x400000u * (4u * kWinDw) + 0x4B400000u - (uint32_t)(kWinR * 4 * kWinDw + kWinR);
         int t0v[4], t1v[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0[r], bb), __fmul_rn(py0[r], a)));
-            const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[r], a), __fmul_rn(py0[r], bb)));
-            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[r], bb), __fmul_rn(py1[r], a)));
-            const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[r], a), __fmul_rn(py1[r], bb)));
-            t0v[r] = win[(r0 + kWinR) * (4 * kWinDw) + c0 + kWinR];
-            t1v[r] = win[(r1 + kWinR) * (4 * kWinDw) + c1 + kWinR];
+            const uint32_t r0 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(px0[r], bb), __fmul_rn(py0[r], a)), kRoundMagic));
+            const uint32_t c0 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(px0[r], a), __fmul_rn(py0[r], bb)), kRoundMagic));
+            const uint32_t r1 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(px1[r], bb), __fmul_rn(py1[r], a)), kRoundMagic));
+            const uint32_t c1 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(px1[r], a), __fmul_rn(py1[r], bb)), kRoundMagic));
+            t0v[r] = win[(uint32_t)__umul24(r0, 4 * kWinDw) + c0 - kRoundFold];
+            t1v[r] = win[(uint32_t)__umul24(r1, 4 * kWinDw) + c1 - kRoundFold];
         }
         unsigned long long mine = 0;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const unsigned long long w = __ballot(t0v[r] < t1v[r]);
+            const unsigned long long w = ORBX_BALLOT(t0v[r] < t1v[r]);
             if (lane == r) mine = w;
         }
         if (lane < 4) out_desc[((size_t)b * kp_total_cap + fi) * 4 + lane] = mine;

@@ -194,6 +194,7 @@ template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64)
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }   // v_mul_u32_u24: low 24 bits of each factor, low 32 bits of the product
 static inline int __mul24(int a, int b) { return a * b; }     // device: v_mul_i32_i24; the callers keep both factors below 2^23
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
