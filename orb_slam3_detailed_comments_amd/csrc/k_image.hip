@@ -141,8 +141,8 @@ __global__ void __launch_bounds__(256) k_resize_rows(const LevelInfo* __restrict
 #endif
     const int ys = strip * strip_rows;
     if (dx0 >= D.pitch || ys >= D.h) return;
-    const uint8_t* src = pyr + (size_t)b * pyr_stride + S.off;
-    uint8_t* dst = pyr + (size_t)b * pyr_stride + D.off;
+    const BufRsrc src = buf_make(pyr + (size_t)b * pyr_stride + S.off);
+    const BufRsrc dst = buf_make(pyr + (size_t)b * pyr_stride + D.off);
     const ResizeTap* xt = xtab + D.xtab_off;
     const ResizeTap* yt = ytab + D.ytab_off;
     // per-column constants: byte selectors into the 8-byte source window that starts at the first column's left tap, and the weight pairs
@@ -155,9 +155,8 @@ __global__ void __launch_bounds__(256) k_resize_rows(const LevelInfo* __restrict
         sel[k] = (uint32_t)i0 | 0x0c00u | ((uint32_t)i1 << 16) | 0x0c000000u;           // bytes (tap0, 0, tap1, 0)
         wgt[k] = dx0 + k < D.w ? (uint32_t)tx.w : 0u;                                   // a0 | a1 << 16; columns in the row padding come out 0
     }
-    const uint8_t* col = src + sx0;
-    struct Win { uint32_t lo, hi; };
-    auto load_row = [&](int r) { Win w; __builtin_memcpy(&w, col + (uint32_t)mul24(imin(r, S.h - 1), S.pitch), 8); return w; };   // one (unaligned) 8-byte load
+    // one (unaligned) 8-byte load: scalar row offset + the thread's first source column, no vector address arithmetic
+    auto load_row = [&](int r) { return buf_load_u64(src, (uint32_t)sx0, (uint32_t)(imin(r, S.h - 1) * S.pitch)); };
     // The strip's source rows are walked once, in order, with the loads two rows ahead of their use; an output row is emitted when its
     // second source row arrives (its first one is the previous row, or the same row where cv::resize clamps at the image border).
     const int ye = imin(ys + strip_rows, D.h);
@@ -167,12 +166,13 @@ __global__ void __launch_bounds__(256) k_resize_rows(const LevelInfo* __restrict
     const ResizeTap tyl = yt[imin(ys + ((int)threadIdx.x & 63), D.h - 1)];                 // strip_rows <= 64
     ResizeTap ty; ty.ofs = ORBX_READLANE(tyl.ofs, 0); ty.w = ORBX_READLANE(tyl.w, 0);
     const int r_first = imin(imax(ty.ofs, 0), S.h - 1), r_last = imin(imax(ORBX_READLANE(tyl.ofs, ye - 1 - ys) + 1, 0), S.h - 1);
-    Win w0 = load_row(r_first), w1 = load_row(r_first + 1);
-    uint32_t Hp[4] = {0u, 0u, 0u, 0u}, Hc[4];
-    for (int r = r_first; r <= r_last; r++) {
-        const Win wn = load_row(r + 2);
+    // horizontal pass of one source row
+    auto hrow = [&](const u32x2& w, uint32_t* H) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) Hc[k] = dot2_u16(byte_perm(w0.hi, w0.lo, sel[k]), wgt[k], 0u) >> 4;
+        for (int k = 0; k < 4; k++) H[k] = dot2_u16(byte_perm(w.hi, w.lo, sel[k]), wgt[k], 0u) >> 4;
+    };
+    // the output rows whose second source row is r (Hc), the first one being the row before (Hp) or the same row
+    auto emit = [&](int r, const uint32_t* Hp, const uint32_t* Hc) {
         while (dy < ye && imin(imax(ty.ofs + 1, 0), S.h - 1) == r) {
             const bool same = imin(imax(ty.ofs, 0), S.h - 1) == r;             // both taps on this row (border clamp)
             const int b0 = (int)(int16_t)(ty.w & 0xFFFF), b1 = ty.w >> 16;
@@ -184,14 +184,19 @@ __global__ void __launch_bounds__(256) k_resize_rows(const LevelInfo* __restrict
                 const int v = ((mul24_forced(b0, (int)(same ? Hc[k] : Hp[k])) >> 16) + (mul24_forced(b1, (int)Hc[k]) >> 16) + 2) >> 2;
                 out |= (uint32_t)v << (8 * k);
             }
-            *(uint32_t*)(dst + (uint32_t)(mul24(dy, D.pitch) + dx0)) = out;
+            buf_store_u32(out, dst, (uint32_t)dx0, (uint32_t)(dy * D.pitch));
             dy++;
             if (dy < ye) { ty.ofs = ORBX_READLANE(tyl.ofs, dy - ys); ty.w = ORBX_READLANE(tyl.w, dy - ys); }
         }
-#pragma unroll
-        for (int k = 0; k < 4; k++) Hp[k] = Hc[k];
-        w0 = w1; w1 = wn;
-    }
+    };
+    // three row registers and two rows of horizontal sums rotate by NAME through six copies of the loop body (no register moves)
+    u32x2 w[3];
+    uint32_t H[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    w[0] = load_row(r_first); w[1] = load_row(r_first + 1);
+    int r = r_first;
+#define ORBX_STEP(i) { if (r > r_last) break; w[((i) + 2) % 3] = load_row(r + 2); hrow(w[(i) % 3], H[(i) % 2]); emit(r, H[((i) + 1) % 2], H[(i) % 2]); r++; }
+    for (;;) { ORBX_STEP(0) ORBX_STEP(1) ORBX_STEP(2) ORBX_STEP(3) ORBX_STEP(4) ORBX_STEP(5) }
+#undef ORBX_STEP
 }
 
 // ---------------------------------------------------------------------------------------------------

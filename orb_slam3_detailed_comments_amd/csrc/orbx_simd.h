@@ -99,6 +99,7 @@ __device__ __forceinline__ pk2 pk_xor_or(pk2 a, uint32_t x, uint32_t o) { return
 __device__ __forceinline__ pk2 pk_xor(pk2 a, uint32_t x) { return __builtin_bit_cast(pk2, __builtin_bit_cast(uint32_t, a) ^ x); }
 __device__ __forceinline__ uint32_t pk_bits(pk2 a) { return __builtin_bit_cast(uint32_t, a); }
 #endif
+struct u32x2 { uint32_t lo, hi; };
 // Buffer addressing (buffer_load_dword v, voffset, s[rsrc], soffset offen): a wave-uniform base (resource descriptor in SGPRs) plus a
 // wave-uniform byte offset (SGPR) plus a per-lane byte offset (VGPR) - streaming kernels that walk rows pay no vector instruction per
 // address.  Raw (stride 0), offsets unchecked up to 2 GiB.
@@ -107,11 +108,17 @@ struct BufRsrc { uint8_t* p; };
 __device__ __forceinline__ BufRsrc buf_make(const void* p) { BufRsrc r; r.p = (uint8_t*)p; return r; }
 __device__ __forceinline__ uint32_t buf_load_u32(BufRsrc r, uint32_t voff, uint32_t soff) { uint32_t v; __builtin_memcpy(&v, r.p + voff + soff, 4); return v; }
 __device__ __forceinline__ void buf_store_u32(uint32_t v, BufRsrc r, uint32_t voff, uint32_t soff) { __builtin_memcpy(r.p + voff + soff, &v, 4); }
+__device__ __forceinline__ u32x2 buf_load_u64(BufRsrc r, uint32_t voff, uint32_t soff) { u32x2 v; __builtin_memcpy(&v, r.p + voff + soff, 8); return v; }
 #else
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
 __device__ __forceinline__ BufRsrc buf_make(const void* p) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7FFFFFFF, 0x00020000); }
 __device__ __forceinline__ uint32_t buf_load_u32(BufRsrc r, uint32_t voff, uint32_t soff) { return __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0); }
 __device__ __forceinline__ void buf_store_u32(uint32_t v, BufRsrc r, uint32_t voff, uint32_t soff) { __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)voff, (int)soff, 0); }
+// 8 bytes from any byte address (no alignment requirement on gfx950)
+__device__ __forceinline__ u32x2 buf_load_u64(BufRsrc r, uint32_t voff, uint32_t soff) {
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0); u32x2 o; o.lo = v.x; o.hi = v.y; return o;
+}
 #endif
 constexpr int kPixBias = 0x6400;     // pixel value b is carried as 0x6400 + b (binary16 1024 + b)
 
