@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) k_resize_rows(const LevelInfo* __restrict
 // Self-test of the instruction wrappers of orbx_simd.h (orbx_debug_simd_selftest): out[op * n + i] = op(a[i], b[i], c[i]).  The CPU tests
 // run the kernels on plain-C stand-ins of these instructions; this entry lets the tests compare instruction and stand-in with an independent
 // definition, operand by operand.  ops: 0 mul24, 1 mul24_forced, 2 byte_perm, 3 align_byte, 4 dot4_u8, 5 dot2_u16, 6 pk_max3, 7 pk_min3,
-// 8 pk_sub, 9 pk_xor(a, c), 10 wave_incl_scan, 11 wave_sum (both of a & 0xFFFF), 12 wave_min_u32(b) (kSimdSelftestOps in all).
+// 8 pk_sub, 9 pk_xor(a, c), 10 wave_incl_scan, 11 wave_sum (both of a & 0xFFFF), 12 wave_min_u32(b), 13 sad4_u8, 14 __umul24 (kSimdSelftestOps in all).
 __global__ void __launch_bounds__(256) k_simd_selftest(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ c, int n,
                                                        uint32_t* __restrict__ out) {
     const int i = (int)(blockIdx.x * 256 + threadIdx.x);
@@ -225,6 +225,8 @@ __global__ void __launch_bounds__(256) k_simd_selftest(const uint32_t* __restric
     out[10 * (size_t)n + i] = (uint32_t)wave_incl_scan<int>((int)(x & 0xFFFFu));
     out[11 * (size_t)n + i] = (uint32_t)wave_sum<int>((int)(x & 0xFFFFu));
     out[12 * (size_t)n + i] = wave_min_u32(y);
+    out[13 * (size_t)n + i] = sad4_u8(x, y, z);
+    out[14 * (size_t)n + i] = (uint32_t)__umul24(x, y);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -8,6 +8,7 @@
 // Descriptors are read as 4 x u64 (the reference reads 8 x int32; the popcount sum is identical).
 #include "orbx_types.h"
 #include "orbx_block.h"
+#include "orbx_simd.h"
 #include "kb8_model.h"
 
 namespace orbx {
@@ -147,29 +148,33 @@ __global__ void __launch_bounds__(256) k_stereo_match(const LevelInfo* __restric
         if (!(iniu < 0 || endu >= (float)Lv.w) && inb) {
             const uint8_t* IL = pyrL + (size_t)b * pyr_stride + Lv.off;
             const uint8_t* IR = pyrR + (size_t)b * pyr_stride + Lv.off;
-            int acc[11];
+            // SAD of the 11 x 11 left window against the right window at the 11 shifts (:1270-1290).  Lane = (row group g = lane >> 4, shift
+            // k = lane & 15 < 11) sums rows g, g + 4, g + 8 for its shift: a row is 11 bytes = three dwords at columns 0, 4 and 7 (the third
+            // overlaps the second by one byte, which is masked on both sides: no byte outside the windows is read), three v_sad_u8 per row.
+            // The four row groups are added across the lanes k, k + 16, k + 32, k + 48; the first minimum over k (:1283 keeps a strictly
+            // smaller SAD while k ascends) is the smallest key sad << 4 | k.
+            const int g = lane >> 4, k = lane & 15;
+            uint32_t acc = 0;
+            if (k < 11) {
 #pragma unroll
-            for (int k = 0; k < 11; k++) acc[k] = 0;
-#pragma unroll
-            for (int rep = 0; rep < 2; rep++) {
-                const int idx = lane + 64 * rep;
-                if (idx < 121) {
-                    const int row = idx / 11, col = idx - row * 11;
-                    const int rofs = __mul24(cv - w + row, Lv.pitch);                                 // rows and pitches are far below 2^23
-                    const int a = IL[(uint32_t)(rofs + (cu - w + col))];
-                    const uint8_t* rp = IR + (uint32_t)(rofs + (cr - w - Lh + col));
-#pragma unroll
-                    for (int k = 0; k < 11; k++) { const int d = a - (int)rp[k]; acc[k] += d < 0 ? -d : d; }
+                for (int t = 0; t < 3; t++) {
+                    const int row = g + 4 * t;
+                    if (row < 11) {
+                        const int rofs = __mul24(cv - w + row, Lv.pitch);                             // rows and pitches are far below 2^23
+                        const uint8_t* lp = IL + (uint32_t)(rofs + (cu - w));
+                        const uint8_t* rp = IR + (uint32_t)(rofs + (cr - w - Lh + k));
+                        const uint32_t l0 = load_u32_any(lp), l1 = load_u32_any(lp + 4), l2 = load_u32_any(lp + 7) & 0xFFFFFF00u;
+                        const uint32_t r0 = load_u32_any(rp), r1 = load_u32_any(rp + 4), r2 = load_u32_any(rp + 7) & 0xFFFFFF00u;
+                        acc = sad4_u8(l0, r0, sad4_u8(l1, r1, sad4_u8(l2, r2, acc)));
+                    }
                 }
             }
-            int bestS = 0x7FFFFFFF, bestinc = 0;
-            int vd[11];
-#pragma unroll
-            for (int k = 0; k < 11; k++) { vd[k] = wave_sum(acc[k]); if (vd[k] < bestS) { bestS = vd[k]; bestinc = k - Lh; } }
+            acc += __shfl_xor(acc, 16);
+            acc += __shfl_xor(acc, 32);
+            const unsigned skey = wave_min_u32(k < 11 ? (acc << 4) | (unsigned)k : 0xFFFFFFFFu);
+            const int bestS = (int)(skey >> 4), bi = (int)(skey & 15u), bestinc = bi - Lh;
             if (!(bestinc == -Lh || bestinc == Lh)) {
-                float dist1 = 0, dist2 = 0, dist3 = 0;
-#pragma unroll
-                for (int k = 1; k < 10; k++) if (k == bestinc + Lh) { dist1 = (float)vd[k - 1]; dist2 = (float)vd[k]; dist3 = (float)vd[k + 1]; }
+                const float dist1 = (float)ORBX_READLANE(acc, bi - 1), dist2 = (float)bestS, dist3 = (float)ORBX_READLANE(acc, bi + 1);
                 const float deltaR = __fdiv_rn(__fsub_rn(dist1, dist3),
                                                __fmul_rn(2.0f, __fsub_rn(__fadd_rn(dist1, dist3), __fmul_rn(2.0f, dist2))));
                 if (!(deltaR < -1 || deltaR > 1)) {

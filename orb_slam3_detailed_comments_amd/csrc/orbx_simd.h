@@ -62,6 +62,17 @@ __device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c)
     return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
 #endif
 }
+// v_sad_u8: sum of the four absolute byte differences + c
+__device__ __forceinline__ uint32_t sad4_u8(uint32_t a, uint32_t b, uint32_t c) {
+#ifdef ORBX_EMU
+    for (int i = 0; i < 4; i++) { const int d = (int)((a >> (8 * i)) & 0xFFu) - (int)((b >> (8 * i)) & 0xFFu); c += (uint32_t)(d < 0 ? -d : d); }
+    return c;
+#else
+    return __builtin_amdgcn_sad_u8(a, b, c);
+#endif
+}
+// 4 bytes from any byte address (global and LDS reads need no alignment on gfx950)
+__device__ __forceinline__ uint32_t load_u32_any(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 // two signed 16-bit lanes in one VGPR (v_pk_sub_i16 / v_pk_min_i16 / v_pk_max_i16)
 #ifdef ORBX_EMU
 struct pk2 { short x, y; };

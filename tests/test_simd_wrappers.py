@@ -31,7 +31,7 @@ def _operands(rng):
 
 
 def _run(ex, a, b, c):
-    out = np.zeros((13, N), np.uint32)
+    out = np.zeros((15, N), np.uint32)
     a, b, c = (np.ascontiguousarray(x, np.uint32) for x in (a, b, c))
     ex._lib.check(ex._lib.L.orbx_debug_simd_selftest(ex._h, a.ctypes.data, b.ctypes.data, c.ctypes.data, N, out.ctypes.data))
     return out
@@ -67,6 +67,11 @@ def _check(ex):
     assert np.array_equal(out[4], exp4.astype(np.uint32)), "dot4_u8"
     al, ah = _halves(a); bl, bh = _halves(b)
     assert np.array_equal(out[5], ((al * bl + ah * bh + c.astype(np.int64)) & 0xFFFFFFFF).astype(np.uint32)), "dot2_u16"
+    # v_sad_u8: sum of absolute byte differences + c; v_mul_u32_u24: product of the low 24 bits, low 32 bits
+    sad = np.abs(_bytes(a).astype(np.int64) - _bytes(b).astype(np.int64)).sum(1) + c.astype(np.int64)
+    assert np.array_equal(out[13], (sad & 0xFFFFFFFF).astype(np.uint32)), "sad4_u8"
+    um = ((a & 0xFFFFFF).astype(np.uint64) * (b & 0xFFFFFF).astype(np.uint64)) & np.uint64(0xFFFFFFFF)
+    assert np.array_equal(out[14], um.astype(np.uint32)), "umul24"
     # packed three-input max / min on biased pixel patterns (positive binary16 numbers order like their bit patterns)
     a, b, c = S["pk3"]; out = _run(ex, a, b, c)
     hs = [_halves(x) for x in (a, b, c)]
