@@ -8,6 +8,7 @@
 // Descriptors are read as 4 x u64 (the reference reads 8 x int32; the popcount sum is identical).
 #include "orbx_types.h"
 #include "orbx_block.h"
+#include "orbx_kernels.h"
 #include "orbx_simd.h"
 #include "kb8_model.h"
 
@@ -27,11 +28,10 @@ __global__ void __launch_bounds__(256) k_hamming_matrix(const unsigned long long
 }
 
 // Row index for the stereo search (the role of vRowIndices, src/Frame.cc:1129-1155): the right keypoints of an image bucketed by the
-// first row of their candidate band (32 rows per bucket, CSR).  A left keypoint at row v then only visits the buckets that can hold
+// first row of their candidate band (1 << kStereoRowShift rows per bucket, CSR).  A left keypoint at row v then only visits the buckets that can hold
 // bands covering v instead of every right keypoint.  Order inside a bucket is arbitrary (atomics): the search reduces full
 // (distance << 16 | index) keys, in the lanes as well as across them, so the visiting order never shows in the result.
 // grid (B), 256 threads, dynamic LDS = 2 * (nb + 1) ints.
-constexpr int kRowBucketShift = 5;
 __global__ void __launch_bounds__(256) k_stereo_rows(const int4* __restrict__ auxR, const int* __restrict__ nR, int cap, int nb,
                                                      int* __restrict__ bucket_start, int* __restrict__ bucket_items) {
     ORBX_DYN_SMEM(smem);
@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) k_stereo_rows(const int4* __restrict__ au
     const int4* ar = auxR + (size_t)b * cap;
     for (int i = tid; i <= nb; i += 256) hist[i] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += 256) atomicAdd(&hist[imin(imax(ar[i].x, 0) >> kRowBucketShift, nb - 1)], 1);
+    for (int i = tid; i < n; i += 256) atomicAdd(&hist[imin(imax(ar[i].x, 0) >> kStereoRowShift, nb - 1)], 1);
     __syncthreads();
     int run = 0;
     for (int c0 = 0; c0 < nb; c0 += 256) {
@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) k_stereo_rows(const int4* __restrict__ au
     if (tid == 0) bucket_start[(size_t)b * (nb + 1) + nb] = run;
     __syncthreads();
     for (int i = tid; i < n; i += 256) {
-        const int pos = atomicAdd(&cursor[imin(imax(ar[i].x, 0) >> kRowBucketShift, nb - 1)], 1);
+        const int pos = atomicAdd(&cursor[imin(imax(ar[i].x, 0) >> kStereoRowShift, nb - 1)], 1);
         bucket_items[(size_t)b * cap + pos] = i;
     }
 }
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256) k_stereo_match(const LevelInfo* __restric
         // contiguous run of row buckets; the exact band / octave / column tests follow
         const int* bs = bucket_start + (size_t)b * (nb + 1);
         const int* items = bucket_items + (size_t)b * cap;
-        const int jbeg = bs[imin(imax(rowL - lookback, 0) >> kRowBucketShift, nb - 1)], jend = bs[imin(imax(rowL, 0) >> kRowBucketShift, nb - 1) + 1];
+        const int jbeg = bs[imin(imax(rowL - lookback, 0) >> kStereoRowShift, nb - 1)], jend = bs[imin(imax(rowL, 0) >> kStereoRowShift, nb - 1) + 1];
         // one candidate: exact band / octave / column tests, then the (distance, index) key
         auto visit = [&](int iR, const int4& a) {
             if (rowL < a.x || rowL > a.y) return;

@@ -816,8 +816,8 @@ int orbm_stereo_match(orbx_extractor* L, int lf, orbx_extractor* R, int rf, int 
     P.debug_flags = L->debug_stereo_flags;
     if (L->profile) rt::event_record(L->ev_stage[ST_MATCH][0], L->s0);
     dim3 grid((cap + 3) / 4, B, 1), blk(256, 1, 1);
-    // row index of the right keypoints (32-row buckets of the first row of each candidate band)
-    const int nb = (R->H >> 5) + 2;
+    // row index of the right keypoints (buckets of 1 << kStereoRowShift rows, by the first row of each candidate band)
+    const int nb = (R->H >> kStereoRowShift) + 2;
     const int lookback = (int)std::ceil(4.0f * R->scale[R->nlevels - 1]) + 2;     // tallest band: 2 * (2 * scale) + rounding
     if (L->d_rowstart.ensure((size_t)B * (nb + 1)) || L->d_rowitems.ensure((size_t)B * cap)) return fail(ORBX_E_DEVICE, "allocation failed");
     {

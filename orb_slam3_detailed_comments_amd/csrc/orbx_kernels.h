@@ -42,6 +42,10 @@ __global__ void k_quadtree(const LevelInfo* __restrict__ lv, const CellInfo* __r
 __global__ void k_layout(const LevelInfo* __restrict__ lv, int nlevels, const uint32_t* __restrict__ lvl_keys,
                          int kp_total_cap, const int* __restrict__ lvl_count, int lap0, int lap1,
                          int* __restrict__ final_idx, int* __restrict__ n_out, int* __restrict__ mono_out);
+#ifndef ORBX_STEREO_ROW_SHIFT
+#define ORBX_STEREO_ROW_SHIFT 3
+#endif
+constexpr int kStereoRowShift = ORBX_STEREO_ROW_SHIFT;   // k_stereo_rows / k_stereo_match: right keypoints are bucketed by (first row of their band) >> shift
 constexpr int kKpPerWaveDecl = 8;      // must equal kKpPerWave in k_describe.hip
 constexpr int kKpPerWaveSmallDecl = 2; // keypoints per wave of k_orient_brief_small
 __global__ void k_orient_brief(const LevelInfo* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,

@@ -1,0 +1,11 @@
+"""Builds build/variants/liborbx_hip_<name>.so for a few compile-time tunables (GPU sweep: tools/gpu_sweep_tunables.sh)."""
+import os, sys
+from concurrent.futures import ThreadPoolExecutor
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from build_fast_variants import build, OUT
+JOBS = [("base+rs%d" % k, ("-DORBX_STEREO_ROW_SHIFT=%d" % k,)) for k in (2, 3, 4, 5)]
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    jobs = [j for j in JOBS if len(sys.argv) == 1 or j[0] in sys.argv[1:]]
+    with ThreadPoolExecutor(4) as ex:
+        for o in ex.map(lambda j: build(*j), jobs): print(o)
