@@ -193,35 +193,42 @@ __global__ void __launch_bounds__(256) k_stereo_match(const LevelInfo* __restric
     if (lane == 0) { uRight[o] = out_u; depth[o] = out_d; sad[o] = out_sad; }
 }
 
-// grid (B), 256 threads.  LDS: cap ints.
+// grid (B), 256 threads.  The median of the reference (:1335-1338: sort the (SAD, index) pairs, take element size / 2) is the SAD of rank
+// cnt / 2; a SAD of an 11 x 11 window is below 2^15, so the rank is located by two 256-bin histograms (high byte, then low 7 bits inside the
+// bin that holds the rank) instead of comparing every pair of values.
 __global__ void __launch_bounds__(256) k_stereo_median(const int* __restrict__ nL, int cap,
                                                        float* __restrict__ uRight, float* __restrict__ depth,
                                                        const int* __restrict__ sad, int* __restrict__ n_matches) {
-    ORBX_DYN_SMEM(smem);
     __shared__ unsigned long long s_scan[20];
-    __shared__ int s_med[2];
-    int* list = (int*)smem;
+    __shared__ int s_hist[256];
+    __shared__ int s_med[3];                                // {median, bin of the rank, rank inside the bin}
     const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
     const int n = nL[b];
-    // the SADs of the matched keypoints, in any order (the median is found by rank, not by position)
-    if (tid == 0) { s_med[0] = -1; s_med[1] = 0; }
-    __syncthreads();
-    for (int i = tid; i < n; i += 256) {
-        const int s = sad[(size_t)b * cap + i];
-        if (s >= 0) list[atomicAdd(&s_med[1], 1)] = s;
+    const int* sd = sad + (size_t)b * cap;
+    int med = -1;
+    for (int pass = 0; pass < 2; pass++) {
+        s_hist[tid] = 0;
+        __syncthreads();
+        const int bin = pass ? s_med[1] : 0;
+        for (int i = tid; i < n; i += 256) {
+            const int s = sd[i];
+            if (s >= 0 && (pass == 0 || (s >> 7) == bin)) atomicAdd(&s_hist[pass ? s & 127 : imin(s >> 7, 255)], 1);
+        }
+        __syncthreads();
+        unsigned long long tot;
+        const int c = s_hist[tid];
+        const int ex = (int)block_excl_scan<unsigned long long>((unsigned long long)c, &tot, s_scan);
+        const int cnt = pass ? 0 : (int)tot;
+        if (pass == 0 && cnt == 0) { if (tid == 0) n_matches[b] = 0; return; }
+        const int k = pass ? s_med[2] : cnt / 2;
+        if (ex <= k && k < ex + c) {                         // exactly one bin holds the rank
+            if (pass == 0) { s_med[1] = tid; s_med[2] = k - ex; }
+            else s_med[0] = (bin << 7) | tid;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    const int cnt = s_med[1];
-    if (cnt == 0) { if (tid == 0) n_matches[b] = 0; return; }
-    const int k = cnt / 2;
-    for (int i = tid; i < cnt; i += 256) {
-        const int e = list[i];
-        int less = 0, eq = 0;
-        for (int j = 0; j < cnt; j++) { const int v = list[j]; less += v < e; eq += v == e; }
-        if (less <= k && k < less + eq) s_med[0] = e;
-    }
-    __syncthreads();
-    const float median = (float)s_med[0];
+    med = s_med[0];
+    const float median = (float)med;
     const float thDist = __fmul_rn(1.5f * 1.4f, median);
     int kept = 0;
     for (int i = tid; i < n; i += 256) {

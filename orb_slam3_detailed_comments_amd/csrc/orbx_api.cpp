@@ -832,7 +832,7 @@ int orbm_stereo_match(orbx_extractor* L, int lf, orbx_extractor* R, int rf, int 
                 (const int*)L->d_rowstart.p, (const int*)L->d_rowitems.p, nb, lookback, cap, (const uint8_t*)(L->d_pyr.p + (size_t)lf * L->pyr_stride), (const uint8_t*)(R->d_pyr.p + (size_t)rf * R->pyr_stride), L->pyr_stride,
                 P, L->d_uRight.p, L->d_depth.p, L->d_sad.p);
     dim3 grid2(B, 1, 1);
-    ORBX_LAUNCH(k_stereo_median, grid2, blk, (size_t)cap * sizeof(int) + 16, L->s0, (const int*)(L->d_nm.p + lf), cap, L->d_uRight.p, L->d_depth.p,
+    ORBX_LAUNCH(k_stereo_median, grid2, blk, 0, L->s0, (const int*)(L->d_nm.p + lf), cap, L->d_uRight.p, L->d_depth.p,
                 (const int*)L->d_sad.p, L->d_nmatch.p);
     if (L->profile) rt::event_record(L->ev_stage[ST_MATCH][1], L->s0);
     if (rt::check_launch()) return fail(ORBX_E_DEVICE, "kernel launch failed: %s", rt::last_error());
