@@ -3,7 +3,8 @@ import os, sys
 from concurrent.futures import ThreadPoolExecutor
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from build_fast_variants import build, OUT
-JOBS = [("base+rs%d" % k, ("-DORBX_STEREO_ROW_SHIFT=%d" % k,)) for k in (2, 3, 4, 5)]
+JOBS = [("base+ref", ()), ("base+blur24", ("-DORBX_BLUR_ROWS=24",)), ("base+blur32", ("-DORBX_BLUR_ROWS=32",)), ("base+strip8", ("-DORBX_RESIZE_STRIP=8",)), ("base+strip32", ("-DORBX_RESIZE_STRIP=32",)),
+        ("base+list1k", ("-DORBX_FAST_LIST_BYTES=1024",)), ("base+list1536", ("-DORBX_FAST_LIST_BYTES=1536",))] + [("base+rs%d" % k, ("-DORBX_STEREO_ROW_SHIFT=%d" % k,)) for k in (2, 4, 5)]
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     jobs = [j for j in JOBS if len(sys.argv) == 1 or j[0] in sys.argv[1:]]
