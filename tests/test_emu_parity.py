@@ -192,3 +192,18 @@ def test_zero_copy_input_emulated(emu_lib):
 def test_zero_copy_input_gpu(hip_lib):
     _zero_copy_case(hip_lib, 752, 480, 1200)
     _zero_copy_case(hip_lib, 512, 512, 1500)
+
+
+@pytest.mark.parametrize("width", list(range(321, 337)))
+def test_row_ends_of_every_width(emu_lib, width):
+    """The streaming kernels (k_resize_rows, k_blur) handle the end of a row by per-thread dword offsets and byte selectors that depend on
+    width mod 4 and on how many columns of the last dword exist: every residue at every level, raw and blurred, against the oracle."""
+    img = synth.uniform_noise(width, 280, seed=300 + width)
+    ex = ORBextractor(300, 1.2, 8, 20, 7, lib=emu_lib)
+    got = ex(img, None, (0, 0))
+    o = ol.OracleExtractor(300)
+    exp = o.extract(img, (0, 0))
+    for l in range(8):
+        assert np.array_equal(ex.pyramid_level(l), o.level_image(l)), "pyramid level %d" % l
+        assert np.array_equal(ex.pyramid_level(l, blurred=True), o.level_image(l, blurred=True)), "blur level %d" % l
+    assert _same(got, exp)

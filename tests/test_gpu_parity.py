@@ -204,3 +204,19 @@ def test_fuzz_gpu(hip_lib):
         ex = ORBextractor(nf, sf, nl, ini, mn)
         ex.set_gaussian_taps(gv)
         assert _same(ex(img, None, lap), ol.OracleExtractor(nf, sf, nl, ini, mn, gv).extract(img, lap)), seed
+
+
+def test_row_ends_of_every_width(hip_lib):
+    """Every width residue (mod 4, and the number of columns in the last dword of a row) at every level, raw and blurred: the streaming kernels
+    handle row ends by per-thread dword offsets and byte selectors (k_resize_rows, k_blur)."""
+    for width in range(321, 337):
+        img = synth.uniform_noise(width, 280, seed=300 + width)
+        ex = ORBextractor(300, 1.2, 8, 20, 7)
+        got = ex(img, None, (0, 0))
+        o = ol.OracleExtractor(300)
+        exp = o.extract(img, (0, 0))
+        for l in range(8):
+            assert np.array_equal(ex.pyramid_level(l), o.level_image(l)), "width %d pyramid level %d" % (width, l)
+            assert np.array_equal(ex.pyramid_level(l, blurred=True), o.level_image(l, blurred=True)), "width %d blur level %d" % (width, l)
+        assert _same(got, exp), width
+        ex.close()
