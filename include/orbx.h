@@ -154,7 +154,9 @@ int orbx_debug_candidates(orbx_extractor* h, int image_index, int level, int* xy
 int orbx_debug_level_keys(orbx_extractor* h, int image_index, int level, int* xys, int cap);       /* quadtree output in list order */
 /* test switches of the stereo row search (orbm_stereo_match): bit 0 visits the candidates of a row band in the opposite order (the result
  * must not change), bit 2 makes every lane walk all candidates from the last to the first (every tie then meets inside one lane; the
- * result must not change either), bit 1 restores the distance-only tie rule of an earlier revision (the tie tests must then fail) */
+ * result must not change either), bit 1 restores the distance-only tie rule of an earlier revision (the tie tests must then fail);
+ * bit 3: the 2-NN of orbm_knn2 / orbm_stereo_fisheye on the vector units (one wave per query) instead of the matrix cores (the result must
+ * not change) */
 int orbx_debug_stereo_flags(orbx_extractor* h, int flags);
 int orbx_debug_quadtree_profile(orbx_extractor* h, long long out[16]);   /* phase timestamps of one quadtree workgroup (profiling mode 2) */
 /* test hook: the byte / packed-16-bit instruction wrappers of the kernels (csrc/orbx_simd.h) applied to n operand triples (n a multiple of 256);

@@ -278,6 +278,119 @@ __global__ void __launch_bounds__(256) k_knn2(const unsigned long long* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Brute-force 2-NN on the matrix cores.  With the descriptor bits as +1 / -1 bytes, the dot product of two descriptors is 256 - 2 * Hamming
+// distance: the all-pairs distance matrix of a query set against a train set is an i8 GEMM (K = 256), and the 2-NN is a row-wise top-2 over it.
+//
+// k_knn2_mfma: same outputs as k_knn2.  grid (ceil(cap / 32), B), 256 threads: the four waves of a workgroup share 32 queries (the B operand of
+// v_mfma_i32_32x32x32_i8: 8 k-steps x 16 bytes per lane, built once per wave) and split the train rows in tiles of 32 (the A operand; wave w takes
+// tiles w, w + 4, ..), then merge their top-2 through LDS.  The descriptors stay packed in memory: lane (row r = l & 31, half h = l >> 5) loads
+// the 16 bytes [16 h, 16 h + 16) of its row - ONE dwordx4 per lane and tile, 1 KB per tile instead of 8 KB of expanded bytes - and expands 16 bits
+// per k-step through a 16-entry nibble -> dword table in LDS (element (k-step s, half h, j) of the MFMA's K = 32 is bit 128 h + 16 s + j of the
+// descriptor: any assignment works as long as both operands use it).  D[train][query] lands with the query in the lane (column l & 31) and 16
+// train rows per lane in the accumulator registers, so the top-2 update is lane-local:
+//   key = (256 - D) << 15 | train row = Hamming distance << 16 | train row,   k1 = min(k1, max(k0, key)),   k0 = min(k0, key)
+// - the lexicographic (distance, index) order of k_knn2 (strict '<' while the index ascends).  The two lanes of a query (l, l + 32: the two halves
+// of a tile's train rows) merge at the end.  1024 pairs cost 8 MFMA + ~130 vector instructions instead of ~340.
+__global__ void __launch_bounds__(256) k_knn2_mfma(const unsigned long long* __restrict__ descQ, const int* __restrict__ qoff, const int* __restrict__ nq,
+                                                   const unsigned long long* __restrict__ descT, const int* __restrict__ toff, const int* __restrict__ nt,
+                                                   int cap, int* __restrict__ idx0, int* __restrict__ dist0, int* __restrict__ idx1,
+                                                   int* __restrict__ dist1, uint8_t* __restrict__ ratio_ok) {
+    __shared__ unsigned s_top[4][32][2];
+    __shared__ uint32_t s_lut[16];
+    const int b = (int)blockIdx.y, lane = lane_id(), w = wave_id();
+    const int qbase = (int)blockIdx.x * 32;
+    const int q0 = qoff ? qoff[b] : 0, t0 = toff ? toff[b] : 0;
+    const int nQ = nq[b] - q0, nT = nt[b] - t0;
+    unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
+    if (qbase < nQ) {                                      // workgroup-uniform
+        if (threadIdx.x < 16) {
+            const uint32_t bits = (uint32_t)__umul24((uint32_t)threadIdx.x, 0x204081u) & 0x01010101u;      // bit i of the nibble -> bit 0 of byte i
+            s_lut[threadIdx.x] = 0x01010101u | ((bits << 8) - bits);                                        // 0 -> 0x01 (+1), 1 -> 0xFF (-1)
+        }
+        __syncthreads();
+        const int r = lane & 31, hoff = 16 * (lane >> 5);
+        // 16 bits (k-step s of this lane's 128) -> 16 bytes
+        auto expand = [&](const uint32_t raw[4], int s) {
+            const uint32_t h = (raw[s >> 1] >> (16 * (s & 1))) & 0xFFFFu;
+            v4i_t v; int e[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) e[j] = (int)s_lut[(h >> (4 * j)) & 15u];
+            __builtin_memcpy(&v, e, 16);
+            return v;
+        };
+        auto load_bits = [&](const unsigned long long* desc, int row, uint32_t raw[4]) {         // rows past the set are masked below; keep the read inside the image's block
+            __builtin_memcpy(raw, (const uint8_t*)(desc + 4 * ((size_t)b * cap + imin(row, cap - 1))) + hoff, 16);
+        };
+        v4i_t qb[8];
+        {
+            uint32_t raw[4];
+            load_bits(descQ, q0 + qbase + r, raw);
+#pragma unroll
+            for (int s = 0; s < 8; s++) qb[s] = expand(raw, s);
+        }
+        const int ntiles = (nT + 31) >> 5;
+        const int mlane = (256 << 15) + 4 * (lane >> 5);    // (256 - D) << 15 + m = D * -2^15 + (256 << 15) + m: one multiply-add and one add per value
+        auto process = [&](const uint32_t raw[4], int tt) {
+            v16i_t acc = v16i_zero();
+#pragma unroll
+            for (int s = 0; s < 8; s++) acc = mfma_i8_32x32x32(expand(raw, s), qb[s], acc);
+            const int base = mlane + tt * 32;
+            if ((tt + 1) * 32 <= nT) {                     // wave-uniform: every row of the tile is a train row
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const unsigned key = (unsigned)(__mul24(acc[i], -32768) + base + ((i & 3) + 8 * (i >> 2)));
+                    k1 = umin32(k1, umax32(k0, key)); k0 = umin32(k0, key);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    unsigned key = (unsigned)(__mul24(acc[i], -32768) + base + ((i & 3) + 8 * (i >> 2)));
+                    if ((int)(key & 0xFFFFu) >= nT) key = 0xFFFFFFFFu;      // the low half of the key is the train row (kp_total_cap < 65535, checked at init)
+                    k1 = umin32(k1, umax32(k0, key)); k0 = umin32(k0, key);
+                }
+            }
+        };
+        // two tile buffers: the load of the next tile is in flight while the matrix cores and the epilogue work on the current one
+        uint32_t ta[4], tb[4];
+        int tt = w;
+        if (tt < ntiles) load_bits(descT, t0 + tt * 32 + r, ta);
+        for (; tt + 4 < ntiles; tt += 8) {
+            load_bits(descT, t0 + (tt + 4) * 32 + r, tb);
+            process(ta, tt);
+            if (tt + 8 < ntiles) load_bits(descT, t0 + (tt + 8) * 32 + r, ta);
+            process(tb, tt + 4);
+        }
+        if (tt < ntiles) process(ta, tt);
+        // the other half of the train rows of this query
+        const unsigned p0 = __shfl_xor(k0, 32), p1 = __shfl_xor(k1, 32);
+        const unsigned b0 = umin32(k0, p0), b1 = umin32(umax32(k0, p0), umin32(k1, p1));
+        k0 = b0; k1 = b1;
+        // the other three waves' train tiles
+        if (lane < 32) { s_top[w][lane][0] = k0; s_top[w][lane][1] = k1; }
+        __syncthreads();
+        if (w == 0 && lane < 32) {
+#pragma unroll
+            for (int o = 1; o < 4; o++) {
+                const unsigned c0 = s_top[o][lane][0], c1 = s_top[o][lane][1];
+                const unsigned n1 = umin32(umax32(k0, c0), umin32(k1, c1));
+                k0 = umin32(k0, c0); k1 = n1;
+            }
+        }
+    }
+    const int q = qbase + lane;
+    if (w == 0 && lane < 32 && q < cap) {
+        const size_t o = (size_t)b * cap + q;
+        if (q >= nQ) { idx0[o] = -1; idx1[o] = -1; dist0[o] = -1; dist1[o] = -1; ratio_ok[o] = 0; }
+        else {
+            const int i0 = k0 == 0xFFFFFFFFu ? -1 : (int)(k0 & 0xFFFF), i1 = k1 == 0xFFFFFFFFu ? -1 : (int)(k1 & 0xFFFF);
+            const int dd0 = i0 < 0 ? -1 : (int)(k0 >> 16), dd1 = i1 < 0 ? -1 : (int)(k1 >> 16);
+            idx0[o] = i0; idx1[o] = i1; dist0[o] = dd0; dist1[o] = dd1;
+            ratio_ok[o] = (i1 >= 0 && (double)(float)dd0 < (double)(float)dd1 * 0.7) ? 1 : 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // The rest of Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1556-1586) after k_knn2: every query (left lapping keypoint) whose best
 // match passed the ratio test is triangulated with KannalaBrandt8::TriangulateMatches; depth > 1e-4 accepts.  One thread per query.
 // l2r / depth / p3d are indexed by left keypoint, r2l by right keypoint (the loop runs over ascending left index, so the last writer of

@@ -867,11 +867,23 @@ int orbm_knn2(orbx_extractor* L, int lf, orbx_extractor* R, int rf, int B) {
     if (L != R) rt::stream_wait_event(L->s0, R->ev_done);
     const int cap = L->kp_total_cap; const size_t bc = (size_t)L->maxB * cap;
     if (L->profile) rt::event_record(L->ev_stage[ST_MATCH][0], L->s0);
-    dim3 grid((cap + 3) / 4, B, 1), blk(256, 1, 1);
-    ORBX_LAUNCH(k_knn2, grid, blk, 0, L->s0,
-                (const unsigned long long*)(L->d_desc.p + (size_t)lf * cap * 4), (const int*)(L->d_nm.p + L->maxB + lf), (const int*)(L->d_nm.p + lf),
-                (const unsigned long long*)(R->d_desc.p + (size_t)rf * cap * 4), (const int*)(R->d_nm.p + R->maxB + rf), (const int*)(R->d_nm.p + rf),
-                cap, L->d_knn.p, L->d_knn.p + bc, L->d_knn.p + 2 * bc, L->d_knn.p + 3 * bc, L->d_ratio.p);
+    const dim3 blk(256, 1, 1);
+    const int* qoff = L->d_nm.p + L->maxB + lf; const int* nq = L->d_nm.p + lf;
+    const int* toff = R->d_nm.p + R->maxB + rf; const int* nt = R->d_nm.p + rf;
+    if (L->debug_stereo_flags & 8) {                       // test switch: the wave-per-query kernel on the vector units
+        dim3 grid((cap + 3) / 4, B, 1);
+        ORBX_LAUNCH(k_knn2, grid, blk, 0, L->s0,
+                    (const unsigned long long*)(L->d_desc.p + (size_t)lf * cap * 4), qoff, nq,
+                    (const unsigned long long*)(R->d_desc.p + (size_t)rf * cap * 4), toff, nt,
+                    cap, L->d_knn.p, L->d_knn.p + bc, L->d_knn.p + 2 * bc, L->d_knn.p + 3 * bc, L->d_ratio.p);
+    } else {
+        // the distance matrix on the matrix cores with the top-2 in its epilogue
+        dim3 grid((cap + 31) / 32, B, 1);
+        ORBX_LAUNCH(k_knn2_mfma, grid, blk, 0, L->s0,
+                    (const unsigned long long*)(L->d_desc.p + (size_t)lf * cap * 4), qoff, nq,
+                    (const unsigned long long*)(R->d_desc.p + (size_t)rf * cap * 4), toff, nt,
+                    cap, L->d_knn.p, L->d_knn.p + bc, L->d_knn.p + 2 * bc, L->d_knn.p + 3 * bc, L->d_ratio.p);
+    }
     if (L->profile) rt::event_record(L->ev_stage[ST_MATCH][1], L->s0);
     if (rt::check_launch()) return fail(ORBX_E_DEVICE, "kernel launch failed: %s", rt::last_error());
     return ORBX_OK;

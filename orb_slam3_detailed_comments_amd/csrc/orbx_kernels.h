@@ -78,6 +78,9 @@ __global__ void k_kb8_stereo(const KeyPointRec* __restrict__ kpsL, const int* __
                              const KeyPointRec* __restrict__ kpsR, const int* __restrict__ monoR, int cap, const int* __restrict__ idx0,
                              const uint8_t* __restrict__ ratio_ok, KB8StereoParams P, int* __restrict__ l2r, int* __restrict__ r2l,
                              float* __restrict__ depth, float* __restrict__ p3d, int* __restrict__ nmatches);
+__global__ void k_knn2_mfma(const unsigned long long* __restrict__ descQ, const int* __restrict__ qoff, const int* __restrict__ nq,
+                            const unsigned long long* __restrict__ descT, const int* __restrict__ toff, const int* __restrict__ nt, int cap,
+                            int* __restrict__ idx0, int* __restrict__ dist0, int* __restrict__ idx1, int* __restrict__ dist1, uint8_t* __restrict__ ratio_ok);
 __global__ void k_knn2(const unsigned long long* __restrict__ descQ, const int* __restrict__ qoff, const int* __restrict__ nq,
                        const unsigned long long* __restrict__ descT, const int* __restrict__ toff, const int* __restrict__ nt,
                        int cap, int* __restrict__ idx0, int* __restrict__ dist0, int* __restrict__ idx1,

@@ -131,6 +131,42 @@ __device__ __forceinline__ u32x2 buf_load_u64(BufRsrc r, uint32_t voff, uint32_t
     const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0); u32x2 o; o.lo = v.x; o.hi = v.y; return o;
 }
 #endif
+// ---------------------------------------------------------------------------------------------------
+// v_mfma_i32_32x32x32_i8: D (32 x 32, i32) += A (32 x 32, i8) * B (32 x 32, i8).  Lane l holds 16 consecutive k of row l & 31 of A (k block
+// l >> 5) and 16 consecutive k of column l & 31 of B; D: column l & 31, rows (r & 3) + 8 * (r >> 2) + 4 * (l >> 5) for register r < 16.
+#ifdef ORBX_EMU
+struct v4i_t { int e[4]; };
+struct v16i_t { int e[16]; int& operator[](int i) { return e[i]; } int operator[](int i) const { return e[i]; } };
+__device__ __forceinline__ v16i_t v16i_zero() { v16i_t z; for (int i = 0; i < 16; i++) z.e[i] = 0; return z; }
+__device__ __forceinline__ v4i_t load_v4i(const uint8_t* p) { v4i_t v; __builtin_memcpy(&v, p, 16); return v; }
+inline v16i_t mfma_i8_32x32x32(v4i_t a, v4i_t b, v16i_t c) {
+    uint64_t m[2][2], A[2][hipemu::kWave], Bv[2][hipemu::kWave];
+    __builtin_memcpy(m[0], &a, 16); __builtin_memcpy(m[1], &b, 16);
+    hipemu::wave_exchange(m[0][0], A[0]); hipemu::wave_exchange(m[0][1], A[1]);
+    hipemu::wave_exchange(m[1][0], Bv[0]); hipemu::wave_exchange(m[1][1], Bv[1]);
+    const int lane = hipemu::cur().lane, col = lane & 31;
+    for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int sum = 0;
+        for (int h = 0; h < 2; h++)
+            for (int j = 0; j < 16; j++) {
+                const int x = (int)(signed char)((A[j >> 3][row + 32 * h] >> (8 * (j & 7))) & 0xFF);
+                const int y = (int)(signed char)((Bv[j >> 3][col + 32 * h] >> (8 * (j & 7))) & 0xFF);
+                sum += x * y;
+            }
+        c.e[r] += sum;
+    }
+    return c;
+}
+#else
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ v16i_t v16i_zero() { v16i_t z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; return z; }
+__device__ __forceinline__ v4i_t load_v4i(const uint8_t* p) { return *(const v4i_t*)p; }
+__device__ __forceinline__ v16i_t mfma_i8_32x32x32(v4i_t a, v4i_t b, v16i_t c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
+#endif
+__device__ __forceinline__ unsigned umin32(unsigned a, unsigned b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned umax32(unsigned a, unsigned b) { return a > b ? a : b; }
 constexpr int kPixBias = 0x6400;     // pixel value b is carried as 0x6400 + b (binary16 1024 + b)
 
 }  // namespace orbx

@@ -77,6 +77,12 @@ def test_batch_and_stereo_and_knn(emu_lib):
     assert nq > 100 and mL > 0
     for key in ref:
         assert np.array_equal(out[key][0, :nq], ref[key]), key
+    # the same through the wave-per-query kernel on the vector units (the default is the distance matrix on the matrix cores, k_knn2_mfma)
+    ex.debug_stereo_flags(8)
+    out2 = M.StereoFishEyeKnn(ex, ex, 0, 1, 1)
+    ex.debug_stereo_flags(0)
+    for key in out:
+        assert np.array_equal(out[key], out2[key]), key
     # all-pairs DescriptorDistance
     Hm = M.ORBmatcher.DescriptorDistance(ex, dL[:40], dR[:50])
     assert np.array_equal(Hm, np.unpackbits(dL[:40, None, :] ^ dR[None, :50, :], axis=2).sum(2))

@@ -126,6 +126,20 @@ def test_fisheye_knn_ratio(hip_lib):
         for key in ref:
             assert np.array_equal(out[key][0, :nq], ref[key]), key
         assert ref["ratio_ok"].sum() > 50
+    # several pairs per call, the matrix-core kernel (default) against the wave-per-query kernel on the vector units and against the oracle
+    pairs = [synth.stereo_pair(512, 512, seed=30 + i) for i in range(3)]
+    res = ex.extract_batch(np.stack([p[0] for p in pairs] + [p[1] for p in pairs]), (40, 470))
+    out = M.StereoFishEyeKnn(ex, ex, 0, 3, 3)
+    ex.debug_stereo_flags(8)
+    out2 = M.StereoFishEyeKnn(ex, ex, 0, 3, 3)
+    ex.debug_stereo_flags(0)
+    for key in out:
+        assert np.array_equal(out[key], out2[key]), key
+    for i in range(3):
+        (mL, kL, dL), (mR, kR, dR) = res[i], res[3 + i]
+        ref = ol.oracle_knn2(dL[mL:], dR[mR:])
+        for key in ref:
+            assert np.array_equal(out[key][i, :len(dL) - mL], ref[key]), (i, key)
 
 
 def test_hamming_matrix(hip_lib):
