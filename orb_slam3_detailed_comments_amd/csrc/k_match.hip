@@ -400,13 +400,25 @@ __global__ void __launch_bounds__(256) k_kb8_stereo(const KeyPointRec* __restric
                                                     const int* __restrict__ idx0, const uint8_t* __restrict__ ratio_ok, KB8StereoParams P,
                                                     int* __restrict__ l2r, int* __restrict__ r2l, float* __restrict__ depth, float* __restrict__ p3d,
                                                     int* __restrict__ nmatches) {
+    // Only the queries that passed the ratio test are triangulated (a fifth of the lapping keypoints, scattered): the workgroup first lists them, then
+    // its first threads take one listed query each, so that the long fp64 path runs in full waves instead of in a few lanes of every wave.
+    __shared__ int s_list[256];
+    __shared__ int s_n;
     const int b = (int)blockIdx.y, i = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (i >= cap) return;
-    const size_t o = (size_t)b * cap + i;
-    int match = -1; float d = -1.0f, X[3] = {0.f, 0.f, 0.f};
-    const int q = i - monoL[b];                                  // query row of the kNN (lapping keypoints start at monoLeft)
-    if (i < nL[b] && q >= 0 && ratio_ok[(size_t)b * cap + q]) {
-        const int j = idx0[(size_t)b * cap + q] + monoR[b];
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    if (i < cap) {
+        const size_t o = (size_t)b * cap + i;
+        l2r[o] = -1; depth[o] = -1.0f;
+        p3d[3 * o] = 0.f; p3d[3 * o + 1] = 0.f; p3d[3 * o + 2] = 0.f;
+        const int q = i - monoL[b];                              // query row of the kNN (lapping keypoints start at monoLeft)
+        if (i < nL[b] && q >= 0 && ratio_ok[(size_t)b * cap + q]) s_list[atomicAdd(&s_n, 1)] = i;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < s_n) {
+        const int i2 = s_list[threadIdx.x];
+        const size_t o = (size_t)b * cap + i2;
+        const int j = idx0[(size_t)b * cap + (i2 - monoL[b])] + monoR[b];
         const KeyPointRec kl = kpsL[o], kr = kpsR[(size_t)b * cap + j];
         KB8Cam c1, c2;
 #pragma unroll
@@ -416,13 +428,12 @@ __global__ void __launch_bounds__(256) k_kb8_stereo(const KeyPointRec* __restric
         kb8_unproject(c2, kr.x, kr.y, r2);
         const float z = kb8_triangulate_matches(c1, c2, r1, r2, kl.x, kl.y, kr.x, kr.y, P.R12, P.t12, P.sigma2[kl.octave], P.sigma2[kr.octave], p);
         if (z > 0.0001f) {
-            match = j; d = z; X[0] = p[0]; X[1] = p[1]; X[2] = p[2];
-            atomicMax(&r2l[(size_t)b * cap + j], i);
+            l2r[o] = j; depth[o] = z;
+            p3d[3 * o] = p[0]; p3d[3 * o + 1] = p[1]; p3d[3 * o + 2] = p[2];
+            atomicMax(&r2l[(size_t)b * cap + j], i2);
             atomicAdd(&nmatches[b], 1);
         }
     }
-    l2r[o] = match; depth[o] = d;
-    p3d[3 * o] = X[0]; p3d[3 * o + 1] = X[1]; p3d[3 * o + 2] = X[2];
 }
 
 // ---------------------------------------------------------------------------------------------------
