@@ -2,8 +2,9 @@
 // (reference ComputeKeyPointsOctTree, src/ORBextractor.cc:1061-1166, on top of cv::FAST(img, kps, th, nonmaxSuppression = true)).
 //
 // Per cell (one single-wave workgroup), F2 of SURVEY.md: result = {p : s(p) >= iniTh and p a strict 3x3 maximum} if that set is not empty,
-// else the same with minTh, where s() = OpenCV's cornerScore (0 if the pixel is not a corner at min(iniTh, minTh)), neighbours outside the
-// cell's detectable interior count as 0, and the output order is row-major.
+// else the same with minTh, where s() = OpenCV's cornerScore (0 if the pixel is not a corner at the threshold of the run), neighbours
+// outside the cell's detectable interior count as 0, and the output order is row-major.  The phases below run at t0 = iniTh; a cell that
+// yields nothing runs them again at t0 = minTh (the reference's own order; rare on textured imagery).
 //
 // Instruction budget.  On gfx950 only the two-operand VOP2 integer forms (v_add/sub/and/or/xor/lshr/mov) issue in ~2.5 clk per wave64;
 // every VOP3 form (v_perm, v_bitop3, v_lshl_or, v_bfe, v_mbcnt, all packed 16-bit ops, v_cmp) takes ~4.4 clk (profiles/r02/valu_survey.txt).
@@ -16,8 +17,8 @@
 //         (no prefix scan, no per-lane counters).
 //   B     exact cornerScore of the listed pixels, two per lane in packed 16-bit lanes (3-input packed min / max), whenever the list is
 //         full and at the end; pixels with a positive score are compacted, in place, to the corner list at the front of the list.
-//   C     strict 3x3 NMS of the corners on the score tile; survivors set a bit in a row-major bitmap (two bitmaps: s >= minTh, s >= iniTh)
-//   D     threshold choice + output in bitmap (= row-major = reference) order: popcount, wave prefix sum, bit extraction.
+//   C     strict 3x3 NMS of the corners on the score tile; survivors set a bit in a row-major bitmap
+//   D     output in bitmap (= row-major = reference) order: popcount, wave prefix sum, bit extraction.
 // Cells with more corners than the list holds (noise) give the corner list up: NMS and compaction then scan the score tile.
 #include "orbx_types.h"
 #include "orbx_block.h"
@@ -72,11 +73,25 @@ template <int WPC>
 __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, const uint8_t* __restrict__ img, int iniTh, int minTh,
                                           uint32_t* __restrict__ out, int* __restrict__ count_out, uint8_t* smem, int tile_bytes, int list_bytes) {
     const int lane = (int)threadIdx.x & 63;
-    const int iw = ci.x1 - ci.x0, ih = ci.y1 - ci.y0, wh = ih + 6, npix = iw * ih;
-    const int gx0 = (ci.x0 - 3) & ~3, gx1 = (ci.x1 + 3 + 3) & ~3;      // dword-aligned window
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int base = 0;
+    // The reference runs FAST at iniTh and, for a cell that yields nothing, again at minTh (:1135-1148).  A corner at threshold t is a pixel
+    // with cornerScore >= t, and a strict 3x3 maximum with score >= t has no neighbour that a lower threshold could add above it, so the
+    // first run only needs the pixels that are corners at iniTh: the quick test and the list work at t0 = iniTh (the headline workload:
+    // -23 % survivors, -29 % corners against t0 = minTh; every cell has corners at 20), and only a cell that comes out empty is done again
+    // at minTh, window reload included (the bitmaps of phase C have overwritten the tile by then).  Wave-uniform loop.
+    int cx0 = ci.x0, cx1 = ci.x1, cy0 = ci.y0, cy1 = ci.y1;
+    for (int pass = 0;; pass++) {
+#ifndef ORBX_EMU
+    // the cell rectangle is made opaque per run: everything derived from it is then computed inside the run, as in a straight-line kernel,
+    // instead of being hoisted out of this loop and kept alive (and spilled) across all phases
+    asm volatile("" : "+s"(cx0), "+s"(cx1), "+s"(cy0), "+s"(cy1));
+#endif
+    const int iw = cx1 - cx0, ih = cy1 - cy0, wh = ih + 6, npix = iw * ih;
+    const int gx0 = (cx0 - 3) & ~3, gx1 = (cx1 + 3 + 3) & ~3;          // dword-aligned window
     const int wpr = gx1 - gx0;                              // window bytes per row
     const int wp = WPC ? WPC : wpr, wpd = wp >> 2;          // LDS pitch
-    const int xo = (ci.x0 - 3) - gx0;                       // tile column of the window's first pixel (0..3)
+    const int xo = (cx0 - 3) - gx0;                         // tile column of the window's first pixel (0..3)
     // LDS: 16 bytes of padding (the dword left of a row start is read, never used) | window tile, raw bytes | score tile | survivor / corner
     // list.  The bitmaps of phases C / D and the keep flags of the list-free NMS live in the window tile, which is dead by then.
     uint8_t* tile = smem + 16;
@@ -89,13 +104,14 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
     const int list_cap = list_bytes >> 1;                   // entries
 #endif
     uint32_t* tile32 = (uint32_t*)tile;
+    const int t0 = pass == 0 ? iniTh : minTh;
     // ---- load ----  aligned dwords of the window -> tile
     if (WPC) {
         // (WPC / 4) dword columns x 5 rows per pass, four passes (20 rows) in flight per lane
         constexpr int kCols = WPC ? WPC / 4 : 1;
         const int r0 = lane / kCols, c = lane - r0 * kCols;
         if (r0 < 5 && 4 * c < wpr) {
-            const uint8_t* src = img + (uint32_t)(mul24(ci.y0 - 3 + r0, L.pitch) + gx0 + 4 * c);
+            const uint8_t* src = img + (uint32_t)(mul24(cy0 - 3 + r0, L.pitch) + gx0 + 4 * c);
             const uint32_t step = (uint32_t)L.pitch * 5u;
             int lo = r0 * kCols + c;
             for (int r = r0; r < wh; r += 20) {
@@ -116,7 +132,7 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
                 const int i = i0 + k * kFastThreads;
                 if (i < wh * wpd) {
                     const int r = (int)((unsigned)mul24(i, (int)Mw) >> 20), c = i - mul24(r, wpd);
-                    v[k] = *(const uint32_t*)(img + (uint32_t)(mul24(ci.y0 - 3 + r, L.pitch) + gx0 + 4 * c));
+                    v[k] = *(const uint32_t*)(img + (uint32_t)(mul24(cy0 - 3 + r, L.pitch) + gx0 + 4 * c));
                 }
             }
 #pragma unroll
@@ -127,7 +143,6 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
     // score offset = tile offset - 2 * wp and the 3x3 NMS reads its 8 neighbours at fixed offsets without bounds tests
     for (int i = lane; i < (sc_bytes + 3) >> 2; i += kFastThreads) ((uint32_t*)sc)[i] = 0u;
     ORBX_WAVE_SYNC();
-    const int t0 = imin(iniTh, minTh);
     // exact score of two (pixel, polarity) entries in the two halves of packed registers
     auto score2 = [&](int eA, int eB, int& sA, int& sB) {
         // a bright candidate is scored on the inverted image (byte ^ 0xFF); the bias that makes every operand a positive binary16 pattern
@@ -270,16 +285,13 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
     }
     ORBX_WAVE_SYNC();
     score_pending();
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    int base = 0;
     if (corners_listed) {
-        // ---- C ----  cell-local strict 3x3 NMS of the corners; survivors mark their (row-major) score offset in two bitmaps
-        uint32_t* bm_lo = tile32;                                      // bit o: corner at score offset o survived with s >= minTh
+        // ---- C ----  cell-local strict 3x3 NMS of the corners (every listed pixel has a score >= t0); survivors mark their (row-major)
+        // score offset in a bitmap
+        uint32_t* bm = tile32;                                         // bit o: corner at score offset o survived
         const int nwords = (sc_bytes + 31) >> 5;
-        uint32_t* bm_hi = bm_lo + nwords;                              // ... with s >= iniTh
-        for (int i = lane; i < 2 * nwords; i += kFastThreads) bm_lo[i] = 0u;
+        for (int i = lane; i < nwords; i += kFastThreads) bm[i] = 0u;
         ORBX_WAVE_SYNC();
-        int any_hi = 0;
         for (int i = lane; i < nc; i += kFastThreads) {
             const int o = list[i];
             const uint8_t* c = sc + o;
@@ -287,16 +299,10 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
             // neighbours outside the cell interior are the zero frame
             const int m0 = imax(imax((int)c[-wp - 1], (int)c[-wp]), imax((int)c[-wp + 1], (int)c[-1]));
             const int m1 = imax(imax((int)c[1], (int)c[wp - 1]), imax((int)c[wp], (int)c[wp + 1]));
-            if (s > imax(m0, m1)) {
-                const uint32_t bit = 1u << (o & 31);
-                if (s >= minTh) atomicOr(&bm_lo[o >> 5], bit);
-                if (s >= iniTh) { atomicOr(&bm_hi[o >> 5], bit); any_hi = 1; }
-            }
+            if (s > imax(m0, m1)) atomicOr(&bm[o >> 5], 1u << (o & 31));
         }
         ORBX_WAVE_SYNC();
-        // ---- D ----  threshold choice of the reference (FAST at iniTh; if that yields nothing, FAST at minTh, :1135-1148), output in
-        // bitmap order = row-major order of the pixels
-        const uint32_t* bm = ORBX_BALLOT(any_hi) != 0ull ? bm_hi : bm_lo;
+        // ---- D ----  output in bitmap order = row-major order of the pixels
         for (int w0 = 0; w0 < nwords; w0 += kFastThreads) {
             const int w = w0 + lane;
             uint32_t bits = w < nwords ? bm[w] : 0u;
@@ -308,7 +314,7 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
                 bits &= bits - 1u;
                 const int o = 32 * w + b;
                 const int y1 = o / (WPC ? WPC : wp), col = o - y1 * wp;      // score row (interior y + 1), tile column
-                out[pos++] = key_pack(ci.x0 + (col - (xo + 3)) - kBorder, ci.y0 + (y1 - 1) - kBorder, (int)sc[o]);
+                out[pos++] = key_pack(cx0 + (col - (xo + 3)) - kBorder, cy0 + (y1 - 1) - kBorder, (int)sc[o]);
             }
             base += ORBX_READLANE(incl, 63);
         }
@@ -316,7 +322,6 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
         // ---- C', D' ----  the same over every interior pixel (cells so dense that their corners do not fit the list)
         const unsigned Mi = (1u << 20) / (unsigned)iw + 1u;     // i / iw == (i * Mi) >> 20 exactly for i < 2^13
         uint8_t* kf = tile;                                     // one keep flag per score-tile byte
-        int any_hi = 0;
         for (int i = lane; i < npix; i += kFastThreads) {
             const int y = (int)((unsigned)mul24(i, (int)Mi) >> 20), x = i - mul24(y, iw);
             const int o = (y + 1) * wp + xo + 3 + x;
@@ -324,12 +329,9 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
             const int s = c[0];
             const int m0 = imax(imax((int)c[-wp - 1], (int)c[-wp]), imax((int)c[-wp + 1], (int)c[-1]));
             const int m1 = imax(imax((int)c[1], (int)c[wp - 1]), imax((int)c[wp], (int)c[wp + 1]));
-            const int keep = s > imax(m0, m1);
-            kf[o] = (uint8_t)keep;
-            any_hi |= (keep && s >= iniTh);
+            kf[o] = (uint8_t)(s > imax(m0, m1));
         }
         ORBX_WAVE_SYNC();
-        const int thr = ORBX_BALLOT(any_hi) != 0ull ? iniTh : minTh;
         for (int i0 = 0; i0 < npix; i0 += kFastThreads) {
             const int i = i0 + lane;
             int flag = 0, x = 0, y = 0, s = 0;
@@ -337,12 +339,15 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
                 y = (int)((unsigned)mul24(i, (int)Mi) >> 20); x = i - mul24(y, iw);
                 const int o = (y + 1) * wp + xo + 3 + x;
                 s = sc[o];
-                flag = kf[o] && s >= thr;
+                flag = kf[o];
             }
             const unsigned long long bal = ORBX_BALLOT(flag);
-            if (flag) out[base + __popcll(bal & lt)] = key_pack(ci.x0 + x - kBorder, ci.y0 + y - kBorder, s);
+            if (flag) out[base + __popcll(bal & lt)] = key_pack(cx0 + x - kBorder, cy0 + y - kBorder, s);
             base += __popcll(bal);
         }
+    }
+    if (base > 0 || pass == 1 || minTh >= iniTh) break;
+    ORBX_WAVE_SYNC();                                           // the second run reloads the window over the bitmap / keep flags
     }
     if (lane == 0) *count_out = base;
 }

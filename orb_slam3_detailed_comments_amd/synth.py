@@ -161,6 +161,29 @@ def natural_stereo_pair(w=752, h=480, seed=0, band=48, max_disp=60, **kw):
     return cv(left), cv(right)
 
 
+def threshold_blocks(w=376, h=240, seed=0, block=37):
+    """Dots on a flat background, one kind per block of about one FAST cell: nothing; weak dots (contrast 9-17: corners at minThFAST = 7 only -
+    the cell's second FAST run, src/ORBextractor.cc:1143-1148, decides); strong dots (only the first run counts); strong dot PAIRS (two
+    adjacent pixels with equal scores: neither is a strict 3x3 maximum, so a cell can hold corners at iniThFAST and still come out empty
+    and fall back); and mixtures of these."""
+    rng = np.random.default_rng(seed)
+    a = np.full((h, w), 60, np.uint8)
+    for by in range(0, h - block + 1, block):
+        for bx in range(0, w - block + 1, block):
+            kind = int(rng.integers(0, 6))
+            def spot():
+                return by + int(rng.integers(4, block - 5)), bx + int(rng.integers(4, block - 5))
+            if kind in (1, 3, 4):                       # weak single dots
+                for _ in range(int(rng.integers(1, 4))):
+                    y, x = spot(); a[y, x] = 60 + int(rng.integers(9, 18))
+            if kind in (2, 3):                          # strong single dots
+                for _ in range(int(rng.integers(1, 3))):
+                    y, x = spot(); a[y, x] = 60 + int(rng.integers(40, 150))
+            if kind in (4, 5):                          # strong tied pairs
+                y, x = spot(); v = 60 + int(rng.integers(40, 150)); a[y, x] = v; a[y, x + 1] = v
+    return a
+
+
 _RING = ((0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3))
 
 

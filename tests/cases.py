@@ -10,6 +10,7 @@ FULL_CASES = [
     ("tumvi_512_n1500_lap", lambda: synth.corner_field(512, 512, seed=3), 1500, (0, 511)),
     ("tum_640x480_n1000", lambda: synth.corner_field(640, 480, seed=4), 1000, (0, 0)),
     ("pink_noise_752x480_n1200", lambda: synth.pink_noise(seed=6), 1200, (0, 0)),
+    ("threshold_fallback_752x480", lambda: synth.threshold_blocks(752, 480, seed=7), 1200, (0, 0)),
     ("euroc_mono_600x350_n5000_init", lambda: synth.corner_field(600, 350, seed=5), 5000, (0, 1000)),
 ]
 
@@ -30,6 +31,7 @@ SMALL_CASES = [
     ("small_square_512", lambda: synth.corner_field(300, 300, seed=14, nrect=700), 300, (0, 299)),
     ("small_280x260_wide_cells", lambda: synth.corner_field(280, 260, seed=16, nrect=500), 300, (0, 0)),   # upper levels: one 60-px cell (128-byte FAST tile pitch)
     ("small_pink_noise", lambda: synth.pink_noise(376, 240, seed=17, beta=1.3), 500, (0, 0)),
+    ("small_threshold_fallback", lambda: synth.threshold_blocks(376, 240, seed=18), 500, (0, 0)),   # cells that need the second FAST run at minThFAST
     ("small_wide_nini3", lambda: synth.corner_field(640, 250, seed=15, nrect=900), 600, (0, 0)),
 ]
 

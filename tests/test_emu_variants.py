@@ -60,7 +60,11 @@ def test_fast_list_flush_path(tmp_path, cap):
     so = str(tmp_path / "liborbx_emu_smalllist.so")
     build_emu_variant(so, ["-DORBX_FAST_LIST_CAP=%d" % cap])
     lib = _lib.OrbxLib(so)
-    for name, factory, nf, lap in SMALL_CASES[:3] + FULL_CASES[:1] + FULL_CASES[4:5]:
+    # low-amplitude noise: next to no corner at iniThFAST, a crowd at minThFAST - the second FAST run of a cell takes the flush / list-free paths
+    low_noise = ("low_noise", lambda: (60 + np.random.default_rng(5).integers(0, 26, (240, 376))).astype(np.uint8), 500, (0, 0))
+    fallback = [c for c in SMALL_CASES if c[0] == "small_threshold_fallback"]
+    assert fallback
+    for name, factory, nf, lap in SMALL_CASES[:3] + FULL_CASES[:1] + FULL_CASES[4:5] + [low_noise] + fallback:
         img = factory()
         got = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib)(img, None, lap)
         exp = ol.OracleExtractor(nf).extract(img, lap)
