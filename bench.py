@@ -174,9 +174,9 @@ def main():
     ap.add_argument("--config", default="stereo", choices=sorted(CONFIGS), help="BASELINE.json configuration (stereo = configs[1] = the headline metric)")
     ap.add_argument("--pairs", type=int, default=128, help="units (stereo pairs, or frames for mono / rgbd) per step per GPU: one step = one batch through the "
                     "whole path (32 -> 52 k, 64 -> 57 k, 96 -> 59 k, 128 -> 60 k pairs/s measured in round 1)")
-    ap.add_argument("--handles", type=int, default=0, help="extractor handles in flight per GPU (each owns its streams).  Default: 4 as a plain process "
-                    "(2 / 3 / 4 / 5 / 6 handles: 68.0 / 75.7 / 80.3 / 70.2 / 69.0 k pairs/s), 3 inside a torch.distributed process, where PyTorch's own "
-                    "streams share the hardware queues and four chains were measured unstable (37-48 k) in round 1")
+    ap.add_argument("--handles", type=int, default=0, help="extractor handles in flight per GPU (each owns its streams).  Default: 4 "
+                    "(2 / 3 / 4 / 5 / 6 handles: 68.0 / 75.7 / 80.3 / 70.2 / 69.0 k pairs/s in round 2), 3 with --allgather: a live RCCL communicator "
+                    "has streams of its own on the same hardware queues and four chains then fall behind three (86 k against 95 k pairs/s)")
     ap.add_argument("--workload", default="corner_field", choices=["corner_field", "natural"], help="synthetic image generator: corner_field = the headline "
                     "workload (random rectangles, 24-52 %% of the pixels are FAST corners at t = 7); natural = 1/f^2 spectrum + sparse edges (1-5 %% corners, "
                     "camera-like statistics) - a second reported line, never the headline")
@@ -218,12 +218,20 @@ def main():
                 raise SystemExit("bench.py: %d ranks but %d visible GPU(s); one process per GPU (ORBX_BENCH_BACKEND=gloo lets ranks share a device in "
                                  "protocol tests)" % (world, ndev))
             torch.cuda.set_device(local)                # rank -> GPU: LOCAL_RANK
-            dist_.init_process_group("nccl", device_id=torch.device("cuda", local), **kw)
+            # The hot path has no collective: ranks only meet at the barriers around the timed region and in the max over ranks, and those go
+            # over CPU tensors (gloo).  The RCCL communicator is created lazily, by the first collective on device tensors (--allgather), so
+            # a plain scaling run has no RCCL streams competing with the extractors' hardware queues: with the communicator alive four
+            # handles per GPU fall from 101 k to 86 k pairs/s (three: 95 k), without it a rank runs as a plain process does
+            # (profiles/r03_final/dist_handles.txt).
+            dist_.init_process_group("cpu:gloo,cuda:nccl", **kw)
         else:
             local = 0
             dist_.init_process_group(backend, **kw)
         dist = dist_
-        dist_dev = "cuda" if backend == "nccl" else "cpu"
+        dist_on_gpu = backend == "nccl"
+
+        def dist_barrier():                             # an all-reduce over CPU tensors: every rank has to arrive
+            dist_.all_reduce(torch.zeros(1))
 
     from orb_slam3_detailed_comments_amd import ORBextractor, load_hip, synth, _lib
     from orb_slam3_detailed_comments_amd import matcher as M
@@ -252,7 +260,7 @@ def main():
     probe = [batch[i] if batch.ndim == 3 else batch[i][..., 1] for i in range(min(4, len(batch)))]
     fast_density = float(np.mean([synth.fast_corner_density(im, MIN) for im in probe]))
     NIMG = 2 * P if paired else P
-    NH = args.handles if args.handles > 0 else (3 if dist is not None else 4)
+    NH = args.handles if args.handles > 0 else (3 if (dist is not None and args.allgather) else 4)
     handles = [ORBextractor(NFEAT, SCALE, NLEVELS, INI, MIN, device_id=local, lib=lib) for _ in range(NH)]
     if kind == "rgbd":
         for h in handles:
@@ -368,7 +376,7 @@ def main():
     ag_stream = None
     if args.allgather:
         from orb_slam3_detailed_comments_amd import multi
-        if dist_dev == "cuda":
+        if dist_on_gpu:
             import torch
             ag_stream = torch.cuda.Stream()
 
@@ -417,10 +425,10 @@ def main():
         for h in handles:
             h.sync()
         if dist is not None:
-            if dist_dev == "cuda":
+            if dist_on_gpu:
                 import torch
                 torch.cuda.synchronize()
-            dist.barrier()
+            dist_barrier()
 
     def timed(nsteps, h2d, min_seconds=0.0):
         """W untimed warm-up steps, then ONE timed region of `repeats` whole blocks of nsteps steps between two barriers (repeats = 1 unless the
@@ -437,7 +445,7 @@ def main():
             repeats = int(min(max(1, np.ceil(min_seconds / max(tw / nwarm * nsteps, 1e-6))), 10000))
         if dist is not None:                       # every rank times the same number of steps
             import torch
-            t = torch.tensor([repeats], dtype=torch.int64, device=dist_dev)
+            t = torch.tensor([repeats], dtype=torch.int64, device="cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             repeats = int(t.item())
             sync_all()
@@ -458,7 +466,7 @@ def main():
     dt, per_step, repeats = timed(args.steps, args.h2d, args.min_seconds)
     if dist is not None:
         import torch
-        t = torch.tensor([dt], dtype=torch.float64, device=dist_dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -475,7 +483,7 @@ def main():
                 w.wait()
         sync_all()
         ta = (time.perf_counter() - ta) / nrep
-        t = torch.tensor([ta], dtype=torch.float64, device=dist_dev)
+        t = torch.tensor([ta], dtype=torch.float64, device="cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         blk_bytes = NIMG * cap * 32 + NIMG * 4
         ag_alone = {"ms_per_batch_alone": round(float(t.item()) * 1e3, 4), "bytes_per_rank": blk_bytes, "bytes_gathered_per_rank": blk_bytes * world,
@@ -599,9 +607,16 @@ def main():
                 res["cpu_baseline"] = cpu_baseline()
             except Exception as e:   # the baseline is reporting only; never fail the bench on it
                 res["cpu_baseline"] = {"value": None, "unit": "stereo pairs/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        # RCCL prints a version banner through C stdio, which is block-buffered when stdout is a pipe and would come out at exit, after the
+        # result: push it out first so that the JSON line is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(res), flush=True)
     if dist is not None:
-        dist.barrier()
+        dist_barrier()
         dist.destroy_process_group()
 
 

@@ -11,7 +11,7 @@ def patch(src, name):
     if name == "base":
         return src
     if name == "load_only":        # return after the tile load
-        return src.replace("    const int t0 = imin(iniTh, minTh);\n", "    const int t0 = imin(iniTh, minTh);\n    if (lane < 64) { if (lane == 0) *count_out = 0; return; }\n", 1)
+        return src.replace("    // exact score of two (pixel, polarity) entries", "    if (lane < 64) { if (lane == 0) *count_out = 0; return; }\n    // exact score of two (pixel, polarity) entries", 1)
     if name == "no_score":         # phase A only: pending entries are dropped instead of scored
         return src.replace("        for (int i0 = pbeg; i0 < cnt; i0 += 2 * kFastThreads) {", "        for (int i0 = pbeg; i0 < cnt && iniTh < 0; i0 += 2 * kFastThreads) {", 1)
     if name == "no_cd":            # no NMS / output
