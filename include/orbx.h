@@ -138,6 +138,11 @@ int orbx_device_id(const orbx_extractor* h);
 int orbx_host_alloc(orbx_extractor* h, size_t bytes, void** hptr);
 int orbx_host_free(orbx_extractor* h, void* hptr);
 
+/* How ComputePyramid (src/ORBextractor.cc:1687-1738) is launched: 0 (default) = by batch size - all levels in one launch for small
+ * batches, where a chain of one launch per level is pure launch latency, one streaming launch per level for large ones; 1 / 2 force
+ * either form (tests compare them).  The levels are bit-identical in every mode. */
+int orbx_set_pyramid_mode(orbx_extractor* h, int mode);
+
 /* Replay the extraction pipeline as one hipGraph (captured on first use, re-captured when the batch size, geometry, input
  * pointer or lapping area change).  Pays off at small batches, where the ~17 kernel launches are latency-bound. */
 int orbx_set_graph_replay(orbx_extractor* h, int on);

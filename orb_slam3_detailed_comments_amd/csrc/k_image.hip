@@ -120,6 +120,143 @@ __global__ void __launch_bounds__(256) k_resize(const LevelInfo* __restrict__ lv
 
 
 // ---------------------------------------------------------------------------------------------------
+// Pyramid, small batches: every level in ONE launch.  A chain of seven dependent launches costs 4.5 us each on this part whatever the
+// work (tools/sync_latency_probe.hip), which is all of the pyramid's 28 us for a single stereo pair.  Level l depends on level l - 1
+// only locally (two taps per axis), so a workgroup that is given a tile of the TOP level can derive everything below it from a window of
+// level 0 alone: the window goes to LDS, each level's region is interpolated from the region of the level before (both in LDS, ping-pong),
+// and every level is partitioned among the tiles (PyrSpan::o0 / o1, built by the host from the tap tables: a tile owns at level l what
+// starts at the left tap of the first pixel it owns at level l + 1), so each workgroup writes the part of each level it owns.  Regions
+// overlap by the taps' reach (about a third more pixels than a level holds); the arithmetic is k_resize's.  Columns are handled as
+// dwords: regions start and end on multiples of 4 and a dword that straddles two owners is written by both, with the same bytes.
+// block kPyrThreads; grid (tiles_x * tiles_y, B); dynamic LDS = bufA + bufB + 8 * (region widths + heights of all levels) + 48 * nlevels.
+__global__ void __launch_bounds__(kPyrThreads) k_pyramid_fused(const LevelInfo* __restrict__ lv, int nlevels, const ResizeTap* __restrict__ xtab,
+                                                       const ResizeTap* __restrict__ ytab, const PyrSpan* __restrict__ xspan,
+                                                       const PyrSpan* __restrict__ yspan, int ntx, uint8_t* __restrict__ pyr, size_t pyr_stride,
+                                                       int buf_a_bytes, int buf_b_bytes, PyrTapOffsets toff) {
+    ORBX_DYN_SMEM(smem);
+    const int tid = (int)threadIdx.x, b = (int)blockIdx.y;
+    const int ty = (int)blockIdx.x / ntx, tx = (int)blockIdx.x - ty * ntx;
+    // taps of every level, rebased to the source regions: per region column (row) the two source offsets (lo | hi << 16) and the weight pair
+    uint32_t* taps = (uint32_t*)(smem + buf_a_bytes + buf_b_bytes);
+    PyrSpan* spx = (PyrSpan*)(taps + 2 * toff.total);                        // this tile's spans, all levels
+    PyrSpan* spy = spx + nlevels;
+    int* lvi = (int*)(spy + nlevels);                                        // per level: w, h, pitch, off, xtab_off, ytab_off (6 ints)
+    int* tox = lvi + 6 * nlevels;                                            // toff.x / toff.y, indexed per lane below
+    int* toy = tox + nlevels;
+    uint8_t* img = pyr + (size_t)b * pyr_stride;
+    // Everything that comes from global memory is fetched up front, in two rounds of independent loads - spans and level records, then the
+    // level-0 window and the taps of all levels - so that the level loop below only touches LDS (a memory latency per level and per table
+    // was most of the first version's 18 us).
+    if (tid < nlevels) spx[tid] = xspan[tx * nlevels + tid];
+    else if (tid < 2 * nlevels) spy[tid - nlevels] = yspan[ty * nlevels + (tid - nlevels)];
+    else if (tid >= 64 && tid < 64 + nlevels) {
+        const LevelInfo L = lv[tid - 64];
+        int* q = lvi + 6 * (tid - 64);
+        q[0] = L.w; q[1] = L.h; q[2] = L.pitch; q[3] = L.off; q[4] = L.xtab_off; q[5] = L.ytab_off;
+    } else if (tid >= 128 && tid < 128 + nlevels) { tox[tid - 128] = toff.x[tid - 128]; toy[tid - 128] = toff.y[tid - 128]; }
+    __syncthreads();
+    {
+        // taps: entry e of the concatenated list [level 1 columns | level 1 rows | level 2 columns | ...]; four entries per thread in flight
+        constexpr int kU = 4;
+        for (int e0 = tid; e0 < toff.total; e0 += kPyrThreads * kU) {
+            ResizeTap t[kU]; int lvl[kU], idx[kU]; bool col[kU];
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+                const int e = e0 + kPyrThreads * u;
+                lvl[u] = 0;
+                if (e < toff.total) {
+                    int l = 1;
+                    while (l + 1 < nlevels && e >= tox[l + 1]) l++;
+                    col[u] = e < toy[l];
+                    idx[u] = e - (col[u] ? tox[l] : toy[l]);
+                    const PyrSpan d = col[u] ? spx[l] : spy[l];
+                    if (idx[u] < d.b - d.a) {                                // (the list is sized for the widest tile)
+                        lvl[u] = l;
+                        t[u] = col[u] ? xtab[lvi[6 * l + 4] + imin(d.a + idx[u], lvi[6 * l] - 1)] : ytab[lvi[6 * l + 5] + d.a + idx[u]];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+                const int l = lvl[u];
+                if (l > 0) {
+                    const int e = e0 + kPyrThreads * u;
+                    const int lim = (col[u] ? lvi[6 * (l - 1)] : lvi[6 * (l - 1) + 1]) - 1, org = col[u] ? spx[l - 1].a : spy[l - 1].a;
+                    const int o0 = imin(imax(t[u].ofs, 0), lim) - org, o1 = imin(imax(t[u].ofs + 1, 0), lim) - org;
+                    taps[2 * e] = (uint32_t)o0 | ((uint32_t)o1 << 16);
+                    taps[2 * e + 1] = (uint32_t)t[u].w;
+                }
+            }
+        }
+        const PyrSpan sx = spx[0], sy = spy[0];
+        const int pitch0 = lvi[2];
+        const int ndw = (sx.b - sx.a) >> 2, n = ndw * (sy.b - sy.a);
+        const unsigned Mc = (1u << 20) / (unsigned)ndw + 1u;                // i / ndw == (i * Mc) >> 20 exactly for i < 2^13 (the host checks the region sizes)
+        const uint8_t* src = img + lvi[3] + mul24(sy.a, pitch0) + sx.a;
+        for (int i0 = tid; i0 < n; i0 += kPyrThreads * kU) {
+            uint32_t v[kU];
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+                const int i = i0 + kPyrThreads * u;
+                if (i < n) {
+                    const int r = (int)((unsigned)mul24(i, (int)Mc) >> 20), c = i - mul24(r, ndw);
+                    v[u] = *(const uint32_t*)(src + mul24(r, pitch0) + 4 * c);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kU; u++) { const int i = i0 + kPyrThreads * u; if (i < n) *(uint32_t*)(smem + 4 * i) = v[u]; }
+        }
+    }
+    __syncthreads();
+    for (int l = 1; l < nlevels; l++) {
+        const int Dw = lvi[6 * l], Dpitch = lvi[6 * l + 2];
+        const PyrSpan dx = spx[l], dy = spy[l];
+        const int sw = spx[l - 1].b - spx[l - 1].a;                          // pitch of the source region
+        const int dw = dx.b - dx.a, dh = dy.b - dy.a;
+        const uint32_t* tapx = taps + 2 * tox[l];
+        const uint32_t* tapy = taps + 2 * toy[l];
+        // (offsets into the one LDS array, not pointers picked from an array: the compiler keeps LDS addressing only that way)
+        const int so = (l & 1) ? 0 : buf_a_bytes, dofs = (l & 1) ? buf_a_bytes : 0;
+        uint8_t* dst = img + lvi[6 * l + 3];
+        const int ndw = dw >> 2, n = ndw * dh;
+        const unsigned Mc = (1u << 20) / (unsigned)ndw + 1u;
+        for (int i = tid; i < n; i += kPyrThreads) {
+            const int r = (int)((unsigned)mul24(i, (int)Mc) >> 20), c = i - mul24(r, ndw);
+            const uint32_t ty0 = tapy[2 * r], tyw = tapy[2 * r + 1];
+            const int s0 = so + mul24((int)(ty0 & 0xFFFFu), sw), s1 = so + mul24((int)(ty0 >> 16), sw);
+            const int b0 = (int)(int16_t)(tyw & 0xFFFFu), b1 = (int)tyw >> 16;
+            // the staged taps of columns beyond the level's width repeat the last column's, so all four pixels are computed without branches
+            // (their sixteen byte reads go out together) and the padding bytes are cleared afterwards
+            uint32_t tx0[4], txw[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { tx0[k] = tapx[2 * (4 * c + k)]; txw[k] = tapx[2 * (4 * c + k) + 1]; }
+            int p00[4], p01[4], p10[4], p11[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int o0 = (int)(tx0[k] & 0xFFFFu), o1 = (int)(tx0[k] >> 16);
+                p00[k] = smem[s0 + o0]; p01[k] = smem[s0 + o1]; p10[k] = smem[s1 + o0]; p11[k] = smem[s1 + o1];
+            }
+            uint32_t out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int a0 = (int)(int16_t)(txw[k] & 0xFFFFu), a1 = (int)txw[k] >> 16;
+                const int h0 = mul24(p00[k], a0) + mul24(p01[k], a1);
+                const int h1 = mul24(p10[k], a0) + mul24(p11[k], a1);
+                int v = ((mul24_forced(b0, h0 >> 4) >> 16) + (mul24_forced(b1, h1 >> 4) >> 16) + 2) >> 2;
+                v = imin(imax(v, 0), 255);
+                out |= (uint32_t)v << (8 * k);
+            }
+            const int x = dx.a + 4 * c, y = dy.a + r;
+            const int nvalid = Dw - x;                                      // columns of this dword inside the level (>= 1)
+            if (nvalid < 4) out &= 0xFFFFFFFFu >> (8 * (4 - nvalid));
+            *(uint32_t*)(smem + dofs + 4 * i) = out;
+            if (y >= dy.o0 && y < dy.o1 && x + 3 >= dx.o0 && x < dx.o1) *(uint32_t*)(dst + mul24(y, Dpitch) + x) = out;
+        }
+        __syncthreads();                                                    // the region of level l is complete
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Pyramid, streaming form (the common case: scale factor <= 2).  A thread owns 4 adjacent output columns and walks down kResizeStrip
 // output rows.  Per source row it loads the 8 source bytes its columns need (one unaligned 8-byte load; neighbouring threads overlap in
 // L1), cuts the two taps of every column out with one v_perm_b32 (as a u16 pair) and forms the horizontal sum with one v_dot2_u32_u16

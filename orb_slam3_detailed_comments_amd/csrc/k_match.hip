@@ -27,43 +27,9 @@ __global__ void __launch_bounds__(256) k_hamming_matrix(const unsigned long long
     out[(size_t)i * nb + j] = hamming256(A + 4 * (size_t)i, Bm + 4 * (size_t)j);
 }
 
-// Row index for the stereo search (the role of vRowIndices, src/Frame.cc:1129-1155): the right keypoints of an image bucketed by the
-// first row of their candidate band (1 << kStereoRowShift rows per bucket, CSR).  A left keypoint at row v then only visits the buckets that can hold
-// bands covering v instead of every right keypoint.  Order inside a bucket is arbitrary (atomics): the search reduces full
-// (distance << 16 | index) keys, in the lanes as well as across them, so the visiting order never shows in the result.
-// grid (B), 256 threads, dynamic LDS = 2 * (nb + 1) ints.
-__global__ void __launch_bounds__(256) k_stereo_rows(const int4* __restrict__ auxR, const int* __restrict__ nR, int cap, int nb,
-                                                     int* __restrict__ bucket_start, int* __restrict__ bucket_items) {
-    ORBX_DYN_SMEM(smem);
-    __shared__ unsigned long long s_scan[20];
-    int* hist = (int*)smem; int* cursor = hist + (nb + 1);
-    const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
-    const int n = nR[b];
-    const int4* ar = auxR + (size_t)b * cap;
-    for (int i = tid; i <= nb; i += 256) hist[i] = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += 256) atomicAdd(&hist[imin(imax(ar[i].x, 0) >> kStereoRowShift, nb - 1)], 1);
-    __syncthreads();
-    int run = 0;
-    for (int c0 = 0; c0 < nb; c0 += 256) {
-        const int c = c0 + tid;
-        const int v = c < nb ? hist[c] : 0;
-        unsigned long long tot;
-        const int ex = run + (int)block_excl_scan<unsigned long long>((unsigned long long)v, &tot, s_scan);
-        if (c < nb) { cursor[c] = ex; bucket_start[(size_t)b * (nb + 1) + c] = ex; }
-        run += (int)tot;
-    }
-    if (tid == 0) bucket_start[(size_t)b * (nb + 1) + nb] = run;
-    __syncthreads();
-    for (int i = tid; i < n; i += 256) {
-        const int pos = atomicAdd(&cursor[imin(imax(ar[i].x, 0) >> kStereoRowShift, nb - 1)], 1);
-        bucket_items[(size_t)b * cap + pos] = i;
-    }
-}
-
-
 // grid (ceil(cap/4), B); one wave per left keypoint.
-// kpsL/descL/nL: left extractor outputs (stride cap); same for right; pyrL/pyrR: raw pyramids.
+// kpsL/descL/nL: left extractor outputs (stride cap); same for right; pyrL/pyrR: raw pyramids; bucket_start / bucket_items: the row index
+// of the right keypoints (k_layout).
 __global__ void __launch_bounds__(256) k_stereo_match(const LevelInfo* __restrict__ lv,
                                                       const KeyPointRec* __restrict__ kpsL, const unsigned long long* __restrict__ descL, const int* __restrict__ nL,
                                                       const KeyPointRec* __restrict__ kpsR, const unsigned long long* __restrict__ descR,

@@ -5,6 +5,9 @@
 #include <mutex>
 #include "orbx_internal.h"
 
+#ifndef ORBX_PYR_FUSED_BATCH
+#define ORBX_PYR_FUSED_BATCH 8     // k_pyramid_fused (all levels in one launch) for batches up to this many images
+#endif
 #ifndef ORBX_RESIZE_STRIP
 #define ORBX_RESIZE_STRIP 16        // k_resize_rows: output rows per wave for large batches
 #endif
@@ -85,6 +88,42 @@ void resize_axis(int ssize, int dsize, bool clamp_edges, std::vector<ResizeTap>&
         a0 = std::min(std::max(a0, -32768), 32767); a1 = std::min(std::max(a1, -32768), 32767);
         ResizeTap t; t.ofs = s; t.w = (a0 & 0xFFFF) | (a1 << 16);
         out.push_back(t);
+    }
+}
+
+// k_pyramid_fused: per tile column (row) of the top level and per level the region a workgroup computes and the interval it owns.
+// Ownership goes down the levels along the left (upper) taps: a tile owns at level l what starts at the left tap of the first pixel it owns
+// at level l + 1, so the intervals of neighbouring tiles meet and cover the level; the region is what the region of the level above reads,
+// widened to the owned interval (scale factors > 2 leave pixels that the next level never reads) and, for columns, to whole dwords.
+void pyramid_spans(const orbx_extractor* h, bool columns, std::vector<PyrSpan>& out, int& ntiles, int* max_extent) {
+    const int nl = h->nlevels, top = nl - 1;
+    auto size_of = [&](int l) { return columns ? h->lv[l].w : h->lv[l].h; };
+    auto taps_of = [&](int l) { return (columns ? h->xtab.data() + h->lv[l].xtab_off : h->ytab.data() + h->lv[l].ytab_off); };   // level l from level l - 1
+    auto lo = [&](int l, int d) { return std::min(std::max(taps_of(l)[d].ofs, 0), size_of(l - 1) - 1); };
+    auto hi = [&](int l, int d) { return std::min(std::max(taps_of(l)[d].ofs + 1, 0), size_of(l - 1) - 1); };
+    const int T = (size_of(top) + kPyrTile - 1) / kPyrTile;
+    ntiles = T;
+    for (int l = 0; l < nl; l++) max_extent[l] = 0;
+    out.assign((size_t)T * nl, PyrSpan{0, 0, 0, 0});
+    std::vector<int> own0((size_t)(T + 1) * nl);
+    for (int t = 0; t <= T; t++) own0[(size_t)t * nl + top] = std::min(t * kPyrTile, size_of(top));
+    for (int l = top - 1; l >= 0; l--)
+        for (int t = 0; t <= T; t++)
+            own0[(size_t)t * nl + l] = t == 0 ? 0 : t == T ? size_of(l) : lo(l + 1, own0[(size_t)t * nl + l + 1]);
+    for (int t = 0; t < T; t++) {
+        int a = 0, b = 0;
+        for (int l = top; l >= 0; l--) {
+            const int o0 = own0[(size_t)t * nl + l], o1 = own0[(size_t)(t + 1) * nl + l];
+            if (l == top) { a = o0; b = o1; }
+            else {
+                const int na = lo(l + 1, a), nb = hi(l + 1, std::min(b, size_of(l + 1)) - 1) + 1;
+                a = l == 0 ? na : std::min(o0, na); b = l == 0 ? nb : std::max(o1, nb);
+            }
+            if (columns) { a &= ~3; b = (b + 3) & ~3; }
+            PyrSpan sp; sp.a = (int16_t)a; sp.b = (int16_t)b; sp.o0 = (int16_t)o0; sp.o1 = (int16_t)o1;
+            out[(size_t)t * nl + l] = sp;
+            max_extent[l] = std::max(max_extent[l], b - a);
+        }
     }
 }
 
@@ -174,17 +213,42 @@ int configure(orbx_extractor* h, int W, int H, int B) {
             }
         }
         h->pyr_stride = off; h->cand_stride = (size_t)cand_off; h->ncells = (int)h->cells.size();
+        h->pyr_fused_ok = false; h->xspan.clear(); h->yspan.clear();
+        if (h->nlevels > 1) {
+            int mw[kMaxLevels], mh[kMaxLevels];
+            pyramid_spans(h, true, h->xspan, h->pyr_ntx, mw);
+            pyramid_spans(h, false, h->yspan, h->pyr_nty, mh);
+            int nt = 0;
+            for (int l = 1; l < h->nlevels; l++) { h->pyr_toff.x[l] = nt; nt += mw[l]; h->pyr_toff.y[l] = nt; nt += mh[l]; }
+            h->pyr_toff.total = nt;
+            // LDS: regions of the even levels in one buffer, of the odd levels in the other; a region must stay below 2^13 dwords (the kernel's
+            // division by multiplication) and the whole below the 64 KB every device grants
+            size_t bufa = 0, bufb = 0, items = 0;
+            for (int tx = 0; tx < h->pyr_ntx; tx++)
+                for (int ty = 0; ty < h->pyr_nty; ty++)
+                    for (int l = 0; l < h->nlevels; l++) {
+                        const PyrSpan& sx = h->xspan[(size_t)tx * h->nlevels + l]; const PyrSpan& sy = h->yspan[(size_t)ty * h->nlevels + l];
+                        const size_t bytes = (size_t)(sx.b - sx.a) * (sy.b - sy.a);
+                        (l & 1 ? bufb : bufa) = std::max(l & 1 ? bufb : bufa, bytes);
+                        items = std::max(items, bytes / 4);
+                    }
+            h->pyr_buf_a = (int)align_up(bufa, 16); h->pyr_buf_b = (int)align_up(bufb, 16);
+            h->pyr_fused_ok = items < 8192 && (size_t)h->pyr_buf_a + h->pyr_buf_b + 8 * (size_t)nt + 48 * (size_t)h->nlevels <= 60000;
+        }
         h->kp_total_cap = kp_off; h->node_cap = node_cap; h->nb_cap = nb_cap;
         h->fast_tile_bytes = (int)align_up((size_t)tile_b, 16); h->fast_inner_bytes = (int)align_up((size_t)inner_b, 16);
         if (h->kp_total_cap >= 65535) { h->kp_total_cap = 0; return fail(ORBX_E_ARG, "nfeatures too large"); }
         int e = 0;
         e |= h->d_lv.ensure(kMaxLevels); e |= h->d_cells.ensure(h->cells.size());
         e |= h->d_xtab.ensure(std::max<size_t>(h->xtab.size(), 1)); e |= h->d_ytab.ensure(std::max<size_t>(h->ytab.size(), 1));
+        e |= h->d_xspan.ensure(std::max<size_t>(h->xspan.size(), 1)); e |= h->d_yspan.ensure(std::max<size_t>(h->yspan.size(), 1));
         if (e) return fail(ORBX_E_DEVICE, "device allocation failed (tables)");
         rt::copy_h2d(h->d_lv.p, h->lv, sizeof(LevelInfo) * kMaxLevels, h->s0);
         rt::copy_h2d(h->d_cells.p, h->cells.data(), sizeof(CellInfo) * h->cells.size(), h->s0);
         if (!h->xtab.empty()) rt::copy_h2d(h->d_xtab.p, h->xtab.data(), sizeof(ResizeTap) * h->xtab.size(), h->s0);
         if (!h->ytab.empty()) rt::copy_h2d(h->d_ytab.p, h->ytab.data(), sizeof(ResizeTap) * h->ytab.size(), h->s0);
+        if (!h->xspan.empty()) rt::copy_h2d(h->d_xspan.p, h->xspan.data(), sizeof(PyrSpan) * h->xspan.size(), h->s0);
+        if (!h->yspan.empty()) rt::copy_h2d(h->d_yspan.p, h->yspan.data(), sizeof(PyrSpan) * h->yspan.size(), h->s0);
         if (rt::stream_sync(h->s0)) return fail(ORBX_E_DEVICE, "table upload failed: %s", rt::last_error());
         h->W = W; h->H = H;                                        // commit
     }
@@ -198,6 +262,7 @@ int configure(orbx_extractor* h, int W, int H, int B) {
         e |= h->d_nm.ensure(2 * b); e |= h->d_status.ensure(4);
         e |= h->d_kps.ensure(b * cap); e |= h->d_desc.ensure(b * cap * 4); e |= h->d_aux.ensure(b * cap * 4);
         e |= h->d_uRight.ensure(b * cap); e |= h->d_depth.ensure(b * cap); e |= h->d_sad.ensure(b * cap); e |= h->d_nmatch.ensure(b);
+        e |= h->d_rowstart.ensure(b * (size_t)((h->H >> kStereoRowShift) + 3)); e |= h->d_rowitems.ensure(b * cap);
         e |= h->d_knn.ensure(4 * b * cap); e |= h->d_ratio.ensure(b * cap);
         e |= h->h_nm.ensure(3 * b + 4); e |= h->d_qtprof.ensure(32);
         if (e) return fail(ORBX_E_DEVICE, "device allocation failed (batch %d of %dx%d)", B, W, H);
@@ -257,7 +322,16 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
     stage_end(h, ST_IMPORT, h->s0);
     rt::event_record(h->ev_import, h->s0);                          // the input images have been consumed
     stage_begin(h, ST_PYRAMID, h->s0);
-    for (int l = 1; l < nl; l++) {
+    // small batches: every level in one launch (a chain of dependent launches costs 4.5 us per level whatever the work); large batches:
+    // the streaming kernel per level (a third of the instructions per pixel, and its launches hide behind the other handles' kernels)
+    const bool fused = nl > 1 && h->pyr_fused_ok && (h->pyramid_mode == 2 || (h->pyramid_mode == 0 && B <= ORBX_PYR_FUSED_BATCH));
+    if (fused) {
+        dim3 grid(h->pyr_ntx * h->pyr_nty, B, 1);
+        const size_t smem = (size_t)h->pyr_buf_a + h->pyr_buf_b + 8 * (size_t)h->pyr_toff.total + 48 * (size_t)nl;
+        ORBX_LAUNCH(k_pyramid_fused, grid, dim3(kPyrThreads, 1, 1), smem, h->s0, (const LevelInfo*)h->d_lv.p, nl, (const ResizeTap*)h->d_xtab.p, (const ResizeTap*)h->d_ytab.p,
+                    (const PyrSpan*)h->d_xspan.p, (const PyrSpan*)h->d_yspan.p, h->pyr_ntx, h->d_pyr.p, h->pyr_stride, h->pyr_buf_a, h->pyr_buf_b, h->pyr_toff);
+    }
+    for (int l = 1; l < nl && !fused; l++) {
         const LevelInfo& L = h->lv[l]; const LevelInfo& S = h->lv[l - 1];
         if (h->resize_rows_ok[l]) {          // streaming form: the taps of 4 adjacent output columns fit an 8-byte source window
             // rows per wave: long strips share more source rows (a strip of n rows computes ~1.2 n + 1 horizontal rows), short ones give
@@ -327,8 +401,10 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
     stage_begin(h, ST_LAYOUT, h->s0);
     {
         dim3 grid(B, 1, 1);
-        ORBX_LAUNCH(k_layout, grid, blk1, 0, h->s0, (const LevelInfo*)h->d_lv.p, nl, (const uint32_t*)h->d_lvl_keys.p, h->kp_total_cap,
-                    (const int*)h->d_lvl_count.p, lap0, lap1, h->d_final_idx.p, h->d_nm.p, h->d_nm.p + h->maxB);
+        // (+ the row index of every image's keypoints for ComputeStereoMatches: k_stereo_match reads the right image's)
+        const int nb = (h->H >> kStereoRowShift) + 2;
+        ORBX_LAUNCH(k_layout, grid, blk1, 2 * (size_t)(nb + 1) * sizeof(int), h->s0, (const LevelInfo*)h->d_lv.p, nl, (const uint32_t*)h->d_lvl_keys.p, h->kp_total_cap,
+                    (const int*)h->d_lvl_count.p, lap0, lap1, h->d_final_idx.p, h->d_nm.p, h->d_nm.p + h->maxB, nb, h->d_rowstart.p, h->d_rowitems.p);
     }
     stage_end(h, ST_LAYOUT, h->s0);
     rt::stream_wait_event(h->s0, h->ev_join);
@@ -397,7 +473,7 @@ void orbx_destroy(orbx_extractor* h) {
         rt::event_destroy(h->ev_fork); rt::event_destroy(h->ev_join); rt::event_destroy(h->ev_done); rt::event_destroy(h->ev_copy); rt::event_destroy(h->ev_import); rt::event_destroy(h->ev_lp);
         rt::stream_destroy(h->s0); rt::stream_destroy(h->s1); rt::stream_destroy(h->s_copy);
     }
-    h->d_lv.release(); h->d_cells.release(); h->d_xtab.release(); h->d_ytab.release(); h->d_pyr.release(); h->d_blur.release(); h->d_stage.release();
+    h->d_lv.release(); h->d_cells.release(); h->d_xtab.release(); h->d_ytab.release(); h->d_xspan.release(); h->d_yspan.release(); h->d_pyr.release(); h->d_blur.release(); h->d_stage.release();
     h->d_slots.release(); h->d_candA.release(); h->d_candB.release(); h->d_lvl_keys.release(); h->d_cell_count.release(); h->d_lvl_count.release();
     h->d_final_idx.release(); h->d_nm.release(); h->d_status.release(); h->d_kps.release(); h->d_desc.release();
     h->d_uRight.release(); h->d_depth.release(); h->d_sad.release(); h->d_nmatch.release(); h->d_knn.release(); h->d_ratio.release();
@@ -479,7 +555,7 @@ int orbx_extract_batch(orbx_extractor* h, int B, const uint8_t* images, int widt
     // is baked into the kernel arguments and re-captured when any of it changes.
     if (h->use_graph && !h->profile && !h->in_active) {
         const bool same = h->graph_exec && h->g_B == B && h->g_images == d_images && h->g_stride == stride && h->g_image_stride == image_stride &&
-                          h->g_lap0 == lap0 && h->g_lap1 == lap1 && h->g_W == h->W && h->g_H == h->H && h->g_pyr == h->d_pyr.p && h->g_gauss == h->gauss_variant && h->g_undist_gen == h->undist_gen;
+                          h->g_lap0 == lap0 && h->g_lap1 == lap1 && h->g_W == h->W && h->g_H == h->H && h->g_pyr == h->d_pyr.p && h->g_gauss == h->gauss_variant && h->g_undist_gen == h->undist_gen && h->g_pyramid_mode == h->pyramid_mode;
         if (!same) {
             if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
             if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
@@ -491,7 +567,7 @@ int orbx_extract_batch(orbx_extractor* h, int B, const uint8_t* images, int widt
                 return fail(ORBX_E_DEVICE, "graph capture/instantiate failed: %s", rt::last_error());
             }
             h->g_B = B; h->g_images = d_images; h->g_stride = stride; h->g_image_stride = image_stride; h->g_lap0 = lap0; h->g_lap1 = lap1;
-            h->g_W = h->W; h->g_H = h->H; h->g_pyr = h->d_pyr.p; h->g_gauss = h->gauss_variant; h->g_undist_gen = h->undist_gen;
+            h->g_W = h->W; h->g_H = h->H; h->g_pyr = h->d_pyr.p; h->g_gauss = h->gauss_variant; h->g_undist_gen = h->undist_gen; h->g_pyramid_mode = h->pyramid_mode;
         }
         if (hipGraphLaunch(h->graph_exec, h->s0) != hipSuccess) return fail(ORBX_E_DEVICE, "graph launch failed: %s", rt::last_error());
         // the records inside the capture belong to the graph; these are the ones other streams can wait on (an upload into the input buffer
@@ -742,6 +818,12 @@ int orbx_device_snapshot(orbx_extractor* h, void* desc_dst, void* n_dst) {
 }
 int orbx_device_id(const orbx_extractor* h) { return h ? (rt::memory_is_host() ? ORBX_DEVICE_HOST : h->device) : ORBX_E_ARG; }
 
+int orbx_set_pyramid_mode(orbx_extractor* h, int mode) {
+    if (!h || mode < 0 || mode > 2) return fail(ORBX_E_ARG, "pyramid mode 0 (by batch size), 1 (one launch per level) or 2 (one launch)");
+    h->pyramid_mode = mode;
+    return ORBX_OK;
+}
+
 int orbx_set_graph_replay(orbx_extractor* h, int on) { if (!h) return ORBX_E_ARG; h->use_graph = on != 0; return ORBX_OK; }
 
 int orbx_profile_enable(orbx_extractor* h, int on) { if (!h) return ORBX_E_ARG; h->profile = on != 0; h->serial = on == 2; return ORBX_OK; }
@@ -816,20 +898,15 @@ int orbm_stereo_match(orbx_extractor* L, int lf, orbx_extractor* R, int rf, int 
     P.debug_flags = L->debug_stereo_flags;
     if (L->profile) rt::event_record(L->ev_stage[ST_MATCH][0], L->s0);
     dim3 grid((cap + 3) / 4, B, 1), blk(256, 1, 1);
-    // row index of the right keypoints (buckets of 1 << kStereoRowShift rows, by the first row of each candidate band)
+    // row index of the right keypoints (buckets of 1 << kStereoRowShift rows, by the first row of each candidate band): built by the
+    // right extractor's k_layout for every image of its batch
     const int nb = (R->H >> kStereoRowShift) + 2;
     const int lookback = (int)std::ceil(4.0f * R->scale[R->nlevels - 1]) + 2;     // tallest band: 2 * (2 * scale) + rounding
-    if (L->d_rowstart.ensure((size_t)B * (nb + 1)) || L->d_rowitems.ensure((size_t)B * cap)) return fail(ORBX_E_DEVICE, "allocation failed");
-    {
-        dim3 gridr(B, 1, 1);
-        ORBX_LAUNCH(k_stereo_rows, gridr, blk, 2 * (size_t)(nb + 1) * sizeof(int), L->s0, (const int4*)(R->d_aux.p + (size_t)rf * cap * 4),
-                    (const int*)(R->d_nm.p + rf), cap, nb, L->d_rowstart.p, L->d_rowitems.p);
-    }
     ORBX_LAUNCH(k_stereo_match, grid, blk, 0, L->s0, (const LevelInfo*)L->d_lv.p,
                 (const KeyPointRec*)(L->d_kps.p + (size_t)lf * cap), (const unsigned long long*)(L->d_desc.p + (size_t)lf * cap * 4), (const int*)(L->d_nm.p + lf),
                 (const KeyPointRec*)(R->d_kps.p + (size_t)rf * cap), (const unsigned long long*)(R->d_desc.p + (size_t)rf * cap * 4),
                 (const int4*)(R->d_aux.p + (size_t)rf * cap * 4), (const int*)(R->d_nm.p + rf),
-                (const int*)L->d_rowstart.p, (const int*)L->d_rowitems.p, nb, lookback, cap, (const uint8_t*)(L->d_pyr.p + (size_t)lf * L->pyr_stride), (const uint8_t*)(R->d_pyr.p + (size_t)rf * R->pyr_stride), L->pyr_stride,
+                (const int*)(R->d_rowstart.p + (size_t)rf * (nb + 1)), (const int*)(R->d_rowitems.p + (size_t)rf * cap), nb, lookback, cap, (const uint8_t*)(L->d_pyr.p + (size_t)lf * L->pyr_stride), (const uint8_t*)(R->d_pyr.p + (size_t)rf * R->pyr_stride), L->pyr_stride,
                 P, L->d_uRight.p, L->d_depth.p, L->d_sad.p);
     dim3 grid2(B, 1, 1);
     ORBX_LAUNCH(k_stereo_median, grid2, blk, 0, L->s0, (const int*)(L->d_nm.p + lf), cap, L->d_uRight.p, L->d_depth.p,

@@ -56,10 +56,17 @@ struct orbx_extractor {
     std::vector<orbx::CellInfo> cells;
     std::vector<orbx::ResizeTap> xtab, ytab;
     bool resize_rows_ok[orbx::kMaxLevels] = {};     // level l can use k_resize_rows (scale factor <= 2)
+    // k_pyramid_fused (small batches: all levels in one launch): tiles of the top level, their regions / owned intervals per level
+    std::vector<orbx::PyrSpan> xspan, yspan;
+    int pyr_ntx = 0, pyr_nty = 0, pyr_buf_a = 0, pyr_buf_b = 0;
+    orbx::PyrTapOffsets pyr_toff = {};
+    bool pyr_fused_ok = false;
+    int pyramid_mode = 0, g_pyramid_mode = 0;       // orbx_set_pyramid_mode: 0 = by batch size, 1 = one launch per level, 2 = one launch
     size_t pyr_stride = 0, cand_stride = 0;
     int ncells = 0, kp_total_cap = 0, node_cap = 0, nb_cap = 1, fast_tile_bytes = 0, fast_inner_bytes = 0;
     // ---- device state ----
     orbx::DevBuf<orbx::LevelInfo> d_lv; orbx::DevBuf<orbx::CellInfo> d_cells; orbx::DevBuf<orbx::ResizeTap> d_xtab, d_ytab;
+    orbx::DevBuf<orbx::PyrSpan> d_xspan, d_yspan;
     orbx::DevBuf<uint8_t> d_pyr, d_blur, d_stage;
     orbx::DevBuf<uint32_t> d_slots, d_candA, d_candB, d_lvl_keys;
     orbx::DevBuf<int> d_cell_count, d_lvl_count, d_final_idx, d_nm, d_status;
@@ -94,7 +101,7 @@ struct orbx_extractor {
     // input pre-step (orbx_set_input): channels / colour order / grey coefficients / geometry, device maps or taps, intermediate frame
     bool in_active = false; int in_channels = 1, in_rgb = 1, in_gray_variant = 0, in_geometry = 0, in_out_w = 0, in_out_h = 0, in_tap_w = 0, in_tap_h = 0;
     orbx::DevBuf<float> d_mapx, d_mapy; orbx::DevBuf<orbx::ResizeTap> d_in_xt, d_in_yt; orbx::DevBuf<uint8_t> d_frame;
-    orbx::DevBuf<int> d_rowstart, d_rowitems;   // row index of the right keypoints (k_stereo_rows)
+    orbx::DevBuf<int> d_rowstart, d_rowitems;   // row index of every image's keypoints for the stereo search (k_layout -> k_stereo_match)
     // batched SearchLocalPoints (orbm_search_local_points_batch): one device block, one pinned result block, the size of the last enqueue
     orbx::DevBuf<uint8_t> d_lp, d_depth_in; orbx::HostBuf<uint8_t> h_lp_in, h_lp_out;
     size_t lp_pool = 0; int lp_B = 0, lp_M = 0, lp_first = 0; size_t lp_o_counter = 0, lp_o_view = 0; bool lp_pending = false, lp_want_view = false;

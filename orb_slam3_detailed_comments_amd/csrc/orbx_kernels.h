@@ -13,6 +13,17 @@ __global__ void k_resize(const LevelInfo* __restrict__ lv, int level, const Resi
 // strip_rows (<= 64): output rows per wave; a block covers 256 columns x 4 strips
 __global__ void k_resize_rows(const LevelInfo* __restrict__ lv, int level, const ResizeTap* __restrict__ xtab,
                               const ResizeTap* __restrict__ ytab, uint8_t* __restrict__ pyr, size_t pyr_stride, int strip_rows);
+#ifndef ORBX_PYR_THREADS
+#define ORBX_PYR_THREADS 512
+#endif
+#ifndef ORBX_PYR_TILE
+#define ORBX_PYR_TILE 16
+#endif
+constexpr int kPyrTile = ORBX_PYR_TILE;        // k_pyramid_fused: a workgroup's tile of the top pyramid level
+constexpr int kPyrThreads = ORBX_PYR_THREADS;  // ... and its threads (the tile is a latency problem: many waves per tile)
+__global__ void k_pyramid_fused(const LevelInfo* __restrict__ lv, int nlevels, const ResizeTap* __restrict__ xtab, const ResizeTap* __restrict__ ytab,
+                                const PyrSpan* __restrict__ xspan, const PyrSpan* __restrict__ yspan, int ntx, uint8_t* __restrict__ pyr, size_t pyr_stride,
+                                int buf_a_bytes, int buf_b_bytes, PyrTapOffsets toff);
 #ifndef ORBX_FAST_XCD_RUN
 #define ORBX_FAST_XCD_RUN 4
 #endif
@@ -41,11 +52,12 @@ __global__ void k_quadtree(const LevelInfo* __restrict__ lv, const CellInfo* __r
                            int wide, int counter_bytes);
 __global__ void k_layout(const LevelInfo* __restrict__ lv, int nlevels, const uint32_t* __restrict__ lvl_keys,
                          int kp_total_cap, const int* __restrict__ lvl_count, int lap0, int lap1,
-                         int* __restrict__ final_idx, int* __restrict__ n_out, int* __restrict__ mono_out);
+                         int* __restrict__ final_idx, int* __restrict__ n_out, int* __restrict__ mono_out,
+                         int nb, int* __restrict__ row_start, int* __restrict__ row_items);
 #ifndef ORBX_STEREO_ROW_SHIFT
 #define ORBX_STEREO_ROW_SHIFT 3
 #endif
-constexpr int kStereoRowShift = ORBX_STEREO_ROW_SHIFT;   // k_stereo_rows / k_stereo_match: right keypoints are bucketed by (first row of their band) >> shift
+constexpr int kStereoRowShift = ORBX_STEREO_ROW_SHIFT;   // k_layout / k_stereo_match: right keypoints are bucketed by (first row of their band) >> shift
 constexpr int kKpPerWaveDecl = 8;      // must equal kKpPerWave in k_describe.hip
 constexpr int kKpPerWaveSmallDecl = 2; // keypoints per wave of k_orient_brief_small
 __global__ void k_orient_brief(const LevelInfo* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,
@@ -63,8 +75,6 @@ __global__ void k_orient_brief_small(const LevelInfo* __restrict__ lv, int nleve
 __global__ void k_undistort(const KeyPointRec* __restrict__ kps, const int* __restrict__ n_per_frame, int cap, UndistortParams U, KeyPointRec* __restrict__ kps_un);
 __global__ void k_hamming_matrix(const unsigned long long* __restrict__ A, int na,
                                  const unsigned long long* __restrict__ Bm, int nb, int* __restrict__ out);
-__global__ void k_stereo_rows(const int4* __restrict__ auxR, const int* __restrict__ nR, int cap, int nb, int* __restrict__ bucket_start,
-                              int* __restrict__ bucket_items);
 __global__ void k_stereo_match(const LevelInfo* __restrict__ lv, const KeyPointRec* __restrict__ kpsL,
                                const unsigned long long* __restrict__ descL, const int* __restrict__ nL,
                                const KeyPointRec* __restrict__ kpsR, const unsigned long long* __restrict__ descR,

@@ -46,6 +46,11 @@ struct CellInfo {
 // Resize coefficient entry: source index + two 11-bit fixed-point weights (a0 | a1 << 16).
 struct ResizeTap { int ofs; int w; };
 
+// k_pyramid_fused: what one tile column (or row) of the top level computes and owns at one level: region [a, b) (for columns a and b are
+// multiples of 4), owned interval [o0, o1).  Index: tile * nlevels + level; level 0 carries the window to load (nothing of it is written).
+struct PyrSpan { int16_t a, b, o0, o1; };
+struct PyrTapOffsets { int x[kMaxLevels], y[kMaxLevels], total; };   // first LDS tap entry of a level's region columns / rows (sized for the widest tile)
+
 struct KeyPointRec { float x, y, size, angle, response; int32_t octave, class_id; };   // = OrbxKeyPoint, 28 B
 
 struct BlurTaps { int k[7]; };                       // 7-tap Gaussian, 8-bit fixed point

@@ -180,6 +180,10 @@ class ORBextractor:
         """Test switches of the stereo row search (orbx_debug_stereo_flags)."""
         self._lib.check(self._lib.L.orbx_debug_stereo_flags(self._h, int(flags)))
 
+    def pyramid_mode(self, mode):
+        """0 = by batch size (default), 1 = one launch per pyramid level, 2 = all levels in one launch (orbx_set_pyramid_mode)."""
+        self._lib.check(self._lib.L.orbx_set_pyramid_mode(self._h, int(mode)))
+
     def graph_replay(self, on=True):
         """Replay the extraction pipeline as one hipGraph (small-batch latency)."""
         self._lib.check(self._lib.L.orbx_set_graph_replay(self._h, int(on)))

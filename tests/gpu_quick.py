@@ -92,3 +92,15 @@ for graph in (False, True):
         ex.enqueue(None, (0,0), device_ptr=dptr, shape=pair.shape); lib.check(lib.L.orbm_stereo_match(ex._h, 0, ex._h, 1, 1, bf, b)); ex.sync()
     dt = (time.time() - t) / K
     print('single pair, graph=%s: %.3f ms per pair (sync each), %.0f pairs/s' % (graph, dt * 1e3, 1 / dt), flush=True)
+
+# the same with the frames written into pyramid level 0 by the producer (orbx_input_buffer: no import launch), as bench.py keeps its inputs
+ex = ORBextractor(1200,1.2,8,20,7)
+ptr, shp, strd, istrd = ex.input_upload(pair)
+for it in range(5):
+    ex.enqueue(None, (0,0), device_ptr=ptr, shape=shp, stride=strd, image_stride=istrd); lib.check(lib.L.orbm_stereo_match(ex._h, 0, ex._h, 1, 1, bf, b)); ex.sync()
+K = 200
+t = time.time()
+for it in range(K):
+    ex.enqueue(None, (0,0), device_ptr=ptr, shape=shp, stride=strd, image_stride=istrd); lib.check(lib.L.orbm_stereo_match(ex._h, 0, ex._h, 1, 1, bf, b)); ex.sync()
+dt = (time.time() - t) / K
+print('single pair, zero-copy input: %.3f ms per pair (sync each), %.0f pairs/s' % (dt * 1e3, 1 / dt), flush=True)

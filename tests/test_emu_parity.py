@@ -213,3 +213,36 @@ def test_row_ends_of_every_width(emu_lib, width):
         assert np.array_equal(ex.pyramid_level(l), o.level_image(l)), "pyramid level %d" % l
         assert np.array_equal(ex.pyramid_level(l, blurred=True), o.level_image(l, blurred=True)), "blur level %d" % l
     assert _same(got, exp)
+
+
+def _pyramid_modes_case(lib, shapes):
+    """ComputePyramid as one launch (k_pyramid_fused: tiles of the top level, each level partitioned among them) against one launch per level
+    and against the oracle: every level, every byte"""
+    for (w, h, sf, nl, nimg) in shapes:
+        imgs = np.stack([synth.pink_noise(w, h, seed=300 + 7 * s + w, beta=1.0) for s in range(nimg)])
+        levels = {}
+        for mode in (1, 2):
+            ex = ORBextractor(200, sf, nl, 20, 7, lib=lib)
+            ex.pyramid_mode(mode)
+            res = ex.extract_batch(imgs)
+            levels[mode] = [[ex.pyramid_level(l, b) for l in range(nl)] for b in range(nimg)]
+            levels[(mode, "res")] = res
+            ex.close()
+        for b in range(nimg):
+            o = ol.OracleExtractor(200, sf, nl, 20, 7)
+            exp = o.extract(imgs[b])
+            for l in range(nl):
+                assert np.array_equal(levels[2][b][l], o.level_image(l)), ("fused vs oracle", w, h, sf, nl, b, l)
+                assert np.array_equal(levels[1][b][l], levels[2][b][l]), ("fused vs per level", w, h, sf, nl, b, l)
+            assert _same(levels[(2, "res")][b], exp) and _same(levels[(1, "res")][b], exp)
+
+
+def test_pyramid_one_launch_emulated(emu_lib):
+    # (width, height, scale factor, levels, images): widths that are no multiple of 4 on any level, a factor of 2 (taps two apart), more
+    # levels than the reference uses, a single level, two levels, factor 1.5
+    _pyramid_modes_case(emu_lib, [(301, 277, 1.2, 8, 2), (422, 360, 2.0, 3, 1), (600, 520, 1.2, 11, 1), (210, 190, 1.2, 1, 1), (263, 251, 1.5, 2, 3), (417, 233, 1.5, 4, 1)])
+
+
+@pytest.mark.gpu
+def test_pyramid_one_launch_gpu(hip_lib):
+    _pyramid_modes_case(hip_lib, [(752, 480, 1.2, 8, 2), (301, 277, 1.2, 8, 3), (644, 400, 2.0, 3, 1), (1241, 376, 1.2, 8, 1), (1001, 841, 1.2, 11, 1), (263, 251, 1.5, 2, 5), (1920, 1080, 1.2, 8, 1)])
