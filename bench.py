@@ -206,6 +206,7 @@ def main():
         # ORBX_BENCH_BACKEND=gloo: test switch - several ranks may then share one GPU (RCCL refuses that) or run without one (ORBX_BENCH_LIB), which
         # lets a box without 8 GPUs run the multi-process path end to end; the barrier and the max-reduce go over CPU tensors in that case
         backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")
+        coll_dev = "cpu"                                # where the barriers and the max over ranks run
         kw = {}
         if "WORLD_SIZE" not in os.environ:              # --allgather in a plain process: a one-rank group on a free local port
             import socket
@@ -223,7 +224,16 @@ def main():
             # a plain scaling run has no RCCL streams competing with the extractors' hardware queues: with the communicator alive four
             # handles per GPU fall from 101 k to 86 k pairs/s (three: 95 k), without it a rank runs as a plain process does
             # (profiles/r03_final/dist_handles.txt).
-            dist_.init_process_group("cpu:gloo,cuda:nccl", **kw)
+            if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: gloo need not resolve the container's hostname
+            try:
+                dist_.init_process_group("cpu:gloo,cuda:nccl", **kw)
+            except Exception as e:                                       # no usable gloo transport: everything over RCCL, as in rounds 1-2
+                sys.stderr.write("bench.py: gloo + nccl group failed (%r); falling back to an nccl-only group\n" % (e,))
+                if dist_.is_initialized():
+                    dist_.destroy_process_group()
+                dist_.init_process_group("nccl", device_id=torch.device("cuda", local), **kw)
+                coll_dev = "cuda"
         else:
             local = 0
             dist_.init_process_group(backend, **kw)
@@ -231,7 +241,7 @@ def main():
         dist_on_gpu = backend == "nccl"
 
         def dist_barrier():                             # an all-reduce over CPU tensors: every rank has to arrive
-            dist_.all_reduce(torch.zeros(1))
+            dist_.all_reduce(torch.zeros(1, device=coll_dev))
 
     from orb_slam3_detailed_comments_amd import ORBextractor, load_hip, synth, _lib
     from orb_slam3_detailed_comments_amd import matcher as M
@@ -260,7 +270,7 @@ def main():
     probe = [batch[i] if batch.ndim == 3 else batch[i][..., 1] for i in range(min(4, len(batch)))]
     fast_density = float(np.mean([synth.fast_corner_density(im, MIN) for im in probe]))
     NIMG = 2 * P if paired else P
-    NH = args.handles if args.handles > 0 else (3 if (dist is not None and args.allgather) else 4)
+    NH = args.handles if args.handles > 0 else (3 if (dist is not None and (args.allgather or coll_dev == "cuda")) else 4)
     handles = [ORBextractor(NFEAT, SCALE, NLEVELS, INI, MIN, device_id=local, lib=lib) for _ in range(NH)]
     if kind == "rgbd":
         for h in handles:
@@ -445,7 +455,7 @@ def main():
             repeats = int(min(max(1, np.ceil(min_seconds / max(tw / nwarm * nsteps, 1e-6))), 10000))
         if dist is not None:                       # every rank times the same number of steps
             import torch
-            t = torch.tensor([repeats], dtype=torch.int64, device="cpu")
+            t = torch.tensor([repeats], dtype=torch.int64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             repeats = int(t.item())
             sync_all()
@@ -466,7 +476,7 @@ def main():
     dt, per_step, repeats = timed(args.steps, args.h2d, args.min_seconds)
     if dist is not None:
         import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu")
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -483,7 +493,7 @@ def main():
                 w.wait()
         sync_all()
         ta = (time.perf_counter() - ta) / nrep
-        t = torch.tensor([ta], dtype=torch.float64, device="cpu")
+        t = torch.tensor([ta], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         blk_bytes = NIMG * cap * 32 + NIMG * 4
         ag_alone = {"ms_per_batch_alone": round(float(t.item()) * 1e3, 4), "bytes_per_rank": blk_bytes, "bytes_gathered_per_rank": blk_bytes * world,

@@ -43,6 +43,8 @@ def test_empty_image_and_errors(emu_lib):
         ex(np.zeros((60, 60), np.uint8))
     with pytest.raises(OrbxError):
         ORBextractor(0, 1.2, 8, 20, 7, lib=emu_lib)
+    with pytest.raises(OrbxError):                                    # orbx_set_pyramid_mode: 0, 1 or 2
+        ex.pyramid_mode(3)
 
 
 def test_other_parameters_and_gauss_variant(emu_lib):

@@ -40,8 +40,12 @@ exs = {}
 for seed in range(2000, 2000 + npairs):
     w, h = [(752, 480), (640, 480), (376, 240), (376, 240)][seed % 4]
     nf = [1200, 1000, 500, 500][seed % 4]
-    kind = seed % 5
-    if kind == 3:
+    kind = seed % 7
+    if kind == 5:                                               # camera-like statistics: some cells need the second FAST run at minThFAST
+        L, R = synth.natural_stereo_pair(w, h, seed=seed)
+    elif kind == 6:                                             # weak dots / tied strong pairs per cell: the threshold fallback and the strict-maximum rule
+        L = synth.threshold_blocks(w, h, seed=seed); R = np.roll(L, -(3 + seed % 20), axis=1)
+    elif kind == 3:
         L = synth.pink_noise(w, h, seed=seed); R = np.roll(L, -7, axis=1)
     elif kind == 4:                                             # exact descriptor copies along the rows: the tie rule of the row search
         L, R = synth.periodic_stereo_pair(w, h, seed=seed, period=[(48, 240), (32, 120), (64, 480)][seed % 3], disparity=5 + seed % 40)
