@@ -69,10 +69,12 @@ __global__ void __launch_bounds__(256) k_layout(const LevelInfo* __restrict__ lv
     int total = 0;
     for (int l = 0; l < nlevels; l++) total += s_cnt[l];
     int mono_run = 0, lap_run = 0;
+    // (declared outside the loop: with the usual feature counts the loop runs once and the row index below places the keypoints from these
+    // registers instead of reading keys and output indices back)
+    int valid[kLayoutPer], lvl[kLayoutPer], fin[kLayoutPer];
+    uint32_t key[kLayoutPer];
     for (int base = 0; base < kp_total_cap; base += 256 * kLayoutPer) {
         const int s0 = base + tid * kLayoutPer;
-        int valid[kLayoutPer], lvl[kLayoutPer];
-        uint32_t key[kLayoutPer];
         int l = 0;
         while (l + 1 < nlevels && s_off[l + 1] <= s0) l++;
 #pragma unroll
@@ -97,7 +99,8 @@ __global__ void __launch_bounds__(256) k_layout(const LevelInfo* __restrict__ lv
         int pm = mono_run + (int)(ex & 0xFFFFFFFFu), pl = lap_run + (int)(ex >> 32);
 #pragma unroll
         for (int k = 0; k < kLayoutPer; k++) {
-            if (valid[k]) final_idx[(size_t)b * kp_total_cap + s0 + k] = lapf[k] ? total - 1 - pl++ : pm++;
+            fin[k] = lapf[k] ? total - 1 - pl : pm;
+            if (valid[k]) { final_idx[(size_t)b * kp_total_cap + s0 + k] = fin[k]; if (lapf[k]) pl++; else pm++; }
         }
         mono_run += (int)(tot & 0xFFFFFFFFu); lap_run += (int)(tot >> 32);
     }
@@ -121,6 +124,12 @@ __global__ void __launch_bounds__(256) k_layout(const LevelInfo* __restrict__ lv
     }
     if (tid == 0) row_start[(size_t)b * (nb + 1) + nb] = run;
     __syncthreads();
+    if (kp_total_cap <= 256 * kLayoutPer) {             // one trip of the loop above: keys, levels and output indices are still in registers
+#pragma unroll
+        for (int k = 0; k < kLayoutPer; k++)
+            if (valid[k]) row_items[(size_t)b * kp_total_cap + atomicAdd(&cursor[bucket_of(key[k], lvl[k])], 1)] = fin[k];
+        return;
+    }
     int l = 0;
     for (int s = tid; s < kp_total_cap; s += 256) {
         while (l + 1 < nlevels && s_off[l + 1] <= s) l++;

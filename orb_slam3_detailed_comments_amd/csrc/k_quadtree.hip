@@ -609,11 +609,12 @@ __global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* 
         for (int c0 = 0; c0 < L.cell_count; c0 += 256) {
             const int c = c0 + (tid >> lgt);
             const int cnt = c < L.cell_count ? ccount[c] : 0;
+            const int soff = c < L.cell_count ? cells[L.cell_begin + c].slot_off : 0;      // (travels with the count: one round trip, not two)
             unsigned long long tot;
             int pos = run + (int)block_excl_scan_n<unsigned long long>((unsigned long long)(sub == 0 ? cnt : 0), &tot, s_scan, NW);
             pos = __shfl(pos, lane & ~(tpc - 1));
             if (cnt > 0) {
-                const uint32_t* sp = slot_base + cells[L.cell_begin + c].slot_off;
+                const uint32_t* sp = slot_base + soff;
                 int sidx = (pos + sub) / seg, send = (sidx + 1) * seg;       // segment of this lane's first key, and where it ends
                 auto count_key = [&](uint32_t key, int p) {
                     while (p >= send) { sidx++; send += seg; }
