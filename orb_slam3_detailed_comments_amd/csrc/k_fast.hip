@@ -62,6 +62,23 @@ __device__ __forceinline__ int lanes_below(unsigned long long bal) {
 #endif
 }
 
+// ballot of "byte J of m is not zero" (the survivor masks of phase A hold 0x00 or 0x80 per byte): one SDWA compare that selects the byte, where
+// the compiler spends a v_bfe_u32 and a v_cmp per byte
+template <int J>
+__device__ __forceinline__ unsigned long long byte_ballot(uint32_t m) {
+#ifdef ORBX_EMU
+    return ORBX_BALLOT((m & (0xFFu << (8 * J))) != 0u);
+#else
+    unsigned long long r;
+    const uint32_t zero = 0u;
+    if (J == 0) asm volatile("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_0 src1_sel:DWORD" : "=s"(r) : "v"(m), "v"(zero));
+    else if (J == 1) asm volatile("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_1 src1_sel:DWORD" : "=s"(r) : "v"(m), "v"(zero));
+    else if (J == 2) asm volatile("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_2 src1_sel:DWORD" : "=s"(r) : "v"(m), "v"(zero));
+    else asm volatile("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_3 src1_sel:DWORD" : "=s"(r) : "v"(m), "v"(zero));
+    return r;
+#endif
+}
+
 constexpr int kFastThreads = 64;                    // one wave per cell
 static_assert(kFastThreads == kFastThreadsDecl, "launch configuration");
 constexpr int kEntOff = 0x3FFF, kEntBright = 0x8000;   // survivor-list entry: tile byte offset of the pixel | bright-candidate flag
@@ -253,16 +270,17 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
             }
             const uint32_t ANY = SD | SB, BOTH = SD & SB;
             unsigned long long bal[4], bald[4];
-            bool pj[4], pdj[4];                                  // lane predicates, kept so that the appends run under the same masks
             int trip = 0;
+            // (the appends below are guarded by ORBX_IN_BALLOT(bal[j]), not by a lane predicate: the compiler tested every bit twice otherwise, as
+            // and + cmp for the branch and as bfe + cmp for the ballot)
+            bal[0] = byte_ballot<0>(ANY); bal[1] = byte_ballot<1>(ANY); bal[2] = byte_ballot<2>(ANY); bal[3] = byte_ballot<3>(ANY);
 #pragma unroll
-            // (the appends below are guarded by ORBX_IN_BALLOT(bal[j]), not by pj[j]: the compiler tested every bit twice otherwise, as and + cmp for
-            // the branch and as bfe + cmp for the ballot)
-            for (int j = 0; j < 4; j++) { pj[j] = (ANY & (0x80u << (8 * j))) != 0u; bal[j] = ORBX_BALLOT(pj[j]); trip += __popcll(bal[j]); }
+            for (int j = 0; j < 4; j++) trip += __popcll(bal[j]);
             const bool dups = ORBX_BALLOT(BOTH != 0u) != 0ull;      // a pixel that passes for both polarities gets a second (dark) entry: rare
             if (dups) {
+                bald[0] = byte_ballot<0>(BOTH); bald[1] = byte_ballot<1>(BOTH); bald[2] = byte_ballot<2>(BOTH); bald[3] = byte_ballot<3>(BOTH);
 #pragma unroll
-                for (int j = 0; j < 4; j++) { pdj[j] = (BOTH & (0x80u << (8 * j))) != 0u; bald[j] = ORBX_BALLOT(pdj[j]); trip += __popcll(bald[j]); }
+                for (int j = 0; j < 4; j++) trip += __popcll(bald[j]);
             }
             if (cnt + trip > list_cap) {                         // wave-uniform: score what is pending, then append behind the corners
                 score_pending();
