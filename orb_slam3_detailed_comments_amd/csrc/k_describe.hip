@@ -101,6 +101,9 @@ __global__ void __launch_bounds__(256) k_layout(const LevelInfo* __restrict__ lv
         for (int k = 0; k < kLayoutPer; k++) {
             fin[k] = lapf[k] ? total - 1 - pl : pm;
             if (valid[k]) { final_idx[(size_t)b * kp_total_cap + s0 + k] = fin[k]; if (lapf[k]) pl++; else pm++; }
+            // an unused slot is given one of the rows [total, cap) - the i-th unused slot row total + i - which k_orient_brief clears: descriptor
+            // rows beyond the count read as zero (fixed-shape blocks for collectives) without a fill launch in front of every extraction
+            else if (s0 + k < kp_total_cap) final_idx[(size_t)b * kp_total_cap + s0 + k] = total + (s0 + k) - (pm + pl);
         }
         mono_run += (int)(tot & 0xFFFFFFFFu); lap_run += (int)(tot >> 32);
     }
@@ -178,6 +181,11 @@ __device__ __forceinline__ void orient_brief_impl(const LevelInfo* __restrict__ 
         for (int l = 1; l < nlevels; l++) if (myslot >= lv[l].kp_off) my_level = l;
         const int i = myslot - lv[my_level].kp_off;
         my_valid = i < lvl_count[(size_t)b * nlevels + my_level];
+        if (!my_valid && lane < KPW) {                      // unused slot: clear the descriptor row k_layout assigned to it
+            const int zrow = final_idx[(size_t)b * kp_total_cap + myslot];
+            unsigned long long* z = out_desc + ((size_t)b * kp_total_cap + zrow) * 4;
+            z[0] = 0ull; z[1] = 0ull; z[2] = 0ull; z[3] = 0ull;
+        }
         if (my_valid) {
             my_key = lvl_keys[(size_t)b * kp_total_cap + myslot];
             my_pitch = lv[my_level].pitch;

@@ -377,8 +377,10 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
                                                     const uint8_t* __restrict__ pyr, size_t pyr_stride,
                                                     int iniTh, int minTh,
                                                     uint32_t* __restrict__ slots, size_t slots_stride,
-                                                    int* __restrict__ cell_count, int tile_bytes, int list_bytes) {
+                                                    int* __restrict__ cell_count, int tile_bytes, int list_bytes, int* __restrict__ status) {
     ORBX_DYN_SMEM(smem);
+    // the batch's status word (the quadtree's capacity flag) is cleared here, by the kernel in front of the quadtree, instead of by a fill launch
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) status[threadIdx.x] = 0;
     // Workgroup -> cell mapping.  Consecutive workgroup ids go to different XCDs (id % 8), each with its own L2; with the plain mapping
     // (workgroup b -> cell b) neighbouring cells never share an L2 and the 6-pixel window overlap plus the dword / cache-line padding of
     // every window row is fetched again per cell.  Runs of kFastXcdRun neighbouring cells are therefore kept on one XCD

@@ -308,8 +308,8 @@ void enqueue_input(orbx_extractor* h, int B, const uint8_t* d_images, int sw, in
 int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w, int src_h, int stride, size_t image_stride, int lap0, int lap1) {
     const int nl = h->nlevels;
     const dim3 blk2(64, 4, 1), blk1(256, 1, 1);
-    rt::memset_async(h->d_status.p, 0, 4 * sizeof(int), h->s0);     // the quadtree's capacity flag is per batch, not per handle
-    rt::memset_async(h->d_desc.p, 0, (size_t)B * h->kp_total_cap * 32, h->s0);   // descriptor rows beyond n[b] read as zero (fixed-shape blocks for collectives)
+    // (no fill launches in front of the chain: the quadtree's capacity flag is cleared by k_fast_cells, and the descriptor rows beyond n[b] -
+    // which read as zero: fixed-shape blocks for collectives - by k_orient_brief, one row per unused keypoint slot)
     stage_begin(h, ST_IMPORT, h->s0);
     if (h->in_active && (h->in_channels != 1 || h->in_geometry != 0)) enqueue_input(h, B, d_images, src_w, src_h, stride, image_stride);
     else if (d_images == h->d_pyr.p + h->lv[0].off && stride == h->lv[0].pitch && image_stride == h->pyr_stride) {
@@ -376,7 +376,7 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
         const size_t smem = 16 + (size_t)h->fast_tile_bytes + (size_t)h->fast_inner_bytes + (size_t)list_bytes + 64;
         ORBX_LAUNCH(k_fast_cells, grid, blkf, smem, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
                     (const uint8_t*)h->d_pyr.p, h->pyr_stride, h->iniTh, h->minTh, h->d_slots.p, h->cand_stride, h->d_cell_count.p,
-                    h->fast_tile_bytes, list_bytes);
+                    h->fast_tile_bytes, list_bytes, h->d_status.p);
     }
     stage_end(h, ST_FAST, h->s0);
     stage_begin(h, ST_QUADTREE, h->s0);

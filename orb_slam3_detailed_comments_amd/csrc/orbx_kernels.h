@@ -33,7 +33,7 @@ constexpr int kFastPitch = 48;         // LDS pitch of the FAST window tile for 
 __global__ void k_fast_cells(const LevelInfo* __restrict__ lv, const CellInfo* __restrict__ cells, int ncells,
                              const uint8_t* __restrict__ pyr, size_t pyr_stride, int iniTh, int minTh,
                              uint32_t* __restrict__ slots, size_t slots_stride, int* __restrict__ cell_count,
-                             int tile_bytes, int list_bytes);
+                             int tile_bytes, int list_bytes, int* __restrict__ status);
 constexpr int kResizeRows = 8;         // output rows per k_resize tile (256 columns wide)
 #ifndef ORBX_BLUR_ROWS
 #define ORBX_BLUR_ROWS 16

@@ -249,3 +249,29 @@ def test_pyramid_one_launch_emulated(emu_lib):
 @pytest.mark.gpu
 def test_pyramid_one_launch_gpu(hip_lib):
     _pyramid_modes_case(hip_lib, [(752, 480, 1.2, 8, 2), (301, 277, 1.2, 8, 3), (644, 400, 2.0, 3, 1), (1241, 376, 1.2, 8, 1), (1001, 841, 1.2, 11, 1), (263, 251, 1.5, 2, 5), (1920, 1080, 1.2, 8, 1)])
+
+
+def _zero_rows_case(lib, w, h, nf):
+    """descriptor rows beyond an image's keypoint count read as zero in the device-resident block, also when the handle's previous batch filled
+    them (no fill launch in front of an extraction: k_orient_brief clears one row per unused keypoint slot).  The fetch with the device's own
+    layout copies the whole block, so the page-locked staging array shows every row."""
+    ex = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib)
+    dense = np.stack([synth.corner_field(w, h, seed=400 + s, nrect=max(300, w * h // 150)) for s in range(3)])
+    sparse = np.stack([synth.sparse_corners(w, h, seed=410, ncorner=9), np.full((h, w), 90, np.uint8), synth.threshold_blocks(w, h, seed=411)])
+    for batch in (dense, sparse, dense[:2], sparse[1:]):
+        res = ex.extract_batch(batch)
+        block = ex._fetch_buf[2]
+        assert block.shape == (len(batch), ex.max_keypoints(), 32)
+        for b, (_, k, desc) in enumerate(res):
+            assert np.array_equal(block[b, :len(k)], desc) and not block[b, len(k):].any(), (b, len(k))
+    assert len(res[-1][1]) > 0 and len(ex.extract_batch(dense)[0][1]) > 100
+    ex.close()
+
+
+def test_descriptor_rows_beyond_count_are_zero_emulated(emu_lib):
+    _zero_rows_case(emu_lib, 376, 240, 500)
+
+
+@pytest.mark.gpu
+def test_descriptor_rows_beyond_count_are_zero_gpu(hip_lib):
+    _zero_rows_case(hip_lib, 752, 480, 1200)
