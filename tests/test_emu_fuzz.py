@@ -38,6 +38,7 @@ def test_fuzz(emu_lib, seed):
     img, nf, sf, nl, ini, mn, lap, gv = _case(seed)
     ex = ORBextractor(nf, sf, nl, ini, mn, lib=emu_lib)
     ex.set_gaussian_taps(gv)
+    ex.pyramid_mode(1 + seed % 2)                  # odd seeds: all pyramid levels in one launch; even seeds: one launch per level
     got = ex(img, None, lap)
     exp = ol.OracleExtractor(nf, sf, nl, ini, mn, gv).extract(img, lap)
     assert got[0] == exp[0] and ol.kps_equal(got[1], exp[1]) and np.array_equal(got[2], exp[2]), (img.shape, nf, sf, nl, ini, mn, lap, gv)
