@@ -242,7 +242,7 @@ def _pyramid_modes_case(lib, shapes):
 def test_pyramid_one_launch_emulated(emu_lib):
     # (width, height, scale factor, levels, images): widths that are no multiple of 4 on any level, a factor of 2 (taps two apart), more
     # levels than the reference uses, a single level, two levels, factor 1.5
-    _pyramid_modes_case(emu_lib, [(301, 277, 1.2, 8, 2), (422, 360, 2.0, 3, 1), (600, 520, 1.2, 11, 1), (210, 190, 1.2, 1, 1), (263, 251, 1.5, 2, 3), (417, 233, 1.5, 4, 1),
+    _pyramid_modes_case(emu_lib, [(301, 277, 1.2, 8, 2), (422, 360, 2.0, 3, 1), (600, 520, 1.2, 11, 1), (210, 190, 1.2, 1, 1), (263, 251, 1.5, 2, 3), (417, 233, 1.5, 4, 1), (431, 397, 2.5, 2, 2), (530, 470, 3.0, 2, 1),   # factors > 2: source pixels no tap reads are still owned and written
                                    (900, 860, 1.2, 14, 1)])   # 14 levels: a tile's level-0 window no longer fits the LDS budget, the library keeps one launch per level
 
 
