@@ -24,7 +24,9 @@ def patch(src, name):
     NS = ("        for (int i0 = pbeg; i0 < cnt; i0 += 2 * kFastThreads) {", "        for (int i0 = pbeg; i0 < cnt && iniTh < 0; i0 += 2 * kFastThreads) {")
     if name == "A_nowrite":        # phase A without the list writes (no scoring either)
         t = src.replace(*NS, 1)
-        t = t.replace("if (pj[j]) list[cnt + lanes_below(bal[j])] = ", "if (pj[j] && iniTh < 0) list[cnt + lanes_below(bal[j])] = ", 1)
+        a = "if (ORBX_IN_BALLOT(bal[j])) list[cnt + lanes_below(bal[j])] = "
+        assert a in t
+        t = t.replace(a, "if (ORBX_IN_BALLOT(bal[j]) && iniTh < 0) list[cnt + lanes_below(bal[j])] = ", 1)
         return t
     if name == "A_noread":         # phase A without its LDS reads
         t = src.replace(*NS, 1)
@@ -48,6 +50,10 @@ def build(name, extra=()):
     p = os.path.join(d, "k_fast.hip")
     s = open(p).read(); t = patch(s, name.split("+")[0])
     assert name.startswith("base") or t != s, name
+    if not name.startswith("base"):        # a cut-out build finds no corners: it must not run the cell a second time at minThFAST
+        a = "    if (base > 0 || pass == 1 || minTh >= iniTh) break;"
+        assert a in t
+        t = t.replace(a, "    break;", 1)
     open(p, "w").write(t)
     os.makedirs(os.path.join(d, "..", "..", "include"), exist_ok=True)
     out = os.path.join(OUT, "liborbx_hip_%s.so" % name.replace("+", "_"))
