@@ -612,6 +612,26 @@ def main():
                                         "step_ms": {"median": round(pct(per2, 50), 4), "p10": round(pct(per2, 10), 4), "p90": round(pct(per2, 90), 4)}}
             except Exception as e:
                 res["h2d_inclusive"] = {"value": None, "error": repr(e)}
+        if kind == "stereo" and world == 1 and not os.environ.get("ORBX_BENCH_LIB"):
+            # reported beside the throughput, never `value`: one stereo pair per call on one fresh handle, synchronised after every pair
+            # (Tracking's rhythm: extract L + R, ComputeStereoMatches, wait), the frames written into pyramid level 0 by the producer
+            try:
+                for h in handles:
+                    h.sync()
+                hl = ORBextractor(NFEAT, SCALE, NLEVELS, INI, MIN, device_id=local, lib=lib)
+                lp, lshape, lstride, listride = hl.input_upload(np.stack([batch[0], batch[P]]))
+                npair = 200
+                for it in range(npair + 20):
+                    if it == 20:
+                        tl = time.perf_counter()
+                    hl.enqueue(None, LAP, device_ptr=lp, shape=lshape, stride=lstride, image_stride=listride)
+                    lib.check(lib.L.orbm_stereo_match(hl._h, 0, hl._h, 1, 1, BF, BASE))
+                    hl.sync()
+                res["latency"] = {"single_pair_ms": round((time.perf_counter() - tl) / npair * 1e3, 4), "pairs": npair,
+                                  "what": "one pair per call on one handle, host waits after every pair; inputs resident in pyramid level 0"}
+                hl.close()
+            except Exception as e:
+                res["latency"] = {"single_pair_ms": None, "error": repr(e)}
         if kind == "stereo" and not args.no_cpu_baseline and world == 1:
             try:
                 res["cpu_baseline"] = cpu_baseline()
