@@ -259,7 +259,10 @@ int configure(orbx_extractor* h, int W, int H, int B) {
         e |= h->d_slots.ensure(b * h->cand_stride + 4); e |= h->d_candA.ensure(b * h->cand_stride + 4); e |= h->d_candB.ensure(b * h->cand_stride + 4);
         e |= h->d_cell_count.ensure(b * h->ncells); e |= h->d_lvl_count.ensure(b * h->nlevels);
         e |= h->d_lvl_keys.ensure(b * cap); e |= h->d_final_idx.ensure(b * cap);
-        e |= h->d_nm.ensure(2 * b); e |= h->d_status.ensure(4);
+        // counts [b] | mono indices [b] | status word (4 ints): one block, so that orbx_fetch brings all three back in one copy; d_status is a
+        // view of its tail (never allocated or freed by itself)
+        e |= h->d_nm.ensure(2 * b + 4);
+        h->d_status.p = h->d_nm.p ? h->d_nm.p + 2 * b : nullptr; h->d_status.n = h->d_nm.p ? 4 : 0;
         e |= h->d_kps.ensure(b * cap); e |= h->d_desc.ensure(b * cap * 4); e |= h->d_aux.ensure(b * cap * 4);
         e |= h->d_uRight.ensure(b * cap); e |= h->d_depth.ensure(b * cap); e |= h->d_sad.ensure(b * cap); e |= h->d_nmatch.ensure(b);
         e |= h->d_rowstart.ensure(b * (size_t)((h->H >> kStereoRowShift) + 3)); e |= h->d_rowitems.ensure(b * cap);
@@ -475,7 +478,7 @@ void orbx_destroy(orbx_extractor* h) {
     }
     h->d_lv.release(); h->d_cells.release(); h->d_xtab.release(); h->d_ytab.release(); h->d_xspan.release(); h->d_yspan.release(); h->d_pyr.release(); h->d_blur.release(); h->d_stage.release();
     h->d_slots.release(); h->d_candA.release(); h->d_candB.release(); h->d_lvl_keys.release(); h->d_cell_count.release(); h->d_lvl_count.release();
-    h->d_final_idx.release(); h->d_nm.release(); h->d_status.release(); h->d_kps.release(); h->d_desc.release();
+    h->d_final_idx.release(); h->d_status.p = nullptr; h->d_status.n = 0; h->d_nm.release(); h->d_kps.release(); h->d_desc.release();
     h->d_uRight.release(); h->d_depth.release(); h->d_sad.release(); h->d_nmatch.release(); h->d_knn.release(); h->d_ratio.release();
     h->d_l2r.release(); h->d_r2l.release(); h->d_p3d.release(); h->d_hamA.release(); h->d_hamB.release(); h->d_hamOut.release(); h->h_stage.release(); h->h_nm.release();
     for (auto& x : h->d_sr) x.release();
@@ -616,8 +619,7 @@ int orbx_fetch(orbx_extractor* h, OrbxKeyPoint* kps, uint8_t* desc, int cap, int
     const size_t kb = (size_t)B * tc * sizeof(KeyPointRec), db = (size_t)B * tc * 32;
     const bool direct = (cap == h->kp_total_cap);   // caller's layout == device layout: no staging, no repack
     if (!direct && h->h_stage.ensure(kb + db + 64)) return fail(ORBX_E_DEVICE, "pinned allocation failed");
-    int e = rt::copy_d2h(h->h_nm.p, h->d_nm.p, sizeof(int) * 2 * h->maxB, h->s0);
-    e |= rt::copy_d2h(h->h_nm.p + 2 * h->maxB, h->d_status.p, sizeof(int), h->s0);
+    int e = rt::copy_d2h(h->h_nm.p, h->d_nm.p, sizeof(int) * (2 * h->maxB + 1), h->s0);      // counts, mono indices and the status word behind them
     if (kps) e |= rt::copy_d2h(direct ? (void*)kps : (void*)h->h_stage.p, h->d_kps.p, kb, h->s0);
     if (desc) e |= rt::copy_d2h(direct ? (void*)desc : (void*)(h->h_stage.p + kb), h->d_desc.p, db, h->s0);
     if (e || rt::stream_sync(h->s0)) return fail(ORBX_E_DEVICE, "D2H failed: %s", rt::last_error());
