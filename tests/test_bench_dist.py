@@ -23,6 +23,7 @@ def test_bench_two_ranks_gloo(emu_lib):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line (rank 0): %r" % r.stdout[-1000:]
+    assert r.stdout.strip().splitlines()[-1].startswith("{"), "the JSON line is the last line of stdout: %r" % r.stdout[-500:]
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["warmup"] == 1 and res["scaling"] == "weak" and res["unit"] == "stereo pairs/s"
     # whole-job aggregate: 2 ranks x 1 pair x 2 steps over the (max over ranks) time
@@ -45,6 +46,7 @@ def test_bench_launches_its_own_ranks(emu_lib):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line (rank 0): %r" % r.stdout[-1000:]
+    assert r.stdout.strip().splitlines()[-1].startswith("{"), "the JSON line is the last line of stdout: %r" % r.stdout[-500:]
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["repeats"] == 1 and res["timed_steps"] == 2
     assert res["config"]["library"].startswith("liborbx_emu.so") and "override" in res["config"]["library"]
