@@ -33,3 +33,9 @@ find $O/prof_trace_rgbd -name '*kernel_stats.csv' -exec cp {} $O/rocprofv3_kerne
 head -12 $O/rocprofv3_kernel_stats.csv | cut -c1-200
 # keep only the small summaries
 rm -rf $O/prof_fetch $O/prof_write $O/prof_sq; find $O/prof_trace $O/prof_trace_rgbd -name '*.csv' -size +4M -delete
+# second half of round 3: per-call latency of the drop-in facade, kernel trace of the single-pair loop, launch / wait latencies, pyramid launch forms
+bash tools/gpu_facade_latency.sh > /dev/null 2>&1; cp gpurun_out/facade_latency.txt $O/facade_latency.txt 2>/dev/null; cat $O/facade_latency.txt
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_single -o trace -- python $R/tools/single_pair_loop.py 300 > $R/$O/prof_single.log 2>&1); tail -1 $O/prof_single.log
+find $O/prof_single -name '*kernel_stats.csv' -exec cp {} $O/rocprofv3_kernel_stats_single_pair.csv \; ; find $O/prof_single -name '*.csv' -size +2M -delete
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -w tools/sync_latency_probe.hip -o /tmp/sync_latency_probe && /tmp/sync_latency_probe > $O/sync_latency_probe.txt; cat $O/sync_latency_probe.txt
+python tools/time_pyramid_modes.py 2 8 16 > $O/pyramid_one_launch_vs_per_level.txt 2>&1; cat $O/pyramid_one_launch_vs_per_level.txt
