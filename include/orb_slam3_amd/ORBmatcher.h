@@ -755,26 +755,36 @@ protected:
             Check(orbm_project_points(SharedHandle(), &spec, &in, &out));
         }
     };
-    // pose, camera and image test of a projection; the tests a method applies are switched on by the method
+    // pose, camera and image test of a projection; the tests a method applies are switched on by the method.  The pose enters as Sophus holds
+    // it - unit quaternion + translation - because `Tcw * p3Dw` is Sophus' quaternion action (so3.hpp:357-367), not a matrix product
     template <class PoseT, class CameraT, class HolderT> static OrbmProjection Spec(const PoseT& T, CameraT* camera, HolderT& image, int boundsMode)
     {
         OrbmProjection s; memset(&s, 0, sizeof s);
-        const auto R = T.rotationMatrix(); const auto t = T.translation();
-        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) s.R[3 * r + c] = R(r, c); s.t[r] = t(r); }
+        const auto& q = T.unit_quaternion(); const auto t = T.translation();
+        s.q[0] = q.x(); s.q[1] = q.y(); s.q[2] = q.z(); s.q[3] = q.w();
+        for (int r = 0; r < 3; r++) s.t[r] = t(r);
         s.camera_type = camera->GetType() == 1 ? 1 : 0;
         for (int i = 0; i < (s.camera_type ? 8 : 4); i++) s.cam[i] = camera->getParameter(i);
         s.min_x = image.mnMinX; s.max_x = image.mnMaxX; s.min_y = image.mnMinY; s.max_y = image.mnMaxY; s.bounds_mode = boundsMode;
         return s;
     }
     template <class Vec3T> static void SpecCentre(OrbmProjection& s, const Vec3T& c) { for (int k = 0; k < 3; k++) s.Ow[k] = c(k); }
-    // a second transform behind the pose: a Sim3 (R, t, s) or an SE3 (scale 1)
-    template <class T> static auto ScaleOf(const T& x, int) -> decltype((float)x.scale()) { return (float)x.scale(); }
-    template <class T> static float ScaleOf(const T&, long) { return 1.0f; }
+    // a second transform behind the pose: a Sim3 (its quaternion carries the scale: |q|^2 = scale(); rxso3.hpp:265-273) or an SE3
+    template <class T> static auto SecondQuaternion(const T& x, OrbmProjection& s, int) -> decltype(x.scale(), void())
+    {
+        const auto& q = x.quaternion(); s.q2[0] = q.x(); s.q2[1] = q.y(); s.q2[2] = q.z(); s.q2[3] = q.w();
+        s.s2 = x.scale(); s.second = 1;              // scale() IS quaternion().squaredNorm() (rxso3.hpp:350), evaluated by the caller's own Eigen
+    }
+    template <class T> static void SecondQuaternion(const T& x, OrbmProjection& s, long)
+    {
+        const auto& q = x.unit_quaternion(); s.q2[0] = q.x(); s.q2[1] = q.y(); s.q2[2] = q.z(); s.q2[3] = q.w();
+        s.s2 = 1.0f; s.second = 2;
+    }
     template <class TransformT> static void SpecSecond(OrbmProjection& s, const TransformT& X)
     {
-        const auto R = X.rotationMatrix(); const auto t = X.translation();
-        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) s.R2[3 * r + c] = R(r, c); s.t2[r] = t(r); }
-        s.s2 = ScaleOf(X, 0); s.has_sim3 = 1;
+        SecondQuaternion(X, s, 0);
+        const auto t = X.translation();
+        for (int r = 0; r < 3; r++) s.t2[r] = t(r);
     }
     // the rigid transform a similarity moves points with up to scale: [R | t / s] (:508, :1559)
     template <class SE3T, class Sim3T> static SE3T RigidPart(const Sim3T& S) { return SE3T(S.rotationMatrix(), S.translation() / S.scale()); }

@@ -161,7 +161,8 @@ int orbx_debug_level_keys(orbx_extractor* h, int image_index, int level, int* xy
  * must not change), bit 2 makes every lane walk all candidates from the last to the first (every tie then meets inside one lane; the
  * result must not change either), bit 1 restores the distance-only tie rule of an earlier revision (the tie tests must then fail);
  * bit 3: the 2-NN of orbm_knn2 / orbm_stereo_fisheye on the vector units (one wave per query) instead of the matrix cores (the result must
- * not change) */
+ * not change); bit 4: orbm_project_points and orbm_search_by_projection_lastframe_batch evaluate `Tcw * p` as q.toRotationMatrix() * p + t
+ * (an earlier revision's form) instead of Sophus' quaternion action (tests/test_sophus_action.py: the reference must then catch it) */
 int orbx_debug_stereo_flags(orbx_extractor* h, int flags);
 int orbx_debug_quadtree_profile(orbx_extractor* h, long long out[16]);   /* phase timestamps of one quadtree workgroup (profiling mode 2) */
 /* test hook: the byte / packed-16-bit instruction wrappers of the kernels (csrc/orbx_simd.h) applied to n operand triples (n a multiple of 256);
@@ -258,12 +259,15 @@ typedef struct OrbmLastFrameView {        /* what SearchByProjection(CurrentFram
 } OrbmLastFrameView;
 
 /* C1 on the device: Frame::isInFrustum (src/Frame.cc:667-773, one camera) + Pinhole / KannalaBrandt8::project + MapPoint::PredictScale
- * (src/MapPoint.cc:688-731) for M map points at once, in the reference's fp32 operation order (Eigen's 3x3 * 3x1 product summed left to
- * right, no fused multiply-adds).  The outputs are the fields the reference stores in the
+ * (src/MapPoint.cc:688-731) for M map points at once, in the reference's fp32 operation order (mRcw * P + mtcw as a matrix product, as the
+ * reference writes it; Eigen >= 3.3 - which the vendored Sophus requires - sums the three terms of a product coefficient, a dot() or a
+ * norm() as a0 + (a1 + a2); no fused multiply-adds).  The outputs are the fields the reference stores in the
  * MapPoint: mbTrackInView, mTrackProjX / Y / XR, mTrackDepth, mTrackViewCos, mnTrackScaleLevel (`out` itself is required; any array pointer in
  * it may be NULL).  MapPoint::PredictScale's log is glibc's logf (the reference's std::log(float)), reproduced bit for bit on the device. */
 typedef struct OrbmFrustumView {
-    float Rcw[9], tcw[3], Ow[3];          /* Frame::mRcw (row-major), mtcw, mOw */
+    float Rcw[9], tcw[3], Ow[3];          /* Frame::mRcw (row-major) = mTcw.rotationMatrix(), mtcw, mOw = mTcw.inverse().translation() (src/Frame.cc:594-598) */
+    float qcw[4];                         /* mTcw.unit_quaternion().coeffs() (x, y, z, w): read by orbm_search_by_projection_lastframe_batch only, which
+                                           * evaluates `Tcw * x3Dw` (src/ORBmatcher.cc:1987) as Sophus does - on the quaternion, not on mRcw */
     int camera_type;                      /* GeometricCamera::GetType(): 0 pinhole (cam = fx, fy, cx, cy), 1 Kannala-Brandt (8 parameters) */
     float cam[8];
     float min_x, max_x, min_y, max_y;     /* mnMinX .. mnMaxY */
@@ -474,12 +478,17 @@ int orbm_search_by_projection_frame_fisheye(orbx_extractor* h, const OrbmFisheye
  * SearchByProjection(Frame, LastFrame) (src/ORBmatcher.cc:1993-2010), (Frame, KeyFrame) (:2228-2256), (KeyFrame, Sim3, ...) x2 (:525-560, :640-690),
  * Fuse x2 (:1388-1430, :1590-1625) and SearchBySim3 (:1745-1790, :1830-1875) all start with the same per-map-point chain: transform, depth test,
  * projection, image test, distance range, viewing angle.  orbm_project_points evaluates it for M points at once in the reference's fp32
- * operation order (a rigid transform is R * p + t with 3-term sums left to right - the order of a matrix product; no fused multiply-adds).
+ * operation order.  The reference multiplies `Tcw * p3Dw` with Sophus types, and Sophus rotates a point by the unit quaternion WITHOUT forming
+ * the matrix (Thirdparty/Sophus/sophus/so3.hpp:357-367: uv = 2 q.vec x p; p + q.w uv + q.vec x uv; se3.hpp:321-324 adds the translation;
+ * rxso3.hpp:265-273 / sim3.hpp:226-229 for a similarity): poses therefore enter as quaternion coefficients in Eigen's coeffs() order
+ * (x, y, z, w) + translation, and the device evaluates exactly those statements (csrc/sophus_action.h; no fused multiply-adds).  R * p + t
+ * with R = q.toRotationMatrix() rounds differently in the last bit, which is enough to move a keypoint across a search-window edge.
  * The spec says which tests the method at hand applies and how it writes its projection.  MapPoint::PredictScale stays with the caller's
  * MapPoint (it reads a protected member): `dist` is its argument.  Blocking. */
 typedef struct OrbmProjection {
-    float R[9], t[3];                     /* p1 = R * p_w + t: the SE3 pose in front (Tcw, T1w, ...) */
-    int has_sim3; float R2[9], t2[3], s2; /* SearchBySim3: p_c = (R2 * p1) * s2 + t2 (Sim3 S21 / S12); else p_c = p1 */
+    float q[4], t[3];                     /* p1 = T * p_w: the SE3 pose in front (Tcw, T1w, ...): T.unit_quaternion().coeffs() (x, y, z, w), T.translation() */
+    int second; float q2[4], t2[3], s2;   /* a second transform behind it, p_c = X * p1: 0 none; 1 a Sim3 (SearchBySim3's S21 / S12): q2 = X.quaternion().coeffs()
+                                           * (not unit: |q2|^2 = scale), t2 = X.translation(), s2 = X.scale(); 2 an SE3 (GetRelativePoseTrl()): unit q2, t2 */
     float Ow[3];                          /* camera centre for the distance / angle tests (dist_mode 0) */
     int dist_mode;                        /* 0: dist = |p_w - Ow|, 1: dist = |p_c| (SearchBySim3, :1771) */
     int depth_test;                       /* 0 none (:2228-2256), 1: p_c.z < 0 rejects, 2: 1 / p_c.z < 0 rejects (:1997-2000) */

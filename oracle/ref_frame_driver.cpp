@@ -22,6 +22,12 @@ struct Holder {
     ORBextractor *left = nullptr, *right = nullptr; Pinhole* cam = nullptr; KannalaBrandt8 *kb1 = nullptr, *kb2 = nullptr; Frame* frame = nullptr;
     ~Holder() { delete frame; delete left; delete right; delete cam; delete kb1; delete kb2; }
 };
+// a pose handed over as (R row-major, t) enters through Sophus' SE3(R, t) constructor (matrix -> unit quaternion, se3.hpp:480-482)
+Sophus::SE3f se3_from(const float* R, const float* t) {
+    Eigen::Matrix3f Rm; Eigen::Vector3f tv;
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Rm(i, j) = R[3 * i + j]; tv(i) = t[i]; }
+    return Sophus::SE3f(Rm, tv);
+}
 void put_keys(const std::vector<cv::KeyPoint>& k, void* out) {
     RefKp* o = (RefKp*)out;
     for (size_t i = 0; i < k.size(); i++) o[i] = {k[i].pt.x, k[i].pt.y, k[i].size, k[i].angle, k[i].response, k[i].octave, k[i].class_id};
@@ -99,7 +105,7 @@ void* ref_frame_fisheye(const uint8_t* L, const uint8_t* R, int w, int h, int nf
     K.at<float>(0, 0) = 190.9f; K.at<float>(1, 1) = 190.9f; K.at<float>(0, 2) = 254.9f; K.at<float>(1, 2) = 256.9f;
     cv::Mat dist(4, 1, CV_32F); for (int i = 0; i < 4; i++) dist.at<float>(i) = 0.0f;
     Sophus::SE3f Tlr;
-    if (cams) { for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Tlr.R(i, j) = cams[16 + 3 * i + j]; Tlr.t[i] = cams[25 + i]; } }
+    if (cams) Tlr = se3_from(cams + 16, cams + 25);
     Frame::mbInitialComputations = true;
     H->frame = new Frame(imL, imR, 0.0, H->left, H->right, nullptr, K, dist, 19.3f, 40.0f, H->kb1, H->kb2, Tlr);
     out[0] = H->frame->Nleft; out[1] = H->frame->Nright; out[2] = H->frame->monoLeft; out[3] = H->frame->monoRight;
@@ -127,8 +133,7 @@ int ref_frame_search_local_points(void* h, const float* R, const float* t, int M
                                   const uint8_t* bad, const uint8_t* has_obs, const uint8_t* desc, float cos_limit, float* track, int do_search, float th, int far_points,
                                   float th_far, float nnratio, int* assigned) {
     Frame* F = ((Holder*)h)->frame;
-    Sophus::SE3f Tcw;
-    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Tcw.R(i, j) = R[3 * i + j]; Tcw.t[i] = t[i]; }
+    const Sophus::SE3f Tcw = se3_from(R, t);
     F->SetPose(Tcw);
     std::vector<MapPoint> mps(M);
     std::vector<MapPoint*> vp(M);
@@ -150,6 +155,87 @@ int ref_frame_search_local_points(void* h, const float* R, const float* t, int M
     return n;
 }
 
+// The checker's Sophus stand-in (oracle/slam_shim/sophus_model.h) evaluated on one pose (R, t) [+ a similarity (s, R2, t2)] and one point, for
+// tests/test_sophus_action.py, which holds the Python host mirror (orb_slam3_detailed_comments_amd/sophus.py) against it.
+// out (48 floats): unit quaternion 4 | rotationMatrix 9 | T * p 3 | inverse: quaternion 4, translation 3 | (T * T) quaternion 4, translation 3 |
+// Sim3: quaternion 4, scale 1, rotationMatrix 9 (first 3 rows... all 9) -> see the layout in the test.
+void ref_sophus_probe(const float* R, const float* t, const float* p, float s, const float* R2, const float* t2, float* out) {
+    const Sophus::SE3f T = se3_from(R, t);
+    const Eigen::Vector3f P(p[0], p[1], p[2]);
+    int o = 0;
+    auto putq = [&](const Eigen::Quaternionf& q) { out[o++] = q.x(); out[o++] = q.y(); out[o++] = q.z(); out[o++] = q.w(); };
+    auto putv = [&](const Eigen::Vector3f& v) { for (int i = 0; i < 3; i++) out[o++] = v(i); };
+    auto putm = [&](const Eigen::Matrix3f& m) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) out[o++] = m(i, j); };
+    putq(T.unit_quaternion()); putm(T.rotationMatrix()); putv(T * P);
+    const Sophus::SE3f Ti = T.inverse(); putq(Ti.unit_quaternion()); putv(Ti.translation());
+    const Sophus::SE3f TT = T * T; putq(TT.unit_quaternion()); putv(TT.translation());
+    Eigen::Matrix3f Rm; Eigen::Vector3f tv;
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Rm(i, j) = R2[3 * i + j]; tv(i) = t2[i]; }
+    const Sophus::Sim3f S(Sophus::RxSO3f(s, Rm), tv);
+    putq(S.quaternion()); out[o++] = S.scale(); putm(S.rotationMatrix()); putv(S * P);
+    const Sophus::Sim3f Si = S.inverse(); putq(Si.quaternion()); putv(Si.translation()); putv(Si * P);
+}
+
+// ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBmatcher.cc:1950-2184), the search of
+// Tracking::TrackWithMotionModel, on the reference's own Frame and matcher.  CurrentFrame = the holder's frame at pose (R, t), keypoints with
+// occupied[i] != 0 hold a map point with observations beforehand.  LastFrame = a copy of it (the reference's copy constructor) at pose (Rl, tl)
+// whose NL keypoints carry the given octave / angle and whose map points are the NL given (valid[i] == 0: no map point).
+// fwd_bwd[0..1] = bForward / bBackward as the reference derives them from the two poses (:1966-1975), recomputed here with the same
+// expressions for the caller of the batched device search, which takes them as flags.  assigned[i] = index of the last-frame point written to
+// CurrentFrame.mvpMapPoints[i], -1 untouched (or pre-occupied), -2 written and reset to NULL by the rotation check.
+int ref_frame_search_lastframe(void* h, const float* R, const float* t, const float* Rl, const float* tl, int NL, const float* pos, const uint8_t* valid, const int* octave,
+                               const float* angle, const uint8_t* has_obs, const uint8_t* desc, float th, int mono, int check_orientation, float nnratio, const uint8_t* occupied,
+                               int* assigned, int* fwd_bwd) {
+    Frame* F = ((Holder*)h)->frame;
+    F->SetPose(se3_from(R, t));
+    Frame Last(*F);
+    Last.SetPose(se3_from(Rl, tl));
+    Last.N = NL;
+    Last.mvKeys.assign(NL, cv::KeyPoint()); Last.mvKeysUn.assign(NL, cv::KeyPoint());
+    Last.mvpMapPoints.assign(NL, (MapPoint*)nullptr); Last.mvbOutlier.assign(NL, false);
+    std::vector<MapPoint> mps(NL);
+    for (int i = 0; i < NL; i++) {
+        Last.mvKeys[i].octave = octave[i]; Last.mvKeysUn[i].octave = octave[i]; Last.mvKeys[i].angle = angle[i]; Last.mvKeysUn[i].angle = angle[i];
+        MapPoint& p = mps[i];
+        p.pos = Eigen::Vector3f(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]); p.nObs = has_obs ? (has_obs[i] ? 2 : 0) : 1;
+        p.descriptor = cv::Mat(1, 32, CV_8U); memcpy(p.descriptor.ptr(0), desc + 32 * (size_t)i, 32);
+        if (valid[i]) Last.mvpMapPoints[i] = &p;
+    }
+    MapPoint resident; resident.nObs = 3;
+    std::vector<uint8_t> was(F->N, 0);
+    for (int i = 0; i < F->N; i++) { was[i] = occupied && occupied[i]; F->mvpMapPoints[i] = was[i] ? &resident : nullptr; }
+    {
+        const Sophus::SE3f Tcw = F->GetPose();
+        const Eigen::Vector3f twc = Tcw.inverse().translation();
+        const Sophus::SE3f Tlw = Last.GetPose();
+        const Eigen::Vector3f tlc = Tlw * twc;
+        fwd_bwd[0] = tlc(2) > F->mb && !mono; fwd_bwd[1] = -tlc(2) > F->mb && !mono;
+    }
+    // a monocular frame has no right coordinates (mvuRight = -1, src/Frame.cc:360): the holder's frame is a stereo one, so hide them for bMono
+    const std::vector<float> saved_u_right = F->mvuRight;
+    if (mono) std::fill(F->mvuRight.begin(), F->mvuRight.end(), -1.0f);
+    ORBmatcher matcher(nnratio, check_orientation != 0);
+    const int n = matcher.SearchByProjection(*F, Last, th, mono != 0);
+    for (int i = 0; i < F->N; i++) {
+        MapPoint* p = F->mvpMapPoints[i];
+        assigned[i] = (p && p != &resident) ? (int)(p - mps.data()) : -1;
+    }
+    // a keypoint that was free, received a point and lost it again to the rotation check is NULL afterwards, like one never touched: tell them
+    // apart by running the search once more without the check
+    if (check_orientation) {
+        for (int i = 0; i < F->N; i++) F->mvpMapPoints[i] = was[i] ? &resident : nullptr;
+        ORBmatcher plain(nnratio, false);
+        plain.SearchByProjection(*F, Last, th, mono != 0);
+        for (int i = 0; i < F->N; i++) {
+            MapPoint* p = F->mvpMapPoints[i];
+            if (p && p != &resident && assigned[i] == -1) assigned[i] = -2;
+        }
+    }
+    std::fill(F->mvpMapPoints.begin(), F->mvpMapPoints.end(), (MapPoint*)nullptr);
+    F->mvuRight = saved_u_right;
+    return n;
+}
+
 // The same for a two-camera rig frame (ref_frame_fisheye): Frame::isInFrustum takes its Nleft != -1 branch (src/Frame.cc:754-766 ->
 // isInFrustumChecks :1592-1650 once per camera) and SearchByProjection its right-camera branch (src/ORBmatcher.cc:170-236).
 // track: 13 arrays of M entries: in_view, proj_x, proj_y, depth, view_cos, scale_level, in_view_r, proj_xr, proj_yr, depth_r, view_cos_r,
@@ -160,8 +246,7 @@ int ref_frame_search_local_points_rig(void* h, const float* R, const float* t, i
                                       const uint8_t* bad, const uint8_t* has_obs, const uint8_t* desc, float cos_limit, float* track, int do_search, float th, int far_points,
                                       float th_far, float nnratio, int* assigned, float* pose_out) {
     Frame* F = ((Holder*)h)->frame;
-    Sophus::SE3f Tcw;
-    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Tcw.R(i, j) = R[3 * i + j]; Tcw.t[i] = t[i]; }
+    const Sophus::SE3f Tcw = se3_from(R, t);
     F->SetPose(Tcw);
     {
         const Eigen::Matrix3f Rcw = F->GetPose().rotationMatrix(), Rwc = F->GetRwc(), Rrl = F->GetRelativePoseTrl().rotationMatrix();

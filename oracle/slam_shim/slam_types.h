@@ -46,7 +46,10 @@ struct Vector3f {
     void setZero() { d[0] = d[1] = d[2] = 0; }
     float* data() { return d; }
     size_t size() const { return 3; }
-    float dot(const Vector3f& o) const { return d[0] * o.d[0] + d[1] * o.d[1] + d[2] * o.d[2]; }
+    // Eigen >= 3.3 (required by the vendored Sophus, Thirdparty/Sophus/CMakeLists.txt:35): a fixed-size reduction of three terms is unrolled by
+    // redux_novec_unroller, which halves the range (Eigen/src/Core/Redux.h): a0 + (a1 + a2).  dot(), norm(), trace() and every coefficient of a
+    // 3x3 product (ProductEvaluators.h: (lhs.row(i).transpose().cwiseProduct(rhs.col(j))).sum()) are such reductions.
+    float dot(const Vector3f& o) const { return d[0] * o.d[0] + (d[1] * o.d[1] + d[2] * o.d[2]); }
     float norm() const { return std::sqrt(dot(*this)); }
 };
 inline Vector3f operator-(const Vector3f& a, const Vector3f& b) { return Vector3f(a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2]); }
@@ -66,61 +69,31 @@ struct Matrix3f {
     size_t size() const { return 9; }
     Vector3f row(int r) const { return Vector3f(m[r][0], m[r][1], m[r][2]); }
     Matrix3f transpose() const { Matrix3f r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = m[j][i]; return r; }
-    Matrix3f inverse() const {          // cofactors / determinant
+    // Eigen/src/LU/InverseImpl.h, compute_inverse<MatrixType, ResultType, 3>: cofactor_3x3<i,j> = m(i1,j1) m(i2,j2) - m(i1,j2) m(i2,j1) with
+    // i1 = (i+1)%3, i2 = (i+2)%3 (likewise j); det = (cofactors_col0.cwiseProduct(matrix.col(0))).sum(); result(i,j) = cofactor<j,i> * (1 / det)
+    float cofactor(int i, int j) const { const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3; return m[i1][j1] * m[i2][j2] - m[i1][j2] * m[i2][j1]; }
+    Matrix3f inverse() const {
         Matrix3f r;
-        const float c00 = m[1][1] * m[2][2] - m[1][2] * m[2][1], c01 = m[1][2] * m[2][0] - m[1][0] * m[2][2], c02 = m[1][0] * m[2][1] - m[1][1] * m[2][0];
-        const float det = m[0][0] * c00 + m[0][1] * c01 + m[0][2] * c02, id = 1.0f / det;
-        r.m[0][0] = c00 * id; r.m[1][0] = c01 * id; r.m[2][0] = c02 * id;
-        r.m[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) * id; r.m[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) * id; r.m[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) * id;
-        r.m[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) * id; r.m[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) * id; r.m[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) * id;
+        const float c0 = cofactor(0, 0), c1 = cofactor(1, 0), c2 = cofactor(2, 0);
+        const float det = c0 * m[0][0] + (c1 * m[1][0] + c2 * m[2][0]), invdet = 1.0f / det;
+        r.m[0][0] = c0 * invdet; r.m[0][1] = c1 * invdet; r.m[0][2] = c2 * invdet;
+        for (int i = 1; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = cofactor(j, i) * invdet;
         return r;
     }
 };
 inline Vector3f operator*(const Matrix3f& A, const Vector3f& v) {
-    return Vector3f(A.m[0][0] * v.d[0] + A.m[0][1] * v.d[1] + A.m[0][2] * v.d[2], A.m[1][0] * v.d[0] + A.m[1][1] * v.d[1] + A.m[1][2] * v.d[2],
-                    A.m[2][0] * v.d[0] + A.m[2][1] * v.d[1] + A.m[2][2] * v.d[2]);
+    return Vector3f(A.m[0][0] * v.d[0] + (A.m[0][1] * v.d[1] + A.m[0][2] * v.d[2]), A.m[1][0] * v.d[0] + (A.m[1][1] * v.d[1] + A.m[1][2] * v.d[2]),
+                    A.m[2][0] * v.d[0] + (A.m[2][1] * v.d[1] + A.m[2][2] * v.d[2]));
 }
 inline Matrix3f operator*(const Matrix3f& A, const Matrix3f& B) {
     Matrix3f r;
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = A.m[i][0] * B.m[0][j] + A.m[i][1] * B.m[1][j] + A.m[i][2] * B.m[2][j];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = A.m[i][0] * B.m[0][j] + (A.m[i][1] * B.m[1][j] + A.m[i][2] * B.m[2][j]);
     return r;
 }
 inline Matrix3f operator*(const Matrix3f& A, float s) { Matrix3f r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = A.m[i][j] * s; return r; }
 }  // namespace Eigen
 
-namespace Sophus {
-struct SO3f {
-    Eigen::Matrix3f R;
-    SO3f operator*(const SO3f& o) const { SO3f r; r.R = R * o.R; return r; }
-    const Eigen::Matrix3f& matrix() const { return R; }
-};
-template <typename T> struct SE3;
-template <> struct SE3<float> {
-    Eigen::Matrix3f R; Eigen::Vector3f t;
-    SE3() : R(Eigen::Matrix3f::Identity()), t() {}
-    SE3(const Eigen::Matrix3f& r, const Eigen::Vector3f& tt) : R(r), t(tt) {}
-    const Eigen::Matrix3f& rotationMatrix() const { return R; }
-    const Eigen::Vector3f& translation() const { return t; }
-    SO3f so3() const { SO3f r; r.R = R; return r; }
-    SE3 inverse() const { const Eigen::Matrix3f Rt = R.transpose(); return SE3(Rt, -(Rt * t)); }
-    SE3 operator*(const SE3& o) const { return SE3(R * o.R, R * o.t + t); }
-    Eigen::Vector3f operator*(const Eigen::Vector3f& p) const { return R * p + t; }
-};
-typedef SE3<float> SE3f;
-template <> struct SE3<double> {};     // include/Frame.h:369 holds an unused Sophus::SE3<double> member
-template <typename T> struct Sim3;
-template <> struct Sim3<float> {
-    Eigen::Matrix3f R; Eigen::Vector3f t; float s;
-    Sim3() : R(Eigen::Matrix3f::Identity()), t(), s(1.0f) {}
-    Sim3(float ss, const Eigen::Matrix3f& r, const Eigen::Vector3f& tt) : R(r), t(tt), s(ss) {}
-    const Eigen::Matrix3f& rotationMatrix() const { return R; }
-    const Eigen::Vector3f& translation() const { return t; }
-    float scale() const { return s; }
-    Sim3 inverse() const { const Eigen::Matrix3f Rt = R.transpose(); const float is = 1.0f / s; return Sim3(is, Rt, -((Rt * t) * is)); }
-    Eigen::Vector3f operator*(const Eigen::Vector3f& p) const { return (R * p) * s + t; }
-};
-typedef Sim3<float> Sim3f;
-}  // namespace Sophus
+#include "sophus_model.h"     // Sophus::SO3f / SE3f / RxSO3f / Sim3f: the vendored Sophus restated over a stand-in Eigen::Quaternionf
 
 namespace ORB_SLAM3 {
 

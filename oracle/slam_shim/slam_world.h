@@ -6,9 +6,11 @@
 //   * this header is force-included (-include) and pre-defines the include guards MAPPOINT_H / KEYFRAME_H / FRAME_H, so the
 //     `#include "MapPoint.h"` ... lines of the reference's ORBmatcher.h (include/ORBmatcher.h:28-30) resolve to the reference's own
 //     files but contribute nothing; `#include "sophus/sim3.hpp"` (:26) resolves to oracle/slam_shim/sophus/sim3.hpp, i.e. here
-//   * Eigen::Vector2f/Vector3f/Matrix3f, Sophus::SE3f/Sim3f: only the operations ORBmatcher.cc uses, plain float arithmetic in the
-//     textbook order (row dot products accumulated left to right).  Real Eigen/Sophus may round differently; that arithmetic sits on the
-//     caller's side of the C ABI (include/orbx.h: "geometry ... enters here as numbers"), so it is not what is being pinned
+//   * Eigen::Vector2f/Vector3f/Matrix3f: only the operations ORBmatcher.cc uses, in the evaluation order of Eigen >= 3.3 (three-term
+//     reductions as a0 + (a1 + a2), see slam_types.h; Eigen itself is an external dependency and not installed: restated, unpinned);
+//     Sophus::SO3f/SE3f/RxSO3f/Sim3f: the reference's VENDORED Sophus restated statement by statement on unit quaternions
+//     (sophus_model.h: point action p + w uv + v x uv, quaternion composition, normalising constructors) - the rigid transforms the
+//     matchers evaluate (Tcw * p3Dw, S21 * p3Dc1, Tcw.inverse().translation(), T1w * Tw2) round exactly as the real types do
 //   * ORB_SLAM3::GeometricCamera (pinhole: project / toK_ / epipolarConstrain restated from src/CameraModels/Pinhole.cpp:61-68, :186-216),
 //     MapPoint, KeyFrame, Frame: the members ORBmatcher.cc reads, with the small methods it calls restated from the reference
 //     (Frame::GetFeaturesInArea src/Frame.cc:859-951, KeyFrame::GetFeaturesInArea src/KeyFrame.cc:843-891, KeyFrame::IsInImage :894-897,

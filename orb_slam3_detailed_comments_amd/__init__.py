@@ -5,4 +5,5 @@ from .extractor import ORBextractor  # noqa: F401
 from .matcher import (ORBmatcher, ComputeStereoMatches, StereoFishEyeKnn, GetFeaturesInArea, AreaSearchBatch,  # noqa: F401
                       ComputeDistinctiveDescriptors)
 from .vocabulary import ORBVocabulary  # noqa: F401
-from . import views  # noqa: F401
+from . import views, sophus  # noqa: F401
+from .sophus import SE3f, Sim3f  # noqa: F401

@@ -15,6 +15,7 @@
 #include "orbx_block.h"
 #include "orbx_kernels.h"
 #include "kb8_model.h"
+#include "sophus_action.h"
 #include "glibc_logf_model.h"
 
 namespace orbx {
@@ -267,10 +268,11 @@ __global__ void __launch_bounds__(256) k_frustum(FrustumParams F, int M, const f
     bool ok = true;
     float u = -1.0f, v = -1.0f, xr = 0.0f, depth = 0.0f, vcos = 0.0f; int lvl = 0;
     // Pc = mRcw * P + mtcw
-    const float x = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(F.Rcw[0], P0), __fmul_rn(F.Rcw[1], P1)), __fmul_rn(F.Rcw[2], P2)), F.tcw[0]);
-    const float y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(F.Rcw[3], P0), __fmul_rn(F.Rcw[4], P1)), __fmul_rn(F.Rcw[5], P2)), F.tcw[1]);
-    const float z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(F.Rcw[6], P0), __fmul_rn(F.Rcw[7], P1)), __fmul_rn(F.Rcw[8], P2)), F.tcw[2]);
-    const float Pc_dist = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+    // (the reference works with the MATRIX here, src/Frame.cc:685; Eigen's 3-term sums are a0 + (a1 + a2), sophus_action.h)
+    float Pc[3];
+    eig_rt3(F.Rcw, F.tcw, P0, P1, P2, Pc);
+    const float x = Pc[0], y = Pc[1], z = Pc[2];
+    const float Pc_dist = sqrtf(eig_dot3(x, y, z, x, y, z));
     const float invz = __fdiv_rn(1.0f, z);
     if (z < 0.0f) ok = false;
     float uu = 0.f, vv = 0.f;
@@ -287,10 +289,10 @@ __global__ void __launch_bounds__(256) k_frustum(FrustumParams F, int M, const f
         if (!F.rig_mode) { u = uu; v = vv; }                          // mTrackProjX / Y are set before the distance tests (:705-706)
         const float maxDistance = __fmul_rn(1.2f, max_dist[i]), minDistance = __fmul_rn(0.8f, min_dist[i]);     // MapPoint.cc:658-671
         const float o0 = __fsub_rn(P0, F.Ow[0]), o1 = __fsub_rn(P1, F.Ow[1]), o2 = __fsub_rn(P2, F.Ow[2]);
-        const float dist = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(o0, o0), __fmul_rn(o1, o1)), __fmul_rn(o2, o2)));
+        const float dist = sqrtf(eig_dot3(o0, o1, o2, o0, o1, o2));
         if (dist < minDistance || dist > maxDistance) ok = false;
         if (ok) {
-            const float dot = __fadd_rn(__fadd_rn(__fmul_rn(o0, normal[3 * i]), __fmul_rn(o1, normal[3 * i + 1])), __fmul_rn(o2, normal[3 * i + 2]));
+            const float dot = eig_dot3(o0, o1, o2, normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]);
             vcos = __fdiv_rn(dot, dist);
             if (vcos < F.cos_limit) ok = false;
         }
@@ -329,22 +331,19 @@ __global__ void __launch_bounds__(256) k_frustum(FrustumParams F, int M, const f
 // caller's MapPoint).  skip[i] != 0: the caller's own tests (bad, already matched, ...) have rejected the point.
 __global__ void __launch_bounds__(256) k_project_points(ProjectParams P, int M, const float* __restrict__ pos, const float* __restrict__ normal,
                                                         const float* __restrict__ min_inv, const float* __restrict__ max_inv, const uint8_t* __restrict__ skip,
-                                                        uint8_t* __restrict__ valid, float* __restrict__ out /* [5][M]: u, v, ur, 1/z, dist */) {
+                                                        uint8_t* __restrict__ valid, float* __restrict__ out /* [5][M]: u, v, ur, 1/z, dist */, int debug_flags) {
     const int i = (int)(blockIdx.x * 256 + threadIdx.x);
     if (i >= M) return;
     bool ok = !(skip && skip[i]);
     float u = 0.f, v = 0.f, ur = 0.f, invz = 0.f, dist = 0.f;
     if (ok) {
         const float P0 = pos[3 * i], P1 = pos[3 * i + 1], P2 = pos[3 * i + 2];
-        float x = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.R[0], P0), __fmul_rn(P.R[1], P1)), __fmul_rn(P.R[2], P2)), P.t[0]);
-        float y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.R[3], P0), __fmul_rn(P.R[4], P1)), __fmul_rn(P.R[5], P2)), P.t[1]);
-        float z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.R[6], P0), __fmul_rn(P.R[7], P1)), __fmul_rn(P.R[8], P2)), P.t[2]);
-        if (P.has_sim3) {                                             // Sim3 * p = (R * p) * s + t
-            const float a = __fadd_rn(__fadd_rn(__fmul_rn(P.R2[0], x), __fmul_rn(P.R2[1], y)), __fmul_rn(P.R2[2], z));
-            const float b = __fadd_rn(__fadd_rn(__fmul_rn(P.R2[3], x), __fmul_rn(P.R2[4], y)), __fmul_rn(P.R2[5], z));
-            const float c = __fadd_rn(__fadd_rn(__fmul_rn(P.R2[6], x), __fmul_rn(P.R2[7], y)), __fmul_rn(P.R2[8], z));
-            x = __fadd_rn(__fmul_rn(a, P.s2), P.t2[0]); y = __fadd_rn(__fmul_rn(b, P.s2), P.t2[1]); z = __fadd_rn(__fmul_rn(c, P.s2), P.t2[2]);
-        }
+        float pc[3];
+        if (debug_flags & 16) se3_act_matrix_form(P.q, P.t, P0, P1, P2, pc);       // test switch: round 3's R * p + t
+        else se3_act(P.q, P.t, P0, P1, P2, pc);                       // Tcw * p3Dw: Sophus' quaternion action (so3.hpp:357-367, se3.hpp:321-324)
+        if (P.second == 1) sim3_act(P.q2, P.s2, P.t2, pc[0], pc[1], pc[2], pc);       // S21 * p3Dc1 (rxso3.hpp:265-273, sim3.hpp:226-229)
+        else if (P.second == 2) se3_act(P.q2, P.t2, pc[0], pc[1], pc[2], pc);         // GetRelativePoseTrl() * x3Dc
+        const float x = pc[0], y = pc[1], z = pc[2];
         invz = __fdiv_rn(1.0f, z);
         if (P.depth_test == 1 && z < 0.0f) ok = false;
         if (P.depth_test == 2 && invz < 0.0f) ok = false;
@@ -363,11 +362,11 @@ __global__ void __launch_bounds__(256) k_project_points(ProjectParams P, int M, 
         if (ok) {
             ur = __fsub_rn(u, __fmul_rn(P.bf, invz));
             const float o0 = __fsub_rn(P0, P.Ow[0]), o1 = __fsub_rn(P1, P.Ow[1]), o2 = __fsub_rn(P2, P.Ow[2]);
-            if (P.dist_mode == 0) dist = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(o0, o0), __fmul_rn(o1, o1)), __fmul_rn(o2, o2)));
-            else dist = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+            if (P.dist_mode == 0) dist = sqrtf(eig_dot3(o0, o1, o2, o0, o1, o2));        // PO.norm(): Eigen reduction, a0 + (a1 + a2)
+            else dist = sqrtf(eig_dot3(x, y, z, x, y, z));
             if (P.distance_test && (dist < min_inv[i] || dist > max_inv[i])) ok = false;
             if (ok && P.angle_test) {                                 // PO.dot(Pn) < 0.5 * dist3D
-                const float dot = __fadd_rn(__fadd_rn(__fmul_rn(o0, normal[3 * i]), __fmul_rn(o1, normal[3 * i + 1])), __fmul_rn(o2, normal[3 * i + 2]));
+                const float dot = eig_dot3(o0, o1, o2, normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]);
                 if (dot < __fmul_rn(0.5f, dist)) ok = false;
             }
         }
@@ -392,9 +391,10 @@ __global__ void __launch_bounds__(256) k_lastframe_queries(const FrustumParams* 
     AreaQuery q; q.x = 0; q.y = 0; q.r = 0; q.ur = 0; q.min_level = 0; q.max_level = 0; q.active = 0; q.gate = 0;
     if (i < n_last[b] && valid[o]) {
         const float P0 = pos[3 * o], P1 = pos[3 * o + 1], P2 = pos[3 * o + 2];
-        const float x = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(F.Rcw[0], P0), __fmul_rn(F.Rcw[1], P1)), __fmul_rn(F.Rcw[2], P2)), F.tcw[0]);
-        const float y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(F.Rcw[3], P0), __fmul_rn(F.Rcw[4], P1)), __fmul_rn(F.Rcw[5], P2)), F.tcw[1]);
-        const float z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(F.Rcw[6], P0), __fmul_rn(F.Rcw[7], P1)), __fmul_rn(F.Rcw[8], P2)), F.tcw[2]);
+        float pc[3];
+        if (F.debug_flags & 16) se3_act_matrix_form(F.qcw, F.tcw, P0, P1, P2, pc);  // test switch: round 3's R * p + t
+        else se3_act(F.qcw, F.tcw, P0, P1, P2, pc);                   // x3Dc = Tcw * x3Dw (:1987): Sophus' quaternion action, not mRcw * p
+        const float x = pc[0], y = pc[1], z = pc[2];
         const float invz = __fdiv_rn(1.0f, z);
         const int oct = octave[o];
         if (!(invz < 0.0f) && oct >= 0 && oct < F.nlevels) {

@@ -9,6 +9,7 @@
 #include <cmath>
 #include "orbx_platform.h"
 #include "glibc_atan2f_model.h"
+#include "sophus_action.h"      // eig_dot3: Eigen's 3-term reductions are a0 + (a1 + a2)
 
 namespace orbx {
 
@@ -81,15 +82,15 @@ ORBX_HD inline void null_vector4(const float A[16], double x[4]) {
 // R12 row-major.  Returns the depth in camera 1 (> 0) or the reference's negative rejection codes; p3D is written on success.
 ORBX_HD inline float kb8_triangulate_matches(const KB8Cam& c1, const KB8Cam& c2, const float r1[3], const float r2[3], float u1, float v1, float u2, float v2,
                                              const float R12[9], const float t12[3], float sigmaLevel, float unc, float p3D[3]) {
-    const float r21[3] = {R12[0] * r2[0] + R12[1] * r2[1] + R12[2] * r2[2], R12[3] * r2[0] + R12[4] * r2[1] + R12[5] * r2[2],
-                          R12[6] * r2[0] + R12[7] * r2[1] + R12[8] * r2[2]};
-    const float n1 = sqrtf(r1[0] * r1[0] + r1[1] * r1[1] + r1[2] * r1[2]), n21 = sqrtf(r21[0] * r21[0] + r21[1] * r21[1] + r21[2] * r21[2]);
-    const float cosParallaxRays = (r1[0] * r21[0] + r1[1] * r21[1] + r1[2] * r21[2]) / (n1 * n21);
+    const float r21[3] = {eig_dot3(R12[0], R12[1], R12[2], r2[0], r2[1], r2[2]), eig_dot3(R12[3], R12[4], R12[5], r2[0], r2[1], r2[2]),
+                          eig_dot3(R12[6], R12[7], R12[8], r2[0], r2[1], r2[2])};
+    const float n1 = sqrtf(eig_dot3(r1[0], r1[1], r1[2], r1[0], r1[1], r1[2])), n21 = sqrtf(eig_dot3(r21[0], r21[1], r21[2], r21[0], r21[1], r21[2]));
+    const float cosParallaxRays = eig_dot3(r1[0], r1[1], r1[2], r21[0], r21[1], r21[2]) / (n1 * n21);
     if ((double)cosParallaxRays > 0.9998) return -1;
     // Tcw1 = [I | 0], Tcw2 = [R21 | -R21 t12]
     float R21[9], tc[3];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R21[3 * i + j] = R12[3 * j + i];
-    for (int i = 0; i < 3; i++) tc[i] = -(R21[3 * i] * t12[0] + R21[3 * i + 1] * t12[1] + R21[3 * i + 2] * t12[2]);
+    for (int i = 0; i < 3; i++) tc[i] = -eig_dot3(R21[3 * i], R21[3 * i + 1], R21[3 * i + 2], t12[0], t12[1], t12[2]);
     // Triangulate (:553-573): A.row(0) = p1.x * Tcw1.row(2) - Tcw1.row(0), ... with p1 = r1.xy, p2 = r2.xy
     float A[16];
     A[0] = r1[0] * 0.f - 1.f; A[1] = r1[0] * 0.f - 0.f; A[2] = r1[0] * 1.f - 0.f; A[3] = r1[0] * 0.f - 0.f;
@@ -102,14 +103,14 @@ ORBX_HD inline float kb8_triangulate_matches(const KB8Cam& c1, const KB8Cam& c2,
     const float x3D[3] = {(float)xh[0] / h3, (float)xh[1] / h3, (float)xh[2] / h3};
     const float z1 = x3D[2];
     if (!(z1 > 0)) return -2;
-    const float z2 = (R21[6] * x3D[0] + R21[7] * x3D[1] + R21[8] * x3D[2]) + tc[2];
+    const float z2 = eig_dot3(R21[6], R21[7], R21[8], x3D[0], x3D[1], x3D[2]) + tc[2];
     if (!(z2 > 0)) return -3;
     float uv1[2];
     kb8_project(c1, x3D, uv1);
     const float errX1 = uv1[0] - u1, errY1 = uv1[1] - v1;
     if ((double)(errX1 * errX1 + errY1 * errY1) > 5.991 * (double)sigmaLevel) return -4;
-    const float x3D2[3] = {(R21[0] * x3D[0] + R21[1] * x3D[1] + R21[2] * x3D[2]) + tc[0], (R21[3] * x3D[0] + R21[4] * x3D[1] + R21[5] * x3D[2]) + tc[1],
-                           (R21[6] * x3D[0] + R21[7] * x3D[1] + R21[8] * x3D[2]) + tc[2]};
+    float x3D2[3];
+    eig_rt3(R21, tc, x3D[0], x3D[1], x3D[2], x3D2);
     float uv2[2];
     kb8_project(c2, x3D2, uv2);
     const float errX2 = uv2[0] - u2, errY2 = uv2[1] - v2;

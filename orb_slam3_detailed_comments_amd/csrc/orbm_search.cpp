@@ -73,7 +73,7 @@ int upload_frame(orbx_extractor* h, const OrbmFrameView* F, DeviceFrame* D) {
 struct Csr { std::vector<int> start, count; std::vector<int> ent; };   // ent: 2 ints per candidate {idx, dist | octave << 16}
 void fill_frustum_params(const OrbmFrustumView* V, float cos_limit, float th, int far_points, float th_far, FrustumParams* Fp) {
     memset(Fp, 0, sizeof *Fp);
-    memcpy(Fp->Rcw, V->Rcw, sizeof Fp->Rcw); memcpy(Fp->tcw, V->tcw, sizeof Fp->tcw); memcpy(Fp->Ow, V->Ow, sizeof Fp->Ow);
+    memcpy(Fp->Rcw, V->Rcw, sizeof Fp->Rcw); memcpy(Fp->tcw, V->tcw, sizeof Fp->tcw); memcpy(Fp->Ow, V->Ow, sizeof Fp->Ow); memcpy(Fp->qcw, V->qcw, sizeof Fp->qcw);
     memcpy(Fp->cam, V->cam, sizeof Fp->cam); Fp->kb8 = V->camera_type == 1;
     Fp->min_x = V->min_x; Fp->max_x = V->max_x; Fp->min_y = V->min_y; Fp->max_y = V->max_y; Fp->mbf = V->mbf; Fp->log_scale_factor = V->log_scale_factor; Fp->nlevels = V->nlevels;
     for (int l = 0; l < V->nlevels; l++) Fp->scale_factors[l] = V->scale_factors[l];
@@ -331,7 +331,8 @@ int orbm_is_in_frustum(orbx_extractor* h, const OrbmFrustumView* V, const OrbmWo
 
 // ---- Frame::isInFrustum with two cameras (Nleft != -1, src/Frame.cc:754-766): isInFrustumChecks (:1592-1650) once per camera ----
 namespace {
-inline float dot3(const float* a, int sa, const float* b, int sb) { return (a[0] * b[0] + a[sa] * b[sb]) + a[2 * sa] * b[2 * sb]; }   // the reference's 3-term sums, left to right
+// a coefficient of an Eigen (>= 3.3) 3x3 product: a0 b0 + (a1 b1 + a2 b2) (sophus_action.h)
+inline float dot3(const float* a, int sa, const float* b, int sb) { return a[0] * b[0] + (a[sa] * b[sb] + a[2 * sa] * b[2 * sb]); }
 // camera 2 of the rig as isInFrustumChecks(pMP, cos, bRight = true) sets it up: mR = Rrl * mRcw, mt = Rrl * mtcw + trl, twc = mRwc * tlr + mOw
 void right_camera_params(const OrbmFrustumRigView* V, float cos_limit, FrustumParams* Fp) {
     OrbmFrustumView R = V->left;
@@ -680,7 +681,7 @@ int orbm_search_by_projection_lastframe_batch(orbx_extractor* h, int first, int 
     FrustumParams* Fp = (FrustumParams*)(hp + u_f);
     for (int b = 0; b < B; b++) {
         fill_frustum_params(&cur[b], 0.0f, th, 0, 0.0f, &Fp[b]);
-        Fp[b].forward = forward ? forward[b] != 0 : 0; Fp[b].backward = backward ? backward[b] != 0 : 0;
+        Fp[b].forward = forward ? forward[b] != 0 : 0; Fp[b].backward = backward ? backward[b] != 0 : 0; Fp[b].debug_flags = h->debug_stereo_flags;
     }
     memcpy(hp + u_n, last->n, 4 * B1); memcpy(hp + u_pos, last->pos, 12 * B1 * M1); memcpy(hp + u_val, last->valid, B1 * M1); memcpy(hp + u_oct, last->octave, 4 * B1 * M1);
     memcpy(hp + u_ang, last->angle, 4 * B1 * M1);
@@ -1425,7 +1426,7 @@ int orbm_project_points(orbx_extractor* h, const OrbmProjection* S, const OrbmPr
     const uint8_t* di = h->d_sr[SR_QUERY].p; uint8_t* dout = h->d_sr[SR_SPARE].p;
     dim3 grid((M + 255) / 256, 1, 1), blk(256, 1, 1);
     ORBX_LAUNCH(k_project_points, grid, blk, 0, h->s0, P, M, (const float*)(di + op), (const float*)(di + on), (const float*)(di + omn), (const float*)(di + omx),
-                (const uint8_t*)(di + os), dout + ov, (float*)(dout + oo));
+                (const uint8_t*)(di + os), dout + ov, (float*)(dout + oo), h->debug_stereo_flags);
     if (rt::copy_d2h(h->h_out.p, dout, out_total, h->s0) || rt::stream_sync(h->s0) || rt::check_launch()) return fail(ORBX_E_DEVICE, "projection kernel failed: %s", rt::last_error());
     const float* f = (const float*)(h->h_out.p + oo);
     if (out->valid) memcpy(out->valid, h->h_out.p + ov, M1);

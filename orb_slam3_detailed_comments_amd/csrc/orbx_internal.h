@@ -83,7 +83,7 @@ struct orbx_extractor {
     orbx::rt::event_t ev_stage[ORBX_NSTAGES][2];
     bool profile = false, serial = false, have_streams = false;
     int lastB = 0;
-    int debug_stereo_flags = 0;   // orbx_debug_stereo_flags (tests): bit 0 reversed candidate visiting order, bit 1 round-1 distance-only compare
+    int debug_stereo_flags = 0;   // orbx_debug_stereo_flags (tests): bit 0 reversed candidate visiting order, bit 1 round-1 distance-only compare, bit 4 matrix form of Tcw * p (sophus_action.h)
     float stage_ms[ORBX_NSTAGES];
     // scratch of the projection / BoW searches (orbm_search.cpp)
     orbx::DevBuf<uint8_t> d_sr[12];

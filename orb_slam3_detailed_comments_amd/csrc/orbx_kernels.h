@@ -110,7 +110,7 @@ __global__ void k_frustum(FrustumParams F, int M, const float* __restrict__ pos,
                           const float* __restrict__ max_dist, const uint8_t* __restrict__ is_bad, uint8_t* __restrict__ in_view, float* __restrict__ track,
                           int* __restrict__ scale_level, AreaQuery* __restrict__ queries, int* __restrict__ zero4, const FrustumParams* __restrict__ Fbatch);
 __global__ void k_project_points(ProjectParams P, int M, const float* __restrict__ pos, const float* __restrict__ normal, const float* __restrict__ min_inv,
-                                 const float* __restrict__ max_inv, const uint8_t* __restrict__ skip, uint8_t* __restrict__ valid, float* __restrict__ out);
+                                 const float* __restrict__ max_inv, const uint8_t* __restrict__ skip, uint8_t* __restrict__ valid, float* __restrict__ out, int debug_flags);
 __global__ void k_area_search_threads(const AreaQuery* __restrict__ queries, const unsigned long long* __restrict__ qdesc, int Q,
                                       const KeyPointRec* __restrict__ kps, const float* __restrict__ u_right,
                                       const unsigned long long* __restrict__ fdesc, GridParams g, const int* __restrict__ cell_start,

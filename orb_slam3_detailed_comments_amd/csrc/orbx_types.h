@@ -69,6 +69,7 @@ struct AreaQuery {                                                // one GetFeat
 };
 struct FrustumParams {                                            // what Frame::isInFrustum reads of the Frame (src/Frame.cc:667-773)
     float Rcw[9], tcw[3], Ow[3];                                  // mRcw (row-major), mtcw, mOw
+    float qcw[4];                                                 // mTcw.unit_quaternion().coeffs() (x, y, z, w): `Tcw * x3Dw` of the LastFrame search (sophus_action.h)
     float cam[8]; int kb8;                                        // mpCamera: pinhole fx, fy, cx, cy or the 8 Kannala-Brandt parameters
     float min_x, max_x, min_y, max_y, mbf;
     float log_scale_factor; int nlevels;                          // mfLogScaleFactor, mnScaleLevels (MapPoint::PredictScale)
@@ -78,12 +79,13 @@ struct FrustumParams {                                            // what Frame:
     float th, th_far; int far_points;
     int rig_mode;                                                 // Frame::isInFrustumChecks: store nothing unless every test passes, level -1 when rejected
     int forward, backward;                                        // SearchByProjection(Frame, LastFrame): bForward / bBackward (k_lastframe_queries)
+    int debug_flags;                                              // orbx_debug_stereo_flags (tests): bit 4 = matrix form of Tcw * p (sophus_action.h)
 };
 // orbm_project_points: the geometry in front of GetFeaturesInArea in the projection-type searches (ORBmatcher.cc:495-732, :1325-1675, :1689-1932,
 // :1950-2030, :2196-2260) - see OrbmProjection in include/orbx.h (same fields)
 struct ProjectParams {
-    float R[9], t[3];
-    int has_sim3; float R2[9], t2[3], s2;
+    float q[4], t[3];
+    int second; float q2[4], t2[3], s2;
     float Ow[3];
     int dist_mode, depth_test, camera_type; float cam[8]; int inline_pinhole;
     float min_x, max_x, min_y, max_y; int bounds_mode;

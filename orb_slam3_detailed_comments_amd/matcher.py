@@ -5,6 +5,8 @@ import ctypes as C
 
 import numpy as np
 
+from .sophus import SE3f, Sim3f, as_se3
+
 
 class ORBmatcher:
     TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 30   # src/ORBmatcher.cc:35-37
@@ -246,7 +248,7 @@ def ComputeStereoFishEyeMatches(left, right, cam1, cam2, R12, t12, left_first=0,
 
 
 class _FrustumView(C.Structure):
-    _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("camera_type", C.c_int), ("cam", C.c_float * 8),
+    _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("qcw", C.c_float * 4), ("camera_type", C.c_int), ("cam", C.c_float * 8),
                 ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float), ("mbf", C.c_float), ("log_scale_factor", C.c_float),
                 ("nlevels", C.c_int), ("scale_factors", C.c_void_p)]
 
@@ -280,7 +282,8 @@ def SearchLocalPointsRig(ext, frame2, pose, cam1, cam2, bounds, scale_factors, p
     pos, normal, mn, mx, sf = f32(pos).reshape(-1, 3), f32(normal).reshape(-1, 3), f32(min_distance), f32(max_distance), f32(scale_factors)
     M = len(pos)
     V = _FrustumRigView()
-    frustum_view(pose["Rcw"], pose["tcw"], cam1, bounds, 0.0, sf, into=V.left)
+    frustum_view(SE3f(), None, cam1, bounds, 0.0, sf, into=V.left)
+    V.left.Rcw[:] = f32(pose["Rcw"]).ravel().tolist(); V.left.tcw[:] = f32(pose["tcw"]).tolist()       # the Frame's own members, untouched
     V.left.Ow[:] = [float(v) for v in f32(pose["Ow"])]
     V.left.scale_factors = sf.ctypes.data
     V.Rrl[:] = f32(pose["Rrl"]).ravel().tolist(); V.trl[:] = f32(pose["trl"]).tolist(); V.tlr[:] = f32(pose["tlr"]).tolist(); V.Rwc[:] = f32(pose["Rwc"]).ravel().tolist()
@@ -312,7 +315,7 @@ def SearchLocalPointsRig(ext, frame2, pose, cam1, cam2, bounds, scale_factors, p
 
 
 class _Projection(C.Structure):
-    _fields_ = [("R", C.c_float * 9), ("t", C.c_float * 3), ("has_sim3", C.c_int), ("R2", C.c_float * 9), ("t2", C.c_float * 3), ("s2", C.c_float), ("Ow", C.c_float * 3),
+    _fields_ = [("q", C.c_float * 4), ("t", C.c_float * 3), ("second", C.c_int), ("q2", C.c_float * 4), ("t2", C.c_float * 3), ("s2", C.c_float), ("Ow", C.c_float * 3),
                 ("dist_mode", C.c_int), ("depth_test", C.c_int), ("camera_type", C.c_int), ("cam", C.c_float * 8), ("inline_pinhole", C.c_int), ("min_x", C.c_float),
                 ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float), ("bounds_mode", C.c_int), ("distance_test", C.c_int), ("angle_test", C.c_int), ("bf", C.c_float)]
 
@@ -325,17 +328,22 @@ class _ProjectOut(C.Structure):
     _fields_ = [("valid", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("ur", C.c_void_p), ("inv_z", C.c_void_p), ("dist", C.c_void_p)]
 
 
-def ProjectPoints(ext, R, t, cam, bounds, pos, normal=None, min_inv=None, max_inv=None, skip=None, Ow=None, sim3=None, depth_test=1, bounds_mode=0, inline_pinhole=False,
+def ProjectPoints(ext, pose, cam, bounds, pos, normal=None, min_inv=None, max_inv=None, skip=None, Ow=None, second=None, depth_test=1, bounds_mode=0, inline_pinhole=False,
                   dist_mode=0, angle_test=False, bf=0.0):
     """orbm_project_points: the geometry in front of the projection-type searches (transform, depth test, projection, image test, distance
-    range, viewing angle) for M map points on the device.  sim3 = (R2, t2, s2) appends a similarity behind the pose (SearchBySim3).
-    Returns dict(valid, u, v, ur, inv_z, dist)."""
+    range, viewing angle) for M map points on the device.  pose = sophus.SE3f (or (R, t), taken through the SE3(R, t) constructor): the device
+    evaluates `pose * p` as Sophus does, on the unit quaternion.  second = a sophus.Sim3f (SearchBySim3's S21 / S12) or SE3f (the rig's Trl)
+    applied behind the pose.  Returns dict(valid, u, v, ur, inv_z, dist)."""
     f32 = lambda a: np.ascontiguousarray(a, np.float32)
     pos = f32(pos).reshape(-1, 3); M = len(pos)
     S = _Projection()
-    S.R[:] = f32(R).ravel().tolist(); S.t[:] = f32(t).tolist()
-    if sim3 is not None:
-        S.has_sim3 = 1; S.R2[:] = f32(sim3[0]).ravel().tolist(); S.t2[:] = f32(sim3[1]).tolist(); S.s2 = float(sim3[2])
+    T = as_se3(pose)
+    S.q[:] = [float(v) for v in T.unit_quaternion()]; S.t[:] = [float(v) for v in T.translation()]
+    if isinstance(second, Sim3f):
+        S.second = 1; S.q2[:] = [float(v) for v in second.quaternion()]; S.t2[:] = [float(v) for v in second.translation()]; S.s2 = float(second.scale())
+    elif second is not None:
+        X = as_se3(second)
+        S.second = 2; S.q2[:] = [float(v) for v in X.unit_quaternion()]; S.t2[:] = [float(v) for v in X.translation()]; S.s2 = 1.0
     if Ow is not None:
         S.Ow[:] = f32(Ow).tolist()
     cam = [float(v) for v in cam]
@@ -373,8 +381,8 @@ class LastFrameBatch:
         self.assigned = np.full((B, self.cap), -1, np.int32); self.nm = np.zeros(B, np.int32)
 
     def set_poses(self, poses):
-        for b, (R, t) in enumerate(poses):
-            frustum_view(R, t, self.cam, self.bounds, self.mbf, self.sf, into=self.views[b])
+        for b, pose in enumerate(poses):
+            frustum_view(as_se3(pose), None, self.cam, self.bounds, self.mbf, self.sf, into=self.views[b])
             self.views[b].scale_factors = self.sf.ctypes.data
 
     def enqueue(self, n, pos, valid, octave, angle, has_obs, desc, th, forward=None, backward=None, check_orientation=True, occupied=None, use_u_right=True, first=0):
@@ -425,16 +433,18 @@ class ResidentPoints:
 
 
 def frustum_view(Rcw, tcw, cam, bounds, mbf, scale_factors, into=None):
-    """OrbmFrustumView of one frame: pose (mRcw, mtcw and mOw = -(Rcw^T tcw) in the reference's fp32 order: the Sophus stand-in sums R^T * t left
-    to right, then negates), camera (4 pinhole or 8 Kannala-Brandt parameters), image bounds (min_x, max_x, min_y, max_y), mbf, the scale
-    factors.  Returns (view, the float32 scale-factor array the view points into - keep it alive)."""
+    """OrbmFrustumView of one frame.  The pose is a sophus.SE3f (pass it as Rcw, tcw = None) or (Rcw, tcw), which enters through Sophus' SE3(R, t)
+    constructor as in Frame::SetPose(Sophus::SE3f(R, t)); the view then holds what Frame::UpdatePoseMatrices derives (src/Frame.cc:594-598):
+    mRcw = mTcw.rotationMatrix(), mtcw, mOw = mTcw.inverse().translation(), plus the unit quaternion for the searches that evaluate Tcw * p.
+    Camera (4 pinhole or 8 Kannala-Brandt parameters), image bounds (min_x, max_x, min_y, max_y), mbf, the scale factors.
+    Returns (view, the float32 scale-factor array the view points into - keep it alive)."""
     f32 = lambda a: np.ascontiguousarray(a, np.float32)
-    Rcw, tcw, sf = f32(Rcw).reshape(3, 3), f32(tcw).reshape(3), f32(scale_factors)
+    T = Rcw if isinstance(Rcw, SE3f) else SE3f(Rcw, tcw)
+    sf = f32(scale_factors)
     V = into if into is not None else _FrustumView()
-    V.Rcw[:] = Rcw.ravel().tolist(); V.tcw[:] = tcw.tolist()
-    Rt = Rcw.T.copy()
-    ow = [-np.float32(np.float32(np.float32(Rt[i, 0] * tcw[0]) + np.float32(Rt[i, 1] * tcw[1])) + np.float32(Rt[i, 2] * tcw[2])) for i in range(3)]
-    V.Ow[:] = [float(v) for v in ow]
+    V.Rcw[:] = [float(v) for v in T.rotationMatrix().ravel()]; V.tcw[:] = [float(v) for v in T.translation()]
+    V.Ow[:] = [float(v) for v in T.inverse().translation()]
+    V.qcw[:] = [float(v) for v in T.unit_quaternion()]
     cam = [float(v) for v in cam]
     V.camera_type = 1 if len(cam) == 8 else 0
     V.cam[:] = cam + [0.0] * (8 - len(cam))
@@ -483,8 +493,8 @@ class LocalPointsBatch:
         self.in_view = np.zeros((B, max(resident.M, 1)), np.uint8)
 
     def set_poses(self, poses):
-        for b, (R, t) in enumerate(poses):
-            frustum_view(R, t, self.cam, self.bounds, self.mbf, self.sf, into=self.views[b])
+        for b, pose in enumerate(poses):
+            frustum_view(as_se3(pose), None, self.cam, self.bounds, self.mbf, self.sf, into=self.views[b])
             self.views[b].scale_factors = self.sf.ctypes.data
 
     def enqueue(self, first=0, is_bad=None, has_obs=None, occupied=None, use_u_right=True, viewing_cos_limit=0.5, th=1.0, far_points=False, th_far=50.0, nnratio=0.8,

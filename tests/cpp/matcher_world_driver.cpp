@@ -75,9 +75,12 @@ template <class HolderT> void fill_holder(World* w, HolderT& H, int N, const KP*
     if (N > 0) memcpy(H.mDescriptors.data, desc, (size_t)N * 32);
     H.mvuRight.assign(N, -1.0f);
     if (u_right) for (int i = 0; i < N; i++) H.mvuRight[i] = u_right[i];
-    Sophus::SE3f Tcw, Trl;
-    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { Tcw.R(r, c) = pose_R[r * 3 + c]; Trl.R(r, c) = trl_R ? trl_R[r * 3 + c] : (r == c ? 1.0f : 0.0f); }
-    for (int r = 0; r < 3; r++) { Tcw.t(r) = pose_t[r]; Trl.t(r) = trl_t ? trl_t[r] : 0.0f; }
+    // poses arrive as (R, t) and go through Sophus' own SE3(R, t) constructor (matrix -> unit quaternion, se3.hpp:480-482), as
+    // Converter::toSophus / Tracking hand them to the reference
+    Eigen::Matrix3f Rc, Rl = Eigen::Matrix3f::Identity(); Eigen::Vector3f tc, tl;
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { Rc(r, c) = pose_R[r * 3 + c]; if (trl_R) Rl(r, c) = trl_R[r * 3 + c]; }
+    for (int r = 0; r < 3; r++) { tc(r) = pose_t[r]; tl(r) = trl_t ? trl_t[r] : 0.0f; }
+    const Sophus::SE3f Tcw(Rc, tc), Trl = trl_R ? Sophus::SE3f(Rl, tl) : Sophus::SE3f(Sophus::SO3f(), tl);
     set_poses(H, Tcw, Trl);
     H.mnMinX = bounds[0]; H.mnMinY = bounds[1]; H.mnMaxX = bounds[2]; H.mnMaxY = bounds[3];
     H.mfGridElementWidthInv = static_cast<float>(FRAME_GRID_COLS) / static_cast<float>(H.mnMaxX - H.mnMinX);     // src/Frame.cc:195-196
@@ -95,7 +98,7 @@ template <class HolderT> void fill_holder(World* w, HolderT& H, int N, const KP*
 Sophus::Sim3f make_sim3(float s, const float* R, const float* t) {
     Eigen::Matrix3f Rm; Eigen::Vector3f tv;
     for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rm(r, c) = R[r * 3 + c]; tv(r) = t[r]; }
-    return Sophus::Sim3f(s, Rm, tv);
+    return Sophus::Sim3f(Sophus::RxSO3f(s, Rm), tv);     // as Converter::toSophus(g2o::Sim3) builds it (src/Converter.cc)
 }
 }  // namespace
 

@@ -515,6 +515,24 @@ class ReferenceFrame:
         n = self.L.ref_frame_features_in_area(self.h, x, y, r, min_level, max_level, idx.ctypes.data, len(idx))
         return idx[:n].copy()
 
+    def search_lastframe(self, R, t, Rl, tl, pos, valid, octave, angle, has_obs, desc, th, mono, check_orientation=True, nnratio=0.9, occupied=None):
+        """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) on the reference's own Frame + ORBmatcher.cc: this frame at pose (R, t) against
+        a last frame at (Rl, tl) with the given map points.  Returns (nmatches, assigned[N], bForward, bBackward)."""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        u8 = lambda a: np.ascontiguousarray(a, np.uint8)
+        R, t, Rl, tl, pos, angle = f32(R), f32(t), f32(Rl), f32(tl), f32(pos), f32(angle)
+        valid, has_obs, desc = u8(valid), u8(has_obs), u8(desc)
+        octave = np.ascontiguousarray(octave, np.int32)
+        occ = None if occupied is None else u8(occupied)
+        assigned = np.full(max(self.N, 1), -1, np.int32); fb = np.zeros(2, np.int32)
+        fn = self.L.ref_frame_search_lastframe
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        n = fn(self.h, R.ctypes.data, t.ctypes.data, Rl.ctypes.data, tl.ctypes.data, len(pos), pos.ctypes.data, valid.ctypes.data, octave.ctypes.data, angle.ctypes.data,
+               has_obs.ctypes.data, desc.ctypes.data, float(th), int(mono), int(check_orientation), float(nnratio), None if occ is None else occ.ctypes.data,
+               assigned.ctypes.data, fb.ctypes.data)
+        return n, assigned[:self.N], bool(fb[0]), bool(fb[1])
+
 
 def reference_frame_repeat(left, right, seconds, nfeatures=1200, scale=1.2, nlevels=8, ini=20, mn=7, fx=458.654, fy=457.296, cx=367.215, cy=248.375, bf=458.654 * 0.110074, th_depth=35.0):
     """Constructs the reference's stereo Frame on (left, right) over and over for `seconds` (long-lived extractors, as Tracking holds them).

@@ -247,15 +247,12 @@ def test_round3_entry_points_reject_bad_arguments(emu_lib):
     # stereo from depth: stride smaller than the image
     assert L.L.orbm_stereo_from_depth(ex._h, 0, 1, np.zeros((240, 320), np.float32).ctypes.data, 100, 320 * 240, 0, 40.0) == ORBX_E_ARG
     # projection: the distance test without distance limits
-    class Spec(C.Structure):
-        _fields_ = [("R", C.c_float * 9), ("t", C.c_float * 3), ("has_sim3", C.c_int), ("R2", C.c_float * 9), ("t2", C.c_float * 3), ("s2", C.c_float), ("Ow", C.c_float * 3),
-                    ("dist_mode", C.c_int), ("depth_test", C.c_int), ("camera_type", C.c_int), ("cam", C.c_float * 8), ("inline_pinhole", C.c_int), ("min_x", C.c_float),
-                    ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float), ("bounds_mode", C.c_int), ("distance_test", C.c_int), ("angle_test", C.c_int), ("bf", C.c_float)]
+    Spec = M._Projection                                       # OrbmProjection (include/orbx.h)
     class PIn(C.Structure):
         _fields_ = [("M", C.c_int), ("pos", C.c_void_p), ("normal", C.c_void_p), ("min_inv", C.c_void_p), ("max_inv", C.c_void_p), ("skip", C.c_void_p)]
     class POut(C.Structure):
         _fields_ = [("valid", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("ur", C.c_void_p), ("inv_z", C.c_void_p), ("dist", C.c_void_p)]
-    sp = Spec(); sp.R[:] = [1, 0, 0, 0, 1, 0, 0, 0, 1]; sp.cam[:] = [300, 300, 160, 120, 0, 0, 0, 0]; sp.max_x, sp.max_y = 320.0, 240.0; sp.distance_test = 1
+    sp = Spec(); sp.q[:] = [0, 0, 0, 1]; sp.cam[:] = [300, 300, 160, 120, 0, 0, 0, 0]; sp.max_x, sp.max_y = 320.0, 240.0; sp.distance_test = 1
     pin = PIn(1, pos.ctypes.data, None, None, None, None); valid = np.zeros(1, np.uint8); u = np.zeros(1, np.float32)
     pout = POut(valid.ctypes.data, u.ctypes.data, None, None, None, None)
     assert L.L.orbm_project_points(ex._h, C.byref(sp), C.byref(pin), C.byref(pout)) == ORBX_E_ARG

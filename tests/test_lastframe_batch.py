@@ -1,36 +1,45 @@
 """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (src/ORBmatcher.cc:1950-2184) for a batch of frames on the device
 (orbm_search_by_projection_lastframe_batch: k_lastframe_queries, k_area_search_threads, k_lastframe_accept incl. the rotation histogram),
-against the single-frame product call (orbm_search_by_projection_frame), which tests/test_matcher_reference.py pins to the reference's own
-ORBmatcher.cc.  Frames with their own last-frame point sets, forward / backward / neutral level windows, occupied keypoints, points without
+against the REFERENCE: its own Frame (stereo constructor, copy constructor for the last frame) and its own ORBmatcher.cc, called once per frame
+(oracle/ref_frame_driver.cpp: ref_frame_search_lastframe), and in addition against the single-frame product call
+(orbm_search_by_projection_frame behind orbm_project_points).  The poses enter both sides as (R, t) through Sophus' SE3(R, t) constructor;
+bForward / bBackward are the reference's (:1966-1975), produced by placing the last frame more than a baseline behind / ahead.  Frames with their own last-frame point sets, forward / backward / neutral level windows, occupied keypoints, points without
 observations, duplicated points (collisions inside the accept kernel's groups of 64), rotated last-frame keypoints (the histogram takes pairs back)."""
 import numpy as np
 import pytest
 
+import oracle_lib as ol
 from orb_slam3_detailed_comments_amd import ORBextractor, synth, views
 from orb_slam3_detailed_comments_amd import matcher as M
 from test_local_points import _rot, FX, FY, CX, CY, BF
+
+BASE = 0.110074
 
 
 def _run(lib, w, h, nf, B, mono):
     rng = np.random.default_rng(808 + B + int(mono))
     pairs = [synth.stereo_pair(w, h, seed=120 + b, nrect=int(3000 * w * h / (752 * 480))) for b in range(B)]
+    refs = [ol.ReferenceFrame(l, r, nf, fx=FX, fy=FY, cx=CX, cy=CY, bf=BF) for l, r in pairs]
     ex = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib)
     cap = ex.max_keypoints()
     res = ex.extract_batch(np.stack([l for l, _ in pairs] + [r for _, r in pairs]))
-    lib.check(lib.L.orbm_stereo_match(ex._h, 0, ex._h, B, B, BF, 0.110074))
+    lib.check(lib.L.orbm_stereo_match(ex._h, 0, ex._h, B, B, BF, BASE))
     u, dep, _ = M.StereoFetch(ex, B)
     sfs = ex.GetScaleFactors()
     cam, bounds = (FX, FY, CX, CY), (0.0, float(w), 0.0, float(h))
     capL = cap + 5
     n = np.zeros(B, np.int32); pos = np.zeros((B, capL, 3), np.float32); valid = np.zeros((B, capL), np.uint8); octave = np.zeros((B, capL), np.int32)
     angle = np.zeros((B, capL), np.float32); has_obs = np.ones((B, capL), np.uint8); desc = np.zeros((B, capL, 32), np.uint8)
-    poses = []
+    poses, last_poses = [], []
     for b in range(B):
         k, d = res[b][1], res[b][2]; N = len(k)
+        assert k.tobytes() == refs[b].keys.tobytes()
         n[b] = N
         # the last frame = the same keypoints seen from a slightly different pose: its map points sit on the current keypoints' rays
         R, t = _rot(*(rng.normal(0, 0.004, 3))), rng.normal(0, 0.02, 3).astype(np.float32)
         poses.append((R, t))
+        # the last frame's pose: the current one moved along the optical axis by 0 / +3 / -3 baselines -> neutral, forward, backward (:1970-1975)
+        last_poses.append((R, (t + np.array([0.0, 0.0, (0.0, 3.0, -3.0)[b % 3] * BASE], np.float32)).astype(np.float32)))
         z = rng.uniform(1.0, 10.0, N)
         Xc = np.stack([(k["x"] + rng.normal(0, 1.0, N) - CX) / FX * z, (k["y"] + rng.normal(0, 1.0, N) - CY) / FY * z, z], 1)
         Xw = (R.astype(np.float64).T @ (Xc - t.astype(np.float64)).T).T
@@ -54,18 +63,29 @@ def _run(lib, w, h, nf, B, mono):
     lf = M.LastFrameBatch(ex, B, cam, bounds, BF, sfs)
     lf.set_poses(poses)
     matcher = M.ORBmatcher(0.9, True)
-    for th, fwd, bwd, occ, ori in ((7.0, None, None, None, True), (15.0, np.arange(B) % 3 == 1, np.arange(B) % 3 == 2, occupied, True), (7.0, None, None, occupied, False)):
+    for th, occ, ori in ((7.0, None, True), (15.0, occupied, True), (7.0, occupied, False)):
         matcher.mbCheckOrientation = ori
+        # the reference, one frame at a time; it also says which way each pair of poses moves
+        ref = [refs[b].search_lastframe(poses[b][0], poses[b][1], last_poses[b][0], last_poses[b][1], pos[b, :n[b]], valid[b, :n[b]], octave[b, :n[b]], angle[b, :n[b]],
+                                        has_obs[b, :n[b]], desc[b, :n[b]], th, mono, ori, 0.9, None if occ is None else occ[b, :n[b]]) for b in range(B)]
+        fwd = np.array([r[2] for r in ref], np.uint8); bwd = np.array([r[3] for r in ref], np.uint8)
+        if not mono:
+            assert [bool(f) for f in fwd] == [b % 3 == 1 for b in range(B)] and [bool(f) for f in bwd] == [b % 3 == 2 for b in range(B)]
+        else:
+            assert not fwd.any() and not bwd.any()
         lf.enqueue(n, pos, valid, octave, angle, has_obs, desc, th, fwd, bwd, ori, occ, use_u_right=not mono)
         asg, nm = lf.fetch()
         total, resets = 0, 0
         for b in range(B):
             N = int(n[b])
-            pr = M.ProjectPoints(ex, poses[b][0], poses[b][1], cam, bounds, pos[b, :N], skip=1 - valid[b, :N], depth_test=2, bounds_mode=0)
+            ref_n, ref_as = ref[b][0], ref[b][1]
+            assert nm[b] == ref_n and np.array_equal(asg[b, :N], ref_as), "frame %d (th %g) vs the reference: %d vs %d matches" % (b, th, nm[b], ref_n)
+            # ... and the single-frame product call behind orbm_project_points
+            pr = M.ProjectPoints(ex, poses[b], cam, bounds, pos[b, :N], skip=1 - valid[b, :N], depth_test=2, bounds_mode=0)
             last = views.last_frame_view(pr["valid"], pr["u"], pr["v"], pr["inv_z"], octave[b, :N], angle[b, :N], has_obs[b, :N], desc[b, :N])
             fv = views.frame_view(res[b][1], res[b][2], sfs, w, h, u_right=None if mono else u[b, :N], mbf=BF, occupied=None if occ is None else occ[b, :N])
-            ref_n, ref_as = matcher.SearchByProjectionFrame(ex, fv, last, th, bool(fwd[b]) if fwd is not None else False, bool(bwd[b]) if bwd is not None else False)
-            assert nm[b] == ref_n and np.array_equal(asg[b, :N], ref_as), "frame %d (th %g): %d vs %d matches" % (b, th, nm[b], ref_n)
+            one_n, one_as = matcher.SearchByProjectionFrame(ex, fv, last, th, bool(fwd[b]), bool(bwd[b]))
+            assert one_n == ref_n and np.array_equal(one_as, ref_as), "frame %d (th %g): single-frame call vs the reference" % (b, th)
             total += ref_n; resets += int((ref_as == -2).sum())
         assert total > 100 * B and (resets > 0) == ori
     ex.close()
