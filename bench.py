@@ -148,6 +148,43 @@ def cpu_baseline(seconds_budget=6.0):
     return {"value": round(n / dt, 2), "unit": "stereo pairs/s", "cores": cores, "kind": "port", "sample": sample}
 
 
+def kernel_sources_sha():
+    """sha256 (16 hex digits) over the device sources of the library: the stamp that ties counter summaries under profiles/ to the kernels they measured."""
+    import hashlib
+    d = os.path.join(ROOT, "orb_slam3_detailed_comments_amd", "csrc")
+    hsh = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".inc")):
+            hsh.update(f.encode()); hsh.update(open(os.path.join(d, f), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
+def other_configs(seconds=1.2):
+    """BASELINE.json configs 0, 2 and 3 beside the headline, in the driver's own line: each is this file run as a child process (`--config X`), i.e. the
+    same setup, warm-up, barrier-bracketed timed region (>= `seconds`) and roofline arithmetic as the headline, reduced to the key figures."""
+    import subprocess
+    out = {}
+    for name in ("mono", "fisheye", "rgbd"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", "20", "--warmup", "5", "--min-seconds", str(seconds), "--no-cpu-baseline", "--no-h2d",
+               "--no-other-configs"]
+        t0 = time.time()
+        try:
+            pr = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            line = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+            if pr.returncode != 0 or not line:
+                out[name] = {"value": None, "error": (pr.stderr or pr.stdout)[-400:]}
+                continue
+            r = json.loads(line[-1])
+            out[name] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "timed_seconds": r["timed_seconds"], "timed_steps": r["timed_steps"],
+                         "units_per_step": r["config"]["units_per_step_per_gpu"], "workload": r["config"]["workload"], "input_mode": r["config"]["input_mode"],
+                         "roofline": {k: r["roofline"][k] for k in ("kernel", "frac", "achieved", "avg_launch_ms", "alone_launch_ms", "end_to_end_frac")},
+                         "avg_keypoints_per_image": r["config"]["avg_keypoints_per_image"], "avg_matches_per_unit": r["config"]["avg_matches_per_unit"],
+                         "wall_seconds_of_child": round(time.time() - t0, 1)}
+        except Exception as e:
+            out[name] = {"value": None, "error": repr(e)}
+    return out
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks (one process per GPU) under torch.distributed.run on
     127.0.0.1 and pass its output and exit code through.  (The round driver starts the ranks itself; WORLD_SIZE is then set and this is skipped.)"""
@@ -183,8 +220,11 @@ def main():
     ap.add_argument("--allgather", action="store_true", help="BASELINE.json configs[4]: after every batch all-gather the descriptor blocks [B, cap, 32] + counts "
                     "of all ranks (RCCL over xGMI) inside the timed region, on a side stream beside the next extraction; the line then also carries the "
                     "collective's own time per batch")
-    ap.add_argument("--min-seconds", type=float, default=1.0, help="the timed region repeats whole blocks of --steps steps until it lasts at least this long "
-                    "(`repeats` in the output; value = all timed units / the whole timed region)")
+    ap.add_argument("--min-seconds", type=float, default=6.0, help="the timed region repeats whole blocks of --steps steps until it lasts at least this long "
+                    "(`repeats` in the output; value = all timed units / the whole timed region).  6 s by default: long enough for an outside observer "
+                    "sampling GPU activity every 5 s (the round driver's rocm-smi sampler) to see the device busy")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the `other_configs` block (mono / fisheye / rgbd = BASELINE.json configs 0, 2, 3, each "
+                    "measured for >= 1 s by this same file in a child process after the headline)")
     ap.add_argument("--import-copy", action="store_true", help="keep the resident inputs in a separate linear device buffer and copy them into the pyramid inside "
                     "every step (the rounds 1-2 measurement) instead of letting the producer write pyramid level 0 directly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -539,13 +579,21 @@ def main():
         ext_stages = ("import", "pyramid", "fast_cells", "quadtree", "blur", "layout", "orient_brief")
         dom = max((k for k in serial_sum if serial_sum[k] > 0 and k in ab), key=lambda k: serial_sum[k])
         achieved = ab[dom] * units[dom] / (stage_ms[dom] * 1e-3) / 1e9
-        traffic = None
+        # HBM traffic of that kernel: NOT measured in this run (counter collection needs rocprofv3 --pmc passes of their own) but read from the
+        # tracked summary of the last such passes and scaled to this launch size; `traffic_source` says which file, which collection and
+        # whether the kernel sources have changed since (then the figure is stale and says so)
+        traffic = None; traffic_source = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc) and kind == "stereo":
             try:
-                traffic = json.load(open(pmc)).get(dom)
+                pj = json.load(open(pmc))
+                traffic = pj.get(dom)
                 if traffic is not None:
                     traffic = int(traffic * NIMG / 128.0)          # the PMC passes ran at 128 images per launch
+                now = kernel_sources_sha()
+                traffic_source = {"file": "profiles/pmc_traffic.json", "collected": pj.get("_source", "round 3 (profiles/r03_final/), before sources carried a stamp"),
+                                  "kernel_sources_sha_then": pj.get("_kernel_sources_sha"), "kernel_sources_sha_now": now,
+                                  "stale": pj.get("_kernel_sources_sha") != now, "measured_in_this_run": False}
             except Exception:
                 traffic = None
         # VALU issue view of the same kernel (the HBM fraction says little for a compute-heavy integer kernel): wave-instructions per launch
@@ -572,7 +620,7 @@ def main():
             "ms_per_step": round(dt / (args.steps * repeats) * 1e3, 4), "repeats": repeats, "timed_steps": args.steps * repeats, "timed_seconds": round(dt, 4),
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": cfg["workload"], "name": args.config,
+            "config": {"workload": cfg["workload"], "name": args.config, "input_mode": "h2d" if args.h2d else ("zero_copy" if zero_copy else "import_copy"),
                        "units_per_step_per_gpu": P, "images_per_step_per_gpu": NIMG, "outputs_copied_to_host": True, "handles_in_flight": NH,
                        "inputs": "uploaded from pinned host memory inside the timed region (PCIe-inclusive variant)" if args.h2d else
                                  ("resident in HBM, written by the producer into the extractor's level-0 layout (orbx_input_buffer): no import pass" if zero_copy else
@@ -587,7 +635,7 @@ def main():
             # per-step completion intervals of the timed region (rank 0; with several handles in flight a step completes every ms_per_step on average)
             "step_ms": {"median": round(pct(per_step, 50), 4), "p10": round(pct(per_step, 10), 4), "p90": round(pct(per_step, 90), 4), "n": int(len(per_step))},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": int(ab[dom] * units[dom]), "avg_launch_ms": round(stage_ms[dom], 4),
                          "alone_launch_ms": round(serial_sum[dom], 4), "alone_GBps": round(ab[dom] * units[dom] / (serial_sum[dom] * 1e-3) / 1e9, 2),
                          "end_to_end_GBps": round(per_unit_bytes * value / world / 1e9, 2),
@@ -632,6 +680,10 @@ def main():
                 hl.close()
             except Exception as e:
                 res["latency"] = {"single_pair_ms": None, "error": repr(e)}
+        if kind == "stereo" and world == 1 and dist is None and not args.no_other_configs and not args.h2d and not os.environ.get("ORBX_BENCH_LIB"):
+            for h in handles:
+                h.sync()
+            res["other_configs"] = other_configs()
         if kind == "stereo" and not args.no_cpu_baseline and world == 1:
             try:
                 res["cpu_baseline"] = cpu_baseline()

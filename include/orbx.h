@@ -115,7 +115,9 @@ int orbx_undistorted_bounds(const orbx_extractor* h, int width, int height, floa
  * A producer that can write there - a camera DMA, a decoder, orbx_input_upload below - hands its frames over without the import pass
  * (one read and one write of every pixel): call orbx_extract_batch(h, B, *dptr, width, height, *stride, *image_stride, 1, ...) with exactly
  * these values and the extraction reads level 0 in place.  Image b starts at dptr + b * image_stride, rows are `stride` bytes apart; bytes
- * beyond `width` in a row are padding.  The buffer stays valid until the handle is reconfigured for another size or a larger batch; level 0
+ * beyond `width` in a row are padding: write ONLY bytes [0, width) of a row.  The padding was zeroed when the buffer was laid out and the
+ * kernels load it as part of whole dwords; no output depends on its value (tests/test_emu_parity.py: test_zero_copy_input_garbage_padding_* fill it with garbage), but a
+ * producer that copies full-pitch rows makes every run read bytes it does not control.  The buffer stays valid until the handle is reconfigured for another size or a larger batch; level 0
  * is never written by the extraction, so a resident batch can be extracted repeatedly. */
 int orbx_input_buffer(orbx_extractor* h, int width, int height, int B, void** dptr, int* stride, size_t* image_stride);
 /* B host images (stride / image_stride as in orbx_extract_batch) into that buffer; blocking */
@@ -336,7 +338,9 @@ int orbm_search_local_points_fetch(orbx_extractor* h, int* assigned, int cap, in
  * forward / backward: [B] bytes, bForward / bBackward of each pair of poses (:1973-1975).  Projection, image test, level window, window search,
  * right-coordinate gate, Hamming distances, the sequential accept loop and the rotation histogram with its three maxima all run on the
  * device.  Asynchronous; orbm_search_local_points_fetch returns assigned [B][cap] (index into the last frame's points, -1 untouched, -2 reset
- * to NULL by the rotation check) and the return value per frame. */
+ * to NULL by the rotation check) and the return value per frame.
+ * ONE pending batch per handle: orbm_search_local_points_batch and this call share the result block; enqueueing either of them discards a
+ * batch that has not been fetched yet, and a call that fails leaves nothing to fetch (orbm_search_local_points_fetch then returns ORBX_E_ARG). */
 typedef struct OrbmLastFrameBatch {
     int cap_last;                          /* rows per frame in the arrays below */
     const int* n;                          /* [B] LastFrame.N */

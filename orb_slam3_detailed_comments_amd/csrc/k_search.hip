@@ -533,7 +533,9 @@ __device__ __forceinline__ void local_accept_body(int M, int cap, const int* __r
         if (LASTFRAME && qi < M) events[qi] = -1;
         while (__ballot(pending) != 0ull) {
             // 1. decision against the current occupancy
-            unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu; int e1 = 0, e2 = 0, idx1 = -1;      // keys (dist << 16 | position), packed dist | level << 16 of both, index of the best
+            // keys (dist << 16 | position), packed dist | level << 16 of both, index of the best.  16 bits hold every position and keypoint index: a
+            // query's candidates are distinct keypoints of one frame, and a frame has fewer than 65535 (kp_total_cap, refused in orbx_api.cpp: configure)
+            unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu; int e1 = 0, e2 = 0, idx1 = -1;
             if (pending) {
                 for (int k = 0; k < cnt; k++) {
                     const int2 e = entries[st + k];

@@ -543,6 +543,7 @@ int orbm_search_local_points_resident(orbx_extractor* h, const OrbmFrameView* F,
 int orbm_stereo_from_depth(orbx_extractor* h, int first, int B, const float* depth, int stride, size_t image_stride, int on_device, float mbf) {
     if (!h || !depth || B <= 0 || first < 0 || first + B > h->lastB) return fail(ORBX_E_ARG, "bad frame range");
     if (stride < h->W || (B > 1 && image_stride < (size_t)stride * (h->H - 1) + h->W)) return fail(ORBX_E_ARG, "depth stride too small");
+    if (undistort_stale(h)) return fail(ORBX_E_ARG, "orbx_set_undistort was called after the last extraction: extract again before orbm_stereo_from_depth");
     rt::set_device(h->device);
     const float* d_depth = depth;
     if (!on_device) {
@@ -554,7 +555,7 @@ int orbm_stereo_from_depth(orbx_extractor* h, int first, int B, const float* dep
     rt::memset_async(h->d_nmatch.p, 0, sizeof(int) * (size_t)B, h->s0);
     dim3 grid((cap + 255) / 256, B, 1), blk(256, 1, 1);
     ORBX_LAUNCH(k_stereo_from_depth, grid, blk, 0, h->s0, (const KeyPointRec*)(h->d_kps.p + (size_t)first * cap),
-                h->undist.active ? (const KeyPointRec*)(h->d_kps_un.p + (size_t)first * cap) : (const KeyPointRec*)nullptr, (const int*)(h->d_nm.p + first), cap,
+                h->ex_undist_active ? (const KeyPointRec*)(h->d_kps_un.p + (size_t)first * cap) : (const KeyPointRec*)nullptr, (const int*)(h->d_nm.p + first), cap,
                 d_depth, stride, image_stride, h->W, h->H, mbf, h->d_uRight.p, h->d_depth.p, h->d_nmatch.p);
     if (rt::check_launch()) return fail(ORBX_E_DEVICE, "kernel launch failed: %s", rt::last_error());
     return ORBX_OK;
@@ -572,9 +573,14 @@ int orbm_search_local_points_batch(orbx_extractor* h, int first, int B, const Or
             return fail(ORBX_E_ARG, "frame %d has other image bounds than frame 0", b);
     }
     if (!(frames[0].max_x > frames[0].min_x) || !(frames[0].max_y > frames[0].min_y)) return fail(ORBX_E_ARG, "empty image bounds");
+    if (undistort_stale(h)) return fail(ORBX_E_ARG, "orbx_set_undistort was called after the last extraction: extract again before searching its frames");
     rt::set_device(h->device);
     const int M = points->M, cap = h->kp_total_cap;
     const size_t B1 = B, M1 = M > 0 ? M : 1, C1 = cap;
+    // every refusal comes BEFORE anything is enqueued into the shared block, and leaves no batch to fetch
+    const size_t smem_accept = 4 * (size_t)((cap + 31) / 32) + 4 * (size_t)cap + 64;
+    if (smem_accept + 1024 > rt::lds_limit(h->device)) { h->lp_B = 0; return fail(ORBX_E_CAPACITY, "%d keypoints per frame need %zu bytes of LDS in the accept kernel", cap, smem_accept); }
+    h->lp_B = 0;                                                // the block is about to be overwritten: a previous, unfetched batch is gone
     if (h->lp_pending) { rt::event_sync(h->ev_lp); }            // the staging block of the previous enqueue has been consumed
     // upload block: poses | bad flags | has-observation flags | occupancy
     const size_t u_f = 0, u_bad = u_f + al16(sizeof(FrustumParams) * B1), u_obs = u_bad + al16(M1), u_occ = u_obs + al16(M1), u_total = u_occ + (occupied ? al16(B1 * C1) : 0);
@@ -606,7 +612,7 @@ int orbm_search_local_points_batch(orbx_extractor* h, int first, int B, const Or
     if (occupied) memcpy(hp + u_occ, occupied, B1 * C1);
     if (rt::copy_h2d(dp, hp, u_total, h->s0) || rt::event_record(h->ev_lp, h->s0)) return fail(ORBX_E_DEVICE, "upload failed: %s", rt::last_error());
     h->lp_pending = true;
-    const KeyPointRec* kps = (h->undist.active ? h->d_kps_un.p : h->d_kps.p) + (size_t)first * cap;     // mvKeysUn
+    const KeyPointRec* kps = (h->ex_undist_active ? h->d_kps_un.p : h->d_kps.p) + (size_t)first * cap;     // mvKeysUn
     const unsigned long long* fdesc = h->d_desc.p + (size_t)first * cap * 4;
     const int* nper = h->d_nm.p + first;
     const float* ur = h->d_uRight.p;
@@ -631,8 +637,7 @@ int orbm_search_local_points_batch(orbx_extractor* h, int first, int B, const Or
     } else rt::memset_async(d_counter, 0, 16, h->s0);
     {
         dim3 grid(B, 1, 1), blk(64, 1, 1);
-        const size_t smem = 4 * (size_t)((cap + 31) / 32) + 4 * (size_t)cap + 64;
-        if (smem + 1024 > rt::lds_limit(h->device)) return fail(ORBX_E_CAPACITY, "%d keypoints per frame need %zu bytes of LDS in the accept kernel", cap, smem);
+        const size_t smem = smem_accept;
         ORBX_LAUNCH(k_local_accept, grid, blk, smem, h->s0, M, cap, nper, (const int*)(dp + o_qs), (const int*)(dp + o_qc), (const int2*)(dp + o_pool),
                     occupied ? (const uint8_t*)(dp + u_occ) : (const uint8_t*)nullptr, (const uint8_t*)(dp + u_obs), nnratio, TH_HIGH, d_assigned, d_nmatch);
     }
@@ -654,9 +659,13 @@ int orbm_search_by_projection_lastframe_batch(orbx_extractor* h, int first, int 
         if (last->n[b] < 0 || last->n[b] > M) return fail(ORBX_E_ARG, "last frame %d: %d points in %d rows", b, last->n[b], M);
     }
     if (!(cur[0].max_x > cur[0].min_x) || !(cur[0].max_y > cur[0].min_y)) return fail(ORBX_E_ARG, "empty image bounds");
+    if (undistort_stale(h)) return fail(ORBX_E_ARG, "orbx_set_undistort was called after the last extraction: extract again before searching its frames");
     rt::set_device(h->device);
     const int cap = h->kp_total_cap;
     const size_t B1 = B, M1 = M, C1 = cap;
+    const size_t smem_accept = 4 * (size_t)((cap + 31) / 32) + 4 * (size_t)cap + 4 * (size_t)M + 64;          // grows with cap_last: checked before anything is enqueued
+    if (smem_accept + 1024 > rt::lds_limit(h->device)) { h->lp_B = 0; return fail(ORBX_E_CAPACITY, "%d keypoints and %d last-frame points per frame need %zu bytes of LDS in the accept kernel", cap, M, smem_accept); }
+    h->lp_B = 0;
     if (h->lp_pending) rt::event_sync(h->ev_lp);
     // upload block: poses | n_last | pos | valid | octave | angle | has_obs | descriptors | occupancy
     const size_t u_f = 0, u_n = u_f + al16(sizeof(FrustumParams) * B1), u_pos = u_n + al16(4 * B1), u_val = u_pos + al16(12 * B1 * M1), u_oct = u_val + al16(B1 * M1),
@@ -690,7 +699,7 @@ int orbm_search_by_projection_lastframe_batch(orbx_extractor* h, int first, int 
     if (occupied) memcpy(hp + u_occ, occupied, B1 * C1);
     if (rt::copy_h2d(dp, hp, u_total, h->s0) || rt::event_record(h->ev_lp, h->s0)) return fail(ORBX_E_DEVICE, "upload failed: %s", rt::last_error());
     h->lp_pending = true;
-    const KeyPointRec* kps = (h->undist.active ? h->d_kps_un.p : h->d_kps.p) + (size_t)first * cap;
+    const KeyPointRec* kps = (h->ex_undist_active ? h->d_kps_un.p : h->d_kps.p) + (size_t)first * cap;
     const unsigned long long* fdesc = h->d_desc.p + (size_t)first * cap * 4;
     const int* nper = h->d_nm.p + first;
     const float* ur = h->d_uRight.p;
@@ -714,8 +723,7 @@ int orbm_search_by_projection_lastframe_batch(orbx_extractor* h, int first, int 
     }
     {
         dim3 grid(B, 1, 1), blka(64, 1, 1);
-        const size_t smem = 4 * (size_t)((cap + 31) / 32) + 4 * (size_t)cap + 4 * (size_t)M + 64;
-        if (smem + 1024 > rt::lds_limit(h->device)) return fail(ORBX_E_CAPACITY, "%d keypoints per frame need %zu bytes of LDS in the accept kernel", cap, smem);
+        const size_t smem = smem_accept;
         ORBX_LAUNCH(k_lastframe_accept, grid, blka, smem, h->s0, M, cap, nper, (const int*)(dp + o_qs), (const int*)(dp + o_qc), (const int2*)(dp + o_pool),
                     occupied ? (const uint8_t*)(dp + u_occ) : (const uint8_t*)nullptr, (const uint8_t*)(dp + u_obs), TH_HIGH, d_assigned, d_nmatch,
                     (const float*)(dp + u_ang), kps, check_ori);

@@ -430,7 +430,7 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
     }
     stage_end(h, ST_DESCRIBE, h->s0);
     rt::event_record(h->ev_done, h->s0);
-    h->lastB = B;
+    h->lastB = B; h->ex_undist_gen = h->undist_gen; h->ex_undist_active = h->undist.active != 0;
     if (rt::check_launch()) return fail(ORBX_E_DEVICE, "kernel launch failed: %s", rt::last_error());
     return ORBX_OK;
 }
@@ -577,7 +577,7 @@ int orbx_extract_batch(orbx_extractor* h, int B, const uint8_t* images, int widt
         // waits for ev_import: after a replay that is the end of the whole graph, which is later than needed but never too early)
         rt::event_record(h->ev_import, h->s0);
         rt::event_record(h->ev_done, h->s0);
-        h->lastB = B;
+        h->lastB = B; h->ex_undist_gen = h->undist_gen; h->ex_undist_active = h->undist.active != 0;
         return ORBX_OK;
     }
 #endif
@@ -772,7 +772,8 @@ int orbx_fetch_undistorted(orbx_extractor* h, OrbxKeyPoint* kps_un, int cap) {
     if (cap < h->kp_total_cap) return fail(ORBX_E_CAPACITY, "rows need %d entries", h->kp_total_cap);
     rt::set_device(h->device);
     const size_t tc = (size_t)h->kp_total_cap;
-    const KeyPointRec* src = h->undist.active ? h->d_kps_un.p : h->d_kps.p;      // without distortion mvKeysUn is mvKeys
+    if (undistort_stale(h)) return fail(ORBX_E_ARG, "orbx_set_undistort was called after the last extraction: mvKeysUn of that batch belongs to the previous model - extract again");
+    const KeyPointRec* src = h->ex_undist_active ? h->d_kps_un.p : h->d_kps.p;      // without distortion mvKeysUn is mvKeys
     int e = 0;
     if ((size_t)cap == tc) e = rt::copy_d2h(kps_un, src, (size_t)h->lastB * tc * sizeof(KeyPointRec), h->s0);
     else for (int b = 0; b < h->lastB; b++) e |= rt::copy_d2h(kps_un + (size_t)b * cap, src + (size_t)b * tc, tc * sizeof(KeyPointRec), h->s0);

@@ -108,5 +108,10 @@ struct orbx_extractor {
     orbx::rt::event_t ev_lp = 0;
     // Frame::UndistortKeyPoints on the device (orbx_set_undistort): mvKeysUn of the last batch
     orbx::UndistortParams undist = {}; int undist_gen = 0, g_undist_gen = 0; orbx::DevBuf<orbx::KeyPointRec> d_kps_un;
+    // the model the LAST EXTRACTION ran with: d_kps_un holds that batch's mvKeysUn (or nothing when it ran without a model).  Consumers read these,
+    // not the live `undist` - orbx_set_undistort between an extraction and a search would otherwise point them at stale or unallocated keypoints
+    int ex_undist_gen = 0; bool ex_undist_active = false;
     orbx::DevBuf<int> d_aux;     // int4 per keypoint: stereo row band / x / octave (k_orient_brief -> k_stereo_match)
 };
+// mvKeysUn of the last extraction no longer matches the undistortion model of the handle (orbx_set_undistort was called in between)
+inline bool undistort_stale(const orbx_extractor* h) { return h->lastB > 0 && h->ex_undist_gen != h->undist_gen; }

@@ -18,7 +18,7 @@ def test_bench_two_ranks_gloo(emu_lib):
     env = dict(os.environ)
     env.update(ORBX_BENCH_BACKEND="gloo", ORBX_BENCH_LIB=os.path.join(ROOT, "tests", "emu", "liborbx_emu.so"), OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "1", "--handles", "1", "--no-cpu-baseline"]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "1", "--handles", "1", "--no-cpu-baseline", "--min-seconds", "0"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -202,6 +202,39 @@ def test_zero_copy_input_gpu(hip_lib):
     _zero_copy_case(hip_lib, 512, 512, 1500)
 
 
+def _garbage_padding_case(lib, w, h, nf):
+    """A producer that copies full-pitch rows leaves arbitrary bytes in the row padding [w, pitch) of level 0; the kernels load them as parts of
+    dwords (k_pyramid_fused, k_resize_rows, the FAST window loads) but no output may depend on them (include/orbx.h: orbx_input_buffer)."""
+    imgs = np.stack([synth.corner_field(w, h, seed=95 + s, nrect=max(200, w * h // 200)) for s in range(2)])
+    a = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib); b = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib)
+    ref = a.extract_batch(imgs)
+    ptr, shape, stride, istride = b.input_upload(imgs)
+    assert stride > w, "this case needs row padding"
+    raw = b.pinned_empty((2, istride), np.uint8)
+    raw[:] = np.random.default_rng(3).integers(0, 256, raw.shape, dtype=np.uint8)           # garbage everywhere, rows included ...
+    for i in range(2):
+        rows = raw[i, :h * stride].reshape(h, stride)
+        rows[:, :w] = imgs[i]                                                                # ... then the pixels where they belong
+    b.device_upload_async(ptr, raw)
+    b.enqueue(None, (0, 0), device_ptr=ptr, shape=shape, stride=stride, image_stride=istride)
+    got = b.fetch()
+    for x, y in zip(got, ref):
+        assert _same(x, y)
+    for l in range(8):
+        assert np.array_equal(b.pyramid_level(l, 1), a.pyramid_level(l, 1)), "level %d" % l
+    a.close(); b.close()
+
+
+def test_zero_copy_input_garbage_padding_emulated(emu_lib):
+    _garbage_padding_case(emu_lib, 376, 240, 400)
+    _garbage_padding_case(emu_lib, 330, 260, 300)
+
+
+@pytest.mark.gpu
+def test_zero_copy_input_garbage_padding_gpu(hip_lib):
+    _garbage_padding_case(hip_lib, 752, 480, 1200)
+
+
 @pytest.mark.parametrize("width", list(range(321, 337)))
 def test_row_ends_of_every_width(emu_lib, width):
     """The streaming kernels (k_resize_rows, k_blur) handle the end of a row by per-thread dword offsets and byte selectors that depend on

@@ -13,6 +13,11 @@ for k, s in stage.items():
     mult = 7 if k == "k_resize" else 1          # the pyramid stage is 7 launches
     out[s] = int((fe + wr) * 1024 * mult)
 out["_note"] = "bytes per stage launch at 128 images/step = (FETCH_SIZE+WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes; 4-B/lane loads, factor 1.0 (calibrated on k_blur)"
+import os, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench
+stamp = {"_kernel_sources_sha": bench.kernel_sources_sha(), "_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ passes of %s (%s)" % (time.strftime("%Y-%m-%d"), os.path.dirname(sys.argv[3]))}
+out.update(stamp)
 json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 print(out)
 
@@ -24,5 +29,6 @@ if len(sys.argv) > 5:
         mult = 7 if k == "k_resize" else 1
         v[s_] = int(q.get(k, {}).get("SQ_INSTS_VALU", {}).get("avg", 0.0) * mult)
     v["_note"] = "VALU wave-instructions per stage launch at 128 images/step (rocprofv3 --pmc SQ_INSTS_VALU, own pass)"
+    v.update(stamp)
     json.dump(v, open(sys.argv[5], "w"), indent=1, sort_keys=True)
     print(v)
