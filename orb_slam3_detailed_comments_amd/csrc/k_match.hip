@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(256) k_kb8_stereo(const KeyPointRec* __restric
         float r1[3], r2[3], p[3];
         kb8_unproject(c1, kl.x, kl.y, r1);
         kb8_unproject(c2, kr.x, kr.y, r2);
-        const float z = kb8_triangulate_matches(c1, c2, r1, r2, kl.x, kl.y, kr.x, kr.y, P.R12, P.t12, P.sigma2[kl.octave], P.sigma2[kr.octave], p);
+        const float z = kb8_triangulate_matches(c1, c2, r1, r2, kl.x, kl.y, kr.x, kr.y, P.R12, P.t12, pick(P.sigma2, kl.octave), pick(P.sigma2, kr.octave), p);
         if (z > 0.0001f) {
             l2r[o] = j; depth[o] = z;
             p3d[3 * o] = p[0]; p3d[3 * o + 1] = p[1]; p3d[3 * o + 2] = p[2];

@@ -250,20 +250,11 @@ __global__ void __launch_bounds__(64 * kAreaWaves) k_area_search(const AreaQuery
 // Batched form: Fbatch != NULL -> blockIdx.y = frame, frame b uses Fbatch[b] and writes at offsets b * M (track: b * 5 * M).
 // F.rig_mode (Frame::isInFrustumChecks, src/Frame.cc:1592-1650, one camera of a two-camera rig; the caller passes that camera's mR, mt, twc
 // and parameters): nothing is stored unless the point passes every test, and the level of a rejected point is -1 (:756-757).
-__global__ void __launch_bounds__(256) k_frustum(FrustumParams F, int M, const float* __restrict__ pos, const float* __restrict__ normal,
-                                                 const float* __restrict__ min_dist, const float* __restrict__ max_dist, const uint8_t* __restrict__ is_bad,
-                                                 uint8_t* __restrict__ in_view, float* __restrict__ track /* [6][M]: x, y, xr, depth, cos, - */,
-                                                 int* __restrict__ scale_level, AreaQuery* __restrict__ queries, int* __restrict__ zero4,
-                                                 const FrustumParams* __restrict__ Fbatch) {
-    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (zero4 && i < 4 && blockIdx.y == 0) zero4[i] = 0;          // the pool counter of the window search that follows (saves a fill launch)
-    if (i >= M) return;
-    if (Fbatch) {
-        const size_t b = blockIdx.y;
-        F = Fbatch[b];
-        in_view += b * (size_t)M; track += 5 * b * (size_t)M; scale_level += b * (size_t)M;
-        if (queries) queries += b * (size_t)M;
-    }
+// (the body takes the frame's parameters by REFERENCE - the kernel argument itself, or the batch's record in global memory: copying one over the
+// other (`F = Fbatch[b]`) made the struct a private variable, 240 bytes of scratch per thread)
+__device__ __forceinline__ void frustum_body(const FrustumParams& F, int i, int M, const float* __restrict__ pos, const float* __restrict__ normal,
+                                             const float* __restrict__ min_dist, const float* __restrict__ max_dist, const uint8_t* __restrict__ is_bad,
+                                             uint8_t* __restrict__ in_view, float* __restrict__ track, int* __restrict__ scale_level, AreaQuery* __restrict__ queries) {
     const float P0 = pos[3 * i], P1 = pos[3 * i + 1], P2 = pos[3 * i + 2];
     bool ok = true;
     float u = -1.0f, v = -1.0f, xr = 0.0f, depth = 0.0f, vcos = 0.0f; int lvl = 0;
@@ -316,11 +307,26 @@ __global__ void __launch_bounds__(256) k_frustum(FrustumParams F, int M, const f
         if (ok && !(F.far_points && depth > F.th_far) && !(is_bad && is_bad[i])) {
             float r = (double)vcos > 0.998 ? 2.5f : 4.0f;             // RadiusByViewingCos, src/ORBmatcher.cc:242-249
             if (F.th != 1.0f) r = __fmul_rn(r, F.th);
-            q.x = u; q.y = v; q.r = __fmul_rn(r, F.scale_factors[lvl]); q.ur = xr;
+            q.x = u; q.y = v; q.r = __fmul_rn(r, pick(F.scale_factors, lvl)); q.ur = xr;
             q.min_level = lvl - 1; q.max_level = lvl; q.active = 1; q.gate = 1;
         }
         queries[i] = q;
     }
+}
+
+__global__ void __launch_bounds__(256) k_frustum(FrustumParams F, int M, const float* __restrict__ pos, const float* __restrict__ normal,
+                                                 const float* __restrict__ min_dist, const float* __restrict__ max_dist, const uint8_t* __restrict__ is_bad,
+                                                 uint8_t* __restrict__ in_view, float* __restrict__ track /* [6][M]: x, y, xr, depth, cos, - */,
+                                                 int* __restrict__ scale_level, AreaQuery* __restrict__ queries, int* __restrict__ zero4,
+                                                 const FrustumParams* __restrict__ Fbatch) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (zero4 && i < 4 && blockIdx.y == 0) zero4[i] = 0;          // the pool counter of the window search that follows (saves a fill launch)
+    if (i >= M) return;
+    if (Fbatch) {
+        const size_t b = blockIdx.y;
+        frustum_body(Fbatch[b], i, M, pos, normal, min_dist, max_dist, is_bad, in_view + b * (size_t)M, track + 5 * b * (size_t)M, scale_level + b * (size_t)M,
+                     queries ? queries + b * (size_t)M : queries);
+    } else frustum_body(F, i, M, pos, normal, min_dist, max_dist, is_bad, in_view, track, scale_level, queries);
 }
 
 // The head of the projection-type searches of ORBmatcher (SearchByProjection(Frame, LastFrame) src/ORBmatcher.cc:1993-2010, (Frame, KeyFrame)
@@ -386,7 +392,7 @@ __global__ void __launch_bounds__(256) k_lastframe_queries(const FrustumParams* 
     const int i = (int)(blockIdx.x * 256 + threadIdx.x);
     if (zero4 && i < 4 && b == 0) zero4[i] = 0;
     if (i >= capL) return;
-    const FrustumParams F = Fb[b];
+    const FrustumParams& F = Fb[b];                                // by reference: a private copy would live in scratch memory
     const size_t o = b * (size_t)capL + i;
     AreaQuery q; q.x = 0; q.y = 0; q.r = 0; q.ur = 0; q.min_level = 0; q.max_level = 0; q.active = 0; q.gate = 0;
     if (i < n_last[b] && valid[o]) {
@@ -402,7 +408,7 @@ __global__ void __launch_bounds__(256) k_lastframe_queries(const FrustumParams* 
             if (F.kb8) { KB8Cam c; for (int k = 0; k < 8; k++) c.p[k] = F.cam[k]; const float pc[3] = {x, y, z}; float uv[2]; kb8_project(c, pc, uv); u = uv[0]; v = uv[1]; }
             else { u = __fadd_rn(__fdiv_rn(__fmul_rn(F.cam[0], x), z), F.cam[2]); v = __fadd_rn(__fdiv_rn(__fmul_rn(F.cam[1], y), z), F.cam[3]); }
             if (!(u < F.min_x || u > F.max_x || v < F.min_y || v > F.max_y)) {
-                q.x = u; q.y = v; q.r = __fmul_rn(F.th, F.scale_factors[oct]); q.ur = __fsub_rn(u, __fmul_rn(F.mbf, invz));
+                q.x = u; q.y = v; q.r = __fmul_rn(F.th, pick(F.scale_factors, oct)); q.ur = __fsub_rn(u, __fmul_rn(F.mbf, invz));
                 if (F.forward) { q.min_level = oct; q.max_level = -1; }
                 else if (F.backward) { q.min_level = 0; q.max_level = oct; }
                 else { q.min_level = oct - 1; q.max_level = oct + 1; }

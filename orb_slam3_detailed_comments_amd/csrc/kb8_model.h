@@ -73,9 +73,18 @@ ORBX_HD inline void null_vector4(const float A[16], double x[4]) {
                 for (int k = 0; k < 4; k++) { const double a = V[k][p], b = V[k][q]; V[k][p] = cs * a - sn * b; V[k][q] = sn * a + cs * b; }
             }
     }
-    int m = 0;
-    for (int i = 1; i < 4; i++) if (M[i][i] < M[m][m]) m = i;
-    for (int k = 0; k < 4; k++) x[k] = V[k][m];
+    // column of V that belongs to the smallest eigenvalue, by selects: an index computed at run time (V[k][m]) would send the whole of V to
+    // private memory (the kernels that inline this carried a 144-byte scratch segment for it)
+    double best = M[0][0];
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = V[k][0];
+#pragma unroll
+    for (int i = 1; i < 4; i++) {
+        const bool take = M[i][i] < best;
+        best = take ? M[i][i] : best;
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[k] = take ? V[k][i] : x[k];
+    }
 }
 
 // KannalaBrandt8::TriangulateMatches (:439-523) with the two rays already unprojected (r1 by this camera, r2 by camera 2).

@@ -84,4 +84,13 @@ __device__ __forceinline__ T block_excl_scan_n(T v, T* total, T* scratch, int nw
     return base + inc - v;
 }
 
+// a[i] of a small array that lives in registers / kernel arguments, by selects: indexing it with a per-lane value would move the whole
+// enclosing struct to private memory (k_frustum and k_lastframe_queries carried a 240-byte scratch segment for F.scale_factors[level])
+template <int N> __device__ __forceinline__ float pick(const float (&a)[N], int i) {
+    float r = a[0];
+#pragma unroll
+    for (int k = 1; k < N; k++) r = (i == k) ? a[k] : r;
+    return r;
+}
+
 }  // namespace orbx

@@ -111,6 +111,8 @@ __device__ __forceinline__ pk2 pk_xor(pk2 a, uint32_t x) { return __builtin_bit_
 __device__ __forceinline__ uint32_t pk_bits(pk2 a) { return __builtin_bit_cast(uint32_t, a); }
 #endif
 struct u32x2 { uint32_t lo, hi; };
+// 8 bytes from any byte address of the LDS / global memory (one ds_read_b64 / global_load_dwordx2; no alignment requirement on gfx950)
+__device__ __forceinline__ u32x2 load_u64_any(const uint8_t* p) { u32x2 v; __builtin_memcpy(&v, p, 8); return v; }
 // Buffer addressing (buffer_load_dword v, voffset, s[rsrc], soffset offen): a wave-uniform base (resource descriptor in SGPRs) plus a
 // wave-uniform byte offset (SGPR) plus a per-lane byte offset (VGPR) - streaming kernels that walk rows pay no vector instruction per
 // address.  Raw (stride 0), offsets unchecked up to 2 GiB.
