@@ -424,13 +424,20 @@ def main():
     # side stream beside the extraction of the following batches and is waited for when its handle comes round again
     ag_works = [None] * NH
     ag_stream = None
+    lib_comm = None
     if args.allgather:
         from orb_slam3_detailed_comments_amd import multi
         if dist_on_gpu:
-            import torch
-            ag_stream = torch.cuda.Stream()
+            # the exchange runs INSIDE the library (include/orbx.h: orbx_comm_*, orbx_allgather_descriptors - the entry a C++ host calls): RCCL on the
+            # communicator's own stream behind a device-to-device snapshot; torch.distributed only carries rank 0's ncclUniqueId to the other ranks
+            lib_comm = multi.Communicator.from_torch_distributed(lib, local)
+        # (gloo test runs keep the torch.distributed path: their ranks are processes without GPUs, which the emulator's in-process stand-in cannot join)
 
     def ag_wait(i):
+        if lib_comm is not None:
+            if ag_works[i] is not None:
+                lib_comm.wait(); ag_works[i] = None
+            return
         if ag_works[i] is not None:
             for w in ag_works[i][2]:
                 w.wait()
@@ -441,7 +448,10 @@ def main():
         lib.check(lib.L.orbx_fetch(h._h, o["k"].ctypes.data, o["d"].ctypes.data, cap, o["n"].ctypes.data, o["m"].ctypes.data))
         if args.allgather and gather:            # (collective: every rank calls it the same number of times)
             ag_wait(i)
-            ag_works[i] = multi.all_gather_extracted(h, ag_stream)
+            if lib_comm is not None:
+                lib_comm.all_gather(h); ag_works[i] = True          # one communicator: it waits for its previous exchange itself
+            else:
+                ag_works[i] = multi.all_gather_extracted(h, ag_stream)
         if kind == "stereo":
             lib.check(lib.L.orbm_stereo_fetch(h._h, P, o["u"].ctypes.data, o["z"].ctypes.data, cap, o["nm"].ctypes.data))
         elif kind == "fisheye":
@@ -528,9 +538,12 @@ def main():
         sync_all()
         ta = time.perf_counter()
         for _ in range(nrep):
-            _, _, ws = multi.all_gather_extracted(handles[0], None)
-            for w in ws:
-                w.wait()
+            if lib_comm is not None:
+                lib_comm.all_gather(handles[0]); lib_comm.wait()
+            else:
+                _, _, ws = multi.all_gather_extracted(handles[0], None)
+                for w in ws:
+                    w.wait()
         sync_all()
         ta = (time.perf_counter() - ta) / nrep
         t = torch.tensor([ta], dtype=torch.float64, device=coll_dev)
@@ -538,6 +551,7 @@ def main():
         blk_bytes = NIMG * cap * 32 + NIMG * 4
         ag_alone = {"ms_per_batch_alone": round(float(t.item()) * 1e3, 4), "bytes_per_rank": blk_bytes, "bytes_gathered_per_rank": blk_bytes * world,
                     "bus_GBps_per_rank": round(blk_bytes * (world - 1) / max(float(t.item()), 1e-9) / 1e9, 2), "backend": backend,
+                    "path": "orbx_allgather_descriptors (RCCL inside the library, C ABI)" if lib_comm is not None else "torch.distributed.all_gather_into_tensor",
                     "where": "side stream, overlapping the next extractions; included in the timed region"}
     if rank == 0:
         total_units = P * args.steps * repeats * world

@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <set>
 #include <stdexcept>
@@ -78,7 +79,6 @@ public:
             if (pKF->mpCamera2) k.v.u_right = nullptr;                            // bStereo = !mpCamera2 && mvuRight[idx] >= 0 (:1126)
             orbm_keyframe* r = nullptr;
             {
-                std::lock_guard<std::mutex> lock(Mutex());
                 Check(orbm_keyframe_create(SharedHandle(), &k.v, &r));
             }
             if (pKF->N > 0 && pKF->mFeatVec.empty()) { transient = r; return r; }
@@ -111,7 +111,6 @@ public:
     static void DescriptorDistances(const cv::Mat &A, const cv::Mat &B, std::vector<int>& out)
     {
         out.resize((size_t)A.rows * B.rows);
-        std::lock_guard<std::mutex> lock(Mutex());
         if (A.rows && B.rows) Check(orbm_hamming_matrix(SharedHandle(), A.ptr(0), A.rows, B.ptr(0), B.rows, out.data()));
     }
 
@@ -137,13 +136,11 @@ public:
         if (!rig) {
             FrameStore fs; FillFrame(F, fs, OccupiedWithObservations);
             assigned.assign(F.N > 0 ? F.N : 1, -1);
-            std::lock_guard<std::mutex> lock(Mutex());
             Check(orbm_search_by_projection_mappoints(SharedHandle(), &fs.v, &mv, th, bFarPoints, thFarPoints, mfNNratio, assigned.data(), &nmatches));
         } else {
             RigStore rs; FillRig(F, rs, OccupiedWithObservations);
             OrbmMapPointRightView mr = {inViewR.data(), pxr.data(), pyr.data(), lvlR.data(), vcosR.data()};
             assigned.assign(F.N > 0 ? F.N : 1, -1);
-            std::lock_guard<std::mutex> lock(Mutex());
             Check(orbm_search_by_projection_mappoints_fisheye(SharedHandle(), &rs.v, &mv, &mr, th, bFarPoints, thFarPoints, mfNNratio, assigned.data(), &nmatches));
         }
         for (int i = 0; i < F.N; i++) if (assigned[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[assigned[i]];
@@ -192,11 +189,9 @@ public:
         int nmatches = 0;
         if (!twoCameras) {
             FrameStore fs; FillFrame(CurrentFrame, fs, OccupiedWithObservations);
-            std::lock_guard<std::mutex> lock(Mutex());
             Check(orbm_search_by_projection_frame(SharedHandle(), &fs.v, &lv, th, towards, away, mbCheckOrientation, assigned.data(), &nmatches));
         } else {
             RigStore rs; FillRig(CurrentFrame, rs, OccupiedWithObservations);
-            std::lock_guard<std::mutex> lock(Mutex());
             Check(orbm_search_by_projection_frame_fisheye(SharedHandle(), &rs.v, &lv, uR.data(), vR.data(), th, towards, away, mbCheckOrientation,
                                                           assigned.data(), &nmatches));
         }
@@ -234,7 +229,6 @@ public:
         std::vector<int> assigned(CurrentFrame.N > 0 ? CurrentFrame.N : 1, -1);
         int nmatches = 0;
         {
-            std::lock_guard<std::mutex> lock(Mutex());
             Check(orbm_search_by_projection_keyframe(SharedHandle(), &fs.v, ps.view(), th, ORBdist, mbCheckOrientation, assigned.data(), &nmatches));
         }
         for (int i = 0; i < CurrentFrame.N; i++) {
@@ -291,14 +285,12 @@ public:
         if (!rig) {
             std::vector<int> m12(pKF->N > 0 ? pKF->N : 1, -1);
             {
-                std::lock_guard<std::mutex> lock(Mutex());
                 Check(orbm_search_by_bow(SharedHandle(), &k1.v, &k2.v, mfNNratio, 1, mbCheckOrientation, m12.data(), &nmatches));
             }
             for (int i = 0; i < pKF->N; i++) if (m12[i] >= 0) vpMapPointMatches[m12[i]] = vpMapPointsKF[i];
         } else {
             std::vector<int> a2(F.N > 0 ? F.N : 1, -1);
             {
-                std::lock_guard<std::mutex> lock(Mutex());
                 Check(orbm_search_by_bow_fisheye(SharedHandle(), &k1.v, &k2.v, F.Nleft, mfNNratio, mbCheckOrientation, a2.data(), &nmatches));
             }
             for (int j = 0; j < F.N; j++) if (a2[j] >= 0) vpMapPointMatches[j] = vpMapPointsKF[a2[j]];
@@ -337,7 +329,6 @@ public:
             m12[i].assign(pKF->N > 0 ? pKF->N : 1, -1); m12p[i] = m12[i].data();
         }
         {
-            std::lock_guard<std::mutex> lock(Mutex());
             Check(orbm_keyframe_create(SharedHandle(), &kf.v, &rf));
             for (int i = 0; i < n; i++) k2[i] = rf;
             const int rc = orbm_search_by_bow_resident(SharedHandle(), n, k1.data(), goodp.data(), k2.data(), nullptr, mfNNratio, 1, mbCheckOrientation, m12p.data(), counts.data());
@@ -365,7 +356,6 @@ public:
         std::vector<int> m12(vpMapPoints1.size() > 0 ? vpMapPoints1.size() : 1, -1);
         int nmatches = 0;
         {
-            std::lock_guard<std::mutex> lock(Mutex());
             Check(orbm_search_by_bow(SharedHandle(), &k1.v, &k2.v, mfNNratio, 0, mbCheckOrientation, m12.data(), &nmatches));
         }
         for (size_t i = 0; i < vpMapPoints1.size(); i++) if (m12[i] >= 0) vpMatches12[i] = vpMapPoints2[m12[i]];
@@ -384,7 +374,6 @@ public:
         int nmatches = 0;
         std::vector<int> m12(N1 > 0 ? N1 : 1, -1);
         {
-            std::lock_guard<std::mutex> lock(Mutex());
             Check(orbm_search_for_initialization(SharedHandle(), &f1.v, &f2.v, prev.data(), windowSize, mfNNratio, mbCheckOrientation, m12.data(), &nmatches));
         }
         for (int i = 0; i < N1; i++) { vnMatches12[i] = m12[i]; vbPrevMatched[i].x = prev[2 * i]; vbPrevMatched[i].y = prev[2 * i + 1]; }
@@ -443,7 +432,6 @@ public:
         std::vector<int> m12(pKF1->N > 0 ? pKF1->N : 1, -1);
         int nmatches = 0;
         {
-            std::lock_guard<std::mutex> lock(Mutex());
             Check(orbm_search_for_triangulation(SharedHandle(), &k1.v, &k2.v, f12, epf, bOnlyStereo, bCoarse, mbCheckOrientation, m12.data(), &nmatches));
         }
         vMatchedPairs.clear();
@@ -487,7 +475,6 @@ public:
         orbm_keyframe* k1 = cache.Get(pKF1);
         std::vector<int> m12((size_t)n2 * N1, -1);
         {
-            std::lock_guard<std::mutex> lock(Mutex());
             if (fisheye) Check(orbm_search_for_triangulation_resident_kb8(SharedHandle(), k1, mp1.data(), n2, k2.data(), mp2p.data(), kbs.data(), eps.data(), bOnlyStereo, bCoarse,
                                                                           mbCheckOrientation, m12.data(), counts.data()));
             else Check(orbm_search_for_triangulation_resident(SharedHandle(), k1, mp1.data(), n2, k2.data(), mp2p.data(), f12s.data(), eps.data(), bOnlyStereo, bCoarse,
@@ -545,7 +532,6 @@ public:
         const float epf[2] = {epx, epy};
         int nmatches = 0;
         {
-            std::lock_guard<std::mutex> lock(Mutex());
             Check(orbm_search_for_triangulation_kb8(SharedHandle(), &k1.v, &k2.v, &kb, epf, bOnlyStereo, bCoarse, mbCheckOrientation, m12.data(), &nmatches));
         }
         vMatchedPairs.clear();
@@ -596,7 +582,6 @@ public:
         std::vector<int> m12(n[0] > 0 ? n[0] : 1, -1);
         int nFound = 0;
         {
-            std::lock_guard<std::mutex> lock(Mutex());
             Check(orbm_search_by_sim3(SharedHandle(), &f1.v, &f2.v, proj[0].view(), proj[1].view(), th, m12.data(), &nFound));
         }
         for (int i = 0; i < n[0]; i++) if (m12[i] >= 0) vpMatches12[i] = own[1][m12[i]];
@@ -639,7 +624,6 @@ public:
         }
         std::vector<int> best(nMPs > 0 ? nMPs : 1, -1);
         {
-            std::lock_guard<std::mutex> lock(Mutex());
             Check(orbm_fuse_candidates(SharedHandle(), &fs.v, ps.view(), th, 1, pKF->mvInvLevelSigma2.data(), best.data(), nullptr));
         }
         if (bRight) for (int i = 0; i < nMPs; i++) if (best[i] >= 0) best[i] += pKF->NLeft;       // :1488
@@ -683,7 +667,6 @@ public:
         FrameStore fs; FillFrame(*pKF, fs);
         std::vector<int> best(nPoints > 0 ? nPoints : 1, -1);
         {
-            std::lock_guard<std::mutex> lock(Mutex());
             Check(orbm_fuse_candidates(SharedHandle(), &fs.v, ps.view(), th, 0, nullptr, best.data(), nullptr));
         }
         int merged = 0;                                     // :1640-1656: here a keypoint that already has a point only reports it
@@ -699,15 +682,31 @@ public:
 public:
     // One library handle (HIP streams + device scratch) per calling THREAD: the reference's matchers are stateless and are called
     // concurrently from the Tracking, LocalMapping and LoopClosing threads; with a handle of its own each of them runs
-    // its searches on its own stream without waiting for the others.  The handle lives as long as its thread.
+    // its searches on its own stream without waiting for the others, and no lock is needed around a call (a handle is never shared).
+    // The handle lives as long as its thread.
+    // Multi-GPU hosts (one SLAM system per GPU, BASELINE.json configs[4]): the handle is created on the GPU chosen by SetDevice() - process-wide,
+    // the default for every thread - or SetThreadDevice() - the calling thread only, e.g. the tracking thread of the system that owns GPU k;
+    // pass the same index as the extractor's device_id.  Changing the device re-creates the thread's handle on the next call.
+    static void SetDevice(int device) { ProcessDevice().store(device); }
+    static void SetThreadDevice(int device) { ThreadDevice() = device; }
+    static int Device() { const int t = ThreadDevice(); return t >= 0 ? t : ProcessDevice().load(); }
     static orbx_extractor* SharedHandle()
     {
-        struct Holder { orbx_extractor* h = nullptr; ~Holder() { if (h) orbx_destroy(h); } };
+        struct Holder { orbx_extractor* h = nullptr; int device = -1; ~Holder() { if (h) orbx_destroy(h); } };
         static thread_local Holder t;
-        if (!t.h && orbx_create(&t.h, 1000, 1.2f, 8, 20, 7, 0) != ORBX_OK) { t.h = nullptr; throw std::runtime_error(std::string("ORBmatcher (HIP): ") + orbx_last_error()); }
+        const int want = Device();
+        if (t.h && t.device != want) { orbx_destroy(t.h); t.h = nullptr; }
+        // (the extractor geometry of a matcher handle is never used: it only owns streams, staging buffers and the search kernels' scratch)
+        if (!t.h) {
+            if (orbx_create(&t.h, 1000, 1.2f, 8, 20, 7, want) != ORBX_OK) { t.h = nullptr; throw std::runtime_error(std::string("ORBmatcher (HIP): ") + orbx_last_error()); }
+            t.device = want;
+        }
         return t.h;
     }
-    static std::mutex& Mutex() { static thread_local std::mutex m; return m; }      // per thread as well: never contended
+private:
+    static std::atomic<int>& ProcessDevice() { static std::atomic<int> d(0); return d; }
+    static int& ThreadDevice() { static thread_local int d = -1; return d; }
+public:
     static void Check(int rc) { if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBmatcher (HIP): ") + orbx_last_error()); }
 
 protected:
@@ -751,7 +750,6 @@ protected:
         {
             OrbmProjectIn in = {M, pos.data(), normal.data(), minInv.data(), maxInv.data(), skip.data()};
             OrbmProjectOut out = {valid.data(), u.data(), v.data(), ur.data(), invz.data(), dist.data()};
-            std::lock_guard<std::mutex> lock(Mutex());
             Check(orbm_project_points(SharedHandle(), &spec, &in, &out));
         }
     };
@@ -911,7 +909,6 @@ protected:
         fs.v.occupied = fs.occ.data();
         assigned.assign(N > 0 ? N : 1, -1);
         int nmatches = 0;
-        std::lock_guard<std::mutex> lock(Mutex());
         Check(orbm_search_by_projection_sim3(SharedHandle(), &fs.v, ps.view(), (float)th, ratioHamming, assigned.data(), &nmatches));
         return nmatches;
     }

@@ -131,6 +131,30 @@ int orbx_device_outputs(orbx_extractor* h, void** kps, void** desc, void** n, vo
  * either may be NULL): device-to-device copies on the handle's stream behind the extraction, complete when the call returns.  The handle's own
  * buffers are rewritten by its next extraction, so a consumer that overlaps that extraction (an asynchronous collective) works on a snapshot. */
 int orbx_device_snapshot(orbx_extractor* h, void* desc_dst, void* n_dst);
+/* ---- the exchange step of the multi-GPU mode (BASELINE.json configs[4]) ----
+ * Streams are independent: one process (or thread) per GPU, each with its own extractor / matcher handles created with that GPU's device_id,
+ * and no collective on the hot path.  The ONE exchange a host may want - every rank's descriptor blocks on every rank, in front of a global
+ * matcher - is an all-gather over RCCL / xGMI, offered here so that a C++ host needs neither Python nor torch.distributed:
+ *   rank 0:      orbx_comm_unique_id(id)  ->  id reaches the other ranks by whatever the host has (MPI, a socket, a file, torch.distributed)
+ *   every rank:  orbx_comm_create(&c, world, rank, id, device_id)         (collective: ncclCommInitRank; or orbx_comm_adopt for an ncclComm_t it owns)
+ *   per batch:   orbx_extract_batch(h, ...); orbx_allgather_descriptors(h, c, &desc_all, &n_all, &B, &cap);  ...next extraction...;  orbx_comm_wait(c)
+ * orbx_allgather_descriptors snapshots the descriptor block [B][cap][32] (rows beyond n[b] zero) and the counts [B] of h's last batch behind the
+ * extraction, then gathers both over the communicator's own stream: ASYNCHRONOUS - the handle may extract its next batch at once.  desc_all
+ * [world][B][cap][32] and n_all [world][B] are device memory of the communicator, valid after orbx_comm_wait and until the next call; every
+ * rank must gather blocks of the same shape (same B, same extractor geometry).  orbx_comm_fetch waits and copies them to the host.
+ * librccl is loaded (dlopen) by the first orbx_comm_* call; hosts that never call them never load it. */
+typedef struct orbx_comm orbx_comm;
+#define ORBX_COMM_ID_BYTES 128            /* sizeof(ncclUniqueId) */
+int orbx_comm_unique_id(uint8_t id[ORBX_COMM_ID_BYTES]);
+int orbx_comm_create(orbx_comm** c, int world, int rank, const uint8_t id[ORBX_COMM_ID_BYTES], int device_id);
+int orbx_comm_adopt(orbx_comm** c, void* nccl_comm /* ncclComm_t of the caller, not destroyed by orbx_comm_destroy */, int world, int rank, int device_id);
+void orbx_comm_destroy(orbx_comm* c);
+int orbx_comm_world(const orbx_comm* c);
+int orbx_comm_rank(const orbx_comm* c);
+int orbx_allgather_descriptors(orbx_extractor* h, orbx_comm* c, void** desc_all, void** n_all, int* B, int* cap);   /* out pointers may be NULL */
+int orbx_comm_wait(orbx_comm* c);
+int orbx_comm_fetch(orbx_comm* c, uint8_t* desc_all_host, int* n_all_host);                                           /* either may be NULL */
+
 /* GPU index the handle was created on; ORBX_DEVICE_HOST when the library's "device" memory is plain host memory (only the CPU emulator build of
  * the kernel sources that the tests use - the product library never returns it) */
 #define ORBX_DEVICE_HOST (-1)

@@ -33,6 +33,8 @@ SYMBOLS = [
     "orbm_project_points", "orbm_search_by_projection_sim3", "orbm_search_by_projection_keyframe", "orbm_fuse_candidates", "orbm_search_by_sim3", "orbm_distinctive_descriptors",
     "orbm_search_by_projection_mappoints_fisheye", "orbm_search_by_projection_frame_fisheye", "orbm_search_for_triangulation_batch",
     "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_words", "orbv_transform", "orbv_transform_extracted", "orbv_fetch",
+    "orbx_comm_unique_id", "orbx_comm_create", "orbx_comm_adopt", "orbx_comm_destroy", "orbx_comm_world", "orbx_comm_rank", "orbx_allgather_descriptors", "orbx_comm_wait",
+    "orbx_comm_fetch",
     "orbx_last_error",
 ]
 
@@ -142,6 +144,14 @@ class OrbxLib:
         L.orbv_transform.argtypes = [vp, vp, vp, i, i, vp, vp, vp, vp, ip, vp, vp, vp, ip]
         L.orbv_transform_extracted.argtypes = [vp, vp, i, i, i]
         L.orbv_fetch.argtypes = [vp, vp, i, vp, vp, i, vp, vp, ip, vp, vp, vp, ip]
+        L.orbx_comm_unique_id.argtypes = [vp]
+        L.orbx_comm_create.argtypes = [C.POINTER(vp), i, i, vp, i]
+        L.orbx_comm_adopt.argtypes = [C.POINTER(vp), vp, i, i, i]
+        L.orbx_comm_destroy.argtypes = [vp]; L.orbx_comm_destroy.restype = None
+        L.orbx_comm_world.argtypes = [vp]; L.orbx_comm_rank.argtypes = [vp]
+        L.orbx_allgather_descriptors.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(vp), ip, ip]
+        L.orbx_comm_wait.argtypes = [vp]
+        L.orbx_comm_fetch.argtypes = [vp, vp, vp]
         L.orbx_last_error.restype = C.c_char_p
 
     def check(self, rc):

@@ -14,7 +14,8 @@ typedef event_s* event_t;
 inline double now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 inline int set_device(int) { return 0; }
 inline bool memory_is_host() { return true; }
-inline int device_count() { return 1; }
+// ORBX_EMU_DEVICES: the tests let the emulator report several "GPUs" (all of them host memory) to exercise the device plumbing of multi-GPU hosts
+inline int device_count() { const char* e = getenv("ORBX_EMU_DEVICES"); const int n = e ? atoi(e) : 1; return n > 0 ? n : 1; }
 inline void* dmalloc(size_t n) { return calloc(n ? n : 1, 1); }
 inline void dfree(void* p) { free(p); }
 inline void* hmalloc(size_t n) { return calloc(n ? n : 1, 1); }

@@ -76,6 +76,64 @@ def all_gather_extracted(extractor, side_stream=None):
     return dall.view((world, B) + tuple(d.shape[1:])), call.view(world, B), (w1, w2)
 
 
+class Communicator:
+    """The exchange step behind the C ABI (include/orbx.h: orbx_comm_*, orbx_allgather_descriptors): RCCL over xGMI inside the library, no torch.
+    A C++ host calls the same entry points.  `unique_id` = Communicator.unique_id(lib) on rank 0, handed to the other ranks by any means
+    (from_torch_distributed below uses the process group that launched the ranks)."""
+
+    def __init__(self, lib, world, rank, unique_id, device_id=0):
+        import ctypes as C
+        self._lib = lib
+        self.world, self.rank = int(world), int(rank)
+        idb = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        h = C.c_void_p()
+        lib.check(lib.L.orbx_comm_create(C.byref(h), self.world, self.rank, idb, int(device_id)))
+        self._c = h
+        self.B = self.cap = 0
+
+    @staticmethod
+    def unique_id(lib):
+        import ctypes as C
+        idb = (C.c_uint8 * 128)()
+        lib.check(lib.L.orbx_comm_unique_id(idb))
+        return bytes(idb)
+
+    @classmethod
+    def from_torch_distributed(cls, lib, device_id=0):
+        """One communicator over the ranks of the default torch.distributed group: rank 0's unique id travels through broadcast_object_list
+        (any backend; gloo in the CPU tests), the collectives themselves run inside the library."""
+        import torch.distributed as dist
+        box = [cls.unique_id(lib) if dist.get_rank() == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls(lib, dist.get_world_size(), dist.get_rank(), box[0], device_id)
+
+    def all_gather(self, extractor):
+        """Enqueue the all-gather of the descriptor blocks + counts of `extractor`'s last batch (asynchronous: the extractor may start its next batch)."""
+        import ctypes as C
+        B = C.c_int(); cap = C.c_int(); d = C.c_void_p(); n = C.c_void_p()
+        self._lib.check(self._lib.L.orbx_allgather_descriptors(extractor._h, self._c, C.byref(d), C.byref(n), C.byref(B), C.byref(cap)))
+        self.B, self.cap, self.desc_ptr, self.n_ptr = B.value, cap.value, d, n
+
+    def wait(self):
+        self._lib.check(self._lib.L.orbx_comm_wait(self._c))
+
+    def fetch(self):
+        """(desc_all [world, B, cap, 32] u8, n_all [world, B] i32) on the host; waits for the exchange."""
+        desc = np.zeros((self.world, self.B, self.cap, 32), np.uint8); n = np.zeros((self.world, self.B), np.int32)
+        self._lib.check(self._lib.L.orbx_comm_fetch(self._c, desc.ctypes.data, n.ctypes.data))
+        return desc, n
+
+    def close(self):
+        if self._c:
+            self._lib.L.orbx_comm_destroy(self._c); self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def process_streams(extractor, frames_of_stream, rank, world, lap=(0, 0)):
     """Extracts one frame batch: frames_of_stream[s] is the current image of stream s (all the same size); this rank
     processes its own streams in one batched launch.  Returns {stream: (mono, kps, desc)}."""

@@ -58,7 +58,11 @@ int main(int argc, char** argv) {
         for (int i = 0; i < dA[t].rows * 32; i++) dA[t].ptr(0)[i] = (unsigned char)rng();
         for (int i = 0; i < dB[t].rows * 32; i++) dB[t].ptr(0)[i] = (unsigned char)rng();
     }
+    // optional 4th argument: number of GPUs D.  Thread t then works on GPU t % D - its matcher handle through ORBmatcher::SetThreadDevice, and
+    // (second part) an extractor of its own with deviceId = t % D plus the all-gather of the descriptor blocks over the C ABI, one rank per GPU.
+    const int D = argc > 4 ? atoi(argv[4]) : 1;
     auto work = [&](int t, std::vector<int>& assign, std::vector<int>& dist) {
+        ORB_SLAM3::ORBmatcher::SetThreadDevice(t % D);
         ORB_SLAM3::ORBmatcher m(0.8f);
         MockFrame& F = frames[t];
         F.mvpMapPoints.assign(F.N, nullptr);
@@ -82,6 +86,40 @@ int main(int argc, char** argv) {
         });
     for (auto& x : th) x.join();
     int matched = 0; for (int v : expect[0]) matched += v >= 0;
-    printf("threads=%d reps=%d mismatches=%d matches(thread 0)=%d\n", T, REPS, bad.load(), matched);
-    return (bad.load() == 0 && matched > 50) ? 0 : 1;
+    printf("threads=%d reps=%d devices=%d mismatches=%d matches(thread 0)=%d\n", T, REPS, D, bad.load(), matched);
+    // ---- one rank per GPU: extractor + matcher on device r, the descriptor exchange of BASELINE.json configs[4] from C++ (no Python, no torch) ----
+    std::atomic<int> bad2(0);
+    if (D > 1) {
+        uint8_t id[ORBX_COMM_ID_BYTES];
+        if (orbx_comm_unique_id(id) != ORBX_OK) { fprintf(stderr, "unique id: %s\n", orbx_last_error()); return 1; }
+        std::vector<std::thread> ranks;
+        for (int r = 0; r < D; r++)
+            ranks.emplace_back([&, r]() {
+                ORB_SLAM3::ORBmatcher::SetThreadDevice(r);
+                ORB_SLAM3::ORBextractor exr(500, 1.2f, 8, 20, 7, /*deviceId*/ r);
+                if (orbx_device_id(exr.Handle()) != r && orbx_device_id(exr.Handle()) != ORBX_DEVICE_HOST) bad2++;
+                orbx_comm* c = nullptr;
+                if (orbx_comm_create(&c, D, r, id, r) != ORBX_OK) { fprintf(stderr, "rank %d: %s\n", r, orbx_last_error()); bad2++; return; }
+                // every rank extracts its own image: the base image, mirrored top to bottom on odd ranks
+                std::vector<unsigned char> br(bl);
+                if (r & 1) for (int y = 0; y < h; y++) memcpy(br.data() + (size_t)y * w, bl.data() + (size_t)(h - 1 - y) * w, w);
+                cv::Mat imr(h, w, CV_8UC1, br.data());
+                std::vector<cv::KeyPoint> kr; cv::Mat dr; std::vector<int> lp = {0, 0};
+                exr(imr, cv::Mat(), kr, dr, lp);
+                if (r == 0 && (kr.size() != base.mvKeysUn.size() || memcmp(dr.data, base.mDescriptors.data, (size_t)dr.rows * 32))) bad2++;   // GPU r == GPU 0's answer
+                int B = 0, cap = 0;
+                if (orbx_allgather_descriptors(exr.Handle(), c, nullptr, nullptr, &B, &cap) != ORBX_OK) { fprintf(stderr, "rank %d: %s\n", r, orbx_last_error()); bad2++; orbx_comm_destroy(c); return; }
+                std::vector<uint8_t> all((size_t)D * B * cap * 32); std::vector<int> nall((size_t)D * B);
+                if (orbx_comm_fetch(c, all.data(), nall.data()) != ORBX_OK || B != 1) { bad2++; orbx_comm_destroy(c); return; }
+                if (nall[r] != dr.rows || memcmp(all.data() + (size_t)r * cap * 32, dr.data, (size_t)dr.rows * 32)) bad2++;                    // my block at my rank
+                if (nall[0] != (int)base.mvKeysUn.size() || memcmp(all.data(), base.mDescriptors.data, (size_t)nall[0] * 32)) bad2++;           // rank 0's block everywhere
+                // the matcher of this thread searches on this GPU
+                std::vector<int> a, d2; work(r, a, d2);
+                if (a != expect[r]) bad2++;
+                orbx_comm_destroy(c);
+            });
+        for (auto& x : ranks) x.join();
+        printf("ranks=%d exchange mismatches=%d\n", D, bad2.load());
+    }
+    return (bad.load() == 0 && bad2.load() == 0 && matched > 50) ? 0 : 1;
 }

@@ -15,7 +15,7 @@ from orb_slam3_detailed_comments_amd.extractor import ORBextractor
 ROOT = ol.ROOT
 CSRC = os.path.join(ROOT, "orb_slam3_detailed_comments_amd", "csrc")
 SOURCES = ("k_image.hip", "k_fast.hip", "k_quadtree.hip", "k_describe.hip", "k_match.hip", "k_search.hip", "k_vocab.hip", "k_input.hip", "orbx_api.cpp", "orbm_search.cpp",
-           "orbv_api.cpp")
+           "orbv_api.cpp", "orbx_comm.cpp")
 
 
 def build_emu_variant(so, defines):

@@ -63,10 +63,18 @@ def _run_matcher_threads(tmp_path, libdir, libname):
                     os.path.join(ROOT, "tests", "cpp", "matcher_threads_test.cpp"), "-L" + libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-lpthread", "-o", str(exe)], check=True)
     r = subprocess.run([str(exe), str(tmp_path / "t.raw"), "376", "240"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+    return exe
 
 
 def test_matcher_facade_three_threads_emulated(tmp_path, emu_lib):
-    _run_matcher_threads(tmp_path, os.path.join(ROOT, "tests", "emu"), "orbx_emu")
+    exe = _run_matcher_threads(tmp_path, os.path.join(ROOT, "tests", "emu"), "orbx_emu")
+    # a multi-GPU C++ host: two "GPUs" (the emulator reports as many as ORBX_EMU_DEVICES says), extractor + matcher handles per device, and the
+    # descriptor all-gather of BASELINE.json configs[4] through the C ABI alone (orbx_comm_*, orbx_allgather_descriptors)
+    r = subprocess.run([str(exe), str(tmp_path / "t.raw"), "376", "240", "2"], capture_output=True, text=True, timeout=600, env=dict(os.environ, ORBX_EMU_DEVICES="2"))
+    assert r.returncode == 0 and "ranks=2 exchange mismatches=0" in r.stdout, r.stdout + r.stderr
+    # ... and a device the node does not have is refused, not silently mapped to GPU 0
+    r = subprocess.run([str(exe), str(tmp_path / "t.raw"), "376", "240", "2"], capture_output=True, text=True, timeout=600, env=dict(os.environ, ORBX_EMU_DEVICES="1"))
+    assert r.returncode != 0
 
 
 @pytest.mark.gpu
