@@ -379,6 +379,29 @@ int orbm_search_by_projection_lastframe_batch(orbx_extractor* h, int first, int 
                                               float th, const uint8_t* forward, const uint8_t* backward, int check_orientation,
                                               const uint8_t* occupied, int use_u_right);
 
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:2196-2324) -
+ * the search of Tracking::Relocalization (src/Tracking.cc:4480, :4500) - for a BATCH of frames on the device: current frames = images
+ * [first, first + B) of the handle's last extraction, cur[b] = pose (quaternion + translation + mOw), camera, bounds and scale factors of frame b;
+ * `kf` = per frame the map points of ITS candidate key frame, cap_kf rows per frame: world position, valid (pMP != NULL && !pMP->isBad() &&
+ * !sAlreadyFound.count(pMP)), mfMinDistance / mfMaxDistance (the device applies the 0.8 / 1.2 of Get*DistanceInvariance and evaluates
+ * MapPoint::PredictScale(dist3D, &CurrentFrame) itself), the angle of the key frame's keypoint i (pKF->mvKeysUn[i].angle), the descriptor.
+ * occupied [B][cap] = CurrentFrame.mvpMapPoints[i] != NULL beforehand (NULL = none).  Projection (Tcw * x3Dw on the quaternion), image test, distance
+ * range, predicted level, window search, Hamming distances, the sequential accept loop (best distance <= orb_dist; every accepted point occupies its
+ * keypoint) and the rotation histogram run on the device.  Asynchronous; orbm_search_local_points_fetch returns assigned [B][cap] (index into the
+ * key frame's rows, -1 untouched, -2 reset by the rotation check) and the return value per frame.  Shares the one pending batch of the handle. */
+typedef struct OrbmKeyFramePointBatch {
+    int cap_kf;                            /* rows per frame in the arrays below */
+    const int* n;                          /* [B] pKF->GetMapPointMatches().size() */
+    const float* pos;                      /* [B][cap_kf][3] */
+    const uint8_t* valid;                  /* [B][cap_kf] */
+    const float* min_distance;             /* [B][cap_kf] mfMinDistance */
+    const float* max_distance;             /* [B][cap_kf] mfMaxDistance */
+    const float* angle;                    /* [B][cap_kf] */
+    const uint8_t* desc;                   /* [B][cap_kf][32] */
+} OrbmKeyFramePointBatch;
+int orbm_search_by_projection_keyframe_batch(orbx_extractor* h, int first, int B, const OrbmFrustumView* cur, const OrbmKeyFramePointBatch* kf,
+                                             float th, int orb_dist, int check_orientation, const uint8_t* occupied);
+
 /* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBmatcher.cc:1950-2184).
  * forward/backward = bForward/bBackward (:1973-1975, computed from the two poses by the caller).
  * assigned[i] = index into LastFrame of the point written to CurrentFrame.mvpMapPoints[i]; -1 untouched;

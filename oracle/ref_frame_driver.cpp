@@ -155,6 +155,44 @@ int ref_frame_search_local_points(void* h, const float* R, const float* t, int M
     return n;
 }
 
+// ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:2196-2324), the
+// search of Tracking::Relocalization, on the reference's own Frame and matcher.  CurrentFrame = the holder's frame at pose (R, t), keypoints with
+// occupied[i] != 0 hold a map point beforehand.  pKF = a key frame whose NK features carry the given map points (kind[i]: 0 none, 1 good, 2 bad,
+// 3 good but in sAlreadyFound) and keypoint angles.  assigned[i] = index of the key-frame point written to CurrentFrame.mvpMapPoints[i], -1 untouched,
+// -2 written and reset to NULL by the rotation check.
+int ref_frame_search_keyframe(void* h, const float* R, const float* t, int NK, const float* pos, const uint8_t* kind, const float* min_dist, const float* max_dist,
+                              const float* angle, const uint8_t* desc, float th, int orb_dist, int check_orientation, float nnratio, const uint8_t* occupied, int* assigned) {
+    Frame* F = ((Holder*)h)->frame;
+    F->SetPose(se3_from(R, t));
+    KeyFrame KF;
+    KF.N = NK; KF.mvKeysUn.assign(NK, cv::KeyPoint()); KF.mvpMapPoints.assign(NK, (MapPoint*)nullptr);
+    std::vector<MapPoint> mps(NK);
+    std::set<MapPoint*> found;
+    for (int i = 0; i < NK; i++) {
+        KF.mvKeysUn[i].angle = angle[i];
+        MapPoint& p = mps[i];
+        p.pos = Eigen::Vector3f(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]); p.minDist = min_dist[i]; p.maxDist = max_dist[i]; p.bad = kind[i] == 2; p.nObs = 1;
+        p.descriptor = cv::Mat(1, 32, CV_8U); memcpy(p.descriptor.ptr(0), desc + 32 * (size_t)i, 32);
+        if (kind[i]) KF.mvpMapPoints[i] = &p;
+        if (kind[i] == 3) found.insert(&p);
+    }
+    MapPoint resident; resident.nObs = 0;          // any occupant blocks a keypoint in this search, observations or not
+    std::vector<uint8_t> was(F->N, 0);
+    auto reset = [&] { for (int i = 0; i < F->N; i++) { was[i] = occupied && occupied[i]; F->mvpMapPoints[i] = was[i] ? &resident : nullptr; } };
+    reset();
+    ORBmatcher matcher(nnratio, check_orientation != 0);
+    const int n = matcher.SearchByProjection(*F, &KF, found, th, orb_dist);
+    for (int i = 0; i < F->N; i++) { MapPoint* p = F->mvpMapPoints[i]; assigned[i] = (p && p != &resident) ? (int)(p - mps.data()) : -1; }
+    if (check_orientation) {                        // keypoints that received a point and lost it to the rotation check: the same search without the check has them
+        reset();
+        ORBmatcher plain(nnratio, false);
+        plain.SearchByProjection(*F, &KF, found, th, orb_dist);
+        for (int i = 0; i < F->N; i++) { MapPoint* p = F->mvpMapPoints[i]; if (p && p != &resident && assigned[i] == -1) assigned[i] = -2; }
+    }
+    std::fill(F->mvpMapPoints.begin(), F->mvpMapPoints.end(), (MapPoint*)nullptr);
+    return n;
+}
+
 // The checker's Sophus stand-in (oracle/slam_shim/sophus_model.h) evaluated on one pose (R, t) [+ a similarity (s, R2, t2)] and one point, for
 // tests/test_sophus_action.py, which holds the Python host mirror (orb_slam3_detailed_comments_amd/sophus.py) against it.
 // out (48 floats): unit quaternion 4 | rotationMatrix 9 | T * p 3 | inverse: quaternion 4, translation 3 | (T * T) quaternion 4, translation 3 |

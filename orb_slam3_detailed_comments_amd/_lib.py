@@ -29,7 +29,7 @@ SYMBOLS = [
     "orbx_profile_get", "orbx_stage_name", "orbx_debug_candidates", "orbx_debug_level_keys", "orbx_debug_quadtree_profile", "orbx_debug_simd_selftest", "orbx_debug_stereo_flags",
     "orbm_hamming_matrix", "orbm_stereo_match", "orbm_stereo_fetch", "orbm_knn2", "orbm_knn2_fetch", "orbm_stereo_fisheye", "orbm_stereo_fisheye_fetch", "orbm_search_for_triangulation_kb8", "orbm_is_in_frustum", "orbm_is_in_frustum_rig", "orbm_search_local_points_fisheye", "orbm_search_local_points",
     "orbm_get_features_in_area", "orbm_search_by_projection_mappoints", "orbm_search_by_projection_frame",
-    "orbm_search_for_triangulation", "orbm_search_by_bow", "orbm_search_by_bow_batch", "orbm_keyframe_create", "orbm_points_create", "orbm_points_destroy", "orbm_search_local_points_resident", "orbm_stereo_from_depth", "orbm_search_local_points_batch", "orbm_search_local_points_fetch", "orbm_search_by_projection_lastframe_batch", "orbm_keyframe_destroy", "orbm_search_for_triangulation_resident", "orbm_search_for_triangulation_resident_kb8", "orbm_search_by_bow_resident", "orbm_search_by_bow_fisheye", "orbm_search_for_initialization", "orbm_area_search_batch",
+    "orbm_search_for_triangulation", "orbm_search_by_bow", "orbm_search_by_bow_batch", "orbm_keyframe_create", "orbm_points_create", "orbm_points_destroy", "orbm_search_local_points_resident", "orbm_stereo_from_depth", "orbm_search_local_points_batch", "orbm_search_local_points_fetch", "orbm_search_by_projection_lastframe_batch", "orbm_search_by_projection_keyframe_batch", "orbm_keyframe_destroy", "orbm_search_for_triangulation_resident", "orbm_search_for_triangulation_resident_kb8", "orbm_search_by_bow_resident", "orbm_search_by_bow_fisheye", "orbm_search_for_initialization", "orbm_area_search_batch",
     "orbm_project_points", "orbm_search_by_projection_sim3", "orbm_search_by_projection_keyframe", "orbm_fuse_candidates", "orbm_search_by_sim3", "orbm_distinctive_descriptors",
     "orbm_search_by_projection_mappoints_fisheye", "orbm_search_by_projection_frame_fisheye", "orbm_search_for_triangulation_batch",
     "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_words", "orbv_transform", "orbv_transform_extracted", "orbv_fetch",
@@ -122,6 +122,7 @@ class OrbxLib:
         L.orbm_search_local_points_batch.argtypes = [vp, i, i, vp, vp, vp, vp, vp, i, f, f, i, f, f, i]
         L.orbm_search_local_points_fetch.argtypes = [vp, vp, i, vp, vp]
         L.orbm_search_by_projection_lastframe_batch.argtypes = [vp, i, i, vp, vp, f, vp, vp, i, vp, i]
+        L.orbm_search_by_projection_keyframe_batch.argtypes = [vp, i, i, vp, vp, f, i, i, vp]
         L.orbm_keyframe_destroy.argtypes = [vp]; L.orbm_keyframe_destroy.restype = None
         L.orbm_search_for_triangulation_resident.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, i, i, i, vp, vp]
         L.orbm_search_for_triangulation_resident_kb8.argtypes = [vp, vp, vp, i, vp, vp, vp, vp, i, i, i, vp, vp]

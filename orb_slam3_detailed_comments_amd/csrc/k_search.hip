@@ -385,9 +385,13 @@ __global__ void __launch_bounds__(256) k_project_points(ProjectParams P, int M, 
 // The head of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (src/ORBmatcher.cc:1970-2023) for a batch of frames: map point
 // i of frame b's last frame -> camera (Tcw * x3Dw), 1 / z < 0 rejects, projection, the Frame's image test, radius = th * mvScaleFactors[octave
 // of the LAST frame's keypoint], the level window by bForward / bBackward, ur = u - mbf / z for the right-coordinate gate.  grid (capL / 256, B).
-__global__ void __launch_bounds__(256) k_lastframe_queries(const FrustumParams* __restrict__ Fb, int capL, const int* __restrict__ n_last, const float* __restrict__ pos,
-                                                           const uint8_t* __restrict__ valid, const int* __restrict__ octave, AreaQuery* __restrict__ queries,
-                                                           int* __restrict__ zero4) {
+// KEYFRAME = true: the head of SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (relocalisation, :2213-2246) instead: no depth
+// test, the distance |x3Dw - Ow| must lie in [0.8 mfMinDistance, 1.2 mfMaxDistance] (MapPoint.cc:658-671), the level is MapPoint::PredictScale
+// (dist3D, &CurrentFrame) (MapPoint.cc:714-731: glibc's logf, float division, ceil), window [level - 1, level + 1], no right-coordinate gate.
+template <bool KEYFRAME>
+__device__ __forceinline__ void projection_queries_body(const FrustumParams* __restrict__ Fb, int capL, const int* __restrict__ n_last, const float* __restrict__ pos,
+                                                        const uint8_t* __restrict__ valid, const int* __restrict__ octave, const float* __restrict__ min_dist,
+                                                        const float* __restrict__ max_dist, AreaQuery* __restrict__ queries, int* __restrict__ zero4) {
     const size_t b = blockIdx.y;
     const int i = (int)(blockIdx.x * 256 + threadIdx.x);
     if (zero4 && i < 4 && b == 0) zero4[i] = 0;
@@ -399,24 +403,47 @@ __global__ void __launch_bounds__(256) k_lastframe_queries(const FrustumParams* 
         const float P0 = pos[3 * o], P1 = pos[3 * o + 1], P2 = pos[3 * o + 2];
         float pc[3];
         if (F.debug_flags & 16) se3_act_matrix_form(F.qcw, F.tcw, P0, P1, P2, pc);  // test switch: round 3's R * p + t
-        else se3_act(F.qcw, F.tcw, P0, P1, P2, pc);                   // x3Dc = Tcw * x3Dw (:1987): Sophus' quaternion action, not mRcw * p
+        else se3_act(F.qcw, F.tcw, P0, P1, P2, pc);                   // x3Dc = Tcw * x3Dw (:1987, :2224): Sophus' quaternion action, not mRcw * p
         const float x = pc[0], y = pc[1], z = pc[2];
         const float invz = __fdiv_rn(1.0f, z);
-        const int oct = octave[o];
-        if (!(invz < 0.0f) && oct >= 0 && oct < F.nlevels) {
+        const int oct = KEYFRAME ? 0 : octave[o];
+        if (KEYFRAME || (!(invz < 0.0f) && oct >= 0 && oct < F.nlevels)) {
             float u, v;
-            if (F.kb8) { KB8Cam c; for (int k = 0; k < 8; k++) c.p[k] = F.cam[k]; const float pc[3] = {x, y, z}; float uv[2]; kb8_project(c, pc, uv); u = uv[0]; v = uv[1]; }
+            if (F.kb8) { KB8Cam c; for (int k = 0; k < 8; k++) c.p[k] = F.cam[k]; const float pcc[3] = {x, y, z}; float uv[2]; kb8_project(c, pcc, uv); u = uv[0]; v = uv[1]; }
             else { u = __fadd_rn(__fdiv_rn(__fmul_rn(F.cam[0], x), z), F.cam[2]); v = __fadd_rn(__fdiv_rn(__fmul_rn(F.cam[1], y), z), F.cam[3]); }
             if (!(u < F.min_x || u > F.max_x || v < F.min_y || v > F.max_y)) {
-                q.x = u; q.y = v; q.r = __fmul_rn(F.th, pick(F.scale_factors, oct)); q.ur = __fsub_rn(u, __fmul_rn(F.mbf, invz));
-                if (F.forward) { q.min_level = oct; q.max_level = -1; }
-                else if (F.backward) { q.min_level = 0; q.max_level = oct; }
-                else { q.min_level = oct - 1; q.max_level = oct + 1; }
-                q.active = 1; q.gate = 1;
+                if (KEYFRAME) {
+                    const float o0 = __fsub_rn(P0, F.Ow[0]), o1 = __fsub_rn(P1, F.Ow[1]), o2 = __fsub_rn(P2, F.Ow[2]);
+                    const float dist3D = sqrtf(eig_dot3(o0, o1, o2, o0, o1, o2));                              // PO.norm()
+                    const float maxDistance = __fmul_rn(1.2f, max_dist[o]), minDistance = __fmul_rn(0.8f, min_dist[o]);
+                    if (!(dist3D < minDistance || dist3D > maxDistance)) {
+                        const float ratio = __fdiv_rn(max_dist[o], dist3D);
+                        int n = (int)ceilf(__fdiv_rn(glibc_logf_model<false>(ratio), F.log_scale_factor));
+                        if (n < 0) n = 0; else if (n >= F.nlevels) n = F.nlevels - 1;
+                        q.x = u; q.y = v; q.r = __fmul_rn(F.th, pick(F.scale_factors, n)); q.ur = 0.0f;
+                        q.min_level = n - 1; q.max_level = n + 1; q.active = 1; q.gate = 0;
+                    }
+                } else {
+                    q.x = u; q.y = v; q.r = __fmul_rn(F.th, pick(F.scale_factors, oct)); q.ur = __fsub_rn(u, __fmul_rn(F.mbf, invz));
+                    if (F.forward) { q.min_level = oct; q.max_level = -1; }
+                    else if (F.backward) { q.min_level = 0; q.max_level = oct; }
+                    else { q.min_level = oct - 1; q.max_level = oct + 1; }
+                    q.active = 1; q.gate = 1;
+                }
             }
         }
     }
     queries[o] = q;
+}
+__global__ void __launch_bounds__(256) k_lastframe_queries(const FrustumParams* __restrict__ Fb, int capL, const int* __restrict__ n_last, const float* __restrict__ pos,
+                                                           const uint8_t* __restrict__ valid, const int* __restrict__ octave, AreaQuery* __restrict__ queries,
+                                                           int* __restrict__ zero4) {
+    projection_queries_body<false>(Fb, capL, n_last, pos, valid, octave, nullptr, nullptr, queries, zero4);
+}
+__global__ void __launch_bounds__(256) k_keyframe_queries(const FrustumParams* __restrict__ Fb, int capL, const int* __restrict__ n_kf, const float* __restrict__ pos,
+                                                          const uint8_t* __restrict__ valid, const float* __restrict__ min_dist, const float* __restrict__ max_dist,
+                                                          AreaQuery* __restrict__ queries, int* __restrict__ zero4) {
+    projection_queries_body<true>(Fb, capL, n_kf, pos, valid, nullptr, min_dist, max_dist, queries, zero4);
 }
 
 // The window search of a BATCH of frames, one THREAD per query (k_area_search spends a wave on a query: right for one frame's few thousand

@@ -647,16 +647,21 @@ int orbm_search_local_points_batch(orbx_extractor* h, int first, int B, const Or
     return ORBX_OK;
 }
 
-int orbm_search_by_projection_lastframe_batch(orbx_extractor* h, int first, int B, const OrbmFrustumView* cur, const OrbmLastFrameBatch* last, float th,
-                                              const uint8_t* forward, const uint8_t* backward, int check_ori, const uint8_t* occupied, int use_u_right) {
-    if (!h || !cur || !last || B <= 0 || first < 0 || first + B > h->lastB) return fail(ORBX_E_ARG, "bad frame range / null");
-    const int M = last->cap_last;
-    if (M <= 0 || !last->n || !last->pos || !last->valid || !last->octave || !last->angle || !last->desc) return fail(ORBX_E_ARG, "bad last-frame batch");
+namespace {
+// one record per frame of map points seen from somewhere else: the LastFrame's (octave of its keypoint, has_obs) or a key frame's (distance limits)
+struct PointRows {
+    int cap; const int* n; const float* pos; const uint8_t* valid; const int* octave; const float* angle; const uint8_t* has_obs; const uint8_t* desc;
+    const float* min_distance; const float* max_distance;          // key-frame form only
+};
+// SearchByProjection(CurrentFrame, LastFrame) (keyframe = false) or (CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (keyframe = true) for B frames
+int projection_batch(orbx_extractor* h, int first, int B, const OrbmFrustumView* cur, const PointRows* last, float th, const uint8_t* forward, const uint8_t* backward,
+                     int check_ori, const uint8_t* occupied, int use_u_right, bool keyframe, int th_accept) {
+    const int M = last->cap;
     for (int b = 0; b < B; b++) {
         if (cur[b].nlevels < 1 || cur[b].nlevels > kMaxLevels || !cur[b].scale_factors) return fail(ORBX_E_ARG, "bad scale levels (frame %d)", b);
         if (cur[b].min_x != cur[0].min_x || cur[b].max_x != cur[0].max_x || cur[b].min_y != cur[0].min_y || cur[b].max_y != cur[0].max_y)
             return fail(ORBX_E_ARG, "frame %d has other image bounds than frame 0", b);
-        if (last->n[b] < 0 || last->n[b] > M) return fail(ORBX_E_ARG, "last frame %d: %d points in %d rows", b, last->n[b], M);
+        if (last->n[b] < 0 || last->n[b] > M) return fail(ORBX_E_ARG, "frame %d: %d points in %d rows", b, last->n[b], M);
     }
     if (!(cur[0].max_x > cur[0].min_x) || !(cur[0].max_y > cur[0].min_y)) return fail(ORBX_E_ARG, "empty image bounds");
     if (undistort_stale(h)) return fail(ORBX_E_ARG, "orbx_set_undistort was called after the last extraction: extract again before searching its frames");
@@ -670,7 +675,7 @@ int orbm_search_by_projection_lastframe_batch(orbx_extractor* h, int first, int 
     // upload block: poses | n_last | pos | valid | octave | angle | has_obs | descriptors | occupancy
     const size_t u_f = 0, u_n = u_f + al16(sizeof(FrustumParams) * B1), u_pos = u_n + al16(4 * B1), u_val = u_pos + al16(12 * B1 * M1), u_oct = u_val + al16(B1 * M1),
                  u_ang = u_oct + al16(4 * B1 * M1), u_obs = u_ang + al16(4 * B1 * M1), u_desc = u_obs + al16(B1 * M1), u_occ = u_desc + al16(32 * B1 * M1),
-                 u_total = u_occ + (occupied ? al16(B1 * C1) : 0);
+                 u_mxd = u_occ + (occupied ? al16(B1 * C1) : 0), u_total = u_mxd + (keyframe ? al16(4 * B1 * M1) : 0);
     size_t o = al16(u_total);
     const size_t o_ur = o; o += use_u_right ? 0 : al16(4 * B1 * C1);
     const size_t o_cof = o; o += al16(4 * B1 * C1);
@@ -692,7 +697,9 @@ int orbm_search_by_projection_lastframe_batch(orbx_extractor* h, int first, int 
         fill_frustum_params(&cur[b], 0.0f, th, 0, 0.0f, &Fp[b]);
         Fp[b].forward = forward ? forward[b] != 0 : 0; Fp[b].backward = backward ? backward[b] != 0 : 0; Fp[b].debug_flags = h->debug_stereo_flags;
     }
-    memcpy(hp + u_n, last->n, 4 * B1); memcpy(hp + u_pos, last->pos, 12 * B1 * M1); memcpy(hp + u_val, last->valid, B1 * M1); memcpy(hp + u_oct, last->octave, 4 * B1 * M1);
+    memcpy(hp + u_n, last->n, 4 * B1); memcpy(hp + u_pos, last->pos, 12 * B1 * M1); memcpy(hp + u_val, last->valid, B1 * M1);
+    if (keyframe) { memcpy(hp + u_oct, last->min_distance, 4 * B1 * M1); memcpy(hp + u_mxd, last->max_distance, 4 * B1 * M1); }     // (the octave rows carry mfMinDistance)
+    else memcpy(hp + u_oct, last->octave, 4 * B1 * M1);
     memcpy(hp + u_ang, last->angle, 4 * B1 * M1);
     if (last->has_obs) memcpy(hp + u_obs, last->has_obs, B1 * M1); else memset(hp + u_obs, 1, B1 * M1);
     memcpy(hp + u_desc, last->desc, 32 * B1 * M1);
@@ -716,22 +723,43 @@ int orbm_search_by_projection_lastframe_batch(orbx_extractor* h, int first, int 
     }
     {
         dim3 grid((M + 255) / 256, B, 1);
-        ORBX_LAUNCH(k_lastframe_queries, grid, blk, 0, h->s0, (const FrustumParams*)(dp + u_f), M, (const int*)(dp + u_n), (const float*)(dp + u_pos), (const uint8_t*)(dp + u_val),
+        if (keyframe) ORBX_LAUNCH(k_keyframe_queries, grid, blk, 0, h->s0, (const FrustumParams*)(dp + u_f), M, (const int*)(dp + u_n), (const float*)(dp + u_pos),
+                                  (const uint8_t*)(dp + u_val), (const float*)(dp + u_oct), (const float*)(dp + u_mxd), (AreaQuery*)(dp + o_q), d_counter);
+        else ORBX_LAUNCH(k_lastframe_queries, grid, blk, 0, h->s0, (const FrustumParams*)(dp + u_f), M, (const int*)(dp + u_n), (const float*)(dp + u_pos), (const uint8_t*)(dp + u_val),
                     (const int*)(dp + u_oct), (AreaQuery*)(dp + o_q), d_counter);
         ORBX_LAUNCH(k_area_search_threads, grid, blk, 0, h->s0, (const AreaQuery*)(dp + o_q), (const unsigned long long*)(dp + u_desc), M, kps, ur, fdesc, g, (const int*)(dp + o_cst),
-                    (const int*)(dp + o_cit), 1, d_counter, (int)pool, (int*)(dp + o_qs), (int*)(dp + o_qc), (int2*)(dp + o_pool), cap, 1);
+                    (const int*)(dp + o_cit), keyframe ? 0 : 1, d_counter, (int)pool, (int*)(dp + o_qs), (int*)(dp + o_qc), (int2*)(dp + o_pool), cap, 1);
     }
     {
         dim3 grid(B, 1, 1), blka(64, 1, 1);
         const size_t smem = smem_accept;
         ORBX_LAUNCH(k_lastframe_accept, grid, blka, smem, h->s0, M, cap, nper, (const int*)(dp + o_qs), (const int*)(dp + o_qc), (const int2*)(dp + o_pool),
-                    occupied ? (const uint8_t*)(dp + u_occ) : (const uint8_t*)nullptr, (const uint8_t*)(dp + u_obs), TH_HIGH, d_assigned, d_nmatch,
+                    occupied ? (const uint8_t*)(dp + u_occ) : (const uint8_t*)nullptr, (const uint8_t*)(dp + u_obs), th_accept, d_assigned, d_nmatch,
                     (const float*)(dp + u_ang), kps, check_ori);
     }
     if (h->profile) rt::event_record(h->ev_stage[ST_MATCH][1], h->s0);
     if (rt::check_launch()) return fail(ORBX_E_DEVICE, "kernel launch failed: %s", rt::last_error());
     h->lp_B = B; h->lp_M = M; h->lp_first = first; h->lp_o_counter = o_res; h->lp_o_view = 0; h->lp_want_view = false;
     return ORBX_OK;
+}
+}  // namespace
+
+int orbm_search_by_projection_lastframe_batch(orbx_extractor* h, int first, int B, const OrbmFrustumView* cur, const OrbmLastFrameBatch* last, float th,
+                                              const uint8_t* forward, const uint8_t* backward, int check_ori, const uint8_t* occupied, int use_u_right) {
+    if (!h || !cur || !last || B <= 0 || first < 0 || first + B > h->lastB) return fail(ORBX_E_ARG, "bad frame range / null");
+    if (last->cap_last <= 0 || !last->n || !last->pos || !last->valid || !last->octave || !last->angle || !last->desc) return fail(ORBX_E_ARG, "bad last-frame batch");
+    const PointRows R = {last->cap_last, last->n, last->pos, last->valid, last->octave, last->angle, last->has_obs, last->desc, nullptr, nullptr};
+    return projection_batch(h, first, B, cur, &R, th, forward, backward, check_ori, occupied, use_u_right, false, TH_HIGH);
+}
+
+int orbm_search_by_projection_keyframe_batch(orbx_extractor* h, int first, int B, const OrbmFrustumView* cur, const OrbmKeyFramePointBatch* kf, float th, int orb_dist,
+                                             int check_ori, const uint8_t* occupied) {
+    if (!h || !cur || !kf || B <= 0 || first < 0 || first + B > h->lastB) return fail(ORBX_E_ARG, "bad frame range / null");
+    if (kf->cap_kf <= 0 || !kf->n || !kf->pos || !kf->valid || !kf->min_distance || !kf->max_distance || !kf->angle || !kf->desc) return fail(ORBX_E_ARG, "bad key-frame batch");
+    if (orb_dist < 0 || orb_dist > 256) return fail(ORBX_E_ARG, "ORBdist out of range");
+    // every accepted point occupies its keypoint (`if(CurrentFrame.mvpMapPoints[i2]) continue;`, :2259-2260): has_obs = all, and no right-coordinate gate
+    const PointRows R = {kf->cap_kf, kf->n, kf->pos, kf->valid, nullptr, kf->angle, nullptr, kf->desc, kf->min_distance, kf->max_distance};
+    return projection_batch(h, first, B, cur, &R, th, nullptr, nullptr, check_ori, occupied, /*use_u_right*/ 0, true, orb_dist);
 }
 
 int orbm_search_local_points_fetch(orbx_extractor* h, int* assigned, int cap, int* nmatches, uint8_t* in_view) {

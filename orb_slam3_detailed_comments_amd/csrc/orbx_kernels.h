@@ -118,6 +118,9 @@ __global__ void k_area_search_threads(const AreaQuery* __restrict__ queries, con
                                       int* __restrict__ q_start, int* __restrict__ q_count, int2* __restrict__ entries, int frame_stride, int qdesc_per_frame);
 __global__ void k_lastframe_queries(const FrustumParams* __restrict__ Fb, int capL, const int* __restrict__ n_last, const float* __restrict__ pos,
                                     const uint8_t* __restrict__ valid, const int* __restrict__ octave, AreaQuery* __restrict__ queries, int* __restrict__ zero4);
+__global__ void k_keyframe_queries(const FrustumParams* __restrict__ Fb, int capL, const int* __restrict__ n_kf, const float* __restrict__ pos,
+                                   const uint8_t* __restrict__ valid, const float* __restrict__ min_dist, const float* __restrict__ max_dist,
+                                   AreaQuery* __restrict__ queries, int* __restrict__ zero4);
 __global__ void k_lastframe_accept(int M, int cap, const int* __restrict__ n_per_frame, const int* __restrict__ q_start, const int* __restrict__ q_count,
                                    const int2* __restrict__ entries, const uint8_t* __restrict__ occupied0, const uint8_t* __restrict__ has_obs, int th_high,
                                    int* __restrict__ assigned, int* __restrict__ nmatches, const float* __restrict__ last_angle,

@@ -408,6 +408,29 @@ class LastFrameBatch:
         return self.assigned, self.nm
 
 
+class _KeyFramePointBatch(C.Structure):
+    _fields_ = [("cap_kf", C.c_int), ("n", C.c_void_p), ("pos", C.c_void_p), ("valid", C.c_void_p), ("min_distance", C.c_void_p), ("max_distance", C.c_void_p),
+                ("angle", C.c_void_p), ("desc", C.c_void_p)]
+
+
+class KeyFrameBatch(LastFrameBatch):
+    """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) - relocalisation - for a batch of frames on the device
+    (orbm_search_by_projection_keyframe_batch): current frames = images [first, first + B) of ext's last extraction, per frame the map points of
+    its candidate key frame.  set_poses() as LastFrameBatch; enqueue() is asynchronous, fetch() returns (assigned [B, cap], nmatches [B])."""
+
+    def enqueue(self, n, pos, valid, min_distance, max_distance, angle, desc, th, orb_dist, check_orientation=True, occupied=None, first=0):
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        u8 = lambda a: None if a is None else np.ascontiguousarray(a, np.uint8)
+        self._again = lambda: self.enqueue(n, pos, valid, min_distance, max_distance, angle, desc, th, orb_dist, check_orientation, occupied, first)
+        pos = f32(pos); capK = pos.shape[1]
+        self._keep = (np.ascontiguousarray(n, np.int32), pos, u8(valid), f32(min_distance), f32(max_distance), f32(angle), u8(desc), u8(occupied))
+        k = self._keep
+        ptr = lambda a: None if a is None else a.ctypes.data
+        kb = _KeyFramePointBatch(capK, ptr(k[0]), ptr(k[1]), ptr(k[2]), ptr(k[3]), ptr(k[4]), ptr(k[5]), ptr(k[6]))
+        L = self.ext._lib
+        L.check(L.L.orbm_search_by_projection_keyframe_batch(self.ext._h, int(first), self.B, self.views, C.byref(kb), float(th), int(orb_dist), int(bool(check_orientation)), ptr(k[7])))
+
+
 class ResidentPoints:
     """orbm_points: position, normal, distance limits and descriptor of a set of map points, uploaded once (the local map)."""
 

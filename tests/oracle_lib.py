@@ -515,6 +515,22 @@ class ReferenceFrame:
         n = self.L.ref_frame_features_in_area(self.h, x, y, r, min_level, max_level, idx.ctypes.data, len(idx))
         return idx[:n].copy()
 
+    def search_keyframe(self, R, t, pos, kind, min_dist, max_dist, angle, desc, th, orb_dist, check_orientation=True, nnratio=0.9, occupied=None):
+        """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (relocalisation) on the reference's own Frame + ORBmatcher.cc.
+        kind[i]: 0 no map point, 1 good, 2 bad, 3 in sAlreadyFound.  Returns (nmatches, assigned[N])."""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        u8 = lambda a: np.ascontiguousarray(a, np.uint8)
+        R, t, pos, min_dist, max_dist, angle = f32(R), f32(t), f32(pos), f32(min_dist), f32(max_dist), f32(angle)
+        kind, desc = u8(kind), u8(desc)
+        occ = None if occupied is None else u8(occupied)
+        assigned = np.full(max(self.N, 1), -1, np.int32)
+        fn = self.L.ref_frame_search_keyframe
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+        n = fn(self.h, R.ctypes.data, t.ctypes.data, len(pos), pos.ctypes.data, kind.ctypes.data, min_dist.ctypes.data, max_dist.ctypes.data, angle.ctypes.data, desc.ctypes.data,
+               float(th), int(orb_dist), int(check_orientation), float(nnratio), None if occ is None else occ.ctypes.data, assigned.ctypes.data)
+        return n, assigned[:self.N]
+
     def search_lastframe(self, R, t, Rl, tl, pos, valid, octave, angle, has_obs, desc, th, mono, check_orientation=True, nnratio=0.9, occupied=None):
         """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) on the reference's own Frame + ORBmatcher.cc: this frame at pose (R, t) against
         a last frame at (Rl, tl) with the given map points.  Returns (nmatches, assigned[N], bForward, bBackward)."""
