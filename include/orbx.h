@@ -684,6 +684,16 @@ int orbv_transform_extracted(orbv_vocabulary* v, orbx_extractor* h, int first, i
 int orbv_fetch(orbv_vocabulary* v, orbx_extractor* h, int b, uint32_t* word_id, uint32_t* node_id, int n_features, uint32_t* bow_id, double* bow_val,
                int* n_bow, uint32_t* fv_node, int* fv_start, uint32_t* fv_feat, int* n_fv);
 
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vpMapPointMatches) (src/ORBmatcher.cc:259-493; Tracking::TrackReferenceKeyFrame
+ * src/Tracking.cc:3183, Relocalization :4371) for a BATCH of frames on the device: frame b = image first + b of h's last extraction, whose
+ * FeatureVector is read where orbv_transform_extracted(v, h, first, B, levelsup) left it (call that first, on the same images); KFs[b] = the
+ * device-resident key frame it is searched against (one key frame may serve many frames); has_map_point[b] [KFs[b]->N] = its features with a good
+ * map point.  The accept loop per vocabulary node, the ratio and TH_LOW tests and the rotation histogram with its three maxima run on the device
+ * (two launches per batch).  matches12[b][i] = frame feature matched to key-frame feature i, or -1, i.e. vpMapPointMatches[matches12[b][i]] =
+ * the key frame's map point i; nmatches[b] = the reference's return value.  Blocking. */
+int orbm_search_by_bow_frames_batch(orbx_extractor* h, const orbv_vocabulary* v, int first, int B, orbm_keyframe* const* KFs,
+                                    const uint8_t* const* has_map_point, float nnratio, int check_orientation, int* const* matches12, int* nmatches);
+
 const char* orbx_last_error(void);
 
 #ifdef __cplusplus

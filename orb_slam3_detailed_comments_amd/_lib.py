@@ -32,7 +32,7 @@ SYMBOLS = [
     "orbm_search_for_triangulation", "orbm_search_by_bow", "orbm_search_by_bow_batch", "orbm_keyframe_create", "orbm_points_create", "orbm_points_destroy", "orbm_search_local_points_resident", "orbm_stereo_from_depth", "orbm_search_local_points_batch", "orbm_search_local_points_fetch", "orbm_search_by_projection_lastframe_batch", "orbm_search_by_projection_keyframe_batch", "orbm_keyframe_destroy", "orbm_search_for_triangulation_resident", "orbm_search_for_triangulation_resident_kb8", "orbm_search_by_bow_resident", "orbm_search_by_bow_fisheye", "orbm_search_for_initialization", "orbm_area_search_batch",
     "orbm_project_points", "orbm_search_by_projection_sim3", "orbm_search_by_projection_keyframe", "orbm_fuse_candidates", "orbm_search_by_sim3", "orbm_distinctive_descriptors",
     "orbm_search_by_projection_mappoints_fisheye", "orbm_search_by_projection_frame_fisheye", "orbm_search_for_triangulation_batch",
-    "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_words", "orbv_transform", "orbv_transform_extracted", "orbv_fetch",
+    "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_words", "orbv_transform", "orbv_transform_extracted", "orbv_fetch", "orbm_search_by_bow_frames_batch",
     "orbx_comm_unique_id", "orbx_comm_create", "orbx_comm_adopt", "orbx_comm_destroy", "orbx_comm_world", "orbx_comm_rank", "orbx_allgather_descriptors", "orbx_comm_wait",
     "orbx_comm_fetch",
     "orbx_last_error",
@@ -145,6 +145,7 @@ class OrbxLib:
         L.orbv_transform.argtypes = [vp, vp, vp, i, i, vp, vp, vp, vp, ip, vp, vp, vp, ip]
         L.orbv_transform_extracted.argtypes = [vp, vp, i, i, i]
         L.orbv_fetch.argtypes = [vp, vp, i, vp, vp, i, vp, vp, ip, vp, vp, vp, ip]
+        L.orbm_search_by_bow_frames_batch.argtypes = [vp, vp, i, i, vp, vp, f, i, vp, vp]
         L.orbx_comm_unique_id.argtypes = [vp]
         L.orbx_comm_create.argtypes = [C.POINTER(vp), i, i, vp, i]
         L.orbx_comm_adopt.argtypes = [C.POINTER(vp), vp, i, i, i]

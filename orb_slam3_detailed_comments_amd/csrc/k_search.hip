@@ -828,7 +828,7 @@ __global__ void __launch_bounds__(256) k_bow_match_resident(const BowPairResiden
     const int a = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), p = (int)blockIdx.y;
     const BowPairResident& B = pairs[p];
     if (a >= B.k1.fv_nodes || B.mp1_off < 0) return;
-    const int b = wave_find_node(B.k2.node_id, B.k2.fv_nodes, B.k1.node_id[a]);
+    const int b = wave_find_node(B.k2.node_id, B.k2_nodes_dev ? *B.k2_nodes_dev : B.k2.fv_nodes, B.k1.node_id[a]);
     if (b < 0) return;
     const int s2 = B.k2.fv_start[b], c2 = B.k2.fv_start[b + 1] - s2;
     if (c2 > 2048) { if (lane == 0) atomicOr(status, 4); return; }
@@ -861,6 +861,53 @@ __global__ void __launch_bounds__(256) k_bow_match_resident(const BowPairResiden
             if (lane == (j1 & 63)) { taken |= 1u << (j1 >> 6); m12[(size_t)p * N1cap + idx1] = B.k2.fv_feat[s2 + j1]; }
         }
     }
+}
+
+// The rotation-consistency pruning behind SearchByBoW (src/ORBmatcher.cc:396-412 fill, :457-479 prune; ComputeThreeMaxima :2335-2377) on the device, one
+// wave per pair: histogram of round((angle1 - angle2 [+ 360]) / 30) over the matches, entries outside the three strongest bins (the second / third
+// only while they hold at least 10 % of the first) are reset to -1; nmatches[p] = matches left.  m12 as written by k_bow_match_resident.
+__global__ void __launch_bounds__(64) k_bow_rotation_prune(const BowPairResident* __restrict__ pairs, int* __restrict__ m12, int N1cap, int check_ori,
+                                                           int* __restrict__ nmatches) {
+    __shared__ int s_hist[32];
+    const int lane = lane_id(), p = (int)blockIdx.x;
+    const BowPairResident& B = pairs[p];
+    const int N1 = B.k1.N;
+    int* m = m12 + (size_t)p * N1cap;
+    if (lane < 32) s_hist[lane] = 0;
+    ORBX_WAVE_SYNC();
+    auto bin_of = [&](int i, int j) {
+        float rot = __fsub_rn(B.k1.kps[i].angle, B.k2.kps[j].angle);
+        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+        int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+        return bin == 30 ? 0 : bin;
+    };
+    int nm = 0;
+    for (int i = lane; i < N1; i += 64) {
+        const int j = m[i];
+        if (j < 0) continue;
+        nm++;
+        if (check_ori) atomicAdd(&s_hist[bin_of(i, j) & 31], 1);
+    }
+    ORBX_WAVE_SYNC();
+    if (check_ori) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < 30; i++) {
+            const int sz = s_hist[i];
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) ind3 = -1;
+        for (int i = lane; i < N1; i += 64) {
+            const int j = m[i];
+            if (j < 0) continue;
+            const int bin = bin_of(i, j);
+            if (bin != ind1 && bin != ind2 && bin != ind3) { m[i] = -1; nm--; }
+        }
+    }
+    nm = wave_sum(nm);
+    if (lane == 0) nmatches[p] = nm;
 }
 
 __global__ void __launch_bounds__(256) k_bow_search(const BowItem* __restrict__ items, int nitems, const KeyPointRec* __restrict__ kps1,

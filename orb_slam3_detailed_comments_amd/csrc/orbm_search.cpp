@@ -1225,7 +1225,7 @@ int orbm_search_by_bow_resident(orbx_extractor* h, int n, orbm_keyframe* const* 
         const orbm_keyframe *K1 = K1s[p], *K2 = K2s[p];
         if (!K1 || !K2 || !matches12[p] || K1->device != h->device || K2->device != h->device) return fail(ORBX_E_ARG, "bad key frame pair %d", p);
         BowPairResident& B = pairs[p];
-        B.k1 = K1->dev; B.k2 = K2->dev;
+        B.k1 = K1->dev; B.k2 = K2->dev; B.k2_nodes_dev = nullptr;
         B.mp1_off = -1; B.elig2_off = -1;
         if (has_mp1 && has_mp1[p] && K1->N > 0) { B.mp1_off = (int)ftotal; ftotal += al16((size_t)K1->N); }
         if (eligible2 && eligible2[p] && K2->N > 0) { B.elig2_off = (int)ftotal; ftotal += al16((size_t)K2->N); }
@@ -1255,6 +1255,64 @@ int orbm_search_by_bow_resident(orbx_extractor* h, int n, orbm_keyframe* const* 
         if (N1 > 0) memcpy(matches12[p], &res[(size_t)p * N1cap], sizeof(int) * (size_t)N1);
         const int nm = prune_by_rotation(K1s[p], K2s[p], matches12[p], check_ori != 0);
         if (nmatches_out) nmatches_out[p] = nm;
+    }
+    return ORBX_OK;
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vpMapPointMatches) (src/ORBmatcher.cc:259-493) for the frames of a batch: frame b of the last
+// extraction (its FeatureVector where orbv_transform_extracted left it) against the resident key frame KFs[b].  Two launches for the whole batch:
+// k_bow_match_resident (the accept loop per vocabulary node) and k_bow_rotation_prune (histogram, three maxima, resets, counts) - nothing but the
+// call-time flags goes up, nothing but the matches comes down.
+int orbm_search_by_bow_frames_batch(orbx_extractor* h, const orbv_vocabulary* v, int first, int B, orbm_keyframe* const* KFs, const uint8_t* const* has_mp1,
+                                    float nnratio, int check_ori, int* const* matches12, int* nmatches_out) {
+    if (!h || !v || B <= 0 || !KFs || !has_mp1 || !matches12) return fail(ORBX_E_ARG, "null");
+    VocFrameArrays V;
+    if (orbv_frame_arrays(v, &V) || V.handle != (const void*)h || V.first != first || V.lastB != B || V.cap != h->kp_total_cap || first < 0 || first + B > h->lastB)
+        return fail(ORBX_E_ARG, "run orbv_transform_extracted(v, h, %d, %d, levelsup) on this extraction first: the FeatureVectors of these frames are read where it leaves them", first, B);
+    if (V.device != h->device) return fail(ORBX_E_ARG, "vocabulary and extractor live on different devices");
+    if (undistort_stale(h)) return fail(ORBX_E_ARG, "orbx_set_undistort was called after the last extraction: extract again before searching its frames");
+    rt::set_device(h->device);
+    const int cap = h->kp_total_cap;
+    size_t ftotal = 0; int N1cap = 1, maxnodes = 1;
+    std::vector<BowPairResident> pairs(B);
+    for (int b = 0; b < B; b++) {
+        const orbm_keyframe* K1 = KFs[b];
+        if (!K1 || !matches12[b] || K1->device != h->device) return fail(ORBX_E_ARG, "bad key frame of frame %d", b);
+        BowPairResident& P = pairs[b];
+        memset(&P, 0, sizeof P);
+        P.k1 = K1->dev;
+        P.k2.kps = (h->ex_undist_active ? h->d_kps_un.p : h->d_kps.p) + (size_t)(first + b) * cap;          // F.mvKeysUn (the angle is what is read of it)
+        P.k2.desc = h->d_desc.p + (size_t)(first + b) * cap * 4; P.k2.ur = nullptr;
+        P.k2.node_id = V.fv_node + (size_t)b * cap; P.k2.fv_start = V.fv_start + (size_t)b * (cap + 1); P.k2.fv_feat = V.fv_feat + (size_t)b * cap;
+        P.k2.node_of_feat = nullptr; P.k2.N = cap; P.k2.fv_nodes = 0;
+        P.k2_nodes_dev = V.nout + 2 * b + 1;
+        P.mp1_off = -1; P.elig2_off = -1;
+        if (has_mp1[b] && K1->N > 0) { P.mp1_off = (int)ftotal; ftotal += al16((size_t)K1->N); }
+        N1cap = std::max(N1cap, K1->N); maxnodes = std::max(maxnodes, K1->fv_nodes);
+    }
+    std::vector<uint8_t> flags(std::max<size_t>(ftotal, 16), 0);
+    for (int b = 0; b < B; b++) if (pairs[b].mp1_off >= 0) memcpy(&flags[pairs[b].mp1_off], has_mp1[b], (size_t)KFs[b]->N);
+    Packer pk(h);
+    const size_t pf = pk.add(flags.data(), flags.size()), pp = pk.add(pairs.data(), sizeof(BowPairResident) * pairs.size());
+    const size_t nout = (size_t)B * N1cap, ntot = nout + 4 + (size_t)B;            // matches | status | nmatches
+    if (pk.flush() || h->d_si[SI_BEST].ensure(ntot)) return fail(ORBX_E_DEVICE, "upload/allocation failed");
+    if (rt::memset_async(h->d_si[SI_BEST].p, 0xFF, sizeof(int) * nout, h->s0) || rt::memset_async(h->d_si[SI_BEST].p + nout, 0, sizeof(int) * (4 + (size_t)B), h->s0))
+        return fail(ORBX_E_DEVICE, "memset failed");
+    if (h->profile) rt::event_record(h->ev_stage[ST_MATCH][0], h->s0);
+    dim3 grid((maxnodes + 3) / 4, B, 1), blk(256, 1, 1);
+    ORBX_LAUNCH(k_bow_match_resident, grid, blk, 0, h->s0, pk.dev<BowPairResident>(pp), pk.dev<uint8_t>(pf), nnratio, TH_LOW, 1, h->d_si[SI_BEST].p, N1cap,
+                h->d_si[SI_BEST].p + nout);
+    dim3 gridp(B, 1, 1), blkp(64, 1, 1);
+    ORBX_LAUNCH(k_bow_rotation_prune, gridp, blkp, 0, h->s0, pk.dev<BowPairResident>(pp), h->d_si[SI_BEST].p, N1cap, check_ori, h->d_si[SI_BEST].p + nout + 4);
+    if (h->profile) rt::event_record(h->ev_stage[ST_MATCH][1], h->s0);
+    std::vector<int> res(ntot);
+    if (rt::copy_d2h(res.data(), h->d_si[SI_BEST].p, sizeof(int) * ntot, h->s0) || rt::stream_sync(h->s0) || rt::check_launch())
+        return fail(ORBX_E_DEVICE, "batched bow search failed: %s", rt::last_error());
+    if (res[nout] & 4) return fail(ORBX_E_CAPACITY, "a vocabulary node holds more than 2048 features of one frame");
+    for (int b = 0; b < B; b++) {
+        const int N1 = KFs[b]->N;
+        if (N1 > 0) memcpy(matches12[b], &res[(size_t)b * N1cap], sizeof(int) * (size_t)N1);
+        if (nmatches_out) nmatches_out[b] = res[nout + 4 + b];
     }
     return ORBX_OK;
 }

@@ -16,6 +16,7 @@ struct orbv_vocabulary {
     DevBuf<unsigned long long> d_desc; DevBuf<VocSlot> d_slots; DevBuf<double> d_weight;
     // per-call scratch / results (sized by reserve())
     int cap = 0, maxB = 0, lastB = 0, run_cap = 0;      // run_cap: per-image stride of the results of the last run
+    int run_first = -1; const void* run_handle = nullptr;   // orbv_transform_extracted: which images of which extractor the results belong to
     DevBuf<unsigned long long> d_fdesc;
     DevBuf<unsigned> d_word, d_node, d_bow_id, d_fv_node, d_fv_feat;
     DevBuf<double> d_wt, d_bow_val;
@@ -57,11 +58,20 @@ int run(orbv_vocabulary* v, orbx_extractor* h, const unsigned long long* fdesc, 
                 n_feat, n_fixed, cap, P, v->weighting, norm_of(v->scoring), v->d_bow_id.p, v->d_bow_val.p, v->d_bow_start.p, v->d_fv_node.p,
                 v->d_fv_start.p, v->d_fv_feat.p, v->d_nout.p);
     if (rt::check_launch()) return fail(ORBX_E_DEVICE, "vocabulary kernels failed to launch: %s", rt::last_error());
-    v->lastB = B; v->run_cap = cap;
+    v->lastB = B; v->run_cap = cap; v->run_first = -1; v->run_handle = nullptr;
     return ORBX_OK;
 }
 
 }  // namespace
+
+namespace orbx {
+int orbv_frame_arrays(const orbv_vocabulary* v, VocFrameArrays* out) {
+    if (!v || v->lastB <= 0) return -1;
+    out->fv_node = (const uint32_t*)v->d_fv_node.p; out->fv_start = v->d_fv_start.p; out->fv_feat = (const int*)v->d_fv_feat.p; out->nout = v->d_nout.p;
+    out->cap = v->run_cap; out->lastB = v->lastB; out->device = v->device; out->first = v->run_first; out->handle = v->run_handle;
+    return 0;
+}
+}  // namespace orbx
 
 extern "C" {
 
@@ -161,7 +171,9 @@ int orbv_transform_extracted(orbv_vocabulary* v, orbx_extractor* h, int first, i
     if (first < 0 || B <= 0 || first + B > h->lastB) return fail(ORBX_E_ARG, "images [%d, %d) are not in the last batch of %d", first, first + B, h->lastB);
     rt::set_device(h->device);
     const int cap = h->kp_total_cap;
-    return run(v, h, (const unsigned long long*)(h->d_desc.p + (size_t)first * cap * 4), (const int*)(h->d_nm.p + first), 0, cap, B, levelsup);
+    const int rc = run(v, h, (const unsigned long long*)(h->d_desc.p + (size_t)first * cap * 4), (const int*)(h->d_nm.p + first), 0, cap, B, levelsup);
+    if (rc == ORBX_OK) { v->run_first = first; v->run_handle = h; }
+    return rc;
 }
 
 int orbv_fetch(orbv_vocabulary* v, orbx_extractor* h, int b, uint32_t* word_id, uint32_t* node_id, int n_features, uint32_t* bow_id, double* bow_val,

@@ -41,7 +41,13 @@ template <typename T> struct HostBuf {
     void release() { rt::hfree(p); p = nullptr; n = 0; }
 };
 
+// where the vocabulary transform of the last orbv_transform_extracted left the FeatureVectors of its frames (orbv_api.cpp), for the searches that
+// read them in place (orbm_search_by_bow_frames_batch): frame b's sorted node ids at fv_node + b * cap, CSR offsets at fv_start + b * (cap + 1),
+// feature indices at fv_feat + b * cap, its node count at nout[2 * b + 1]
+struct VocFrameArrays { const uint32_t* fv_node; const int* fv_start; const int* fv_feat; const int* nout; int cap, lastB, device, first; const void* handle; };
 }  // namespace orbx
+struct orbv_vocabulary;
+namespace orbx { int orbv_frame_arrays(const orbv_vocabulary* v, VocFrameArrays* out); }
 
 struct orbx_extractor {
     // ---- reference constructor state (src/ORBextractor.cc:468-571) ----

@@ -145,6 +145,7 @@ __global__ void k_sft_resident(ResidentKF k1, const uint8_t* __restrict__ flags,
 __global__ void k_sft_resident_kb8(ResidentKF k1, const uint8_t* __restrict__ flags, const SftNeighbour* __restrict__ nb, int* __restrict__ best);
 __global__ void k_bow_match_resident(const BowPairResident* __restrict__ pairs, const uint8_t* __restrict__ flags, float nnratio, int th_low,
                                      int th_inclusive, int* __restrict__ m12, int N1cap, int* __restrict__ status);
+__global__ void k_bow_rotation_prune(const BowPairResident* __restrict__ pairs, int* __restrict__ m12, int N1cap, int check_ori, int* __restrict__ nmatches);
 __global__ void k_bow_dists(const BowItem* __restrict__ items, int nitems, const unsigned long long* __restrict__ desc1,
                             const unsigned long long* __restrict__ desc2, const uint8_t* __restrict__ eligible2,
                             const int* __restrict__ feat2, int* __restrict__ out);

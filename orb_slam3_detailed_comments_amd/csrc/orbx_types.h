@@ -114,7 +114,9 @@ struct ResidentKF {
     int N, fv_nodes;
 };
 struct SftNeighbour { ResidentKF k2; BowParams P; int mp2_off; int _pad; };        // one neighbour of orbm_search_for_triangulation_resident
-struct BowPairResident { ResidentKF k1, k2; int mp1_off, elig2_off; };             // one pair of orbm_search_by_bow_resident (offsets into the flag block, -1 = none / all)
+// one pair of orbm_search_by_bow_resident (offsets into the flag block, -1 = none / all).  k2_nodes_dev != NULL: K2 is a FRAME of the last extraction
+// whose FeatureVector the vocabulary transform left on the device; its node count is read there (orbm_search_by_bow_frames_batch)
+struct BowPairResident { ResidentKF k1, k2; int mp1_off, elig2_off; const int* k2_nodes_dev; };
 struct KB8StereoParams {                     // Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1530-1587)
     float cam1[8], cam2[8];                  // mpCamera, mpCamera2
     float R12[9], t12[3];                    // mRlr, mtlr

@@ -101,6 +101,20 @@ class ORBmatcher:
         ext._lib.check(ext._lib.L.orbm_search_by_bow_resident(ext._h, n, p1, q1, p2, q2, self.mfNNratio, int(frame_version), int(self.mbCheckOrientation), po, nm.ctypes.data))
         return [(int(nm[p]), outs[p][:kf1s[p].N]) for p in range(n)]
 
+    def SearchByBoWFramesBatch(self, ext, voc, kfs, mps, first=0):
+        """ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) for the frames [first, first + len(kfs)) of ext's last extraction on the device
+        (orbm_search_by_bow_frames_batch): voc = the ORBVocabulary whose transform_extracted(ext, first, B, levelsup) has run on these frames, kfs[b] = the
+        ResidentKeyFrame frame b is searched against, mps[b] = uint8 flags "feature of kfs[b] has a good map point".  Returns [(nmatches, matches12)]
+        with matches12[i] = frame feature matched to key-frame feature i or -1."""
+        B = len(kfs)
+        p1 = (C.c_void_p * max(B, 1))(*[k._kf for k in kfs])
+        a1 = [np.ascontiguousarray(m, np.uint8) for m in mps]
+        q1 = (C.c_void_p * max(B, 1))(*[m.ctypes.data for m in a1])
+        outs = [np.full(max(k.N, 1), -1, np.int32) for k in kfs]
+        po = (C.c_void_p * max(B, 1))(*[o.ctypes.data for o in outs]); nm = np.zeros(max(B, 1), np.int32)
+        ext._lib.check(ext._lib.L.orbm_search_by_bow_frames_batch(ext._h, voc._v, int(first), B, p1, q1, self.mfNNratio, int(self.mbCheckOrientation), po, nm.ctypes.data))
+        return [(int(nm[b]), outs[b][:kfs[b].N]) for b in range(B)]
+
     def SearchByBoWFisheye(self, ext, kf, frame, nleft):
         """SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) for a fisheye-rig frame (F.Nleft = nleft != -1), src/ORBmatcher.cc:259-493.
         Both views list all features by index (camera 1 first).  Returns (nmatches, assigned[N_frame] = key-frame feature or -1)."""
