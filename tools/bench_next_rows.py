@@ -159,6 +159,62 @@ def main():
     st = ex3.stage_ms()
     out["cv::remap rectification, 128 x 752x480 (k_input_remap -> level 0)"] = {"gpu_ms": round(st["import"], 4), "GBps": round(128 * 752 * 480 * (1 + 8 + 1) / (st["import"] * 1e-3) / 1e9, 1),
                                                                                  "cpu_oracle_ms_per_image": round(best(lambda: ol.oracle_remap(imgs[0], mx, my), 2), 2)}
+    # ---- round 4: the remaining per-frame searches in batched device form, BASELINE.json config-4 size: 128 frames of 640x480, 1000 features ----
+    import test_local_points as tlp
+    Bf = 128
+    ex5 = ORBextractor(1000, 1.2, 8, 20, 7)
+    imgs5 = np.stack([synth.corner_field(640, 480, seed=400 + (i % 16), nrect=int(3000 * 640 * 480 / (752 * 480))) for i in range(Bf)])
+    res5 = ex5.extract_batch(imgs5)
+    sfs5 = ex5.GetScaleFactors(); cap5 = ex5.max_keypoints()
+    cam5, bounds5 = (tlp.FX, tlp.FY, tlp.CX, tlp.CY), (0.0, 640.0, 0.0, 480.0)
+    # relocalisation: SearchByProjection(CurrentFrame, pKF, sAlreadyFound, 10, 100), every frame against the ~1000 map points of its candidate key frame
+    capK = cap5
+    nK = np.zeros(Bf, np.int32); posK = np.zeros((Bf, capK, 3), np.float32); validK = np.zeros((Bf, capK), np.uint8); mnK = np.zeros((Bf, capK), np.float32)
+    mxK = np.zeros((Bf, capK), np.float32); angK = np.zeros((Bf, capK), np.float32); descK = np.zeros((Bf, capK, 32), np.uint8); poses5 = []
+    for b in range(Bf):
+        k, d = res5[b][1], res5[b][2]; N = len(k); nK[b] = N
+        R5, t5 = tlp._rot(*(rng.normal(0, 0.01, 3))), rng.normal(0, 0.05, 3).astype(np.float32); poses5.append((R5, t5))
+        z = rng.uniform(1.0, 10.0, N)
+        Xc = np.stack([(k["x"] + rng.normal(0, 1.5, N) - tlp.CX) / tlp.FX * z, (k["y"] + rng.normal(0, 1.5, N) - tlp.CY) / tlp.FY * z, z], 1)
+        Xw = (R5.astype(np.float64).T @ (Xc - t5.astype(np.float64)).T).T
+        posK[b, :N] = Xw; validK[b, :N] = rng.uniform(size=N) < 0.85
+        dist = np.linalg.norm(Xw + (R5.astype(np.float64).T @ t5.astype(np.float64)), axis=1)
+        mx = dist * 1.2 ** k["octave"].astype(np.float64); mxK[b, :N] = mx; mnK[b, :N] = mx / 1.2 ** 7
+        angK[b, :N] = k["angle"]; dd = d.copy()
+        flips = rng.integers(0, 256, (N, 12))
+        for j in range(12):
+            dd[np.arange(N), flips[:, j] >> 3] ^= (1 << (flips[:, j] & 7)).astype(np.uint8)
+        descK[b, :N] = dd
+    kb = M.KeyFrameBatch(ex5, Bf, cam5, bounds5, tlp.BF, sfs5); kb.set_poses(poses5)
+
+    def reloc():
+        kb.enqueue(nK, posK, validK, mnK, mxK, angK, descK, 10.0, 100, True, None); return kb.fetch()
+    t_rel = best(reloc, 8); _, nm_rel = reloc()
+    out["SearchByProjection(Frame, KeyFrame, sAlreadyFound, 10, 100) x 128 frames, batched on the device (relocalisation)"] = {
+        "gpu_ms_per_batch": round(t_rel, 3), "frames_per_s": round(Bf / (t_rel * 1e-3), 1), "avg_matches_per_frame": round(float(nm_rel.mean()), 1), "points_per_key_frame": int(nK.mean())}
+    # TrackReferenceKeyFrame / Relocalization: SearchByBoW(pKF, F, vpMapPointMatches), every frame against a resident key frame; vocabulary k = 10, L = 5
+    voc5 = ORBVocabulary.loadFromTextFile(ex5, path)
+    kfs5, mps5 = [], []
+    for b in range(16):                                     # 16 distinct key frames serve the 128 frames (frame b and b + 16 show the same scene)
+        k, d = res5[b][1], res5[b][2]
+        bw = voc5.transform(descK[b, :len(k)], 4)
+        from orb_slam3_detailed_comments_amd import views as V5
+        kfs5.append(M.ResidentKeyFrame(ex5, V5.key_frame_view(k, descK[b, :len(k)], sfs5, sfs5 * sfs5, bw.fv_node, bw.fv_start, bw.fv_feat, None, None)))
+        mps5.append((rng.uniform(size=len(k)) < 0.85).astype(np.uint8))
+    kf_list = [kfs5[b % 16] for b in range(Bf)]; mp_list = [mps5[b % 16] for b in range(Bf)]
+    mb5 = M.ORBmatcher(0.7, True)
+
+    def bow_frames():
+        voc5.transform_extracted(ex5, 0, Bf, 4)
+        return mb5.SearchByBoWFramesBatch(ex5, voc5, kf_list, mp_list)
+
+    def bow_only():
+        return mb5.SearchByBoWFramesBatch(ex5, voc5, kf_list, mp_list)
+    t_bow = best(bow_frames, 6); t_bow_only = best(bow_only, 6); rb = bow_frames()
+    out["SearchByBoW(KeyFrame, Frame) x 128 frames, batched on the device (frames' FeatureVectors from the device vocabulary transform)"] = {
+        "gpu_ms_per_batch_with_vocabulary_transform": round(t_bow, 3), "frames_per_s_with_vocabulary_transform": round(Bf / (t_bow * 1e-3), 1),
+        "gpu_ms_per_batch_search_only": round(t_bow_only, 3), "frames_per_s_search_only": round(Bf / (t_bow_only * 1e-3), 1),
+        "avg_matches_per_frame": round(float(np.mean([r[0] for r in rb])), 1)}
     print(json.dumps(out, indent=1))
 
 
