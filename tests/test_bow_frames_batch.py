@@ -19,10 +19,10 @@ REF = os.path.join(ol.ROOT, "oracle", "_ref", "libmw_ref.so")
 pytestmark = pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/libmw_ref.so not built (needs /root/reference)")
 
 
-def _run(lib, w, h, nf, B):
-    rng = np.random.default_rng(97 + B)
+def _run(lib, w, h, nf, B, seed=0):
+    rng = np.random.default_rng(97 + B + 1000 * seed)
     ex = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib)
-    imgs = np.stack([synth.corner_field(w, h, seed=700 + b, nrect=int(3000 * w * h / (752 * 480))) for b in range(B)])
+    imgs = np.stack([synth.corner_field(w, h, seed=700 + b + 37 * seed, nrect=int(3000 * w * h / (752 * 480))) for b in range(B)])
     res = ex.extract_batch(imgs)
     header, parent, leaf, desc, weight = vs.make_vocabulary(rng, 6, 3)
     voc = ORBVocabulary.from_arrays(ex, header[0], header[1], header[2], header[3], parent, leaf, desc, weight)

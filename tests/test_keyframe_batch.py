@@ -18,9 +18,9 @@ pytestmark = pytest.mark.skipif(ol.reference_frame_lib() is None, reason="oracle
 BASE = 0.110074
 
 
-def _run(lib, w, h, nf, B):
-    rng = np.random.default_rng(4242 + B)
-    pairs = [synth.stereo_pair(w, h, seed=520 + b, nrect=int(3000 * w * h / (752 * 480))) for b in range(B)]
+def _run(lib, w, h, nf, B, seed=0):
+    rng = np.random.default_rng(4242 + B + 1000 * seed)
+    pairs = [synth.stereo_pair(w, h, seed=520 + b + 37 * seed, nrect=int(3000 * w * h / (752 * 480))) for b in range(B)]
     refs = [ol.ReferenceFrame(l, r, nf, fx=FX, fy=FY, cx=CX, cy=CY, bf=BF) for l, r in pairs]
     ex = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib)
     cap = ex.max_keypoints()

@@ -16,9 +16,9 @@ from test_local_points import _rot, FX, FY, CX, CY, BF
 BASE = 0.110074
 
 
-def _run(lib, w, h, nf, B, mono):
-    rng = np.random.default_rng(808 + B + int(mono))
-    pairs = [synth.stereo_pair(w, h, seed=120 + b, nrect=int(3000 * w * h / (752 * 480))) for b in range(B)]
+def _run(lib, w, h, nf, B, mono, seed=0):
+    rng = np.random.default_rng(808 + B + int(mono) + 1000 * seed)
+    pairs = [synth.stereo_pair(w, h, seed=120 + b + 37 * seed, nrect=int(3000 * w * h / (752 * 480))) for b in range(B)]
     refs = [ol.ReferenceFrame(l, r, nf, fx=FX, fy=FY, cx=CX, cy=CY, bf=BF) for l, r in pairs]
     ex = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib)
     cap = ex.max_keypoints()

@@ -101,9 +101,9 @@ def _edge_points(F, sfs, T, th, rng, want):
     return np.array(pos, f32), np.array(octv, np.int32), np.array(desc, np.uint8), hits
 
 
-def _run(lib, w, h, nf, B):
-    rng = np.random.default_rng(77)
-    pairs = [synth.stereo_pair(w, h, seed=300 + b, nrect=int(3000 * w * h / (752 * 480))) for b in range(B)]
+def _run(lib, w, h, nf, B, seed=0):
+    rng = np.random.default_rng(77 + 1000 * seed)
+    pairs = [synth.stereo_pair(w, h, seed=300 + b + 37 * seed, nrect=int(3000 * w * h / (752 * 480))) for b in range(B)]
     refs = [ol.ReferenceFrame(l, r, nf, fx=FX, fy=FY, cx=CX, cy=CY, bf=BF) for l, r in pairs]
     ex = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib)
     cap = ex.max_keypoints()
