@@ -228,6 +228,8 @@ def main():
     ap.add_argument("--import-copy", action="store_true", help="keep the resident inputs in a separate linear device buffer and copy them into the pyramid inside "
                     "every step (the rounds 1-2 measurement) instead of letting the producer write pyramid level 0 directly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-pair latency loop (220 tiny launches of every kernel: profiling runs leave it out so that "
+                    "per-kernel averages of rocprofv3 are averages over the timed launches)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the second, PCIe-inclusive measurement (never `value`)")
     ap.add_argument("--h2d", action="store_true", help="make the PCIe-inclusive variant the timed loop (NOT the headline value)")
     args = ap.parse_args()
@@ -674,7 +676,7 @@ def main():
                                         "step_ms": {"median": round(pct(per2, 50), 4), "p10": round(pct(per2, 10), 4), "p90": round(pct(per2, 90), 4)}}
             except Exception as e:
                 res["h2d_inclusive"] = {"value": None, "error": repr(e)}
-        if kind == "stereo" and world == 1 and not os.environ.get("ORBX_BENCH_LIB"):
+        if kind == "stereo" and world == 1 and not args.no_latency and not os.environ.get("ORBX_BENCH_LIB"):
             # reported beside the throughput, never `value`: one stereo pair per call on one fresh handle, synchronised after every pair
             # (Tracking's rhythm: extract L + R, ComputeStereoMatches, wait), the frames written into pyramid level 0 by the producer
             try:
