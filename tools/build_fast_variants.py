@@ -74,7 +74,6 @@ if __name__ == "__main__":
     jobs = [("base", ()), ("load_only", ()), ("no_score", ()), ("no_cd", ()), ("no_gather", ()), ("no_network", ()),
             ("base+list1k", ("-DORBX_FAST_LIST_BYTES=1024",)), ("base+list3k", ("-DORBX_FAST_LIST_BYTES=3072",)), ("base+xcd1", ("-DORBX_FAST_XCD_RUN=1",)),
             ("A_nowrite", ()), ("A_noread", ()), ("A_noappend", ()),
-            ("base+p44", ("-DORBX_FAST_PITCH_NARROW=44",)),
             ("base+strip4", ("-DORBX_RESIZE_STRIP=4",)), ("base+strip8", ("-DORBX_RESIZE_STRIP=8",)), ("base+strip32", ("-DORBX_RESIZE_STRIP=32",))]
     if len(sys.argv) > 1: jobs = [j for j in jobs if j[0] in sys.argv[1:]]
     with ThreadPoolExecutor(4) as ex:
