@@ -564,6 +564,7 @@ int orbm_stereo_from_depth(orbx_extractor* h, int first, int B, const float* dep
 int orbm_search_local_points_batch(orbx_extractor* h, int first, int B, const OrbmFrustumView* frames, const orbm_points* points, const uint8_t* is_bad,
                                    const uint8_t* has_obs, const uint8_t* occupied, int use_u_right, float cos_limit, float th, int far_points, float th_far,
                                    float nnratio, int want_in_view) {
+    if (h) h->lp_B = 0;            // a new enqueue - accepted or refused - ends the previous batch: a refused call leaves nothing to fetch
     if (!h || !frames || !points || B <= 0 || first < 0 || first + B > h->lastB) return fail(ORBX_E_ARG, "bad frame range / null");
     if (points->device != h->device) return fail(ORBX_E_ARG, "map points live on another device");
     for (int b = 0; b < B; b++) {
@@ -746,6 +747,7 @@ int projection_batch(orbx_extractor* h, int first, int B, const OrbmFrustumView*
 
 int orbm_search_by_projection_lastframe_batch(orbx_extractor* h, int first, int B, const OrbmFrustumView* cur, const OrbmLastFrameBatch* last, float th,
                                               const uint8_t* forward, const uint8_t* backward, int check_ori, const uint8_t* occupied, int use_u_right) {
+    if (h) h->lp_B = 0;
     if (!h || !cur || !last || B <= 0 || first < 0 || first + B > h->lastB) return fail(ORBX_E_ARG, "bad frame range / null");
     if (last->cap_last <= 0 || !last->n || !last->pos || !last->valid || !last->octave || !last->angle || !last->desc) return fail(ORBX_E_ARG, "bad last-frame batch");
     const PointRows R = {last->cap_last, last->n, last->pos, last->valid, last->octave, last->angle, last->has_obs, last->desc, nullptr, nullptr};
@@ -754,6 +756,7 @@ int orbm_search_by_projection_lastframe_batch(orbx_extractor* h, int first, int 
 
 int orbm_search_by_projection_keyframe_batch(orbx_extractor* h, int first, int B, const OrbmFrustumView* cur, const OrbmKeyFramePointBatch* kf, float th, int orb_dist,
                                              int check_ori, const uint8_t* occupied) {
+    if (h) h->lp_B = 0;
     if (!h || !cur || !kf || B <= 0 || first < 0 || first + B > h->lastB) return fail(ORBX_E_ARG, "bad frame range / null");
     if (kf->cap_kf <= 0 || !kf->n || !kf->pos || !kf->valid || !kf->min_distance || !kf->max_distance || !kf->angle || !kf->desc) return fail(ORBX_E_ARG, "bad key-frame batch");
     if (orb_dist < 0 || orb_dist > 256) return fail(ORBX_E_ARG, "ORBdist out of range");

@@ -98,3 +98,41 @@ def test_bow_frames_batch_emulated(emu_lib):
 @pytest.mark.gpu
 def test_bow_frames_batch_gpu(hip_lib):
     _run(hip_lib, 752, 480, 1200, 8)
+
+
+def test_bow_frames_batch_edge_cases(emu_lib):
+    """Empty and ragged inputs of orbm_search_by_bow_frames_batch: a frame without keypoints (flat image), a key frame none of whose features carries a
+    map point, an empty key frame, a key frame whose vocabulary nodes the frame does not have; one key frame serving several frames."""
+    rng = np.random.default_rng(5)
+    w, h, nf = 376, 240, 400
+    ex = ORBextractor(nf, 1.2, 8, 20, 7, lib=emu_lib)
+    imgs = np.stack([np.full((h, w), 90, np.uint8), synth.corner_field(w, h, seed=31, nrect=900), synth.corner_field(w, h, seed=31, nrect=900),
+                     synth.corner_field(w, h, seed=32, nrect=900)])
+    res = ex.extract_batch(imgs)
+    assert len(res[0][1]) == 0 and len(res[1][1]) > 100
+    header, parent, leaf, desc, weight = vs.make_vocabulary(rng, 5, 3)
+    voc = ORBVocabulary.from_arrays(ex, header[0], header[1], header[2], header[3], parent, leaf, desc, weight)
+    sfs = ex.GetScaleFactors()
+
+    def resident(k, d, flags):
+        bw = voc.transform(d, 2) if len(d) else None
+        z = np.zeros(0, np.uint32)
+        kv = views.key_frame_view(k, d if len(d) else np.zeros((0, 32), np.uint8), sfs, sfs * sfs, bw.fv_node if bw else z, bw.fv_start if bw else np.zeros(1, np.int32),
+                                  bw.fv_feat if bw else z, None, flags)
+        return M.ResidentKeyFrame(ex, kv)
+    k1, d1 = res[1][1], res[1][2]
+    kk = np.zeros(len(k1), KP)
+    for f in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+        kk[f] = k1[f]
+    full = resident(kk, d1, np.ones(len(k1), np.uint8))
+    empty = resident(np.zeros(0, KP), np.zeros((0, 32), np.uint8), np.zeros(0, np.uint8))
+    voc.transform_extracted(ex, 0, 4, 2)
+    m = M.ORBmatcher(0.7, True)
+    got = m.SearchByBoWFramesBatch(ex, voc, [full, full, full, empty], [np.ones(full.N, np.uint8), np.zeros(full.N, np.uint8), np.ones(full.N, np.uint8), np.zeros(1, np.uint8)])
+    assert got[0][0] == 0 and (got[0][1] == -1).all()                    # the flat frame has nothing to match
+    assert got[1][0] == 0 and (got[1][1] == -1).all()                    # no feature of the key frame carries a map point
+    # frame 2 shows the key frame's own image: every feature in a node with a non-zero word finds itself (distance 0, unique within the ratio), nearly all survive
+    n2, m2 = got[2]
+    assert n2 > 0.5 * full.N and all(m2[i] in (-1, i) for i in range(full.N)), n2
+    assert got[3][0] == 0 and len(got[3][1]) == 0                        # the empty key frame
+    full.close(); empty.close(); voc.close(); ex.close()
