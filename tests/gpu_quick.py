@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))));
 import oracle_lib as ol
 from orb_slam3_detailed_comments_amd import synth, _lib, ORBextractor
 from orb_slam3_detailed_comments_amd import matcher as M
-lib = _lib.load_hip()
+lib = _lib.OrbxLib(os.environ["ORBX_QUICK_LIB"]) if os.environ.get("ORBX_QUICK_LIB") else _lib.load_hip()      # ORBX_QUICK_LIB: A/B of library builds (tools/gpu_r4_ab3.sh)
 print('devices', lib.L.orbx_device_count())
 ok_all = True
 for name, img, nf, lap in [
