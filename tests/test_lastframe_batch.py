@@ -11,7 +11,9 @@ import pytest
 import oracle_lib as ol
 from orb_slam3_detailed_comments_amd import ORBextractor, synth, views
 from orb_slam3_detailed_comments_amd import matcher as M
+from orb_slam3_detailed_comments_amd import sophus
 from test_local_points import _rot, FX, FY, CX, CY, BF
+from test_models import _predict_scale_float
 
 BASE = 0.110074
 
@@ -100,3 +102,76 @@ def test_lastframe_batch_emulated(emu_lib, mono):
 @pytest.mark.parametrize("mono", [False, True])
 def test_lastframe_batch_gpu(hip_lib, mono):
     _run(hip_lib, 752, 480, 1200, 24, mono)
+
+
+def _kb8_case(lib, w, h, nf, B):
+    """Frames of ONE Kannala-Brandt camera (Nleft == -1, mpCamera->project = KannalaBrandt8::project with the glibc atan2f model): the batched LastFrame
+    and relocalisation searches take the camera's eight parameters; checked against the single-frame calls behind orbm_project_points, which
+    tests/test_matcher_reference.py pins to the reference's ORBmatcher.cc on Kannala-Brandt worlds (the reference Frame of the other tests is a pinhole one)."""
+    rng = np.random.default_rng(31 + B)
+    KB = (190.978477, 190.973307, w / 2 + 1.3, h / 2 - 0.7, 0.003482389402, 0.000715034845, -0.002053236141, 0.000202936736)
+    imgs = np.stack([synth.corner_field(w, h, seed=640 + b, nrect=int(3000 * w * h / (752 * 480))) for b in range(B)])
+    ex = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib)
+    cap = ex.max_keypoints()
+    res = ex.extract_batch(imgs)
+    sfs = ex.GetScaleFactors()
+    bounds = (0.0, float(w), 0.0, float(h))
+    capL = cap + 3
+    n = np.zeros(B, np.int32); pos = np.zeros((B, capL, 3), np.float32); valid = np.zeros((B, capL), np.uint8); octave = np.zeros((B, capL), np.int32)
+    angle = np.zeros((B, capL), np.float32); has_obs = np.ones((B, capL), np.uint8); desc = np.zeros((B, capL, 32), np.uint8)
+    mind = np.zeros((B, capL), np.float32); maxd = np.zeros((B, capL), np.float32)
+    poses = []
+    for b in range(B):
+        k, d = res[b][1], res[b][2]; N = len(k); n[b] = N
+        R, t = _rot(*(rng.normal(0, 0.004, 3))), rng.normal(0, 0.02, 3).astype(np.float32); poses.append((R, t))
+        # back-project through the fisheye model: theta_d = r / f, theta from the polynomial (a few Newton steps in double), ray = (sin th cos psi, sin th sin psi, cos th)
+        xd, yd = (k["x"] + rng.normal(0, 1.0, N) - KB[2]) / KB[0], (k["y"] + rng.normal(0, 1.0, N) - KB[3]) / KB[1]
+        td = np.hypot(xd, yd); th = td.copy()
+        for _ in range(8):
+            th = th - (th * (1 + KB[4] * th ** 2 + KB[5] * th ** 4 + KB[6] * th ** 6 + KB[7] * th ** 8) - td) / (1 + 3 * KB[4] * th ** 2 + 5 * KB[5] * th ** 4 + 7 * KB[6] * th ** 6 + 9 * KB[7] * th ** 8)
+        psi = np.arctan2(yd, xd); rho = rng.uniform(1.0, 10.0, N)
+        Xc = np.stack([np.sin(th) * np.cos(psi), np.sin(th) * np.sin(psi), np.cos(th)], 1) * rho[:, None]
+        Xw = (R.astype(np.float64).T @ (Xc - t.astype(np.float64)).T).T
+        pos[b, :N] = Xw; valid[b, :N] = rng.uniform(size=N) < 0.85; octave[b, :N] = np.clip(k["octave"] + rng.integers(-1, 2, N), 0, 7)
+        angle[b, :N] = np.mod(k["angle"] + rng.normal(0, 4.0, N), 360.0)
+        dist = np.linalg.norm(Xw + R.astype(np.float64).T @ t.astype(np.float64), axis=1)
+        maxd[b, :N] = dist * 1.2 ** k["octave"].astype(np.float64); mind[b, :N] = maxd[b, :N] / 1.2 ** 7
+        dd = d.copy(); fl = rng.integers(0, 256, (N, 10))
+        for j in range(10):
+            dd[np.arange(N), fl[:, j] >> 3] ^= (1 << (fl[:, j] & 7)).astype(np.uint8)
+        desc[b, :N] = dd
+    matcher = M.ORBmatcher(0.9, True)
+    lf = M.LastFrameBatch(ex, B, KB, bounds, 0.0, sfs); lf.set_poses(poses)
+    lf.enqueue(n, pos, valid, octave, angle, has_obs, desc, 7.0, None, None, True, None, use_u_right=False)
+    asg, nm = lf.fetch()
+    kb = M.KeyFrameBatch(ex, B, KB, bounds, 0.0, sfs); kb.set_poses(poses)
+    kb.enqueue(n, pos, valid, mind, maxd, angle, desc, 10.0, 100, True, None)
+    asg_k, nm_k = kb.fetch()
+    total = 0
+    for b in range(B):
+        N = int(n[b])
+        pr = M.ProjectPoints(ex, poses[b], KB, bounds, pos[b, :N], skip=1 - valid[b, :N], depth_test=2, bounds_mode=0)
+        last = views.last_frame_view(pr["valid"], pr["u"], pr["v"], pr["inv_z"], octave[b, :N], angle[b, :N], has_obs[b, :N], desc[b, :N])
+        fv = views.frame_view(res[b][1], res[b][2], sfs, w, h, u_right=None, mbf=0.0)
+        one_n, one_as = matcher.SearchByProjectionFrame(ex, fv, last, 7.0, False, False)
+        assert nm[b] == one_n and np.array_equal(asg[b, :N], one_as), "Kannala-Brandt LastFrame batch, frame %d: %d vs %d" % (b, nm[b], one_n)
+        total += one_n
+        # relocalisation: the single-frame call (orbm_project_points with the distance test + PredictScale by glibc's logf on the host, as the facade does)
+        T = sophus.SE3f(*poses[b])
+        pk = M.ProjectPoints(ex, T, KB, bounds, pos[b, :N], min_inv=0.8 * mind[b, :N], max_inv=1.2 * maxd[b, :N], skip=1 - valid[b, :N], Ow=T.inverse().translation(),
+                             depth_test=0, bounds_mode=0)
+        lvl = _predict_scale_float(maxd[b, :N] / np.maximum(pk["dist"], np.float32(1e-30)), np.float32(np.log(np.float64(sfs[1]))), len(sfs))
+        pts = views.projected_point_view(pk["valid"], pk["u"], pk["v"], lvl, desc[b, :N], angle=angle[b, :N])
+        k_n, k_as = matcher.SearchByProjectionKeyFrame(ex, fv, pts, 10.0, 100)
+        assert nm_k[b] == k_n > 50 and np.array_equal(asg_k[b, :N], k_as), "Kannala-Brandt relocalisation batch, frame %d: %d vs %d" % (b, nm_k[b], k_n)
+    assert total > 100 * B
+    ex.close()
+
+
+def test_lastframe_and_keyframe_batch_kb8_emulated(emu_lib):
+    _kb8_case(emu_lib, 400, 400, 500, 2)
+
+
+@pytest.mark.gpu
+def test_lastframe_and_keyframe_batch_kb8_gpu(hip_lib):
+    _kb8_case(hip_lib, 512, 512, 1500, 6)
