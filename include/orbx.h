@@ -499,7 +499,7 @@ int orbm_search_by_projection_mappoints_fisheye(orbx_extractor* h, const OrbmFis
                                                 float nnratio, int* assigned, int* nmatches);
 /* Frame::isInFrustum for a two-camera rig (Nleft != -1, src/Frame.cc:754-766): Frame::isInFrustumChecks (:1592-1650) once per camera on the
  * device.  `left` = camera 1 as in OrbmFrustumView (mRcw, mtcw, mOw, mpCamera, the image bounds); camera 2 is derived exactly as the reference
- * derives it: mR = Rrl * mRcw, mt = Rrl * mtcw + trl, twc = mRwc * tlr + mOw (3-term sums left to right), projected with mpCamera2.  A point
+ * derives it: mR = Rrl * mRcw, mt = Rrl * mtcw + trl, twc = mRwc * tlr + mOw (Eigen >= 3.3's sums: a0 + (a1 + a2)), projected with mpCamera2.  A point
  * that fails any test of a camera leaves that camera's fields untouched in the reference; here its in-view flag is 0, its level -1 and the
  * other fields unspecified. */
 typedef struct OrbmFrustumRigView {

@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(64 * kAreaWaves) k_area_search(const AreaQuery
 }
 
 // Frame::isInFrustum (src/Frame.cc:667-773, one camera) + MapPoint::PredictScale (src/MapPoint.cc:688-731) for M map points, one thread each,
-// in the reference's fp32 operation order (Eigen's 3x3 * 3x1 is sum-of-products left to right; no fused multiply-adds).  Writes the tracking
+// in the reference's fp32 operation order (Eigen >= 3.3 sums a 3-term product coefficient as a0 + (a1 + a2), sophus_action.h; no fused multiply-adds).  Writes the tracking
 // fields the reference stores in the MapPoint (mbTrackInView, mTrackProjX / Y / XR, mTrackDepth, mnTrackScaleLevel, mTrackViewCos) and,
 // when `queries` is given, the window query of ORBmatcher::SearchByProjection(Frame, MapPoints) for that point (src/ORBmatcher.cc:53-82).
 // Batched form: Fbatch != NULL -> blockIdx.y = frame, frame b uses Fbatch[b] and writes at offsets b * M (track: b * 5 * M).
@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(256) k_frustum(FrustumParams F, int M, const f
 // The head of the projection-type searches of ORBmatcher (SearchByProjection(Frame, LastFrame) src/ORBmatcher.cc:1993-2010, (Frame, KeyFrame)
 // :2228-2256, (KeyFrame, Sim3, ...) :525-560 / :640-690, Fuse :1388-1430 / :1590-1625, SearchBySim3 :1745-1790 / :1830-1875): transform the map
 // point, depth test, projection, image test, distance range, viewing angle - one thread per point, the reference's fp32 operation order
-// (3-term sums left to right, no fused multiply-adds).  Which tests run and how the projection is written differ between the reference's
+// (Sophus' quaternion action for the transform, Eigen's a0 + (a1 + a2) for norms and dot products; no fused multiply-adds).  Which tests run and how the projection is written differ between the reference's
 // methods; P says which.  Outputs: valid, u, v, ur = u - bf / z, 1 / z, dist (the argument of MapPoint::PredictScale, which stays with the
 // caller's MapPoint).  skip[i] != 0: the caller's own tests (bad, already matched, ...) have rejected the point.
 __global__ void __launch_bounds__(256) k_project_points(ProjectParams P, int M, const float* __restrict__ pos, const float* __restrict__ normal,
