@@ -13,6 +13,7 @@
 // frames, an interleaved intermediate that k_input_gray then converts - the order System (geometry) -> Tracking (grey) of the reference.
 #include "orbx_types.h"
 #include "orbx_block.h"
+#include "orbx_simd.h"
 
 namespace orbx {
 
@@ -64,18 +65,39 @@ __global__ void __launch_bounds__(256) k_input_resize(const uint8_t* __restrict_
     }
 }
 
-// grid (ceil(dst_pitch/64), ceil(h/4), B), block (64,4).  src: C = 3 or 4 interleaved channels; ridx = index of the red channel
+// grid (ceil(dst_pitch/256), ceil(h/4), B), block (64,4).  src: C = 3 or 4 interleaved channels; ridx = index of the red channel
 // (0 for RGB / RGBA, 2 for BGR / BGRA); (ry, gy, by, shift) = the OpenCV version's coefficients.
+// A thread converts FOUR adjacent pixels: their 12 / 16 source bytes come in as three / four dwords (any byte address: global loads need no alignment
+// on gfx950) and leave as one dword - a byte load per channel and a byte store per pixel ran this streaming kernel at 1.4 TB/s (round 4).
 __global__ void __launch_bounds__(256) k_input_gray(const uint8_t* __restrict__ src, int sstride, size_t simg, int C, int ridx,
                                                     int ry, int gy, int by, int shift, int w, int h,
                                                     uint8_t* __restrict__ dst, int dst_pitch, size_t dst_stride) {
-    const int x = (int)(blockIdx.x * 64 + threadIdx.x), y = (int)(blockIdx.y * 4 + threadIdx.y), b = (int)blockIdx.z;
-    if (y >= h || x >= dst_pitch) return;
-    uint8_t* o = dst + (size_t)b * dst_stride + (size_t)y * dst_pitch + x;
-    if (x >= w) { *o = 0; return; }
+    const int x = 4 * (int)(blockIdx.x * 64 + threadIdx.x), y = (int)(blockIdx.y * 4 + threadIdx.y), b = (int)blockIdx.z;
+    if (y >= h || x >= dst_pitch) return;                       // (the pitch is a multiple of 64: a thread's dword lies inside the row)
+    uint32_t* o = (uint32_t*)(dst + (size_t)b * dst_stride + (size_t)y * dst_pitch + x);
+    if (x >= w) { *o = 0u; return; }
     const uint8_t* p = src + (size_t)b * simg + (size_t)y * sstride + (size_t)x * C;
-    const int r = p[ridx], g = p[1], bl = p[2 - ridx];
-    *o = (uint8_t)((r * ry + g * gy + bl * by + (1 << (shift - 1))) >> shift);
+    const int half = 1 << (shift - 1);
+    uint32_t out = 0;
+    if (x + 4 <= w) {
+        uint32_t d[4];
+        d[0] = load_u32_any(p); d[1] = load_u32_any(p + 4); d[2] = load_u32_any(p + 8); d[3] = C == 4 ? load_u32_any(p + 12) : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            // channel c of pixel j is byte j * C + c of the 12 / 16 loaded bytes
+            auto byte_at = [&](int k) { return (int)((d[k >> 2] >> (8 * (k & 3))) & 0xFFu); };
+            int r, g, bl;
+            if (C == 4) { const uint32_t q = d[j]; r = (int)((q >> (8 * ridx)) & 0xFFu); g = (int)((q >> 8) & 0xFFu); bl = (int)((q >> (8 * (2 - ridx))) & 0xFFu); }
+            else { r = byte_at(3 * j + ridx); g = byte_at(3 * j + 1); bl = byte_at(3 * j + 2 - ridx); }
+            out |= (uint32_t)((mul24(r, ry) + mul24(g, gy) + mul24(bl, by) + half) >> shift) << (8 * j);
+        }
+    } else {                                                    // the row's last, partial group: pixel by pixel, zeros behind the width
+        for (int j = 0; j < 4 && x + j < w; j++) {
+            const uint8_t* q = p + j * C;
+            out |= (uint32_t)(((int)q[ridx] * ry + (int)q[1] * gy + (int)q[2 - ridx] * by + half) >> shift) << (8 * j);
+        }
+    }
+    *o = out;
 }
 
 }  // namespace orbx

@@ -303,7 +303,7 @@ void enqueue_input(orbx_extractor* h, int B, const uint8_t* d_images, int sw, in
     }
     // cv::cvtColor 8U: OpenCV 4.x (RY15, GY15, BY15, 15) or 3.x (R2Y, G2Y, B2Y, yuv_shift = 14)
     const int ry = h->in_gray_variant ? 4899 : 9798, gy = h->in_gray_variant ? 9617 : 19235, by = h->in_gray_variant ? 1868 : 3735;
-    dim3 grid((L0.pitch + 63) / 64, (L0.h + 3) / 4, B);
+    dim3 grid((L0.pitch + 255) / 256, (L0.h + 3) / 4, B);      // four pixels per thread
     ORBX_LAUNCH(k_input_gray, grid, blk2, 0, h->s0, cur, cur_stride, cur_img, C, h->in_rgb ? 0 : 2, ry, gy, by, h->in_gray_variant ? 14 : 15, L0.w, L0.h,
                 lvl0, L0.pitch, h->pyr_stride);
 }

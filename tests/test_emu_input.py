@@ -79,6 +79,12 @@ def test_input_prestep_emulated(emu_lib):
     run(emu_lib, 480, 360, 500)
 
 
+def test_input_prestep_odd_width_emulated(emu_lib):
+    """widths that are no multiple of 4 and rows that are no multiple of 4 bytes (3 x 483): k_input_gray converts four pixels per thread from
+    dword loads at arbitrary byte addresses and handles the row's last, partial group pixel by pixel"""
+    run(emu_lib, 483, 361, 500)
+
+
 def test_grey_weights_sum_and_remap_table_quirk():
     """The kernel uses the exact weight 32768 where OpenCV's table holds (32767, 0, 0, 1): both give the same byte for every pair."""
     p = np.arange(256)
