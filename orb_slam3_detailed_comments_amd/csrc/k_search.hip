@@ -459,6 +459,10 @@ __global__ void __launch_bounds__(256) k_area_search_threads(const AreaQuery* __
                                                              int qdesc_per_frame) {
     __shared__ int s_scan[20];
     __shared__ int s_base;
+    // the first kAreaKeep accepted keypoints of every query (index | octave << 16), [slot][thread]: the second pass - Hamming distances and the
+    // writes - then reads them back instead of walking the window, its cells, keypoint records and gates again (round 4; most queries accept fewer)
+    constexpr int kAreaKeep = 12;
+    __shared__ uint32_t s_keep[kAreaKeep * 256];
     const size_t b = blockIdx.y;
     const int q = (int)(blockIdx.x * 256 + threadIdx.x);
     queries += b * (size_t)Q; q_start += b * (size_t)Q; q_count += b * (size_t)Q;
@@ -480,7 +484,10 @@ __global__ void __launch_bounds__(256) k_area_search_threads(const AreaQuery* __
             for (int j = s; j < e; j++) {
                 const int idx = cell_items[j];
                 const KeyPointRec k = kps[idx];
-                cnt += (area_accept(A, k, idx, check_levels, gate_right, u_right) && (A.gate != 2 || chi2_accept(A, k, u_right[idx], g))) ? 1 : 0;
+                if (area_accept(A, k, idx, check_levels, gate_right, u_right) && (A.gate != 2 || chi2_accept(A, k, u_right[idx], g))) {
+                    if (cnt < kAreaKeep) s_keep[cnt * 256 + (int)threadIdx.x] = (uint32_t)idx | ((uint32_t)k.octave << 16);
+                    cnt++;
+                }
             }
         }
     }
@@ -494,6 +501,16 @@ __global__ void __launch_bounds__(256) k_area_search_threads(const AreaQuery* __
         const unsigned long long* dq = qdesc + 4 * (size_t)q;
         const unsigned long long d0 = dq[0], d1 = dq[1], d2 = dq[2], d3 = dq[3];
         int pos = start;
+        if (cnt <= kAreaKeep) {
+            for (int i = 0; i < cnt; i++) {
+                const uint32_t e = s_keep[i * 256 + (int)threadIdx.x];
+                const int idx = (int)(e & 0xFFFFu);
+                const unsigned long long* df = fdesc + 4 * (size_t)idx;
+                const int dist = __popcll(d0 ^ df[0]) + __popcll(d1 ^ df[1]) + __popcll(d2 ^ df[2]) + __popcll(d3 ^ df[3]);
+                int2 ent; ent.x = idx; ent.y = dist | (int)(e & 0xFFFF0000u);
+                entries[pos++] = ent;
+            }
+        } else
         for (int ix = nMinX; ix <= nMaxX; ix++) {
             const int s = cell_start[ix * kGridRows + nMinY], e = cell_start[ix * kGridRows + nMaxY + 1];
             for (int j = s; j < e; j++) {
