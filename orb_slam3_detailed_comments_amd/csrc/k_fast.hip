@@ -24,6 +24,7 @@
 #include "orbx_block.h"
 #include "orbx_kernels.h"
 #include "orbx_simd.h"
+#include "blur_body.h"
 
 namespace orbx {
 
@@ -371,21 +372,18 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
 }
 
 // One single-wave workgroup per (cell, image).  slots: per-cell candidate lists in the reference order; cell_count[b * ncells + cell] =
-// number kept.  dynamic LDS = 16 + tile_bytes + score-tile bytes + list_bytes.
-__global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __restrict__ lv,
-                                                    const CellInfo* __restrict__ cells, int ncells,
-                                                    const uint8_t* __restrict__ pyr, size_t pyr_stride,
-                                                    int iniTh, int minTh,
-                                                    uint32_t* __restrict__ slots, size_t slots_stride,
-                                                    int* __restrict__ cell_count, int tile_bytes, int list_bytes, int* __restrict__ status) {
-    ORBX_DYN_SMEM(smem);
+// number kept.  dynamic LDS = 16 + tile_bytes + score-tile bytes + list_bytes.  bx = the workgroup's index among the FAST workgroups of its image.
+__device__ __forceinline__ void fast_block(int bx, const LevelInfo* __restrict__ lv, const CellInfo* __restrict__ cells, int ncells,
+                                           const uint8_t* __restrict__ pyr, size_t pyr_stride, int iniTh, int minTh,
+                                           uint32_t* __restrict__ slots, size_t slots_stride, int* __restrict__ cell_count, int tile_bytes, int list_bytes,
+                                           int* __restrict__ status, uint8_t* smem) {
     // the batch's status word (the quadtree's capacity flag) is cleared here, by the kernel in front of the quadtree, instead of by a fill launch
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) status[threadIdx.x] = 0;
+    if (bx == 0 && blockIdx.y == 0 && threadIdx.x < 4) status[threadIdx.x] = 0;
     // Workgroup -> cell mapping.  Consecutive workgroup ids go to different XCDs (id % 8), each with its own L2; with the plain mapping
     // (workgroup b -> cell b) neighbouring cells never share an L2 and the 6-pixel window overlap plus the dword / cache-line padding of
     // every window row is fetched again per cell.  Runs of kFastXcdRun neighbouring cells are therefore kept on one XCD
     // (run length 1 / 2 / 4 / 20: 305 / 186 / 131 / 80 MB fetched per 128 images; long runs skew the mix of dense and sparse cells per XCD).
-    const int bx = (int)blockIdx.x, xcd = bx & 7, jj = bx >> 3;
+    const int xcd = bx & 7, jj = bx >> 3;
     const int cell = ((jj / kFastXcdRun) * 8 + xcd) * kFastXcdRun + (jj % kFastXcdRun), b = (int)blockIdx.y;
     if (cell >= ncells) return;
     const CellInfo ci = cells[cell];
@@ -400,6 +398,33 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
     const int wpr = ((ci.x1 + 3 + 3) & ~3) - ((ci.x0 - 3) & ~3);
     if (wpr <= kFastPitch) fast_cell<kFastPitch>(ci, L, img, iniTh, minTh, out, count_out, smem, tile_bytes, list_bytes);
     else fast_cell<0>(ci, L, img, iniTh, minTh, out, count_out, smem, tile_bytes, list_bytes);
+}
+
+__global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __restrict__ lv,
+                                                    const CellInfo* __restrict__ cells, int ncells,
+                                                    const uint8_t* __restrict__ pyr, size_t pyr_stride,
+                                                    int iniTh, int minTh,
+                                                    uint32_t* __restrict__ slots, size_t slots_stride,
+                                                    int* __restrict__ cell_count, int tile_bytes, int list_bytes, int* __restrict__ status) {
+    ORBX_DYN_SMEM(smem);
+    fast_block((int)blockIdx.x, lv, cells, ncells, pyr, pyr_stride, iniTh, minTh, slots, slots_stride, cell_count, tile_bytes, list_bytes, status, smem);
+}
+
+// Small batches (one pair per call: Tracking's rhythm): the blur of the pyramid depends on the pyramid alone, like FAST, and at large batches
+// runs beside it on a second stream.  A fork and a join of two streams cost a kernel behind each of them ~6 us (barrier packets), 12 of the 166 us
+// of a stereo pair - so here the two share ONE launch instead: the first `blur_waves` single-wave workgroups of an image blur one strip each
+// (blur_body.h; no LDS, the launch's allocation goes unused), the others are the FAST cells.  Both halves are the kernels above, unchanged.
+__global__ void __launch_bounds__(kFastThreads) k_fast_cells_blur(const LevelInfo* __restrict__ lv,
+                                                    const CellInfo* __restrict__ cells, int ncells,
+                                                    const uint8_t* __restrict__ pyr, size_t pyr_stride,
+                                                    int iniTh, int minTh,
+                                                    uint32_t* __restrict__ slots, size_t slots_stride,
+                                                    int* __restrict__ cell_count, int tile_bytes, int list_bytes, int* __restrict__ status,
+                                                    int nlevels, uint8_t* __restrict__ blur, BlurTaps taps, BlurTiles tiles, int blur_waves) {
+    ORBX_DYN_SMEM(smem);
+    const int bx = (int)blockIdx.x;
+    if (bx < blur_waves) { blur_strip(lv, nlevels, pyr, blur, pyr_stride, taps, tiles, bx >> 2, bx & 3, (int)threadIdx.x, (int)blockIdx.y); return; }
+    fast_block(bx - blur_waves, lv, cells, ncells, pyr, pyr_stride, iniTh, minTh, slots, slots_stride, cell_count, tile_bytes, list_bytes, status, smem);
 }
 
 }  // namespace orbx

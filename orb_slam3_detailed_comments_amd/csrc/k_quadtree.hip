@@ -21,6 +21,7 @@
 #include "orbx_types.h"
 #include "orbx_block.h"
 #include "orbx_kernels.h"
+#include "layout_body.h"
 #include "libstdcxx_sort_model.h"
 
 namespace orbx {
@@ -510,32 +511,24 @@ __device__ __forceinline__ void presort_keys(const uint32_t* __restrict__ bufB, 
     }
 }
 
-// grid (B, nlevels), kQuadtreeThreads threads of which the first L.qt_threads (256 or 1024, by the size of the level) work on the level
-// and the rest exits at once.  Dynamic LDS: see carve below (host passes node_cap).
-__global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* __restrict__ lv,
-                                                  const CellInfo* __restrict__ cells, int ncells,
-                                                  const int* __restrict__ cell_count,
-                                                  const uint32_t* __restrict__ slots, size_t slots_stride,
-                                                  uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
-                                                  uint32_t* __restrict__ lvl_keys, int kp_total_cap,
-                                                  int* __restrict__ lvl_count, int nlevels, int node_cap, int nb_cap, int lut_x, int lut_y,
-                                                  int* __restrict__ status, long long* __restrict__ qt_prof, int wide, int counter_bytes) {
-    ORBX_DYN_SMEM(smem);
+// one tree: the keypoints of pyramid level `level` of image b (the body of k_quadtree; every thread of the workgroup's first NT threads runs it,
+// and all of them return from it together)
+__device__ __forceinline__ void quadtree_level(const LevelInfo& L, const int level, const int b, const int NT,
+                                               const CellInfo* __restrict__ cells, int ncells,
+                                               const int* __restrict__ cell_count,
+                                               const uint32_t* __restrict__ slots, size_t slots_stride,
+                                               uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
+                                               uint32_t* __restrict__ lvl_keys, int kp_total_cap,
+                                               int* __restrict__ lvl_count, int nlevels, int node_cap, int nb_cap, int lut_x, int lut_y,
+                                               int* __restrict__ status, long long* __restrict__ qt_prof, int counter_bytes, uint8_t* smem) {
     __shared__ unsigned long long s_scan[20];
     __shared__ int s_i[80];
     int* s_part = s_i;                                  // block_partition4: 4 counts per wave
     int* s_ndiv = s_i + 64;
     int* s_sortctr = s_i + 66;
     int* s_kinds = s_i + 68;                            // kinds of deep nodes met in the current pass (kDeepSmall | kDeepBig)
-    // grid (B, nlevels): workgroups are dispatched image-fastest, i.e. every image's level 0 (the longest tree by far) starts first and the
-    // short trees of the small levels fill the remaining slots
-    const int level = (int)blockIdx.y, b = (int)blockIdx.x;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const LevelInfo L = lv[level];
-    // wide: the large levels get L.qt_threads threads (small batches: the latency of one tree is what counts); otherwise every level runs on
-    // four waves, which packs more trees on a CU (large batches)
-    const int NT = wide ? L.qt_threads : 256, NW = NT >> 6, lgNW = NT == 256 ? 2 : NT == 512 ? 3 : 4;
-    if (tid >= NT) return;
+    const int NW = NT >> 6, lgNW = NT == 256 ? 2 : NT == 512 ? 3 : 4;
     const int N = L.quota;
 #ifdef ORBX_EMU
 #define QT_STAMP(i)
@@ -980,6 +973,43 @@ __global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* 
     }
     if (tid == 0) lvl_count[(size_t)b * nlevels + level] = nnodes;
     QT_STAMP(9)
+}
+
+// grid (B, nlevels), kQuadtreeThreads threads of which the first L.qt_threads (256 or 1024, by the size of the level) work on the level
+// and the rest exits at once.  Dynamic LDS: see the carve in quadtree_level (host passes node_cap).  Workgroups are dispatched image-fastest,
+// i.e. every image's level 0 (the longest tree by far) starts first and the short trees of the small levels fill the remaining slots.
+// done != nullptr (small batches): the workgroup that finishes the LAST tree of an image also runs k_layout's body for that image (layout_body.h) -
+// one launch less in a chain that is launch-latency bound at one pair per call.  Every workgroup publishes its level (device-scope fence), then
+// draws a ticket from the image's counter; the one that draws nlevels - 1 sees all the others' keys and counts.  The counters are zero before
+// the first launch and are left zero.
+__global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* __restrict__ lv,
+                                                  const CellInfo* __restrict__ cells, int ncells,
+                                                  const int* __restrict__ cell_count,
+                                                  const uint32_t* __restrict__ slots, size_t slots_stride,
+                                                  uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
+                                                  uint32_t* __restrict__ lvl_keys, int kp_total_cap,
+                                                  int* __restrict__ lvl_count, int nlevels, int node_cap, int nb_cap, int lut_x, int lut_y,
+                                                  int* __restrict__ status, long long* __restrict__ qt_prof, int wide, int counter_bytes,
+                                                  int* __restrict__ done, LayoutArgs LA) {
+    ORBX_DYN_SMEM(smem);
+    const int level = (int)blockIdx.y, b = (int)blockIdx.x;
+    const LevelInfo L = lv[level];
+    // wide: the large levels get L.qt_threads threads (small batches: the latency of one tree is what counts); otherwise every level runs on
+    // four waves, which packs more trees on a CU (large batches)
+    const int NT = wide ? L.qt_threads : 256;
+    if ((int)threadIdx.x >= NT) return;
+    quadtree_level(L, level, b, NT, cells, ncells, cell_count, slots, slots_stride, candA, candB, cand_stride, lvl_keys, kp_total_cap, lvl_count, nlevels,
+                   node_cap, nb_cap, lut_x, lut_y, status, qt_prof, counter_bytes, smem);
+    if (done == nullptr) return;
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&done[b], 1) == nlevels - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x == 0) done[b] = 0;
+    layout_body(lv, nlevels, lvl_keys, kp_total_cap, lvl_count, LA.lap0, LA.lap1, LA.final_idx, LA.n_out, LA.mono_out, LA.nb, LA.row_start, LA.row_items, b, NT, smem);
 }
 
 }  // namespace orbx

@@ -267,9 +267,10 @@ int configure(orbx_extractor* h, int W, int H, int B) {
         e |= h->d_uRight.ensure(b * cap); e |= h->d_depth.ensure(b * cap); e |= h->d_sad.ensure(b * cap); e |= h->d_nmatch.ensure(b);
         e |= h->d_rowstart.ensure(b * (size_t)((h->H >> kStereoRowShift) + 3)); e |= h->d_rowitems.ensure(b * cap);
         e |= h->d_knn.ensure(4 * b * cap); e |= h->d_ratio.ensure(b * cap);
-        e |= h->h_nm.ensure(3 * b + 4); e |= h->d_qtprof.ensure(32);
+        e |= h->h_nm.ensure(3 * b + 4); e |= h->d_qtprof.ensure(32); e |= h->d_qt_done.ensure(b);
         if (e) return fail(ORBX_E_DEVICE, "device allocation failed (batch %d of %dx%d)", B, W, H);
         rt::memset_async(h->d_status.p, 0, 4 * sizeof(int), h->s0);
+        rt::memset_async(h->d_qt_done.p, 0, b * sizeof(int), h->s0);          // k_quadtree's tickets: zero between launches
         rt::memset_async(h->d_pyr.p, 0, b * h->pyr_stride + 256, h->s0);     // defined row padding for frames written in place (orbx_input_buffer)
         h->maxB = B;
     }
@@ -323,7 +324,10 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
         ORBX_LAUNCH(k_import, grid, blk2, 0, h->s0, (const LevelInfo*)h->d_lv.p, d_images, stride, image_stride, h->d_pyr.p, h->pyr_stride);
     }
     stage_end(h, ST_IMPORT, h->s0);
-    rt::event_record(h->ev_import, h->s0);                          // the input images have been consumed
+    // the input images have been consumed: an upload into the caller's buffer may start (orbx_device_upload_async).  Large batches record it here
+    // (the upload of batch i + 1 overlaps the rest of batch i); small ones on demand (orbx_internal.h: a record costs the next kernel ~6 us)
+    if (B > ORBX_QT_WIDE_BATCH) { rt::event_record(h->ev_import, h->s0); h->import_lazy = false; }
+    else h->import_lazy = true;
     stage_begin(h, ST_PYRAMID, h->s0);
     // small batches: every level in one launch (a chain of dependent launches costs 4.5 us per level whatever the work); large batches:
     // the streaming kernel per level (a third of the instructions per pixel, and its launches hide behind the other handles' kernels)
@@ -354,34 +358,51 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
                     (const ResizeTap*)h->d_ytab.p, h->d_pyr.p, h->pyr_stride, lds_pitch, lds_rows);
     }
     stage_end(h, ST_PYRAMID, h->s0);
-    // fork: the blur only depends on the pyramid and runs beside FAST + quadtree on the second stream
-    rt::stream_t sb = h->serial ? h->s0 : h->s1;    // serial profiling mode keeps every kernel on one stream
-    rt::event_record(h->ev_fork, h->s0);
-    rt::stream_wait_event(sb, h->ev_fork);
-    stage_begin(h, ST_BLUR, sb);
+    BlurTaps taps;
     {
-        BlurTaps taps;
         static const int A[7] = {18, 34, 48, 56, 48, 34, 18}, Bt[7] = {18, 34, 49, 55, 49, 34, 18};
         for (int i = 0; i < 7; i++) taps.k[i] = h->gauss_variant == 1 ? Bt[i] : A[i];
-        BlurTiles tiles; int nt = 0;
-        for (int l = 0; l < nl; l++) { tiles.begin[l] = nt; nt += ((h->lv[l].w + 255) / 256) * ((h->lv[l].h + 4 * kBlurRows - 1) / (4 * kBlurRows)); }
-        for (int l = nl; l <= kMaxLevels; l++) tiles.begin[l] = nt;
-        dim3 grid(nt, B, 1);
-        ORBX_LAUNCH(k_blur, grid, blk2, 0, sb, (const LevelInfo*)h->d_lv.p, nl, (const uint8_t*)h->d_pyr.p, h->d_blur.p, h->pyr_stride, taps, tiles);
     }
-    stage_end(h, ST_BLUR, sb);
-    rt::event_record(h->ev_join, sb);
-    stage_begin(h, ST_FAST, h->s0);
-    {
-        dim3 grid((h->ncells + 8 * kFastXcdRun - 1) / (8 * kFastXcdRun) * (8 * kFastXcdRun), B, 1), blkf(kFastThreadsDecl, 1, 1);   // whole XCD runs (k_fast_cells)
-        // pad | window tile | score tile | u16 list: corners found so far + pending survivors of the quick test (scored whenever it fills up)
-        const int list_bytes = ORBX_FAST_LIST_BYTES;
-        const size_t smem = 16 + (size_t)h->fast_tile_bytes + (size_t)h->fast_inner_bytes + (size_t)list_bytes + 64;
-        ORBX_LAUNCH(k_fast_cells, grid, blkf, smem, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
+    BlurTiles tiles; int nt = 0;
+    for (int l = 0; l < nl; l++) { tiles.begin[l] = nt; nt += ((h->lv[l].w + 255) / 256) * ((h->lv[l].h + 4 * kBlurRows - 1) / (4 * kBlurRows)); }
+    for (int l = nl; l <= kMaxLevels; l++) tiles.begin[l] = nt;
+    const int fast_blocks = (h->ncells + 8 * kFastXcdRun - 1) / (8 * kFastXcdRun) * (8 * kFastXcdRun);   // whole XCD runs (k_fast_cells)
+    // pad | window tile | score tile | u16 list: corners found so far + pending survivors of the quick test (scored whenever it fills up)
+    const int list_bytes = ORBX_FAST_LIST_BYTES;
+    const size_t fast_smem = 16 + (size_t)h->fast_tile_bytes + (size_t)h->fast_inner_bytes + (size_t)list_bytes + 64;
+    const dim3 blkf(kFastThreadsDecl, 1, 1);
+    // small batches: blur and FAST in one launch on one stream (k_fast_cells_blur: no fork / join).  The stage timers of the profiling modes keep
+    // the two apart, so those run the large-batch form
+    const bool small_forms = B <= ORBX_QT_WIDE_BATCH && !h->profile && !h->serial;
+    const bool one_launch = small_forms && (h->small_forms & 1), layout_in_tree = small_forms && (h->small_forms & 2);
+    if (one_launch) {
+        dim3 grid(4 * nt + fast_blocks, B, 1);
+        ORBX_LAUNCH(k_fast_cells_blur, grid, blkf, fast_smem, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
                     (const uint8_t*)h->d_pyr.p, h->pyr_stride, h->iniTh, h->minTh, h->d_slots.p, h->cand_stride, h->d_cell_count.p,
-                    h->fast_tile_bytes, list_bytes, h->d_status.p);
+                    h->fast_tile_bytes, list_bytes, h->d_status.p, nl, h->d_blur.p, taps, tiles, 4 * nt);
+    } else {
+        // fork: the blur only depends on the pyramid and runs beside FAST + quadtree on the second stream
+        rt::stream_t sb = h->serial ? h->s0 : h->s1;    // serial profiling mode keeps every kernel on one stream
+        rt::event_record(h->ev_fork, h->s0);
+        rt::stream_wait_event(sb, h->ev_fork);
+        stage_begin(h, ST_BLUR, sb);
+        {
+            dim3 grid(nt, B, 1);
+            ORBX_LAUNCH(k_blur, grid, blk2, 0, sb, (const LevelInfo*)h->d_lv.p, nl, (const uint8_t*)h->d_pyr.p, h->d_blur.p, h->pyr_stride, taps, tiles);
+        }
+        stage_end(h, ST_BLUR, sb);
+        rt::event_record(h->ev_join, sb);
+        stage_begin(h, ST_FAST, h->s0);
+        {
+            dim3 grid(fast_blocks, B, 1);
+            ORBX_LAUNCH(k_fast_cells, grid, blkf, fast_smem, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
+                        (const uint8_t*)h->d_pyr.p, h->pyr_stride, h->iniTh, h->minTh, h->d_slots.p, h->cand_stride, h->d_cell_count.p,
+                        h->fast_tile_bytes, list_bytes, h->d_status.p);
+        }
     }
     stage_end(h, ST_FAST, h->s0);
+    // (+ the row index of every image's keypoints for ComputeStereoMatches: k_stereo_match reads the right image's)
+    const int nb_rows = (h->H >> kStereoRowShift) + 2;
     stage_begin(h, ST_QUADTREE, h->s0);
     {
         dim3 grid(B, nl, 1);
@@ -391,26 +412,28 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
         int qt_block = 256;
         if (B <= ORBX_QT_WIDE_BATCH) for (int l = 0; l < nl; l++) qt_block = std::max(qt_block, h->lv[l].qt_threads);
         const int wide = qt_block > 256, counter_bytes = wide ? 32 : 16;
-        const size_t smem = (size_t)h->node_cap * 81 + (size_t)(h->nb_cap + 2) * 4 + (size_t)counter_bytes * h->nb_cap + 2 * (size_t)(lut_x + lut_y) + 64;
+        const size_t smem = std::max((size_t)h->node_cap * 81 + (size_t)(h->nb_cap + 2) * 4 + (size_t)counter_bytes * h->nb_cap + 2 * (size_t)(lut_x + lut_y) + 64,
+                                     2 * (size_t)(nb_rows + 1) * sizeof(int));
         const dim3 blkq(qt_block, 1, 1);
         if (smem + 2048 > rt::lds_limit(h->device))
             return fail(ORBX_E_CAPACITY, "nfeatures %d at %dx%d needs %zu bytes of LDS per quadtree workgroup, the device allows %zu", h->nfeatures, h->W, h->H, smem + 2048, rt::lds_limit(h->device));
+        // small batches: the last tree of an image to finish lays out the image's keypoints (k_layout's body; its row index lives in the tree's LDS)
+        LayoutArgs LA = {lap0, lap1, nb_rows, h->d_final_idx.p, h->d_nm.p, h->d_nm.p + h->maxB, h->d_rowstart.p, h->d_rowitems.p};
         ORBX_LAUNCH(k_quadtree, grid, blkq, smem, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
                     (const int*)h->d_cell_count.p, (const uint32_t*)h->d_slots.p, h->cand_stride, h->d_candA.p, h->d_candB.p, h->cand_stride,
                     h->d_lvl_keys.p, h->kp_total_cap, h->d_lvl_count.p, nl, h->node_cap, h->nb_cap, lut_x, lut_y, h->d_status.p,
-                    h->serial ? (long long*)h->d_qtprof.p : (long long*)nullptr, wide, counter_bytes);
+                    h->serial ? (long long*)h->d_qtprof.p : (long long*)nullptr, wide, counter_bytes,
+                    layout_in_tree ? h->d_qt_done.p : (int*)nullptr, LA);
     }
     stage_end(h, ST_QUADTREE, h->s0);
     stage_begin(h, ST_LAYOUT, h->s0);
-    {
+    if (!layout_in_tree) {
         dim3 grid(B, 1, 1);
-        // (+ the row index of every image's keypoints for ComputeStereoMatches: k_stereo_match reads the right image's)
-        const int nb = (h->H >> kStereoRowShift) + 2;
-        ORBX_LAUNCH(k_layout, grid, blk1, 2 * (size_t)(nb + 1) * sizeof(int), h->s0, (const LevelInfo*)h->d_lv.p, nl, (const uint32_t*)h->d_lvl_keys.p, h->kp_total_cap,
-                    (const int*)h->d_lvl_count.p, lap0, lap1, h->d_final_idx.p, h->d_nm.p, h->d_nm.p + h->maxB, nb, h->d_rowstart.p, h->d_rowitems.p);
+        ORBX_LAUNCH(k_layout, grid, blk1, 2 * (size_t)(nb_rows + 1) * sizeof(int), h->s0, (const LevelInfo*)h->d_lv.p, nl, (const uint32_t*)h->d_lvl_keys.p, h->kp_total_cap,
+                    (const int*)h->d_lvl_count.p, lap0, lap1, h->d_final_idx.p, h->d_nm.p, h->d_nm.p + h->maxB, nb_rows, h->d_rowstart.p, h->d_rowitems.p);
     }
     stage_end(h, ST_LAYOUT, h->s0);
-    rt::stream_wait_event(h->s0, h->ev_join);
+    if (!one_launch) rt::stream_wait_event(h->s0, h->ev_join);
     stage_begin(h, ST_DESCRIBE, h->s0);
     {
         const bool small = B <= ORBX_QT_WIDE_BATCH;                 // latency-tuned variant: 2 keypoints per wave instead of 8
@@ -429,7 +452,7 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
         ORBX_LAUNCH(k_undistort, grid, blk1, 0, h->s0, (const KeyPointRec*)h->d_kps.p, (const int*)h->d_nm.p, h->kp_total_cap, h->undist, h->d_kps_un.p);
     }
     stage_end(h, ST_DESCRIBE, h->s0);
-    rt::event_record(h->ev_done, h->s0);
+    h->done_lazy = true;                                            // ev_done: recorded by whoever waits for it (record_done_if_pending)
     h->lastB = B; h->ex_undist_gen = h->undist_gen; h->ex_undist_active = h->undist.active != 0;
     if (rt::check_launch()) return fail(ORBX_E_DEVICE, "kernel launch failed: %s", rt::last_error());
     return ORBX_OK;
@@ -477,7 +500,7 @@ void orbx_destroy(orbx_extractor* h) {
         rt::stream_destroy(h->s0); rt::stream_destroy(h->s1); rt::stream_destroy(h->s_copy);
     }
     h->d_lv.release(); h->d_cells.release(); h->d_xtab.release(); h->d_ytab.release(); h->d_xspan.release(); h->d_yspan.release(); h->d_pyr.release(); h->d_blur.release(); h->d_stage.release();
-    h->d_slots.release(); h->d_candA.release(); h->d_candB.release(); h->d_lvl_keys.release(); h->d_cell_count.release(); h->d_lvl_count.release();
+    h->d_slots.release(); h->d_candA.release(); h->d_candB.release(); h->d_lvl_keys.release(); h->d_cell_count.release(); h->d_lvl_count.release(); h->d_qt_done.release();
     h->d_final_idx.release(); h->d_status.p = nullptr; h->d_status.n = 0; h->d_nm.release(); h->d_kps.release(); h->d_desc.release();
     h->d_uRight.release(); h->d_depth.release(); h->d_sad.release(); h->d_nmatch.release(); h->d_knn.release(); h->d_ratio.release();
     h->d_l2r.release(); h->d_r2l.release(); h->d_p3d.release(); h->d_hamA.release(); h->d_hamB.release(); h->d_hamOut.release(); h->h_stage.release(); h->h_nm.release();
@@ -558,7 +581,7 @@ int orbx_extract_batch(orbx_extractor* h, int B, const uint8_t* images, int widt
     // is baked into the kernel arguments and re-captured when any of it changes.
     if (h->use_graph && !h->profile && !h->in_active) {
         const bool same = h->graph_exec && h->g_B == B && h->g_images == d_images && h->g_stride == stride && h->g_image_stride == image_stride &&
-                          h->g_lap0 == lap0 && h->g_lap1 == lap1 && h->g_W == h->W && h->g_H == h->H && h->g_pyr == h->d_pyr.p && h->g_gauss == h->gauss_variant && h->g_undist_gen == h->undist_gen && h->g_pyramid_mode == h->pyramid_mode;
+                          h->g_lap0 == lap0 && h->g_lap1 == lap1 && h->g_W == h->W && h->g_H == h->H && h->g_pyr == h->d_pyr.p && h->g_gauss == h->gauss_variant && h->g_undist_gen == h->undist_gen && h->g_pyramid_mode == h->pyramid_mode && h->g_small_forms == h->small_forms;
         if (!same) {
             if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
             if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
@@ -570,13 +593,12 @@ int orbx_extract_batch(orbx_extractor* h, int B, const uint8_t* images, int widt
                 return fail(ORBX_E_DEVICE, "graph capture/instantiate failed: %s", rt::last_error());
             }
             h->g_B = B; h->g_images = d_images; h->g_stride = stride; h->g_image_stride = image_stride; h->g_lap0 = lap0; h->g_lap1 = lap1;
-            h->g_W = h->W; h->g_H = h->H; h->g_pyr = h->d_pyr.p; h->g_gauss = h->gauss_variant; h->g_undist_gen = h->undist_gen; h->g_pyramid_mode = h->pyramid_mode;
+            h->g_W = h->W; h->g_H = h->H; h->g_pyr = h->d_pyr.p; h->g_gauss = h->gauss_variant; h->g_undist_gen = h->undist_gen; h->g_pyramid_mode = h->pyramid_mode; h->g_small_forms = h->small_forms;
         }
         if (hipGraphLaunch(h->graph_exec, h->s0) != hipSuccess) return fail(ORBX_E_DEVICE, "graph launch failed: %s", rt::last_error());
         // the records inside the capture belong to the graph; these are the ones other streams can wait on (an upload into the input buffer
         // waits for ev_import: after a replay that is the end of the whole graph, which is later than needed but never too early)
-        rt::event_record(h->ev_import, h->s0);
-        rt::event_record(h->ev_done, h->s0);
+        h->import_lazy = true; h->done_lazy = true;
         h->lastB = B; h->ex_undist_gen = h->undist_gen; h->ex_undist_active = h->undist.active != 0;
         return ORBX_OK;
     }
@@ -701,6 +723,7 @@ int orbx_device_upload(orbx_extractor* h, void* dptr, const void* host, size_t b
 int orbx_device_upload_async(orbx_extractor* h, void* dptr, const void* host, size_t bytes) {
     if (!h || !dptr || !host) return fail(ORBX_E_ARG, "null");
     rt::set_device(h->device);
+    record_import_if_pending(h);
     if (h->lastB > 0 && rt::stream_wait_event(h->s_copy, h->ev_import)) return fail(ORBX_E_DEVICE, "upload could not be ordered behind the previous extraction: %s", rt::last_error());
     if (rt::copy_h2d(dptr, host, bytes, h->s_copy) || rt::event_record(h->ev_copy, h->s_copy)) return fail(ORBX_E_DEVICE, "upload failed: %s", rt::last_error());
     h->copy_pending = true;
@@ -827,6 +850,12 @@ int orbx_set_pyramid_mode(orbx_extractor* h, int mode) {
     return ORBX_OK;
 }
 
+int orbx_set_small_batch_forms(orbx_extractor* h, int forms) {
+    if (!h || forms < 0 || forms > 3) return fail(ORBX_E_ARG, "small-batch forms: a mask of bits 0 (blur + FAST in one launch) and 1 (layout inside the quadtree launch)");
+    h->small_forms = forms;
+    return ORBX_OK;
+}
+
 int orbx_set_graph_replay(orbx_extractor* h, int on) { if (!h) return ORBX_E_ARG; h->use_graph = on != 0; return ORBX_OK; }
 
 int orbx_profile_enable(orbx_extractor* h, int on) { if (!h) return ORBX_E_ARG; h->profile = on != 0; h->serial = on == 2; return ORBX_OK; }
@@ -895,7 +924,7 @@ static int check_pair(orbx_extractor* L, int lf, orbx_extractor* R, int rf, int 
 int orbm_stereo_match(orbx_extractor* L, int lf, orbx_extractor* R, int rf, int B, float bf, float bl) {
     int rc = check_pair(L, lf, R, rf, B); if (rc) return rc;
     rt::set_device(L->device);
-    if (L != R) rt::stream_wait_event(L->s0, R->ev_done);
+    if (L != R) { record_done_if_pending(R); rt::stream_wait_event(L->s0, R->ev_done); }
     const int cap = L->kp_total_cap;
     StereoParams P; P.mbf = bf; P.mb = bl; P.th_high = 100; P.th_orb = (100 + 50) / 2;   // ORBmatcher::TH_HIGH/TH_LOW, src/ORBmatcher.cc:35-36
     P.debug_flags = L->debug_stereo_flags;
@@ -944,7 +973,7 @@ int orbm_stereo_fetch(orbx_extractor* L, int B, float* uRight, float* depth, int
 int orbm_knn2(orbx_extractor* L, int lf, orbx_extractor* R, int rf, int B) {
     int rc = check_pair(L, lf, R, rf, B); if (rc) return rc;
     rt::set_device(L->device);
-    if (L != R) rt::stream_wait_event(L->s0, R->ev_done);
+    if (L != R) { record_done_if_pending(R); rt::stream_wait_event(L->s0, R->ev_done); }
     const int cap = L->kp_total_cap; const size_t bc = (size_t)L->maxB * cap;
     if (L->profile) rt::event_record(L->ev_stage[ST_MATCH][0], L->s0);
     const dim3 blk(256, 1, 1);

@@ -67,6 +67,8 @@ struct orbx_extractor {
     int pyr_ntx = 0, pyr_nty = 0, pyr_buf_a = 0, pyr_buf_b = 0;
     orbx::PyrTapOffsets pyr_toff = {};
     bool pyr_fused_ok = false;
+    int small_forms = 3, g_small_forms = 3;         // orbx_set_small_batch_forms: bit 0 blur + FAST in one launch, bit 1 layout at the end of the quadtree launch (batches <= 32)
+    orbx::DevBuf<int> d_qt_done;                    // per image: trees of the current quadtree launch that have finished (bit 1; zero between launches)
     int pyramid_mode = 0, g_pyramid_mode = 0;       // orbx_set_pyramid_mode: 0 = by batch size, 1 = one launch per level, 2 = one launch
     size_t pyr_stride = 0, cand_stride = 0;
     int ncells = 0, kp_total_cap = 0, node_cap = 0, nb_cap = 1, fast_tile_bytes = 0, fast_inner_bytes = 0;
@@ -86,6 +88,10 @@ struct orbx_extractor {
     orbx::rt::stream_t s0 = 0, s1 = 0, s_copy = 0;          // s_copy: orbx_device_upload_async (input uploads beside the kernels of the previous batch)
     orbx::rt::event_t ev_fork = 0, ev_join = 0, ev_done = 0, ev_copy = 0, ev_import = 0;
     bool copy_pending = false;
+    // ev_done / ev_import are recorded when somebody is about to wait for them (another handle's stereo search, an input upload on s_copy), not
+    // after every extraction: a record in the middle of a stream is a barrier packet, and the kernel behind it starts ~6 us later - a third of a
+    // FAST launch at one pair per call.  Recorded late they cover more of the stream than needed, never less.
+    bool done_lazy = false, import_lazy = false;
     orbx::rt::event_t ev_stage[ORBX_NSTAGES][2];
     bool profile = false, serial = false, have_streams = false;
     int lastB = 0;
@@ -120,4 +126,6 @@ struct orbx_extractor {
     orbx::DevBuf<int> d_aux;     // int4 per keypoint: stereo row band / x / octave (k_orient_brief -> k_stereo_match)
 };
 // mvKeysUn of the last extraction no longer matches the undistortion model of the handle (orbx_set_undistort was called in between)
+inline void record_done_if_pending(orbx_extractor* h) { if (h->done_lazy) { orbx::rt::event_record(h->ev_done, h->s0); h->done_lazy = false; } }
+inline void record_import_if_pending(orbx_extractor* h) { if (h->import_lazy) { orbx::rt::event_record(h->ev_import, h->s0); h->import_lazy = false; } }
 inline bool undistort_stale(const orbx_extractor* h) { return h->lastB > 0 && h->ex_undist_gen != h->undist_gen; }

@@ -44,12 +44,18 @@ __global__ void k_simd_selftest(const uint32_t* __restrict__ a, const uint32_t* 
 __global__ void k_blur(const LevelInfo* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,
                        uint8_t* __restrict__ blur, size_t pyr_stride, BlurTaps taps, BlurTiles tiles);
 constexpr int kQuadtreeThreads = 1024; // workgroup size of k_quadtree; a level uses its first LevelInfo::qt_threads threads
+// small batches: the blur strips and the FAST cells of an image in one launch (k_fast.hip)
+__global__ void k_fast_cells_blur(const LevelInfo* __restrict__ lv, const CellInfo* __restrict__ cells, int ncells,
+                                  const uint8_t* __restrict__ pyr, size_t pyr_stride, int iniTh, int minTh,
+                                  uint32_t* __restrict__ slots, size_t slots_stride, int* __restrict__ cell_count,
+                                  int tile_bytes, int list_bytes, int* __restrict__ status,
+                                  int nlevels, uint8_t* __restrict__ blur, BlurTaps taps, BlurTiles tiles, int blur_waves);
 __global__ void k_quadtree(const LevelInfo* __restrict__ lv, const CellInfo* __restrict__ cells, int ncells,
                            const int* __restrict__ cell_count, const uint32_t* __restrict__ slots, size_t slots_stride,
                            uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
                            uint32_t* __restrict__ lvl_keys, int kp_total_cap, int* __restrict__ lvl_count,
                            int nlevels, int node_cap, int nb_cap, int lut_x, int lut_y, int* __restrict__ status, long long* __restrict__ qt_prof,
-                           int wide, int counter_bytes);
+                           int wide, int counter_bytes, int* __restrict__ done, LayoutArgs LA);
 __global__ void k_layout(const LevelInfo* __restrict__ lv, int nlevels, const uint32_t* __restrict__ lvl_keys,
                          int kp_total_cap, const int* __restrict__ lvl_count, int lap0, int lap1,
                          int* __restrict__ final_idx, int* __restrict__ n_out, int* __restrict__ mono_out,

@@ -284,6 +284,50 @@ def test_pyramid_one_launch_gpu(hip_lib):
     _pyramid_modes_case(hip_lib, [(752, 480, 1.2, 8, 2), (301, 277, 1.2, 8, 3), (644, 400, 2.0, 3, 1), (1241, 376, 1.2, 8, 1), (1001, 841, 1.2, 11, 1), (263, 251, 1.5, 2, 5), (1920, 1080, 1.2, 8, 1)])
 
 
+def _launch_forms_case(lib, shapes):
+    """the launch forms of small batches (blur strips + FAST cells in one launch on one stream; the keypoint layout by the workgroup that finishes
+    an image's last quadtree; no event records inside the chain: orbx_set_small_batch_forms) against the large-batch forms of the same kernels on the same images, and against the oracle: blurred pyramid,
+    keypoints, descriptors, stereo matches; then a second handle as the right camera (the left one waits for the right one's ev_done, which is
+    recorded on demand)"""
+    for (w, h, nf, pairs) in shapes:
+        Ls, Rs = zip(*[synth.stereo_pair(w, h, seed=500 + 3 * s + w, nrect=max(300, w * h // 200)) for s in range(pairs)])
+        batch = np.stack(list(Ls) + list(Rs))
+        out = {}
+        for on in (True, False, 1, 2):
+            ex = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib)
+            ex.set_small_batch_forms(on)
+            res = ex.extract_batch(batch)
+            u, d, n = M.ComputeStereoMatches(ex, ex, EUROC_BF, EUROC_B, 0, pairs, pairs)
+            out[on] = (res, u.copy(), d.copy(), n.copy(), [[ex.pyramid_level(l, b, blurred=True) for l in range(8)] for b in range(2 * pairs)])
+            ex.close()
+        for b in range(2 * pairs):
+            for form in (False, 1, 2):
+                assert _same(out[True][0][b], out[form][0][b]), (w, h, b, form)
+            o = ol.OracleExtractor(nf)
+            assert _same(out[True][0][b], o.extract(batch[b])), (w, h, b)
+            for l in range(8):
+                assert np.array_equal(out[True][4][b][l], out[False][4][b][l]) and np.array_equal(out[True][4][b][l], o.level_image(l, blurred=True)), (w, h, b, l)
+        for k in (1, 2, 3):
+            for form in (False, 1, 2):
+                assert out[True][k].tobytes() == out[form][k].tobytes(), (w, h, k, form)
+        assert out[True][3].min() > 20
+        # two handles: left and right extracted by different extractors, the stereo search of the left one waits for the right one
+        exL, exR = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib), ORBextractor(nf, 1.2, 8, 20, 7, lib=lib)
+        exL.extract_batch(np.stack(Ls)); exR.extract_batch(np.stack(Rs))
+        u2, d2, n2 = M.ComputeStereoMatches(exL, exR, EUROC_BF, EUROC_B, 0, 0, pairs)
+        assert u2.tobytes() == out[True][1].tobytes() and d2.tobytes() == out[True][2].tobytes() and n2.tobytes() == out[True][3].tobytes()
+        exL.close(); exR.close()
+
+
+def test_small_batch_launch_forms_emulated(emu_lib):
+    _launch_forms_case(emu_lib, [(376, 240, 500, 1), (301, 277, 300, 2)])
+
+
+@pytest.mark.gpu
+def test_small_batch_launch_forms_gpu(hip_lib):
+    _launch_forms_case(hip_lib, [(752, 480, 1200, 1), (376, 240, 500, 3), (1241, 376, 2000, 1), (640, 480, 1000, 16)])
+
+
 def _zero_rows_case(lib, w, h, nf):
     """descriptor rows beyond an image's keypoint count read as zero in the device-resident block, also when the handle's previous batch filled
     them (no fill launch in front of an extraction: k_orient_brief clears one row per unused keypoint slot).  The fetch with the device's own
