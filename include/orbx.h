@@ -169,12 +169,11 @@ int orbx_host_free(orbx_extractor* h, void* hptr);
  * either form (tests compare them).  The levels are bit-identical in every mode. */
 int orbx_set_pyramid_mode(orbx_extractor* h, int mode);
 
-/* Small batches (up to 32 images per call; one stereo pair per call is Tracking's rhythm) are launch-latency bound and run launch forms of
- * their own.  forms is a mask: bit 0 = the blur strips and the FAST cells in ONE launch on one stream (large batches: two launches on two
- * streams, i.e. a fork and a join of ~6 us each); bit 1 = the keypoint layout at the end of the quadtree launch, by the workgroup that
- * finishes an image's last tree, instead of a launch of its own.  Default 3; 0 = the large-batch forms at every batch size (tests compare
- * them: the outputs are bit-identical).  The profiling modes (orbx_profile_enable) time stages and always run the large-batch forms. */
-int orbx_set_small_batch_forms(orbx_extractor* h, int forms);
+/* Small batches (up to 32 images per call; one stereo pair per call is Tracking's rhythm) are launch-latency bound and run a launch form of
+ * their own: the blur strips and the FAST cells in ONE launch on one stream (large batches: two launches on two streams, i.e. a fork and a
+ * join of ~6 us each).  on = 1 (default) / 0 = the large-batch form at every batch size (tests compare them: the outputs are bit-identical).
+ * The profiling modes (orbx_profile_enable) time stages and always run the large-batch form. */
+int orbx_set_small_batch_forms(orbx_extractor* h, int on);
 
 /* Replay the extraction pipeline as one hipGraph (captured on first use, re-captured when the batch size, geometry, input
  * pointer or lapping area change).  Pays off at small batches, where the ~17 kernel launches are latency-bound. */

@@ -21,7 +21,6 @@
 #include "orbx_types.h"
 #include "orbx_block.h"
 #include "orbx_kernels.h"
-#include "layout_body.h"
 #include "libstdcxx_sort_model.h"
 
 namespace orbx {
@@ -408,10 +407,12 @@ __device__ __forceinline__ void presorted_child_counts(const QNode& nd, int D, c
     }
 }
 
-// position of a candidate in the reference's vToDistributeKeys: FAST cells row-major (:1097-1166), row-major inside a cell
-__device__ __forceinline__ unsigned long long vkeys_order(uint32_t key, int wcell, int hcell) {
+// position of a candidate in the reference's vToDistributeKeys: FAST cells row-major (:1097-1166), row-major inside a cell.
+// Mw, Mh = (1 << 20) / cell size + 1: v / d == (v * M) >> 20 exactly for v * d < 2^20 (coordinates < 4096, cells <= 240 px: orbx_api.cpp) - the
+// two integer divisions were most of the selection phase (a workgroup of 1024 threads pays ~7 ns per instruction per thread)
+__device__ __forceinline__ unsigned long long vkeys_order(uint32_t key, unsigned Mw, unsigned Mh) {
     const int x = key_x(key), y = key_y(key);
-    const unsigned long long ci = (unsigned long long)((y - 3) / hcell), cj = (unsigned long long)((x - 3) / wcell);
+    const unsigned long long ci = (unsigned long long)(((unsigned)(y - 3) * Mh) >> 20), cj = (unsigned long long)(((unsigned)(x - 3) * Mw) >> 20);
     return (ci << 36) | (cj << 24) | ((unsigned long long)y << 12) | (unsigned long long)x;
 }
 
@@ -471,8 +472,6 @@ __device__ __forceinline__ void presort_keys(const uint32_t* __restrict__ bufB, 
     const int beg = imin(n, wave * seg), end = wave < nseg ? imin(n, beg + seg) : beg;
     CT* mycount = counts + (wave < nseg ? wave : 0) * NB;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    int nbits = 0;
-    while ((1 << nbits) < NB) nbits++;
     __syncthreads();                                               // the histogram (counted by the gather) is complete
     // exclusive scan over buckets of the totals
     int run = 0;
@@ -489,16 +488,27 @@ __device__ __forceinline__ void presort_keys(const uint32_t* __restrict__ bufB, 
     if (tid == 0) bucket_start[NB] = run;
     __syncthreads();
     // stable scatter: same match; rank inside the group = number of lower lanes in it
+    // (the keys of the next four chunks are requested before the ballots of the current four: the chunks of a segment depend on each other
+    // through the cursors, so nothing else hides the L2 latency of a wave's three or four trips)
+    uint32_t next[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int i = beg + 64 * u + lane; next[u] = i < end ? bufB[i] : 0u; }
     for (int i0 = beg; i0 < end; i0 += 256) {
         uint32_t key[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u + lane; key[u] = i < end ? bufB[i] : 0u; }
+        for (int u = 0; u < 4; u++) key[u] = next[u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int i = i0 + 256 + 64 * u + lane; next[u] = i < end ? bufB[i] : 0u; }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const bool in = i0 + 64 * u + lane < end;
             const uint32_t code = in ? ((uint32_t)xpart[key_x(key[u])] + (uint32_t)ypart[key_y(key[u])]) : 0xFFFFFFFFu;
+            // lanes with the same code: a match over the bits in which the codes of this chunk differ at all - its 64 keys are neighbours in
+            // one or two cells, i.e. a handful of buckets that differ in two or three bits of the nine or ten
             unsigned long long same = __ballot(in);
-            for (int bit = 0; bit < nbits; bit++) {
+            const uint32_t cref = (uint32_t)ORBX_READLANE((int)code, 0);                   // lane 0 is in whenever any lane is
+            for (uint32_t diff = wave_or_u32(in ? code ^ cref : 0u); diff != 0u; diff &= diff - 1u) {
+                const int bit = __ffsll((unsigned long long)diff) - 1;
                 const unsigned long long bb = __ballot((code >> bit) & 1u);
                 same &= ((code >> bit) & 1u) ? bb : ~bb;
             }
@@ -511,29 +521,40 @@ __device__ __forceinline__ void presort_keys(const uint32_t* __restrict__ bufB, 
     }
 }
 
-// one tree: the keypoints of pyramid level `level` of image b (the body of k_quadtree; every thread of the workgroup's first NT threads runs it,
-// and all of them return from it together)
-__device__ __forceinline__ void quadtree_level(const LevelInfo& L, const int level, const int b, const int NT,
-                                               const CellInfo* __restrict__ cells, int ncells,
-                                               const int* __restrict__ cell_count,
-                                               const uint32_t* __restrict__ slots, size_t slots_stride,
-                                               uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
-                                               uint32_t* __restrict__ lvl_keys, int kp_total_cap,
-                                               int* __restrict__ lvl_count, int nlevels, int node_cap, int nb_cap, int lut_x, int lut_y,
-                                               int* __restrict__ status, long long* __restrict__ qt_prof, int counter_bytes, uint8_t* smem) {
+// grid (B, nlevels), kQuadtreeThreads threads of which the first L.qt_threads (256 or 1024, by the size of the level) work on the level
+// and the rest exits at once.  Dynamic LDS: see carve below (host passes node_cap).
+__global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* __restrict__ lv,
+                                                  const CellInfo* __restrict__ cells, int ncells,
+                                                  const int* __restrict__ cell_count,
+                                                  const uint32_t* __restrict__ slots, size_t slots_stride,
+                                                  uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
+                                                  uint32_t* __restrict__ lvl_keys, int kp_total_cap,
+                                                  int* __restrict__ lvl_count, int nlevels, int node_cap, int nb_cap, int lut_x, int lut_y,
+                                                  int* __restrict__ status, long long* __restrict__ qt_prof, int wide, int counter_bytes) {
+    ORBX_DYN_SMEM(smem);
     __shared__ unsigned long long s_scan[20];
     __shared__ int s_i[80];
     int* s_part = s_i;                                  // block_partition4: 4 counts per wave
     int* s_ndiv = s_i + 64;
     int* s_sortctr = s_i + 66;
     int* s_kinds = s_i + 68;                            // kinds of deep nodes met in the current pass (kDeepSmall | kDeepBig)
+    // grid (B, nlevels): workgroups are dispatched image-fastest, i.e. every image's level 0 (the longest tree by far) starts first and the
+    // short trees of the small levels fill the remaining slots
+    const int level = (int)blockIdx.y, b = (int)blockIdx.x;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int NW = NT >> 6, lgNW = NT == 256 ? 2 : NT == 512 ? 3 : 4;
+    const LevelInfo L = lv[level];
+    // wide: the large levels get L.qt_threads threads (small batches: the latency of one tree is what counts); otherwise every level runs on
+    // four waves, which packs more trees on a CU (large batches)
+    const int NT = wide ? L.qt_threads : 256, NW = NT >> 6, lgNW = NT == 256 ? 2 : NT == 512 ? 3 : 4;
+    if (tid >= NT) return;
     const int N = L.quota;
+#ifndef ORBX_QT_STAMP_LEVEL
+#define ORBX_QT_STAMP_LEVEL 0      // the tree whose phases orbx_debug_quadtree_profile reports (experimental builds look at other levels)
+#endif
 #ifdef ORBX_EMU
 #define QT_STAMP(i)
 #else
-#define QT_STAMP(i) if (qt_prof && tid == 0 && level == 0 && b == 0) qt_prof[i] = wall_clock64();
+#define QT_STAMP(i) if (qt_prof && tid == 0 && level == ORBX_QT_STAMP_LEVEL && b == 0) qt_prof[i] = wall_clock64();
 #endif
     QT_STAMP(0)
     if (tid == 0) *s_kinds = 0;
@@ -582,30 +603,49 @@ __device__ __forceinline__ void quadtree_level(const LevelInfo& L, const int lev
         }
         ypart[y] = (uint16_t)code;
     }
+    // Lanes per cell: as many as the workgroup has for every cell of the level at once (a power of two, at most a wave), so that the usual level
+    // is gathered in ONE trip - counts and slot offsets in one round trip, the keys in a second one with up to 16 loads per lane in flight -
+    // and a level of a few large cells (the top of the pyramid) still uses every lane.  Levels with more cells than threads take trips of NT cells.
+    // (One lane per KEY with a search for its cell coalesces better and is slower: a workgroup of 1024 threads on one CU pays 6.7 ns per
+    // instruction per thread, and the search is ~50 of them per key - profiles/r04/quadtree_gather_key_parallel_variant.patch.txt.)
+    int lgt = 0;
+    while (lgt < 6 && (L.cell_count << (lgt + 1)) <= NT) lgt++;
+    const int tpc = 1 << lgt, sub = tid & (tpc - 1), cpt = NT >> lgt;          // lanes per cell, lane within the cell, cells per trip
+    const bool one_trip = L.cell_count <= cpt;
     // number of keys first: it decides the counter width and the segment length
-    int n = 0;
-    for (int c0 = 0; c0 < L.cell_count; c0 += NT) {
-        const int c = c0 + tid;
+    int n = 0, cnt0 = 0, soff0 = 0, pos0 = 0;
+    if (one_trip) {
+        const int c = tid >> lgt;
+        if (c < L.cell_count) { cnt0 = ccount[c]; soff0 = cells[L.cell_begin + c].slot_off; }      // (travels with the count: one round trip, not two)
         unsigned long long tot;
-        (void)block_excl_scan_n<unsigned long long>((unsigned long long)(c < L.cell_count ? ccount[c] : 0), &tot, s_scan, NW);
-        n += (int)tot;
+        pos0 = (int)block_excl_scan_n<unsigned long long>((unsigned long long)(sub == 0 ? cnt0 : 0), &tot, s_scan, NW);
+        pos0 = __shfl(pos0, lane & ~(tpc - 1));
+        n = (int)tot;
+    } else {
+        for (int c0 = 0; c0 < L.cell_count; c0 += NT) {
+            const int c = c0 + tid;
+            unsigned long long tot;
+            (void)block_excl_scan_n<unsigned long long>((unsigned long long)(c < L.cell_count ? ccount[c] : 0), &tot, s_scan, NW);
+            n += (int)tot;
+        }
     }
     const bool narrow_counters = n <= kPresortU16Max;
     const int nseg = narrow_counters ? imin(NW, counter_bytes >> 1) : imin(NW, counter_bytes >> 2);
     const int seg = ((n + 64 * nseg - 1) / (64 * nseg)) << 6;     // keys per sort segment (whole 64-key chunks)
     for (int i = tid; i < (narrow_counters ? (nseg * NB + 1) >> 1 : nseg * NB); i += NT) counts[i] = 0;
     __syncthreads();
-    // NT / 256 lanes per cell, 256 cells per trip
     {
-        const int lgt = lgNW - 2, sub = tid & ((1 << lgt) - 1), tpc = 1 << lgt;
         int run = 0;
-        for (int c0 = 0; c0 < L.cell_count; c0 += 256) {
-            const int c = c0 + (tid >> lgt);
-            const int cnt = c < L.cell_count ? ccount[c] : 0;
-            const int soff = c < L.cell_count ? cells[L.cell_begin + c].slot_off : 0;      // (travels with the count: one round trip, not two)
-            unsigned long long tot;
-            int pos = run + (int)block_excl_scan_n<unsigned long long>((unsigned long long)(sub == 0 ? cnt : 0), &tot, s_scan, NW);
-            pos = __shfl(pos, lane & ~(tpc - 1));
+        for (int c0 = 0; c0 < L.cell_count; c0 += cpt) {
+            int cnt = cnt0, soff = soff0, pos = pos0;
+            unsigned long long tot = 0;
+            if (!one_trip) {
+                const int c = c0 + (tid >> lgt);
+                cnt = c < L.cell_count ? ccount[c] : 0;
+                soff = c < L.cell_count ? cells[L.cell_begin + c].slot_off : 0;
+                pos = run + (int)block_excl_scan_n<unsigned long long>((unsigned long long)(sub == 0 ? cnt : 0), &tot, s_scan, NW);
+                pos = __shfl(pos, lane & ~(tpc - 1));
+            }
             if (cnt > 0) {
                 const uint32_t* sp = slot_base + soff;
                 int sidx = (pos + sub) / seg, send = (sidx + 1) * seg;       // segment of this lane's first key, and where it ends
@@ -615,15 +655,15 @@ __device__ __forceinline__ void quadtree_level(const LevelInfo& L, const int lev
                     if (narrow_counters) atomicAdd((unsigned*)counts + (slot >> 1), 1u << (16 * (slot & 1)));
                     else atomicAdd(counts + slot, 1);
                 };
-                int k = sub;
-                for (; k + 7 * tpc < cnt; k += 8 * tpc) {          // eight loads in flight
-                    uint32_t v[8];
+                // (16-byte accesses - four keys per load and store - change nothing: what this loop waits for is the LDS pipe, 12 k table reads
+                // and atomics per level-0 tree)
+                for (int k = sub; k < cnt; k += 16 * tpc) {        // sixteen loads in flight, the tail of a cell included
+                    uint32_t v[16];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) v[u] = sp[k + u * tpc];
+                    for (int u = 0; u < 16; u++) if (k + u * tpc < cnt) v[u] = sp[k + u * tpc];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) { bufB[pos + k + u * tpc] = v[u]; count_key(v[u], pos + k + u * tpc); }
+                    for (int u = 0; u < 16; u++) if (k + u * tpc < cnt) { bufB[pos + k + u * tpc] = v[u]; count_key(v[u], pos + k + u * tpc); }
                 }
-                for (; k < cnt; k += tpc) { const uint32_t v = sp[k]; bufB[pos + k] = v; count_key(v, pos + k); }
             }
             run += (int)tot;
         }
@@ -790,7 +830,7 @@ __device__ __forceinline__ void quadtree_level(const LevelInfo& L, const int lev
         if (nnodes >= N || nnodes == prevSize) { finish = true; }
         else if (nnodes + nexp * 3 > N) {
             QT_STAMP(3)
-            if (qt_prof && tid == 0 && level == 0 && b == 0) { qt_prof[10] = n; qt_prof[11] = nnodes; qt_prof[12] = nexp; }
+            if (qt_prof && tid == 0 && level == ORBX_QT_STAMP_LEVEL && b == 0) { qt_prof[10] = n; qt_prof[11] = nnodes; qt_prof[12] = nexp; }
             // ---- final rounds (:940-1020): split largest-first until the quota is reached ----
             while (!finish) {
                 const int prev2 = nnodes;
@@ -941,31 +981,35 @@ __device__ __forceinline__ void quadtree_level(const LevelInfo& L, const int lev
     }
     // "first key with the largest response" in vKeys order (:1028-1053).  vKeys order = FAST emission order = cells row-major, then y, then
     // x, which is a function of the key itself; spans that were never physically partitioned are ordered by bucket instead, so the order is
-    // recomputed rather than read off the position.  Four lanes share a node (keys k = r, r + 4, ..; four loads in flight per lane) and
-    // combine their candidates with the same rule.
-    for (int i0 = 0; i0 < nnodes; i0 += NT >> 2) {
-        const int i = i0 + (tid >> 2), r = tid & 3;
+    // recomputed rather than read off the position.  A power of two of lanes shares a node - as many as there are for all nodes at once (a
+    // level that fills its quota of 257 with four lanes per node on 1024 threads made a second trip for its last node), at most 16 - with
+    // keys k = r, r + lanes, .. and eight loads in flight per lane; the lanes combine their candidates with the same rule.
+    const unsigned Mw = (1u << 20) / (unsigned)L.wcell + 1u, Mh = (1u << 20) / (unsigned)L.hcell + 1u;
+    int lgl = 0;
+    while (lgl < 4 && (nnodes << (lgl + 1)) <= NT) lgl++;
+    const int lpn = 1 << lgl;
+    for (int i0 = 0; i0 < nnodes; i0 += NT >> lgl) {
+        const int i = i0 + (tid >> lgl), r = tid & (lpn - 1);
         uint32_t best = 0; int bs = -1; unsigned long long bo = ~0ull;
         if (i < nnodes) {
             const QNode nd = cur[i];
             const uint32_t* kb = (node_buf(nd) ? bufB : bufA) + nd.start;
             const int c = node_cnt(nd);
-            for (int k0 = r; k0 < c; k0 += 16) {
-                uint32_t key[4];
+            for (int k0 = r; k0 < c; k0 += 8 * lpn) {
+                uint32_t key[8];
 #pragma unroll
-                for (int u = 0; u < 4; u++) key[u] = k0 + 4 * u < c ? kb[k0 + 4 * u] : 0u;
+                for (int u = 0; u < 8; u++) key[u] = k0 + lpn * u < c ? kb[k0 + lpn * u] : 0u;
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (k0 + 4 * u >= c) continue;
+                for (int u = 0; u < 8; u++) {
+                    if (k0 + lpn * u >= c) continue;
                     const int ds = key_s(key[u]) - bs;
                     if (ds < 0) continue;
-                    const unsigned long long ko = vkeys_order(key[u], L.wcell, L.hcell);
+                    const unsigned long long ko = vkeys_order(key[u], Mw, Mh);
                     if (ds > 0 || ko < bo) { best = key[u]; bs = key_s(key[u]); bo = ko; }
                 }
             }
         }
-#pragma unroll
-        for (int d = 1; d <= 2; d <<= 1) {
+        for (int d = 1; d < lpn; d <<= 1) {
             const uint32_t ob = __shfl_xor(best, d); const int os = __shfl_xor(bs, d); const unsigned long long oo = __shfl_xor(bo, d);
             if (os > bs || (os == bs && oo < bo)) { best = ob; bs = os; bo = oo; }
         }
@@ -973,43 +1017,6 @@ __device__ __forceinline__ void quadtree_level(const LevelInfo& L, const int lev
     }
     if (tid == 0) lvl_count[(size_t)b * nlevels + level] = nnodes;
     QT_STAMP(9)
-}
-
-// grid (B, nlevels), kQuadtreeThreads threads of which the first L.qt_threads (256 or 1024, by the size of the level) work on the level
-// and the rest exits at once.  Dynamic LDS: see the carve in quadtree_level (host passes node_cap).  Workgroups are dispatched image-fastest,
-// i.e. every image's level 0 (the longest tree by far) starts first and the short trees of the small levels fill the remaining slots.
-// done != nullptr (small batches): the workgroup that finishes the LAST tree of an image also runs k_layout's body for that image (layout_body.h) -
-// one launch less in a chain that is launch-latency bound at one pair per call.  Every workgroup publishes its level (device-scope fence), then
-// draws a ticket from the image's counter; the one that draws nlevels - 1 sees all the others' keys and counts.  The counters are zero before
-// the first launch and are left zero.
-__global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* __restrict__ lv,
-                                                  const CellInfo* __restrict__ cells, int ncells,
-                                                  const int* __restrict__ cell_count,
-                                                  const uint32_t* __restrict__ slots, size_t slots_stride,
-                                                  uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
-                                                  uint32_t* __restrict__ lvl_keys, int kp_total_cap,
-                                                  int* __restrict__ lvl_count, int nlevels, int node_cap, int nb_cap, int lut_x, int lut_y,
-                                                  int* __restrict__ status, long long* __restrict__ qt_prof, int wide, int counter_bytes,
-                                                  int* __restrict__ done, LayoutArgs LA) {
-    ORBX_DYN_SMEM(smem);
-    const int level = (int)blockIdx.y, b = (int)blockIdx.x;
-    const LevelInfo L = lv[level];
-    // wide: the large levels get L.qt_threads threads (small batches: the latency of one tree is what counts); otherwise every level runs on
-    // four waves, which packs more trees on a CU (large batches)
-    const int NT = wide ? L.qt_threads : 256;
-    if ((int)threadIdx.x >= NT) return;
-    quadtree_level(L, level, b, NT, cells, ncells, cell_count, slots, slots_stride, candA, candB, cand_stride, lvl_keys, kp_total_cap, lvl_count, nlevels,
-                   node_cap, nb_cap, lut_x, lut_y, status, qt_prof, counter_bytes, smem);
-    if (done == nullptr) return;
-    __shared__ int s_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&done[b], 1) == nlevels - 1;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    if (threadIdx.x == 0) done[b] = 0;
-    layout_body(lv, nlevels, lvl_keys, kp_total_cap, lvl_count, LA.lap0, LA.lap1, LA.final_idx, LA.n_out, LA.mono_out, LA.nb, LA.row_start, LA.row_items, b, NT, smem);
 }
 
 }  // namespace orbx

@@ -15,7 +15,8 @@
 #define ORBX_FAST_LIST_BYTES 2048   // k_fast_cells: 1024 list entries (corners of the cell so far + survivors waiting for their score)
 #endif
 #ifndef ORBX_QT_BIG_PIXELS
-#define ORBX_QT_BIG_PIXELS 150000    // levels whose detection area has at least this many pixels get 1024 quadtree threads (tests also build 0)
+#define ORBX_QT_BIG_PIXELS 40000     // levels whose detection area has at least this many pixels get 1024 quadtree threads at small batches (tests also build 0).
+                                     // 150000 left level 2 of a 752x480 pyramid (6 k candidates) on 256 threads: the longest tree of a stereo pair, 66 us against level 0's 57
 #endif
 #ifndef ORBX_QT_WIDE_BATCH
 #define ORBX_QT_WIDE_BATCH 32        // batches of up to this many images run the quadtree of their large levels on 1024 threads
@@ -267,10 +268,9 @@ int configure(orbx_extractor* h, int W, int H, int B) {
         e |= h->d_uRight.ensure(b * cap); e |= h->d_depth.ensure(b * cap); e |= h->d_sad.ensure(b * cap); e |= h->d_nmatch.ensure(b);
         e |= h->d_rowstart.ensure(b * (size_t)((h->H >> kStereoRowShift) + 3)); e |= h->d_rowitems.ensure(b * cap);
         e |= h->d_knn.ensure(4 * b * cap); e |= h->d_ratio.ensure(b * cap);
-        e |= h->h_nm.ensure(3 * b + 4); e |= h->d_qtprof.ensure(32); e |= h->d_qt_done.ensure(b);
+        e |= h->h_nm.ensure(3 * b + 4); e |= h->d_qtprof.ensure(32);
         if (e) return fail(ORBX_E_DEVICE, "device allocation failed (batch %d of %dx%d)", B, W, H);
         rt::memset_async(h->d_status.p, 0, 4 * sizeof(int), h->s0);
-        rt::memset_async(h->d_qt_done.p, 0, b * sizeof(int), h->s0);          // k_quadtree's tickets: zero between launches
         rt::memset_async(h->d_pyr.p, 0, b * h->pyr_stride + 256, h->s0);     // defined row padding for frames written in place (orbx_input_buffer)
         h->maxB = B;
     }
@@ -374,7 +374,7 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
     // small batches: blur and FAST in one launch on one stream (k_fast_cells_blur: no fork / join).  The stage timers of the profiling modes keep
     // the two apart, so those run the large-batch form
     const bool small_forms = B <= ORBX_QT_WIDE_BATCH && !h->profile && !h->serial;
-    const bool one_launch = small_forms && (h->small_forms & 1), layout_in_tree = small_forms && (h->small_forms & 2);
+    const bool one_launch = small_forms && h->small_forms;
     if (one_launch) {
         dim3 grid(4 * nt + fast_blocks, B, 1);
         ORBX_LAUNCH(k_fast_cells_blur, grid, blkf, fast_smem, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
@@ -412,22 +412,18 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
         int qt_block = 256;
         if (B <= ORBX_QT_WIDE_BATCH) for (int l = 0; l < nl; l++) qt_block = std::max(qt_block, h->lv[l].qt_threads);
         const int wide = qt_block > 256, counter_bytes = wide ? 32 : 16;
-        const size_t smem = std::max((size_t)h->node_cap * 81 + (size_t)(h->nb_cap + 2) * 4 + (size_t)counter_bytes * h->nb_cap + 2 * (size_t)(lut_x + lut_y) + 64,
-                                     2 * (size_t)(nb_rows + 1) * sizeof(int));
+        const size_t smem = (size_t)h->node_cap * 81 + (size_t)(h->nb_cap + 2) * 4 + (size_t)counter_bytes * h->nb_cap + 2 * (size_t)(lut_x + lut_y) + 64;
         const dim3 blkq(qt_block, 1, 1);
         if (smem + 2048 > rt::lds_limit(h->device))
             return fail(ORBX_E_CAPACITY, "nfeatures %d at %dx%d needs %zu bytes of LDS per quadtree workgroup, the device allows %zu", h->nfeatures, h->W, h->H, smem + 2048, rt::lds_limit(h->device));
-        // small batches: the last tree of an image to finish lays out the image's keypoints (k_layout's body; its row index lives in the tree's LDS)
-        LayoutArgs LA = {lap0, lap1, nb_rows, h->d_final_idx.p, h->d_nm.p, h->d_nm.p + h->maxB, h->d_rowstart.p, h->d_rowitems.p};
         ORBX_LAUNCH(k_quadtree, grid, blkq, smem, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
                     (const int*)h->d_cell_count.p, (const uint32_t*)h->d_slots.p, h->cand_stride, h->d_candA.p, h->d_candB.p, h->cand_stride,
                     h->d_lvl_keys.p, h->kp_total_cap, h->d_lvl_count.p, nl, h->node_cap, h->nb_cap, lut_x, lut_y, h->d_status.p,
-                    h->serial ? (long long*)h->d_qtprof.p : (long long*)nullptr, wide, counter_bytes,
-                    layout_in_tree ? h->d_qt_done.p : (int*)nullptr, LA);
+                    h->serial ? (long long*)h->d_qtprof.p : (long long*)nullptr, wide, counter_bytes);
     }
     stage_end(h, ST_QUADTREE, h->s0);
     stage_begin(h, ST_LAYOUT, h->s0);
-    if (!layout_in_tree) {
+    {
         dim3 grid(B, 1, 1);
         ORBX_LAUNCH(k_layout, grid, blk1, 2 * (size_t)(nb_rows + 1) * sizeof(int), h->s0, (const LevelInfo*)h->d_lv.p, nl, (const uint32_t*)h->d_lvl_keys.p, h->kp_total_cap,
                     (const int*)h->d_lvl_count.p, lap0, lap1, h->d_final_idx.p, h->d_nm.p, h->d_nm.p + h->maxB, nb_rows, h->d_rowstart.p, h->d_rowitems.p);
@@ -500,7 +496,7 @@ void orbx_destroy(orbx_extractor* h) {
         rt::stream_destroy(h->s0); rt::stream_destroy(h->s1); rt::stream_destroy(h->s_copy);
     }
     h->d_lv.release(); h->d_cells.release(); h->d_xtab.release(); h->d_ytab.release(); h->d_xspan.release(); h->d_yspan.release(); h->d_pyr.release(); h->d_blur.release(); h->d_stage.release();
-    h->d_slots.release(); h->d_candA.release(); h->d_candB.release(); h->d_lvl_keys.release(); h->d_cell_count.release(); h->d_lvl_count.release(); h->d_qt_done.release();
+    h->d_slots.release(); h->d_candA.release(); h->d_candB.release(); h->d_lvl_keys.release(); h->d_cell_count.release(); h->d_lvl_count.release();
     h->d_final_idx.release(); h->d_status.p = nullptr; h->d_status.n = 0; h->d_nm.release(); h->d_kps.release(); h->d_desc.release();
     h->d_uRight.release(); h->d_depth.release(); h->d_sad.release(); h->d_nmatch.release(); h->d_knn.release(); h->d_ratio.release();
     h->d_l2r.release(); h->d_r2l.release(); h->d_p3d.release(); h->d_hamA.release(); h->d_hamB.release(); h->d_hamOut.release(); h->h_stage.release(); h->h_nm.release();
@@ -850,11 +846,7 @@ int orbx_set_pyramid_mode(orbx_extractor* h, int mode) {
     return ORBX_OK;
 }
 
-int orbx_set_small_batch_forms(orbx_extractor* h, int forms) {
-    if (!h || forms < 0 || forms > 3) return fail(ORBX_E_ARG, "small-batch forms: a mask of bits 0 (blur + FAST in one launch) and 1 (layout inside the quadtree launch)");
-    h->small_forms = forms;
-    return ORBX_OK;
-}
+int orbx_set_small_batch_forms(orbx_extractor* h, int on) { if (!h) return ORBX_E_ARG; h->small_forms = on != 0; return ORBX_OK; }
 
 int orbx_set_graph_replay(orbx_extractor* h, int on) { if (!h) return ORBX_E_ARG; h->use_graph = on != 0; return ORBX_OK; }
 

@@ -40,6 +40,23 @@ template <> __device__ __forceinline__ unsigned wave_incl_scan<unsigned>(unsigne
 template <> __device__ __forceinline__ int wave_sum<int>(int v) { return __builtin_amdgcn_readlane(wave_incl_scan_i32_dpp(v), 63); }
 template <> __device__ __forceinline__ unsigned wave_sum<unsigned>(unsigned v) { return (unsigned)__builtin_amdgcn_readlane(wave_incl_scan_i32_dpp((int)v), 63); }
 #endif
+// bitwise OR over the wave, the same in every lane (a wave-uniform scalar on the GPU: the DPP sequence of the scan with | for +)
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
+#ifdef ORBX_EMU
+    for (int d = 32; d >= 1; d >>= 1) v |= __shfl_xor(v, d);
+    return v;
+#else
+    int x = (int)v;
+    x |= __builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    x |= __builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    x |= __builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, false);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xe, false);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xc, false);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return (unsigned)__builtin_amdgcn_readlane(x, 63);
+#endif
+}
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { unsigned long long o = __shfl_xor(v, d); v = o < v ? o : v; }

@@ -67,8 +67,7 @@ struct orbx_extractor {
     int pyr_ntx = 0, pyr_nty = 0, pyr_buf_a = 0, pyr_buf_b = 0;
     orbx::PyrTapOffsets pyr_toff = {};
     bool pyr_fused_ok = false;
-    int small_forms = 3, g_small_forms = 3;         // orbx_set_small_batch_forms: bit 0 blur + FAST in one launch, bit 1 layout at the end of the quadtree launch (batches <= 32)
-    orbx::DevBuf<int> d_qt_done;                    // per image: trees of the current quadtree launch that have finished (bit 1; zero between launches)
+    bool small_forms = true, g_small_forms = true;  // orbx_set_small_batch_forms: blur + FAST in one launch on one stream (batches <= 32)
     int pyramid_mode = 0, g_pyramid_mode = 0;       // orbx_set_pyramid_mode: 0 = by batch size, 1 = one launch per level, 2 = one launch
     size_t pyr_stride = 0, cand_stride = 0;
     int ncells = 0, kp_total_cap = 0, node_cap = 0, nb_cap = 1, fast_tile_bytes = 0, fast_inner_bytes = 0;

@@ -55,7 +55,7 @@ __global__ void k_quadtree(const LevelInfo* __restrict__ lv, const CellInfo* __r
                            uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
                            uint32_t* __restrict__ lvl_keys, int kp_total_cap, int* __restrict__ lvl_count,
                            int nlevels, int node_cap, int nb_cap, int lut_x, int lut_y, int* __restrict__ status, long long* __restrict__ qt_prof,
-                           int wide, int counter_bytes, int* __restrict__ done, LayoutArgs LA);
+                           int wide, int counter_bytes);
 __global__ void k_layout(const LevelInfo* __restrict__ lv, int nlevels, const uint32_t* __restrict__ lvl_keys,
                          int kp_total_cap, const int* __restrict__ lvl_count, int lap0, int lap1,
                          int* __restrict__ final_idx, int* __restrict__ n_out, int* __restrict__ mono_out,

@@ -54,8 +54,6 @@ struct PyrTapOffsets { int x[kMaxLevels], y[kMaxLevels], total; };   // first LD
 struct KeyPointRec { float x, y, size, angle, response; int32_t octave, class_id; };   // = OrbxKeyPoint, 28 B
 
 struct BlurTaps { int k[7]; };                       // 7-tap Gaussian, 8-bit fixed point
-// k_layout's arguments, for the launch forms that run its body at the end of another kernel (k_quadtree at small batches)
-struct LayoutArgs { int lap0, lap1, nb; int* final_idx; int* n_out; int* mono_out; int* row_start; int* row_items; };
 struct BlurTiles { int begin[kMaxLevels + 1]; };         // first tile (256 cols x 64 rows) of each level in k_blur's grid
 struct UmaxTab { int u[16]; };                        // circular patch half-widths (src/ORBextractor.cc:542-570)
 struct StereoParams { float mbf, mb; int th_high, th_orb; int debug_flags; };   // ORBmatcher::TH_HIGH, (TH_HIGH+TH_LOW)/2

@@ -184,12 +184,10 @@ class ORBextractor:
         """0 = by batch size (default), 1 = one launch per pyramid level, 2 = all levels in one launch (orbx_set_pyramid_mode)."""
         self._lib.check(self._lib.L.orbx_set_pyramid_mode(self._h, int(mode)))
 
-    def set_small_batch_forms(self, forms):
-        """Launch forms of batches of up to 32 images (orbx_set_small_batch_forms): a mask of bit 0 (blur + FAST in one launch on one stream)
-        and bit 1 (keypoint layout at the end of the quadtree launch); True = both (default), False = the large-batch forms at every batch
-        size.  Bit-identical outputs."""
-        forms = 3 if forms is True else 0 if forms is False else int(forms)
-        self._lib.check(self._lib.L.orbx_set_small_batch_forms(self._h, forms))
+    def set_small_batch_forms(self, on):
+        """True (default): batches of up to 32 images run the blur strips and the FAST cells in one launch on one stream; False: the large-batch
+        form (two launches on two streams) at every batch size (orbx_set_small_batch_forms).  Bit-identical outputs."""
+        self._lib.check(self._lib.L.orbx_set_small_batch_forms(self._h, 1 if on else 0))
 
     def graph_replay(self, on=True):
         """Replay the extraction pipeline as one hipGraph (small-batch latency)."""

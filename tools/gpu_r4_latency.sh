@@ -6,13 +6,13 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 timeout 600 python -m pytest tests/test_emu_parity.py tests/test_gpu_parity.py tests/test_frame_reference.py -m gpu -x -q 2>&1 | tail -4 | tee $O/pytest.log
 timeout 300 python tools/single_pair_loop.py 400 ab 2>&1 | tee $O/single_pair_ab.txt
-for f in 3 0; do
+for f in 1 0; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_forms$f -o trace -- python tools/single_pair_loop.py 150 $f > $O/prof_forms$f.log 2>&1
   cp $O/prof_forms$f/trace_kernel_stats.csv $O/kernel_stats_forms$f.csv 2>/dev/null
 done
 python - <<'P' | tee $O/timeline.txt
 import csv, glob
-for f in (3, 0):
+for f in (1, 0):
     p = glob.glob('gpurun_out/r04_latency/prof_forms%d/**/trace_kernel_trace.csv' % f, recursive=True) + glob.glob('gpurun_out/r04_latency/prof_forms%d/trace_kernel_trace.csv' % f)
     if not p: print("no trace", f); continue
     rows = sorted(csv.DictReader(open(p[0])), key=lambda r: int(r['Start_Timestamp']))

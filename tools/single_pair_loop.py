@@ -1,24 +1,24 @@
 """One stereo pair per call, synchronised after every pair (Tracking's rhythm), frames written into pyramid level 0 by the producer:
 the loop that tests/gpu_quick.py times, alone, for a rocprofv3 kernel trace of the launch chain.
 
-    python tools/single_pair_loop.py [N] [forms]     forms: the mask of orbx_set_small_batch_forms (default 3; 0 = the large-batch forms), ab = 3 / 1 / 2 / 0 alternating
+    python tools/single_pair_loop.py [N] [forms]     forms: 1 (default) the small-batch launch form, 0 the large-batch form, ab = both, alternating
 Also times one image per call (the monocular rhythm: extract, wait)."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from orb_slam3_detailed_comments_amd import synth, load_hip
+from orb_slam3_detailed_comments_amd import synth, load_hip, _lib
 from orb_slam3_detailed_comments_amd.extractor import ORBextractor
-lib = load_hip()
+lib = _lib.OrbxLib(os.environ['ORBX_QUICK_LIB']) if os.environ.get('ORBX_QUICK_LIB') else load_hip()      # ORBX_QUICK_LIB: A/B of library builds
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-mode = sys.argv[2] if len(sys.argv) > 2 else "3"
+mode = sys.argv[2] if len(sys.argv) > 2 else "1"
 L, R = synth.stereo_pair(seed=100)
 pair = np.stack([L, R])
 bf, b = 458.654 * 0.110074, 0.110074
 
 
 def run(forms, n):
-    ex = ORBextractor(1200, 1.2, 8, 20, 7)
+    ex = ORBextractor(1200, 1.2, 8, 20, 7, lib=lib)
     ex.set_small_batch_forms(forms)
     ptr, shp, strd, istrd = ex.input_upload(pair)
 
@@ -31,7 +31,7 @@ def run(forms, n):
         one_pair()
     pair_ms = (time.perf_counter() - t) / n * 1e3
     ex.close()
-    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, lib=lib)
     ex.set_small_batch_forms(forms)
     ptr, shp, strd, istrd = ex.input_upload(L[None])
     for it in range(20):
@@ -46,7 +46,7 @@ def run(forms, n):
     for P in (4, 16):
         Ls, Rs = zip(*[synth.stereo_pair(seed=100 + s) for s in range(P)])
         arr = np.stack(list(Ls) + list(Rs))
-        ex = ORBextractor(1200, 1.2, 8, 20, 7)
+        ex = ORBextractor(1200, 1.2, 8, 20, 7, lib=lib)
         ex.set_small_batch_forms(forms)
         ptr, shp, strd, istrd = ex.input_upload(arr)
         for it in range(3):
@@ -64,7 +64,7 @@ def run(forms, n):
 
 if mode == "ab":
     for rep in range(3):
-        for forms in (3, 1, 2, 0):
+        for forms in (1, 0):
             p, m, rates = run(forms, N)
             print("small-batch forms %s: single pair %.4f ms, single image %.4f ms (%d calls each, zero-copy input, sync after every call); %s" % (forms, p, m, N, "; ".join(rates)), flush=True)
 else:
