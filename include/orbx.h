@@ -198,8 +198,9 @@ int orbx_debug_level_keys(orbx_extractor* h, int image_index, int level, int* xy
 int orbx_debug_stereo_flags(orbx_extractor* h, int flags);
 int orbx_debug_quadtree_profile(orbx_extractor* h, long long out[16]);   /* phase timestamps of one quadtree workgroup (profiling mode 2) */
 /* test hook: the byte / packed-16-bit instruction wrappers of the kernels (csrc/orbx_simd.h) applied to n operand triples (n a multiple of 256);
- * out = 15 x n results in the order mul24, mul24 (forced), v_perm_b32, v_alignbyte_b32, v_dot4_u32_u8, v_dot2_u32_u16, packed max3, packed min3,
- * packed sub, packed xor(a, c), wave inclusive scan / wave sum of a & 0xFFFF, wave minimum of b (per 64 consecutive elements), v_sad_u8, v_mul_u32_u24 */
+ * out = 20 x n results in the order mul24, mul24 (forced), v_perm_b32, v_alignbyte_b32, v_dot4_u32_u8, v_dot2_u32_u16, packed max3, packed min3,
+ * packed sub, packed xor(a, c), wave inclusive scan / wave sum of a & 0xFFFF, wave minimum of b (per 64 consecutive elements), v_sad_u8, v_mul_u32_u24,
+ * the 64-bit wave scan (two words), the 64-bit workgroup scan (two words), the wave OR */
 int orbx_debug_simd_selftest(orbx_extractor* h, const uint32_t* a, const uint32_t* b, const uint32_t* c, int n, uint32_t* out);
 
 /* ---------------------------------------------------------------------------------------------------------- */

@@ -341,7 +341,8 @@ __global__ void __launch_bounds__(256) k_resize_rows(const LevelInfo* __restrict
 // Self-test of the instruction wrappers of orbx_simd.h (orbx_debug_simd_selftest): out[op * n + i] = op(a[i], b[i], c[i]).  The CPU tests
 // run the kernels on plain-C stand-ins of these instructions; this entry lets the tests compare instruction and stand-in with an independent
 // definition, operand by operand.  ops: 0 mul24, 1 mul24_forced, 2 byte_perm, 3 align_byte, 4 dot4_u8, 5 dot2_u16, 6 pk_max3, 7 pk_min3,
-// 8 pk_sub, 9 pk_xor(a, c), 10 wave_incl_scan, 11 wave_sum (both of a & 0xFFFF), 12 wave_min_u32(b), 13 sad4_u8, 14 __umul24 (kSimdSelftestOps in all).
+// 8 pk_sub, 9 pk_xor(a, c), 10 wave_incl_scan, 11 wave_sum (both of a & 0xFFFF), 12 wave_min_u32(b), 13 sad4_u8, 14 __umul24,
+// 15 / 16 wave_incl_scan of a 64-bit value (low / high word), 17 / 18 block_excl_scan_n of it + 2 x total, 19 wave_or_u32 (kSimdSelftestOps in all).
 __global__ void __launch_bounds__(256) k_simd_selftest(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ c, int n,
                                                        uint32_t* __restrict__ out) {
     const int i = (int)(blockIdx.x * 256 + threadIdx.x);
@@ -365,6 +366,15 @@ __global__ void __launch_bounds__(256) k_simd_selftest(const uint32_t* __restric
     out[12 * (size_t)n + i] = wave_min_u32(y);
     out[13 * (size_t)n + i] = sad4_u8(x, y, z);
     out[14 * (size_t)n + i] = (uint32_t)__umul24(x, y);
+    // 64-bit scans (three 20-bit fields, as k_quadtree packs them): over the wave, and exclusive over the four waves of this workgroup
+    __shared__ unsigned long long s_scan[20];
+    const unsigned long long f = (unsigned long long)(x & 0xFFFFFu) | ((unsigned long long)(y & 0xFFFFFu) << 20) | ((unsigned long long)(z & 0xFFFFFu) << 40);
+    const unsigned long long ws = wave_incl_scan<unsigned long long>(f);
+    out[15 * (size_t)n + i] = (uint32_t)ws; out[16 * (size_t)n + i] = (uint32_t)(ws >> 32);
+    unsigned long long tot;
+    const unsigned long long bs = block_excl_scan_n<unsigned long long>(f, &tot, s_scan, 4) + (tot << 1);      // (the total goes in as well)
+    out[17 * (size_t)n + i] = (uint32_t)bs; out[18 * (size_t)n + i] = (uint32_t)(bs >> 32);
+    out[19 * (size_t)n + i] = wave_or_u32((y & 7u) == 0u ? 1u << (x & 31u) : 0u);
 }
 
 // ---------------------------------------------------------------------------------------------------

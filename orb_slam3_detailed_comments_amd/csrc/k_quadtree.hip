@@ -899,9 +899,11 @@ __global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* 
                 __syncthreads();
                 QT_STAMP(7)
                 const int ndiv = *s_ndiv;
-                // totals over the divided set (division order t = 0..ndiv-1 <-> sorted index nexp-1-t)
+                // totals over the divided set (division order t = 0..ndiv-1 <-> sorted index nexp-1-t): a pass of its own only when the set
+                // takes more than one trip - otherwise the scan of the placement loop below delivers them
+                const bool one_trip = ndiv <= NT;
                 unsigned long long total_all = 0;
-                for (int t0 = 0; t0 < ndiv; t0 += NT) {
+                for (int t0 = 0; t0 < ndiv && !one_trip; t0 += NT) {
                     const int t = t0 + tid;
                     unsigned long long v = 0;
                     if (t < ndiv) {
@@ -915,9 +917,11 @@ __global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* 
                     (void)block_excl_scan_n<unsigned long long>(v, &tot, s_scan, NW);
                     total_all += tot;
                 }
-                const int T2 = (int)(total_all & 0xFFFFF), E2 = (int)((total_all >> 20) & 0xFFFFF);
-                __syncthreads();
-                if (T2 + (prev2 - ndiv) > node_cap) { overflow = 1; break; }
+                int T2 = (int)(total_all & 0xFFFFF), E2 = (int)((total_all >> 20) & 0xFFFFF);
+                if (!one_trip) {
+                    __syncthreads();
+                    if (T2 + (prev2 - ndiv) > node_cap) { overflow = 1; break; }
+                }
                 unsigned long long run = 0;
                 for (int t0 = 0; t0 < ndiv; t0 += NT) {
                     const int t = t0 + tid;
@@ -928,10 +932,15 @@ __global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* 
                         int e = 0;
                         for (int q = 0; q < 4; q++) { cq[q] = (int)childcnt[4 * idx + q]; m += cq[q] > 0; e += cq[q] > 1; }
                         v = (unsigned long long)m | ((unsigned long long)e << 20);
+                        if (one_trip) erased[idx] = 1;             // (read by the kept-list loop below, behind the barriers of this scan)
                     }
                     unsigned long long tot;
                     const unsigned long long ex = run + block_excl_scan_n<unsigned long long>(v, &tot, s_scan, NW);
                     run += tot;
+                    if (one_trip) {
+                        T2 = (int)(tot & 0xFFFFF); E2 = (int)((tot >> 20) & 0xFFFFF);
+                        if (T2 + (prev2 - ndiv) > node_cap) { overflow = 1; break; }      // uniform, before anything is written
+                    }
                     if (t < ndiv) {
                         const int Pm = (int)(ex & 0xFFFFF), Pe = (int)((ex >> 20) & 0xFFFFF);
                         const int newbuf = node_buf(nd) ^ ((int)nd.depth >= D ? 1 : 0);
@@ -951,6 +960,7 @@ __global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* 
                         }
                     }
                 }
+                if (overflow) break;
                 // old list minus the erased parents, in old order, after the new blocks
                 int kept_run = 0;
                 for (int i0 = 0; i0 < prev2; i0 += NT) {

@@ -734,7 +734,7 @@ int orbx_debug_quadtree_profile(orbx_extractor* h, long long out[16]) {
     return ORBX_OK;
 }
 
-// debug: the instruction wrappers of csrc/orbx_simd.h applied to n operand triples; out: 15 x n results (see k_simd_selftest)
+// debug: the instruction wrappers of csrc/orbx_simd.h applied to n operand triples; out: kSimdSelftestOps (20) x n results (see k_simd_selftest)
 int orbx_debug_simd_selftest(orbx_extractor* h, const uint32_t* a, const uint32_t* b, const uint32_t* c, int n, uint32_t* out) {
     if (!h || !a || !b || !c || !out || n <= 0 || (n & 255)) return fail(ORBX_E_ARG, "bad arguments (n must be a positive multiple of 256)");
     rt::set_device(h->device);

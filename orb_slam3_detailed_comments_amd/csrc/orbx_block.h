@@ -35,6 +35,27 @@ __device__ __forceinline__ int wave_incl_scan_i32_dpp(int v) {
     x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);       // row_bcast:31 -> rows 2 and 3
     return x;
 }
+// 64-bit integers (the workgroup scans of k_quadtree carry two or three 20-bit fields in one value): both halves move through the same DPP
+// steps and are added with carry - 28 instructions where six ds_bpermute round trips of both halves took 48 and the latency of the LDS crossbar.
+// rows_only: the first five steps, i.e. an inclusive scan inside every row of 16 lanes (all a scan over <= 16 per-wave totals needs).
+template <bool rows_only>
+__device__ __forceinline__ unsigned long long wave_incl_scan_u64_dpp(unsigned long long v) {
+    unsigned long long x = v;
+#define ORBX_DPP64(src, ctrl, rmask, bmask) ((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(src), ctrl, rmask, bmask, false) | \
+                                             ((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)((src) >> 32), ctrl, rmask, bmask, false) << 32))
+    x += ORBX_DPP64(v, 0x111, 0xf, 0xf);
+    x += ORBX_DPP64(v, 0x112, 0xf, 0xf);
+    x += ORBX_DPP64(v, 0x113, 0xf, 0xf);
+    x += ORBX_DPP64(x, 0x114, 0xf, 0xe);
+    x += ORBX_DPP64(x, 0x118, 0xf, 0xc);
+    if (!rows_only) {
+        x += ORBX_DPP64(x, 0x142, 0xa, 0xf);
+        x += ORBX_DPP64(x, 0x143, 0xc, 0xf);
+    }
+#undef ORBX_DPP64
+    return x;
+}
+template <> __device__ __forceinline__ unsigned long long wave_incl_scan<unsigned long long>(unsigned long long v) { return wave_incl_scan_u64_dpp<false>(v); }
 template <> __device__ __forceinline__ int wave_incl_scan<int>(int v) { return wave_incl_scan_i32_dpp(v); }
 template <> __device__ __forceinline__ unsigned wave_incl_scan<unsigned>(unsigned v) { return (unsigned)wave_incl_scan_i32_dpp((int)v); }
 template <> __device__ __forceinline__ int wave_sum<int>(int v) { return __builtin_amdgcn_readlane(wave_incl_scan_i32_dpp(v), 63); }
@@ -100,6 +121,26 @@ __device__ __forceinline__ T block_excl_scan_n(T v, T* total, T* scratch, int nw
     *total = tot;
     return base + inc - v;
 }
+#ifndef ORBX_EMU
+// 64-bit values on the GPU: the <= 16 per-wave totals are scanned by the first row of lanes of every wave (five DPP steps) and picked out
+// with two lane reads, instead of a loop over the waves in every thread (a workgroup of 1024 threads pays ~7 ns per instruction per thread,
+// and k_quadtree's critical tree runs a dozen of these scans)
+template <>
+__device__ __forceinline__ unsigned long long block_excl_scan_n<unsigned long long>(unsigned long long v, unsigned long long* total, unsigned long long* scratch, int nw) {
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned long long inc = wave_incl_scan_u64_dpp<false>(v);
+    if (lane == 63) scratch[wave] = inc;
+    __syncthreads();
+    const unsigned long long w = wave_incl_scan_u64_dpp<true>(lane < nw ? scratch[lane] : 0ull);
+    __syncthreads();
+    const unsigned wl = (unsigned)w, wh = (unsigned)(w >> 32);
+    const int pw = wave > 0 ? wave - 1 : 0;
+    const unsigned long long below = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)wl, pw) | ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)wh, pw) << 32);
+    *total = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)wl, nw - 1) | ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)wh, nw - 1) << 32);
+    return (wave > 0 ? below : 0ull) + inc - v;
+}
+#endif
 
 // a[i] of a small array that lives in registers / kernel arguments, by selects: indexing it with a per-lane value would move the whole
 // enclosing struct to private memory (k_frustum and k_lastframe_queries carried a 240-byte scratch segment for F.scale_factors[level])

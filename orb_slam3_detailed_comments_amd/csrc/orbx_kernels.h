@@ -39,7 +39,7 @@ constexpr int kResizeRows = 8;         // output rows per k_resize tile (256 col
 #define ORBX_BLUR_ROWS 16
 #endif
 constexpr int kBlurRows = ORBX_BLUR_ROWS;   // output rows per k_blur thread (a block covers 256 columns x 4 * kBlurRows rows)
-constexpr int kSimdSelftestOps = 15;
+constexpr int kSimdSelftestOps = 20;
 __global__ void k_simd_selftest(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ c, int n, uint32_t* __restrict__ out);
 __global__ void k_blur(const LevelInfo* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,
                        uint8_t* __restrict__ blur, size_t pyr_stride, BlurTaps taps, BlurTiles tiles);

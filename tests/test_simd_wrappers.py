@@ -31,7 +31,7 @@ def _operands(rng):
 
 
 def _run(ex, a, b, c):
-    out = np.zeros((15, N), np.uint32)
+    out = np.zeros((20, N), np.uint32)
     a, b, c = (np.ascontiguousarray(x, np.uint32) for x in (a, b, c))
     ex._lib.check(ex._lib.L.orbx_debug_simd_selftest(ex._h, a.ctypes.data, b.ctypes.data, c.ctypes.data, N, out.ctypes.data))
     return out
@@ -88,6 +88,15 @@ def _check(ex):
     assert np.array_equal(out[10], np.cumsum(v, 1).reshape(-1).astype(np.uint32)), "wave_incl_scan"
     assert np.array_equal(out[11], np.repeat(v.sum(1), 64).astype(np.uint32)), "wave_sum"
     assert np.array_equal(out[12], np.repeat(b.reshape(-1, 64).min(1), 64)), "wave_min_u32"
+    # 64-bit scans of three 20-bit fields (on the GPU: DPP steps on both halves with carry; k_quadtree's workgroup scans)
+    f = (a & 0xFFFFF).astype(np.uint64) | (b & 0xFFFFF).astype(np.uint64) << np.uint64(20) | (c & 0xFFFFF).astype(np.uint64) << np.uint64(40)
+    ws = np.cumsum(f.reshape(-1, 64), 1, dtype=np.uint64).reshape(-1)
+    assert np.array_equal(out[15].astype(np.uint64) | out[16].astype(np.uint64) << np.uint64(32), ws), "wave_incl_scan (64-bit)"
+    fb = f.reshape(-1, 256)
+    bs = (np.cumsum(fb, 1, dtype=np.uint64) - fb + (fb.sum(1, dtype=np.uint64) << np.uint64(1))[:, None]).reshape(-1)
+    assert np.array_equal(out[17].astype(np.uint64) | out[18].astype(np.uint64) << np.uint64(32), bs), "block_excl_scan_n (64-bit)"
+    bit = np.where((b & 7) == 0, np.uint32(1) << (a & 31), np.uint32(0)).astype(np.uint32).reshape(-1, 64)
+    assert np.array_equal(out[19], np.repeat(np.bitwise_or.reduce(bit, 1), 64)), "wave_or_u32"
 
 
 def test_simd_wrappers_emulated(emu_lib):

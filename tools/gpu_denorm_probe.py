@@ -9,7 +9,7 @@ pix = lambda: (rng.integers(0, 256, N) | rng.integers(0, 256, N) << 16).astype(n
 a, b, c = pix(), pix(), pix()
 a[:8] = [0, 0, 0x00FF00FF, 0x00010000, 0x00000001, 0x00FF0000, 0x000000FF, 0x00800080]
 ex = ORBextractor(500, 1.2, 8, 20, 7)
-out = np.zeros((15, N), np.uint32)
+out = np.zeros((20, N), np.uint32)
 ex._lib.check(ex._lib.L.orbx_debug_simd_selftest(ex._h, a.ctypes.data, b.ctypes.data, c.ctypes.data, N, out.ctypes.data))
 h = lambda x: ((x & 0xFFFF).astype(np.int64), (x >> 16).astype(np.int64))
 hs = [h(x) for x in (a, b, c)]
