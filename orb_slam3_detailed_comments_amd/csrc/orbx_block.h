@@ -83,10 +83,24 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     for (int d = 32; d >= 1; d >>= 1) { unsigned long long o = __shfl_xor(v, d); v = o < v ? o : v; }
     return v;
 }
+// minimum over the wave, the same in every lane (on the GPU the DPP sequence of the scan with min for +, lanes that a step does not feed
+// take the identity: seven v_min_u32_dpp and a lane read where six ds_bpermute round trips went through the LDS crossbar)
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-#pragma unroll
+#ifdef ORBX_EMU
     for (int d = 32; d >= 1; d >>= 1) { unsigned o = __shfl_xor(v, d); v = o < v ? o : v; }
     return v;
+#else
+    auto mn = [](unsigned a, unsigned b) { return a < b ? a : b; };
+    unsigned x = v;
+    x = mn(x, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xf, 0xf, false));
+    x = mn(x, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false));
+    x = mn(x, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x113, 0xf, 0xf, false));
+    x = mn(x, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)x, 0x114, 0xf, 0xe, false));
+    x = mn(x, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)x, 0x118, 0xf, 0xc, false));
+    x = mn(x, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)x, 0x142, 0xa, 0xf, false));
+    x = mn(x, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)x, 0x143, 0xc, 0xf, false));
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+#endif
 }
 
 // Exclusive scan over the workgroup (blockDim.x*blockDim.y*blockDim.z <= 1024, multiple of 64).
