@@ -225,6 +225,41 @@ def _garbage_padding_case(lib, w, h, nf):
     a.close(); b.close()
 
 
+def _async_upload_pipeline_case(lib, w, h, nf, rounds):
+    """A producer that uploads the next pair into level 0 (orbx_device_upload_async, copy stream) right behind the enqueue of the current one: the
+    upload has to wait, on the device, until the extraction in flight has read its frames - for small batches the event it waits for is recorded
+    on demand, behind the whole chain (orbx_internal.h).  Three different pairs in turn; a premature overwrite shows up as another pair's keypoints."""
+    sets = [np.stack(synth.stereo_pair(w, h, seed=700 + k, nrect=max(300, w * h // 200))) for k in range(3)]
+    ref_ex = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib)
+    refs = [ref_ex.extract_batch(x) for x in sets]
+    ref_ex.close()
+    ex = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib)
+    ptr, shape, stride, istride = ex.input_upload(sets[0])
+    stage = []
+    for k in range(3):
+        raw = ex.pinned_empty((2, istride), np.uint8); raw[:] = 0
+        for i in range(2):
+            raw[i, :h * stride].reshape(h, stride)[:, :w] = sets[k][i]
+        stage.append(raw)
+    ex.device_upload_async(ptr, stage[0])
+    for it in range(rounds):
+        ex.enqueue(None, (0, 0), device_ptr=ptr, shape=shape, stride=stride, image_stride=istride)
+        ex.device_upload_async(ptr, stage[(it + 1) % 3])          # the next pair, while this one is being extracted
+        got = ex.fetch()
+        for x, y in zip(got, refs[it % 3]):
+            assert _same(x, y), "round %d" % it
+    ex.close()
+
+
+def test_async_upload_pipeline_emulated(emu_lib):
+    _async_upload_pipeline_case(emu_lib, 376, 240, 400, 4)
+
+
+@pytest.mark.gpu
+def test_async_upload_pipeline_gpu(hip_lib):
+    _async_upload_pipeline_case(hip_lib, 752, 480, 1200, 60)
+
+
 def test_zero_copy_input_garbage_padding_emulated(emu_lib):
     _garbage_padding_case(emu_lib, 376, 240, 400)
     _garbage_padding_case(emu_lib, 330, 260, 300)
