@@ -84,7 +84,7 @@ class OracleExtractor:
     def __init__(self, nfeatures=1200, scale=1.2, nlevels=8, ini=20, mn=7, gauss_variant=0):
         self.L = oracle()
         self.nlevels = nlevels
-        self.cap = nfeatures + 3 * nlevels + 64
+        self.cap = nfeatures + 16 * nlevels + 64        # (a level returns up to max(quota + 3, 4 * roots) keypoints: 12 per level for a one-feature budget on a wide image)
         self.h = self.L.orbo_create(nfeatures, scale, nlevels, ini, mn, gauss_variant)
 
     def __del__(self):
@@ -141,7 +141,7 @@ class ReferenceExtractor:
         assert self.L is not None, "oracle/_ref/libref_orb.so missing"
         self.nlevels = nlevels
         self.gv = gauss_variant
-        self.cap = nfeatures + 3 * nlevels + 64
+        self.cap = nfeatures + 16 * nlevels + 64        # (a level returns up to max(quota + 3, 4 * roots) keypoints: 12 per level for a one-feature budget on a wide image)
         self.h = self.L.ref_orb_create(nfeatures, scale, nlevels, ini, mn)
 
     def __del__(self):
