@@ -694,6 +694,16 @@ def main():
                 res["latency"] = {"single_pair_ms": round((time.perf_counter() - tl) / npair * 1e3, 4), "pairs": npair,
                                   "what": "one pair per call on one handle, host waits after every pair; inputs resident in pyramid level 0"}
                 hl.close()
+                # the monocular rhythm: one image per call (extract, wait)
+                hm = ORBextractor(NFEAT, SCALE, NLEVELS, INI, MIN, device_id=local, lib=lib)
+                lp, lshape, lstride, listride = hm.input_upload(batch[:1])
+                for it in range(npair + 20):
+                    if it == 20:
+                        tl = time.perf_counter()
+                    hm.enqueue(None, LAP, device_ptr=lp, shape=lshape, stride=lstride, image_stride=listride)
+                    hm.sync()
+                res["latency"]["single_image_ms"] = round((time.perf_counter() - tl) / npair * 1e3, 4)
+                hm.close()
             except Exception as e:
                 res["latency"] = {"single_pair_ms": None, "error": repr(e)}
         if kind == "stereo" and world == 1 and dist is None and not args.no_other_configs and not args.h2d and not os.environ.get("ORBX_BENCH_LIB"):
