@@ -179,6 +179,7 @@ def other_configs(seconds=1.2):
                          "units_per_step": r["config"]["units_per_step_per_gpu"], "workload": r["config"]["workload"], "input_mode": r["config"]["input_mode"],
                          "roofline": {k: r["roofline"][k] for k in ("kernel", "frac", "achieved", "avg_launch_ms", "alone_launch_ms", "end_to_end_frac")},
                          "avg_keypoints_per_image": r["config"]["avg_keypoints_per_image"], "avg_matches_per_unit": r["config"]["avg_matches_per_unit"],
+                         "parity_check": r.get("parity_check"),
                          "wall_seconds_of_child": round(time.time() - t0, 1)}
         except Exception as e:
             out[name] = {"value": None, "error": repr(e)}
@@ -228,6 +229,7 @@ def main():
     ap.add_argument("--import-copy", action="store_true", help="keep the resident inputs in a separate linear device buffer and copy them into the pyramid inside "
                     "every step (the rounds 1-2 measurement) instead of letting the producer write pyramid level 0 directly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the post-run check of the last timed step's outputs against the reference (oracle/_ref)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-pair latency loop (220 tiny launches of every kernel: profiling runs leave it out so that "
                     "per-kernel averages of rocprofv3 are averages over the timed launches)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the second, PCIe-inclusive measurement (never `value`)")
@@ -389,7 +391,8 @@ def main():
             rp = M.ResidentPoints(h, X, nrm, mind, maxd, dsc)
             lp = M.LocalPointsBatch(h, rp, P, (FX, FY, CX, CY), (0.0, float(W), 0.0, float(H)), RGBD_BF, sfs)
             lp.set_poses(poses)
-            local_map.append(dict(rp=rp, lp=lp, depth=h.device_upload(np.broadcast_to(depth, (P, H, W)).copy()), bf=RGBD_BF))
+            local_map.append(dict(rp=rp, lp=lp, depth=h.device_upload(np.broadcast_to(depth, (P, H, W)).copy()), bf=RGBD_BF,
+                                  depth_host=depth, poses=poses, X=X, nrm=nrm, mind=mind, maxd=maxd, dsc=dsc))
 
     # PCIe-inclusive variant: page-locked host copies of the inputs and two device buffers per handle (upload of the next batch beside the kernels)
     host_in, dbuf, dsel = None, None, None
@@ -460,8 +463,9 @@ def main():
             lib.check(lib.L.orbm_stereo_fisheye_fetch(h._h, P, o["l2r"].ctypes.data, o["r2l"].ctypes.data, o["z"].ctypes.data, o["p3"].ctypes.data, o["nm"].ctypes.data, cap))
         elif kind == "rgbd":
             lib.check(lib.L.orbm_stereo_fetch(h._h, P, o["u"].ctypes.data, o["z"].ctypes.data, cap, o["nm"].ctypes.data))
-            _, nm_frames, _ = local_map[i]["lp"].fetch()
+            asg_frames, nm_frames, _ = local_map[i]["lp"].fetch()
             o["nm"][0] = int(nm_frames.sum())
+            o["lp_asg"], o["lp_nm"] = asg_frames, nm_frames             # (kept for the post-run parity check)
         if record:
             step_end.append(time.perf_counter())
             for k, v in h.stage_ms().items():
@@ -526,6 +530,65 @@ def main():
     if args.h2d:
         setup_h2d()
     dt, per_step, repeats = timed(args.steps, args.h2d, args.min_seconds)
+
+    def parity_check(per_handle=4):
+        """CHECKER, after the timed region: what the LAST timed step of every handle left in its output buffers - keypoints, descriptors and the
+        association results of `per_handle` units per handle (other units on every handle) - against the reference's own code compiled into
+        oracle/_ref (src/Frame.cc:105-230 stereo constructor; :1432-1528 fisheye rig; :235-345 RGB-D constructor + Frame::isInFrustum +
+        ORBmatcher::SearchByProjection; src/ORBextractor.cc for mono), or the oracle restatement where oracle/_ref is absent.  Byte-identical
+        or the run fails (exit code 3).  tests/headline_check.py is test infrastructure: nothing here runs inside the timed region."""
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as ol
+        import headline_check as hc
+        t0 = time.time()
+        checked, mism, against = 0, [], None
+        for i in range(NH):
+            o = out[i]
+            for j in range(per_handle):
+                p = (i * per_handle + j) % P
+                if kind == "stereo":
+                    e = hc.StereoExpectation(batch[p], batch[P + p], NFEAT, FX, BF, BASE)
+                    bad = e.differences(o["k"][p], o["d"][p], o["n"][p], o["k"][P + p], o["d"][P + p], o["n"][P + p], o["u"][p], o["z"][p], o["nm"][p])
+                    against = "src/Frame.cc:105-230 (oracle/_ref/libref_frame.so)" if e.kind == "reference" else "oracle restatement (oracle/_ref absent)"
+                elif kind == "mono":
+                    bad = hc.mono_differences(batch[p], LAP, NFEAT, o["k"][p], o["d"][p], o["n"][p], o["m"][p])
+                    against = "src/ORBextractor.cc (oracle/_ref/libref_orb.so)" if ol.reference() is not None else "oracle restatement (oracle/_ref absent)"
+                elif kind == "fisheye":
+                    bad = hc.fisheye_differences(batch[p], batch[P + p], LAP, NFEAT, (KB_CAM1, KB_CAM2, KB_RLR, KB_TLR), o["k"][p], o["d"][p], o["n"][p], o["k"][P + p], o["d"][P + p],
+                                                 o["n"][P + p], o["l2r"][p], o["r2l"][p], o["z"][p], o["p3"][p], o["nm"][p])
+                    against = "src/Frame.cc:1432-1528 (oracle/_ref/libref_frame.so); mvDepth / mvStereo3Dpoints within 1e-4 relative"
+                else:
+                    if ol.reference_frame_lib() is None:
+                        bad = ["oracle/_ref/libref_frame.so missing"]
+                    else:
+                        lm = local_map[i]
+                        grey = ol.oracle_gray(batch[p], True, 0)
+                        F = ol.ReferenceFrame(grey, None, NFEAT, fx=FX, fy=FY, cx=CX, cy=CY, bf=lm["bf"], depth=lm["depth_host"])
+                        bad = []
+                        if int(o["n"][p]) != F.N:
+                            bad.append("count %d != %d" % (o["n"][p], F.N))
+                        else:
+                            if o["k"][p][:F.N].tobytes() != F.keys.tobytes(): bad.append("mvKeys")
+                            if o["d"][p][:F.N].tobytes() != F.desc.tobytes(): bad.append("mDescriptors")
+                            if o["u"][p][:F.N].tobytes() != F.u_right.tobytes(): bad.append("mvuRight")
+                            if o["z"][p][:F.N].tobytes() != F.depth.tobytes(): bad.append("mvDepth")
+                            Rp, tp = lm["poses"][p]
+                            _, ref_as, ref_n = F.search_local_points(Rp, tp, lm["X"], lm["nrm"], lm["mind"], lm["maxd"], np.zeros(len(lm["X"]), np.uint8),
+                                                                     np.ones(len(lm["X"]), np.uint8), lm["dsc"], 0.5, True, 3.0, False, 50.0, 0.8)
+                            if int(o["lp_nm"][p]) != ref_n or not np.array_equal(o["lp_asg"][p][:F.N], ref_as): bad.append("SearchLocalPoints assignments")
+                    against = "src/Frame.cc:235-345 + Frame::isInFrustum + ORBmatcher::SearchByProjection (oracle/_ref/libref_frame.so)"
+                checked += 1
+                if bad:
+                    mism.append({"handle": i, "unit": p, "fields": bad})
+        return {"units": checked, "pairs": checked if paired else None, "per_handle": per_handle, "handles": NH, "identical": not mism, "against": against,
+                "what": "outputs of the last timed step of every handle, fetched inside the timed region", "mismatches": mism[:8], "seconds": round(time.time() - t0, 2)}
+
+    parity = None
+    if rank == 0 and not args.no_parity_check and not args.h2d:
+        try:
+            parity = parity_check()
+        except Exception as e:
+            parity = {"units": 0, "identical": False, "error": repr(e)}
     if dist is not None:
         import torch
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
@@ -656,6 +719,7 @@ def main():
                          "alone_launch_ms": round(serial_sum[dom], 4), "alone_GBps": round(ab[dom] * units[dom] / (serial_sum[dom] * 1e-3) / 1e9, 2),
                          "end_to_end_GBps": round(per_unit_bytes * value / world / 1e9, 2),
                          "end_to_end_frac": round(per_unit_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5), "valu_issue": valu},
+            "parity_check": parity,
             "allgather": ag_alone,
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_alone": {k: round(v, 4) for k, v in serial_sum.items()},
@@ -726,6 +790,9 @@ def main():
     if dist is not None:
         dist_barrier()
         dist.destroy_process_group()
+    if parity is not None and not parity.get("identical"):
+        sys.stderr.write("bench.py: parity_check FAILED - the timed loop's outputs differ from the reference: %s\n" % json.dumps(parity))
+        return 3
 
 
 if __name__ == "__main__":
