@@ -287,7 +287,7 @@ def main():
         def dist_barrier():                             # an all-reduce over CPU tensors: every rank has to arrive
             dist_.all_reduce(torch.zeros(1, device=coll_dev))
 
-    from orb_slam3_detailed_comments_amd import ORBextractor, load_hip, synth, _lib
+    from orb_slam3_detailed_comments_amd import ORBextractor, load_hip, synth, _lib, sophus
     from orb_slam3_detailed_comments_amd import matcher as M
     # ORBX_BENCH_LIB: test switch (tests/test_multi_gloo.py runs this file's distributed path on the CPU emulator build of the kernels)
     lib = _lib.OrbxLib(os.environ["ORBX_BENCH_LIB"]) if os.environ.get("ORBX_BENCH_LIB") else load_hip()
@@ -348,7 +348,7 @@ def main():
         class Cams(C.Structure):
             _fields_ = [("cam1", C.c_float * 8), ("cam2", C.c_float * 8), ("R12", C.c_float * 9), ("t12", C.c_float * 3)]
         kb = Cams()
-        kb.cam1[:] = KB_CAM1; kb.cam2[:] = KB_CAM2; kb.R12[:] = KB_RLR.ravel().tolist(); kb.t12[:] = KB_TLR.tolist()
+        kb.cam1[:] = KB_CAM1; kb.cam2[:] = KB_CAM2; kb.R12[:] = sophus.SE3f(KB_RLR, KB_TLR).rotationMatrix().ravel().tolist()          # mRlr (src/Frame.cc:1498-1501); kb.t12[:] = KB_TLR.tolist()
     local_map = None
     if kind == "rgbd":
         # BASELINE.json configs[3]: per frame ComputeStereoFromRGBD (uRight from the depth image) + Tracking::SearchLocalPoints against a local map
@@ -556,7 +556,7 @@ def main():
                 elif kind == "fisheye":
                     bad = hc.fisheye_differences(batch[p], batch[P + p], LAP, NFEAT, (KB_CAM1, KB_CAM2, KB_RLR, KB_TLR), o["k"][p], o["d"][p], o["n"][p], o["k"][P + p], o["d"][P + p],
                                                  o["n"][P + p], o["l2r"][p], o["r2l"][p], o["z"][p], o["p3"][p], o["nm"][p])
-                    against = "src/Frame.cc:1432-1528 (oracle/_ref/libref_frame.so); mvDepth / mvStereo3Dpoints within 1e-4 relative"
+                    against = "src/Frame.cc:1432-1528 + src/CameraModels/KannalaBrandt8.cpp (oracle/_ref/libref_frame.so), mvDepth / mvStereo3Dpoints included"
                 else:
                     if ol.reference_frame_lib() is None:
                         bad = ["oracle/_ref/libref_frame.so missing"]
@@ -589,8 +589,13 @@ def main():
             parity = parity_check()
         except Exception as e:
             parity = {"units": 0, "identical": False, "error": repr(e)}
+    per_rank_dt = None
     if dist is not None:
         import torch
+        own = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+        every = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(every, own)                 # each rank's own clock over the same barrier-bracketed region: a straggler GPU shows up here
+        per_rank_dt = [float(e.item()) for e in every]
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -720,6 +725,10 @@ def main():
                          "end_to_end_GBps": round(per_unit_bytes * value / world / 1e9, 2),
                          "end_to_end_frac": round(per_unit_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5), "valu_issue": valu},
             "parity_check": parity,
+            # each rank's own rate over the same barrier-bracketed region (its units / its own clock): `value` uses the slowest rank's time
+            "per_rank": None if per_rank_dt is None else {
+                "unit": cfg["unit"], "values": [round(P * args.steps * repeats / t, 1) for t in per_rank_dt],
+                "min": round(P * args.steps * repeats / max(per_rank_dt), 1), "max": round(P * args.steps * repeats / min(per_rank_dt), 1)},
             "allgather": ag_alone,
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_alone": {k: round(v, 4) for k, v in serial_sum.items()},

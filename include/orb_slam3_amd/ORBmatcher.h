@@ -67,6 +67,9 @@ public:
         // mFeatVec is still empty (ComputeBoW has not run) is uploaded for this call only and not cached.
         orbm_keyframe* Get(KeyFrameT* pKF)
         {
+            // device objects belong to one GPU: when SetDevice / SetThreadDevice has moved this thread to another one, everything cached for the
+            // previous GPU is dropped and uploaded again on demand (a search would otherwise refuse the pair: "bad key frame")
+            if (device != Device()) { Clear(); device = Device(); }
             const Tag tag = {(long long)pKF->mnId, (long long)pKF->N, (long long)pKF->mFeatVec.size()};
             auto it = m.find(pKF);
             if (it != m.end()) {
@@ -96,6 +99,7 @@ public:
         struct Entry { orbm_keyframe* dev; Tag tag; };
         std::map<KeyFrameT*, Entry> m;
         orbm_keyframe* transient = nullptr;
+        int device = -1;
     };
 
     // Computes the Hamming distance between two ORB descriptors (src/ORBmatcher.cc:2383).
@@ -686,7 +690,8 @@ public:
     // The handle lives as long as its thread.
     // Multi-GPU hosts (one SLAM system per GPU, BASELINE.json configs[4]): the handle is created on the GPU chosen by SetDevice() - process-wide,
     // the default for every thread - or SetThreadDevice() - the calling thread only, e.g. the tracking thread of the system that owns GPU k;
-    // pass the same index as the extractor's device_id.  Changing the device re-creates the thread's handle on the next call.
+    // pass the same index as the extractor's device_id.  Choose the device BEFORE a thread's first matcher call: changing it later re-creates the
+    // thread's handle on its next call (SetDevice: every thread without a SetThreadDevice of its own) and empties its ResidentKeyFrames caches.
     static void SetDevice(int device) { ProcessDevice().store(device); }
     static void SetThreadDevice(int device) { ThreadDevice() = device; }
     static int Device() { const int t = ThreadDevice(); return t >= 0 ? t : ProcessDevice().load(); }

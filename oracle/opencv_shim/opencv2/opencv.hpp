@@ -81,6 +81,7 @@ public:
     Mat(Size s, int type) : Mat() { create(s.height, s.width, type); }
     // user-data constructor (no ownership)
     Mat(int r, int c, int type, void* d, size_t st = 0) : rows(r), cols(c), data((uchar*)d), step(st ? st : (size_t)c * esz(type)), type_(type) {}
+    static Mat eye(int r, int c, int type) { Mat m = zeros(r, c, type); for (int i = 0; i < r && i < c; i++) m.at<float>(i, i) = 1.0f; return m; }
     static Mat zeros(int r, int c, int type) { Mat m(r, c, type); if (m.data) memset(m.data, 0, (size_t)r * m.step); return m; }
     void create(int r, int c, int type) {
         if (data && r == rows && c == cols && type == type_) return;
@@ -135,6 +136,22 @@ public:
 };
 typedef const _InputArray& InputArray;
 typedef const _OutputArray& OutputArray;
+
+// What src/CameraModels/{Pinhole,KannalaBrandt8}.cpp name to compile: (cv::Mat_<float>(r, c) << a, b, ...) for toK() (:255-258 / :296-302),
+// Mat::eye is below, cv::fisheye::undistortPoints only inside ReconstructWithTwoViews (monocular initialisation: out of scope, never called).
+template <typename T> class Mat_ : public Mat {
+public:
+    Mat_(int r, int c) : Mat(r, c, CV_32F) { static_assert(sizeof(T) == 4, "float matrices only"); }
+};
+template <typename T> struct MatCommaInitializer_ {
+    Mat m; int k;
+    MatCommaInitializer_& operator,(T v) { m.at<T>(k / m.cols, k % m.cols) = v; k++; return *this; }
+    operator Mat() const { return m; }
+};
+template <typename T> MatCommaInitializer_<T> operator<<(const Mat_<T>& m, T v) { MatCommaInitializer_<T> ci{m, 0}; ci, v; return ci; }
+namespace fisheye {
+static inline void undistortPoints(const std::vector<Point2f>&, std::vector<Point2f>&, const Mat&, const Mat&, const Mat&, const Mat&) { abort(); }
+}
 
 static inline float fastAtan2(float y, float x) { return orbp::fast_atan2_deg(y, x); }
 

@@ -43,7 +43,7 @@ void* ref_frame_stereo(const uint8_t* L, const uint8_t* R, int w, int h, int nfe
     Holder* H = new Holder();
     H->left = new ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th);
     H->right = new ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th);
-    H->cam = new Pinhole(fx, fy, cx, cy);
+    H->cam = new Pinhole(std::vector<float>{fx, fy, cx, cy});
     cv::Mat imL(h, w, CV_8UC1, (void*)L, (size_t)w), imR(h, w, CV_8UC1, (void*)R, (size_t)w);
     cv::Mat K = H->cam->toK();
     cv::Mat dist(4, 1, CV_32F); for (int i = 0; i < 4; i++) dist.at<float>(i) = 0.0f;
@@ -68,7 +68,7 @@ void* ref_frame_rgbd(const uint8_t* gray, const float* depth, int w, int h, int 
     cv::shim_gauss_variant() = gauss_variant;
     Holder* H = new Holder();
     H->left = new ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th);
-    H->cam = new Pinhole(fx, fy, cx, cy);
+    H->cam = new Pinhole(std::vector<float>{fx, fy, cx, cy});
     cv::Mat im(h, w, CV_8UC1, (void*)gray, (size_t)w), imD(h, w, CV_32F, (void*)depth, (size_t)w * sizeof(float));
     cv::Mat K = H->cam->toK();
     // dist5 = (k1, k2, p1, p2, k3) as Examples/RGB-D/TUM1.yaml gives them: UndistortKeyPoints (:1003-1034) and ComputeImageBounds (:1043-1075) then
@@ -81,24 +81,46 @@ void* ref_frame_rgbd(const uint8_t* gray, const float* depth, int w, int h, int 
 }
 
 // The fisheye-rig constructor (src/Frame.cc:1432-1528): two extractions with the cameras' lapping areas, ComputeStereoFishEyeMatches
-// (:1530-1587: BFMatcher 2-NN on the lapping parts + the 0.7 ratio test; the triangulation gate accepts everything, see frame_world.h),
+// (:1530-1587: BFMatcher 2-NN on the lapping parts + the 0.7 ratio test + the triangulation gate),
 // vconcat of the descriptors, AssignFeaturesToGrid.  out = {Nleft, Nright, monoLeft, monoRight}.
-// cams == NULL: a camera whose triangulation gate accepts every pair, so that what the reference's loop leaves in mvLeftToRightMatch /
-// mvRightToLeftMatch is exactly its kNN + ratio decision; else cams = {cam1[8], cam2[8], Rlr[9] row-major, tlr[3]} and the gate is
-// KannalaBrandt8::TriangulateMatches (restated, oracle/slam_shim/kb8_camera.h).
-struct KB8AcceptAll : KannalaBrandt8 {
-    float TriangulateMatches(GeometricCamera*, const cv::KeyPoint&, const cv::KeyPoint&, const Eigen::Matrix3f&, const Eigen::Vector3f&, const float, const float, Eigen::Vector3f& p3D) override {
-        p3D = Eigen::Vector3f(0, 0, 1); return 1.0f;
-    }
-};
+// cams = {cam1[8], cam2[8], Rlr[9] row-major, tlr[3]}: the gate is the reference's own KannalaBrandt8::TriangulateMatches
+// (src/CameraModels/KannalaBrandt8.cpp:439-523, compiled unmodified into this library).  cams == NULL is served only by the ORBX_KB8_ACCEPT_ALL
+// build of this driver (oracle/_ref/libref_frame_knn.so): there KannalaBrandt8.cpp is NOT linked and the class's members are defined below with a
+// TriangulateMatches that accepts every pair, so that what the reference's loop leaves in mvLeftToRightMatch / mvRightToLeftMatch is exactly
+// its kNN + ratio decision (TriangulateMatches is not virtual: it cannot be overridden in a subclass).
+#ifdef ORBX_KB8_ACCEPT_ALL
+namespace ORB_SLAM3 {
+cv::Point2f KannalaBrandt8::project(const cv::Point3f&) { abort(); }
+Eigen::Vector2d KannalaBrandt8::project(const Eigen::Vector3d&) { abort(); }
+Eigen::Vector2f KannalaBrandt8::project(const Eigen::Vector3f&) { abort(); }
+Eigen::Vector2f KannalaBrandt8::projectMat(const cv::Point3f&) { abort(); }
+float KannalaBrandt8::uncertainty2(const Eigen::Matrix<double, 2, 1>&) { abort(); }
+Eigen::Vector3f KannalaBrandt8::unprojectEig(const cv::Point2f&) { abort(); }
+cv::Point3f KannalaBrandt8::unproject(const cv::Point2f&) { abort(); }
+Eigen::Matrix<double, 2, 3> KannalaBrandt8::projectJac(const Eigen::Vector3d&) { abort(); }
+bool KannalaBrandt8::ReconstructWithTwoViews(const std::vector<cv::KeyPoint>&, const std::vector<cv::KeyPoint>&, const std::vector<int>&, Sophus::SE3f&, std::vector<cv::Point3f>&,
+                                             std::vector<bool>&) { abort(); }
+cv::Mat KannalaBrandt8::toK() { abort(); }
+Eigen::Matrix3f KannalaBrandt8::toK_() { abort(); }
+bool KannalaBrandt8::epipolarConstrain(GeometricCamera*, const cv::KeyPoint&, const cv::KeyPoint&, const Eigen::Matrix3f&, const Eigen::Vector3f&, const float, const float) { abort(); }
+bool KannalaBrandt8::matchAndtriangulate(const cv::KeyPoint&, const cv::KeyPoint&, GeometricCamera*, Sophus::SE3f&, Sophus::SE3f&, const float, const float, Eigen::Vector3f&) { abort(); }
+float KannalaBrandt8::TriangulateMatches(GeometricCamera*, const cv::KeyPoint&, const cv::KeyPoint&, const Eigen::Matrix3f&, const Eigen::Vector3f&, const float, const float,
+                                         Eigen::Vector3f& p3D) { p3D = Eigen::Vector3f(0, 0, 1); return 1.0f; }
+}
+#endif
 void* ref_frame_fisheye(const uint8_t* L, const uint8_t* R, int w, int h, int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, int gauss_variant,
                         int lap_l0, int lap_l1, int lap_r0, int lap_r1, const float* cams, int* out) {
     cv::shim_gauss_variant() = gauss_variant;
     Holder* H = new Holder();
     H->left = new ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th);
     H->right = new ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th);
-    if (cams) { H->kb1 = new KannalaBrandt8(cams); H->kb2 = new KannalaBrandt8(cams + 8); }
-    else { H->kb1 = new KB8AcceptAll(); H->kb2 = new KB8AcceptAll(); }
+#ifdef ORBX_KB8_ACCEPT_ALL
+    if (cams) { delete H; return nullptr; }
+    H->kb1 = new KannalaBrandt8(std::vector<float>(8, 1.0f)); H->kb2 = new KannalaBrandt8(std::vector<float>(8, 1.0f));
+#else
+    if (!cams) { delete H; return nullptr; }
+    H->kb1 = new KannalaBrandt8(std::vector<float>(cams, cams + 8)); H->kb2 = new KannalaBrandt8(std::vector<float>(cams + 8, cams + 16));
+#endif
     H->kb1->mvLappingArea[0] = lap_l0; H->kb1->mvLappingArea[1] = lap_l1; H->kb2->mvLappingArea[0] = lap_r0; H->kb2->mvLappingArea[1] = lap_r1;
     cv::Mat imL(h, w, CV_8UC1, (void*)L, (size_t)w), imR(h, w, CV_8UC1, (void*)R, (size_t)w);
     cv::Mat K(3, 3, CV_32F); for (int i = 0; i < 9; i++) K.at<float>(i / 3, i % 3) = (i % 4 == 0) ? 1.0f : 0.0f;
@@ -322,7 +344,7 @@ int ref_frame_search_local_points_rig(void* h, const float* R, const float* t, i
 int ref_frame_stereo_repeat(const uint8_t* L, const uint8_t* R, int w, int h, int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th,
                             float fx, float fy, float cx, float cy, float bf, float th_depth, double seconds, double* elapsed, int* matches, double* stage_ms) {
     ORBextractor left(nfeatures, scale_factor, nlevels, ini_th, min_th), right(nfeatures, scale_factor, nlevels, ini_th, min_th);
-    Pinhole cam(fx, fy, cx, cy);
+    Pinhole cam(std::vector<float>{fx, fy, cx, cy});
     cv::Mat imL(h, w, CV_8UC1, (void*)L, (size_t)w), imR(h, w, CV_8UC1, (void*)R, (size_t)w);
     cv::Mat K = cam.toK();
     cv::Mat dist(4, 1, CV_32F); for (int i = 0; i < 4; i++) dist.at<float>(i) = 0.0f;

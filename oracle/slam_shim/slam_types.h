@@ -1,6 +1,8 @@
-// slam_types.h — TEST INFRASTRUCTURE (part of oracle/; never shipped).  Stand-ins for Eigen / Sophus and for the GeometricCamera, MapPoint and
-// KeyFrame classes of the reference, shared by slam_world.h (the world the reference's ORBmatcher.cc is compiled over) and frame_world.h
-// (the world the reference's Frame.cc is compiled over).  See slam_world.h for what is restated here and why.
+// slam_types.h — TEST INFRASTRUCTURE (part of oracle/; never shipped).  Stand-ins for Eigen / Sophus and for the MapPoint and KeyFrame classes
+// of the reference, shared by slam_world.h (the world the reference's ORBmatcher.cc is compiled over) and frame_world.h (the world the
+// reference's Frame.cc is compiled over).  See slam_world.h for what is restated here and why.  The CAMERA MODELS are the reference's own:
+// include/CameraModels/{GeometricCamera,Pinhole,KannalaBrandt8}.h are included from here, and src/CameraModels/Pinhole.cpp + KannalaBrandt8.cpp
+// are compiled unmodified into every _ref library (oracle/Makefile, CAMSRC) over the stand-in Eigen of this file and eigen_small.h.
 #ifndef ORBX_SLAM_TYPES_H
 #define ORBX_SLAM_TYPES_H
 
@@ -44,6 +46,7 @@ struct Vector3f {
     float& operator[](int i) { return d[i]; }
     const float& operator[](int i) const { return d[i]; }
     void setZero() { d[0] = d[1] = d[2] = 0; }
+    static Vector3f Zero() { return Vector3f(); }
     float* data() { return d; }
     size_t size() const { return 3; }
     // Eigen >= 3.3 (required by the vendored Sophus, Thirdparty/Sophus/CMakeLists.txt:35): a fixed-size reduction of three terms is unrolled by
@@ -90,10 +93,31 @@ inline Matrix3f operator*(const Matrix3f& A, const Matrix3f& B) {
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = A.m[i][0] * B.m[0][j] + (A.m[i][1] * B.m[1][j] + A.m[i][2] * B.m[2][j]);
     return r;
 }
+inline Matrix3f operator-(const Matrix3f& A) { Matrix3f r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = -A.m[i][j]; return r; }
 inline Matrix3f operator*(const Matrix3f& A, float s) { Matrix3f r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = A.m[i][j] * s; return r; }
 }  // namespace Eigen
 
+#include "eigen_small.h"       // what the reference's camera models need beyond the types above: Matrix<float,3,4>, Matrix4f, JacobiSVD<Matrix4f>, ...
 #include "sophus_model.h"     // Sophus::SO3f / SE3f / RxSO3f / Sim3f: the vendored Sophus restated over a stand-in Eigen::Quaternionf
+
+// The reference's own camera models.  GeometricCamera.h pulls in Converter.h and GeometricTools.h (g2o, Eigen/Dense: unbuildable here, and nothing
+// of them is used by the camera models); Pinhole.h / KannalaBrandt8.h name TwoViewReconstruction (monocular initialisation, out of scope,
+// SURVEY.md 8): a two-method stand-in that is never called.
+#ifndef CONVERTER_H
+#define CONVERTER_H
+#endif
+#define GEOMETRIC_TOOLS_H
+#define TwoViewReconstruction_H
+namespace ORB_SLAM3 {
+class TwoViewReconstruction {
+public:
+    TwoViewReconstruction(const Eigen::Matrix3f&) {}
+    bool Reconstruct(const std::vector<cv::KeyPoint>&, const std::vector<cv::KeyPoint>&, const std::vector<int>&, Sophus::SE3f&, std::vector<cv::Point3f>&, std::vector<bool>&) { return false; }
+};
+}
+#include "CameraModels/GeometricCamera.h"
+#include "CameraModels/Pinhole.h"
+#include "CameraModels/KannalaBrandt8.h"
 
 namespace ORB_SLAM3 {
 
@@ -102,50 +126,8 @@ class Frame;
 class MapPoint;
 class Map;
 
-// pinhole GeometricCamera: parameters fx, fy, cx, cy
-class GeometricCamera {
-public:
-    float mvParameters[4];
-    const static unsigned int CAM_PINHOLE = 0, CAM_FISHEYE = 1;                                      // include/CameraModels/GeometricCamera.h:93-94
-    GeometricCamera(float fx, float fy, float cx, float cy) : mvParameters{fx, fy, cx, cy} {}
-    virtual ~GeometricCamera() {}
-    unsigned int GetId() { return 0; }
-    virtual unsigned int GetType() { return CAM_PINHOLE; }
-    virtual float getParameter(const int i) { return mvParameters[i]; }
-    virtual Eigen::Vector3f unprojectEig(const cv::Point2f& p2D) {                                  // Pinhole.cpp:85-89
-        return Eigen::Vector3f((p2D.x - mvParameters[2]) / mvParameters[0], (p2D.y - mvParameters[3]) / mvParameters[1], 1.f);
-    }
-    virtual Eigen::Vector2f project(const Eigen::Vector3f& v3D) {                                    // Pinhole.cpp:61-68
-        Eigen::Vector2f res;
-        res[0] = mvParameters[0] * v3D[0] / v3D[2] + mvParameters[2];
-        res[1] = mvParameters[1] * v3D[1] / v3D[2] + mvParameters[3];
-        return res;
-    }
-    virtual Eigen::Matrix3f toK_() {
-        Eigen::Matrix3f K; K(0, 0) = mvParameters[0]; K(1, 1) = mvParameters[1]; K(0, 2) = mvParameters[2]; K(1, 2) = mvParameters[3]; K(2, 2) = 1.0f; return K;
-    }
-    static Eigen::Matrix3f hat(const Eigen::Vector3f& t) {
-        Eigen::Matrix3f x; x(0, 1) = -t(2); x(0, 2) = t(1); x(1, 0) = t(2); x(1, 2) = -t(0); x(2, 0) = -t(1); x(2, 1) = t(0); return x;
-    }
-    Eigen::Matrix3f fundamental(GeometricCamera* pCamera2, const Eigen::Matrix3f& R12, const Eigen::Vector3f& t12) {   // Pinhole.cpp:191-194
-        return toK_().transpose().inverse() * hat(t12) * R12 * pCamera2->toK_().inverse();
-    }
-    virtual bool epipolarConstrain(GeometricCamera* pCamera2, const cv::KeyPoint& kp1, const cv::KeyPoint& kp2, const Eigen::Matrix3f& R12,
-                                   const Eigen::Vector3f& t12, const float sigmaLevel, const float unc) {              // Pinhole.cpp:186-216
-        const Eigen::Matrix3f F12 = fundamental(pCamera2, R12, t12);
-        const float a = kp1.pt.x * F12(0, 0) + kp1.pt.y * F12(1, 0) + F12(2, 0);
-        const float b = kp1.pt.x * F12(0, 1) + kp1.pt.y * F12(1, 1) + F12(2, 1);
-        const float c = kp1.pt.x * F12(0, 2) + kp1.pt.y * F12(1, 2) + F12(2, 2);
-        const float num = a * kp2.pt.x + b * kp2.pt.y + c;
-        const float den = a * a + b * b;
-        if (den == 0) return false;
-        const float dsqr = num * num / den;
-        return dsqr < 3.84 * unc;
-    }
-};
-
 }  // namespace ORB_SLAM3
-#include "kb8_camera.h"
+
 namespace ORB_SLAM3 {
 
 #ifndef ORBX_REAL_MAPPOINT

@@ -103,6 +103,11 @@ public:
     const Eigen::Quaternionf& unit_quaternion() const { return unit_quaternion_; }
     SO3f inverse() const { return SO3f(unit_quaternion_.conjugate()); }                            // so3.hpp:229-231
     Eigen::Matrix3f matrix() const { return unit_quaternion_.toRotationMatrix(); }                 // so3.hpp:310-312
+    static Eigen::Matrix3f hat(const Eigen::Vector3f& omega) {                                     // so3.hpp:673-682
+        Eigen::Matrix3f Omega;
+        Omega(0, 1) = -omega(2); Omega(0, 2) = omega(1); Omega(1, 0) = omega(2); Omega(1, 2) = -omega(0); Omega(2, 0) = -omega(1); Omega(2, 1) = omega(0);
+        return Omega;
+    }
     SO3f operator*(const SO3f& other) const {                                                      // so3.hpp:325-340
         const Eigen::Quaternionf& a = unit_quaternion_; const Eigen::Quaternionf& b = other.unit_quaternion_;
         return SO3f(Eigen::Quaternionf(a.w() * b.w() - a.x() * b.x() - a.y() * b.y() - a.z() * b.z(),
@@ -132,6 +137,7 @@ public:
     const Eigen::Vector3f& translation() const { return translation_; }
     const Eigen::Quaternionf& unit_quaternion() const { return so3_.unit_quaternion(); }           // se3.hpp:419-421
     Eigen::Matrix3f rotationMatrix() const { return so3_.matrix(); }                                // se3.hpp:363
+    Eigen::Matrix34f matrix3x4() const { Eigen::Matrix34f M; M << rotationMatrix(), translation_; return M; }            // se3.hpp:285-290
     SE3 inverse() const { const SO3f invR = so3_.inverse(); return SE3(invR, invR * (translation_ * -1.0f)); }            // se3.hpp:208-211
     SE3 operator*(const SE3& other) const { return SE3(so3_ * other.so3_, translation_ + so3_ * other.translation_); }     // se3.hpp:304-308
     Eigen::Vector3f operator*(const Eigen::Vector3f& p) const { return so3_ * p + translation_; }                         // se3.hpp:321-324

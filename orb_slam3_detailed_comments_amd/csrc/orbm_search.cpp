@@ -1272,6 +1272,8 @@ int orbm_search_by_bow_frames_batch(orbx_extractor* h, const orbv_vocabulary* v,
     VocFrameArrays V;
     if (orbv_frame_arrays(v, &V) || V.handle != (const void*)h || V.first != first || V.lastB != B || V.cap != h->kp_total_cap || first < 0 || first + B > h->lastB)
         return fail(ORBX_E_ARG, "run orbv_transform_extracted(v, h, %d, %d, levelsup) on this extraction first: the FeatureVectors of these frames are read where it leaves them", first, B);
+    if (V.extract_gen != h->extract_gen)
+        return fail(ORBX_E_ARG, "the handle has extracted another batch since orbv_transform_extracted ran: its FeatureVectors index the keypoints of the previous batch - transform again");
     if (V.device != h->device) return fail(ORBX_E_ARG, "vocabulary and extractor live on different devices");
     if (undistort_stale(h)) return fail(ORBX_E_ARG, "orbx_set_undistort was called after the last extraction: extract again before searching its frames");
     rt::set_device(h->device);

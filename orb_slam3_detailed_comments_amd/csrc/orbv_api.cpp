@@ -16,7 +16,7 @@ struct orbv_vocabulary {
     DevBuf<unsigned long long> d_desc; DevBuf<VocSlot> d_slots; DevBuf<double> d_weight;
     // per-call scratch / results (sized by reserve())
     int cap = 0, maxB = 0, lastB = 0, run_cap = 0;      // run_cap: per-image stride of the results of the last run
-    int run_first = -1; const void* run_handle = nullptr;   // orbv_transform_extracted: which images of which extractor the results belong to
+    int run_first = -1; const void* run_handle = nullptr; uint64_t run_extract_gen = 0;   // orbv_transform_extracted: which images of which extractor the results belong to
     DevBuf<unsigned long long> d_fdesc;
     DevBuf<unsigned> d_word, d_node, d_bow_id, d_fv_node, d_fv_feat;
     DevBuf<double> d_wt, d_bow_val;
@@ -68,7 +68,7 @@ namespace orbx {
 int orbv_frame_arrays(const orbv_vocabulary* v, VocFrameArrays* out) {
     if (!v || v->lastB <= 0) return -1;
     out->fv_node = (const uint32_t*)v->d_fv_node.p; out->fv_start = v->d_fv_start.p; out->fv_feat = (const int*)v->d_fv_feat.p; out->nout = v->d_nout.p;
-    out->cap = v->run_cap; out->lastB = v->lastB; out->device = v->device; out->first = v->run_first; out->handle = v->run_handle;
+    out->cap = v->run_cap; out->lastB = v->lastB; out->device = v->device; out->first = v->run_first; out->handle = v->run_handle; out->extract_gen = v->run_extract_gen;
     return 0;
 }
 }  // namespace orbx
@@ -172,7 +172,7 @@ int orbv_transform_extracted(orbv_vocabulary* v, orbx_extractor* h, int first, i
     rt::set_device(h->device);
     const int cap = h->kp_total_cap;
     const int rc = run(v, h, (const unsigned long long*)(h->d_desc.p + (size_t)first * cap * 4), (const int*)(h->d_nm.p + first), 0, cap, B, levelsup);
-    if (rc == ORBX_OK) { v->run_first = first; v->run_handle = h; }
+    if (rc == ORBX_OK) { v->run_first = first; v->run_handle = h; v->run_extract_gen = h->extract_gen; }
     return rc;
 }
 

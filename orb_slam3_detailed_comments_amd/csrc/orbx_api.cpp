@@ -449,7 +449,7 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
     }
     stage_end(h, ST_DESCRIBE, h->s0);
     h->done_lazy = true;                                            // ev_done: recorded by whoever waits for it (record_done_if_pending)
-    h->lastB = B; h->ex_undist_gen = h->undist_gen; h->ex_undist_active = h->undist.active != 0;
+    h->lastB = B; h->extract_gen++; h->ex_undist_gen = h->undist_gen; h->ex_undist_active = h->undist.active != 0;
     if (rt::check_launch()) return fail(ORBX_E_DEVICE, "kernel launch failed: %s", rt::last_error());
     return ORBX_OK;
 }
@@ -595,7 +595,7 @@ int orbx_extract_batch(orbx_extractor* h, int B, const uint8_t* images, int widt
         // the records inside the capture belong to the graph; these are the ones other streams can wait on (an upload into the input buffer
         // waits for ev_import: after a replay that is the end of the whole graph, which is later than needed but never too early)
         h->import_lazy = true; h->done_lazy = true;
-        h->lastB = B; h->ex_undist_gen = h->undist_gen; h->ex_undist_active = h->undist.active != 0;
+        h->lastB = B; h->extract_gen++; h->ex_undist_gen = h->undist_gen; h->ex_undist_active = h->undist.active != 0;
         return ORBX_OK;
     }
 #endif

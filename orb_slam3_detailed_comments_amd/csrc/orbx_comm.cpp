@@ -20,6 +20,7 @@
 #include <memory>
 #else
 #include <dlfcn.h>
+#include <string>
 #endif
 
 using namespace orbx;
@@ -39,6 +40,7 @@ struct Rccl {
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     bool ok = false;
+    std::string err;                       // why it is not ok: dlerror() read once, where the failure happened
 };
 Rccl& rccl() {
     static Rccl r;
@@ -47,6 +49,8 @@ Rccl& rccl() {
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
             r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.lib) break;
+            const char* e = dlerror();
+            if (e && r.err.empty()) r.err = e;
         }
         if (!r.lib) return;
         r.GetUniqueId = (int (*)(NcclId*))dlsym(r.lib, "ncclGetUniqueId");
@@ -57,6 +61,7 @@ Rccl& rccl() {
         r.GroupEnd = (int (*)())dlsym(r.lib, "ncclGroupEnd");
         r.GetErrorString = (const char* (*)(int))dlsym(r.lib, "ncclGetErrorString");
         r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GroupStart && r.GroupEnd;
+        r.err = r.ok ? "" : "symbols missing";
     });
     return r;
 }
@@ -94,7 +99,7 @@ int orbx_comm_unique_id(uint8_t id[ORBX_COMM_ID_BYTES]) {
     memset(id, 0, ORBX_COMM_ID_BYTES);
 #ifndef ORBX_EMU
     Rccl& r = rccl();
-    if (!r.ok) return fail(ORBX_E_DEVICE, "librccl could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing");
+    if (!r.ok) return fail(ORBX_E_DEVICE, "librccl could not be loaded (%s)", r.err.c_str());
     NcclId nid; const int e = r.GetUniqueId(&nid);
     if (e) return fail(ORBX_E_DEVICE, "ncclGetUniqueId: %s", nccl_err(e));
     static_assert(sizeof(NcclId) == ORBX_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
@@ -124,7 +129,7 @@ int orbx_comm_create(orbx_comm** out, int world, int rank, const uint8_t id[ORBX
     if (rc) { orbx_comm_destroy(c); return rc; }
 #ifndef ORBX_EMU
     Rccl& r = rccl();
-    if (!r.ok) { orbx_comm_destroy(c); return fail(ORBX_E_DEVICE, "librccl could not be loaded"); }
+    if (!r.ok) { orbx_comm_destroy(c); return fail(ORBX_E_DEVICE, "librccl could not be loaded (%s)", r.err.c_str()); }
     NcclId nid; memcpy(&nid, id, sizeof nid);
     const int e = r.CommInitRank(&c->nccl, world, nid, rank);           // collective over the ranks: every rank calls it with the same id
     if (e) { orbx_comm_destroy(c); return fail(ORBX_E_DEVICE, "ncclCommInitRank(rank %d of %d, GPU %d): %s", rank, world, device_id, nccl_err(e)); }
@@ -178,11 +183,17 @@ int orbx_allgather_descriptors(orbx_extractor* h, orbx_comm* c, void** desc_all,
     if (!h || !c || h->lastB <= 0) return fail(ORBX_E_ARG, "nothing extracted yet / null");
     if (h->device != c->device) return fail(ORBX_E_ARG, "the extractor lives on GPU %d, the communicator on GPU %d", h->device, c->device);
     rt::set_device(c->device);
-    if (c->pending) { rt::event_sync(c->ev_done); c->pending = false; }           // the previous exchange still owns the buffers
     const int B = h->lastB, cap = h->kp_total_cap;
     const size_t db = (size_t)B * cap * 32, nb = sizeof(int) * (size_t)B, W = (size_t)c->world;
+    if (c->pending) {
+        // the previous exchange still reads the snapshot and writes the gathered blocks: this call's snapshot copies wait for it ON THE DEVICE (the
+        // handle's stream waits for ev_done), the host goes on; only a reallocation of the buffers needs the previous exchange to have finished
+        const bool grows = !(c->snap.p && db + nb + 64 <= c->snap.n && c->all.p && W * (db + nb) + 64 <= c->all.n);
+        if (grows) { rt::event_sync(c->ev_done); c->pending = false; }
+        else if (rt::stream_wait_event(h->s0, c->ev_done)) return fail(ORBX_E_DEVICE, "waiting for the previous exchange failed: %s", rt::last_error());
+    }
+    c->B = 0;                                                                      // nothing to fetch until this exchange has been enqueued completely
     if (c->snap.ensure(db + nb + 64) || c->all.ensure(W * (db + nb) + 64)) return fail(ORBX_E_DEVICE, "allocation failed (%zu bytes gathered)", W * (db + nb));
-    c->B = B; c->cap = cap; c->desc_bytes = db;
     // snapshot on the HANDLE's stream (behind the extraction that is producing the block), everything after it on the communicator's stream: the handle
     // is free for its next batch as soon as the two copies have run
     if (rt::copy_d2d(c->snap.p, h->d_desc.p, db, h->s0) || rt::copy_d2d(c->snap.p + db, h->d_nm.p, nb, h->s0) || rt::event_record(c->ev_snap, h->s0) ||
@@ -204,18 +215,19 @@ int orbx_allgather_descriptors(orbx_extractor* h, orbx_comm* c, void** desc_all,
         m.src[c->rank] = c->snap.p; m.bytes[c->rank] = db + nb;
         if (++m.arrived == m.world) { m.arrived = 0; m.generation++; m.cv.notify_all(); }
         else m.cv.wait(l, [&] { return m.generation != gen; });
-        for (int r = 0; r < m.world; r++) {
-            if (m.bytes[r] != db + nb) return fail(ORBX_E_ARG, "rank %d gathers blocks of another shape", r);
-            memcpy(all_desc + (size_t)r * db, m.src[r], db); memcpy(all_n + (size_t)r * nb, (const uint8_t*)m.src[r] + db, nb);
-        }
+        int odd = -1;
+        for (int r = 0; r < m.world; r++) if (m.bytes[r] != db + nb) odd = r;
+        for (int r = 0; r < m.world && odd < 0; r++) { memcpy(all_desc + (size_t)r * db, m.src[r], db); memcpy(all_n + (size_t)r * nb, (const uint8_t*)m.src[r] + db, nb); }
         // nobody may overwrite its snapshot before everybody has copied it
         const int gen2 = m.generation;
         if (++m.arrived == m.world) { m.arrived = 0; m.generation++; m.cv.notify_all(); }
         else m.cv.wait(l, [&] { return m.generation != gen2; });
+        if (odd >= 0) return fail(ORBX_E_ARG, "rank %d gathers blocks of another shape", odd);        // after the second rendezvous: no rank is left waiting
     }
 #endif
     if (rt::event_record(c->ev_done, c->stream)) return fail(ORBX_E_DEVICE, "event record failed");
     c->pending = true;
+    c->B = B; c->cap = cap; c->desc_bytes = db;
     if (desc_all) *desc_all = all_desc;
     if (n_all) *n_all = all_n;
     if (B_out) *B_out = B;

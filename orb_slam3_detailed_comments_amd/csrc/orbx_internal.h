@@ -44,7 +44,7 @@ template <typename T> struct HostBuf {
 // where the vocabulary transform of the last orbv_transform_extracted left the FeatureVectors of its frames (orbv_api.cpp), for the searches that
 // read them in place (orbm_search_by_bow_frames_batch): frame b's sorted node ids at fv_node + b * cap, CSR offsets at fv_start + b * (cap + 1),
 // feature indices at fv_feat + b * cap, its node count at nout[2 * b + 1]
-struct VocFrameArrays { const uint32_t* fv_node; const int* fv_start; const int* fv_feat; const int* nout; int cap, lastB, device, first; const void* handle; };
+struct VocFrameArrays { const uint32_t* fv_node; const int* fv_start; const int* fv_feat; const int* nout; int cap, lastB, device, first; const void* handle; uint64_t extract_gen; };
 }  // namespace orbx
 struct orbv_vocabulary;
 namespace orbx { int orbv_frame_arrays(const orbv_vocabulary* v, VocFrameArrays* out); }
@@ -94,6 +94,7 @@ struct orbx_extractor {
     orbx::rt::event_t ev_stage[ORBX_NSTAGES][2];
     bool profile = false, serial = false, have_streams = false;
     int lastB = 0;
+    uint64_t extract_gen = 0;     // counts the extractions enqueued on this handle: results derived from a batch (the vocabulary transform's FeatureVectors) name the one they belong to
     int debug_stereo_flags = 0;   // orbx_debug_stereo_flags (tests): bit 0 reversed candidate visiting order, bit 1 round-1 distance-only compare, bit 4 matrix form of Tcw * p (sophus_action.h)
     float stage_ms[ORBX_NSTAGES];
     // scratch of the projection / BoW searches (orbm_search.cpp)

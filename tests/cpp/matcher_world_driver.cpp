@@ -34,7 +34,7 @@ std::set<MapPoint*> KeyFrame::GetMapPoints() { std::set<MapPoint*> s; for (MapPo
 
 namespace {
 struct World {
-    std::vector<std::unique_ptr<GeometricCamera>> cams;
+    std::vector<GeometricCamera*> cams;                    // the reference's own Pinhole / KannalaBrandt8 (GeometricCamera has no virtual destructor: kept for the world's lifetime)
     std::vector<std::unique_ptr<MapPoint>> mps;
     std::vector<std::unique_ptr<Frame>> frames;
     std::vector<std::unique_ptr<KeyFrame>> kfs;
@@ -90,8 +90,8 @@ template <class HolderT> void fill_holder(World* w, HolderT& H, int N, const KP*
     H.mvScaleFactors[0] = 1.0f; H.mvLevelSigma2[0] = 1.0f;
     for (int i = 1; i < nlevels; i++) { H.mvScaleFactors[i] = H.mvScaleFactors[i - 1] * scale_factor; H.mvLevelSigma2[i] = H.mvScaleFactors[i] * H.mvScaleFactors[i]; }
     for (int i = 0; i < nlevels; i++) H.mvInvLevelSigma2[i] = 1.0f / H.mvLevelSigma2[i];
-    H.mpCamera = w->cams[cam].get(); H.mpCamera2 = cam2 >= 0 ? w->cams[cam2].get() : nullptr;
-    H.fx = H.mpCamera->mvParameters[0]; H.fy = H.mpCamera->mvParameters[1]; H.cx = H.mpCamera->mvParameters[2]; H.cy = H.mpCamera->mvParameters[3];
+    H.mpCamera = w->cams[cam]; H.mpCamera2 = cam2 >= 0 ? w->cams[cam2] : nullptr;
+    H.fx = H.mpCamera->getParameter(0); H.fy = H.mpCamera->getParameter(1); H.cx = H.mpCamera->getParameter(2); H.cy = H.mpCamera->getParameter(3);
     H.mbf = mbf; H.mb = mb;
     assign_grid(H, n_right >= 0 ? n_left : -1);
 }
@@ -127,10 +127,10 @@ void mw_destroy(void* w) {
 }
 
 int mw_add_camera(void* wv, float fx, float fy, float cx, float cy) {
-    World* w = (World*)wv; w->cams.emplace_back(new GeometricCamera(fx, fy, cx, cy)); return (int)w->cams.size() - 1;
+    World* w = (World*)wv; w->cams.push_back(new Pinhole(std::vector<float>{fx, fy, cx, cy})); return (int)w->cams.size() - 1;
 }
 int mw_add_camera_kb8(void* wv, const float* p8) {
-    World* w = (World*)wv; w->cams.emplace_back(new KannalaBrandt8(p8)); return (int)w->cams.size() - 1;
+    World* w = (World*)wv; w->cams.push_back(new KannalaBrandt8(std::vector<float>(p8, p8 + 8))); return (int)w->cams.size() - 1;
 }
 int mw_add_mappoint(void* wv, const float* pos, const float* normal, float min_dist, float max_dist, const uint8_t* desc, int bad, int n_obs) {
     World* w = (World*)wv;

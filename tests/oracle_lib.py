@@ -451,6 +451,21 @@ def reference_frame_lib():
     return _REF_FRAME
 
 
+_REF_FRAME_KNN = None
+
+
+def reference_frame_knn_lib():
+    """oracle/_ref/libref_frame_knn.so: the Frame driver built with a Kannala-Brandt camera whose TriangulateMatches accepts every pair (the
+    reference's KannalaBrandt8.cpp left out; oracle/ref_frame_driver.cpp, ORBX_KB8_ACCEPT_ALL)."""
+    global _REF_FRAME_KNN
+    if _REF_FRAME_KNN is None:
+        p = os.path.join(ORACLE_DIR, "_ref", "libref_frame_knn.so")
+        if not os.path.exists(p) and os.path.exists("/root/reference/src/Frame.cc"):
+            build()
+        _REF_FRAME_KNN = _bind_frame_lib(C.CDLL(p))
+    return _REF_FRAME_KNN
+
+
 def dropin_frame_lib(orbx_path):
     """oracle/_ref/libref_frame_dropin.so: the reference's own Frame.cc compiled against the drop-in ORBextractor.h, i.e. the
     reference's stereo Frame constructor running on the product library `orbx_path` (HIP or emulator build).  Load once per process."""
@@ -633,10 +648,11 @@ class ReferenceRigFrame:
 
 
 def reference_fisheye_frame(left, right, lap_left, lap_right, nfeatures=1500, scale=1.2, nlevels=8, ini=20, mn=7, gauss_variant=0, cams=None):
-    """The reference's fisheye-rig Frame constructor (src/Frame.cc:1432-1528).  cams = None: accept-all triangulation gate (the result is the
-    kNN + ratio decision); cams = (cam1[8], cam2[8], Rlr[3,3], tlr[3]): gate = KannalaBrandt8::TriangulateMatches (restated camera).
+    """The reference's fisheye-rig Frame constructor (src/Frame.cc:1432-1528).  cams = (cam1[8], cam2[8], Rlr[3,3], tlr[3]): the gate is the
+    reference's own KannalaBrandt8::TriangulateMatches (src/CameraModels/KannalaBrandt8.cpp compiled into libref_frame.so); cams = None: the
+    accept-all build (libref_frame_knn.so), whose result is the kNN + ratio decision alone.
     Returns dict(keys, keys_right, desc [Nleft+Nright,32], mono_left, mono_right, l2r, r2l, depth, p3d)."""
-    L = reference_frame_lib()
+    L = reference_frame_lib() if cams is not None else reference_frame_knn_lib()
     left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
     out = np.zeros(4, np.int32)
     cp = None
@@ -644,6 +660,7 @@ def reference_fisheye_frame(left, right, lap_left, lap_right, nfeatures=1500, sc
         cp = np.concatenate([np.asarray(c, np.float32).ravel() for c in cams]).astype(np.float32); assert cp.size == 28
     h = L.ref_frame_fisheye(left.ctypes.data, right.ctypes.data, left.shape[1], left.shape[0], nfeatures, scale, nlevels, ini, mn, gauss_variant,
                             lap_left[0], lap_left[1], lap_right[0], lap_right[1], None if cp is None else cp.ctypes.data, out.ctypes.data)
+    assert h, "ref_frame_fisheye refused (camera mode of the library does not match)"
     nl, nr, ml, mr = [int(v) for v in out]
     keys = np.zeros(nl, KP_DTYPE); keys_r = np.zeros(nr, KP_DTYPE); desc = np.zeros((nl + nr, 32), np.uint8)
     l2r = np.zeros(max(nl, 1), np.int32); r2l = np.zeros(max(nr, 1), np.int32)

@@ -31,6 +31,8 @@ def test_bench_two_ranks_gloo(emu_lib):
     assert res["roofline"]["kernel"] in res["stage_ms_alone"] and res["roofline"]["avg_launch_ms"] > 0
     assert "cpu_baseline" not in res and "h2d_inclusive" not in res          # rank-0 / N = 1 extras only
     assert res["config"]["parallelism"].startswith("independent streams, 2 GPU")
+    pr = res["per_rank"]                                                     # every rank's own rate: a straggler is visible in the line
+    assert len(pr["values"]) == 2 and pr["min"] == min(pr["values"]) and pr["max"] == max(pr["values"]) and abs(2 * pr["min"] - res["value"]) < 0.2
 
 
 def test_bench_launches_its_own_ranks(emu_lib):
@@ -64,3 +66,30 @@ def test_bench_refuses_more_ranks_than_gpus():
     n = torch.cuda.device_count() + 1
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(max(n, 2))], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
     assert r.returncode != 0 and "one process per GPU" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu(hip_lib):
+    """Pre-flight of the multi-GPU run on a 1-GPU box: `bench.py --gpus 2` with the HIP library, two processes on GPU 0,
+    rendezvous / barriers / max over ranks over gloo (RCCL refuses two ranks on one device).  The ranks share the GPU, so the whole-job value is about
+    the 1-rank rate, not twice it; what is checked is the protocol with the real library and that no rank starves."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "ORBX_BENCH_LIB"):
+        env.pop(k, None)
+    env.update(ORBX_BENCH_BACKEND="gloo")
+    common = ["--steps", "20", "--warmup", "5", "--pairs", "64", "--handles", "2", "--no-cpu-baseline", "--no-h2d", "--no-other-configs", "--no-latency", "--min-seconds", "1"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
+    r1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r2 = json.loads(lines[0])
+    assert r2["n_gpus"] == 2 and r2["config"]["library"] == "liborbx_hip.so" and r2["parity_check"]["identical"] is True
+    assert 0.6 * r1["value"] < r2["value"] < 1.5 * r1["value"], (r1["value"], r2["value"])             # one GPU's worth of work, shared
+    pr = r2["per_rank"]
+    assert len(pr["values"]) == 2 and pr["min"] > 0.25 * r1["value"], pr                                # nobody starves

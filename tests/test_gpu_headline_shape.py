@@ -96,7 +96,7 @@ def test_headline_shape_stereo_gpu(hip_lib, P, graph, profile):
 @pytest.mark.skipif(ol.reference_frame_lib() is None, reason="oracle/_ref/libref_frame.so not built (needs /root/reference)")
 def test_headline_shape_fisheye_gpu(hip_lib):
     """BASELINE.json configs[2] at the size bench.py --config fisheye runs it: 64 pairs per handle, four handles, lapping {0, 511}"""
-    from test_kb8 import CAM1, CAM2, RLR, TLR, _fisheye_pair
+    from test_kb8 import CAM1, CAM2, RLR, MRLR, TLR, _fisheye_pair
     lib, P, NH, nf, lap, nunique = hip_lib, 64, 4, 1500, (0, 511), 16
     uniq = [_fisheye_pair(400 + i) for i in range(nunique)]
     handles = [ORBextractor(nf, 1.2, 8, 20, 7, lib=lib) for _ in range(NH)]
@@ -105,7 +105,7 @@ def test_headline_shape_fisheye_gpu(hip_lib):
     class Cams(C.Structure):
         _fields_ = [("cam1", C.c_float * 8), ("cam2", C.c_float * 8), ("R12", C.c_float * 9), ("t12", C.c_float * 3)]
     kb = Cams()
-    kb.cam1[:] = CAM1; kb.cam2[:] = CAM2; kb.R12[:] = RLR.ravel().tolist(); kb.t12[:] = TLR.tolist()
+    kb.cam1[:] = CAM1; kb.cam2[:] = CAM2; kb.R12[:] = MRLR.ravel().tolist(); kb.t12[:] = TLR.tolist()
     ups, outs = [], []
     for i, h in enumerate(handles):
         ups.append(h.input_upload(np.stack([uniq[u][0] for u in order[i]] + [uniq[u][1] for u in order[i]])))

@@ -3,7 +3,7 @@
 ORBmatcher::SearchByProjection with its right-camera branch (src/ORBmatcher.cc:170-236) - orbm_is_in_frustum_rig / orbm_search_local_points_fisheye.
 
 Checker: the reference's own Frame.cc (fisheye-rig constructor, SetPose, isInFrustum) and ORBmatcher.cc compiled in place
-(oracle/_ref/libref_frame.so) over the Kannala-Brandt camera restated in oracle/slam_shim/kb8_camera.h (KannalaBrandt8::project :87-104; the
+(oracle/_ref/libref_frame.so) over the reference's own KannalaBrandt8.cpp (KannalaBrandt8::project :87-104; the
 camera arithmetic itself is restated on both sides - see DESIGN.md section 2).  Bar: mbTrackInView / mbTrackInViewR and every stored field
 bit-identical, the same keypoint -> map point assignment over both cameras."""
 import numpy as np

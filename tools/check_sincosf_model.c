@@ -1,4 +1,4 @@
-/* Exhaustive check of csrc/glibc_sincosf_model.h against the live libm for every float in [0, 6.5].
+/* Exhaustive check of csrc/glibc_sincosf_model.h against the live libm for every float in [-6.5, 6.5].
    Build: g++ -O2 -ffp-contract=off -x c++ tools/check_sincosf_model.c -Iorb_slam3_detailed_comments_amd/csrc -lpthread -o /tmp/chk && /tmp/chk
    (about 3 s on 8 cores).  Result recorded in DESIGN.md. */
 #include <math.h>
@@ -14,6 +14,8 @@ static void* run(void* a) {
     Job* j = (Job*)a;
     for (uint32_t u = j->lo; u < j->hi; u++) {
         float x = asf(u);
+        if (asu(cosf(x)) != asu(orbx::glibc_cosf(x)) || asu(sinf(x)) != asu(orbx::glibc_sinf(x))) j->bad++;
+        x = -x;            /* psi = atan2f(y, x) of KannalaBrandt8::project is in [-pi, pi] */
         if (asu(cosf(x)) != asu(orbx::glibc_cosf(x)) || asu(sinf(x)) != asu(orbx::glibc_sinf(x))) j->bad++;
     }
     return 0;
