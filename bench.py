@@ -13,6 +13,7 @@ Prints ONE JSON line (rank 0).  See DESIGN.md §Measurement for the roofline / c
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -110,19 +111,42 @@ def cpu_baseline(seconds_budget=6.0):
             return n, dt, out[0][2], ext, st
 
         res = {}
-        settings = [("one_core", avail[:1], 1), ("two_cores", avail[:2], 1), ("all_cores", avail, max(1, cores // 2))]
-        for name, cpus, streams in settings:
+        for name, cpus in (("one_core", avail[:1]), ("two_cores", avail[:2])):
             if hasattr(os, "sched_setaffinity"):
                 os.sched_setaffinity(0, set(cpus))
-            n, dt, matches, ext, st = run(streams, seconds_budget)
-            res[name] = {"value": round(n / dt, 2), "cores": len(cpus), "pair_streams": streams, "pairs": n, "seconds": round(dt, 2),
+            n, dt, matches, ext, st = run(1, seconds_budget)
+            res[name] = {"value": round(n / dt, 2), "cores": len(cpus), "pair_streams": 1, "pairs": n, "seconds": round(dt, 2),
                          "stage_ms": {"ORB Extraction": round(ext, 3), "Stereo Matching": round(st, 3)}, "stereo_matches_last_pair": matches}
         if hasattr(os, "sched_setaffinity"):
             os.sched_setaffinity(0, set(avail))
+        # every core: one PROCESS per pair stream (a fresh interpreter: no threads, no GPU runtime inherited), each pinned to two cores of its own - the
+        # two std::threads of the reference's constructor.  (Rounds 1-4 ran the streams as threads of this process: 128 streams x 2 std::threads created
+        # per frame in one address space measured the allocator and thread creation, 11.6x on 256 cores.)
+        streams = max(1, cores // 2)
+        start_at = time.time() + 2.0 + 0.02 * streams
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "%d,%d,%.3f,%.3f,%d" % (avail[2 * t], avail[min(2 * t + 1, cores - 1)], start_at, seconds_budget, 1000 + t)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for t in range(streams)]
+        outs = []
+        for pr in procs:
+            o, _ = pr.communicate()
+            lines = [l for l in o.splitlines() if l.startswith("{")]
+            if pr.returncode == 0 and lines:
+                outs.append(json.loads(lines[-1]))
+        if outs:
+            n = sum(o["pairs"] for o in outs)
+            window = max(o["t_end"] for o in outs) - min(o["t_start"] for o in outs)
+            per = [o["pairs"] / o["seconds"] for o in outs]
+            res["all_cores"] = {"value": round(n / window, 2), "cores": cores, "pair_streams": len(outs), "pairs": n, "seconds": round(window, 2),
+                                "stage_ms": {"ORB Extraction": round(sum(o["ext_ms"] for o in outs) / max(n, 1), 3), "Stereo Matching": round(sum(o["stereo_ms"] for o in outs) / max(n, 1), 3)},
+                                "stereo_matches_last_pair": outs[0]["matches"], "processes": len(outs), "late_starters": sum(1 for o in outs if o["late"]),
+                                "per_stream_pairs_per_s": {"min": round(min(per), 2), "max": round(max(per), 2)},
+                                "scaling_efficiency_vs_two_cores": round(n / window / (res["two_cores"]["value"] * len(outs)), 3)}
+        else:
+            res["all_cores"] = dict(res["two_cores"], note="worker processes failed; two_cores repeated")
         a = res["all_cores"]
-        sample = ("%d pairs in %.1f s: %d concurrent streams of the reference's own stereo Frame constructor (src/Frame.cc:105-230 = 2 extractor threads + "
-                  "ComputeStereoMatches + grid) on %d cores; one_core / two_cores = one stream with the process pinned to 1 / 2 cores; OpenCV primitives are the "
-                  "scalar shim, not SIMD OpenCV, so this under-states a real OpenCV build" % (a["pairs"], a["seconds"], a["pair_streams"], a["cores"]))
+        sample = ("%d pairs in %.1f s: %d concurrent PROCESSES, each one stream of the reference's own stereo Frame constructor (src/Frame.cc:105-230 = 2 extractor threads + "
+                  "ComputeStereoMatches + grid) pinned to 2 cores of its own, on %d cores; one_core / two_cores = one stream with the process pinned to 1 / 2 cores; OpenCV "
+                  "primitives are the scalar shim, not SIMD OpenCV, so this under-states a real OpenCV build" % (a["pairs"], a["seconds"], a["pair_streams"], a["cores"]))
         return {"value": a["value"], "unit": "stereo pairs/s", "cores": a["cores"], "kind": "reference", "sample": sample,
                 "one_core": res["one_core"], "two_cores": res["two_cores"], "all_cores": a, "stage_ms": a["stage_ms"]}
     pairs = [synth.stereo_pair(W, H, seed=1000 + i) for i in range(cores)]
@@ -148,6 +172,26 @@ def cpu_baseline(seconds_budget=6.0):
     return {"value": round(n / dt, 2), "unit": "stereo pairs/s", "cores": cores, "kind": "port", "sample": sample}
 
 
+def cpu_worker(spec):
+    """One pair stream of cpu_baseline's all-core setting, in a process of its own: pinned to two cores, waits for the common start time, runs the
+    reference's stereo Frame constructor for the given time and prints its counts."""
+    c0, c1, start_at, secs, seed = spec.split(",")
+    if hasattr(os, "sched_setaffinity"):
+        os.sched_setaffinity(0, {int(c0), int(c1)})
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    from orb_slam3_detailed_comments_amd import synth
+    c = CONFIGS["stereo"]
+    L, R = synth.stereo_pair(c["W"], c["H"], seed=int(seed))
+    ol.reference_frame_repeat(L, R, 0.0, c["nf"], fx=FX, bf=BF)                   # library loaded, tables built, one frame through
+    late = time.time() > float(start_at)
+    while time.time() < float(start_at):
+        time.sleep(0.001)
+    t0 = time.time()
+    n, el, m, ext, st = ol.reference_frame_repeat(L, R, float(secs), c["nf"], fx=FX, bf=BF)
+    print(json.dumps({"pairs": n, "seconds": el, "t_start": t0, "t_end": time.time(), "matches": m, "ext_ms": ext, "stereo_ms": st, "late": late}))
+
+
 def kernel_sources_sha():
     """sha256 (16 hex digits) over the device sources of the library: the stamp that ties counter summaries under profiles/ to the kernels they measured."""
     import hashlib
@@ -159,14 +203,16 @@ def kernel_sources_sha():
     return hsh.hexdigest()[:16]
 
 
-def other_configs(seconds=1.2):
+def other_configs(seconds=2.5):
     """BASELINE.json configs 0, 2 and 3 beside the headline, in the driver's own line: each is this file run as a child process (`--config X`), i.e. the
     same setup, warm-up, barrier-bracketed timed region (>= `seconds`) and roofline arithmetic as the headline, reduced to the key figures."""
     import subprocess
     out = {}
-    for name in ("mono", "fisheye", "rgbd"):
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", "20", "--warmup", "5", "--min-seconds", str(seconds), "--no-cpu-baseline", "--no-h2d",
-               "--no-other-configs"]
+    for name in ("mono", "fisheye", "rgbd", "stereo_natural"):
+        # stereo_natural: the headline's configuration on the second generator (--workload natural: camera-like imagery, 1-5 % FAST corner density
+        # instead of the corner field's 23.5 %) - no EuRoC frame can be had offline, this is the closest the run can get to one
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", "stereo" if name == "stereo_natural" else name, "--steps", "20", "--warmup", "5", "--min-seconds", str(seconds),
+               "--no-cpu-baseline", "--no-h2d", "--no-other-configs", "--no-latency"] + (["--workload", "natural"] if name == "stereo_natural" else [])
         t0 = time.time()
         try:
             pr = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
@@ -179,6 +225,7 @@ def other_configs(seconds=1.2):
                          "units_per_step": r["config"]["units_per_step_per_gpu"], "workload": r["config"]["workload"], "input_mode": r["config"]["input_mode"],
                          "roofline": {k: r["roofline"][k] for k in ("kernel", "frac", "achieved", "avg_launch_ms", "alone_launch_ms", "end_to_end_frac")},
                          "avg_keypoints_per_image": r["config"]["avg_keypoints_per_image"], "avg_matches_per_unit": r["config"]["avg_matches_per_unit"],
+                         "generator": r["config"].get("generator"), "fast_corner_density": next((v for k, v in r["config"].items() if k.startswith("fast_corner_density")), None),
                          "parity_check": r.get("parity_check"),
                          "wall_seconds_of_child": round(time.time() - t0, 1)}
         except Exception as e:
@@ -234,7 +281,11 @@ def main():
                     "per-kernel averages of rocprofv3 are averages over the timed launches)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the second, PCIe-inclusive measurement (never `value`)")
     ap.add_argument("--h2d", action="store_true", help="make the PCIe-inclusive variant the timed loop (NOT the headline value)")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)        # one pair stream of cpu_baseline's all-core setting (internal)
     args = ap.parse_args()
+    if args.cpu_worker:
+        cpu_worker(args.cpu_worker)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus)
     cfg = CONFIGS[args.config]
@@ -348,7 +399,8 @@ def main():
         class Cams(C.Structure):
             _fields_ = [("cam1", C.c_float * 8), ("cam2", C.c_float * 8), ("R12", C.c_float * 9), ("t12", C.c_float * 3)]
         kb = Cams()
-        kb.cam1[:] = KB_CAM1; kb.cam2[:] = KB_CAM2; kb.R12[:] = sophus.SE3f(KB_RLR, KB_TLR).rotationMatrix().ravel().tolist()          # mRlr (src/Frame.cc:1498-1501); kb.t12[:] = KB_TLR.tolist()
+        kb.cam1[:] = KB_CAM1; kb.cam2[:] = KB_CAM2; kb.t12[:] = KB_TLR.tolist()
+        kb.R12[:] = sophus.SE3f(KB_RLR, KB_TLR).rotationMatrix().ravel().tolist()          # mRlr = mTlr.rotationMatrix() (src/Frame.cc:1498-1501)
     local_map = None
     if kind == "rgbd":
         # BASELINE.json configs[3]: per frame ComputeStereoFromRGBD (uRight from the depth image) + Tracking::SearchLocalPoints against a local map
@@ -641,9 +693,9 @@ def main():
         if zero_copy and not args.h2d:
             ab["import"] = 0                                   # level 0 is read where the producer wrote it
         if kind == "rgbd":
-            # the batched local-point search per frame: 5000 points x (88 B resident point + 32 B query written and read) + ~4 candidates per point
-            # x (28 B keypoint + 32 B descriptor + 4 B uRight read, 8 B entry written and read)
-            ab["match"] = 5000 * (88 + 64) + 4 * 5000 * (64 + 16)
+            # M4 = 5000 map points x (32 B descriptor + 20 candidates x 32 B) = 3.36 MB per frame.  (Rounds 3-4 priced this
+            # kernel on what the batched search actually moves - 5000 x (88 + 64) + 4 x 5000 x (64 + 16) = 2.36 MB - the survey's figure is the contract.)
+            ab["match"] = 5000 * (32 + 20 * 32)
         units = {k: NIMG for k in ab}
         units["match"] = P
         # Which kernel dominates is decided on a clean schedule: a few extra steps on ONE handle with every kernel alone on one
@@ -744,8 +796,19 @@ def main():
                     h.profile(False)
                 n2 = max(min(args.steps, 100), 10)
                 dt2, per2, _ = timed(n2, True)
+                # what the link gives by itself, same box, same run: the same page-locked batch uploaded back to back on one copy stream, nothing else running
+                sync_all()
+                h0 = handles[0]
+                h0.device_upload_async(dbuf[0][0], host_in[0]); h0.sync()
+                tp = time.perf_counter()
+                for _ in range(8):
+                    h0.device_upload_async(dbuf[0][0], host_in[0])
+                h0.sync()
+                probe = 8 * batch.nbytes / (time.perf_counter() - tp) / 1e9
                 res["h2d_inclusive"] = {"value": round(P * n2 / dt2, 1), "unit": cfg["unit"], "steps": n2, "ms_per_step": round(dt2 / n2 * 1e3, 4),
                                         "input_MB_per_step": round(batch.nbytes / 1e6, 1), "PCIe_GBps": round(batch.nbytes * n2 / dt2 / 1e9, 1),
+                                        "PCIe_probe_GBps": round(probe, 1), "PCIe_frac": round(batch.nbytes * n2 / dt2 / 1e9 / probe, 3),
+                                        "PCIe_probe": "8 uploads of one %0.1f-MB batch from page-locked memory (hipMemcpyAsync) on one copy stream, alone" % (batch.nbytes / 1e6),
                                         "step_ms": {"median": round(pct(per2, 50), 4), "p10": round(pct(per2, 10), 4), "p90": round(pct(per2, 90), 4)}}
             except Exception as e:
                 res["h2d_inclusive"] = {"value": None, "error": repr(e)}

@@ -626,6 +626,7 @@ int orbx_sync(orbx_extractor* h) {
     if (!h) return fail(ORBX_E_ARG, "null handle");
     rt::set_device(h->device);
     if (rt::stream_sync(h->s0) || rt::stream_sync(h->s1)) return fail(ORBX_E_DEVICE, "stream sync failed: %s", rt::last_error());
+    if (h->copy_pending && rt::stream_sync(h->s_copy)) return fail(ORBX_E_DEVICE, "copy stream sync failed: %s", rt::last_error());   // uploads nobody has consumed yet
     if (h->profile) for (int i = 0; i < ORBX_NSTAGES; i++) if (i != ST_MATCH) h->stage_ms[i] = rt::event_elapsed_ms(h->ev_stage[i][0], h->ev_stage[i][1]);
     return ORBX_OK;
 }

@@ -3,8 +3,8 @@
 ORBmatcher::SearchByProjection with its right-camera branch (src/ORBmatcher.cc:170-236) - orbm_is_in_frustum_rig / orbm_search_local_points_fisheye.
 
 Checker: the reference's own Frame.cc (fisheye-rig constructor, SetPose, isInFrustum) and ORBmatcher.cc compiled in place
-(oracle/_ref/libref_frame.so) over the reference's own KannalaBrandt8.cpp (KannalaBrandt8::project :87-104; the
-camera arithmetic itself is restated on both sides - see DESIGN.md section 2).  Bar: mbTrackInView / mbTrackInViewR and every stored field
+(oracle/_ref/libref_frame.so) over the reference's own KannalaBrandt8.cpp (KannalaBrandt8::project :87-104, compiled unmodified:
+DESIGN.md section 2).  Bar: mbTrackInView / mbTrackInViewR and every stored field
 bit-identical, the same keypoint -> map point assignment over both cameras."""
 import numpy as np
 import pytest
