@@ -70,7 +70,7 @@ public:
             // device objects belong to one GPU: when SetDevice / SetThreadDevice has moved this thread to another one, everything cached for the
             // previous GPU is dropped and uploaded again on demand (a search would otherwise refuse the pair: "bad key frame")
             if (device != Device()) { Clear(); device = Device(); }
-            const Tag tag = {(long long)pKF->mnId, (long long)pKF->N, (long long)pKF->mFeatVec.size()};
+            const Tag tag = {(long long)pKF->mnId, (long long)pKF->N, (long long)pKF->mFeatVec.size(), Fingerprint(pKF)};
             auto it = m.find(pKF);
             if (it != m.end()) {
                 if (it->second.tag == tag) return it->second.dev;
@@ -95,12 +95,37 @@ public:
     private:
         ResidentKeyFrames(const ResidentKeyFrames&);
         ResidentKeyFrames& operator=(const ResidentKeyFrames&);
-        struct Tag { long long id, n, nodes; bool operator==(const Tag& o) const { return id == o.id && n == o.n && nodes == o.nodes; } };
+        struct Tag { long long id, n, nodes; unsigned long long print; bool operator==(const Tag& o) const { return id == o.id && n == o.n && nodes == o.nodes && print == o.print; } };
+        // eight descriptor rows spread over the key frame, folded into 64 bits: tells apart two key frames that reuse an address AND an id (a second SLAM
+        // system in the process, a test that builds world after world); 256 bytes read per lookup
+        static unsigned long long Fingerprint(KeyFrameT* pKF)
+        {
+            unsigned long long f = 0x9E3779B97F4A7C15ull;
+            const int n = pKF->mDescriptors.rows;
+            for (int k = 0; k < 8 && n > 0; k++) {
+                unsigned long long w[4];
+                memcpy(w, pKF->mDescriptors.ptr((int)((long long)k * (n - 1) / 7)), 32);
+                for (int i = 0; i < 4; i++) { f ^= w[i]; f *= 0x100000001B3ull; f ^= f >> 29; }
+            }
+            return f;
+        }
         struct Entry { orbm_keyframe* dev; Tag tag; };
         std::map<KeyFrameT*, Entry> m;
         orbm_keyframe* transient = nullptr;
         int device = -1;
     };
+    // The cache behind the reference's own single-call signatures (SearchByBoW(pKF, F, ...) of Tracking.cc:3183 / :4371, SearchForTriangulation(pKF1, pKF2, ...)
+    // of LocalMapping.cc:610): one per calling thread and key-frame type, so an unchanged call site pays the upload of a key frame once, not per call.
+    // Nothing tells it when the map erases a key frame (an unchanged caller has no Erase to call), so it is bounded instead: beyond
+    // kImplicitCacheEntries key frames it is emptied and refills on demand (a key frame is ~64 B per keypoint + its FeatureVector on the device).
+    enum { kImplicitCacheEntries = 4096 };
+    template <class KeyFrameT>
+    static ResidentKeyFrames<KeyFrameT>& ImplicitCache()
+    {
+        static thread_local ResidentKeyFrames<KeyFrameT> c;
+        if (c.size() > (size_t)kImplicitCacheEntries) c.Clear();
+        return c;
+    }
 
     // Computes the Hamming distance between two ORB descriptors (src/ORBmatcher.cc:2383).
     static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b)
@@ -272,6 +297,13 @@ public:
     template <class KeyFrameT, class FrameT, class MapPointT>
     int SearchByBoW(KeyFrameT* pKF, FrameT &F, std::vector<MapPointT*> &vpMapPointMatches)
     {
+        if (F.Nleft == -1 && !pKF->mpCamera2 && !pKF->mFeatVec.empty()) {
+            // one camera: the key frame stays on the device between calls (ImplicitCache), the frame goes up once, the accept loop runs on the device
+            std::vector<std::vector<MapPointT*> > vv;
+            const std::vector<int> counts = SearchByBoW(std::vector<KeyFrameT*>(1, pKF), F, ImplicitCache<KeyFrameT>(), vv);
+            vpMapPointMatches.swap(vv[0]);
+            return counts[0];
+        }
         const std::vector<MapPointT*> vpMapPointsKF = pKF->GetMapPointMatches();
         vpMapPointMatches = std::vector<MapPointT*>(F.N,static_cast<MapPointT*>(NULL));
         const bool rig = F.Nleft != -1;
@@ -419,6 +451,14 @@ public:
     template <class KeyFrameT>
     int SearchForTriangulation(KeyFrameT *pKF1, KeyFrameT* pKF2, std::vector<std::pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo, const bool bCoarse = false)
     {
+        if (pKF1->N > 0 && !pKF1->mFeatVec.empty() && !pKF2->mFeatVec.empty()) {
+            // both key frames stay on the device between calls (ImplicitCache): LocalMapping::CreateNewMapPoints asks for the same pKF1 against every
+            // neighbour in a row, and a neighbour comes back for many key frames - nothing but the per-call flags and the pose-dependent matrices goes up
+            std::vector<std::vector<std::pair<size_t, size_t> > > vv;
+            const std::vector<int> counts = SearchForTriangulation(pKF1, std::vector<KeyFrameT*>(1, pKF2), ImplicitCache<KeyFrameT>(), vv, bOnlyStereo, bCoarse);
+            vMatchedPairs.swap(vv[0]);
+            return counts[0];
+        }
         float f12[9], epf[2];
         if (pKF1->mpCamera->GetType() == 1 /* GeometricCamera::CAM_FISHEYE */) {
             Epipole(pKF1, pKF2, epf);

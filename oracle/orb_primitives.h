@@ -290,6 +290,11 @@ static inline void gaussian_blur7_u8(const uint8_t* src, int w, int h, size_t ss
 }
 
 // ---- cv::fastAtan2(y, x): degrees in [0,360], fp32 polynomial, no FMA contraction ---------------
+// (pinned even inside a translation unit built with the reference's own -O3 -march=native, oracle/Makefile _ref/libref_orb_native.so: OpenCV is a
+// separately built library, the flags of the reference's CMakeLists.txt do not reach it)
+#if defined(__GNUC__) && !defined(__clang__)
+__attribute__((optimize("fp-contract=off")))
+#endif
 static inline float fast_atan2_deg(float y, float x) {
     const float s = (float)(180.0 / 3.1415926535897932384626433832795);
     const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s;

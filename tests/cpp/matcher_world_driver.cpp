@@ -120,6 +120,9 @@ int mw_real_classes() {
 }
 void* mw_create() { return new World(); }
 void mw_destroy(void* w) {
+#ifdef MW_FACADE
+    ORBmatcher::ImplicitCache<KeyFrame>().Clear();      // the world's key frames die with it (a SLAM system keeps its map; a test builds world after world)
+#endif
 #ifdef MW_FULL
     for (auto& k : ((World*)w)->kfs) k.release();      // arena objects (never freed: a test process)
 #endif

@@ -56,11 +56,12 @@ def oracle():
     return _ORACLE
 
 
-def reference():
-    """The reference's own ORBextractor.cc built against the shim (oracle/_ref); None if absent."""
+def reference(fma=False):
+    """The reference's own ORBextractor.cc built against the shim (oracle/_ref); None if absent.  fma = True: the build with the reference's own
+    optimisation flags on an FMA host (-O3, AVX2 + FMA, contraction on: oracle/Makefile _ref/libref_orb_fma.so) - not cached, for tests/test_fma_contract.py."""
     global _REF
-    if _REF is None:
-        p = os.path.join(ORACLE_DIR, "_ref", "libref_orb.so")
+    if _REF is None or fma:
+        p = os.path.join(ORACLE_DIR, "_ref", "libref_orb_fma.so" if fma else "libref_orb.so")
         if not os.path.exists(p) and os.path.exists("/root/reference/src/ORBextractor.cc"):
             build()
         if not os.path.exists(p):
@@ -74,6 +75,8 @@ def reference():
         L.ref_orb_pyramid_level.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ref_orb_keypoints_per_level.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.ref_orb_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+        if fma:
+            return L
         _REF = L
     return _REF
 
@@ -136,8 +139,8 @@ class OracleExtractor:
 class ReferenceExtractor:
     """The reference's own ORBextractor (src/ORBextractor.cc) built against the OpenCV shim."""
 
-    def __init__(self, nfeatures=1200, scale=1.2, nlevels=8, ini=20, mn=7, gauss_variant=0):
-        self.L = reference()
+    def __init__(self, nfeatures=1200, scale=1.2, nlevels=8, ini=20, mn=7, gauss_variant=0, fma=False):
+        self.L = reference(fma)
         assert self.L is not None, "oracle/_ref/libref_orb.so missing"
         self.nlevels = nlevels
         self.gv = gauss_variant

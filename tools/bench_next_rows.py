@@ -101,6 +101,28 @@ def main():
     for name, host_views, resident, cpu in raw:
         out[name + " (C ABI, no Python wrapper)"] = {"gpu_ms_host_views": round(best(host_views, 10), 3), "gpu_ms_resident_key_frames": round(best(resident, 10), 3),
                                                        "cpu_oracle_ms": round(best(cpu, 3), 3)}
+    # The reference's own single-call signatures at the C ABI, the way the facade serves an UNCHANGED call site since round 5 (ORBmatcher::ImplicitCache:
+    # key frames stay on the device between calls): SearchForTriangulation(pKF1, pKF2, ...) = one resident search with one neighbour;
+    # SearchByBoW(pKF, F, ...) = the frame uploaded as a transient object + one resident search + its release.  Beside them the floor of ANY synchronous
+    # device call: 32 bytes up, one tiny kernel, 4 bytes down, host waits (orbm_hamming_matrix on one pair of descriptors).
+    r2v1 = vp([rk2._kf]); f2v1 = vp([f2.ctypes.data]); r1v1 = vp([rk1._kf]); f1v1 = vp([f1.ctypes.data]); po1 = vp([m10[0].ctypes.data])
+    one = np.zeros(1, np.int32); da = np.zeros(32, np.uint8); db = np.ones(32, np.uint8)
+
+    def bow_one():
+        rf = C.c_void_p()
+        L.orbm_keyframe_create(ex._h, kf2[0].ref(), C.byref(rf))
+        L.orbm_search_by_bow_resident(ex._h, 1, r1v1, f1v1, vp([rf]), None, 0.7, 1, 1, po1, nm10.ctypes.data)
+        L.orbm_keyframe_destroy(rf)
+    floor = round(best(lambda: L.orbm_hamming_matrix(ex._h, da.ctypes.data, 1, db.ctypes.data, 1, one.ctypes.data), 50), 4)
+    out["single calls at the C ABI, key frames resident (the unchanged facade call sites)"] = {
+        "synchronous_round_trip_floor_ms": floor,
+        "SearchForTriangulation(pKF1, pKF2) gpu_ms": round(best(lambda: L.orbm_search_for_triangulation_resident(ex._h, rk1._kf, f1.ctypes.data, 1, r2v1, f2v1, Fs.ctypes.data, Es.ctypes.data, 0, 0, 0,
+                                                                                                                   m20.ctypes.data, nm20.ctypes.data), 30), 4),
+        "SearchForTriangulation(pKF1, pKF2) cpu_oracle_ms": round(best(lambda: OL.orbo_search_for_triangulation(kf1[0].ref(), kf2[0].ref(), F9.ctypes.data, E2.ctypes.data, 0, 0, 0, mo.ctypes.data), 10), 4),
+        "SearchByBoW(pKF, F) gpu_ms": round(best(bow_one, 30), 4),
+        "SearchByBoW(pKF, F) gpu_ms_both_resident": round(best(lambda: L.orbm_search_by_bow_resident(ex._h, 1, r1v1, f1v1, r2v1, f2v1, 0.7, 1, 1, po1, nm10.ctypes.data), 30), 4),
+        "SearchByBoW(pKF, F) cpu_oracle_ms": round(best(lambda: OL.orbo_search_by_bow(kf1[0].ref(), kf2[0].ref(), 0.7, 1, 1, mo.ctypes.data), 10), 4),
+        "note": "a CPU function that takes less than the round-trip floor cannot be beaten by a synchronous device call, whatever the kernel; the batched / neighbour forms amortise the floor"}
     # Tracking::SearchLocalPoints: Frame::isInFrustum for 5000 map points + SearchByProjection on those in view, device vs the reference's own
     # Frame.cc / ORBmatcher.cc (oracle/_ref/libref_frame.so)
     if ol.reference_frame_lib() is not None:
