@@ -932,7 +932,7 @@ static int search_for_triangulation_impl(orbx_extractor* h, const OrbmKeyFrameVi
                 pk.dev<KeyPointRec>(pk2), pk.dev<unsigned long long>(pd2), pk.dev<float>(pu2),
                 pk.dev<uint8_t>(pm2), pk.dev<int>(pf2), pk.dev<BowParams>(pps), h->d_si[SI_BEST].p);
     std::vector<int> best(items.size());
-    if (rt::copy_d2h(best.data(), h->d_si[SI_BEST].p, sizeof(int) * items.size(), h->s0) || rt::stream_sync(h->s0) || rt::check_launch())
+    if (fetch_sync(h, best.data(), h->d_si[SI_BEST].p, sizeof(int) * items.size()) || rt::check_launch())
         return fail(ORBX_E_DEVICE, "bow search failed: %s", rt::last_error());
     for (int j = 0; j < n2; j++) {
         const OrbmKeyFrameView* K2 = K2s[j];
@@ -1034,7 +1034,7 @@ int orbm_search_by_bow_batch(orbx_extractor* h, int n, const OrbmKeyFrameView* c
     ORBX_LAUNCH(k_bow_dists, grid, blk, 0, h->s0, pk.dev<BowItem>(pit), (int)items.size(), pk.dev<unsigned long long>(pd1), pk.dev<unsigned long long>(pd2),
                 pk.dev<uint8_t>(pel), pk.dev<int>(pf2), h->d_si[SI_BEST].p);
     std::vector<int> dist((size_t)total);
-    if (rt::copy_d2h(dist.data(), h->d_si[SI_BEST].p, sizeof(int) * (size_t)total, h->s0) || rt::stream_sync(h->s0) || rt::check_launch())
+    if (fetch_sync(h, dist.data(), h->d_si[SI_BEST].p, sizeof(int) * (size_t)total) || rt::check_launch())
         return fail(ORBX_E_DEVICE, "bow distances failed: %s", rt::last_error());
     for (int p = 0; p < n; p++) {
         const OrbmKeyFrameView *K1 = K1s[p], *K2 = K2s[p];
@@ -1194,7 +1194,7 @@ static int sft_resident_impl(orbx_extractor* h, orbm_keyframe* K1, const uint8_t
     dim3 grid((N1 + 3) / 4, n2, 1), blk(256, 1, 1);
     if (kb8) ORBX_LAUNCH(k_sft_resident_kb8, grid, blk, 0, h->s0, K1->dev, pk.dev<uint8_t>(pf), pk.dev<SftNeighbour>(pn), h->d_si[SI_BEST].p);
     else ORBX_LAUNCH(k_sft_resident, grid, blk, 0, h->s0, K1->dev, pk.dev<uint8_t>(pf), pk.dev<SftNeighbour>(pn), h->d_si[SI_BEST].p);
-    if (rt::copy_d2h(matches12, h->d_si[SI_BEST].p, sizeof(int) * (size_t)n2 * N1, h->s0) || rt::stream_sync(h->s0) || rt::check_launch())
+    if (fetch_sync(h, matches12, h->d_si[SI_BEST].p, sizeof(int) * (size_t)n2 * N1) || rt::check_launch())
         return fail(ORBX_E_DEVICE, "resident triangulation search failed: %s", rt::last_error());
     for (int j = 0; j < n2; j++) {
         const int nm = prune_by_rotation(K1, K2s[j], matches12 + (size_t)j * N1, check_ori != 0);
@@ -1250,7 +1250,7 @@ int orbm_search_by_bow_resident(orbx_extractor* h, int n, orbm_keyframe* const* 
     ORBX_LAUNCH(k_bow_match_resident, grid, blk, 0, h->s0, pk.dev<BowPairResident>(pp), pk.dev<uint8_t>(pf), nnratio, TH_LOW, th_inclusive,
                 h->d_si[SI_BEST].p, N1cap, h->d_si[SI_BEST].p + nout);
     std::vector<int> res(nout + 4);
-    if (rt::copy_d2h(res.data(), h->d_si[SI_BEST].p, sizeof(int) * (nout + 4), h->s0) || rt::stream_sync(h->s0) || rt::check_launch())
+    if (fetch_sync(h, res.data(), h->d_si[SI_BEST].p, sizeof(int) * (nout + 4)) || rt::check_launch())
         return fail(ORBX_E_DEVICE, "resident bow search failed: %s", rt::last_error());
     if (res[nout] & 4) return fail(ORBX_E_CAPACITY, "a vocabulary node holds more than 2048 features of one key frame");
     for (int p = 0; p < n; p++) {
@@ -1311,7 +1311,7 @@ int orbm_search_by_bow_frames_batch(orbx_extractor* h, const orbv_vocabulary* v,
     ORBX_LAUNCH(k_bow_rotation_prune, gridp, blkp, 0, h->s0, pk.dev<BowPairResident>(pp), h->d_si[SI_BEST].p, N1cap, check_ori, h->d_si[SI_BEST].p + nout + 4);
     if (h->profile) rt::event_record(h->ev_stage[ST_MATCH][1], h->s0);
     std::vector<int> res(ntot);
-    if (rt::copy_d2h(res.data(), h->d_si[SI_BEST].p, sizeof(int) * ntot, h->s0) || rt::stream_sync(h->s0) || rt::check_launch())
+    if (fetch_sync(h, res.data(), h->d_si[SI_BEST].p, sizeof(int) * ntot) || rt::check_launch())
         return fail(ORBX_E_DEVICE, "batched bow search failed: %s", rt::last_error());
     if (res[nout] & 4) return fail(ORBX_E_CAPACITY, "a vocabulary node holds more than 2048 features of one frame");
     for (int b = 0; b < B; b++) {
@@ -1370,7 +1370,7 @@ int orbm_search_by_bow_fisheye(orbx_extractor* h, const OrbmKeyFrameView* K1, co
         ORBX_LAUNCH(k_bow_dists, grid, blk, 0, h->s0, pk.dev<BowItem>(pit), (int)items.size(), pk.dev<unsigned long long>(pd1), pk.dev<unsigned long long>(pd2),
                     pk.dev<uint8_t>(pel), pk.dev<int>(pf2), h->d_si[SI_BEST].p);
         std::vector<int> dist((size_t)total);
-        if (rt::copy_d2h(dist.data(), h->d_si[SI_BEST].p, sizeof(int) * (size_t)total, h->s0) || rt::stream_sync(h->s0) || rt::check_launch())
+        if (fetch_sync(h, dist.data(), h->d_si[SI_BEST].p, sizeof(int) * (size_t)total) || rt::check_launch())
             return fail(ORBX_E_DEVICE, "bow distances failed: %s", rt::last_error());
         std::vector<int> rotHist[HISTO_LENGTH];
         for (const BowItem& it : items) {
@@ -1664,8 +1664,7 @@ int orbm_distinctive_descriptors(orbx_extractor* h, const uint8_t* desc, const i
     if (e) return fail(ORBX_E_DEVICE, "upload/allocation failed");
     dim3 grid((P + 3) / 4, 1, 1), blk(256, 1, 1);
     ORBX_LAUNCH(k_distinctive, grid, blk, 0, h->s0, (const unsigned long long*)h->d_sr[SR_DESC].p, (const int*)h->d_si[SI_QSTART].p, P, h->d_si[SI_BEST].p);
-    rt::copy_d2h(best, h->d_si[SI_BEST].p, sizeof(int) * (size_t)P, h->s0);
-    if (rt::stream_sync(h->s0) || rt::check_launch()) return fail(ORBX_E_DEVICE, "distinctive-descriptor kernel failed: %s", rt::last_error());
+    if (fetch_sync(h, best, h->d_si[SI_BEST].p, sizeof(int) * (size_t)P) || rt::check_launch()) return fail(ORBX_E_DEVICE, "distinctive-descriptor kernel failed: %s", rt::last_error());
     return ORBX_OK;
 }
 

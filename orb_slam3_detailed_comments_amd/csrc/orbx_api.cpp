@@ -501,7 +501,7 @@ void orbx_destroy(orbx_extractor* h) {
     h->d_uRight.release(); h->d_depth.release(); h->d_sad.release(); h->d_nmatch.release(); h->d_knn.release(); h->d_ratio.release();
     h->d_l2r.release(); h->d_r2l.release(); h->d_p3d.release(); h->d_hamA.release(); h->d_hamB.release(); h->d_hamOut.release(); h->h_stage.release(); h->h_nm.release();
     for (auto& x : h->d_sr) x.release();
-    h->h_packA.release(); h->h_packB.release(); h->h_out.release();
+    h->h_packA.release(); h->h_packB.release(); h->h_out.release(); h->h_res.release();
     for (auto& x : h->d_si) x.release();
     h->d_kps_un.release();
     h->d_lp.release(); h->d_depth_in.release(); h->h_lp_in.release(); h->h_lp_out.release();
@@ -898,11 +898,15 @@ int orbm_hamming_matrix(orbx_extractor* h, const uint8_t* a, int na, const uint8
     if (!h || !a || !b || !out || na <= 0 || nb <= 0) return fail(ORBX_E_ARG, "bad hamming arguments");
     rt::set_device(h->device);
     if (h->d_hamA.ensure((size_t)na * 4) || h->d_hamB.ensure((size_t)nb * 4) || h->d_hamOut.ensure((size_t)na * nb)) return fail(ORBX_E_DEVICE, "allocation failed");
-    rt::copy_h2d(h->d_hamA.p, a, (size_t)na * 32, h->s0);
-    rt::copy_h2d(h->d_hamB.p, b, (size_t)nb * 32, h->s0);
+    // both descriptor sets go up from page-locked memory of the handle, the matrix comes back into it (fetch_sync): the caller's arrays are pageable
+    const size_t ba = (size_t)na * 32, bb = (size_t)nb * 32;
+    if (h->h_packA.ensure(ba + bb + 16)) return fail(ORBX_E_DEVICE, "allocation failed");
+    memcpy(h->h_packA.p, a, ba); memcpy(h->h_packA.p + ba, b, bb);
+    rt::copy_h2d(h->d_hamA.p, h->h_packA.p, ba, h->s0);
+    rt::copy_h2d(h->d_hamB.p, h->h_packA.p + ba, bb, h->s0);
     dim3 grid((nb + 255) / 256, na, 1), blk(256, 1, 1);
     ORBX_LAUNCH(k_hamming_matrix, grid, blk, 0, h->s0, (const unsigned long long*)h->d_hamA.p, na, (const unsigned long long*)h->d_hamB.p, nb, h->d_hamOut.p);
-    if (rt::copy_d2h(out, h->d_hamOut.p, sizeof(int) * (size_t)na * nb, h->s0) || rt::stream_sync(h->s0)) return fail(ORBX_E_DEVICE, "hamming failed: %s", rt::last_error());
+    if (fetch_sync(h, out, h->d_hamOut.p, sizeof(int) * (size_t)na * nb)) return fail(ORBX_E_DEVICE, "hamming failed: %s", rt::last_error());
     return ORBX_OK;
 }
 

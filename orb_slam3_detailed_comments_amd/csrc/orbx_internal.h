@@ -100,6 +100,7 @@ struct orbx_extractor {
     // scratch of the projection / BoW searches (orbm_search.cpp)
     orbx::DevBuf<uint8_t> d_sr[12];
     orbx::HostBuf<uint8_t> h_packA, h_packB, h_out;      // pinned staging of the window searches (frame, queries, results)
+    orbx::HostBuf<uint8_t> h_res;                        // pinned landing area of results that end in caller (pageable) memory: orbx::fetch_sync
     size_t area_pool = 0, area_last_total = 0;
     orbx::DevBuf<int> d_si[8];
     orbx::DevBuf<long long> d_qtprof;
@@ -128,4 +129,15 @@ struct orbx_extractor {
 // mvKeysUn of the last extraction no longer matches the undistortion model of the handle (orbx_set_undistort was called in between)
 inline void record_done_if_pending(orbx_extractor* h) { if (h->done_lazy) { orbx::rt::event_record(h->ev_done, h->s0); h->done_lazy = false; } }
 inline void record_import_if_pending(orbx_extractor* h) { if (h->import_lazy) { orbx::rt::event_record(h->ev_import, h->s0); h->import_lazy = false; } }
+// Device results -> caller memory, waiting for them: the copy lands in page-locked memory of the handle and is moved on by the host.  A hipMemcpyAsync into
+// pageable memory is staged by the runtime chunk by chunk behind a blocking wait of its own (a synchronous call of a few KB cost 33 us that way, 17 us this way:
+// profiles/r05/sync_latency_probe.txt, next_rows.json).
+inline int fetch_sync(orbx_extractor* h, void* dst, const void* dev_src, size_t bytes) {
+    if (bytes == 0) return orbx::rt::stream_sync(h->s0);
+    if (orbx::rt::memory_is_host()) { if (orbx::rt::stream_sync(h->s0)) return -1; memcpy(dst, dev_src, bytes); return 0; }
+    if (h->h_res.ensure(bytes + 64)) return -1;
+    if (orbx::rt::copy_d2h(h->h_res.p, dev_src, bytes, h->s0) || orbx::rt::stream_sync(h->s0)) return -1;
+    memcpy(dst, h->h_res.p, bytes);
+    return 0;
+}
 inline bool undistort_stale(const orbx_extractor* h) { return h->lastB > 0 && h->ex_undist_gen != h->undist_gen; }

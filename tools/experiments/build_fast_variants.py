@@ -1,5 +1,5 @@
 """Experimental builds of liborbx_hip.so with parts of k_fast_cells cut out (timing attribution on the GPU; results are wrong by construction).
-   python tools/build_fast_variants.py  ->  build/variants/liborbx_hip_<name>.so"""
+   python tools/experiments/build_fast_variants.py  ->  build/variants/liborbx_hip_<name>.so"""
 import os, shutil, subprocess, sys, tempfile
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# experimental builds for tools/qt_spans_probe.py: the product sources + two wall-clock stamps per quadtree workgroup and the phase stamps of one level
+# experimental builds for tools/experiments/qt_spans_probe.py: the product sources + two wall-clock stamps per quadtree workgroup and the phase stamps of one level
 # (ORBX_QT_STAMP_LEVEL) -> build/variants/liborbx_hip_qtspan<level>.so
 set -e
 R=$(cd $(dirname $0)/.. && pwd)

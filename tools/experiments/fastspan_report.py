@@ -1,4 +1,4 @@
-"""reads the FASTCELL lines of tools/fastspan_probe.py (last run) and prints when the cells of image 0 start and end inside the launch"""
+"""reads the FASTCELL lines of tools/experiments/fastspan_probe.py (last run) and prints when the cells of image 0 start and end inside the launch"""
 import sys
 runs = open(sys.argv[1]).read().split("--- run")[1:]
 rows = [l.split()[1:] for l in runs[-1].splitlines() if l.startswith("FASTCELL")]      # (device printf is flushed late: the last block may hold several runs)

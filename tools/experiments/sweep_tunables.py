@@ -1,4 +1,4 @@
-"""Builds build/variants/liborbx_hip_<name>.so for a few compile-time tunables (GPU sweep: tools/gpu_sweep_tunables.sh)."""
+"""Builds build/variants/liborbx_hip_<name>.so for a few compile-time tunables (GPU sweep: tools/experiments/gpu_sweep_tunables.sh)."""
 import os, sys
 from concurrent.futures import ThreadPoolExecutor
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 from orb_slam3_detailed_comments_amd import synth
 from orb_slam3_detailed_comments_amd.extractor import ORBextractor
 from orb_slam3_detailed_comments_amd import _lib
-LIB = _lib.OrbxLib(os.environ["ORBX_BENCH_LIB"]) if os.environ.get("ORBX_BENCH_LIB") else None      # a variant build (tools/sweep_tunables.py)
+LIB = _lib.OrbxLib(os.environ["ORBX_BENCH_LIB"]) if os.environ.get("ORBX_BENCH_LIB") else None      # a variant build (tools/experiments/sweep_tunables.py)
 BATCHES = [int(a) for a in sys.argv[1:]] or [2, 4, 8, 16, 32, 64]
 imgs = np.stack([synth.stereo_pair(seed=100 + s)[s & 1] for s in range(64)])
 for B in BATCHES:
