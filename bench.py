@@ -221,7 +221,9 @@ def kernel_sources_sha():
     d = os.path.join(ROOT, "orb_slam3_detailed_comments_amd", "csrc")
     hsh = hashlib.sha256()
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h", ".inc")):
+        # device code: the kernel files and every header they include; orbx_internal.h / orbx_rt.h are host-only (the handle, the runtime wrappers) and no
+        # .hip file includes them - a change there does not touch a kernel
+        if f.endswith((".hip", ".h", ".inc")) and f not in ("orbx_internal.h", "orbx_rt.h"):
             hsh.update(f.encode()); hsh.update(open(os.path.join(d, f), "rb").read())
     return hsh.hexdigest()[:16]
 
