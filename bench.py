@@ -228,6 +228,52 @@ def kernel_sources_sha():
     return hsh.hexdigest()[:16]
 
 
+def live_traffic(dom, timeout=150):
+    """HBM bytes of the dominant kernel, measured now: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (one counter per pass, nothing else enabled), each over a
+    child run of this file with 64 pairs per step on three handles (= 128 images per launch, the shape of profiles/pmc_traffic.json).  Returns None when rocprofv3 is
+    missing or a pass fails; the caller then keeps the tracked figure.  Units and the gfx950 caveat as in tools/make_pmc_traffic.py: KB per dispatch, 4-B/lane loads."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    kname = {"fast_cells": "k_fast_cells", "blur": "k_blur", "quadtree": "k_quadtree", "orient_brief": "k_orient_brief", "match": "k_stereo_match", "pyramid": "k_resize"}.get(dom)
+    if not exe or not kname:
+        return None
+    tmp = tempfile.mkdtemp(prefix="orbx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2", "--pairs", "64", "--handles", "3", "--no-cpu-baseline", "--no-h2d", "--no-other-configs",
+             "--no-latency", "--no-parity-check", "--no-live-traffic", "--min-seconds", "0"]
+    out = {}
+    t0 = time.time()
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            pr = subprocess.Popen([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + child, cwd="/tmp", env=env,
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            try:
+                pr.wait(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                pr.kill(); pr.wait()                      # this very process, by its handle
+                return None
+            n = 0; tot = 0.0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if kname in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                        n += 1; tot += float(r["Counter_Value"])
+            if n == 0:
+                return None
+            out[counter] = {"dispatches": n, "avg_KB": round(tot / n, 1)}
+        mult = 7 if kname == "k_resize" else 1
+        return {"kernel": kname, "FETCH_SIZE": out["FETCH_SIZE"], "WRITE_SIZE": out["WRITE_SIZE"],
+                "bytes_per_launch_128_images": int((out["FETCH_SIZE"]["avg_KB"] + out["WRITE_SIZE"]["avg_KB"]) * 1024 * mult),
+                "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over `bench.py --pairs 64 --handles 3 --steps 4` inside this run", "seconds": round(time.time() - t0, 1)}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def other_configs(seconds=2.5):
     """BASELINE.json configs 0, 2 and 3 beside the headline, in the driver's own line: each is this file run as a child process (`--config X`), i.e. the
     same setup, warm-up, barrier-bracketed timed region (>= `seconds`) and roofline arithmetic as the headline, reduced to the key figures."""
@@ -237,7 +283,7 @@ def other_configs(seconds=2.5):
         # stereo_natural: the headline's configuration on the second generator (--workload natural: camera-like imagery, 1-5 % FAST corner density
         # instead of the corner field's 23.5 %) - no EuRoC frame can be had offline, this is the closest the run can get to one
         cmd = [sys.executable, os.path.abspath(__file__), "--config", "stereo" if name == "stereo_natural" else name, "--steps", "20", "--warmup", "5", "--min-seconds", str(seconds),
-               "--no-cpu-baseline", "--no-h2d", "--no-other-configs", "--no-latency"] + (["--workload", "natural"] if name == "stereo_natural" else [])
+               "--no-cpu-baseline", "--no-h2d", "--no-other-configs", "--no-latency", "--no-live-traffic"] + (["--workload", "natural"] if name == "stereo_natural" else [])
         t0 = time.time()
         try:
             pr = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
@@ -306,6 +352,8 @@ def main():
                     "per-kernel averages of rocprofv3 are averages over the timed launches)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the second, PCIe-inclusive measurement (never `value`)")
     ap.add_argument("--h2d", action="store_true", help="make the PCIe-inclusive variant the timed loop (NOT the headline value)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not measure roofline.traffic with two short rocprofv3 --pmc passes inside this run (keep the tracked figure); the passes belong to the full "
+                    "default line and are also left out with --no-other-configs and under a profiler")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)        # one pair stream of cpu_baseline's all-core setting (internal)
     args = ap.parse_args()
     if args.cpu_worker:
@@ -757,6 +805,16 @@ def main():
                                   "stale": pj.get("_kernel_sources_sha") != now, "measured_in_this_run": False}
             except Exception:
                 traffic = None
+        # ... and, in the default run on one GPU, MEASURED in this run: two rocprofv3 --pmc passes of their own (FETCH_SIZE, WRITE_SIZE; never combined with
+        # a trace) over a short child run of this file at 128 images per launch, summed over the dominant kernel's dispatches.  The file above stays the
+        # fallback (no rocprofv3, a pass that times out) and the cross-check (`traffic_file`).
+        under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+        if (kind == "stereo" and world == 1 and dist is None and not args.no_live_traffic and not args.no_other_configs and not args.h2d and not under_profiler
+                and not os.environ.get("ORBX_BENCH_LIB")):
+            live = live_traffic(dom)
+            if live is not None:
+                traffic_source = dict(traffic_source or {}, traffic_file=traffic, measured_in_this_run=True, live=live)
+                traffic = int(live["bytes_per_launch_128_images"] * NIMG / 128.0)
         # VALU issue view of the same kernel (the HBM fraction says little for a compute-heavy integer kernel): wave-instructions per launch
         # from the SQ counter pass (profiles/pmc_valu.json, scaled to this launch size) against the SIMD-32 issue peak of one wave64
         # instruction per 2 clk (1024 SIMDs x 2.4 GHz / 2 = 1228.8 G wave-instr/s; profiles/r02/valu_survey.txt: only the VOP2 integer forms
