@@ -338,6 +338,30 @@ int mw_search_for_triangulation(void* wv, int kf1, int kf2, int only_stereo, int
     for (size_t i = 0; i < vp.size() && (int)i < cap; i++) { pairs[2 * i] = (int)vp[i].first; pairs[2 * i + 1] = (int)vp[i].second; }
     return n;
 }
+// The facade keeps the key frames of the single-call signatures on the device by itself (ORBmatcher::ImplicitCache).  A key frame whose content changes
+// behind the same address, id and size must not be served from a stale upload: the descriptors of kf2 are flipped in place between two calls and the second
+// result is compared with the one a cleared cache gives.  0 = the change was seen (and made a difference), 1 = stale device data, 2 = the scene cannot tell.
+// The reference build has no cache: 0.
+int mw_implicit_cache_probe(void* wv, int kf1, int kf2) {
+#ifdef MW_FACADE
+    World* w = (World*)wv;
+    KeyFrame *A = w->kfs[kf1].get(), *B = w->kfs[kf2].get();
+    ORBmatcher m(0.6f, true);
+    std::vector<std::pair<size_t, size_t>> p0, p1, p2;
+    cv::Mat D = B->mDescriptors;                          // shares the key frame's buffer (the member itself is const in the reference's class)
+    m.SearchForTriangulation(A, B, p0, false);
+    for (int r = 0; r < D.rows; r++) for (int c = 0; c < 32; c++) D.ptr(r)[c] ^= (unsigned char)(0x35 + 7 * (r & 7));
+    m.SearchForTriangulation(A, B, p1, false);
+    ORBmatcher::ImplicitCache<KeyFrame>().Clear();
+    m.SearchForTriangulation(A, B, p2, false);
+    for (int r = 0; r < D.rows; r++) for (int c = 0; c < 32; c++) D.ptr(r)[c] ^= (unsigned char)(0x35 + 7 * (r & 7));
+    ORBmatcher::ImplicitCache<KeyFrame>().Clear();
+    return p1 != p2 ? 1 : (p1 != p0 ? 0 : 2);
+#else
+    (void)wv; (void)kf1; (void)kf2;
+    return 0;
+#endif
+}
 // the same against n2 neighbours: the facade's one-call form over device-resident key frames, the reference's method once per neighbour.
 // pairs: n2 blocks of cap (idx1, idx2) pairs; n_pairs / nmatches: n2 entries.  `rounds` repeats the call (the facade's cache is reused).
 int mw_search_for_triangulation_neighbours(void* wv, int kf1, int n2, const int* kf2s, int only_stereo, int coarse, int* pairs, int cap, int* n_pairs, int* nmatches,

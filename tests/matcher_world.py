@@ -271,6 +271,8 @@ def build_and_run(drv, seed, variant):
     pairs = i32(2 * len(kkA)); npairs = C.c_int()
     n = L.mw_search_for_triangulation(drv.w, kA, kB, 0, 0, _p(pairs), len(kkA), C.byref(npairs), C.c_float(0.6), 0)
     out["triang_noori"] = np.concatenate([[n, npairs.value], pairs])
+    if hasattr(L, "mw_implicit_cache_probe"):                # the facade's implicit resident cache must notice a key frame whose content changed in place
+        out["implicit_cache_probe"] = np.array([L.mw_implicit_cache_probe(drv.w, kA, kB)], np.int32)
 
     # the same against several neighbours: the facade answers them in one call over device-resident key frames (twice: the second round
     # reuses the cached uploads), the reference is called once per neighbour

@@ -9,6 +9,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from orb_slam3_detailed_comments_amd import OrbxError
+
 import oracle_lib as ol
 import vocab_scenes as vs
 from matcher_world import Driver, KP
@@ -135,4 +137,13 @@ def test_bow_frames_batch_edge_cases(emu_lib):
     n2, m2 = got[2]
     assert n2 > 0.5 * full.N and all(m2[i] in (-1, i) for i in range(full.N)), n2
     assert got[3][0] == 0 and len(got[3][1]) == 0                        # the empty key frame
+    # a new batch of the same shape on the handle makes the transform's FeatureVectors stale (they index the previous batch's keypoints): the search
+    # refuses instead of pairing old feature indices with new descriptors (extraction generation counter)
+    ex.extract_batch(imgs[::-1].copy())
+    with pytest.raises(OrbxError) as err:
+        m.SearchByBoWFramesBatch(ex, voc, [full, full, full, empty], [np.ones(full.N, np.uint8), np.zeros(full.N, np.uint8), np.ones(full.N, np.uint8), np.zeros(1, np.uint8)])
+    assert "transform again" in str(err.value)
+    voc.transform_extracted(ex, 0, 4, 2)
+    again = m.SearchByBoWFramesBatch(ex, voc, [full, full, full, empty], [np.ones(full.N, np.uint8), np.zeros(full.N, np.uint8), np.ones(full.N, np.uint8), np.zeros(1, np.uint8)])
+    assert again[3][0] == 0 and again[2][0] > 0.5 * full.N               # frame 2 is the key frame's own image again
     full.close(); empty.close(); voc.close(); ex.close()
