@@ -633,7 +633,13 @@ def main():
         tw = time.perf_counter() - tw
         repeats = 1
         if nwarm > 0 and min_seconds > 0:
-            repeats = int(min(max(1, np.ceil(min_seconds / max(tw / nwarm * nsteps, 1e-6))), 10000))
+            # the warm-up steps are slower than steady state (first launches, the clocks ramping up) and would predict too few blocks: a second untimed
+            # run of the same length, now warm, sets the rate the prediction uses, so that the timed region does last min_seconds
+            tc = time.perf_counter()
+            run(nwarm, False, h2d)
+            sync_all()
+            tc = min(tw, time.perf_counter() - tc)
+            repeats = int(min(max(1, np.ceil(1.03 * min_seconds / max(tc / nwarm * nsteps, 1e-6))), 10000))
         if dist is not None:                       # every rank times the same number of steps
             import torch
             t = torch.tensor([repeats], dtype=torch.int64, device=coll_dev)
