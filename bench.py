@@ -228,7 +228,7 @@ def kernel_sources_sha():
     return hsh.hexdigest()[:16]
 
 
-def live_traffic(dom, timeout=150):
+def live_traffic(dom, timeout=60):
     """HBM bytes of the dominant kernel, measured now: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (one counter per pass, nothing else enabled), each over a
     child run of this file with 64 pairs per step on three handles (= 128 images per launch, the shape of profiles/pmc_traffic.json).  Returns None when rocprofv3 is
     missing or a pass fails; the caller then keeps the tracked figure.  Units and the gfx950 caveat as in tools/make_pmc_traffic.py: KB per dispatch, 4-B/lane loads."""
