@@ -635,11 +635,12 @@ def main():
         if nwarm > 0 and min_seconds > 0:
             # the warm-up steps are slower than steady state (first launches, the clocks ramping up) and would predict too few blocks: a second untimed
             # run of the same length, now warm, sets the rate the prediction uses, so that the timed region does last min_seconds
+            ncal = max(nwarm, 40)                           # (a handful of steps is dominated by filling and draining the handles in flight)
             tc = time.perf_counter()
-            run(nwarm, False, h2d)
+            run(ncal, False, h2d)
             sync_all()
-            tc = min(tw, time.perf_counter() - tc)
-            repeats = int(min(max(1, np.ceil(1.03 * min_seconds / max(tc / nwarm * nsteps, 1e-6))), 10000))
+            tc = time.perf_counter() - tc
+            repeats = int(min(max(1, np.ceil(1.03 * min_seconds / max(tc / ncal * nsteps, 1e-6))), 10000))
         if dist is not None:                       # every rank times the same number of steps
             import torch
             t = torch.tensor([repeats], dtype=torch.int64, device=coll_dev)
