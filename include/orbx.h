@@ -205,6 +205,10 @@ int orbx_debug_quadtree_profile(orbx_extractor* h, long long out[16]);   /* phas
  * packed sub, packed xor(a, c), wave inclusive scan / wave sum of a & 0xFFFF, wave minimum of b (per 64 consecutive elements), v_sad_u8, v_mul_u32_u24,
  * the 64-bit wave scan (two words), the 64-bit workgroup scan (two words), the wave OR */
 int orbx_debug_simd_selftest(orbx_extractor* h, const uint32_t* a, const uint32_t* b, const uint32_t* c, int n, uint32_t* out);
+/* what the library holds at this moment, process-wide: out = { device allocations, page-locked host allocations, streams, events }.  The lifetime
+ * tests create, use and destroy every kind of handle (extractor, key frames, map points, vocabulary, communicator, caller buffers) and expect the
+ * four counts back where they started (tests/test_lifetime.py). */
+int orbx_debug_live_resources(long long out[4]);
 
 /* ---------------------------------------------------------------------------------------------------------- */
 /* ORBmatcher::DescriptorDistance (include/ORBmatcher.h:44, src/ORBmatcher.cc:2383-2403), all pairs:

@@ -475,8 +475,8 @@ int orbx_create(orbx_extractor** out, int nfeatures, float scale_factor, int nle
     int e = rt::stream_create(&h->s0) | rt::stream_create(&h->s1) | rt::stream_create(&h->s_copy) | rt::event_create(&h->ev_fork) | rt::event_create(&h->ev_join) |
             rt::event_create(&h->ev_done) | rt::event_create(&h->ev_copy) | rt::event_create(&h->ev_import) | rt::event_create(&h->ev_lp);
     for (int i = 0; i < ORBX_NSTAGES; i++) { e |= rt::event_create(&h->ev_stage[i][0]); e |= rt::event_create(&h->ev_stage[i][1]); h->stage_ms[i] = 0; }
-    if (e) { delete h; return fail(ORBX_E_DEVICE, "stream/event creation failed"); }
     h->have_streams = true;
+    if (e) { orbx_destroy(h); return fail(ORBX_E_DEVICE, "stream/event creation failed"); }      // (gives back whatever was created)
     *out = h;
     return ORBX_OK;
 }
@@ -748,6 +748,13 @@ int orbx_debug_simd_selftest(orbx_extractor* h, const uint32_t* a, const uint32_
     e |= rt::copy_d2h(out, d.p + 3 * N, 4 * N * kSimdSelftestOps, h->s0);
     if (e || rt::stream_sync(h->s0) || rt::check_launch()) { d.release(); return fail(ORBX_E_DEVICE, "self-test failed: %s", rt::last_error()); }
     d.release();
+    return ORBX_OK;
+}
+
+int orbx_debug_live_resources(long long out[4]) {
+    if (!out) return fail(ORBX_E_ARG, "null out");
+    const rt::Live& l = rt::live();
+    out[0] = l.dev.load(); out[1] = l.pinned.load(); out[2] = l.streams.load(); out[3] = l.events.load();
     return ORBX_OK;
 }
 

@@ -173,6 +173,7 @@ void orbx_comm_destroy(orbx_comm* c) {
     if (c->nccl && c->owned) rccl().CommDestroy(c->nccl);
 #endif
     if (c->have_stream) { rt::stream_destroy(c->stream); rt::event_destroy(c->ev_snap); rt::event_destroy(c->ev_done); }
+    c->snap.release(); c->all.release();        // (DevBuf has no destructor: found by tests/test_lifetime.py)
     delete c;
 }
 

@@ -91,7 +91,7 @@ struct orbx_extractor {
     // after every extraction: a record in the middle of a stream is a barrier packet, and the kernel behind it starts ~6 us later - a third of a
     // FAST launch at one pair per call.  Recorded late they cover more of the stream than needed, never less.
     bool done_lazy = false, import_lazy = false;
-    orbx::rt::event_t ev_stage[ORBX_NSTAGES][2];
+    orbx::rt::event_t ev_stage[ORBX_NSTAGES][2] = {};
     bool profile = false, serial = false, have_streams = false;
     int lastB = 0;
     uint64_t extract_gen = 0;     // counts the extractions enqueued on this handle: results derived from a batch (the vocabulary transform's FeatureVectors) name the one they belong to

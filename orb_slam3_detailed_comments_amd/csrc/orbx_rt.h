@@ -3,9 +3,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include "orbx_platform.h"
 
 namespace orbx { namespace rt {
+
+// what the library holds right now, process-wide: device allocations, page-locked allocations, streams, events (orbx_debug_live_resources:
+// the lifetime tests create and destroy every kind of handle and expect these to return to where they started)
+struct Live { std::atomic<long long> dev{0}, pinned{0}, streams{0}, events{0}; };
+inline Live& live() { static Live l; return l; }
 
 #ifdef ORBX_EMU
 typedef int stream_t;
@@ -16,10 +22,10 @@ inline int set_device(int) { return 0; }
 inline bool memory_is_host() { return true; }
 // ORBX_EMU_DEVICES: the tests let the emulator report several "GPUs" (all of them host memory) to exercise the device plumbing of multi-GPU hosts
 inline int device_count() { const char* e = getenv("ORBX_EMU_DEVICES"); const int n = e ? atoi(e) : 1; return n > 0 ? n : 1; }
-inline void* dmalloc(size_t n) { return calloc(n ? n : 1, 1); }
-inline void dfree(void* p) { free(p); }
-inline void* hmalloc(size_t n) { return calloc(n ? n : 1, 1); }
-inline void hfree(void* p) { free(p); }
+inline void* dmalloc(size_t n) { void* p = calloc(n ? n : 1, 1); if (p) live().dev++; return p; }
+inline void dfree(void* p) { if (p) { live().dev--; free(p); } }
+inline void* hmalloc(size_t n) { void* p = calloc(n ? n : 1, 1); if (p) live().pinned++; return p; }
+inline void hfree(void* p) { if (p) { live().pinned--; free(p); } }
 inline int copy_h2d(void* d, const void* s, size_t n, stream_t) { memcpy(d, s, n); return 0; }
 inline int copy_d2h(void* d, const void* s, size_t n, stream_t) { memcpy(d, s, n); return 0; }
 inline int copy_d2d(void* d, const void* s, size_t n, stream_t) { memmove(d, s, n); return 0; }
@@ -28,11 +34,11 @@ inline int copy2d(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t
     return 0;
 }
 inline int memset_async(void* d, int v, size_t n, stream_t) { memset(d, v, n); return 0; }
-inline int stream_create(stream_t* s) { *s = 0; return 0; }
-inline void stream_destroy(stream_t) {}
+inline int stream_create(stream_t* s) { *s = 0; live().streams++; return 0; }
+inline void stream_destroy(stream_t) { live().streams--; }
 inline int stream_sync(stream_t) { return 0; }
-inline int event_create(event_t* e) { *e = new event_s{0}; return 0; }
-inline void event_destroy(event_t e) { delete e; }
+inline int event_create(event_t* e) { *e = new event_s{0}; live().events++; return 0; }
+inline void event_destroy(event_t e) { if (e) { live().events--; delete e; } }
 inline int event_record(event_t e, stream_t) { e->t = now_ms(); return 0; }
 inline int stream_wait_event(stream_t, event_t) { return 0; }
 inline int event_sync(event_t) { return 0; }
@@ -52,10 +58,10 @@ inline int hip_ok(hipError_t e) { if (e == hipSuccess) return 0; last_code() = e
 inline int set_device(int d) { return ORBX_HIP_OK(hipSetDevice(d)); }
 inline bool memory_is_host() { return false; }
 inline int device_count() { int n = 0; if (hip_ok(hipGetDeviceCount(&n))) return 0; return n; }
-inline void* dmalloc(size_t n) { void* p = nullptr; if (hip_ok(hipMalloc(&p, n ? n : 1))) return nullptr; return p; }
-inline void dfree(void* p) { if (p) (void)hip_ok(hipFree(p)); }
-inline void* hmalloc(size_t n) { void* p = nullptr; if (hip_ok(hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault))) return nullptr; return p; }
-inline void hfree(void* p) { if (p) (void)hip_ok(hipHostFree(p)); }
+inline void* dmalloc(size_t n) { void* p = nullptr; if (hip_ok(hipMalloc(&p, n ? n : 1))) return nullptr; live().dev++; return p; }
+inline void dfree(void* p) { if (p) { live().dev--; (void)hip_ok(hipFree(p)); } }
+inline void* hmalloc(size_t n) { void* p = nullptr; if (hip_ok(hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault))) return nullptr; live().pinned++; return p; }
+inline void hfree(void* p) { if (p) { live().pinned--; (void)hip_ok(hipHostFree(p)); } }
 inline int copy_h2d(void* d, const void* s, size_t n, stream_t st) { return ORBX_HIP_OK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st)); }
 inline int copy_d2h(void* d, const void* s, size_t n, stream_t st) { return ORBX_HIP_OK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, st)); }
 inline int copy_d2d(void* d, const void* s, size_t n, stream_t st) { return ORBX_HIP_OK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, st)); }
@@ -64,11 +70,11 @@ inline int copy2d(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t
     return ORBX_HIP_OK(hipMemcpy2DAsync(d, dp, s, sp, w, h, kind ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
 }
 inline int memset_async(void* d, int v, size_t n, stream_t st) { return ORBX_HIP_OK(hipMemsetAsync(d, v, n, st)); }
-inline int stream_create(stream_t* s) { return ORBX_HIP_OK(hipStreamCreateWithFlags(s, hipStreamNonBlocking)); }
-inline void stream_destroy(stream_t s) { (void)hip_ok(hipStreamDestroy(s)); }
+inline int stream_create(stream_t* s) { if (ORBX_HIP_OK(hipStreamCreateWithFlags(s, hipStreamNonBlocking))) return -1; live().streams++; return 0; }
+inline void stream_destroy(stream_t s) { if (s) { live().streams--; (void)hip_ok(hipStreamDestroy(s)); } }
 inline int stream_sync(stream_t s) { return ORBX_HIP_OK(hipStreamSynchronize(s)); }
-inline int event_create(event_t* e) { return ORBX_HIP_OK(hipEventCreate(e)); }
-inline void event_destroy(event_t e) { (void)hip_ok(hipEventDestroy(e)); }
+inline int event_create(event_t* e) { if (ORBX_HIP_OK(hipEventCreate(e))) return -1; live().events++; return 0; }
+inline void event_destroy(event_t e) { if (e) { live().events--; (void)hip_ok(hipEventDestroy(e)); } }
 inline int event_record(event_t e, stream_t s) { return ORBX_HIP_OK(hipEventRecord(e, s)); }
 inline int stream_wait_event(stream_t s, event_t e) { return ORBX_HIP_OK(hipStreamWaitEvent(s, e, 0)); }
 inline int event_sync(event_t e) { return ORBX_HIP_OK(hipEventSynchronize(e)); }
