@@ -483,5 +483,18 @@ if __name__ == "__main__":
     drv_path, orbx_path, seed, variant, dst = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
     d = Driver(drv_path, orbx_path or None)
     res = build_and_run_rig(d, seed) if variant == "rig" else build_and_run_kb8(d, seed) if variant == "kb8" else build_and_run(d, seed, variant)
-    np.savez(dst, flavour=np.frombuffer(d.L.mw_flavour(), np.uint8), **res)
+    extra = {}
     d.close()
+    if len(sys.argv) > 6 and sys.argv[6] == "twice" and orbx_path:
+        # tests/test_lifetime.py: the same world built, searched and destroyed again must leave the library holding what it held after the first
+        # (the facade's per-thread handle and its scratch stay; key frames, caches and everything per world have to be gone)
+        def live():
+            a = (C.c_longlong * 4)(); assert d._orbx.orbx_debug_live_resources(a) == 0; return list(a)
+        first = live()
+        for _ in range(2):
+            d2 = Driver(drv_path, None)
+            res2 = build_and_run_rig(d2, seed) if variant == "rig" else build_and_run_kb8(d2, seed) if variant == "kb8" else build_and_run(d2, seed, variant)
+            assert all(np.array_equal(res[k], res2[k]) for k in res)
+            d2.close()
+        extra = dict(live_first=np.array(first), live_again=np.array(live()))
+    np.savez(dst, flavour=np.frombuffer(d.L.mw_flavour(), np.uint8), **res, **extra)

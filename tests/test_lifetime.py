@@ -152,3 +152,22 @@ def test_every_buffer_member_is_released_in_destroy():
             assert looped or re.search(r"%s->%s\.release\(\)" % (var, n), body), "%s::%s is never released in %s" % (struct, n, sig)
         total += len(names)
     assert total > 60
+
+
+def test_facade_worlds_leave_nothing_behind(tmp_path, emu_lib):
+    """The header-only facade (include/orb_slam3_amd/ORBmatcher.h) over the emulator library: worlds of key frames, frames and map points are
+    built, searched through all thirteen methods (the implicit resident cache included) and destroyed three times in one process."""
+    import os
+    import subprocess
+    import sys
+    import oracle_lib as ol
+    facade = os.path.join(ol.ROOT, "oracle", "_ref", "libmw_facade.so")
+    if not os.path.exists(facade):
+        pytest.skip("oracle/_ref/libmw_facade.so not built (needs /root/reference)")
+    orbx = os.path.join(ol.ROOT, "tests", "emu", "liborbx_emu.so")
+    for seed, variant in [(1, "base"), (4, "rig"), (6, "kb8")]:
+        dst = str(tmp_path / ("w_%s.npz" % variant))
+        r = subprocess.run([sys.executable, os.path.join(ol.ROOT, "tests", "matcher_world.py"), facade, orbx, str(seed), variant, dst, "twice"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        z = np.load(dst)
+        assert z["live_first"][2] >= 3 and np.array_equal(z["live_first"], z["live_again"]), (variant, z["live_first"], z["live_again"])
