@@ -729,7 +729,7 @@ int orbx_device_upload_async(orbx_extractor* h, void* dptr, const void* host, si
 
 // debug: phase timestamps (100 MHz wall clock) of the level-0 quadtree workgroup of image 0 (serial profiling mode only)
 int orbx_debug_quadtree_profile(orbx_extractor* h, long long out[16]) {
-    if (!h || !h->d_qtprof.p) return ORBX_E_ARG;
+    if (!h || !out || !h->d_qtprof.p) return ORBX_E_ARG;
     rt::set_device(h->device);
     if (rt::copy_d2h(out, h->d_qtprof.p, sizeof(long long) * 16, h->s0) || rt::stream_sync(h->s0)) return ORBX_E_DEVICE;
     return ORBX_OK;
@@ -860,14 +860,14 @@ int orbx_set_graph_replay(orbx_extractor* h, int on) { if (!h) return ORBX_E_ARG
 
 int orbx_profile_enable(orbx_extractor* h, int on) { if (!h) return ORBX_E_ARG; h->profile = on != 0; h->serial = on == 2; return ORBX_OK; }
 int orbx_profile_get(orbx_extractor* h, float ms[ORBX_NSTAGES]) {
-    if (!h) return ORBX_E_ARG;
+    if (!h || !ms) return ORBX_E_ARG;
     for (int i = 0; i < ORBX_NSTAGES; i++) ms[i] = h->stage_ms[i];
     return ORBX_OK;
 }
 
 // ---- stage probes -------------------------------------------------------------------------------------
 int orbx_debug_candidates(orbx_extractor* h, int b, int level, int* xys, int cap) {
-    if (!h || level < 0 || level >= h->nlevels || b < 0 || b >= h->lastB) return fail(ORBX_E_ARG, "bad probe");
+    if (!h || (!xys && cap > 0) || level < 0 || level >= h->nlevels || b < 0 || b >= h->lastB) return fail(ORBX_E_ARG, "bad probe");
     rt::set_device(h->device);
     rt::stream_sync(h->s0);
     const LevelInfo& L = h->lv[level];
@@ -887,7 +887,7 @@ int orbx_debug_candidates(orbx_extractor* h, int b, int level, int* xys, int cap
     return n;
 }
 int orbx_debug_level_keys(orbx_extractor* h, int b, int level, int* xys, int cap) {
-    if (!h || level < 0 || level >= h->nlevels || b < 0 || b >= h->lastB) return fail(ORBX_E_ARG, "bad probe");
+    if (!h || (!xys && cap > 0) || level < 0 || level >= h->nlevels || b < 0 || b >= h->lastB) return fail(ORBX_E_ARG, "bad probe");
     rt::set_device(h->device);
     rt::stream_sync(h->s0);
     const LevelInfo& L = h->lv[level];

@@ -63,3 +63,14 @@ def test_header_is_plain_c(tmp_path):
     src = tmp_path / "cabi.c"
     src.write_text('#include "orbx.h"\nint main(void) { OrbxInputSpec s; OrbmFrameView f; OrbmFisheyeFrameView g; (void)s; (void)f; (void)g; return orbx_device_count() < 0; }\n')
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "cabi.o")], check=True)
+
+
+def test_null_arguments_are_refused_not_dereferenced(emu_lib):
+    """~280 calls with null pointers and zero sizes (tests/null_argument_runner.py), on the emulator build of the same host code."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "null_argument_runner.py"), os.path.join(ROOT, "tests", "emu", "liborbx_emu.so"), ROOT],
+                       capture_output=True, text=True)
+    lines = r.stdout.strip().splitlines()
+    assert r.returncode == 0 and lines and lines[-1].startswith("DONE"), "crashed in: %s (rc %d)\n%s" % (lines[-1] if lines else "?", r.returncode, r.stderr[-500:])
+    assert int(lines[-1].split()[1]) > 250
