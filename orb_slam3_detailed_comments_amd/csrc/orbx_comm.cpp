@@ -21,6 +21,7 @@
 #else
 #include <dlfcn.h>
 #include <string>
+#include <vector>
 #endif
 
 using namespace orbx;
@@ -41,14 +42,27 @@ struct Rccl {
     const char* (*GetErrorString)(int) = nullptr;
     bool ok = false;
     std::string err;                       // why it is not ok: dlerror() read once, where the failure happened
+    std::string path;                      // the file that was loaded
 };
 Rccl& rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (r.lib) break;
+        // RCCL has to sit on the SAME HIP runtime as this library: its streams and buffers are handed to it.  A process may hold two runtimes - this
+        // library bound to /opt/rocm's, then `import torch` maps the copy bundled in torch/lib together with its own librccl.so.1 - and a dlopen by
+        // soname then returns the RCCL that is already there, on the other runtime (ncclCommInitRank: "unhandled cuda error", found by
+        // tests/test_lifetime.py on the GPU).  So the first candidates are the librccl files next to the libamdhip64 this library resolved.
+        std::vector<std::string> names;
+        Dl_info di;
+        if (dladdr((const void*)&hipDeviceSynchronize, &di) && di.dli_fname) {
+            std::string dir(di.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) { dir.resize(slash + 1); names.push_back(dir + "librccl.so.1"); names.push_back(dir + "librccl.so"); }
+        }
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) names.push_back(name);
+        for (const std::string& name : names) {
+            r.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) { r.path = name; break; }
             const char* e = dlerror();
             if (e && r.err.empty()) r.err = e;
         }
@@ -132,7 +146,7 @@ int orbx_comm_create(orbx_comm** out, int world, int rank, const uint8_t id[ORBX
     if (!r.ok) { orbx_comm_destroy(c); return fail(ORBX_E_DEVICE, "librccl could not be loaded (%s)", r.err.c_str()); }
     NcclId nid; memcpy(&nid, id, sizeof nid);
     const int e = r.CommInitRank(&c->nccl, world, nid, rank);           // collective over the ranks: every rank calls it with the same id
-    if (e) { orbx_comm_destroy(c); return fail(ORBX_E_DEVICE, "ncclCommInitRank(rank %d of %d, GPU %d): %s", rank, world, device_id, nccl_err(e)); }
+    if (e) { orbx_comm_destroy(c); return fail(ORBX_E_DEVICE, "ncclCommInitRank(rank %d of %d, GPU %d): %s [%s]", rank, world, device_id, nccl_err(e), rccl().path.c_str()); }
 #else
     std::vector<uint8_t> key(id, id + ORBX_COMM_ID_BYTES);
     {

@@ -72,3 +72,72 @@ def test_allgather_one_rank_rccl_gpu(hip_lib):
         k = len(res[b][2])
         assert n[0, b] == k and np.array_equal(d[0, b, :k], res[b][2]) and not d[0, b, k:].any()
     comm.close(); ex.close()
+
+
+_ORDER_PROBE = r'''
+import ctypes as C, os, sys
+order, root, want_exchange = sys.argv[1], sys.argv[2], sys.argv[3] == "1"
+sys.path.insert(0, root)
+if order == "torch_first":
+    import torch
+from orb_slam3_detailed_comments_amd import _lib, multi
+lib = _lib.load_hip()
+def mapped(key):
+    return sorted(set(l.split()[-1] for l in open("/proc/self/maps") if key in l))
+hip_of_library = [p for p in mapped("libamdhip64")]
+if order == "lib_first":
+    import torch
+idb = (C.c_uint8 * 128)()
+rc = lib.L.orbx_comm_unique_id(idb)                 # loads RCCL
+print("HIP", hip_of_library); print("RCCL", mapped("librccl")); print("rc", rc)
+if want_exchange:
+    import numpy as np
+    from orb_slam3_detailed_comments_amd import synth
+    from orb_slam3_detailed_comments_amd.extractor import ORBextractor
+    ex = ORBextractor(1200, 1.2, 8, 20, 7, device_id=0, lib=lib)
+    res = ex.extract_batch(np.stack([synth.corner_field(752, 480, seed=s) for s in range(2)]))
+    if order == "lib_first":
+        torch.zeros(4, device="cuda").sum().item()   # torch's own runtime is alive beside the library's
+    comm = multi.Communicator(lib, 1, 0, multi.Communicator.unique_id(lib), device_id=0)
+    comm.all_gather(ex); d, n = comm.fetch()
+    assert all(n[0, b] == len(res[b][2]) and np.array_equal(d[0, b, :n[0, b]], res[b][2]) for b in range(2))
+    comm.close(); ex.close()
+    print("EXCHANGE OK")
+'''
+
+
+def _order_probe(order, exchange):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _ORDER_PROBE, order, root, "1" if exchange else "0"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = dict(l.split(" ", 1) for l in r.stdout.splitlines() if " " in l)
+    return eval(out["HIP"]), eval(out["RCCL"]), r.stdout
+
+
+def _check_same_directory(hip, rccl):
+    # the library resolved exactly one HIP runtime, and an RCCL from that runtime's directory is mapped (the one it talks to)
+    assert len(hip) == 1, hip
+    d = os.path.dirname(os.path.realpath(hip[0]))
+    assert any(os.path.dirname(os.path.realpath(p)) == d for p in rccl), (hip, rccl)
+
+
+def test_rccl_is_taken_from_the_hip_runtime_the_library_is_bound_to():
+    """A process can hold two HIP runtimes: this library on /opt/rocm's, PyTorch (imported later) on the copy bundled in torch/lib, which brings its
+    own librccl.so.1.  A dlopen by soname would hand the library torch's RCCL - on the other runtime (found on the GPU by tests/test_lifetime.py:
+    ncclCommInitRank "unhandled cuda error").  The loader therefore looks next to the libamdhip64 it resolved; both load orders are checked."""
+    lib_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "orb_slam3_detailed_comments_amd", "liborbx_hip.so")
+    if not os.path.exists(lib_path):
+        pytest.skip("liborbx_hip.so not built")
+    for order in ("lib_first", "torch_first"):
+        hip, rccl, _ = _order_probe(order, False)
+        _check_same_directory(hip, rccl)
+
+
+@pytest.mark.gpu
+def test_allgather_one_rank_rccl_in_both_load_orders_gpu(hip_lib):
+    for order in ("lib_first", "torch_first"):
+        hip, rccl, out = _order_probe(order, True)
+        _check_same_directory(hip, rccl)
+        assert "EXCHANGE OK" in out
