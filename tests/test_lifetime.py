@@ -112,10 +112,11 @@ def test_everything_is_given_back_gpu(hip_lib):
     """+ the device's own account of free memory (hipMemGetInfo of the runtime the library is bound to).  PyTorch is imported in between on purpose:
     mapped after the library it brings a second HIP runtime and its own RCCL into the process, and the communicator of `exercise` has to keep
     working on the library's (tests/test_multi_comm.py)."""
-    import torch  # noqa: F401
     lib = hip_lib
-    hip_path = [l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l][0]        # the first one mapped: the library's
-    hip = C.CDLL(hip_path)
+    runtimes = sorted(set(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l))
+    assert len(runtimes) == 1, runtimes                   # the library's (nothing else of this test session has brought one)
+    hip = C.CDLL(runtimes[0])
+    import torch  # noqa: F401
 
     def free_bytes():
         gc.collect()
