@@ -89,7 +89,7 @@ if order == "lib_first":
     import torch
 idb = (C.c_uint8 * 128)()
 rc = lib.L.orbx_comm_unique_id(idb)                 # loads RCCL
-print("HIP", hip_of_library); print("RCCL", mapped("librccl")); print("rc", rc)
+print("ORBX_HIP=%r" % (hip_of_library,)); print("ORBX_RCCL=%r" % (mapped("librccl"),)); print("ORBX_RC=%d" % rc)
 if want_exchange:
     import numpy as np
     from orb_slam3_detailed_comments_amd import synth
@@ -110,8 +110,8 @@ def _order_probe(order, exchange):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _ORDER_PROBE, order, root, "1" if exchange else "0"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-    out = dict(l.split(" ", 1) for l in r.stdout.splitlines() if " " in l)
-    return eval(out["HIP"]), eval(out["RCCL"]), r.stdout
+    out = dict(l.split("=", 1) for l in r.stdout.splitlines() if l.startswith("ORBX_"))       # (RCCL prints a banner of its own on stdout)
+    return eval(out["ORBX_HIP"]), eval(out["ORBX_RCCL"]), r.stdout
 
 
 def _check_same_directory(hip, rccl):
