@@ -43,7 +43,8 @@ def emu_lib():
     with open(os.path.join(d, ".build.lock"), "w") as lock:          # the workers of a parallel run build it once, one after the other
         fcntl.flock(lock, fcntl.LOCK_EX)
         subprocess.run(["make", "-C", d, "-s"], check=True, stdout=subprocess.DEVNULL)
-    return _lib.OrbxLib(os.path.join(d, "liborbx_emu.so"))
+    # ORBX_EMU_LIB: another build of the same sources (tools/emu_sanitizers.sh: AddressSanitizer / UBSan builds, run with libasan preloaded)
+    return _lib.OrbxLib(os.environ.get("ORBX_EMU_LIB") or os.path.join(d, "liborbx_emu.so"))
 
 
 @pytest.fixture(scope="session")

@@ -61,6 +61,9 @@ struct Tls {
     Fiber* cur = nullptr;
     std::vector<Fiber> pool;
     std::vector<unsigned char> smem;
+    // the workers of a launch are threads of that launch: their fiber stacks go with them (they were left mapped until round 5 - a few MB of touched
+    // pages per launch, tens of GB over a sanitizer run of the suite)
+    ~Tls() { for (Fiber& f : pool) if (f.stack) munmap(f.stack, kStack); }
 };
 inline Tls& tls() { static thread_local Tls t; return t; }
 inline Fiber& cur() { return *tls().cur; }
