@@ -1,5 +1,5 @@
-"""Batches whose buffers cross 4 GB: the pyramid and its blurred copy of 3000 EuRoC images are 4.9 GB each, the candidate lists 3.6 GB - any batch offset
-computed in 32 bits would read or write the wrong image.  Six distinct stereo pairs are tiled over the batch; every image of the batch has to come out exactly as
+"""Batches whose buffers cross 4 GB: the pyramid and its blurred copy of 4600 EuRoC images are 5.4 GB each (1 167 616 bytes per image; the 4-GB mark falls
+on image 3678) - any batch offset computed in 32 bits would read or write the wrong image.  Six distinct stereo pairs are tiled over the batch; every image of the batch has to come out exactly as
 the same image extracted in a batch of twelve (itself checked against the reference elsewhere), and so has every stereo pair - the later half of the batch lies
 beyond the 4-GB mark.  Runs in a process of its own: a wild access would take the process down, not the test session."""
 import os
@@ -46,7 +46,7 @@ print("RESULT images %d wrong %d pairs %d wrong %d matches_per_pair %.1f" % (2 *
 
 
 def test_batch_buffers_beyond_4GB():
-    r = subprocess.run([sys.executable, "-c", _RUNNER, ROOT, "1500"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, "-c", _RUNNER, ROOT, "2300"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()
-    assert line[1:5] == ["images", "3000", "wrong", "0"] and line[5:9] == ["pairs", "1500", "wrong", "0"] and float(line[-1]) > 100, line
+    assert line[1:5] == ["images", "4600", "wrong", "0"] and line[5:9] == ["pairs", "2300", "wrong", "0"] and float(line[-1]) > 100, line
