@@ -7,7 +7,7 @@ namespace orbx {
 
 __device__ __forceinline__ int mul24(int a, int b) {
 #ifdef ORBX_EMU
-    return (int)((unsigned)a * (unsigned)b);        // (the self-test feeds operands beyond the kernels' ranges: wrap like the instruction instead of overflowing)
+    return a * b;
 #else
     return __mul24(a, b);      // operands < 2^23: full-rate 24-bit multiply instead of the quarter-rate 32-bit one
 #endif
@@ -15,7 +15,7 @@ __device__ __forceinline__ int mul24(int a, int b) {
 // the same, but immune to the compiler turning it back into v_mul_lo_u32 (it does where it has proven narrower operand ranges)
 __device__ __forceinline__ int mul24_forced(int a, int b) {
 #ifdef ORBX_EMU
-    return (int)((unsigned)a * (unsigned)b);
+    return a * b;
 #else
     int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
 #endif
