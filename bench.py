@@ -469,9 +469,7 @@ def main():
     import ctypes as C
     kb = None
     if kind == "fisheye":
-        class Cams(C.Structure):
-            _fields_ = [("cam1", C.c_float * 8), ("cam2", C.c_float * 8), ("R12", C.c_float * 9), ("t12", C.c_float * 3)]
-        kb = Cams()
+        kb = M.KB8Stereo()
         kb.cam1[:] = KB_CAM1; kb.cam2[:] = KB_CAM2; kb.t12[:] = KB_TLR.tolist()
         kb.R12[:] = sophus.SE3f(KB_RLR, KB_TLR).rotationMatrix().ravel().tolist()          # mRlr = mTlr.rotationMatrix() (src/Frame.cc:1498-1501)
     local_map = None

@@ -9,6 +9,13 @@ from . import _lib
 from ._lib import KP_DTYPE
 
 
+class InputSpec(C.Structure):
+    """OrbxInputSpec (include/orbx.h)"""
+    _fields_ = [("channels", C.c_int), ("rgb", C.c_int), ("gray_variant", C.c_int),
+                ("geometry", C.c_int), ("out_w", C.c_int), ("out_h", C.c_int),
+                ("map_x", C.c_void_p), ("map_y", C.c_void_p)]
+
+
 class ORBextractor:
     HARRIS_SCORE, FAST_SCORE = 0, 1   # include/ORBextractor.h:47 (only FAST_SCORE is ever computed)
 
@@ -80,10 +87,7 @@ class ORBextractor:
         Settings::newImSize (:295-297); channels 3/4 + rgb = the cvtColor of Tracking::GrabImage* (src/Tracking.cc:1532-1560).
         Frames are then passed as [B,H,W] (1 channel) or [B,H,W,C].  set_input(None) restores plain 8UC1 input."""
         import ctypes as C
-
-        class Spec(C.Structure):
-            _fields_ = [("channels", C.c_int), ("rgb", C.c_int), ("gray_variant", C.c_int), ("geometry", C.c_int), ("out_w", C.c_int),
-                        ("out_h", C.c_int), ("map_x", C.c_void_p), ("map_y", C.c_void_p)]
+        Spec = InputSpec
         if channels is None:
             self._lib.check(self._lib.L.orbx_set_input(self._h, None)); self._in_channels = 1
             return

@@ -239,16 +239,17 @@ def StereoFishEyeKnn(left, right, left_first=0, right_first=0, B=None):
     return out
 
 
+class KB8Stereo(C.Structure):
+    """OrbmKB8Stereo (include/orbx.h): the two cameras' Kannala-Brandt parameters, Frame::mRlr (row-major), mtlr"""
+    _fields_ = [("cam1", C.c_float * 8), ("cam2", C.c_float * 8), ("R12", C.c_float * 9), ("t12", C.c_float * 3)]
+
+
 def ComputeStereoFishEyeMatches(left, right, cam1, cam2, R12, t12, left_first=0, right_first=0, B=None):
     """Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1530-1587) for B fisheye pairs extracted with the cameras' lapping areas: 2-NN + ratio
     test, then KannalaBrandt8::TriangulateMatches on the device.  cam1 / cam2 = the 8 Kannala-Brandt parameters, (R12, t12) = mRlr, mtlr.
     Returns dict(l2r [B,cap], r2l [B,cap], depth [B,cap], p3d [B,cap,3], n [B])."""
-    import ctypes as C
-
-    class Cams(C.Structure):
-        _fields_ = [("cam1", C.c_float * 8), ("cam2", C.c_float * 8), ("R12", C.c_float * 9), ("t12", C.c_float * 3)]
     B = B or min(left._B - left_first, right._B - right_first)
-    c = Cams()
+    c = KB8Stereo()
     c.cam1[:] = [float(v) for v in cam1]; c.cam2[:] = [float(v) for v in cam2]
     c.R12[:] = [float(v) for v in np.asarray(R12, np.float32).ravel()]; c.t12[:] = [float(v) for v in np.asarray(t12, np.float32).ravel()]
     L = left._lib

@@ -102,9 +102,7 @@ def test_headline_shape_fisheye_gpu(hip_lib):
     handles = [ORBextractor(nf, 1.2, 8, 20, 7, lib=lib) for _ in range(NH)]
     order = [[(p * (2 * i + 1) + 3 * i) % nunique for p in range(P)] for i in range(NH)]
 
-    class Cams(C.Structure):
-        _fields_ = [("cam1", C.c_float * 8), ("cam2", C.c_float * 8), ("R12", C.c_float * 9), ("t12", C.c_float * 3)]
-    kb = Cams()
+    kb = M.KB8Stereo()
     kb.cam1[:] = CAM1; kb.cam2[:] = CAM2; kb.R12[:] = MRLR.ravel().tolist(); kb.t12[:] = TLR.tolist()
     ups, outs = [], []
     for i, h in enumerate(handles):
