@@ -491,7 +491,7 @@ if __name__ == "__main__":
         def live():
             a = (C.c_longlong * 4)(); assert d._orbx.orbx_debug_live_resources(a) == 0; return list(a)
         first = live()
-        for _ in range(2):
+        for _ in range(int(sys.argv[7]) if len(sys.argv) > 7 else 1):
             d2 = Driver(drv_path, None)
             res2 = build_and_run_rig(d2, seed) if variant == "rig" else build_and_run_kb8(d2, seed) if variant == "kb8" else build_and_run(d2, seed, variant)
             assert all(np.array_equal(res[k], res2[k]) for k in res)
