@@ -45,6 +45,10 @@ def test_empty_image_and_errors(emu_lib):
         ORBextractor(0, 1.2, 8, 20, 7, lib=emu_lib)
     with pytest.raises(OrbxError):                                    # orbx_set_pyramid_mode: 0, 1 or 2
         ex.pyramid_mode(3)
+    for shape in ((300, 4128), (4128, 300)):                          # one pixel beyond the largest size (tests/cases.py: max_4127x4127 on the GPU)
+        with pytest.raises(OrbxError, match="4127"):
+            ex(np.zeros(shape, np.uint8))
+    assert len(ex(synth.corner_field(376, 240, seed=10, nrect=800))[1]) > 300       # the handle is still usable after the refusals
 
 
 def test_other_parameters_and_gauss_variant(emu_lib):
