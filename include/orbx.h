@@ -46,7 +46,12 @@ typedef struct orbx_extractor orbx_extractor;
 int orbx_device_count(void);
 
 /* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)  include/ORBextractor.h:49-50,
- * src/ORBextractor.cc:468-571.  device_id selects the GPU (one process per GPU in multi-GPU runs). */
+ * src/ORBextractor.cc:468-571.  device_id selects the GPU (one process per GPU in multi-GPU runs).
+ * Limits, all reported loudly: images of at most 4127 x 4127 pixels and at least the 35-px FAST cell grid on the smallest level (ORBX_E_ARG from the
+ * extraction); the quadtree of a level works in LDS, 81 bytes per node: beside it the bucket counters and the coordinate tables of the level (16 - 55 KB, growing
+ * with the image).  With the 160 KB of gfx950, scale factor 1.2 and 8 levels (level 0 takes 21.7 % of the features) that is nfeatures up to 7 800 at 752 x 480
+ * and about 6 100 at 4127 x 4127 when one to 32 images are extracted per call, more in larger batches (narrower counters) - ORBX_E_CAPACITY from the
+ * extraction beyond that, the handle stays usable (the reference's settings files ask for 1 000 - 2 000); fewer than 65 535 keypoints per image over all levels. */
 int orbx_create(orbx_extractor** out, int nfeatures, float scale_factor, int nlevels,
                 int ini_th_fast, int min_th_fast, int device_id);
 void orbx_destroy(orbx_extractor* h);

@@ -45,7 +45,8 @@ inline int event_sync(event_t) { return 0; }
 inline float event_elapsed_ms(event_t a, event_t b) { return (float)(b->t - a->t); }
 inline const char* last_error() { return "emu"; }
 inline int check_launch() { return 0; }
-inline size_t lds_limit(int) { return (size_t)1 << 30; }
+// ORBX_EMU_LDS_LIMIT: the tests give the emulator the device's LDS size (163840 on gfx950) to reach the capacity refusals on the CPU
+inline size_t lds_limit(int) { const char* e = getenv("ORBX_EMU_LDS_LIMIT"); const long long v = e ? atoll(e) : 0; return v > 0 ? (size_t)v : (size_t)1 << 30; }
 #else
 typedef hipStream_t stream_t;
 typedef hipEvent_t event_t;

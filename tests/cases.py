@@ -23,7 +23,7 @@ LARGE_CASES = [   # sizes outside BASELINE.json that real rigs use (KITTI, HD): 
     # the largest image the library takes (keypoint coordinates are packed in 12 bits per axis on the device: 4095 + the 2 x 16-px border) - 17 Mpixel,
     # 10 148 FAST cells on level 0; with noise every cell overflows its list and the quadtree starts from 2.6 M candidates
     ("max_4127x4127_n5000", lambda: synth.corner_field(4127, 4127, seed=5, nrect=int(3000 * 4127 * 4127 / (752 * 480))), 5000, (0, 0)),
-    ("max_noise_4127x4127_n8000", lambda: synth.uniform_noise(4127, 4127, seed=6), 8000, (0, 0)),
+    ("max_noise_4127x4127_n6000", lambda: synth.uniform_noise(4127, 4127, seed=6), 6000, (0, 0)),     # (about 6 100 is what the quadtree's LDS takes at this size)
 ]
 
 SMALL_CASES = [
