@@ -37,6 +37,10 @@ SMALL_CASES = [
     ("small_pink_noise", lambda: synth.pink_noise(376, 240, seed=17, beta=1.3), 500, (0, 0)),
     ("small_threshold_fallback", lambda: synth.threshold_blocks(376, 240, seed=18), 500, (0, 0)),   # cells that need the second FAST run at minThFAST
     ("small_wide_nini3", lambda: synth.corner_field(640, 250, seed=15, nrect=900), 600, (0, 0)),
+    # the smallest images the reference can take with 8 levels at 1.2 (level 7: 67 px = one 35-px cell between the borders; one pixel less and its cell
+    # count is 0 and it divides by it - the library refuses that size), square and at the smallest aspect ratio (0.5)
+    ("min_239x239_noise_n1000", lambda: synth.uniform_noise(239, 239, seed=19), 1000, (0, 0)),
+    ("min_477x239_aspect_n100", lambda: synth.corner_field(477, 239, seed=20, nrect=450), 100, (0, 0)),
 ]
 
 EUROC_BF, EUROC_B = 458.654 * 0.110074, 0.110074   # Examples/Stereo/EuRoC.yaml:23,57 (fx * baseline, baseline)

@@ -45,6 +45,10 @@ def test_empty_image_and_errors(emu_lib):
         ORBextractor(0, 1.2, 8, 20, 7, lib=emu_lib)
     with pytest.raises(OrbxError):                                    # orbx_set_pyramid_mode: 0, 1 or 2
         ex.pyramid_mode(3)
+    with pytest.raises(OrbxError, match="too small"):                 # one pixel below the smallest size (tests/cases.py: min_239x239)
+        ex(np.zeros((238, 238), np.uint8))
+    with pytest.raises(OrbxError, match="aspect ratio"):              # taller than twice the width: the reference's nIni is 0 and it divides by it
+        ex(np.zeros((479, 239), np.uint8))
     for shape in ((300, 4128), (4128, 300)):                          # one pixel beyond the largest size (tests/cases.py: max_4127x4127 on the GPU)
         with pytest.raises(OrbxError, match="4127"):
             ex(np.zeros(shape, np.uint8))
