@@ -10,8 +10,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 @pytest.hookimpl(tryfirst=True)
 def pytest_cmdline_main(config):
-    """The CPU suite (`-m "not gpu"`: oracle pinning, models, the kernel sources on the SIMT emulator) is ~150 independent tests and 8 minutes
-    on one core; when pytest-xdist is installed it is spread over the cores (4 minutes on 8).  GPU runs (`-m gpu`) stay in one process: the
+    """The CPU suite (`-m "not gpu"`: oracle pinning, models, the kernel sources on the SIMT emulator) is ~200 independent tests; when pytest-xdist is installed it is spread over the cores
+    (a minute and a half on 8 since the emulator switches fibers without system calls and keeps its worker threads, round 5; 7 minutes before).  GPU runs (`-m gpu`) stay in one process: the
     tests time kernels and share one device.  An explicit -n / -p no:xdist on the command line wins."""
     try:
         import xdist  # noqa: F401

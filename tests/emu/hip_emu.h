@@ -22,7 +22,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 struct dim3 {
@@ -35,9 +38,29 @@ namespace hipemu {
 constexpr int kWave = 64;
 constexpr size_t kStack = 256 * 1024;
 
+// Switching fibers: by default a six-register stack switch (x86-64 SysV: rbx, rbp, r12-r15 + the stack pointer; the kernels never touch the FP control
+// words) - swapcontext() saves and restores the signal mask with a system call per switch, which was a third of the CPU time of the emulated suite.
+// -DHIPEMU_UCONTEXT keeps ucontext (the sanitizer builds: ASan knows swapcontext, not a hand-made switch; other architectures).
+#if !defined(__x86_64__) && !defined(HIPEMU_UCONTEXT)
+#define HIPEMU_UCONTEXT
+#endif
+#ifdef HIPEMU_UCONTEXT
+typedef ucontext_t Ctx;
+#else
+struct Ctx { void* sp = nullptr; };
+static __attribute__((naked, noinline)) void switch_ctx(Ctx* /*from: rdi*/, Ctx* /*to: rsi*/) {
+    __asm__ volatile(
+        "pushq %rbp\n\t" "pushq %rbx\n\t" "pushq %r12\n\t" "pushq %r13\n\t" "pushq %r14\n\t" "pushq %r15\n\t"
+        "movq %rsp, (%rdi)\n\t"
+        "movq (%rsi), %rsp\n\t"
+        "popq %r15\n\t" "popq %r14\n\t" "popq %r13\n\t" "popq %r12\n\t" "popq %rbx\n\t" "popq %rbp\n\t"
+        "ret\n\t");
+}
+#endif
+
 struct Block;
 struct Fiber {
-    ucontext_t ctx;
+    Ctx ctx;
     dim3 tid;
     int flat = 0, lane = 0, wave = 0;
     bool done = false;
@@ -54,7 +77,7 @@ struct Block {
     int bar_count = 0, bar_gen = 0;
     std::vector<WaveState> waves;
     unsigned char* dyn_smem = nullptr;
-    ucontext_t sched;
+    Ctx sched;
     const std::function<void()>* fn = nullptr;
 };
 struct Tls {
@@ -68,7 +91,10 @@ struct Tls {
 inline Tls& tls() { static thread_local Tls t; return t; }
 inline Fiber& cur() { return *tls().cur; }
 
-inline void yield() { Fiber* f = tls().cur; swapcontext(&f->ctx, &f->blk->sched); }
+#ifdef HIPEMU_UCONTEXT
+inline void switch_ctx(Ctx* from, Ctx* to) { swapcontext(from, to); }
+#endif
+inline void yield() { Fiber* f = tls().cur; switch_ctx(&f->ctx, &f->blk->sched); }
 
 inline void block_barrier() {
     Block* b = cur().blk;
@@ -104,7 +130,8 @@ inline void trampoline() {
     WaveState& w = b->waves[f->wave];
     w.lanes--;
     if (w.count > 0 && w.count >= w.lanes) { w.count = 0; w.gen++; }
-    swapcontext(&f->ctx, &b->sched);
+    switch_ctx(&f->ctx, &b->sched);
+    __builtin_unreachable();            // a finished fiber is never resumed
 }
 
 inline void run_block(const std::function<void()>& fn, dim3 bid, dim3 bdim, dim3 gdim, size_t smem_bytes) {
@@ -128,15 +155,25 @@ inline void run_block(const std::function<void()>& fn, dim3 bid, dim3 bdim, dim3
         f.flat = i; f.lane = i % kWave; f.wave = i / kWave; f.done = false; f.blk = &b;
         f.tid = dim3(i % bdim.x, (i / bdim.x) % bdim.y, i / (bdim.x * bdim.y));
         b.waves[f.wave].lanes++;
+#ifdef HIPEMU_UCONTEXT
         getcontext(&f.ctx);
         f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = kStack; f.ctx.uc_link = nullptr;
         makecontext(&f.ctx, (void (*)())trampoline, 0);
+#else
+        // first switch into the fiber: six zeroed callee-saved registers are popped, `ret` enters trampoline() with the stack pointer where a call
+        // would have left it (8 below a 16-byte boundary), above it a null return address (trampoline never returns)
+        uint64_t* sp = (uint64_t*)(((uintptr_t)f.stack + kStack) & ~(uintptr_t)15);
+        *--sp = 0;
+        *--sp = (uint64_t)(uintptr_t)(void (*)())trampoline;
+        for (int r = 0; r < 6; r++) *--sp = 0;
+        f.ctx.sp = sp;
+#endif
     }
     while (b.alive > 0) {
         for (int i = 0; i < n; i++) {
             if (t.pool[i].done) continue;
             t.cur = &t.pool[i];
-            swapcontext(&b.sched, &t.pool[i].ctx);
+            switch_ctx(&b.sched, &t.pool[i].ctx);
         }
     }
     t.cur = nullptr;
@@ -144,11 +181,52 @@ inline void run_block(const std::function<void()>& fn, dim3 bid, dim3 bdim, dim3
 
 inline int& num_workers() { static int n = std::max(1u, std::min(8u, std::thread::hardware_concurrency())); return n; }
 
+// The workers are threads that live as long as the process (round 5; a launch used to create and join its own, with their fiber stacks mapped anew -
+// most launches of the test suite are small, and that was most of their cost).  One launch runs at a time; a launch from another host thread waits.
+struct Pool {
+    std::mutex launch_m, m;
+    std::condition_variable cv_job, cv_done;
+    const std::function<void()>* job = nullptr;
+    long gen = 0;
+    int want = 0, running = 0, nthreads = 0;
+    pid_t pid = 0;
+};
+inline void pool_thread(Pool* p, int index) {
+    long seen = 0;
+    for (;;) {
+        const std::function<void()>* job;
+        {
+            std::unique_lock<std::mutex> l(p->m);
+            p->cv_job.wait(l, [&] { return p->gen != seen; });
+            seen = p->gen;
+            if (index >= p->want) continue;
+            job = p->job;
+        }
+        (*job)();
+        {
+            std::lock_guard<std::mutex> l(p->m);
+            if (--p->running == 0) p->cv_done.notify_all();
+        }
+    }
+}
+inline Pool* pool() {
+    static std::mutex m;
+    static Pool* p = nullptr;
+    std::lock_guard<std::mutex> l(m);
+    if (!p || p->pid != getpid()) {                 // (a forked child has none of the parent's threads: it gets a pool of its own; the old one is left alone)
+        p = new Pool();
+        p->pid = getpid();
+        p->nthreads = num_workers();
+        for (int i = 0; i < p->nthreads; i++) std::thread(pool_thread, p, i).detach();
+    }
+    return p;
+}
+
 inline void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> fn) {
     const long total = (long)grid.x * grid.y * grid.z;
     if (total == 0) return;
     std::atomic<long> next(0);
-    auto worker = [&]() {
+    const std::function<void()> worker = [&]() {
         for (;;) {
             long i = next.fetch_add(1);
             if (i >= total) break;
@@ -158,9 +236,12 @@ inline void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> fn)
     };
     const int nw = (int)std::min<long>(num_workers(), total);
     if (nw <= 1) { worker(); return; }
-    std::vector<std::thread> th;
-    for (int i = 0; i < nw; i++) th.emplace_back(worker);
-    for (auto& t : th) t.join();
+    Pool* p = pool();
+    std::lock_guard<std::mutex> one(p->launch_m);
+    std::unique_lock<std::mutex> l(p->m);
+    p->job = &worker; p->want = std::min(nw, p->nthreads); p->running = p->want; p->gen++;
+    p->cv_job.notify_all();
+    p->cv_done.wait(l, [&] { return p->running == 0; });
 }
 
 }  // namespace hipemu
