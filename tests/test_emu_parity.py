@@ -415,3 +415,12 @@ def test_feature_counts_beyond_the_lds_are_refused(emu_lib, monkeypatch):
     ok = ORBextractor(7800, 1.2, 8, 20, 7, lib=emu_lib)(img)
     exp = ol.OracleExtractor(7800).extract(img)
     assert ol.kps_equal(ok[1], exp[1]) and np.array_equal(ok[2], exp[2])
+
+
+def test_largest_image_emulated(emu_lib):
+    """4127 x 4127 (tests/cases.py: max_* on the GPU) through the kernel sources on the CPU: 12-bit packed coordinates at their limit, 10 148 cells on level 0"""
+    img = synth.corner_field(4127, 4127, seed=5, nrect=int(3000 * 4127 * 4127 / (752 * 480)))
+    got = ORBextractor(5000, 1.2, 8, 20, 7, lib=emu_lib)(img)
+    exp = ol.OracleExtractor(5000).extract(img)
+    assert len(exp[1]) > 4900 and ol.kps_equal(got[1], exp[1]) and np.array_equal(got[2], exp[2])
+    assert int(got[1]["x"].max()) > 4000 and int(got[1]["y"].max()) > 4000
