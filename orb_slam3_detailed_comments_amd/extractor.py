@@ -168,6 +168,9 @@ class ORBextractor:
         cap = 1 << 18
         a = np.zeros((cap, 3), np.int32)
         n = self._lib.L.orbx_debug_candidates(self._h, image_index, level, a.ctypes.data, cap)
+        if n > cap:                                   # the call reports the full count and fills what fits: ask again with room for all of it
+            a = np.zeros((n, 3), np.int32)
+            n = self._lib.L.orbx_debug_candidates(self._h, image_index, level, a.ctypes.data, n)
         if n < 0:
             self._lib.check(n)
         return a[:n].copy()
