@@ -26,14 +26,15 @@ for seed in range(1000, 1000 + n):
     for variant in ("base", "dense", "hard", "rig"):
         a = os.path.join(tmp, "a.npz"); b = os.path.join(tmp, "b.npz")
         subprocess.run([sys.executable, RUN, REF, "", str(seed), variant, a], check=True)
-        subprocess.run([sys.executable, RUN, FAC, _lib.HIP_LIB_PATH, str(seed), variant, b], check=True)
+        subprocess.run([sys.executable, RUN, FAC, (os.environ.get("ORBX_SOAK_LIB") or _lib.HIP_LIB_PATH), str(seed), variant, b], check=True)
         A, B = np.load(a), np.load(b)
         for k in A.files:
             if k != "flavour" and not np.array_equal(A[k], B[k]):
                 print("DIFF world seed %d %s: %s" % (seed, variant, k)); bad += 1
 print("matcher worlds: %d seeds x 4 variants, %d differences" % (n, bad))
 
-lib = _lib.load_hip()
+LIB_PATH = os.environ.get("ORBX_SOAK_LIB") or _lib.HIP_LIB_PATH      # ORBX_SOAK_LIB=tests/emu/liborbx_emu.so: the same soak on the CPU emulator build
+lib = _lib.OrbxLib(LIB_PATH) if os.environ.get("ORBX_SOAK_LIB") else _lib.load_hip()
 FX = 458.654; BF = FX * 0.110074
 bad2 = 0
 exs = {}

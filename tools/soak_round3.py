@@ -16,7 +16,8 @@ import test_undistort as t_und                               # noqa: E402
 import test_lastframe_batch as t_last                        # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-lib = _lib.load_hip()
+LIB_PATH = os.environ.get("ORBX_SOAK_LIB") or _lib.HIP_LIB_PATH      # ORBX_SOAK_LIB=tests/emu/liborbx_emu.so: the same soak on the CPU emulator build
+lib = _lib.OrbxLib(LIB_PATH) if os.environ.get("ORBX_SOAK_LIB") else _lib.load_hip()
 t_rig._check(lib, tuple(range(200, 200 + n)), 5000)
 print("rig isInFrustum + rig SearchByProjection vs the reference rig Frame: %d frames x 5000 points x 2 settings, 0 differences" % n, flush=True)
 for i in range(max(1, n // 3)):

@@ -15,7 +15,8 @@ import test_bow_frames_batch as t_bow                        # noqa: E402
 import test_sophus_action as t_so3                           # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-lib = _lib.load_hip()
+LIB_PATH = os.environ.get("ORBX_SOAK_LIB") or _lib.HIP_LIB_PATH      # ORBX_SOAK_LIB=tests/emu/liborbx_emu.so: the same soak on the CPU emulator build
+lib = _lib.OrbxLib(LIB_PATH) if os.environ.get("ORBX_SOAK_LIB") else _lib.load_hip()
 for s in range(1, n + 1):
     t_last._run(lib, 752, 480, 1200, 6, bool(s & 1), seed=s)
 print("batched LastFrame search vs the reference Frame + ORBmatcher.cc per frame: %d batches of 6 frames x 3 settings, 0 differences" % n, flush=True)

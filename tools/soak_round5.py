@@ -20,14 +20,15 @@ import test_matcher_reference as t_mw                        # noqa: E402
 import test_lastframe_batch as t_last                        # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-lib = _lib.load_hip()
+LIB_PATH = os.environ.get("ORBX_SOAK_LIB") or _lib.HIP_LIB_PATH      # ORBX_SOAK_LIB=tests/emu/liborbx_emu.so: the same soak on the CPU emulator build
+lib = _lib.OrbxLib(LIB_PATH) if os.environ.get("ORBX_SOAK_LIB") else _lib.load_hip()
 acc = t_kb8._check(lib, tuple(range(100, 100 + n)), (0, 511), 1500) + t_kb8._check(lib, tuple(range(200, 200 + max(1, n // 2))), (100, 400), 1000)
 print("fisheye-rig Frame constructor vs the reference Frame.cc + KannalaBrandt8.cpp: %d pairs, %d accepted matches, mvDepth / mvStereo3Dpoints identical to the bit" % (n + max(1, n // 2), acc), flush=True)
 t_rig._check(lib, tuple(range(300, 300 + max(2, n // 2))), 3000)
 print("isInFrustum + SearchByProjection over the rig vs the reference: %d frames x 2 settings, 0 differences" % max(2, n // 2), flush=True)
 tmp = pathlib.Path(tempfile.mkdtemp())
-t_mw._compare(tmp, _lib.HIP_LIB_PATH, [(s, "kb8") for s in range(400, 400 + n)])
-t_mw._compare(tmp, _lib.HIP_LIB_PATH, [(s, "kb8") for s in range(500, 500 + max(2, n // 2))] + [(s, "base") for s in range(600, 600 + max(2, n // 2))], t_mw.REF_REAL, t_mw.FACADE_REAL)
+t_mw._compare(tmp, LIB_PATH, [(s, "kb8") for s in range(400, 400 + n)])
+t_mw._compare(tmp, LIB_PATH, [(s, "kb8") for s in range(500, 500 + max(2, n // 2))] + [(s, "base") for s in range(600, 600 + max(2, n // 2))], t_mw.REF_REAL, t_mw.FACADE_REAL)
 print("matcher worlds (Kannala-Brandt key frames, one camera and rig; single calls through the implicit resident cache) vs the reference ORBmatcher.cc: %d stand-in + %d real-class worlds, 0 differences"
       % (n, 2 * max(2, n // 2)), flush=True)
 for s in range(max(2, n // 2)):
