@@ -41,7 +41,9 @@ namespace {
 // One upload stream per GPU for all handles of the process (round 5).  The link gives one stream of uploads 57 GB/s and four streams uploading at once
 // 50.6 (tools/pcie_duplex_probe.hip, profiles/r05/pcie_duplex_probe.txt): with a copy stream per handle the PCIe-inclusive bench line sat at 0.85 of the
 // link.  Uploads of different handles queue behind one another in the order the host issued them; results travelling the other way (on the handles' own
-// streams) share the link in full duplex.
+// streams) share the link in full duplex.  The stream is created at the first asynchronous upload, AFTER the handles' own streams: HIP deals streams onto its
+// four hardware queues round robin, and every handle keeps three streams of its own (the third a spare since this change) so that the main streams of four
+// handles land on four different queues - with two streams per handle two of them shared a queue and the headline lost 14 % (profiles/r05/shared_upload_stream.txt).
 struct SharedCopyStream { rt::stream_t s{}; int refs = 0; };
 std::mutex g_copy_m;
 std::map<int, SharedCopyStream> g_copy;
@@ -496,11 +498,10 @@ int orbx_create(orbx_extractor** out, int nfeatures, float scale_factor, int nle
     orbx_extractor* h = new orbx_extractor();
     h->nfeatures = nfeatures; h->scaleFactor = scale_factor; h->nlevels = nlevels; h->iniTh = ini_th; h->minTh = min_th; h->device = device_id;
     init_tables(h);
-    int e = rt::stream_create(&h->s0) | rt::stream_create(&h->s1) | rt::event_create(&h->ev_fork) | rt::event_create(&h->ev_join) |
+    int e = rt::stream_create(&h->s0) | rt::stream_create(&h->s1) | rt::stream_create(&h->s_spare) | rt::event_create(&h->ev_fork) | rt::event_create(&h->ev_join) |
             rt::event_create(&h->ev_done) | rt::event_create(&h->ev_copy) | rt::event_create(&h->ev_import) | rt::event_create(&h->ev_lp);
     for (int i = 0; i < ORBX_NSTAGES; i++) { e |= rt::event_create(&h->ev_stage[i][0]); e |= rt::event_create(&h->ev_stage[i][1]); h->stage_ms[i] = 0; }
     h->have_streams = true;
-    if (!e) { e = acquire_copy_stream(device_id, &h->s_copy); h->have_copy_stream = !e; }
     if (e) { orbx_destroy(h); return fail(ORBX_E_DEVICE, "stream/event creation failed"); }      // (gives back whatever was created)
     *out = h;
     return ORBX_OK;
@@ -518,7 +519,7 @@ void orbx_destroy(orbx_extractor* h) {
         for (int i = 0; i < ORBX_NSTAGES; i++) { rt::event_destroy(h->ev_stage[i][0]); rt::event_destroy(h->ev_stage[i][1]); }
         if (h->have_copy_stream) rt::stream_sync(h->s_copy);
         rt::event_destroy(h->ev_fork); rt::event_destroy(h->ev_join); rt::event_destroy(h->ev_done); rt::event_destroy(h->ev_copy); rt::event_destroy(h->ev_import); rt::event_destroy(h->ev_lp);
-        rt::stream_destroy(h->s0); rt::stream_destroy(h->s1);
+        rt::stream_destroy(h->s0); rt::stream_destroy(h->s1); rt::stream_destroy(h->s_spare);
         if (h->have_copy_stream) release_copy_stream(h->device);
     }
     h->d_lv.release(); h->d_cells.release(); h->d_xtab.release(); h->d_ytab.release(); h->d_xspan.release(); h->d_yspan.release(); h->d_pyr.release(); h->d_blur.release(); h->d_stage.release();
@@ -746,6 +747,10 @@ int orbx_device_upload(orbx_extractor* h, void* dptr, const void* host, size_t b
 int orbx_device_upload_async(orbx_extractor* h, void* dptr, const void* host, size_t bytes) {
     if (!h || !dptr || !host) return fail(ORBX_E_ARG, "null");
     rt::set_device(h->device);
+    if (!h->have_copy_stream) {            // the GPU's upload stream, created at the first asynchronous upload of the process (see SharedCopyStream)
+        if (acquire_copy_stream(h->device, &h->s_copy)) return fail(ORBX_E_DEVICE, "copy stream creation failed: %s", rt::last_error());
+        h->have_copy_stream = true;
+    }
     record_import_if_pending(h);
     if (h->lastB > 0 && rt::stream_wait_event(h->s_copy, h->ev_import)) return fail(ORBX_E_DEVICE, "upload could not be ordered behind the previous extraction: %s", rt::last_error());
     if (rt::copy_h2d(dptr, host, bytes, h->s_copy) || rt::event_record(h->ev_copy, h->s_copy)) return fail(ORBX_E_DEVICE, "upload failed: %s", rt::last_error());
