@@ -2,7 +2,6 @@
 // src/ORBextractor.cc:468-571), per-resolution geometry (pyramid sizes :1691-1692, FAST cell grid
 // :1069-1129, resize coefficients of cv::resize), device memory, stream orchestration and the C ABI of
 // include/orbx.h.  Compiled by hipcc for gfx950 (product) or by g++ against tests/emu (tests only).
-#include <map>
 #include <mutex>
 #include "orbx_internal.h"
 
@@ -36,31 +35,6 @@ int fail(int code, const char* fmt, ...) {
 }
 const char* last_error_string() { return g_err.c_str(); }
 }  // namespace orbx
-
-namespace {
-// One upload stream per GPU for all handles of the process (round 5).  The link gives one stream of uploads 57 GB/s and four streams uploading at once
-// 50.6 (tools/pcie_duplex_probe.hip, profiles/r05/pcie_duplex_probe.txt): with a copy stream per handle the PCIe-inclusive bench line sat at 0.85 of the
-// link.  Uploads of different handles queue behind one another in the order the host issued them; results travelling the other way (on the handles' own
-// streams) share the link in full duplex.  The stream is created at the first asynchronous upload, AFTER the handles' own streams: HIP deals streams onto its
-// four hardware queues round robin, and every handle keeps three streams of its own (the third a spare since this change) so that the main streams of four
-// handles land on four different queues - with two streams per handle two of them shared a queue and the headline lost 14 % (profiles/r05/shared_upload_stream.txt).
-struct SharedCopyStream { rt::stream_t s{}; int refs = 0; };
-std::mutex g_copy_m;
-std::map<int, SharedCopyStream> g_copy;
-int acquire_copy_stream(int device, rt::stream_t* out) {
-    std::lock_guard<std::mutex> l(g_copy_m);
-    SharedCopyStream& c = g_copy[device];
-    if (c.refs == 0 && rt::stream_create(&c.s)) return -1;
-    c.refs++; *out = c.s;
-    return 0;
-}
-void release_copy_stream(int device) {
-    std::lock_guard<std::mutex> l(g_copy_m);
-    auto it = g_copy.find(device);
-    if (it == g_copy.end() || it->second.refs <= 0) return;
-    if (--it->second.refs == 0) { rt::stream_destroy(it->second.s); g_copy.erase(it); }
-}
-}
 
 namespace {
 const char* kStageNames[ORBX_NSTAGES] = {"import", "pyramid", "fast_cells", "quadtree", "blur", "layout", "orient_brief", "match"};
@@ -498,7 +472,7 @@ int orbx_create(orbx_extractor** out, int nfeatures, float scale_factor, int nle
     orbx_extractor* h = new orbx_extractor();
     h->nfeatures = nfeatures; h->scaleFactor = scale_factor; h->nlevels = nlevels; h->iniTh = ini_th; h->minTh = min_th; h->device = device_id;
     init_tables(h);
-    int e = rt::stream_create(&h->s0) | rt::stream_create(&h->s1) | rt::stream_create(&h->s_spare) | rt::event_create(&h->ev_fork) | rt::event_create(&h->ev_join) |
+    int e = rt::stream_create(&h->s0) | rt::stream_create(&h->s1) | rt::stream_create(&h->s_copy) | rt::event_create(&h->ev_fork) | rt::event_create(&h->ev_join) |
             rt::event_create(&h->ev_done) | rt::event_create(&h->ev_copy) | rt::event_create(&h->ev_import) | rt::event_create(&h->ev_lp);
     for (int i = 0; i < ORBX_NSTAGES; i++) { e |= rt::event_create(&h->ev_stage[i][0]); e |= rt::event_create(&h->ev_stage[i][1]); h->stage_ms[i] = 0; }
     h->have_streams = true;
@@ -517,10 +491,9 @@ void orbx_destroy(orbx_extractor* h) {
         if (h->graph) (void)hipGraphDestroy(h->graph);
 #endif
         for (int i = 0; i < ORBX_NSTAGES; i++) { rt::event_destroy(h->ev_stage[i][0]); rt::event_destroy(h->ev_stage[i][1]); }
-        if (h->have_copy_stream) rt::stream_sync(h->s_copy);
+        rt::stream_sync(h->s_copy);
         rt::event_destroy(h->ev_fork); rt::event_destroy(h->ev_join); rt::event_destroy(h->ev_done); rt::event_destroy(h->ev_copy); rt::event_destroy(h->ev_import); rt::event_destroy(h->ev_lp);
-        rt::stream_destroy(h->s0); rt::stream_destroy(h->s1); rt::stream_destroy(h->s_spare);
-        if (h->have_copy_stream) release_copy_stream(h->device);
+        rt::stream_destroy(h->s0); rt::stream_destroy(h->s1); rt::stream_destroy(h->s_copy);
     }
     h->d_lv.release(); h->d_cells.release(); h->d_xtab.release(); h->d_ytab.release(); h->d_xspan.release(); h->d_yspan.release(); h->d_pyr.release(); h->d_blur.release(); h->d_stage.release();
     h->d_slots.release(); h->d_candA.release(); h->d_candB.release(); h->d_lvl_keys.release(); h->d_cell_count.release(); h->d_lvl_count.release();
@@ -747,10 +720,6 @@ int orbx_device_upload(orbx_extractor* h, void* dptr, const void* host, size_t b
 int orbx_device_upload_async(orbx_extractor* h, void* dptr, const void* host, size_t bytes) {
     if (!h || !dptr || !host) return fail(ORBX_E_ARG, "null");
     rt::set_device(h->device);
-    if (!h->have_copy_stream) {            // the GPU's upload stream, created at the first asynchronous upload of the process (see SharedCopyStream)
-        if (acquire_copy_stream(h->device, &h->s_copy)) return fail(ORBX_E_DEVICE, "copy stream creation failed: %s", rt::last_error());
-        h->have_copy_stream = true;
-    }
     record_import_if_pending(h);
     if (h->lastB > 0 && rt::stream_wait_event(h->s_copy, h->ev_import)) return fail(ORBX_E_DEVICE, "upload could not be ordered behind the previous extraction: %s", rt::last_error());
     if (rt::copy_h2d(dptr, host, bytes, h->s_copy) || rt::event_record(h->ev_copy, h->s_copy)) return fail(ORBX_E_DEVICE, "upload failed: %s", rt::last_error());

@@ -84,9 +84,7 @@ struct orbx_extractor {
     orbx::DevBuf<unsigned long long> d_hamA, d_hamB; orbx::DevBuf<int> d_hamOut;
     orbx::HostBuf<uint8_t> h_stage;
     orbx::HostBuf<int> h_nm;
-    orbx::rt::stream_t s0 = 0, s1 = 0, s_copy = 0;          // s_copy: orbx_device_upload_async (input uploads beside the kernels of the previous batch); ONE per GPU, shared by the handles of the process (orbx_api.cpp)
-    bool have_copy_stream = false;
-    orbx::rt::stream_t s_spare = 0;          // keeps the stride of three streams per handle over HIP's hardware queues (orbx_api.cpp: SharedCopyStream)
+    orbx::rt::stream_t s0 = 0, s1 = 0, s_copy = 0;          // s_copy: orbx_device_upload_async (input uploads beside the kernels of the previous batch)
     orbx::rt::event_t ev_fork = 0, ev_join = 0, ev_done = 0, ev_copy = 0, ev_import = 0;
     bool copy_pending = false;
     // ev_done / ev_import are recorded when somebody is about to wait for them (another handle's stereo search, an input upload on s_copy), not
