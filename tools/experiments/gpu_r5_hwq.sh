@@ -4,7 +4,7 @@
 O=gpurun_out/r05_hwq
 mkdir -p $O
 A="--no-cpu-baseline --no-h2d --no-other-configs --no-latency --no-live-traffic --min-seconds 3"
-for q in default 8 12 2 default; do
+for q in ${QS:-default 8 12 2 default}; do
   if [ $q = default ]; then unset GPU_MAX_HW_QUEUES; else export GPU_MAX_HW_QUEUES=$q; fi
   python bench.py $A 2>> $O/err.txt | python -c "
 import json,sys
