@@ -135,7 +135,7 @@ __device__ __forceinline__ bool area_accept(const AreaQuery& A, const KeyPointRe
         if (A.max_level >= 0 && k.octave > A.max_level) return false;
     }
     if (!(fabsf(__fsub_rn(k.x, A.x)) < A.r && fabsf(__fsub_rn(k.y, A.y)) < A.r)) return false;
-    if (gate_right && A.gate) {
+    if (gate_right && A.gate == 1) {       // (gate 2 = Fuse's chi-square test, which has no radius test on the right coordinate: src/ORBmatcher.cc:1437-1469)
         const float ur = u_right[idx];
         if (ur > 0 && fabsf(__fsub_rn(A.ur, ur)) > A.r) return false;
     }

@@ -308,6 +308,25 @@ def build_and_run(drv, seed, variant):
     st_kf = np.array([drv.mappoint_state(int(c), kF) for c in idsF if c >= 0]).ravel()
     out["fuse"] = np.concatenate([[n], drv.get_map_points(True, kF, len(kkF)), st, st_kf])
 
+    # the same with a search radius below the chi-square bound (th = 1: radius 1 x scale, the test admits |e| up to 2.8 x scale): Fuse has no radius test on
+    # the right coordinate, only the chi-square one (round 5: the product applied SearchByProjection's right-coordinate gate here as well; invisible at the
+    # reference's th = 3, found by tools/soak_search_fuzz.py)
+    kF1, kkF1, dF1, uF1, ptF1, idsF1 = make(True, poses[2], 0.0, 0.45)
+    drv.set_map_points(True, kF1, idsF1)
+    dup1 = []
+    for i in rng.permutation(len(sc.X))[:500]:
+        PO = sc.X[i]; d = float(np.linalg.norm(PO)); maxd = d * SCALE ** int(sc.level0[i])
+        # moved along the viewing ray of this key frame: (u, v) stay, the right coordinate moves by 1.2 - 2.6 pixels of the predicted level
+        Ow1 = -poses[2][0].T.astype(np.float64) @ poses[2][1].astype(np.float64)
+        ray = sc.X[i] - Ow1; z = float(np.linalg.norm(ray))
+        eps = float(rng.uniform(1.2, 2.6)) * SCALE ** int(sc.level0[i]) * z / BF * float(rng.choice([-1.0, 1.0]))
+        dup1.append(drv.mappoint(Ow1 + ray * (1.0 + eps) + rng.normal(0, 0.002, 3), PO / d, maxd / SCALE ** (NLEVELS - 1), maxd * 1.3,
+                                 sc.noisy_desc(np.array([i]), 25)[0], n_obs=int(rng.integers(0, 6))))
+    cand1 = np.array(dup1, np.int32)
+    n = L.mw_fuse(drv.w, kF1, _p(cand1), len(cand1), C.c_float(1.0), 0)
+    st1 = np.array([drv.mappoint_state(int(c), kF1) for c in cand1]).ravel()
+    out["fuse_th1"] = np.concatenate([[n], drv.get_map_points(True, kF1, len(kkF1)), st1])
+
     kG, kkG, dG, uG, ptG, idsG = make(True, poses[1], 0.0, 0.45)
     drv.set_map_points(True, kG, idsG)
     cand = np.array(dup, np.int32)[rng.permutation(len(dup))[:400]]

@@ -31,7 +31,7 @@ RUNNER = os.path.join(ROOT, "tests", "matcher_world.py")
 pytestmark = pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(FACADE)), reason="oracle/_ref/libmw_*.so not built (needs /root/reference)")
 
 MIN_MATCHES = {"sbp_mappoints_0": 100, "sbp_frame_fwd_7": 100, "sbp_keyframe_100": 100, "sbp_sim3_100_0": 100, "bow_frame_1": 80, "bow_keyframes_1": 60,
-               "init_0": 30, "triang_0_0": 10, "sim3_100": 60, "fuse": 100, "fuse_sim3": 60, "rig_sbp_mappoints_1": 200, "rig_sbp_frame_fwd_1": 300, "rig_fuse_0": 50, "rig_fuse_1": 25, "rig_bow_frame_1": 80, "rig_bow_keyframes_1": 40,
+               "init_0": 30, "triang_0_0": 10, "sim3_100": 60, "fuse": 100, "fuse_th1": 15, "fuse_sim3": 60, "rig_sbp_mappoints_1": 200, "rig_sbp_frame_fwd_1": 300, "rig_fuse_0": 50, "rig_fuse_1": 25, "rig_bow_frame_1": 80, "rig_bow_keyframes_1": 40,
                "kb8_triangulation_rig0_001": 40, "kb8_triangulation_rig1_001": 60, "kb8_triangulation_rig1_011": 60}
 
 
