@@ -693,6 +693,8 @@ int orbv_words(const orbv_vocabulary* v);                                       
 
 /* transform(features, BowVector&, FeatureVector&, levelsup) for n host descriptors (n x 32).  Any output pointer may be NULL.
  * word_id/node_id [n]: per-feature word and ancestor at level L - levelsup (transform(feature, id, weight, &nid, levelsup), :1218-1259).
+ * One case differs from the reference by necessity: a word whose leaf lies ABOVE level L - levelsup (a ragged vocabulary) leaves the reference's `nid` an
+ * uninitialised local (:1150, undefined); here the node is then the leaf itself.  ORBvoc.txt at levelsup = 4 has no such leaf.
  * BowVector: bow_id/bow_val (capacity n), ascending word ids, *n_bow entries.  FeatureVector as CSR: fv_node (capacity n, ascending),
  * fv_start (capacity n + 1), fv_feat (capacity n; feature indices in insertion order), *n_fv nodes. */
 int orbv_transform(orbv_vocabulary* v, orbx_extractor* h, const uint8_t* desc, int n, int levelsup, uint32_t* word_id, uint32_t* node_id,
