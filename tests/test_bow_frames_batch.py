@@ -21,6 +21,11 @@ REF = os.path.join(ol.ROOT, "oracle", "_ref", "libmw_ref.so")
 pytestmark = pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/libmw_ref.so not built (needs /root/reference)")
 
 
+# (nnratio, mbCheckOrientation) of the runs; tools/soak_batched_fuzz.py replaces them with random draws
+PARAM_SETS = ((0.7, True), (0.9, False))
+STRICT_SCENES = True
+
+
 def _run(lib, w, h, nf, B, seed=0):
     rng = np.random.default_rng(97 + B + 1000 * seed)
     ex = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib)
@@ -53,7 +58,7 @@ def _run(lib, w, h, nf, B, seed=0):
         kfs.append(M.ResidentKeyFrame(ex, kfv)); mps.append(has_mp)
         worlds.append((kk, dk, bow_k, has_mp))
     voc.transform_extracted(ex, 0, B, levelsup)
-    for ratio, ori in ((0.7, True), (0.9, False)):
+    for ratio, ori in PARAM_SETS:
         got = M.ORBmatcher(ratio, ori).SearchByBoWFramesBatch(ex, voc, kfs, mps)
         total = 0
         for b in range(B):
@@ -84,7 +89,7 @@ def _run(lib, w, h, nf, B, seed=0):
                 exp[m12[i]] = ids[i]
             assert n_got == n_ref and np.array_equal(exp, out) and int((m12 >= 0).sum()) == n_ref, "frame %d ratio %g: %d vs %d matches" % (b, ratio, n_got, n_ref)
             total += n_ref
-        assert total > 40 * B
+        assert not STRICT_SCENES or total > 40 * B
     # the vocabulary results must belong to these frames: another range is refused
     with pytest.raises(Exception):
         M.ORBmatcher(0.7, True).SearchByBoWFramesBatch(ex, voc, kfs[:1], mps[:1], first=1)

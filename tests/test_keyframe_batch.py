@@ -18,6 +18,11 @@ pytestmark = pytest.mark.skipif(ol.reference_frame_lib() is None, reason="oracle
 BASE = 0.110074
 
 
+# (th, ORBdist, with occupied keypoints, mbCheckOrientation) of the runs; tools/soak_batched_fuzz.py replaces them with random draws
+PARAM_SETS = ((10.0, 100, False, True), (3.0, 64, True, True), (10.0, 100, True, False))
+STRICT_SCENES = True
+
+
 def _run(lib, w, h, nf, B, seed=0):
     rng = np.random.default_rng(4242 + B + 1000 * seed)
     pairs = [synth.stereo_pair(w, h, seed=520 + b + 37 * seed, nrect=int(3000 * w * h / (752 * 480))) for b in range(B)]
@@ -71,7 +76,8 @@ def _run(lib, w, h, nf, B, seed=0):
     kb = M.KeyFrameBatch(ex, B, cam, bounds, BF, sfs)
     kb.set_poses(poses)
     matcher = M.ORBmatcher(0.9, True)
-    for th, orb_dist, occ, ori in ((10.0, 100, None, True), (3.0, 64, occupied, True), (10.0, 100, occupied, False)):
+    for th, orb_dist, use_occ, ori in PARAM_SETS:
+        occ = occupied if use_occ else None
         matcher.mbCheckOrientation = ori
         kb.enqueue(n, pos, valid, mind, maxd, angle, desc, th, orb_dist, ori, occ)
         asg, nm = kb.fetch()
@@ -82,7 +88,7 @@ def _run(lib, w, h, nf, B, seed=0):
                                                     None if occ is None else occ[b, :N])
             assert nm[b] == ref_n and np.array_equal(asg[b, :N], ref_as), "frame %d (th %g) vs the reference: %d vs %d matches" % (b, th, nm[b], ref_n)
             total += ref_n; resets += int((ref_as == -2).sum())
-        assert total > 60 * B and (resets > 0) == ori
+        assert not STRICT_SCENES or (total > 60 * B and (resets > 0) == ori)
     ex.close()
 
 

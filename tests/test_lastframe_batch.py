@@ -18,6 +18,11 @@ from test_models import _predict_scale_float
 BASE = 0.110074
 
 
+# (th, with occupied keypoints, mbCheckOrientation) of the runs; tools/soak_batched_fuzz.py replaces them with random draws
+PARAM_SETS = ((7.0, False, True), (15.0, True, True), (7.0, True, False))
+STRICT_SCENES = True
+
+
 def _run(lib, w, h, nf, B, mono, seed=0):
     rng = np.random.default_rng(808 + B + int(mono) + 1000 * seed)
     pairs = [synth.stereo_pair(w, h, seed=120 + b + 37 * seed, nrect=int(3000 * w * h / (752 * 480))) for b in range(B)]
@@ -65,7 +70,8 @@ def _run(lib, w, h, nf, B, mono, seed=0):
     lf = M.LastFrameBatch(ex, B, cam, bounds, BF, sfs)
     lf.set_poses(poses)
     matcher = M.ORBmatcher(0.9, True)
-    for th, occ, ori in ((7.0, None, True), (15.0, occupied, True), (7.0, occupied, False)):
+    for th, use_occ, ori in PARAM_SETS:
+        occ = occupied if use_occ else None
         matcher.mbCheckOrientation = ori
         # the reference, one frame at a time; it also says which way each pair of poses moves
         ref = [refs[b].search_lastframe(poses[b][0], poses[b][1], last_poses[b][0], last_poses[b][1], pos[b, :n[b]], valid[b, :n[b]], octave[b, :n[b]], angle[b, :n[b]],
@@ -89,7 +95,7 @@ def _run(lib, w, h, nf, B, mono, seed=0):
             one_n, one_as = matcher.SearchByProjectionFrame(ex, fv, last, th, bool(fwd[b]), bool(bwd[b]))
             assert one_n == ref_n and np.array_equal(one_as, ref_as), "frame %d (th %g): single-frame call vs the reference" % (b, th)
             total += ref_n; resets += int((ref_as == -2).sum())
-        assert total > 100 * B and (resets > 0) == ori
+        assert not STRICT_SCENES or (total > 100 * B and (resets > 0) == ori)          # (the scene has to be a test: enough matches, rotation outliers)
     ex.close()
 
 
