@@ -142,6 +142,13 @@ class Scene:
         return keys[perm], desc[perm], ur[perm], pt[perm], node[perm]
 
 
+FUZZ = None         # variant "fuzz": a generator that replaces the methods' parameters (th, ratios, windows) by random draws - the same draws for both flavours
+
+
+def P(default, choices):
+    return default if FUZZ is None else type(default)(FUZZ.choice(choices))
+
+
 def build_and_run(drv, seed, variant):
     """Runs every method on a world derived from (seed, variant); returns {name: array}."""
     rng = np.random.default_rng(seed)
@@ -197,7 +204,7 @@ def build_and_run(drv, seed, variant):
     sel = rng.permutation(len(mp_ids))[:700]
     for far in (0, 1):
         drv.set_map_points(False, f0, ids0)
-        n = L.mw_search_by_projection_mappoints(drv.w, f0, _p(mp_ids[sel].astype(np.int32)), len(sel), C.c_float(3.0 if far else 1.0), far, C.c_float(9.0), C.c_float(0.8), 1)
+        n = L.mw_search_by_projection_mappoints(drv.w, f0, _p(mp_ids[sel].astype(np.int32)), len(sel), C.c_float(P(3.0 if far else 1.0, [0.5, 1.0, 2.0, 3.0, 6.0])), far, C.c_float(P(9.0, [3.0, 9.0, 30.0])), C.c_float(P(0.8, [0.6, 0.8, 0.95])), 1)
         out["sbp_mappoints_%d" % far] = np.concatenate([[n], drv.get_map_points(False, f0, len(k0))])
 
     # ---- SearchByProjection(CurrentFrame, LastFrame) : motion model ----------------------------------------
@@ -208,10 +215,10 @@ def build_and_run(drv, seed, variant):
         drv.set_map_points(False, fc, idsc)
         for th in (7.0, 15.0):
             drv.set_map_points(False, fc, idsc)
-            n = L.mw_search_by_projection_frame(drv.w, fc, fl, C.c_float(th), mono, C.c_float(0.9), 1)
+            n = L.mw_search_by_projection_frame(drv.w, fc, fl, C.c_float(P(th, [1.0, 3.0, 7.0, 15.0, 30.0])), mono, C.c_float(P(0.9, [0.7, 0.9, 1.0])), 1)
             out["sbp_frame_%s_%d" % (tag, int(th))] = np.concatenate([[n], drv.get_map_points(False, fc, len(kc))])
         drv.set_map_points(False, fc, idsc)
-        n = L.mw_search_by_projection_frame(drv.w, fc, fl, C.c_float(15.0), mono, C.c_float(0.9), 0)
+        n = L.mw_search_by_projection_frame(drv.w, fc, fl, C.c_float(P(15.0, [2.0, 15.0, 40.0])), mono, C.c_float(0.9), 0)
         out["sbp_frame_%s_noori" % tag] = np.concatenate([[n], drv.get_map_points(False, fc, len(kc))])
 
     # ---- key frames ---------------------------------------------------------------------------------------------
@@ -225,7 +232,7 @@ def build_and_run(drv, seed, variant):
     found = idsr[idsr >= 0][::2].astype(np.int32)
     for th, od in ((10.0, 100), (3.0, 64)):
         drv.set_map_points(False, fr, idsr)
-        n = L.mw_search_by_projection_keyframe(drv.w, fr, kA, _p(found), len(found), C.c_float(th), od, C.c_float(0.9), 1)
+        n = L.mw_search_by_projection_keyframe(drv.w, fr, kA, _p(found), len(found), C.c_float(P(th, [1.0, 3.0, 6.0, 10.0, 25.0])), P(od, [30, 50, 64, 100, 160]), C.c_float(P(0.9, [0.7, 0.9])), 1)
         out["sbp_keyframe_%d" % od] = np.concatenate([[n], drv.get_map_points(False, fr, len(kr))])
 
     # ---- SearchByProjection(KeyFrame, Sim3, ...) : loop detection / place recognition ----------------------
@@ -237,17 +244,17 @@ def build_and_run(drv, seed, variant):
             mkf = i32(len(kkB))
             pkf = rng.integers(0, 2, len(pts)).astype(np.int32)
             n = L.mw_search_by_projection_sim3(drv.w, kB, C.c_float(s), _p(Rs), _p((ts * s).astype(np.float32)), _p(mp_ids[pts].astype(np.int32)), len(pts), _p(pkf), with_kfs,
-                                               _p(matched), _p(mkf), 8, C.c_float(1.0 if with_kfs else 1.5))
+                                               _p(matched), _p(mkf), P(8, [1, 3, 8, 14]), C.c_float(P(1.0 if with_kfs else 1.5, [0.7, 1.0, 1.5])))
             out["sbp_sim3_%d_%d" % (int(s * 100), with_kfs)] = np.concatenate([[n], matched, mkf])
 
     # ---- SearchByBoW -----------------------------------------------------------------------------------------------
     fb, kb, db, ub, ptb, idsb = make(False, poses[1], 20.0, 0.0)
     for ori in (1, 0):
         o = i32(len(kb))
-        n = L.mw_search_by_bow_frame(drv.w, kA, fb, _p(o), C.c_float(0.75), ori)
+        n = L.mw_search_by_bow_frame(drv.w, kA, fb, _p(o), C.c_float(P(0.75, [0.55, 0.75, 0.9, 1.0])), ori)
         out["bow_frame_%d" % ori] = np.concatenate([[n], o])
         o = i32(len(kkA))
-        n = L.mw_search_by_bow_keyframes(drv.w, kA, kB, _p(o), C.c_float(0.8), ori)
+        n = L.mw_search_by_bow_keyframes(drv.w, kA, kB, _p(o), C.c_float(P(0.8, [0.55, 0.8, 0.95])), ori)
         out["bow_keyframes_%d" % ori] = np.concatenate([[n], o])
         if hasattr(L, "mw_search_by_bow_frame_many"):        # relocalisation: several candidates against the frame at once
             cand = np.array([kA, kB, kA], np.int32); oo = i32(len(cand) * len(kb)); cc = i32(len(cand))
@@ -260,7 +267,7 @@ def build_and_run(drv, seed, variant):
     prev = np.stack([ki1["x"], ki1["y"]], 1).astype(np.float32).copy()
     for rnd in range(2):                                   # second round starts from the updated vbPrevMatched, as Tracking does
         m12 = i32(len(ki1))
-        n = L.mw_search_for_initialization(drv.w, fi1, fi2, _p(prev), _p(m12), 40 if dense else 100, C.c_float(0.9), 1)
+        n = L.mw_search_for_initialization(drv.w, fi1, fi2, _p(prev), _p(m12), P(40 if dense else 100, [15, 40, 100, 160]), C.c_float(P(0.9, [0.7, 0.9, 1.0])), 1)
         out["init_%d" % rnd] = np.concatenate([[n], m12, prev.view(np.int32).ravel()])
 
     # ---- SearchForTriangulation -----------------------------------------------------------------------------------
@@ -289,7 +296,7 @@ def build_and_run(drv, seed, variant):
     R12 = (R1 @ R2.T).astype(np.float32); t12 = (t1 - R12 @ t2 + np.array([0.01, -0.01, 0.02])).astype(np.float32)
     for s in (1.0, 0.97):
         m12 = np.where(rng.uniform(size=len(kkA)) < 0.1, idsA, -1).astype(np.int32)
-        n = L.mw_search_by_sim3(drv.w, kA, kB, _p(m12), C.c_float(s), _p(R12), _p(t12), C.c_float(7.5))
+        n = L.mw_search_by_sim3(drv.w, kA, kB, _p(m12), C.c_float(s), _p(R12), _p(t12), C.c_float(P(7.5, [1.5, 4.0, 7.5, 15.0])))
         out["sim3_%d" % int(s * 100)] = np.concatenate([[n], m12])
 
     # ---- Fuse ----------------------------------------------------------------------------------------------------------
@@ -303,7 +310,7 @@ def build_and_run(drv, seed, variant):
                                 n_obs=int(rng.integers(0, 6))))
     cand = np.concatenate([np.array(dup), idsF[idsF >= 0][:40], [-1, -1]]).astype(np.int32)
     rng.shuffle(cand)
-    n = L.mw_fuse(drv.w, kF, _p(cand), len(cand), C.c_float(3.0), 0)
+    n = L.mw_fuse(drv.w, kF, _p(cand), len(cand), C.c_float(P(3.0, [0.7, 1.5, 2.5, 3.0, 6.0])), 0)
     st = np.array([drv.mappoint_state(int(c), kF) for c in cand if c >= 0]).ravel()
     st_kf = np.array([drv.mappoint_state(int(c), kF) for c in idsF if c >= 0]).ravel()
     out["fuse"] = np.concatenate([[n], drv.get_map_points(True, kF, len(kkF)), st, st_kf])
@@ -331,7 +338,7 @@ def build_and_run(drv, seed, variant):
     drv.set_map_points(True, kG, idsG)
     cand = np.array(dup, np.int32)[rng.permutation(len(dup))[:400]]
     rep = i32(len(cand))
-    n = L.mw_fuse_sim3(drv.w, kG, C.c_float(1.03), _p(Rs), _p((ts * 1.03).astype(np.float32)), _p(cand), len(cand), C.c_float(4.0), _p(rep))
+    n = L.mw_fuse_sim3(drv.w, kG, C.c_float(1.03), _p(Rs), _p((ts * 1.03).astype(np.float32)), _p(cand), len(cand), C.c_float(P(4.0, [1.0, 2.0, 4.0, 9.0])), _p(rep))
     st = np.array([drv.mappoint_state(int(c), kG) for c in cand]).ravel()
     out["fuse_sim3"] = np.concatenate([[n], rep, drv.get_map_points(True, kG, len(kkG)), st])
 
@@ -501,6 +508,8 @@ def build_and_run_kb8(drv, seed):
 if __name__ == "__main__":
     drv_path, orbx_path, seed, variant, dst = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
     d = Driver(drv_path, orbx_path or None)
+    if variant == "fuzz":
+        FUZZ = np.random.default_rng(50000 + seed); variant = "base"
     res = build_and_run_rig(d, seed) if variant == "rig" else build_and_run_kb8(d, seed) if variant == "kb8" else build_and_run(d, seed, variant)
     extra = {}
     d.close()

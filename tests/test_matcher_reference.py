@@ -89,3 +89,16 @@ def test_matcher_facade_equals_reference_real_classes_emulated(tmp_path, emu_lib
 @pytest.mark.gpu
 def test_matcher_facade_equals_reference_real_classes_gpu(tmp_path, hip_lib):
     _compare(tmp_path, _lib.HIP_LIB_PATH, [(1, "base"), (2, "dense"), (3, "hard"), (4, "rig"), (21, "base"), (22, "rig"), (23, "kb8")], REF_REAL, FACADE_REAL)
+
+
+def test_matcher_facade_equals_reference_random_parameters_emulated(tmp_path, emu_lib):
+    """the same worlds with the methods' parameters (th, nnratio, ORBdist, window, ratioHamming) drawn at random per seed instead of the reference's call-site
+    values (variant "fuzz"; tools/soak_world_fuzz.py runs more seeds): Fuse below th = 2.8 is what the fixed values had hidden (round 5)"""
+    orbx = os.path.join(ROOT, "tests", "emu", "liborbx_emu.so")
+    for seed in (11, 12, 13):
+        a = _run(tmp_path, REF, "", seed, "fuzz", "ref")
+        b = _run(tmp_path, FACADE, orbx, seed, "fuzz", "facade")
+        assert set(a.files) == set(b.files) and len(a.files) > 20
+        for k in a.files:
+            if k != "flavour":
+                assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), "%s differs from the reference's ORBmatcher.cc (seed %d, random parameters)" % (k, seed)
