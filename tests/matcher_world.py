@@ -400,7 +400,7 @@ def build_and_run_rig(drv, seed):
     sel = rng.permutation(len(mp_ids))[:700]
     for th in (1.0, 3.0):
         drv.set_map_points(False, f0, ids0)
-        n = L.mw_search_by_projection_mappoints(drv.w, f0, _p(mp_ids[sel].astype(np.int32)), len(sel), C.c_float(th), 0, C.c_float(50.0), C.c_float(0.8), 1)
+        n = L.mw_search_by_projection_mappoints(drv.w, f0, _p(mp_ids[sel].astype(np.int32)), len(sel), C.c_float(P(th, [0.7, 1.5, 3.0, 6.0, 12.0])), 0, C.c_float(50.0), C.c_float(P(0.8, [0.6, 0.8, 0.95])), 1)
         out["rig_sbp_mappoints_%d" % int(th)] = np.concatenate([[n], drv.get_map_points(False, f0, nl + nr)])
 
     for tag, pose_c in (("fwd", pose), ("near", (rot(0.0, 0.0, 0.01), np.array([0.01, 0.0, 0.02], np.float32)))):
@@ -409,7 +409,7 @@ def build_and_run_rig(drv, seed):
         fc, nlc, nrc, idsc, _ = make_rig(pose_c, 6.0, 0.1)
         for ori in (1, 0):
             drv.set_map_points(False, fc, idsc)
-            n = L.mw_search_by_projection_frame(drv.w, fc, fl, C.c_float(10.0), 0, C.c_float(0.9), ori)
+            n = L.mw_search_by_projection_frame(drv.w, fc, fl, C.c_float(P(10.0, [1.5, 4.0, 10.0, 25.0])), 0, C.c_float(P(0.9, [0.7, 0.9, 1.0])), ori)
             out["rig_sbp_frame_%s_%d" % (tag, ori)] = np.concatenate([[n], drv.get_map_points(False, fc, nlc + nrc)])
 
     # ---- Fuse(pKF, vpMapPoints, th, bRight) on a rig key frame: left camera, then right camera (LocalMapping::SearchInNeighbors) ----
@@ -423,7 +423,7 @@ def build_and_run_rig(drv, seed):
     cand = np.concatenate([np.array(dup), idsF[idsF >= 0][:30], [-1]]).astype(np.int32)
     rng.shuffle(cand)
     for right in (0, 1):
-        n = L.mw_fuse(drv.w, kF, _p(cand), len(cand), C.c_float(3.0), right)
+        n = L.mw_fuse(drv.w, kF, _p(cand), len(cand), C.c_float(P(3.0, [0.7, 1.5, 3.0, 6.0])), right)
         st = np.array([drv.mappoint_state(int(c), kF) for c in cand if c >= 0]).ravel()
         out["rig_fuse_%d" % right] = np.concatenate([[n], drv.get_map_points(True, kF, nlF + nrF), st])
 
@@ -433,10 +433,10 @@ def build_and_run_rig(drv, seed):
     fb, nlb, nrb, _, _ = make_rig(pose, 15.0, 0.0)
     for ori in (1, 0):
         o = np.full(nlb + nrb, -1, np.int32)
-        n = L.mw_search_by_bow_frame(drv.w, kA, fb, _p(o), C.c_float(0.75), ori)
+        n = L.mw_search_by_bow_frame(drv.w, kA, fb, _p(o), C.c_float(P(0.75, [0.55, 0.75, 0.95])), ori)
         out["rig_bow_frame_%d" % ori] = np.concatenate([[n], o])
         o = np.full(nlA + nrA, -1, np.int32)
-        n = L.mw_search_by_bow_keyframes(drv.w, kA, kF, _p(o), C.c_float(0.8), ori)
+        n = L.mw_search_by_bow_keyframes(drv.w, kA, kF, _p(o), C.c_float(P(0.8, [0.55, 0.8, 0.95])), ori)
         out["rig_bow_keyframes_%d" % ori] = np.concatenate([[n], o])
     return out
 
@@ -508,8 +508,8 @@ def build_and_run_kb8(drv, seed):
 if __name__ == "__main__":
     drv_path, orbx_path, seed, variant, dst = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
     d = Driver(drv_path, orbx_path or None)
-    if variant == "fuzz":
-        FUZZ = np.random.default_rng(50000 + seed); variant = "base"
+    if variant in ("fuzz", "rigfuzz"):
+        FUZZ = np.random.default_rng(50000 + seed); variant = "base" if variant == "fuzz" else "rig"
     res = build_and_run_rig(d, seed) if variant == "rig" else build_and_run_kb8(d, seed) if variant == "kb8" else build_and_run(d, seed, variant)
     extra = {}
     d.close()

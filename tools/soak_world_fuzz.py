@@ -8,6 +8,7 @@ import numpy as np
 from orb_slam3_detailed_comments_amd import _lib
 
 kind, first, last = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+VARIANT = sys.argv[4] if len(sys.argv) > 4 else "fuzz"          # "fuzz": one-camera worlds, "rigfuzz": the two-camera rig branches
 orbx = _lib.HIP_LIB_PATH if kind == "hip" else os.path.join(ROOT, "tests", "emu", "liborbx_emu.so")
 RUN = os.path.join(ROOT, "tests", "matcher_world.py")
 REF = os.path.join(ROOT, "oracle", "_ref", "libmw_ref.so"); FAC = os.path.join(ROOT, "oracle", "_ref", "libmw_facade.so")
@@ -15,8 +16,8 @@ tmp = tempfile.mkdtemp()
 bad = 0
 for seed in range(first, last + 1):
     a = os.path.join(tmp, "a.npz"); b = os.path.join(tmp, "b.npz")
-    subprocess.run([sys.executable, RUN, REF, "", str(seed), "fuzz", a], check=True)
-    subprocess.run([sys.executable, RUN, FAC, orbx, str(seed), "fuzz", b], check=True)
+    subprocess.run([sys.executable, RUN, REF, "", str(seed), VARIANT, a], check=True)
+    subprocess.run([sys.executable, RUN, FAC, orbx, str(seed), VARIANT, b], check=True)
     A, B = np.load(a), np.load(b)
     diff = [k for k in A.files if k != "flavour" and not (A[k].shape == B[k].shape and np.array_equal(A[k], B[k]))]
     if diff or set(A.files) != set(B.files):
@@ -24,4 +25,4 @@ for seed in range(first, last + 1):
         print("seed %d DIFFERS in %s" % (seed, diff), flush=True)
     if (seed - first) % 10 == 9:
         print("seeds %d..%d: %d differences so far" % (first, seed, bad), flush=True)
-print("matcher worlds with random parameters (%s library, facade vs the reference ORBmatcher.cc): seeds %d..%d, %d differences" % (kind, first, last, bad))
+print("matcher worlds with random parameters, variant %s (%s library, facade vs the reference ORBmatcher.cc): seeds %d..%d, %d differences" % (VARIANT, kind, first, last, bad))
