@@ -9,7 +9,7 @@ from orb_slam3_detailed_comments_amd import _lib
 import test_lastframe_batch as t_last, test_keyframe_batch as t_kf, test_bow_frames_batch as t_bow, test_local_points_batch as t_lp
 
 kind, first, last = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-lib = _lib.load_hip() if kind == "hip" else _lib.OrbxLib(os.path.join(ROOT, "tests", "emu", "liborbx_emu.so"))
+lib = _lib.load_hip() if kind == "hip" else _lib.OrbxLib(os.environ.get("ORBX_SOAK_LIB") or os.path.join(ROOT, "tests", "emu", "liborbx_emu.so"))
 for m in (t_last, t_kf, t_bow, t_lp): m.STRICT_SCENES = False
 bad = runs = 0
 for seed in range(first, last + 1):

@@ -13,7 +13,7 @@ from orb_slam3_detailed_comments_amd import matcher as M
 from matcher_world import rot
 
 kind, first, last = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-lib = _lib.load_hip() if kind == "hip" else _lib.OrbxLib(os.path.join(ROOT, "tests", "emu", "liborbx_emu.so"))
+lib = _lib.load_hip() if kind == "hip" else _lib.OrbxLib(os.environ.get("ORBX_SOAK_LIB") or os.path.join(ROOT, "tests", "emu", "liborbx_emu.so"))
 assert ol.reference_frame_lib() is not None, "oracle/_ref/libref_frame.so not built (needs /root/reference)"
 bad = pairs = accepted = rejected = 0
 for seed in range(first, last + 1):

@@ -12,7 +12,7 @@ from orb_slam3_detailed_comments_amd import matcher as M
 import test_local_points as t
 
 kind, first, last = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-lib = _lib.load_hip() if kind == "hip" else _lib.OrbxLib(os.path.join(ROOT, "tests", "emu", "liborbx_emu.so"))
+lib = _lib.load_hip() if kind == "hip" else _lib.OrbxLib(os.environ.get("ORBX_SOAK_LIB") or os.path.join(ROOT, "tests", "emu", "liborbx_emu.so"))
 bad = runs = 0
 for seed in range(first, last + 1):
     rng = np.random.default_rng(13000 + seed)

@@ -7,7 +7,7 @@ from orb_slam3_detailed_comments_amd import _lib
 import test_emu_search_fuzz as t
 
 kind, first, last = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-lib = _lib.load_hip() if kind == "hip" else _lib.OrbxLib(os.path.join(ROOT, "tests", "emu", "liborbx_emu.so"))
+lib = _lib.load_hip() if kind == "hip" else _lib.OrbxLib(os.environ.get("ORBX_SOAK_LIB") or os.path.join(ROOT, "tests", "emu", "liborbx_emu.so"))
 bad = 0
 for seed in range(first, last + 1):
     try:

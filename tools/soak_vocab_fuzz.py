@@ -11,7 +11,7 @@ from orb_slam3_detailed_comments_amd.extractor import ORBextractor
 import test_emu_vocab as t
 
 kind, first, last = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-lib = _lib.load_hip() if kind == "hip" else _lib.OrbxLib(os.path.join(ROOT, "tests", "emu", "liborbx_emu.so"))
+lib = _lib.load_hip() if kind == "hip" else _lib.OrbxLib(os.environ.get("ORBX_SOAK_LIB") or os.path.join(ROOT, "tests", "emu", "liborbx_emu.so"))
 ex = ORBextractor(500, 1.2, 8, 20, 7, lib=lib)
 tmp = pathlib.Path(tempfile.mkdtemp())
 bad = 0
