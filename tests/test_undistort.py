@@ -14,6 +14,7 @@ from orb_slam3_detailed_comments_amd import matcher as M
 # Examples/RGB-D/TUM1.yaml: Camera.fx .. k3
 K_TUM1 = (517.306408, 516.469215, 318.643040, 255.313989)
 D_TUM1 = (0.262383, -0.953104, -0.005358, 0.002628, 1.163314)
+STRICT_SCENES = True          # (the random-coefficient sweep of round 5 switches the "the scene has to be a test" assertions off)
 
 
 def _numpy_undistort(p, K, d, variant):
@@ -83,10 +84,10 @@ def _product_case(lib, w, h, nf, B, npts, gpu):
         F = refs[b]
         assert res[b][1].tobytes() == F.keys.tobytes()
         assert kun[b, :F.N].tobytes() == F.keys_un.tobytes(), "mvKeysUn, frame %d" % b
-        assert (F.keys_un["x"] != F.keys["x"]).mean() > 0.9
+        assert not STRICT_SCENES or (F.keys_un["x"] != F.keys["x"]).mean() > 0.9
         assert u[b, :F.N].tobytes() == F.u_right.tobytes() and dep[b, :F.N].tobytes() == F.depth.tobytes()
         assert np.array_equal(np.float32(bounds), F.bounds[[0, 2, 1, 3]]), (bounds, F.bounds)          # ref_frame_constants: minX, minY, maxX, maxY
-    assert bounds[0] != 0.0 and bounds[1] != float(w)
+    assert not STRICT_SCENES or (bounds[0] != 0.0 and bounds[1] != float(w))
     # the batched SearchLocalPoints on the undistorted keypoints, with the undistorted image bounds, against the reference frames
     from test_local_points import _rot
     sfs = ex.GetScaleFactors()
@@ -111,7 +112,7 @@ def _product_case(lib, w, h, nf, B, npts, gpu):
         tr, ref_as, ref_n = F.search_local_points(poses[b][0], poses[b][1], pos, normal, mind, maxd, bad, obs, desc, 0.5, True, 3.0, False, 50.0, 0.8)
         assert np.array_equal(inv[b].astype(bool), tr["in_view"]) and nm[b] == ref_n and np.array_equal(asg[b, :F.N], ref_as), "frame %d" % b
         total += ref_n
-    assert total > 15 * B
+    assert not STRICT_SCENES or total > 15 * B
     # switched off again: mvKeysUn = mvKeys
     ex.set_undistort(None)
     ex.extract_batch(np.stack(imgs[:1]))
