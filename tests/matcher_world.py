@@ -459,9 +459,16 @@ def build_and_run_kb8(drv, seed):
     # a 640 x 480 fisheye pair in the style of Examples/Stereo/TUM-VI.yaml, scaled to the world's image size
     P1 = np.array([FX * 0.62, FY * 0.62, CX + 1.5, CY - 2.0, 0.0035, 0.0007, -0.0020, 0.0002], np.float32)
     P2 = np.array([FX * 0.618, FY * 0.621, CX - 2.0, CY + 1.0, 0.0034, 0.0018, -0.0027, 0.0003], np.float32)
+    trl = (rot(0.0, 0.03, 0.001), np.array([-0.101, 0.0006, 0.001], np.float32))
+    if FUZZ is not None:                 # variant "kb8fuzz": random focal lengths, principal points, distortion coefficients, rig rotation and baseline
+        f = float(FUZZ.uniform(0.45, 0.9))
+        P1 = np.array([FX * f, FY * f * float(FUZZ.uniform(0.98, 1.02)), CX + float(FUZZ.uniform(-12, 12)), CY + float(FUZZ.uniform(-12, 12))] +
+                      [float(FUZZ.normal(0, sd)) for sd in (0.02, 0.008, 0.004, 0.001)], np.float32)
+        P2 = np.array([P1[0] * float(FUZZ.uniform(0.98, 1.02)), P1[1] * float(FUZZ.uniform(0.98, 1.02)), CX + float(FUZZ.uniform(-12, 12)), CY + float(FUZZ.uniform(-12, 12))] +
+                      [float(FUZZ.normal(0, sd)) for sd in (0.02, 0.008, 0.004, 0.001)], np.float32)
+        trl = (rot(*FUZZ.normal(0, 0.02, 3)), np.array([-float(FUZZ.uniform(0.05, 0.25)), float(FUZZ.normal(0, 0.002)), float(FUZZ.normal(0, 0.002))], np.float32))
     L.mw_add_camera_kb8.restype = C.c_int
     c1 = L.mw_add_camera_kb8(drv.w, _p(P1)); c2 = L.mw_add_camera_kb8(drv.w, _p(P2))
-    trl = (rot(0.0, 0.03, 0.001), np.array([-0.101, 0.0006, 0.001], np.float32))
     mp_ids = []
     for i in range(len(sc.X)):
         d = float(np.linalg.norm(sc.X[i])); maxd = d * SCALE ** int(sc.level0[i])
@@ -508,8 +515,8 @@ def build_and_run_kb8(drv, seed):
 if __name__ == "__main__":
     drv_path, orbx_path, seed, variant, dst = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
     d = Driver(drv_path, orbx_path or None)
-    if variant in ("fuzz", "rigfuzz"):
-        FUZZ = np.random.default_rng(50000 + seed); variant = "base" if variant == "fuzz" else "rig"
+    if variant in ("fuzz", "rigfuzz", "kb8fuzz"):
+        FUZZ = np.random.default_rng(50000 + seed); variant = {"fuzz": "base", "rigfuzz": "rig", "kb8fuzz": "kb8"}[variant]
     res = build_and_run_rig(d, seed) if variant == "rig" else build_and_run_kb8(d, seed) if variant == "kb8" else build_and_run(d, seed, variant)
     extra = {}
     d.close()

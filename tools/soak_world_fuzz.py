@@ -8,7 +8,7 @@ import numpy as np
 from orb_slam3_detailed_comments_amd import _lib
 
 kind, first, last = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-VARIANT = sys.argv[4] if len(sys.argv) > 4 else "fuzz"          # "fuzz": one-camera worlds, "rigfuzz": the two-camera rig branches
+VARIANT = sys.argv[4] if len(sys.argv) > 4 else "fuzz"          # "fuzz": one-camera worlds, "rigfuzz": the two-camera rig branches, "kb8fuzz": SearchForTriangulation over random Kannala-Brandt cameras and rigs
 orbx = _lib.HIP_LIB_PATH if kind == "hip" else os.path.join(ROOT, "tests", "emu", "liborbx_emu.so")
 RUN = os.path.join(ROOT, "tests", "matcher_world.py")
 REF = os.path.join(ROOT, "oracle", "_ref", "libmw_ref.so"); FAC = os.path.join(ROOT, "oracle", "_ref", "libmw_facade.so")
