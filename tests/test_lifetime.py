@@ -183,3 +183,41 @@ def test_facade_worlds_leave_nothing_behind(tmp_path, emu_lib):
         assert r.returncode == 0, r.stdout + r.stderr
         z = np.load(dst)
         assert z["live_first"][2] >= 3 and np.array_equal(z["live_first"], z["live_again"]), (variant, z["live_first"], z["live_again"])
+
+
+def test_many_host_threads_with_their_own_handles(emu_lib):
+    """Eight host threads, each with its own extractor handle, extract, associate and search at the same time (the documented threading model: a handle belongs
+    to one thread at a time; the library's shared state - error strings, the runtime's counters, the emulator's worker pool - has to cope); every thread gets
+    exactly what a serial run gets, and nothing stays behind."""
+    import threading
+    import search_scenes as sc
+    lib = emu_lib
+    before = live(lib)
+    NT, ITER = 8, 3
+    pairs = [synth.stereo_pair(376, 240, seed=40 + i, nrect=800) for i in range(NT)]
+
+    def one(ex, i, fv=None, mps=None):
+        r = ex.extract_batch(np.stack(pairs[i])); u, d, n = M.ComputeStereoMatches(ex, ex, 47.9, 0.11, 0, 1, 1)
+        if fv is None:
+            rng = np.random.default_rng(i); fv, k, dd, uu, scales = sc.frame_from_image(pairs[i][0], 500, rng)
+            mps = sc.map_points_for_frame(k, dd, uu, scales, 300, rng, 376, 240)
+        a = M.ORBmatcher(0.8).SearchByProjection(ex, fv, mps, 3.0, False, 0.0)
+        return (r[0][1].tobytes(), r[0][2].tobytes(), u.tobytes(), int(n[0]), a[0], a[1].tobytes()), fv, mps
+    exp = []
+    for i in range(NT):
+        ex = ORBextractor(500, 1.2, 8, 20, 7, lib=lib); exp.append(one(ex, i)); ex.close()
+    errs = []
+
+    def work(i):
+        try:
+            ex = ORBextractor(500, 1.2, 8, 20, 7, lib=lib)
+            for it in range(ITER):
+                if one(ex, i, exp[i][1], exp[i][2])[0] != exp[i][0]: errs.append((i, it))
+            ex.close()
+        except Exception as e:                          # noqa: BLE001
+            errs.append((i, repr(e)[:200]))
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(NT)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert errs == [] and exp[0][0][3] > 50 and exp[0][0][4] > 20
+    del exp
+    assert live(lib) == before
