@@ -33,7 +33,19 @@ struct dim3 {
     dim3(unsigned _x = 1, unsigned _y = 1, unsigned _z = 1) : x(_x), y(_y), z(_z) {}
 };
 
+// The two flavours of the fiber switch (below) live in different inline namespaces: function-local statics of inline functions (the per-thread fiber pool, the
+// worker pool) are unified process-wide by the dynamic linker, and a process may hold two emulator builds at once (tests/test_emu_variants.py builds its
+// own; the sanitizer runs load a ucontext build beside them) - with one name for both, builds with different Fiber layouts shared one pool and crashed.
+#if !defined(__x86_64__) && !defined(HIPEMU_UCONTEXT)
+#define HIPEMU_UCONTEXT
+#endif
+#ifdef HIPEMU_UCONTEXT
+#define HIPEMU_FLAVOUR uctx
+#else
+#define HIPEMU_FLAVOUR stackswitch
+#endif
 namespace hipemu {
+inline namespace HIPEMU_FLAVOUR {
 
 constexpr int kWave = 64;
 constexpr size_t kStack = 256 * 1024;
@@ -41,9 +53,6 @@ constexpr size_t kStack = 256 * 1024;
 // Switching fibers: by default a six-register stack switch (x86-64 SysV: rbx, rbp, r12-r15 + the stack pointer; the kernels never touch the FP control
 // words) - swapcontext() saves and restores the signal mask with a system call per switch, which was a third of the CPU time of the emulated suite.
 // -DHIPEMU_UCONTEXT keeps ucontext (the sanitizer builds: ASan knows swapcontext, not a hand-made switch; other architectures).
-#if !defined(__x86_64__) && !defined(HIPEMU_UCONTEXT)
-#define HIPEMU_UCONTEXT
-#endif
 #ifdef HIPEMU_UCONTEXT
 typedef ucontext_t Ctx;
 #else
@@ -244,6 +253,7 @@ inline void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> fn)
     p->cv_done.wait(l, [&] { return p->running == 0; });
 }
 
+}  // inline namespace
 }  // namespace hipemu
 
 // ---- the HIP device-side vocabulary the kernels use ------------------------------------------------

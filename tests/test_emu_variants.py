@@ -22,7 +22,7 @@ def build_emu_variant(so, defines):
     """the kernel sources for the CPU SIMT emulator with extra -D switches; the translation units are compiled side by side"""
     from concurrent.futures import ThreadPoolExecutor
     d = os.path.dirname(so)
-    flags = ["-O2", "-std=c++17", "-ffp-contract=off", "-DORBX_EMU"] + list(defines) + ["-I" + os.path.join(ROOT, "tests", "emu"), "-I" + CSRC, "-fPIC", "-w"]
+    flags = ["-O2", "-std=c++17", "-ffp-contract=off", "-fwrapv", "-fno-gnu-unique", "-DORBX_EMU"] + list(defines) + ["-I" + os.path.join(ROOT, "tests", "emu"), "-I" + CSRC, "-fPIC", "-w"]
 
     def one(f):
         o = os.path.join(d, f + ".o")
