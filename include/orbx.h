@@ -48,10 +48,12 @@ int orbx_device_count(void);
 /* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)  include/ORBextractor.h:49-50,
  * src/ORBextractor.cc:468-571.  device_id selects the GPU (one process per GPU in multi-GPU runs).
  * Limits, all reported loudly: images of at most 4127 x 4127 pixels and at least the 35-px FAST cell grid on the smallest level (ORBX_E_ARG from the
- * extraction); the quadtree of a level works in LDS, 81 bytes per node: beside it the bucket counters and the coordinate tables of the level (16 - 55 KB, growing
- * with the image).  With the 160 KB of gfx950, scale factor 1.2 and 8 levels (level 0 takes 21.7 % of the features) that is nfeatures up to 7 800 at 752 x 480
- * and about 6 100 at 4127 x 4127 when one to 32 images are extracted per call, more in larger batches (narrower counters) - ORBX_E_CAPACITY from the
- * extraction beyond that, the handle stays usable (the reference's settings files ask for 1 000 - 2 000); fewer than 65 535 keypoints per image over all levels. */
+ * extraction); fewer than 65 535 keypoints per image over all levels (16-bit node indices; the reference's settings files ask for 500 - 2 000 and
+ * Tracking builds its monocular initialisation extractor with five times that, src/Tracking.cc:634-635, :1331-1332: up to 10 000).
+ * The quadtree of a level (src/ORBextractor.cc:711-1057) works in LDS when its node lists fit - 81 bytes per node beside 16 - 55 KB of bucket
+ * counters and coordinate tables: with the 160 KB of gfx950 that is every level of up to ~1 400 - 1 800 keypoints, i.e. every level of every stereo,
+ * RGB-D and post-initialisation monocular setting - and in a global node pool otherwise (level 0 of 10 000 features at 1241 x 376 holds 2 172):
+ * the same algorithm and the same result, without a bound of its own. */
 int orbx_create(orbx_extractor** out, int nfeatures, float scale_factor, int nlevels,
                 int ini_th_fast, int min_th_fast, int device_id);
 void orbx_destroy(orbx_extractor* h);
@@ -205,6 +207,11 @@ int orbx_debug_level_keys(orbx_extractor* h, int image_index, int level, int* xy
  * (an earlier revision's form) instead of Sophus' quaternion action (tests/test_sophus_action.py: the reference must then catch it) */
 int orbx_debug_stereo_flags(orbx_extractor* h, int flags);
 int orbx_debug_quadtree_profile(orbx_extractor* h, long long out[16]);   /* phase timestamps of one quadtree workgroup (profiling mode 2) */
+/* test hook: the largest quadtree (nodes per level) that is given the LDS form; levels above it keep their node lists in the global node pool
+ * (the form the 5 x nFeatures extractor of the monocular initialisation takes for its first levels).  0 = every level in the pool; the default and
+ * the largest value is 4 000.  Bit-identical outputs. */
+int orbx_debug_quadtree_lds_nodes(orbx_extractor* h, int max_nodes);
+int orbx_debug_quadtree_pool_levels(orbx_extractor* h);                   /* number of levels (0 .. n-1) the last extraction ran in the pool form */
 /* test hook: the byte / packed-16-bit instruction wrappers of the kernels (csrc/orbx_simd.h) applied to n operand triples (n a multiple of 256);
  * out = 20 x n results in the order mul24, mul24 (forced), v_perm_b32, v_alignbyte_b32, v_dot4_u32_u8, v_dot2_u32_u16, packed max3, packed min3,
  * packed sub, packed xor(a, c), wave inclusive scan / wave sum of a & 0xFFFF, wave minimum of b (per 64 consecutive elements), v_sad_u8, v_mul_u32_u24,

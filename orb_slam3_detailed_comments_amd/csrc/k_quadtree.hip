@@ -162,6 +162,37 @@ struct QuadCls {    // DivideNode's key -> child test (:651-661)
 #endif
 constexpr int kWaveSortRange = ORBX_WAVE_SORT_RANGE;     // ranges longer than this are partitioned by a wave instead of one thread
 
+// Lanes of one wave hand values to each other through the arrays of the tree.  In LDS the wave's accesses are performed in issue order and the
+// scheduling barrier is all that is needed; when the arrays live in the global node pool (kSpill) the compiler is also told that the hand-over is a
+// release / acquire at wavefront scope (no instruction: a wave's vector memory accesses go through one L1 in issue order).
+template <bool kSpill>
+__device__ __forceinline__ void wave_sync_mem() {
+#ifdef ORBX_EMU
+    ORBX_WAVE_SYNC();
+#else
+    if (kSpill) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    ORBX_WAVE_SYNC();
+    if (kSpill) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+// A pending range of the sort: first | last | depth budget.  The LDS form of the tree holds fewer than 4096 nodes (12-bit positions in a dword);
+// the node-pool form takes up to 65 535 (20-bit positions in a qword).
+template <bool kWide> struct SortSeg;
+template <> struct SortSeg<false> {
+    typedef uint32_t T;
+    static __device__ __forceinline__ T pack(int first, int last, int depth) { return (uint32_t)first | ((uint32_t)last << 12) | ((uint32_t)depth << 24); }
+    static __device__ __forceinline__ int first(T s) { return (int)(s & 0xFFF); }
+    static __device__ __forceinline__ int last(T s) { return (int)((s >> 12) & 0xFFF); }
+    static __device__ __forceinline__ int depth(T s) { return (int)(s >> 24); }
+};
+template <> struct SortSeg<true> {
+    typedef unsigned long long T;
+    static __device__ __forceinline__ T pack(int first, int last, int depth) { return (T)first | ((T)last << 20) | ((T)depth << 40); }
+    static __device__ __forceinline__ int first(T s) { return (int)(s & 0xFFFFF); }
+    static __device__ __forceinline__ int last(T s) { return (int)((s >> 20) & 0xFFFFF); }
+    static __device__ __forceinline__ int depth(T s) { return (int)(s >> 40); }
+};
+
 // libstdc++'s __unguarded_partition (sm_unguarded_partition) of a[lo, hi) around a[pivot] by one wave, same result and same array state.
 // The sequential loop alternates "first walks up to the next element >= pivot" and "last walks down to the next element <= pivot" and
 // swaps the two while first < last.  A walk never revisits a swapped position except the most recent one, so with
@@ -169,6 +200,7 @@ constexpr int kWaveSortRange = ORBX_WAVE_SORT_RANGE;     // ranges longer than t
 // swap k exchanges a[L_k] and a[R_k], K = #{k : L_k < R_k} swaps happen (the predicate is monotone in k), and the walk of `first` that
 // ends the loop stops at L_K or at R_(K-1) (which holds an element >= pivot since swap K-1), whichever comes first.
 // scratch: 4 * (hi - lo) uint16.  Returns the cut in every lane.
+template <bool kSpill>
 __device__ __forceinline__ int wave_unguarded_partition(unsigned long long* a, int lo, int hi, int pivot, uint16_t* scratch) {
     const int lane = lane_id();
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -188,7 +220,7 @@ __device__ __forceinline__ int wave_unguarded_partition(unsigned long long* a, i
         if (isR) Rasc[nR + __popcll(bR & lt)] = (uint16_t)i;
         nL += __popcll(bL); nR += __popcll(bR);
     }
-    ORBX_WAVE_SYNC();
+    wave_sync_mem<kSpill>();
     const int mn = nL < nR ? nL : nR;
     int K = 0;
     for (int k0 = 0; k0 < mn; k0 += 64) {
@@ -201,7 +233,7 @@ __device__ __forceinline__ int wave_unguarded_partition(unsigned long long* a, i
         K += __popcll(bal);
         if (bal != ~0ull) break;
     }
-    ORBX_WAVE_SYNC();
+    wave_sync_mem<kSpill>();
     int cut = 0x7FFFFFFF;
     if (K < nL) cut = Lpos[K];
     if (K >= 1) { const int r = Rasc[nR - K]; cut = r < cut ? r : cut; }
@@ -216,10 +248,13 @@ __device__ __forceinline__ int wave_unguarded_partition(unsigned long long* a, i
 //  * __final_insertion_sort never moves an element across a partition cut (left of a cut is <= pivot <= right of it) and
 //    insertion sort is stable, so it equals a stable rank-sort inside every final range of <= 16 elements: each thread
 //    ranks one element among its <= 16 range-mates.
-// seg0/seg1: two range lists (first | last << 12 | depth << 24), capacity >= n/8 + 8 each; flags: n bytes
+// seg0/seg1: two range lists (SortSeg: first | last | depth), capacity >= n/8 + 8 each; flags: n bytes
 // (1 = a final range starts here, 2 = a heap-sorted range starts here); tmp: n elements.  All NT threads of the workgroup must call.
+template <bool kSpill>
 __device__ __forceinline__ void block_sort_libstdcxx(unsigned long long* a, unsigned long long* tmp, int n,
-                                                     uint32_t* seg0, uint32_t* seg1, uint8_t* flags, int* s_ctr, int NT) {
+                                                     typename SortSeg<kSpill>::T* seg0, typename SortSeg<kSpill>::T* seg1, uint8_t* flags, int* s_ctr, int NT) {
+    typedef SortSeg<kSpill> Seg;
+    typedef typename Seg::T SegT;
     const int tid = (int)threadIdx.x;
     SortLess less;
     for (int i = tid; i < n; i += NT) flags[i] = 0;
@@ -228,10 +263,10 @@ __device__ __forceinline__ void block_sort_libstdcxx(unsigned long long* a, unsi
         for (int t = n; t > 1; t >>= 1) lg++;
         flags[0] = 1;
         s_ctr[0] = 0; s_ctr[1] = 0;
-        if (n > 16) { seg0[0] = 0u | ((uint32_t)n << 12) | ((uint32_t)(lg * 2) << 24); s_ctr[0] = 1; }
+        if (n > 16) { seg0[0] = Seg::pack(0, n, lg * 2); s_ctr[0] = 1; }
     }
     __syncthreads();
-    uint32_t* cur = seg0; uint32_t* nxt = seg1;
+    SegT* cur = seg0; SegT* nxt = seg1;
     int which = 0;
     const int lane = lane_id(), wave = tid >> 6, nwaves = NT >> 6;
     for (;;) {
@@ -239,24 +274,24 @@ __device__ __forceinline__ void block_sort_libstdcxx(unsigned long long* a, unsi
         if (ncur == 0) break;
         // long ranges (the first levels of the partition tree): one wave each, wave_unguarded_partition
         for (int j = wave; j < ncur; j += nwaves) {
-            const uint32_t sg = cur[j];
-            const int first = (int)(sg & 0xFFF), last = (int)((sg >> 12) & 0xFFF);
-            int depth = (int)(sg >> 24);
+            const SegT sg = cur[j];
+            const int first = Seg::first(sg), last = Seg::last(sg);
+            int depth = Seg::depth(sg);
             if (depth == 0 || last - first <= kWaveSortRange) continue;
             --depth;
             if (lane == 0) sm_move_median_to_first(a, first, first + 1, first + (last - first) / 2, last - 1, less);
-            ORBX_WAVE_SYNC();
-            const int cut = wave_unguarded_partition(a, first + 1, last, first, (uint16_t*)(tmp + first));
+            wave_sync_mem<kSpill>();
+            const int cut = wave_unguarded_partition<kSpill>(a, first + 1, last, first, (uint16_t*)(tmp + first));
             if (lane == 0) {
-                if (last - cut > 16) nxt[atomicAdd(&s_ctr[which ^ 1], 1)] = (uint32_t)cut | ((uint32_t)last << 12) | ((uint32_t)depth << 24);
+                if (last - cut > 16) nxt[atomicAdd(&s_ctr[which ^ 1], 1)] = Seg::pack(cut, last, depth);
                 if (cut < last) flags[cut] = flags[cut] ? flags[cut] : 1;
-                if (cut - first > 16) nxt[atomicAdd(&s_ctr[which ^ 1], 1)] = (uint32_t)first | ((uint32_t)cut << 12) | ((uint32_t)depth << 24);
+                if (cut - first > 16) nxt[atomicAdd(&s_ctr[which ^ 1], 1)] = Seg::pack(first, cut, depth);
             }
         }
         for (int j = tid; j < ncur; j += NT) {
-            const uint32_t sg = cur[j];
-            const int first = (int)(sg & 0xFFF), last = (int)((sg >> 12) & 0xFFF);
-            int depth = (int)(sg >> 24);
+            const SegT sg = cur[j];
+            const int first = Seg::first(sg), last = Seg::last(sg);
+            int depth = Seg::depth(sg);
             if (depth == 0) {
                 sm_heap_sort(a, first, last, less);
                 flags[first] = 2;
@@ -266,15 +301,15 @@ __device__ __forceinline__ void block_sort_libstdcxx(unsigned long long* a, unsi
                 sm_move_median_to_first(a, first, first + 1, mid, last - 1, less);
                 const int cut = sm_unguarded_partition(a, first + 1, last, first, less);
                 // right range [cut, last), left range [first, cut): both continue with the decremented budget
-                if (last - cut > 16) nxt[atomicAdd(&s_ctr[which ^ 1], 1)] = (uint32_t)cut | ((uint32_t)last << 12) | ((uint32_t)depth << 24);
+                if (last - cut > 16) nxt[atomicAdd(&s_ctr[which ^ 1], 1)] = Seg::pack(cut, last, depth);
                 if (cut < last) flags[cut] = flags[cut] ? flags[cut] : 1;
-                if (cut - first > 16) nxt[atomicAdd(&s_ctr[which ^ 1], 1)] = (uint32_t)first | ((uint32_t)cut << 12) | ((uint32_t)depth << 24);
+                if (cut - first > 16) nxt[atomicAdd(&s_ctr[which ^ 1], 1)] = Seg::pack(first, cut, depth);
             }
         }
         __syncthreads();
         if (tid == 0) s_ctr[which] = 0;
         which ^= 1;
-        { uint32_t* t = cur; cur = nxt; nxt = t; }
+        { SegT* t = cur; cur = nxt; nxt = t; }
         __syncthreads();
     }
     // final insertion sort == stable rank inside each final range
@@ -521,26 +556,31 @@ __device__ __forceinline__ void presort_keys(const uint32_t* __restrict__ bufB, 
     }
 }
 
-// grid (B, nlevels), kQuadtreeThreads threads of which the first L.qt_threads (256 or 1024, by the size of the level) work on the level
-// and the rest exits at once.  Dynamic LDS: see carve below (host passes node_cap).
-__global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* __restrict__ lv,
-                                                  const CellInfo* __restrict__ cells, int ncells,
-                                                  const int* __restrict__ cell_count,
-                                                  const uint32_t* __restrict__ slots, size_t slots_stride,
-                                                  uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
-                                                  uint32_t* __restrict__ lvl_keys, int kp_total_cap,
-                                                  int* __restrict__ lvl_count, int nlevels, int node_cap, int nb_cap, int lut_x, int lut_y,
-                                                  int* __restrict__ status, long long* __restrict__ qt_prof, int wide, int counter_bytes) {
-    ORBX_DYN_SMEM(smem);
+// One tree = one workgroup: kQuadtreeThreads threads of which the first L.qt_threads (256 or 1024, by the size of the level) work on the level
+// and the rest exits at once.
+// kSpill = false: node lists, child counts, expand lists and flags are carved from dynamic LDS (81 bytes per node) beside the bucket tables - the
+// form every level of the reference's stereo / RGB-D settings takes.
+// kSpill = true: the same arrays live in a per-tree slice of a global node pool (L2-resident: a level of 10 000 nodes is 0.8 MB) and LDS only
+// holds the bucket tables; this is what levels take whose node lists exceed the LDS of the device - the monocular initialisation extractor,
+// ORBextractor(5 * nFeatures, ..) (src/Tracking.cc:634-635, :1331-1332): 10 000 features at 1241 x 376 (KITTI), 7 500 at 512 x 512 (TUM-VI).
+// The reference's std::list has no bound (src/ORBextractor.cc:711-1057), and neither has this form below the 65 535 keypoints per image of the
+// 16-bit node indices.
+template <bool kSpill>
+__device__ __forceinline__ void quadtree_tree(unsigned char* smem, unsigned char* pool, const int level, const int b,
+                                              const LevelInfo* __restrict__ lv,
+                                              const CellInfo* __restrict__ cells, int ncells,
+                                              const int* __restrict__ cell_count,
+                                              const uint32_t* __restrict__ slots, size_t slots_stride,
+                                              uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
+                                              uint32_t* __restrict__ lvl_keys, int kp_total_cap,
+                                              int* __restrict__ lvl_count, int nlevels, int node_cap, int nb_cap, int lut_x, int lut_y,
+                                              int* __restrict__ status, long long* __restrict__ qt_prof, int wide, int counter_bytes) {
     __shared__ unsigned long long s_scan[20];
     __shared__ int s_i[80];
     int* s_part = s_i;                                  // block_partition4: 4 counts per wave
     int* s_ndiv = s_i + 64;
     int* s_sortctr = s_i + 66;
     int* s_kinds = s_i + 68;                            // kinds of deep nodes met in the current pass (kDeepSmall | kDeepBig)
-    // grid (B, nlevels): workgroups are dispatched image-fastest, i.e. every image's level 0 (the longest tree by far) starts first and the
-    // short trees of the small levels fill the remaining slots
-    const int level = (int)blockIdx.y, b = (int)blockIdx.x;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const LevelInfo L = lv[level];
     // wide: the large levels get L.qt_threads threads (small batches: the latency of one tree is what counts); otherwise every level runs on
@@ -558,18 +598,19 @@ __global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* 
 #endif
     QT_STAMP(0)
     if (tid == 0) *s_kinds = 0;
-    // LDS carve: nodes[2][cap] (24 B) | childcnt[cap][4] (u32) | expand[2][cap] (u64) | bucket_start[nb+1] | counts (counter_bytes per bucket: u16 or u32 per
-    // segment) | code LUTs | erased[cap] (u8)
-    QNode* nodes0 = (QNode*)smem;
+    // carve: nodes[2][cap] (24 B) | childcnt[cap][4] (u32) | expand[2][cap] (u64) | erased[cap] (u8) - from LDS, or from this tree's slice of the
+    // node pool (kSpill) - then, always in LDS: bucket_start[nb+1] | counts (counter_bytes per bucket: u16 or u32 per segment) | code LUTs
+    unsigned char* node_mem = kSpill ? pool : smem;
+    QNode* nodes0 = (QNode*)node_mem;
     QNode* nodes1 = nodes0 + node_cap;
     uint32_t* childcnt = (uint32_t*)(nodes1 + node_cap);
     unsigned long long* exp0 = (unsigned long long*)(childcnt + 4 * (size_t)node_cap);
     unsigned long long* exp1 = exp0 + node_cap;
-    int* bucket_start = (int*)(exp1 + node_cap);
+    uint8_t* erased = (uint8_t*)(exp1 + node_cap);
+    int* bucket_start = kSpill ? (int*)smem : (int*)(smem + (((size_t)node_cap * 81 + 15) & ~(size_t)15));
     int* counts = bucket_start + (nb_cap + 2);
     uint16_t* xpart = (uint16_t*)(counts + (size_t)(counter_bytes >> 2) * nb_cap);     // bucket code = xpart[x] + ypart[y]
     uint16_t* ypart = xpart + lut_x;
-    uint8_t* erased = (uint8_t*)(ypart + lut_y);
     const int D = L.presort_depth, NBr = 1 << (2 * D), NB = L.nini * NBr;     // buckets per root / in total
     uint32_t* bufA = candA + (size_t)b * cand_stride + L.cand_off;
     uint32_t* bufB = candB + (size_t)b * cand_stride + L.cand_off;
@@ -837,7 +878,8 @@ __global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* 
                 QT_STAMP(4)
                 // scratch: the child-count table is not live here (range lists), `erased` doubles as the range-start flags,
                 // the other expand array is the rank-sort target
-                block_sort_libstdcxx(expc, expn, nexp, childcnt, childcnt + 2 * (size_t)node_cap, erased, s_sortctr, NT);
+                block_sort_libstdcxx<kSpill>(expc, expn, nexp, (typename SortSeg<kSpill>::T*)childcnt, (typename SortSeg<kSpill>::T*)(childcnt + 2 * (size_t)node_cap),
+                                             erased, s_sortctr, NT);
                 QT_STAMP(5)
                 for (int i = tid; i < nnodes; i += NT) erased[i] = 0;
                 if (tid == 0) *s_ndiv = nexp;
@@ -1027,6 +1069,38 @@ __global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* 
     }
     if (tid == 0) lvl_count[(size_t)b * nlevels + level] = nnodes;
     QT_STAMP(9)
+}
+
+// grid (B, number of levels of this launch): workgroups are dispatched image-fastest, i.e. every image's largest level (the longest tree by far)
+// starts first and the short trees of the small levels fill the remaining slots.  The launch covers levels level0 .. level0 + gridDim.y - 1.
+// Dynamic LDS: node arrays + tables (host: quadtree_lds_bytes).
+__global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* __restrict__ lv,
+                                                  const CellInfo* __restrict__ cells, int ncells,
+                                                  const int* __restrict__ cell_count,
+                                                  const uint32_t* __restrict__ slots, size_t slots_stride,
+                                                  uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
+                                                  uint32_t* __restrict__ lvl_keys, int kp_total_cap,
+                                                  int* __restrict__ lvl_count, int nlevels, int node_cap, int nb_cap, int lut_x, int lut_y,
+                                                  int* __restrict__ status, long long* __restrict__ qt_prof, int wide, int counter_bytes, int level0) {
+    ORBX_DYN_SMEM(smem);
+    quadtree_tree<false>(smem, nullptr, (int)blockIdx.y + level0, (int)blockIdx.x, lv, cells, ncells, cell_count, slots, slots_stride, candA, candB, cand_stride,
+                         lvl_keys, kp_total_cap, lvl_count, nlevels, node_cap, nb_cap, lut_x, lut_y, status, qt_prof, wide, counter_bytes);
+}
+// The levels whose node lists do not fit the LDS: levels 0 .. gridDim.y - 1, tree (b, level) works in pool + (b * gridDim.y + level) * pool_stride.
+// Dynamic LDS: the tables only.
+__global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree_spill(const LevelInfo* __restrict__ lv,
+                                                  const CellInfo* __restrict__ cells, int ncells,
+                                                  const int* __restrict__ cell_count,
+                                                  const uint32_t* __restrict__ slots, size_t slots_stride,
+                                                  uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
+                                                  uint32_t* __restrict__ lvl_keys, int kp_total_cap,
+                                                  int* __restrict__ lvl_count, int nlevels, int node_cap, int nb_cap, int lut_x, int lut_y,
+                                                  int* __restrict__ status, long long* __restrict__ qt_prof, int wide, int counter_bytes,
+                                                  unsigned char* __restrict__ pool, size_t pool_stride) {
+    ORBX_DYN_SMEM(smem);
+    quadtree_tree<true>(smem, pool + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * pool_stride, (int)blockIdx.y, (int)blockIdx.x, lv, cells, ncells, cell_count,
+                        slots, slots_stride, candA, candB, cand_stride, lvl_keys, kp_total_cap, lvl_count, nlevels, node_cap, nb_cap, lut_x, lut_y, status,
+                        qt_prof, wide, counter_bytes);
 }
 
 }  // namespace orbx

@@ -128,10 +128,32 @@ void pyramid_spans(const orbx_extractor* h, bool columns, std::vector<PyrSpan>& 
     }
 }
 
+// How the quadtree stage is launched (k_quadtree.hip).  A tree's node arrays take 81 bytes per node; beside them the bucket offsets, the per-segment
+// bucket counters (counter_bytes per bucket) and the two coordinate tables of the level.  Levels first_lds .. nlevels-1 run in the LDS form with
+// node_cap_lds nodes each; levels 0 .. first_lds-1 (the big quotas of a 5 x nFeatures extractor) keep their node arrays in the global pool.
+struct QuadtreePlan { int first_lds, node_cap_lds, lut_x, lut_y; size_t smem_lds, smem_spill, pool_stride; };
+QuadtreePlan quadtree_plan(const orbx_extractor* h, int counter_bytes) {
+    QuadtreePlan p;
+    p.lut_x = (int)align_up((size_t)h->lv[0].bw + 1, 8); p.lut_y = (int)align_up((size_t)h->lv[0].bh + 1, 8);       // level 0 is the largest
+    const size_t tables = (size_t)(h->nb_cap + 2) * 4 + (size_t)counter_bytes * h->nb_cap + 2 * (size_t)(p.lut_x + p.lut_y) + 64;
+    const size_t limit = rt::lds_limit(h->device);
+    p.first_lds = h->nlevels; p.node_cap_lds = 0; p.smem_lds = 0;
+    int cap = 0;
+    for (int l = h->nlevels - 1; l >= 0; l--) {
+        cap = std::max(cap, h->lv[l].kp_cap + 8);
+        const size_t smem = align_up((size_t)cap * 81, 16) + tables;
+        if (cap > h->qt_lds_nodes || smem + 2048 > limit) break;
+        p.first_lds = l; p.node_cap_lds = cap; p.smem_lds = smem;
+    }
+    p.smem_spill = tables;
+    p.pool_stride = align_up((size_t)h->node_cap * 81, 256);
+    return p;
+}
+
 int configure(orbx_extractor* h, int W, int H, int B) {
     if (W <= 0 || H <= 0 || B <= 0) return fail(ORBX_E_ARG, "bad size %dx%d batch %d", W, H, B);
     const bool same_geom = (W == h->W && H == h->H);
-    if (same_geom && B <= h->maxB) return ORBX_OK;
+    if (same_geom && B <= h->maxB && h->cfg_qt_lds_nodes == h->qt_lds_nodes) return ORBX_OK;
     if (rt::set_device(h->device)) return fail(ORBX_E_DEVICE, "hipSetDevice(%d) failed", h->device);
     if (!same_geom) {
         if (W - 2 * kBorder > 4095 || H - 2 * kBorder > 4095) return fail(ORBX_E_ARG, "image larger than 4127 px is not supported");
@@ -252,6 +274,13 @@ int configure(orbx_extractor* h, int W, int H, int B) {
         if (!h->yspan.empty()) rt::copy_h2d(h->d_yspan.p, h->yspan.data(), sizeof(PyrSpan) * h->yspan.size(), h->s0);
         if (rt::stream_sync(h->s0)) return fail(ORBX_E_DEVICE, "table upload failed: %s", rt::last_error());
         h->W = W; h->H = H;                                        // commit
+    }
+    if (B > h->maxB || h->cfg_qt_lds_nodes != h->qt_lds_nodes) {
+        // node pool of the quadtree levels beyond the LDS: sized for the wider counters (small batches), which leave the LDS form the fewest levels
+        const QuadtreePlan qp = quadtree_plan(h, 32);
+        if (qp.first_lds > 0 && h->d_qtpool.ensure((size_t)std::max(B, h->maxB) * qp.first_lds * qp.pool_stride))
+            return fail(ORBX_E_DEVICE, "device allocation failed (quadtree node pool, batch %d of %dx%d)", B, W, H);
+        h->cfg_qt_lds_nodes = h->qt_lds_nodes;
     }
     if (B > h->maxB) {
         const size_t b = (size_t)B, cap = (size_t)h->kp_total_cap;
@@ -405,21 +434,29 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
     const int nb_rows = (h->H >> kStereoRowShift) + 2;
     stage_begin(h, ST_QUADTREE, h->s0);
     {
-        dim3 grid(B, nl, 1);
-        // nodes 2x24 B + child counts 16 B + expand lists 2x8 B + flags 1 B per node; bucket offsets + 32 B of per-wave cursors per bucket
-        const int lut_x = (int)align_up((size_t)h->lv[0].bw + 1, 8), lut_y = (int)align_up((size_t)h->lv[0].bh + 1, 8);   // level 0 is the largest
         // small batches: the large levels run on 1024 threads (half the latency of one tree); large batches: four waves per tree, more trees per CU
         int qt_block = 256;
         if (B <= ORBX_QT_WIDE_BATCH) for (int l = 0; l < nl; l++) qt_block = std::max(qt_block, h->lv[l].qt_threads);
         const int wide = qt_block > 256, counter_bytes = wide ? 32 : 16;
-        const size_t smem = (size_t)h->node_cap * 81 + (size_t)(h->nb_cap + 2) * 4 + (size_t)counter_bytes * h->nb_cap + 2 * (size_t)(lut_x + lut_y) + 64;
+        const QuadtreePlan qp = quadtree_plan(h, counter_bytes);
+        h->qt_pool_levels = qp.first_lds;
         const dim3 blkq(qt_block, 1, 1);
-        if (smem + 2048 > rt::lds_limit(h->device))
-            return fail(ORBX_E_CAPACITY, "nfeatures %d at %dx%d needs %zu bytes of LDS per quadtree workgroup, the device allows %zu", h->nfeatures, h->W, h->H, smem + 2048, rt::lds_limit(h->device));
-        ORBX_LAUNCH(k_quadtree, grid, blkq, smem, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
-                    (const int*)h->d_cell_count.p, (const uint32_t*)h->d_slots.p, h->cand_stride, h->d_candA.p, h->d_candB.p, h->cand_stride,
-                    h->d_lvl_keys.p, h->kp_total_cap, h->d_lvl_count.p, nl, h->node_cap, h->nb_cap, lut_x, lut_y, h->d_status.p,
-                    h->serial ? (long long*)h->d_qtprof.p : (long long*)nullptr, wide, counter_bytes);
+        long long* prof = h->serial ? (long long*)h->d_qtprof.p : (long long*)nullptr;
+        if (qp.smem_spill + 2048 > rt::lds_limit(h->device))
+            return fail(ORBX_E_CAPACITY, "the quadtree's bucket tables at %dx%d need %zu bytes of LDS, the device allows %zu", h->W, h->H, qp.smem_spill + 2048, rt::lds_limit(h->device));
+        if (qp.first_lds > 0) {
+            // the trees of the largest quotas first (they are the longest): node arrays in the pool, tables in LDS
+            if (h->d_qtpool.n < (size_t)B * qp.first_lds * qp.pool_stride) return fail(ORBX_E_INTERNAL, "quadtree node pool not allocated");
+            ORBX_LAUNCH(k_quadtree_spill, dim3(B, qp.first_lds, 1), blkq, qp.smem_spill, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
+                        (const int*)h->d_cell_count.p, (const uint32_t*)h->d_slots.p, h->cand_stride, h->d_candA.p, h->d_candB.p, h->cand_stride,
+                        h->d_lvl_keys.p, h->kp_total_cap, h->d_lvl_count.p, nl, h->node_cap, h->nb_cap, qp.lut_x, qp.lut_y, h->d_status.p,
+                        prof, wide, counter_bytes, h->d_qtpool.p, qp.pool_stride);
+        }
+        if (qp.first_lds < nl)
+            ORBX_LAUNCH(k_quadtree, dim3(B, nl - qp.first_lds, 1), blkq, qp.smem_lds, h->s0, (const LevelInfo*)h->d_lv.p, (const CellInfo*)h->d_cells.p, h->ncells,
+                        (const int*)h->d_cell_count.p, (const uint32_t*)h->d_slots.p, h->cand_stride, h->d_candA.p, h->d_candB.p, h->cand_stride,
+                        h->d_lvl_keys.p, h->kp_total_cap, h->d_lvl_count.p, nl, qp.node_cap_lds, h->nb_cap, qp.lut_x, qp.lut_y, h->d_status.p,
+                        prof, wide, counter_bytes, qp.first_lds);
     }
     stage_end(h, ST_QUADTREE, h->s0);
     stage_begin(h, ST_LAYOUT, h->s0);
@@ -505,7 +542,7 @@ void orbx_destroy(orbx_extractor* h) {
     for (auto& x : h->d_si) x.release();
     h->d_kps_un.release();
     h->d_lp.release(); h->d_depth_in.release(); h->h_lp_in.release(); h->h_lp_out.release();
-    h->d_aux.release(); h->d_qtprof.release(); h->d_rowstart.release(); h->d_rowitems.release();
+    h->d_aux.release(); h->d_qtprof.release(); h->d_qtpool.release(); h->d_rowstart.release(); h->d_rowitems.release();
     h->d_mapx.release(); h->d_mapy.release(); h->d_in_xt.release(); h->d_in_yt.release(); h->d_frame.release();
     delete h;
 }
@@ -855,6 +892,13 @@ int orbx_set_pyramid_mode(orbx_extractor* h, int mode) {
 }
 
 int orbx_set_small_batch_forms(orbx_extractor* h, int on) { if (!h) return ORBX_E_ARG; h->small_forms = on != 0; return ORBX_OK; }
+int orbx_debug_quadtree_pool_levels(orbx_extractor* h) { return h ? h->qt_pool_levels : ORBX_E_ARG; }
+int orbx_debug_quadtree_lds_nodes(orbx_extractor* h, int max_nodes) {
+    if (!h || max_nodes < 0) return ORBX_E_ARG;
+    h->qt_lds_nodes = std::min(max_nodes, kQuadtreeLdsNodes);
+    h->g_B = 0;                 // a captured graph holds the launches of the old plan
+    return ORBX_OK;
+}
 
 int orbx_set_graph_replay(orbx_extractor* h, int on) { if (!h) return ORBX_E_ARG; h->use_graph = on != 0; return ORBX_OK; }
 

@@ -104,6 +104,9 @@ struct orbx_extractor {
     size_t area_pool = 0, area_last_total = 0;
     orbx::DevBuf<int> d_si[8];
     orbx::DevBuf<long long> d_qtprof;
+    // k_quadtree_spill: node pool of the levels whose quadtree does not fit the LDS (orbx_api.cpp: quadtree_plan); qt_lds_nodes = largest tree the LDS form
+    // is given (orbx_debug_quadtree_lds_nodes: tests lower it to run small cases through the pool form)
+    orbx::DevBuf<uint8_t> d_qtpool; int qt_lds_nodes = orbx::kQuadtreeLdsNodes, cfg_qt_lds_nodes = 0, qt_pool_levels = 0;      // qt_pool_levels: levels the last extraction ran in the pool form
     // hipGraph replay of the extraction pipeline (orbx_set_graph_replay)
     bool use_graph = false;
 #ifndef ORBX_EMU

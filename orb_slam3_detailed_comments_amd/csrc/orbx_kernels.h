@@ -55,7 +55,15 @@ __global__ void k_quadtree(const LevelInfo* __restrict__ lv, const CellInfo* __r
                            uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
                            uint32_t* __restrict__ lvl_keys, int kp_total_cap, int* __restrict__ lvl_count,
                            int nlevels, int node_cap, int nb_cap, int lut_x, int lut_y, int* __restrict__ status, long long* __restrict__ qt_prof,
-                           int wide, int counter_bytes);
+                           int wide, int counter_bytes, int level0);
+// levels whose node lists exceed the LDS (the 5 x nFeatures extractor of the monocular initialisation): node arrays in a global pool
+__global__ void k_quadtree_spill(const LevelInfo* __restrict__ lv, const CellInfo* __restrict__ cells, int ncells,
+                           const int* __restrict__ cell_count, const uint32_t* __restrict__ slots, size_t slots_stride,
+                           uint32_t* __restrict__ candA, uint32_t* __restrict__ candB, size_t cand_stride,
+                           uint32_t* __restrict__ lvl_keys, int kp_total_cap, int* __restrict__ lvl_count,
+                           int nlevels, int node_cap, int nb_cap, int lut_x, int lut_y, int* __restrict__ status, long long* __restrict__ qt_prof,
+                           int wide, int counter_bytes, unsigned char* __restrict__ pool, size_t pool_stride);
+constexpr int kQuadtreeLdsNodes = 4000;     // the LDS form packs positions of its sort ranges in 12 bits: trees with more nodes take the pool form whatever the LDS
 __global__ void k_layout(const LevelInfo* __restrict__ lv, int nlevels, const uint32_t* __restrict__ lvl_keys,
                          int kp_total_cap, const int* __restrict__ lvl_count, int lap0, int lap1,
                          int* __restrict__ final_idx, int* __restrict__ n_out, int* __restrict__ mono_out,

@@ -196,6 +196,15 @@ class ORBextractor:
         form (two launches on two streams) at every batch size (orbx_set_small_batch_forms).  Bit-identical outputs."""
         self._lib.check(self._lib.L.orbx_set_small_batch_forms(self._h, 1 if on else 0))
 
+    def debug_quadtree_lds_nodes(self, max_nodes):
+        """Test hook: levels whose quadtree may hold more than max_nodes nodes keep their node lists in the global node pool instead of LDS
+        (orbx_debug_quadtree_lds_nodes; 0 = every level).  Bit-identical outputs."""
+        self._lib.check(self._lib.L.orbx_debug_quadtree_lds_nodes(self._h, int(max_nodes)))
+
+    def debug_quadtree_pool_levels(self):
+        """Number of pyramid levels whose quadtree the last extraction ran in the pool form (orbx_debug_quadtree_pool_levels)."""
+        return int(self._lib.L.orbx_debug_quadtree_pool_levels(self._h))
+
     def graph_replay(self, on=True):
         """Replay the extraction pipeline as one hipGraph (small-batch latency)."""
         self._lib.check(self._lib.L.orbx_set_graph_replay(self._h, int(on)))

@@ -401,24 +401,25 @@ def test_descriptor_rows_beyond_count_are_zero_gpu(hip_lib):
     _zero_rows_case(hip_lib, 752, 480, 1200)
 
 
-def test_feature_counts_beyond_the_lds_are_refused(emu_lib, monkeypatch):
-    """The quadtree of a level lives in LDS (81 bytes per node): with gfx950's 160 KB a single 752x480 image takes nfeatures = 7800 and refuses 8000
-    (ORBX_E_CAPACITY), a batch of 40 (the narrow-counter form) still takes 8000; the emulator is given the device's LDS size for this test.  The handle
-    and the library stay usable, and what was accepted is still the reference's result."""
-    from orb_slam3_detailed_comments_amd._lib import OrbxError
+def test_feature_counts_beyond_the_lds_take_the_node_pool(emu_lib, monkeypatch):
+    """The quadtree of a level lives in LDS (81 bytes per node) when it fits: with gfx950's 160 KB a single 752x480 image takes nfeatures = 7800 in LDS on
+    every level; 8000 (refused until round 6) runs its level 0 in the global node pool, a batch of 40 (the narrow-counter form) still in LDS; the
+    emulator is given the device's LDS size for this test.  All of them are the reference's result (tests/test_mono_init.py: the shipped settings)."""
     monkeypatch.setenv("ORBX_EMU_LDS_LIMIT", "163840")
     img = synth.uniform_noise(752, 480, seed=3)
     ex = ORBextractor(8000, 1.2, 8, 20, 7, lib=emu_lib)
-    with pytest.raises(OrbxError, match="bytes of LDS per quadtree workgroup") as e:
-        ex(img)
-    assert e.value.code == -4
+    exp = ol.OracleExtractor(8000).extract(img)
+    got = ex(img)
+    assert ex.debug_quadtree_pool_levels() == 1
+    assert ol.kps_equal(got[1], exp[1]) and np.array_equal(got[2], exp[2]) and len(got[1]) > 7000
     sparse = synth.sparse_corners(752, 480, seed=4, ncorner=60)          # (34 noise images would take the emulator a minute)
     got = ex.extract_batch(np.stack([sparse] * 33 + [img]))             # > ORBX_QT_WIDE_BATCH images: 16-byte counters
+    assert ex.debug_quadtree_pool_levels() == 0
     for g, im in ((got[0], sparse), (got[33], img)):
-        exp = ol.OracleExtractor(8000).extract(im)
-        assert ol.kps_equal(g[1], exp[1]) and np.array_equal(g[2], exp[2])
-    assert len(got[33][1]) > 7000
-    ok = ORBextractor(7800, 1.2, 8, 20, 7, lib=emu_lib)(img)
+        e2 = ol.OracleExtractor(8000).extract(im)
+        assert ol.kps_equal(g[1], e2[1]) and np.array_equal(g[2], e2[2])
+    ex2 = ORBextractor(7800, 1.2, 8, 20, 7, lib=emu_lib)
+    ok = ex2(img)
     exp = ol.OracleExtractor(7800).extract(img)
-    assert ol.kps_equal(ok[1], exp[1]) and np.array_equal(ok[2], exp[2])
+    assert ex2.debug_quadtree_pool_levels() == 0 and ol.kps_equal(ok[1], exp[1]) and np.array_equal(ok[2], exp[2])
 
