@@ -21,6 +21,7 @@
 #ifndef ORB_SLAM3_AMD_ORBMATCHER_H
 #define ORB_SLAM3_AMD_ORBMATCHER_H
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -73,7 +74,7 @@ public:
             const Tag tag = {(long long)pKF->mnId, (long long)pKF->N, (long long)pKF->mFeatVec.size(), Fingerprint(pKF)};
             auto it = m.find(pKF);
             if (it != m.end()) {
-                if (it->second.tag == tag) return it->second.dev;
+                if (it->second.tag == tag) { it->second.stamp = ++clock; return it->second.dev; }
                 orbm_keyframe_destroy(it->second.dev); m.erase(it);
             }
             if (transient) { orbm_keyframe_destroy(transient); transient = nullptr; }
@@ -85,19 +86,35 @@ public:
                 Check(orbm_keyframe_create(SharedHandle(), &k.v, &r));
             }
             if (pKF->N > 0 && pKF->mFeatVec.empty()) { transient = r; return r; }
-            Entry e; e.dev = r; e.tag = tag;
+            Entry e; e.dev = r; e.tag = tag; e.stamp = ++clock;
             m[pKF] = e;
             return r;
         }
         void Erase(KeyFrameT* pKF) { auto it = m.find(pKF); if (it != m.end()) { orbm_keyframe_destroy(it->second.dev); m.erase(it); } }
         void Clear() { for (auto& e : m) orbm_keyframe_destroy(e.second.dev); m.clear(); if (transient) { orbm_keyframe_destroy(transient); transient = nullptr; } }
         size_t size() const { return m.size(); }
+        // Bound on the number of resident key frames (0 = none, the default of an explicit cache whose owner calls Erase).  Trim() - called by the
+        // searches BEFORE they collect the key frames of a call, never while device objects of the call are in use - drops the least recently
+        // used entries down to the bound; one call may exceed it by the key frames it names.
+        void SetCapacity(size_t n) { capacity = n; }
+        size_t Capacity() const { return capacity; }
+        void Trim()
+        {
+            if (capacity == 0 || m.size() <= capacity) return;
+            std::vector<std::pair<unsigned long long, KeyFrameT*> > byAge;
+            byAge.reserve(m.size());
+            for (auto& e : m) byAge.push_back(std::make_pair(e.second.stamp, e.first));
+            const size_t drop = m.size() - capacity + capacity / 8;            // a little below the bound: not one eviction per insertion
+            std::nth_element(byAge.begin(), byAge.begin() + (drop < byAge.size() ? drop : byAge.size() - 1), byAge.end());
+            for (size_t i = 0; i < drop && i < byAge.size(); i++) Erase(byAge[i].second);
+        }
     private:
         ResidentKeyFrames(const ResidentKeyFrames&);
         ResidentKeyFrames& operator=(const ResidentKeyFrames&);
         struct Tag { long long id, n, nodes; unsigned long long print; bool operator==(const Tag& o) const { return id == o.id && n == o.n && nodes == o.nodes && print == o.print; } };
         // eight descriptor rows spread over the key frame, folded into 64 bits: tells apart two key frames that reuse an address AND an id (a second SLAM
-        // system in the process, a test that builds world after world); 256 bytes read per lookup
+        // system in the process, a test that builds world after world); 256 bytes read per lookup.  Like every search of the reference it reads
+        // mDescriptors without a lock: the matrix is written once, by the Frame the key frame is made from, before the key frame is published.
         static unsigned long long Fingerprint(KeyFrameT* pKF)
         {
             unsigned long long f = 0x9E3779B97F4A7C15ull;
@@ -109,23 +126,31 @@ public:
             }
             return f;
         }
-        struct Entry { orbm_keyframe* dev; Tag tag; };
+        struct Entry { orbm_keyframe* dev; Tag tag; unsigned long long stamp; };
         std::map<KeyFrameT*, Entry> m;
         orbm_keyframe* transient = nullptr;
         int device = -1;
+        size_t capacity = 0;
+        unsigned long long clock = 0;
     };
     // The cache behind the reference's own single-call signatures (SearchByBoW(pKF, F, ...) of Tracking.cc:3183 / :4371, SearchForTriangulation(pKF1, pKF2, ...)
     // of LocalMapping.cc:610): one per calling thread and key-frame type, so an unchanged call site pays the upload of a key frame once, not per call.
-    // Nothing tells it when the map erases a key frame (an unchanged caller has no Erase to call), so it is bounded instead: beyond
-    // kImplicitCacheEntries key frames it is emptied and refills on demand (a key frame is ~64 B per keypoint + its FeatureVector on the device).
-    enum { kImplicitCacheEntries = 4096 };
+    // An unchanged caller has no Erase to call when the map drops a key frame, so this cache is bounded: at most kImplicitCacheEntries key frames
+    // (about the covisibility window LocalMapping and Tracking revisit) stay resident per thread, least recently used first out - ~130 KB each at
+    // 2 000 keypoints (64 B per keypoint + the FeatureVector), i.e. <= 33 MB of device memory per thread and key-frame type.  A host that edits
+    // Map::EraseKeyFrame anyway can release an entry at once: ORBmatcher::EraseImplicit(pKF) on the thread that searched it (or on every thread:
+    // an entry of a deleted key frame is never matched again - the tag of a new key frame at the same address differs - and ages out).
+    enum { kImplicitCacheEntries = 256 };
     template <class KeyFrameT>
     static ResidentKeyFrames<KeyFrameT>& ImplicitCache()
     {
         static thread_local ResidentKeyFrames<KeyFrameT> c;
-        if (c.size() > (size_t)kImplicitCacheEntries) c.Clear();
+        if (c.Capacity() == 0) c.SetCapacity((size_t)kImplicitCacheEntries);
         return c;
     }
+    template <class KeyFrameT> static void EraseImplicit(KeyFrameT* pKF) { ImplicitCache<KeyFrameT>().Erase(pKF); }
+    template <class KeyFrameT> static void ClearImplicit() { ImplicitCache<KeyFrameT>().Clear(); }
+    template <class KeyFrameT> static void SetImplicitCapacity(size_t n) { ImplicitCache<KeyFrameT>().SetCapacity(n ? n : 1); }
 
     // Computes the Hamming distance between two ORB descriptors (src/ORBmatcher.cc:2383).
     static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b)
@@ -346,6 +371,7 @@ public:
         std::vector<int> counts(n, 0);
         if (n == 0) return counts;
         if (F.Nleft != -1) throw std::runtime_error("ORBmatcher (HIP): the batched SearchByBoW covers frames of one camera");
+        cache.Trim();
         BowStore kf; FillBow(F, F.N, kf);
         orbm_keyframe* rf = nullptr;
         std::vector<orbm_keyframe*> k1(n), k2(n);
@@ -496,6 +522,7 @@ public:
         vvMatchedPairs.assign(n2, std::vector<std::pair<size_t, size_t> >());
         std::vector<int> counts(n2, 0);
         if (n2 == 0 || N1 == 0) return counts;
+        cache.Trim();
         const bool fisheye = pKF1->mpCamera->GetType() == 1 /* GeometricCamera::CAM_FISHEYE */;
         std::vector<float> f12s((size_t)n2 * 9), eps((size_t)n2 * 2);
         std::vector<OrbmKB8Pair> kbs(fisheye ? n2 : 0);

@@ -213,9 +213,9 @@ int orbx_debug_quadtree_profile(orbx_extractor* h, long long out[16]);   /* phas
 int orbx_debug_quadtree_lds_nodes(orbx_extractor* h, int max_nodes);
 int orbx_debug_quadtree_pool_levels(orbx_extractor* h);                   /* number of levels (0 .. n-1) the last extraction ran in the pool form */
 /* test hook: the byte / packed-16-bit instruction wrappers of the kernels (csrc/orbx_simd.h) applied to n operand triples (n a multiple of 256);
- * out = 20 x n results in the order mul24, mul24 (forced), v_perm_b32, v_alignbyte_b32, v_dot4_u32_u8, v_dot2_u32_u16, packed max3, packed min3,
+ * out = 22 x n results in the order mul24, mul24 (forced), v_perm_b32, v_alignbyte_b32, v_dot4_u32_u8, v_dot2_u32_u16, packed max3, packed min3,
  * packed sub, packed xor(a, c), wave inclusive scan / wave sum of a & 0xFFFF, wave minimum of b (per 64 consecutive elements), v_sad_u8, v_mul_u32_u24,
- * the 64-bit wave scan (two words), the 64-bit workgroup scan (two words), the wave OR */
+ * the 64-bit wave scan (two words), the 64-bit workgroup scan (two words), the wave OR, v_mul_hi_u32_u24, v_add3_u32 */
 int orbx_debug_simd_selftest(orbx_extractor* h, const uint32_t* a, const uint32_t* b, const uint32_t* c, int n, uint32_t* out);
 /* what the library holds at this moment, process-wide: out = { device allocations, page-locked host allocations, streams, events }.  The lifetime
  * tests create, use and destroy every kind of handle (extractor, key frames, map points, vocabulary, communicator, caller buffers) and expect the

@@ -21,9 +21,15 @@
 
 namespace ORB_SLAM3 {
 namespace IMU {
+#ifdef ORBX_LOCALMAPPING_WORLD     // (localmapping_world.h: the members LocalMapping.cc names, declared only)
+struct Bias { float bax = 0, bay = 0, baz = 0, bwx = 0, bwy = 0, bwz = 0; Bias() {} Bias(float, float, float, float, float, float); };
+struct Calib { Sophus::SE3f mTcb, mTbc; bool mbIsSet = false; };
+struct Preintegrated { void SetNewBias(const Bias&) {} void CopyFrom(Preintegrated*) {} void MergePrevious(Preintegrated*); Eigen::Vector3f GetUpdatedDeltaVelocity(); float dT; };
+#else
 struct Bias { float bax = 0, bay = 0, baz = 0, bwx = 0, bwy = 0, bwz = 0; };
 struct Calib { Sophus::SE3f mTcb, mTbc; bool mbIsSet = false; };
 struct Preintegrated { void SetNewBias(const Bias&) {} void CopyFrom(Preintegrated*) {} };
+#endif
 }
 class ConstraintPoseImu {};
 class Converter {

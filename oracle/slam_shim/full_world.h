@@ -31,6 +31,13 @@ public:
     bool isImuInitialized() { return false; }
     void EraseMapPoint(MapPoint*) {}
     void EraseKeyFrame(KeyFrame*) {}
+#ifdef ORBX_LOCALMAPPING_WORLD     // (localmapping_world.h: what LocalMapping.cc asks of the map, declared only)
+    bool GetIniertialBA1(); bool GetIniertialBA2(); void SetIniertialBA1(); void SetIniertialBA2(); void SetImuInitialized();
+    void ApplyScaledRotation(const Sophus::SE3f& T, const float s, const bool bScaledVel = false);
+    std::vector<KeyFrame*> GetAllKeyFrames(); std::vector<MapPoint*> GetAllMapPoints(); long unsigned int KeyFramesInMap();
+    void IncreaseChangeIndex(); void InformNewBigChange(); void AddKeyFrame(KeyFrame*); void AddMapPoint(MapPoint*);
+    std::vector<KeyFrame*> mvpKeyFrameOrigins;
+#endif
 };
 class KeyFrameDatabase {
 public:

@@ -37,8 +37,17 @@ struct Vector2f {
     float& operator[](int i) { return d[i]; }
     const float& operator[](int i) const { return d[i]; }
 };
+#ifdef ORBX_LOCALMAPPING_WORLD     // (localmapping_world.h: declarations for the compile check of LocalMapping.cc; nothing of it is linked)
+template <class T> struct LmCastV3;
+template <class T> struct LmCastM3;
+#endif
 struct Vector3f {
     float d[3];
+#ifdef ORBX_LOCALMAPPING_WORLD
+    Vector3f cross(const Vector3f& o) const;
+    Vector3f& operator-=(const Vector3f& o);
+    template <class T> typename LmCastV3<T>::type cast() const;
+#endif
     Vector3f() : d{0, 0, 0} {}
     Vector3f(float x, float y, float z) : d{x, y, z} {}
     float& operator()(int i) { return d[i]; }
@@ -63,6 +72,9 @@ inline Vector3f operator*(const Vector3f& a, float s) { return Vector3f(a.d[0] *
 inline Vector3f operator*(float s, const Vector3f& a) { return a * s; }
 struct Matrix3f {
     float m[3][3];
+#ifdef ORBX_LOCALMAPPING_WORLD
+    template <class T> typename LmCastM3<T>::type cast() const;
+#endif
     Matrix3f() : m{{0, 0, 0}, {0, 0, 0}, {0, 0, 0}} {}
     static Matrix3f Identity() { Matrix3f r; r.m[0][0] = r.m[1][1] = r.m[2][2] = 1.0f; return r; }
     static Matrix3f Zero() { return Matrix3f(); }

@@ -96,6 +96,9 @@ namespace Sophus {
 class SO3f {
     Eigen::Quaternionf unit_quaternion_;
 public:
+#ifdef ORBX_LOCALMAPPING_WORLD     // (localmapping_world.h: declared only)
+    static SO3f exp(const Eigen::Vector3f& omega);
+#endif
     SO3f() : unit_quaternion_(1.0f, 0.0f, 0.0f, 0.0f) {}                                           // so3.hpp:451-452
     SO3f(const Eigen::Matrix3f& R) : unit_quaternion_(R) {}                                        // so3.hpp:469 (SOPHUS_ENSUREs only; no normalisation)
     explicit SO3f(const Eigen::Quaternionf& quat) : unit_quaternion_(quat) { normalize(); }        // so3.hpp:480-487

@@ -11,12 +11,13 @@ namespace orbx {
 // ---------------------------------------------------------------------------------------------------
 // 7x7 Gaussian blur, taps k[7] (symmetric; sum 256 or 257), REFLECT_101,
 //   out = sat((sum_j k_j * (sum_i k_i * p) + 32768) >> 16).
-// Streaming design: a thread owns 4 adjacent columns (one dword) and walks down a strip of kBlurRows rows with the
+// Streaming design: a thread owns 4 adjacent columns (one dword) and walks down a strip of kRows rows with the
 // last 7 horizontal sums in registers, so every input dword is fetched once per strip (+6 halo rows, L1/L2 hits) and
 // every output is one coalesced dword store.  No LDS, no barriers.
 // A tile is 256 columns x 4 strips; one wave owns one strip (tile = index into the tile table in BlurTiles, strip 0..3, lane 0..63).
-static_assert(kBlurRows % 2 == 0, "rows are produced in pairs");
+static_assert(kBlurRows % 2 == 0 && kBlurRowsLarge % 2 == 0, "rows are produced in pairs");
 
+template <int kRows>
 __device__ __forceinline__ void blur_strip(const LevelInfo* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
                                            size_t pyr_stride, const BlurTaps& taps, const BlurTiles& tiles, int tile, int strip, int lane, int b) {
     int level = 0;
@@ -26,7 +27,7 @@ __device__ __forceinline__ void blur_strip(const LevelInfo* __restrict__ lv, int
     const int tcols = (L.w + 255) >> 8;
     const int ty = t / tcols, tx = t - ty * tcols;
     const int x0 = (tx * 64 + lane) * 4;
-    const int ys = ORBX_UNIFORM((ty * 4 + strip) * kBlurRows);      // one strip per wave: the row bookkeeping (reflection, row offsets) is scalar
+    const int ys = ORBX_UNIFORM((ty * 4 + strip) * kRows);      // one strip per wave: the row bookkeeping (reflection, row offsets) is scalar
     if (x0 >= L.w || ys >= L.h) return;
     const BufRsrc src = buf_make(pyr + (size_t)b * pyr_stride + L.off);
     const BufRsrc dst = buf_make(blur + (size_t)b * pyr_stride + L.off);
@@ -73,7 +74,7 @@ __device__ __forceinline__ void blur_strip(const LevelInfo* __restrict__ lv, int
 #pragma unroll
     for (int i = 0; i < 4; i++) { Q[i][0] = Q[i][1] = Q[i][2] = Q[i][3] = 0u; }
 #pragma unroll
-    for (int m = 0; m < (kBlurRows + 6) / 2; m++) {
+    for (int m = 0; m < (kRows + 6) / 2; m++) {
         const int yo = ys + 2 * (m - 3);                // first of the two output rows completed by this pair of input rows
         if (m >= 3 && yo >= L.h) break;
         uint32_t Hr[2][4];

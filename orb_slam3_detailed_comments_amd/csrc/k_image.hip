@@ -268,6 +268,7 @@ __global__ void __launch_bounds__(kPyrThreads) k_pyramid_fused(const LevelInfo* 
 __global__ void __launch_bounds__(256) k_resize_rows(const LevelInfo* __restrict__ lv, int level,
                                                      const ResizeTap* __restrict__ xtab, const ResizeTap* __restrict__ ytab,
                                                      uint8_t* __restrict__ pyr, size_t pyr_stride, int strip_rows) {
+    ORBX_SETPRIO(ORBX_PRIO_RESIZE);
     const LevelInfo D = lv[level];
     const LevelInfo S = lv[level - 1];
     const int b = (int)blockIdx.z;
@@ -307,21 +308,20 @@ __global__ void __launch_bounds__(256) k_resize_rows(const LevelInfo* __restrict
     // horizontal pass of one source row
     auto hrow = [&](const u32x2& w, uint32_t* H) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) H[k] = dot2_u16(byte_perm(w.hi, w.lo, sel[k]), wgt[k], 0u) >> 4;
+        for (int k = 0; k < 4; k++) H[k] = dot2_u16(byte_perm(w.hi, w.lo, sel[k]), wgt[k], 0u) & ~15u;      // (S >> 4) << 4: the vertical pass multiplies by 2^12 * beta and keeps bits 32.. of the product
     };
     // the output rows whose second source row is r (Hc), the first one being the row before (Hp) or the same row
     auto emit = [&](int r, const uint32_t* Hp, const uint32_t* Hc) {
         while (dy < ye && imin(imax(ty.ofs + 1, 0), S.h - 1) == r) {
             const bool same = imin(imax(ty.ofs, 0), S.h - 1) == r;             // both taps on this row (border clamp)
-            const int b0 = (int)(int16_t)(ty.w & 0xFFFF), b1 = ty.w >> 16;
-            uint32_t out = 0;
+            // cv::resize: ((beta0 * (S0 >> 4)) >> 16) + ((beta1 * (S1 >> 4)) >> 16) + 2) >> 2 with 0 <= beta <= 2048 and S <= 255 * 2048.  H holds (S >> 4) << 4 <
+            // 2^19 and the weights are scaled by 2^12 (< 2^24, scalar registers): (beta * (S >> 4)) >> 16 is then bits 32.. of a 24 x 24-bit product, one
+            // v_mul_hi_u32_u24 per term; the sum cannot exceed 4 * 255 + 3, so two sums share a register and one byte-permute cuts the four results out
+            const uint32_t b0 = (uint32_t)(ty.w & 0xFFFF) << 12, b1 = (uint32_t)(ty.w >> 16) << 12;
+            uint32_t s[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                // every factor is below 2^23 and every product below 2^31: 24-bit multiplies.  The result cannot exceed 255 (weights sum to
-                // 2048 +- 1), so no clamp
-                const int v = ((mul24_forced(b0, (int)(same ? Hc[k] : Hp[k])) >> 16) + (mul24_forced(b1, (int)Hc[k]) >> 16) + 2) >> 2;
-                out |= (uint32_t)v << (8 * k);
-            }
+            for (int k = 0; k < 4; k++) s[k] = add3_u32(mulhi_u24_uniform(b0, same ? Hc[k] : Hp[k]), mulhi_u24_uniform(b1, Hc[k]), 2u);
+            const uint32_t out = byte_perm((s[2] | (s[3] << 16)) >> 2, (s[0] | (s[1] << 16)) >> 2, 0x06040200u);
             buf_store_u32(out, dst, (uint32_t)dx0, (uint32_t)(dy * D.pitch));
             dy++;
             if (dy < ye) { ty.ofs = ORBX_READLANE(tyl.ofs, dy - ys); ty.w = ORBX_READLANE(tyl.w, dy - ys); }
@@ -342,7 +342,8 @@ __global__ void __launch_bounds__(256) k_resize_rows(const LevelInfo* __restrict
 // run the kernels on plain-C stand-ins of these instructions; this entry lets the tests compare instruction and stand-in with an independent
 // definition, operand by operand.  ops: 0 mul24, 1 mul24_forced, 2 byte_perm, 3 align_byte, 4 dot4_u8, 5 dot2_u16, 6 pk_max3, 7 pk_min3,
 // 8 pk_sub, 9 pk_xor(a, c), 10 wave_incl_scan, 11 wave_sum (both of a & 0xFFFF), 12 wave_min_u32(b), 13 sad4_u8, 14 __umul24,
-// 15 / 16 wave_incl_scan of a 64-bit value (low / high word), 17 / 18 block_excl_scan_n of it + 2 x total, 19 wave_or_u32 (kSimdSelftestOps in all).
+// 15 / 16 wave_incl_scan of a 64-bit value (low / high word), 17 / 18 block_excl_scan_n of it + 2 x total, 19 wave_or_u32, 20 mulhi_u24, 21 add3_u32
+// (kSimdSelftestOps in all).
 __global__ void __launch_bounds__(256) k_simd_selftest(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ c, int n,
                                                        uint32_t* __restrict__ out) {
     const int i = (int)(blockIdx.x * 256 + threadIdx.x);
@@ -375,6 +376,8 @@ __global__ void __launch_bounds__(256) k_simd_selftest(const uint32_t* __restric
     const unsigned long long bs = block_excl_scan_n<unsigned long long>(f, &tot, s_scan, 4) + (tot << 1);      // (the total goes in as well)
     out[17 * (size_t)n + i] = (uint32_t)bs; out[18 * (size_t)n + i] = (uint32_t)(bs >> 32);
     out[19 * (size_t)n + i] = wave_or_u32((y & 7u) == 0u ? 1u << (x & 31u) : 0u);
+    out[20 * (size_t)n + i] = mulhi_u24(x, y);
+    out[21 * (size_t)n + i] = add3_u32(x, y, z);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -382,7 +385,15 @@ __global__ void __launch_bounds__(256) k_simd_selftest(const uint32_t* __restric
 __global__ void __launch_bounds__(256) k_blur(const LevelInfo* __restrict__ lv, int nlevels,
                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
                                               size_t pyr_stride, BlurTaps taps, BlurTiles tiles) {
-    blur_strip(lv, nlevels, pyr, blur, pyr_stride, taps, tiles, (int)blockIdx.x, (int)threadIdx.y, (int)threadIdx.x, (int)blockIdx.y);
+    ORBX_SETPRIO(ORBX_PRIO_BLUR);
+    blur_strip<kBlurRows>(lv, nlevels, pyr, blur, pyr_stride, taps, tiles, (int)blockIdx.x, (int)threadIdx.y, (int)threadIdx.x, (int)blockIdx.y);
+}
+// the same with strips of kBlurRowsLarge rows (large batches; the tile table counts tiles of 4 x kBlurRowsLarge rows)
+__global__ void __launch_bounds__(256) k_blur_large(const LevelInfo* __restrict__ lv, int nlevels,
+                                                    const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
+                                                    size_t pyr_stride, BlurTaps taps, BlurTiles tiles) {
+    ORBX_SETPRIO(ORBX_PRIO_BLUR);
+    blur_strip<kBlurRowsLarge>(lv, nlevels, pyr, blur, pyr_stride, taps, tiles, (int)blockIdx.x, (int)threadIdx.y, (int)threadIdx.x, (int)blockIdx.y);
 }
 
 }  // namespace orbx

@@ -74,8 +74,12 @@ ORBX_HD inline void eigen_jacobi_svd4_null(const float A[16], float x[4]) {
         for (int j = 0; j < 4; j++) { W[i][j] = A[4 * i + j] / scale; V[i][j] = i == j ? 1.f : 0.f; }
     float maxDiagEntry = fmaxf(fmaxf(fabsf(W[0][0]), fabsf(W[1][1])), fmaxf(fabsf(W[2][2]), fabsf(W[3][3])));
     const float precision = 2.f * FLT_EPSILON, considerAsZero = FLT_MIN;
+    // Eigen sweeps until nothing is left above the threshold, without a limit; so does this model - up to 64 sweeps (a convergent input takes 3 to 6, so
+    // the cap never changes a result; it keeps a workgroup of a device kernel from spinning forever on an input whose fp32 rotations stop making
+    // progress: the pair is then triangulated from the current V like Eigen's would be if it were stopped there, and fails the reference's own
+    // parallax / depth / reprojection gates or not on its merits)
     bool finished = false;
-    while (!finished) {
+    for (int sweep = 0; sweep < 64 && !finished; sweep++) {
         finished = true;
 #pragma unroll
         for (int p = 1; p < 4; p++)

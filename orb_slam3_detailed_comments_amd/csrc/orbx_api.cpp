@@ -392,13 +392,16 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
         static const int A[7] = {18, 34, 48, 56, 48, 34, 18}, Bt[7] = {18, 34, 49, 55, 49, 34, 18};
         for (int i = 0; i < 7; i++) taps.k[i] = h->gauss_variant == 1 ? Bt[i] : A[i];
     }
+    // strips of 16 rows for small batches (more waves; the fused blur + FAST launch), of 32 rows for large ones (fewer halo rows)
+    const bool blur_large = B > ORBX_QT_WIDE_BATCH;
+    const int blur_rows = blur_large ? kBlurRowsLarge : kBlurRows;
     BlurTiles tiles; int nt = 0;
-    for (int l = 0; l < nl; l++) { tiles.begin[l] = nt; nt += ((h->lv[l].w + 255) / 256) * ((h->lv[l].h + 4 * kBlurRows - 1) / (4 * kBlurRows)); }
+    for (int l = 0; l < nl; l++) { tiles.begin[l] = nt; nt += ((h->lv[l].w + 255) / 256) * ((h->lv[l].h + 4 * blur_rows - 1) / (4 * blur_rows)); }
     for (int l = nl; l <= kMaxLevels; l++) tiles.begin[l] = nt;
     const int fast_blocks = (h->ncells + 8 * kFastXcdRun - 1) / (8 * kFastXcdRun) * (8 * kFastXcdRun);   // whole XCD runs (k_fast_cells)
     // pad | window tile | score tile | u16 list: corners found so far + pending survivors of the quick test (scored whenever it fills up)
     const int list_bytes = ORBX_FAST_LIST_BYTES;
-    const size_t fast_smem = 16 + (size_t)h->fast_tile_bytes + (size_t)h->fast_inner_bytes + (size_t)list_bytes + 64;
+    const size_t fast_smem = 16 + (size_t)h->fast_tile_bytes + (size_t)h->fast_inner_bytes + (size_t)list_bytes + 64 + (kFastHTile ? (size_t)h->fast_tile_bytes : 0);
     const dim3 blkf(kFastThreadsDecl, 1, 1);
     // small batches: blur and FAST in one launch on one stream (k_fast_cells_blur: no fork / join).  The stage timers of the profiling modes keep
     // the two apart, so those run the large-batch form
@@ -417,7 +420,8 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
         stage_begin(h, ST_BLUR, sb);
         {
             dim3 grid(nt, B, 1);
-            ORBX_LAUNCH(k_blur, grid, blk2, 0, sb, (const LevelInfo*)h->d_lv.p, nl, (const uint8_t*)h->d_pyr.p, h->d_blur.p, h->pyr_stride, taps, tiles);
+            if (blur_large) ORBX_LAUNCH(k_blur_large, grid, blk2, 0, sb, (const LevelInfo*)h->d_lv.p, nl, (const uint8_t*)h->d_pyr.p, h->d_blur.p, h->pyr_stride, taps, tiles);
+            else ORBX_LAUNCH(k_blur, grid, blk2, 0, sb, (const LevelInfo*)h->d_lv.p, nl, (const uint8_t*)h->d_pyr.p, h->d_blur.p, h->pyr_stride, taps, tiles);
         }
         stage_end(h, ST_BLUR, sb);
         rt::event_record(h->ev_join, sb);
@@ -772,7 +776,7 @@ int orbx_debug_quadtree_profile(orbx_extractor* h, long long out[16]) {
     return ORBX_OK;
 }
 
-// debug: the instruction wrappers of csrc/orbx_simd.h applied to n operand triples; out: kSimdSelftestOps (20) x n results (see k_simd_selftest)
+// debug: the instruction wrappers of csrc/orbx_simd.h applied to n operand triples; out: kSimdSelftestOps (22) x n results (see k_simd_selftest)
 int orbx_debug_simd_selftest(orbx_extractor* h, const uint32_t* a, const uint32_t* b, const uint32_t* c, int n, uint32_t* out) {
     if (!h || !a || !b || !c || !out || n <= 0 || (n & 255)) return fail(ORBX_E_ARG, "bad arguments (n must be a positive multiple of 256)");
     rt::set_device(h->device);

@@ -29,20 +29,34 @@ __global__ void k_pyramid_fused(const LevelInfo* __restrict__ lv, int nlevels, c
 #endif
 constexpr int kFastXcdRun = ORBX_FAST_XCD_RUN;   // neighbouring FAST cells kept on one XCD (k_fast_cells)
 constexpr int kFastThreadsDecl = 64;   // must equal kFastThreads in k_fast.hip
+#ifndef ORBX_FAST_HTILE
+#define ORBX_FAST_HTILE 0
+#endif
+// k_fast_cells keeps a second copy of the window tile in the "H form" of its quick test ((p >> 1) | 0x80 per byte), written once by the load phase: the
+// test then reads its nine ring dwords ready-made instead of converting them in every trip (18 of its ~67 vector instructions); costs tile_bytes of LDS per wave
+constexpr bool kFastHTile = ORBX_FAST_HTILE != 0;
 constexpr int kFastPitch = 48;         // LDS pitch of the FAST window tile for cells whose dword-aligned window fits in it (cells up to 39 px wide)
 __global__ void k_fast_cells(const LevelInfo* __restrict__ lv, const CellInfo* __restrict__ cells, int ncells,
                              const uint8_t* __restrict__ pyr, size_t pyr_stride, int iniTh, int minTh,
                              uint32_t* __restrict__ slots, size_t slots_stride, int* __restrict__ cell_count,
                              int tile_bytes, int list_bytes, int* __restrict__ status);
 constexpr int kResizeRows = 8;         // output rows per k_resize tile (256 columns wide)
+// Output rows per k_blur wave (a block covers 256 columns x 4 strips of that many rows).  A strip reads 6 halo rows on top of its own: large batches
+// run strips of 32 rows (the horizontal pass of 38 input rows per 32 outputs instead of 22 per 16: +1.0 % on the headline, profiles/r06/ab_experiments.txt),
+// small batches - where the number of waves in flight is what counts, and the blur shares its launch with the FAST cells - strips of 16.
 #ifndef ORBX_BLUR_ROWS
 #define ORBX_BLUR_ROWS 16
 #endif
-constexpr int kBlurRows = ORBX_BLUR_ROWS;   // output rows per k_blur thread (a block covers 256 columns x 4 * kBlurRows rows)
-constexpr int kSimdSelftestOps = 20;
+#ifndef ORBX_BLUR_ROWS_LARGE
+#define ORBX_BLUR_ROWS_LARGE 32
+#endif
+constexpr int kBlurRows = ORBX_BLUR_ROWS, kBlurRowsLarge = ORBX_BLUR_ROWS_LARGE;
+constexpr int kSimdSelftestOps = 22;
 __global__ void k_simd_selftest(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ c, int n, uint32_t* __restrict__ out);
 __global__ void k_blur(const LevelInfo* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,
                        uint8_t* __restrict__ blur, size_t pyr_stride, BlurTaps taps, BlurTiles tiles);
+__global__ void k_blur_large(const LevelInfo* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,
+                             uint8_t* __restrict__ blur, size_t pyr_stride, BlurTaps taps, BlurTiles tiles);     // strips of kBlurRowsLarge rows
 constexpr int kQuadtreeThreads = 1024; // workgroup size of k_quadtree; a level uses its first LevelInfo::qt_threads threads
 // small batches: the blur strips and the FAST cells of an image in one launch (k_fast.hip)
 __global__ void k_fast_cells_blur(const LevelInfo* __restrict__ lv, const CellInfo* __restrict__ cells, int ncells,

@@ -20,6 +20,31 @@ __device__ __forceinline__ int mul24_forced(int a, int b) {
     int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
 #endif
 }
+// v_mul_hi_u32_u24: bits 32..47 of the product of the low 24 bits of both operands.  (x * y) >> 16 for x < 2^a, y < 2^b is mulhi_u24(x << (24 - a), y << (24 - b))
+// when a + b <= 32: one instruction for the "multiply, keep the high part" of cv::resize's vertical pass
+__device__ __forceinline__ uint32_t mulhi_u24(uint32_t a, uint32_t b) {
+#ifdef ORBX_EMU
+    return (uint32_t)(((unsigned long long)(a & 0xFFFFFFu) * (unsigned long long)(b & 0xFFFFFFu)) >> 32);
+#else
+    uint32_t r; asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+#endif
+}
+// the same with a wave-uniform first factor (a scalar register as src0 of the VOP2 form: no copy into a vector register)
+__device__ __forceinline__ uint32_t mulhi_u24_uniform(uint32_t uniform_a, uint32_t b) {
+#ifdef ORBX_EMU
+    return (uint32_t)(((unsigned long long)(uniform_a & 0xFFFFFFu) * (unsigned long long)(b & 0xFFFFFFu)) >> 32);
+#else
+    uint32_t r; asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "s"(uniform_a), "v"(b)); return r;
+#endif
+}
+// v_add3_u32
+__device__ __forceinline__ uint32_t add3_u32(uint32_t a, uint32_t b, uint32_t c) {
+#ifdef ORBX_EMU
+    return a + b + c;
+#else
+    uint32_t r; asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+#endif
+}
 // ---------------------------------------------------------------------------------------------------
 // Small CDNA byte / packed-16-bit helpers (with plain-C equivalents for the test emulator).
 // byte permute (v_perm_b32): result byte i = byte sel_i (0..7) of the 8-byte pair {hi:lo}; selector 0x0c gives 0x00

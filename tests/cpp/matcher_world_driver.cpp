@@ -362,6 +362,39 @@ int mw_implicit_cache_probe(void* wv, int kf1, int kf2) {
     return 0;
 #endif
 }
+// The implicit cache is bounded, least recently used first out (an unchanged caller never tells it that the map erased a key frame): with room for ONE key
+// frame the single-call search over (A, B), (B, A), (A, B) keeps at most the two key frames of the running call resident, gives what a fresh cache gives, and
+// EraseImplicit releases an entry at once.  0 = all of that holds; the reference build has no cache: 0.
+int mw_implicit_cache_lru_probe(void* wv, int kf1, int kf2) {
+#ifdef MW_FACADE
+    World* w = (World*)wv;
+    KeyFrame *A = w->kfs[kf1].get(), *B = w->kfs[kf2].get();
+    ORBmatcher m(0.6f, true);
+    std::vector<std::pair<size_t, size_t>> fresh_ab, fresh_ba, p;
+    ORBmatcher::ClearImplicit<KeyFrame>();
+    m.SearchForTriangulation(A, B, fresh_ab, false);
+    ORBmatcher::ClearImplicit<KeyFrame>();
+    m.SearchForTriangulation(B, A, fresh_ba, false);
+    ORBmatcher::ClearImplicit<KeyFrame>();
+    ORBmatcher::SetImplicitCapacity<KeyFrame>(1);
+    int rc = 0;
+    for (int round = 0; round < 3 && rc == 0; round++) {
+        const bool ab = round != 1;
+        m.SearchForTriangulation(ab ? A : B, ab ? B : A, p, false);
+        if (p != (ab ? fresh_ab : fresh_ba)) rc = 1;
+        if (ORBmatcher::ImplicitCache<KeyFrame>().size() > 2) rc = 2;
+    }
+    ORBmatcher::EraseImplicit(A);
+    if (rc == 0 && ORBmatcher::ImplicitCache<KeyFrame>().size() != 1) rc = 3;
+    ORBmatcher::EraseImplicit(B);
+    if (rc == 0 && ORBmatcher::ImplicitCache<KeyFrame>().size() != 0) rc = 4;
+    ORBmatcher::SetImplicitCapacity<KeyFrame>(ORBmatcher::kImplicitCacheEntries);
+    return rc;
+#else
+    (void)wv; (void)kf1; (void)kf2;
+    return 0;
+#endif
+}
 // the same against n2 neighbours: the facade's one-call form over device-resident key frames, the reference's method once per neighbour.
 // pairs: n2 blocks of cap (idx1, idx2) pairs; n_pairs / nmatches: n2 entries.  `rounds` repeats the call (the facade's cache is reused).
 int mw_search_for_triangulation_neighbours(void* wv, int kf1, int n2, const int* kf2s, int only_stereo, int coarse, int* pairs, int cap, int* n_pairs, int* nmatches,

@@ -280,6 +280,8 @@ def build_and_run(drv, seed, variant):
     out["triang_noori"] = np.concatenate([[n, npairs.value], pairs])
     if hasattr(L, "mw_implicit_cache_probe"):                # the facade's implicit resident cache must notice a key frame whose content changed in place
         out["implicit_cache_probe"] = np.array([L.mw_implicit_cache_probe(drv.w, kA, kB)], np.int32)
+    if hasattr(L, "mw_implicit_cache_lru_probe"):            # ... and is bounded: least recently used out, EraseImplicit releases at once
+        out["implicit_cache_lru_probe"] = np.array([L.mw_implicit_cache_lru_probe(drv.w, kA, kB)], np.int32)
 
     # the same against several neighbours: the facade answers them in one call over device-resident key frames (twice: the second round
     # reuses the cached uploads), the reference is called once per neighbour

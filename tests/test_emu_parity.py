@@ -333,6 +333,35 @@ def test_pyramid_one_launch_gpu(hip_lib):
     _pyramid_modes_case(hip_lib, [(752, 480, 1.2, 8, 2), (301, 277, 1.2, 8, 3), (644, 400, 2.0, 3, 1), (1241, 376, 1.2, 8, 1), (1001, 841, 1.2, 11, 1), (263, 251, 1.5, 2, 5), (1920, 1080, 1.2, 8, 1)])
 
 
+def _blur_strip_rows_case(lib, shapes):
+    """batches above 32 images blur strips of 32 rows (k_blur_large), smaller ones strips of 16 (k_blur / the fused launch): the blurred pyramids of the same
+    image must be byte-equal in both and equal to the oracle's - heights that leave partial strips and partial row pairs, widths with partial dwords,
+    both OpenCV tap generations"""
+    for (w, h, gv) in shapes:
+        img = synth.pink_noise(w, h, seed=w + h)
+        other = synth.sparse_corners(w, h, seed=5, ncorner=30)
+        o = ol.OracleExtractor(300, 1.2, 8, 20, 7, gv)
+        o.extract(img)
+        ex = ORBextractor(300, 1.2, 8, 20, 7, lib=lib)
+        ex.set_gaussian_taps(gv)
+        ex.extract_batch(np.stack([other] * 32 + [img]))             # 33 images: 32-row strips; the image under test is the last one
+        large = [ex.pyramid_level(l, 32, blurred=True) for l in range(8)]
+        ex(img)
+        for l in range(8):
+            exp = o.level_image(l, blurred=True)
+            assert np.array_equal(large[l], exp), "32-row strips, level %d of %dx%d" % (l, w, h)
+            assert np.array_equal(ex.pyramid_level(l, blurred=True), exp), "16-row strips, level %d of %dx%d" % (l, w, h)
+
+
+def test_blur_strip_rows_emulated(emu_lib):
+    _blur_strip_rows_case(emu_lib, [(301, 277, 0), (376, 240, 1), (333, 257, 0)])
+
+
+@pytest.mark.gpu
+def test_blur_strip_rows_gpu(hip_lib):
+    _blur_strip_rows_case(hip_lib, [(752, 480, 0), (301, 277, 1), (1241, 376, 0), (515, 513, 0)])
+
+
 def _launch_forms_case(lib, shapes):
     """the launch forms of small batches (blur strips + FAST cells in one launch on one stream, no event records inside the chain:
     orbx_set_small_batch_forms) against the large-batch forms of the same kernels on the same images, and against the oracle: blurred pyramid,

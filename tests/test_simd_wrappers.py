@@ -31,7 +31,7 @@ def _operands(rng):
 
 
 def _run(ex, a, b, c):
-    out = np.zeros((20, N), np.uint32)
+    out = np.zeros((22, N), np.uint32)
     a, b, c = (np.ascontiguousarray(x, np.uint32) for x in (a, b, c))
     ex._lib.check(ex._lib.L.orbx_debug_simd_selftest(ex._h, a.ctypes.data, b.ctypes.data, c.ctypes.data, N, out.ctypes.data))
     return out
@@ -72,6 +72,10 @@ def _check(ex):
     assert np.array_equal(out[13], (sad & 0xFFFFFFFF).astype(np.uint32)), "sad4_u8"
     um = ((a & 0xFFFFFF).astype(np.uint64) * (b & 0xFFFFFF).astype(np.uint64)) & np.uint64(0xFFFFFFFF)
     assert np.array_equal(out[14], um.astype(np.uint32)), "umul24"
+    # v_mul_hi_u32_u24: bits 32.. of the product of the low 24 bits; v_add3_u32 (32-bit wrap)
+    uh = ((a & 0xFFFFFF).astype(np.uint64) * (b & 0xFFFFFF).astype(np.uint64)) >> np.uint64(32)
+    assert np.array_equal(out[20], uh.astype(np.uint32)), "mulhi_u24"
+    assert np.array_equal(out[21], ((a.astype(np.uint64) + b.astype(np.uint64) + c.astype(np.uint64)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)), "add3_u32"
     # packed three-input max / min on biased pixel patterns (positive binary16 numbers order like their bit patterns)
     a, b, c = S["pk3"]; out = _run(ex, a, b, c)
     hs = [_halves(x) for x in (a, b, c)]
