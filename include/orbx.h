@@ -150,8 +150,10 @@ int orbx_device_snapshot(orbx_extractor* h, void* desc_dst, void* n_dst);
  * [world][B][cap][32] and n_all [world][B] are device memory of the communicator, valid after orbx_comm_wait and until the next call; every
  * rank must gather blocks of the same shape (same B, same extractor geometry).  orbx_comm_fetch waits and copies them to the host.
  * A call that finds the communicator's previous exchange still in flight does not wait for it on the host: its snapshot is ordered behind that exchange
- * on the device (several handles may share one communicator); consume desc_all / n_all of an exchange before the next call can overwrite them.  After a
- * failed call orbx_comm_fetch refuses (nothing was gathered).
+ * on the device (several handles may share one communicator).  The gathered blocks are double-buffered: what a call returned is written again by the
+ * SECOND call after it, not by the next one, so a consumer of exchange k (on a stream of its own, after orbx_comm_wait) may run beside exchange k + 1;
+ * n_all sits behind desc_all at world * B * cap * 32 bytes - take both pointers from the call, they move when B changes.  After a failed call
+ * orbx_comm_fetch refuses (nothing was gathered).
  * librccl is loaded (dlopen) by the first orbx_comm_* call; hosts that never call them never load it. */
 typedef struct orbx_comm orbx_comm;
 #define ORBX_COMM_ID_BYTES 128            /* sizeof(ncclUniqueId) */

@@ -97,7 +97,8 @@ struct orbx_comm {
     int world = 1, rank = 0, device = 0;
     bool owned = true;                      // created here (destroyed here) or adopted from the host
     rt::stream_t stream{}; rt::event_t ev_snap{}, ev_done{}; bool have_stream = false;
-    DevBuf<uint8_t> snap, all;              // this rank's snapshot [B * cap * 32 | B * 4]; the gathered blocks [world][B * cap * 32] | [world][B * 4]
+    DevBuf<uint8_t> snap, all2[2];          // this rank's snapshot [B * cap * 32 | B * 4]; the gathered blocks [world][B * cap * 32] | [world][B * 4], two of them:
+    int cur = 0;                            // exchanges alternate, so that what exchange k returned stays untouched until exchange k + 2 is enqueued
     int B = 0, cap = 0; size_t desc_bytes = 0; bool pending = false;
 #ifndef ORBX_EMU
     nccl_comm_t nccl = nullptr;
@@ -187,7 +188,7 @@ void orbx_comm_destroy(orbx_comm* c) {
     if (c->nccl && c->owned) rccl().CommDestroy(c->nccl);
 #endif
     if (c->have_stream) { rt::stream_destroy(c->stream); rt::event_destroy(c->ev_snap); rt::event_destroy(c->ev_done); }
-    c->snap.release(); c->all.release();        // (DevBuf has no destructor: found by tests/test_lifetime.py)
+    c->snap.release(); for (auto& x : c->all2) x.release();        // (DevBuf has no destructor: found by tests/test_lifetime.py)
     delete c;
 }
 
@@ -203,18 +204,21 @@ int orbx_allgather_descriptors(orbx_extractor* h, orbx_comm* c, void** desc_all,
     if (c->pending) {
         // the previous exchange still reads the snapshot and writes the gathered blocks: this call's snapshot copies wait for it ON THE DEVICE (the
         // handle's stream waits for ev_done), the host goes on; only a reallocation of the buffers needs the previous exchange to have finished
-        const bool grows = !(c->snap.p && db + nb + 64 <= c->snap.n && c->all.p && W * (db + nb) + 64 <= c->all.n);
+        DevBuf<uint8_t>& nxt = c->all2[c->cur ^ 1];
+        const bool grows = !(c->snap.p && db + nb + 64 <= c->snap.n && nxt.p && W * (db + nb) + 64 <= nxt.n);
         if (grows) { rt::event_sync(c->ev_done); c->pending = false; }
         else if (rt::stream_wait_event(h->s0, c->ev_done)) return fail(ORBX_E_DEVICE, "waiting for the previous exchange failed: %s", rt::last_error());
     }
     c->B = 0;                                                                      // nothing to fetch until this exchange has been enqueued completely
-    if (c->snap.ensure(db + nb + 64) || c->all.ensure(W * (db + nb) + 64)) return fail(ORBX_E_DEVICE, "allocation failed (%zu bytes gathered)", W * (db + nb));
+    c->cur ^= 1;                                                                   // the other gathered block: the previous exchange's result is not written by this one
+    DevBuf<uint8_t>& all = c->all2[c->cur];
+    if (c->snap.ensure(db + nb + 64) || all.ensure(W * (db + nb) + 64)) return fail(ORBX_E_DEVICE, "allocation failed (%zu bytes gathered)", W * (db + nb));
     // snapshot on the HANDLE's stream (behind the extraction that is producing the block), everything after it on the communicator's stream: the handle
     // is free for its next batch as soon as the two copies have run
     if (rt::copy_d2d(c->snap.p, h->d_desc.p, db, h->s0) || rt::copy_d2d(c->snap.p + db, h->d_nm.p, nb, h->s0) || rt::event_record(c->ev_snap, h->s0) ||
         rt::stream_wait_event(c->stream, c->ev_snap))
         return fail(ORBX_E_DEVICE, "snapshot failed: %s", rt::last_error());
-    uint8_t* all_desc = c->all.p; uint8_t* all_n = c->all.p + W * db;
+    uint8_t* all_desc = all.p; uint8_t* all_n = all.p + W * db;
 #ifndef ORBX_EMU
     Rccl& r = rccl();
     int e = r.GroupStart();
@@ -262,8 +266,8 @@ int orbx_comm_fetch(orbx_comm* c, uint8_t* desc_all_host, int* n_all_host) {
     rt::set_device(c->device);
     const size_t W = (size_t)c->world, db = c->desc_bytes, nb = sizeof(int) * (size_t)c->B;
     int e = 0;
-    if (desc_all_host) e |= rt::copy_d2h(desc_all_host, c->all.p, W * db, c->stream);
-    if (n_all_host) e |= rt::copy_d2h(n_all_host, c->all.p + W * db, W * nb, c->stream);
+    if (desc_all_host) e |= rt::copy_d2h(desc_all_host, c->all2[c->cur].p, W * db, c->stream);
+    if (n_all_host) e |= rt::copy_d2h(n_all_host, c->all2[c->cur].p + W * db, W * nb, c->stream);
     if (e || rt::stream_sync(c->stream)) return fail(ORBX_E_DEVICE, "D2H failed: %s", rt::last_error());
     c->pending = false;
     return ORBX_OK;

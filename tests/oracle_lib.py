@@ -617,8 +617,8 @@ class ReferenceRigFrame:
     """The reference's fisheye-rig Frame (src/Frame.cc:1432-1528) kept alive for Frame::isInFrustum (two cameras) and
     ORBmatcher::SearchByProjection(F, points, ...) with its right-camera branch.  cams = (cam1[8], cam2[8], Rlr[3,3], tlr[3])."""
 
-    def __init__(self, left, right, lap_left, lap_right, nfeatures, cams, scale=1.2, nlevels=8, ini=20, mn=7):
-        L = self.L = reference_frame_lib()
+    def __init__(self, left, right, lap_left, lap_right, nfeatures, cams, scale=1.2, nlevels=8, ini=20, mn=7, lib=None):
+        L = self.L = lib or reference_frame_lib()
         left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
         out = np.zeros(4, np.int32)
         cp = np.concatenate([np.asarray(c, np.float32).ravel() for c in cams]).astype(np.float32); assert cp.size == 28
@@ -652,12 +652,18 @@ class ReferenceRigFrame:
         return left, right, assigned[:self.nl + self.nr], n, p
 
 
-def reference_fisheye_frame(left, right, lap_left, lap_right, nfeatures=1500, scale=1.2, nlevels=8, ini=20, mn=7, gauss_variant=0, cams=None):
+def reference_frame_fma_lib():
+    """oracle/_ref/libref_frame_fma.so: the frame driver built as the reference's CMakeLists.txt builds on an FMA host (-O3, AVX2 + FMA, contraction on); None if absent"""
+    p = os.path.join(ORACLE_DIR, "_ref", "libref_frame_fma.so")
+    return _bind_frame_lib(C.CDLL(p)) if os.path.exists(p) else None
+
+
+def reference_fisheye_frame(left, right, lap_left, lap_right, nfeatures=1500, scale=1.2, nlevels=8, ini=20, mn=7, gauss_variant=0, cams=None, lib=None):
     """The reference's fisheye-rig Frame constructor (src/Frame.cc:1432-1528).  cams = (cam1[8], cam2[8], Rlr[3,3], tlr[3]): the gate is the
     reference's own KannalaBrandt8::TriangulateMatches (src/CameraModels/KannalaBrandt8.cpp compiled into libref_frame.so); cams = None: the
     accept-all build (libref_frame_knn.so), whose result is the kNN + ratio decision alone.
     Returns dict(keys, keys_right, desc [Nleft+Nright,32], mono_left, mono_right, l2r, r2l, depth, p3d)."""
-    L = reference_frame_lib() if cams is not None else reference_frame_knn_lib()
+    L = lib or (reference_frame_lib() if cams is not None else reference_frame_knn_lib())
     left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
     out = np.zeros(4, np.int32)
     cp = None
