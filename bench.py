@@ -636,6 +636,8 @@ def main():
                 torch.cuda.synchronize()
             dist_barrier()
 
+    timed_cpu = [0.0]
+
     def timed(nsteps, h2d, min_seconds=0.0):
         """W untimed warm-up steps, then ONE timed region of `repeats` whole blocks of nsteps steps between two barriers (repeats = 1 unless the
         warm-up predicts a region shorter than min_seconds: 20 steps last 30 ms, and four handles' completions bunch differently from run to run).
@@ -663,10 +665,12 @@ def main():
             repeats = int(t.item())
             sync_all()
         del step_end[:]
+        cpu0 = time.process_time()
         t0 = time.perf_counter()
         run(nsteps * repeats, True, h2d)
         sync_all()
         dt = time.perf_counter() - t0
+        timed_cpu[0] = time.process_time() - cpu0           # host CPU seconds (user + system, all threads) this rank spent inside the timed region
         ends = [t0] + list(step_end)
         per = np.diff(np.array(ends)) * 1e3
         return dt, per, repeats
@@ -677,6 +681,7 @@ def main():
     if args.h2d:
         setup_h2d()
     dt, per_step, repeats = timed(args.steps, args.h2d, args.min_seconds)
+    own_cpu_s = timed_cpu[0]
 
     def parity_check(per_handle=4):
         """CHECKER, after the timed region: what the LAST timed step of every handle left in its output buffers - keypoints, descriptors and the
@@ -736,13 +741,17 @@ def main():
             parity = parity_check()
         except Exception as e:
             parity = {"units": 0, "identical": False, "error": repr(e)}
-    per_rank_dt = None
+    per_rank_dt = None; per_rank_cpu = [own_cpu_s]
     if dist is not None:
         import torch
         own = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         every = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
         dist.all_gather(every, own)                 # each rank's own clock over the same barrier-bracketed region: a straggler GPU shows up here
         per_rank_dt = [float(e.item()) for e in every]
+        own = torch.tensor([own_cpu_s], dtype=torch.float64, device=coll_dev)
+        every = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(every, own)
+        per_rank_cpu = [float(e.item()) for e in every]
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -917,6 +926,12 @@ def main():
             "per_rank": None if per_rank_dt is None else {
                 "unit": cfg["unit"], "values": [round(P * args.steps * repeats / t, 1) for t in per_rank_dt],
                 "min": round(P * args.steps * repeats / max(per_rank_dt), 1), "max": round(P * args.steps * repeats / min(per_rank_dt), 1)},
+            # what the host side costs: CPU seconds (user + system, every thread of the rank's process) per step inside the timed region - enqueueing four handles'
+            # launches, waiting for and fetching ~20 MB of pinned results per step; x n ranks must fit the cores the node grants
+            "host_cpu": {"cpu_ms_per_step_per_rank": [round(c / (args.steps * repeats) * 1e3, 4) for c in per_rank_cpu],
+                         "cpu_cores_busy_per_rank": [round(c / max(dt, 1e-9), 3) for c in per_rank_cpu],
+                         "cpu_cores_busy_all_ranks": round(sum(per_rank_cpu) / max(dt, 1e-9), 3),
+                         "cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, "cpu_quota_cores": cpu_quota_cores()},
             "allgather": ag_alone,
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_alone": {k: round(v, 4) for k, v in serial_sum.items()},

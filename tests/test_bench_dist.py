@@ -93,3 +93,38 @@ def test_bench_two_ranks_share_one_gpu(hip_lib):
     assert 0.6 * r1["value"] < r2["value"] < 1.5 * r1["value"], (r1["value"], r2["value"])             # one GPU's worth of work, shared
     pr = r2["per_rank"]
     assert len(pr["values"]) == 2 and pr["min"] > 0.25 * r1["value"], pr                                # nobody starves
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_share_one_gpu_in_16_cores(hip_lib):
+    """Pre-flight of the driver's 8-GPU scaling run under its real host constraints: `bench.py --gpus 8` with the HIP library - eight
+    processes x four handles on GPU 0, confined to 16 cores (what the GPU boxes grant), rendezvous / barriers / max over ranks over gloo - with and without the
+    descriptor all-gather.  The ranks share one GPU, so the whole-job value is about one GPU's; checked: the protocol at world size 8, parity, no rank starves,
+    the host side of eight ranks fits the cores, and the whole command stays far inside the driver's 1 800 s."""
+    import time
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "ORBX_BENCH_LIB"):
+        env.pop(k, None)
+    env.update(ORBX_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    cpus = sorted(os.sched_getaffinity(0))[:16]
+    out = {}
+    for name, extra in (("plain", []), ("allgather", ["--allgather"])):
+        cmd = ["taskset", "-c", ",".join(str(c) for c in cpus), sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--pairs", "32",
+               "--no-cpu-baseline", "--no-h2d", "--no-other-configs", "--no-latency", "--min-seconds", "2"] + extra
+        t0 = time.time()
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=1500)
+        wall = time.time() - t0
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        res = json.loads(lines[0]); res["command_wall_s"] = round(wall, 1); out[name] = res
+        assert res["n_gpus"] == 8 and res["config"]["library"] == "liborbx_hip.so" and res["parity_check"]["identical"] is True
+        pr = res["per_rank"]
+        assert len(pr["values"]) == 8 and pr["min"] > 0.5 * pr["max"], pr                               # nobody starves
+        hc = res["host_cpu"]
+        assert len(hc["cpu_ms_per_step_per_rank"]) == 8 and hc["cpu_cores_busy_all_ranks"] < len(cpus), hc
+        assert wall < 600, wall
+    assert out["allgather"]["allgather"]["backend"] == "gloo" and out["allgather"]["allgather"]["ms_per_batch_alone"] > 0
+    dst = os.path.join(ROOT, "gpurun_out", "bench_n8_one_gpu.json")
+    os.makedirs(os.path.dirname(dst), exist_ok=True)
+    json.dump(out, open(dst, "w"), indent=1)
