@@ -229,6 +229,24 @@ def kernel_sources_sha():
     return hsh.hexdigest()[:16]
 
 
+def thread_cpu_seconds():
+    """CPU seconds (user + system) of every thread of this process, by thread id, with the thread's name: which thread the host cost of a step sits in"""
+    out = {}
+    try:
+        tck = float(os.sysconf("SC_CLK_TCK"))
+        for t in os.listdir("/proc/self/task"):
+            try:
+                st = open("/proc/self/task/%s/stat" % t).read()
+                name = st[st.index("(") + 1:st.rindex(")")]
+                f = st[st.rindex(")") + 2:].split()
+                out[int(t)] = (name, (int(f[11]) + int(f[12])) / tck)
+            except Exception:
+                continue
+    except Exception:
+        pass
+    return out
+
+
 def pcie_links():
     """What sysfs says about the PCIe links of the AMD GPUs of this host (speed, width, NUMA node): the host-fed rate follows the link, and boxes differ."""
     import glob
@@ -369,6 +387,10 @@ def main():
                     "per-kernel averages of rocprofv3 are averages over the timed launches)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the second, PCIe-inclusive measurement (never `value`)")
     ap.add_argument("--h2d", action="store_true", help="make the PCIe-inclusive variant the timed loop (NOT the headline value)")
+    ap.add_argument("--host-wait", choices=["auto", "spin", "block"], default="auto",
+                    help="how the host thread waits for the GPU (orbx_set_host_wait): spin = the HIP default, lowest latency, one core per waiting thread; block = sleep on the "
+                         "completion interrupt. auto = spin for one rank, block for --gpus N > 1, where N ranks share the host's cores (8 ranks x 2 spinning threads on a "
+                         "16-core grant is the whole grant)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not measure roofline.traffic with two short rocprofv3 --pmc passes inside this run (keep the tracked figure); the passes belong to the full "
                     "default line and are also left out with --no-other-configs and under a profiler")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)        # one pair stream of cpu_baseline's all-core setting (internal)
@@ -432,6 +454,9 @@ def main():
     from orb_slam3_detailed_comments_amd import matcher as M
     # ORBX_BENCH_LIB: test switch (tests/test_multi_gloo.py runs this file's distributed path on the CPU emulator build of the kernels)
     lib = _lib.OrbxLib(os.environ["ORBX_BENCH_LIB"]) if os.environ.get("ORBX_BENCH_LIB") else load_hip()
+    host_wait_mode = args.host_wait if args.host_wait != "auto" else ("block" if world > 1 else "spin")
+    if host_wait_mode == "block" and not os.environ.get("ORBX_BENCH_LIB"):
+        lib.check(lib.L.orbx_set_host_wait(local, 1))
     P = args.pairs
     # synthetic inputs shaped like the configuration's dataset; every rank (= camera stream shard) gets its own seeds
     nat = args.workload == "natural"
@@ -665,12 +690,15 @@ def main():
             repeats = int(t.item())
             sync_all()
         del step_end[:]
+        thr0 = thread_cpu_seconds()
         cpu0 = time.process_time()
         t0 = time.perf_counter()
         run(nsteps * repeats, True, h2d)
         sync_all()
         dt = time.perf_counter() - t0
         timed_cpu[0] = time.process_time() - cpu0           # host CPU seconds (user + system, all threads) this rank spent inside the timed region
+        thr1 = thread_cpu_seconds()
+        timed_cpu[1:] = [sorted(((round(thr1[t][1] - thr0.get(t, (None, 0.0))[1], 3), thr1[t][0]) for t in thr1), reverse=True)[:4]]
         ends = [t0] + list(step_end)
         per = np.diff(np.array(ends)) * 1e3
         return dt, per, repeats
@@ -682,6 +710,7 @@ def main():
         setup_h2d()
     dt, per_step, repeats = timed(args.steps, args.h2d, args.min_seconds)
     own_cpu_s = timed_cpu[0]
+    own_threads = timed_cpu[1] if len(timed_cpu) > 1 else None
 
     def parity_check(per_handle=4):
         """CHECKER, after the timed region: what the LAST timed step of every handle left in its output buffers - keypoints, descriptors and the
@@ -931,7 +960,8 @@ def main():
             "host_cpu": {"cpu_ms_per_step_per_rank": [round(c / (args.steps * repeats) * 1e3, 4) for c in per_rank_cpu],
                          "cpu_cores_busy_per_rank": [round(c / max(dt, 1e-9), 3) for c in per_rank_cpu],
                          "cpu_cores_busy_all_ranks": round(sum(per_rank_cpu) / max(dt, 1e-9), 3),
-                         "cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, "cpu_quota_cores": cpu_quota_cores()},
+                         "cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, "cpu_quota_cores": cpu_quota_cores(),
+                         "rank0_busiest_threads_cpu_s": own_threads, "timed_seconds": round(dt, 3), "host_wait": host_wait_mode},
             "allgather": ag_alone,
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_alone": {k: round(v, 4) for k, v in serial_sum.items()},

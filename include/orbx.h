@@ -44,6 +44,11 @@ typedef struct orbx_extractor orbx_extractor;
 
 /* number of usable GPUs (0 if none) */
 int orbx_device_count(void);
+/* How the host threads of this process wait for GPU `device_id` inside the synchronous calls (orbx_extract, orbx_fetch, orbx_sync, the orbm_* searches):
+ * 0 = the HIP runtime's default (the waiting thread spins: lowest latency - one pair per call is 0.127 ms - and one host core per waiting thread),
+ * 1 = blocking (the thread sleeps on the completion interrupt: a wake-up of ~10 - 20 us per wait and no core: what a host that runs one process per GPU on
+ * fewer cores than 2 x GPUs wants - bench.py --gpus N uses it for N > 1), 2 = spin, 3 = yield.  Process-wide per device (hipSetDeviceFlags). */
+int orbx_set_host_wait(int device_id, int mode);
 
 /* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)  include/ORBextractor.h:49-50,
  * src/ORBextractor.cc:468-571.  device_id selects the GPU (one process per GPU in multi-GPU runs).

@@ -26,7 +26,7 @@ SYMBOLS = [
     "orbx_get_levels", "orbx_get_scale_factor", "orbx_get_level_tables", "orbx_max_keypoints",
     "orbx_extract", "orbx_extract_batch", "orbx_set_input", "orbx_fetch", "orbx_sync", "orbx_pyramid_level", "orbx_pyramid_fetch",
     "orbx_device_alloc", "orbx_device_free", "orbx_device_upload", "orbx_device_upload_async", "orbx_set_undistort", "orbx_fetch_undistorted", "orbx_undistorted_bounds", "orbx_input_buffer", "orbx_input_upload", "orbx_device_outputs", "orbx_device_snapshot", "orbx_device_id", "orbx_host_alloc", "orbx_host_free", "orbx_set_graph_replay", "orbx_set_pyramid_mode", "orbx_set_small_batch_forms", "orbx_profile_enable",
-    "orbx_profile_get", "orbx_stage_name", "orbx_debug_candidates", "orbx_debug_level_keys", "orbx_debug_quadtree_profile", "orbx_debug_quadtree_lds_nodes", "orbx_debug_quadtree_pool_levels", "orbx_debug_simd_selftest", "orbx_debug_stereo_flags", "orbx_debug_live_resources",
+    "orbx_profile_get", "orbx_stage_name", "orbx_debug_candidates", "orbx_debug_level_keys", "orbx_debug_quadtree_profile", "orbx_set_host_wait", "orbx_debug_quadtree_lds_nodes", "orbx_debug_quadtree_pool_levels", "orbx_debug_simd_selftest", "orbx_debug_stereo_flags", "orbx_debug_live_resources",
     "orbm_hamming_matrix", "orbm_stereo_match", "orbm_stereo_fetch", "orbm_knn2", "orbm_knn2_fetch", "orbm_stereo_fisheye", "orbm_stereo_fisheye_fetch", "orbm_search_for_triangulation_kb8", "orbm_is_in_frustum", "orbm_is_in_frustum_rig", "orbm_search_local_points_fisheye", "orbm_search_local_points",
     "orbm_get_features_in_area", "orbm_search_by_projection_mappoints", "orbm_search_by_projection_frame",
     "orbm_search_for_triangulation", "orbm_search_by_bow", "orbm_search_by_bow_batch", "orbm_keyframe_create", "orbm_points_create", "orbm_points_destroy", "orbm_search_local_points_resident", "orbm_stereo_from_depth", "orbm_search_local_points_batch", "orbm_search_local_points_fetch", "orbm_search_by_projection_lastframe_batch", "orbm_search_by_projection_keyframe_batch", "orbm_keyframe_destroy", "orbm_search_for_triangulation_resident", "orbm_search_for_triangulation_resident_kb8", "orbm_search_by_bow_resident", "orbm_search_by_bow_fisheye", "orbm_search_for_initialization", "orbm_area_search_batch",
@@ -95,6 +95,7 @@ class OrbxLib:
         L.orbx_debug_level_keys.argtypes = [vp, i, i, vp, i]
         L.orbx_debug_quadtree_profile.argtypes = [vp, vp]
         L.orbx_debug_quadtree_lds_nodes.argtypes = [vp, i]
+        L.orbx_set_host_wait.argtypes = [i, i]
         L.orbx_debug_quadtree_pool_levels.argtypes = [vp]
         L.orbx_debug_simd_selftest.argtypes = [vp, vp, vp, vp, i, vp]
         L.orbx_debug_stereo_flags.argtypes = [vp, i]

@@ -896,6 +896,12 @@ int orbx_set_pyramid_mode(orbx_extractor* h, int mode) {
 }
 
 int orbx_set_small_batch_forms(orbx_extractor* h, int on) { if (!h) return ORBX_E_ARG; h->small_forms = on != 0; return ORBX_OK; }
+int orbx_set_host_wait(int device_id, int mode) {
+    if (mode < 0 || mode > 3) return fail(ORBX_E_ARG, "host wait mode %d (0 default, 1 blocking, 2 spin, 3 yield)", mode);
+    if (device_id < 0 || device_id >= rt::device_count()) return fail(ORBX_E_DEVICE, "no usable GPU %d", device_id);
+    if (rt::set_host_wait(device_id, mode)) return fail(ORBX_E_DEVICE, "hipSetDeviceFlags failed: %s", rt::last_error());
+    return ORBX_OK;
+}
 int orbx_debug_quadtree_pool_levels(orbx_extractor* h) { return h ? h->qt_pool_levels : ORBX_E_ARG; }
 int orbx_debug_quadtree_lds_nodes(orbx_extractor* h, int max_nodes) {
     if (!h || max_nodes < 0) return ORBX_E_ARG;

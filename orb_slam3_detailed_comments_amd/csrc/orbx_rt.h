@@ -19,6 +19,7 @@ struct event_s { double t; };
 typedef event_s* event_t;
 inline double now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 inline int set_device(int) { return 0; }
+inline int set_host_wait(int, int) { return 0; }
 inline bool memory_is_host() { return true; }
 // ORBX_EMU_DEVICES: the tests let the emulator report several "GPUs" (all of them host memory) to exercise the device plumbing of multi-GPU hosts
 inline int device_count() { const char* e = getenv("ORBX_EMU_DEVICES"); const int n = e ? atoi(e) : 1; return n > 0 ? n : 1; }
@@ -57,6 +58,13 @@ inline hipError_t& last_code() { static thread_local hipError_t e = hipSuccess; 
 inline int hip_ok(hipError_t e) { if (e == hipSuccess) return 0; last_code() = e; (void)hipGetLastError(); return -1; }
 #define ORBX_HIP_OK(x) ::orbx::rt::hip_ok(x)
 inline int set_device(int d) { return ORBX_HIP_OK(hipSetDevice(d)); }
+// how a host thread waits for the device in hipStreamSynchronize / hipEventSynchronize: 0 = the runtime's choice (it spins: lowest latency, one core per waiting
+// thread), 1 = blocking (sleeps on the completion interrupt: ~10 us later, no core), 2 = spin, 3 = yield
+inline int set_host_wait(int d, int mode) {
+    if (ORBX_HIP_OK(hipSetDevice(d))) return -1;
+    const unsigned f = mode == 1 ? hipDeviceScheduleBlockingSync : mode == 2 ? hipDeviceScheduleSpin : mode == 3 ? hipDeviceScheduleYield : hipDeviceScheduleAuto;
+    return ORBX_HIP_OK(hipSetDeviceFlags(f));
+}
 inline bool memory_is_host() { return false; }
 inline int device_count() { int n = 0; if (hip_ok(hipGetDeviceCount(&n))) return 0; return n; }
 inline void* dmalloc(size_t n) { void* p = nullptr; if (hip_ok(hipMalloc(&p, n ? n : 1))) return nullptr; live().dev++; return p; }
