@@ -11,6 +11,13 @@
  */
 #ifndef ORB_SLAM3_AMD_ORBEXTRACTOR_H
 #define ORB_SLAM3_AMD_ORBEXTRACTOR_H
+// This header REPLACES the reference's include/ORBextractor.h and takes its include guard, so that the `#include "ORBextractor.h"` lines inside the
+// reference's own headers (KeyFrame.h:27, Tracking.h:34 - a quoted include looks in the including file's directory first, whatever the include path
+// says) contribute nothing once this header has been seen.  If the reference's header was seen first the two classes would collide: fail with a reason.
+#ifdef ORBEXTRACTOR_H
+#error "the reference's include/ORBextractor.h was included before the drop-in ORBextractor.h: replace that file with this one, or force-include this header (-include); see INTEGRATION.md section 2"
+#endif
+#define ORBEXTRACTOR_H
 
 #include <stdexcept>
 #include <string>

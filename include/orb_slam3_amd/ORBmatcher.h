@@ -20,6 +20,11 @@
  */
 #ifndef ORB_SLAM3_AMD_ORBMATCHER_H
 #define ORB_SLAM3_AMD_ORBMATCHER_H
+// This header REPLACES the reference's include/ORBmatcher.h and takes its include guard (see ORBextractor.h)
+#ifdef ORBMATCHER_H
+#error "the reference's include/ORBmatcher.h was included before the drop-in ORBmatcher.h: replace that file with this one, or put this directory first on the include path; see INTEGRATION.md section 4"
+#endif
+#define ORBMATCHER_H
 
 #include <algorithm>
 #include <cmath>

@@ -108,6 +108,9 @@ public:
     template <typename T> T& at(int i) { return rows == 1 ? at<T>(0, i) : at<T>(i, 0); }
     template <typename T> const T& at(int i) const { return rows == 1 ? at<T>(0, i) : at<T>(i, 0); }
     size_t total() const { return (size_t)rows * cols; }
+#ifdef ORBX_TRACKING_WORLD      // (oracle/slam_shim/tracking_world.h: compile check of Tracking.cc; declared only, nothing of it is linked)
+    int channels() const; void resize(size_t rows_); void convertTo(Mat& m, int rtype, double alpha = 1, double beta = 0) const;
+#endif
     Mat reshape(int /*cn*/) const { return *this; }             // only reached with lens distortion, which the oracle never configures
     uchar* ptr(int y = 0) { return data + (size_t)y * step; }
     const uchar* ptr(int y = 0) const { return data + (size_t)y * step; }
@@ -247,6 +250,10 @@ public:
     operator int() const { return 0; }
     operator double() const { return 0.0; }
     operator std::string() const { return std::string(); }
+#ifdef ORBX_TRACKING_WORLD
+    bool empty() const; bool isReal() const; bool isInt() const; bool isString() const; double real() const; Mat mat() const; operator float() const;
+    template <typename T> T operator>>(T&) const;
+#endif
 };
 class FileStorage {
 public:
@@ -259,5 +266,10 @@ public:
     FileNode operator[](const std::string&) const { return FileNode(); }
 };
 template <typename T> static inline FileStorage& operator<<(FileStorage& fs, const T&) { return fs; }
+#ifdef ORBX_TRACKING_WORLD
+enum { COLOR_BGR2GRAY = 6, COLOR_RGB2GRAY = 7, COLOR_BGRA2GRAY = 10, COLOR_RGBA2GRAY = 11 };
+void cvtColor(InputArray src, OutputArray dst, int code, int dstCn = 0);
+std::ostream& operator<<(std::ostream& os, const Mat& m);
+#endif
 
 }  // namespace cv

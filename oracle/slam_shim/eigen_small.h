@@ -208,7 +208,15 @@ template <> struct MatrixSel<float, 2, 1> { typedef Vector2f type; };
 template <> struct MatrixSel<float, 1, 3> { typedef Vector3f type; };
 template <> struct MatrixSel<float, 3, 4> { typedef Matrix34f type; };
 template <> struct MatrixSel<float, 4, 1> { typedef Vector4f type; };
+#ifdef ORBX_TRACKING_WORLD         // (tracking_world.h: Eigen::Matrix<float, 4, 4, Eigen::RowMajor> m(ptr) of Tracking.cc:1370, declared only)
+enum { ColMajor = 0, RowMajor = 1 };
+struct RowMajorMatrix4f { explicit RowMajorMatrix4f(const float* data); };
+template <typename T, int R, int C, int Opt> struct MatrixSelOpt { typedef typename MatrixSel<T, R, C>::type type; };
+template <> struct MatrixSelOpt<float, 4, 4, 1> { typedef RowMajorMatrix4f type; };
+template <typename T, int R, int C, int Opt = 0> using Matrix = typename MatrixSelOpt<T, R, C, Opt>::type;
+#else
 template <typename T, int R, int C> using Matrix = typename MatrixSel<T, R, C>::type;
+#endif
 
 }  // namespace Eigen
 #endif

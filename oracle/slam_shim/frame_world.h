@@ -21,10 +21,22 @@
 
 namespace ORB_SLAM3 {
 namespace IMU {
-#ifdef ORBX_LOCALMAPPING_WORLD     // (localmapping_world.h: the members LocalMapping.cc names, declared only)
+#ifdef ORBX_LOCALMAPPING_WORLD     // (localmapping_world.h / tracking_world.h: the members LocalMapping.cc and Tracking.cc name, declared only)
 struct Bias { float bax = 0, bay = 0, baz = 0, bwx = 0, bwy = 0, bwz = 0; Bias() {} Bias(float, float, float, float, float, float); };
-struct Calib { Sophus::SE3f mTcb, mTbc; bool mbIsSet = false; };
-struct Preintegrated { void SetNewBias(const Bias&) {} void CopyFrom(Preintegrated*) {} void MergePrevious(Preintegrated*); Eigen::Vector3f GetUpdatedDeltaVelocity(); float dT; };
+struct Calib { Sophus::SE3f mTcb, mTbc; bool mbIsSet = false; Calib() {} Calib(const Sophus::SE3f& Tbc, const float& ng, const float& na, const float& ngw, const float& naw); };
+struct Point { Point(const float&, const float&, const float&, const float&, const float&, const float&, const double&); Point(const cv::Point3f, const cv::Point3f, const double&);
+               Eigen::Vector3f a, w; double t; };
+const float GRAVITY_VALUE = 9.81;
+Eigen::Matrix3f NormalizeRotation(const Eigen::Matrix3f& R);
+struct Preintegrated {
+    Preintegrated() {} Preintegrated(const Bias& b_, const Calib& calib); Preintegrated(Preintegrated* pImuPre);
+    void SetNewBias(const Bias&) {} void CopyFrom(Preintegrated*) {} void MergePrevious(Preintegrated*);
+    void IntegrateNewMeasurement(const Eigen::Vector3f& acceleration, const Eigen::Vector3f& angVel, const float& dt);
+    Eigen::Vector3f GetUpdatedDeltaVelocity(); Eigen::Matrix3f GetUpdatedDeltaRotation(); Eigen::Vector3f GetUpdatedDeltaPosition();
+    Eigen::Vector3f GetDeltaVelocity(const Bias& b_); Eigen::Matrix3f GetDeltaRotation(const Bias& b_); Eigen::Vector3f GetDeltaPosition(const Bias& b_);
+    Bias GetUpdatedBias();
+    float dT; Eigen::Vector3f avgA, avgW;
+};
 #else
 struct Bias { float bax = 0, bay = 0, baz = 0, bwx = 0, bwy = 0, bwz = 0; };
 struct Calib { Sophus::SE3f mTcb, mTbc; bool mbIsSet = false; };
@@ -40,6 +52,9 @@ public:
         return r;
     }
     static std::vector<cv::Mat> toDescriptorVector(const cv::Mat& D) { std::vector<cv::Mat> v; for (int j = 0; j < D.rows; j++) v.push_back(D.row(j)); return v; }
+#ifdef ORBX_TRACKING_WORLD
+    static Sophus::SE3<float> toSophus(const cv::Mat& T);
+#endif
 };
 }  // namespace ORB_SLAM3
 #endif

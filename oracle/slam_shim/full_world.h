@@ -37,11 +37,18 @@ public:
     std::vector<KeyFrame*> GetAllKeyFrames(); std::vector<MapPoint*> GetAllMapPoints(); long unsigned int KeyFramesInMap();
     void IncreaseChangeIndex(); void InformNewBigChange(); void AddKeyFrame(KeyFrame*); void AddMapPoint(MapPoint*);
     std::vector<KeyFrame*> mvpKeyFrameOrigins;
+    unsigned int GetLowerKFID(); long unsigned int GetMaxKFid(); KeyFrame* GetOriginKF(); void SetCurrentMap(); void SetInertialSensor(); bool IsInertial();
+    int GetMapChangeIndex(); int GetLastMapChange(); void SetLastMapChange(int currentChangeId); void SetReferenceMapPoints(const std::vector<MapPoint*>& vpMPs);
+    long unsigned int MapPointsInMap();
 #endif
 };
+class Frame;
 class KeyFrameDatabase {
 public:
     void erase(KeyFrame*) {}
+#ifdef ORBX_TRACKING_WORLD
+    void clear(); void clearMap(Map* pMap); std::vector<KeyFrame*> DetectRelocalizationCandidates(Frame* F, Map* pMap);
+#endif
 };
 // names used inside the never-instantiated serialize() templates of KeyFrame.h / MapPoint.h
 template <class Archive, class T> void serializeMatrix(Archive&, T&, const unsigned int) {}

@@ -46,6 +46,9 @@ struct Vector3f {
 #ifdef ORBX_LOCALMAPPING_WORLD
     Vector3f cross(const Vector3f& o) const;
     Vector3f& operator-=(const Vector3f& o);
+    Vector3f& operator*=(float s);
+    struct CommaInitV3 { CommaInitV3& operator,(float v); };
+    CommaInitV3 operator<<(float v);
     template <class T> typename LmCastV3<T>::type cast() const;
 #endif
     Vector3f() : d{0, 0, 0} {}
@@ -74,6 +77,7 @@ struct Matrix3f {
     float m[3][3];
 #ifdef ORBX_LOCALMAPPING_WORLD
     template <class T> typename LmCastM3<T>::type cast() const;
+    void setIdentity();
 #endif
     Matrix3f() : m{{0, 0, 0}, {0, 0, 0}, {0, 0, 0}} {}
     static Matrix3f Identity() { Matrix3f r; r.m[0][0] = r.m[1][1] = r.m[2][2] = 1.0f; return r; }

@@ -98,6 +98,7 @@ class SO3f {
 public:
 #ifdef ORBX_LOCALMAPPING_WORLD     // (localmapping_world.h: declared only)
     static SO3f exp(const Eigen::Vector3f& omega);
+    Eigen::Vector3f log() const;
 #endif
     SO3f() : unit_quaternion_(1.0f, 0.0f, 0.0f, 0.0f) {}                                           // so3.hpp:451-452
     SO3f(const Eigen::Matrix3f& R) : unit_quaternion_(R) {}                                        // so3.hpp:469 (SOPHUS_ENSUREs only; no normalisation)
@@ -138,6 +139,10 @@ public:
     SE3(const Eigen::Quaternionf& quaternion, const Eigen::Vector3f& translation) : so3_(quaternion), translation_(translation) {}          // se3.hpp:488-490
     const SO3f& so3() const { return so3_; }
     const Eigen::Vector3f& translation() const { return translation_; }
+#ifdef ORBX_TRACKING_WORLD         // (tracking_world.h: declared only)
+    Eigen::Vector3f& translation();
+    template <class M4> explicit SE3(const M4& T);
+#endif
     const Eigen::Quaternionf& unit_quaternion() const { return so3_.unit_quaternion(); }           // se3.hpp:419-421
     Eigen::Matrix3f rotationMatrix() const { return so3_.matrix(); }                                // se3.hpp:363
     Eigen::Matrix34f matrix3x4() const { Eigen::Matrix34f M; M << rotationMatrix(), translation_; return M; }            // se3.hpp:285-290

@@ -1,6 +1,8 @@
-"""The reference's src/LocalMapping.cc - the caller of ORBmatcher::SearchForTriangulation (LocalMapping.cc:610) and of both Fuse overloads
-(:999-1040) - compiles UNMODIFIED AND IN PLACE against the drop-in include/orb_slam3_amd/ORBmatcher.h, over the reference's own KeyFrame / MapPoint /
-Frame headers (oracle/Makefile: _ref/localmapping_dropin.o; its other collaborators are declarations, oracle/slam_shim/localmapping_world.h).
+"""The reference's callers compile UNMODIFIED AND IN PLACE against the drop-in headers, over the reference's own KeyFrame / MapPoint / Frame headers:
+src/LocalMapping.cc - SearchForTriangulation (LocalMapping.cc:610) and both Fuse overloads (:999-1040) - against include/orb_slam3_amd/ORBmatcher.h
+(oracle/Makefile: _ref/localmapping_dropin.o), and src/Tracking.cc - the extractors' constructors (Tracking.cc:631-635, :1328-1332), SearchByBoW (:3183, :4371),
+SearchByProjection x 3 (:3389, :4062, :4480-4500), SearchForInitialization (:2875) - against BOTH ORBextractor.h and ORBmatcher.h (_ref/tracking_dropin.o).
+Their other collaborators are declarations (oracle/slam_shim/localmapping_world.h, tracking_world.h).
 Compile check only - nothing is linked or run: the object must name the C ABI (orbm_*) where the control object (the same file against the
 reference's own ORBmatcher.h, _ref/localmapping_ref.o) names ORB_SLAM3::ORBmatcher::* member functions."""
 import os
@@ -34,3 +36,37 @@ def test_localmapping_compiles_against_the_dropin_matcher():
     # both were compiled from the same translation unit: the same LocalMapping members are defined
     defs = lambda p: {l.split(" T ", 1)[1] for l in subprocess.run(["nm", "-C", "--defined-only", p], capture_output=True, text=True, check=True).stdout.splitlines() if " T ORB_SLAM3::LocalMapping::" in l}
     assert defs(DROPIN) == defs(CONTROL) and len(defs(DROPIN)) > 25
+
+
+TR_DROPIN = os.path.join(ol.ROOT, "oracle", "_ref", "tracking_dropin.o")
+TR_CONTROL = os.path.join(ol.ROOT, "oracle", "_ref", "tracking_ref.o")
+
+
+@pytest.mark.skipif(not (os.path.exists(TR_DROPIN) and os.path.exists(TR_CONTROL)), reason="oracle/_ref/tracking_*.o not built (needs /root/reference)")
+def test_tracking_compiles_against_both_dropin_headers():
+    if os.path.isdir("/root/reference/src"):
+        subprocess.run(["make", "-s", "-C", os.path.join(ol.ROOT, "oracle"), "_ref/tracking_dropin.o", "_ref/tracking_ref.o"], check=True)
+    ours, ref = _undefined(TR_DROPIN), _undefined(TR_CONTROL)
+    # the control names the reference's out-of-line members: five matcher methods, the matcher's and the extractor's constructors ...
+    for member in ("ORBmatcher::SearchByBoW(", "ORBmatcher::SearchByProjection(", "ORBmatcher::SearchForInitialization(", "ORBmatcher::ORBmatcher(", "ORBextractor::ORBextractor("):
+        assert any(s.startswith("ORB_SLAM3::" + member) for s in ref), member
+    assert sum(s.startswith("ORB_SLAM3::ORBmatcher::SearchByProjection(") for s in ref) == 3
+    # ... the drop-in build none of them: `new ORBextractor(nFeatures, ...)` and `new ORBextractor(5*nFeatures, ...)` became orbx_create, the searches orbm_*
+    assert not [s for s in ours if s.startswith(("ORB_SLAM3::ORBmatcher::", "ORB_SLAM3::ORBextractor::"))]
+    for sym in ("orbx_create", "orbx_get_level_tables", "orbm_search_by_bow_resident", "orbm_search_by_projection_frame", "orbm_search_by_projection_mappoints",
+                "orbm_search_by_projection_keyframe", "orbm_search_for_initialization"):
+        assert sym in ours, sym
+    defs = lambda p: {l.split(" T ", 1)[1] for l in subprocess.run(["nm", "-C", "--defined-only", p], capture_output=True, text=True, check=True).stdout.splitlines() if " T ORB_SLAM3::Tracking::" in l}
+    assert defs(TR_DROPIN) == defs(TR_CONTROL) and len(defs(TR_DROPIN)) > 40
+
+
+def test_dropin_headers_refuse_to_follow_the_reference_headers(tmp_path):
+    """The reference's KeyFrame.h:27 and Tracking.h:34 say #include "ORBextractor.h": a quoted include finds the file beside the including one first, whatever the
+    include path says.  The drop-in headers therefore stand for REPLACED files: they take the reference's include guards, and a translation unit that saw the
+    reference's header first stops with a reason instead of two ORB_SLAM3::ORBextractor classes (or a link error later)."""
+    for name, guard in (("ORBextractor.h", "ORBEXTRACTOR_H"), ("ORBmatcher.h", "ORBMATCHER_H")):
+        src = tmp_path / ("t_" + name + ".cpp")
+        src.write_text("#define %s\n#include \"%s\"\nint main() { return 0; }\n" % (guard, name))
+        r = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-I" + os.path.join(ol.ROOT, "include", "orb_slam3_amd"), "-I" + os.path.join(ol.ROOT, "oracle", "opencv_shim"), str(src)],
+                           capture_output=True, text=True)
+        assert r.returncode != 0 and "was included before the drop-in" in r.stderr, r.stderr[-500:]
