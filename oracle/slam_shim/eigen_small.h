@@ -17,6 +17,7 @@
 #include <cmath>
 #include <limits>
 
+#include <type_traits>
 namespace Eigen {
 
 enum { ComputeFullU = 0x04, ComputeThinU = 0x08, ComputeFullV = 0x10, ComputeThinV = 0x20 };
@@ -43,6 +44,15 @@ template <typename T, int R, int C> struct SmallMatrix {
     SmallMatrix<T, 1, C> row(int r) const { SmallMatrix<T, 1, C> v; for (int j = 0; j < C; j++) v.m[0][j] = m[r][j]; return v; }
     RowRef<T, R, C> row(int r) { return RowRef<T, R, C>{this, r}; }
     static SmallMatrix Identity() { SmallMatrix I; for (int i = 0; i < R && i < C; i++) I.m[i][i] = T(1); return I; }
+#ifdef ORBX_LOOPCLOSING_WORLD      // (loopclosing_world.h: compile check of LoopClosing.cc; declared only, nothing of it is linked)
+    template <class U> SmallMatrix<U, R, C> castTo() const;
+    template <class U> typename std::conditional<std::is_same<U, float>::value && R == 3 && C == 1, Vector3f, SmallMatrix<U, R, C> >::type cast() const;
+    struct CommaInitSM { CommaInitSM& operator,(T v); };
+    CommaInitSM operator<<(T v);
+    SmallMatrix operator/(T s) const; SmallMatrix operator*(T s) const; SmallMatrix operator+(const SmallMatrix& o) const; SmallMatrix operator-(const SmallMatrix& o) const;
+    SmallMatrix& operator*=(T s); T norm() const; void setZero(); static SmallMatrix Zero(); SmallMatrix<T, C, R> transpose() const;
+    friend std::ostream& operator<<(std::ostream& os, const SmallMatrix& M) { return os; }
+#endif
 };
 template <typename T, int C> SmallMatrix<T, 1, C> operator*(T s, const SmallMatrix<T, 1, C>& v) { SmallMatrix<T, 1, C> r; for (int j = 0; j < C; j++) r.m[0][j] = s * v.m[0][j]; return r; }
 template <typename T, int C> SmallMatrix<T, 1, C> operator-(const SmallMatrix<T, 1, C>& a, const SmallMatrix<T, 1, C>& b) {

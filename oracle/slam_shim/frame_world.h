@@ -55,6 +55,9 @@ public:
 #ifdef ORBX_TRACKING_WORLD
     static Sophus::SE3<float> toSophus(const cv::Mat& T);
 #endif
+#ifdef ORBX_LOOPCLOSING_WORLD
+    template <class S3> static Sophus::Sim3<float> toSophus(const S3& S);          // (g2o::Sim3: declared in loopclosing_world.h)
+#endif
 };
 }  // namespace ORB_SLAM3
 #endif

@@ -40,6 +40,7 @@ public:
     unsigned int GetLowerKFID(); long unsigned int GetMaxKFid(); KeyFrame* GetOriginKF(); void SetCurrentMap(); void SetInertialSensor(); bool IsInertial();
     int GetMapChangeIndex(); int GetLastMapChange(); void SetLastMapChange(int currentChangeId); void SetReferenceMapPoints(const std::vector<MapPoint*>& vpMPs);
     long unsigned int MapPointsInMap();
+    void ChangeId(long unsigned int nId); bool CheckEssentialGraph(); void PrintEssentialGraph(); int GetLastBigChangeIdx();
 #endif
 };
 class Frame;
@@ -48,6 +49,8 @@ public:
     void erase(KeyFrame*) {}
 #ifdef ORBX_TRACKING_WORLD
     void clear(); void clearMap(Map* pMap); std::vector<KeyFrame*> DetectRelocalizationCandidates(Frame* F, Map* pMap);
+    void add(KeyFrame* pKF);
+    void DetectNBestCandidates(KeyFrame* pKF, std::vector<KeyFrame*>& vpLoopCand, std::vector<KeyFrame*>& vpMergeCand, int nNumCandidates);
 #endif
 };
 // names used inside the never-instantiated serialize() templates of KeyFrame.h / MapPoint.h

@@ -35,6 +35,11 @@ inline Vector3f cross3(const Vector3f& a, const Vector3f& b) {          // Eigen
 }
 
 struct Quaternionf {
+#ifdef ORBX_LOOPCLOSING_WORLD      // (loopclosing_world.h: declared only)
+    template <class T> struct CastQ;
+    template <class T> typename CastQ<T>::type cast() const;
+    Vector3f operator*(const Vector3f& v) const;
+#endif
     float c[4];                                                          // coeffs(): x, y, z, w
     Quaternionf() : c{0, 0, 0, 1} {}
     Quaternionf(float w, float x, float y, float z) : c{x, y, z, w} {}   // Eigen's constructor takes w first
@@ -143,6 +148,9 @@ public:
     Eigen::Vector3f& translation();
     template <class M4> explicit SE3(const M4& T);
 #endif
+#ifdef ORBX_LOOPCLOSING_WORLD
+    template <class T> SE3<T> cast() const;
+#endif
     const Eigen::Quaternionf& unit_quaternion() const { return so3_.unit_quaternion(); }           // se3.hpp:419-421
     Eigen::Matrix3f rotationMatrix() const { return so3_.matrix(); }                                // se3.hpp:363
     Eigen::Matrix34f matrix3x4() const { Eigen::Matrix34f M; M << rotationMatrix(), translation_; return M; }            // se3.hpp:285-290
@@ -151,7 +159,22 @@ public:
     Eigen::Vector3f operator*(const Eigen::Vector3f& p) const { return so3_ * p + translation_; }                         // se3.hpp:321-324
 };
 typedef SE3<float> SE3f;
+#ifdef ORBX_LOOPCLOSING_WORLD
+typedef SE3<double> SE3d;
+#endif
+#ifdef ORBX_LOOPCLOSING_WORLD      // (loopclosing_world.h: the double-precision poses LoopClosing.cc handles, declared only)
+}
+namespace Eigen { struct Quaterniond; struct Matrix3d; }
+namespace Sophus {
+struct SO3d { SO3d(); explicit SO3d(const Eigen::Matrix3d& R); };
+template <> struct SE3<double> {
+    SE3(); SE3(const Eigen::Quaterniond& q, const Eigen::Vector3d& t); SE3(const Eigen::Matrix3d& R, const Eigen::Vector3d& t);
+    SE3 operator*(const SE3& o) const; SE3 inverse() const; const Eigen::Quaterniond& unit_quaternion() const; const Eigen::Vector3d& translation() const; Eigen::Vector3d& translation();
+    Eigen::Matrix3d rotationMatrix() const; template <class T> SE3<T> cast() const;
+};
+#else
 template <> struct SE3<double> {};     // include/Frame.h:369 holds an unused Sophus::SE3<double> member
+#endif
 
 class RxSO3f {
     Eigen::Quaternionf quaternion_;                                                                // |q|^2 = scale
@@ -192,6 +215,9 @@ template <> struct Sim3<float> {
 private:
     RxSO3f rxso3_; Eigen::Vector3f translation_;
 public:
+#ifdef ORBX_LOOPCLOSING_WORLD
+    void setScale(const float& scale);
+#endif
     Sim3() : rxso3_(), translation_() {}                                                           // sim3.hpp:370
     Sim3(const RxSO3f& rxso3, const Eigen::Vector3f& translation) : rxso3_(rxso3), translation_(translation) {}           // sim3.hpp:388-395
     Sim3(const Eigen::Quaternionf& quaternion, const Eigen::Vector3f& translation) : rxso3_(quaternion), translation_(translation) {}   // sim3.hpp:402-409
