@@ -483,6 +483,9 @@ def main():
     NIMG = 2 * P if paired else P
     NH = args.handles if args.handles > 0 else (3 if (dist is not None and (args.allgather or coll_dev == "cuda")) else 4)
     handles = [ORBextractor(NFEAT, SCALE, NLEVELS, INI, MIN, device_id=local, lib=lib) for _ in range(NH)]
+    if os.environ.get("ORBX_BENCH_QT_LDS_NODES"):            # experiment switch: quadtree levels above this many nodes keep their node lists in the global pool
+        for h in handles:
+            h.debug_quadtree_lds_nodes(int(os.environ["ORBX_BENCH_QT_LDS_NODES"]))
     if kind == "rgbd":
         for h in handles:
             h.set_input(3, rgb=True)
