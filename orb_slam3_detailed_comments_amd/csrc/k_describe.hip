@@ -49,7 +49,6 @@ __global__ void __launch_bounds__(256) k_layout(const LevelInfo* __restrict__ lv
                                                 const int* __restrict__ lvl_count, int lap0, int lap1,
                                                 int* __restrict__ final_idx, int* __restrict__ n_out, int* __restrict__ mono_out,
                                                 int nb, int* __restrict__ row_start, int* __restrict__ row_items) {
-    ORBX_SETPRIO(ORBX_PRIO_LAYOUT);
     ORBX_DYN_SMEM(smem);                                // row index: histogram and cursors, (nb + 1) ints each
     __shared__ unsigned long long s_scan[20];
     __shared__ int s_cnt[kMaxLevels], s_off[kMaxLevels + 1];
@@ -315,7 +314,6 @@ __global__ void __launch_bounds__(256) k_orient_brief(const LevelInfo* __restric
                                                       const int* __restrict__ lvl_count, const int* __restrict__ final_idx,
                                                       UmaxTab umax, KeyPointRec* __restrict__ out_kps,
                                                       unsigned long long* __restrict__ out_desc, int4* __restrict__ out_aux, int B, int groups_per_image) {
-    ORBX_SETPRIO(ORBX_PRIO_ORIENT);
     orient_brief_impl<kKpPerWave>(lv, nlevels, pyr, blur, pyr_stride, lvl_keys, kp_total_cap, lvl_count, final_idx, umax, out_kps, out_desc, out_aux, B, groups_per_image);
 }
 // the same with fewer keypoints per wave: four times as many, shorter waves (small batches, where one wave's chain of keypoints is the stage time)

@@ -122,7 +122,6 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
     const int list_cap = list_bytes >> 1;                   // entries
 #endif
     uint32_t* tile32 = (uint32_t*)tile;
-    uint32_t* tileH32 = (uint32_t*)((uint8_t*)list + list_bytes);      // kFastHTile: the window tile in H form (same pitch, same offsets)
     const int t0 = pass == 0 ? iniTh : minTh;
     // ---- load ----  aligned dwords of the window -> tile
     if (WPC) {
@@ -138,7 +137,7 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
 #pragma unroll
                 for (int k = 0; k < 4; k++) if (r + 5 * k < wh) v[k] = *(const uint32_t*)(src + k * step);
 #pragma unroll
-                for (int k = 0; k < 4; k++) if (r + 5 * k < wh) { tile32[lo + 5 * k * kCols] = v[k]; if (kFastHTile) tileH32[lo + 5 * k * kCols] = (v[k] >> 1) | kH; }
+                for (int k = 0; k < 4; k++) if (r + 5 * k < wh) tile32[lo + 5 * k * kCols] = v[k];
                 src += 4 * step; lo += 20 * kCols;
             }
         }
@@ -155,7 +154,7 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++) { const int i = i0 + k * kFastThreads; if (i < wh * wpd) { tile32[i] = v[k]; if (kFastHTile) tileH32[i] = (v[k] >> 1) | kH; } }
+            for (int k = 0; k < 4; k++) { const int i = i0 + k * kFastThreads; if (i < wh * wpd) tile32[i] = v[k]; }
         }
     }
     // score tile: same pitch as the window tile, rows -1 .. ih of the interior (one zero row / column around it), so that
@@ -241,7 +240,7 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
         for (int j = 0; j < 4; j++) if (lane_used && xbase + j >= 0 && xbase + j < iw) VM |= 0x80u << (8 * j);
         const int td = (t0 + 1) >> 1;
         const uint32_t Cd = (uint32_t)(td - 1) * 0x01010101u, Tb = (uint32_t)td * 0x01010101u;
-        const uint32_t* hb_lane = (kFastHTile ? tileH32 : tile32) + yl * wpd + (g - 1);  // window row (interior row - 3), dword g - 1
+        const uint32_t* hb_lane = tile32 + yl * wpd + (g - 1);  // window row (interior row - 3), dword g - 1
         const int toff_lane = (yl + 3) * wp + 4 * g;            // tile byte offset of the lane's first pixel in trip 0
         for (int it0 = 0; it0 < ih; it0 += rpt) {
             uint32_t SD = 0, SB = 0;
@@ -250,7 +249,7 @@ __device__ __forceinline__ void fast_cell(const CellInfo ci, const LevelInfo L, 
                     const uint32_t* hb = hb_lane + it0 * wpd;
                     const uint32_t C0 = hb[1], L1 = hb[wpd], C1 = hb[wpd + 1], R1 = hb[wpd + 2], L3 = hb[3 * wpd], C3 = hb[3 * wpd + 1], R3 = hb[3 * wpd + 2],
                                    L5 = hb[5 * wpd], C5 = hb[5 * wpd + 1], R5 = hb[5 * wpd + 2], C6 = hb[6 * wpd + 1];
-#define ORBX_H(w) (kFastHTile ? (w) : (((w) >> 1) | kH))
+#define ORBX_H(w) (((w) >> 1) | kH)
                     // thresholds from the centre dword
                     const uint32_t c3 = ORBX_H(C3);
                     const uint32_t x = c3 - Cd;                     // 128 + V - (td - 1) >= 1
@@ -407,7 +406,6 @@ __global__ void __launch_bounds__(kFastThreads) k_fast_cells(const LevelInfo* __
                                                     int iniTh, int minTh,
                                                     uint32_t* __restrict__ slots, size_t slots_stride,
                                                     int* __restrict__ cell_count, int tile_bytes, int list_bytes, int* __restrict__ status) {
-    ORBX_SETPRIO(ORBX_PRIO_FAST);
     ORBX_DYN_SMEM(smem);
     fast_block((int)blockIdx.x, lv, cells, ncells, pyr, pyr_stride, iniTh, minTh, slots, slots_stride, cell_count, tile_bytes, list_bytes, status, smem);
 }

@@ -268,7 +268,6 @@ __global__ void __launch_bounds__(kPyrThreads) k_pyramid_fused(const LevelInfo* 
 __global__ void __launch_bounds__(256) k_resize_rows(const LevelInfo* __restrict__ lv, int level,
                                                      const ResizeTap* __restrict__ xtab, const ResizeTap* __restrict__ ytab,
                                                      uint8_t* __restrict__ pyr, size_t pyr_stride, int strip_rows) {
-    ORBX_SETPRIO(ORBX_PRIO_RESIZE);
     const LevelInfo D = lv[level];
     const LevelInfo S = lv[level - 1];
     const int b = (int)blockIdx.z;
@@ -385,14 +384,12 @@ __global__ void __launch_bounds__(256) k_simd_selftest(const uint32_t* __restric
 __global__ void __launch_bounds__(256) k_blur(const LevelInfo* __restrict__ lv, int nlevels,
                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
                                               size_t pyr_stride, BlurTaps taps, BlurTiles tiles) {
-    ORBX_SETPRIO(ORBX_PRIO_BLUR);
     blur_strip<kBlurRows>(lv, nlevels, pyr, blur, pyr_stride, taps, tiles, (int)blockIdx.x, (int)threadIdx.y, (int)threadIdx.x, (int)blockIdx.y);
 }
 // the same with strips of kBlurRowsLarge rows (large batches; the tile table counts tiles of 4 x kBlurRowsLarge rows)
 __global__ void __launch_bounds__(256) k_blur_large(const LevelInfo* __restrict__ lv, int nlevels,
                                                     const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
                                                     size_t pyr_stride, BlurTaps taps, BlurTiles tiles) {
-    ORBX_SETPRIO(ORBX_PRIO_BLUR);
     blur_strip<kBlurRowsLarge>(lv, nlevels, pyr, blur, pyr_stride, taps, tiles, (int)blockIdx.x, (int)threadIdx.y, (int)threadIdx.x, (int)blockIdx.y);
 }
 

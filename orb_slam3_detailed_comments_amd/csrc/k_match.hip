@@ -37,7 +37,6 @@ __global__ void __launch_bounds__(256) k_stereo_match(const LevelInfo* __restric
                                                       const int* __restrict__ bucket_start, const int* __restrict__ bucket_items, int nb, int lookback,
                                                       int cap, const uint8_t* __restrict__ pyrL, const uint8_t* __restrict__ pyrR, size_t pyr_stride,
                                                       StereoParams P, float* __restrict__ uRight, float* __restrict__ depth, int* __restrict__ sad) {
-    ORBX_SETPRIO(ORBX_PRIO_MATCH);
     const int b = (int)blockIdx.y, lane = lane_id();
     const int iL = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     if (iL >= cap) return;
@@ -166,7 +165,6 @@ __global__ void __launch_bounds__(256) k_stereo_match(const LevelInfo* __restric
 __global__ void __launch_bounds__(256) k_stereo_median(const int* __restrict__ nL, int cap,
                                                        float* __restrict__ uRight, float* __restrict__ depth,
                                                        const int* __restrict__ sad, int* __restrict__ n_matches) {
-    ORBX_SETPRIO(ORBX_PRIO_MATCH);
     __shared__ unsigned long long s_scan[20];
     __shared__ int s_hist[256];
     __shared__ int s_med[3];                                // {median, bin of the rank, rank inside the bin}

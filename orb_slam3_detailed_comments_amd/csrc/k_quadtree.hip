@@ -1082,7 +1082,6 @@ __global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree(const LevelInfo* 
                                                   uint32_t* __restrict__ lvl_keys, int kp_total_cap,
                                                   int* __restrict__ lvl_count, int nlevels, int node_cap, int nb_cap, int lut_x, int lut_y,
                                                   int* __restrict__ status, long long* __restrict__ qt_prof, int wide, int counter_bytes, int level0) {
-    ORBX_SETPRIO(ORBX_PRIO_QUADTREE);
     ORBX_DYN_SMEM(smem);
     quadtree_tree<false>(smem, nullptr, (int)blockIdx.y + level0, (int)blockIdx.x, lv, cells, ncells, cell_count, slots, slots_stride, candA, candB, cand_stride,
                          lvl_keys, kp_total_cap, lvl_count, nlevels, node_cap, nb_cap, lut_x, lut_y, status, qt_prof, wide, counter_bytes);
@@ -1098,7 +1097,6 @@ __global__ void __launch_bounds__(kQuadtreeThreads) k_quadtree_spill(const Level
                                                   int* __restrict__ lvl_count, int nlevels, int node_cap, int nb_cap, int lut_x, int lut_y,
                                                   int* __restrict__ status, long long* __restrict__ qt_prof, int wide, int counter_bytes,
                                                   unsigned char* __restrict__ pool, size_t pool_stride) {
-    ORBX_SETPRIO(ORBX_PRIO_QUADTREE);
     ORBX_DYN_SMEM(smem);
     quadtree_tree<true>(smem, pool + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * pool_stride, (int)blockIdx.y, (int)blockIdx.x, lv, cells, ncells, cell_count,
                         slots, slots_stride, candA, candB, cand_stride, lvl_keys, kp_total_cap, lvl_count, nlevels, node_cap, nb_cap, lut_x, lut_y, status,

@@ -401,7 +401,7 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
     const int fast_blocks = (h->ncells + 8 * kFastXcdRun - 1) / (8 * kFastXcdRun) * (8 * kFastXcdRun);   // whole XCD runs (k_fast_cells)
     // pad | window tile | score tile | u16 list: corners found so far + pending survivors of the quick test (scored whenever it fills up)
     const int list_bytes = ORBX_FAST_LIST_BYTES;
-    const size_t fast_smem = 16 + (size_t)h->fast_tile_bytes + (size_t)h->fast_inner_bytes + (size_t)list_bytes + 64 + (kFastHTile ? (size_t)h->fast_tile_bytes : 0);
+    const size_t fast_smem = 16 + (size_t)h->fast_tile_bytes + (size_t)h->fast_inner_bytes + (size_t)list_bytes + 64;
     const dim3 blkf(kFastThreadsDecl, 1, 1);
     // small batches: blur and FAST in one launch on one stream (k_fast_cells_blur: no fork / join).  The stage timers of the profiling modes keep
     // the two apart, so those run the large-batch form

@@ -29,12 +29,6 @@ __global__ void k_pyramid_fused(const LevelInfo* __restrict__ lv, int nlevels, c
 #endif
 constexpr int kFastXcdRun = ORBX_FAST_XCD_RUN;   // neighbouring FAST cells kept on one XCD (k_fast_cells)
 constexpr int kFastThreadsDecl = 64;   // must equal kFastThreads in k_fast.hip
-#ifndef ORBX_FAST_HTILE
-#define ORBX_FAST_HTILE 0
-#endif
-// k_fast_cells keeps a second copy of the window tile in the "H form" of its quick test ((p >> 1) | 0x80 per byte), written once by the load phase: the
-// test then reads its nine ring dwords ready-made instead of converting them in every trip (18 of its ~67 vector instructions); costs tile_bytes of LDS per wave
-constexpr bool kFastHTile = ORBX_FAST_HTILE != 0;
 constexpr int kFastPitch = 48;         // LDS pitch of the FAST window tile for cells whose dword-aligned window fits in it (cells up to 39 px wide)
 __global__ void k_fast_cells(const LevelInfo* __restrict__ lv, const CellInfo* __restrict__ cells, int ncells,
                              const uint8_t* __restrict__ pyr, size_t pyr_stride, int iniTh, int minTh,

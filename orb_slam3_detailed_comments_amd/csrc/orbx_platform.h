@@ -38,36 +38,6 @@
 #define ORBX_IN_BALLOT(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
 #endif
 
-// Issue priority of a kernel's waves inside their SIMD (s_setprio 0..3; 0 = the hardware default).  The kernels of an extraction share the CUs with the
-// kernels of the other handles in flight; a build can give the short, latency-bound links of the chain (quadtree, layout, stereo search) or the memory-bound ones
-// precedence over the instruction-bound FAST waves (-DORBX_PRIO_<KERNEL>=n; every default is 0 = no instruction emitted).
-#if defined(ORBX_EMU)
-#define ORBX_SETPRIO(n)
-#else
-#define ORBX_SETPRIO(n) do { if ((n) > 0) __builtin_amdgcn_s_setprio(n); } while (0)
-#endif
-#ifndef ORBX_PRIO_QUADTREE
-#define ORBX_PRIO_QUADTREE 0
-#endif
-#ifndef ORBX_PRIO_LAYOUT
-#define ORBX_PRIO_LAYOUT 0
-#endif
-#ifndef ORBX_PRIO_MATCH
-#define ORBX_PRIO_MATCH 0
-#endif
-#ifndef ORBX_PRIO_RESIZE
-#define ORBX_PRIO_RESIZE 0
-#endif
-#ifndef ORBX_PRIO_BLUR
-#define ORBX_PRIO_BLUR 0
-#endif
-#ifndef ORBX_PRIO_ORIENT
-#define ORBX_PRIO_ORIENT 0
-#endif
-#ifndef ORBX_PRIO_FAST
-#define ORBX_PRIO_FAST 0
-#endif
-
 namespace orbx {
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
