@@ -271,14 +271,17 @@ __global__ void __launch_bounds__(256) k_resize_rows(const LevelInfo* __restrict
     const LevelInfo D = lv[level];
     const LevelInfo S = lv[level - 1];
     const int b = (int)blockIdx.z;
-    const int dx0 = ((int)blockIdx.x * 64 + (int)threadIdx.x) * 4;
+    // (lanes beyond the row pitch - the last workgroup of a row - redo its last dword and store the same bytes: every lane of a wave stays alive, because
+    // lane i also carries the vertical taps of output row ys + i for the whole wave, below.  Until round 6 those lanes left the kernel, which was correct only
+    // while a strip had at most 16 rows = the lanes a 64-byte pitch always fills: ORBX_RESIZE_STRIP = 32 read taps out of dead lanes.)
+    const int dx0 = imin(((int)blockIdx.x * 64 + (int)threadIdx.x) * 4, D.pitch - 4);
 #ifdef ORBX_EMU
     const int strip = (int)blockIdx.y * 4 + (int)threadIdx.y;
 #else
     const int strip = __builtin_amdgcn_readfirstlane((int)blockIdx.y * 4 + (int)threadIdx.y);     // one strip per wave: row bookkeeping stays scalar
 #endif
     const int ys = strip * strip_rows;
-    if (dx0 >= D.pitch || ys >= D.h) return;
+    if (ys >= D.h) return;
     const BufRsrc src = buf_make(pyr + (size_t)b * pyr_stride + S.off);
     const BufRsrc dst = buf_make(pyr + (size_t)b * pyr_stride + D.off);
     const ResizeTap* xt = xtab + D.xtab_off;

@@ -69,3 +69,23 @@ def test_fast_list_flush_path(tmp_path, cap):
         got = ORBextractor(nf, 1.2, 8, 20, 7, lib=lib)(img, None, lap)
         exp = ol.OracleExtractor(nf).extract(img, lap)
         assert got[0] == exp[0] and ol.kps_equal(got[1], exp[1]) and np.array_equal(got[2], exp[2]), name
+
+
+@pytest.mark.parametrize("strip", [32, 64])
+def test_resize_strips_longer_than_a_pitch_quantum(tmp_path, strip):
+    """k_resize_rows: lane i of a wave carries the vertical taps of output row ys + i for the whole wave.  Until round 6 the lanes beyond the row pitch left
+    the kernel at once - correct only while a strip had at most 16 rows (a 64-byte pitch always fills 16 lanes); a build with ORBX_RESIZE_STRIP = 32 read
+    taps out of dead lanes on the last workgroup of a row (found when the strip length was tried as an experiment: parity_check of bench.py failed).  Now every
+    lane stays alive (the surplus lanes redo the row's last dword).  Batches above 32 images use the configured strip length."""
+    from orb_slam3_detailed_comments_amd import synth
+    so = str(tmp_path / "liborbx_emu_strip.so")
+    build_emu_variant(so, ["-DORBX_RESIZE_STRIP=%d" % strip])
+    lib = _lib.OrbxLib(so)
+    for (w, h) in ((522, 333),):                                   # level widths 435, 363, 302 ..: pitches whose last workgroup fills 48, 32, 16 .. lanes
+        img = synth.pink_noise(w, h, seed=w)
+        other = synth.sparse_corners(w, h, seed=5, ncorner=20)
+        o = ol.OracleExtractor(300); o.extract(img)
+        ex = ORBextractor(300, 1.2, 8, 20, 7, lib=lib)
+        ex.extract_batch(np.stack([other] * 599 + [img]))          # enough workgroups that the library keeps the configured strip on the first levels
+        for l in range(8):
+            assert np.array_equal(ex.pyramid_level(l, 599), o.level_image(l)), "level %d of %dx%d, strips of %d rows" % (l, w, h, strip)

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 KIND=${1:-asan}
 CSRC=orb_slam3_detailed_comments_amd/csrc
 SRCS=$(grep "^SRCS" tests/emu/Makefile | sed "s/SRCS = //; s#\$(CSRC)#$CSRC#g")
-SEL="(emu or resident or batch or local_points or kb8 or ties or undistort or sophus or simd or lifetime or multi_comm or abi) and not rccl"        # (the rccl load-order probe loads the HIP build)
+SEL="(emu or mono_init or resident or batch or local_points or kb8 or ties or undistort or sophus or simd or lifetime or multi_comm or abi) and not rccl"        # (the rccl load-order probe loads the HIP build)
 if [ "$KIND" = asan ]; then
     g++ -O1 -g -fno-omit-frame-pointer -fsanitize=address -std=c++17 -ffp-contract=off -fwrapv -fno-gnu-unique -DORBX_EMU -DHIPEMU_UCONTEXT -Itests/emu -I$CSRC -fPIC -shared -w -x c++ $SRCS -o /tmp/liborbx_emu_asan.so -lpthread
     LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1:log_path=/tmp/orbx_asan_report \
