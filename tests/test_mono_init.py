@@ -70,6 +70,25 @@ def test_mono_init_extractor_gpu(hip_lib, key):
     _init_case(hip_lib, key)
 
 
+# ... and mpORBextractorLeft = ORBextractor(nFeatures, ..) of the same files (what runs after initialisation): every distinct (size, nFeatures), same two image kinds
+POST = sorted({(k[0], k[1], k[2] // 5) + k[3:] for k in INIT_KEYS})
+POST_IDS = ["%dx%d_n%d" % k[:3] for k in POST]
+
+
+@pytest.mark.parametrize("key", POST, ids=POST_IDS)
+def test_mono_extractor_after_initialisation_emulated(emu_lib, monkeypatch, key):
+    monkeypatch.setenv("ORBX_EMU_LDS_LIMIT", GFX950_LDS)
+    INIT.setdefault(key, ["(nFeatures of " + INIT[(key[0], key[1], 5 * key[2]) + key[3:]][0] + ")"])
+    assert _init_case(emu_lib, key).debug_quadtree_pool_levels() == 0          # every level of the post-initialisation extractors fits the LDS
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", POST, ids=POST_IDS)
+def test_mono_extractor_after_initialisation_gpu(hip_lib, key):
+    INIT.setdefault(key, ["(nFeatures of " + INIT[(key[0], key[1], 5 * key[2]) + key[3:]][0] + ")"])
+    assert _init_case(hip_lib, key).debug_quadtree_pool_levels() == 0
+
+
 def test_pool_form_is_what_the_big_settings_take(emu_lib, monkeypatch):
     """KITTI's 10 000 and TUM-VI's 7 500 need more LDS than gfx950 has in the LDS form - the refusal of the earlier revisions - so they do exercise the pool
     form above, and (2000, KITTI) after initialisation does not."""
