@@ -31,9 +31,15 @@ def test_stand_in_probe_runs(tmp_path):
     assert out.count("\n") == 2000 * (2 + 3 + 3 + 9 + 9 + 3 + 3 + 9 + 3 + 4) and "nan" not in out
 
 
-@pytest.mark.skipif(not (os.path.exists(os.path.join(EIGEN, "Eigen", "Dense")) and os.path.exists(os.path.join(SOPHUS, "sophus", "se3.hpp"))),
+HAVE_REAL = os.path.exists(os.path.join(EIGEN, "Eigen", "Dense")) and os.path.exists(os.path.join(SOPHUS, "sophus", "se3.hpp"))
+
+
+# A CI that is supposed to carry a real Eigen sets ORBX_REQUIRE_REAL_EIGEN=1: the comparison then FAILS instead of skipping when the headers are missing
+# (a skipped pin is no pin).  The build image has no Eigen anywhere (no network): there it skips, and DESIGN.md section 2.2 says "unpinned".
+@pytest.mark.skipif(not HAVE_REAL and os.environ.get("ORBX_REQUIRE_REAL_EIGEN") != "1",
                     reason="no real Eigen on this machine (install libeigen3-dev or set EIGEN3_INCLUDE) / no vendored Sophus")
 def test_stand_in_equals_real_eigen(tmp_path):
+    assert HAVE_REAL, "ORBX_REQUIRE_REAL_EIGEN=1 but %s/Eigen/Dense or %s/sophus/se3.hpp is missing" % (EIGEN, SOPHUS)
     real = _run(tmp_path, "probe_real", ["-DPROBE_REAL_EIGEN", "-I" + EIGEN, "-I" + SOPHUS])
     shim = _run(tmp_path, "probe_shim", SHIM + ["-include", os.path.join(ROOT, "oracle", "slam_shim", "slam_world.h")])
     a, b = real.splitlines(), shim.splitlines()
