@@ -147,6 +147,10 @@ def test_pool_form_batches_gpu(hip_lib):
         assert ex.debug_quadtree_pool_levels() > 0
         for i in range(B):
             assert _same(got[i], exp[i % 4]), (B, i)
+    ex.graph_replay(True)                                      # the two quadtree launches (pool + LDS) inside a captured hipGraph, replayed
+    for _ in range(3):
+        got = ex.extract_batch(np.stack(imgs[:2]))
+        assert _same(got[0], exp[0]) and _same(got[1], exp[1]) and ex.debug_quadtree_pool_levels() > 0
 
 
 # ---- the C++ facade: ORBextractor(5 * nFeatures, ...) for every settings file, against the reference build of the same driver ----
