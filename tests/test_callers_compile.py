@@ -91,3 +91,16 @@ def test_loopclosing_compiles_against_the_dropin_matcher():
         assert sym in ours, sym
     defs = lambda p: {l.split(" T ", 1)[1] for l in subprocess.run(["nm", "-C", "--defined-only", p], capture_output=True, text=True, check=True).stdout.splitlines() if " T ORB_SLAM3::LoopClosing::" in l}
     assert defs(LC_DROPIN) == defs(LC_CONTROL) and len(defs(LC_DROPIN)) > 20
+
+
+def test_replaced_header_recipe_of_the_integration_guide(tmp_path):
+    """the drop-in ORBextractor.h is COPIED over the reference's include/ORBextractor.h and <repo>/include/orb_slam3_amd goes on the
+    include path - the copied header's `#include "../orbx.h"` must then resolve (it is looked up beside the copy first, then along the include path)."""
+    inc = tmp_path / "include"; src = tmp_path / "src"
+    inc.mkdir(); src.mkdir()
+    (inc / "ORBextractor.h").write_bytes(open(os.path.join(ol.ROOT, "include", "orb_slam3_amd", "ORBextractor.h"), "rb").read())
+    (inc / "KeyFrameLike.h").write_text('#include "ORBextractor.h"\nstruct KeyFrameLike { ORB_SLAM3::ORBextractor* mpExtractor; };\n')      # what KeyFrame.h:27 does
+    (src / "t.cpp").write_text('#include "KeyFrameLike.h"\n#include "ORBextractor.h"\nint main() { return sizeof(KeyFrameLike) > 0 ? 0 : 1; }\n')
+    r = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-I" + str(inc), "-I" + os.path.join(ol.ROOT, "include", "orb_slam3_amd"),
+                        "-I" + os.path.join(ol.ROOT, "oracle", "opencv_shim"), str(src / "t.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-800:]
