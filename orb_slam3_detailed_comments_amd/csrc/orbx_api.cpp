@@ -8,6 +8,9 @@
 #ifndef ORBX_PYR_FUSED_BATCH
 #define ORBX_PYR_FUSED_BATCH 8     // k_pyramid_fused (all levels in one launch) for batches up to this many images
 #endif
+#ifndef ORBX_RESIZE_MIN_BLOCKS
+#define ORBX_RESIZE_MIN_BLOCKS 2048 // k_resize_rows: strips are halved until a level gives at least this many workgroups (tests lower it to keep long strips at small batches)
+#endif
 #ifndef ORBX_RESIZE_STRIP
 #define ORBX_RESIZE_STRIP 16        // k_resize_rows: output rows per wave for large batches
 #endif
@@ -373,7 +376,7 @@ int enqueue_extract(orbx_extractor* h, int B, const uint8_t* d_images, int src_w
             // rows per wave: long strips share more source rows (a strip of n rows computes ~1.2 n + 1 horizontal rows), short ones give
             // small batches enough waves to hide the row loads
             int strip = ORBX_RESIZE_STRIP;
-            while (strip > 4 && (long)((L.pitch + 255) / 256) * ((L.h + 4 * strip - 1) / (4 * strip)) * B < 2048) strip >>= 1;
+            while (strip > 4 && (long)((L.pitch + 255) / 256) * ((L.h + 4 * strip - 1) / (4 * strip)) * B < ORBX_RESIZE_MIN_BLOCKS) strip >>= 1;
             dim3 gridr((L.pitch + 255) / 256, (L.h + 4 * strip - 1) / (4 * strip), B);
             ORBX_LAUNCH(k_resize_rows, gridr, blk2, 0, h->s0, (const LevelInfo*)h->d_lv.p, l, (const ResizeTap*)h->d_xtab.p, (const ResizeTap*)h->d_ytab.p,
                         h->d_pyr.p, h->pyr_stride, strip);

@@ -79,13 +79,13 @@ def test_resize_strips_longer_than_a_pitch_quantum(tmp_path, strip):
     lane stays alive (the surplus lanes redo the row's last dword).  Batches above 32 images use the configured strip length."""
     from orb_slam3_detailed_comments_amd import synth
     so = str(tmp_path / "liborbx_emu_strip.so")
-    build_emu_variant(so, ["-DORBX_RESIZE_STRIP=%d" % strip])
+    build_emu_variant(so, ["-DORBX_RESIZE_STRIP=%d" % strip, "-DORBX_RESIZE_MIN_BLOCKS=1"])       # (the library then keeps the configured strip at any batch size)
     lib = _lib.OrbxLib(so)
-    for (w, h) in ((522, 333),):                                   # level widths 435, 363, 302 ..: pitches whose last workgroup fills 48, 32, 16 .. lanes
+    for (w, h) in ((522, 333), (752, 480)):                        # level widths 435, 363, 302 ..: pitches whose last workgroup fills 48, 32, 16 .. lanes
         img = synth.pink_noise(w, h, seed=w)
         other = synth.sparse_corners(w, h, seed=5, ncorner=20)
         o = ol.OracleExtractor(300); o.extract(img)
         ex = ORBextractor(300, 1.2, 8, 20, 7, lib=lib)
-        ex.extract_batch(np.stack([other] * 599 + [img]))          # enough workgroups that the library keeps the configured strip on the first levels
+        ex.extract_batch(np.stack([other] * 33 + [img]))           # 34 images: the large-batch launch form (one launch per level, configured strips)
         for l in range(8):
-            assert np.array_equal(ex.pyramid_level(l, 599), o.level_image(l)), "level %d of %dx%d, strips of %d rows" % (l, w, h, strip)
+            assert np.array_equal(ex.pyramid_level(l, 33), o.level_image(l)), "level %d of %dx%d, strips of %d rows" % (l, w, h, strip)
